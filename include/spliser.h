@@ -1,0 +1,161 @@
+/*
+ * spliser.h -- C ABI of libspliser_hip.so, the MI355X (gfx950) implementation of the hot path of
+ * SpliSER v0.1.8 `process`: per-splice-site beta1 / beta2Simple / double-count read classification
+ * and the beta2 + SSE vector pass.
+ *
+ * The reference (pure Python) has no FFI; the seam this library replaces is the batch
+ *
+ *     processSites(inBAM, qChrom, isStranded, strandedType, isbeta2Cryptic)   SpliSER_v0_1_8.py:681-692
+ *       = for every site: checkBam(...)                                       SpliSER_v0_1_8.py:408-559
+ *         for every site: findBeta2Counts(...); calculateSSE(...)             SpliSER_v0_1_8.py:581-639
+ *
+ * and, upstream of it, the per-site `samtools view` child process (SpliSER_v0_1_8.py:422), which is
+ * replaced by one whole-file BAM decode into structure-of-arrays buffers (spl_bam_*).
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative spl_status on failure; the message of the
+ *     last failure on the calling thread is available from spl_last_error();
+ *   - the caller owns every buffer it passes in; the library never keeps a caller pointer past the
+ *     return of the call that received it;
+ *   - a spl_ctx is bound to one GPU and one HIP stream; calls on different contexts may run
+ *     concurrently from different threads, calls on the same context must be serialised;
+ *   - there is NO CPU fallback: spl_create() fails when no gfx950 device is visible.
+ *
+ * Coordinates: all positions are the reference's integers -- 1-based SAM POS for reads; for sites the
+ * values computed at SpliSER_v0_1_8.py:275-276 (left site = last exonic base, right site = last
+ * intronic base, both 1-based), so a CIGAR N op of length d ending at cur gives lSite = cur-d-1,
+ * rSite = cur-1 (SpliSER_v0_1_8.py:482-483) and equality tests are direct.  One call covers one
+ * *shard*: a single int32 coordinate space (one chromosome, or several chromosomes the host has laid
+ * side by side with offsets -- see spliser_amd/shard.py); every coordinate must stay below 2^31-2.
+ */
+#ifndef SPLISER_H
+#define SPLISER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPL_ABI_VERSION 1
+
+typedef enum spl_status {
+    SPL_OK = 0,
+    SPL_ERR_ARG = -1,       /* bad argument (null pointer, negative size, unsorted table, ...)   */
+    SPL_ERR_NO_DEVICE = -2, /* no usable gfx950 device / HIP runtime failure at start-up          */
+    SPL_ERR_HIP = -3,       /* a HIP call failed; message carries hipGetErrorString               */
+    SPL_ERR_IO = -4,        /* file missing / unreadable / truncated                              */
+    SPL_ERR_FORMAT = -5,    /* not BGZF/BAM, corrupt block, unsupported CIGAR op                   */
+    SPL_ERR_RANGE = -6,     /* coordinate overflow: a read or site exceeds the int32 shard space   */
+    SPL_ERR_NOMEM = -7
+} spl_status;
+
+typedef struct spl_ctx spl_ctx;       /* one GPU + one stream                                       */
+typedef struct spl_dsites spl_dsites; /* a site table resident in HBM (+ its output counters)       */
+typedef struct spl_dreads spl_dreads; /* a read set resident in HBM                                  */
+typedef struct spl_bam spl_bam;       /* an opened + decoded BAM file                                */
+
+/* Site table of one shard: the state the reference keeps in Site objects
+ * (Gene_Site_Iter_Graph_v0_1_8.py:98-120) after findAlphaCounts + findCompetitorPos
+ * (SpliSER_v0_1_8.py:227-372), flattened to SoA + CSR.  Row order = Site.__lt__ order
+ * (Gene_Site_Iter_Graph_v0_1_8.py:123-136): ascending pos, '+' before '-' at equal pos. */
+typedef struct spl_sites {
+    int64_t n_sites;
+    const int32_t *pos;        /* [n_sites]   Site.pos, non-decreasing                               */
+    const uint8_t *strand;     /* [n_sites]   Site.strand as ASCII ('+', '-', anything else = none)  */
+    const uint32_t *part_off;  /* [n_sites+1] CSR offsets into part_*                                */
+    const int32_t *part_pos;   /* [n_part]    keys of Site.PartnerCounts, insertion order            */
+    const int32_t *part_site;  /* [n_part]    row of that partner in this table, -1 when absent; may
+                                              be NULL for spl_count (only spl_sse reads it)         */
+    const uint32_t *comp_off;  /* [n_sites+1] CSR offsets into comp_pos                              */
+    const int32_t *comp_pos;   /* [n_comp]    Site.CompetitorPos (sorted unique)                     */
+    const int64_t *alpha;      /* [n_sites]   Site.alphaCounts[sample]; may be NULL for spl_count    */
+    const int64_t *edge_cnt;   /* [n_part]    Site.PartnerCounts[part_pos][sample]; may be NULL for
+                                              spl_count                                             */
+} spl_sites;
+
+/* Reads of one shard, in file order (coordinate-sorted input gives the best locality but is not
+ * required for correctness).  This is exactly what checkBam consumes from each SAM line:
+ * column 2 (flag), column 4 (POS), column 6 (CIGAR)  -- SpliSER_v0_1_8.py:434-437. */
+typedef struct spl_reads {
+    int64_t n_reads;
+    const int32_t *pos;       /* [n_reads]   1-based leftmost position (SAM POS)                     */
+    const uint16_t *flag;     /* [n_reads]   SAM FLAG                                                */
+    const uint32_t *cig_off;  /* [n_reads+1] offsets into cigar; cig_off[0] == 0                     */
+    const uint32_t *cigar;    /* [cig_off[n_reads]] BAM-native ops: len<<4 | op, op = MIDNSHP=X 0..8 */
+} spl_reads;
+
+typedef struct spl_opts {
+    int32_t stranded;     /* 0 = unstranded, 1 = "fr", 2 = "rf"   (check_strand, SpliSER_v0_1_8.py:374-406) */
+    int32_t combine_mode; /* 0 = `process`; 1 = `combine`/`combineShallow`: a flanking read also counts
+                             toward beta2Simple (SpliSER_v0_1_8.py:529-536)                            */
+} spl_opts;
+
+/* ---- library / context ------------------------------------------------------------------------ */
+int spl_abi_version(void);
+const char *spl_last_error(void);
+int spl_device_count(int *n_out);
+int spl_create(int device_id, spl_ctx **out);
+/* Same, but work is enqueued on a caller-provided hipStream_t (e.g. torch's current stream). */
+int spl_create_on_stream(int device_id, void *hip_stream, spl_ctx **out);
+void spl_destroy(spl_ctx *ctx);
+int spl_sync(spl_ctx *ctx);
+/* HIP-event stopwatch on the context's stream (what bench.py times the kernels with). */
+int spl_timer_begin(spl_ctx *ctx);
+int spl_timer_end(spl_ctx *ctx, float *elapsed_ms_out);
+
+/* ---- one-shot entry points on host buffers (what the `process` driver calls per shard) ---------
+ * spl_count  == the checkBam loop of processSites (SpliSER_v0_1_8.py:686-688) for all sites at once.
+ *   beta1[s]         += reads classified "beta1" for site s           (SpliSER_v0_1_8.py:558-559)
+ *   beta2s_reads[s]  += reads that add to beta2SimpleCounts in checkBam (:532, :541, :552)
+ *   dbl[e]           += PartnerBeta2DoubleCounts increments for partner edge e (:527, :551)
+ * Outputs are overwritten (not accumulated). */
+int spl_count(spl_ctx *ctx, const spl_sites *sites, const spl_reads *reads, const spl_opts *opts,
+              uint32_t *beta1, uint32_t *beta2s_reads, uint32_t *dbl);
+
+/* spl_sse == findBeta2Counts + calculateSSE for every site (SpliSER_v0_1_8.py:690-692, 581-639).
+ * Needs sites->alpha, sites->edge_cnt and sites->part_site.  All arithmetic is IEEE binary64 with
+ * no contraction, in the reference's operation order, so results are bit-identical to CPython's. */
+int spl_sse(spl_ctx *ctx, const spl_sites *sites, const uint32_t *beta1, const uint32_t *beta2s_reads,
+            const uint32_t *dbl, int beta2_cryptic, int64_t *beta2_simple, int64_t *beta2_cryptic_count,
+            double *beta2_weighted, double *sse);
+
+/* ---- device-resident pipeline (bench.py, multi-shard overlap) ---------------------------------- */
+int spl_sites_upload(spl_ctx *ctx, const spl_sites *sites, spl_dsites **out);
+void spl_sites_free(spl_ctx *ctx, spl_dsites *ds);
+int spl_reads_upload(spl_ctx *ctx, const spl_reads *reads, spl_dreads **out);
+void spl_reads_free(spl_ctx *ctx, spl_dreads *dr);
+/* Zero the shard's counters and enqueue the classification kernel (asynchronous). */
+int spl_count_launch(spl_ctx *ctx, spl_dsites *ds, const spl_dreads *dr, const spl_opts *opts);
+/* Enqueue the beta2/SSE kernel on the counters currently held by ds (asynchronous). */
+int spl_sse_launch(spl_ctx *ctx, spl_dsites *ds, int beta2_cryptic);
+/* Synchronise and copy results back; any output pointer may be NULL. */
+int spl_counters_download(spl_ctx *ctx, const spl_dsites *ds, uint32_t *beta1, uint32_t *beta2s_reads,
+                          uint32_t *dbl);
+int spl_sse_download(spl_ctx *ctx, const spl_dsites *ds, int64_t *beta2_simple,
+                     int64_t *beta2_cryptic_count, double *beta2_weighted, double *sse);
+/* Bytes the classification kernel must move at minimum for (ds, dr): each input once, each output
+ * once -- the numerator of bench.py's roofline.achieved. */
+int spl_count_algorithmic_bytes(const spl_dsites *ds, const spl_dreads *dr, int64_t *bytes_out);
+/* Launch geometry of the last spl_count_launch on this context (for DESIGN.md / profiles). */
+int spl_last_launch_info(const spl_ctx *ctx, int32_t *grid_out, int32_t *block_out, int32_t *lds_bytes_out);
+
+/* ---- BAM ingest: replaces `samtools view` (SpliSER_v0_1_8.py:422) ------------------------------
+ * spl_bam_open reads and inflates the whole BGZF file on n_threads host threads (0 = all cores)
+ * and splits the alignment records per reference sequence into SoA buffers (page-locked when a
+ * GPU is present).  Like `samtools view` without -F/-q it keeps EVERY record that has a reference
+ * id (secondary, supplementary, duplicate, QC-fail, unmapped-but-placed ...). */
+int spl_bam_open(const char *path, int n_threads, spl_bam **out);
+void spl_bam_close(spl_bam *bam);
+int spl_bam_n_ref(const spl_bam *bam);
+const char *spl_bam_ref_name(const spl_bam *bam, int tid);
+int64_t spl_bam_ref_length(const spl_bam *bam, int tid);
+int64_t spl_bam_n_records(const spl_bam *bam); /* all records, including those without a reference */
+/* Borrowed view (valid until spl_bam_close) of the reads placed on reference `tid`;
+ * *max_end_out = largest 1-based end coordinate any of them reaches (for shard packing). */
+int spl_bam_reads(const spl_bam *bam, int tid, spl_reads *out, int64_t *max_end_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLISER_H */

@@ -1,0 +1,77 @@
+"""ctypes front-end of oracle/spliser_oracle.c -- TEST INFRASTRUCTURE (see that file's header).
+
+Callers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.  The product never imports it.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(HERE, "liboracle.so")
+    src = os.path.join(HERE, "spliser_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.orc_check_bam.restype = ctypes.c_int
+        _LIB.orc_beta2_sse.restype = ctypes.c_int
+        _LIB.orc_check_strand.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def check_bam(site_pos, site_strand, part_off, part_pos, comp_off, comp_pos, r_pos, r_flag, cig_off, cigar,
+              stranded=0, combine_mode=0):
+    """checkBam over every site of one chromosome -> (beta1, beta2s_reads, dbl) uint32 arrays."""
+    site_pos, site_strand = _c(site_pos, np.int32), _c(site_strand, np.uint8)
+    part_off, part_pos = _c(part_off, np.uint32), _c(part_pos, np.int32)
+    comp_off, comp_pos = _c(comp_off, np.uint32), _c(comp_pos, np.int32)
+    r_pos, r_flag = _c(r_pos, np.int32), _c(r_flag, np.uint16)
+    cig_off, cigar = _c(cig_off, np.uint32), _c(cigar, np.uint32)
+    n = site_pos.shape[0]
+    beta1 = np.zeros(n, np.uint32)
+    b2s = np.zeros(n, np.uint32)
+    dbl = np.zeros(max(int(part_off[-1]) if n else 0, 1), np.uint32)
+    rc = lib().orc_check_bam(ctypes.c_int64(n), _p(site_pos), _p(site_strand), _p(part_off), _p(part_pos),
+                             _p(comp_off), _p(comp_pos), ctypes.c_int64(r_pos.shape[0]), _p(r_pos), _p(r_flag),
+                             _p(cig_off), _p(cigar), ctypes.c_int(stranded), ctypes.c_int(combine_mode),
+                             _p(beta1), _p(b2s), _p(dbl))
+    if rc != 0:
+        raise MemoryError("orc_check_bam failed")
+    return beta1, b2s, dbl[: int(part_off[-1]) if n else 0]
+
+
+def beta2_sse(site_pos, part_off, part_pos, part_site, alpha, edge_cnt, beta1, b2s_reads, dbl, cryptic):
+    """findBeta2Counts + calculateSSE -> (beta2_simple i64, beta2_cryptic i64, beta2_weighted f64, sse f64)."""
+    site_pos = _c(site_pos, np.int32)
+    part_off, part_pos, part_site = _c(part_off, np.uint32), _c(part_pos, np.int32), _c(part_site, np.int32)
+    alpha, edge_cnt = _c(alpha, np.int64), _c(edge_cnt, np.int64)
+    beta1, b2s_reads = _c(beta1, np.uint32), _c(b2s_reads, np.uint32)
+    dbl = _c(dbl if len(dbl) else np.zeros(1), np.uint32)
+    n = site_pos.shape[0]
+    b2s = np.zeros(n, np.int64)
+    b2c = np.zeros(n, np.int64)
+    b2w = np.zeros(n, np.float64)
+    sse = np.zeros(n, np.float64)
+    lib().orc_beta2_sse(ctypes.c_int64(n), _p(site_pos), _p(part_off), _p(part_pos), _p(part_site), _p(alpha),
+                        _p(edge_cnt), _p(beta1), _p(b2s_reads), _p(dbl), ctypes.c_int(1 if cryptic else 0),
+                        _p(b2s), _p(b2c), _p(b2w), _p(sse))
+    return b2s, b2c, b2w, sse
