@@ -104,6 +104,12 @@ int spl_sync(spl_ctx *ctx);
 int spl_timer_begin(spl_ctx *ctx);
 int spl_timer_end(spl_ctx *ctx, float *elapsed_ms_out);
 
+/* Per-launch stopwatch around the classification kernel ALONE (HIP events recorded on the context's
+ * stream immediately before and after each spl_count_kernel launch).  begin() arms up to max_records
+ * launches; collect() synchronises and returns their durations in launch order. */
+int spl_kernel_timing_begin(spl_ctx *ctx, int max_records);
+int spl_kernel_timing_collect(spl_ctx *ctx, float *ms_out, int capacity, int *n_out);
+
 /* ---- one-shot entry points on host buffers (what the `process` driver calls per shard) ---------
  * spl_count  == the checkBam loop of processSites (SpliSER_v0_1_8.py:686-688) for all sites at once.
  *   beta1[s]         += reads classified "beta1" for site s           (SpliSER_v0_1_8.py:558-559)

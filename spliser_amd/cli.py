@@ -1,0 +1,77 @@
+"""Command line of the MI355X build: the sub-commands, flags and argparse dests of SpliSER v0.1.8
+(SpliSER_v0_1_8.py:1295-1361), so existing pipelines only swap the script name.
+
+Extra flags (all optional, none changes results): ``--gpus`` / ``--devices`` to shard chromosomes over
+several MI355X of one node, ``--threads`` for the BAM decode pool.
+"""
+import argparse
+import sys
+import timeit
+
+VERSION = "v0.1.8-mi355x"
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="SpliSER - Splice Site Strength Estimates from RNA-seq (MI355X build)")
+    sub = parser.add_subparsers(dest="command")
+    p = sub.add_parser("process")
+    p.add_argument("-B", "--BAMFile", dest="inBAM", required=True, help="The mapped RNA-seq file in BAM format")
+    p.add_argument("-b", "--bedFile", dest="inBed", required=True, help="The Tophat-style splice junction bed file")
+    p.add_argument("-o", "--outputPath", dest="outputPath", required=True,
+                   help="Absolute path, including file prefix where the .SpliSER.tsv file is written")
+    p.add_argument("-A", "--annotationFile", dest="annotationFile", required=False,
+                   help="optional: gff3 or gtf file matching the reference genome used for alignment")
+    p.add_argument("-t", "--annotationType", dest="aType", nargs="?", default="gene", type=str, required=False,
+                   help="optional: the feature to be extracted from the annotation file - default: gene")
+    p.add_argument("-c", "--chromosome", dest="qChrom", nargs="?", default="All", type=str, required=False,
+                   help="optional: limit SpliSER to one chromosome/scaffold - default: All")
+    p.add_argument("-g", "--gene", dest="qGene", nargs="?", default="All", type=str, required=False,
+                   help="optional: limit SpliSER to splice sites falling in a single locus "
+                        "(requires --chromosome, --annotationFile and --maxIntronSize)")
+    p.add_argument("-m", "--maxIntronSize", dest="maxIntronSize", nargs="?", default=0, type=int, required=False,
+                   help="optional: required with --gene, the max intron size used in aligning the bam file")
+    p.add_argument("--isStranded", dest="isStranded", default=False, action="store_true")
+    p.add_argument("-s", "--strandedType", dest="strandedType", nargs="?", type=str, required=False,
+                   help='optional: strand specificity of the library, "rf" (first-strand) or "fr" (second-strand)')
+    p.add_argument("--beta2Cryptic", dest="isbeta2Cryptic", default=False, action="store_true",
+                   help="optional: weight the utilisation of competing splice sites into SSE (legacy)")
+    _engine_flags(p)
+    return parser
+
+
+def _engine_flags(p):
+    p.add_argument("--gpus", dest="gpus", type=int, default=1, help="number of MI355X devices to shard chromosomes over")
+    p.add_argument("--devices", dest="devices", type=str, default=None, help="explicit device list, e.g. 0,2,3")
+    p.add_argument("--threads", dest="threads", type=int, default=0, help="host threads for BAM decode (0 = all cores)")
+
+
+def main(argv=None):
+    print("\nSpliSER " + VERSION + " (MI355X / gfx950 build of SpliSER v0.1.8, SKB LAB)\n")
+    start = timeit.default_timer()
+    parser = build_parser()
+    kwargs = vars(parser.parse_args(argv))
+    command = kwargs.pop("command")
+    if command is None:
+        parser.error("a sub-command is required")
+    gpus = kwargs.pop("gpus", 1)
+    devices = kwargs.pop("devices", None)
+    devices = tuple(int(d) for d in devices.split(",")) if devices else tuple(range(max(1, gpus)))
+    threads = kwargs.pop("threads", 0)
+    # same validation rules as SpliSER_v0_1_8.py:1350-1355
+    if command == "process" and kwargs.get("qGene") != "All" and (kwargs.get("annotationFile") is None or kwargs.get("maxIntronSize") is None):
+        print(kwargs.get("qGene"))
+        print(kwargs.get("annotationFile"))
+        parser.error("--gene requires --annotationFile and --maxIntronSize")
+    elif command in ("process", "combine", "combineShallow") and kwargs.get("isStranded") is True and kwargs.get("strandedType") is None:
+        parser.error("--isStranded requires parameter --strandedType/-s as fr or rf")
+    if command == "process":
+        from .process import process
+        process(devices=devices, threads=threads, **kwargs)
+    else:
+        parser.error("sub-command %r is not part of this build yet" % command)
+    print("Total runtime (s): \t" + str(timeit.default_timer() - start))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,480 @@
+// spl_capi.cpp -- the C ABI of include/spliser.h over the HIP runtime: contexts, HBM residency of site
+// tables and read sets, kernel launches, result download.  No torch, no CPU compute fallback.
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/spliser.h"
+#include "spl_device.h"
+#include "spl_error.h"
+
+// ---- error plumbing -------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+int spl_set_error(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return spl_set_error(SPL_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *spl_last_error(void) { return g_last_error.c_str(); }
+extern "C" int spl_abi_version(void) { return SPL_ABI_VERSION; }
+
+// ---- objects --------------------------------------------------------------------------------------------
+struct spl_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int32_t *d_err = nullptr;
+    int last_grid = 0;
+    // optional per-launch stopwatch around spl_count_kernel alone (bench.py's roofline numerator)
+    std::vector<hipEvent_t> k_ev; // pairs
+    int k_used = 0;
+    bool k_on = false;
+};
+
+struct spl_dsites {
+    int64_t n_sites = 0, n_part = 0, n_comp = 0;
+    char *slab = nullptr; // one allocation; the pointers below live inside it
+    size_t slab_bytes = 0;
+    int32_t *pos = nullptr;
+    uint8_t *strand = nullptr;
+    uint4 *meta = nullptr;
+    uint32_t *part_off = nullptr;
+    int32_t *part_pos = nullptr, *part_site = nullptr, *comp_pos = nullptr;
+    int64_t *alpha = nullptr, *edge_cnt = nullptr;
+    uint32_t *bucket = nullptr;
+    uint32_t n_buckets = 0;
+    int32_t bucket_base = 0, bucket_shift = 0;
+    bool has_sse_inputs = false;
+    // outputs
+    uint32_t *beta1 = nullptr, *beta2s = nullptr, *dbl = nullptr; // contiguous: one memset clears all three
+    size_t counter_bytes = 0;
+    int64_t *b2_simple = nullptr, *b2_cryptic = nullptr;
+    double *b2_weighted = nullptr, *sse = nullptr;
+};
+
+struct spl_dreads {
+    int64_t n_reads = 0, n_cigar = 0;
+    char *slab = nullptr;
+    int32_t *pos = nullptr;
+    uint16_t *flag = nullptr;
+    uint32_t *cig_off = nullptr, *cigar = nullptr;
+};
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// ---- context --------------------------------------------------------------------------------------------
+extern "C" int spl_device_count(int *n_out)
+{
+    if (!n_out) return spl_set_error(SPL_ERR_ARG, "spl_device_count: null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *n_out = 0; return spl_set_error(SPL_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n_out = n;
+    return SPL_OK;
+}
+
+static int create_ctx(int device_id, void *stream, bool use_given, spl_ctx **out)
+{
+    if (!out) return spl_set_error(SPL_ERR_ARG, "spl_create: null output");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return spl_set_error(SPL_ERR_NO_DEVICE, "no HIP device visible (%s); libspliser_hip has no CPU fallback",
+                             e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return spl_set_error(SPL_ERR_ARG, "device %d out of range (0..%d)", device_id, n - 1);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return spl_set_error(SPL_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device_id,
+                             prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device_id));
+    spl_ctx *c = new (std::nothrow) spl_ctx();
+    if (!c) return spl_set_error(SPL_ERR_NOMEM, "out of host memory");
+    c->device = device_id;
+    if (use_given) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) { delete c; return spl_set_error(SPL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc((void **)&c->d_err, sizeof(int32_t)) != hipSuccess) {
+        spl_destroy(c);
+        return spl_set_error(SPL_ERR_HIP, "context resources could not be created");
+    }
+    *out = c;
+    return SPL_OK;
+}
+
+extern "C" int spl_create(int device_id, spl_ctx **out) { return create_ctx(device_id, nullptr, false, out); }
+extern "C" int spl_create_on_stream(int device_id, void *hip_stream, spl_ctx **out) { return create_ctx(device_id, hip_stream, true, out); }
+
+extern "C" void spl_destroy(spl_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->k_ev) (void)hipEventDestroy(e);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int spl_sync(spl_ctx *c)
+{
+    if (!c) return spl_set_error(SPL_ERR_ARG, "spl_sync: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPL_OK;
+}
+
+extern "C" int spl_timer_begin(spl_ctx *c)
+{
+    if (!c) return spl_set_error(SPL_ERR_ARG, "spl_timer_begin: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return SPL_OK;
+}
+
+extern "C" int spl_timer_end(spl_ctx *c, float *ms)
+{
+    if (!c || !ms) return spl_set_error(SPL_ERR_ARG, "spl_timer_end: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return SPL_OK;
+}
+
+extern "C" int spl_kernel_timing_begin(spl_ctx *c, int max_records)
+{
+    if (!c || max_records < 0) return spl_set_error(SPL_ERR_ARG, "spl_kernel_timing_begin: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    while ((int)c->k_ev.size() < 2 * max_records) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->k_ev.push_back(e);
+    }
+    c->k_used = 0;
+    c->k_on = max_records > 0;
+    return SPL_OK;
+}
+
+extern "C" int spl_kernel_timing_collect(spl_ctx *c, float *ms_out, int capacity, int *n_out)
+{
+    if (!c || !n_out || (capacity > 0 && !ms_out)) return spl_set_error(SPL_ERR_ARG, "spl_kernel_timing_collect: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int n = std::min(c->k_used, capacity);
+    for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms_out[i], c->k_ev[2 * i], c->k_ev[2 * i + 1]));
+    *n_out = n;
+    c->k_on = false;
+    return SPL_OK;
+}
+
+// ---- site table upload ----------------------------------------------------------------------------------
+static int validate_sites(const spl_sites *s)
+{
+    if (!s) return spl_set_error(SPL_ERR_ARG, "null site table");
+    if (s->n_sites < 0 || s->n_sites > 0x7ffffff0LL) return spl_set_error(SPL_ERR_ARG, "n_sites out of range");
+    if (s->n_sites == 0) return SPL_OK;
+    if (!s->pos || !s->strand || !s->part_off || !s->comp_off) return spl_set_error(SPL_ERR_ARG, "site table has null arrays");
+    if (s->part_off[0] != 0 || s->comp_off[0] != 0) return spl_set_error(SPL_ERR_ARG, "CSR offsets must start at 0");
+    for (int64_t i = 0; i < s->n_sites; ++i) {
+        if (i && s->pos[i] < s->pos[i - 1]) return spl_set_error(SPL_ERR_ARG, "site positions must be non-decreasing (row %lld)", (long long)i);
+        if (s->part_off[i + 1] < s->part_off[i] || s->comp_off[i + 1] < s->comp_off[i])
+            return spl_set_error(SPL_ERR_ARG, "CSR offsets must be non-decreasing (row %lld)", (long long)i);
+    }
+    if (s->pos[0] < 0 || s->pos[s->n_sites - 1] > SPL_COORD_MAX) return spl_set_error(SPL_ERR_RANGE, "site position outside [0, %d]", SPL_COORD_MAX);
+    if (s->part_off[s->n_sites] && !s->part_pos) return spl_set_error(SPL_ERR_ARG, "part_pos is null");
+    if (s->comp_off[s->n_sites] && !s->comp_pos) return spl_set_error(SPL_ERR_ARG, "comp_pos is null");
+    return SPL_OK;
+}
+
+extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out)
+{
+    if (!c || !out) return spl_set_error(SPL_ERR_ARG, "spl_sites_upload: null argument");
+    *out = nullptr;
+    int rc = validate_sites(s);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t S = s->n_sites;
+    const int64_t P = S ? s->part_off[S] : 0, C = S ? s->comp_off[S] : 0;
+    spl_dsites *d = new (std::nothrow) spl_dsites();
+    if (!d) return spl_set_error(SPL_ERR_NOMEM, "out of host memory");
+    d->n_sites = S; d->n_part = P; d->n_comp = C;
+    d->has_sse_inputs = s->alpha && s->edge_cnt && (s->part_site || P == 0);
+
+    // position -> row bucket index: <= 16 buckets per site, buckets at least 16 bp wide
+    std::vector<uint32_t> bucket;
+    if (S > 0) {
+        const int64_t extent = (int64_t)s->pos[S - 1] - (int64_t)s->pos[0] + 1;
+        int shift = 4;
+        while ((extent >> shift) > 16 * S) ++shift;
+        d->bucket_shift = shift;
+        d->bucket_base = s->pos[0];
+        d->n_buckets = (uint32_t)((extent - 1) >> shift) + 1;
+        bucket.resize((size_t)d->n_buckets + 1);
+        int64_t row = 0;
+        for (uint32_t b = 0; b <= d->n_buckets; ++b) {
+            const int64_t start = (int64_t)d->bucket_base + ((int64_t)b << shift);
+            while (row < S && (int64_t)s->pos[row] < start) ++row;
+            bucket[b] = (uint32_t)row;
+        }
+        bucket[d->n_buckets] = (uint32_t)S;
+    }
+    std::vector<uint4> meta((size_t)S);
+    for (int64_t i = 0; i < S; ++i)
+        meta[(size_t)i] = make_uint4(s->part_off[i], s->part_off[i + 1] - s->part_off[i], s->comp_off[i], s->comp_off[i + 1] - s->comp_off[i]);
+
+    // slab layout
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+    const size_t o_pos = take(4 * S), o_strand = take(S), o_meta = take(16 * S), o_poff = take(4 * (S + 1));
+    const size_t o_ppos = take(4 * P), o_psite = take(4 * P), o_cpos = take(4 * C);
+    const size_t o_alpha = take(8 * S), o_ecnt = take(8 * P), o_bucket = take(4 * bucket.size());
+    const size_t o_cnt = off;
+    const size_t o_b1 = take(4 * S), o_b2 = take(4 * S), o_dbl = take(4 * P);
+    d->counter_bytes = off - o_cnt;
+    const size_t o_b2s = take(8 * S), o_b2c = take(8 * S), o_b2w = take(8 * S), o_sse = take(8 * S);
+    d->slab_bytes = std::max<size_t>(off, 256);
+    hipError_t e = hipMalloc((void **)&d->slab, d->slab_bytes);
+    if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the site table: %s", d->slab_bytes, hipGetErrorString(e)); }
+    d->pos = (int32_t *)(d->slab + o_pos); d->strand = (uint8_t *)(d->slab + o_strand); d->meta = (uint4 *)(d->slab + o_meta);
+    d->part_off = (uint32_t *)(d->slab + o_poff); d->part_pos = (int32_t *)(d->slab + o_ppos); d->part_site = (int32_t *)(d->slab + o_psite);
+    d->comp_pos = (int32_t *)(d->slab + o_cpos); d->alpha = (int64_t *)(d->slab + o_alpha); d->edge_cnt = (int64_t *)(d->slab + o_ecnt);
+    d->bucket = (uint32_t *)(d->slab + o_bucket);
+    d->beta1 = (uint32_t *)(d->slab + o_b1); d->beta2s = (uint32_t *)(d->slab + o_b2); d->dbl = (uint32_t *)(d->slab + o_dbl);
+    d->b2_simple = (int64_t *)(d->slab + o_b2s); d->b2_cryptic = (int64_t *)(d->slab + o_b2c);
+    d->b2_weighted = (double *)(d->slab + o_b2w); d->sse = (double *)(d->slab + o_sse);
+
+    auto up = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        if (!bytes || !src) return hipSuccess;
+        return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); // synchronous: host vectors above die at return
+    };
+    hipError_t r = hipSuccess;
+    if (r == hipSuccess) r = up(d->pos, s->pos, 4 * S);
+    if (r == hipSuccess) r = up(d->strand, s->strand, S);
+    if (r == hipSuccess) r = up(d->meta, meta.data(), 16 * S);
+    if (r == hipSuccess) r = up(d->part_off, s->part_off, S ? 4 * (S + 1) : 0);
+    if (r == hipSuccess) r = up(d->part_pos, s->part_pos, 4 * P);
+    if (r == hipSuccess) r = up(d->part_site, s->part_site, 4 * P);
+    if (r == hipSuccess) r = up(d->comp_pos, s->comp_pos, 4 * C);
+    if (r == hipSuccess) r = up(d->alpha, s->alpha, 8 * S);
+    if (r == hipSuccess) r = up(d->edge_cnt, s->edge_cnt, 8 * P);
+    if (r == hipSuccess) r = up(d->bucket, bucket.data(), 4 * bucket.size());
+    if (r == hipSuccess) r = hipMemset(d->slab + o_cnt, 0, d->slab_bytes > o_cnt ? d->slab_bytes - o_cnt : 0);
+    if (r != hipSuccess) { (void)hipFree(d->slab); delete d; return spl_set_error(SPL_ERR_HIP, "site table upload: %s", hipGetErrorString(r)); }
+    *out = d;
+    return SPL_OK;
+}
+
+extern "C" void spl_sites_free(spl_ctx *c, spl_dsites *d)
+{
+    if (!d) return;
+    if (c) (void)hipSetDevice(c->device);
+    if (d->slab) (void)hipFree(d->slab);
+    delete d;
+}
+
+// ---- reads upload ---------------------------------------------------------------------------------------
+extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out)
+{
+    if (!c || !r || !out) return spl_set_error(SPL_ERR_ARG, "spl_reads_upload: null argument");
+    *out = nullptr;
+    if (r->n_reads < 0 || r->n_reads > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "n_reads out of range (counters are 32-bit)");
+    const int64_t R = r->n_reads;
+    if (R && (!r->pos || !r->flag || !r->cig_off)) return spl_set_error(SPL_ERR_ARG, "read set has null arrays");
+    if (R && r->cig_off[0] != 0) return spl_set_error(SPL_ERR_ARG, "cig_off[0] must be 0");
+    const int64_t G = R ? r->cig_off[R] : 0;
+    if (G && !r->cigar) return spl_set_error(SPL_ERR_ARG, "cigar is null");
+    HIP_TRY(hipSetDevice(c->device));
+    spl_dreads *d = new (std::nothrow) spl_dreads();
+    if (!d) return spl_set_error(SPL_ERR_NOMEM, "out of host memory");
+    d->n_reads = R; d->n_cigar = G;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+    const size_t o_pos = take(4 * R), o_flag = take(2 * R), o_off = take(4 * (R + 1)), o_cig = take(4 * G);
+    hipError_t e = hipMalloc((void **)&d->slab, std::max<size_t>(off, 256));
+    if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the read set: %s", off, hipGetErrorString(e)); }
+    d->pos = (int32_t *)(d->slab + o_pos); d->flag = (uint16_t *)(d->slab + o_flag);
+    d->cig_off = (uint32_t *)(d->slab + o_off); d->cigar = (uint32_t *)(d->slab + o_cig);
+    hipError_t q = hipSuccess;
+    if (R) {
+        q = hipMemcpyAsync(d->pos, r->pos, 4 * R, hipMemcpyHostToDevice, c->stream);
+        if (q == hipSuccess) q = hipMemcpyAsync(d->flag, r->flag, 2 * R, hipMemcpyHostToDevice, c->stream);
+        if (q == hipSuccess) q = hipMemcpyAsync(d->cig_off, r->cig_off, 4 * (R + 1), hipMemcpyHostToDevice, c->stream);
+        if (q == hipSuccess && G) q = hipMemcpyAsync(d->cigar, r->cigar, 4 * G, hipMemcpyHostToDevice, c->stream);
+        if (q == hipSuccess) q = hipStreamSynchronize(c->stream); // caller buffers are free to go after return
+    }
+    if (q != hipSuccess) { (void)hipFree(d->slab); delete d; return spl_set_error(SPL_ERR_HIP, "read set upload: %s", hipGetErrorString(q)); }
+    *out = d;
+    return SPL_OK;
+}
+
+extern "C" void spl_reads_free(spl_ctx *c, spl_dreads *d)
+{
+    if (!d) return;
+    if (c) (void)hipSetDevice(c->device);
+    if (d->slab) (void)hipFree(d->slab);
+    delete d;
+}
+
+// ---- launches -------------------------------------------------------------------------------------------
+extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr, const spl_opts *o)
+{
+    if (!c || !ds || !dr || !o) return spl_set_error(SPL_ERR_ARG, "spl_count_launch: null argument");
+    if (o->stranded < 0 || o->stranded > 2)
+        return spl_set_error(SPL_ERR_ARG, "stranded must be 0 (unstranded), 1 (fr) or 2 (rf); the reference raises "
+                                          "UnboundLocalError for any other strandedType");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(ds->beta1, 0, ds->counter_bytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int32_t), c->stream));
+    spl_count_params p;
+    memset(&p, 0, sizeof(p));
+    p.n_reads = dr->n_reads;
+    p.n_chunks = (uint32_t)((dr->n_reads + SPL_CHUNK - 1) / SPL_CHUNK);
+    p.r_pos = dr->pos; p.r_flag = dr->flag; p.cig_off = dr->cig_off; p.cigar = dr->cigar;
+    p.n_sites = (int32_t)ds->n_sites;
+    p.site_pos = ds->pos; p.site_strand = ds->strand; p.site_meta = ds->meta; p.part_pos = ds->part_pos; p.comp_pos = ds->comp_pos;
+    p.bucket = ds->bucket; p.n_buckets = ds->n_buckets; p.bucket_base = ds->bucket_base; p.bucket_shift = ds->bucket_shift;
+    p.stranded = o->stranded; p.combine_mode = o->combine_mode ? 1 : 0;
+    p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = c->d_err;
+    int grid = 0;
+    const bool timed = c->k_on && (size_t)(2 * c->k_used + 1) < c->k_ev.size();
+    if (timed) HIP_TRY(hipEventRecord(c->k_ev[2 * c->k_used], c->stream));
+    int rc = spl_dev_launch_count(&p, c->stream, &grid);
+    if (timed) { HIP_TRY(hipEventRecord(c->k_ev[2 * c->k_used + 1], c->stream)); c->k_used++; }
+    c->last_grid = grid;
+    if (rc != 0) return spl_set_error(SPL_ERR_HIP, "spl_count_kernel launch: %s", hipGetErrorString((hipError_t)rc));
+    return SPL_OK;
+}
+
+extern "C" int spl_sse_launch(spl_ctx *c, spl_dsites *ds, int cryptic)
+{
+    if (!c || !ds) return spl_set_error(SPL_ERR_ARG, "spl_sse_launch: null argument");
+    if (!ds->has_sse_inputs) return spl_set_error(SPL_ERR_ARG, "spl_sse needs sites->alpha, sites->edge_cnt and sites->part_site");
+    HIP_TRY(hipSetDevice(c->device));
+    spl_sse_params p;
+    memset(&p, 0, sizeof(p));
+    p.n_sites = ds->n_sites; p.site_pos = ds->pos; p.part_off = ds->part_off; p.part_pos = ds->part_pos; p.part_site = ds->part_site;
+    p.alpha = ds->alpha; p.edge_cnt = ds->edge_cnt; p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl;
+    p.cryptic = cryptic ? 1 : 0;
+    p.beta2_simple = ds->b2_simple; p.beta2_cryptic = ds->b2_cryptic; p.beta2_weighted = ds->b2_weighted; p.sse = ds->sse;
+    int rc = spl_dev_launch_sse(&p, c->stream);
+    if (rc != 0) return spl_set_error(SPL_ERR_HIP, "spl_sse_kernel launch: %s", hipGetErrorString((hipError_t)rc));
+    return SPL_OK;
+}
+
+static int check_device_error(spl_ctx *c)
+{
+    int32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(err), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err & SPL_DEV_ERR_RANGE)
+        return spl_set_error(SPL_ERR_RANGE, "a read starts below 0 or ends beyond coordinate %d: split the shard (spliser_amd/shard.py)", SPL_COORD_MAX);
+    return SPL_OK;
+}
+
+extern "C" int spl_counters_download(spl_ctx *c, const spl_dsites *ds, uint32_t *beta1, uint32_t *b2s, uint32_t *dbl)
+{
+    if (!c || !ds) return spl_set_error(SPL_ERR_ARG, "spl_counters_download: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (beta1 && ds->n_sites) HIP_TRY(hipMemcpyAsync(beta1, ds->beta1, 4 * ds->n_sites, hipMemcpyDeviceToHost, c->stream));
+    if (b2s && ds->n_sites) HIP_TRY(hipMemcpyAsync(b2s, ds->beta2s, 4 * ds->n_sites, hipMemcpyDeviceToHost, c->stream));
+    if (dbl && ds->n_part) HIP_TRY(hipMemcpyAsync(dbl, ds->dbl, 4 * ds->n_part, hipMemcpyDeviceToHost, c->stream));
+    return check_device_error(c);
+}
+
+extern "C" int spl_sse_download(spl_ctx *c, const spl_dsites *ds, int64_t *b2s, int64_t *b2c, double *b2w, double *sse)
+{
+    if (!c || !ds) return spl_set_error(SPL_ERR_ARG, "spl_sse_download: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = 8 * (size_t)ds->n_sites;
+    if (n) {
+        if (b2s) HIP_TRY(hipMemcpyAsync(b2s, ds->b2_simple, n, hipMemcpyDeviceToHost, c->stream));
+        if (b2c) HIP_TRY(hipMemcpyAsync(b2c, ds->b2_cryptic, n, hipMemcpyDeviceToHost, c->stream));
+        if (b2w) HIP_TRY(hipMemcpyAsync(b2w, ds->b2_weighted, n, hipMemcpyDeviceToHost, c->stream));
+        if (sse) HIP_TRY(hipMemcpyAsync(sse, ds->sse, n, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPL_OK;
+}
+
+extern "C" int spl_count_algorithmic_bytes(const spl_dsites *ds, const spl_dreads *dr, int64_t *out)
+{
+    if (!ds || !dr || !out) return spl_set_error(SPL_ERR_ARG, "spl_count_algorithmic_bytes: null argument");
+    // every input once, every output once.
+    const int64_t R = dr->n_reads, G = dr->n_cigar, S = ds->n_sites, P = ds->n_part, C = ds->n_comp;
+    *out = R * (4 + 2 + 4) + 4 * G + S * (4 + 1 + 8) + 4 * (P + C) + S * 8 + 4 * P;
+    return SPL_OK;
+}
+
+extern "C" int spl_last_launch_info(const spl_ctx *c, int32_t *grid, int32_t *block, int32_t *lds)
+{
+    if (!c) return spl_set_error(SPL_ERR_ARG, "spl_last_launch_info: null context");
+    if (grid) *grid = c->last_grid;
+    if (block) *block = SPL_BLOCK;
+    if (lds) *lds = 2 * SPL_WIN * 4 + 4;
+    return SPL_OK;
+}
+
+// ---- one-shot entry points ------------------------------------------------------------------------------
+extern "C" int spl_count(spl_ctx *c, const spl_sites *s, const spl_reads *r, const spl_opts *o, uint32_t *beta1, uint32_t *b2s, uint32_t *dbl)
+{
+    if (!c || !s || !r || !o) return spl_set_error(SPL_ERR_ARG, "spl_count: null argument");
+    spl_dsites *ds = nullptr;
+    spl_dreads *dr = nullptr;
+    int rc = spl_sites_upload(c, s, &ds);
+    if (rc == SPL_OK) rc = spl_reads_upload(c, r, &dr);
+    if (rc == SPL_OK) rc = spl_count_launch(c, ds, dr, o);
+    if (rc == SPL_OK) rc = spl_counters_download(c, ds, beta1, b2s, dbl);
+    spl_reads_free(c, dr);
+    spl_sites_free(c, ds);
+    return rc;
+}
+
+extern "C" int spl_sse(spl_ctx *c, const spl_sites *s, const uint32_t *beta1, const uint32_t *b2s_reads, const uint32_t *dbl, int cryptic,
+                       int64_t *b2s, int64_t *b2c, double *b2w, double *sse)
+{
+    if (!c || !s) return spl_set_error(SPL_ERR_ARG, "spl_sse: null argument");
+    if (s->n_sites && (!beta1 || !b2s_reads)) return spl_set_error(SPL_ERR_ARG, "spl_sse: null counters");
+    spl_dsites *ds = nullptr;
+    int rc = spl_sites_upload(c, s, &ds);
+    if (rc != SPL_OK) return rc;
+    hipError_t e = hipSuccess;
+    if (ds->n_sites) {
+        e = hipMemcpyAsync(ds->beta1, beta1, 4 * ds->n_sites, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ds->beta2s, b2s_reads, 4 * ds->n_sites, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && ds->n_part && dbl) e = hipMemcpyAsync(ds->dbl, dbl, 4 * ds->n_part, hipMemcpyHostToDevice, c->stream);
+    }
+    if (e != hipSuccess) rc = spl_set_error(SPL_ERR_HIP, "spl_sse upload: %s", hipGetErrorString(e));
+    if (rc == SPL_OK) rc = spl_sse_launch(c, ds, cryptic);
+    if (rc == SPL_OK) rc = spl_sse_download(c, ds, b2s, b2c, b2w, sse);
+    spl_sites_free(c, ds);
+    return rc;
+}

@@ -1,0 +1,328 @@
+"""ctypes binding of libspliser_hip.so (C ABI: include/spliser.h).
+
+This is the only door to the compute path.  There is no Python/numpy fallback: if the shared library
+is missing or no MI355X is visible, every entry point raises -- loudly -- instead of computing on the
+host.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libspliser_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+STRANDED_CODE = {None: 0, False: 0, "": 0, "fr": 1, "rf": 2}
+
+
+class SpliserNativeError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "libspliser_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+class spl_sites(ctypes.Structure):
+    _fields_ = [("n_sites", ctypes.c_int64), ("pos", ctypes.c_void_p), ("strand", ctypes.c_void_p),
+                ("part_off", ctypes.c_void_p), ("part_pos", ctypes.c_void_p), ("part_site", ctypes.c_void_p),
+                ("comp_off", ctypes.c_void_p), ("comp_pos", ctypes.c_void_p), ("alpha", ctypes.c_void_p),
+                ("edge_cnt", ctypes.c_void_p)]
+
+
+class spl_reads(ctypes.Structure):
+    _fields_ = [("n_reads", ctypes.c_int64), ("pos", ctypes.c_void_p), ("flag", ctypes.c_void_p),
+                ("cig_off", ctypes.c_void_p), ("cigar", ctypes.c_void_p)]
+
+
+class spl_opts(ctypes.Structure):
+    _fields_ = [("stranded", ctypes.c_int32), ("combine_mode", ctypes.c_int32)]
+
+
+EXPORTS = [
+    "spl_abi_version", "spl_last_error", "spl_device_count", "spl_create", "spl_create_on_stream", "spl_destroy",
+    "spl_sync", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
+    "spl_reads_upload", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
+    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_last_launch_info", "spl_bam_open", "spl_bam_close",
+    "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads",
+]
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libspliser_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-C", CSRC])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SpliserNativeError(-2, "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                         "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.spl_last_error.restype = ctypes.c_char_p
+        L.spl_bam_ref_name.restype = ctypes.c_char_p
+        L.spl_bam_ref_length.restype = ctypes.c_int64
+        L.spl_bam_n_records.restype = ctypes.c_int64
+        for name in ("spl_destroy", "spl_sites_free", "spl_reads_free", "spl_bam_close"):
+            getattr(L, name).restype = None
+        if L.spl_abi_version() != 1:
+            raise SpliserNativeError(-1, "ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise SpliserNativeError(rc, lib().spl_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _arr(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _to_i32(a, what):
+    a = np.asarray(a)
+    if a.size and (a.max() > 2147483645 or a.min() < -2147483648):
+        raise SpliserNativeError(-6, "%s exceeds the int32 shard coordinate space; split the shard" % what)
+    return _arr(a, np.int32)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    _check(lib().spl_device_count(ctypes.byref(n)))
+    return n.value
+
+
+class SiteArrays(object):
+    """Keeps the numpy arrays behind a ``spl_sites`` alive."""
+
+    def __init__(self, pos, strand, part_off, part_pos, comp_off, comp_pos, part_site=None, alpha=None, edge_cnt=None):
+        self.pos = _to_i32(pos, "site position")
+        self.strand = _arr(strand, np.uint8)
+        self.part_off = _arr(part_off, np.uint32)
+        self.part_pos = _to_i32(part_pos, "partner position")
+        self.comp_off = _arr(comp_off, np.uint32)
+        self.comp_pos = _to_i32(comp_pos, "competitor position")
+        self.part_site = None if part_site is None else _arr(part_site, np.int32)
+        self.alpha = None if alpha is None else _arr(alpha, np.int64)
+        self.edge_cnt = None if edge_cnt is None else _arr(edge_cnt, np.int64)
+        self.n = int(self.pos.shape[0])
+        self.n_part = int(self.part_off[-1]) if self.n else 0
+        self.c = spl_sites(self.n, _ptr(self.pos), _ptr(self.strand), _ptr(self.part_off), _ptr(self.part_pos),
+                           _ptr(self.part_site), _ptr(self.comp_off), _ptr(self.comp_pos), _ptr(self.alpha),
+                           _ptr(self.edge_cnt))
+
+    @classmethod
+    def from_chrom(cls, arr, offset=0):
+        """From sites.ChromArrays, optionally shifted into a shard coordinate space."""
+        return cls(arr.pos + offset, arr.strand, arr.part_off, arr.part_pos + offset, arr.comp_off,
+                   arr.comp_pos + offset, arr.part_site, arr.alpha, arr.edge_cnt)
+
+
+class ReadArrays(object):
+    def __init__(self, pos, flag, cig_off, cigar):
+        self.pos = _to_i32(pos, "read position")
+        self.flag = _arr(flag, np.uint16)
+        self.cig_off = _arr(cig_off, np.uint32)
+        self.cigar = _arr(cigar, np.uint32)
+        self.n = int(self.pos.shape[0])
+        if self.cig_off.shape[0] != self.n + 1:
+            raise ValueError("cig_off must have n_reads + 1 entries")
+        self.c = spl_reads(self.n, _ptr(self.pos), _ptr(self.flag), _ptr(self.cig_off), _ptr(self.cigar))
+
+
+class Context(object):
+    """One GPU + one stream (``spl_ctx``)."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = ctypes.c_void_p()
+        if stream is None:
+            _check(lib().spl_create(ctypes.c_int(device), ctypes.byref(self._h)))
+        else:
+            _check(lib().spl_create_on_stream(ctypes.c_int(device), ctypes.c_void_p(stream), ctypes.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().spl_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- one-shot host-buffer calls ----------------------------------------------------------------
+    def count(self, sites, reads, stranded=0, combine_mode=0):
+        """checkBam for all sites of a shard -> (beta1, beta2s_reads, dbl) uint32."""
+        beta1 = np.zeros(max(sites.n, 1), np.uint32)
+        b2s = np.zeros(max(sites.n, 1), np.uint32)
+        dbl = np.zeros(max(sites.n_part, 1), np.uint32)
+        opts = spl_opts(int(stranded), int(combine_mode))
+        _check(lib().spl_count(self._h, ctypes.byref(sites.c), ctypes.byref(reads.c), ctypes.byref(opts),
+                               _ptr(beta1), _ptr(b2s), _ptr(dbl)))
+        return beta1[:sites.n], b2s[:sites.n], dbl[:sites.n_part]
+
+    def sse(self, sites, beta1, b2s_reads, dbl, cryptic):
+        """findBeta2Counts + calculateSSE -> (beta2_simple, beta2_cryptic, beta2_weighted, sse)."""
+        n = sites.n
+        beta1, b2s_reads = _arr(beta1, np.uint32), _arr(b2s_reads, np.uint32)
+        dbl = _arr(dbl if len(dbl) else np.zeros(1), np.uint32)
+        o = [np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.float64),
+             np.zeros(max(n, 1), np.float64)]
+        _check(lib().spl_sse(self._h, ctypes.byref(sites.c), _ptr(beta1), _ptr(b2s_reads), _ptr(dbl),
+                             ctypes.c_int(1 if cryptic else 0), _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), _ptr(o[3])))
+        return tuple(a[:n] for a in o)
+
+    # -- device-resident pipeline --------------------------------------------------------------------
+    def upload_sites(self, sites):
+        h = ctypes.c_void_p()
+        _check(lib().spl_sites_upload(self._h, ctypes.byref(sites.c), ctypes.byref(h)))
+        return DeviceSites(self, h, sites.n, sites.n_part)
+
+    def upload_reads(self, reads):
+        h = ctypes.c_void_p()
+        _check(lib().spl_reads_upload(self._h, ctypes.byref(reads.c), ctypes.byref(h)))
+        return DeviceReads(self, h, reads.n)
+
+    def count_launch(self, dsites, dreads, stranded=0, combine_mode=0):
+        opts = spl_opts(int(stranded), int(combine_mode))
+        _check(lib().spl_count_launch(self._h, dsites._h, dreads._h, ctypes.byref(opts)))
+
+    def sse_launch(self, dsites, cryptic):
+        _check(lib().spl_sse_launch(self._h, dsites._h, ctypes.c_int(1 if cryptic else 0)))
+
+    def sync(self):
+        _check(lib().spl_sync(self._h))
+
+    def timer_begin(self):
+        _check(lib().spl_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = ctypes.c_float(0)
+        _check(lib().spl_timer_end(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def kernel_timing_begin(self, max_records):
+        _check(lib().spl_kernel_timing_begin(self._h, ctypes.c_int(max_records)))
+
+    def kernel_timing_collect(self, capacity=4096):
+        ms = (ctypes.c_float * capacity)()
+        n = ctypes.c_int(0)
+        _check(lib().spl_kernel_timing_collect(self._h, ms, ctypes.c_int(capacity), ctypes.byref(n)))
+        return [ms[i] for i in range(n.value)]
+
+    def launch_info(self):
+        g, b, l = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        _check(lib().spl_last_launch_info(self._h, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)))
+        return dict(grid=g.value, block=b.value, lds_bytes=l.value)
+
+
+class DeviceSites(object):
+    def __init__(self, ctx, h, n, n_part):
+        self.ctx, self._h, self.n, self.n_part = ctx, h, n, n_part
+
+    def counters(self):
+        beta1 = np.zeros(max(self.n, 1), np.uint32)
+        b2s = np.zeros(max(self.n, 1), np.uint32)
+        dbl = np.zeros(max(self.n_part, 1), np.uint32)
+        _check(lib().spl_counters_download(self.ctx._h, self._h, _ptr(beta1), _ptr(b2s), _ptr(dbl)))
+        return beta1[:self.n], b2s[:self.n], dbl[:self.n_part]
+
+    def sse_results(self):
+        n = self.n
+        o = [np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.float64),
+             np.zeros(max(n, 1), np.float64)]
+        _check(lib().spl_sse_download(self.ctx._h, self._h, _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), _ptr(o[3])))
+        return tuple(a[:n] for a in o)
+
+    def free(self):
+        if self._h:
+            lib().spl_sites_free(self.ctx._h, self._h)
+            self._h = ctypes.c_void_p()
+
+
+class DeviceReads(object):
+    def __init__(self, ctx, h, n):
+        self.ctx, self._h, self.n = ctx, h, n
+
+    def free(self):
+        if self._h:
+            lib().spl_reads_free(self.ctx._h, self._h)
+            self._h = ctypes.c_void_p()
+
+
+def algorithmic_bytes(dsites, dreads):
+    out = ctypes.c_int64(0)
+    _check(lib().spl_count_algorithmic_bytes(dsites._h, dreads._h, ctypes.byref(out)))
+    return out.value
+
+
+class BamFile(object):
+    """Whole-file BAM decode on host threads (``spl_bam_*``); replaces ``samtools view`` per site."""
+
+    def __init__(self, path, threads=0):
+        self._h = ctypes.c_void_p()
+        _check(lib().spl_bam_open(os.fsencode(path), ctypes.c_int(threads), ctypes.byref(self._h)))
+        self.ref_names = [lib().spl_bam_ref_name(self._h, i).decode("ascii") for i in range(lib().spl_bam_n_ref(self._h))]
+        self.ref_lengths = [lib().spl_bam_ref_length(self._h, i) for i in range(len(self.ref_names))]
+        self.n_records = lib().spl_bam_n_records(self._h)
+        self._tid = {n: i for i, n in enumerate(self.ref_names)}
+
+    def reads(self, chrom):
+        """-> samio.ReadSet-compatible views (borrowed from the native object) or None when the file has
+        no such reference (the reference's samtools call would print an error and yield nothing)."""
+        from .samio import ReadSet
+        tid = self._tid.get(chrom)
+        if tid is None:
+            return None
+        r = spl_reads()
+        me = ctypes.c_int64(0)
+        _check(lib().spl_bam_reads(self._h, ctypes.c_int(tid), ctypes.byref(r), ctypes.byref(me)))
+        n = r.n_reads
+        if n == 0:
+            return ReadSet.empty()
+
+        def view(ptr, count, dt):
+            buf = (ctypes.c_char * (count * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt, count=count)
+        cig_off = view(r.cig_off, n + 1, np.uint32)
+        n_cig = int(cig_off[-1])
+        rs = ReadSet.__new__(ReadSet)
+        rs.pos = view(r.pos, n, np.int32)
+        rs.flag = view(r.flag, n, np.uint16)
+        rs.cig_off = cig_off
+        rs.cigar = view(r.cigar, n_cig, np.uint32) if n_cig else np.zeros(0, np.uint32)
+        rs.max_end = me.value
+        rs_owner = self  # keep the native object alive as long as the views
+        setattr(self, "_views", getattr(self, "_views", []) + [rs])
+        del rs_owner
+        return rs
+
+    def close(self):
+        if self._h:
+            lib().spl_bam_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -186,10 +186,11 @@ def write_bam(path, ref_names, ref_lengths, chrom_reads, level=1, with_seq=False
                 pos0 = int(rs.pos[k]) - 1
                 tags = b""
                 rec_ops = ops
-                if long_cigar_tag and len(ops) > 3:
-                    rec_ops = [(qlen << 4) | 4, (rlen << 4) | 3]
-                    tags = b"CGBI" + struct.pack("<i", len(ops)) + struct.pack("<%dI" % len(ops), *ops)
                 l_seq = qlen if with_seq else 0
+                if long_cigar_tag and len(ops) > 3:
+                    rec_ops = [(qlen << 4) | 4, (rlen << 4) | 3]   # htslib: <l_seq>S<rlen>N placeholder
+                    tags = b"NMC\x00" + b"CGBI" + struct.pack("<i", len(ops)) + struct.pack("<%dI" % len(ops), *ops)
+                    l_seq = qlen
                 seq = bytes([0x11]) * ((l_seq + 1) // 2)
                 qual = bytes([30]) * l_seq
                 flag = int(rs.flag[k])

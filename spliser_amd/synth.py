@@ -1,0 +1,352 @@
+"""Deterministic synthetic RNA-seq workloads: genomes with multi-isoform genes,
+150 bp spliced reads as SoA, and the matching junction BED12 (+ GFF).
+
+There is no network and the reference ships no data, so every BASELINE.json configuration is
+synthesised here from a seed.  Reads are produced directly as the structure-of-arrays the GPU
+consumes; ``write_inputs`` can also materialise BAM/SAM + BED + GFF files for end-to-end runs.
+
+Site convention (SpliSER_v0_1_8.py:275-276, :482-483): for an intron between an exon ending at ``eA``
+and one starting at ``sB`` (1-based, inclusive) the left site is ``eA`` and the right site ``sB - 1``.
+"""
+import numpy as np
+
+from . import samio
+
+ARABIDOPSIS = [("Chr1", 30427671), ("Chr2", 19698289), ("Chr3", 23459830), ("Chr4", 18585056), ("Chr5", 26975502)]
+HG38 = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259),
+        ("chr6", 170805979), ("chr7", 159345973), ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422),
+        ("chr11", 135086622), ("chr12", 133275309), ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189),
+        ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285), ("chr19", 58617616), ("chr20", 64444167),
+        ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
+MM39 = [("chr%d" % i, n) for i, n in enumerate(
+    [195154279, 181755017, 159745316, 156860686, 151758149, 149588044, 144995196, 130127694, 124359700, 130530862,
+     121973369, 120092757, 120883175, 125139656, 104073951, 98008968, 95294699, 90720763, 61420004], 1)] + \
+    [("chrX", 169476592), ("chrY", 91455967)]
+
+WORKLOADS = {
+    # name: chroms, genes, reads, intron (median, min, max), exons mean, seed, paired/stranded flags
+    "single_gene": dict(chroms=[("Chr1", 200000)], n_genes=12, n_reads=2000, intron=(100, 70, 6000), seed=1),
+    "arabidopsis": dict(chroms=ARABIDOPSIS, n_genes=27000, n_reads=20_000_000, intron=(100, 70, 6000), seed=2),
+    "human": dict(chroms=HG38, n_genes=30000, n_reads=200_000_000, intron=(1500, 70, 500000), seed=3),
+    "mouse_stranded": dict(chroms=MM39, n_genes=28000, n_reads=100_000_000, intron=(1200, 70, 400000), seed=5, paired=True),
+}
+
+READ_LEN = 150
+MAX_BLOCKS = 8  # a 150 bp read crosses at most MAX_BLOCKS - 1 introns (exons are >= 30 bp)
+
+
+class Genome(object):
+    """Genes with isoforms, flattened: isoform i owns exons [iso_off[i], iso_off[i+1])."""
+
+    def __init__(self):
+        self.chrom_names, self.chrom_lengths = [], []
+        self.gene_chrom = self.gene_start = self.gene_end = self.gene_strand = None  # per gene
+        self.gene_names = []
+        self.iso_gene = self.iso_weight = self.iso_off = None                         # per isoform
+        self.ex_start = self.ex_end = None                                             # per exon (1-based inclusive)
+
+
+def make_genome(chroms, n_genes, intron=(100, 70, 6000), seed=0, exons_mean=5.0, alt_fraction=0.3, gene_prefix="G"):
+    rng = np.random.default_rng(seed)
+    g = Genome()
+    g.chrom_names = [c for c, _ in chroms]
+    g.chrom_lengths = [n for _, n in chroms]
+    total = float(sum(g.chrom_lengths))
+    med, imin, imax = intron
+    gene_chrom, gene_start, gene_end, gene_strand, names = [], [], [], [], []
+    iso_gene, iso_weight, iso_off, ex_s, ex_e = [], [], [0], [], []
+    gid = 0
+    for ci, (cname, clen) in enumerate(chroms):
+        k = max(1, int(round(n_genes * clen / total)))
+        # gene bodies first, then spread them over the chromosome with random gaps
+        bodies = []
+        for _ in range(k):
+            n_ex = max(2, int(rng.poisson(exons_mean - 1)) + 1)
+            ex_len = np.clip(rng.lognormal(np.log(170.0), 0.6, n_ex).astype(np.int64), 30, 3000)
+            in_len = np.clip(rng.lognormal(np.log(med), 1.0, n_ex - 1).astype(np.int64), imin, imax)
+            bodies.append((ex_len, in_len))
+        span = sum(int(a.sum() + b.sum()) for a, b in bodies)
+        free = max(clen - span - 2000, k * 50)
+        gaps = rng.dirichlet(np.ones(k + 1)) * free
+        cursor = 1000
+        for gi, (ex_len, in_len) in enumerate(bodies):
+            cursor += int(gaps[gi]) + 20
+            starts = np.empty(len(ex_len), np.int64)
+            pos = cursor
+            for j in range(len(ex_len)):
+                starts[j] = pos
+                pos += int(ex_len[j]) + (int(in_len[j]) if j < len(in_len) else 0)
+            ends = starts + ex_len - 1
+            cursor = int(ends[-1]) + 1
+            strand = "+" if rng.random() < 0.5 else "-"
+            expr = float(rng.lognormal(0.0, 2.0))
+            isoforms = [(starts, ends, 1.0)]
+            n_ex = len(starts)
+            if n_ex >= 3 and rng.random() < alt_fraction:      # exon skipping
+                drop = int(rng.integers(1, n_ex - 1))
+                keep = np.arange(n_ex) != drop
+                isoforms.append((starts[keep], ends[keep], 0.25))
+            if rng.random() < alt_fraction:                     # alternative 5'/3' site: move one exon edge
+                j = int(rng.integers(0, n_ex - 1))
+                s2, e2 = starts.copy(), ends.copy()
+                shift = int(rng.integers(3, 31))
+                if rng.random() < 0.5:
+                    if e2[j] - shift - s2[j] >= 20:
+                        e2[j] -= shift                            # alternative left (donor-side) site
+                else:
+                    if e2[j + 1] - (s2[j + 1] + shift) >= 20:
+                        s2[j + 1] += shift                        # alternative right (acceptor-side) site
+                isoforms.append((s2, e2, 0.2))
+            gene_chrom.append(ci)
+            gene_start.append(int(starts[0]))
+            gene_end.append(int(ends[-1]))
+            gene_strand.append(strand)
+            names.append("%s%05d" % (gene_prefix, gid))
+            for s_, e_, w in isoforms:
+                iso_gene.append(gid)
+                iso_weight.append(expr * w)
+                ex_s.append(s_)
+                ex_e.append(e_)
+                iso_off.append(iso_off[-1] + len(s_))
+            gid += 1
+    g.gene_chrom = np.asarray(gene_chrom, np.int64)
+    g.gene_start, g.gene_end = np.asarray(gene_start, np.int64), np.asarray(gene_end, np.int64)
+    g.gene_strand = np.asarray([ord(s) for s in gene_strand], np.uint8)
+    g.gene_names = names
+    g.iso_gene = np.asarray(iso_gene, np.int64)
+    g.iso_weight = np.asarray(iso_weight, np.float64)
+    g.iso_off = np.asarray(iso_off, np.int64)
+    g.ex_start, g.ex_end = np.concatenate(ex_s), np.concatenate(ex_e)
+    return g
+
+
+class ReadBatch(object):
+    """Reads of all chromosomes, sorted by (chromosome, pos)."""
+    __slots__ = ("chrom", "pos", "flag", "cig_off", "cigar", "junc_chrom", "junc_left", "junc_right", "junc_strand")
+
+
+def _paired_flags(rng, n, gene_minus):
+    """fr-firststrand-like flags: read 1 on the transcript strand, mate opposite (99/147 for '+', 83/163 for '-')."""
+    first = rng.random(n) < 0.5
+    flag = np.where(gene_minus, np.where(first, 83, 163), np.where(first, 99, 147)).astype(np.uint16)
+    return flag
+
+
+def make_reads(genome, n_reads, seed=0, read_len=READ_LEN, genomic_fraction=0.10, paired=False, stranded_single=False):
+    """Sample reads.  (1 - genomic_fraction) come from isoforms (spliced where they cross exon edges),
+    the rest are unspliced genomic reads inside gene spans (pre-mRNA / retained introns -> beta1)."""
+    rng = np.random.default_rng(seed)
+    g = genome
+    ex_len = g.ex_end - g.ex_start + 1
+    n_iso = len(g.iso_gene)
+    ex_iso = np.repeat(np.arange(n_iso), np.diff(g.iso_off))
+    csum = np.concatenate(([0], np.cumsum(ex_len)))
+    iso_tlen = csum[g.iso_off[1:]] - csum[g.iso_off[:-1]]
+    ex_tstart = csum[:-1] - csum[g.iso_off[:-1]][ex_iso]          # transcript offset of each exon's first base
+    usable = np.maximum(iso_tlen - read_len + 1, 0)
+    w = g.iso_weight * usable
+    cw = np.cumsum(w)
+    n_gen = int(round(n_reads * genomic_fraction))
+    n_tx = n_reads - n_gen
+
+    # ---- transcript reads
+    iso = np.searchsorted(cw, rng.random(n_tx) * cw[-1], side="right")
+    iso = np.minimum(iso, n_iso - 1)
+    x = (rng.random(n_tx) * usable[iso]).astype(np.int64)           # transcript offset of the read start
+    # first exon: largest e in the isoform with ex_tstart[e] <= x  (global searchsorted on a monotone key)
+    big = int(iso_tlen.max()) + 1
+    key_ex = ex_iso * big + ex_tstart
+    e = np.searchsorted(key_ex, iso * big + x, side="right") - 1
+    d0 = x - ex_tstart[e]
+    pos = g.ex_start[e] + d0
+    ops = np.zeros((n_tx, 2 * MAX_BLOCKS - 1), np.uint32)
+    n_ops = np.zeros(n_tx, np.int64)
+    jl = np.zeros((n_tx, MAX_BLOCKS - 1), np.int64)
+    jr = np.zeros((n_tx, MAX_BLOCKS - 1), np.int64)
+    remaining = np.full(n_tx, read_len, np.int64)
+    avail = ex_len[e] - d0
+    cur = e.copy()
+    active = np.ones(n_tx, bool)
+    for b in range(MAX_BLOCKS):
+        take = np.minimum(avail, remaining)
+        if b == MAX_BLOCKS - 1:
+            take = np.where(active, remaining, take)                  # safety: dump the rest into the last block
+        ops[active, 2 * b] = (take[active].astype(np.uint32) << 4)    # M
+        n_ops[active] = 2 * b + 1
+        remaining = remaining - np.where(active, take, 0)
+        active = active & (remaining > 0)
+        if b == MAX_BLOCKS - 1 or not active.any():
+            break
+        nxt = cur + 1
+        idx = np.nonzero(active)[0]
+        left = g.ex_end[cur[idx]]
+        right = g.ex_start[nxt[idx]] - 1
+        ops[idx, 2 * b + 1] = ((right - left).astype(np.uint32) << 4) | 3   # N
+        jl[idx, b], jr[idx, b] = left, right
+        cur = np.where(active, nxt, cur)
+        avail = np.where(active, ex_len[cur], avail)
+    gene = g.iso_gene[iso]
+
+    # ---- genomic (unspliced) reads inside gene spans
+    gw = np.bincount(g.iso_gene, weights=g.iso_weight, minlength=len(g.gene_start)) * np.maximum(g.gene_end - g.gene_start + 1, 1)
+    cg = np.cumsum(gw)
+    gg = np.minimum(np.searchsorted(cg, rng.random(n_gen) * cg[-1], side="right"), len(gw) - 1)
+    gpos = g.gene_start[gg] - read_len // 2 + (rng.random(n_gen) * (g.gene_end[gg] - g.gene_start[gg] + 1)).astype(np.int64)
+    gpos = np.maximum(gpos, 1)
+
+    all_gene = np.concatenate((gene, gg))
+    all_pos = np.concatenate((pos, gpos))
+    all_nops = np.concatenate((n_ops, np.ones(n_gen, np.int64)))
+    chrom = g.gene_chrom[all_gene]
+    minus = g.gene_strand[all_gene] == ord("-")
+    n = n_reads
+    if paired:
+        flag = _paired_flags(rng, n, minus)
+    elif stranded_single:
+        flag = np.where(minus, 16, 0).astype(np.uint16)
+    else:
+        flag = np.where(rng.random(n) < 0.5, 16, 0).astype(np.uint16)
+    order = np.lexsort((all_pos, chrom))
+    # ragged CIGAR in sorted order
+    flat_tx = ops.reshape(-1)
+    col = np.arange(ops.shape[1])[None, :]
+    valid_tx = (col < n_ops[:, None]).reshape(-1)
+    tx_ops = flat_tx[valid_tx]
+    gen_ops = np.full(n_gen, (read_len << 4), np.uint32)
+    all_ops = np.concatenate((tx_ops, gen_ops))
+    src_off = np.zeros(n + 1, np.int64)
+    np.cumsum(all_nops, out=src_off[1:])
+    nops_sorted = all_nops[order]
+    dst_off = np.zeros(n + 1, np.int64)
+    np.cumsum(nops_sorted, out=dst_off[1:])
+    # gather: for each destination op slot, its source slot
+    rep = np.repeat(src_off[:-1][order] - dst_off[:-1], nops_sorted)
+    cigar = all_ops[np.arange(dst_off[-1]) + rep]
+
+    out = ReadBatch()
+    out.chrom = chrom[order]
+    out.pos = all_pos[order]
+    out.flag = flag[order]
+    out.cig_off = dst_off
+    out.cigar = cigar
+    # junction usage (what regtools/tophat would put in the BED): one entry per N op
+    jmask = jr > 0
+    rows = np.nonzero(jmask)[0]
+    out.junc_chrom = g.gene_chrom[gene[rows]]
+    out.junc_left = jl[jmask]
+    out.junc_right = jr[jmask]
+    out.junc_strand = g.gene_strand[gene[rows]]
+    return out
+
+
+def split_by_chrom(batch, n_chroms):
+    """-> list of samio.ReadSet (one per chromosome index; empty ones included)."""
+    bounds = np.searchsorted(batch.chrom, np.arange(n_chroms + 1), side="left")
+    sets = []
+    for c in range(n_chroms):
+        a, b = int(bounds[c]), int(bounds[c + 1])
+        off = batch.cig_off[a:b + 1] - batch.cig_off[a]
+        sets.append(samio.ReadSet(batch.pos[a:b], batch.flag[a:b], off, batch.cigar[batch.cig_off[a]:batch.cig_off[b]]))
+    return sets
+
+
+def junction_table(batches, min_count=1):
+    """Aggregate junction usage over read batches -> arrays (chrom, left, right, strand, count), sorted."""
+    chrom = np.concatenate([b.junc_chrom for b in batches])
+    left = np.concatenate([b.junc_left for b in batches])
+    right = np.concatenate([b.junc_right for b in batches])
+    strand = np.concatenate([b.junc_strand for b in batches])
+    if len(chrom) == 0:
+        z = np.zeros(0, np.int64)
+        return z, z, z, np.zeros(0, np.uint8), z
+    key = np.stack((chrom, left, right, strand.astype(np.int64)), axis=1)
+    uniq, counts = np.unique(key, axis=0, return_counts=True)
+    keep = counts >= min_count
+    uniq, counts = uniq[keep], counts[keep]
+    return uniq[:, 0], uniq[:, 1], uniq[:, 2], uniq[:, 3].astype(np.uint8), counts
+
+
+def write_bed(path, chrom_names, junctions, overhang=20, stranded=True):
+    chrom, left, right, strand, count = junctions
+    with open(path, "w") as fh:
+        fh.write('track name=junctions description="synthetic junctions"\n')
+        for i in range(len(chrom)):
+            a = b = overhang
+            start, end = int(left[i]) - a, int(right[i]) + b
+            st = chr(int(strand[i])) if stranded else "?"
+            fh.write("%s\t%d\t%d\tJUNC%08d\t%d\t%s\t%d\t%d\t255,0,0\t2\t%d,%d\t0,%d\n" % (
+                chrom_names[int(chrom[i])], start, end, i + 1, int(count[i]), st, start, end, a, b, end - start - b))
+
+
+def write_gff(path, genome):
+    with open(path, "w") as fh:
+        fh.write("##gff-version 3\n")
+        for i, name in enumerate(genome.gene_names):
+            fh.write("%s\tsynth\tgene\t%d\t%d\t.\t%s\t.\tID=%s;Name=%s\n" % (
+                genome.chrom_names[int(genome.gene_chrom[i])], int(genome.gene_start[i]), int(genome.gene_end[i]),
+                chr(int(genome.gene_strand[i])), name, name))
+
+
+class Workload(object):
+    """A genome + reads per chromosome + the site table inputs derived from them."""
+
+    def __init__(self, name, n_reads=None, seed=None, scale=1.0, batch=20_000_000, **over):
+        cfg = dict(WORKLOADS[name])
+        cfg.update(over)
+        self.name = name
+        self.seed = cfg["seed"] if seed is None else seed
+        n_reads = int((cfg["n_reads"] if n_reads is None else n_reads) * scale)
+        n_genes = max(2, int(cfg["n_genes"] * (scale if scale < 1.0 else 1.0)))
+        self.paired = bool(cfg.get("paired"))
+        self.genome = make_genome(cfg["chroms"], n_genes, cfg["intron"], seed=self.seed)
+        nchr = len(self.genome.chrom_names)
+        per_chrom = [[] for _ in range(nchr)]
+        batches = []
+        done = 0
+        k = 0
+        while done < n_reads:
+            m = min(batch, n_reads - done)
+            rb = make_reads(self.genome, m, seed=self.seed * 1000 + k, paired=self.paired)
+            for c, rs in enumerate(split_by_chrom(rb, nchr)):
+                per_chrom[c].append(rs)
+            rb.cigar = rb.cig_off = rb.pos = rb.flag = rb.chrom = None
+            batches.append(rb)
+            done += m
+            k += 1
+        self.reads = [_merge_sorted(parts) for parts in per_chrom]
+        self.junctions = junction_table(batches)
+        self.n_reads = n_reads
+
+    def write_inputs(self, prefix, bam=True, sam=False, gff=True, level=1):
+        names, lens = self.genome.chrom_names, self.genome.chrom_lengths
+        write_bed(prefix + ".bed", names, self.junctions)
+        if gff:
+            write_gff(prefix + ".gff", self.genome)
+        pairs = [(names[c], self.reads[c]) for c in range(len(names))]
+        if bam:
+            samio.write_bam(prefix + ".bam", names, lens, pairs, level=level, with_seq=True)
+        if sam:
+            samio.write_sam(prefix + ".sam", names, lens, pairs)
+        return prefix
+
+
+def _merge_sorted(parts):
+    """Merge per-batch ReadSets of one chromosome into one coordinate-sorted ReadSet."""
+    parts = [p for p in parts if p.n]
+    if not parts:
+        return samio.ReadSet.empty()
+    if len(parts) == 1:
+        return parts[0]
+    pos = np.concatenate([p.pos for p in parts])
+    flag = np.concatenate([p.flag for p in parts])
+    nops = np.concatenate([np.diff(p.cig_off.astype(np.int64)) for p in parts])
+    ops = np.concatenate([p.cigar for p in parts])
+    order = np.argsort(pos, kind="stable")
+    src_off = np.zeros(len(pos) + 1, np.int64)
+    np.cumsum(nops, out=src_off[1:])
+    nops_s = nops[order]
+    dst_off = np.zeros(len(pos) + 1, np.int64)
+    np.cumsum(nops_s, out=dst_off[1:])
+    rep = np.repeat(src_off[:-1][order] - dst_off[:-1], nops_s)
+    cigar = ops[np.arange(dst_off[-1]) + rep]
+    return samio.ReadSet(pos[order], flag[order], dst_off, cigar, max_end=max(p.max_end for p in parts))

@@ -1,0 +1,192 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_cases
+import helpers
+from spliser_amd import native, samio, shard, sites, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_engine(ctx):
+    def count(arr, reads, stranded, combine_mode):
+        s = native.SiteArrays.from_chrom(arr)
+        r = native.ReadArrays(reads.pos, reads.flag, reads.cig_off, reads.cigar)
+        return ctx.count(s, r, stranded, combine_mode)
+
+    def sse(arr, beta1, b2s_reads, dbl, cryptic):
+        return ctx.sse(native.SiteArrays.from_chrom(arr), beta1, b2s_reads, dbl, cryptic)
+    return count, sse
+
+
+@pytest.mark.parametrize("case,variant,opts", golden_cases(), ids=lambda v: v if isinstance(v, str) else "")
+def test_gpu_reproduces_reference_goldens(case, variant, opts, ctx):
+    text, rows = helpers.run_case(case, opts, gpu_engine(ctx))
+    ref_text, ref_rows = helpers.expected(case, variant)
+    assert text == ref_text
+    helpers.assert_rows_match(rows, ref_rows, bool(opts.get("cryptic")))
+
+
+@pytest.mark.parametrize("case", ["cigar_corners", "random_b", "kat1", "random_unstranded_q"])
+@pytest.mark.parametrize("stranded", [0, 1, 2])
+@pytest.mark.parametrize("combine", [0, 1])
+def test_gpu_counters_match_oracle_all_modes(case, stranded, combine, ctx, oracle_lib):
+    table = helpers.build_table(os.path.join(helpers.GOLDEN, case), {"stranded": "fr" if stranded else None})
+    _, reads = samio.read_sam(os.path.join(helpers.GOLDEN, case, "reads.sam"))
+    ocount, _ = helpers.oracle_engine(oracle_lib)
+    gcount, _ = gpu_engine(ctx)
+    for chrom in table.chrom_index:
+        arr = table.chrom_arrays(chrom)
+        rs = reads.get(chrom, samio.ReadSet.empty())
+        for w, g in zip(ocount(arr, rs, stranded, combine), gcount(arr, rs, stranded, combine)):
+            assert np.array_equal(w, g)
+
+
+def _table_for(wl, tmp_path, stranded):
+    bed = str(tmp_path / "j.bed")
+    synth.write_bed(bed, wl.genome.chrom_names, wl.junctions)
+    table = sites.SiteTable(is_stranded=stranded)
+    table.add_bed(bed)
+    table.find_competitors()
+    return table
+
+
+@pytest.mark.parametrize("stranded,cryptic", [(0, False), (1, True), (2, True)])
+def test_gpu_matches_oracle_on_synthetic_genome(stranded, cryptic, ctx, oracle_lib, tmp_path):
+    """~400k reads over 5 chromosomes, packed into one shard (one launch) vs per-chromosome oracle."""
+    wl = synth.Workload("arabidopsis", scale=0.02, seed=21 + stranded)
+    table = _table_for(wl, tmp_path, bool(stranded))
+    names = wl.genome.chrom_names
+    items = [(c, table.chrom_arrays(c), wl.reads[i]) for i, c in enumerate(names) if table.chrom_arrays(c).n]
+    shards = shard.pack(items)
+    assert len(shards) == 1
+    sh = shards[0]
+    ds, dr = ctx.upload_sites(sh.sites), ctx.upload_reads(sh.reads)
+    ctx.count_launch(ds, dr, stranded, 0)
+    ctx.sse_launch(ds, cryptic)
+    beta1, b2s_reads, dbl = ds.counters()
+    b2s, b2c, b2w, sse = ds.sse_results()
+    dr.free()
+    ds.free()
+    total = 0
+    for (chrom, arr, reads), (r0, r1), (e0, e1) in zip(items, sh.site_rows, sh.edge_rows):
+        w1, w2, w3 = oracle_lib.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos,
+                                          reads.pos, reads.flag, reads.cig_off, reads.cigar, stranded, 0)
+        assert np.array_equal(beta1[r0:r1], w1) and np.array_equal(b2s_reads[r0:r1], w2) and np.array_equal(dbl[e0:e1], w3)
+        ws = oracle_lib.beta2_sse(arr.pos, arr.part_off, arr.part_pos, arr.part_site, arr.alpha, arr.edge_cnt, w1, w2, w3, cryptic)
+        for g, w in zip((b2s[r0:r1], b2c[r0:r1], b2w[r0:r1], sse[r0:r1]), ws):
+            assert np.array_equal(g, w)
+        assert np.all(np.abs(sse[r0:r1] - ws[3]) <= 1e-9)
+        total += int(w1.sum()) + int(w2.sum())
+    assert total > 10000
+
+
+def test_gpu_long_introns_and_hot_sites(ctx, oracle_lib):
+    """Skew: reads whose introns span thousands of sites (wave-cooperative path), one site hit by 200k reads
+    (LDS counter contention), sites outside the LDS window (global-atomic path), unsorted reads."""
+    rng = np.random.default_rng(5)
+    n_sites = 30000
+    pos = np.sort(rng.choice(np.arange(1000, 3_000_000), n_sites, replace=False)).astype(np.int64)
+    strand = np.where(rng.random(n_sites) < 0.5, ord("+"), ord("-")).astype(np.uint8)
+    # partners: pair consecutive sites; competitors: a few
+    part_off = np.arange(n_sites + 1, dtype=np.uint32)
+    partner = np.arange(n_sites) ^ 1
+    part_pos = pos[partner]
+    comp_off = np.zeros(n_sites + 1, np.uint32)
+    has_comp = rng.random(n_sites) < 0.2
+    comp_off[1:] = np.cumsum(has_comp)
+    comp_pos = pos[(np.arange(n_sites)[has_comp] + 2) % n_sites]
+    recs = []
+    for _ in range(300):   # long introns: 10 kb .. 2.5 Mb
+        p = int(rng.integers(1000, 400000))
+        recs.append((int(rng.choice([0, 16, 99, 147])), p, "20M%dN30M" % int(rng.integers(10000, 2_500_000))))
+    hot = int(pos[1234])
+    recs += [(0, hot - 40, "100M")] * 3000
+    hot_reads = samio.ReadSet.from_records(recs)
+    # bulk: 200k unspliced reads on the hot site + random 150M reads; then shuffle a slice to break sortedness
+    bulk_pos = np.concatenate((np.full(200000, hot - 70), rng.integers(1000, 2_999_000, 300000))).astype(np.int64)
+    bulk = samio.ReadSet(bulk_pos, rng.choice([0, 16], bulk_pos.shape[0]), np.arange(bulk_pos.shape[0] + 1),
+                         np.full(bulk_pos.shape[0], 150 << 4, np.uint32))
+    allpos = np.concatenate((hot_reads.pos, bulk.pos)).astype(np.int64)
+    allflag = np.concatenate((hot_reads.flag, bulk.flag))
+    nops = np.concatenate((np.diff(hot_reads.cig_off.astype(np.int64)), np.ones(bulk.n, np.int64)))
+    ops = np.concatenate((hot_reads.cigar, bulk.cigar))
+    order = np.argsort(allpos, kind="stable")
+    order[1000:5000] = order[1000:5000][::-1]
+    src = np.concatenate(([0], np.cumsum(nops)))
+    cig = np.concatenate([ops[src[i]:src[i + 1]] for i in order])
+    off = np.concatenate(([0], np.cumsum(nops[order])))
+    sites_c = native.SiteArrays(pos, strand, part_off, part_pos, comp_off, comp_pos)
+    reads_c = native.ReadArrays(allpos[order], allflag[order], off, cig)
+    for stranded in (0, 1):
+        got = ctx.count(sites_c, reads_c, stranded, 0)
+        want = oracle_lib.check_bam(pos, strand, part_off, part_pos, comp_off, comp_pos, reads_c.pos, reads_c.flag,
+                                    reads_c.cig_off, reads_c.cigar, stranded, 0)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+    assert int(want[0][1234]) >= 100000 or int(got[0][1234]) >= 100000
+
+
+def test_gpu_empty_and_degenerate_inputs(ctx):
+    empty_sites = native.SiteArrays(np.zeros(0), np.zeros(0, np.uint8), np.zeros(1), np.zeros(0), np.zeros(1), np.zeros(0))
+    one_read = native.ReadArrays([100], [0], [0, 1], [50 << 4])
+    b1, b2, d = ctx.count(empty_sites, one_read)
+    assert len(b1) == 0 and len(b2) == 0 and len(d) == 0
+    sites_c = native.SiteArrays([120], [ord("+")], [0, 1], [300], [0, 0], np.zeros(0))
+    no_reads = native.ReadArrays(np.zeros(0), np.zeros(0), [0], np.zeros(0))
+    b1, b2, d = ctx.count(sites_c, no_reads)
+    assert b1.tolist() == [0] and b2.tolist() == [0]
+    b1, _, _ = ctx.count(sites_c, one_read)
+    assert b1.tolist() == [1]
+    star = native.ReadArrays([120, 120], [0, 4], [0, 0, 1], [60 << 4])   # CIGAR '*' and unmapped-with-CIGAR at t
+    b1, _, _ = ctx.count(sites_c, star)
+    assert b1.tolist() == [1]
+
+
+def test_gpu_rejects_bad_arguments(ctx):
+    sites_c = native.SiteArrays([200, 100], [43, 43], [0, 0, 0], np.zeros(0), [0, 0, 0], np.zeros(0))
+    reads_c = native.ReadArrays([100], [0], [0, 1], [50 << 4])
+    with pytest.raises(native.SpliserNativeError):
+        ctx.count(sites_c, reads_c)          # unsorted site table
+    ok_sites = native.SiteArrays([100], [43], [0, 0], np.zeros(0), [0, 0], np.zeros(0))
+    with pytest.raises(native.SpliserNativeError):
+        ctx.count(ok_sites, reads_c, stranded=3)
+    far = native.ReadArrays([2147483000], [0], [0, 1], [(1 << 20) << 4])
+    with pytest.raises(native.SpliserNativeError) as err:
+        ctx.count(ok_sites, far)
+    assert err.value.code == -6
+
+
+def test_process_cli_end_to_end_bam(ctx, tmp_path, oracle_lib):
+    """BAM file -> native decoder -> packed shard -> kernels -> .SpliSER.tsv, vs the committed golden."""
+    from spliser_amd import cli
+    for case, variant in (("random_b", "fr_cryptic"), ("multichrom", "annot"), ("single_gene", "gene")):
+        d = os.path.join(helpers.GOLDEN, case)
+        opts = dict(__import__("json").load(open(os.path.join(helpers.GOLDEN, "manifest.json")))[case][variant])
+        names, sets = samio.read_sam(os.path.join(d, "reads.sam"))
+        bam = str(tmp_path / (case + ".bam"))
+        samio.write_bam(bam, names, [10 ** 8] * len(names), [(c, sets[c]) for c in names if c in sets], with_seq=True)
+        argv = ["process", "-B", bam, "-b", os.path.join(d, "junctions.bed"), "-o", str(tmp_path / case)]
+        if opts.get("gff"):
+            argv += ["-A", os.path.join(d, "genes.gff")]
+        if opts.get("chrom"):
+            argv += ["-c", opts["chrom"]]
+        if opts.get("gene"):
+            argv += ["-g", opts["gene"], "-m", str(opts["max_intron"])]
+        if opts.get("stranded"):
+            argv += ["--isStranded", "-s", opts["stranded"]]
+        if opts.get("cryptic"):
+            argv += ["--beta2Cryptic"]
+        assert cli.main(argv) == 0
+        got = open(str(tmp_path / case) + ".SpliSER.tsv").read()
+        assert got == helpers.expected(case, variant)[0]
