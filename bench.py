@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--stranded", default=None, choices=[None, "fr", "rf"])
     ap.add_argument("--beta2Cryptic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache", default=None, help="directory to cache the generated sample in (.npz); a cached "
+                    "sample is loaded instead of regenerated (use under rocprofv3: no generator worker processes)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -45,22 +47,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-
     from spliser_amd import native, shard, sites, synth
 
-    # ---- synthetic sample of this rank -------------------------------------------------------------
+    # ---- synthetic sample of this rank (generated BEFORE the GPU is touched: the generator forks) -----
     t_gen = time.perf_counter()
     cfg = synth.WORKLOADS[args.workload]
     stranded = args.stranded or ("fr" if cfg.get("paired") else None)
-    wl = synth.Workload(args.workload, scale=args.scale, seed=cfg["seed"] + rank)
+    cache = None
+    if args.cache:
+        os.makedirs(args.cache, exist_ok=True)
+        cache = os.path.join(args.cache, "%s_s%g_seed%d.npz" % (args.workload, args.scale, cfg["seed"] + rank))
+    if cache and os.path.exists(cache):
+        wl = synth.Workload.load(cache, args.workload)
+    else:
+        wl = synth.Workload(args.workload, scale=args.scale, seed=cfg["seed"] + rank,
+                            workers=max(1, min(8, (os.cpu_count() or 1) // max(world, 1))))
+        if cache:
+            wl.save(cache)
     tmp = tempfile.mkdtemp(prefix="spliser_bench_")
     bed = os.path.join(tmp, "junctions.bed")
     synth.write_bed(bed, wl.genome.chrom_names, wl.junctions)
@@ -77,6 +80,13 @@ def main():
     n_reads = sum(sh.reads.n for sh in shards)
     n_sites = sum(sh.sites.n for sh in shards)
     t_gen = time.perf_counter() - t_gen
+
+    import torch
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     scode = native.STRANDED_CODE[stranded]
     ctx = native.Context(local_rank)

@@ -8,6 +8,8 @@ consumes; ``write_inputs`` can also materialise BAM/SAM + BED + GFF files for en
 Site convention (SpliSER_v0_1_8.py:275-276, :482-483): for an intron between an exon ending at ``eA``
 and one starting at ``sB`` (1-based, inclusive) the left site is ``eA`` and the right site ``sB - 1``.
 """
+import os
+
 import numpy as np
 
 from . import samio
@@ -259,11 +261,13 @@ def junction_table(batches, min_count=1):
     if len(chrom) == 0:
         z = np.zeros(0, np.int64)
         return z, z, z, np.zeros(0, np.uint8), z
-    key = np.stack((chrom, left, right, strand.astype(np.int64)), axis=1)
-    uniq, counts = np.unique(key, axis=0, return_counts=True)
+    # pack (chrom, left, right - left, strand) into one int64 key: 6 + 29 + 27 + 1 bits
+    span = right - left
+    key = (((chrom << 29 | left) << 27 | span) << 1) | (strand == ord("-")).astype(np.int64)
+    uniq, first, counts = np.unique(key, return_index=True, return_counts=True)
     keep = counts >= min_count
-    uniq, counts = uniq[keep], counts[keep]
-    return uniq[:, 0], uniq[:, 1], uniq[:, 2], uniq[:, 3].astype(np.uint8), counts
+    first, counts = first[keep], counts[keep]
+    return chrom[first], left[first], right[first], strand[first], counts
 
 
 def write_bed(path, chrom_names, junctions, overhang=20, stranded=True):
@@ -287,10 +291,30 @@ def write_gff(path, genome):
                 chr(int(genome.gene_strand[i])), name, name))
 
 
+_POOL_STATE = None
+
+
+class _Junctions(object):
+    __slots__ = ("junc_chrom", "junc_left", "junc_right", "junc_strand")
+
+
+def _batch_job(job):
+    m, seed = job
+    genome, paired, nchr = _POOL_STATE
+    rb = make_reads(genome, m, seed=seed, paired=paired)
+    j = _Junctions()
+    j.junc_chrom, j.junc_left, j.junc_right, j.junc_strand = rb.junc_chrom, rb.junc_left, rb.junc_right, rb.junc_strand
+    return split_by_chrom(rb, nchr), j
+
+
 class Workload(object):
     """A genome + reads per chromosome + the site table inputs derived from them."""
 
-    def __init__(self, name, n_reads=None, seed=None, scale=1.0, batch=20_000_000, **over):
+    def __init__(self, name, n_reads=None, seed=None, scale=1.0, batch=2_500_000, workers=None, **over):
+        """``workers`` processes (fork) generate ``batch``-read slices in parallel; call this BEFORE the
+        process touches the GPU (a forked child must not inherit an initialised HIP runtime)."""
+        if workers is None:
+            workers = min(8, os.cpu_count() or 1)
         cfg = dict(WORKLOADS[name])
         cfg.update(over)
         self.name = name
@@ -301,21 +325,56 @@ class Workload(object):
         self.genome = make_genome(cfg["chroms"], n_genes, cfg["intron"], seed=self.seed)
         nchr = len(self.genome.chrom_names)
         per_chrom = [[] for _ in range(nchr)]
-        batches = []
-        done = 0
-        k = 0
+        jobs = []
+        done = k = 0
         while done < n_reads:
             m = min(batch, n_reads - done)
-            rb = make_reads(self.genome, m, seed=self.seed * 1000 + k, paired=self.paired)
-            for c, rs in enumerate(split_by_chrom(rb, nchr)):
-                per_chrom[c].append(rs)
-            rb.cigar = rb.cig_off = rb.pos = rb.flag = rb.chrom = None
-            batches.append(rb)
+            jobs.append((m, self.seed * 1000 + k))
             done += m
             k += 1
+        global _POOL_STATE
+        _POOL_STATE = (self.genome, self.paired, nchr)
+        if workers > 1 and len(jobs) > 1:
+            import multiprocessing
+            with multiprocessing.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+                results = pool.map(_batch_job, jobs)
+        else:
+            results = [_batch_job(j) for j in jobs]
+        _POOL_STATE = None
+        batches = []
+        for sets, junc in results:
+            for c, rs in enumerate(sets):
+                per_chrom[c].append(rs)
+            batches.append(junc)
         self.reads = [_merge_sorted(parts) for parts in per_chrom]
         self.junctions = junction_table(batches)
         self.n_reads = n_reads
+
+    # -- on-disk cache (profiling runs must not fork generator workers under rocprofv3) ----------------
+    def save(self, path):
+        arrays = {"junc%d" % i: a for i, a in enumerate(self.junctions)}
+        for c, rs in enumerate(self.reads):
+            arrays.update({"pos%d" % c: rs.pos, "flag%d" % c: rs.flag, "off%d" % c: rs.cig_off, "cig%d" % c: rs.cigar,
+                           "end%d" % c: np.asarray([rs.max_end])})
+        arrays["chrom_lengths"] = np.asarray(self.genome.chrom_lengths, np.int64)
+        arrays["chrom_names"] = np.asarray(self.genome.chrom_names)
+        arrays["meta"] = np.asarray([self.n_reads, self.seed, int(self.paired)], np.int64)
+        np.savez(path, **arrays)
+
+    @classmethod
+    def load(cls, path, name):
+        z = np.load(path)
+        self = cls.__new__(cls)
+        self.name = name
+        self.n_reads, self.seed, paired = (int(v) for v in z["meta"])
+        self.paired = bool(paired)
+        self.genome = Genome()
+        self.genome.chrom_names = [str(c) for c in z["chrom_names"]]
+        self.genome.chrom_lengths = [int(v) for v in z["chrom_lengths"]]
+        self.junctions = tuple(z["junc%d" % i] for i in range(5))
+        self.reads = [samio.ReadSet(z["pos%d" % c], z["flag%d" % c], z["off%d" % c], z["cig%d" % c], int(z["end%d" % c][0]))
+                      for c in range(len(self.genome.chrom_names))]
+        return self
 
     def write_inputs(self, prefix, bam=True, sam=False, gff=True, level=1):
         names, lens = self.genome.chrom_names, self.genome.chrom_lengths
