@@ -128,43 +128,47 @@ def main():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         tot_reads, tot_sites = float(c[0].item()), float(c[1].item())
 
-    # ---- parity spot check + CPU baseline (rank 0, N = 1 only for the baseline) ---------------------
+    # ---- whole-workload parity check + CPU baseline (rank 0; the baseline only at N = 1) -------------
+    # The oracle is the checker here, never the thing measured as "value".  It is so much faster than the
+    # Python reference (tens of M reads/s on one core) that the bounded sample is the ENTIRE workload,
+    # repeated until ~cpu-seconds of CPU work have been timed.
     cpu = None
     parity = None
     if rank == 0:
         from oracle import oracle
-        c0, arr0, reads0 = max(items, key=lambda it: it[2].n)
-        probe = min(reads0.n, 200_000)
+        gpu_counts = [ds.counters() for ds, _ in dev]          # results of the last timed step
+        gpu_sse = [ds.sse_results() for ds, _ in dev]
 
-        def sample(m):
-            off = reads0.cig_off[: m + 1]
-            return reads0.pos[:m], reads0.flag[:m], off, reads0.cigar[: int(off[-1])]
-
-        def run_oracle(m):
-            p, f, o, g = sample(m)
+        def run_oracle():
+            res = {}
             t = time.perf_counter()
-            cnt = oracle.check_bam(arr0.pos, arr0.strand, arr0.part_off, arr0.part_pos, arr0.comp_off, arr0.comp_pos,
-                                   p, f, o, g, scode, 0)
-            sse = oracle.beta2_sse(arr0.pos, arr0.part_off, arr0.part_pos, arr0.part_site, arr0.alpha, arr0.edge_cnt,
-                                   cnt[0], cnt[1], cnt[2], args.beta2Cryptic)
-            return time.perf_counter() - t, cnt, sse
+            for c, arr, rd in items:
+                cnt = oracle.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos,
+                                       rd.pos, rd.flag, rd.cig_off, rd.cigar, scode, 0)
+                sse = oracle.beta2_sse(arr.pos, arr.part_off, arr.part_pos, arr.part_site, arr.alpha, arr.edge_cnt,
+                                       cnt[0], cnt[1], cnt[2], args.beta2Cryptic)
+                res[c] = (cnt, sse)
+            return time.perf_counter() - t, res
 
-        t_probe, cnt, sse = run_oracle(probe)
-        m = probe
+        t_cpu, want = run_oracle()
+        exact = True
+        for sh, cnts, sses in zip(shards, gpu_counts, gpu_sse):
+            for chrom, (r0, r1), (e0, e1) in zip(sh.chroms, sh.site_rows, sh.edge_rows):
+                (w1, w2, w3), wsse = want[chrom]
+                exact &= np.array_equal(cnts[0][r0:r1], w1) and np.array_equal(cnts[1][r0:r1], w2) and np.array_equal(cnts[2][e0:e1], w3)
+                exact &= all(np.array_equal(g[r0:r1], w) for g, w in zip(sses, wsse))
+        parity = {"reads": n_reads, "sites": n_sites, "bit_exact_vs_oracle": bool(exact),
+                  "checked": "beta1, beta2Simple(reads), double counts, beta2Simple, beta2Cryptic, beta2Weighted, SSE"}
         if world == 1 and not args.no_cpu_baseline:
-            rate = probe / max(t_probe, 1e-6)
-            m = int(min(reads0.n, max(probe, rate * args.cpu_seconds)))
-            t_cpu, cnt, sse = run_oracle(m)
-            cpu = {"value": m / t_cpu, "unit": "reads/s", "cores": 1, "kind": "port",
-                   "sites_per_sec": arr0.n / t_cpu,
-                   "sample": "first %d coordinate-sorted reads of %s x its %d sites, oracle/spliser_oracle.c "
-                             "(site-centric C restatement, 1 thread), %.1f s" % (m, c0, arr0.n, t_cpu)}
-        p, f, o, g = sample(m)
-        s_arr = native.SiteArrays.from_chrom(arr0)
-        got = ctx.count(s_arr, native.ReadArrays(p, f, o, g), scode, 0)
-        got_sse = ctx.sse(s_arr, got[0], got[1], got[2], args.beta2Cryptic)
-        exact = all(np.array_equal(a, b) for a, b in zip(got, cnt)) and all(np.array_equal(a, b) for a, b in zip(got_sse, sse))
-        parity = {"reads": m, "sites": arr0.n, "bit_exact_vs_oracle": bool(exact)}
+            times = [t_cpu]
+            while sum(times) < args.cpu_seconds and len(times) < 50:
+                times.append(run_oracle()[0])
+            best = min(times)
+            cpu = {"value": n_sites / best, "unit": "splice sites/s", "reads_per_sec": n_reads / best, "cores": 1,
+                   "kind": "port",
+                   "sample": "the whole workload (%d reads x %d sites), oracle/spliser_oracle.c site-centric C "
+                             "restatement on 1 thread, best of %d passes (%.2f s each, %.1f s total)"
+                             % (n_reads, n_sites, len(times), best, sum(times))}
 
     for ds, dr in dev:
         dr.free()
