@@ -65,8 +65,9 @@ typedef struct spl_sites {
     const uint8_t *strand;     /* [n_sites]   Site.strand as ASCII ('+', '-', anything else = none)  */
     const uint32_t *part_off;  /* [n_sites+1] CSR offsets into part_*                                */
     const int32_t *part_pos;   /* [n_part]    keys of Site.PartnerCounts, insertion order            */
-    const int32_t *part_site;  /* [n_part]    row of that partner in this table, -1 when absent; may
-                                              be NULL for spl_count (only spl_sse reads it)         */
+    const int32_t *part_site;  /* [n_part]    row of that partner in this table, -1 when absent; when
+                                              NULL spl_count falls back to the pair kernel and spl_sse
+                                              is unavailable                                        */
     const uint32_t *comp_off;  /* [n_sites+1] CSR offsets into comp_pos                              */
     const int32_t *comp_pos;   /* [n_comp]    Site.CompetitorPos (sorted unique)                     */
     const int64_t *alpha;      /* [n_sites]   Site.alphaCounts[sample]; may be NULL for spl_count    */
@@ -89,7 +90,13 @@ typedef struct spl_opts {
     int32_t stranded;     /* 0 = unstranded, 1 = "fr", 2 = "rf"   (check_strand, SpliSER_v0_1_8.py:374-406) */
     int32_t combine_mode; /* 0 = `process`; 1 = `combine`/`combineShallow`: a flanking read also counts
                              toward beta2Simple (SpliSER_v0_1_8.py:529-536)                            */
+    int32_t flags;        /* SPL_OPT_* bits                                                            */
 } spl_opts;
+
+/* Force the literal per-(read, site) kernel.  By default spl_count uses the range kernel whenever every
+ * partner edge of the table has its reverse edge (tables built like findAlphaCounts builds them), and the
+ * pair kernel otherwise (e.g. combine gap-fill queries); both give identical counters. */
+#define SPL_OPT_PAIR_KERNEL 1
 
 /* ---- library / context ------------------------------------------------------------------------ */
 int spl_abi_version(void);

@@ -45,7 +45,7 @@ struct spl_ctx {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int32_t *d_err = nullptr;
-    int last_grid = 0;
+    int last_grid = 0, last_lds = 0, last_variant = 0;
     // optional per-launch stopwatch around spl_count_kernel alone (bench.py's roofline numerator)
     std::vector<hipEvent_t> k_ev; // pairs
     int k_used = 0;
@@ -57,7 +57,7 @@ struct spl_dsites {
     char *slab = nullptr; // one allocation; the pointers below live inside it
     size_t slab_bytes = 0;
     int32_t *pos = nullptr;
-    uint8_t *strand = nullptr;
+    uint8_t *strand = nullptr, *flags = nullptr;
     uint4 *meta = nullptr;
     uint32_t *part_off = nullptr;
     int32_t *part_pos = nullptr, *part_site = nullptr, *comp_pos = nullptr;
@@ -66,6 +66,10 @@ struct spl_dsites {
     uint32_t n_buckets = 0;
     int32_t bucket_base = 0, bucket_shift = 0;
     bool has_sse_inputs = false;
+    bool mutual_links = false; // every partner edge has its reverse edge: the range kernel is applicable
+    int32_t *diff = nullptr;   // 4 difference arrays of diff_stride int32 (range kernel)
+    int32_t *block_sums = nullptr;
+    int32_t diff_stride = 0, scan_blocks = 0;
     // outputs
     uint32_t *beta1 = nullptr, *beta2s = nullptr, *dbl = nullptr; // contiguous: one memset clears all three
     size_t counter_bytes = 0;
@@ -248,23 +252,48 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
         bucket[d->n_buckets] = (uint32_t)S;
     }
     std::vector<uint4> meta((size_t)S);
-    for (int64_t i = 0; i < S; ++i)
-        meta[(size_t)i] = make_uint4(s->part_off[i], s->part_off[i + 1] - s->part_off[i], s->comp_off[i], s->comp_off[i + 1] - s->comp_off[i]);
+    std::vector<uint8_t> flags((size_t)S);
+    for (int64_t i = 0; i < S; ++i) {
+        const uint32_t np = s->part_off[i + 1] - s->part_off[i];
+        meta[(size_t)i] = make_uint4(s->part_off[i], np, s->comp_off[i], s->comp_off[i + 1] - s->comp_off[i]);
+        flags[(size_t)i] = (uint8_t)((s->strand[i] == '+' ? SPL_SF_PLUS : 0u) | (s->strand[i] == '-' ? SPL_SF_MINUS : 0u) |
+                                     (np >= 2 ? SPL_SF_BRANCH : 0u));
+    }
+    // The range kernel finds the sites whose outcome depends on their own partner / competitor lists by walking
+    // the partner edges of the rows at a read's junction ends; that needs every edge s -> p to exist as p -> s
+    // (true for tables built like findAlphaCounts does, SpliSER_v0_1_8.py:352-355).  Otherwise: pair kernel.
+    d->mutual_links = s->part_site != nullptr || P == 0;
+    for (int64_t i = 0; i < S && d->mutual_links; ++i) {
+        for (uint32_t e = s->part_off[i]; e < s->part_off[i + 1] && d->mutual_links; ++e) {
+            const int32_t q = s->part_site[e];
+            bool ok = q >= 0 && q < S && s->pos[q] == s->part_pos[e];
+            if (ok) {
+                ok = false;
+                for (uint32_t f = s->part_off[q]; f < s->part_off[q + 1]; ++f) ok |= (s->part_site[f] == (int32_t)i);
+            }
+            if (!ok) d->mutual_links = false;
+        }
+    }
+    d->diff_stride = (int32_t)align_up((size_t)S + 1, 64);
+    d->scan_blocks = (int32_t)((S + SPL_SCAN_BLOCK - 1) / SPL_SCAN_BLOCK);
 
     // slab layout
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
-    const size_t o_pos = take(4 * S), o_strand = take(S), o_meta = take(16 * S), o_poff = take(4 * (S + 1));
+    const size_t o_pos = take(4 * S), o_strand = take(S), o_flags = take(S), o_meta = take(16 * S), o_poff = take(4 * (S + 1));
     const size_t o_ppos = take(4 * P), o_psite = take(4 * P), o_cpos = take(4 * C);
     const size_t o_alpha = take(8 * S), o_ecnt = take(8 * P), o_bucket = take(4 * bucket.size());
     const size_t o_cnt = off;
     const size_t o_b1 = take(4 * S), o_b2 = take(4 * S), o_dbl = take(4 * P);
+    const size_t o_diff = take(4 * 4 * (size_t)d->diff_stride);
     d->counter_bytes = off - o_cnt;
+    const size_t o_bsum = take(4 * 4 * (size_t)std::max(d->scan_blocks, 1));
     const size_t o_b2s = take(8 * S), o_b2c = take(8 * S), o_b2w = take(8 * S), o_sse = take(8 * S);
     d->slab_bytes = std::max<size_t>(off, 256);
     hipError_t e = hipMalloc((void **)&d->slab, d->slab_bytes);
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the site table: %s", d->slab_bytes, hipGetErrorString(e)); }
     d->pos = (int32_t *)(d->slab + o_pos); d->strand = (uint8_t *)(d->slab + o_strand); d->meta = (uint4 *)(d->slab + o_meta);
+    d->flags = (uint8_t *)(d->slab + o_flags); d->diff = (int32_t *)(d->slab + o_diff); d->block_sums = (int32_t *)(d->slab + o_bsum);
     d->part_off = (uint32_t *)(d->slab + o_poff); d->part_pos = (int32_t *)(d->slab + o_ppos); d->part_site = (int32_t *)(d->slab + o_psite);
     d->comp_pos = (int32_t *)(d->slab + o_cpos); d->alpha = (int64_t *)(d->slab + o_alpha); d->edge_cnt = (int64_t *)(d->slab + o_ecnt);
     d->bucket = (uint32_t *)(d->slab + o_bucket);
@@ -280,6 +309,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (r == hipSuccess) r = up(d->pos, s->pos, 4 * S);
     if (r == hipSuccess) r = up(d->strand, s->strand, S);
     if (r == hipSuccess) r = up(d->meta, meta.data(), 16 * S);
+    if (r == hipSuccess) r = up(d->flags, flags.data(), S);
     if (r == hipSuccess) r = up(d->part_off, s->part_off, S ? 4 * (S + 1) : 0);
     if (r == hipSuccess) r = up(d->part_pos, s->part_pos, 4 * P);
     if (r == hipSuccess) r = up(d->part_site, s->part_site, 4 * P);
@@ -360,17 +390,32 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.n_chunks = (uint32_t)((dr->n_reads + SPL_CHUNK - 1) / SPL_CHUNK);
     p.r_pos = dr->pos; p.r_flag = dr->flag; p.cig_off = dr->cig_off; p.cigar = dr->cigar;
     p.n_sites = (int32_t)ds->n_sites;
-    p.site_pos = ds->pos; p.site_strand = ds->strand; p.site_meta = ds->meta; p.part_pos = ds->part_pos; p.comp_pos = ds->comp_pos;
+    p.site_pos = ds->pos; p.site_strand = ds->strand; p.site_flags = ds->flags; p.site_meta = ds->meta;
+    p.part_pos = ds->part_pos; p.part_site = ds->part_site; p.comp_pos = ds->comp_pos;
+    p.diff = ds->diff; p.diff_stride = ds->diff_stride;
     p.bucket = ds->bucket; p.n_buckets = ds->n_buckets; p.bucket_base = ds->bucket_base; p.bucket_shift = ds->bucket_shift;
     p.stranded = o->stranded; p.combine_mode = o->combine_mode ? 1 : 0;
     p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = c->d_err;
-    int grid = 0;
+    // range kernel whenever the table allows it; the literal pair kernel otherwise or on request
+    const int variant = (!ds->mutual_links || (o->flags & SPL_OPT_PAIR_KERNEL)) ? 1 : 0;
+    int grid = 0, lds = 0;
     const bool timed = c->k_on && (size_t)(2 * c->k_used + 1) < c->k_ev.size();
     if (timed) HIP_TRY(hipEventRecord(c->k_ev[2 * c->k_used], c->stream));
-    int rc = spl_dev_launch_count(&p, c->stream, &grid);
+    int rc = spl_dev_launch_count(&p, variant, c->stream, &grid, &lds);
     if (timed) { HIP_TRY(hipEventRecord(c->k_ev[2 * c->k_used + 1], c->stream)); c->k_used++; }
     c->last_grid = grid;
-    if (rc != 0) return spl_set_error(SPL_ERR_HIP, "spl_count_kernel launch: %s", hipGetErrorString((hipError_t)rc));
+    c->last_lds = lds;
+    c->last_variant = variant;
+    if (rc != 0) return spl_set_error(SPL_ERR_HIP, "count kernel launch: %s", hipGetErrorString((hipError_t)rc));
+    if (variant == 0 && grid > 0) { // difference arrays -> counters
+        spl_scan_params q;
+        memset(&q, 0, sizeof(q));
+        q.n_sites = (int32_t)ds->n_sites; q.n_arrays = o->stranded ? 4 : 2; q.diff_stride = ds->diff_stride;
+        q.n_blocks = ds->scan_blocks; q.diff = ds->diff; q.block_sums = ds->block_sums; q.site_flags = ds->flags;
+        q.beta1 = ds->beta1; q.beta2s_reads = ds->beta2s;
+        rc = spl_dev_launch_scan(&q, c->stream);
+        if (rc != 0) return spl_set_error(SPL_ERR_HIP, "scan kernel launch: %s", hipGetErrorString((hipError_t)rc));
+    }
     return SPL_OK;
 }
 
@@ -439,7 +484,7 @@ extern "C" int spl_last_launch_info(const spl_ctx *c, int32_t *grid, int32_t *bl
     if (!c) return spl_set_error(SPL_ERR_ARG, "spl_last_launch_info: null context");
     if (grid) *grid = c->last_grid;
     if (block) *block = SPL_BLOCK;
-    if (lds) *lds = 2 * SPL_WIN * 4 + 4;
+    if (lds) *lds = c->last_lds;
     return SPL_OK;
 }
 

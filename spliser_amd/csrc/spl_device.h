@@ -5,17 +5,23 @@
 #include <stdint.h>
 #include <hip/hip_vector_types.h>
 
-// Launch geometry of spl_count_kernel (see DESIGN.md "Kernels").
+// Launch geometry of the classification kernels (see DESIGN.md "Kernels").
 #define SPL_BLOCK 256                    // threads per workgroup = 4 waves
 #define SPL_RPT 8                        // reads per thread
 #define SPL_CHUNK (SPL_BLOCK * SPL_RPT)  // consecutive reads per workgroup
-#define SPL_WIN 2048                     // sites whose counters a workgroup privatises in LDS (2 x 8 KiB)
-#define SPL_SERIAL_MAX 8                 // sites a lane classifies alone before the wave takes the read over
+#define SPL_WIN 2048                     // site rows whose counters a workgroup privatises in LDS
+#define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
+#define SPL_SCAN_BLOCK 1024              // rows per workgroup in the difference-array scan
 
 // Coordinates (read end, site position) must stay <= SPL_COORD_MAX so that t+1 and cur never wrap int32.
 #define SPL_COORD_MAX 2147483645
 
 #define SPL_DEV_ERR_RANGE 1
+
+// per-row flag byte (built at upload)
+#define SPL_SF_PLUS 1u    // Site.strand == '+'
+#define SPL_SF_MINUS 2u   // Site.strand == '-'
+#define SPL_SF_BRANCH 4u  // the row has >= 2 partners: a junction ending here has rival sites
 
 struct spl_count_params {
     // reads
@@ -28,23 +34,39 @@ struct spl_count_params {
     // sites
     int32_t n_sites;
     const int32_t *site_pos;
-    const uint8_t *site_strand;
-    const uint4 *site_meta;   // {part_off, n_part, comp_off, n_comp}
+    const uint8_t *site_strand;  // ASCII, pair kernel
+    const uint8_t *site_flags;   // SPL_SF_*, range kernel
+    const uint4 *site_meta;      // {part_off, n_part, comp_off, n_comp}
     const int32_t *part_pos;
+    const int32_t *part_site;
     const int32_t *comp_pos;
     // position -> first-row index
-    const uint32_t *bucket;   // n_buckets + 1 entries
+    const uint32_t *bucket;      // n_buckets + 1 entries
     uint32_t n_buckets;
     int32_t bucket_base;
     int32_t bucket_shift;
     // options
-    int32_t stranded;         // 0 none, 1 fr, 2 rf
+    int32_t stranded;            // 0 none, 1 fr, 2 rf
     int32_t combine_mode;
     // outputs
-    uint32_t *beta1;
+    uint32_t *beta1;             // point counters (pair kernel, rival-site corrections); the scan adds the ranges
     uint32_t *beta2s_reads;
     uint32_t *dbl;
+    int32_t *diff;               // range kernel: n_diff difference arrays of (n_sites + 1) int32, row-major
+    int32_t diff_stride;         // n_sites + 1 rounded up
     int32_t *err;
+};
+
+struct spl_scan_params {
+    int32_t n_sites;
+    int32_t n_arrays;            // 2 unstranded {beta1, ME}; 4 stranded {beta1+, beta1-, ME+, ME-}
+    int32_t diff_stride;
+    int32_t n_blocks;
+    const int32_t *diff;
+    int32_t *block_sums;         // [n_arrays][n_blocks]
+    const uint8_t *site_flags;
+    uint32_t *beta1;
+    uint32_t *beta2s_reads;
 };
 
 struct spl_sse_params {
@@ -68,7 +90,9 @@ struct spl_sse_params {
 #ifdef __cplusplus
 extern "C" {
 #endif
-int spl_dev_launch_count(const spl_count_params *p, void *stream, int *grid_out);
+// variant: 0 = range kernel (needs mutual partner links), 1 = pair kernel (any table)
+int spl_dev_launch_count(const spl_count_params *p, int variant, void *stream, int *grid_out, int *lds_out);
+int spl_dev_launch_scan(const spl_scan_params *p, void *stream);
 int spl_dev_launch_sse(const spl_sse_params *p, void *stream);
 #ifdef __cplusplus
 }

@@ -1,11 +1,21 @@
 // spl_kernels.hip -- CDNA4 (gfx950, wave64) kernels of the SpliSER `process` hot path.
 //
-//   spl_count_kernel  read-centric restatement of the checkBam loop (SpliSER_v0_1_8.py:408-559, called per
-//                     site from processSites :686-688): every read finds the splice sites it would have been
-//                     fetched for and classifies itself against each of them.
-//   spl_sse_kernel    findBeta2Counts + calculateSSE (SpliSER_v0_1_8.py:581-639), one site per lane.
+//   spl_count_ranges_kernel  the checkBam loop (SpliSER_v0_1_8.py:408-559, called per site from processSites
+//                            :686-688) turned inside out: every read walks its CIGAR ONCE and turns each op
+//                            into a range of site rows -- an aligned block makes every row it covers (t and
+//                            t+1) a beta1 read, an N op makes every row strictly inside it a
+//                            mutually-exclusive (beta2Simple) read -- recorded as +1/-1 in LDS-privatised
+//                            difference arrays.  Cost per read is O(ops), whatever the number of sites a
+//                            500 kb intron spans.  Only the sites whose outcome can depend on their own
+//                            partner / competitor lists (rivals of the read's junction ends) are classified
+//                            one by one with the literal state machine (spl_classify.h) and corrected.
+//   spl_scan_*_kernel        prefix sums that turn the difference arrays into beta1 / beta2Simple counters.
+//   spl_count_pairs_kernel   the literal formulation: every (read, site) pair through spl_classify_pair.
+//                            Used for tables whose partner links are not mutual (combine gap-fill queries)
+//                            and as an on-device cross-check of the range kernel in the tests.
+//   spl_sse_kernel           findBeta2Counts + calculateSSE (SpliSER_v0_1_8.py:581-639), one site per lane.
 //
-// Integer / indexing work: no MFMA.  The roofline that bounds spl_count_kernel is HBM.
+// Integer / indexing work: no MFMA.  The roofline that bounds the count kernels is HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -35,7 +45,38 @@ __device__ __forceinline__ int32_t first_site_at_or_after(const spl_count_params
     return (int32_t)lo;
 }
 
-// One counter increment: LDS-privatised when the site falls in this workgroup's window, global otherwise.
+// XCD-aware chunk order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one contiguous
+// eighth of the (coordinate-sorted) reads -- its L2 then sees one moving window of the site table.
+__device__ __forceinline__ uint32_t my_chunk()
+{
+    const uint32_t per = (gridDim.x + 7u) >> 3;
+    return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+}
+
+// ---- literal (read, site) pair: shared by the pair kernel and by the slow paths of the range kernel ------
+
+// Counter updates of one classified pair, straight to HBM (SpliSER_v0_1_8.py:519-559).
+__device__ __forceinline__ void apply_pair_global(const spl_count_params &p, const spl_pair &r, int32_t s, int32_t pos,
+                                                  const uint32_t *ops, uint32_t n_ops, const int32_t *part,
+                                                  uint32_t n_part, uint32_t part_off)
+{
+    switch (r.cls) {
+    case SPL_CLS_BETA1: atomicAdd(&p.beta1[s], 1u); break;
+    case SPL_CLS_ME: atomicAdd(&p.beta2s_reads[s], 1u); break;
+    case SPL_CLS_FLANK: if (p.combine_mode) atomicAdd(&p.beta2s_reads[s], 1u); break;
+    case SPL_CLS_B1TYPE: atomicAdd(&p.beta2s_reads[s], 1u); [[fallthrough]];
+    case SPL_CLS_ALPHA_COMP:
+        for (uint32_t e = 0; e < n_part; ++e) { // PartnerBeta2DoubleCounts (:519-527, :544-551)
+            const int32_t pp = part[e];
+            if (r.cls == SPL_CLS_ALPHA_COMP && r.has_partner_used && pp == r.partner_used) continue;
+            if (spl_read_splices_at(pos, ops, n_ops, pp)) atomicAdd(&p.dbl[part_off + e], 1u);
+        }
+        break;
+    default: break;
+    }
+}
+
+// One counter increment: LDS-privatised when the row falls in this workgroup's window, global otherwise.
 __device__ __forceinline__ void bump(uint32_t *lds_cnt, uint32_t *glob, int32_t s, int32_t wbase)
 {
     const uint32_t loc = (uint32_t)(s - wbase);
@@ -52,7 +93,7 @@ __device__ __forceinline__ void do_pair(const spl_count_params &p, uint32_t *lds
     const int32_t *part = nullptr, *comp = nullptr;
     uint32_t n_part = 0, n_comp = 0, part_off = 0;
     if (has_n) {
-        const uint4 m = p.site_meta[s]; // {part_off, n_part, comp_off, n_comp}
+        const uint4 m = p.site_meta[s];
         part_off = m.x;
         if (m.w != 0u) { // without competitors compSplicing can never be set (:494-501): lists not needed
             n_part = m.y;
@@ -62,47 +103,25 @@ __device__ __forceinline__ void do_pair(const spl_count_params &p, uint32_t *lds
         }
     }
     const spl_pair r = spl_classify_pair(pos, ops, n_ops, t, part, n_part, comp, n_comp, strand_ok);
-    switch (r.cls) {
-    case SPL_CLS_BETA1:
-        bump(lds, p.beta1, s, wbase);
-        break;
-    case SPL_CLS_ME:
-        bump(lds + SPL_WIN, p.beta2s_reads, s, wbase);
-        break;
-    case SPL_CLS_FLANK:
-        if (p.combine_mode) bump(lds + SPL_WIN, p.beta2s_reads, s, wbase);
-        break;
-    case SPL_CLS_B1TYPE:
-        bump(lds + SPL_WIN, p.beta2s_reads, s, wbase);
-        [[fallthrough]];
-    case SPL_CLS_ALPHA_COMP:
-        // PartnerBeta2DoubleCounts (:519-527, :544-551): rare, straight to HBM.
-        for (uint32_t e = 0; e < n_part; ++e) {
-            const int32_t pp = part[e];
-            if (r.cls == SPL_CLS_ALPHA_COMP && r.has_partner_used && pp == r.partner_used) continue;
-            if (spl_read_splices_at(pos, ops, n_ops, pp)) atomicAdd(&p.dbl[part_off + e], 1u);
-        }
-        break;
-    default:
-        break;
-    }
+    if (r.cls == SPL_CLS_BETA1) bump(lds, p.beta1, s, wbase);
+    else if (r.cls == SPL_CLS_ME) bump(lds + SPL_WIN, p.beta2s_reads, s, wbase);
+    else if (r.cls != SPL_CLS_NONE) apply_pair_global(p, r, s, pos, ops, n_ops, part, n_part, part_off);
 }
 
 } // namespace
 
+// =========================================================================================================
+// Pair kernel: every read against every site of its fetch window, literally.
+// =========================================================================================================
 template <bool STRANDED>
-__global__ __launch_bounds__(SPL_BLOCK) void spl_count_kernel(const spl_count_params p)
+__global__ __launch_bounds__(SPL_BLOCK) void spl_count_pairs_kernel(const spl_count_params p)
 {
     __shared__ uint32_t lds[2 * SPL_WIN]; // [0,WIN): beta1   [WIN,2WIN): beta2Simple (read-derived)
     __shared__ int32_t s_wbase;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    // XCD-aware chunk order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one
-    // contiguous eighth of the (coordinate-sorted) reads -- its L2 then sees one moving site window.
-    const uint32_t nblk = gridDim.x;
-    const uint32_t per = (nblk + 7u) >> 3;
-    uint32_t chunk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const uint32_t chunk = my_chunk();
     const bool live = chunk < p.n_chunks;
     const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
 
@@ -165,7 +184,7 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_kernel(const spl_count_pa
                     int32_t t = 0;
                     const bool in = my < n_sites && (t = p.site_pos[my]) <= b_end;
                     if (in) do_pair<STRANDED>(p, lds, wbase, my, t, b_pos, p.cigar + b_o0, b_nops, b_has_n, b_rs);
-                    if (__ballot(in) != ~0ull) break; // sites are sorted: a lane out of range ends the read
+                    if (__ballot(in) != ~0ull) break; // rows are sorted: a lane out of range ends the read
                 }
             }
         }
@@ -178,12 +197,312 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_kernel(const spl_count_pa
     }
 }
 
-template __global__ void spl_count_kernel<false>(const spl_count_params);
-template __global__ void spl_count_kernel<true>(const spl_count_params);
+// =========================================================================================================
+// Range kernel.
+//
+// With compSplicing false -- which is the case for every site except the rivals enumerated below -- the
+// if/elif chain of checkBam (:519-559) reduces to two coordinate tests per (read, site t):
+//     beta1        <=>  one aligned op [c, c2-1] has c <= t and t+1 <= c2-1      (:469-477)
+//     beta2Simple  <=>  one N op has lSite < t < rSite  (mutually exclusive)      (:507-512)
+// (an alpha read changes no counter; flanking reads need compSplicing).  Both are "all rows with position in
+// [c, c2-2]", a contiguous row range [lo, hi) of the sorted table, so each op costs two +-1 updates of a
+// difference array instead of one classification per site.  Strand: a read only counts for rows of its own
+// strand, so a stranded run keeps one pair of arrays per read strand and the scan picks by row strand.
+//
+// compSplicing can only become true for a site t that has a junction end of the read in its partner list
+// (:494-501 need lSite or rSite in `partners`); partner links are mutual (:352-355), so those sites are the
+// partners of the table rows AT the read's junction ends.  Only rows with >= 2 partners (SPL_SF_BRANCH) have
+// any partner besides the read's own junction.  Each such rival inside the read's fetch window is classified
+// literally, with and without its lists; if the two outcomes differ the range contribution is taken back and
+// the literal one applied.
+// =========================================================================================================
+namespace {
 
-// findBeta2Counts + calculateSSE, one site per lane.  IEEE binary64, compiled with -ffp-contract=off:
-// every operation below is one correctly rounded operation in the reference's order, so the doubles
-// are the ones CPython produces (int/int true division included for |values| < 2^53).
+template <int NARR>
+__device__ __forceinline__ void diff_add(const spl_count_params &p, int32_t *lds, int32_t wbase, int arr, int32_t row, int32_t v)
+{
+    const uint32_t loc = (uint32_t)(row - wbase);
+    if (loc <= (uint32_t)SPL_WIN) atomicAdd(&lds[arr * (SPL_WIN + 1) + (int)loc], v);
+    else atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + row], v);
+}
+
+// Is any junction end of the read that comes before (stop_op, stop_side) -- in lSite, rSite order per N op --
+// a member of `part`?  Used to visit a rival exactly once.
+__device__ __forceinline__ bool earlier_end_in(int32_t pos, const uint32_t *ops, uint32_t stop_op, int stop_side,
+                                               const int32_t *part, uint32_t n_part)
+{
+    int32_t cur = pos;
+    for (uint32_t k = 0; k <= stop_op; ++k) {
+        const uint32_t op = ops[k];
+        const uint32_t code = op & 15u;
+        if (!((SPL_PROG_MASK >> code) & 1u)) continue;
+        const int32_t d = (int32_t)(op >> 4);
+        cur += d;
+        if (code != SPL_OP_N) continue;
+        const int32_t l = cur - d - 1, r = cur - 1;
+        if (k < stop_op) {
+            if (spl_contains(part, n_part, l) || spl_contains(part, n_part, r)) return true;
+        } else if (stop_side == 1) {
+            if (spl_contains(part, n_part, l)) return true;
+        }
+    }
+    return false;
+}
+
+template <bool STRANDED>
+__device__ __forceinline__ void rivals_of_end(const spl_count_params &p, int32_t pos, uint32_t flag, const uint32_t *ops,
+                                           uint32_t n_ops, int32_t end_fetch, uint32_t k_op, int side, int32_t x)
+{
+    const int32_t n_sites = p.n_sites;
+    const int32_t r0 = first_site_at_or_after(p, x);
+    for (int32_t row = r0; row < n_sites && p.site_pos[row] == x; ++row) {
+        const uint4 m = p.site_meta[row];
+        if (m.y < 2u) continue;
+        for (uint32_t e = 0; e < m.y; ++e) {
+            const int32_t trow = p.part_site[m.x + e];
+            if (trow < 0) continue;
+            const int32_t t = p.site_pos[trow];
+            if (t < pos || t > end_fetch) continue;
+            const uint4 mt = p.site_meta[trow];
+            if (mt.w == 0u) continue; // no competitors: compSplicing impossible
+            const int32_t *part = p.part_pos + mt.x;
+            const int32_t *comp = p.comp_pos + mt.z;
+            // visit once: skip when an earlier junction end of this read also leads here, or an earlier row at x does
+            if (earlier_end_in(pos, ops, k_op, side, part, mt.y)) continue;
+            bool dup = false;
+            for (int32_t row2 = r0; row2 < row && !dup; ++row2) {
+                const uint4 m2 = p.site_meta[row2];
+                for (uint32_t e2 = 0; e2 < m2.y; ++e2) dup |= (p.part_site[m2.x + e2] == trow);
+            }
+            for (uint32_t e2 = 0; e2 < e; ++e2) dup |= (p.part_site[m.x + e2] == trow);
+            if (dup) continue;
+            bool strand_ok = true;
+            if (STRANDED) strand_ok = (p.site_strand[trow] == spl_read_strand(flag, p.stranded));
+            const spl_pair full = spl_classify_pair(pos, ops, n_ops, t, part, mt.y, comp, mt.w, strand_ok);
+            const spl_pair base = spl_classify_pair(pos, ops, n_ops, t, nullptr, 0u, nullptr, 0u, strand_ok);
+            if (full.cls == base.cls) continue;
+            // take back what the ranges counted for this row, apply the literal outcome
+            if (base.cls == SPL_CLS_BETA1) atomicAdd(&p.beta1[trow], 0xffffffffu);
+            else if (base.cls == SPL_CLS_ME) atomicAdd(&p.beta2s_reads[trow], 0xffffffffu);
+            apply_pair_global(p, full, trow, pos, ops, n_ops, part, mt.y, mt.x);
+        }
+    }
+}
+
+template <bool STRANDED>
+__device__ __forceinline__ void rivals_pass(const spl_count_params &p, int32_t pos, uint32_t flag, const uint32_t *ops,
+                                         uint32_t n_ops, int32_t end_fetch)
+{
+    int32_t cur = pos;
+    for (uint32_t k = 0; k < n_ops; ++k) {
+        const uint32_t op = ops[k];
+        const uint32_t code = op & 15u;
+        if (!((SPL_PROG_MASK >> code) & 1u)) continue;
+        const int32_t d = (int32_t)(op >> 4);
+        cur += d;
+        if (code != SPL_OP_N) continue;
+        rivals_of_end<STRANDED>(p, pos, flag, ops, n_ops, end_fetch, k, 0, cur - d - 1);
+        rivals_of_end<STRANDED>(p, pos, flag, ops, n_ops, end_fetch, k, 1, cur - 1);
+    }
+}
+
+// A read flagged unmapped (0x4) is fetched as a 1-base record (htslib bam_endpos) whatever its CIGAR says,
+// then walked with its full CIGAR: window [pos, pos], literal pairs.
+template <bool STRANDED>
+__device__ __forceinline__ void unmapped_read(const spl_count_params &p, int32_t pos, uint32_t flag, const uint32_t *ops, uint32_t n_ops)
+{
+    const int32_t n_sites = p.n_sites;
+    for (int32_t s = first_site_at_or_after(p, pos); s < n_sites && p.site_pos[s] == pos; ++s) {
+        bool strand_ok = true;
+        if (STRANDED) strand_ok = (p.site_strand[s] == spl_read_strand(flag, p.stranded));
+        const uint4 m = p.site_meta[s];
+        const spl_pair r = spl_classify_pair(pos, ops, n_ops, pos, p.part_pos + m.x, m.y, p.comp_pos + m.z, m.w, strand_ok);
+        apply_pair_global(p, r, s, pos, ops, n_ops, p.part_pos + m.x, m.y, m.x);
+    }
+}
+
+} // namespace
+
+template <bool STRANDED>
+__global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_count_params p)
+{
+    constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
+    __shared__ int32_t lds[NARR * (SPL_WIN + 1)];
+    __shared__ int32_t s_wbase;
+
+    const int tid = threadIdx.x;
+    const uint32_t chunk = my_chunk();
+    const bool live = chunk < p.n_chunks;
+    const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
+
+    for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) lds[j] = 0;
+    if (tid == 0) s_wbase = live ? first_site_at_or_after(p, p.r_pos[chunk_base] - 1) : 0;
+    __syncthreads();
+    const int32_t wbase = s_wbase;
+    const int32_t n_sites = p.n_sites;
+
+    if (live) {
+        for (int it = 0; it < SPL_RPT; ++it) {
+            const int64_t i = chunk_base + (int64_t)it * SPL_BLOCK + tid;
+            if (i >= p.n_reads) continue;
+            const int32_t pos = p.r_pos[i];
+            const uint32_t flag = p.r_flag[i];
+            const uint32_t o0 = p.cig_off[i];
+            const uint32_t n_ops = p.cig_off[i + 1] - o0;
+            const uint32_t *ops = p.cigar + o0;
+            if (pos < 0) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
+            if (flag & 4u) {
+                int64_t ref_len; bool hn;
+                spl_read_extent(ops, n_ops, &ref_len, &hn);
+                if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) atomicOr(p.err, SPL_DEV_ERR_RANGE);
+                else unmapped_read<STRANDED>(p, pos, flag, ops, n_ops);
+                continue;
+            }
+            int sidx = 0; // which strand pair of arrays this read writes
+            if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1 : 0;
+
+            // rows at position pos-1 are [prev_hi, idx); idx = first row >= pos
+            int32_t prev_hi = first_site_at_or_after(p, pos - 1);
+            int32_t idx = prev_hi;
+            while (idx < n_sites && p.site_pos[idx] < pos) ++idx;
+            int32_t c = pos;
+            int64_t ref_len = 0;
+            bool need_rivals = false;
+            for (uint32_t k = 0; k < n_ops; ++k) {
+                const uint32_t op = ops[k];
+                const uint32_t code = op & 15u;
+                if (!((SPL_PROG_MASK >> code) & 1u)) continue;
+                const int32_t d = (int32_t)(op >> 4);
+                const bool is_n = (code == SPL_OP_N);
+                if (d == 0) { // covers nothing; a 0N still names a junction (lSite == rSite == c-1)
+                    if (is_n) for (int32_t r = prev_hi; r < idx; ++r) need_rivals |= (p.site_flags[r] & SPL_SF_BRANCH) != 0;
+                    continue;
+                }
+                ref_len += d;
+                if (ref_len + pos > (int64_t)SPL_COORD_MAX) break; // flagged below; coordinates would wrap
+                const int32_t c2 = c + d;
+                // hi = first row with position >= c2-1: rows [idx, hi) have positions in [c, c2-2]
+                int32_t hi = idx;
+                if (d <= 512) {
+                    int steps = 0;
+                    while (hi < n_sites && p.site_pos[hi] < c2 - 1) {
+                        ++hi;
+                        if (++steps == 6) { hi = first_site_at_or_after(p, c2 - 1); break; }
+                    }
+                } else {
+                    hi = first_site_at_or_after(p, c2 - 1);
+                }
+                if (hi > idx && code != SPL_OP_D) {
+                    const int arr = (is_n ? (STRANDED ? 2 : 1) : 0) + sidx;
+                    diff_add<NARR>(p, lds, wbase, arr, idx, 1);
+                    diff_add<NARR>(p, lds, wbase, arr, hi, -1);
+                }
+                // rows at position c2-1 (the op's last base; rSite of an N op) are [hi, v2)
+                int32_t v2 = hi;
+                while (v2 < n_sites && p.site_pos[v2] == c2 - 1) ++v2;
+                if (is_n) { // junction rows: lSite = c-1 -> [prev_hi, idx), rSite = c2-1 -> [hi, v2)
+                    for (int32_t r = prev_hi; r < idx; ++r) need_rivals |= (p.site_flags[r] & SPL_SF_BRANCH) != 0;
+                    for (int32_t r = hi; r < v2; ++r) need_rivals |= (p.site_flags[r] & SPL_SF_BRANCH) != 0;
+                }
+                prev_hi = hi;
+                idx = v2;
+                c = c2;
+            }
+            if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
+            if (need_rivals) rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) {
+        const int32_t v = lds[j];
+        if (v) {
+            const int arr = j / (SPL_WIN + 1), loc = j - arr * (SPL_WIN + 1);
+            atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + wbase + loc], v);
+        }
+    }
+}
+
+// =========================================================================================================
+// Difference arrays -> counters: two tiny launches (block sums, then offset + local inclusive scan).
+// =========================================================================================================
+__global__ __launch_bounds__(256) void spl_scan_sums_kernel(const spl_scan_params p)
+{
+    __shared__ int32_t red[4];
+    const int arr = blockIdx.y;
+    const int32_t base = blockIdx.x * SPL_SCAN_BLOCK;
+    const int32_t *d = p.diff + (int64_t)arr * p.diff_stride;
+    int32_t acc = 0;
+    for (int j = threadIdx.x; j < SPL_SCAN_BLOCK; j += 256) {
+        const int32_t r = base + j;
+        if (r < p.n_sites) acc += d[r];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) p.block_sums[arr * p.n_blocks + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void spl_scan_apply_kernel(const spl_scan_params p)
+{
+    __shared__ int32_t red[4][4];   // [array][wave]
+    __shared__ int32_t wave_tot[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t base = blockIdx.x * SPL_SCAN_BLOCK;
+    int32_t run[4] = {0, 0, 0, 0};
+    // offset of this block = sum of the sums of all blocks before it
+    for (int a = 0; a < p.n_arrays; ++a) {
+        int32_t acc = 0;
+        for (int j = tid; j < (int)blockIdx.x; j += 256) acc += p.block_sums[a * p.n_blocks + j];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+        if (lane == 0) red[a][wave] = acc;
+    }
+    // each thread owns 4 consecutive rows
+    int32_t v[4][4];
+    const int32_t r0 = base + tid * 4;
+    for (int a = 0; a < p.n_arrays; ++a) {
+        const int32_t *d = p.diff + (int64_t)a * p.diff_stride;
+        int32_t s = 0;
+        for (int q = 0; q < 4; ++q) {
+            const int32_t r = r0 + q;
+            s += (r < p.n_sites) ? d[r] : 0;
+            v[a][q] = s; // inclusive within the thread
+        }
+        // wave-inclusive scan of thread totals
+        int32_t incl = s;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        run[a] = incl - s; // exclusive prefix of this thread inside its wave
+        if (lane == 63) wave_tot[a][wave] = incl;
+    }
+    __syncthreads();
+    for (int a = 0; a < p.n_arrays; ++a) {
+        int32_t off = red[a][0] + red[a][1] + red[a][2] + red[a][3];
+        for (int w = 0; w < wave; ++w) off += wave_tot[a][w];
+        run[a] += off;
+    }
+    for (int q = 0; q < 4; ++q) {
+        const int32_t r = r0 + q;
+        if (r >= p.n_sites) break;
+        int32_t b1, me;
+        if (p.n_arrays == 2) { b1 = run[0] + v[0][q]; me = run[1] + v[1][q]; }
+        else {
+            const uint8_t f = p.site_flags[r];
+            if (f & SPL_SF_PLUS) { b1 = run[0] + v[0][q]; me = run[2] + v[2][q]; }
+            else if (f & SPL_SF_MINUS) { b1 = run[1] + v[1][q]; me = run[3] + v[3][q]; }
+            else { b1 = 0; me = 0; } // a row without strand matches no read in a stranded run (:406)
+        }
+        if (b1) p.beta1[r] += (uint32_t)b1;
+        if (me) p.beta2s_reads[r] += (uint32_t)me;
+    }
+}
+
+// =========================================================================================================
+// findBeta2Counts + calculateSSE, one site per lane.  IEEE binary64, compiled with -ffp-contract=off: every
+// operation below is one correctly rounded operation in the reference's order, so the doubles are the ones
+// CPython produces (int/int true division included for |values| < 2^53).
+// =========================================================================================================
 __global__ __launch_bounds__(256) void spl_sse_kernel(const spl_sse_params p)
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,16 +556,33 @@ __global__ __launch_bounds__(256) void spl_sse_kernel(const spl_sse_params p)
 
 // ---- launchers (called from spl_capi.cpp through spl_device.h) ------------------------------------------
 
-extern "C" int spl_dev_launch_count(const spl_count_params *p, void *stream, int *grid_out)
+extern "C" int spl_dev_launch_count(const spl_count_params *p, int variant, void *stream, int *grid_out, int *lds_out)
 {
-    if (p->n_reads <= 0 || p->n_sites <= 0) { *grid_out = 0; return 0; }
-    const uint32_t n_chunks = p->n_chunks;
+    *grid_out = 0;
+    *lds_out = 0;
+    if (p->n_reads <= 0 || p->n_sites <= 0) return 0;
     // grid = 8 * ceil(n_chunks / 8) so that every XCD slice has the same number of slots
-    const uint32_t grid = ((n_chunks + 7u) / 8u) * 8u;
+    const uint32_t grid = ((p->n_chunks + 7u) / 8u) * 8u;
     *grid_out = (int)grid;
     hipStream_t st = (hipStream_t)stream;
-    if (p->stranded) hipLaunchKernelGGL(spl_count_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
-    else hipLaunchKernelGGL(spl_count_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
+    if (variant == 1) {
+        *lds_out = 2 * SPL_WIN * 4 + 4;
+        if (p->stranded) hipLaunchKernelGGL(spl_count_pairs_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
+        else hipLaunchKernelGGL(spl_count_pairs_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
+    } else {
+        *lds_out = (p->stranded ? 4 : 2) * (SPL_WIN + 1) * 4 + 4;
+        if (p->stranded) hipLaunchKernelGGL(spl_count_ranges_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
+        else hipLaunchKernelGGL(spl_count_ranges_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int spl_dev_launch_scan(const spl_scan_params *p, void *stream)
+{
+    if (p->n_sites <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(spl_scan_sums_kernel, dim3(p->n_blocks, p->n_arrays), dim3(256), 0, st, *p);
+    hipLaunchKernelGGL(spl_scan_apply_kernel, dim3(p->n_blocks), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
 

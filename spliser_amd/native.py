@@ -36,7 +36,10 @@ class spl_reads(ctypes.Structure):
 
 
 class spl_opts(ctypes.Structure):
-    _fields_ = [("stranded", ctypes.c_int32), ("combine_mode", ctypes.c_int32)]
+    _fields_ = [("stranded", ctypes.c_int32), ("combine_mode", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+OPT_PAIR_KERNEL = 1
 
 
 EXPORTS = [
@@ -170,12 +173,12 @@ class Context(object):
             pass
 
     # -- one-shot host-buffer calls ----------------------------------------------------------------
-    def count(self, sites, reads, stranded=0, combine_mode=0):
+    def count(self, sites, reads, stranded=0, combine_mode=0, flags=0):
         """checkBam for all sites of a shard -> (beta1, beta2s_reads, dbl) uint32."""
         beta1 = np.zeros(max(sites.n, 1), np.uint32)
         b2s = np.zeros(max(sites.n, 1), np.uint32)
         dbl = np.zeros(max(sites.n_part, 1), np.uint32)
-        opts = spl_opts(int(stranded), int(combine_mode))
+        opts = spl_opts(int(stranded), int(combine_mode), int(flags))
         _check(lib().spl_count(self._h, ctypes.byref(sites.c), ctypes.byref(reads.c), ctypes.byref(opts),
                                _ptr(beta1), _ptr(b2s), _ptr(dbl)))
         return beta1[:sites.n], b2s[:sites.n], dbl[:sites.n_part]
@@ -202,8 +205,8 @@ class Context(object):
         _check(lib().spl_reads_upload(self._h, ctypes.byref(reads.c), ctypes.byref(h)))
         return DeviceReads(self, h, reads.n)
 
-    def count_launch(self, dsites, dreads, stranded=0, combine_mode=0):
-        opts = spl_opts(int(stranded), int(combine_mode))
+    def count_launch(self, dsites, dreads, stranded=0, combine_mode=0, flags=0):
+        opts = spl_opts(int(stranded), int(combine_mode), int(flags))
         _check(lib().spl_count_launch(self._h, dsites._h, dreads._h, ctypes.byref(opts)))
 
     def sse_launch(self, dsites, cryptic):

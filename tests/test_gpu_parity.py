@@ -18,20 +18,24 @@ def ctx():
     c.close()
 
 
-def gpu_engine(ctx):
+KERNELS = {"ranges": 0, "pairs": native.OPT_PAIR_KERNEL}
+
+
+def gpu_engine(ctx, flags=0):
     def count(arr, reads, stranded, combine_mode):
         s = native.SiteArrays.from_chrom(arr)
         r = native.ReadArrays(reads.pos, reads.flag, reads.cig_off, reads.cigar)
-        return ctx.count(s, r, stranded, combine_mode)
+        return ctx.count(s, r, stranded, combine_mode, flags)
 
     def sse(arr, beta1, b2s_reads, dbl, cryptic):
         return ctx.sse(native.SiteArrays.from_chrom(arr), beta1, b2s_reads, dbl, cryptic)
     return count, sse
 
 
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
 @pytest.mark.parametrize("case,variant,opts", golden_cases(), ids=lambda v: v if isinstance(v, str) else "")
-def test_gpu_reproduces_reference_goldens(case, variant, opts, ctx):
-    text, rows = helpers.run_case(case, opts, gpu_engine(ctx))
+def test_gpu_reproduces_reference_goldens(case, variant, opts, kernel, ctx):
+    text, rows = helpers.run_case(case, opts, gpu_engine(ctx, KERNELS[kernel]))
     ref_text, ref_rows = helpers.expected(case, variant)
     assert text == ref_text
     helpers.assert_rows_match(rows, ref_rows, bool(opts.get("cryptic")))
@@ -40,11 +44,12 @@ def test_gpu_reproduces_reference_goldens(case, variant, opts, ctx):
 @pytest.mark.parametrize("case", ["cigar_corners", "random_b", "kat1", "random_unstranded_q"])
 @pytest.mark.parametrize("stranded", [0, 1, 2])
 @pytest.mark.parametrize("combine", [0, 1])
-def test_gpu_counters_match_oracle_all_modes(case, stranded, combine, ctx, oracle_lib):
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
+def test_gpu_counters_match_oracle_all_modes(case, stranded, combine, kernel, ctx, oracle_lib):
     table = helpers.build_table(os.path.join(helpers.GOLDEN, case), {"stranded": "fr" if stranded else None})
     _, reads = samio.read_sam(os.path.join(helpers.GOLDEN, case, "reads.sam"))
     ocount, _ = helpers.oracle_engine(oracle_lib)
-    gcount, _ = gpu_engine(ctx)
+    gcount, _ = gpu_engine(ctx, KERNELS[kernel])
     for chrom in table.chrom_index:
         arr = table.chrom_arrays(chrom)
         rs = reads.get(chrom, samio.ReadSet.empty())
@@ -61,8 +66,9 @@ def _table_for(wl, tmp_path, stranded):
     return table
 
 
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
 @pytest.mark.parametrize("stranded,cryptic", [(0, False), (1, True), (2, True)])
-def test_gpu_matches_oracle_on_synthetic_genome(stranded, cryptic, ctx, oracle_lib, tmp_path):
+def test_gpu_matches_oracle_on_synthetic_genome(stranded, cryptic, kernel, ctx, oracle_lib, tmp_path):
     """~400k reads over 5 chromosomes, packed into one shard (one launch) vs per-chromosome oracle."""
     wl = synth.Workload("arabidopsis", scale=0.02, seed=21 + stranded)
     table = _table_for(wl, tmp_path, bool(stranded))
@@ -72,7 +78,7 @@ def test_gpu_matches_oracle_on_synthetic_genome(stranded, cryptic, ctx, oracle_l
     assert len(shards) == 1
     sh = shards[0]
     ds, dr = ctx.upload_sites(sh.sites), ctx.upload_reads(sh.reads)
-    ctx.count_launch(ds, dr, stranded, 0)
+    ctx.count_launch(ds, dr, stranded, 0, KERNELS[kernel])
     ctx.sse_launch(ds, cryptic)
     beta1, b2s_reads, dbl = ds.counters()
     b2s, b2c, b2w, sse = ds.sse_results()
@@ -126,15 +132,22 @@ def test_gpu_long_introns_and_hot_sites(ctx, oracle_lib):
     src = np.concatenate(([0], np.cumsum(nops)))
     cig = np.concatenate([ops[src[i]:src[i + 1]] for i in order])
     off = np.concatenate(([0], np.cumsum(nops[order])))
-    sites_c = native.SiteArrays(pos, strand, part_off, part_pos, comp_off, comp_pos)
+    sites_c = native.SiteArrays(pos, strand, part_off, part_pos, comp_off, comp_pos, part_site=partner)
     reads_c = native.ReadArrays(allpos[order], allflag[order], off, cig)
-    for stranded in (0, 1):
-        got = ctx.count(sites_c, reads_c, stranded, 0)
+    for stranded, flags in ((0, 0), (1, 0), (0, native.OPT_PAIR_KERNEL), (2, native.OPT_PAIR_KERNEL)):
+        got = ctx.count(sites_c, reads_c, stranded, 0, flags)
         want = oracle_lib.check_bam(pos, strand, part_off, part_pos, comp_off, comp_pos, reads_c.pos, reads_c.flag,
                                     reads_c.cig_off, reads_c.cigar, stranded, 0)
         for g, w in zip(got, want):
             assert np.array_equal(g, w)
-    assert int(want[0][1234]) >= 100000 or int(got[0][1234]) >= 100000
+    assert int(want[0][1234]) >= 50000
+    # a table without part_site (or with one-way partner links) must silently take the pair kernel
+    one_way = native.SiteArrays(pos, strand, part_off, part_pos, comp_off, comp_pos)
+    got = ctx.count(one_way, reads_c, 1, 0)
+    want = oracle_lib.check_bam(pos, strand, part_off, part_pos, comp_off, comp_pos, reads_c.pos, reads_c.flag,
+                                reads_c.cig_off, reads_c.cigar, 1, 0)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
 
 
 def test_gpu_empty_and_degenerate_inputs(ctx):
