@@ -256,8 +256,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     for (int64_t i = 0; i < S; ++i) {
         const uint32_t np = s->part_off[i + 1] - s->part_off[i];
         meta[(size_t)i] = make_uint4(s->part_off[i], np, s->comp_off[i], s->comp_off[i + 1] - s->comp_off[i]);
-        flags[(size_t)i] = (uint8_t)((s->strand[i] == '+' ? SPL_SF_PLUS : 0u) | (s->strand[i] == '-' ? SPL_SF_MINUS : 0u) |
-                                     (np >= 2 ? SPL_SF_BRANCH : 0u));
+        flags[(size_t)i] = (uint8_t)((s->strand[i] == '+' ? SPL_SF_PLUS : 0u) | (s->strand[i] == '-' ? SPL_SF_MINUS : 0u));
     }
     // The range kernel finds the sites whose outcome depends on their own partner / competitor lists by walking
     // the partner edges of the rows at a read's junction ends; that needs every edge s -> p to exist as p -> s
@@ -274,6 +273,14 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
             if (!ok) d->mutual_links = false;
         }
     }
+    // SPL_SF_RIVALS: a partner of this row has competitors, i.e. for a read whose junction ends on this row there
+    // may be sites whose compSplicing test (:494-501) can succeed.  Rows without the flag keep reads on the fast path.
+    if (d->mutual_links && s->part_site)
+        for (int64_t i = 0; i < S; ++i)
+            for (uint32_t e = s->part_off[i]; e < s->part_off[i + 1]; ++e) {
+                const int32_t q = s->part_site[e];
+                if (s->comp_off[q + 1] != s->comp_off[q]) { flags[(size_t)i] |= SPL_SF_RIVALS; break; }
+            }
     d->diff_stride = (int32_t)align_up((size_t)S + 1, 64);
     d->scan_blocks = (int32_t)((S + SPL_SCAN_BLOCK - 1) / SPL_SCAN_BLOCK);
 

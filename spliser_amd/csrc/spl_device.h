@@ -21,7 +21,7 @@
 // per-row flag byte (built at upload)
 #define SPL_SF_PLUS 1u    // Site.strand == '+'
 #define SPL_SF_MINUS 2u   // Site.strand == '-'
-#define SPL_SF_BRANCH 4u  // the row has >= 2 partners: a junction ending here has rival sites
+#define SPL_SF_RIVALS 4u  // some partner of this row has competitors: a junction ending here may have rival sites
 
 struct spl_count_params {
     // reads

@@ -211,10 +211,11 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_pairs_kernel(const spl_co
 //
 // compSplicing can only become true for a site t that has a junction end of the read in its partner list
 // (:494-501 need lSite or rSite in `partners`); partner links are mutual (:352-355), so those sites are the
-// partners of the table rows AT the read's junction ends.  Only rows with >= 2 partners (SPL_SF_BRANCH) have
-// any partner besides the read's own junction.  Each such rival inside the read's fetch window is classified
-// literally, with and without its lists; if the two outcomes differ the range contribution is taken back and
-// the literal one applied.
+// partners of the table rows AT the read's junction ends, and only those of them that have competitors at all
+// (rows leading to such a partner carry SPL_SF_RIVALS; a constitutive junction has none).  Each rival inside
+// the read's fetch window is classified literally, with and without its lists; if the two outcomes differ the
+// range contribution is taken back and the literal one applied.  A rival reachable from several junction ends
+// of one read is handled at the first of them.
 // =========================================================================================================
 namespace {
 
@@ -224,6 +225,27 @@ __device__ __forceinline__ void diff_add(const spl_count_params &p, int32_t *lds
     const uint32_t loc = (uint32_t)(row - wbase);
     if (loc <= (uint32_t)SPL_WIN) atomicAdd(&lds[arr * (SPL_WIN + 1) + (int)loc], v);
     else atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + row], v);
+}
+
+// All 64 lanes call this together.  Lanes that add `sign` to the same (array, row) and sit next to each other
+// form a run; the first lane of each run adds sign * run-length once.  (Equal keys that are NOT adjacent simply
+// make several runs: still correct, just more atomics -- that only happens for unsorted input.)
+template <int NARR>
+__device__ __forceinline__ void commit_run(const spl_count_params &p, int32_t *lds, int32_t wbase, bool valid, int arr,
+                                           int32_t row, int32_t sign)
+{
+    const int lane = threadIdx.x & 63;
+    const int32_t key = valid ? row : -1;
+    const int32_t prev_key = __shfl_up(key, 1);
+    const int prev_arr = __shfl_up(arr, 1);
+    const bool head = valid && (lane == 0 || prev_key != key || prev_arr != arr);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long act = __ballot(valid);
+    if (head) {
+        const unsigned long long stop = (heads | ~act) & ~((2ull << lane) - 1ull); // later lanes that end my run
+        const int len = stop ? (__ffsll((long long)stop) - 1 - lane) : (64 - lane);
+        diff_add<NARR>(p, lds, wbase, arr, row, sign * len);
+    }
 }
 
 // Is any junction end of the read that comes before (stop_op, stop_side) -- in lSite, rSite order per N op --
@@ -257,7 +279,6 @@ __device__ __forceinline__ void rivals_of_end(const spl_count_params &p, int32_t
     const int32_t r0 = first_site_at_or_after(p, x);
     for (int32_t row = r0; row < n_sites && p.site_pos[row] == x; ++row) {
         const uint4 m = p.site_meta[row];
-        if (m.y < 2u) continue;
         for (uint32_t e = 0; e < m.y; ++e) {
             const int32_t trow = p.part_site[m.x + e];
             if (trow < 0) continue;
@@ -343,73 +364,92 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_c
 
     if (live) {
         for (int it = 0; it < SPL_RPT; ++it) {
+            // Control flow below is wave-uniform (every lane reaches every commit_run) so that lanes whose ranges
+            // start or end on the same row -- the normal case for coordinate-sorted reads -- share ONE LDS atomic.
             const int64_t i = chunk_base + (int64_t)it * SPL_BLOCK + tid;
-            if (i >= p.n_reads) continue;
-            const int32_t pos = p.r_pos[i];
-            const uint32_t flag = p.r_flag[i];
-            const uint32_t o0 = p.cig_off[i];
-            const uint32_t n_ops = p.cig_off[i + 1] - o0;
-            const uint32_t *ops = p.cigar + o0;
-            if (pos < 0) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
-            if (flag & 4u) {
-                int64_t ref_len; bool hn;
-                spl_read_extent(ops, n_ops, &ref_len, &hn);
-                if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) atomicOr(p.err, SPL_DEV_ERR_RANGE);
-                else unmapped_read<STRANDED>(p, pos, flag, ops, n_ops);
-                continue;
+            bool alive = i < p.n_reads;
+            int32_t pos = 0;
+            uint32_t flag = 0, n_ops = 0;
+            const uint32_t *ops = p.cigar;
+            if (alive) {
+                pos = p.r_pos[i];
+                flag = p.r_flag[i];
+                const uint32_t o0 = p.cig_off[i];
+                n_ops = p.cig_off[i + 1] - o0;
+                ops = p.cigar + o0;
+                if (pos < 0) { atomicOr(p.err, SPL_DEV_ERR_RANGE); alive = false; }
+                else if (flag & 4u) {
+                    int64_t rl; bool hn;
+                    spl_read_extent(ops, n_ops, &rl, &hn);
+                    if ((int64_t)pos + rl > (int64_t)SPL_COORD_MAX) atomicOr(p.err, SPL_DEV_ERR_RANGE);
+                    else unmapped_read<STRANDED>(p, pos, flag, ops, n_ops);
+                    alive = false;
+                }
             }
             int sidx = 0; // which strand pair of arrays this read writes
             if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1 : 0;
 
             // rows at position pos-1 are [prev_hi, idx); idx = first row >= pos
-            int32_t prev_hi = first_site_at_or_after(p, pos - 1);
-            int32_t idx = prev_hi;
-            while (idx < n_sites && p.site_pos[idx] < pos) ++idx;
+            int32_t prev_hi = 0, idx = 0;
+            if (alive) {
+                prev_hi = first_site_at_or_after(p, pos - 1);
+                idx = prev_hi;
+                while (idx < n_sites && p.site_pos[idx] < pos) ++idx;
+            }
             int32_t c = pos;
             int64_t ref_len = 0;
             bool need_rivals = false;
-            for (uint32_t k = 0; k < n_ops; ++k) {
-                const uint32_t op = ops[k];
-                const uint32_t code = op & 15u;
-                if (!((SPL_PROG_MASK >> code) & 1u)) continue;
-                const int32_t d = (int32_t)(op >> 4);
-                const bool is_n = (code == SPL_OP_N);
-                if (d == 0) { // covers nothing; a 0N still names a junction (lSite == rSite == c-1)
-                    if (is_n) for (int32_t r = prev_hi; r < idx; ++r) need_rivals |= (p.site_flags[r] & SPL_SF_BRANCH) != 0;
-                    continue;
-                }
-                ref_len += d;
-                if (ref_len + pos > (int64_t)SPL_COORD_MAX) break; // flagged below; coordinates would wrap
-                const int32_t c2 = c + d;
-                // hi = first row with position >= c2-1: rows [idx, hi) have positions in [c, c2-2]
-                int32_t hi = idx;
-                if (d <= 512) {
-                    int steps = 0;
-                    while (hi < n_sites && p.site_pos[hi] < c2 - 1) {
-                        ++hi;
-                        if (++steps == 6) { hi = first_site_at_or_after(p, c2 - 1); break; }
+            for (uint32_t k = 0; __any(alive && k < n_ops); ++k) {
+                bool emit = false;
+                int arr = 0;
+                int32_t lo = 0, hi = 0;
+                if (alive && k < n_ops) {
+                    const uint32_t op = ops[k];
+                    const uint32_t code = op & 15u;
+                    const int32_t d = (int32_t)(op >> 4);
+                    const bool is_n = (code == SPL_OP_N);
+                    if (!((SPL_PROG_MASK >> code) & 1u)) {
+                        // I, S, H, P: no progression (:463-464)
+                    } else if (d == 0) { // covers nothing; a 0N still names a junction (lSite == rSite == c-1)
+                        if (is_n) for (int32_t r = prev_hi; r < idx; ++r) need_rivals |= (p.site_flags[r] & SPL_SF_RIVALS) != 0;
+                    } else if ((ref_len += d) + pos > (int64_t)SPL_COORD_MAX) {
+                        alive = false; // flagged below; coordinates would wrap
+                    } else {
+                        const int32_t c2 = c + d;
+                        // hi = first row with position >= c2-1: rows [idx, hi) have positions in [c, c2-2]
+                        hi = idx;
+                        if (d <= 512) {
+                            int steps = 0;
+                            while (hi < n_sites && p.site_pos[hi] < c2 - 1) {
+                                ++hi;
+                                if (++steps == 6) { hi = first_site_at_or_after(p, c2 - 1); break; }
+                            }
+                        } else {
+                            hi = first_site_at_or_after(p, c2 - 1);
+                        }
+                        lo = idx;
+                        emit = hi > lo && code != SPL_OP_D;
+                        arr = (is_n ? (STRANDED ? 2 : 1) : 0) + sidx;
+                        // rows at position c2-1 (the op's last base; rSite of an N op) are [hi, v2)
+                        int32_t v2 = hi;
+                        while (v2 < n_sites && p.site_pos[v2] == c2 - 1) ++v2;
+                        if (is_n) { // junction rows: lSite = c-1 -> [prev_hi, idx), rSite = c2-1 -> [hi, v2)
+                            for (int32_t r = prev_hi; r < idx; ++r) need_rivals |= (p.site_flags[r] & SPL_SF_RIVALS) != 0;
+                            for (int32_t r = hi; r < v2; ++r) need_rivals |= (p.site_flags[r] & SPL_SF_RIVALS) != 0;
+                        }
+                        prev_hi = hi;
+                        idx = v2;
+                        c = c2;
                     }
-                } else {
-                    hi = first_site_at_or_after(p, c2 - 1);
                 }
-                if (hi > idx && code != SPL_OP_D) {
-                    const int arr = (is_n ? (STRANDED ? 2 : 1) : 0) + sidx;
-                    diff_add<NARR>(p, lds, wbase, arr, idx, 1);
-                    diff_add<NARR>(p, lds, wbase, arr, hi, -1);
+                if (__any(emit)) {
+                    commit_run<NARR>(p, lds, wbase, emit, arr, lo, 1);
+                    commit_run<NARR>(p, lds, wbase, emit, arr, hi, -1);
                 }
-                // rows at position c2-1 (the op's last base; rSite of an N op) are [hi, v2)
-                int32_t v2 = hi;
-                while (v2 < n_sites && p.site_pos[v2] == c2 - 1) ++v2;
-                if (is_n) { // junction rows: lSite = c-1 -> [prev_hi, idx), rSite = c2-1 -> [hi, v2)
-                    for (int32_t r = prev_hi; r < idx; ++r) need_rivals |= (p.site_flags[r] & SPL_SF_BRANCH) != 0;
-                    for (int32_t r = hi; r < v2; ++r) need_rivals |= (p.site_flags[r] & SPL_SF_BRANCH) != 0;
-                }
-                prev_hi = hi;
-                idx = v2;
-                c = c2;
             }
-            if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
-            if (need_rivals) rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
+            if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); alive = false; }
+            if (alive && need_rivals)
+                rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
         }
     }
     __syncthreads();
