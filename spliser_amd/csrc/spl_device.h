@@ -7,9 +7,10 @@
 
 // Launch geometry of the classification kernels (see DESIGN.md "Kernels").
 #define SPL_BLOCK 256                    // threads per workgroup = 4 waves
-#define SPL_RPT 8                        // reads per thread
+#define SPL_RPT 4                        // reads per thread
 #define SPL_CHUNK (SPL_BLOCK * SPL_RPT)  // consecutive reads per workgroup
-#define SPL_WIN 2048                     // site rows whose counters a workgroup privatises in LDS
+#define SPL_WIN 1024                     // site rows whose counters a workgroup privatises in LDS
+#define SPL_OPS_CAP 3072                 // raw CIGAR ops of a chunk staged in LDS (more -> serial fallback)
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
 #define SPL_SCAN_BLOCK 1024              // rows per workgroup in the difference-array scan
 

@@ -344,25 +344,15 @@ __device__ __forceinline__ void unmapped_read(const spl_count_params &p, int32_t
 
 } // namespace
 
+// One read per lane, ops walked in a loop: the fallback for chunks whose CIGARs do not fit the LDS staging area
+// (long-read data); same ranges, same commits, just latency-bound.
 template <bool STRANDED>
-__global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_count_params p)
+__device__ __forceinline__ void ranges_chunk_serial(const spl_count_params &p, int32_t *lds, int32_t wbase, int64_t chunk_base)
 {
-    constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
-    __shared__ int32_t lds[NARR * (SPL_WIN + 1)];
-    __shared__ int32_t s_wbase;
-
+    constexpr int NARR = STRANDED ? 4 : 2;
     const int tid = threadIdx.x;
-    const uint32_t chunk = my_chunk();
-    const bool live = chunk < p.n_chunks;
-    const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
-
-    for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) lds[j] = 0;
-    if (tid == 0) s_wbase = live ? first_site_at_or_after(p, p.r_pos[chunk_base] - 1) : 0;
-    __syncthreads();
-    const int32_t wbase = s_wbase;
     const int32_t n_sites = p.n_sites;
-
-    if (live) {
+    {
         for (int it = 0; it < SPL_RPT; ++it) {
             // Control flow below is wave-uniform (every lane reaches every commit_run) so that lanes whose ranges
             // start or end on the same row -- the normal case for coordinate-sorted reads -- share ONE LDS atomic.
@@ -452,7 +442,186 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_c
                 rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
         }
     }
+}
+
+// Record byte of one boundary slot (see spl_count_ranges_kernel).
+#define SPL_K_LIVE 1u
+#define SPL_K_KIND(k) (((k) >> 1) & 3u) // 0 read start, 1 aligned op, 2 N op, 3 D op
+#define SPL_K_SIDX(k) (((k) >> 3) & 1u)
+#define SPL_K_RIVAL 16u
+#define SPL_K_NV(k) (((k) >> 5) & 3u)   // rows AT the boundary's last position (3 = three or more: recount)
+
+// The range kernel proper.  A workgroup owns SPL_CHUNK consecutive reads and runs four passes over LDS:
+//   P0  stage the chunk's raw CIGAR ops (one coalesced sweep of the op array);
+//   P1  one read per lane: walk its ops (LDS latency only) and lay down one *boundary record* per reference-
+//       consuming op, preceded by one for the read start: slot = coordinate just past the op, kind, strand;
+//   P2  FLAT over slots, perfectly balanced and free of cross-lane dependence: row lookup of each boundary
+//       (first row at or after coordinate-1, and how many rows sit exactly there);
+//   P3  FLAT over slots: an op's row range is [start boundary's rows end, end boundary's rows begin); commit
+//       +1/-1 (adjacent lanes hitting one row share an atomic); N ops look at the rival flag of their junction rows;
+//   P4  one read per lane: reads with a flagged junction end run the literal rival pass.
+template <bool STRANDED>
+__global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_count_params p)
+{
+    constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
+    constexpr int SLOTS = SPL_CHUNK + SPL_OPS_CAP;
+    __shared__ int32_t lds[NARR * (SPL_WIN + 1)];
+    __shared__ uint32_t s_op[SPL_OPS_CAP];
+    __shared__ int32_t s_b[SLOTS];
+    __shared__ uint8_t s_kind[SLOTS];
+    __shared__ int32_t s_wbase;
+
+    const int tid = threadIdx.x;
+    const uint32_t chunk = my_chunk();
+    const bool live = chunk < p.n_chunks;
+    const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
+    const int32_t n_sites = p.n_sites;
+
+    uint32_t ob = 0, n_co = 0;
+    int n_rd = 0;
+    if (live) {
+        const int64_t chunk_end = (chunk_base + SPL_CHUNK < p.n_reads) ? chunk_base + SPL_CHUNK : p.n_reads;
+        n_rd = (int)(chunk_end - chunk_base);
+        ob = p.cig_off[chunk_base];
+        n_co = p.cig_off[chunk_end] - ob;
+    }
+    const bool staged = live && n_co <= (uint32_t)SPL_OPS_CAP;
+    const int n_slots = staged ? n_rd + (int)n_co : 0;
+
+    // ---- P0 ------------------------------------------------------------------------------------------------
+    for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) lds[j] = 0;
+    if (staged) {
+        for (uint32_t j = tid; j < n_co; j += SPL_BLOCK) s_op[j] = p.cigar[ob + j];
+        for (int j = tid; j < n_slots; j += SPL_BLOCK) s_kind[j] = 0;
+    }
+    if (tid == 0) s_wbase = live ? first_site_at_or_after(p, p.r_pos[chunk_base] - 1) : 0;
     __syncthreads();
+    const int32_t wbase = s_wbase;
+
+    if (live && !staged) ranges_chunk_serial<STRANDED>(p, lds, wbase, chunk_base);
+
+    // ---- P1 ------------------------------------------------------------------------------------------------
+    int32_t r_pos[SPL_RPT];
+    uint32_t r_flag[SPL_RPT], r_o0[SPL_RPT], r_nops[SPL_RPT];
+    int r_base[SPL_RPT], r_nrec[SPL_RPT];
+    int64_t r_len[SPL_RPT];
+#pragma unroll
+    for (int q = 0; q < SPL_RPT; ++q) {
+        const int r = q * SPL_BLOCK + tid;
+        r_nrec[q] = 0; r_pos[q] = 0; r_flag[q] = 0; r_o0[q] = 0; r_nops[q] = 0; r_base[q] = 0; r_len[q] = 0;
+        if (staged && r < n_rd) {
+            const int64_t i = chunk_base + r;
+            r_pos[q] = p.r_pos[i];
+            r_flag[q] = p.r_flag[i];
+            r_o0[q] = p.cig_off[i];
+            r_nops[q] = p.cig_off[i + 1] - r_o0[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SPL_RPT; ++q) {
+        const int r = q * SPL_BLOCK + tid;
+        if (!(staged && r < n_rd)) continue;
+        const int32_t pos = r_pos[q];
+        const uint32_t flag = r_flag[q], n_ops = r_nops[q];
+        const uint32_t lo0 = r_o0[q] - ob; // first raw op of this read in s_op
+        if (pos < 0) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
+        if (flag & 4u) {
+            int64_t rl; bool hn;
+            spl_read_extent(p.cigar + r_o0[q], n_ops, &rl, &hn);
+            if ((int64_t)pos + rl > (int64_t)SPL_COORD_MAX) atomicOr(p.err, SPL_DEV_ERR_RANGE);
+            else unmapped_read<STRANDED>(p, pos, flag, p.cigar + r_o0[q], n_ops);
+            continue;
+        }
+        uint32_t sbit = 0;
+        if (STRANDED) sbit = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 8u : 0u;
+        const int base = (int)lo0 + r;
+        int32_t cur = pos;
+        int64_t ref_len = 0;
+        int nrec = 0;
+        bool ok = true;
+        for (uint32_t k = 0; k < n_ops; ++k) {
+            const uint32_t op = s_op[lo0 + k];
+            const uint32_t code = op & 15u;
+            if (!((SPL_PROG_MASK >> code) & 1u)) continue;
+            const int32_t d = (int32_t)(op >> 4);
+            ref_len += d;
+            if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { ok = false; break; }
+            cur += d;
+            ++nrec;
+            const uint32_t kind = (code == SPL_OP_N) ? 2u : (code == SPL_OP_D ? 3u : 1u);
+            s_b[base + nrec] = cur;
+            s_kind[base + nrec] = (uint8_t)(SPL_K_LIVE | (kind << 1) | sbit);
+        }
+        if (!ok) {
+            atomicOr(p.err, SPL_DEV_ERR_RANGE);
+            for (int j = 1; j <= nrec; ++j) s_kind[base + j] = 0;
+            continue;
+        }
+        s_b[base] = pos;
+        s_kind[base] = (uint8_t)SPL_K_LIVE; // kind 0: read start
+        r_base[q] = base;
+        r_nrec[q] = nrec;
+        r_len[q] = ref_len;
+    }
+    __syncthreads();
+
+    // ---- P2: boundary -> rows ----------------------------------------------------------------------------
+    for (int g = tid; g < n_slots; g += SPL_BLOCK) {
+        const uint32_t kd = s_kind[g];
+        if (!(kd & SPL_K_LIVE)) continue;
+        const int32_t x = s_b[g] - 1;
+        const int32_t u = first_site_at_or_after(p, x);
+        uint32_t nv = 0;
+        while (nv < 3u && u + (int32_t)nv < n_sites && p.site_pos[u + nv] == x) ++nv;
+        s_b[g] = u;
+        s_kind[g] = (uint8_t)(kd | (nv << 5));
+    }
+    __syncthreads();
+
+    // ---- P3: ranges -> difference arrays ------------------------------------------------------------------
+    for (int g0 = 0; g0 < n_slots; g0 += SPL_BLOCK) { // wave-uniform trip count: every lane reaches commit_run
+        const int g = g0 + tid;
+        bool emit = false;
+        int arr = 0;
+        int32_t lo = 0, hi = 0;
+        if (g < n_slots) {
+            const uint32_t kd = s_kind[g];
+            const uint32_t kind = SPL_K_KIND(kd);
+            if ((kd & SPL_K_LIVE) && kind != 0u) {
+                const uint32_t ks = s_kind[g - 1];
+                const int32_t us = s_b[g - 1];
+                uint32_t nvs = SPL_K_NV(ks), nve = SPL_K_NV(kd);
+                hi = s_b[g];
+                if (nvs == 3u) { const int32_t x = p.site_pos[us]; while (us + (int32_t)nvs < n_sites && p.site_pos[us + nvs] == x) ++nvs; }
+                lo = us + (int32_t)nvs;
+                emit = hi > lo && kind != 3u;
+                arr = (kind == 2u ? (STRANDED ? 2 : 1) : 0) + (int)SPL_K_SIDX(kd);
+                if (kind == 2u) { // junction rows: lSite -> [us, lo), rSite -> [hi, hi + nve)
+                    if (nve == 3u) { const int32_t x = p.site_pos[hi]; while (hi + (int32_t)nve < n_sites && p.site_pos[hi + nve] == x) ++nve; }
+                    bool rival = false;
+                    for (int32_t r = us; r < lo; ++r) rival |= (p.site_flags[r] & SPL_SF_RIVALS) != 0;
+                    for (int32_t r = hi; r < hi + (int32_t)nve; ++r) rival |= (p.site_flags[r] & SPL_SF_RIVALS) != 0;
+                    if (rival) s_kind[g] = (uint8_t)(kd | SPL_K_RIVAL);
+                }
+            }
+        }
+        if (__any(emit)) {
+            commit_run<NARR>(p, lds, wbase, emit, arr, lo, 1);
+            commit_run<NARR>(p, lds, wbase, emit, arr, hi, -1);
+        }
+    }
+    __syncthreads();
+
+    // ---- P4: rivals ----------------------------------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < SPL_RPT; ++q) {
+        bool need = false;
+        for (int j = 1; j <= r_nrec[q]; ++j) need |= (s_kind[r_base[q] + j] & SPL_K_RIVAL) != 0;
+        if (need)
+            rivals_pass<STRANDED>(p, r_pos[q], r_flag[q], p.cigar + r_o0[q], r_nops[q],
+                                  (int32_t)((int64_t)r_pos[q] + (r_len[q] > 0 ? r_len[q] : 1) - 1));
+    }
+
     for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) {
         const int32_t v = lds[j];
         if (v) {
@@ -610,7 +779,7 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, int variant, void
         if (p->stranded) hipLaunchKernelGGL(spl_count_pairs_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
         else hipLaunchKernelGGL(spl_count_pairs_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
     } else {
-        *lds_out = (p->stranded ? 4 : 2) * (SPL_WIN + 1) * 4 + 4;
+        *lds_out = (p->stranded ? 4 : 2) * (SPL_WIN + 1) * 4 + 4 * SPL_OPS_CAP + 5 * (SPL_CHUNK + SPL_OPS_CAP) + 4;
         if (p->stranded) hipLaunchKernelGGL(spl_count_ranges_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
         else hipLaunchKernelGGL(spl_count_ranges_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
     }
