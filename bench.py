@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default="ranges", choices=["ranges", "pairs"],
                     help="ranges = default product path; pairs = the literal per-(read, site) kernel")
+    ap.add_argument("--alt-fraction", type=float, default=None, help="(experiment) fraction of genes with alternative isoforms")
     ap.add_argument("--cache", default=None, help="directory to cache the generated sample in (.npz); a cached "
                     "sample is loaded instead of regenerated (use under rocprofv3: no generator worker processes)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
@@ -62,7 +63,8 @@ def main():
     if cache and os.path.exists(cache):
         wl = synth.Workload.load(cache, args.workload)
     else:
-        wl = synth.Workload(args.workload, scale=args.scale, seed=cfg["seed"] + rank,
+        over = {} if args.alt_fraction is None else {"alt_fraction": args.alt_fraction}
+        wl = synth.Workload(args.workload, scale=args.scale, seed=cfg["seed"] + rank, **over,
                             workers=max(1, min(8, (os.cpu_count() or 1) // max(world, 1))))
         if cache:
             wl.save(cache)

@@ -67,9 +67,14 @@ struct spl_dsites {
     int32_t bucket_base = 0, bucket_shift = 0;
     bool has_sse_inputs = false;
     bool mutual_links = false; // every partner edge has its reverse edge: the range kernel is applicable
-    int32_t *diff = nullptr;   // 4 difference arrays of diff_stride int32 (range kernel)
+    int32_t *diff = nullptr;   // 4 difference arrays of diff_stride int32 over distinct positions (range kernel)
     int32_t *block_sums = nullptr;
     int32_t diff_stride = 0, scan_blocks = 0;
+    int32_t n_dpos = 0;        // distinct site positions
+    int32_t *dpos_first_row = nullptr; // [n_dpos + 1]
+    uint4 *dbucket = nullptr;  // 64 bp buckets {first dpos, -, occupancy mask}
+    uint32_t n_dbuckets = 0;
+    uint32_t *rival_bits = nullptr;
     // outputs
     uint32_t *beta1 = nullptr, *beta2s = nullptr, *dbl = nullptr; // contiguous: one memset clears all three
     size_t counter_bytes = 0;
@@ -281,8 +286,35 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
                 const int32_t q = s->part_site[e];
                 if (s->comp_off[q + 1] != s->comp_off[q]) { flags[(size_t)i] |= SPL_SF_RIVALS; break; }
             }
-    d->diff_stride = (int32_t)align_up((size_t)S + 1, 64);
-    d->scan_blocks = (int32_t)((S + SPL_SCAN_BLOCK - 1) / SPL_SCAN_BLOCK);
+    // distinct positions ("dpos"), their 64 bp occupancy buckets and the rival bitmap
+    std::vector<int32_t> dfirst;
+    std::vector<uint4> dbucket;
+    std::vector<uint32_t> rbits;
+    for (int64_t i = 0; i < S; ++i)
+        if (i == 0 || s->pos[i] != s->pos[i - 1]) dfirst.push_back((int32_t)i);
+    const int64_t D = (int64_t)dfirst.size();
+    dfirst.push_back((int32_t)S);
+    d->n_dpos = (int32_t)D;
+    rbits.assign((size_t)(D + 31) / 32 + 1, 0u);
+    if (S > 0) {
+        const int64_t extent = (int64_t)s->pos[S - 1] - (int64_t)s->pos[0] + 1;
+        d->n_dbuckets = (uint32_t)((extent - 1) >> 6) + 1;
+        dbucket.assign((size_t)d->n_dbuckets, make_uint4(0, 0, 0, 0));
+        int64_t di = 0;
+        for (uint32_t b = 0; b < d->n_dbuckets; ++b) {
+            const int64_t start = (int64_t)s->pos[0] + ((int64_t)b << 6);
+            while (di < D && (int64_t)s->pos[dfirst[(size_t)di]] < start) ++di;
+            unsigned long long mask = 0;
+            for (int64_t j = di; j < D && (int64_t)s->pos[dfirst[(size_t)j]] < start + 64; ++j)
+                mask |= 1ull << ((int64_t)s->pos[dfirst[(size_t)j]] - start);
+            dbucket[b] = make_uint4((uint32_t)di, 0u, (uint32_t)(mask & 0xffffffffu), (uint32_t)(mask >> 32));
+        }
+        for (int64_t j = 0; j < D; ++j)
+            for (int32_t r = dfirst[(size_t)j]; r < dfirst[(size_t)j + 1]; ++r)
+                if (flags[(size_t)r] & SPL_SF_RIVALS) rbits[(size_t)j >> 5] |= 1u << (j & 31);
+    }
+    d->diff_stride = (int32_t)align_up((size_t)D + 1, 64);
+    d->scan_blocks = (int32_t)((D + SPL_SCAN_BLOCK - 1) / SPL_SCAN_BLOCK);
 
     // slab layout
     size_t off = 0;
@@ -290,6 +322,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     const size_t o_pos = take(4 * S), o_strand = take(S), o_flags = take(S), o_meta = take(16 * S), o_poff = take(4 * (S + 1));
     const size_t o_ppos = take(4 * P), o_psite = take(4 * P), o_cpos = take(4 * C);
     const size_t o_alpha = take(8 * S), o_ecnt = take(8 * P), o_bucket = take(4 * bucket.size());
+    const size_t o_dfirst = take(4 * dfirst.size()), o_dbucket = take(16 * dbucket.size()), o_rbits = take(4 * rbits.size());
     const size_t o_cnt = off;
     const size_t o_b1 = take(4 * S), o_b2 = take(4 * S), o_dbl = take(4 * P);
     const size_t o_diff = take(4 * 4 * (size_t)d->diff_stride);
@@ -301,6 +334,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the site table: %s", d->slab_bytes, hipGetErrorString(e)); }
     d->pos = (int32_t *)(d->slab + o_pos); d->strand = (uint8_t *)(d->slab + o_strand); d->meta = (uint4 *)(d->slab + o_meta);
     d->flags = (uint8_t *)(d->slab + o_flags); d->diff = (int32_t *)(d->slab + o_diff); d->block_sums = (int32_t *)(d->slab + o_bsum);
+    d->dpos_first_row = (int32_t *)(d->slab + o_dfirst); d->dbucket = (uint4 *)(d->slab + o_dbucket); d->rival_bits = (uint32_t *)(d->slab + o_rbits);
     d->part_off = (uint32_t *)(d->slab + o_poff); d->part_pos = (int32_t *)(d->slab + o_ppos); d->part_site = (int32_t *)(d->slab + o_psite);
     d->comp_pos = (int32_t *)(d->slab + o_cpos); d->alpha = (int64_t *)(d->slab + o_alpha); d->edge_cnt = (int64_t *)(d->slab + o_ecnt);
     d->bucket = (uint32_t *)(d->slab + o_bucket);
@@ -317,6 +351,9 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (r == hipSuccess) r = up(d->strand, s->strand, S);
     if (r == hipSuccess) r = up(d->meta, meta.data(), 16 * S);
     if (r == hipSuccess) r = up(d->flags, flags.data(), S);
+    if (r == hipSuccess) r = up(d->dpos_first_row, dfirst.data(), 4 * dfirst.size());
+    if (r == hipSuccess) r = up(d->dbucket, dbucket.data(), 16 * dbucket.size());
+    if (r == hipSuccess) r = up(d->rival_bits, rbits.data(), 4 * rbits.size());
     if (r == hipSuccess) r = up(d->part_off, s->part_off, S ? 4 * (S + 1) : 0);
     if (r == hipSuccess) r = up(d->part_pos, s->part_pos, 4 * P);
     if (r == hipSuccess) r = up(d->part_site, s->part_site, 4 * P);
@@ -400,6 +437,8 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.site_pos = ds->pos; p.site_strand = ds->strand; p.site_flags = ds->flags; p.site_meta = ds->meta;
     p.part_pos = ds->part_pos; p.part_site = ds->part_site; p.comp_pos = ds->comp_pos;
     p.diff = ds->diff; p.diff_stride = ds->diff_stride;
+    p.dbucket = ds->dbucket; p.n_dbuckets = ds->n_dbuckets; p.dbase = ds->n_sites ? ds->bucket_base : 0; p.n_dpos = ds->n_dpos;
+    p.rival_bits = ds->rival_bits;
     p.bucket = ds->bucket; p.n_buckets = ds->n_buckets; p.bucket_base = ds->bucket_base; p.bucket_shift = ds->bucket_shift;
     p.stranded = o->stranded; p.combine_mode = o->combine_mode ? 1 : 0;
     p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = c->d_err;
@@ -417,7 +456,8 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     if (variant == 0 && grid > 0) { // difference arrays -> counters
         spl_scan_params q;
         memset(&q, 0, sizeof(q));
-        q.n_sites = (int32_t)ds->n_sites; q.n_arrays = o->stranded ? 4 : 2; q.diff_stride = ds->diff_stride;
+        q.n_dpos = ds->n_dpos; q.dpos_first_row = ds->dpos_first_row;
+        q.n_arrays = o->stranded ? 4 : 2; q.diff_stride = ds->diff_stride;
         q.n_blocks = ds->scan_blocks; q.diff = ds->diff; q.block_sums = ds->block_sums; q.site_flags = ds->flags;
         q.beta1 = ds->beta1; q.beta2s_reads = ds->beta2s;
         rc = spl_dev_launch_scan(&q, c->stream);

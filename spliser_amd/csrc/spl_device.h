@@ -10,7 +10,7 @@
 #define SPL_RPT 4                        // reads per thread
 #define SPL_CHUNK (SPL_BLOCK * SPL_RPT)  // consecutive reads per workgroup
 #define SPL_WIN 1024                     // site rows whose counters a workgroup privatises in LDS
-#define SPL_OPS_CAP 3072                 // raw CIGAR ops of a chunk staged in LDS (more -> serial fallback)
+#define SPL_INLINE_OPS 3                 // CIGAR ops per read resolved in the straight-line part (M N M = 3)
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
 #define SPL_SCAN_BLOCK 1024              // rows per workgroup in the difference-array scan
 
@@ -46,6 +46,12 @@ struct spl_count_params {
     uint32_t n_buckets;
     int32_t bucket_base;
     int32_t bucket_shift;
+    // position -> distinct-position index (range kernel): 64 bp buckets {first dpos, -, occupancy mask lo, hi}
+    const uint4 *dbucket;
+    uint32_t n_dbuckets;
+    int32_t dbase;
+    int32_t n_dpos;
+    const uint32_t *rival_bits;  // bit d: some row at distinct position d carries SPL_SF_RIVALS
     // options
     int32_t stranded;            // 0 none, 1 fr, 2 rf
     int32_t combine_mode;
@@ -53,13 +59,14 @@ struct spl_count_params {
     uint32_t *beta1;             // point counters (pair kernel, rival-site corrections); the scan adds the ranges
     uint32_t *beta2s_reads;
     uint32_t *dbl;
-    int32_t *diff;               // range kernel: n_diff difference arrays of (n_sites + 1) int32, row-major
-    int32_t diff_stride;         // n_sites + 1 rounded up
+    int32_t *diff;               // range kernel: difference arrays over distinct positions, diff_stride apart
+    int32_t diff_stride;         // n_dpos + 1 rounded up
     int32_t *err;
 };
 
 struct spl_scan_params {
-    int32_t n_sites;
+    int32_t n_dpos;
+    const int32_t *dpos_first_row; // [n_dpos + 1]
     int32_t n_arrays;            // 2 unstranded {beta1, ME}; 4 stranded {beta1+, beta1-, ME+, ME-}
     int32_t diff_stride;
     int32_t n_blocks;

@@ -344,92 +344,173 @@ __device__ __forceinline__ void unmapped_read(const spl_count_params &p, int32_t
 
 } // namespace
 
-// One read per lane, ops walked in a loop: the fallback for chunks whose CIGARs do not fit the LDS staging area
-// (long-read data); same ranges, same commits, just latency-bound.
-template <bool STRANDED>
-__device__ __forceinline__ void ranges_chunk_serial(const spl_count_params &p, int32_t *lds, int32_t wbase, int64_t chunk_base)
+// Position -> distinct-position index ("dpos": rows sharing a position, e.g. the '+' and '-' site of a stranded
+// table, share one index).  64 bp buckets, one 16-byte entry each: {dpos of the first site at or after the bucket
+// start, unused, 64-bit occupancy mask}.  One load answers both "how many site positions are < x" and "is x a
+// site" with a popcount -- no dependent second access, so all boundaries of a read resolve in one memory trip.
+__device__ __forceinline__ uint32_t dbk_slot(const spl_count_params &p, int32_t x)
 {
-    constexpr int NARR = STRANDED ? 4 : 2;
+    int64_t b = ((int64_t)x - (int64_t)p.dbase) >> 6;
+    if (b < 0) b = 0;
+    if (b >= (int64_t)p.n_dbuckets) b = (int64_t)p.n_dbuckets - 1;
+    return (uint32_t)b;
+}
+
+__device__ __forceinline__ void dbk_resolve(const spl_count_params &p, int32_t x, const uint4 e, int32_t &u, uint32_t &nv)
+{
+    const int64_t rel = (int64_t)x - (int64_t)p.dbase;
+    const int64_t b = rel >> 6;
+    if (rel < 0) { u = 0; nv = 0; return; }
+    if (b >= (int64_t)p.n_dbuckets) { u = p.n_dpos; nv = 0; return; }
+    const uint32_t bit = (uint32_t)rel & 63u;
+    const unsigned long long mask = (unsigned long long)e.z | ((unsigned long long)e.w << 32);
+    u = (int32_t)(e.x + (uint32_t)__popcll(mask & ((1ull << bit) - 1ull)));
+    nv = (uint32_t)((mask >> bit) & 1ull);
+}
+
+__device__ __forceinline__ bool rival_bit(const spl_count_params &p, int32_t d)
+{
+    return (p.rival_bits[(uint32_t)d >> 5] >> ((uint32_t)d & 31u)) & 1u;
+}
+
+// The range kernel proper: one read per lane, straight-line, three batched memory trips per read --
+//   trip 1  pos, flag, cig_off[i], cig_off[i+1]                       (coalesced)
+//   trip 2  the read's first SPL_INLINE_OPS CIGAR ops                   (neighbouring lanes, neighbouring words)
+//   trip 3  one bucket entry per boundary (read start + end of every reference-consuming op), all independent
+// then popcounts turn boundaries into dpos ranges and adjacent lanes that start or end a range on the same dpos
+// share one LDS atomic.  No LDS staging, no barriers inside the loop, few registers: 8 waves per SIMD hide the trips.
+// Reads with more ops continue one op at a time (long-read CIGARs work, they just are not the tuned case).
+template <bool STRANDED>
+__global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_count_params p)
+{
+    constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
+    __shared__ int32_t lds[NARR * (SPL_WIN + 1)];
+    __shared__ int32_t s_wbase;
+
     const int tid = threadIdx.x;
-    const int32_t n_sites = p.n_sites;
-    {
+    const uint32_t chunk = my_chunk();
+    const bool live = chunk < p.n_chunks;
+    const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
+
+    for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) lds[j] = 0;
+    if (tid == 0) {
+        int32_t u = 0; uint32_t nv = 0;
+        if (live) { const int32_t x = p.r_pos[chunk_base] - 1; dbk_resolve(p, x, p.dbucket[dbk_slot(p, x)], u, nv); }
+        s_wbase = u;
+    }
+    __syncthreads();
+    const int32_t wbase = s_wbase;
+
+    if (live) {
         for (int it = 0; it < SPL_RPT; ++it) {
-            // Control flow below is wave-uniform (every lane reaches every commit_run) so that lanes whose ranges
-            // start or end on the same row -- the normal case for coordinate-sorted reads -- share ONE LDS atomic.
+            // Control flow is wave-uniform around every commit_run (all 64 lanes reach it).
             const int64_t i = chunk_base + (int64_t)it * SPL_BLOCK + tid;
             bool alive = i < p.n_reads;
             int32_t pos = 0;
-            uint32_t flag = 0, n_ops = 0;
-            const uint32_t *ops = p.cigar;
-            if (alive) {
+            uint32_t flag = 0, o0 = 0, n_ops = 0;
+            if (alive) {                                                        // ---- trip 1
                 pos = p.r_pos[i];
                 flag = p.r_flag[i];
-                const uint32_t o0 = p.cig_off[i];
+                o0 = p.cig_off[i];
                 n_ops = p.cig_off[i + 1] - o0;
-                ops = p.cigar + o0;
-                if (pos < 0) { atomicOr(p.err, SPL_DEV_ERR_RANGE); alive = false; }
-                else if (flag & 4u) {
-                    int64_t rl; bool hn;
-                    spl_read_extent(ops, n_ops, &rl, &hn);
-                    if ((int64_t)pos + rl > (int64_t)SPL_COORD_MAX) atomicOr(p.err, SPL_DEV_ERR_RANGE);
-                    else unmapped_read<STRANDED>(p, pos, flag, ops, n_ops);
-                    alive = false;
-                }
             }
-            int sidx = 0; // which strand pair of arrays this read writes
+            uint32_t op[SPL_INLINE_OPS];
+#pragma unroll
+            for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = (alive && (uint32_t)k < n_ops) ? p.cigar[o0 + k] : 0xfu; // ---- trip 2
+            if (alive && pos < 0) { atomicOr(p.err, SPL_DEV_ERR_RANGE); alive = false; }
+            if (alive && (flag & 4u)) {
+                int64_t rl; bool hn;
+                spl_read_extent(p.cigar + o0, n_ops, &rl, &hn);
+                if ((int64_t)pos + rl > (int64_t)SPL_COORD_MAX) atomicOr(p.err, SPL_DEV_ERR_RANGE);
+                else unmapped_read<STRANDED>(p, pos, flag, p.cigar + o0, n_ops);
+                alive = false;
+            }
+            int sidx = 0;
             if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1 : 0;
 
-            // rows at position pos-1 are [prev_hi, idx); idx = first row >= pos
-            int32_t prev_hi = 0, idx = 0;
-            if (alive) {
-                prev_hi = first_site_at_or_after(p, pos - 1);
-                idx = prev_hi;
-                while (idx < n_sites && p.site_pos[idx] < pos) ++idx;
-            }
+            // boundaries of the inline ops (op code 0xf = absent: not a reference-consuming op)
             int32_t c = pos;
             int64_t ref_len = 0;
+            int32_t cend[SPL_INLINE_OPS];
+            uint32_t kind[SPL_INLINE_OPS]; // 0 none, 1 aligned, 2 N, 3 D
+#pragma unroll
+            for (int k = 0; k < SPL_INLINE_OPS; ++k) {
+                const uint32_t code = op[k] & 15u;
+                kind[k] = 0u;
+                cend[k] = c;
+                if (alive && ((SPL_PROG_MASK >> code) & 1u)) {
+                    const int32_t d = (int32_t)(op[k] >> 4);
+                    ref_len += d;
+                    if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { alive = false; }
+                    else {
+                        c += d;
+                        cend[k] = c;
+                        kind[k] = (code == SPL_OP_N) ? 2u : (code == SPL_OP_D ? 3u : 1u);
+                    }
+                }
+            }
+            // ---- trip 3: bucket entries of the start boundary and of every inline op end
+            uint4 e0 = make_uint4(0, 0, 0, 0), ek[SPL_INLINE_OPS];
+            if (alive) e0 = p.dbucket[dbk_slot(p, pos - 1)];
+#pragma unroll
+            for (int k = 0; k < SPL_INLINE_OPS; ++k) {
+                ek[k] = make_uint4(0, 0, 0, 0);
+                if (alive && kind[k]) ek[k] = p.dbucket[dbk_slot(p, cend[k] - 1)];
+            }
+            int32_t pu = 0; uint32_t pnv = 0; // rows AT the previous boundary's last base: [pu, pu + pnv)
+            if (alive) dbk_resolve(p, pos - 1, e0, pu, pnv);
             bool need_rivals = false;
-            for (uint32_t k = 0; __any(alive && k < n_ops); ++k) {
+#pragma unroll
+            for (int k = 0; k < SPL_INLINE_OPS; ++k) {
+                bool emit = false;
+                int arr = 0;
+                int32_t lo = 0, hi = 0;
+                if (alive && kind[k]) {
+                    int32_t u; uint32_t nv;
+                    dbk_resolve(p, cend[k] - 1, ek[k], u, nv);
+                    lo = pu + (int32_t)pnv; // first dpos at or after the op's first base
+                    hi = u;                 // first dpos at or after the op's last base
+                    emit = hi > lo && kind[k] != 3u;
+                    arr = (kind[k] == 2u ? (STRANDED ? 2 : 1) : 0) + sidx;
+                    if (kind[k] == 2u) {    // junction ends: lSite is the previous boundary's position, rSite this one's
+                        if (pnv) need_rivals |= rival_bit(p, pu);
+                        if (nv) need_rivals |= rival_bit(p, u);
+                    }
+                    pu = u;
+                    pnv = nv;
+                }
+                if (__any(emit)) {
+                    commit_run<NARR>(p, lds, wbase, emit, arr, lo, 1);
+                    commit_run<NARR>(p, lds, wbase, emit, arr, hi, -1);
+                }
+            }
+            // ---- reads with more ops than the inline window: one op at a time
+            for (uint32_t k = SPL_INLINE_OPS; __any(alive && k < n_ops); ++k) {
                 bool emit = false;
                 int arr = 0;
                 int32_t lo = 0, hi = 0;
                 if (alive && k < n_ops) {
-                    const uint32_t op = ops[k];
-                    const uint32_t code = op & 15u;
-                    const int32_t d = (int32_t)(op >> 4);
-                    const bool is_n = (code == SPL_OP_N);
-                    if (!((SPL_PROG_MASK >> code) & 1u)) {
-                        // I, S, H, P: no progression (:463-464)
-                    } else if (d == 0) { // covers nothing; a 0N still names a junction (lSite == rSite == c-1)
-                        if (is_n) for (int32_t r = prev_hi; r < idx; ++r) need_rivals |= (p.site_flags[r] & SPL_SF_RIVALS) != 0;
-                    } else if ((ref_len += d) + pos > (int64_t)SPL_COORD_MAX) {
-                        alive = false; // flagged below; coordinates would wrap
-                    } else {
-                        const int32_t c2 = c + d;
-                        // hi = first row with position >= c2-1: rows [idx, hi) have positions in [c, c2-2]
-                        hi = idx;
-                        if (d <= 512) {
-                            int steps = 0;
-                            while (hi < n_sites && p.site_pos[hi] < c2 - 1) {
-                                ++hi;
-                                if (++steps == 6) { hi = first_site_at_or_after(p, c2 - 1); break; }
+                    const uint32_t o = p.cigar[o0 + k];
+                    const uint32_t code = o & 15u;
+                    if ((SPL_PROG_MASK >> code) & 1u) {
+                        const int32_t d = (int32_t)(o >> 4);
+                        ref_len += d;
+                        if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) alive = false;
+                        else {
+                            c += d;
+                            int32_t u; uint32_t nv;
+                            dbk_resolve(p, c - 1, p.dbucket[dbk_slot(p, c - 1)], u, nv);
+                            lo = pu + (int32_t)pnv;
+                            hi = u;
+                            emit = hi > lo && code != SPL_OP_D;
+                            arr = (code == SPL_OP_N ? (STRANDED ? 2 : 1) : 0) + sidx;
+                            if (code == SPL_OP_N) {
+                                if (pnv) need_rivals |= rival_bit(p, pu);
+                                if (nv) need_rivals |= rival_bit(p, u);
                             }
-                        } else {
-                            hi = first_site_at_or_after(p, c2 - 1);
+                            pu = u;
+                            pnv = nv;
                         }
-                        lo = idx;
-                        emit = hi > lo && code != SPL_OP_D;
-                        arr = (is_n ? (STRANDED ? 2 : 1) : 0) + sidx;
-                        // rows at position c2-1 (the op's last base; rSite of an N op) are [hi, v2)
-                        int32_t v2 = hi;
-                        while (v2 < n_sites && p.site_pos[v2] == c2 - 1) ++v2;
-                        if (is_n) { // junction rows: lSite = c-1 -> [prev_hi, idx), rSite = c2-1 -> [hi, v2)
-                            for (int32_t r = prev_hi; r < idx; ++r) need_rivals |= (p.site_flags[r] & SPL_SF_RIVALS) != 0;
-                            for (int32_t r = hi; r < v2; ++r) need_rivals |= (p.site_flags[r] & SPL_SF_RIVALS) != 0;
-                        }
-                        prev_hi = hi;
-                        idx = v2;
-                        c = c2;
                     }
                 }
                 if (__any(emit)) {
@@ -439,189 +520,10 @@ __device__ __forceinline__ void ranges_chunk_serial(const spl_count_params &p, i
             }
             if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); alive = false; }
             if (alive && need_rivals)
-                rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
-        }
-    }
-}
-
-// Record byte of one boundary slot (see spl_count_ranges_kernel).
-#define SPL_K_LIVE 1u
-#define SPL_K_KIND(k) (((k) >> 1) & 3u) // 0 read start, 1 aligned op, 2 N op, 3 D op
-#define SPL_K_SIDX(k) (((k) >> 3) & 1u)
-#define SPL_K_RIVAL 16u
-#define SPL_K_NV(k) (((k) >> 5) & 3u)   // rows AT the boundary's last position (3 = three or more: recount)
-
-// The range kernel proper.  A workgroup owns SPL_CHUNK consecutive reads and runs four passes over LDS:
-//   P0  stage the chunk's raw CIGAR ops (one coalesced sweep of the op array);
-//   P1  one read per lane: walk its ops (LDS latency only) and lay down one *boundary record* per reference-
-//       consuming op, preceded by one for the read start: slot = coordinate just past the op, kind, strand;
-//   P2  FLAT over slots, perfectly balanced and free of cross-lane dependence: row lookup of each boundary
-//       (first row at or after coordinate-1, and how many rows sit exactly there);
-//   P3  FLAT over slots: an op's row range is [start boundary's rows end, end boundary's rows begin); commit
-//       +1/-1 (adjacent lanes hitting one row share an atomic); N ops look at the rival flag of their junction rows;
-//   P4  one read per lane: reads with a flagged junction end run the literal rival pass.
-template <bool STRANDED>
-__global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_count_params p)
-{
-    constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
-    constexpr int SLOTS = SPL_CHUNK + SPL_OPS_CAP;
-    __shared__ int32_t lds[NARR * (SPL_WIN + 1)];
-    __shared__ uint32_t s_op[SPL_OPS_CAP];
-    __shared__ int32_t s_b[SLOTS];
-    __shared__ uint8_t s_kind[SLOTS];
-    __shared__ int32_t s_wbase;
-
-    const int tid = threadIdx.x;
-    const uint32_t chunk = my_chunk();
-    const bool live = chunk < p.n_chunks;
-    const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
-    const int32_t n_sites = p.n_sites;
-
-    uint32_t ob = 0, n_co = 0;
-    int n_rd = 0;
-    if (live) {
-        const int64_t chunk_end = (chunk_base + SPL_CHUNK < p.n_reads) ? chunk_base + SPL_CHUNK : p.n_reads;
-        n_rd = (int)(chunk_end - chunk_base);
-        ob = p.cig_off[chunk_base];
-        n_co = p.cig_off[chunk_end] - ob;
-    }
-    const bool staged = live && n_co <= (uint32_t)SPL_OPS_CAP;
-    const int n_slots = staged ? n_rd + (int)n_co : 0;
-
-    // ---- P0 ------------------------------------------------------------------------------------------------
-    for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) lds[j] = 0;
-    if (staged) {
-        for (uint32_t j = tid; j < n_co; j += SPL_BLOCK) s_op[j] = p.cigar[ob + j];
-        for (int j = tid; j < n_slots; j += SPL_BLOCK) s_kind[j] = 0;
-    }
-    if (tid == 0) s_wbase = live ? first_site_at_or_after(p, p.r_pos[chunk_base] - 1) : 0;
-    __syncthreads();
-    const int32_t wbase = s_wbase;
-
-    if (live && !staged) ranges_chunk_serial<STRANDED>(p, lds, wbase, chunk_base);
-
-    // ---- P1 ------------------------------------------------------------------------------------------------
-    int32_t r_pos[SPL_RPT];
-    uint32_t r_flag[SPL_RPT], r_o0[SPL_RPT], r_nops[SPL_RPT];
-    int r_base[SPL_RPT], r_nrec[SPL_RPT];
-    int64_t r_len[SPL_RPT];
-#pragma unroll
-    for (int q = 0; q < SPL_RPT; ++q) {
-        const int r = q * SPL_BLOCK + tid;
-        r_nrec[q] = 0; r_pos[q] = 0; r_flag[q] = 0; r_o0[q] = 0; r_nops[q] = 0; r_base[q] = 0; r_len[q] = 0;
-        if (staged && r < n_rd) {
-            const int64_t i = chunk_base + r;
-            r_pos[q] = p.r_pos[i];
-            r_flag[q] = p.r_flag[i];
-            r_o0[q] = p.cig_off[i];
-            r_nops[q] = p.cig_off[i + 1] - r_o0[q];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < SPL_RPT; ++q) {
-        const int r = q * SPL_BLOCK + tid;
-        if (!(staged && r < n_rd)) continue;
-        const int32_t pos = r_pos[q];
-        const uint32_t flag = r_flag[q], n_ops = r_nops[q];
-        const uint32_t lo0 = r_o0[q] - ob; // first raw op of this read in s_op
-        if (pos < 0) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
-        if (flag & 4u) {
-            int64_t rl; bool hn;
-            spl_read_extent(p.cigar + r_o0[q], n_ops, &rl, &hn);
-            if ((int64_t)pos + rl > (int64_t)SPL_COORD_MAX) atomicOr(p.err, SPL_DEV_ERR_RANGE);
-            else unmapped_read<STRANDED>(p, pos, flag, p.cigar + r_o0[q], n_ops);
-            continue;
-        }
-        uint32_t sbit = 0;
-        if (STRANDED) sbit = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 8u : 0u;
-        const int base = (int)lo0 + r;
-        int32_t cur = pos;
-        int64_t ref_len = 0;
-        int nrec = 0;
-        bool ok = true;
-        for (uint32_t k = 0; k < n_ops; ++k) {
-            const uint32_t op = s_op[lo0 + k];
-            const uint32_t code = op & 15u;
-            if (!((SPL_PROG_MASK >> code) & 1u)) continue;
-            const int32_t d = (int32_t)(op >> 4);
-            ref_len += d;
-            if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { ok = false; break; }
-            cur += d;
-            ++nrec;
-            const uint32_t kind = (code == SPL_OP_N) ? 2u : (code == SPL_OP_D ? 3u : 1u);
-            s_b[base + nrec] = cur;
-            s_kind[base + nrec] = (uint8_t)(SPL_K_LIVE | (kind << 1) | sbit);
-        }
-        if (!ok) {
-            atomicOr(p.err, SPL_DEV_ERR_RANGE);
-            for (int j = 1; j <= nrec; ++j) s_kind[base + j] = 0;
-            continue;
-        }
-        s_b[base] = pos;
-        s_kind[base] = (uint8_t)SPL_K_LIVE; // kind 0: read start
-        r_base[q] = base;
-        r_nrec[q] = nrec;
-        r_len[q] = ref_len;
-    }
-    __syncthreads();
-
-    // ---- P2: boundary -> rows ----------------------------------------------------------------------------
-    for (int g = tid; g < n_slots; g += SPL_BLOCK) {
-        const uint32_t kd = s_kind[g];
-        if (!(kd & SPL_K_LIVE)) continue;
-        const int32_t x = s_b[g] - 1;
-        const int32_t u = first_site_at_or_after(p, x);
-        uint32_t nv = 0;
-        while (nv < 3u && u + (int32_t)nv < n_sites && p.site_pos[u + nv] == x) ++nv;
-        s_b[g] = u;
-        s_kind[g] = (uint8_t)(kd | (nv << 5));
-    }
-    __syncthreads();
-
-    // ---- P3: ranges -> difference arrays ------------------------------------------------------------------
-    for (int g0 = 0; g0 < n_slots; g0 += SPL_BLOCK) { // wave-uniform trip count: every lane reaches commit_run
-        const int g = g0 + tid;
-        bool emit = false;
-        int arr = 0;
-        int32_t lo = 0, hi = 0;
-        if (g < n_slots) {
-            const uint32_t kd = s_kind[g];
-            const uint32_t kind = SPL_K_KIND(kd);
-            if ((kd & SPL_K_LIVE) && kind != 0u) {
-                const uint32_t ks = s_kind[g - 1];
-                const int32_t us = s_b[g - 1];
-                uint32_t nvs = SPL_K_NV(ks), nve = SPL_K_NV(kd);
-                hi = s_b[g];
-                if (nvs == 3u) { const int32_t x = p.site_pos[us]; while (us + (int32_t)nvs < n_sites && p.site_pos[us + nvs] == x) ++nvs; }
-                lo = us + (int32_t)nvs;
-                emit = hi > lo && kind != 3u;
-                arr = (kind == 2u ? (STRANDED ? 2 : 1) : 0) + (int)SPL_K_SIDX(kd);
-                if (kind == 2u) { // junction rows: lSite -> [us, lo), rSite -> [hi, hi + nve)
-                    if (nve == 3u) { const int32_t x = p.site_pos[hi]; while (hi + (int32_t)nve < n_sites && p.site_pos[hi + nve] == x) ++nve; }
-                    bool rival = false;
-                    for (int32_t r = us; r < lo; ++r) rival |= (p.site_flags[r] & SPL_SF_RIVALS) != 0;
-                    for (int32_t r = hi; r < hi + (int32_t)nve; ++r) rival |= (p.site_flags[r] & SPL_SF_RIVALS) != 0;
-                    if (rival) s_kind[g] = (uint8_t)(kd | SPL_K_RIVAL);
-                }
-            }
-        }
-        if (__any(emit)) {
-            commit_run<NARR>(p, lds, wbase, emit, arr, lo, 1);
-            commit_run<NARR>(p, lds, wbase, emit, arr, hi, -1);
+                rivals_pass<STRANDED>(p, pos, flag, p.cigar + o0, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
         }
     }
     __syncthreads();
-
-    // ---- P4: rivals ----------------------------------------------------------------------------------------
-#pragma unroll
-    for (int q = 0; q < SPL_RPT; ++q) {
-        bool need = false;
-        for (int j = 1; j <= r_nrec[q]; ++j) need |= (s_kind[r_base[q] + j] & SPL_K_RIVAL) != 0;
-        if (need)
-            rivals_pass<STRANDED>(p, r_pos[q], r_flag[q], p.cigar + r_o0[q], r_nops[q],
-                                  (int32_t)((int64_t)r_pos[q] + (r_len[q] > 0 ? r_len[q] : 1) - 1));
-    }
-
     for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) {
         const int32_t v = lds[j];
         if (v) {
@@ -643,7 +545,7 @@ __global__ __launch_bounds__(256) void spl_scan_sums_kernel(const spl_scan_param
     int32_t acc = 0;
     for (int j = threadIdx.x; j < SPL_SCAN_BLOCK; j += 256) {
         const int32_t r = base + j;
-        if (r < p.n_sites) acc += d[r];
+        if (r < p.n_dpos) acc += d[r];
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -665,19 +567,18 @@ __global__ __launch_bounds__(256) void spl_scan_apply_kernel(const spl_scan_para
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
         if (lane == 0) red[a][wave] = acc;
     }
-    // each thread owns 4 consecutive rows
+    // each thread owns 4 consecutive distinct positions
     int32_t v[4][4];
-    const int32_t r0 = base + tid * 4;
+    const int32_t d0 = base + tid * 4;
     for (int a = 0; a < p.n_arrays; ++a) {
         const int32_t *d = p.diff + (int64_t)a * p.diff_stride;
         int32_t s = 0;
         for (int q = 0; q < 4; ++q) {
-            const int32_t r = r0 + q;
-            s += (r < p.n_sites) ? d[r] : 0;
+            const int32_t r = d0 + q;
+            s += (r < p.n_dpos) ? d[r] : 0;
             v[a][q] = s; // inclusive within the thread
         }
-        // wave-inclusive scan of thread totals
-        int32_t incl = s;
+        int32_t incl = s; // wave-inclusive scan of thread totals
         for (int o = 1; o < 64; o <<= 1) {
             const int32_t up = __shfl_up(incl, o);
             if (lane >= o) incl += up;
@@ -692,18 +593,20 @@ __global__ __launch_bounds__(256) void spl_scan_apply_kernel(const spl_scan_para
         run[a] += off;
     }
     for (int q = 0; q < 4; ++q) {
-        const int32_t r = r0 + q;
-        if (r >= p.n_sites) break;
-        int32_t b1, me;
-        if (p.n_arrays == 2) { b1 = run[0] + v[0][q]; me = run[1] + v[1][q]; }
-        else {
-            const uint8_t f = p.site_flags[r];
-            if (f & SPL_SF_PLUS) { b1 = run[0] + v[0][q]; me = run[2] + v[2][q]; }
-            else if (f & SPL_SF_MINUS) { b1 = run[1] + v[1][q]; me = run[3] + v[3][q]; }
-            else { b1 = 0; me = 0; } // a row without strand matches no read in a stranded run (:406)
+        const int32_t d = d0 + q;
+        if (d >= p.n_dpos) break;
+        for (int32_t r = p.dpos_first_row[d]; r < p.dpos_first_row[d + 1]; ++r) { // the rows at this position
+            int32_t b1, me;
+            if (p.n_arrays == 2) { b1 = run[0] + v[0][q]; me = run[1] + v[1][q]; }
+            else {
+                const uint8_t f = p.site_flags[r];
+                if (f & SPL_SF_PLUS) { b1 = run[0] + v[0][q]; me = run[2] + v[2][q]; }
+                else if (f & SPL_SF_MINUS) { b1 = run[1] + v[1][q]; me = run[3] + v[3][q]; }
+                else { b1 = 0; me = 0; } // a row without strand matches no read in a stranded run (:406)
+            }
+            if (b1) p.beta1[r] += (uint32_t)b1;
+            if (me) p.beta2s_reads[r] += (uint32_t)me;
         }
-        if (b1) p.beta1[r] += (uint32_t)b1;
-        if (me) p.beta2s_reads[r] += (uint32_t)me;
     }
 }
 
@@ -779,7 +682,7 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, int variant, void
         if (p->stranded) hipLaunchKernelGGL(spl_count_pairs_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
         else hipLaunchKernelGGL(spl_count_pairs_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
     } else {
-        *lds_out = (p->stranded ? 4 : 2) * (SPL_WIN + 1) * 4 + 4 * SPL_OPS_CAP + 5 * (SPL_CHUNK + SPL_OPS_CAP) + 4;
+        *lds_out = (p->stranded ? 4 : 2) * (SPL_WIN + 1) * 4 + 4;
         if (p->stranded) hipLaunchKernelGGL(spl_count_ranges_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
         else hipLaunchKernelGGL(spl_count_ranges_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
     }
@@ -788,7 +691,7 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, int variant, void
 
 extern "C" int spl_dev_launch_scan(const spl_scan_params *p, void *stream)
 {
-    if (p->n_sites <= 0) return 0;
+    if (p->n_dpos <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(spl_scan_sums_kernel, dim3(p->n_blocks, p->n_arrays), dim3(256), 0, st, *p);
     hipLaunchKernelGGL(spl_scan_apply_kernel, dim3(p->n_blocks), dim3(256), 0, st, *p);

@@ -322,7 +322,8 @@ class Workload(object):
         n_reads = int((cfg["n_reads"] if n_reads is None else n_reads) * scale)
         n_genes = max(2, int(cfg["n_genes"] * (scale if scale < 1.0 else 1.0)))
         self.paired = bool(cfg.get("paired"))
-        self.genome = make_genome(cfg["chroms"], n_genes, cfg["intron"], seed=self.seed)
+        self.genome = make_genome(cfg["chroms"], n_genes, cfg["intron"], seed=self.seed,
+                                  alt_fraction=cfg.get("alt_fraction", 0.3))
         nchr = len(self.genome.chrom_names)
         per_chrom = [[] for _ in range(nchr)]
         jobs = []
