@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--stranded", default=None, choices=[None, "fr", "rf"])
     ap.add_argument("--beta2Cryptic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel", default="ranges", choices=["ranges", "pairs"],
+    ap.add_argument("--kernel", default="ranges", choices=["ranges", "ranges_noagg", "pairs"],
                     help="ranges = default product path; pairs = the literal per-(read, site) kernel")
     ap.add_argument("--alt-fraction", type=float, default=None, help="(experiment) fraction of genes with alternative isoforms")
     ap.add_argument("--cache", default=None, help="directory to cache the generated sample in (.npz); a cached "
@@ -93,7 +93,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     scode = native.STRANDED_CODE[stranded]
-    kflags = native.OPT_PAIR_KERNEL if args.kernel == "pairs" else 0
+    kflags = {"pairs": native.OPT_PAIR_KERNEL, "ranges_noagg": native.OPT_NO_WAVE_AGGREGATION, "ranges": 0}[args.kernel]
     ctx = native.Context(local_rank)
     dev = [(ctx.upload_sites(sh.sites), ctx.upload_reads(sh.reads)) for sh in shards]
     alg_bytes = sum(native.algorithmic_bytes(ds, dr) for ds, dr in dev)
@@ -199,7 +199,7 @@ def main():
                        "scale": args.scale, "parallelism": "chromosome/sample shards, no collectives", "seed": cfg["seed"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "spl_count_%s_kernel" % args.kernel, "kernel_ms_avg": k_avg_ms, "launches_timed": len(kernel_ms),
+                         "kernel": "spl_count_%s_kernel" % args.kernel.split("_")[0], "kernel_ms_avg": k_avg_ms, "launches_timed": len(kernel_ms),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"]},
             "cpu_baseline": cpu,

@@ -97,6 +97,8 @@ typedef struct spl_opts {
  * partner edge of the table has its reverse edge (tables built like findAlphaCounts builds them), and the
  * pair kernel otherwise (e.g. combine gap-fill queries); both give identical counters. */
 #define SPL_OPT_PAIR_KERNEL 1
+/* Tuning experiment: range kernel without wave-level aggregation of its LDS atomics (same results). */
+#define SPL_OPT_NO_WAVE_AGGREGATION 2
 
 /* ---- library / context ------------------------------------------------------------------------ */
 int spl_abi_version(void);

@@ -4,7 +4,7 @@ TAG=$1; shift
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out /tmp/wl
-cd $R && python bench.py --cache /tmp/wl --no-cpu-baseline --steps 3 "$@" > $R/gpurun_out/${TAG}_warm.log 2>&1
+cd $R && python bench.py --cache /tmp/wl --no-cpu-baseline --steps 3 $EXTRA > $R/gpurun_out/${TAG}_warm.log 2>&1
 cd /tmp
 run() { # name, counters
   rocprofv3 --pmc $2 --output-format csv -d $R/gpurun_out/pmc_${TAG}_$1 -- python3 $R/bench.py --cache /tmp/wl --no-cpu-baseline --steps 3 --warmup 1 "$@" > $R/gpurun_out/pmc_${TAG}_$1.log 2>&1

@@ -88,6 +88,7 @@ struct spl_dreads {
     int32_t *pos = nullptr;
     uint16_t *flag = nullptr;
     uint32_t *cig_off = nullptr, *cigar = nullptr;
+    uint32_t *queue = nullptr, *queue_n = nullptr; // reads the range kernel hands to the literal kernel
 };
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -209,7 +210,7 @@ extern "C" int spl_kernel_timing_collect(spl_ctx *c, float *ms_out, int capacity
 static int validate_sites(const spl_sites *s)
 {
     if (!s) return spl_set_error(SPL_ERR_ARG, "null site table");
-    if (s->n_sites < 0 || s->n_sites > 0x7ffffff0LL) return spl_set_error(SPL_ERR_ARG, "n_sites out of range");
+    if (s->n_sites < 0 || s->n_sites > 0x3ffffff0LL) return spl_set_error(SPL_ERR_ARG, "n_sites out of range");
     if (s->n_sites == 0) return SPL_OK;
     if (!s->pos || !s->strand || !s->part_off || !s->comp_off) return spl_set_error(SPL_ERR_ARG, "site table has null arrays");
     if (s->part_off[0] != 0 || s->comp_off[0] != 0) return spl_set_error(SPL_ERR_ARG, "CSR offsets must start at 0");
@@ -393,10 +394,12 @@ extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     const size_t o_pos = take(4 * R), o_flag = take(2 * R), o_off = take(4 * (R + 1)), o_cig = take(4 * G);
+    const size_t o_queue = take(4 * R), o_qn = take(4);
     hipError_t e = hipMalloc((void **)&d->slab, std::max<size_t>(off, 256));
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the read set: %s", off, hipGetErrorString(e)); }
     d->pos = (int32_t *)(d->slab + o_pos); d->flag = (uint16_t *)(d->slab + o_flag);
     d->cig_off = (uint32_t *)(d->slab + o_off); d->cigar = (uint32_t *)(d->slab + o_cig);
+    d->queue = (uint32_t *)(d->slab + o_queue); d->queue_n = (uint32_t *)(d->slab + o_qn);
     hipError_t q = hipSuccess;
     if (R) {
         q = hipMemcpyAsync(d->pos, r->pos, 4 * R, hipMemcpyHostToDevice, c->stream);
@@ -438,22 +441,31 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.part_pos = ds->part_pos; p.part_site = ds->part_site; p.comp_pos = ds->comp_pos;
     p.diff = ds->diff; p.diff_stride = ds->diff_stride;
     p.dbucket = ds->dbucket; p.n_dbuckets = ds->n_dbuckets; p.dbase = ds->n_sites ? ds->bucket_base : 0; p.n_dpos = ds->n_dpos;
-    p.rival_bits = ds->rival_bits;
+    p.rival_bits = ds->rival_bits; p.dpos_first_row = ds->dpos_first_row;
+    spl_hot_params h;
+    memset(&h, 0, sizeof(h));
+    h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos = p.r_pos; h.r_flag = p.r_flag; h.cig_off = p.cig_off; h.cigar = p.cigar;
+    h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.rival_bits = p.rival_bits;
+    h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
+    h.queue = dr->queue; h.queue_n = dr->queue_n; h.err = c->d_err;
+    HIP_TRY(hipMemsetAsync(dr->queue_n, 0, sizeof(uint32_t), c->stream));
     p.bucket = ds->bucket; p.n_buckets = ds->n_buckets; p.bucket_base = ds->bucket_base; p.bucket_shift = ds->bucket_shift;
     p.stranded = o->stranded; p.combine_mode = o->combine_mode ? 1 : 0;
     p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = c->d_err;
     // range kernel whenever the table allows it; the literal pair kernel otherwise or on request
-    const int variant = (!ds->mutual_links || (o->flags & SPL_OPT_PAIR_KERNEL)) ? 1 : 0;
+    const int variant = (!ds->mutual_links || (o->flags & SPL_OPT_PAIR_KERNEL)) ? 1 : ((o->flags & SPL_OPT_NO_WAVE_AGGREGATION) ? 2 : 0);
     int grid = 0, lds = 0;
     const bool timed = c->k_on && (size_t)(2 * c->k_used + 1) < c->k_ev.size();
     if (timed) HIP_TRY(hipEventRecord(c->k_ev[2 * c->k_used], c->stream));
-    int rc = spl_dev_launch_count(&p, variant, c->stream, &grid, &lds);
+    int rc = spl_dev_launch_count(&p, &h, variant, c->stream, &grid, &lds);
     if (timed) { HIP_TRY(hipEventRecord(c->k_ev[2 * c->k_used + 1], c->stream)); c->k_used++; }
     c->last_grid = grid;
     c->last_lds = lds;
     c->last_variant = variant;
     if (rc != 0) return spl_set_error(SPL_ERR_HIP, "count kernel launch: %s", hipGetErrorString((hipError_t)rc));
-    if (variant == 0 && grid > 0) { // difference arrays -> counters
+    if (variant != 1 && grid > 0) { // queued reads through the literal kernel, then difference arrays -> counters
+        rc = spl_dev_launch_literal(&p, dr->queue, dr->queue_n, c->stream);
+        if (rc != 0) return spl_set_error(SPL_ERR_HIP, "literal kernel launch: %s", hipGetErrorString((hipError_t)rc));
         spl_scan_params q;
         memset(&q, 0, sizeof(q));
         q.n_dpos = ds->n_dpos; q.dpos_first_row = ds->dpos_first_row;

@@ -12,7 +12,8 @@
 #define SPL_WIN 1024                     // site rows whose counters a workgroup privatises in LDS
 #define SPL_INLINE_OPS 3                 // CIGAR ops per read resolved in the straight-line part (M N M = 3)
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
-#define SPL_SCAN_BLOCK 1024              // rows per workgroup in the difference-array scan
+#define SPL_SCAN_BLOCK 1024              // distinct positions per workgroup in the difference-array scan
+#define SPL_LITERAL_GRID 2048            // workgroups of the literal kernel (grid-stride over its queue)
 
 // Coordinates (read end, site position) must stay <= SPL_COORD_MAX so that t+1 and cur never wrap int32.
 #define SPL_COORD_MAX 2147483645
@@ -52,6 +53,7 @@ struct spl_count_params {
     int32_t dbase;
     int32_t n_dpos;
     const uint32_t *rival_bits;  // bit d: some row at distinct position d carries SPL_SF_RIVALS
+    const int32_t *dpos_first_row;
     // options
     int32_t stranded;            // 0 none, 1 fr, 2 rf
     int32_t combine_mode;
@@ -61,6 +63,27 @@ struct spl_count_params {
     uint32_t *dbl;
     int32_t *diff;               // range kernel: difference arrays over distinct positions, diff_stride apart
     int32_t diff_stride;         // n_dpos + 1 rounded up
+    int32_t *err;
+};
+
+// Argument block of the range kernel: only what the straight-line path touches (keeps it out of SGPR spills).
+struct spl_hot_params {
+    int64_t n_reads;
+    uint32_t n_chunks;
+    const int32_t *r_pos;
+    const uint16_t *r_flag;
+    const uint32_t *cig_off;
+    const uint32_t *cigar;
+    const uint4 *dbucket;
+    uint32_t n_dbuckets;
+    int32_t dbase;
+    int32_t n_dpos;
+    const uint32_t *rival_bits;
+    int32_t stranded;
+    int32_t *diff;
+    int32_t diff_stride;
+    uint32_t *queue;             // reads handed to spl_count_literal_kernel
+    uint32_t *queue_n;
     int32_t *err;
 };
 
@@ -98,8 +121,10 @@ struct spl_sse_params {
 #ifdef __cplusplus
 extern "C" {
 #endif
-// variant: 0 = range kernel (needs mutual partner links), 1 = pair kernel (any table)
-int spl_dev_launch_count(const spl_count_params *p, int variant, void *stream, int *grid_out, int *lds_out);
+// variant: 0 = range kernel (needs mutual partner links), 1 = pair kernel (any table), 2 = range kernel without
+// wave-level aggregation of LDS atomics (experiment)
+int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out);
+int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, void *stream);
 int spl_dev_launch_scan(const spl_scan_params *p, void *stream);
 int spl_dev_launch_sse(const spl_sse_params *p, void *stream);
 #ifdef __cplusplus

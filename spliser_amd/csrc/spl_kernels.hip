@@ -219,35 +219,6 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_pairs_kernel(const spl_co
 // =========================================================================================================
 namespace {
 
-template <int NARR>
-__device__ __forceinline__ void diff_add(const spl_count_params &p, int32_t *lds, int32_t wbase, int arr, int32_t row, int32_t v)
-{
-    const uint32_t loc = (uint32_t)(row - wbase);
-    if (loc <= (uint32_t)SPL_WIN) atomicAdd(&lds[arr * (SPL_WIN + 1) + (int)loc], v);
-    else atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + row], v);
-}
-
-// All 64 lanes call this together.  Lanes that add `sign` to the same (array, row) and sit next to each other
-// form a run; the first lane of each run adds sign * run-length once.  (Equal keys that are NOT adjacent simply
-// make several runs: still correct, just more atomics -- that only happens for unsorted input.)
-template <int NARR>
-__device__ __forceinline__ void commit_run(const spl_count_params &p, int32_t *lds, int32_t wbase, bool valid, int arr,
-                                           int32_t row, int32_t sign)
-{
-    const int lane = threadIdx.x & 63;
-    const int32_t key = valid ? row : -1;
-    const int32_t prev_key = __shfl_up(key, 1);
-    const int prev_arr = __shfl_up(arr, 1);
-    const bool head = valid && (lane == 0 || prev_key != key || prev_arr != arr);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long act = __ballot(valid);
-    if (head) {
-        const unsigned long long stop = (heads | ~act) & ~((2ull << lane) - 1ull); // later lanes that end my run
-        const int len = stop ? (__ffsll((long long)stop) - 1 - lane) : (64 - lane);
-        diff_add<NARR>(p, lds, wbase, arr, row, sign * len);
-    }
-}
-
 // Is any junction end of the read that comes before (stop_op, stop_side) -- in lSite, rSite order per N op --
 // a member of `part`?  Used to visit a rival exactly once.
 __device__ __forceinline__ bool earlier_end_in(int32_t pos, const uint32_t *ops, uint32_t stop_op, int stop_side,
@@ -342,46 +313,77 @@ __device__ __forceinline__ void unmapped_read(const spl_count_params &p, int32_t
     }
 }
 
-} // namespace
-
 // Position -> distinct-position index ("dpos": rows sharing a position, e.g. the '+' and '-' site of a stranded
 // table, share one index).  64 bp buckets, one 16-byte entry each: {dpos of the first site at or after the bucket
 // start, unused, 64-bit occupancy mask}.  One load answers both "how many site positions are < x" and "is x a
 // site" with a popcount -- no dependent second access, so all boundaries of a read resolve in one memory trip.
-__device__ __forceinline__ uint32_t dbk_slot(const spl_count_params &p, int32_t x)
+template <class P>
+__device__ __forceinline__ uint32_t dbk_slot(const P &p, int32_t x)
 {
-    int64_t b = ((int64_t)x - (int64_t)p.dbase) >> 6;
-    if (b < 0) b = 0;
-    if (b >= (int64_t)p.n_dbuckets) b = (int64_t)p.n_dbuckets - 1;
-    return (uint32_t)b;
+    int32_t b = (x - p.dbase) >> 6; // x >= -1 and dbase >= 0: no overflow
+    b = b < 0 ? 0 : b;
+    const int32_t last = (int32_t)p.n_dbuckets - 1;
+    return (uint32_t)(b > last ? last : b);
 }
 
-__device__ __forceinline__ void dbk_resolve(const spl_count_params &p, int32_t x, const uint4 e, int32_t &u, uint32_t &nv)
+template <class P>
+__device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint4 e, int32_t &u, uint32_t &nv)
 {
-    const int64_t rel = (int64_t)x - (int64_t)p.dbase;
-    const int64_t b = rel >> 6;
-    if (rel < 0) { u = 0; nv = 0; return; }
-    if (b >= (int64_t)p.n_dbuckets) { u = p.n_dpos; nv = 0; return; }
+    const int32_t rel = x - p.dbase;
     const uint32_t bit = (uint32_t)rel & 63u;
-    const unsigned long long mask = (unsigned long long)e.z | ((unsigned long long)e.w << 32);
-    u = (int32_t)(e.x + (uint32_t)__popcll(mask & ((1ull << bit) - 1ull)));
-    nv = (uint32_t)((mask >> bit) & 1ull);
+    const bool upper = bit >= 32u;
+    const uint32_t sh = bit & 31u;
+    const uint32_t below = (1u << sh) - 1u;
+    const uint32_t cnt = __popc(e.z & (upper ? 0xffffffffu : below)) + __popc(e.w & (upper ? below : 0u));
+    u = (int32_t)(e.x + cnt);
+    nv = ((upper ? e.w : e.z) >> sh) & 1u;
+    if (rel < 0) { u = 0; nv = 0; }
+    if ((rel >> 6) >= (int32_t)p.n_dbuckets) { u = p.n_dpos; nv = 0; }
 }
 
-__device__ __forceinline__ bool rival_bit(const spl_count_params &p, int32_t d)
+// All 64 lanes call this together.  Lanes that add `sign` to the same key = (dpos << 2 | array) and sit next to each
+// other form a run; the first lane of each run adds sign * run-length once.  (Equal keys that are NOT adjacent make
+// several runs: still correct, just more atomics -- that only happens for unsorted input.)
+template <int NARR, bool AGG>
+__device__ __forceinline__ void commit_key(const spl_hot_params &p, int32_t *lds, int32_t wbase, bool valid, uint32_t key, int32_t sign)
 {
-    return (p.rival_bits[(uint32_t)d >> 5] >> ((uint32_t)d & 31u)) & 1u;
+    int32_t amount = sign;
+    bool go = valid;
+    if (AGG) {
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const uint32_t k = valid ? key : 0xffffffffu;
+        const uint32_t prev = (uint32_t)__shfl_up((int)k, 1);
+        const bool head = valid && (lane == 0 || prev != k);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long act = __ballot(valid);
+        const unsigned long long stop = (heads | ~act) & ~((2ull << lane) - 1ull); // later lanes that end my run
+        const int len = stop ? (__ffsll((long long)stop) - 1 - lane) : (64 - lane);
+        amount = sign * len;
+        go = head;
+    }
+    if (go) {
+        const int arr = (int)(key & 3u);
+        const int32_t d = (int32_t)(key >> 2);
+        const uint32_t loc = (uint32_t)(d - wbase);
+        if (loc <= (uint32_t)SPL_WIN) atomicAdd(&lds[arr * (SPL_WIN + 1) + (int)loc], amount);
+        else atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + d], amount);
+    }
 }
+
+} // namespace
 
 // The range kernel proper: one read per lane, straight-line, three batched memory trips per read --
 //   trip 1  pos, flag, cig_off[i], cig_off[i+1]                       (coalesced)
 //   trip 2  the read's first SPL_INLINE_OPS CIGAR ops                   (neighbouring lanes, neighbouring words)
 //   trip 3  one bucket entry per boundary (read start + end of every reference-consuming op), all independent
 // then popcounts turn boundaries into dpos ranges and adjacent lanes that start or end a range on the same dpos
-// share one LDS atomic.  No LDS staging, no barriers inside the loop, few registers: 8 waves per SIMD hide the trips.
-// Reads with more ops continue one op at a time (long-read CIGARs work, they just are not the tuned case).
-template <bool STRANDED>
-__global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_count_params p)
+// share one LDS atomic.  No LDS staging, no barriers inside the loop, few registers and a small argument block
+// (everything the literal paths need lives in spl_count_literal_kernel): reads that need a literal decision --
+// unmapped-but-placed records and reads with a junction end that has rival sites -- are appended to a queue.
+// Reads with more than SPL_INLINE_OPS ops continue one op at a time (long-read CIGARs work, they just are not
+// the tuned case).
+template <bool STRANDED, bool AGG>
+__global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_hot_params p)
 {
     constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
     __shared__ int32_t lds[NARR * (SPL_WIN + 1)];
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_c
 
     if (live) {
         for (int it = 0; it < SPL_RPT; ++it) {
-            // Control flow is wave-uniform around every commit_run (all 64 lanes reach it).
+            // Control flow is wave-uniform around every commit_key (all 64 lanes reach it).
             const int64_t i = chunk_base + (int64_t)it * SPL_BLOCK + tid;
             bool alive = i < p.n_reads;
             int32_t pos = 0;
@@ -417,37 +419,25 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_c
             uint32_t op[SPL_INLINE_OPS];
 #pragma unroll
             for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = (alive && (uint32_t)k < n_ops) ? p.cigar[o0 + k] : 0xfu; // ---- trip 2
-            if (alive && pos < 0) { atomicOr(p.err, SPL_DEV_ERR_RANGE); alive = false; }
-            if (alive && (flag & 4u)) {
-                int64_t rl; bool hn;
-                spl_read_extent(p.cigar + o0, n_ops, &rl, &hn);
-                if ((int64_t)pos + rl > (int64_t)SPL_COORD_MAX) atomicOr(p.err, SPL_DEV_ERR_RANGE);
-                else unmapped_read<STRANDED>(p, pos, flag, p.cigar + o0, n_ops);
-                alive = false;
-            }
-            int sidx = 0;
-            if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1 : 0;
+            bool bad = alive && pos < 0;
+            bool literal = alive && !bad && (flag & 4u); // fetched as a 1-base record: literal kernel
+            alive = alive && !bad && !literal;
+            uint32_t sidx = 0;
+            if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
 
             // boundaries of the inline ops (op code 0xf = absent: not a reference-consuming op)
-            int32_t c = pos;
-            int64_t ref_len = 0;
+            const uint32_t room = (uint32_t)(SPL_COORD_MAX - (pos < 0 ? 0 : pos));
+            uint32_t len = 0;
             int32_t cend[SPL_INLINE_OPS];
             uint32_t kind[SPL_INLINE_OPS]; // 0 none, 1 aligned, 2 N, 3 D
 #pragma unroll
             for (int k = 0; k < SPL_INLINE_OPS; ++k) {
                 const uint32_t code = op[k] & 15u;
-                kind[k] = 0u;
-                cend[k] = c;
-                if (alive && ((SPL_PROG_MASK >> code) & 1u)) {
-                    const int32_t d = (int32_t)(op[k] >> 4);
-                    ref_len += d;
-                    if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { alive = false; }
-                    else {
-                        c += d;
-                        cend[k] = c;
-                        kind[k] = (code == SPL_OP_N) ? 2u : (code == SPL_OP_D ? 3u : 1u);
-                    }
-                }
+                const bool prog = alive && ((SPL_PROG_MASK >> code) & 1u);
+                len += prog ? (op[k] >> 4) : 0u;               // three lengths < 2^28: no wrap
+                if (prog && len > room) { bad = true; alive = false; }
+                cend[k] = pos + (int32_t)len;
+                kind[k] = (prog && alive) ? ((code == SPL_OP_N) ? 2u : (code == SPL_OP_D ? 3u : 1u)) : 0u;
             }
             // ---- trip 3: bucket entries of the start boundary and of every inline op end
             uint4 e0 = make_uint4(0, 0, 0, 0), ek[SPL_INLINE_OPS];
@@ -455,58 +445,51 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_c
 #pragma unroll
             for (int k = 0; k < SPL_INLINE_OPS; ++k) {
                 ek[k] = make_uint4(0, 0, 0, 0);
-                if (alive && kind[k]) ek[k] = p.dbucket[dbk_slot(p, cend[k] - 1)];
+                if (kind[k]) ek[k] = p.dbucket[dbk_slot(p, cend[k] - 1)];
             }
-            int32_t pu = 0; uint32_t pnv = 0; // rows AT the previous boundary's last base: [pu, pu + pnv)
-            if (alive) dbk_resolve(p, pos - 1, e0, pu, pnv);
-            bool need_rivals = false;
+            int32_t pu = 0; uint32_t pnv = 0; // the dpos AT the previous boundary's last base, if pnv
+            dbk_resolve(p, pos - 1, e0, pu, pnv);
+            bool rival = false;
 #pragma unroll
             for (int k = 0; k < SPL_INLINE_OPS; ++k) {
-                bool emit = false;
-                int arr = 0;
-                int32_t lo = 0, hi = 0;
-                if (alive && kind[k]) {
-                    int32_t u; uint32_t nv;
-                    dbk_resolve(p, cend[k] - 1, ek[k], u, nv);
-                    lo = pu + (int32_t)pnv; // first dpos at or after the op's first base
-                    hi = u;                 // first dpos at or after the op's last base
-                    emit = hi > lo && kind[k] != 3u;
-                    arr = (kind[k] == 2u ? (STRANDED ? 2 : 1) : 0) + sidx;
-                    if (kind[k] == 2u) {    // junction ends: lSite is the previous boundary's position, rSite this one's
-                        if (pnv) need_rivals |= rival_bit(p, pu);
-                        if (nv) need_rivals |= rival_bit(p, u);
-                    }
-                    pu = u;
-                    pnv = nv;
+                int32_t u; uint32_t nv;
+                dbk_resolve(p, cend[k] - 1, ek[k], u, nv);
+                const int32_t lo = pu + (int32_t)pnv; // first dpos at or after the op's first base
+                const bool emit = kind[k] != 0u && kind[k] != 3u && u > lo;
+                const uint32_t arr = (kind[k] == 2u ? (STRANDED ? 2u : 1u) : 0u) + sidx;
+                if (kind[k] == 2u) { // junction ends: lSite is the previous boundary's position, rSite this one's
+                    if (pnv) rival |= (p.rival_bits[(uint32_t)pu >> 5] >> ((uint32_t)pu & 31u)) & 1u;
+                    if (nv) rival |= (p.rival_bits[(uint32_t)u >> 5] >> ((uint32_t)u & 31u)) & 1u;
                 }
                 if (__any(emit)) {
-                    commit_run<NARR>(p, lds, wbase, emit, arr, lo, 1);
-                    commit_run<NARR>(p, lds, wbase, emit, arr, hi, -1);
+                    commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
+                    commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)u << 2) | arr, -1);
                 }
+                if (kind[k]) { pu = u; pnv = nv; }
             }
             // ---- reads with more ops than the inline window: one op at a time
+            int32_t c = pos + (int32_t)len;
             for (uint32_t k = SPL_INLINE_OPS; __any(alive && k < n_ops); ++k) {
                 bool emit = false;
-                int arr = 0;
+                uint32_t arr = 0;
                 int32_t lo = 0, hi = 0;
                 if (alive && k < n_ops) {
                     const uint32_t o = p.cigar[o0 + k];
                     const uint32_t code = o & 15u;
                     if ((SPL_PROG_MASK >> code) & 1u) {
-                        const int32_t d = (int32_t)(o >> 4);
-                        ref_len += d;
-                        if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) alive = false;
+                        len += o >> 4; // len <= 2^31 before, o>>4 < 2^28: no wrap
+                        if (len > room) { bad = true; alive = false; }
                         else {
-                            c += d;
+                            c = pos + (int32_t)len;
                             int32_t u; uint32_t nv;
                             dbk_resolve(p, c - 1, p.dbucket[dbk_slot(p, c - 1)], u, nv);
                             lo = pu + (int32_t)pnv;
                             hi = u;
                             emit = hi > lo && code != SPL_OP_D;
-                            arr = (code == SPL_OP_N ? (STRANDED ? 2 : 1) : 0) + sidx;
+                            arr = (code == SPL_OP_N ? (STRANDED ? 2u : 1u) : 0u) + sidx;
                             if (code == SPL_OP_N) {
-                                if (pnv) need_rivals |= rival_bit(p, pu);
-                                if (nv) need_rivals |= rival_bit(p, u);
+                                if (pnv) rival |= (p.rival_bits[(uint32_t)pu >> 5] >> ((uint32_t)pu & 31u)) & 1u;
+                                if (nv) rival |= (p.rival_bits[(uint32_t)u >> 5] >> ((uint32_t)u & 31u)) & 1u;
                             }
                             pu = u;
                             pnv = nv;
@@ -514,13 +497,12 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_c
                     }
                 }
                 if (__any(emit)) {
-                    commit_run<NARR>(p, lds, wbase, emit, arr, lo, 1);
-                    commit_run<NARR>(p, lds, wbase, emit, arr, hi, -1);
+                    commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
+                    commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)hi << 2) | arr, -1);
                 }
             }
-            if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); alive = false; }
-            if (alive && need_rivals)
-                rivals_pass<STRANDED>(p, pos, flag, p.cigar + o0, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
+            if (bad) atomicOr(p.err, SPL_DEV_ERR_RANGE);
+            if (literal || (alive && rival)) p.queue[atomicAdd(p.queue_n, 1u)] = (uint32_t)i;
         }
     }
     __syncthreads();
@@ -530,6 +512,137 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_c
             const int arr = j / (SPL_WIN + 1), loc = j - arr * (SPL_WIN + 1);
             atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + wbase + loc], v);
         }
+    }
+}
+
+namespace {
+
+// Rivals of a read with exactly ONE N op and at most four aligned blocks (every short spliced read) in closed form:
+// with a single junction (l, r) compSplicing is one membership test and the if/elif chain (:516-559) has four
+// possible outcomes per rival t.  Returns false (nothing done) when the read does not fit; the caller then takes
+// the general walk.
+template <bool STRANDED>
+__device__ __forceinline__ bool rivals_single_junction(const spl_count_params &p, int32_t pos, uint32_t flag,
+                                                       const uint32_t *ops, uint32_t n_ops)
+{
+    int32_t blk_a[4], blk_b[4];
+    int n_blk = 0, n_n = 0;
+    int32_t l = 0, r = 0, cur = pos;
+    int64_t ref_len = 0;
+    for (uint32_t k = 0; k < n_ops; ++k) {
+        const uint32_t op = ops[k];
+        const uint32_t code = op & 15u;
+        if (!((SPL_PROG_MASK >> code) & 1u)) continue;
+        const int32_t d = (int32_t)(op >> 4);
+        const int32_t start = cur;
+        cur += d;
+        ref_len += d;
+        if (code == SPL_OP_N) { ++n_n; l = start - 1; r = cur - 1; }
+        else if (code != SPL_OP_D && d >= 2) { // an aligned block can hold t and t+1
+            if (n_blk == 4) return false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (j == n_blk) { blk_a[j] = start; blk_b[j] = cur - 1; }
+            ++n_blk;
+        }
+    }
+    if (n_n != 1) return false;
+    const int32_t end_fetch = (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1);
+    // rows at the two junction ends
+    int32_t row0[2], row1[2];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int32_t x = side ? r : l;
+        int32_t u; uint32_t nv;
+        dbk_resolve(p, x, p.dbucket[dbk_slot(p, x)], u, nv);
+        row0[side] = row1[side] = 0;
+        if (nv) { row0[side] = p.dpos_first_row[u]; row1[side] = p.dpos_first_row[u + 1]; }
+        if (row1[side] - row0[side] > 2) return false;
+    }
+    uint8_t rstrand = 0;
+    if (STRANDED) rstrand = spl_read_strand(flag, p.stranded);
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        if (side == 1 && l == r) break; // 0N: both ends are the same rows
+        for (int32_t row = row0[side]; row < row1[side]; ++row) {
+            const uint4 m = p.site_meta[row];
+            for (uint32_t e = 0; e < m.y; ++e) {
+                const int32_t t = p.part_pos[m.x + e];
+                if (t < pos || t > end_fetch) continue;
+                const bool alpha = (t == l) || (t == r);
+                const bool inside = (t > l) && (t < r);
+                bool cov = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cov |= (j < n_blk) && (blk_a[j] <= t) && (t + 1 <= blk_b[j]);
+                if (!(alpha || inside || cov)) continue; // no counter can change for this site
+                const int32_t trow = p.part_site[m.x + e];
+                if (trow < 0) continue;
+                const uint4 mt = p.site_meta[trow];
+                if (mt.w == 0u) continue;
+                const int32_t *part = p.part_pos + mt.x;
+                const int32_t *comp = p.comp_pos + mt.z;
+                const bool in_l = spl_contains(part, mt.y, l), in_r = spl_contains(part, mt.y, r);
+                const bool comp_spl = (in_l && spl_contains(comp, mt.w, r)) || (in_r && spl_contains(comp, mt.w, l)); // :494-501
+                if (!comp_spl) continue;
+                if (side == 1 && in_l) continue; // already met from the lSite rows
+                if (row > row0[side]) {           // listed by the previous row at this position too?
+                    const uint4 m2 = p.site_meta[row - 1];
+                    bool dup = false;
+                    for (uint32_t e2 = 0; e2 < m2.y; ++e2) dup |= (p.part_site[m2.x + e2] == trow);
+                    if (dup) continue;
+                }
+                bool dup_edge = false;
+                for (uint32_t e2 = 0; e2 < e; ++e2) dup_edge |= (p.part_site[m.x + e2] == trow);
+                if (dup_edge) continue;
+                bool strand_ok = true;
+                if (STRANDED) strand_ok = (p.site_strand[trow] == rstrand);
+                const bool beta1 = cov && strand_ok;
+                // what the ranges counted (compSplicing false): ME (:507-512) else beta1 (:558)
+                if (!alpha && inside && strand_ok) atomicAdd(&p.beta2s_reads[trow], 0xffffffffu);
+                else if (beta1) atomicAdd(&p.beta1[trow], 0xffffffffu);
+                // the literal outcome with compSplicing true
+                if (alpha) { // :519-527
+                    int32_t pu = 0;
+                    if (l == t) pu = r;
+                    if (r == t) pu = l;
+                    for (uint32_t e2 = 0; e2 < mt.y; ++e2) {
+                        const int32_t pp = part[e2];
+                        if ((pp == l || pp == r) && pp != pu) atomicAdd(&p.dbl[mt.x + e2], 1u);
+                    }
+                } else if (inside) { // flanking, :529-536
+                    if (p.combine_mode) atomicAdd(&p.beta2s_reads[trow], 1u);
+                } else if (beta1) { // beta1-type, :544-556
+                    for (uint32_t e2 = 0; e2 < mt.y; ++e2) {
+                        const int32_t pp = part[e2];
+                        if (pp == l || pp == r) atomicAdd(&p.dbl[mt.x + e2], 1u);
+                    }
+                    atomicAdd(&p.beta2s_reads[trow], 1u);
+                }
+            }
+        }
+    }
+    return true;
+}
+
+} // namespace
+
+// The literal kernel: one queued read per lane (grid-stride over the queue the range kernel filled).
+template <bool STRANDED>
+__global__ __launch_bounds__(256) void spl_count_literal_kernel(const spl_count_params p, const uint32_t *queue, const uint32_t *queue_n)
+{
+    const uint32_t n = *queue_n;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        const int64_t i = queue[q];
+        const int32_t pos = p.r_pos[i];
+        const uint32_t flag = p.r_flag[i];
+        const uint32_t o0 = p.cig_off[i];
+        const uint32_t n_ops = p.cig_off[i + 1] - o0;
+        const uint32_t *ops = p.cigar + o0;
+        int64_t ref_len; bool hn;
+        spl_read_extent(ops, n_ops, &ref_len, &hn);
+        if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
+        if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
+        if (rivals_single_junction<STRANDED>(p, pos, flag, ops, n_ops)) continue;
+        rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
     }
 }
 
@@ -668,7 +781,7 @@ __global__ __launch_bounds__(256) void spl_sse_kernel(const spl_sse_params p)
 
 // ---- launchers (called from spl_capi.cpp through spl_device.h) ------------------------------------------
 
-extern "C" int spl_dev_launch_count(const spl_count_params *p, int variant, void *stream, int *grid_out, int *lds_out)
+extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out)
 {
     *grid_out = 0;
     *lds_out = 0;
@@ -683,9 +796,24 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, int variant, void
         else hipLaunchKernelGGL(spl_count_pairs_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
     } else {
         *lds_out = (p->stranded ? 4 : 2) * (SPL_WIN + 1) * 4 + 4;
-        if (p->stranded) hipLaunchKernelGGL(spl_count_ranges_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
-        else hipLaunchKernelGGL(spl_count_ranges_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
+        const bool agg = !(variant & 2);
+        if (p->stranded) {
+            if (agg) hipLaunchKernelGGL((spl_count_ranges_kernel<true, true>), dim3(grid), dim3(SPL_BLOCK), 0, st, *h);
+            else hipLaunchKernelGGL((spl_count_ranges_kernel<true, false>), dim3(grid), dim3(SPL_BLOCK), 0, st, *h);
+        } else {
+            if (agg) hipLaunchKernelGGL((spl_count_ranges_kernel<false, true>), dim3(grid), dim3(SPL_BLOCK), 0, st, *h);
+            else hipLaunchKernelGGL((spl_count_ranges_kernel<false, false>), dim3(grid), dim3(SPL_BLOCK), 0, st, *h);
+        }
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, void *stream)
+{
+    if (p->n_reads <= 0 || p->n_sites <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(SPL_LITERAL_GRID), dim3(256), 0, st, *p, queue, queue_n);
+    else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(SPL_LITERAL_GRID), dim3(256), 0, st, *p, queue, queue_n);
     return (int)hipGetLastError();
 }
 
