@@ -122,6 +122,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ctx.kernel_timing_collect(args.steps * len(dev) + 8)
+    literal_reads = sum(dr.literal_queue_size() for _, dr in dev) if args.kernel != "pairs" else None
     info = ctx.launch_info()
 
     tot_reads, tot_sites = float(n_reads), float(n_sites)
@@ -204,6 +205,7 @@ def main():
                          "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"]},
             "cpu_baseline": cpu,
             "parity": parity,
+            "literal_kernel_reads": literal_reads,
             "gen_seconds": t_gen,
         }
         print(json.dumps(out))

@@ -152,6 +152,9 @@ int spl_sse_download(spl_ctx *ctx, const spl_dsites *ds, int64_t *beta2_simple,
 /* Bytes the classification kernel must move at minimum for (ds, dr): each input once, each output
  * once -- the numerator of bench.py's roofline.achieved. */
 int spl_count_algorithmic_bytes(const spl_dsites *ds, const spl_dreads *dr, int64_t *bytes_out);
+/* Reads the last range-kernel launch on dr handed to the literal kernel (unmapped-but-placed records and reads
+ * whose junction ends have rival sites); synchronises.  Diagnostic. */
+int spl_literal_queue_size(spl_ctx *ctx, const spl_dreads *dr, int64_t *n_out);
 /* Launch geometry of the last spl_count_launch on this context (for DESIGN.md / profiles). */
 int spl_last_launch_info(const spl_ctx *ctx, int32_t *grid_out, int32_t *block_out, int32_t *lds_bytes_out);
 

@@ -394,7 +394,8 @@ extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     const size_t o_pos = take(4 * R), o_flag = take(2 * R), o_off = take(4 * (R + 1)), o_cig = take(4 * G);
-    const size_t o_queue = take(4 * R), o_qn = take(4);
+    const size_t n_chunks = (size_t)((R + SPL_CHUNK - 1) / SPL_CHUNK);
+    const size_t o_queue = take(4 * n_chunks * SPL_CHUNK), o_qn = take(4 * (n_chunks + 1));
     hipError_t e = hipMalloc((void **)&d->slab, std::max<size_t>(off, 256));
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the read set: %s", off, hipGetErrorString(e)); }
     d->pos = (int32_t *)(d->slab + o_pos); d->flag = (uint16_t *)(d->slab + o_flag);
@@ -448,7 +449,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.rival_bits = p.rival_bits;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = dr->queue; h.queue_n = dr->queue_n; h.err = c->d_err;
-    HIP_TRY(hipMemsetAsync(dr->queue_n, 0, sizeof(uint32_t), c->stream));
+
     p.bucket = ds->bucket; p.n_buckets = ds->n_buckets; p.bucket_base = ds->bucket_base; p.bucket_shift = ds->bucket_shift;
     p.stranded = o->stranded; p.combine_mode = o->combine_mode ? 1 : 0;
     p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = c->d_err;
@@ -535,6 +536,22 @@ extern "C" int spl_count_algorithmic_bytes(const spl_dsites *ds, const spl_dread
     // every input once, every output once.
     const int64_t R = dr->n_reads, G = dr->n_cigar, S = ds->n_sites, P = ds->n_part, C = ds->n_comp;
     *out = R * (4 + 2 + 4) + 4 * G + S * (4 + 1 + 8) + 4 * (P + C) + S * 8 + 4 * P;
+    return SPL_OK;
+}
+
+extern "C" int spl_literal_queue_size(spl_ctx *c, const spl_dreads *dr, int64_t *n_out)
+{
+    if (!c || !dr || !n_out) return spl_set_error(SPL_ERR_ARG, "spl_literal_queue_size: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n_chunks = (size_t)((dr->n_reads + SPL_CHUNK - 1) / SPL_CHUNK);
+    std::vector<uint32_t> counts(n_chunks);
+    if (n_chunks) {
+        HIP_TRY(hipMemcpyAsync(counts.data(), dr->queue_n, 4 * n_chunks, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    int64_t total = 0;
+    for (uint32_t v : counts) total += v;
+    *n_out = total;
     return SPL_OK;
 }
 

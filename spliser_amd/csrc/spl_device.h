@@ -82,8 +82,8 @@ struct spl_hot_params {
     int32_t stranded;
     int32_t *diff;
     int32_t diff_stride;
-    uint32_t *queue;             // reads handed to spl_count_literal_kernel
-    uint32_t *queue_n;
+    uint32_t *queue;             // reads handed to spl_count_literal_kernel: SPL_CHUNK slots per chunk
+    uint32_t *queue_n;           // [n_chunks] entries used per chunk
     int32_t *err;
 };
 

@@ -387,6 +387,8 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
 {
     constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
     __shared__ int32_t lds[NARR * (SPL_WIN + 1)];
+    __shared__ uint32_t s_q[SPL_CHUNK]; // this chunk's reads for the literal kernel (chunk-relative index)
+    __shared__ uint32_t s_qn;
     __shared__ int32_t s_wbase;
 
     const int tid = threadIdx.x;
@@ -399,6 +401,7 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
         int32_t u = 0; uint32_t nv = 0;
         if (live) { const int32_t x = p.r_pos[chunk_base] - 1; dbk_resolve(p, x, p.dbucket[dbk_slot(p, x)], u, nv); }
         s_wbase = u;
+        s_qn = 0u;
     }
     __syncthreads();
     const int32_t wbase = s_wbase;
@@ -502,10 +505,15 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
                 }
             }
             if (bad) atomicOr(p.err, SPL_DEV_ERR_RANGE);
-            if (literal || (alive && rival)) p.queue[atomicAdd(p.queue_n, 1u)] = (uint32_t)i;
+            if (literal || (alive && rival)) s_q[atomicAdd(&s_qn, 1u)] = (uint32_t)(it * SPL_BLOCK + tid);
         }
     }
     __syncthreads();
+    if (live) { // the queue needs no global atomics: every chunk owns SPL_CHUNK slots and publishes its count
+        const uint32_t qn = s_qn;
+        for (uint32_t j = tid; j < qn; j += SPL_BLOCK) p.queue[chunk_base + j] = s_q[j];
+        if (tid == 0) p.queue_n[chunk] = qn;
+    }
     for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) {
         const int32_t v = lds[j];
         if (v) {
@@ -516,6 +524,27 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
 }
 
 namespace {
+
+// atomicAdd(addr, delta) with delta = +1 or -1, merged over the lanes of the wave that are executing it right now
+// and target the same word: one atomic per distinct address instead of one per lane.
+__device__ __forceinline__ void agg_add(uint32_t *addr, int32_t delta)
+{
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned long long todo = __ballot(1);
+    const uint32_t lo = (uint32_t)(uintptr_t)addr, hi = (uint32_t)((uintptr_t)addr >> 32);
+    for (;;) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const bool same = (__shfl((int)lo, leader) == (int)lo) && (__shfl((int)hi, leader) == (int)hi);
+        const unsigned long long grp = __ballot(same);
+        const unsigned long long plus = __ballot(same && delta > 0);
+        if (lane == leader) {
+            const int32_t sum = 2 * (int32_t)__popcll(plus) - (int32_t)__popcll(grp);
+            if (sum) atomicAdd(addr, (uint32_t)sum);
+        }
+        if (same) break;
+        todo &= ~grp;
+    }
+}
 
 // Rivals of a read with exactly ONE N op and at most four aligned blocks (every short spliced read) in closed form:
 // with a single junction (l, r) compSplicing is one membership test and the if/elif chain (:516-559) has four
@@ -597,8 +626,8 @@ __device__ __forceinline__ bool rivals_single_junction(const spl_count_params &p
                 if (STRANDED) strand_ok = (p.site_strand[trow] == rstrand);
                 const bool beta1 = cov && strand_ok;
                 // what the ranges counted (compSplicing false): ME (:507-512) else beta1 (:558)
-                if (!alpha && inside && strand_ok) atomicAdd(&p.beta2s_reads[trow], 0xffffffffu);
-                else if (beta1) atomicAdd(&p.beta1[trow], 0xffffffffu);
+                if (!alpha && inside && strand_ok) agg_add(&p.beta2s_reads[trow], -1);
+                else if (beta1) agg_add(&p.beta1[trow], -1);
                 // the literal outcome with compSplicing true
                 if (alpha) { // :519-527
                     int32_t pu = 0;
@@ -606,16 +635,16 @@ __device__ __forceinline__ bool rivals_single_junction(const spl_count_params &p
                     if (r == t) pu = l;
                     for (uint32_t e2 = 0; e2 < mt.y; ++e2) {
                         const int32_t pp = part[e2];
-                        if ((pp == l || pp == r) && pp != pu) atomicAdd(&p.dbl[mt.x + e2], 1u);
+                        if ((pp == l || pp == r) && pp != pu) agg_add(&p.dbl[mt.x + e2], 1);
                     }
                 } else if (inside) { // flanking, :529-536
-                    if (p.combine_mode) atomicAdd(&p.beta2s_reads[trow], 1u);
+                    if (p.combine_mode) agg_add(&p.beta2s_reads[trow], 1);
                 } else if (beta1) { // beta1-type, :544-556
                     for (uint32_t e2 = 0; e2 < mt.y; ++e2) {
                         const int32_t pp = part[e2];
-                        if (pp == l || pp == r) atomicAdd(&p.dbl[mt.x + e2], 1u);
+                        if (pp == l || pp == r) agg_add(&p.dbl[mt.x + e2], 1);
                     }
-                    atomicAdd(&p.beta2s_reads[trow], 1u);
+                    agg_add(&p.beta2s_reads[trow], 1);
                 }
             }
         }
@@ -625,24 +654,33 @@ __device__ __forceinline__ bool rivals_single_junction(const spl_count_params &p
 
 } // namespace
 
-// The literal kernel: one queued read per lane (grid-stride over the queue the range kernel filled).
+// The literal kernel: one wave per chunk queue, one queued read per lane.  Neighbouring lanes hold neighbouring
+// reads, which in coordinate-sorted input cross the same junction and therefore update the same counters: those
+// updates are merged across the wave before they reach HBM (agg_add), because one counter word takes only so many
+// atomics per microsecond no matter how many CUs send them.
 template <bool STRANDED>
 __global__ __launch_bounds__(256) void spl_count_literal_kernel(const spl_count_params p, const uint32_t *queue, const uint32_t *queue_n)
 {
-    const uint32_t n = *queue_n;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
-        const int64_t i = queue[q];
-        const int32_t pos = p.r_pos[i];
-        const uint32_t flag = p.r_flag[i];
-        const uint32_t o0 = p.cig_off[i];
-        const uint32_t n_ops = p.cig_off[i + 1] - o0;
-        const uint32_t *ops = p.cigar + o0;
-        int64_t ref_len; bool hn;
-        spl_read_extent(ops, n_ops, &ref_len, &hn);
-        if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
-        if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
-        if (rivals_single_junction<STRANDED>(p, pos, flag, ops, n_ops)) continue;
-        rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t chunk = wave; chunk < p.n_chunks; chunk += n_waves) {
+        const uint32_t n = queue_n[chunk];
+        const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
+        for (uint32_t j = lane; j < n; j += 64u) {
+            const int64_t i = chunk_base + queue[chunk_base + j];
+            const int32_t pos = p.r_pos[i];
+            const uint32_t flag = p.r_flag[i];
+            const uint32_t o0 = p.cig_off[i];
+            const uint32_t n_ops = p.cig_off[i + 1] - o0;
+            const uint32_t *ops = p.cigar + o0;
+            int64_t ref_len; bool hn;
+            spl_read_extent(ops, n_ops, &ref_len, &hn);
+            if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
+            if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
+            if (rivals_single_junction<STRANDED>(p, pos, flag, ops, n_ops)) continue;
+            rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
+        }
     }
 }
 
@@ -812,8 +850,11 @@ extern "C" int spl_dev_launch_literal(const spl_count_params *p, const uint32_t 
 {
     if (p->n_reads <= 0 || p->n_sites <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(SPL_LITERAL_GRID), dim3(256), 0, st, *p, queue, queue_n);
-    else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(SPL_LITERAL_GRID), dim3(256), 0, st, *p, queue, queue_n);
+    // one wave per chunk queue, at most SPL_LITERAL_GRID workgroups
+    uint32_t grid = (p->n_chunks + 3u) / 4u;
+    if (grid > (uint32_t)SPL_LITERAL_GRID) grid = SPL_LITERAL_GRID;
+    if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(grid), dim3(256), 0, st, *p, queue, queue_n);
+    else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(grid), dim3(256), 0, st, *p, queue, queue_n);
     return (int)hipGetLastError();
 }
 

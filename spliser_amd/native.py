@@ -47,7 +47,7 @@ EXPORTS = [
     "spl_abi_version", "spl_last_error", "spl_device_count", "spl_create", "spl_create_on_stream", "spl_destroy",
     "spl_sync", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
-    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_last_launch_info", "spl_bam_open", "spl_bam_close",
+    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads",
 ]
 
@@ -266,6 +266,11 @@ class DeviceSites(object):
 class DeviceReads(object):
     def __init__(self, ctx, h, n):
         self.ctx, self._h, self.n = ctx, h, n
+
+    def literal_queue_size(self):
+        out = ctypes.c_int64(0)
+        _check(lib().spl_literal_queue_size(self.ctx._h, self._h, ctypes.byref(out)))
+        return out.value
 
     def free(self):
         if self._h:
