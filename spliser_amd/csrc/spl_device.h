@@ -13,7 +13,6 @@
 #define SPL_INLINE_OPS 3                 // CIGAR ops per read resolved in the straight-line part (M N M = 3)
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
 #define SPL_SCAN_BLOCK 1024              // distinct positions per workgroup in the difference-array scan
-#define SPL_LITERAL_GRID 2048            // workgroups of the literal kernel (grid-stride over its queue)
 
 // Coordinates (read end, site position) must stay <= SPL_COORD_MAX so that t+1 and cur never wrap int32.
 #define SPL_COORD_MAX 2147483645

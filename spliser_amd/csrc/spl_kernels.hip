@@ -546,17 +546,20 @@ __device__ __forceinline__ void agg_add(uint32_t *addr, int32_t delta)
     }
 }
 
-// Rivals of a read with exactly ONE N op and at most four aligned blocks (every short spliced read) in closed form:
-// with a single junction (l, r) compSplicing is one membership test and the if/elif chain (:516-559) has four
-// possible outcomes per rival t.  Returns false (nothing done) when the read does not fit; the caller then takes
-// the general walk.
+// Rivals of a short read (at most SPL_CF_JUNC N ops and SPL_CF_BLK aligned blocks: every short-read CIGAR) in closed
+// form.  With the read's junctions (l_j, r_j) and aligned blocks in registers, the CIGAR walk of checkBam for a rival
+// site t collapses to: alpha/comp prefix flags per junction, "t strictly inside junction j", "a block covers t and
+// t+1" -- evaluated in junction order so that the stickiness of compSplicing and alpha_read (:487-512) is kept.
+// Returns false (nothing done) when the read does not fit; the caller then takes the general walk.
+#define SPL_CF_JUNC 4
+#define SPL_CF_BLK 5
 template <bool STRANDED>
-__device__ __forceinline__ bool rivals_single_junction(const spl_count_params &p, int32_t pos, uint32_t flag,
-                                                       const uint32_t *ops, uint32_t n_ops)
+__device__ __forceinline__ bool rivals_closed_form(const spl_count_params &p, int32_t pos, uint32_t flag,
+                                                   const uint32_t *ops, uint32_t n_ops)
 {
-    int32_t blk_a[4], blk_b[4];
-    int n_blk = 0, n_n = 0;
-    int32_t l = 0, r = 0, cur = pos;
+    int32_t blk_a[SPL_CF_BLK], blk_b[SPL_CF_BLK], jl[SPL_CF_JUNC], jr[SPL_CF_JUNC];
+    int n_blk = 0, n_j = 0;
+    int32_t cur = pos;
     int64_t ref_len = 0;
     for (uint32_t k = 0; k < n_ops; ++k) {
         const uint32_t op = ops[k];
@@ -566,54 +569,66 @@ __device__ __forceinline__ bool rivals_single_junction(const spl_count_params &p
         const int32_t start = cur;
         cur += d;
         ref_len += d;
-        if (code == SPL_OP_N) { ++n_n; l = start - 1; r = cur - 1; }
-        else if (code != SPL_OP_D && d >= 2) { // an aligned block can hold t and t+1
-            if (n_blk == 4) return false;
+        if (code == SPL_OP_N) {
+            if (n_j == SPL_CF_JUNC) return false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (j == n_blk) { blk_a[j] = start; blk_b[j] = cur - 1; }
+            for (int j = 0; j < SPL_CF_JUNC; ++j) if (j == n_j) { jl[j] = start - 1; jr[j] = cur - 1; }
+            ++n_j;
+        } else if (code != SPL_OP_D && d >= 2) { // an aligned block that can hold t and t+1
+            if (n_blk == SPL_CF_BLK) return false;
+#pragma unroll
+            for (int j = 0; j < SPL_CF_BLK; ++j) if (j == n_blk) { blk_a[j] = start; blk_b[j] = cur - 1; }
             ++n_blk;
         }
     }
-    if (n_n != 1) return false;
+    if (n_j == 0) return true; // no junction: nothing can set compSplicing
     const int32_t end_fetch = (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1);
-    // rows at the two junction ends
-    int32_t row0[2], row1[2];
+    // rows at the junction ends, in checkBam's order lSite_1, rSite_1, lSite_2, ...
+    int32_t row0[2 * SPL_CF_JUNC], row1[2 * SPL_CF_JUNC];
 #pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const int32_t x = side ? r : l;
-        int32_t u; uint32_t nv;
-        dbk_resolve(p, x, p.dbucket[dbk_slot(p, x)], u, nv);
-        row0[side] = row1[side] = 0;
-        if (nv) { row0[side] = p.dpos_first_row[u]; row1[side] = p.dpos_first_row[u + 1]; }
-        if (row1[side] - row0[side] > 2) return false;
+    for (int q = 0; q < 2 * SPL_CF_JUNC; ++q) {
+        row0[q] = row1[q] = 0;
+        if (q < 2 * n_j) {
+            const int32_t x = (q & 1) ? jr[q >> 1] : jl[q >> 1];
+            int32_t u; uint32_t nv;
+            dbk_resolve(p, x, p.dbucket[dbk_slot(p, x)], u, nv);
+            if (nv) { row0[q] = p.dpos_first_row[u]; row1[q] = p.dpos_first_row[u + 1]; }
+            if (row1[q] - row0[q] > 2) return false;
+        }
     }
     uint8_t rstrand = 0;
     if (STRANDED) rstrand = spl_read_strand(flag, p.stranded);
 #pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        if (side == 1 && l == r) break; // 0N: both ends are the same rows
-        for (int32_t row = row0[side]; row < row1[side]; ++row) {
+    for (int q = 0; q < 2 * SPL_CF_JUNC; ++q) {
+        if (q >= 2 * n_j) break;
+        const int32_t x = (q & 1) ? jr[q >> 1] : jl[q >> 1];
+        bool repeat = false; // the same position earlier in the list (0N, back-to-back N ops): rows already done
+#pragma unroll
+        for (int q2 = 0; q2 < q; ++q2) repeat |= (((q2 & 1) ? jr[q2 >> 1] : jl[q2 >> 1]) == x);
+        if (repeat) continue;
+        for (int32_t row = row0[q]; row < row1[q]; ++row) {
             const uint4 m = p.site_meta[row];
             for (uint32_t e = 0; e < m.y; ++e) {
                 const int32_t t = p.part_pos[m.x + e];
                 if (t < pos || t > end_fetch) continue;
-                const bool alpha = (t == l) || (t == r);
-                const bool inside = (t > l) && (t < r);
+                bool touches = false;
+#pragma unroll
+                for (int j = 0; j < SPL_CF_JUNC; ++j) touches |= (j < n_j) && (t >= jl[j]) && (t <= jr[j]);
                 bool cov = false;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cov |= (j < n_blk) && (blk_a[j] <= t) && (t + 1 <= blk_b[j]);
-                if (!(alpha || inside || cov)) continue; // no counter can change for this site
+                for (int j = 0; j < SPL_CF_BLK; ++j) cov |= (j < n_blk) && (blk_a[j] <= t) && (t + 1 <= blk_b[j]);
+                if (!(touches || cov)) continue; // neither alpha, inside an intron nor beta1: no counter can change
                 const int32_t trow = p.part_site[m.x + e];
                 if (trow < 0) continue;
                 const uint4 mt = p.site_meta[trow];
                 if (mt.w == 0u) continue;
                 const int32_t *part = p.part_pos + mt.x;
                 const int32_t *comp = p.comp_pos + mt.z;
-                const bool in_l = spl_contains(part, mt.y, l), in_r = spl_contains(part, mt.y, r);
-                const bool comp_spl = (in_l && spl_contains(comp, mt.w, r)) || (in_r && spl_contains(comp, mt.w, l)); // :494-501
-                if (!comp_spl) continue;
-                if (side == 1 && in_l) continue; // already met from the lSite rows
-                if (row > row0[side]) {           // listed by the previous row at this position too?
+                bool seen = false; // reachable from an earlier junction end: handled there
+#pragma unroll
+                for (int q2 = 0; q2 < q; ++q2) seen |= spl_contains(part, mt.y, (q2 & 1) ? jr[q2 >> 1] : jl[q2 >> 1]);
+                if (seen) continue;
+                if (row > row0[q]) { // listed by the previous row at this position too?
                     const uint4 m2 = p.site_meta[row - 1];
                     bool dup = false;
                     for (uint32_t e2 = 0; e2 < m2.y; ++e2) dup |= (p.part_site[m2.x + e2] == trow);
@@ -624,27 +639,43 @@ __device__ __forceinline__ bool rivals_single_junction(const spl_count_params &p
                 if (dup_edge) continue;
                 bool strand_ok = true;
                 if (STRANDED) strand_ok = (p.site_strand[trow] == rstrand);
+                // the CIGAR walk, junction by junction (:480-512)
+                bool alpha = false, comp_spl = false, flank = false, me = false, me_base = false, has_pu = false;
+                int32_t pu = 0;
+#pragma unroll
+                for (int j = 0; j < SPL_CF_JUNC; ++j) {
+                    if (j >= n_j) break;
+                    const int32_t l = jl[j], r = jr[j];
+                    if (l == t) { pu = r; has_pu = true; alpha = true; }
+                    if (r == t) { pu = l; has_pu = true; alpha = true; }
+                    if (spl_contains(comp, mt.w, r) && spl_contains(part, mt.y, l)) comp_spl = true;
+                    if (spl_contains(comp, mt.w, l) && spl_contains(part, mt.y, r)) comp_spl = true;
+                    const bool inside = (t > l) && (t < r);
+                    if (comp_spl && inside) flank = true;
+                    if (!alpha && !comp_spl && inside && strand_ok) me = true;
+                    if (!alpha && inside && strand_ok) me_base = true; // what the ranges assumed: compSplicing false
+                }
+                if (!comp_spl) continue; // the ranges were right
                 const bool beta1 = cov && strand_ok;
-                // what the ranges counted (compSplicing false): ME (:507-512) else beta1 (:558)
-                if (!alpha && inside && strand_ok) agg_add(&p.beta2s_reads[trow], -1);
-                else if (beta1) agg_add(&p.beta1[trow], -1);
-                // the literal outcome with compSplicing true
-                if (alpha) { // :519-527
-                    int32_t pu = 0;
-                    if (l == t) pu = r;
-                    if (r == t) pu = l;
-                    for (uint32_t e2 = 0; e2 < mt.y; ++e2) {
+                const int base = me_base ? SPL_CLS_ME : (beta1 ? SPL_CLS_BETA1 : SPL_CLS_NONE);
+                const int full = (alpha && comp_spl) ? SPL_CLS_ALPHA_COMP : flank ? SPL_CLS_FLANK : me ? SPL_CLS_ME
+                                 : beta1 ? SPL_CLS_B1TYPE : SPL_CLS_NONE;
+                if (full == base) continue;
+                if (base == SPL_CLS_ME) agg_add(&p.beta2s_reads[trow], -1);
+                else if (base == SPL_CLS_BETA1) agg_add(&p.beta1[trow], -1);
+                if (full == SPL_CLS_ME) agg_add(&p.beta2s_reads[trow], 1);
+                else if (full == SPL_CLS_FLANK) { if (p.combine_mode) agg_add(&p.beta2s_reads[trow], 1); }
+                else if (full == SPL_CLS_B1TYPE || full == SPL_CLS_ALPHA_COMP) {
+                    if (full == SPL_CLS_B1TYPE) agg_add(&p.beta2s_reads[trow], 1);
+                    for (uint32_t e2 = 0; e2 < mt.y; ++e2) { // set(partners) & set(spliceSites) (:519-527, :544-551)
                         const int32_t pp = part[e2];
-                        if ((pp == l || pp == r) && pp != pu) agg_add(&p.dbl[mt.x + e2], 1);
+                        bool is_end = false;
+#pragma unroll
+                        for (int j = 0; j < SPL_CF_JUNC; ++j) is_end |= (j < n_j) && (pp == jl[j] || pp == jr[j]);
+                        if (!is_end) continue;
+                        if (full == SPL_CLS_ALPHA_COMP && has_pu && pp == pu) continue;
+                        agg_add(&p.dbl[mt.x + e2], 1);
                     }
-                } else if (inside) { // flanking, :529-536
-                    if (p.combine_mode) agg_add(&p.beta2s_reads[trow], 1);
-                } else if (beta1) { // beta1-type, :544-556
-                    for (uint32_t e2 = 0; e2 < mt.y; ++e2) {
-                        const int32_t pp = part[e2];
-                        if (pp == l || pp == r) agg_add(&p.dbl[mt.x + e2], 1);
-                    }
-                    agg_add(&p.beta2s_reads[trow], 1);
                 }
             }
         }
@@ -654,34 +685,31 @@ __device__ __forceinline__ bool rivals_single_junction(const spl_count_params &p
 
 } // namespace
 
-// The literal kernel: one wave per chunk queue, one queued read per lane.  Neighbouring lanes hold neighbouring
-// reads, which in coordinate-sorted input cross the same junction and therefore update the same counters: those
-// updates are merged across the wave before they reach HBM (agg_add), because one counter word takes only so many
-// atomics per microsecond no matter how many CUs send them.
+// The literal kernel: one thread per queue SLOT (SPL_CHUNK slots per chunk, the used ones first), so the hardware
+// dispatcher balances chunks with long and short queues; workgroups over unused slots exit at once.  Neighbouring
+// lanes hold neighbouring reads, which in coordinate-sorted input cross the same junction and therefore update the
+// same counters: those updates are merged across the wave before they reach HBM (agg_add), because one counter word
+// takes only so many atomics per microsecond no matter how many CUs send them.
 template <bool STRANDED>
 __global__ __launch_bounds__(256) void spl_count_literal_kernel(const spl_count_params p, const uint32_t *queue, const uint32_t *queue_n)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t chunk = wave; chunk < p.n_chunks; chunk += n_waves) {
-        const uint32_t n = queue_n[chunk];
-        const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
-        for (uint32_t j = lane; j < n; j += 64u) {
-            const int64_t i = chunk_base + queue[chunk_base + j];
-            const int32_t pos = p.r_pos[i];
-            const uint32_t flag = p.r_flag[i];
-            const uint32_t o0 = p.cig_off[i];
-            const uint32_t n_ops = p.cig_off[i + 1] - o0;
-            const uint32_t *ops = p.cigar + o0;
-            int64_t ref_len; bool hn;
-            spl_read_extent(ops, n_ops, &ref_len, &hn);
-            if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
-            if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
-            if (rivals_single_junction<STRANDED>(p, pos, flag, ops, n_ops)) continue;
-            rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
-        }
-    }
+    constexpr uint32_t BPC = SPL_CHUNK / 256; // workgroups per chunk
+    const uint32_t chunk = blockIdx.x / BPC;
+    const uint32_t slot = (blockIdx.x % BPC) * 256u + threadIdx.x;
+    if (slot >= queue_n[chunk]) return;
+    const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
+    const int64_t i = chunk_base + queue[chunk_base + slot];
+    const int32_t pos = p.r_pos[i];
+    const uint32_t flag = p.r_flag[i];
+    const uint32_t o0 = p.cig_off[i];
+    const uint32_t n_ops = p.cig_off[i + 1] - o0;
+    const uint32_t *ops = p.cigar + o0;
+    int64_t ref_len; bool hn;
+    spl_read_extent(ops, n_ops, &ref_len, &hn);
+    if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); return; }
+    if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); return; }
+    if (rivals_closed_form<STRANDED>(p, pos, flag, ops, n_ops)) return;
+    rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
 }
 
 // =========================================================================================================
@@ -850,9 +878,7 @@ extern "C" int spl_dev_launch_literal(const spl_count_params *p, const uint32_t 
 {
     if (p->n_reads <= 0 || p->n_sites <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    // one wave per chunk queue, at most SPL_LITERAL_GRID workgroups
-    uint32_t grid = (p->n_chunks + 3u) / 4u;
-    if (grid > (uint32_t)SPL_LITERAL_GRID) grid = SPL_LITERAL_GRID;
+    const uint32_t grid = p->n_chunks * (SPL_CHUNK / 256); // one thread per queue slot
     if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(grid), dim3(256), 0, st, *p, queue, queue_n);
     else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(grid), dim3(256), 0, st, *p, queue, queue_n);
     return (int)hipGetLastError();
