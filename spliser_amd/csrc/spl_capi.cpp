@@ -454,6 +454,9 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.stranded = o->stranded; p.combine_mode = o->combine_mode ? 1 : 0;
     p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = c->d_err;
     // range kernel whenever the table allows it; the literal pair kernel otherwise or on request
+    static int dbg_state = 0;
+    const int dbg_want = (o->flags >> 8) & 1;
+    if (dbg_want != dbg_state) { spl_dev_set_debug(dbg_want); dbg_state = dbg_want; }
     const int variant = (!ds->mutual_links || (o->flags & SPL_OPT_PAIR_KERNEL)) ? 1 : ((o->flags & SPL_OPT_NO_WAVE_AGGREGATION) ? 2 : 0);
     int grid = 0, lds = 0;
     const bool timed = c->k_on && (size_t)(2 * c->k_used + 1) < c->k_ev.size();

@@ -124,6 +124,7 @@ extern "C" {
 // wave-level aggregation of LDS atomics (experiment)
 int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out);
 int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, void *stream);
+int spl_dev_set_debug(int no_literal_atomics);
 int spl_dev_launch_scan(const spl_scan_params *p, void *stream);
 int spl_dev_launch_sse(const spl_sse_params *p, void *stream);
 #ifdef __cplusplus

@@ -527,8 +527,11 @@ namespace {
 
 // atomicAdd(addr, delta) with delta = +1 or -1, merged over the lanes of the wave that are executing it right now
 // and target the same word: one atomic per distinct address instead of one per lane.
+__device__ int g_spl_debug_no_literal_atomics = 0; // timing experiment (SPL_OPT_DEBUG_*): results are wrong when set
+
 __device__ __forceinline__ void agg_add(uint32_t *addr, int32_t delta)
 {
+    if (g_spl_debug_no_literal_atomics) return;
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     unsigned long long todo = __ballot(1);
     const uint32_t lo = (uint32_t)(uintptr_t)addr, hi = (uint32_t)((uintptr_t)addr >> 32);
@@ -583,19 +586,6 @@ __device__ __forceinline__ bool rivals_closed_form(const spl_count_params &p, in
     }
     if (n_j == 0) return true; // no junction: nothing can set compSplicing
     const int32_t end_fetch = (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1);
-    // rows at the junction ends, in checkBam's order lSite_1, rSite_1, lSite_2, ...
-    int32_t row0[2 * SPL_CF_JUNC], row1[2 * SPL_CF_JUNC];
-#pragma unroll
-    for (int q = 0; q < 2 * SPL_CF_JUNC; ++q) {
-        row0[q] = row1[q] = 0;
-        if (q < 2 * n_j) {
-            const int32_t x = (q & 1) ? jr[q >> 1] : jl[q >> 1];
-            int32_t u; uint32_t nv;
-            dbk_resolve(p, x, p.dbucket[dbk_slot(p, x)], u, nv);
-            if (nv) { row0[q] = p.dpos_first_row[u]; row1[q] = p.dpos_first_row[u + 1]; }
-            if (row1[q] - row0[q] > 2) return false;
-        }
-    }
     uint8_t rstrand = 0;
     if (STRANDED) rstrand = spl_read_strand(flag, p.stranded);
 #pragma unroll
@@ -606,7 +596,12 @@ __device__ __forceinline__ bool rivals_closed_form(const spl_count_params &p, in
 #pragma unroll
         for (int q2 = 0; q2 < q; ++q2) repeat |= (((q2 & 1) ? jr[q2 >> 1] : jl[q2 >> 1]) == x);
         if (repeat) continue;
-        for (int32_t row = row0[q]; row < row1[q]; ++row) {
+        // rows at this junction end (checkBam's order: lSite_1, rSite_1, lSite_2, ...)
+        int32_t xu; uint32_t xnv;
+        dbk_resolve(p, x, p.dbucket[dbk_slot(p, x)], xu, xnv);
+        if (!xnv) continue;
+        const int32_t row_first = p.dpos_first_row[xu], row_end = p.dpos_first_row[xu + 1];
+        for (int32_t row = row_first; row < row_end; ++row) {
             const uint4 m = p.site_meta[row];
             for (uint32_t e = 0; e < m.y; ++e) {
                 const int32_t t = p.part_pos[m.x + e];
@@ -628,12 +623,12 @@ __device__ __forceinline__ bool rivals_closed_form(const spl_count_params &p, in
 #pragma unroll
                 for (int q2 = 0; q2 < q; ++q2) seen |= spl_contains(part, mt.y, (q2 & 1) ? jr[q2 >> 1] : jl[q2 >> 1]);
                 if (seen) continue;
-                if (row > row0[q]) { // listed by the previous row at this position too?
-                    const uint4 m2 = p.site_meta[row - 1];
-                    bool dup = false;
+                bool dup = false; // listed by an earlier row at this position too?
+                for (int32_t row2 = row_first; row2 < row; ++row2) {
+                    const uint4 m2 = p.site_meta[row2];
                     for (uint32_t e2 = 0; e2 < m2.y; ++e2) dup |= (p.part_site[m2.x + e2] == trow);
-                    if (dup) continue;
                 }
+                if (dup) continue;
                 bool dup_edge = false;
                 for (uint32_t e2 = 0; e2 < e; ++e2) dup_edge |= (p.part_site[m.x + e2] == trow);
                 if (dup_edge) continue;
@@ -691,11 +686,12 @@ __device__ __forceinline__ bool rivals_closed_form(const spl_count_params &p, in
 // same counters: those updates are merged across the wave before they reach HBM (agg_add), because one counter word
 // takes only so many atomics per microsecond no matter how many CUs send them.
 template <bool STRANDED>
-__global__ __launch_bounds__(256) void spl_count_literal_kernel(const spl_count_params p, const uint32_t *queue, const uint32_t *queue_n)
+__global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_params p, const uint32_t *queue, const uint32_t *queue_n)
 {
-    constexpr uint32_t BPC = SPL_CHUNK / 256; // workgroups per chunk
+    // one-wave workgroups: a workgroup over unused slots frees its wave slot at once, so the live waves stay dense
+    constexpr uint32_t BPC = SPL_CHUNK / 64; // workgroups per chunk
     const uint32_t chunk = blockIdx.x / BPC;
-    const uint32_t slot = (blockIdx.x % BPC) * 256u + threadIdx.x;
+    const uint32_t slot = (blockIdx.x % BPC) * 64u + threadIdx.x;
     if (slot >= queue_n[chunk]) return;
     const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
     const int64_t i = chunk_base + queue[chunk_base + slot];
@@ -874,13 +870,18 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
     return (int)hipGetLastError();
 }
 
+extern "C" int spl_dev_set_debug(int no_literal_atomics)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_spl_debug_no_literal_atomics), &no_literal_atomics, sizeof(int));
+}
+
 extern "C" int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, void *stream)
 {
     if (p->n_reads <= 0 || p->n_sites <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const uint32_t grid = p->n_chunks * (SPL_CHUNK / 256); // one thread per queue slot
-    if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(grid), dim3(256), 0, st, *p, queue, queue_n);
-    else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(grid), dim3(256), 0, st, *p, queue, queue_n);
+    const uint32_t grid = p->n_chunks * (SPL_CHUNK / 64); // one thread per queue slot
+    if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(grid), dim3(64), 0, st, *p, queue, queue_n);
+    else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(grid), dim3(64), 0, st, *p, queue, queue_n);
     return (int)hipGetLastError();
 }
 
