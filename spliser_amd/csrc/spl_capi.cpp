@@ -75,6 +75,9 @@ struct spl_dsites {
     uint4 *dbucket = nullptr;  // 64 bp buckets {first dpos, -, occupancy mask}
     uint32_t n_dbuckets = 0;
     uint32_t *rival_bits = nullptr;
+    uint4 *jhash = nullptr;    // junction table (see build_junction_table)
+    uint32_t jhash_mask = 0;
+    uint4 *jrivals = nullptr;
     // outputs
     uint32_t *beta1 = nullptr, *beta2s = nullptr, *dbl = nullptr; // contiguous: one memset clears all three
     size_t counter_bytes = 0;
@@ -225,6 +228,89 @@ static int validate_sites(const spl_sites *s)
     return SPL_OK;
 }
 
+// Junction table for the range kernel: every BED junction (l, r) -- a partner edge of the table -- with a flagged end,
+// mapped to the sites t for which checkBam's compSplicing test (SpliSER_v0_1_8.py:494-501) succeeds given that
+// junction alone:  (l in P_t and r in C_t) or (r in P_t and l in C_t), evaluated literally on the table's own lists.
+// Candidates are the partners of the rows at l and at r (partner links are mutual).  Open-addressing hash on (l, r).
+static void build_junction_table(const spl_sites *s, const std::vector<uint8_t> &flags, const std::vector<int32_t> &dfirst,
+                                 const std::vector<int32_t> &row_dpos, std::vector<uint4> &jhash, std::vector<uint4> &jrivals)
+{
+    const int64_t S = s->n_sites;
+    auto in_list = [](const int32_t *list, uint32_t a, uint32_t b, int32_t v) { for (uint32_t i = a; i < b; ++i) if (list[i] == v) return true; return false; };
+    auto rows_at = [&](int32_t row, int32_t &r0, int32_t &r1) { const int32_t d = row_dpos[(size_t)row]; r0 = dfirst[(size_t)d]; r1 = dfirst[(size_t)d + 1]; };
+    struct Junc { int32_t l, r; uint32_t off, info; };
+    std::vector<Junc> juncs;
+    for (int64_t a = 0; a < S; ++a) {
+        const int32_t l = s->pos[a];
+        for (uint32_t e = s->part_off[a]; e < s->part_off[a + 1]; ++e) {
+            const int32_t q = s->part_site[e];
+            const int32_t r = s->part_pos[e];
+            if (q < 0 || !(l < r)) continue; // every junction is seen from both ends: keep the (left, right) view
+            int32_t l0, l1, r0, r1;
+            rows_at((int32_t)a, l0, l1);
+            rows_at(q, r0, r1);
+            bool flagged = false;
+            for (int32_t x = l0; x < l1; ++x) flagged |= (flags[(size_t)x] & SPL_SF_RIVALS) != 0;
+            for (int32_t x = r0; x < r1; ++x) flagged |= (flags[(size_t)x] & SPL_SF_RIVALS) != 0;
+            if (!flagged) continue;
+            bool seen = false; // the same junction listed by an earlier row at l (other strand, duplicate edge)
+            for (int32_t x = l0; x < l1 && !seen; ++x)
+                for (uint32_t e2 = s->part_off[x]; e2 < s->part_off[x + 1]; ++e2)
+                    if (s->part_pos[e2] == r && ((int64_t)x < a || ((int64_t)x == a && e2 < e))) { seen = true; break; }
+            if (seen) continue;
+            Junc j;
+            j.l = l; j.r = r; j.off = (uint32_t)jrivals.size(); j.info = 0;
+            std::vector<int32_t> done;
+            for (int side = 0; side < 2; ++side) {
+                const int32_t x0 = side ? r0 : l0, x1 = side ? r1 : l1;
+                for (int32_t x = x0; x < x1; ++x)
+                    for (uint32_t e2 = s->part_off[x]; e2 < s->part_off[x + 1]; ++e2) {
+                        const int32_t t = s->part_site[e2];
+                        if (t < 0 || std::find(done.begin(), done.end(), t) != done.end()) continue;
+                        done.push_back(t);
+                        const uint32_t pa = s->part_off[t], pb = s->part_off[t + 1], ca = s->comp_off[t], cb = s->comp_off[t + 1];
+                        const bool comp = (in_list(s->part_pos, pa, pb, l) && in_list(s->comp_pos, ca, cb, r)) ||
+                                          (in_list(s->part_pos, pa, pb, r) && in_list(s->comp_pos, ca, cb, l));
+                        if (!comp) continue;
+                        const int32_t tpos = s->pos[t];
+                        if (tpos == l || tpos == r) j.info |= SPL_JF_COMPLEX; // alpha read with compSplicing: literal
+                        int32_t t0, t1;
+                        rows_at(t, t0, t1);
+                        if (t1 - t0 > 1) {
+                            j.info |= SPL_JF_MULTIROW;
+                            for (int32_t y = t0; y < t1; ++y)
+                                if (y != t && (flags[(size_t)y] & 3u) == (flags[(size_t)t] & 3u)) j.info |= SPL_JF_COMPLEX;
+                        }
+                        uint32_t edges[2] = {0xffffffffu, 0xffffffffu};
+                        int ne = 0;
+                        for (uint32_t e3 = pa; e3 < pb; ++e3)
+                            if (s->part_pos[e3] == l || s->part_pos[e3] == r) { if (ne < 2) edges[ne] = e3; ++ne; }
+                        if (ne > 2) j.info |= SPL_JF_COMPLEX;
+                        const uint32_t scode = (flags[(size_t)t] & SPL_SF_PLUS) ? 1u : ((flags[(size_t)t] & SPL_SF_MINUS) ? 2u : 0u);
+                        jrivals.push_back(make_uint4((uint32_t)tpos, (uint32_t)row_dpos[(size_t)t] | (scode << 30), edges[0], edges[1]));
+                    }
+            }
+            const uint32_t n = (uint32_t)jrivals.size() - j.off;
+            if (n > 255u) { j.info |= SPL_JF_COMPLEX; }
+            j.info |= (n > 255u ? 255u : n);
+            juncs.push_back(j);
+        }
+    }
+    size_t cap = 16;
+    while (cap < 2 * juncs.size() + 1) cap <<= 1;
+    jhash.assign(cap, make_uint4(0x80000000u, 0, 0, 0));
+    for (const Junc &j : juncs) {
+        uint32_t h = (uint32_t)j.l * 0x9E3779B1u ^ (uint32_t)j.r * 0x85EBCA77u;
+        h ^= h >> 15;
+        // the kernel gives up after 8 probes: an entry that cannot be placed within 8 is simply left out (-> literal kernel)
+        for (uint32_t probe = 0; probe < 8; ++probe) {
+            uint4 &slot = jhash[(h + probe) & (cap - 1)];
+            if (slot.x == 0x80000000u) { slot = make_uint4((uint32_t)j.l, (uint32_t)j.r, j.off, j.info); break; }
+        }
+    }
+    if (jrivals.empty()) jrivals.push_back(make_uint4(0, 0, 0xffffffffu, 0xffffffffu));
+}
+
 extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out)
 {
     if (!c || !out) return spl_set_error(SPL_ERR_ARG, "spl_sites_upload: null argument");
@@ -314,7 +400,16 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
             for (int32_t r = dfirst[(size_t)j]; r < dfirst[(size_t)j + 1]; ++r)
                 if (flags[(size_t)r] & SPL_SF_RIVALS) rbits[(size_t)j >> 5] |= 1u << (j & 31);
     }
-    d->diff_stride = (int32_t)align_up((size_t)D + 1, 64);
+    std::vector<uint4> jhash, jrivals;
+    {
+        std::vector<int32_t> row_dpos((size_t)S);
+        for (int64_t j = 0; j < D; ++j)
+            for (int32_t r = dfirst[(size_t)j]; r < dfirst[(size_t)j + 1]; ++r) row_dpos[(size_t)r] = (int32_t)j;
+        if (d->mutual_links && s->part_site) build_junction_table(s, flags, dfirst, row_dpos, jhash, jrivals);
+        if (jhash.empty()) { jhash.assign(16, make_uint4(0x80000000u, 0, 0, 0)); jrivals.assign(1, make_uint4(0, 0, 0xffffffffu, 0xffffffffu)); }
+    }
+    d->jhash_mask = (uint32_t)jhash.size() - 1u;
+    d->diff_stride = (int32_t)align_up((size_t)D + 2, 64);
     d->scan_blocks = (int32_t)((D + SPL_SCAN_BLOCK - 1) / SPL_SCAN_BLOCK);
 
     // slab layout
@@ -324,6 +419,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     const size_t o_ppos = take(4 * P), o_psite = take(4 * P), o_cpos = take(4 * C);
     const size_t o_alpha = take(8 * S), o_ecnt = take(8 * P), o_bucket = take(4 * bucket.size());
     const size_t o_dfirst = take(4 * dfirst.size()), o_dbucket = take(16 * dbucket.size()), o_rbits = take(4 * rbits.size());
+    const size_t o_jhash = take(16 * jhash.size()), o_jriv = take(16 * jrivals.size());
     const size_t o_cnt = off;
     const size_t o_b1 = take(4 * S), o_b2 = take(4 * S), o_dbl = take(4 * P);
     const size_t o_diff = take(4 * 4 * (size_t)d->diff_stride);
@@ -336,6 +432,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     d->pos = (int32_t *)(d->slab + o_pos); d->strand = (uint8_t *)(d->slab + o_strand); d->meta = (uint4 *)(d->slab + o_meta);
     d->flags = (uint8_t *)(d->slab + o_flags); d->diff = (int32_t *)(d->slab + o_diff); d->block_sums = (int32_t *)(d->slab + o_bsum);
     d->dpos_first_row = (int32_t *)(d->slab + o_dfirst); d->dbucket = (uint4 *)(d->slab + o_dbucket); d->rival_bits = (uint32_t *)(d->slab + o_rbits);
+    d->jhash = (uint4 *)(d->slab + o_jhash); d->jrivals = (uint4 *)(d->slab + o_jriv);
     d->part_off = (uint32_t *)(d->slab + o_poff); d->part_pos = (int32_t *)(d->slab + o_ppos); d->part_site = (int32_t *)(d->slab + o_psite);
     d->comp_pos = (int32_t *)(d->slab + o_cpos); d->alpha = (int64_t *)(d->slab + o_alpha); d->edge_cnt = (int64_t *)(d->slab + o_ecnt);
     d->bucket = (uint32_t *)(d->slab + o_bucket);
@@ -355,6 +452,8 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (r == hipSuccess) r = up(d->dpos_first_row, dfirst.data(), 4 * dfirst.size());
     if (r == hipSuccess) r = up(d->dbucket, dbucket.data(), 16 * dbucket.size());
     if (r == hipSuccess) r = up(d->rival_bits, rbits.data(), 4 * rbits.size());
+    if (r == hipSuccess) r = up(d->jhash, jhash.data(), 16 * jhash.size());
+    if (r == hipSuccess) r = up(d->jrivals, jrivals.data(), 16 * jrivals.size());
     if (r == hipSuccess) r = up(d->part_off, s->part_off, S ? 4 * (S + 1) : 0);
     if (r == hipSuccess) r = up(d->part_pos, s->part_pos, 4 * P);
     if (r == hipSuccess) r = up(d->part_site, s->part_site, 4 * P);
@@ -449,14 +548,12 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.rival_bits = p.rival_bits;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = dr->queue; h.queue_n = dr->queue_n; h.err = c->d_err;
+    h.jhash = ds->jhash; h.jhash_mask = ds->jhash_mask; h.jrivals = ds->jrivals; h.dbl = ds->dbl; h.combine_mode = p.combine_mode;
 
     p.bucket = ds->bucket; p.n_buckets = ds->n_buckets; p.bucket_base = ds->bucket_base; p.bucket_shift = ds->bucket_shift;
     p.stranded = o->stranded; p.combine_mode = o->combine_mode ? 1 : 0;
     p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = c->d_err;
     // range kernel whenever the table allows it; the literal pair kernel otherwise or on request
-    static int dbg_state = 0;
-    const int dbg_want = (o->flags >> 8) & 1;
-    if (dbg_want != dbg_state) { spl_dev_set_debug(dbg_want); dbg_state = dbg_want; }
     const int variant = (!ds->mutual_links || (o->flags & SPL_OPT_PAIR_KERNEL)) ? 1 : ((o->flags & SPL_OPT_NO_WAVE_AGGREGATION) ? 2 : 0);
     int grid = 0, lds = 0;
     const bool timed = c->k_on && (size_t)(2 * c->k_used + 1) < c->k_ev.size();

@@ -19,6 +19,10 @@
 
 #define SPL_DEV_ERR_RANGE 1
 
+// junction table entry flags (word 3, above the 8-bit rival count)
+#define SPL_JF_COMPLEX 0x100u   // needs the literal kernel (a rival is a junction end, too many rivals, ...)
+#define SPL_JF_MULTIROW 0x200u  // a rival shares its position with another row: unstranded runs cannot address it by dpos
+
 // per-row flag byte (built at upload)
 #define SPL_SF_PLUS 1u    // Site.strand == '+'
 #define SPL_SF_MINUS 2u   // Site.strand == '-'
@@ -81,6 +85,12 @@ struct spl_hot_params {
     int32_t stranded;
     int32_t *diff;
     int32_t diff_stride;
+    // junction table: BED junctions with a flagged end -> their rival sites (built at upload)
+    const uint4 *jhash;          // {l, r, first rival record, n_rivals | SPL_JF_*}; l == 0x80000000 = empty slot
+    uint32_t jhash_mask;
+    const uint4 *jrivals;        // {t_pos, t_dpos | strand code << 30, double-count edge 0, edge 1 (0xffffffff = none)}
+    uint32_t *dbl;
+    int32_t combine_mode;
     uint32_t *queue;             // reads handed to spl_count_literal_kernel: SPL_CHUNK slots per chunk
     uint32_t *queue_n;           // [n_chunks] entries used per chunk
     int32_t *err;
@@ -124,7 +134,6 @@ extern "C" {
 // wave-level aggregation of LDS atomics (experiment)
 int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out);
 int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, void *stream);
-int spl_dev_set_debug(int no_literal_atomics);
 int spl_dev_launch_scan(const spl_scan_params *p, void *stream);
 int spl_dev_launch_sse(const spl_sse_params *p, void *stream);
 #ifdef __cplusplus

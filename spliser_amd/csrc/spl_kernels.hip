@@ -370,6 +370,79 @@ __device__ __forceinline__ void commit_key(const spl_hot_params &p, int32_t *lds
     }
 }
 
+// atomicAdd(addr, delta) with delta = +1 or -1, merged over the lanes of the wave that are executing it right now
+// and target the same word: one atomic per distinct address instead of one per lane.
+__device__ __forceinline__ void agg_add(uint32_t *addr, int32_t delta)
+{
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned long long todo = __ballot(1);
+    const uint32_t lo = (uint32_t)(uintptr_t)addr, hi = (uint32_t)((uintptr_t)addr >> 32);
+    for (;;) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const bool same = (__shfl((int)lo, leader) == (int)lo) && (__shfl((int)hi, leader) == (int)hi);
+        const unsigned long long grp = __ballot(same);
+        const unsigned long long plus = __ballot(same && delta > 0);
+        if (lane == leader) {
+            const int32_t sum = 2 * (int32_t)__popcll(plus) - (int32_t)__popcll(grp);
+            if (sum) atomicAdd(addr, (uint32_t)sum);
+        }
+        if (same) break;
+        todo &= ~grp;
+    }
+}
+
+
+// Rivals of a read whose ONLY junction (l, r) is a junction of the BED file, resolved inside the range kernel from a
+// table built at upload (spl_capi.cpp, build_junction_table): the sites t for which compSplicing is true given (l, r)
+// -- evaluated there with the literal membership tests of checkBam (:494-501) -- with their dpos, strand and the
+// partner edges that take a double count.  With one junction the if/elif chain (:516-559) leaves two corrections:
+//   t strictly inside the intron  -> flanking read: the +1 the ME range gave t's beta2Simple is taken back;
+//   an aligned block covers t,t+1 -> beta1-type read: -1 beta1, +1 beta2Simple, +1 double count per listed edge.
+// Point updates go to the same LDS difference arrays as the ranges.  Returns false when the read must take the
+// literal kernel instead (junction not in the table = not a BED junction, table entry marked complex, ...).
+template <bool STRANDED, int NARR>
+__device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, int32_t *lds, int32_t wbase, int32_t l, int32_t r,
+                                              const int32_t *blk_a, const int32_t *blk_b, uint32_t sidx)
+{
+    uint32_t h = (uint32_t)l * 0x9E3779B1u ^ (uint32_t)r * 0x85EBCA77u;
+    h ^= h >> 15;
+    uint4 ent = make_uint4(0, 0, 0, 0);
+    bool found = false;
+    for (int probe = 0; probe < 8; ++probe) {
+        ent = p.jhash[(h + (uint32_t)probe) & p.jhash_mask];
+        if ((int32_t)ent.x == l && (int32_t)ent.y == r) { found = true; break; }
+        if (ent.x == 0x80000000u) break; // empty slot: not a BED junction with flagged ends
+    }
+    if (!found) return false;
+    const uint32_t n_riv = ent.w & 0xffu;
+    if ((ent.w & SPL_JF_COMPLEX) || n_riv > 4u) return false;
+    if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) return false; // several rows share a rival's position: per-row only
+    for (uint32_t i = 0; i < n_riv; ++i) {
+        const uint4 rv = p.jrivals[ent.z + i]; // {t_pos, t_dpos | strand << 30, edge0, edge1}
+        const int32_t t = (int32_t)rv.x;
+        const uint32_t td = rv.y & 0x3fffffffu;
+        if (STRANDED && ((rv.y >> 30) != (sidx ? 2u : 1u))) continue; // strand_ok false: the ranges added nothing
+        const uint32_t a_b1 = sidx, a_me = (STRANDED ? 2u : 1u) + sidx;
+        if (t > l && t < r) { // flanking: not counted by `process` (:529-536)
+            commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_me, -1);
+            commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, 1);
+        } else {
+            bool cov = false;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) cov |= (blk_a[j] <= t) && (t + 1 <= blk_b[j]);
+            if (cov) { // beta1-type (:544-556)
+                commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_b1, -1);
+                commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_b1, 1);
+                commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_me, 1);
+                commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, -1);
+                if (rv.z != 0xffffffffu) agg_add(&p.dbl[rv.z], 1);
+                if (rv.w != 0xffffffffu) agg_add(&p.dbl[rv.w], 1);
+            }
+        }
+    }
+    return true;
+}
+
 } // namespace
 
 // The range kernel proper: one read per lane, straight-line, three batched memory trips per read --
@@ -505,7 +578,27 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
                 }
             }
             if (bad) atomicOr(p.err, SPL_DEV_ERR_RANGE);
-            if (literal || (alive && rival)) s_q[atomicAdd(&s_qn, 1u)] = (uint32_t)(it * SPL_BLOCK + tid);
+            bool to_queue = literal;
+            if (alive && rival) {
+                // one junction among <= SPL_INLINE_OPS ops, everything else aligned: rivals come from the junction table
+                int n_n = 0, n_b = 0;
+                int32_t jl = 0, jr = 0, blk_a[2] = {1, 1}, blk_b[2] = {0, 0};
+                bool simple = !p.combine_mode && n_ops <= (uint32_t)SPL_INLINE_OPS;
+#pragma unroll
+                for (int k = 0; k < SPL_INLINE_OPS; ++k) {
+                    const int32_t start = k ? cend[k - 1] : pos;
+                    if (kind[k] == 2u) { ++n_n; jl = start - 1; jr = cend[k] - 1; }
+                    else if (kind[k] == 3u) simple = false;
+                    else if (kind[k] == 1u) {
+                        if (n_b == 0) { blk_a[0] = start; blk_b[0] = cend[k] - 1; }
+                        else { blk_a[1] = start; blk_b[1] = cend[k] - 1; }
+                        ++n_b;
+                    }
+                }
+                simple = simple && n_n == 1 && n_b <= 2;
+                if (!simple || !rivals_inline<STRANDED, NARR>(p, lds, wbase, jl, jr, blk_a, blk_b, sidx)) to_queue = true;
+            }
+            if (to_queue) s_q[atomicAdd(&s_qn, 1u)] = (uint32_t)(it * SPL_BLOCK + tid);
         }
     }
     __syncthreads();
@@ -524,30 +617,6 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
 }
 
 namespace {
-
-// atomicAdd(addr, delta) with delta = +1 or -1, merged over the lanes of the wave that are executing it right now
-// and target the same word: one atomic per distinct address instead of one per lane.
-__device__ int g_spl_debug_no_literal_atomics = 0; // timing experiment (SPL_OPT_DEBUG_*): results are wrong when set
-
-__device__ __forceinline__ void agg_add(uint32_t *addr, int32_t delta)
-{
-    if (g_spl_debug_no_literal_atomics) return;
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    unsigned long long todo = __ballot(1);
-    const uint32_t lo = (uint32_t)(uintptr_t)addr, hi = (uint32_t)((uintptr_t)addr >> 32);
-    for (;;) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const bool same = (__shfl((int)lo, leader) == (int)lo) && (__shfl((int)hi, leader) == (int)hi);
-        const unsigned long long grp = __ballot(same);
-        const unsigned long long plus = __ballot(same && delta > 0);
-        if (lane == leader) {
-            const int32_t sum = 2 * (int32_t)__popcll(plus) - (int32_t)__popcll(grp);
-            if (sum) atomicAdd(addr, (uint32_t)sum);
-        }
-        if (same) break;
-        todo &= ~grp;
-    }
-}
 
 // Rivals of a short read (at most SPL_CF_JUNC N ops and SPL_CF_BLK aligned blocks: every short-read CIGAR) in closed
 // form.  With the read's junctions (l_j, r_j) and aligned blocks in registers, the CIGAR walk of checkBam for a rival
@@ -868,11 +937,6 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
         }
     }
     return (int)hipGetLastError();
-}
-
-extern "C" int spl_dev_set_debug(int no_literal_atomics)
-{
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_spl_debug_no_literal_atomics), &no_literal_atomics, sizeof(int));
 }
 
 extern "C" int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, void *stream)
