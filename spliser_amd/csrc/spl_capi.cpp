@@ -494,7 +494,9 @@ extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     const size_t o_pos = take(4 * R), o_flag = take(2 * R), o_off = take(4 * (R + 1)), o_cig = take(4 * G);
     const size_t n_chunks = (size_t)((R + SPL_CHUNK - 1) / SPL_CHUNK);
-    const size_t o_queue = take(4 * n_chunks * SPL_CHUNK), o_qn = take(4 * (n_chunks + 1));
+    // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks
+    const size_t shard_cap = ((n_chunks + 7) / 8) * SPL_CHUNK;
+    const size_t o_queue = take(4 * 8 * shard_cap), o_qn = take(4 * 8);
     hipError_t e = hipMalloc((void **)&d->slab, std::max<size_t>(off, 256));
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the read set: %s", off, hipGetErrorString(e)); }
     d->pos = (int32_t *)(d->slab + o_pos); d->flag = (uint16_t *)(d->slab + o_flag);
@@ -548,7 +550,9 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.rival_bits = p.rival_bits;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = dr->queue; h.queue_n = dr->queue_n; h.err = c->d_err;
-    h.jhash = ds->jhash; h.jhash_mask = ds->jhash_mask; h.jrivals = ds->jrivals; h.dbl = ds->dbl; h.combine_mode = p.combine_mode;
+    h.queue_cap = (uint32_t)(((p.n_chunks + 7u) / 8u) * SPL_CHUNK);
+    HIP_TRY(hipMemsetAsync(dr->queue_n, 0, 8 * sizeof(uint32_t), c->stream));
+    h.jhash = ds->jhash; h.jhash_mask = ds->jhash_mask; h.jrivals = ds->jrivals; h.dbl = ds->dbl; h.combine_mode = o->combine_mode ? 1 : 0;
 
     p.bucket = ds->bucket; p.n_buckets = ds->n_buckets; p.bucket_base = ds->bucket_base; p.bucket_shift = ds->bucket_shift;
     p.stranded = o->stranded; p.combine_mode = o->combine_mode ? 1 : 0;
@@ -565,7 +569,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     c->last_variant = variant;
     if (rc != 0) return spl_set_error(SPL_ERR_HIP, "count kernel launch: %s", hipGetErrorString((hipError_t)rc));
     if (variant != 1 && grid > 0) { // queued reads through the literal kernel, then difference arrays -> counters
-        rc = spl_dev_launch_literal(&p, dr->queue, dr->queue_n, c->stream);
+        rc = spl_dev_launch_literal(&p, dr->queue, dr->queue_n, h.queue_cap, c->stream);
         if (rc != 0) return spl_set_error(SPL_ERR_HIP, "literal kernel launch: %s", hipGetErrorString((hipError_t)rc));
         spl_scan_params q;
         memset(&q, 0, sizeof(q));
@@ -643,12 +647,9 @@ extern "C" int spl_literal_queue_size(spl_ctx *c, const spl_dreads *dr, int64_t 
 {
     if (!c || !dr || !n_out) return spl_set_error(SPL_ERR_ARG, "spl_literal_queue_size: null argument");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t n_chunks = (size_t)((dr->n_reads + SPL_CHUNK - 1) / SPL_CHUNK);
-    std::vector<uint32_t> counts(n_chunks);
-    if (n_chunks) {
-        HIP_TRY(hipMemcpyAsync(counts.data(), dr->queue_n, 4 * n_chunks, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
+    std::vector<uint32_t> counts(8);
+    HIP_TRY(hipMemcpyAsync(counts.data(), dr->queue_n, 4 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     int64_t total = 0;
     for (uint32_t v : counts) total += v;
     *n_out = total;

@@ -12,6 +12,7 @@
 #define SPL_WIN 1024                     // site rows whose counters a workgroup privatises in LDS
 #define SPL_INLINE_OPS 3                 // CIGAR ops per read resolved in the straight-line part (M N M = 3)
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
+#define SPL_LITERAL_WAVES 4096           // one-wave workgroups of the literal kernel (grid-stride over the queue)
 #define SPL_SCAN_BLOCK 1024              // distinct positions per workgroup in the difference-array scan
 
 // Coordinates (read end, site position) must stay <= SPL_COORD_MAX so that t+1 and cur never wrap int32.
@@ -91,8 +92,9 @@ struct spl_hot_params {
     const uint4 *jrivals;        // {t_pos, t_dpos | strand code << 30, double-count edge 0, edge 1 (0xffffffff = none)}
     uint32_t *dbl;
     int32_t combine_mode;
-    uint32_t *queue;             // reads handed to spl_count_literal_kernel: SPL_CHUNK slots per chunk
-    uint32_t *queue_n;           // [n_chunks] entries used per chunk
+    uint32_t *queue;             // reads handed to spl_count_literal_kernel: 8 regions (workgroup & 7) of queue_cap
+    uint32_t *queue_n;           // [8] entries used per region
+    uint32_t queue_cap;
     int32_t *err;
 };
 
@@ -133,7 +135,7 @@ extern "C" {
 // variant: 0 = range kernel (needs mutual partner links), 1 = pair kernel (any table), 2 = range kernel without
 // wave-level aggregation of LDS atomics (experiment)
 int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out);
-int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, void *stream);
+int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, uint32_t queue_cap, void *stream);
 int spl_dev_launch_scan(const spl_scan_params *p, void *stream);
 int spl_dev_launch_sse(const spl_sse_params *p, void *stream);
 #ifdef __cplusplus

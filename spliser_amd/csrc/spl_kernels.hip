@@ -461,7 +461,7 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
     constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
     __shared__ int32_t lds[NARR * (SPL_WIN + 1)];
     __shared__ uint32_t s_q[SPL_CHUNK]; // this chunk's reads for the literal kernel (chunk-relative index)
-    __shared__ uint32_t s_qn;
+    __shared__ uint32_t s_qn, s_qbase;
     __shared__ int32_t s_wbase;
 
     const int tid = threadIdx.x;
@@ -602,10 +602,16 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
         }
     }
     __syncthreads();
-    if (live) { // the queue needs no global atomics: every chunk owns SPL_CHUNK slots and publishes its count
-        const uint32_t qn = s_qn;
-        for (uint32_t j = tid; j < qn; j += SPL_BLOCK) p.queue[chunk_base + j] = s_q[j];
-        if (tid == 0) p.queue_n[chunk] = qn;
+    // Hand the chunk's queue over: one returning atomic per workgroup on the counter of its XCD shard (8 counters, so
+    // no single word sees more than a few reservations per microsecond), then a dense copy.
+    const uint32_t qn = s_qn; // uniform: read after the barrier above
+    if (qn) {
+        const uint32_t shard = blockIdx.x & 7u;
+        if (tid == 0) s_qbase = atomicAdd(&p.queue_n[shard], qn);
+        __syncthreads();
+        uint32_t *dst = p.queue + (size_t)shard * p.queue_cap + s_qbase;
+        const uint32_t first = (uint32_t)chunk_base;
+        for (uint32_t j = tid; j < qn; j += SPL_BLOCK) dst[j] = first + s_q[j];
     }
     for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) {
         const int32_t v = lds[j];
@@ -749,32 +755,32 @@ __device__ __forceinline__ bool rivals_closed_form(const spl_count_params &p, in
 
 } // namespace
 
-// The literal kernel: one thread per queue SLOT (SPL_CHUNK slots per chunk, the used ones first), so the hardware
-// dispatcher balances chunks with long and short queues; workgroups over unused slots exit at once.  Neighbouring
-// lanes hold neighbouring reads, which in coordinate-sorted input cross the same junction and therefore update the
-// same counters: those updates are merged across the wave before they reach HBM (agg_add), because one counter word
-// takes only so many atomics per microsecond no matter how many CUs send them.
+// The literal kernel: SPL_LITERAL_WAVES one-wave workgroups stride over the dense queue, one queued read per lane.
+// Neighbouring lanes hold neighbouring reads, which in coordinate-sorted input cross the same junction and therefore
+// update the same counters: those updates are merged across the wave before they reach HBM (agg_add), because one
+// counter word takes only so many atomics per microsecond no matter how many CUs send them.
 template <bool STRANDED>
-__global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_params p, const uint32_t *queue, const uint32_t *queue_n)
+__global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_params p, const uint32_t *queue, const uint32_t *queue_n,
+                                                                uint32_t queue_cap)
 {
-    // one-wave workgroups: a workgroup over unused slots frees its wave slot at once, so the live waves stay dense
-    constexpr uint32_t BPC = SPL_CHUNK / 64; // workgroups per chunk
-    const uint32_t chunk = blockIdx.x / BPC;
-    const uint32_t slot = (blockIdx.x % BPC) * 64u + threadIdx.x;
-    if (slot >= queue_n[chunk]) return;
-    const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
-    const int64_t i = chunk_base + queue[chunk_base + slot];
-    const int32_t pos = p.r_pos[i];
-    const uint32_t flag = p.r_flag[i];
-    const uint32_t o0 = p.cig_off[i];
-    const uint32_t n_ops = p.cig_off[i + 1] - o0;
-    const uint32_t *ops = p.cigar + o0;
-    int64_t ref_len; bool hn;
-    spl_read_extent(ops, n_ops, &ref_len, &hn);
-    if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); return; }
-    if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); return; }
-    if (rivals_closed_form<STRANDED>(p, pos, flag, ops, n_ops)) return;
-    rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
+    for (uint32_t shard = 0; shard < 8u; ++shard) {
+        const uint32_t n = queue_n[shard];
+        const uint32_t *q = queue + (size_t)shard * queue_cap;
+        for (uint32_t j = blockIdx.x * 64u + threadIdx.x; j < n; j += gridDim.x * 64u) {
+            const int64_t i = q[j];
+            const int32_t pos = p.r_pos[i];
+            const uint32_t flag = p.r_flag[i];
+            const uint32_t o0 = p.cig_off[i];
+            const uint32_t n_ops = p.cig_off[i + 1] - o0;
+            const uint32_t *ops = p.cigar + o0;
+            int64_t ref_len; bool hn;
+            spl_read_extent(ops, n_ops, &ref_len, &hn);
+            if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
+            if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
+            if (rivals_closed_form<STRANDED>(p, pos, flag, ops, n_ops)) continue;
+            rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
+        }
+    }
 }
 
 // =========================================================================================================
@@ -939,13 +945,12 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
     return (int)hipGetLastError();
 }
 
-extern "C" int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, void *stream)
+extern "C" int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, uint32_t queue_cap, void *stream)
 {
     if (p->n_reads <= 0 || p->n_sites <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const uint32_t grid = p->n_chunks * (SPL_CHUNK / 64); // one thread per queue slot
-    if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(grid), dim3(64), 0, st, *p, queue, queue_n);
-    else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(grid), dim3(64), 0, st, *p, queue, queue_n);
+    if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(SPL_LITERAL_WAVES), dim3(64), 0, st, *p, queue, queue_n, queue_cap);
+    else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(SPL_LITERAL_WAVES), dim3(64), 0, st, *p, queue, queue_n, queue_cap);
     return (int)hipGetLastError();
 }
 
