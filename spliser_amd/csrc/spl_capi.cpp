@@ -399,6 +399,15 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
         for (int64_t j = 0; j < D; ++j)
             for (int32_t r = dfirst[(size_t)j]; r < dfirst[(size_t)j + 1]; ++r)
                 if (flags[(size_t)r] & SPL_SF_RIVALS) rbits[(size_t)j >> 5] |= 1u << (j & 31);
+        // second word of a bucket entry: bit k = the k-th site position inside the bucket has a rival flag
+        for (uint32_t b = 0; b < d->n_dbuckets; ++b) {
+            const int64_t first = dbucket[b].x;
+            const int n_in = __builtin_popcountll((unsigned long long)dbucket[b].z | ((unsigned long long)dbucket[b].w << 32));
+            uint32_t rm = 0;
+            for (int k = 0; k < n_in && k < 32; ++k)
+                if ((rbits[(size_t)(first + k) >> 5] >> ((first + k) & 31)) & 1u) rm |= 1u << k;
+            dbucket[b].y = rm;
+        }
     }
     std::vector<uint4> jhash, jrivals;
     {
@@ -547,7 +556,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     spl_hot_params h;
     memset(&h, 0, sizeof(h));
     h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos = p.r_pos; h.r_flag = p.r_flag; h.cig_off = p.cig_off; h.cigar = p.cigar;
-    h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.rival_bits = p.rival_bits;
+    h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.n_cigar = (uint32_t)dr->n_cigar;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = dr->queue; h.queue_n = dr->queue_n; h.err = c->d_err;
     h.queue_cap = (uint32_t)(((p.n_chunks + 7u) / 8u) * SPL_CHUNK);

@@ -74,6 +74,7 @@ struct spl_count_params {
 struct spl_hot_params {
     int64_t n_reads;
     uint32_t n_chunks;
+    uint32_t n_cigar;
     const int32_t *r_pos;
     const uint16_t *r_flag;
     const uint32_t *cig_off;
@@ -82,7 +83,6 @@ struct spl_hot_params {
     uint32_t n_dbuckets;
     int32_t dbase;
     int32_t n_dpos;
-    const uint32_t *rival_bits;
     int32_t stranded;
     int32_t *diff;
     int32_t diff_stride;

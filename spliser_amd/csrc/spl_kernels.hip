@@ -326,8 +326,9 @@ __device__ __forceinline__ uint32_t dbk_slot(const P &p, int32_t x)
     return (uint32_t)(b > last ? last : b);
 }
 
+// e.y: bit j = the j-th site position of the bucket has a rival flag (conservatively all ones past 32 sites).
 template <class P>
-__device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint4 e, int32_t &u, uint32_t &nv)
+__device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint4 e, int32_t &u, uint32_t &nv, uint32_t &rv)
 {
     const int32_t rel = x - p.dbase;
     const uint32_t bit = (uint32_t)rel & 63u;
@@ -335,10 +336,17 @@ __device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint4 e
     const uint32_t sh = bit & 31u;
     const uint32_t below = (1u << sh) - 1u;
     const uint32_t cnt = __popc(e.z & (upper ? 0xffffffffu : below)) + __popc(e.w & (upper ? below : 0u));
-    u = (int32_t)(e.x + cnt);
-    nv = ((upper ? e.w : e.z) >> sh) & 1u;
-    if (rel < 0) { u = 0; nv = 0; }
-    if ((rel >> 6) >= (int32_t)p.n_dbuckets) { u = p.n_dpos; nv = 0; }
+    const bool out = rel < 0 || (rel >> 6) >= (int32_t)p.n_dbuckets;
+    u = out ? (rel < 0 ? 0 : p.n_dpos) : (int32_t)(e.x + cnt);
+    nv = out ? 0u : (((upper ? e.w : e.z) >> sh) & 1u);
+    rv = cnt < 32u ? ((e.y >> cnt) & 1u) : 1u;
+}
+
+template <class P>
+__device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint4 e, int32_t &u, uint32_t &nv)
+{
+    uint32_t rv;
+    dbk_resolve(p, x, e, u, nv, rv);
 }
 
 // All 64 lanes call this together.  Lanes that add `sign` to the same key = (dpos << 2 | array) and sit next to each
@@ -480,28 +488,33 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
     const int32_t wbase = s_wbase;
 
     if (live) {
+        const int64_t last_read = p.n_reads - 1;
+        const uint32_t last_op = p.n_cigar ? p.n_cigar - 1u : 0u;
         for (int it = 0; it < SPL_RPT; ++it) {
-            // Control flow is wave-uniform around every commit_key (all 64 lanes reach it).
+            // Straight-line and branch-free up to the commits: out-of-range lanes re-read the last read / last op and
+            // are masked at the end, so all loads of a trip issue back to back.  Control flow is wave-uniform around
+            // every commit_key (all 64 lanes reach it).
             const int64_t i = chunk_base + (int64_t)it * SPL_BLOCK + tid;
-            bool alive = i < p.n_reads;
-            int32_t pos = 0;
-            uint32_t flag = 0, o0 = 0, n_ops = 0;
-            if (alive) {                                                        // ---- trip 1
-                pos = p.r_pos[i];
-                flag = p.r_flag[i];
-                o0 = p.cig_off[i];
-                n_ops = p.cig_off[i + 1] - o0;
-            }
+            bool alive = i <= last_read;
+            const int64_t ii = alive ? i : last_read;
+            const int32_t pos = p.r_pos[ii];                                     // ---- trip 1
+            const uint32_t flag = p.r_flag[ii];
+            const uint32_t o0 = p.cig_off[ii];
+            const uint32_t n_ops = p.cig_off[ii + 1] - o0;
             uint32_t op[SPL_INLINE_OPS];
 #pragma unroll
-            for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = (alive && (uint32_t)k < n_ops) ? p.cigar[o0 + k] : 0xfu; // ---- trip 2
+            for (int k = 0; k < SPL_INLINE_OPS; ++k) {                           // ---- trip 2
+                const uint32_t at = o0 + (uint32_t)k;
+                const uint32_t raw = p.cigar[at < last_op ? at : last_op];
+                op[k] = ((uint32_t)k < n_ops) ? raw : 0xfu; // 0xf: absent, not a reference-consuming op
+            }
             bool bad = alive && pos < 0;
-            bool literal = alive && !bad && (flag & 4u); // fetched as a 1-base record: literal kernel
+            const bool literal = alive && !bad && (flag & 4u); // fetched as a 1-base record: literal kernel
             alive = alive && !bad && !literal;
             uint32_t sidx = 0;
             if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
 
-            // boundaries of the inline ops (op code 0xf = absent: not a reference-consuming op)
+            // boundaries of the inline ops
             const uint32_t room = (uint32_t)(SPL_COORD_MAX - (pos < 0 ? 0 : pos));
             uint32_t len = 0;
             int32_t cend[SPL_INLINE_OPS];
@@ -515,33 +528,28 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
                 cend[k] = pos + (int32_t)len;
                 kind[k] = (prog && alive) ? ((code == SPL_OP_N) ? 2u : (code == SPL_OP_D ? 3u : 1u)) : 0u;
             }
-            // ---- trip 3: bucket entries of the start boundary and of every inline op end
-            uint4 e0 = make_uint4(0, 0, 0, 0), ek[SPL_INLINE_OPS];
-            if (alive) e0 = p.dbucket[dbk_slot(p, pos - 1)];
+            // ---- trip 3: bucket entries of the start boundary and of every inline op end (slots are clamped: always legal)
+            const uint4 e0 = p.dbucket[dbk_slot(p, pos - 1)];
+            uint4 ek[SPL_INLINE_OPS];
 #pragma unroll
-            for (int k = 0; k < SPL_INLINE_OPS; ++k) {
-                ek[k] = make_uint4(0, 0, 0, 0);
-                if (kind[k]) ek[k] = p.dbucket[dbk_slot(p, cend[k] - 1)];
-            }
-            int32_t pu = 0; uint32_t pnv = 0; // the dpos AT the previous boundary's last base, if pnv
-            dbk_resolve(p, pos - 1, e0, pu, pnv);
+            for (int k = 0; k < SPL_INLINE_OPS; ++k) ek[k] = p.dbucket[dbk_slot(p, cend[k] - 1)];
+            int32_t pu = 0; uint32_t pnv = 0, prv = 0; // the dpos AT the previous boundary's last base (if pnv) and its rival bit
+            dbk_resolve(p, pos - 1, e0, pu, pnv, prv);
             bool rival = false;
 #pragma unroll
             for (int k = 0; k < SPL_INLINE_OPS; ++k) {
-                int32_t u; uint32_t nv;
-                dbk_resolve(p, cend[k] - 1, ek[k], u, nv);
+                int32_t u; uint32_t nv, rv;
+                dbk_resolve(p, cend[k] - 1, ek[k], u, nv, rv);
                 const int32_t lo = pu + (int32_t)pnv; // first dpos at or after the op's first base
                 const bool emit = kind[k] != 0u && kind[k] != 3u && u > lo;
                 const uint32_t arr = (kind[k] == 2u ? (STRANDED ? 2u : 1u) : 0u) + sidx;
-                if (kind[k] == 2u) { // junction ends: lSite is the previous boundary's position, rSite this one's
-                    if (pnv) rival |= (p.rival_bits[(uint32_t)pu >> 5] >> ((uint32_t)pu & 31u)) & 1u;
-                    if (nv) rival |= (p.rival_bits[(uint32_t)u >> 5] >> ((uint32_t)u & 31u)) & 1u;
-                }
+                // junction ends: lSite is the previous boundary's position, rSite this one's
+                rival |= (kind[k] == 2u) && ((pnv & prv) | (nv & rv));
                 if (__any(emit)) {
                     commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
                     commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)u << 2) | arr, -1);
                 }
-                if (kind[k]) { pu = u; pnv = nv; }
+                if (kind[k]) { pu = u; pnv = nv; prv = rv; }
             }
             // ---- reads with more ops than the inline window: one op at a time
             int32_t c = pos + (int32_t)len;
@@ -557,18 +565,16 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
                         if (len > room) { bad = true; alive = false; }
                         else {
                             c = pos + (int32_t)len;
-                            int32_t u; uint32_t nv;
-                            dbk_resolve(p, c - 1, p.dbucket[dbk_slot(p, c - 1)], u, nv);
+                            int32_t u; uint32_t nv, rv;
+                            dbk_resolve(p, c - 1, p.dbucket[dbk_slot(p, c - 1)], u, nv, rv);
                             lo = pu + (int32_t)pnv;
                             hi = u;
                             emit = hi > lo && code != SPL_OP_D;
                             arr = (code == SPL_OP_N ? (STRANDED ? 2u : 1u) : 0u) + sidx;
-                            if (code == SPL_OP_N) {
-                                if (pnv) rival |= (p.rival_bits[(uint32_t)pu >> 5] >> ((uint32_t)pu & 31u)) & 1u;
-                                if (nv) rival |= (p.rival_bits[(uint32_t)u >> 5] >> ((uint32_t)u & 31u)) & 1u;
-                            }
+                            rival |= (code == SPL_OP_N) && ((pnv & prv) | (nv & rv));
                             pu = u;
                             pnv = nv;
+                            prv = rv;
                         }
                     }
                 }
