@@ -286,6 +286,7 @@ static void build_junction_table(const spl_sites *s, const std::vector<uint8_t> 
                         for (uint32_t e3 = pa; e3 < pb; ++e3)
                             if (s->part_pos[e3] == l || s->part_pos[e3] == r) { if (ne < 2) edges[ne] = e3; ++ne; }
                         if (ne > 2) j.info |= SPL_JF_COMPLEX;
+                        if ((int)(pb - pa) > ne && edges[0] != 0xffffffffu) edges[0] |= 0x80000000u; // t has partners besides l, r
                         const uint32_t scode = (flags[(size_t)t] & SPL_SF_PLUS) ? 1u : ((flags[(size_t)t] & SPL_SF_MINUS) ? 2u : 0u);
                         jrivals.push_back(make_uint4((uint32_t)tpos, (uint32_t)row_dpos[(size_t)t] | (scode << 30), edges[0], edges[1]));
                     }
@@ -553,6 +554,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.diff = ds->diff; p.diff_stride = ds->diff_stride;
     p.dbucket = ds->dbucket; p.n_dbuckets = ds->n_dbuckets; p.dbase = ds->n_sites ? ds->bucket_base : 0; p.n_dpos = ds->n_dpos;
     p.rival_bits = ds->rival_bits; p.dpos_first_row = ds->dpos_first_row;
+    p.jhash = ds->jhash; p.jhash_mask = ds->jhash_mask; p.jrivals = ds->jrivals;
     spl_hot_params h;
     memset(&h, 0, sizeof(h));
     h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos = p.r_pos; h.r_flag = p.r_flag; h.cig_off = p.cig_off; h.cigar = p.cigar;

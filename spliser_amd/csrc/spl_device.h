@@ -58,6 +58,9 @@ struct spl_count_params {
     int32_t n_dpos;
     const uint32_t *rival_bits;  // bit d: some row at distinct position d carries SPL_SF_RIVALS
     const int32_t *dpos_first_row;
+    const uint4 *jhash;          // junction table (see spl_hot_params)
+    uint32_t jhash_mask;
+    const uint4 *jrivals;
     // options
     int32_t stranded;            // 0 none, 1 fr, 2 rf
     int32_t combine_mode;

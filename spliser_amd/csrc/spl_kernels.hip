@@ -443,7 +443,7 @@ __device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, int32_t *
                 commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_b1, 1);
                 commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_me, 1);
                 commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, -1);
-                if (rv.z != 0xffffffffu) agg_add(&p.dbl[rv.z], 1);
+                if (rv.z != 0xffffffffu) agg_add(&p.dbl[rv.z & 0x7fffffffu], 1);
                 if (rv.w != 0xffffffffu) agg_add(&p.dbl[rv.w], 1);
             }
         }
@@ -759,6 +759,118 @@ __device__ __forceinline__ bool rivals_closed_form(const spl_count_params &p, in
     return true;
 }
 
+// The same junction table the range kernel uses for single-junction reads, applied to reads with up to SPL_CF_JUNC
+// junctions: compSplicing of junction j for site t is "t is listed under (l_j, r_j)", so no partner / competitor list is
+// scanned.  A rival is handled under the FIRST junction that lists it (that is where compSplicing becomes true and
+// stays true, :494-501): strictly inside that or a later intron -> flanking read (the ME range's +1 is taken back);
+// covered with t+1 by an aligned block -> beta1-type.  Anything the table cannot decide exactly (a junction that is not
+// in the BED file but touches flagged sites, a rival that is itself a junction end of the read, entries marked complex,
+// combine mode) returns false and the read takes rivals_closed_form.  Updates go to the global difference arrays.
+template <bool STRANDED>
+__device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int32_t pos, uint32_t flag, const uint32_t *ops, uint32_t n_ops)
+{
+    if (p.combine_mode) return false;
+    int32_t blk_a[SPL_CF_BLK], blk_b[SPL_CF_BLK], jl[SPL_CF_JUNC], jr[SPL_CF_JUNC];
+    int n_blk = 0, n_j = 0;
+    int32_t cur = pos;
+    for (uint32_t k = 0; k < n_ops; ++k) {
+        const uint32_t op = ops[k];
+        const uint32_t code = op & 15u;
+        if (!((SPL_PROG_MASK >> code) & 1u)) continue;
+        const int32_t d = (int32_t)(op >> 4);
+        const int32_t start = cur;
+        cur += d;
+        if (code == SPL_OP_N) {
+            if (n_j == SPL_CF_JUNC) return false;
+#pragma unroll
+            for (int j = 0; j < SPL_CF_JUNC; ++j) if (j == n_j) { jl[j] = start - 1; jr[j] = cur - 1; }
+            ++n_j;
+        } else if (code != SPL_OP_D && d >= 2) {
+            if (n_blk == SPL_CF_BLK) return false;
+#pragma unroll
+            for (int j = 0; j < SPL_CF_BLK; ++j) if (j == n_blk) { blk_a[j] = start; blk_b[j] = cur - 1; }
+            ++n_blk;
+        }
+    }
+    if (n_j == 0) return true;
+    // pass 1: table entries of all junctions; everything that needs the literal walk bails out before any update
+    uint32_t r_off[SPL_CF_JUNC], r_n[SPL_CF_JUNC];
+#pragma unroll
+    for (int j = 0; j < SPL_CF_JUNC; ++j) {
+        r_off[j] = 0; r_n[j] = 0;
+        if (j >= n_j) continue;
+        const int32_t l = jl[j], r = jr[j];
+        uint32_t h = (uint32_t)l * 0x9E3779B1u ^ (uint32_t)r * 0x85EBCA77u;
+        h ^= h >> 15;
+        bool found = false;
+        uint4 ent = make_uint4(0, 0, 0, 0);
+        for (int probe = 0; probe < 8; ++probe) {
+            ent = p.jhash[(h + (uint32_t)probe) & p.jhash_mask];
+            if ((int32_t)ent.x == l && (int32_t)ent.y == r) { found = true; break; }
+            if (ent.x == 0x80000000u) break;
+        }
+        if (found) {
+            if ((ent.w & SPL_JF_COMPLEX) || (ent.w & 0xffu) > 8u) return false;
+            if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) return false;
+            r_off[j] = ent.z; r_n[j] = ent.w & 0xffu;
+        } else { // not a listed junction: fine only when neither end has a rival flag
+            int32_t u; uint32_t nv, rv;
+            dbk_resolve(p, l, p.dbucket[dbk_slot(p, l)], u, nv, rv);
+            if (nv & rv) return false;
+            dbk_resolve(p, r, p.dbucket[dbk_slot(p, r)], u, nv, rv);
+            if (nv & rv) return false;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SPL_CF_JUNC; ++j) {
+        for (uint32_t i = 0; i < r_n[j]; ++i) {
+            const uint4 rv = p.jrivals[r_off[j] + i];
+            const int32_t t = (int32_t)rv.x;
+            bool is_end = false, cov = false;
+#pragma unroll
+            for (int a = 0; a < SPL_CF_JUNC; ++a) is_end |= (a < n_j) && (t == jl[a] || t == jr[a]);
+            if (is_end) return false; // alpha read with compSplicing (:519-527): literal
+#pragma unroll
+            for (int b = 0; b < SPL_CF_BLK; ++b) cov |= (b < n_blk) && (blk_a[b] <= t) && (t + 1 <= blk_b[b]);
+            if (cov && n_j > 1 && (rv.z & 0x80000000u)) return false; // its double counts may involve other junction ends
+        }
+    }
+    // pass 2: apply
+    const uint32_t want = (spl_read_strand(flag, STRANDED ? p.stranded : 1) == (uint8_t)'-') ? 2u : 1u;
+    const uint32_t sidx = STRANDED ? (want - 1u) : 0u;
+    uint32_t *b1 = (uint32_t *)(p.diff + (int64_t)sidx * p.diff_stride);
+    uint32_t *me = (uint32_t *)(p.diff + (int64_t)((STRANDED ? 2u : 1u) + sidx) * p.diff_stride);
+#pragma unroll
+    for (int j = 0; j < SPL_CF_JUNC; ++j) {
+        for (uint32_t i = 0; i < r_n[j]; ++i) {
+            const uint4 rv = p.jrivals[r_off[j] + i];
+            bool earlier = false; // listed under an earlier junction of this read: handled there
+#pragma unroll
+            for (int j2 = 0; j2 < SPL_CF_JUNC; ++j2)
+                if (j2 < j) for (uint32_t i2 = 0; i2 < r_n[j2]; ++i2) earlier |= (p.jrivals[r_off[j2] + i2].y == rv.y);
+            if (earlier) continue;
+            if (STRANDED && (rv.y >> 30) != want) continue; // strand_ok false: ranges added nothing, nothing to add
+            const int32_t t = (int32_t)rv.x;
+            const uint32_t td = rv.y & 0x3fffffffu;
+            int inside = -1;
+            bool cov = false;
+#pragma unroll
+            for (int a = 0; a < SPL_CF_JUNC; ++a) if (a < n_j && t > jl[a] && t < jr[a]) inside = a;
+#pragma unroll
+            for (int b = 0; b < SPL_CF_BLK; ++b) cov |= (b < n_blk) && (blk_a[b] <= t) && (t + 1 <= blk_b[b]);
+            if (inside >= 0) {
+                if (inside >= j) { agg_add(&me[td], -1); agg_add(&me[td + 1u], 1); } // flanking (:503-505, :529)
+            } else if (cov) { // beta1-type (:544-556)
+                agg_add(&b1[td], -1); agg_add(&b1[td + 1u], 1);
+                agg_add(&me[td], 1); agg_add(&me[td + 1u], -1);
+                if (rv.z != 0xffffffffu) agg_add(&p.dbl[rv.z & 0x7fffffffu], 1);
+                if (rv.w != 0xffffffffu) agg_add(&p.dbl[rv.w], 1);
+            }
+        }
+    }
+    return true;
+}
+
 } // namespace
 
 // The literal kernel: SPL_LITERAL_WAVES one-wave workgroups stride over the dense queue, one queued read per lane.
@@ -783,6 +895,7 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
             spl_read_extent(ops, n_ops, &ref_len, &hn);
             if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
             if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
+            if (rivals_table_path<STRANDED>(p, pos, flag, ops, n_ops)) continue;
             if (rivals_closed_form<STRANDED>(p, pos, flag, ops, n_ops)) continue;
             rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
         }
