@@ -259,7 +259,7 @@ static void build_junction_table(const spl_sites *s, const std::vector<uint8_t> 
                     if (s->part_pos[e2] == r && ((int64_t)x < a || ((int64_t)x == a && e2 < e))) { seen = true; break; }
             if (seen) continue;
             Junc j;
-            j.l = l; j.r = r; j.off = (uint32_t)jrivals.size(); j.info = 0;
+            j.l = l; j.r = r; j.off = (uint32_t)(jrivals.size() / 2); j.info = 0;
             std::vector<int32_t> done;
             for (int side = 0; side < 2; ++side) {
                 const int32_t x0 = side ? r0 : l0, x1 = side ? r1 : l1;
@@ -286,12 +286,12 @@ static void build_junction_table(const spl_sites *s, const std::vector<uint8_t> 
                         for (uint32_t e3 = pa; e3 < pb; ++e3)
                             if (s->part_pos[e3] == l || s->part_pos[e3] == r) { if (ne < 2) edges[ne] = e3; ++ne; }
                         if (ne > 2) j.info |= SPL_JF_COMPLEX;
-                        if ((int)(pb - pa) > ne && edges[0] != 0xffffffffu) edges[0] |= 0x80000000u; // t has partners besides l, r
                         const uint32_t scode = (flags[(size_t)t] & SPL_SF_PLUS) ? 1u : ((flags[(size_t)t] & SPL_SF_MINUS) ? 2u : 0u);
                         jrivals.push_back(make_uint4((uint32_t)tpos, (uint32_t)row_dpos[(size_t)t] | (scode << 30), edges[0], edges[1]));
+                        jrivals.push_back(make_uint4((uint32_t)t, pa, pb - pa, 0u));
                     }
             }
-            const uint32_t n = (uint32_t)jrivals.size() - j.off;
+            const uint32_t n = (uint32_t)(jrivals.size() / 2) - j.off;
             if (n > 255u) { j.info |= SPL_JF_COMPLEX; }
             j.info |= (n > 255u ? 255u : n);
             juncs.push_back(j);
@@ -309,7 +309,7 @@ static void build_junction_table(const spl_sites *s, const std::vector<uint8_t> 
             if (slot.x == 0x80000000u) { slot = make_uint4((uint32_t)j.l, (uint32_t)j.r, j.off, j.info); break; }
         }
     }
-    if (jrivals.empty()) jrivals.push_back(make_uint4(0, 0, 0xffffffffu, 0xffffffffu));
+    if (jrivals.empty()) jrivals.assign(2, make_uint4(0, 0, 0xffffffffu, 0xffffffffu));
 }
 
 extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out)
@@ -416,7 +416,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
         for (int64_t j = 0; j < D; ++j)
             for (int32_t r = dfirst[(size_t)j]; r < dfirst[(size_t)j + 1]; ++r) row_dpos[(size_t)r] = (int32_t)j;
         if (d->mutual_links && s->part_site) build_junction_table(s, flags, dfirst, row_dpos, jhash, jrivals);
-        if (jhash.empty()) { jhash.assign(16, make_uint4(0x80000000u, 0, 0, 0)); jrivals.assign(1, make_uint4(0, 0, 0xffffffffu, 0xffffffffu)); }
+        if (jhash.empty()) { jhash.assign(16, make_uint4(0x80000000u, 0, 0, 0)); jrivals.assign(2, make_uint4(0, 0, 0xffffffffu, 0xffffffffu)); }
     }
     d->jhash_mask = (uint32_t)jhash.size() - 1u;
     d->diff_stride = (int32_t)align_up((size_t)D + 2, 64);

@@ -426,7 +426,7 @@ __device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, int32_t *
     if ((ent.w & SPL_JF_COMPLEX) || n_riv > 4u) return false;
     if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) return false; // several rows share a rival's position: per-row only
     for (uint32_t i = 0; i < n_riv; ++i) {
-        const uint4 rv = p.jrivals[ent.z + i]; // {t_pos, t_dpos | strand << 30, edge0, edge1}
+        const uint4 rv = p.jrivals[2u * (ent.z + i)]; // {t_pos, t_dpos | strand << 30, edge0, edge1} (+ a second quad: literal kernel)
         const int32_t t = (int32_t)rv.x;
         const uint32_t td = rv.y & 0x3fffffffu;
         if (STRANDED && ((rv.y >> 30) != (sidx ? 2u : 1u))) continue; // strand_ok false: the ranges added nothing
@@ -810,7 +810,7 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
             if (ent.x == 0x80000000u) break;
         }
         if (found) {
-            if ((ent.w & SPL_JF_COMPLEX) || (ent.w & 0xffu) > 8u) return false;
+            if ((ent.w & SPL_JF_COMPLEX) || (ent.w & 0xffu) > 16u) return false;
             if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) return false;
             r_off[j] = ent.z; r_n[j] = ent.w & 0xffu;
         } else { // not a listed junction: fine only when neither end has a rival flag
@@ -821,20 +821,6 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
             if (nv & rv) return false;
         }
     }
-#pragma unroll
-    for (int j = 0; j < SPL_CF_JUNC; ++j) {
-        for (uint32_t i = 0; i < r_n[j]; ++i) {
-            const uint4 rv = p.jrivals[r_off[j] + i];
-            const int32_t t = (int32_t)rv.x;
-            bool is_end = false, cov = false;
-#pragma unroll
-            for (int a = 0; a < SPL_CF_JUNC; ++a) is_end |= (a < n_j) && (t == jl[a] || t == jr[a]);
-            if (is_end) return false; // alpha read with compSplicing (:519-527): literal
-#pragma unroll
-            for (int b = 0; b < SPL_CF_BLK; ++b) cov |= (b < n_blk) && (blk_a[b] <= t) && (t + 1 <= blk_b[b]);
-            if (cov && n_j > 1 && (rv.z & 0x80000000u)) return false; // its double counts may involve other junction ends
-        }
-    }
     // pass 2: apply
     const uint32_t want = (spl_read_strand(flag, STRANDED ? p.stranded : 1) == (uint8_t)'-') ? 2u : 1u;
     const uint32_t sidx = STRANDED ? (want - 1u) : 0u;
@@ -843,28 +829,44 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
 #pragma unroll
     for (int j = 0; j < SPL_CF_JUNC; ++j) {
         for (uint32_t i = 0; i < r_n[j]; ++i) {
-            const uint4 rv = p.jrivals[r_off[j] + i];
+            const uint4 rv = p.jrivals[2u * (r_off[j] + i)];
             bool earlier = false; // listed under an earlier junction of this read: handled there
 #pragma unroll
             for (int j2 = 0; j2 < SPL_CF_JUNC; ++j2)
-                if (j2 < j) for (uint32_t i2 = 0; i2 < r_n[j2]; ++i2) earlier |= (p.jrivals[r_off[j2] + i2].y == rv.y);
+                if (j2 < j) for (uint32_t i2 = 0; i2 < r_n[j2]; ++i2) earlier |= (p.jrivals[2u * (r_off[j2] + i2)].y == rv.y);
             if (earlier) continue;
-            if (STRANDED && (rv.y >> 30) != want) continue; // strand_ok false: ranges added nothing, nothing to add
             const int32_t t = (int32_t)rv.x;
             const uint32_t td = rv.y & 0x3fffffffu;
+            const bool strand_ok = !STRANDED || (rv.y >> 30) == want;
             int inside = -1;
-            bool cov = false;
+            bool cov = false, alpha = false;
+            int32_t pu = 0;
 #pragma unroll
-            for (int a = 0; a < SPL_CF_JUNC; ++a) if (a < n_j && t > jl[a] && t < jr[a]) inside = a;
+            for (int a = 0; a < SPL_CF_JUNC; ++a) {
+                if (a >= n_j) break;
+                if (t > jl[a] && t < jr[a]) inside = a;
+                if (jl[a] == t) { pu = jr[a]; alpha = true; } // :487-492, in op order
+                if (jr[a] == t) { pu = jl[a]; alpha = true; }
+            }
 #pragma unroll
             for (int b = 0; b < SPL_CF_BLK; ++b) cov |= (b < n_blk) && (blk_a[b] <= t) && (t + 1 <= blk_b[b]);
-            if (inside >= 0) {
-                if (inside >= j) { agg_add(&me[td], -1); agg_add(&me[td + 1u], 1); } // flanking (:503-505, :529)
-            } else if (cov) { // beta1-type (:544-556)
-                agg_add(&b1[td], -1); agg_add(&b1[td + 1u], 1);
-                agg_add(&me[td], 1); agg_add(&me[td + 1u], -1);
-                if (rv.z != 0xffffffffu) agg_add(&p.dbl[rv.z & 0x7fffffffu], 1);
-                if (rv.w != 0xffffffffu) agg_add(&p.dbl[rv.w], 1);
+            const bool beta1type = !alpha && inside < 0 && cov && strand_ok;
+            if (alpha || beta1type) {
+                // double counts: set(partners) & set(spliceSites), minus partnerUsed for the alpha case (:519-527, :544-551)
+                const uint4 rx = p.jrivals[2u * (r_off[j] + i) + 1u]; // {row of t, its partner list offset, length, -}
+                for (uint32_t e2 = 0; e2 < rx.z; ++e2) {
+                    const int32_t pp = p.part_pos[rx.y + e2];
+                    bool is_end = false;
+#pragma unroll
+                    for (int a = 0; a < SPL_CF_JUNC; ++a) is_end |= (a < n_j) && (pp == jl[a] || pp == jr[a]);
+                    if (is_end && !(alpha && pp == pu)) agg_add(&p.dbl[rx.y + e2], 1);
+                }
+                if (beta1type) { // beta1-type (:544-556): the ranges counted it as beta1
+                    agg_add(&b1[td], -1); agg_add(&b1[td + 1u], 1);
+                    agg_add(&me[td], 1); agg_add(&me[td + 1u], -1);
+                }
+            } else if (inside >= j && strand_ok) { // flanking (:503-505, :529): the ME range counted it, `process` does not
+                agg_add(&me[td], -1); agg_add(&me[td + 1u], 1);
             }
         }
     }
