@@ -36,6 +36,23 @@ def build_parser():
     p.add_argument("--beta2Cryptic", dest="isbeta2Cryptic", default=False, action="store_true",
                    help="optional: weight the utilisation of competing splice sites into SSE (legacy)")
     _engine_flags(p)
+    c = sub.add_parser("combine")
+    c.add_argument("-S", "--samplesFile", dest="samplesFile", required=True,
+                   help="three-column .tsv: sample name, path of its .SpliSER.tsv, path of its BAM")
+    c.add_argument("-o", "--outputPath", dest="outputPath", required=True, help="output prefix (.combined.tsv is appended)")
+    c.add_argument("-g", "--gene", dest="qGene", nargs="?", default="All", type=str, required=False)
+    c.add_argument("--isStranded", dest="isStranded", default=False, action="store_true")
+    c.add_argument("-s", "--strandedType", dest="strandedType", nargs="?", default="fr", type=str, required=False)
+    c.add_argument("--beta2Cryptic", dest="isbeta2Cryptic", default=False, action="store_true")
+    _engine_flags(c)
+    o = sub.add_parser("output")
+    o.add_argument("-S", "--samplesFile", dest="samplesFile", required=True)
+    o.add_argument("-C", "--combinedFile", dest="combinedFile", required=True)
+    o.add_argument("-t", "--outputType", dest="outputType", required=True, help="DiffSpliSER or GWAS")
+    o.add_argument("-o", "--outputPath", dest="outputPath", required=True)
+    o.add_argument("-r", "--minReads", dest="minReads", required=False, nargs="?", default=10, type=int)
+    o.add_argument("-g", "--gene", dest="qGene", required=False, nargs="?", default="All", type=str)
+    o.add_argument("-m", "--minSamples", dest="minSamples", required=False, nargs="?", default=50, type=int)
     return parser
 
 
@@ -67,6 +84,12 @@ def main(argv=None):
     if command == "process":
         from .process import process
         process(devices=devices, threads=threads, **kwargs)
+    elif command == "combine":
+        from .combine import combine
+        combine(devices=devices, threads=threads, **kwargs)
+    elif command == "output":
+        from .output import output
+        output(**kwargs)
     else:
         parser.error("sub-command %r is not part of this build yet" % command)
     print("Total runtime (s): \t" + str(timeit.default_timer() - start))

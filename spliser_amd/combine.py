@@ -1,0 +1,282 @@
+"""``combine`` -- merge per-sample ``.SpliSER.tsv`` files and fill the gaps from each sample's BAM.
+
+Reference: ``combine`` SpliSER_v0_1_8.py:742-917, ``outputCombinedLines`` :722-740, region ordering through
+``Graph.topologicalSort`` Gene_Site_Iter_Graph_v0_1_8.py:358-396.
+
+The reference walks all sample files in lock-step and, for every site a sample does not list, calls ``checkBam`` on
+that sample's BAM (one ``samtools view`` per missing (site, sample), :903).  Here the walk is done once on the host
+without touching any BAM and emits the missing (site, sample) pairs as *queries*; each sample's BAM is then decoded
+once and all of its queries are answered by ONE kernel launch per shard in ``combine_mode`` (a flanking read counts
+toward beta2Simple, :529-536).  Query tables have one-way partner lists (no mutual links), so the library answers them
+with its pair kernel -- same counters.
+
+Order dependence that is kept: the gap-fill of sample ``idx`` sees the strand, partners and competitors
+contributed only by samples with a LOWER index that list the site (:869-904); a stranded gap-fill with no such sample
+has site strand '' and therefore counts nothing.
+"""
+import sys
+from ast import literal_eval
+
+import numpy as np
+
+from . import native, samio, shard
+from .process import open_alignments
+
+HEADER = ("Sample\tRegion\tSite\tStrand\tGene\tSSE\talpha_count\tbeta1_count\tbeta2Simple_count\tbeta2Cryptic_count\t"
+          "beta2_weighted\tPartners\tCompetitors\n")
+
+
+def _log(msg):
+    print(msg)
+    sys.stdout.flush()
+
+
+def read_samples_file(path):
+    """Three tab-separated columns per line: title, .SpliSER.tsv path, BAM path (:750-759)."""
+    titles, tsvs, bams = [], [], []
+    with open(path, "r") as fh:
+        for line in fh:
+            values = line.split("\t")
+            if len(values) == 3:
+                titles.append(values[0])
+                tsvs.append(values[1])
+                bams.append(values[2].rstrip())
+            else:
+                raise Exception("Samples File contains lines that do not have exactly 3 tab-separated columns")
+    return titles, tsvs, bams
+
+
+class _Row(object):
+    __slots__ = ("chrom", "pos", "strand", "gene", "alpha", "beta1", "b2s", "b2c", "b2w", "partners", "competitors")
+
+
+def _parse_tsv(path):
+    rows = []
+    with open(path, "r") as fh:
+        for i, line in enumerate(fh):
+            if i == 0:
+                continue
+            v = line.rstrip().split("\t")
+            r = _Row()
+            r.chrom, r.pos, r.strand, r.gene = v[0], int(v[1]), v[2], v[3]
+            r.alpha, r.beta1, r.b2s = int(v[5]), int(v[6]), int(v[7])
+            r.b2c = None if v[8] == "NA" else int(v[8])
+            r.b2w = None if v[8] == "NA" else float(v[9])
+            r.partners = literal_eval(v[10])
+            r.competitors = literal_eval(v[11])
+            rows.append(r)
+    return rows
+
+
+def region_order(per_sample_rows):
+    """Deduce one order of regions consistent with every file (:761-790): edges between consecutive regions of each
+    file (from an artificial first region), depth-first topological sort in the reference's visiting order."""
+    nodes, before, after = [], [], []
+    for rows in per_sample_rows:
+        prev = "-1"
+        for r in rows:
+            if r.chrom != prev:
+                before.append(prev)
+                after.append(r.chrom)
+                prev = r.chrom
+                if r.chrom not in nodes:
+                    nodes.insert(0, r.chrom)
+    if not nodes:
+        return []
+    nodes.insert(0, "-1")
+    adj = {}
+    for b, a in zip(before, after):
+        lst = adj.setdefault(b, [])
+        if a not in lst:
+            lst.append(a)
+    visited, order = set(), []
+
+    def visit(n):            # recursive like the reference; region counts are small
+        visited.add(n)
+        for m in adj.get(n, ()):
+            if m not in visited:
+                visit(m)
+        order.insert(0, n)
+    for n in nodes:
+        if n not in visited:
+            visit(n)
+    return order[1:]
+
+
+class _Merged(object):
+    __slots__ = ("chrom", "pos", "strand", "gene", "has_row", "alpha", "beta1", "b2s", "b2c", "b2w", "partner_keys",
+                 "partner_counts", "competitors", "queries")
+
+
+def merge_sites(per_sample_rows, chroms, n_samples, is_stranded, q_gene):
+    """The lock-step walk of :820-915 without the BAM access.  -> list of _Merged in output order."""
+    cursor = [0] * n_samples
+    out = []
+    for chrom in chroms:
+        while True:
+            lowest, lowest_strand, gene = -1, "?", ""
+            for idx in range(n_samples):
+                rows = per_sample_rows[idx]
+                if cursor[idx] < len(rows) and rows[cursor[idx]].chrom == chrom:
+                    r = rows[cursor[idx]]
+                    if r.pos < lowest or lowest == -1 or (is_stranded and r.pos == lowest and r.strand == "+"):   # :847
+                        lowest, lowest_strand, gene = r.pos, r.strand, r.gene
+            if lowest == -1:
+                break
+            m = _Merged()
+            m.chrom, m.pos, m.strand, m.gene = chrom, lowest, "", gene
+            m.has_row = [False] * n_samples
+            m.alpha, m.beta1, m.b2s, m.b2c = [0] * n_samples, [0] * n_samples, [0] * n_samples, [0] * n_samples
+            m.b2w = [0.0] * n_samples
+            m.partner_keys, m.partner_counts, m.competitors, m.queries = [], {}, [], []
+            wanted = (q_gene == "All" or q_gene == gene)
+            for idx in range(n_samples):
+                rows = per_sample_rows[idx]
+                r = rows[cursor[idx]] if cursor[idx] < len(rows) else None
+                if r is not None and r.chrom == chrom and r.pos == lowest and (not is_stranded or r.strand == lowest_strand):   # :870
+                    cursor[idx] += 1
+                    m.has_row[idx] = True
+                    m.strand = str(r.strand)
+                    m.alpha[idx] += r.alpha
+                    m.beta1[idx] += r.beta1
+                    m.b2s[idx] += r.b2s
+                    if r.b2c is not None:
+                        m.b2c[idx] += r.b2c
+                        m.b2w[idx] += r.b2w
+                    for key, val in r.partners.items():
+                        if key not in m.partner_counts:
+                            m.partner_counts[key] = [0] * n_samples
+                            m.partner_keys.append(key)
+                        m.partner_counts[key][idx] += val
+                    for c in r.competitors:
+                        if c not in m.competitors:
+                            m.competitors.append(int(c))
+                            m.competitors.sort()
+                elif wanted:
+                    # gap: checkBam on this sample's BAM with the site as it stands NOW (:899-904)
+                    m.queries.append((idx, m.strand, list(m.partner_keys), list(m.competitors)))
+            if wanted:
+                out.append(m)
+    return out
+
+
+def _sse(alpha, beta1, b2s, b2w, cryptic):
+    """calculateSSE (:626-639) for one sample."""
+    betas = beta1 + b2s
+    if cryptic:
+        den = alpha + (betas + b2w)
+    else:
+        den = alpha + betas
+    return (alpha / den) if den > 0.0 else 0.0
+
+
+def gap_queries(merged):
+    """{sample idx: [(site index, chrom, pos, strand, partner keys, competitors), ...]}"""
+    per_sample = {}
+    for si, m in enumerate(merged):
+        for (idx, strand, pkeys, comps) in m.queries:
+            per_sample.setdefault(idx, []).append((si, m.chrom, m.pos, strand, pkeys, comps))
+    return per_sample
+
+
+def query_shards(queries, source):
+    """Pack one sample's queries with that sample's reads.  -> (shards, rows, absent) where rows[k] lists, for
+    shard k, (chrom, [site index per table row]) and ``absent`` the site indices on references the BAM lacks."""
+    by_chrom = {}
+    for q in queries:
+        by_chrom.setdefault(q[1], []).append(q)
+    items, keep, absent = [], {}, []
+    for chrom, qs in by_chrom.items():
+        reads = source.reads(chrom)
+        if reads is None or reads.n == 0:
+            absent.extend(q[0] for q in qs)
+            continue
+        qs.sort(key=lambda q: q[2])
+        items.append((chrom, _query_arrays(chrom, qs), reads))
+        keep[chrom] = [q[0] for q in qs]
+    shards = shard.pack(items) if items else []
+    rows = [[(chrom, keep[chrom]) for chrom in sh.chroms] for sh in shards]
+    return shards, rows, absent
+
+
+def fill_gaps(merged, bam_paths, is_stranded, stranded_type, devices=(0,), threads=0, log=_log):
+    """Answer every (site, sample) query on the GPU: each sample's BAM is decoded once, one combine-mode launch per
+    shard (``spl_count`` with ``combine_mode = 1``).  -> {(site index, sample idx): (beta1, beta2Simple)}"""
+    stranded = native.STRANDED_CODE[stranded_type] if is_stranded else 0
+    results = {}
+    with native.Context(devices[0]) as ctx:
+        for idx, queries in sorted(gap_queries(merged).items()):
+            source = open_alignments(bam_paths[idx], threads=threads)
+            shards, rows, absent = query_shards(queries, source)
+            for si in absent:
+                results[(si, idx)] = (0, 0)
+            for sh, sh_rows in zip(shards, rows):
+                beta1, b2s, _ = ctx.count(sh.sites, sh.reads, stranded, 1)
+                for (chrom, sis), (r0, r1) in zip(sh_rows, sh.site_rows):
+                    for k, si in enumerate(sis):
+                        results[(si, idx)] = (int(beta1[r0 + k]), int(b2s[r0 + k]))
+            if hasattr(source, "close"):
+                source.close()
+    return results
+
+
+class _QueryArrays(object):
+    __slots__ = ("chrom", "n", "pos", "strand", "part_off", "part_pos", "part_site", "edge_cnt", "comp_off", "comp_pos", "alpha")
+
+
+def _query_arrays(chrom, qs):
+    a = _QueryArrays()
+    a.chrom, a.n = chrom, len(qs)
+    a.pos = np.array([q[2] for q in qs], np.int64)
+    a.strand = np.array([ord(q[3][0]) if q[3] else 0 for q in qs], np.uint8)
+    pdeg = np.array([len(q[4]) for q in qs], np.int64)
+    cdeg = np.array([len(q[5]) for q in qs], np.int64)
+    a.part_off = np.zeros(a.n + 1, np.uint32)
+    a.comp_off = np.zeros(a.n + 1, np.uint32)
+    np.cumsum(pdeg, out=a.part_off[1:])
+    np.cumsum(cdeg, out=a.comp_off[1:])
+    a.part_pos = np.array([p for q in qs for p in q[4]], np.int64)
+    a.comp_pos = np.array([c for q in qs for c in q[5]], np.int64)
+    a.part_site = np.full(a.part_pos.shape[0], -1, np.int32)     # one-way lists: the library takes its pair kernel
+    a.edge_cnt = np.zeros(a.part_pos.shape[0], np.int64)
+    a.alpha = np.zeros(a.n, np.int64)
+    return a
+
+
+def write_combined(path, merged, titles, results, cryptic):
+    """outputCombinedLines (:722-740)."""
+    with open(path, "w") as fh:
+        fh.write(HEADER)
+        for si, m in enumerate(merged):
+            comp_txt = "[" + ", ".join(str(c) for c in m.competitors) + "]"
+            for idx, title in enumerate(titles):
+                if m.has_row[idx]:
+                    alpha, beta1, b2s = m.alpha[idx], m.beta1[idx], m.b2s[idx]
+                    sse = _sse(alpha, beta1, b2s, m.b2w[idx], cryptic)
+                else:
+                    alpha = 0
+                    beta1, b2s = results.get((si, idx), (0, 0))
+                    sse = 0.0
+                mid = ("%d\t%s" % (m.b2c[idx], str(m.b2w[idx]))) if cryptic else "NA\tNA"
+                part_txt = "{" + ", ".join("%d: %d" % (k, m.partner_counts[k][idx]) for k in m.partner_keys) + "}"
+                fh.write("%s\t%s\t%d\t%s\t%s\t%s\t%d\t%d\t%d\t%s\t%s\t%s\n" % (
+                    title, m.chrom, m.pos, m.strand, m.gene, "{0:.3f}".format(sse), alpha, beta1, b2s, mid, part_txt, comp_txt))
+
+
+def combine(samplesFile, outputPath, qGene="All", isStranded=False, strandedType="fr", isbeta2Cryptic=False,
+            devices=(0,), threads=0, log=_log):
+    log("Combining samples...")
+    titles, tsvs, bams = read_samples_file(samplesFile)
+    rows = [_parse_tsv(p) for p in tsvs]
+    log("Establishing order of genomic regions.")
+    chroms = region_order(rows)
+    if not chroms:
+        log("No genomic regions found - EXITING")
+        return
+    log("order of genomic regions deduced: {}".format(chroms))
+    log("Iterating through files in parallel, to interleave lines and fill gaps.")
+    merged = merge_sites(rows, chroms, len(titles), isStranded, qGene)
+    n_gap_sites = sum(1 for m in merged if m.queries)
+    results = fill_gaps(merged, bams, isStranded, strandedType, devices=devices, threads=threads, log=log) if n_gap_sites else {}
+    write_combined(outputPath + ".combined.tsv", merged, titles, results, isbeta2Cryptic)
+    log("Filled in Beta read counts for {} Sites not detected in some samples".format(n_gap_sites))

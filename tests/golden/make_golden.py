@@ -304,6 +304,77 @@ def build(outroot, names=None, cross_check=True):
     return manifest
 
 
+# --------------------------------------------------------------------------------------
+# combine / output goldens: three samples of one gene model with sample-specific junctions and reads
+
+
+def combine_case(seed, n_samples=3):
+    reads, juncs, gff = random_case(seed, n_genes=7, n_reads=1500, chroms=("Chr1", "Chr2"))
+    rng = random.Random(seed * 7 + 1)
+    samples = []
+    for k in range(n_samples):
+        jk = [(c, l, r, max(0, sc + rng.randint(-2, 6)), st) for (c, l, r, sc, st) in juncs if rng.random() < 0.72]
+        rk = [r for r in reads if rng.random() < 0.7]
+        samples.append((rk, jk))
+    return samples, gff
+
+
+COMBINE_VARIANTS = {
+    "unstranded": dict(process={}, combine=[]),
+    "fr_cryptic": dict(process={"stranded": "fr", "cryptic": True}, combine=["--isStranded", "-s", "fr", "--beta2Cryptic"]),
+    "annot_gene": dict(process={"gff": True}, combine=["-g", "GChr1_2"]),
+    "rf_crypticlate": dict(process={"stranded": "rf"}, combine=["--isStranded", "-s", "rf", "--beta2Cryptic"]),
+}
+
+
+def build_combine(outroot, name="combine_a", seed=21):
+    samples, gff = combine_case(seed)
+    d = os.path.join(outroot, name)
+    os.makedirs(d, exist_ok=True)
+    for k, (reads, juncs) in enumerate(samples):
+        write_case(os.path.join(d, "sample%d" % k), reads, juncs, gff=gff)
+    manifest = {}
+    for vname, v in COMBINE_VARIANTS.items():
+        tmp = tempfile.mkdtemp()
+        try:
+            lines = []
+            for k in range(len(samples)):
+                sd = os.path.join(d, "sample%d" % k)
+                kw = dict(stranded=v["process"].get("stranded"), cryptic=v["process"].get("cryptic", False),
+                          gff=os.path.join(sd, "genes.gff") if v["process"].get("gff") else None)
+                text, _ = run_reference.run_process(os.path.join(sd, "reads.sam"), os.path.join(sd, "junctions.bed"),
+                                                    os.path.join(tmp, "s%d" % k), inprocess=True, **kw)
+                with open(os.path.join(sd, "expected.%s.tsv" % vname), "w") as fh:
+                    fh.write(text)
+                lines.append("S%d\t%s\t%s\n" % (k, os.path.join(tmp, "s%d.SpliSER.tsv" % k), os.path.join(sd, "reads.sam")))
+            sfile = os.path.join(tmp, "samples.tsv")
+            with open(sfile, "w") as fh:
+                fh.writelines(lines)
+            rc, log = run_reference.run_cli(["combine", "-S", sfile, "-o", os.path.join(tmp, "all")] + v["combine"], inprocess=True)
+            assert rc == 0, log
+            shutil.copy(os.path.join(tmp, "all.combined.tsv"), os.path.join(d, "expected.%s.combined.tsv" % vname))
+            # output -t DiffSpliSER / GWAS on the reference's own combined file
+            rc, log = run_reference.run_cli(["output", "-S", sfile, "-C", os.path.join(tmp, "all.combined.tsv"), "-t", "DiffSpliSER",
+                                             "-o", os.path.join(tmp, "diff_"), "-r", "5"], inprocess=True)
+            assert rc == 0, log
+            shutil.copy(os.path.join(tmp, "diff_All.DiffSpliSER.tsv"), os.path.join(d, "expected.%s.DiffSpliSER.tsv" % vname))
+            gdir = os.path.join(tmp, "gwas") + os.sep
+            os.makedirs(gdir)
+            rc, log = run_reference.run_cli(["output", "-S", sfile, "-C", os.path.join(tmp, "all.combined.tsv"), "-t", "GWAS",
+                                             "-o", gdir, "-r", "5", "-m", "2"], inprocess=True)
+            assert rc == 0, log
+            files = {f: open(os.path.join(gdir, f)).read() for f in sorted(os.listdir(gdir))}
+            with open(os.path.join(d, "expected.%s.GWAS.json" % vname), "w") as fh:
+                json.dump(files, fh, indent=0, sort_keys=True)
+            manifest[vname] = v
+            print("golden %-22s %-22s %4d combined lines, %d GWAS files" % (
+                name, vname, open(os.path.join(d, "expected.%s.combined.tsv" % vname)).read().count("\n") - 1, len(files)))
+        finally:
+            shutil.rmtree(tmp)
+    with open(os.path.join(d, "combine_manifest.json"), "w") as fh:
+        json.dump({"n_samples": len(samples), "variants": manifest}, fh, indent=1, sort_keys=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -318,13 +389,17 @@ def main():
             bad = 0
             for name in sorted(os.listdir(tmp)):
                 cmp = filecmp.dircmp(os.path.join(tmp, name), os.path.join(HERE, name))
-                if cmp.diff_files or cmp.left_only or [f for f in cmp.right_only if not f.startswith("expected.combine")]:
+                if cmp.diff_files or cmp.left_only or cmp.right_only:
                     print("MISMATCH", name, cmp.diff_files, cmp.left_only, cmp.right_only)
                     bad += 1
             sys.exit(1 if bad else 0)
         finally:
             shutil.rmtree(tmp)
-    manifest = build(HERE, a.names)
+    if not a.names or "combine_a" in a.names:
+        build_combine(HERE)
+        if a.names == ["combine_a"]:
+            return
+    manifest = build(HERE, [n for n in a.names if n != "combine_a"] or None)
     mpath = os.path.join(HERE, "manifest.json")
     old = {}
     if a.names and os.path.exists(mpath):
