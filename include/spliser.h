@@ -173,6 +173,11 @@ int64_t spl_bam_n_records(const spl_bam *bam); /* all records, including those w
  * *max_end_out = largest 1-based end coordinate any of them reaches (for shard packing). */
 int spl_bam_reads(const spl_bam *bam, int tid, spl_reads *out, int64_t *max_end_out);
 
+/* Test / synthetic-workload utility (no reference counterpart): write per-reference read sets as a coordinate-ordered
+ * BAM with dummy names, SEQ and QUAL of the query length, BGZF blocks deflated on n_threads (0 = all cores). */
+int spl_bam_write(const char *path, int n_ref, const char *const *ref_names, const int64_t *ref_lengths,
+                  const spl_reads *per_ref, int level, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -164,8 +165,181 @@ struct spl_bam {
 
 namespace {
 
+
+// Where a parsing thread puts what it extracts: (reference id, reads) parts in file order.  A coordinate-sorted BAM
+// changes reference rarely, so "same tid as the last part" is the common case.
+struct Sink {
+    struct Part { int32_t tid; RefReads reads; };
+    std::vector<Part> &parts;
+    explicit Sink(std::vector<Part> &p) : parts(p) {}
+    RefReads &at(int32_t tid)
+    {
+        if (parts.empty() || parts.back().tid != tid) { parts.emplace_back(); parts.back().tid = tid; }
+        return parts.back().reads;
+    }
+};
+
+// Parse alignment records starting at p, which MUST be a record boundary.  Stops at the first boundary >= stop_at
+// (when given) or at the last complete record.  Returns the position reached (a record boundary).
+const uint8_t *parse_records(const uint8_t *p, const uint8_t *end, const uint8_t *stop_at, int n_ref, Sink &sink, int64_t &n_records,
+                             std::string &err, bool &fatal)
+{
+    while (end - p >= 4 && (!stop_at || p < stop_at)) {
+        const uint32_t bs = le32(p);
+        if (bs < 32) { err = "corrupt record (block_size < 32)"; fatal = true; break; }
+        if ((size_t)(end - p) < 4 + (size_t)bs) break;
+        const uint8_t *r = p + 4;
+        const int32_t tid = le32s(r);
+        const int32_t pos0 = le32s(r + 4);
+        const uint32_t l_name = r[8];
+        uint32_t n_cig = le16(r + 12);
+        const uint16_t flag = le16(r + 14);
+        const uint32_t l_seq = le32(r + 16);
+        const size_t fixed = 32;
+        const size_t need = fixed + l_name + 4ull * n_cig + ((size_t)l_seq + 1) / 2 + l_seq;
+        if (need > bs) { err = "corrupt record (fields exceed block_size)"; fatal = true; break; }
+        n_records++;
+        if (tid >= 0 && tid < n_ref && pos0 >= 0) {
+            const uint8_t *cig = r + fixed + l_name;
+            // real CIGAR parked in a CG tag? (htslib bam_tag2cigar)
+            if (n_cig > 0 && (le32(cig) & 15u) == 4u && (le32(cig) >> 4) == l_seq) {
+                uint32_t n_real = 0;
+                const uint8_t *cg = find_cg_tag(r + need, r + bs, &n_real);
+                if (cg && n_real >= n_cig && n_real < (1u << 29)) { cig = cg; n_cig = n_real; }
+            }
+            RefReads &rr = sink.at(tid);
+            int64_t ref_len = 0;
+            const size_t base = rr.cigar.size();
+            rr.cigar.resize(base + n_cig);
+            uint32_t *dst = rr.cigar.data() + base;
+            for (uint32_t k = 0; k < n_cig; ++k) {
+                const uint32_t op = le32(cig + 4ull * k);
+                dst[k] = op;
+                const uint32_t code = op & 15u;
+                if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) ref_len += op >> 4;
+            }
+            rr.pos.push_back(pos0 + 1);
+            rr.flag.push_back(flag);
+            rr.cig_off.push_back((uint32_t)rr.cigar.size());
+            const int64_t e = (int64_t)pos0 + 1 + (ref_len > 0 ? ref_len : 1) - 1;
+            if (e > rr.max_end) rr.max_end = e;
+        }
+        p += 4 + (size_t)bs;
+    }
+    return p;
+}
+
+// Does a record plausibly start at c?  Every fixed field is checked against the BAM specification; the caller also
+// requires the next records to chain.  A false positive only costs time: the chunk results are accepted only when
+// every chunk's walk ends exactly on the next chunk's start (see parse_segment_parallel).
+bool plausible_record(const uint8_t *c, const uint8_t *end, int n_ref, size_t *len_out)
+{
+    if (end - c < 36) return false;
+    const uint32_t bs = le32(c);
+    if (bs < 33 || bs > (1u << 29)) return false;
+    const uint8_t *r = c + 4;
+    const int32_t tid = le32s(r), pos0 = le32s(r + 4);
+    const uint32_t l_name = r[8];
+    const uint32_t n_cig = le16(r + 12);
+    const int32_t l_seq = le32s(r + 16), next_tid = le32s(r + 20), next_pos = le32s(r + 24);
+    if (tid < -1 || tid >= n_ref || next_tid < -1 || next_tid >= n_ref || pos0 < -1 || next_pos < -1 || l_seq < 0 || l_name < 1) return false;
+    const size_t need = 32 + (size_t)l_name + 4ull * n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    if (need > bs) return false;
+    if ((size_t)(end - c) >= 4 + 32 + (size_t)l_name) {
+        const uint8_t *name = r + 32;
+        if (name[l_name - 1] != 0) return false;
+        for (uint32_t i = 0; i + 1 < l_name; ++i) if (name[i] < 33 || name[i] > 126) return false;
+    }
+    *len_out = 4 + (size_t)bs;
+    return true;
+}
+
+const uint8_t *find_record_start(const uint8_t *from, const uint8_t *end, int n_ref)
+{
+    for (const uint8_t *c = from; c + 36 <= end; ++c) {
+        size_t len = 0;
+        if (!plausible_record(c, end, n_ref, &len)) continue;
+        const uint8_t *q = c + len;
+        bool ok = true;
+        for (int k = 0; k < 3 && ok && q + 36 <= end; ++k) { // the next three records must chain
+            size_t l2 = 0;
+            ok = plausible_record(q, end, n_ref, &l2);
+            q += l2;
+        }
+        if (ok) return c;
+    }
+    return end;
+}
+
+void merge_parts(spl_bam *bam, std::vector<Sink::Part> &parts)
+{
+    for (Sink::Part &pt : parts) {
+        RefReads &dst = bam->refs[(size_t)pt.tid];
+        RefReads &src = pt.reads;
+        const uint32_t base = (uint32_t)dst.cigar.size();
+        dst.pos.insert(dst.pos.end(), src.pos.begin(), src.pos.end());
+        dst.flag.insert(dst.flag.end(), src.flag.begin(), src.flag.end());
+        dst.cigar.insert(dst.cigar.end(), src.cigar.begin(), src.cigar.end());
+        const size_t n0 = dst.cig_off.size();
+        dst.cig_off.resize(n0 + src.cig_off.size() - 1);
+        for (size_t k = 1; k < src.cig_off.size(); ++k) dst.cig_off[n0 + k - 1] = base + src.cig_off[k];
+        if (src.max_end > dst.max_end) dst.max_end = src.max_end;
+    }
+}
+
+// Parse the records of one inflated segment on several threads.  Thread t looks for the first record boundary at or
+// after its nominal start (plausibility + chaining), parses to the first boundary at or after its nominal end, and
+// the results are accepted only if every walk ends exactly where the next one started -- by induction from the known
+// true boundary at the segment start, every accepted start is then a true boundary.  Otherwise: one thread.
+const uint8_t *parse_segment_parallel(spl_bam *bam, const uint8_t *p, const uint8_t *end, int n_threads, std::string &err, bool &fatal)
+{
+    const int n_ref = (int)bam->refs.size();
+    const size_t bytes = (size_t)(end - p);
+    int T = n_threads > 16 ? 16 : n_threads;
+    if (bytes < (size_t)(8u << 20) || T < 2) T = 1;
+    std::vector<std::vector<Sink::Part>> parts((size_t)T);
+    std::vector<const uint8_t *> start((size_t)T + 1), reached((size_t)T);
+    std::vector<int64_t> nrec((size_t)T, 0);
+    std::vector<std::string> errs((size_t)T);
+    std::vector<char> fat((size_t)T, 0);
+    start[0] = p;
+    start[(size_t)T] = end;
+    auto work = [&](int t) {
+        const uint8_t *nominal_start = p + bytes / (size_t)T * (size_t)t;
+        const uint8_t *nominal_end = (t + 1 == T) ? nullptr : p + bytes / (size_t)T * (size_t)(t + 1);
+        if (t > 0) start[(size_t)t] = find_record_start(nominal_start, end, n_ref);
+        Sink sink(parts[(size_t)t]);
+        bool f = false;
+        reached[(size_t)t] = parse_records(start[(size_t)t], end, nominal_end, n_ref, sink, nrec[(size_t)t], errs[(size_t)t], f);
+        fat[(size_t)t] = f ? 1 : 0;
+    };
+    if (T > 1) {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+    } else {
+        work(0);
+    }
+    bool consistent = true;
+    for (int t = 0; t + 1 < T; ++t) consistent &= (reached[(size_t)t] == start[(size_t)t + 1]) && !fat[(size_t)t];
+    if (!consistent) { // a guessed boundary was wrong (or the data is corrupt): redo sequentially, authoritative
+        std::vector<Sink::Part> seq;
+        Sink sink(seq);
+        int64_t n = 0;
+        const uint8_t *r = parse_records(p, end, nullptr, n_ref, sink, n, err, fatal);
+        merge_parts(bam, seq);
+        bam->n_records += n;
+        return r;
+    }
+    if (fat[(size_t)T - 1]) { err = errs[(size_t)T - 1]; fatal = true; }
+    for (int t = 0; t < T; ++t) { merge_parts(bam, parts[(size_t)t]); bam->n_records += nrec[(size_t)t]; }
+    return reached[(size_t)T - 1];
+}
+
 struct Parser {
     spl_bam *bam;
+    int n_threads = 1;
     bool header_done = false;
     std::string err;
 
@@ -200,49 +374,7 @@ struct Parser {
             header_done = true;
             p = q;
         }
-        while (end - p >= 4) {
-            const uint32_t bs = le32(p);
-            if (bs < 32) { err = "corrupt record (block_size < 32)"; fatal = true; break; }
-            if ((size_t)(end - p) < 4 + (size_t)bs) break;
-            const uint8_t *r = p + 4;
-            const int32_t tid = le32s(r);
-            const int32_t pos0 = le32s(r + 4);
-            const uint32_t l_name = r[8];
-            uint32_t n_cig = le16(r + 12);
-            const uint16_t flag = le16(r + 14);
-            const uint32_t l_seq = le32(r + 16);
-            const size_t fixed = 32;
-            const size_t need = fixed + l_name + 4ull * n_cig + ((size_t)l_seq + 1) / 2 + l_seq;
-            if (need > bs) { err = "corrupt record (fields exceed block_size)"; fatal = true; break; }
-            bam->n_records++;
-            if (tid >= 0 && (size_t)tid < bam->refs.size() && pos0 >= 0) {
-                const uint8_t *cig = r + fixed + l_name;
-                // real CIGAR parked in a CG tag? (htslib bam_tag2cigar)
-                if (n_cig > 0 && (le32(cig) & 15u) == 4u && (le32(cig) >> 4) == l_seq) {
-                    uint32_t n_real = 0;
-                    const uint8_t *cg = find_cg_tag(r + need, r + bs, &n_real);
-                    if (cg && n_real >= n_cig && n_real < (1u << 29)) { cig = cg; n_cig = n_real; }
-                }
-                RefReads &rr = bam->refs[(size_t)tid];
-                int64_t ref_len = 0;
-                const size_t base = rr.cigar.size();
-                rr.cigar.resize(base + n_cig);
-                uint32_t *dst = rr.cigar.data() + base;
-                for (uint32_t k = 0; k < n_cig; ++k) {
-                    const uint32_t op = le32(cig + 4ull * k);
-                    dst[k] = op;
-                    const uint32_t code = op & 15u;
-                    if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) ref_len += op >> 4;
-                }
-                if (rr.cigar.size() > 0xfffffff0ull) { err = "more than 2^32 CIGAR ops on one reference"; fatal = true; break; }
-                rr.pos.push_back(pos0 + 1);
-                rr.flag.push_back(flag);
-                rr.cig_off.push_back((uint32_t)rr.cigar.size());
-                const int64_t e = (int64_t)pos0 + 1 + (ref_len > 0 ? ref_len : 1) - 1;
-                if (e > rr.max_end) rr.max_end = e;
-            }
-            p += 4 + (size_t)bs;
-        }
+        p = parse_segment_parallel(bam, p, end, n_threads, err, fatal);
         return (size_t)(p - start);
     }
 };
@@ -311,8 +443,13 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
     size_t carry = 0; // bytes of an incomplete record kept at the front of buf
     Parser parser;
     parser.bam = bam;
+    parser.n_threads = n_threads;
     std::string fail;
+    const bool timing = getenv("SPL_BAM_TIMING") != nullptr;
+    double t_inflate = 0, t_parse = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t b0 = 0; b0 < blocks.size() && fail.empty(); b0 += SEG_BLOCKS) {
+        const double t0 = now();
         const size_t b1 = std::min(blocks.size(), b0 + SEG_BLOCKS);
         std::vector<size_t> uoff(b1 - b0 + 1);
         uoff[0] = carry;
@@ -336,13 +473,17 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
         work();
         for (auto &t : pool) t.join();
         if (bad.load()) { fail = "inflate or CRC32 failure in a BGZF block (corrupt file)"; break; }
+        const double t1 = now();
         bool fatal = false;
         const size_t used = parser.feed(buf.data(), buf.data() + total, fatal);
+        t_inflate += t1 - t0;
+        t_parse += now() - t1;
         if (fatal) { fail = parser.err; break; }
         carry = total - used;
         if (carry) memmove(buf.data(), buf.data() + used, carry);
     }
     munmap(map, fsize);
+    if (timing) fprintf(stderr, "[spl_bam_open] %zu blocks, %d threads: inflate %.3f s, parse %.3f s\n", blocks.size(), n_threads, t_inflate, t_parse);
     if (fail.empty() && !parser.header_done) fail = "no BAM header found";
     if (fail.empty() && carry != 0) fail = "file ends inside a record (truncated)";
     if (!fail.empty()) {
@@ -379,4 +520,122 @@ extern "C" int spl_bam_reads(const spl_bam *bam, int tid, spl_reads *out, int64_
     out->cigar = rr.cigar.data();
     if (max_end_out) *max_end_out = rr.max_end;
     return SPL_OK;
+}
+
+// ---- BAM writer (synthetic workloads, tests): the inverse of the reader above -------------------------------------
+// Records carry a dummy read name, SEQ and QUAL of the query length so that the file has the size and block structure
+// of a real BAM; BGZF blocks are deflated in parallel.  Only what spl_bam_open reads back is meaningful.
+namespace {
+
+struct OutBlock { std::vector<uint8_t> raw, comp; };
+
+void put32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+void put16(std::vector<uint8_t> &v, uint32_t x) { v.push_back((uint8_t)x); v.push_back((uint8_t)(x >> 8)); }
+
+bool deflate_block(OutBlock &b, int level)
+{
+    const size_t n = b.raw.size();
+    b.comp.resize(n + n / 8 + 64);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    zs.next_in = b.raw.data(); zs.avail_in = (uInt)n;
+    zs.next_out = b.comp.data() + 18; zs.avail_out = (uInt)(b.comp.size() - 18 - 8);
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) return false;
+    const size_t bsize = 18 + clen + 8;
+    if (bsize > 65536) return false;
+    static const uint8_t head[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
+    memcpy(b.comp.data(), head, 12);
+    b.comp[12] = 'B'; b.comp[13] = 'C'; b.comp[14] = 2; b.comp[15] = 0;
+    b.comp[16] = (uint8_t)((bsize - 1) & 0xff); b.comp[17] = (uint8_t)((bsize - 1) >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), b.raw.data(), (uInt)n);
+    uint8_t *t = b.comp.data() + 18 + clen;
+    for (int i = 0; i < 4; ++i) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i)); }
+    b.comp.resize(bsize);
+    return true;
+}
+
+} // namespace
+
+extern "C" int spl_bam_write(const char *path, int n_ref, const char *const *ref_names, const int64_t *ref_lengths,
+                             const spl_reads *per_ref, int level, int n_threads)
+{
+    if (!path || n_ref < 0 || (n_ref && (!ref_names || !ref_lengths || !per_ref))) return spl_set_error(SPL_ERR_ARG, "spl_bam_write: bad argument");
+    FILE *fh = fopen(path, "wb");
+    if (!fh) return spl_set_error(SPL_ERR_IO, "cannot create %s", path);
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    const size_t BLOCK = 0xff00, BATCH = 2048;
+    std::vector<OutBlock> batch;
+    std::vector<uint8_t> cur;
+    cur.reserve(BLOCK + 1024);
+    int rc = SPL_OK;
+    auto flush_batch = [&]() {
+        std::atomic<size_t> next(0);
+        std::atomic<bool> bad(false);
+        auto work = [&]() { for (;;) { size_t i = next.fetch_add(1); if (i >= batch.size()) break; if (!deflate_block(batch[i], level)) bad.store(true); } };
+        std::vector<std::thread> pool;
+        const int nt = (int)std::min<size_t>((size_t)n_threads, batch.size());
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        if (bad.load()) { rc = spl_set_error(SPL_ERR_IO, "deflate failed while writing %s", path); }
+        for (auto &b : batch) if (rc == SPL_OK && fwrite(b.comp.data(), 1, b.comp.size(), fh) != b.comp.size()) rc = spl_set_error(SPL_ERR_IO, "short write to %s", path);
+        batch.clear();
+    };
+    auto cut = [&](bool force) {
+        while (cur.size() >= BLOCK || (force && !cur.empty())) {
+            OutBlock b;
+            const size_t n = std::min(cur.size(), BLOCK);
+            b.raw.assign(cur.begin(), cur.begin() + n);
+            cur.erase(cur.begin(), cur.begin() + n);
+            batch.push_back(std::move(b));
+            if (batch.size() >= BATCH) flush_batch();
+        }
+    };
+    // header
+    std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+    for (int i = 0; i < n_ref; ++i) text += std::string("@SQ\tSN:") + ref_names[i] + "\tLN:" + std::to_string((long long)ref_lengths[i]) + "\n";
+    cur.insert(cur.end(), {'B', 'A', 'M', 1});
+    put32(cur, (uint32_t)text.size());
+    cur.insert(cur.end(), text.begin(), text.end());
+    put32(cur, (uint32_t)n_ref);
+    for (int i = 0; i < n_ref; ++i) {
+        const size_t ln = strlen(ref_names[i]) + 1;
+        put32(cur, (uint32_t)ln);
+        cur.insert(cur.end(), ref_names[i], ref_names[i] + ln);
+        put32(cur, (uint32_t)ref_lengths[i]);
+    }
+    uint64_t serial = 0;
+    for (int tid = 0; tid < n_ref && rc == SPL_OK; ++tid) {
+        const spl_reads &r = per_ref[tid];
+        for (int64_t k = 0; k < r.n_reads && rc == SPL_OK; ++k) {
+            const uint32_t o0 = r.cig_off[k], n_ops = r.cig_off[k + 1] - o0;
+            uint32_t qlen = 0;
+            for (uint32_t j = 0; j < n_ops; ++j) { const uint32_t c = r.cigar[o0 + j] & 15u; if (c == 0 || c == 1 || c == 4 || c == 7 || c == 8) qlen += r.cigar[o0 + j] >> 4; }
+            char name[24];
+            const int l_name = snprintf(name, sizeof(name), "r%llu", (unsigned long long)serial++) + 1;
+            const uint32_t bs = 32 + (uint32_t)l_name + 4 * n_ops + (qlen + 1) / 2 + qlen;
+            put32(cur, bs);
+            put32(cur, (uint32_t)tid);
+            put32(cur, (uint32_t)(r.pos[k] - 1));
+            cur.push_back((uint8_t)l_name); cur.push_back(60);
+            put16(cur, 4680); put16(cur, n_ops); put16(cur, r.flag[k]);
+            put32(cur, qlen); put32(cur, 0xffffffffu); put32(cur, 0xffffffffu); put32(cur, 0);
+            cur.insert(cur.end(), name, name + l_name);
+            for (uint32_t j = 0; j < n_ops; ++j) put32(cur, r.cigar[o0 + j]);
+            cur.insert(cur.end(), (qlen + 1) / 2, (uint8_t)0x12);
+            cur.insert(cur.end(), qlen, (uint8_t)30);
+            if (cur.size() >= BLOCK) cut(false);
+        }
+    }
+    cut(true);
+    if (!batch.empty()) flush_batch();
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (rc == SPL_OK && fwrite(eof, 1, 28, fh) != 28) rc = spl_set_error(SPL_ERR_IO, "short write to %s", path);
+    fclose(fh);
+    return rc;
 }

@@ -48,7 +48,7 @@ EXPORTS = [
     "spl_sync", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_close",
-    "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads",
+    "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write",
 ]
 
 _lib = None
@@ -282,6 +282,20 @@ def algorithmic_bytes(dsites, dreads):
     out = ctypes.c_int64(0)
     _check(lib().spl_count_algorithmic_bytes(dsites._h, dreads._h, ctypes.byref(out)))
     return out.value
+
+
+def write_bam(path, ref_names, ref_lengths, read_sets, level=1, threads=0):
+    """Fast native BAM writer for synthetic workloads: read_sets[i] = samio.ReadSet of reference i."""
+    n = len(ref_names)
+    names = (ctypes.c_char_p * n)(*[s.encode("ascii") for s in ref_names])
+    lens = (ctypes.c_int64 * n)(*[int(v) for v in ref_lengths])
+    arr = (spl_reads * n)()
+    keep = []
+    for i, rs in enumerate(read_sets):
+        ra = ReadArrays(rs.pos, rs.flag, rs.cig_off, rs.cigar)
+        keep.append(ra)
+        arr[i] = ra.c
+    _check(lib().spl_bam_write(os.fsencode(path), ctypes.c_int(n), names, lens, arr, ctypes.c_int(level), ctypes.c_int(threads)))
 
 
 class BamFile(object):
