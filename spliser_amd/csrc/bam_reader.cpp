@@ -295,7 +295,7 @@ const uint8_t *parse_segment_parallel(spl_bam *bam, const uint8_t *p, const uint
 {
     const int n_ref = (int)bam->refs.size();
     const size_t bytes = (size_t)(end - p);
-    int T = n_threads > 16 ? 16 : n_threads;
+    int T = n_threads > 32 ? 32 : n_threads;
     if (bytes < (size_t)(8u << 20) || T < 2) T = 1;
     std::vector<std::vector<Sink::Part>> parts((size_t)T);
     std::vector<const uint8_t *> start((size_t)T + 1), reached((size_t)T);
@@ -437,27 +437,26 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads <= 0) n_threads = 1;
 
-    // 2. segments of blocks: parallel inflate, then one sequential field-extraction pass.
-    const size_t SEG_BLOCKS = 4096; // <= 256 MiB uncompressed
-    std::vector<uint8_t> buf;
-    size_t carry = 0; // bytes of an incomplete record kept at the front of buf
-    Parser parser;
-    parser.bam = bam;
-    parser.n_threads = n_threads;
-    std::string fail;
+    // 2. segments of blocks, double-buffered: while the records of segment k are being extracted (parse threads), the
+    //    blocks of segment k+1 are already being inflated (inflate threads).
+    const size_t SEG_BLOCKS = 2048; // <= 128 MiB uncompressed
+    const size_t HEAD = 4u << 20;   // room in front of a segment for the incomplete record carried over from the previous one
+    const size_t n_seg = (blocks.size() + SEG_BLOCKS - 1) / SEG_BLOCKS;
+    std::vector<uint8_t> bufs[2];
+    size_t seg_bytes[2] = {0, 0};
+    std::atomic<bool> bad(false);
     const bool timing = getenv("SPL_BAM_TIMING") != nullptr;
-    double t_inflate = 0, t_parse = 0;
+    double t_wait = 0, t_parse = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    for (size_t b0 = 0; b0 < blocks.size() && fail.empty(); b0 += SEG_BLOCKS) {
-        const double t0 = now();
-        const size_t b1 = std::min(blocks.size(), b0 + SEG_BLOCKS);
+    auto inflate_segment = [&](size_t seg) {
+        const size_t b0 = seg * SEG_BLOCKS, b1 = std::min(blocks.size(), b0 + SEG_BLOCKS);
         std::vector<size_t> uoff(b1 - b0 + 1);
-        uoff[0] = carry;
+        uoff[0] = HEAD;
         for (size_t i = b0; i < b1; ++i) uoff[i - b0 + 1] = uoff[i - b0] + blocks[i].isize;
-        const size_t total = uoff[b1 - b0];
-        if (buf.size() < total) buf.resize(total);
+        std::vector<uint8_t> &buf = bufs[seg & 1];
+        if (buf.size() < uoff[b1 - b0]) buf.resize(uoff[b1 - b0]);
+        seg_bytes[seg & 1] = uoff[b1 - b0] - HEAD;
         std::atomic<size_t> next(b0);
-        std::atomic<bool> bad(false);
         auto work = [&]() {
             void *ld = deflate_lib().ok ? deflate_lib().alloc() : nullptr;
             for (;;) {
@@ -472,18 +471,46 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
         for (int t = 1; t < nt; ++t) pool.emplace_back(work);
         work();
         for (auto &t : pool) t.join();
+    };
+    Parser parser;
+    parser.bam = bam;
+    parser.n_threads = n_threads;
+    std::string fail;
+    std::vector<uint8_t> carry_bytes;
+    size_t carry = 0;
+    inflate_segment(0);
+    for (size_t seg = 0; seg < n_seg && fail.empty(); ++seg) {
         if (bad.load()) { fail = "inflate or CRC32 failure in a BGZF block (corrupt file)"; break; }
-        const double t1 = now();
+        std::thread ahead;
+        if (seg + 1 < n_seg) ahead = std::thread(inflate_segment, seg + 1);
+        const double t0 = now();
+        std::vector<uint8_t> &buf = bufs[seg & 1];
+        uint8_t *begin = buf.data() + HEAD;
+        const size_t total = seg_bytes[seg & 1];
+        std::vector<uint8_t> joined;
+        const uint8_t *p0 = begin, *p1 = begin + total;
+        if (carry) {
+            if (carry <= HEAD) { memcpy(begin - carry, carry_bytes.data(), carry); p0 = begin - carry; }
+            else { // a record larger than the head room: splice into a fresh buffer
+                joined.resize(carry + total);
+                memcpy(joined.data(), carry_bytes.data(), carry);
+                memcpy(joined.data() + carry, begin, total);
+                p0 = joined.data(); p1 = joined.data() + joined.size();
+            }
+        }
         bool fatal = false;
-        const size_t used = parser.feed(buf.data(), buf.data() + total, fatal);
-        t_inflate += t1 - t0;
-        t_parse += now() - t1;
-        if (fatal) { fail = parser.err; break; }
-        carry = total - used;
-        if (carry) memmove(buf.data(), buf.data() + used, carry);
+        const size_t used = parser.feed(p0, p1, fatal);
+        if (fatal) fail = parser.err;
+        carry = (size_t)(p1 - p0) - used;
+        carry_bytes.assign(p0 + used, p1);
+        const double t1 = now();
+        if (ahead.joinable()) ahead.join();
+        t_parse += t1 - t0;
+        t_wait += now() - t1;
     }
+    if (fail.empty() && bad.load()) fail = "inflate or CRC32 failure in a BGZF block (corrupt file)";
     munmap(map, fsize);
-    if (timing) fprintf(stderr, "[spl_bam_open] %zu blocks, %d threads: inflate %.3f s, parse %.3f s\n", blocks.size(), n_threads, t_inflate, t_parse);
+    if (timing) fprintf(stderr, "[spl_bam_open] %zu blocks, %d threads: parse %.3f s, waiting for inflate %.3f s\n", blocks.size(), n_threads, t_parse, t_wait);
     if (fail.empty() && !parser.header_done) fail = "no BAM header found";
     if (fail.empty() && carry != 0) fail = "file ends inside a record (truncated)";
     if (!fail.empty()) {
