@@ -434,7 +434,10 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
 
     spl_bam *bam = new (std::nothrow) spl_bam();
     if (!bam) { munmap(map, fsize); return spl_set_error(SPL_ERR_NOMEM, "out of host memory"); }
-    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) { // default: all cores up to 32 (beyond that thread start-up per segment costs more than it buys)
+        n_threads = (int)std::thread::hardware_concurrency();
+        if (n_threads > 32) n_threads = 32;
+    }
     if (n_threads <= 0) n_threads = 1;
 
     // 2. segments of blocks, double-buffered: while the records of segment k are being extracted (parse threads), the
