@@ -183,6 +183,14 @@ def main():
     ctx.close()
 
     if rank == 0:
+        # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from the committed
+        # rocprofv3 --pmc passes of the same command (profiles/), and only for the exact workload they were measured on.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01c_traffic.json")
+        if (args.workload == "arabidopsis" and args.scale == 1.0 and args.kernel == "ranges" and not stranded
+                and args.alt_fraction is None and os.path.exists(tpath)):
+            with open(tpath) as fh:
+                traffic = json.load(fh)["hbm_bytes_per_launch"]
         k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         # one step = len(dev) launches; bytes per launch and time per launch are both averaged over launches
         bytes_per_launch = alg_bytes / max(len(dev), 1)
@@ -200,7 +208,7 @@ def main():
                                    % (args.workload, n_reads, n_sites, len(items), len(dev), stranded or "unstranded"),
                        "scale": args.scale, "parallelism": "chromosome/sample shards, no collectives", "seed": cfg["seed"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "spl_count_%s_kernel" % args.kernel.split("_")[0], "kernel_ms_avg": k_avg_ms, "launches_timed": len(kernel_ms),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"]},
