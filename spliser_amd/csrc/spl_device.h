@@ -12,7 +12,7 @@
 #define SPL_WIN 1024                     // site rows whose counters a workgroup privatises in LDS
 #define SPL_INLINE_OPS 3                 // CIGAR ops per read resolved in the straight-line part (M N M = 3)
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
-#define SPL_LITERAL_WAVES 4096           // one-wave workgroups of the literal kernel (grid-stride over the queue)
+#define SPL_LITERAL_WAVES 8192           // one-wave workgroups of the literal kernel (grid-stride over the queue)
 #define SPL_SCAN_BLOCK 1024              // distinct positions per workgroup in the difference-array scan
 
 // Coordinates (read end, site position) must stay <= SPL_COORD_MAX so that t+1 and cur never wrap int32.

@@ -897,24 +897,32 @@ template <bool STRANDED>
 __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_params p, const uint32_t *queue, const uint32_t *queue_n,
                                                                 uint32_t queue_cap)
 {
-    for (uint32_t shard = 0; shard < 8u; ++shard) {
-        const uint32_t n = queue_n[shard];
-        const uint32_t *q = queue + (size_t)shard * queue_cap;
-        for (uint32_t j = blockIdx.x * 64u + threadIdx.x; j < n; j += gridDim.x * 64u) {
-            const int64_t i = q[j];
-            const int32_t pos = p.r_pos[i];
-            const uint32_t flag = p.r_flag[i];
-            const uint32_t o0 = p.cig_off[i];
-            const uint32_t n_ops = p.cig_off[i + 1] - o0;
-            const uint32_t *ops = p.cigar + o0;
-            int64_t ref_len; bool hn;
-            spl_read_extent(ops, n_ops, &ref_len, &hn);
-            if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
-            if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
-            if (rivals_table_path<STRANDED>(p, pos, flag, ops, n_ops)) continue;
-            if (rivals_closed_form<STRANDED>(p, pos, flag, ops, n_ops)) continue;
-            rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
-        }
+    // the 8 shard regions are walked as ONE index space (a wave must not pay the latency chain once per shard)
+    uint32_t start[9];
+    start[0] = 0;
+#pragma unroll
+    for (int sh = 0; sh < 8; ++sh) start[sh + 1] = start[sh] + queue_n[sh];
+    const uint32_t total = start[8];
+    for (uint32_t g = blockIdx.x * 64u + threadIdx.x; g < total; g += gridDim.x * 64u) {
+        uint32_t shard = 0;
+#pragma unroll
+        for (int sh = 1; sh < 8; ++sh) shard += (g >= start[sh]) ? 1u : 0u;
+        uint32_t base = 0;
+#pragma unroll
+        for (int sh = 0; sh < 8; ++sh) base = (shard == (uint32_t)sh) ? start[sh] : base;
+        const int64_t i = queue[(size_t)shard * queue_cap + (g - base)];
+        const int32_t pos = p.r_pos[i];
+        const uint32_t flag = p.r_flag[i];
+        const uint32_t o0 = p.cig_off[i];
+        const uint32_t n_ops = p.cig_off[i + 1] - o0;
+        const uint32_t *ops = p.cigar + o0;
+        int64_t ref_len; bool hn;
+        spl_read_extent(ops, n_ops, &ref_len, &hn);
+        if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
+        if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
+        if (rivals_table_path<STRANDED>(p, pos, flag, ops, n_ops)) continue;
+        if (rivals_closed_form<STRANDED>(p, pos, flag, ops, n_ops)) continue;
+        rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
     }
 }
 
