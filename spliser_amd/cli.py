@@ -45,6 +45,17 @@ def build_parser():
     c.add_argument("-s", "--strandedType", dest="strandedType", nargs="?", default="fr", type=str, required=False)
     c.add_argument("--beta2Cryptic", dest="isbeta2Cryptic", default=False, action="store_true")
     _engine_flags(c)
+    h = sub.add_parser("combineShallow")
+    h.add_argument("-S", "--samplesFile", dest="samplesFile", required=True)
+    h.add_argument("-g", "--gene", dest="qGene", nargs="?", default="All", type=str, required=False)
+    h.add_argument("-o", "--outputPath", dest="outputPath", required=True)
+    h.add_argument("--isStranded", dest="isStranded", default=False, action="store_true")
+    h.add_argument("-m", "--minSamples", dest="minSamples", required=False, nargs="?", default=0, type=int)
+    h.add_argument("-r", "--minReads", dest="minReads", required=False, nargs="?", default=10, type=int)
+    h.add_argument("-e", "--minSSE", dest="minSSE", required=False, nargs="?", default=0.00, type=float)
+    h.add_argument("-s", "--strandedType", dest="strandedType", nargs="?", type=str, required=False)
+    h.add_argument("--beta2Cryptic", dest="isbeta2Cryptic", default=False, action="store_true")
+    _engine_flags(h)
     o = sub.add_parser("output")
     o.add_argument("-S", "--samplesFile", dest="samplesFile", required=True)
     o.add_argument("-C", "--combinedFile", dest="combinedFile", required=True)
@@ -87,6 +98,9 @@ def main(argv=None):
     elif command == "combine":
         from .combine import combine
         combine(devices=devices, threads=threads, **kwargs)
+    elif command == "combineShallow":
+        from .combine import combineShallow
+        combineShallow(devices=devices, threads=threads, **kwargs)
     elif command == "output":
         from .output import output
         output(**kwargs)

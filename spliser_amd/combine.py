@@ -31,8 +31,9 @@ def _log(msg):
     sys.stdout.flush()
 
 
-def read_samples_file(path):
-    """Three tab-separated columns per line: title, .SpliSER.tsv path, BAM path (:750-759)."""
+def read_samples_file(path, strict=True):
+    """Three tab-separated columns per line: title, .SpliSER.tsv path, BAM path (:750-759).  ``combine`` rejects
+    any other line; ``combineShallow`` skips it (:929-935)."""
     titles, tsvs, bams = [], [], []
     with open(path, "r") as fh:
         for line in fh:
@@ -41,13 +42,13 @@ def read_samples_file(path):
                 titles.append(values[0])
                 tsvs.append(values[1])
                 bams.append(values[2].rstrip())
-            else:
+            elif strict:
                 raise Exception("Samples File contains lines that do not have exactly 3 tab-separated columns")
     return titles, tsvs, bams
 
 
 class _Row(object):
-    __slots__ = ("chrom", "pos", "strand", "gene", "alpha", "beta1", "b2s", "b2c", "b2w", "partners", "competitors")
+    __slots__ = ("chrom", "pos", "strand", "gene", "sse", "alpha", "beta1", "b2s", "b2c", "b2w", "partners", "competitors")
 
 
 def _parse_tsv(path):
@@ -59,6 +60,7 @@ def _parse_tsv(path):
             v = line.rstrip().split("\t")
             r = _Row()
             r.chrom, r.pos, r.strand, r.gene = v[0], int(v[1]), v[2], v[3]
+            r.sse = float(v[4])
             r.alpha, r.beta1, r.b2s = int(v[5]), int(v[6]), int(v[7])
             r.b2c = None if v[8] == "NA" else int(v[8])
             r.b2w = None if v[8] == "NA" else float(v[9])
@@ -108,21 +110,40 @@ class _Merged(object):
                  "partner_counts", "competitors", "queries")
 
 
-def merge_sites(per_sample_rows, chroms, n_samples, is_stranded, q_gene):
-    """The lock-step walk of :820-915 without the BAM access.  -> list of _Merged in output order."""
+def merge_sites(per_sample_rows, chroms, n_samples, is_stranded, q_gene, shallow=None, log=None):
+    """The lock-step walk of ``combine`` (:820-915) -- or, with ``shallow = (minSamples, minReads, minSSE)``, of
+    ``combineShallow`` (:1007-1166) -- without the BAM access.  -> list of _Merged in output order."""
     cursor = [0] * n_samples
     out = []
     for chrom in chroms:
         while True:
-            lowest, lowest_strand, gene = -1, "?", ""
+            lowest, lowest_strand, gene, seen = -1, "?", "", 0
             for idx in range(n_samples):
                 rows = per_sample_rows[idx]
                 if cursor[idx] < len(rows) and rows[cursor[idx]].chrom == chrom:
                     r = rows[cursor[idx]]
-                    if r.pos < lowest or lowest == -1 or (is_stranded and r.pos == lowest and r.strand == "+"):   # :847
-                        lowest, lowest_strand, gene = r.pos, r.strand, r.gene
+                    if shallow is None:
+                        if r.pos < lowest or lowest == -1 or (is_stranded and r.pos == lowest and r.strand == "+"):   # :847
+                            lowest, lowest_strand, gene = r.pos, r.strand, r.gene
+                    else:
+                        good = (r.alpha + r.beta1 + r.b2s) >= shallow[1] and r.sse >= shallow[2]
+                        if r.pos < lowest or lowest == -1 or (is_stranded and r.pos == lowest and r.strand != lowest_strand and r.strand == "+"):   # :1066
+                            lowest, lowest_strand, gene = r.pos, r.strand, r.gene
+                            seen = 1 if good else 0      # a new lowest position restarts the tally (:1071-1077)
+                        elif r.pos == lowest and good:   # whatever the strand (:1079-1084)
+                            seen += 1
             if lowest == -1:
                 break
+            if shallow is not None and seen < shallow[0]:
+                # not enough samples with evidence: drop it from every file whose next line has this POSITION -- the
+                # reference compares the number only, not region or strand (:1150-1156)
+                if log:
+                    log("Skipped site {} for insufficient evidence, only {} samples with Site using minimum reads".format(lowest, seen))
+                for idx in range(n_samples):
+                    rows = per_sample_rows[idx]
+                    if cursor[idx] < len(rows) and rows[cursor[idx]].pos == lowest:
+                        cursor[idx] += 1
+                continue
             m = _Merged()
             m.chrom, m.pos, m.strand, m.gene = chrom, lowest, "", gene
             m.has_row = [False] * n_samples
@@ -264,9 +285,9 @@ def write_combined(path, merged, titles, results, cryptic):
 
 
 def combine(samplesFile, outputPath, qGene="All", isStranded=False, strandedType="fr", isbeta2Cryptic=False,
-            devices=(0,), threads=0, log=_log):
+            devices=(0,), threads=0, log=_log, shallow=None):
     log("Combining samples...")
-    titles, tsvs, bams = read_samples_file(samplesFile)
+    titles, tsvs, bams = read_samples_file(samplesFile, strict=shallow is None)
     rows = [_parse_tsv(p) for p in tsvs]
     log("Establishing order of genomic regions.")
     chroms = region_order(rows)
@@ -274,9 +295,20 @@ def combine(samplesFile, outputPath, qGene="All", isStranded=False, strandedType
         log("No genomic regions found - EXITING")
         return
     log("order of genomic regions deduced: {}".format(chroms))
+    if shallow is not None and qGene != "All":   # combineShallow keeps only the query gene's lines in memory (:948-955)
+        rows = [[r for r in file_rows if r.gene == qGene] for file_rows in rows]
     log("Iterating through files in parallel, to interleave lines and fill gaps.")
-    merged = merge_sites(rows, chroms, len(titles), isStranded, qGene)
+    merged = merge_sites(rows, chroms, len(titles), isStranded, qGene, shallow=shallow, log=log)
     n_gap_sites = sum(1 for m in merged if m.queries)
     results = fill_gaps(merged, bams, isStranded, strandedType, devices=devices, threads=threads, log=log) if n_gap_sites else {}
     write_combined(outputPath + ".combined.tsv", merged, titles, results, isbeta2Cryptic)
     log("Filled in Beta read counts for {} Sites not detected in some samples".format(n_gap_sites))
+
+
+def combineShallow(samplesFile, outputPath, qGene="All", isStranded=False, minSamples=0, minReads=10, minSSE=0.0,
+                   strandedType=None, isbeta2Cryptic=False, devices=(0,), threads=0, log=_log):
+    """SpliSER_v0_1_8.py:920-1167: ``combine`` with the per-site evidence filter (a site is processed only when at
+    least ``minSamples`` samples list it with >= ``minReads`` reads and SSE >= ``minSSE``)."""
+    combine(samplesFile, outputPath, qGene=qGene, isStranded=isStranded, strandedType=strandedType,
+            isbeta2Cryptic=isbeta2Cryptic, devices=devices, threads=threads, log=log,
+            shallow=(int(minSamples), int(minReads), float(minSSE)))

@@ -324,6 +324,11 @@ COMBINE_VARIANTS = {
     "fr_cryptic": dict(process={"stranded": "fr", "cryptic": True}, combine=["--isStranded", "-s", "fr", "--beta2Cryptic"]),
     "annot_gene": dict(process={"gff": True}, combine=["-g", "GChr1_2"]),
     "rf_crypticlate": dict(process={"stranded": "rf"}, combine=["--isStranded", "-s", "rf", "--beta2Cryptic"]),
+    # combineShallow: evidence filter (command name is part of the variant)
+    "shallow": dict(process={}, combine=["-m", "2", "-r", "4", "-e", "0.2"], command="combineShallow"),
+    "shallow_fr": dict(process={"stranded": "fr", "cryptic": True}, command="combineShallow",
+                       combine=["--isStranded", "-s", "fr", "--beta2Cryptic", "-m", "3", "-r", "2"]),
+    "shallow_gene": dict(process={"gff": True}, combine=["-g", "GChr2_1", "-m", "1", "-r", "1"], command="combineShallow"),
 }
 
 
@@ -350,7 +355,7 @@ def build_combine(outroot, name="combine_a", seed=21):
             sfile = os.path.join(tmp, "samples.tsv")
             with open(sfile, "w") as fh:
                 fh.writelines(lines)
-            rc, log = run_reference.run_cli(["combine", "-S", sfile, "-o", os.path.join(tmp, "all")] + v["combine"], inprocess=True)
+            rc, log = run_reference.run_cli([v.get("command", "combine"), "-S", sfile, "-o", os.path.join(tmp, "all")] + v["combine"], inprocess=True)
             assert rc == 0, log
             shutil.copy(os.path.join(tmp, "all.combined.tsv"), os.path.join(d, "expected.%s.combined.tsv" % vname))
             # output -t DiffSpliSER / GWAS on the reference's own combined file

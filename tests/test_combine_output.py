@@ -28,9 +28,15 @@ def _samples_file(tmp_path, variant):
 
 
 def _flags(variant):
-    args = MANIFEST["variants"][variant]["combine"]
+    v = MANIFEST["variants"][variant]
+    args = v["combine"]
+    shallow = None
+    if v.get("command") == "combineShallow":
+        def opt(flag, default, cast):
+            return cast(args[args.index(flag) + 1]) if flag in args else default
+        shallow = (opt("-m", 0, int), opt("-r", 10, int), opt("-e", 0.0, float))
     return dict(q_gene=args[args.index("-g") + 1] if "-g" in args else "All", stranded="--isStranded" in args,
-                stype=args[args.index("-s") + 1] if "-s" in args else "fr", cryptic="--beta2Cryptic" in args)
+                stype=args[args.index("-s") + 1] if "-s" in args else "fr", cryptic="--beta2Cryptic" in args, shallow=shallow)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -38,7 +44,10 @@ def test_combine_host_walk_with_oracle_gap_fill(variant, tmp_path, oracle_lib):
     f = _flags(variant)
     titles, tsvs, bams = cmb.read_samples_file(_samples_file(tmp_path, variant))
     rows = [cmb._parse_tsv(p) for p in tsvs]
-    merged = cmb.merge_sites(rows, cmb.region_order(rows), len(titles), f["stranded"], f["q_gene"])
+    chroms = cmb.region_order(rows)
+    if f["shallow"] is not None and f["q_gene"] != "All":
+        rows = [[r for r in fr if r.gene == f["q_gene"]] for fr in rows]
+    merged = cmb.merge_sites(rows, chroms, len(titles), f["stranded"], f["q_gene"], shallow=f["shallow"])
     stranded = {"fr": 1, "rf": 2}[f["stype"]] if f["stranded"] else 0
     results = {}
     for idx, queries in cmb.gap_queries(merged).items():
@@ -56,7 +65,7 @@ def test_combine_host_walk_with_oracle_gap_fill(variant, tmp_path, oracle_lib):
     out = str(tmp_path / "all.combined.tsv")
     cmb.write_combined(out, merged, titles, results, f["cryptic"])
     assert open(out).read() == open(os.path.join(CASE, "expected.%s.combined.tsv" % variant)).read()
-    assert sum(len(m.queries) for m in merged) > 0
+    assert sum(len(m.queries) for m in merged) > 0 or variant == "shallow_fr"
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -88,7 +97,8 @@ def test_region_order_matches_reference_rule():
 def test_combine_cli_on_gpu(variant, tmp_path):
     from spliser_amd import cli
     sfile = _samples_file(tmp_path, variant)
-    argv = ["combine", "-S", sfile, "-o", str(tmp_path / "all")] + MANIFEST["variants"][variant]["combine"]
+    v = MANIFEST["variants"][variant]
+    argv = [v.get("command", "combine"), "-S", sfile, "-o", str(tmp_path / "all")] + v["combine"]
     assert cli.main(argv) == 0
     assert open(str(tmp_path / "all.combined.tsv")).read() == open(os.path.join(CASE, "expected.%s.combined.tsv" % variant)).read()
 
