@@ -1,0 +1,82 @@
+"""Seeded adversarial cases: small site tables built through the product's own host code from random junction lists
+that force what real data makes rare -- both strands at one position, shared ends, nested / crossing junctions, 0N ops,
+adjacent N ops, clipped and indel CIGARs, unmapped-but-placed records, novel junctions next to known ones."""
+import os
+import tempfile
+
+import numpy as np
+
+from spliser_amd import samio, sites
+
+
+def make_case(seed, stranded):
+    rng = np.random.default_rng(seed)
+    n_pos = int(rng.integers(6, 18))
+    positions = np.sort(rng.choice(np.arange(100, 100 + 40 * n_pos), n_pos, replace=False))
+    juncs = []
+    for _ in range(int(rng.integers(4, 22))):
+        a, b = np.sort(rng.choice(n_pos, 2, replace=False))
+        strand = "+" if rng.random() < 0.5 else "-"
+        if not stranded and rng.random() < 0.3:
+            strand = "?"
+        juncs.append(("c1", int(positions[a]), int(positions[b]), int(rng.integers(0, 9)), strand))
+    tmp = tempfile.mkdtemp(prefix="spl_rand_")
+    bed = os.path.join(tmp, "j.bed")
+    with open(bed, "w") as fh:
+        for (c, l, r, sc, st) in juncs:
+            fh.write("%s\t%d\t%d\tJ\t%d\t%s\t%d\t%d\t0\t2\t10,10\t0,%d\n" % (c, l - 10, r + 10, sc, st, l - 10, r + 10, r - l + 10))
+    table = sites.SiteTable(is_stranded=stranded)
+    table.add_bed(bed)
+    table.find_competitors()
+    arr = table.chrom_arrays("c1")
+    # reads
+    recs = []
+    flags = [0, 16, 99, 147, 83, 163, 4, 20, 256, 1024]
+    lo, hi = int(positions[0]) - 60, int(positions[-1]) + 60
+    for _ in range(int(rng.integers(40, 160))):
+        kind = rng.random()
+        flag = int(rng.choice(flags))
+        if kind < 0.3:
+            start = int(rng.integers(lo, hi))
+            ln = int(rng.integers(1, 120))
+            c = rng.random()
+            if c < 0.6:
+                cig = "%dM" % ln
+            elif c < 0.75:
+                a = int(rng.integers(1, ln + 1))
+                cig = "%dM%dI%dM" % (a, int(rng.integers(1, 4)), ln + 1 - a)
+            elif c < 0.9:
+                a = int(rng.integers(1, ln + 1))
+                cig = "%dM%dD%dM" % (a, int(rng.integers(0, 4)), ln + 1 - a)
+            else:
+                cig = "%dS%d=%dX%dH" % (int(rng.integers(1, 5)), ln, int(rng.integers(0, 3)), 2)
+            recs.append((flag, start, cig))
+        else:
+            nj = int(rng.integers(1, 4))
+            chosen = sorted(rng.choice(n_pos, min(2 * nj, n_pos - n_pos % 2), replace=False).tolist())
+            pairs = [(int(positions[chosen[2 * k]]), int(positions[chosen[2 * k + 1]])) for k in range(len(chosen) // 2)]
+            if rng.random() < 0.25:      # novel end next to a known one
+                k = int(rng.integers(0, len(pairs)))
+                pairs[k] = (pairs[k][0] + int(rng.choice([-1, 1, 2])), pairs[k][1])
+                if pairs[k][0] >= pairs[k][1]:
+                    pairs[k] = (pairs[k][1] - 3, pairs[k][1])
+            pre = int(rng.integers(1, 60))
+            ops, cur = ["%dM" % pre], pairs[0][0] + 1
+            start = pairs[0][0] - pre + 1
+            ok = True
+            for k, (l, r) in enumerate(pairs):
+                if l + 1 < cur:
+                    ok = False
+                    break
+                if l + 1 > cur:
+                    ops.append("%dM" % (l + 1 - cur))
+                ops.append("%dN" % (r - l))
+                cur = r + 1
+                if rng.random() < 0.1:
+                    ops.append("0N")
+            if not ok or start < 1:
+                continue
+            ops.append("%dM" % int(rng.integers(0, 60)))
+            recs.append((flag, start, "".join(ops)))
+    recs.sort(key=lambda r: r[1])
+    return arr, samio.ReadSet.from_records(recs)
