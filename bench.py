@@ -94,7 +94,6 @@ def main():
 
     scode = native.STRANDED_CODE[stranded]
     kflags = {"pairs": native.OPT_PAIR_KERNEL, "ranges_noagg": native.OPT_NO_WAVE_AGGREGATION, "ranges": 0}[args.kernel]
-    kflags |= int(os.environ.get("SPL_BENCH_DEBUG_MODE", "0")) << 8   # timing experiments (wrong results)
     ctx = native.Context(local_rank)
     dev = [(ctx.upload_sites(sh.sites), ctx.upload_reads(sh.reads)) for sh in shards]
     alg_bytes = sum(native.algorithmic_bytes(ds, dr) for ds, dr in dev)

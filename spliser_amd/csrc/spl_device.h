@@ -75,7 +75,6 @@ struct spl_count_params {
 
 // Argument block of the range kernel: only what the straight-line path touches (keeps it out of SGPR spills).
 struct spl_hot_params {
-    int32_t debug_mode;          // timing experiments only (results are wrong when non-zero)
     int64_t n_reads;
     uint32_t n_chunks;
     uint32_t n_cigar;

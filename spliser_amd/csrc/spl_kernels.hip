@@ -360,7 +360,8 @@ __device__ __forceinline__ void commit_key(const spl_hot_params &p, int32_t *lds
     if (AGG) {
         const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         const uint32_t k = valid ? key : 0xffffffffu;
-        const uint32_t prev = (uint32_t)__shfl_up((int)k, 1);
+        // previous lane's key by a DPP wave shift (no LDS round trip); lane 0 keeps its own and is a head anyway
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
         const bool head = valid && (lane == 0 || prev != k);
         const unsigned long long heads = __ballot(head);
         const unsigned long long act = __ballot(valid);
@@ -508,13 +509,6 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
                 const uint32_t raw = p.cigar[at < last_op ? at : last_op];
                 op[k] = ((uint32_t)k < n_ops) ? raw : 0xfu; // 0xf: absent, not a reference-consuming op
             }
-            if (p.debug_mode == 1) { // timing experiment: trips 1 + 2 only
-                uint32_t x = (uint32_t)pos ^ flag;
-#pragma unroll
-                for (int k = 0; k < SPL_INLINE_OPS; ++k) x ^= op[k];
-                if (x == 0x7fffffffu) atomicOr(p.err, 2);
-                continue;
-            }
             bool bad = alive && pos < 0;
             const bool literal = alive && !bad && (flag & 4u); // fetched as a 1-base record: literal kernel
             alive = alive && !bad && !literal;
@@ -540,13 +534,6 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
             uint4 ek[SPL_INLINE_OPS];
 #pragma unroll
             for (int k = 0; k < SPL_INLINE_OPS; ++k) ek[k] = p.dbucket[dbk_slot(p, cend[k] - 1)];
-            if (p.debug_mode == 2) { // timing experiment: trips 1 + 2 + 3 only
-                uint32_t x = e0.x ^ e0.z;
-#pragma unroll
-                for (int k = 0; k < SPL_INLINE_OPS; ++k) x ^= ek[k].x ^ ek[k].w;
-                if (x == 0x7ffffff1u) atomicOr(p.err, 2);
-                continue;
-            }
             int32_t pu = 0; uint32_t pnv = 0, prv = 0; // the dpos AT the previous boundary's last base (if pnv) and its rival bit
             dbk_resolve(p, pos - 1, e0, pu, pnv, prv);
             bool rival = false;
@@ -558,8 +545,8 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
                 const bool emit = kind[k] != 0u && kind[k] != 3u && u > lo;
                 const uint32_t arr = (kind[k] == 2u ? (STRANDED ? 2u : 1u) : 0u) + sidx;
                 // junction ends: lSite is the previous boundary's position, rSite this one's
-                rival |= (kind[k] == 2u) && ((pnv & prv) | (nv & rv));
-                if (__any(emit) && p.debug_mode != 3) {
+                rival |= (kind[k] == 2u) & (((pnv & prv) | (nv & rv)) != 0u);
+                if (__any(emit)) {
                     commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
                     commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)u << 2) | arr, -1);
                 }
@@ -585,7 +572,7 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
                             hi = u;
                             emit = hi > lo && code != SPL_OP_D;
                             arr = (code == SPL_OP_N ? (STRANDED ? 2u : 1u) : 0u) + sidx;
-                            rival |= (code == SPL_OP_N) && ((pnv & prv) | (nv & rv));
+                            rival |= (code == SPL_OP_N) & (((pnv & prv) | (nv & rv)) != 0u);
                             pu = u;
                             pnv = nv;
                             prv = rv;
@@ -615,7 +602,7 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
                         ++n_b;
                     }
                 }
-                simple = simple && n_n == 1 && n_b <= 2 && p.debug_mode != 4;
+                simple = simple && n_n == 1 && n_b <= 2;
                 if (!simple || !rivals_inline<STRANDED, NARR>(p, lds, wbase, jl, jr, blk_a, blk_b, sidx)) to_queue = true;
             }
             if (to_queue) s_q[atomicAdd(&s_qn, 1u)] = (uint32_t)(it * SPL_BLOCK + tid);
