@@ -79,8 +79,10 @@ struct spl_hot_params {
     uint32_t n_chunks;
     uint32_t n_cigar;
     const int32_t *r_pos;
-    const uint16_t *r_flag;
-    const uint32_t *cig_off;
+    const uint32_t *r_fn;        // packed at upload: flag | min(n_ops, 65535) << 16
+    const uint32_t *r_ops3;      // packed at upload, 3 words per read: the ops of a read with <= 3 ops (absent = 0xf);
+                                 // for longer reads {op0, op1, index of op2 in cigar[]}
+    const uint32_t *cig_off;     // only for reads with >= 65535 ops
     const uint32_t *cigar;
     const uint4 *dbucket;
     uint32_t n_dbuckets;
@@ -139,6 +141,8 @@ extern "C" {
 // wave-level aggregation of LDS atomics (experiment)
 int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out);
 int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, uint32_t queue_cap, void *stream);
+int spl_dev_launch_pack(int64_t n_reads, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar, uint32_t *fn,
+                        uint32_t *ops3, void *stream);
 int spl_dev_launch_scan(const spl_scan_params *p, void *stream);
 int spl_dev_launch_sse(const spl_sse_params *p, void *stream);
 #ifdef __cplusplus

@@ -490,25 +490,27 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
 
     if (live) {
         const int64_t last_read = p.n_reads - 1;
-        const uint32_t last_op = p.n_cigar ? p.n_cigar - 1u : 0u;
         for (int it = 0; it < SPL_RPT; ++it) {
-            // Straight-line and branch-free up to the commits: out-of-range lanes re-read the last read / last op and
-            // are masked at the end, so all loads of a trip issue back to back.  Control flow is wave-uniform around
-            // every commit_key (all 64 lanes reach it).
+            // Straight-line and branch-free up to the commits: out-of-range lanes re-read the last read and are masked
+            // at the end, so all loads of a trip issue back to back.  Control flow is wave-uniform around every
+            // commit_key (all 64 lanes reach it).
             const int64_t i = chunk_base + (int64_t)it * SPL_BLOCK + tid;
             bool alive = i <= last_read;
             const int64_t ii = alive ? i : last_read;
-            const int32_t pos = p.r_pos[ii];                                     // ---- trip 1
-            const uint32_t flag = p.r_flag[ii];
-            const uint32_t o0 = p.cig_off[ii];
-            const uint32_t n_ops = p.cig_off[ii + 1] - o0;
+            const int32_t pos = p.r_pos[ii];                                     // ---- trip 1: 20 bytes per read
+            const uint32_t fn = p.r_fn[ii];
             uint32_t op[SPL_INLINE_OPS];
 #pragma unroll
-            for (int k = 0; k < SPL_INLINE_OPS; ++k) {                           // ---- trip 2
-                const uint32_t at = o0 + (uint32_t)k;
-                const uint32_t raw = p.cigar[at < last_op ? at : last_op];
-                op[k] = ((uint32_t)k < n_ops) ? raw : 0xfu; // 0xf: absent, not a reference-consuming op
+            for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = p.r_ops3[3 * ii + k];
+            const uint32_t flag = fn & 0xffffu;
+            uint32_t n_ops = fn >> 16;
+            uint32_t o0 = 0; // index of op 0 in cigar[]: known (and needed) only for reads with more than 3 ops
+            if (n_ops > (uint32_t)SPL_INLINE_OPS) {
+                o0 = op[2] - 2u;
+                op[2] = 0xfu; // the third word was the pointer: ops 2.. are walked one at a time below
+                if (n_ops == 0xffffu) n_ops = p.cig_off[ii + 1] - o0;
             }
+            const uint32_t n_inline = n_ops > (uint32_t)SPL_INLINE_OPS ? 2u : n_ops;
             bool bad = alive && pos < 0;
             const bool literal = alive && !bad && (flag & 4u); // fetched as a 1-base record: literal kernel
             alive = alive && !bad && !literal;
@@ -554,11 +556,11 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
             }
             // ---- reads with more ops than the inline window: one op at a time
             int32_t c = pos + (int32_t)len;
-            for (uint32_t k = SPL_INLINE_OPS; __any(alive && k < n_ops); ++k) {
+            for (uint32_t k = n_inline; __any(alive && k >= 2u && k < n_ops && n_ops > (uint32_t)SPL_INLINE_OPS); ++k) {
                 bool emit = false;
                 uint32_t arr = 0;
                 int32_t lo = 0, hi = 0;
-                if (alive && k < n_ops) {
+                if (alive && k < n_ops && n_ops > (uint32_t)SPL_INLINE_OPS) {
                     const uint32_t o = p.cigar[o0 + k];
                     const uint32_t code = o & 15u;
                     if ((SPL_PROG_MASK >> code) & 1u) {
@@ -913,6 +915,22 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
     }
 }
 
+// The range kernel's read layout, derived once per upload from the BAM-native arrays: one word with flag and op count,
+// three words with the first ops (or two ops and where the rest start), so that everything a typical read needs
+// arrives in ONE memory trip without going through cig_off first.
+__global__ __launch_bounds__(256) void spl_pack_reads_kernel(int64_t n_reads, const uint16_t *flag, const uint32_t *cig_off,
+                                                             const uint32_t *cigar, uint32_t *fn, uint32_t *ops3)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_reads) return;
+    const uint32_t o0 = cig_off[i], n = cig_off[i + 1] - o0;
+    fn[i] = (uint32_t)flag[i] | ((n < 0xffffu ? n : 0xffffu) << 16);
+    uint32_t w[3] = {0xfu, 0xfu, 0xfu};
+    if (n <= 3u) { for (uint32_t k = 0; k < n; ++k) w[k] = cigar[o0 + k]; }
+    else { w[0] = cigar[o0]; w[1] = cigar[o0 + 1]; w[2] = o0 + 2u; }
+    ops3[3 * i] = w[0]; ops3[3 * i + 1] = w[1]; ops3[3 * i + 2] = w[2];
+}
+
 // =========================================================================================================
 // Difference arrays -> counters: two tiny launches (block sums, then offset + local inclusive scan).
 // =========================================================================================================
@@ -1081,6 +1099,15 @@ extern "C" int spl_dev_launch_literal(const spl_count_params *p, const uint32_t 
     hipStream_t st = (hipStream_t)stream;
     if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(SPL_LITERAL_WAVES), dim3(64), 0, st, *p, queue, queue_n, queue_cap);
     else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(SPL_LITERAL_WAVES), dim3(64), 0, st, *p, queue, queue_n, queue_cap);
+    return (int)hipGetLastError();
+}
+
+extern "C" int spl_dev_launch_pack(int64_t n_reads, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar, uint32_t *fn,
+                                   uint32_t *ops3, void *stream)
+{
+    if (n_reads <= 0) return 0;
+    hipLaunchKernelGGL(spl_pack_reads_kernel, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_reads, flag,
+                       cig_off, cigar, fn, ops3);
     return (int)hipGetLastError();
 }
 
