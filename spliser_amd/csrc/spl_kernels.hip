@@ -508,7 +508,6 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
             if (n_ops > (uint32_t)SPL_INLINE_OPS) {
                 o0 = op[2] - 2u;
                 op[2] = 0xfu; // the third word was the pointer: ops 2.. are walked one at a time below
-                if (n_ops == 0xffffu) n_ops = p.cig_off[ii + 1] - o0;
             }
             const uint32_t n_inline = n_ops > (uint32_t)SPL_INLINE_OPS ? 2u : n_ops;
             bool bad = alive && pos < 0;
@@ -555,6 +554,7 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
                 if (kind[k]) { pu = u; pnv = nv; prv = rv; }
             }
             // ---- reads with more ops than the inline window: one op at a time
+            if (n_ops == 0xffffu) n_ops = p.cig_off[ii + 1] - o0; // the packed word saturates: true count from cig_off
             int32_t c = pos + (int32_t)len;
             for (uint32_t k = n_inline; __any(alive && k >= 2u && k < n_ops && n_ops > (uint32_t)SPL_INLINE_OPS); ++k) {
                 bool emit = false;
