@@ -26,7 +26,7 @@
  * intronic base, both 1-based), so a CIGAR N op of length d ending at cur gives lSite = cur-d-1,
  * rSite = cur-1 (SpliSER_v0_1_8.py:482-483) and equality tests are direct.  One call covers one
  * *shard*: a single int32 coordinate space (one chromosome, or several chromosomes the host has laid
- * side by side with offsets -- see spliser_amd/shard.py); every coordinate must stay below 2^31-2.
+ * side by side with offsets -- see spliser_amd/shard.py); every coordinate must stay at or below 2^31-67.
  */
 #ifndef SPLISER_H
 #define SPLISER_H

@@ -74,6 +74,7 @@ struct spl_dsites {
     int32_t *dpos_first_row = nullptr; // [n_dpos + 1]
     uint4 *dbucket = nullptr;  // 64 bp buckets {first dpos, -, occupancy mask}
     uint32_t n_dbuckets = 0;
+    int32_t dbase = 0;         // coordinate of the first (empty) bucket
     uint32_t *rival_bits = nullptr;
     uint4 *jhash = nullptr;    // junction table (see build_junction_table)
     uint32_t jhash_mask = 0;
@@ -386,12 +387,13 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     d->n_dpos = (int32_t)D;
     rbits.assign((size_t)(D + 31) / 32 + 1, 0u);
     if (S > 0) {
-        const int64_t extent = (int64_t)s->pos[S - 1] - (int64_t)s->pos[0] + 1;
-        d->n_dbuckets = (uint32_t)((extent - 1) >> 6) + 1;
+        // one empty bucket in front of the first site, one behind the last (first dpos = D): the kernels only clamp
+        d->dbase = s->pos[0] >= 64 ? (int32_t)(s->pos[0] - 64) : -64;
+        d->n_dbuckets = (uint32_t)(((int64_t)s->pos[S - 1] - (int64_t)d->dbase) >> 6) + 2;
         dbucket.assign((size_t)d->n_dbuckets, make_uint4(0, 0, 0, 0));
         int64_t di = 0;
         for (uint32_t b = 0; b < d->n_dbuckets; ++b) {
-            const int64_t start = (int64_t)s->pos[0] + ((int64_t)b << 6);
+            const int64_t start = (int64_t)d->dbase + ((int64_t)b << 6);
             while (di < D && (int64_t)s->pos[dfirst[(size_t)di]] < start) ++di;
             unsigned long long mask = 0;
             for (int64_t j = di; j < D && (int64_t)s->pos[dfirst[(size_t)j]] < start + 64; ++j)
@@ -557,7 +559,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.site_pos = ds->pos; p.site_strand = ds->strand; p.site_flags = ds->flags; p.site_meta = ds->meta;
     p.part_pos = ds->part_pos; p.part_site = ds->part_site; p.comp_pos = ds->comp_pos;
     p.diff = ds->diff; p.diff_stride = ds->diff_stride;
-    p.dbucket = ds->dbucket; p.n_dbuckets = ds->n_dbuckets; p.dbase = ds->n_sites ? ds->bucket_base : 0; p.n_dpos = ds->n_dpos;
+    p.dbucket = ds->dbucket; p.n_dbuckets = ds->n_dbuckets; p.dbase = ds->dbase; p.n_dpos = ds->n_dpos;
     p.rival_bits = ds->rival_bits; p.dpos_first_row = ds->dpos_first_row;
     p.jhash = ds->jhash; p.jhash_mask = ds->jhash_mask; p.jrivals = ds->jrivals;
     spl_hot_params h;

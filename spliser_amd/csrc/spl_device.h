@@ -15,8 +15,10 @@
 #define SPL_LITERAL_WAVES 8192           // one-wave workgroups of the literal kernel (grid-stride over the queue)
 #define SPL_SCAN_BLOCK 1024              // distinct positions per workgroup in the difference-array scan
 
-// Coordinates (read end, site position) must stay <= SPL_COORD_MAX so that t+1 and cur never wrap int32.
-#define SPL_COORD_MAX 2147483645
+// Coordinates (read end, site position) must stay <= SPL_COORD_MAX so that t+1, cur and x - dbase never wrap int32.
+#define SPL_COORD_MAX 2147483581
+// op code -> 2-bit kind (see spl_count_ranges_kernel): M(0)=1 D(2)=3 N(3)=2 =(7)=1 X(8)=1, others 0
+#define SPL_KIND_TABLE ((1u << 0) | (3u << 4) | (2u << 6) | (1u << 14) | (1u << 16))
 
 #define SPL_DEV_ERR_RANGE 1
 

@@ -320,25 +320,27 @@ __device__ __forceinline__ void unmapped_read(const spl_count_params &p, int32_t
 template <class P>
 __device__ __forceinline__ uint32_t dbk_slot(const P &p, int32_t x)
 {
-    int32_t b = (x - p.dbase) >> 6; // x >= -1 and dbase >= 0: no overflow
+    // the table starts one empty bucket before the first site (dbase >= -64) and ends with an empty bucket whose first
+    // dpos is n_dpos, so clamping the index is all the range handling there is; x - dbase cannot wrap because
+    // coordinates stay <= SPL_COORD_MAX = 2^31 - 67
+    int32_t b = (x - p.dbase) >> 6;
     b = b < 0 ? 0 : b;
     const int32_t last = (int32_t)p.n_dbuckets - 1;
     return (uint32_t)(b > last ? last : b);
 }
 
 // e.y: bit j = the j-th site position of the bucket has a rival flag (conservatively all ones past 32 sites).
+// For x outside the table the clamped entry is an empty bucket: count 0, not a site, whatever `bit` says.
 template <class P>
 __device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint4 e, int32_t &u, uint32_t &nv, uint32_t &rv)
 {
-    const int32_t rel = x - p.dbase;
-    const uint32_t bit = (uint32_t)rel & 63u;
+    const uint32_t bit = (uint32_t)(x - p.dbase) & 63u;
     const bool upper = bit >= 32u;
     const uint32_t sh = bit & 31u;
     const uint32_t below = (1u << sh) - 1u;
     const uint32_t cnt = __popc(e.z & (upper ? 0xffffffffu : below)) + __popc(e.w & (upper ? below : 0u));
-    const bool out = rel < 0 || (rel >> 6) >= (int32_t)p.n_dbuckets;
-    u = out ? (rel < 0 ? 0 : p.n_dpos) : (int32_t)(e.x + cnt);
-    nv = out ? 0u : (((upper ? e.w : e.z) >> sh) & 1u);
+    u = (int32_t)(e.x + cnt);
+    nv = ((upper ? e.w : e.z) >> sh) & 1u;
     rv = cnt < 32u ? ((e.y >> cnt) & 1u) : 1u;
 }
 
@@ -523,12 +525,12 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
             uint32_t kind[SPL_INLINE_OPS]; // 0 none, 1 aligned, 2 N, 3 D
 #pragma unroll
             for (int k = 0; k < SPL_INLINE_OPS; ++k) {
-                const uint32_t code = op[k] & 15u;
-                const bool prog = alive && ((SPL_PROG_MASK >> code) & 1u);
-                len += prog ? (op[k] >> 4) : 0u;               // three lengths < 2^28: no wrap
-                if (prog && len > room) { bad = true; alive = false; }
+                // 2 bits per op code: M,=,X -> 1 (aligned), N -> 2, D -> 3, everything else 0 (does not consume the reference)
+                const uint32_t kd = alive ? ((SPL_KIND_TABLE >> (2u * (op[k] & 15u))) & 3u) : 0u;
+                len += kd ? (op[k] >> 4) : 0u;                 // three lengths < 2^28: no wrap
+                if (kd && len > room) { bad = true; alive = false; }
                 cend[k] = pos + (int32_t)len;
-                kind[k] = (prog && alive) ? ((code == SPL_OP_N) ? 2u : (code == SPL_OP_D ? 3u : 1u)) : 0u;
+                kind[k] = alive ? kd : 0u;
             }
             // ---- trip 3: bucket entries of the start boundary and of every inline op end (slots are clamped: always legal)
             const uint4 e0 = p.dbucket[dbk_slot(p, pos - 1)];

@@ -96,7 +96,7 @@ def _arr(a, dt):
 
 def _to_i32(a, what):
     a = np.asarray(a)
-    if a.size and (a.max() > 2147483645 or a.min() < -2147483648):
+    if a.size and (a.max() > 2147483581 or a.min() < -2147483648):
         raise SpliserNativeError(-6, "%s exceeds the int32 shard coordinate space; split the shard" % what)
     return _arr(a, np.int32)
 

@@ -17,7 +17,7 @@ import numpy as np
 
 from . import native
 
-COORD_MAX = 2147483645
+COORD_MAX = 2147483581
 GAP = 1024
 
 
