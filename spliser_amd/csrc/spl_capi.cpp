@@ -93,6 +93,8 @@ struct spl_dreads {
     uint16_t *flag = nullptr;
     uint32_t *cig_off = nullptr, *cigar = nullptr;
     uint32_t *fn = nullptr, *ops3 = nullptr;       // the range kernel's own layout, packed on the device at upload
+    int32_t *ppos = nullptr;
+    uint16_t *perm = nullptr;
     uint32_t *queue = nullptr, *queue_n = nullptr; // reads the range kernel hands to the literal kernel
 };
 
@@ -506,7 +508,7 @@ extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     const size_t o_pos = take(4 * R), o_flag = take(2 * R), o_off = take(4 * (R + 1)), o_cig = take(4 * G);
-    const size_t o_fn = take(4 * R), o_ops3 = take(12 * R);
+    const size_t o_fn = take(4 * R), o_ops3 = take(12 * R), o_ppos = take(4 * R), o_perm = take(2 * R);
     const size_t n_chunks = (size_t)((R + SPL_CHUNK - 1) / SPL_CHUNK);
     // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks
     const size_t shard_cap = ((n_chunks + 7) / 8) * SPL_CHUNK;
@@ -517,6 +519,7 @@ extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out
     d->cig_off = (uint32_t *)(d->slab + o_off); d->cigar = (uint32_t *)(d->slab + o_cig);
     d->queue = (uint32_t *)(d->slab + o_queue); d->queue_n = (uint32_t *)(d->slab + o_qn);
     d->fn = (uint32_t *)(d->slab + o_fn); d->ops3 = (uint32_t *)(d->slab + o_ops3);
+    d->ppos = (int32_t *)(d->slab + o_ppos); d->perm = (uint16_t *)(d->slab + o_perm);
     hipError_t q = hipSuccess;
     if (R) {
         q = hipMemcpyAsync(d->pos, r->pos, 4 * R, hipMemcpyHostToDevice, c->stream);
@@ -524,7 +527,7 @@ extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out
         if (q == hipSuccess) q = hipMemcpyAsync(d->cig_off, r->cig_off, 4 * (R + 1), hipMemcpyHostToDevice, c->stream);
         if (q == hipSuccess && G) q = hipMemcpyAsync(d->cigar, r->cigar, 4 * G, hipMemcpyHostToDevice, c->stream);
         // the range kernel's layout (flag + op count in one word, first ops inline) is derived on the device
-        if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack(R, d->flag, d->cig_off, d->cigar, d->fn, d->ops3, c->stream);
+        if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack(R, d->pos, d->flag, d->cig_off, d->cigar, d->ppos, d->fn, d->ops3, d->perm, c->stream);
         if (q == hipSuccess) q = hipStreamSynchronize(c->stream); // caller buffers are free to go after return
     }
     if (q != hipSuccess) { (void)hipFree(d->slab); delete d; return spl_set_error(SPL_ERR_HIP, "read set upload: %s", hipGetErrorString(q)); }
@@ -564,7 +567,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.jhash = ds->jhash; p.jhash_mask = ds->jhash_mask; p.jrivals = ds->jrivals;
     spl_hot_params h;
     memset(&h, 0, sizeof(h));
-    h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos = p.r_pos; h.r_fn = dr->fn; h.r_ops3 = dr->ops3; h.cig_off = p.cig_off; h.cigar = p.cigar;
+    h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos_orig = p.r_pos; h.r_pos = dr->ppos; h.perm = dr->perm; h.r_fn = dr->fn; h.r_ops3 = dr->ops3; h.cig_off = p.cig_off; h.cigar = p.cigar;
     h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.n_cigar = (uint32_t)dr->n_cigar;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = dr->queue; h.queue_n = dr->queue_n; h.err = c->d_err;
@@ -587,7 +590,10 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     c->last_variant = variant;
     if (rc != 0) return spl_set_error(SPL_ERR_HIP, "count kernel launch: %s", hipGetErrorString((hipError_t)rc));
     if (variant != 1 && grid > 0) { // queued reads through the literal kernel, then difference arrays -> counters
-        rc = spl_dev_launch_literal(&p, dr->queue, dr->queue_n, h.queue_cap, c->stream);
+        spl_queue_params lq;
+        lq.queue = dr->queue; lq.queue_n = dr->queue_n; lq.queue_cap = h.queue_cap;
+        lq.r_pos = dr->ppos; lq.r_fn = dr->fn; lq.r_ops3 = dr->ops3; lq.perm = dr->perm;
+        rc = spl_dev_launch_literal(&p, &lq, c->stream);
         if (rc != 0) return spl_set_error(SPL_ERR_HIP, "literal kernel launch: %s", hipGetErrorString((hipError_t)rc));
         spl_scan_params q;
         memset(&q, 0, sizeof(q));

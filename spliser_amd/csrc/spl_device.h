@@ -7,7 +7,12 @@
 
 // Launch geometry of the classification kernels (see DESIGN.md "Kernels").
 #define SPL_BLOCK 256                    // threads per workgroup = 4 waves
-#define SPL_RPT 4                        // reads per thread
+#ifndef SPL_BUCKET_AHEAD
+#define SPL_BUCKET_AHEAD 0              // 1: prefetch the next read's bucket entries too (registers!)
+#endif
+#ifndef SPL_RPT
+#define SPL_RPT 8                        // reads per thread
+#endif
 #define SPL_CHUNK (SPL_BLOCK * SPL_RPT)  // consecutive reads per workgroup
 #define SPL_WIN 1024                     // site rows whose counters a workgroup privatises in LDS
 #define SPL_INLINE_OPS 3                 // CIGAR ops per read resolved in the straight-line part (M N M = 3)
@@ -80,8 +85,10 @@ struct spl_hot_params {
     int64_t n_reads;
     uint32_t n_chunks;
     uint32_t n_cigar;
-    const int32_t *r_pos;
-    const uint32_t *r_fn;        // packed at upload: flag | min(n_ops, 65535) << 16
+    const int32_t *r_pos_orig;   // BAM-native order (window base of a chunk)
+    const int32_t *r_pos;        // the arrays below are packed at upload, chunk-locally reordered (simple reads first)
+    const uint16_t *perm;        // packed slot -> place of the read in its chunk
+    const uint32_t *r_fn;        // flag | min(n_ops, 65535) << 16
     const uint32_t *r_ops3;      // packed at upload, 3 words per read: the ops of a read with <= 3 ops (absent = 0xf);
                                  // for longer reads {op0, op1, index of op2 in cigar[]}
     const uint32_t *cig_off;     // only for reads with >= 65535 ops
@@ -99,10 +106,21 @@ struct spl_hot_params {
     const uint4 *jrivals;        // {t_pos, t_dpos | strand code << 30, double-count edge 0, edge 1 (0xffffffff = none)}
     uint32_t *dbl;
     int32_t combine_mode;
-    uint32_t *queue;             // reads handed to spl_count_literal_kernel: 8 regions (workgroup & 7) of queue_cap
+    uint32_t *queue;             // reads handed to spl_count_literal_kernel (packed indexes): 8 regions (workgroup & 7) of queue_cap
     uint32_t *queue_n;           // [8] entries used per region
     uint32_t queue_cap;
     int32_t *err;
+};
+
+// the literal kernel's view of the queue and of the packed read arrays it indexes
+struct spl_queue_params {
+    const uint32_t *queue;       // 8 regions of queue_cap entries
+    const uint32_t *queue_n;     // [8]
+    uint32_t queue_cap;
+    const int32_t *r_pos;        // packed (see spl_hot_params)
+    const uint32_t *r_fn;
+    const uint32_t *r_ops3;
+    const uint16_t *perm;
 };
 
 struct spl_scan_params {
@@ -142,9 +160,9 @@ extern "C" {
 // variant: 0 = range kernel (needs mutual partner links), 1 = pair kernel (any table), 2 = range kernel without
 // wave-level aggregation of LDS atomics (experiment)
 int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out);
-int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, uint32_t queue_cap, void *stream);
-int spl_dev_launch_pack(int64_t n_reads, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar, uint32_t *fn,
-                        uint32_t *ops3, void *stream);
+int spl_dev_launch_literal(const spl_count_params *p, const spl_queue_params *q, void *stream);
+int spl_dev_launch_pack(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar,
+                        int32_t *p_pos, uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm, void *stream);
 int spl_dev_launch_scan(const spl_scan_params *p, void *stream);
 int spl_dev_launch_sse(const spl_sse_params *p, void *stream);
 #ifdef __cplusplus

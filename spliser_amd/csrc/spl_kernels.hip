@@ -17,6 +17,8 @@
 //
 // Integer / indexing work: no MFMA.  The roofline that bounds the count kernels is HBM.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <stdint.h>
 
 #define SPL_HD __device__ __forceinline__
@@ -466,44 +468,109 @@ __device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, int32_t *
 // unmapped-but-placed records and reads with a junction end that has rival sites -- are appended to a queue.
 // Reads with more than SPL_INLINE_OPS ops continue one op at a time (long-read CIGARs work, they just are not
 // the tuned case).
+// Development aid, compiled out of the product (make EXTRA=-DSPL_PHASE_TIMING): wave 0 of every workgroup stamps the
+// 100 MHz wall clock at the phase borders of the range kernel; tools/phase_report.py turns the dump into a timeline.
+#ifdef SPL_PHASE_TIMING
+__device__ uint64_t *g_phase;
+#define SPL_PHASE_DECL uint64_t ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define SPL_PHASE(slot) do { if ((slot) < 8) ph_[(slot) < 8 ? (slot) : 0] = wall_clock64(); } while (0)
+#define SPL_PHASE_WRITE do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) g_phase[(size_t)blockIdx.x * 8 + k_] = ph_[k_]; } while (0)
+#else
+#define SPL_PHASE_DECL do { } while (0)
+#define SPL_PHASE(slot) do { } while (0)
+#define SPL_PHASE_WRITE do { } while (0)
+#endif
+
+#ifdef SPL_WAVES_PER_EU
+#define SPL_RANGE_ATTR __attribute__((amdgpu_waves_per_eu(SPL_WAVES_PER_EU, SPL_WAVES_PER_EU)))
+#else
+#define SPL_RANGE_ATTR
+#endif
 template <bool STRANDED, bool AGG>
-__global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_hot_params p)
+__global__ __launch_bounds__(SPL_BLOCK) SPL_RANGE_ATTR void spl_count_ranges_kernel(const spl_hot_params p)
 {
     constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
+    constexpr bool AHEAD = SPL_BUCKET_AHEAD != 0;
     __shared__ int32_t lds[NARR * (SPL_WIN + 1)];
-    __shared__ uint32_t s_q[SPL_CHUNK]; // this chunk's reads for the literal kernel (chunk-relative index)
+    __shared__ uint32_t s_q[SPL_CHUNK]; // this chunk's reads for the literal kernel (chunk-relative packed slot)
     __shared__ uint32_t s_qn, s_qbase;
-    __shared__ int32_t s_wbase;
 
     const int tid = threadIdx.x;
     const uint32_t chunk = my_chunk();
     const bool live = chunk < p.n_chunks;
     const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
+    SPL_PHASE_DECL;
+    SPL_PHASE(0);
 
+    // Pipeline over the chunk's reads: while read `it` is worked on the packed words of the next read are in flight
+    // (SPL_BUCKET_AHEAD: also its bucket entries, at the price of 25 more registers -- measured slower, occupancy 4).
+    const int64_t last_read = p.n_reads - 1;
+    auto fetch_read = [&](int it, int32_t &f_pos, uint32_t &f_fn, uint32_t (&f_op)[SPL_INLINE_OPS]) {
+        const int64_t i = chunk_base + (int64_t)it * SPL_BLOCK + tid;
+        const int64_t ii = live ? (i <= last_read ? i : last_read) : 0;
+        f_pos = p.r_pos[ii];                                                     // ---- trip 1: 20 bytes per read
+        f_fn = p.r_fn[ii];
+#pragma unroll
+        for (int k = 0; k < SPL_INLINE_OPS; ++k) f_op[k] = p.r_ops3[3 * ii + k];
+    };
+    // ---- trip 2: bucket entries of the start boundary and of every inline op end (slots are clamped: always legal).
+    //      The ends are recomputed when the read is worked on; for a read that turns out bad the entries go unused.
+    auto fetch_buckets = [&](int32_t f_pos, uint32_t f_fn, const uint32_t (&f_op)[SPL_INLINE_OPS], uint4 (&f_e)[SPL_INLINE_OPS + 1]) {
+        const bool wide = (f_fn >> 16) > (uint32_t)SPL_INLINE_OPS;
+        uint32_t len = 0;
+        f_e[0] = p.dbucket[dbk_slot(p, f_pos - 1)];
+#pragma unroll
+        for (int k = 0; k < SPL_INLINE_OPS; ++k) {
+            const uint32_t o = (k == 2 && wide) ? 0xfu : f_op[k];
+            const uint32_t kd = (SPL_KIND_TABLE >> (2u * (o & 15u))) & 3u;
+            len += kd ? (o >> 4) : 0u;
+            f_e[k + 1] = p.dbucket[dbk_slot(p, (int32_t)((uint32_t)f_pos + len) - 1)];
+        }
+    };
+    int32_t cu_pos, nx_pos = 0;
+    uint32_t cu_fn, nx_fn = 0, cu_op[SPL_INLINE_OPS], nx_op[SPL_INLINE_OPS];
+    uint4 cu_e[SPL_INLINE_OPS + 1];
+    fetch_read(0, cu_pos, cu_fn, cu_op);
+    if (AHEAD && SPL_RPT > 1) fetch_read(1, nx_pos, nx_fn, nx_op);
+    const int32_t first_pos = p.r_pos_orig[live ? chunk_base : 0]; // wave-uniform: the window base of the chunk
+    if (AHEAD) fetch_buckets(cu_pos, cu_fn, cu_op, cu_e);
+    int32_t wbase = 0;
+    { uint32_t nv; dbk_resolve(p, first_pos - 1, p.dbucket[dbk_slot(p, first_pos - 1)], wbase, nv); }
     for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) lds[j] = 0;
-    if (tid == 0) {
-        int32_t u = 0; uint32_t nv = 0;
-        if (live) { const int32_t x = p.r_pos[chunk_base] - 1; dbk_resolve(p, x, p.dbucket[dbk_slot(p, x)], u, nv); }
-        s_wbase = u;
-        s_qn = 0u;
-    }
+    if (tid == 0) s_qn = 0u;
     __syncthreads();
-    const int32_t wbase = s_wbase;
+    SPL_PHASE(1);
 
     if (live) {
-        const int64_t last_read = p.n_reads - 1;
         for (int it = 0; it < SPL_RPT; ++it) {
+            if (it >= 1 && it < 4) SPL_PHASE(2 + it); // reads 1..3 of the chunk get a stamp each (read 0 starts at stamp 1)
             // Straight-line and branch-free up to the commits: out-of-range lanes re-read the last read and are masked
             // at the end, so all loads of a trip issue back to back.  Control flow is wave-uniform around every
             // commit_key (all 64 lanes reach it).
             const int64_t i = chunk_base + (int64_t)it * SPL_BLOCK + tid;
             bool alive = i <= last_read;
             const int64_t ii = alive ? i : last_read;
-            const int32_t pos = p.r_pos[ii];                                     // ---- trip 1: 20 bytes per read
-            const uint32_t fn = p.r_fn[ii];
+            const int32_t pos = cu_pos;
+            const uint32_t fn = cu_fn;
             uint32_t op[SPL_INLINE_OPS];
+            uint4 e0, ek[SPL_INLINE_OPS];
 #pragma unroll
-            for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = p.r_ops3[3 * ii + k];
+            for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = cu_op[k];
+            if (AHEAD) {
+                e0 = cu_e[0];
+#pragma unroll
+                for (int k = 0; k < SPL_INLINE_OPS; ++k) ek[k] = cu_e[k + 1];
+                // next read's buckets, next-but-one read's words
+                if (it + 1 < SPL_RPT) {
+                    cu_pos = nx_pos; cu_fn = nx_fn;
+#pragma unroll
+                    for (int k = 0; k < SPL_INLINE_OPS; ++k) cu_op[k] = nx_op[k];
+                    fetch_buckets(cu_pos, cu_fn, cu_op, cu_e);
+                }
+                if (it + 2 < SPL_RPT) fetch_read(it + 2, nx_pos, nx_fn, nx_op);
+            } else {
+                if (it + 1 < SPL_RPT) fetch_read(it + 1, cu_pos, cu_fn, cu_op); // next read's words
+            }
             const uint32_t flag = fn & 0xffffu;
             uint32_t n_ops = fn >> 16;
             uint32_t o0 = 0; // index of op 0 in cigar[]: known (and needed) only for reads with more than 3 ops
@@ -512,81 +579,78 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
                 op[2] = 0xfu; // the third word was the pointer: ops 2.. are walked one at a time below
             }
             const uint32_t n_inline = n_ops > (uint32_t)SPL_INLINE_OPS ? 2u : n_ops;
+            // ---- a wave of simple reads (one aligned op, mapped: the pack kernel put them first in the chunk) takes the
+            //      short road: two boundaries, one range, nothing else can happen to such a read
+            const bool simple = n_ops == 1u && ((SPL_KIND_TABLE >> (2u * (op[0] & 15u))) & 3u) == 1u && !(flag & 4u) && pos >= 0 &&
+                                (op[0] >> 4) <= (uint32_t)(SPL_COORD_MAX - (pos < 0 ? 0 : pos));
+            if (__all(simple)) {
+                const int32_t c1 = pos + (int32_t)(op[0] >> 4);
+                if (!AHEAD) { e0 = p.dbucket[dbk_slot(p, pos - 1)]; ek[0] = p.dbucket[dbk_slot(p, c1 - 1)]; }
+                int32_t ua, ub; uint32_t nva, nvb;
+                dbk_resolve(p, pos - 1, e0, ua, nva);
+                dbk_resolve(p, c1 - 1, ek[0], ub, nvb);
+                const int32_t lo = ua + (int32_t)nva;
+                const bool emit = alive && ub > lo;
+                uint32_t arr = 0;
+                if (STRANDED) arr = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
+                if (__any(emit)) {
+                    commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
+                    commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)ub << 2) | arr, -1);
+                }
+                continue;
+            }
             bool bad = alive && pos < 0;
             const bool literal = alive && !bad && (flag & 4u); // fetched as a 1-base record: literal kernel
             alive = alive && !bad && !literal;
             uint32_t sidx = 0;
             if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
-
-            // boundaries of the inline ops
+            const bool wide = n_ops > (uint32_t)SPL_INLINE_OPS;
+            if (n_ops == 0xffffu) n_ops = p.cig_off[ii + 1] - o0; // the packed word saturates: true count from cig_off
             const uint32_t room = (uint32_t)(SPL_COORD_MAX - (pos < 0 ? 0 : pos));
             uint32_t len = 0;
             int32_t cend[SPL_INLINE_OPS];
             uint32_t kind[SPL_INLINE_OPS]; // 0 none, 1 aligned, 2 N, 3 D
-#pragma unroll
-            for (int k = 0; k < SPL_INLINE_OPS; ++k) {
-                // 2 bits per op code: M,=,X -> 1 (aligned), N -> 2, D -> 3, everything else 0 (does not consume the reference)
-                const uint32_t kd = alive ? ((SPL_KIND_TABLE >> (2u * (op[k] & 15u))) & 3u) : 0u;
-                len += kd ? (op[k] >> 4) : 0u;                 // three lengths < 2^28: no wrap
-                if (kd && len > room) { bad = true; alive = false; }
-                cend[k] = pos + (int32_t)len;
-                kind[k] = alive ? kd : 0u;
-            }
-            // ---- trip 3: bucket entries of the start boundary and of every inline op end (slots are clamped: always legal)
-            const uint4 e0 = p.dbucket[dbk_slot(p, pos - 1)];
-            uint4 ek[SPL_INLINE_OPS];
-#pragma unroll
-            for (int k = 0; k < SPL_INLINE_OPS; ++k) ek[k] = p.dbucket[dbk_slot(p, cend[k] - 1)];
             int32_t pu = 0; uint32_t pnv = 0, prv = 0; // the dpos AT the previous boundary's last base (if pnv) and its rival bit
-            dbk_resolve(p, pos - 1, e0, pu, pnv, prv);
             bool rival = false;
+            // The ops go through in batches of SPL_INLINE_OPS: the first batch is the packed words (every read of a typical
+            // short-read library ends there), further batches of a wide read cost two memory trips each (ops, then buckets).
+            uint32_t k_next = n_inline;
+            for (bool first = true;; first = false) {
 #pragma unroll
-            for (int k = 0; k < SPL_INLINE_OPS; ++k) {
-                int32_t u; uint32_t nv, rv;
-                dbk_resolve(p, cend[k] - 1, ek[k], u, nv, rv);
-                const int32_t lo = pu + (int32_t)pnv; // first dpos at or after the op's first base
-                const bool emit = kind[k] != 0u && kind[k] != 3u && u > lo;
-                const uint32_t arr = (kind[k] == 2u ? (STRANDED ? 2u : 1u) : 0u) + sidx;
-                // junction ends: lSite is the previous boundary's position, rSite this one's
-                rival |= (kind[k] == 2u) & (((pnv & prv) | (nv & rv)) != 0u);
-                if (__any(emit)) {
-                    commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
-                    commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)u << 2) | arr, -1);
+                for (int k = 0; k < SPL_INLINE_OPS; ++k) {
+                    // 2 bits per op code: M,=,X -> 1 (aligned), N -> 2, D -> 3, everything else 0 (does not consume the reference)
+                    const uint32_t kd = alive ? ((SPL_KIND_TABLE >> (2u * (op[k] & 15u))) & 3u) : 0u;
+                    len += kd ? (op[k] >> 4) : 0u;                 // len <= 2^31 before, three lengths < 2^28: no wrap
+                    if (kd && len > room) { bad = true; alive = false; }
+                    cend[k] = pos + (int32_t)len;
+                    kind[k] = alive ? kd : 0u;
                 }
-                if (kind[k]) { pu = u; pnv = nv; prv = rv; }
-            }
-            // ---- reads with more ops than the inline window: one op at a time
-            if (n_ops == 0xffffu) n_ops = p.cig_off[ii + 1] - o0; // the packed word saturates: true count from cig_off
-            int32_t c = pos + (int32_t)len;
-            for (uint32_t k = n_inline; __any(alive && k >= 2u && k < n_ops && n_ops > (uint32_t)SPL_INLINE_OPS); ++k) {
-                bool emit = false;
-                uint32_t arr = 0;
-                int32_t lo = 0, hi = 0;
-                if (alive && k < n_ops && n_ops > (uint32_t)SPL_INLINE_OPS) {
-                    const uint32_t o = p.cigar[o0 + k];
-                    const uint32_t code = o & 15u;
-                    if ((SPL_PROG_MASK >> code) & 1u) {
-                        len += o >> 4; // len <= 2^31 before, o>>4 < 2^28: no wrap
-                        if (len > room) { bad = true; alive = false; }
-                        else {
-                            c = pos + (int32_t)len;
-                            int32_t u; uint32_t nv, rv;
-                            dbk_resolve(p, c - 1, p.dbucket[dbk_slot(p, c - 1)], u, nv, rv);
-                            lo = pu + (int32_t)pnv;
-                            hi = u;
-                            emit = hi > lo && code != SPL_OP_D;
-                            arr = (code == SPL_OP_N ? (STRANDED ? 2u : 1u) : 0u) + sidx;
-                            rival |= (code == SPL_OP_N) & (((pnv & prv) | (nv & rv)) != 0u);
-                            pu = u;
-                            pnv = nv;
-                            prv = rv;
-                        }
+                if (!AHEAD || !first) { // ---- trip 2 (see fetch_buckets)
+                    if (first) e0 = p.dbucket[dbk_slot(p, pos - 1)];
+#pragma unroll
+                    for (int k = 0; k < SPL_INLINE_OPS; ++k) ek[k] = p.dbucket[dbk_slot(p, cend[k] - 1)];
+                }
+                if (first) dbk_resolve(p, pos - 1, e0, pu, pnv, prv);
+#pragma unroll
+                for (int k = 0; k < SPL_INLINE_OPS; ++k) {
+                    int32_t u; uint32_t nv, rv;
+                    dbk_resolve(p, cend[k] - 1, ek[k], u, nv, rv);
+                    const int32_t lo = pu + (int32_t)pnv; // first dpos at or after the op's first base
+                    const bool emit = kind[k] != 0u && kind[k] != 3u && u > lo;
+                    const uint32_t arr = (kind[k] == 2u ? (STRANDED ? 2u : 1u) : 0u) + sidx;
+                    // junction ends: lSite is the previous boundary's position, rSite this one's
+                    rival |= (kind[k] == 2u) & (((pnv & prv) | (nv & rv)) != 0u);
+                    if (__any(emit)) {
+                        commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
+                        commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)u << 2) | arr, -1);
                     }
+                    if (kind[k]) { pu = u; pnv = nv; prv = rv; }
                 }
-                if (__any(emit)) {
-                    commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
-                    commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)hi << 2) | arr, -1);
-                }
+                const bool more = alive && wide && k_next < n_ops;
+                if (!__any(more)) break;
+#pragma unroll
+                for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = (more && k_next + (uint32_t)k < n_ops) ? p.cigar[o0 + k_next + (uint32_t)k] : 0xfu;
+                k_next += (uint32_t)SPL_INLINE_OPS;
             }
             if (bad) atomicOr(p.err, SPL_DEV_ERR_RANGE);
             bool to_queue = literal;
@@ -612,9 +676,12 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
             if (to_queue) s_q[atomicAdd(&s_qn, 1u)] = (uint32_t)(it * SPL_BLOCK + tid);
         }
     }
+    SPL_PHASE(6);
     __syncthreads();
     // Hand the chunk's queue over: one returning atomic per workgroup on the counter of its XCD shard (8 counters, so
-    // no single word sees more than a few reservations per microsecond), then a dense copy.
+    // no single word sees more than a few reservations per microsecond), then a dense copy of packed indexes.
+    // (Per-chunk regions without any atomic were tried: the range kernel gains 1 %, the literal kernel then has to walk
+    // regions of very uneven fill and loses far more.)
     const uint32_t qn = s_qn; // uniform: read after the barrier above
     if (qn) {
         const uint32_t shard = blockIdx.x & 7u;
@@ -631,6 +698,11 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_ranges_kernel(const spl_h
             atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + wbase + loc], v);
         }
     }
+    SPL_PHASE(7);
+#ifdef SPL_PHASE_TIMING
+    ph_[2] = (uint64_t)__builtin_amdgcn_s_getreg(0xF804) | ((uint64_t)__builtin_amdgcn_s_getreg(0xF814) << 32); // HW_ID, XCC_ID
+#endif
+    SPL_PHASE_WRITE;
 }
 
 namespace {
@@ -885,52 +957,113 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
 // update the same counters: those updates are merged across the wave before they reach HBM (agg_add), because one
 // counter word takes only so many atomics per microsecond no matter how many CUs send them.
 template <bool STRANDED>
-__global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_params p, const uint32_t *queue, const uint32_t *queue_n,
-                                                                uint32_t queue_cap)
+__global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_params p, const spl_queue_params q)
 {
-    // the 8 shard regions are walked as ONE index space (a wave must not pay the latency chain once per shard)
+    // The 8 shard regions are walked as ONE index space (a wave must not pay the latency chain once per shard).
+    // Entries are packed indexes: the read is taken from the range kernel's own arrays (one trip), its ops are inline
+    // or start at the stored offset.
     uint32_t start[9];
     start[0] = 0;
 #pragma unroll
-    for (int sh = 0; sh < 8; ++sh) start[sh + 1] = start[sh] + queue_n[sh];
+    for (int sh = 0; sh < 8; ++sh) start[sh + 1] = start[sh] + q.queue_n[sh];
     const uint32_t total = start[8];
-    for (uint32_t g = blockIdx.x * 64u + threadIdx.x; g < total; g += gridDim.x * 64u) {
-        uint32_t shard = 0;
+    {
+        for (uint32_t g = blockIdx.x * 64u + threadIdx.x; g < total; g += gridDim.x * 64u) {
+            uint32_t shard = 0;
 #pragma unroll
-        for (int sh = 1; sh < 8; ++sh) shard += (g >= start[sh]) ? 1u : 0u;
-        uint32_t base = 0;
+            for (int sh = 1; sh < 8; ++sh) shard += (g >= start[sh]) ? 1u : 0u;
+            uint32_t base = 0;
 #pragma unroll
-        for (int sh = 0; sh < 8; ++sh) base = (shard == (uint32_t)sh) ? start[sh] : base;
-        const int64_t i = queue[(size_t)shard * queue_cap + (g - base)];
-        const int32_t pos = p.r_pos[i];
-        const uint32_t flag = p.r_flag[i];
-        const uint32_t o0 = p.cig_off[i];
-        const uint32_t n_ops = p.cig_off[i + 1] - o0;
-        const uint32_t *ops = p.cigar + o0;
-        int64_t ref_len; bool hn;
-        spl_read_extent(ops, n_ops, &ref_len, &hn);
-        if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
-        if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
-        if (rivals_table_path<STRANDED>(p, pos, flag, ops, n_ops)) continue;
-        if (rivals_closed_form<STRANDED>(p, pos, flag, ops, n_ops)) continue;
-        rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
+            for (int sh = 0; sh < 8; ++sh) base = (shard == (uint32_t)sh) ? start[sh] : base;
+            const int64_t idx = q.queue[(size_t)shard * q.queue_cap + (g - base)];
+            const int32_t pos = q.r_pos[idx];
+            const uint32_t fn = q.r_fn[idx];
+            const uint32_t flag = fn & 0xffffu;
+            uint32_t n_ops = fn >> 16;
+            const uint32_t *ops = q.r_ops3 + 3 * idx;
+            if (n_ops > (uint32_t)SPL_INLINE_OPS) {
+                const uint32_t o0 = ops[2] - 2u;
+                ops = p.cigar + o0;
+                if (n_ops == 0xffffu) { // the packed count saturates: the true one from the BAM-native offsets
+                    const int64_t i = (idx / SPL_CHUNK) * SPL_CHUNK + q.perm[idx];
+                    n_ops = p.cig_off[i + 1] - o0;
+                }
+            }
+            int64_t ref_len; bool hn;
+            spl_read_extent(ops, n_ops, &ref_len, &hn);
+            if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
+            if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
+            if (rivals_table_path<STRANDED>(p, pos, flag, ops, n_ops)) continue;
+            if (rivals_closed_form<STRANDED>(p, pos, flag, ops, n_ops)) continue;
+            rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
+        }
     }
 }
 
-// The range kernel's read layout, derived once per upload from the BAM-native arrays: one word with flag and op count,
-// three words with the first ops (or two ops and where the rest start), so that everything a typical read needs
-// arrives in ONE memory trip without going through cig_off first.
-__global__ __launch_bounds__(256) void spl_pack_reads_kernel(int64_t n_reads, const uint16_t *flag, const uint32_t *cig_off,
-                                                             const uint32_t *cigar, uint32_t *fn, uint32_t *ops3)
+// The range kernel's read layout, derived once per upload from the BAM-native arrays (one workgroup per chunk):
+//   * one word with flag and op count, three words with the first ops (or two ops and where the rest start), so that
+//     everything a typical read needs arrives in ONE memory trip without going through cig_off first;
+//   * inside each chunk the reads are stably partitioned into three runs: "simple" reads (exactly one aligned op,
+//     mapped, in range -- every unspliced short read), other reads of at most SPL_INLINE_OPS ops, wide reads.  Each run
+//     keeps coordinate order.  A wave of the range kernel then sees (almost always) one kind of read: simple ones take
+//     a path of their own on a wave-uniform branch, and only waves of wide reads walk further batches of ops.
+//   perm[] maps a packed slot back to the read's place in the chunk.
+__global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_reads, const int32_t *pos, const uint16_t *flag,
+                                                                   const uint32_t *cig_off, const uint32_t *cigar, int32_t *p_pos,
+                                                                   uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_reads) return;
-    const uint32_t o0 = cig_off[i], n = cig_off[i + 1] - o0;
-    fn[i] = (uint32_t)flag[i] | ((n < 0xffffu ? n : 0xffffu) << 16);
-    uint32_t w[3] = {0xfu, 0xfu, 0xfu};
-    if (n <= 3u) { for (uint32_t k = 0; k < n; ++k) w[k] = cigar[o0 + k]; }
-    else { w[0] = cigar[o0]; w[1] = cigar[o0 + 1]; w[2] = o0 + 2u; }
-    ops3[3 * i] = w[0]; ops3[3 * i + 1] = w[1]; ops3[3 * i + 2] = w[2];
+    constexpr int NW = SPL_BLOCK / 64;
+    __shared__ uint32_t cnt[3][SPL_RPT][NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t cb = (int64_t)blockIdx.x * SPL_CHUNK;
+    int32_t r_pos[SPL_RPT];
+    uint32_t r_fn[SPL_RPT], w[SPL_RPT][3], rank[SPL_RPT];
+    int cls[SPL_RPT]; // 0 simple, 1 narrow, 2 wide, 3 past the end
+#pragma unroll
+    for (int it = 0; it < SPL_RPT; ++it) {
+        const int64_t i = cb + (int64_t)it * SPL_BLOCK + tid;
+        cls[it] = 3;
+        r_pos[it] = 0; r_fn[it] = 0; w[it][0] = w[it][1] = w[it][2] = 0xfu;
+        if (i < n_reads) {
+            const uint32_t o0 = cig_off[i], n = cig_off[i + 1] - o0;
+            r_pos[it] = pos[i];
+            r_fn[it] = (uint32_t)flag[i] | ((n < 0xffffu ? n : 0xffffu) << 16);
+            if (n <= 3u) { for (uint32_t k = 0; k < n; ++k) w[it][k] = cigar[o0 + k]; }
+            else { w[it][0] = cigar[o0]; w[it][1] = cigar[o0 + 1]; w[it][2] = o0 + 2u; }
+            const bool simple = n == 1u && ((SPL_KIND_TABLE >> (2u * (w[it][0] & 15u))) & 3u) == 1u && !(flag[i] & 4u) && r_pos[it] >= 0 &&
+                                (int64_t)r_pos[it] + (int64_t)(w[it][0] >> 4) <= (int64_t)SPL_COORD_MAX;
+            cls[it] = simple ? 0 : (n <= 3u ? 1 : 2);
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        rank[it] = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned long long m = __ballot(cls[it] == c);
+            if (cls[it] == c) rank[it] = (uint32_t)__popcll(m & below);
+            if (lane == 0) cnt[c][it][wave] = (uint32_t)__popcll(m);
+        }
+    }
+    __syncthreads();
+    uint32_t total[3] = {0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (int it = 0; it < SPL_RPT; ++it)
+            for (int wv = 0; wv < NW; ++wv) total[c] += cnt[c][it][wv];
+#pragma unroll
+    for (int it = 0; it < SPL_RPT; ++it) {
+        if (cls[it] == 3) continue;
+        const int c = cls[it];
+        uint32_t before = c == 0 ? 0u : (c == 1 ? total[0] : total[0] + total[1]); // runs of the classes before mine
+        // reads of my class in earlier (it, wave) groups: chunk order is it-major, then wave, then lane
+        for (int it2 = 0; it2 <= it; ++it2)
+            for (int wv = 0; wv < NW; ++wv)
+                if (it2 < it || wv < wave) before += cnt[c][it2][wv];
+        const int64_t dst = cb + before + rank[it];
+        p_pos[dst] = r_pos[it];
+        p_fn[dst] = r_fn[it];
+        p_ops3[3 * dst] = w[it][0]; p_ops3[3 * dst + 1] = w[it][1]; p_ops3[3 * dst + 2] = w[it][2];
+        perm[dst] = (uint16_t)(it * SPL_BLOCK + tid);
+    }
 }
 
 // =========================================================================================================
@@ -1084,6 +1217,16 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
     } else {
         *lds_out = (p->stranded ? 4 : 2) * (SPL_WIN + 1) * 4 + 4;
         const bool agg = !(variant & 2);
+#ifdef SPL_PHASE_TIMING
+        static uint64_t *phase_buf = nullptr;
+        static size_t phase_cap = 0;
+        if (phase_cap < (size_t)grid * 8) {
+            if (phase_buf) (void)hipFree(phase_buf);
+            phase_cap = (size_t)grid * 8;
+            if (hipMalloc((void **)&phase_buf, phase_cap * 8) != hipSuccess) return (int)hipErrorOutOfMemory;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), &phase_buf, sizeof(phase_buf));
+        }
+#endif
         if (p->stranded) {
             if (agg) hipLaunchKernelGGL((spl_count_ranges_kernel<true, true>), dim3(grid), dim3(SPL_BLOCK), 0, st, *h);
             else hipLaunchKernelGGL((spl_count_ranges_kernel<true, false>), dim3(grid), dim3(SPL_BLOCK), 0, st, *h);
@@ -1091,25 +1234,35 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
             if (agg) hipLaunchKernelGGL((spl_count_ranges_kernel<false, true>), dim3(grid), dim3(SPL_BLOCK), 0, st, *h);
             else hipLaunchKernelGGL((spl_count_ranges_kernel<false, false>), dim3(grid), dim3(SPL_BLOCK), 0, st, *h);
         }
+#ifdef SPL_PHASE_TIMING
+        if (const char *path = getenv("SPL_PHASE_DUMP")) {
+            (void)hipStreamSynchronize(st);
+            uint64_t *host = (uint64_t *)malloc((size_t)grid * 64);
+            (void)hipMemcpy(host, phase_buf, (size_t)grid * 64, hipMemcpyDeviceToHost);
+            if (FILE *f = fopen(path, "wb")) { fwrite(host, 64, grid, f); fclose(f); }
+            free(host);
+        }
+#endif
     }
     return (int)hipGetLastError();
 }
 
-extern "C" int spl_dev_launch_literal(const spl_count_params *p, const uint32_t *queue, const uint32_t *queue_n, uint32_t queue_cap, void *stream)
+extern "C" int spl_dev_launch_literal(const spl_count_params *p, const spl_queue_params *q, void *stream)
 {
     if (p->n_reads <= 0 || p->n_sites <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(SPL_LITERAL_WAVES), dim3(64), 0, st, *p, queue, queue_n, queue_cap);
-    else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(SPL_LITERAL_WAVES), dim3(64), 0, st, *p, queue, queue_n, queue_cap);
+    const uint32_t grid = SPL_LITERAL_WAVES;
+    if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(grid), dim3(64), 0, st, *p, *q);
+    else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(grid), dim3(64), 0, st, *p, *q);
     return (int)hipGetLastError();
 }
 
-extern "C" int spl_dev_launch_pack(int64_t n_reads, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar, uint32_t *fn,
-                                   uint32_t *ops3, void *stream)
+extern "C" int spl_dev_launch_pack(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar,
+                                   int32_t *p_pos, uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm, void *stream)
 {
     if (n_reads <= 0) return 0;
-    hipLaunchKernelGGL(spl_pack_reads_kernel, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_reads, flag,
-                       cig_off, cigar, fn, ops3);
+    hipLaunchKernelGGL(spl_pack_reads_kernel, dim3((uint32_t)((n_reads + SPL_CHUNK - 1) / SPL_CHUNK)), dim3(SPL_BLOCK), 0, (hipStream_t)stream,
+                       n_reads, pos, flag, cig_off, cigar, p_pos, p_fn, p_ops3, perm);
     return (int)hipGetLastError();
 }
 

@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libspliser_hip.so")
+# SPLISER_HIP_LIB: load another build of the same library (kernel experiments: tools/exp_modes.sh)
+LIB_PATH = os.environ.get("SPLISER_HIP_LIB") or os.path.join(HERE, "libspliser_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 
 STRANDED_CODE = {None: 0, False: 0, "": 0, "fr": 1, "rf": 2}
