@@ -551,8 +551,9 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
         return spl_set_error(SPL_ERR_ARG, "stranded must be 0 (unstranded), 1 (fr) or 2 (rf); the reference raises "
                                           "UnboundLocalError for any other strandedType");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(ds->beta1, 0, ds->counter_bytes, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int32_t), c->stream));
+    // counters, difference arrays, error word and queue counters start from zero: one launch for all of them
+    if (int rc0 = spl_dev_launch_clear(ds->beta1, ds->counter_bytes, c->d_err, dr->queue_n, c->stream))
+        return spl_set_error(SPL_ERR_HIP, "clear kernel launch: %s", hipGetErrorString((hipError_t)rc0));
     spl_count_params p;
     memset(&p, 0, sizeof(p));
     p.n_reads = dr->n_reads;
@@ -572,7 +573,6 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = dr->queue; h.queue_n = dr->queue_n; h.err = c->d_err;
     h.queue_cap = (uint32_t)(((p.n_chunks + 7u) / 8u) * SPL_CHUNK);
-    HIP_TRY(hipMemsetAsync(dr->queue_n, 0, 8 * sizeof(uint32_t), c->stream));
     h.jhash = ds->jhash; h.jhash_mask = ds->jhash_mask; h.jrivals = ds->jrivals; h.dbl = ds->dbl; h.combine_mode = o->combine_mode ? 1 : 0;
 
     p.bucket = ds->bucket; p.n_buckets = ds->n_buckets; p.bucket_base = ds->bucket_base; p.bucket_shift = ds->bucket_shift;

@@ -473,7 +473,10 @@ __device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, int32_t *
 #ifdef SPL_PHASE_TIMING
 __device__ uint64_t *g_phase;
 #define SPL_PHASE_DECL uint64_t ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define SPL_PHASE(slot) do { if ((slot) < 8) ph_[(slot) < 8 ? (slot) : 0] = wall_clock64(); } while (0)
+#ifndef SPL_PHASE_SET
+#define SPL_PHASE_SET 0xc3 /* which stamps are taken (bit per slot): every stamp costs two SGPRs the kernel does not have */
+#endif
+#define SPL_PHASE(slot) do { if ((SPL_PHASE_SET >> (slot)) & 1) ph_[slot] = wall_clock64(); } while (0) /* constant slots only */
 #define SPL_PHASE_WRITE do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) g_phase[(size_t)blockIdx.x * 8 + k_] = ph_[k_]; } while (0)
 #else
 #define SPL_PHASE_DECL do { } while (0)
@@ -543,7 +546,11 @@ __global__ __launch_bounds__(SPL_BLOCK) SPL_RANGE_ATTR void spl_count_ranges_ker
 
     if (live) {
         for (int it = 0; it < SPL_RPT; ++it) {
-            if (it >= 1 && it < 4) SPL_PHASE(2 + it); // reads 1..3 of the chunk get a stamp each (read 0 starts at stamp 1)
+#ifndef SPL_PHASE_TAIL
+            if (it == 1) SPL_PHASE(3); // reads 1..3 of the chunk get a stamp each (read 0 starts at stamp 1)
+            if (it == 2) SPL_PHASE(4);
+            if (it == 3) SPL_PHASE(5);
+#endif
             // Straight-line and branch-free up to the commits: out-of-range lanes re-read the last read and are masked
             // at the end, so all loads of a trip issue back to back.  Control flow is wave-uniform around every
             // commit_key (all 64 lanes reach it).
@@ -678,6 +685,9 @@ __global__ __launch_bounds__(SPL_BLOCK) SPL_RANGE_ATTR void spl_count_ranges_ker
     }
     SPL_PHASE(6);
     __syncthreads();
+#ifdef SPL_PHASE_TAIL
+    SPL_PHASE(3); // with SPL_PHASE_TAIL slots 3 and 4 look inside the epilogue: barrier passed, queue handed over
+#endif
     // Hand the chunk's queue over: one returning atomic per workgroup on the counter of its XCD shard (8 counters, so
     // no single word sees more than a few reservations per microsecond), then a dense copy of packed indexes.
     // (Per-chunk regions without any atomic were tried: the range kernel gains 1 %, the literal kernel then has to walk
@@ -691,6 +701,9 @@ __global__ __launch_bounds__(SPL_BLOCK) SPL_RANGE_ATTR void spl_count_ranges_ker
         const uint32_t first = (uint32_t)chunk_base;
         for (uint32_t j = tid; j < qn; j += SPL_BLOCK) dst[j] = first + s_q[j];
     }
+#ifdef SPL_PHASE_TAIL
+    SPL_PHASE(4);
+#endif
     for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) {
         const int32_t v = lds[j];
         if (v) {
@@ -1199,7 +1212,26 @@ __global__ __launch_bounds__(256) void spl_sse_kernel(const spl_sse_params p)
     p.sse[s] = value;
 }
 
+// Everything a counting pass starts from zero, in one launch: the counter / difference-array region of the site table
+// (16-byte aligned, a multiple of 16 bytes), the device error word and the queue counters.
+__global__ __launch_bounds__(256) void spl_clear_kernel(uint4 *region, size_t n16, int32_t *err, uint32_t *queue_n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n16; j += stride) region[j] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x < 8) queue_n[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 8) *err = 0;
+}
+
 // ---- launchers (called from spl_capi.cpp through spl_device.h) ------------------------------------------
+
+extern "C" int spl_dev_launch_clear(void *region, size_t bytes, int32_t *err, uint32_t *queue_n, void *stream)
+{
+    const size_t n16 = bytes / 16;
+    size_t blocks = (n16 + 256 * 4 - 1) / (256 * 4); // four stores per thread
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(spl_clear_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, (uint4 *)region, n16, err, queue_n);
+    return (int)hipGetLastError();
+}
 
 extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out)
 {

@@ -6,21 +6,24 @@ import sys
 import numpy as np
 
 raw = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
-ok = (raw[:, 7] > 0) & (raw[:, 3] > 0)
-raw = raw[ok]
+raw = raw[raw[:, 7] > 0]
 hw = raw[:, 2].copy()
 t = raw.astype(np.int64)
-t[:, 2] = t[:, 1]
+t[:, 2] = 0  # slot 2 carries HW_ID / XCC_ID, not a stamp
+have = [k for k in range(8) if (t[:, k] > 0).all()]
 t0 = t[:, 0].min()
 us = (t - t0) / 100.0
 span = us[:, 7].max()
-names = ["prologue (loads ahead, zero LDS, barrier)", None, "read 0", "read 1", "read 2", "read 3 .. last", "barrier + queue + flush"]
-print("workgroups %d   kernel span %.1f us" % (len(t), span))
-for k, name in enumerate(names):
-    if name is None:
-        continue
-    d = us[:, k + 1] - us[:, k]
-    print("  %-44s mean %7.2f us   p50 %7.2f   p90 %7.2f" % (name, d.mean(), np.percentile(d, 50), np.percentile(d, 90)))
+label = {0: "start", 1: "loads ahead issued, LDS zeroed, barrier passed", 3: "read 1 begins", 4: "read 2 begins", 5: "read 3 begins",
+         6: "last read done (wave 0)", 7: "barrier, queue handed over, LDS flushed"}
+if len(sys.argv) > 2 and sys.argv[2] == "tail":  # built with -DSPL_PHASE_TAIL: slots 3, 4 are epilogue stamps
+    label.update({3: "barrier after the loop passed", 4: "queue handed over", 7: "LDS flushed"})
+    order = [0, 1, 6, 3, 4, 7]
+    have = [k for k in order if k in have]
+print("workgroups %d   kernel span %.1f us   stamps %s" % (len(t), span, have))
+for a, b in zip(have[:-1], have[1:]):
+    d = us[:, b] - us[:, a]
+    print("  %-62s mean %7.2f us   p50 %7.2f   p90 %7.2f" % ("-> " + label[b], d.mean(), np.percentile(d, 50), np.percentile(d, 90)))
 life = us[:, 7] - us[:, 0]
 print("  %-44s mean %7.2f us   p50 %7.2f   p90 %7.2f" % ("workgroup lifetime", life.mean(), np.percentile(life, 50), np.percentile(life, 90)))
 print("  mean resident workgroups %.1f (= sum of lifetimes / span)" % (life.sum() / span))
