@@ -303,14 +303,20 @@ static void build_junction_table(const spl_sites *s, const std::vector<uint8_t> 
     }
     size_t cap = 16;
     while (cap < 2 * juncs.size() + 1) cap <<= 1;
-    jhash.assign(cap, make_uint4(0x80000000u, 0, 0, 0));
+    // a slot is two quads: {l, r, first rival record, count | flags} and a copy of the first rival's first quad, so that
+    // the common one-rival junction costs the range kernel one memory trip instead of two
+    jhash.assign(2 * cap, make_uint4(0x80000000u, 0, 0, 0));
     for (const Junc &j : juncs) {
         uint32_t h = (uint32_t)j.l * 0x9E3779B1u ^ (uint32_t)j.r * 0x85EBCA77u;
         h ^= h >> 15;
         // the kernel gives up after 8 probes: an entry that cannot be placed within 8 is simply left out (-> literal kernel)
         for (uint32_t probe = 0; probe < 8; ++probe) {
-            uint4 &slot = jhash[(h + probe) & (cap - 1)];
-            if (slot.x == 0x80000000u) { slot = make_uint4((uint32_t)j.l, (uint32_t)j.r, j.off, j.info); break; }
+            uint4 *slot = &jhash[2 * ((h + probe) & (cap - 1))];
+            if (slot[0].x == 0x80000000u) {
+                slot[0] = make_uint4((uint32_t)j.l, (uint32_t)j.r, j.off, j.info);
+                slot[1] = (j.info & 0xffu) ? jrivals[2 * (size_t)j.off] : make_uint4(0, 0, 0xffffffffu, 0xffffffffu);
+                break;
+            }
         }
     }
     if (jrivals.empty()) jrivals.assign(2, make_uint4(0, 0, 0xffffffffu, 0xffffffffu));
@@ -421,9 +427,9 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
         for (int64_t j = 0; j < D; ++j)
             for (int32_t r = dfirst[(size_t)j]; r < dfirst[(size_t)j + 1]; ++r) row_dpos[(size_t)r] = (int32_t)j;
         if (d->mutual_links && s->part_site) build_junction_table(s, flags, dfirst, row_dpos, jhash, jrivals);
-        if (jhash.empty()) { jhash.assign(16, make_uint4(0x80000000u, 0, 0, 0)); jrivals.assign(2, make_uint4(0, 0, 0xffffffffu, 0xffffffffu)); }
+        if (jhash.empty()) { jhash.assign(32, make_uint4(0x80000000u, 0, 0, 0)); jrivals.assign(2, make_uint4(0, 0, 0xffffffffu, 0xffffffffu)); }
     }
-    d->jhash_mask = (uint32_t)jhash.size() - 1u;
+    d->jhash_mask = (uint32_t)(jhash.size() / 2) - 1u;
     d->diff_stride = (int32_t)align_up((size_t)D + 2, 64);
     d->scan_blocks = (int32_t)((D + SPL_SCAN_BLOCK - 1) / SPL_SCAN_BLOCK);
 

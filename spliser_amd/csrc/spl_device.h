@@ -101,7 +101,7 @@ struct spl_hot_params {
     int32_t *diff;
     int32_t diff_stride;
     // junction table: BED junctions with a flagged end -> their rival sites (built at upload)
-    const uint4 *jhash;          // {l, r, first rival record, n_rivals | SPL_JF_*}; l == 0x80000000 = empty slot
+    const uint4 *jhash;          // two quads per slot: {l, r, first rival record, n_rivals | SPL_JF_*} (l == 0x80000000 = empty), first rival
     uint32_t jhash_mask;
     const uint4 *jrivals;        // {t_pos, t_dpos | strand code << 30, double-count edge 0, edge 1 (0xffffffff = none)}
     uint32_t *dbl;

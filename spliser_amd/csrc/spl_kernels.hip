@@ -419,10 +419,12 @@ __device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, int32_t *
 {
     uint32_t h = (uint32_t)l * 0x9E3779B1u ^ (uint32_t)r * 0x85EBCA77u;
     h ^= h >> 15;
-    uint4 ent = make_uint4(0, 0, 0, 0);
+    uint4 ent = make_uint4(0, 0, 0, 0), first = make_uint4(0, 0, 0, 0);
     bool found = false;
     for (int probe = 0; probe < 8; ++probe) {
-        ent = p.jhash[(h + (uint32_t)probe) & p.jhash_mask];
+        const uint4 *slot = p.jhash + 2u * ((h + (uint32_t)probe) & p.jhash_mask);
+        ent = slot[0];
+        first = slot[1]; // the first rival's record rides along: one trip for the usual one-rival junction
         if ((int32_t)ent.x == l && (int32_t)ent.y == r) { found = true; break; }
         if (ent.x == 0x80000000u) break; // empty slot: not a BED junction with flagged ends
     }
@@ -431,7 +433,7 @@ __device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, int32_t *
     if ((ent.w & SPL_JF_COMPLEX) || n_riv > 4u) return false;
     if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) return false; // several rows share a rival's position: per-row only
     for (uint32_t i = 0; i < n_riv; ++i) {
-        const uint4 rv = p.jrivals[2u * (ent.z + i)]; // {t_pos, t_dpos | strand << 30, edge0, edge1} (+ a second quad: literal kernel)
+        const uint4 rv = i ? p.jrivals[2u * (ent.z + i)] : first; // {t_pos, t_dpos | strand << 30, edge0, edge1} (+ a second quad: literal kernel)
         const int32_t t = (int32_t)rv.x;
         const uint32_t td = rv.y & 0x3fffffffu;
         if (STRANDED && ((rv.y >> 30) != (sidx ? 2u : 1u))) continue; // strand_ok false: the ranges added nothing
@@ -895,7 +897,7 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
         bool found = false;
         uint4 ent = make_uint4(0, 0, 0, 0);
         for (int probe = 0; probe < 8; ++probe) {
-            ent = p.jhash[(h + (uint32_t)probe) & p.jhash_mask];
+            ent = p.jhash[2u * ((h + (uint32_t)probe) & p.jhash_mask)];
             if ((int32_t)ent.x == l && (int32_t)ent.y == r) { found = true; break; }
             if (ent.x == 0x80000000u) break;
         }
