@@ -76,6 +76,8 @@ struct spl_dsites {
     uint32_t n_dbuckets = 0;
     int32_t dbase = 0;         // coordinate of the first (empty) bucket
     uint32_t *rival_bits = nullptr;
+    uint32_t *ucl_off = nullptr; // per distinct position: competitor positions of the partners of its rows (flagged rows only)
+    int32_t *ucl_pos = nullptr;
     uint4 *jhash = nullptr;    // junction table (see build_junction_table)
     uint32_t jhash_mask = 0;
     uint4 *jrivals = nullptr;
@@ -430,6 +432,29 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
         if (jhash.empty()) { jhash.assign(32, make_uint4(0x80000000u, 0, 0, 0)); jrivals.assign(2, make_uint4(0, 0, 0xffffffffu, 0xffffffffu)); }
     }
     d->jhash_mask = (uint32_t)(jhash.size() / 2) - 1u;
+    // For a read junction that is NOT an edge of the table but ends on a flagged position x, a rival t needs x in P_t and
+    // the other end in C_t (:494-501).  With mutual links such t are partners of the rows at x, so the union of their
+    // competitor lists decides in one short scan whether the literal walk is needed at all (it almost never is).
+    std::vector<uint32_t> ucl_off((size_t)D + 1, 0u);
+    std::vector<int32_t> ucl_pos;
+    if (d->mutual_links && s->part_site) {
+        std::vector<int32_t> tmp;
+        for (int64_t j = 0; j < D; ++j) {
+            ucl_off[(size_t)j] = (uint32_t)ucl_pos.size();
+            if (!((rbits[(size_t)j >> 5] >> (j & 31)) & 1u)) continue;
+            tmp.clear();
+            for (int32_t x = dfirst[(size_t)j]; x < dfirst[(size_t)j + 1]; ++x)
+                for (uint32_t e = s->part_off[x]; e < s->part_off[x + 1]; ++e) {
+                    const int32_t t = s->part_site[e];
+                    if (t < 0) continue;
+                    for (uint32_t f = s->comp_off[t]; f < s->comp_off[t + 1]; ++f) tmp.push_back(s->comp_pos[f]);
+                }
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            ucl_pos.insert(ucl_pos.end(), tmp.begin(), tmp.end());
+        }
+    }
+    ucl_off[(size_t)D] = (uint32_t)ucl_pos.size();
     d->diff_stride = (int32_t)align_up((size_t)D + 2, 64);
     d->scan_blocks = (int32_t)((D + SPL_SCAN_BLOCK - 1) / SPL_SCAN_BLOCK);
 
@@ -441,6 +466,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     const size_t o_alpha = take(8 * S), o_ecnt = take(8 * P), o_bucket = take(4 * bucket.size());
     const size_t o_dfirst = take(4 * dfirst.size()), o_dbucket = take(16 * dbucket.size()), o_rbits = take(4 * rbits.size());
     const size_t o_jhash = take(16 * jhash.size()), o_jriv = take(16 * jrivals.size());
+    const size_t o_uoff = take(4 * ucl_off.size()), o_upos = take(4 * ucl_pos.size());
     const size_t o_cnt = off;
     const size_t o_b1 = take(4 * S), o_b2 = take(4 * S), o_dbl = take(4 * P);
     const size_t o_diff = take(4 * 4 * (size_t)d->diff_stride);
@@ -454,6 +480,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     d->flags = (uint8_t *)(d->slab + o_flags); d->diff = (int32_t *)(d->slab + o_diff); d->block_sums = (int32_t *)(d->slab + o_bsum);
     d->dpos_first_row = (int32_t *)(d->slab + o_dfirst); d->dbucket = (uint4 *)(d->slab + o_dbucket); d->rival_bits = (uint32_t *)(d->slab + o_rbits);
     d->jhash = (uint4 *)(d->slab + o_jhash); d->jrivals = (uint4 *)(d->slab + o_jriv);
+    d->ucl_off = (uint32_t *)(d->slab + o_uoff); d->ucl_pos = (int32_t *)(d->slab + o_upos);
     d->part_off = (uint32_t *)(d->slab + o_poff); d->part_pos = (int32_t *)(d->slab + o_ppos); d->part_site = (int32_t *)(d->slab + o_psite);
     d->comp_pos = (int32_t *)(d->slab + o_cpos); d->alpha = (int64_t *)(d->slab + o_alpha); d->edge_cnt = (int64_t *)(d->slab + o_ecnt);
     d->bucket = (uint32_t *)(d->slab + o_bucket);
@@ -475,6 +502,8 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (r == hipSuccess) r = up(d->rival_bits, rbits.data(), 4 * rbits.size());
     if (r == hipSuccess) r = up(d->jhash, jhash.data(), 16 * jhash.size());
     if (r == hipSuccess) r = up(d->jrivals, jrivals.data(), 16 * jrivals.size());
+    if (r == hipSuccess) r = up(d->ucl_off, ucl_off.data(), 4 * ucl_off.size());
+    if (r == hipSuccess) r = up(d->ucl_pos, ucl_pos.data(), 4 * ucl_pos.size());
     if (r == hipSuccess) r = up(d->part_off, s->part_off, S ? 4 * (S + 1) : 0);
     if (r == hipSuccess) r = up(d->part_pos, s->part_pos, 4 * P);
     if (r == hipSuccess) r = up(d->part_site, s->part_site, 4 * P);
@@ -570,7 +599,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.part_pos = ds->part_pos; p.part_site = ds->part_site; p.comp_pos = ds->comp_pos;
     p.diff = ds->diff; p.diff_stride = ds->diff_stride;
     p.dbucket = ds->dbucket; p.n_dbuckets = ds->n_dbuckets; p.dbase = ds->dbase; p.n_dpos = ds->n_dpos;
-    p.rival_bits = ds->rival_bits; p.dpos_first_row = ds->dpos_first_row;
+    p.rival_bits = ds->rival_bits; p.dpos_first_row = ds->dpos_first_row; p.ucl_off = ds->ucl_off; p.ucl_pos = ds->ucl_pos;
     p.jhash = ds->jhash; p.jhash_mask = ds->jhash_mask; p.jrivals = ds->jrivals;
     spl_hot_params h;
     memset(&h, 0, sizeof(h));

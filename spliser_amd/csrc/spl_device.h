@@ -64,6 +64,8 @@ struct spl_count_params {
     int32_t dbase;
     int32_t n_dpos;
     const uint32_t *rival_bits;  // bit d: some row at distinct position d carries SPL_SF_RIVALS
+    const uint32_t *ucl_off;     // [n_dpos + 1] per distinct position: the competitor positions of all partners of its rows
+    const int32_t *ucl_pos;      //   (sorted, unique) -- a junction from there to anywhere else cannot make a rival
     const int32_t *dpos_first_row;
     const uint4 *jhash;          // junction table (see spl_hot_params)
     uint32_t jhash_mask;

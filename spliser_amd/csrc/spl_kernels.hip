@@ -472,8 +472,10 @@ __device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, int32_t *
 // the tuned case).
 // Development aid, compiled out of the product (make EXTRA=-DSPL_PHASE_TIMING): wave 0 of every workgroup stamps the
 // 100 MHz wall clock at the phase borders of the range kernel; tools/phase_report.py turns the dump into a timeline.
-#ifdef SPL_PHASE_TIMING
+#if defined(SPL_PHASE_TIMING) || defined(SPL_PHASE_LITERAL)
 __device__ uint64_t *g_phase;
+#endif
+#ifdef SPL_PHASE_TIMING
 #define SPL_PHASE_DECL uint64_t ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #ifndef SPL_PHASE_SET
 #define SPL_PHASE_SET 0xc3 /* which stamps are taken (bit per slot): every stamp costs two SGPRs the kernel does not have */
@@ -858,10 +860,24 @@ __device__ __forceinline__ bool rivals_closed_form(const spl_count_params &p, in
 // covered with t+1 by an aligned block -> beta1-type.  Anything the table cannot decide exactly (a junction that is not
 // in the BED file but touches flagged sites, a rival that is itself a junction end of the read, entries marked complex,
 // combine mode) returns false and the read takes rivals_closed_form.  Updates go to the global difference arrays.
+// Is position x among the competitor positions of any partner of the rows at distinct position d?  (built at upload)
+__device__ __forceinline__ bool ucl_contains(const spl_count_params &p, int32_t d, int32_t x)
+{
+    bool hit = false;
+    for (uint32_t k = p.ucl_off[d], e = p.ucl_off[d + 1]; k < e; ++k) hit |= (p.ucl_pos[k] == x);
+    return hit;
+}
+
+#ifdef SPL_PHASE_LITERAL
+__device__ unsigned long long g_tp_fail[8]; // why reads leave the table path (development aid)
+#define SPL_TP_FAIL(code) do { atomicAdd(&g_tp_fail[code], 1ull); return false; } while (0)
+#else
+#define SPL_TP_FAIL(code) return false
+#endif
 template <bool STRANDED>
 __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int32_t pos, uint32_t flag, const uint32_t *ops, uint32_t n_ops)
 {
-    if (p.combine_mode) return false;
+    if (p.combine_mode) SPL_TP_FAIL(1);
     int32_t blk_a[SPL_CF_BLK], blk_b[SPL_CF_BLK], jl[SPL_CF_JUNC], jr[SPL_CF_JUNC];
     int n_blk = 0, n_j = 0;
     int32_t cur = pos;
@@ -873,12 +889,12 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
         const int32_t start = cur;
         cur += d;
         if (code == SPL_OP_N) {
-            if (n_j == SPL_CF_JUNC) return false;
+            if (n_j == SPL_CF_JUNC) SPL_TP_FAIL(2);
 #pragma unroll
             for (int j = 0; j < SPL_CF_JUNC; ++j) if (j == n_j) { jl[j] = start - 1; jr[j] = cur - 1; }
             ++n_j;
         } else if (code != SPL_OP_D && d >= 2) {
-            if (n_blk == SPL_CF_BLK) return false;
+            if (n_blk == SPL_CF_BLK) SPL_TP_FAIL(3);
 #pragma unroll
             for (int j = 0; j < SPL_CF_BLK; ++j) if (j == n_blk) { blk_a[j] = start; blk_b[j] = cur - 1; }
             ++n_blk;
@@ -902,15 +918,17 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
             if (ent.x == 0x80000000u) break;
         }
         if (found) {
-            if ((ent.w & SPL_JF_COMPLEX) || (ent.w & 0xffu) > 16u) return false;
-            if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) return false;
+            if (ent.w & SPL_JF_COMPLEX) SPL_TP_FAIL(4);
+            if ((ent.w & 0xffu) > 16u) SPL_TP_FAIL(5);
+            if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) SPL_TP_FAIL(6);
             r_off[j] = ent.z; r_n[j] = ent.w & 0xffu;
         } else { // not a listed junction: fine only when neither end has a rival flag
             int32_t u; uint32_t nv, rv;
             dbk_resolve(p, l, p.dbucket[dbk_slot(p, l)], u, nv, rv);
-            if (nv & rv) return false;
+            // a rival t would need this end in P_t and the other end in C_t: the union list of the end decides
+            if ((nv & rv) && ucl_contains(p, u, r)) SPL_TP_FAIL(7);
             dbk_resolve(p, r, p.dbucket[dbk_slot(p, r)], u, nv, rv);
-            if (nv & rv) return false;
+            if ((nv & rv) && ucl_contains(p, u, l)) SPL_TP_FAIL(7);
         }
     }
     // pass 2: apply
@@ -977,6 +995,9 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
     // The 8 shard regions are walked as ONE index space (a wave must not pay the latency chain once per shard).
     // Entries are packed indexes: the read is taken from the range kernel's own arrays (one trip), its ops are inline
     // or start at the stored offset.
+#ifdef SPL_PHASE_LITERAL
+    uint64_t lt_[4] = {(uint64_t)wall_clock64(), 0, 0, 0};
+#endif
     uint32_t start[9];
     start[0] = 0;
 #pragma unroll
@@ -1004,15 +1025,38 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
                     n_ops = p.cig_off[i + 1] - o0;
                 }
             }
+#ifdef SPL_PHASE_LITERAL
+            asm volatile("s_nop 0" ::"v"(pos), "v"(fn));
+            lt_[1] = wall_clock64(); // after the read's words arrived
+#endif
             int64_t ref_len; bool hn;
             spl_read_extent(ops, n_ops, &ref_len, &hn);
+#ifdef SPL_PHASE_LITERAL
+            asm volatile("s_nop 0" ::"v"((int32_t)ref_len));
+            lt_[2] = wall_clock64(); // after the ops were walked once
+#endif
             if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
             if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
+#ifdef SPL_PHASE_LITERAL
+            const bool tp_ = rivals_table_path<STRANDED>(p, pos, flag, ops, n_ops);
+            bool cf_ = false;
+            if (!tp_) cf_ = rivals_closed_form<STRANDED>(p, pos, flag, ops, n_ops);
+            if (!tp_ && !cf_) rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
+            atomicAdd((unsigned long long *)&g_phase[(size_t)blockIdx.x * 8 + 4], tp_ ? 1ull : 0ull);
+            atomicAdd((unsigned long long *)&g_phase[(size_t)blockIdx.x * 8 + 5], cf_ ? 1ull : 0ull);
+            atomicAdd((unsigned long long *)&g_phase[(size_t)blockIdx.x * 8 + 6], (!tp_ && !cf_) ? 1ull : 0ull);
+            continue;
+#endif
             if (rivals_table_path<STRANDED>(p, pos, flag, ops, n_ops)) continue;
             if (rivals_closed_form<STRANDED>(p, pos, flag, ops, n_ops)) continue;
             rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
         }
     }
+#ifdef SPL_PHASE_LITERAL
+    lt_[3] = wall_clock64();
+    if (threadIdx.x == 0) for (int k_ = 0; k_ < 4; ++k_) g_phase[(size_t)blockIdx.x * 8 + k_] = lt_[k_];
+    if (threadIdx.x == 0) g_phase[(size_t)blockIdx.x * 8 + 7] = (uint64_t)__popcll(__ballot(1)) + 1; // marks the row as written
+#endif
 }
 
 // The range kernel's read layout, derived once per upload from the BAM-native arrays (one workgroup per chunk):
@@ -1286,8 +1330,29 @@ extern "C" int spl_dev_launch_literal(const spl_count_params *p, const spl_queue
     if (p->n_reads <= 0 || p->n_sites <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t grid = SPL_LITERAL_WAVES;
+#ifdef SPL_PHASE_LITERAL
+    static uint64_t *phase_buf = nullptr;
+    if (!phase_buf) {
+        if (hipMalloc((void **)&phase_buf, (size_t)grid * 64) != hipSuccess) return (int)hipErrorOutOfMemory;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), &phase_buf, sizeof(phase_buf));
+    }
+    (void)hipMemsetAsync(phase_buf, 0, (size_t)grid * 64, st);
+#endif
     if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(grid), dim3(64), 0, st, *p, *q);
     else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(grid), dim3(64), 0, st, *p, *q);
+#ifdef SPL_PHASE_LITERAL
+    if (const char *path = getenv("SPL_PHASE_DUMP")) {
+        (void)hipStreamSynchronize(st);
+        uint64_t *host = (uint64_t *)malloc((size_t)grid * 64);
+        (void)hipMemcpy(host, phase_buf, (size_t)grid * 64, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(path, "wb")) { fwrite(host, 64, grid, f); fclose(f); }
+        free(host);
+        unsigned long long why[8];
+        (void)hipMemcpyFromSymbol(why, HIP_SYMBOL(g_tp_fail), sizeof(why));
+        fprintf(stderr, "table path left for: combine %llu, junctions %llu, blocks %llu, complex %llu, >16 rivals %llu, multirow %llu, unlisted+flag %llu (cumulative)\n",
+                why[1], why[2], why[3], why[4], why[5], why[6], why[7]);
+    }
+#endif
     return (int)hipGetLastError();
 }
 
