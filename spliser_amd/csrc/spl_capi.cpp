@@ -547,7 +547,7 @@ extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out
     const size_t n_chunks = (size_t)((R + SPL_CHUNK - 1) / SPL_CHUNK);
     // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks
     const size_t shard_cap = ((n_chunks + 7) / 8) * SPL_CHUNK;
-    const size_t o_queue = take(4 * 8 * shard_cap), o_qn = take(4 * 8);
+    const size_t o_queue = take(4 * 8 * shard_cap), o_qn = take(4 * 8 * SPL_COUNTER_STRIDE);
     hipError_t e = hipMalloc((void **)&d->slab, std::max<size_t>(off, 256));
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the read set: %s", off, hipGetErrorString(e)); }
     d->pos = (int32_t *)(d->slab + o_pos); d->flag = (uint16_t *)(d->slab + o_flag);
@@ -706,11 +706,11 @@ extern "C" int spl_literal_queue_size(spl_ctx *c, const spl_dreads *dr, int64_t 
 {
     if (!c || !dr || !n_out) return spl_set_error(SPL_ERR_ARG, "spl_literal_queue_size: null argument");
     HIP_TRY(hipSetDevice(c->device));
-    std::vector<uint32_t> counts(8);
-    HIP_TRY(hipMemcpyAsync(counts.data(), dr->queue_n, 4 * 8, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint32_t> counts(8 * SPL_COUNTER_STRIDE);
+    HIP_TRY(hipMemcpyAsync(counts.data(), dr->queue_n, 4 * counts.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int64_t total = 0;
-    for (uint32_t v : counts) total += v;
+    for (int k = 0; k < 8; ++k) total += counts[(size_t)k * SPL_COUNTER_STRIDE];
     *n_out = total;
     return SPL_OK;
 }

@@ -7,6 +7,8 @@
 
 // Launch geometry of the classification kernels (see DESIGN.md "Kernels").
 #define SPL_BLOCK 256                    // threads per workgroup = 4 waves
+#define SPL_COUNTER_STRIDE 64            // words between the 8 queue counters: a 256-byte line each (counters sharing a
+                                         // line serialise the atomics of all XCDs: measured 11 ns per atomic, chip-wide)
 #ifndef SPL_BUCKET_AHEAD
 #define SPL_BUCKET_AHEAD 0              // 1: prefetch the next read's bucket entries too (registers!)
 #endif
@@ -109,7 +111,7 @@ struct spl_hot_params {
     uint32_t *dbl;
     int32_t combine_mode;
     uint32_t *queue;             // reads handed to spl_count_literal_kernel (packed indexes): 8 regions (workgroup & 7) of queue_cap
-    uint32_t *queue_n;           // [8] entries used per region
+    uint32_t *queue_n;           // entries used per region, counter k at word k * SPL_COUNTER_STRIDE
     uint32_t queue_cap;
     int32_t *err;
 };
@@ -117,7 +119,7 @@ struct spl_hot_params {
 // the literal kernel's view of the queue and of the packed read arrays it indexes
 struct spl_queue_params {
     const uint32_t *queue;       // 8 regions of queue_cap entries
-    const uint32_t *queue_n;     // [8]
+    const uint32_t *queue_n;     // counter k at word k * SPL_COUNTER_STRIDE
     uint32_t queue_cap;
     const int32_t *r_pos;        // packed (see spl_hot_params)
     const uint32_t *r_fn;

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(SPL_BLOCK) SPL_RANGE_ATTR void spl_count_ranges_ker
     const uint32_t qn = s_qn; // uniform: read after the barrier above
     if (qn) {
         const uint32_t shard = blockIdx.x & 7u;
-        if (tid == 0) s_qbase = atomicAdd(&p.queue_n[shard], qn);
+        if (tid == 0) s_qbase = atomicAdd(&p.queue_n[shard * SPL_COUNTER_STRIDE], qn); // a cache line per counter
         __syncthreads();
         uint32_t *dst = p.queue + (size_t)shard * p.queue_cap + s_qbase;
         const uint32_t first = (uint32_t)chunk_base;
@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
     uint32_t start[9];
     start[0] = 0;
 #pragma unroll
-    for (int sh = 0; sh < 8; ++sh) start[sh + 1] = start[sh] + q.queue_n[sh];
+    for (int sh = 0; sh < 8; ++sh) start[sh + 1] = start[sh] + q.queue_n[sh * SPL_COUNTER_STRIDE];
     const uint32_t total = start[8];
     {
         for (uint32_t g = blockIdx.x * 64u + threadIdx.x; g < total; g += gridDim.x * 64u) {
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(256) void spl_clear_kernel(uint4 *region, size_t n1
 {
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n16; j += stride) region[j] = make_uint4(0, 0, 0, 0);
-    if (blockIdx.x == 0 && threadIdx.x < 8) queue_n[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 8) queue_n[threadIdx.x * SPL_COUNTER_STRIDE] = 0u;
     if (blockIdx.x == 0 && threadIdx.x == 8) *err = 0;
 }
 
