@@ -185,7 +185,9 @@ def main():
         # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from the committed
         # rocprofv3 --pmc passes of the same command (profiles/), and only for the exact workload they were measured on.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01e_traffic.json")
+        import glob
+        tfiles = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_traffic.json")))
+        tpath = tfiles[-1] if tfiles else ""  # the newest committed measurement (file names sort by round and build)
         if (args.workload == "arabidopsis" and args.scale == 1.0 and args.kernel == "ranges" and not stranded
                 and args.alt_fraction is None and os.path.exists(tpath)):
             with open(tpath) as fh:

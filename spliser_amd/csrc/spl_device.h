@@ -15,7 +15,7 @@
 #ifndef SPL_RPT
 #define SPL_RPT 8                        // reads per thread
 #endif
-#define SPL_CHUNK (SPL_BLOCK * SPL_RPT)  // consecutive reads per workgroup
+#define SPL_CHUNK (SPL_BLOCK * SPL_RPT)  // consecutive reads per workgroup (chunk-relative slots travel as 16-bit numbers)
 #define SPL_WIN 1024                     // site rows whose counters a workgroup privatises in LDS
 #define SPL_INLINE_OPS 3                 // CIGAR ops per read resolved in the straight-line part (M N M = 3)
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(SPL_BLOCK) SPL_RANGE_ATTR void spl_count_ranges_ker
     constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
     constexpr bool AHEAD = SPL_BUCKET_AHEAD != 0;
     __shared__ int32_t lds[NARR * (SPL_WIN + 1)];
-    __shared__ uint32_t s_q[SPL_CHUNK]; // this chunk's reads for the literal kernel (chunk-relative packed slot)
+    __shared__ uint16_t s_q[SPL_CHUNK]; // this chunk's reads for the literal kernel (chunk-relative packed slot)
     __shared__ uint32_t s_qn, s_qbase;
 
     const int tid = threadIdx.x;
@@ -626,6 +626,7 @@ __global__ __launch_bounds__(SPL_BLOCK) SPL_RANGE_ATTR void spl_count_ranges_ker
             // The ops go through in batches of SPL_INLINE_OPS: the first batch is the packed words (every read of a typical
             // short-read library ends there), further batches of a wide read cost two memory trips each (ops, then buckets).
             uint32_t k_next = n_inline;
+            bool mine = true; // this lane has ops in the batch (a narrow read in a wave of wide ones sits the later batches out)
             for (bool first = true;; first = false) {
 #pragma unroll
                 for (int k = 0; k < SPL_INLINE_OPS; ++k) {
@@ -633,8 +634,10 @@ __global__ __launch_bounds__(SPL_BLOCK) SPL_RANGE_ATTR void spl_count_ranges_ker
                     const uint32_t kd = alive ? ((SPL_KIND_TABLE >> (2u * (op[k] & 15u))) & 3u) : 0u;
                     len += kd ? (op[k] >> 4) : 0u;                 // len <= 2^31 before, three lengths < 2^28: no wrap
                     if (kd && len > room) { bad = true; alive = false; }
-                    cend[k] = pos + (int32_t)len;
-                    kind[k] = alive ? kd : 0u;
+                    if (first || mine) { // keeps the first batch's summary intact for the junction-table path below
+                        cend[k] = pos + (int32_t)len;
+                        kind[k] = alive ? kd : 0u;
+                    }
                 }
                 if (!AHEAD || !first) { // ---- trip 2 (see fetch_buckets)
                     if (first) e0 = p.dbucket[dbk_slot(p, pos - 1)];
@@ -646,19 +649,21 @@ __global__ __launch_bounds__(SPL_BLOCK) SPL_RANGE_ATTR void spl_count_ranges_ker
                 for (int k = 0; k < SPL_INLINE_OPS; ++k) {
                     int32_t u; uint32_t nv, rv;
                     dbk_resolve(p, cend[k] - 1, ek[k], u, nv, rv);
+                    const uint32_t kk = (first || mine) ? kind[k] : 0u;
                     const int32_t lo = pu + (int32_t)pnv; // first dpos at or after the op's first base
-                    const bool emit = kind[k] != 0u && kind[k] != 3u && u > lo;
-                    const uint32_t arr = (kind[k] == 2u ? (STRANDED ? 2u : 1u) : 0u) + sidx;
+                    const bool emit = kk != 0u && kk != 3u && u > lo;
+                    const uint32_t arr = (kk == 2u ? (STRANDED ? 2u : 1u) : 0u) + sidx;
                     // junction ends: lSite is the previous boundary's position, rSite this one's
-                    rival |= (kind[k] == 2u) & (((pnv & prv) | (nv & rv)) != 0u);
+                    rival |= (kk == 2u) & (((pnv & prv) | (nv & rv)) != 0u);
                     if (__any(emit)) {
                         commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
                         commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)u << 2) | arr, -1);
                     }
-                    if (kind[k]) { pu = u; pnv = nv; prv = rv; }
+                    if (kk) { pu = u; pnv = nv; prv = rv; }
                 }
                 const bool more = alive && wide && k_next < n_ops;
                 if (!__any(more)) break;
+                mine = more;
 #pragma unroll
                 for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = (more && k_next + (uint32_t)k < n_ops) ? p.cigar[o0 + k_next + (uint32_t)k] : 0xfu;
                 k_next += (uint32_t)SPL_INLINE_OPS;
@@ -684,7 +689,7 @@ __global__ __launch_bounds__(SPL_BLOCK) SPL_RANGE_ATTR void spl_count_ranges_ker
                 simple = simple && n_n == 1 && n_b <= 2;
                 if (!simple || !rivals_inline<STRANDED, NARR>(p, lds, wbase, jl, jr, blk_a, blk_b, sidx)) to_queue = true;
             }
-            if (to_queue) s_q[atomicAdd(&s_qn, 1u)] = (uint32_t)(it * SPL_BLOCK + tid);
+            if (to_queue) s_q[atomicAdd(&s_qn, 1u)] = (uint16_t)(it * SPL_BLOCK + tid);
         }
     }
     SPL_PHASE(6);
@@ -703,7 +708,7 @@ __global__ __launch_bounds__(SPL_BLOCK) SPL_RANGE_ATTR void spl_count_ranges_ker
         __syncthreads();
         uint32_t *dst = p.queue + (size_t)shard * p.queue_cap + s_qbase;
         const uint32_t first = (uint32_t)chunk_base;
-        for (uint32_t j = tid; j < qn; j += SPL_BLOCK) dst[j] = first + s_q[j];
+        for (uint32_t j = tid; j < qn; j += SPL_BLOCK) dst[j] = first + (uint32_t)s_q[j];
     }
 #ifdef SPL_PHASE_TAIL
     SPL_PHASE(4);
@@ -1293,7 +1298,7 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
         if (p->stranded) hipLaunchKernelGGL(spl_count_pairs_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
         else hipLaunchKernelGGL(spl_count_pairs_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
     } else {
-        *lds_out = (p->stranded ? 4 : 2) * (SPL_WIN + 1) * 4 + 4;
+        *lds_out = (p->stranded ? 4 : 2) * (SPL_WIN + 1) * 4 + SPL_CHUNK * 2 + 8; // difference windows + the chunk's queue
         const bool agg = !(variant & 2);
 #ifdef SPL_PHASE_TIMING
         static uint64_t *phase_buf = nullptr;
