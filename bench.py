@@ -38,9 +38,11 @@ def main():
     ap.add_argument("--stranded", default=None, choices=[None, "fr", "rf"])
     ap.add_argument("--beta2Cryptic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel", default="ranges", choices=["ranges", "ranges_noagg", "pairs"],
+    ap.add_argument("--kernel", default="ranges", choices=["ranges", "ranges_agg", "pairs"],
                     help="ranges = default product path; pairs = the literal per-(read, site) kernel")
     ap.add_argument("--alt-fraction", type=float, default=None, help="(experiment) fraction of genes with alternative isoforms")
+    ap.add_argument("--genes", type=int, default=None, help="(experiment) number of genes the reads are spread over: fewer genes = "
+                    "deeper coverage per site")
     ap.add_argument("--cache", default=None, help="directory to cache the generated sample in (.npz); a cached "
                     "sample is loaded instead of regenerated (use under rocprofv3: no generator worker processes)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
@@ -59,11 +61,14 @@ def main():
     cache = None
     if args.cache:
         os.makedirs(args.cache, exist_ok=True)
-        cache = os.path.join(args.cache, "%s_s%g_seed%d.npz" % (args.workload, args.scale, cfg["seed"] + rank))
+        cache = os.path.join(args.cache, "%s_s%g_seed%d%s.npz" % (args.workload, args.scale, cfg["seed"] + rank,
+                                                                   "" if args.genes is None else "_g%d" % args.genes))
     if cache and os.path.exists(cache):
         wl = synth.Workload.load(cache, args.workload)
     else:
         over = {} if args.alt_fraction is None else {"alt_fraction": args.alt_fraction}
+        if args.genes is not None:
+            over["n_genes"] = args.genes
         wl = synth.Workload(args.workload, scale=args.scale, seed=cfg["seed"] + rank, **over,
                             workers=max(1, min(8, (os.cpu_count() or 1) // max(world, 1))))
         if cache:
@@ -93,7 +98,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     scode = native.STRANDED_CODE[stranded]
-    kflags = {"pairs": native.OPT_PAIR_KERNEL, "ranges_noagg": native.OPT_NO_WAVE_AGGREGATION, "ranges": 0}[args.kernel]
+    kflags = {"pairs": native.OPT_PAIR_KERNEL, "ranges_agg": native.OPT_WAVE_AGGREGATION, "ranges": 0}[args.kernel]
     ctx = native.Context(local_rank)
     dev = [(ctx.upload_sites(sh.sites), ctx.upload_reads(sh.reads)) for sh in shards]
     alg_bytes = sum(native.algorithmic_bytes(ds, dr) for ds, dr in dev)
@@ -189,7 +194,7 @@ def main():
         tfiles = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_traffic.json")))
         tpath = tfiles[-1] if tfiles else ""  # the newest committed measurement (file names sort by round and build)
         if (args.workload == "arabidopsis" and args.scale == 1.0 and args.kernel == "ranges" and not stranded
-                and args.alt_fraction is None and os.path.exists(tpath)):
+                and args.alt_fraction is None and args.genes is None and os.path.exists(tpath)):
             with open(tpath) as fh:
                 traffic = json.load(fh)["hbm_bytes_per_launch"]
         k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")

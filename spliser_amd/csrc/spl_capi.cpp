@@ -614,7 +614,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.stranded = o->stranded; p.combine_mode = o->combine_mode ? 1 : 0;
     p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = c->d_err;
     // range kernel whenever the table allows it; the literal pair kernel otherwise or on request
-    const int variant = (!ds->mutual_links || (o->flags & SPL_OPT_PAIR_KERNEL)) ? 1 : ((o->flags & SPL_OPT_NO_WAVE_AGGREGATION) ? 2 : 0);
+    const int variant = (!ds->mutual_links || (o->flags & SPL_OPT_PAIR_KERNEL)) ? 1 : ((o->flags & SPL_OPT_WAVE_AGGREGATION) ? 2 : 0);
     int grid = 0, lds = 0;
     const bool timed = c->k_on && (size_t)(2 * c->k_used + 1) < c->k_ev.size();
     if (timed) HIP_TRY(hipEventRecord(c->k_ev[2 * c->k_used], c->stream));

@@ -16,7 +16,7 @@
 #define SPL_RPT 8                        // reads per thread
 #endif
 #define SPL_CHUNK (SPL_BLOCK * SPL_RPT)  // consecutive reads per workgroup (chunk-relative slots travel as 16-bit numbers)
-#define SPL_WIN 1024                     // site rows whose counters a workgroup privatises in LDS
+#define SPL_WIN 1020                     // distinct site positions a workgroup privatises in LDS (4 arrays + queue: 8 workgroups in 160 KB)
 #define SPL_INLINE_OPS 3                 // CIGAR ops per read resolved in the straight-line part (M N M = 3)
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
 #define SPL_LITERAL_WAVES 8192           // one-wave workgroups of the literal kernel (grid-stride over the queue)

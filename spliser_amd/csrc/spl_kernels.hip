@@ -488,13 +488,12 @@ __device__ uint64_t *g_phase;
 #define SPL_PHASE_WRITE do { } while (0)
 #endif
 
-#ifdef SPL_WAVES_PER_EU
-#define SPL_RANGE_ATTR __attribute__((amdgpu_waves_per_eu(SPL_WAVES_PER_EU, SPL_WAVES_PER_EU)))
-#else
-#define SPL_RANGE_ATTR
-#endif
+// Default (AGG false): plain LDS atomics, 64 VGPRs = 8 waves per SIMD (the kernel lives on how many waves are there to
+// cover each other's memory trips and barriers; the register cap costs nothing -- no scratch).  Merging the atomics of
+// neighbouring lanes first (AGG, SPL_OPT_WAVE_AGGREGATION) needs a few more registers than that cap allows and was
+// never faster in measurements, not even at 8000 reads per site; it stays as a variant for parity tests.
 template <bool STRANDED, bool AGG>
-__global__ __launch_bounds__(SPL_BLOCK) SPL_RANGE_ATTR void spl_count_ranges_kernel(const spl_hot_params p)
+__global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ? 4 : 8, 8))) void spl_count_ranges_kernel(const spl_hot_params p)
 {
     constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
     constexpr bool AHEAD = SPL_BUCKET_AHEAD != 0;
@@ -1299,7 +1298,7 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
         else hipLaunchKernelGGL(spl_count_pairs_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
     } else {
         *lds_out = (p->stranded ? 4 : 2) * (SPL_WIN + 1) * 4 + SPL_CHUNK * 2 + 8; // difference windows + the chunk's queue
-        const bool agg = !(variant & 2);
+        const bool agg = (variant & 2) != 0;
 #ifdef SPL_PHASE_TIMING
         static uint64_t *phase_buf = nullptr;
         static size_t phase_cap = 0;

@@ -41,7 +41,7 @@ class spl_opts(ctypes.Structure):
 
 
 OPT_PAIR_KERNEL = 1
-OPT_NO_WAVE_AGGREGATION = 2
+OPT_WAVE_AGGREGATION = 2
 
 
 EXPORTS = [

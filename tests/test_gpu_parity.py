@@ -18,7 +18,7 @@ def ctx():
     c.close()
 
 
-KERNELS = {"ranges": 0, "pairs": native.OPT_PAIR_KERNEL, "ranges_noagg": native.OPT_NO_WAVE_AGGREGATION}
+KERNELS = {"ranges": 0, "pairs": native.OPT_PAIR_KERNEL, "ranges_agg": native.OPT_WAVE_AGGREGATION}
 
 
 def gpu_engine(ctx, flags=0):

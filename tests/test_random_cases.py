@@ -30,10 +30,10 @@ def test_host_core_matches_oracle_on_random_cases(stranded, oracle_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("stranded", [0, 1, 2])
-@pytest.mark.parametrize("kernel", ["ranges", "pairs", "ranges_noagg"])
+@pytest.mark.parametrize("kernel", ["ranges", "pairs", "ranges_agg"])
 def test_gpu_matches_oracle_on_random_cases(stranded, kernel, oracle_lib):
     from spliser_amd import native
-    flags = {"ranges": 0, "pairs": native.OPT_PAIR_KERNEL, "ranges_noagg": native.OPT_NO_WAVE_AGGREGATION}[kernel]
+    flags = {"ranges": 0, "pairs": native.OPT_PAIR_KERNEL, "ranges_agg": native.OPT_WAVE_AGGREGATION}[kernel]
     with native.Context(0) as ctx:
         for seed in SEEDS:
             arr, rs = randcase.make_case(seed, bool(stranded))
