@@ -615,7 +615,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             uint32_t sidx = 0;
             if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
             const bool wide = n_ops > (uint32_t)SPL_INLINE_OPS;
-            if (n_ops == 0xffffu) n_ops = p.cig_off[ii + 1] - o0; // the packed word saturates: true count from cig_off
+            if (n_ops == 0xffffu) // the packed word saturates: the true count is with the read's own place in the input
+                n_ops = p.cig_off[chunk_base + p.perm[ii] + 1] - o0;
             const uint32_t room = (uint32_t)(SPL_COORD_MAX - (pos < 0 ? 0 : pos));
             uint32_t len = 0;
             int32_t cend[SPL_INLINE_OPS];

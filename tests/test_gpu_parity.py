@@ -150,6 +150,37 @@ def test_gpu_long_introns_and_hot_sites(ctx, oracle_lib):
         assert np.array_equal(g, w)
 
 
+def test_gpu_read_with_more_ops_than_the_packed_count_holds(ctx, oracle_lib):
+    """A read of 70 000 CIGAR ops (the packed op count saturates at 65 535) between ordinary reads: the kernels must find
+    its true op count although the chunk-local partition moves it away from its place in the input."""
+    # the long read ends at 105 099: a walk that borrowed the ops of the next reads would run on over the site at 105 150
+    pos = np.array([150, 400, 100300, 100900, 105150, 200500], np.int64)
+    strand = np.full(6, ord("+"), np.uint8)
+    part_off = np.array([0, 1, 2, 3, 4, 4, 4], np.uint32)
+    part_pos = np.array([400, 150, 100900, 100300], np.int64)
+    part_site = np.array([1, 0, 3, 2], np.int32)
+    comp_off = np.zeros(7, np.uint32)
+    comp_pos = np.zeros(0, np.int64)
+    sites_c = native.SiteArrays(pos, strand, part_off, part_pos, comp_off, comp_pos, part_site=part_site)
+    n_pairs = 35000
+    long_ops = np.empty(2 * n_pairs, np.uint32)       # 1M 2D 1M 2D ...: 70 000 ops, 105 000 reference bases
+    long_ops[0::2] = (1 << 4) | 0
+    long_ops[1::2] = (2 << 4) | 2
+    recs_ops = [long_ops, np.array([(100 << 4) | 0], np.uint32), np.array([(50 << 4) | 0, (249 << 4) | 3, (60 << 4) | 0], np.uint32),
+                np.array([(120 << 4) | 0], np.uint32)]
+    rpos = np.array([100, 120, 101, 100250], np.int64)
+    order = np.argsort(rpos, kind="stable")
+    off = np.concatenate(([0], np.cumsum([len(recs_ops[i]) for i in order])))
+    reads_c = native.ReadArrays(rpos[order], np.zeros(4, np.uint16), off, np.concatenate([recs_ops[i] for i in order]))
+    want = oracle_lib.check_bam(pos, strand, part_off, part_pos, comp_off, comp_pos, reads_c.pos, reads_c.flag,
+                                reads_c.cig_off, reads_c.cigar, 0, 0)
+    for flags in KERNELS.values():
+        got = ctx.count(sites_c, reads_c, 0, 0, flags)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+    assert int(want[0].sum()) > 0
+
+
 def test_gpu_empty_and_degenerate_inputs(ctx):
     empty_sites = native.SiteArrays(np.zeros(0), np.zeros(0, np.uint8), np.zeros(1), np.zeros(0), np.zeros(1), np.zeros(0))
     one_read = native.ReadArrays([100], [0], [0, 1], [50 << 4])
