@@ -6,7 +6,9 @@
 #include <hip/hip_vector_types.h>
 
 // Launch geometry of the classification kernels (see DESIGN.md "Kernels").
+#ifndef SPL_BLOCK
 #define SPL_BLOCK 256                    // threads per workgroup = 4 waves
+#endif
 #define SPL_COUNTER_STRIDE 64            // words between the 8 queue counters: a 256-byte line each (counters sharing a
                                          // line serialise the atomics of all XCDs: measured 11 ns per atomic, chip-wide)
 #ifndef SPL_BUCKET_AHEAD
