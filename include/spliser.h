@@ -179,6 +179,13 @@ int spl_bam_reads(const spl_bam *bam, int tid, spl_reads *out, int64_t *max_end_
 int spl_bam_write(const char *path, int n_ref, const char *const *ref_names, const int64_t *ref_lengths,
                   const spl_reads *per_ref, int level, int n_threads);
 
+/* ---- host helper of Step 1 ---------------------------------------------------------------------------
+ * binary_gene_search (SpliSER_v0_1_8.py:118-173) for a batch of query positions against one chromosome's gene list
+ * (in list order), probe for probe like the reference.  Strand bytes are '+', '-' or 0 for anything else;
+ * out[q] = index of the gene found or -1.  No GPU involved. */
+int spl_gene_search(const int64_t *left, const int64_t *right, const uint8_t *gene_strand, int64_t n_genes,
+                    const int64_t *q_pos, const uint8_t *q_strand, int64_t n_queries, int is_stranded, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

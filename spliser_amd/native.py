@@ -50,6 +50,7 @@ EXPORTS = [
     "spl_reads_upload", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write",
+    "spl_gene_search",
 ]
 
 _lib = None
@@ -283,6 +284,19 @@ def algorithmic_bytes(dsites, dreads):
     out = ctypes.c_int64(0)
     _check(lib().spl_count_algorithmic_bytes(dsites._h, dreads._h, ctypes.byref(out)))
     return out.value
+
+
+def gene_search(g_left, g_right, g_strand, q_pos, q_strand, is_stranded):
+    """binary_gene_search for a batch (``spl_gene_search``): -> int32 gene index per query, -1 = none."""
+    g_left = np.ascontiguousarray(g_left, np.int64)
+    g_right = np.ascontiguousarray(g_right, np.int64)
+    g_strand = np.ascontiguousarray(g_strand, np.uint8)
+    q_pos = np.ascontiguousarray(q_pos, np.int64)
+    q_strand = np.ascontiguousarray(q_strand, np.uint8)
+    out = np.empty(q_pos.shape[0], np.int32)
+    _check(lib().spl_gene_search(_ptr(g_left), _ptr(g_right), _ptr(g_strand), ctypes.c_int64(g_left.shape[0]), _ptr(q_pos),
+                                 _ptr(q_strand), ctypes.c_int64(q_pos.shape[0]), ctypes.c_int(1 if is_stranded else 0), _ptr(out)))
+    return out
 
 
 def write_bam(path, ref_names, ref_lengths, read_sets, level=1, threads=0):

@@ -19,17 +19,31 @@ def format_chrom(arr, res, cryptic):
     """Rows of one chromosome.  ``arr``: sites.ChromArrays; ``res``: dict with beta1, beta2_simple,
     beta2_cryptic, beta2_weighted, sse arrays."""
     out = []
-    po, co = arr.part_off, arr.comp_off
-    strand, genes = arr.strand, arr.genes
-    for i in range(arr.n):
-        a, b = int(po[i]), int(po[i + 1])
-        c, d = int(co[i]), int(co[i + 1])
-        if cryptic:
-            mid = "%d\t%s" % (int(res["beta2_cryptic"][i]), "{0:.5f}".format(float(res["beta2_weighted"][i])))
-        else:
-            mid = "NA\tNA"
+    n = arr.n
+    # plain Python lists: indexing numpy scalars one by one costs more than the formatting itself
+    po, co = arr.part_off.tolist(), arr.comp_off.tolist()
+    pos, alpha = arr.pos.tolist(), arr.alpha.tolist()
+    ppos, pcnt, cpos = arr.part_pos.tolist(), arr.edge_cnt.tolist(), arr.comp_pos.tolist()
+    beta1, b2s = _ints(res["beta1"]), _ints(res["beta2_simple"])
+    sse = ["%.3f" % v for v in _floats(res["sse"])]          # same digits as "{0:.3f}".format (:655)
+    if cryptic:
+        b2c = _ints(res["beta2_cryptic"])
+        b2w = ["%.5f" % v for v in _floats(res["beta2_weighted"])]
+    strand_text, genes, chrom = arr.strand_text, arr.genes, arr.chrom
+    for i in range(n):
+        a, b = po[i], po[i + 1]
+        c, d = co[i], co[i + 1]
+        mid = ("%d\t%s" % (b2c[i], b2w[i])) if cryptic else "NA\tNA"
+        partners = "{" + ", ".join(["%d: %d" % pc for pc in zip(ppos[a:b], pcnt[a:b])]) + "}"
+        competitors = "[" + ", ".join(map(str, cpos[c:d])) + "]"
         out.append("%s\t%d\t%s\t%s\t%s\t%d\t%d\t%d\t%s\t%s\t%s\n" % (
-            arr.chrom, int(arr.pos[i]), arr.strand_text[i], genes[i], "{0:.3f}".format(float(res["sse"][i])),
-            int(arr.alpha[i]), int(res["beta1"][i]), int(res["beta2_simple"][i]), mid,
-            partners_repr(arr.part_pos[a:b], arr.edge_cnt[a:b]), competitors_repr(arr.comp_pos[c:d])))
+            chrom, pos[i], strand_text[i], genes[i], sse[i], alpha[i], beta1[i], b2s[i], mid, partners, competitors))
     return out
+
+
+def _ints(a):
+    return [int(v) for v in a.tolist()] if hasattr(a, "tolist") else [int(v) for v in a]
+
+
+def _floats(a):
+    return [float(v) for v in a.tolist()] if hasattr(a, "tolist") else [float(v) for v in a]
