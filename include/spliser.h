@@ -140,6 +140,10 @@ int spl_sse(spl_ctx *ctx, const spl_sites *sites, const uint32_t *beta1, const u
 int spl_sites_upload(spl_ctx *ctx, const spl_sites *sites, spl_dsites **out);
 void spl_sites_free(spl_ctx *ctx, spl_dsites *ds);
 int spl_reads_upload(spl_ctx *ctx, const spl_reads *reads, spl_dreads **out);
+/* Same, from n_seg host segments laid end to end -- e.g. the per-reference views of spl_bam_reads, uploaded straight
+ * from the decoder's buffers: segment k is moved by pos_shift[k] into the shard's coordinate space on the device
+ * (spliser_amd/shard.py packs several chromosomes into one launch that way).  Reads keep segment order. */
+int spl_reads_upload_segments(spl_ctx *ctx, int n_seg, const spl_reads *segs, const int32_t *pos_shift, spl_dreads **out);
 void spl_reads_free(spl_ctx *ctx, spl_dreads *dr);
 /* Zero the shard's counters and enqueue the classification kernel (asynchronous). */
 int spl_count_launch(spl_ctx *ctx, spl_dsites *ds, const spl_dreads *dr, const spl_opts *opts);

@@ -526,16 +526,24 @@ extern "C" void spl_sites_free(spl_ctx *c, spl_dsites *d)
 }
 
 // ---- reads upload ---------------------------------------------------------------------------------------
-extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out)
+// One read set on the device from n_seg host segments laid end to end (segment k shifted by pos_shift[k]); a plain
+// spl_reads_upload is the one-segment case.
+static int upload_segments(spl_ctx *c, int n_seg, const spl_reads *segs, const int32_t *pos_shift, spl_dreads **out, const char *who)
 {
-    if (!c || !r || !out) return spl_set_error(SPL_ERR_ARG, "spl_reads_upload: null argument");
     *out = nullptr;
-    if (r->n_reads < 0 || r->n_reads > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "n_reads out of range (counters are 32-bit)");
-    const int64_t R = r->n_reads;
-    if (R && (!r->pos || !r->flag || !r->cig_off)) return spl_set_error(SPL_ERR_ARG, "read set has null arrays");
-    if (R && r->cig_off[0] != 0) return spl_set_error(SPL_ERR_ARG, "cig_off[0] must be 0");
-    const int64_t G = R ? r->cig_off[R] : 0;
-    if (G && !r->cigar) return spl_set_error(SPL_ERR_ARG, "cigar is null");
+    int64_t R = 0, G = 0;
+    for (int k = 0; k < n_seg; ++k) {
+        const spl_reads *r = &segs[k];
+        if (r->n_reads < 0) return spl_set_error(SPL_ERR_ARG, "%s: negative n_reads", who);
+        if (r->n_reads && (!r->pos || !r->flag || !r->cig_off)) return spl_set_error(SPL_ERR_ARG, "read set has null arrays");
+        if (r->n_reads && r->cig_off[0] != 0) return spl_set_error(SPL_ERR_ARG, "cig_off[0] must be 0");
+        const int64_t g = r->n_reads ? r->cig_off[r->n_reads] : 0;
+        if (g && !r->cigar) return spl_set_error(SPL_ERR_ARG, "cigar is null");
+        R += r->n_reads;
+        G += g;
+    }
+    if (R > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "n_reads out of range (counters are 32-bit)");
+    if (G > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops in one read set: use more shards");
     HIP_TRY(hipSetDevice(c->device));
     spl_dreads *d = new (std::nothrow) spl_dreads();
     if (!d) return spl_set_error(SPL_ERR_NOMEM, "out of host memory");
@@ -556,11 +564,23 @@ extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out
     d->fn = (uint32_t *)(d->slab + o_fn); d->ops3 = (uint32_t *)(d->slab + o_ops3);
     d->ppos = (int32_t *)(d->slab + o_ppos); d->perm = (uint16_t *)(d->slab + o_perm);
     hipError_t q = hipSuccess;
+    const uint32_t total_ops = (uint32_t)G; // lives until the synchronize below
     if (R) {
-        q = hipMemcpyAsync(d->pos, r->pos, 4 * R, hipMemcpyHostToDevice, c->stream);
-        if (q == hipSuccess) q = hipMemcpyAsync(d->flag, r->flag, 2 * R, hipMemcpyHostToDevice, c->stream);
-        if (q == hipSuccess) q = hipMemcpyAsync(d->cig_off, r->cig_off, 4 * (R + 1), hipMemcpyHostToDevice, c->stream);
-        if (q == hipSuccess && G) q = hipMemcpyAsync(d->cigar, r->cigar, 4 * G, hipMemcpyHostToDevice, c->stream);
+        int64_t r0 = 0, g0 = 0;
+        for (int k = 0; k < n_seg && q == hipSuccess; ++k) {
+            const spl_reads *r = &segs[k];
+            const int64_t n = r->n_reads;
+            if (!n) continue;
+            const int64_t g = r->cig_off[n];
+            q = hipMemcpyAsync(d->pos + r0, r->pos, 4 * n, hipMemcpyHostToDevice, c->stream);
+            if (q == hipSuccess) q = hipMemcpyAsync(d->flag + r0, r->flag, 2 * n, hipMemcpyHostToDevice, c->stream);
+            if (q == hipSuccess) q = hipMemcpyAsync(d->cig_off + r0, r->cig_off, 4 * n, hipMemcpyHostToDevice, c->stream);
+            if (q == hipSuccess && g) q = hipMemcpyAsync(d->cigar + g0, r->cigar, 4 * g, hipMemcpyHostToDevice, c->stream);
+            if (q == hipSuccess) q = (hipError_t)spl_dev_launch_rebase(d->pos + r0, d->cig_off + r0, n, pos_shift ? pos_shift[k] : 0, (uint32_t)g0, c->stream);
+            r0 += n;
+            g0 += g;
+        }
+        if (q == hipSuccess) q = hipMemcpyAsync(d->cig_off + R, &total_ops, 4, hipMemcpyHostToDevice, c->stream);
         // the range kernel's layout (flag + op count in one word, first ops inline) is derived on the device
         if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack(R, d->pos, d->flag, d->cig_off, d->cigar, d->ppos, d->fn, d->ops3, d->perm, c->stream);
         if (q == hipSuccess) q = hipStreamSynchronize(c->stream); // caller buffers are free to go after return
@@ -568,6 +588,19 @@ extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out
     if (q != hipSuccess) { (void)hipFree(d->slab); delete d; return spl_set_error(SPL_ERR_HIP, "read set upload: %s", hipGetErrorString(q)); }
     *out = d;
     return SPL_OK;
+}
+
+extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out)
+{
+    if (!c || !r || !out) return spl_set_error(SPL_ERR_ARG, "spl_reads_upload: null argument");
+    return upload_segments(c, 1, r, nullptr, out, "spl_reads_upload");
+}
+
+extern "C" int spl_reads_upload_segments(spl_ctx *c, int n_seg, const spl_reads *segs, const int32_t *pos_shift, spl_dreads **out)
+{
+    if (!c || !out || n_seg < 0 || (n_seg && (!segs || !pos_shift)))
+        return spl_set_error(SPL_ERR_ARG, "spl_reads_upload_segments: null argument");
+    return upload_segments(c, n_seg, segs, pos_shift, out, "spl_reads_upload_segments");
 }
 
 extern "C" void spl_reads_free(spl_ctx *c, spl_dreads *d)

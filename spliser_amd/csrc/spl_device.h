@@ -166,6 +166,7 @@ extern "C" {
 // variant: 0 = range kernel (needs mutual partner links), 1 = pair kernel (any table), 2 = range kernel without
 // wave-level aggregation of LDS atomics (experiment)
 int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out);
+int spl_dev_launch_rebase(int32_t *pos, uint32_t *cig_off, int64_t n, int32_t shift, uint32_t cig_base, void *stream);
 int spl_dev_launch_clear(void *region, size_t bytes, int32_t *err, uint32_t *queue_n, void *stream);
 int spl_dev_launch_literal(const spl_count_params *p, const spl_queue_params *q, void *stream);
 int spl_dev_launch_pack(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar,

@@ -1263,6 +1263,17 @@ __global__ __launch_bounds__(256) void spl_sse_kernel(const spl_sse_params p)
     p.sse[s] = value;
 }
 
+// A read segment (one chromosome of a shard) was copied into place as it is; this moves it into the shard's coordinate
+// space and makes its CIGAR offsets global.
+__global__ __launch_bounds__(256) void spl_rebase_kernel(int32_t *pos, uint32_t *cig_off, int64_t n, int32_t shift, uint32_t cig_base)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
+        pos[j] += shift;
+        cig_off[j] += cig_base;
+    }
+}
+
 // Everything a counting pass starts from zero, in one launch: the counter / difference-array region of the site table
 // (16-byte aligned, a multiple of 16 bytes), the device error word and the queue counters.
 __global__ __launch_bounds__(256) void spl_clear_kernel(uint4 *region, size_t n16, int32_t *err, uint32_t *queue_n)
@@ -1274,6 +1285,15 @@ __global__ __launch_bounds__(256) void spl_clear_kernel(uint4 *region, size_t n1
 }
 
 // ---- launchers (called from spl_capi.cpp through spl_device.h) ------------------------------------------
+
+extern "C" int spl_dev_launch_rebase(int32_t *pos, uint32_t *cig_off, int64_t n, int32_t shift, uint32_t cig_base, void *stream)
+{
+    if (n <= 0 || (shift == 0 && cig_base == 0)) return 0;
+    int64_t blocks = (n + 1023) / 1024;
+    blocks = blocks > 8192 ? 8192 : blocks;
+    hipLaunchKernelGGL(spl_rebase_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, pos, cig_off, n, shift, cig_base);
+    return (int)hipGetLastError();
+}
 
 extern "C" int spl_dev_launch_clear(void *region, size_t bytes, int32_t *err, uint32_t *queue_n, void *stream)
 {

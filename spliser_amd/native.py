@@ -47,7 +47,7 @@ OPT_WAVE_AGGREGATION = 2
 EXPORTS = [
     "spl_abi_version", "spl_last_error", "spl_device_count", "spl_create", "spl_create_on_stream", "spl_destroy",
     "spl_sync", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
-    "spl_reads_upload", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
+    "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write",
     "spl_gene_search",
@@ -207,6 +207,21 @@ class Context(object):
         h = ctypes.c_void_p()
         _check(lib().spl_reads_upload(self._h, ctypes.byref(reads.c), ctypes.byref(h)))
         return DeviceReads(self, h, reads.n)
+
+    def upload_read_segments(self, segments):
+        """segments: [(ReadArrays-like with .c, position shift)] laid end to end as ONE device read set, copied straight
+        from where they are (``spl_reads_upload_segments``)."""
+        n = len(segments)
+        segs = (spl_reads * max(n, 1))()
+        shifts = (ctypes.c_int32 * max(n, 1))()
+        total = 0
+        for k, (reads, shift) in enumerate(segments):
+            segs[k] = reads.c
+            shifts[k] = int(shift)
+            total += reads.n
+        h = ctypes.c_void_p()
+        _check(lib().spl_reads_upload_segments(self._h, ctypes.c_int(n), segs, shifts, ctypes.byref(h)))
+        return DeviceReads(self, h, total)
 
     def count_launch(self, dsites, dreads, stranded=0, combine_mode=0, flags=0):
         opts = spl_opts(int(stranded), int(combine_mode), int(flags))

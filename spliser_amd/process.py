@@ -77,12 +77,12 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                 return
             t0 = time.perf_counter()
             order = [c for c in table.chrom_index if c in chroms]
-            shards = shard.pack([(c, items[c][0], items[c][1]) for c in order])
+            shards = shard.pack([(c, items[c][0], items[c][1]) for c in order], concat_reads=False)
             t1 = time.perf_counter()
             with native.Context(device) as ctx:
                 for sh in shards:
                     ds = ctx.upload_sites(sh.sites)
-                    dr = ctx.upload_reads(sh.reads)
+                    dr = ctx.upload_read_segments(sh.read_segments)  # straight from the decoder's buffers
                     ctx.count_launch(ds, dr, stranded, combine_mode)
                     ctx.sse_launch(ds, is_beta2_cryptic)
                     beta1, _, _ = ds.counters()

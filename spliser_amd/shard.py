@@ -41,7 +41,8 @@ class Shard(object):
         self.site_rows = []    # (row_begin, row_end) per chromosome in the packed table
         self.edge_rows = []    # (edge_begin, edge_end) per chromosome in the packed partner CSR
         self.sites = None      # native.SiteArrays
-        self.reads = None      # native.ReadArrays
+        self.reads = None      # native.ReadArrays of the whole shard (pack(..., concat_reads=True))
+        self.read_segments = []  # [(native.ReadArrays of one chromosome, coordinate shift)]: Context.upload_read_segments
 
 
 def _extent(arr, reads):
@@ -55,8 +56,11 @@ def _extent(arr, reads):
     return lo, hi
 
 
-def pack(items):
-    """items: list of (chrom, ChromArrays, ReadSet-or-None).  -> list of Shard (usually one)."""
+def pack(items, concat_reads=True):
+    """items: list of (chrom, ChromArrays, ReadSet-or-None).  -> list of Shard (usually one).
+
+    ``concat_reads=False`` skips building the shard-wide read arrays on the host: the per-chromosome arrays stay where they
+    are (e.g. in the BAM decoder's buffers) and ``read_segments`` tells the device where to put them."""
     shards, cur, cursor = [], [], 0
     groups = []
     for chrom, arr, reads in items:
@@ -93,10 +97,12 @@ def pack(items):
             part_deg.append(np.diff(arr.part_off.astype(np.int64)))
             comp_deg.append(np.diff(arr.comp_off.astype(np.int64)))
             if reads is not None and reads.n:
-                r_pos.append(reads.pos.astype(np.int64) + off)
-                r_flag.append(reads.flag)
-                r_ops.append(reads.cigar)
-                r_nops.append(np.diff(reads.cig_off.astype(np.int64)))
+                sh.read_segments.append((native.ReadArrays(reads.pos, reads.flag, reads.cig_off, reads.cigar), off))
+                if concat_reads:
+                    r_pos.append(reads.pos.astype(np.int64) + off)
+                    r_flag.append(reads.flag)
+                    r_ops.append(reads.cigar)
+                    r_nops.append(np.diff(reads.cig_off.astype(np.int64)))
             row += arr.n
             edge += n_edge
 
@@ -114,6 +120,7 @@ def pack(items):
         sh.sites = native.SiteArrays(cat(pos, np.int64), cat(strand, np.uint8), csr(part_deg), cat(part_pos, np.int64),
                                      csr(comp_deg), cat(comp_pos, np.int64), cat(part_site, np.int32),
                                      cat(alpha, np.int64), cat(edge_cnt, np.int64))
-        sh.reads = native.ReadArrays(cat(r_pos, np.int64), cat(r_flag, np.uint16), csr(r_nops), cat(r_ops, np.uint32))
+        if concat_reads:
+            sh.reads = native.ReadArrays(cat(r_pos, np.int64), cat(r_flag, np.uint16), csr(r_nops), cat(r_ops, np.uint32))
         shards.append(sh)
     return shards

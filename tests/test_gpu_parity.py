@@ -97,6 +97,32 @@ def test_gpu_matches_oracle_on_synthetic_genome(stranded, cryptic, kernel, ctx, 
     assert total > 10000
 
 
+def test_gpu_segment_upload_equals_packed_upload(ctx, tmp_path):
+    """spl_reads_upload_segments (per-chromosome arrays shifted on the device) against the host-packed shard."""
+    wl = synth.Workload("arabidopsis", scale=0.01, seed=77)
+    table = _table_for(wl, tmp_path, False)
+    names = wl.genome.chrom_names
+    items = [(c, table.chrom_arrays(c), wl.reads[i]) for i, c in enumerate(names) if table.chrom_arrays(c).n]
+    items.insert(2, (names[0] + "_empty", table.chrom_arrays(names[0]), None))   # a chromosome without reads
+    sh, = shard.pack(items)
+    assert len(sh.read_segments) == len(items) - 1
+    ds = ctx.upload_sites(sh.sites)
+    got = []
+    for dr in (ctx.upload_reads(sh.reads), ctx.upload_read_segments(sh.read_segments)):
+        assert dr.n == sh.reads.n
+        ctx.count_launch(ds, dr, 0, 0)
+        ctx.sse_launch(ds, True)
+        got.append(ds.counters() + ds.sse_results())
+        dr.free()
+    ds.free()
+    for a, b in zip(*got):
+        assert np.array_equal(a, b)
+    assert int(got[0][0].sum()) > 1000
+    empty = ctx.upload_read_segments([])
+    assert empty.n == 0
+    empty.free()
+
+
 def test_gpu_long_introns_and_hot_sites(ctx, oracle_lib):
     """Skew: reads whose introns span thousands of sites (wave-cooperative path), one site hit by 200k reads
     (LDS counter contention), sites outside the LDS window (global-atomic path), unsorted reads."""
