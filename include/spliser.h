@@ -183,6 +183,21 @@ int spl_bam_reads(const spl_bam *bam, int tid, spl_reads *out, int64_t *max_end_
 int spl_bam_write(const char *path, int n_ref, const char *const *ref_names, const int64_t *ref_lengths,
                   const spl_reads *per_ref, int level, int n_threads);
 
+/* ---- junction table of a read set (what the pipeline otherwise takes from `regtools junctions extract`) --------------
+ * Every N op of every mapped read is a junction (left, right) in SpliSER's site convention (left = last base before the
+ * intron, right = last intronic base, SpliSER_v0_1_8.py:482-483 -- the numbers findAlphaCounts derives from a BED12 line,
+ * :275-276).  spl_junctions builds, on the device, the table of distinct (left, right[, read strand]) with the number of
+ * reads carrying each and the longest anchors on either side (reference bases of the read between the junction and the
+ * previous / next N op or read end: the block sizes of a BED12 line), and returns their number; spl_junctions_get copies
+ * the table of the last call, sorted by (left, right, strand), into caller arrays (any may be NULL).  stranded: 0 ->
+ * strand '?', 1 = fr / 2 = rf -> '+' / '-' of the read by check_strand's rule (:374-406).  Policy knobs in the sense of
+ * regtools' -a / -m / -M: a read supports a junction only if both of ITS anchors are >= min_anchor and the intron length
+ * is in [min_intron, max_intron] (max_intron 0 = no upper limit); 0, 0, 0 counts every N op. */
+int spl_junctions(spl_ctx *ctx, const spl_dreads *dr, int stranded, int32_t min_anchor, int32_t min_intron, int32_t max_intron,
+                  int64_t *n_out);
+int spl_junctions_get(const spl_ctx *ctx, int32_t *left, int32_t *right, uint8_t *strand, uint32_t *count,
+                      uint32_t *anchor_left, uint32_t *anchor_right);
+
 /* ---- host helper of Step 1 ---------------------------------------------------------------------------
  * binary_gene_search (SpliSER_v0_1_8.py:118-173) for a batch of query positions against one chromosome's gene list
  * (in list order), probe for probe like the reference.  Strand bytes are '+', '-' or 0 for anything else;

@@ -75,3 +75,47 @@ def beta2_sse(site_pos, part_off, part_pos, part_site, alpha, edge_cnt, beta1, b
                         _p(edge_cnt), _p(beta1), _p(b2s_reads), _p(dbl), ctypes.c_int(1 if cryptic else 0),
                         _p(b2s), _p(b2c), _p(b2w), _p(sse))
     return b2s, b2c, b2w, sse
+
+
+def junction_table(r_pos, r_flag, cig_off, cigar, stranded=0):
+    """Plain-Python restatement of the junction table (checker for spl_junctions; small inputs only).
+
+    Walks every read like checkBam walks its CIGAR (SpliSER_v0_1_8.py:457-483): M,=,X,D,N advance the cursor, an N op of
+    length d ending at ``cur`` is the junction (cur-d-1, cur-1).  Records flagged unmapped (0x4) carry none.  Read strand
+    by check_strand's rule (:374-406) when ``stranded`` is 1 (fr) or 2 (rf).  -> sorted list of
+    (left, right, strand byte, count, anchor_left, anchor_right); anchors = reference bases of the read between the
+    junction and the neighbouring N op / read end, maximum over the reads.
+    """
+    table = {}
+    for i in range(len(r_pos)):
+        flag = int(r_flag[i])
+        if flag & 4 or int(r_pos[i]) < 0:
+            continue
+        if stranded:
+            first = bool(flag & 64) or not (flag & 1)
+            rev = bool(flag & 16)
+            plus = (first != rev) if stranded == 1 else (first == rev)
+            strand = ord("+") if plus else ord("-")
+        else:
+            strand = ord("?")
+        ops = [(int(o) & 15, int(o) >> 4) for o in cigar[int(cig_off[i]):int(cig_off[i + 1])]]
+        cur = int(r_pos[i])
+        before = 0
+        for k, (code, d) in enumerate(ops):
+            if code not in (0, 2, 3, 7, 8):
+                continue
+            cur += d
+            if code != 3:
+                before += d
+                continue
+            after = 0
+            for code2, d2 in ops[k + 1:]:
+                if code2 == 3:
+                    break
+                if code2 in (0, 2, 7, 8):
+                    after += d2
+            key = (cur - d - 1, cur - 1, strand)
+            c, a, b = table.get(key, (0, 0, 0))
+            table[key] = (c + 1, max(a, before), max(b, after))
+            before = 0
+    return [k + table[k] for k in sorted(table)]

@@ -2,7 +2,8 @@
 (SpliSER_v0_1_8.py:1295-1361), so existing pipelines only swap the script name.
 
 Extra flags (all optional, none changes results): ``--gpus`` / ``--devices`` to shard chromosomes over
-several MI355X of one node, ``--threads`` for the BAM decode pool.
+several MI355X of one node, ``--threads`` for the BAM decode pool.  Extra sub-command: ``junctions`` writes the BED12
+junction file ``process -b`` wants from the BAM itself (the reference leaves that to regtools).
 """
 import argparse
 import sys
@@ -64,6 +65,16 @@ def build_parser():
     o.add_argument("-r", "--minReads", dest="minReads", required=False, nargs="?", default=10, type=int)
     o.add_argument("-g", "--gene", dest="qGene", required=False, nargs="?", default="All", type=str)
     o.add_argument("-m", "--minSamples", dest="minSamples", required=False, nargs="?", default=50, type=int)
+    j = sub.add_parser("junctions", help="(this build only) BED12 junction file for `process -b`, derived from the BAM on the GPU")
+    j.add_argument("-B", "--BAMFile", dest="inBAM", required=True)
+    j.add_argument("-o", "--outputPath", dest="outputPath", required=True, help="path of the BED12 file to write")
+    j.add_argument("-c", "--chromosome", dest="qChrom", nargs="?", default="All", type=str, required=False)
+    j.add_argument("--isStranded", dest="isStranded", default=False, action="store_true")
+    j.add_argument("-s", "--strandedType", dest="strandedType", nargs="?", type=str, required=False)
+    j.add_argument("-a", "--minAnchor", dest="minAnchor", type=int, default=8, help="both anchors of a read must be this long (regtools -a)")
+    j.add_argument("-m", "--minIntron", dest="minIntron", type=int, default=70, help="regtools -m")
+    j.add_argument("-M", "--maxIntron", dest="maxIntron", type=int, default=500000, help="regtools -M; 0 = no limit")
+    _engine_flags(j)
     return parser
 
 
@@ -90,7 +101,7 @@ def main(argv=None):
         print(kwargs.get("qGene"))
         print(kwargs.get("annotationFile"))
         parser.error("--gene requires --annotationFile and --maxIntronSize")
-    elif command in ("process", "combine", "combineShallow") and kwargs.get("isStranded") is True and kwargs.get("strandedType") is None:
+    elif command in ("process", "combine", "combineShallow", "junctions") and kwargs.get("isStranded") is True and kwargs.get("strandedType") is None:
         parser.error("--isStranded requires parameter --strandedType/-s as fr or rf")
     if command == "process":
         from .process import process
@@ -104,6 +115,9 @@ def main(argv=None):
     elif command == "output":
         from .output import output
         output(**kwargs)
+    elif command == "junctions":
+        from .junctions import junctions
+        junctions(devices=devices, threads=threads, **kwargs)
     else:
         parser.error("sub-command %r is not part of this build yet" % command)
     print("Total runtime (s): \t" + str(timeit.default_timer() - start))

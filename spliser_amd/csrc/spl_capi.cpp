@@ -46,6 +46,8 @@ struct spl_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int32_t *d_err = nullptr;
     int last_grid = 0, last_lds = 0, last_variant = 0;
+    struct Junction { int32_t left, right; uint8_t strand; uint32_t count, anchor_left, anchor_right; };
+    std::vector<Junction> junctions; // result of the last spl_junctions call, sorted
     // optional per-launch stopwatch around spl_count_kernel alone (bench.py's roofline numerator)
     std::vector<hipEvent_t> k_ev; // pairs
     int k_used = 0;
@@ -732,6 +734,81 @@ extern "C" int spl_count_algorithmic_bytes(const spl_dsites *ds, const spl_dread
     // every input once, every output once.
     const int64_t R = dr->n_reads, G = dr->n_cigar, S = ds->n_sites, P = ds->n_part, C = ds->n_comp;
     *out = R * (4 + 2 + 4) + 4 * G + S * (4 + 1 + 8) + 4 * (P + C) + S * 8 + 4 * P;
+    return SPL_OK;
+}
+
+// ---- junction table of a read set ---------------------------------------------------------
+extern "C" int spl_junctions(spl_ctx *c, const spl_dreads *dr, int stranded, int32_t min_anchor, int32_t min_intron, int32_t max_intron,
+                             int64_t *n_out)
+{
+    if (!c || !dr || !n_out) return spl_set_error(SPL_ERR_ARG, "spl_junctions: null argument");
+    if (min_anchor < 0 || min_intron < 0 || max_intron < 0) return spl_set_error(SPL_ERR_ARG, "spl_junctions: negative filter value");
+    if (stranded < 0 || stranded > 2) return spl_set_error(SPL_ERR_ARG, "stranded must be 0, 1 (fr) or 2 (rf)");
+    HIP_TRY(hipSetDevice(c->device));
+    c->junctions.clear();
+    *n_out = 0;
+    // an N op needs an aligned op on both sides: fewer than half of all ops are junctions, so a table with one slot per op
+    // (rounded up to a power of two) stays under half full
+    uint64_t slots = 1024;
+    while (slots < (uint64_t)dr->n_cigar) slots <<= 1;
+    if (slots > 0x80000000ull) return spl_set_error(SPL_ERR_ARG, "read set too large for one junction table: use more shards");
+    char *buf = nullptr;
+    const size_t bytes = (size_t)slots * (8 + 12) * 2 + 256;
+    hipError_t e = hipMalloc((void **)&buf, bytes);
+    if (e != hipSuccess) return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the junction table: %s", bytes, hipGetErrorString(e));
+    unsigned long long *keys = (unsigned long long *)buf, *out_keys = keys + slots;
+    uint32_t *vals = (uint32_t *)(out_keys + slots), *out_vals = vals + 3 * slots, *n_dev = out_vals + 3 * slots;
+    int rc = spl_dev_launch_junctions(dr->n_reads, dr->pos, dr->flag, dr->cig_off, dr->cigar, stranded, (uint32_t)min_anchor, (uint32_t)min_intron,
+                                      (uint32_t)max_intron, keys, vals, (uint32_t)slots, out_keys,
+                                      out_vals, n_dev, c->d_err, c->stream);
+    uint32_t n = 0;
+    int32_t err = 0;
+    hipError_t q = rc ? (hipError_t)rc : hipMemcpyAsync(&n, n_dev, 4, hipMemcpyDeviceToHost, c->stream);
+    if (q == hipSuccess) q = hipMemcpyAsync(&err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream);
+    if (q == hipSuccess) q = hipStreamSynchronize(c->stream);
+    std::vector<unsigned long long> hk;
+    std::vector<uint32_t> hv;
+    if (q == hipSuccess && n) {
+        hk.resize(n);
+        hv.resize(3 * (size_t)n);
+        q = hipMemcpy(hk.data(), out_keys, 8 * (size_t)n, hipMemcpyDeviceToHost);
+        if (q == hipSuccess) q = hipMemcpy(hv.data(), out_vals, 12 * (size_t)n, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(buf);
+    if (q != hipSuccess) return spl_set_error(SPL_ERR_HIP, "junction table: %s", hipGetErrorString(q));
+    if (err & SPL_DEV_ERR_RANGE) return spl_set_error(SPL_ERR_RANGE, "a read ends beyond coordinate %d: split the shard", SPL_COORD_MAX);
+    if (err & SPL_DEV_ERR_TABLE) return spl_set_error(SPL_ERR_HIP, "junction table overflow (internal error)");
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hk[a] < hk[b]; }); // left, right, strand
+    c->junctions.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const unsigned long long k = hk[order[i]];
+        spl_ctx::Junction &j = c->junctions[i];
+        j.left = (int32_t)(k >> 32);
+        j.right = (int32_t)((k & 0xffffffffull) >> 1);
+        j.strand = stranded ? ((k & 1ull) ? (uint8_t)'-' : (uint8_t)'+') : (uint8_t)'?';
+        j.count = hv[3 * (size_t)order[i]];
+        j.anchor_left = hv[3 * (size_t)order[i] + 1];
+        j.anchor_right = hv[3 * (size_t)order[i] + 2];
+    }
+    *n_out = n;
+    return SPL_OK;
+}
+
+extern "C" int spl_junctions_get(const spl_ctx *c, int32_t *left, int32_t *right, uint8_t *strand, uint32_t *count, uint32_t *anchor_left,
+                                 uint32_t *anchor_right)
+{
+    if (!c) return spl_set_error(SPL_ERR_ARG, "spl_junctions_get: null context");
+    for (size_t i = 0; i < c->junctions.size(); ++i) {
+        const spl_ctx::Junction &j = c->junctions[i];
+        if (left) left[i] = j.left;
+        if (right) right[i] = j.right;
+        if (strand) strand[i] = j.strand;
+        if (count) count[i] = j.count;
+        if (anchor_left) anchor_left[i] = j.anchor_left;
+        if (anchor_right) anchor_right[i] = j.anchor_right;
+    }
     return SPL_OK;
 }
 

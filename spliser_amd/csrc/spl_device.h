@@ -30,6 +30,7 @@
 #define SPL_KIND_TABLE ((1u << 0) | (3u << 4) | (2u << 6) | (1u << 14) | (1u << 16))
 
 #define SPL_DEV_ERR_RANGE 1
+#define SPL_DEV_ERR_TABLE 2
 
 // junction table entry flags (word 3, above the 8-bit rival count)
 #define SPL_JF_COMPLEX 0x100u   // needs the literal kernel (a rival is a junction end, too many rivals, ...)
@@ -166,6 +167,10 @@ extern "C" {
 // variant: 0 = range kernel (needs mutual partner links), 1 = pair kernel (any table), 2 = range kernel without
 // wave-level aggregation of LDS atomics (experiment)
 int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out);
+int spl_dev_launch_junctions(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar,
+                             int stranded, uint32_t min_anchor, uint32_t min_intron, uint32_t max_intron, unsigned long long *keys,
+                             uint32_t *vals, uint32_t n_slots, unsigned long long *out_keys,
+                             uint32_t *out_vals, uint32_t *n_out, int32_t *err, void *stream);
 int spl_dev_launch_rebase(int32_t *pos, uint32_t *cig_off, int64_t n, int32_t shift, uint32_t cig_base, void *stream);
 int spl_dev_launch_clear(void *region, size_t bytes, int32_t *err, uint32_t *queue_n, void *stream);
 int spl_dev_launch_literal(const spl_count_params *p, const spl_queue_params *q, void *stream);

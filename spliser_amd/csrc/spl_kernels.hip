@@ -1263,6 +1263,105 @@ __global__ __launch_bounds__(256) void spl_sse_kernel(const spl_sse_params p)
     p.sse[s] = value;
 }
 
+// =========================================================================================================
+// Junction table of a read set (what the pipeline otherwise gets from `regtools junctions extract`).
+// Every N op of every mapped read is a junction (l, r) in SpliSER's site convention (l = last base before the intron,
+// r = last intronic base; SpliSER_v0_1_8.py:482-483); the table holds, per distinct (l, r[, read strand]), the number
+// of reads carrying it and the longest anchors seen on either side (reference bases of the read between the junction and
+// the previous / next N op or read end -- the block sizes of a BED12 junction line).  Open addressing on a 64-bit key,
+// one insert per N op; lanes of a wave that insert the same key (neighbours in a sorted file) merge first.
+__global__ __launch_bounds__(256) void spl_junction_kernel(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off,
+                                                           const uint32_t *cigar, int stranded, uint32_t min_anchor, uint32_t min_intron,
+                                                           uint32_t max_intron, unsigned long long *keys, uint32_t *vals, uint32_t mask,
+                                                           int32_t *err)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n_reads;
+    uint32_t o = 0, n_ops = 0, fl = 0;
+    int32_t cur = 0;
+    if (valid) { o = cig_off[i]; n_ops = cig_off[i + 1] - o; cur = pos[i]; fl = flag[i]; }
+    const bool skip = !valid || (fl & 4u) || cur < 0; // unmapped records carry no junctions
+    const unsigned long long sbit = (stranded && spl_read_strand(fl, stranded) == (uint8_t)'-') ? 1ull : 0ull;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t k = 0;
+    uint32_t before = 0; // reference bases since the previous N op (or the read start)
+    // all lanes stay in the loop while any lane has ops left: the merge below is a wave-wide conversation
+    while (__any(!skip && k < n_ops)) {
+        bool have = false;
+        unsigned long long key = ~0ull;
+        uint32_t a_left = 0, a_right = 0;
+        while (!skip && k < n_ops && !have) {
+            const uint32_t op = cigar[o + k];
+            const uint32_t code = op & 15u, d = op >> 4;
+            ++k;
+            if (!((SPL_PROG_MASK >> code) & 1u)) continue;
+            if ((int64_t)cur + d > (int64_t)SPL_COORD_MAX) { atomicOr(err, SPL_DEV_ERR_RANGE); k = n_ops; break; }
+            cur += (int32_t)d;
+            if (code != SPL_OP_N) { before += d; continue; }
+            // anchor on the right: reference bases up to the next N op or the end of the read
+            uint32_t after = 0;
+            for (uint32_t k2 = k; k2 < n_ops; ++k2) {
+                const uint32_t op2 = cigar[o + k2];
+                const uint32_t c2 = op2 & 15u;
+                if (c2 == SPL_OP_N) break;
+                if ((SPL_PROG_MASK >> c2) & 1u) after += op2 >> 4;
+            }
+            const int32_t l = cur - (int32_t)d - 1, r = cur - 1;
+            key = ((unsigned long long)(uint32_t)l << 32) | ((unsigned long long)(uint32_t)r << 1) | sbit;
+            a_left = before;
+            a_right = after;
+            before = 0;
+            // the caller's policy (regtools' -a / -m / -M): a read supports a junction only with both anchors long enough
+            have = a_left >= min_anchor && a_right >= min_anchor && d >= min_intron && (max_intron == 0u || d <= max_intron);
+        }
+        // merge equal keys across the wave: one insert per distinct key
+        unsigned long long todo = __ballot(have);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t klo = (uint32_t)__shfl((int)(uint32_t)key, leader), khi = (uint32_t)__shfl((int)(uint32_t)(key >> 32), leader);
+            const bool same = have && (uint32_t)key == klo && (uint32_t)(key >> 32) == khi;
+            const unsigned long long grp = __ballot(same);
+            uint32_t ml = same ? a_left : 0u, mr = same ? a_right : 0u;
+            for (int off = 32; off > 0; off >>= 1) { // wave max over the group (others contribute 0)
+                const uint32_t xl = (uint32_t)__shfl_xor((int)ml, off), xr = (uint32_t)__shfl_xor((int)mr, off);
+                ml = xl > ml ? xl : ml;
+                mr = xr > mr ? xr : mr;
+            }
+            if (lane == leader) {
+                const unsigned long long kk = ((unsigned long long)khi << 32) | klo;
+                uint32_t h = (uint32_t)(kk * 0x9E3779B97F4A7C15ull >> 32);
+                for (uint32_t probe = 0;; ++probe) {
+                    const uint32_t slot = (h + probe) & mask;
+                    const unsigned long long old = atomicCAS(&keys[slot], ~0ull, kk);
+                    if (old == ~0ull || old == kk) {
+                        atomicAdd(&vals[3u * slot], (uint32_t)__popcll(grp));
+                        atomicMax(&vals[3u * slot + 1u], ml);
+                        atomicMax(&vals[3u * slot + 2u], mr);
+                        break;
+                    }
+                    if (probe > mask) { atomicOr(err, SPL_DEV_ERR_TABLE); break; } // cannot happen: the table has a free slot per op
+                }
+            }
+            todo &= ~grp;
+        }
+    }
+}
+
+// Non-empty slots -> dense arrays (order arbitrary; the host sorts).
+__global__ __launch_bounds__(256) void spl_junction_compact_kernel(const unsigned long long *keys, const uint32_t *vals, uint32_t n_slots,
+                                                                   unsigned long long *out_keys, uint32_t *out_vals, uint32_t *n_out)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n_slots) return;
+    const unsigned long long k = keys[j];
+    if (k == ~0ull) return;
+    const uint32_t at = atomicAdd(n_out, 1u);
+    out_keys[at] = k;
+    out_vals[3u * at] = vals[3u * j];
+    out_vals[3u * at + 1u] = vals[3u * j + 1u];
+    out_vals[3u * at + 2u] = vals[3u * j + 2u];
+}
+
 // A read segment (one chromosome of a shard) was copied into place as it is; this moves it into the shard's coordinate
 // space and makes its CIGAR offsets global.
 __global__ __launch_bounds__(256) void spl_rebase_kernel(int32_t *pos, uint32_t *cig_off, int64_t n, int32_t shift, uint32_t cig_base)
@@ -1285,6 +1384,24 @@ __global__ __launch_bounds__(256) void spl_clear_kernel(uint4 *region, size_t n1
 }
 
 // ---- launchers (called from spl_capi.cpp through spl_device.h) ------------------------------------------
+
+extern "C" int spl_dev_launch_junctions(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar,
+                                        int stranded, uint32_t min_anchor, uint32_t min_intron, uint32_t max_intron,
+                                        unsigned long long *keys, uint32_t *vals, uint32_t n_slots,
+                                        unsigned long long *out_keys, uint32_t *out_vals, uint32_t *n_out, int32_t *err, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(keys, 0xff, (size_t)n_slots * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(vals, 0, (size_t)n_slots * 12, st);
+    if (e == hipSuccess) e = hipMemsetAsync(n_out, 0, 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(err, 0, 4, st);
+    if (e != hipSuccess) return (int)e;
+    if (n_reads > 0)
+        hipLaunchKernelGGL(spl_junction_kernel, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, n_reads, pos, flag, cig_off, cigar,
+                           stranded, min_anchor, min_intron, max_intron, keys, vals, n_slots - 1u, err);
+    hipLaunchKernelGGL(spl_junction_compact_kernel, dim3((n_slots + 255u) / 256u), dim3(256), 0, st, keys, vals, n_slots, out_keys, out_vals, n_out);
+    return (int)hipGetLastError();
+}
 
 extern "C" int spl_dev_launch_rebase(int32_t *pos, uint32_t *cig_off, int64_t n, int32_t shift, uint32_t cig_base, void *stream)
 {

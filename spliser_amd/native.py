@@ -50,7 +50,7 @@ EXPORTS = [
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write",
-    "spl_gene_search",
+    "spl_gene_search", "spl_junctions", "spl_junctions_get",
 ]
 
 _lib = None
@@ -288,6 +288,19 @@ class DeviceReads(object):
         out = ctypes.c_int64(0)
         _check(lib().spl_literal_queue_size(self.ctx._h, self._h, ctypes.byref(out)))
         return out.value
+
+    def junctions(self, stranded=0, min_anchor=0, min_intron=0, max_intron=0):
+        """Junction table of this read set, computed on the device (``spl_junctions``): dict of arrays left, right,
+        strand (bytes '+', '-' or '?'), count, anchor_left, anchor_right, sorted by (left, right, strand)."""
+        n = ctypes.c_int64(0)
+        _check(lib().spl_junctions(self.ctx._h, self._h, ctypes.c_int(int(stranded)), ctypes.c_int32(int(min_anchor)),
+                                   ctypes.c_int32(int(min_intron)), ctypes.c_int32(int(max_intron)), ctypes.byref(n)))
+        n = n.value
+        out = dict(left=np.empty(n, np.int32), right=np.empty(n, np.int32), strand=np.empty(n, np.uint8),
+                   count=np.empty(n, np.uint32), anchor_left=np.empty(n, np.uint32), anchor_right=np.empty(n, np.uint32))
+        _check(lib().spl_junctions_get(self.ctx._h, _ptr(out["left"]), _ptr(out["right"]), _ptr(out["strand"]), _ptr(out["count"]),
+                                       _ptr(out["anchor_left"]), _ptr(out["anchor_right"])))
+        return out
 
     def free(self):
         if self._h:

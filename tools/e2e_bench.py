@@ -37,4 +37,21 @@ for rep in range(2):
     print("process wall %.2f s = %.1f M reads/s end to end; stages %s" % (dt, wl.n_reads / dt / 1e6, {k: round(v, 3) for k, v in timings.items()}))
     out["process_s"] = dt
     out["stages"] = timings
+from spliser_amd.junctions import junctions  # noqa: E402
+t = time.time()
+n_j = junctions(prefix + ".bam", prefix + "_junctions.bed", log=lambda m: None)
+out["junctions_s"] = time.time() - t
+print("junctions CLI wall %.2f s, %d junctions" % (out["junctions_s"], n_j))
+b = native.BamFile(prefix + ".bam")
+with native.Context(0) as ctx:
+    segs = [native.ReadArrays(r.pos, r.flag, r.cig_off, r.cigar) for r in (b.reads(c) for c in b.ref_names) if r is not None and r.n]
+    dr = ctx.upload_read_segments([(s, 0) for s in segs[:1]])
+    dr.junctions()
+    t = time.time()
+    for _ in range(5):
+        dr.junctions(0, 8, 70, 500000)
+    out["junction_table_call_s"] = (time.time() - t) / 5
+    print("spl_junctions on %d reads: %.4f s per call (table build + download + sort)" % (dr.n, out["junction_table_call_s"]))
+    dr.free()
+b.close()
 print(json.dumps(out))
