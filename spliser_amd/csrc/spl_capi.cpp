@@ -306,7 +306,7 @@ static void build_junction_table(const spl_sites *s, const std::vector<uint8_t> 
         }
     }
     size_t cap = 16;
-    while (cap < 2 * juncs.size() + 1) cap <<= 1;
+    while (cap < 4 * juncs.size() + 1) cap <<= 1; // load <= 1/4: at 1/2 one junction in a hundred missed its 8 probes and its reads paid the literal walk
     // a slot is two quads: {l, r, first rival record, count | flags} and a copy of the first rival's first quad, so that
     // the common one-rival junction costs the range kernel one memory trip instead of two
     jhash.assign(2 * cap, make_uint4(0x80000000u, 0, 0, 0));
