@@ -11,6 +11,13 @@
 #endif
 #define SPL_COUNTER_STRIDE 64            // words between the 8 queue counters: a 256-byte line each (counters sharing a
                                          // line serialise the atomics of all XCDs: measured 11 ns per atomic, chip-wide)
+// Packed read word r_fn: flag (16 bits) | op count saturating at SPL_NOPS_SAT (14 bits) | class (2 bits), the class being
+// what the pack kernel partitions a chunk by: the range kernel branches on it wave-uniformly.
+#define SPL_NOPS_SAT 0x3fffu
+#define SPL_RC_SIMPLE 0u                 // one aligned op, mapped, in range: every unspliced short read
+#define SPL_RC_MNM 1u                    // aligned, N, aligned; mapped, in range: every once-spliced short read
+#define SPL_RC_NARROW 2u                 // anything else of at most SPL_INLINE_OPS ops
+#define SPL_RC_WIDE 3u                   // more ops than that
 #ifndef SPL_BUCKET_AHEAD
 #define SPL_BUCKET_AHEAD 0              // 1: prefetch the next read's bucket entries too (registers!)
 #endif

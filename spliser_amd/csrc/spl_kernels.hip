@@ -353,11 +353,13 @@ __device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint4 e
     dbk_resolve(p, x, e, u, nv, rv);
 }
 
+typedef __attribute__((address_space(3))) int32_t spl_lds_i32; // the difference windows, typed as what they are: LDS
+
 // All 64 lanes call this together.  Lanes that add `sign` to the same key = (dpos << 2 | array) and sit next to each
 // other form a run; the first lane of each run adds sign * run-length once.  (Equal keys that are NOT adjacent make
 // several runs: still correct, just more atomics -- that only happens for unsorted input.)
 template <int NARR, bool AGG>
-__device__ __forceinline__ void commit_key(const spl_hot_params &p, int32_t *lds, int32_t wbase, bool valid, uint32_t key, int32_t sign)
+__device__ __forceinline__ void commit_key(const spl_hot_params &p, spl_lds_i32 *lds, int32_t wbase, bool valid, uint32_t key, int32_t sign)
 {
     int32_t amount = sign;
     bool go = valid;
@@ -378,7 +380,8 @@ __device__ __forceinline__ void commit_key(const spl_hot_params &p, int32_t *lds
         const int arr = (int)(key & 3u);
         const int32_t d = (int32_t)(key >> 2);
         const uint32_t loc = (uint32_t)(d - wbase);
-        if (loc <= (uint32_t)SPL_WIN) atomicAdd(&lds[arr * (SPL_WIN + 1) + (int)loc], amount);
+        // (an LDS-typed pointer: ds_add on one side, a global atomic on the other, never a flat atomic on a selected address)
+        if (loc <= (uint32_t)SPL_WIN) __hip_atomic_fetch_add(lds + (arr * (SPL_WIN + 1) + (int)loc), amount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + d], amount);
     }
 }
@@ -414,7 +417,7 @@ __device__ __forceinline__ void agg_add(uint32_t *addr, int32_t delta)
 // Point updates go to the same LDS difference arrays as the ranges.  Returns false when the read must take the
 // literal kernel instead (junction not in the table = not a BED junction, table entry marked complex, ...).
 template <bool STRANDED, int NARR>
-__device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, int32_t *lds, int32_t wbase, int32_t l, int32_t r,
+__device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, spl_lds_i32 *lds, int32_t wbase, int32_t l, int32_t r,
                                               const int32_t *blk_a, const int32_t *blk_b, uint32_t sidx)
 {
     uint32_t h = (uint32_t)l * 0x9E3779B1u ^ (uint32_t)r * 0x85EBCA77u;
@@ -497,9 +500,12 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
 {
     constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
     constexpr bool AHEAD = SPL_BUCKET_AHEAD != 0;
-    __shared__ int32_t lds[NARR * (SPL_WIN + 1)];
-    __shared__ uint16_t s_q[SPL_CHUNK]; // this chunk's reads for the literal kernel (chunk-relative packed slot)
-    __shared__ uint32_t s_qn, s_qbase;
+    __shared__ int32_t lds_words[NARR * (SPL_WIN + 1)];
+    spl_lds_i32 *const lds = (spl_lds_i32 *)lds_words;
+    // one array, two lists of chunk-relative packed slots: from the front the reads for the literal kernel, from the back
+    // the once-spliced reads whose junction has rivals (finished from the junction table after the loop, see below)
+    __shared__ uint16_t s_q[SPL_CHUNK];
+    __shared__ uint32_t s_qn, s_rn, s_qbase;
 
     const int tid = threadIdx.x;
     const uint32_t chunk = my_chunk();
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     // ---- trip 2: bucket entries of the start boundary and of every inline op end (slots are clamped: always legal).
     //      The ends are recomputed when the read is worked on; for a read that turns out bad the entries go unused.
     auto fetch_buckets = [&](int32_t f_pos, uint32_t f_fn, const uint32_t (&f_op)[SPL_INLINE_OPS], uint4 (&f_e)[SPL_INLINE_OPS + 1]) {
-        const bool wide = (f_fn >> 16) > (uint32_t)SPL_INLINE_OPS;
+        const bool wide = (f_fn >> 30) == SPL_RC_WIDE;
         uint32_t len = 0;
         f_e[0] = p.dbucket[dbk_slot(p, f_pos - 1)];
 #pragma unroll
@@ -543,7 +549,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     int32_t wbase = 0;
     { uint32_t nv; dbk_resolve(p, first_pos - 1, p.dbucket[dbk_slot(p, first_pos - 1)], wbase, nv); }
     for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) lds[j] = 0;
-    if (tid == 0) s_qn = 0u;
+    if (tid == 0) { s_qn = 0u; s_rn = 0u; }
     __syncthreads();
     SPL_PHASE(1);
 
@@ -582,18 +588,10 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 if (it + 1 < SPL_RPT) fetch_read(it + 1, cu_pos, cu_fn, cu_op); // next read's words
             }
             const uint32_t flag = fn & 0xffffu;
-            uint32_t n_ops = fn >> 16;
-            uint32_t o0 = 0; // index of op 0 in cigar[]: known (and needed) only for reads with more than 3 ops
-            if (n_ops > (uint32_t)SPL_INLINE_OPS) {
-                o0 = op[2] - 2u;
-                op[2] = 0xfu; // the third word was the pointer: ops 2.. are walked one at a time below
-            }
-            const uint32_t n_inline = n_ops > (uint32_t)SPL_INLINE_OPS ? 2u : n_ops;
-            // ---- a wave of simple reads (one aligned op, mapped: the pack kernel put them first in the chunk) takes the
-            //      short road: two boundaries, one range, nothing else can happen to such a read
-            const bool simple = n_ops == 1u && ((SPL_KIND_TABLE >> (2u * (op[0] & 15u))) & 3u) == 1u && !(flag & 4u) && pos >= 0 &&
-                                (op[0] >> 4) <= (uint32_t)(SPL_COORD_MAX - (pos < 0 ? 0 : pos));
-            if (__all(simple)) {
+            const uint32_t cls = fn >> 30; // lanes past the end repeat the last read of the chunk: same class, masked by `alive`
+            // ---- a wave of simple reads (one aligned op, mapped, in range: the pack kernel checked all that and put them
+            //      first in the chunk) takes the short road: two boundaries, one range, nothing else can happen
+            if (__all(cls == SPL_RC_SIMPLE)) {
                 const int32_t c1 = pos + (int32_t)(op[0] >> 4);
                 if (!AHEAD) { e0 = p.dbucket[dbk_slot(p, pos - 1)]; ek[0] = p.dbucket[dbk_slot(p, c1 - 1)]; }
                 int32_t ua, ub; uint32_t nva, nvb;
@@ -609,13 +607,73 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 }
                 continue;
             }
+            // ---- a wave of once-spliced reads (aligned, N, aligned): the kinds are known, so are the arrays; three ranges
+            //      and the junction-table look-up when an end of the junction has rivals
+            if (__all(cls == SPL_RC_MNM)) {
+                const int32_t c0 = pos + (int32_t)(op[0] >> 4), c1 = c0 + (int32_t)(op[1] >> 4), c2 = c1 + (int32_t)(op[2] >> 4);
+                if (!AHEAD) {
+                    e0 = p.dbucket[dbk_slot(p, pos - 1)];
+                    ek[0] = p.dbucket[dbk_slot(p, c0 - 1)];
+                    ek[1] = p.dbucket[dbk_slot(p, c1 - 1)];
+                    ek[2] = p.dbucket[dbk_slot(p, c2 - 1)];
+                }
+                uint32_t sidx = 0;
+                if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
+                const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx;
+                // boundary by boundary, so that a bucket entry dies as soon as it is resolved (the kernel lives on 64 VGPRs)
+                int32_t ua, ub; uint32_t nva, nvb, rva, rvb, nv1, rv1;
+                dbk_resolve(p, pos - 1, e0, ua, nva, rva);
+                dbk_resolve(p, c0 - 1, ek[0], ub, nvb, rvb);
+                {
+                    const int32_t lo = ua + (int32_t)nva;
+                    const bool em = alive && ub > lo;
+                    if (__any(em)) {
+                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | sidx, 1);
+                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | sidx, -1);
+                    }
+                }
+                nv1 = nvb; rv1 = rvb;
+                ua = ub; nva = nvb;
+                dbk_resolve(p, c1 - 1, ek[1], ub, nvb, rvb);
+                {
+                    const int32_t lo = ua + (int32_t)nva;
+                    const bool em = alive && ub > lo;
+                    if (__any(em)) {
+                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | a_me, 1);
+                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | a_me, -1);
+                    }
+                }
+                const uint32_t nv2 = nvb, rv2 = rvb;
+                ua = ub; nva = nvb;
+                dbk_resolve(p, c2 - 1, ek[2], ub, nvb);
+                {
+                    const int32_t lo = ua + (int32_t)nva;
+                    const bool em = alive && ub > lo;
+                    if (__any(em)) {
+                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | sidx, 1);
+                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | sidx, -1);
+                    }
+                }
+                if (alive && (((nv1 & rv1) | (nv2 & rv2)) != 0u)) { // an end of the junction (c0 - 1, c1 - 1) has rivals
+                    if (p.combine_mode) s_q[atomicAdd(&s_qn, 1u)] = (uint16_t)(it * SPL_BLOCK + tid);
+                    else s_q[SPL_CHUNK - 1u - atomicAdd(&s_rn, 1u)] = (uint16_t)(it * SPL_BLOCK + tid);
+                }
+                continue;
+            }
+            uint32_t n_ops = (fn >> 16) & SPL_NOPS_SAT;
+            uint32_t o0 = 0; // index of op 0 in cigar[]: known (and needed) only for reads with more than 3 ops
+            if (n_ops > (uint32_t)SPL_INLINE_OPS) {
+                o0 = op[2] - 2u;
+                op[2] = 0xfu; // the third word was the pointer: ops 2.. are walked one at a time below
+            }
+            const uint32_t n_inline = n_ops > (uint32_t)SPL_INLINE_OPS ? 2u : n_ops;
             bool bad = alive && pos < 0;
             const bool literal = alive && !bad && (flag & 4u); // fetched as a 1-base record: literal kernel
             alive = alive && !bad && !literal;
             uint32_t sidx = 0;
             if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
             const bool wide = n_ops > (uint32_t)SPL_INLINE_OPS;
-            if (n_ops == 0xffffu) // the packed word saturates: the true count is with the read's own place in the input
+            if (n_ops == SPL_NOPS_SAT) // the packed word saturates: the true count is with the read's own place in the input
                 n_ops = p.cig_off[chunk_base + p.perm[ii] + 1] - o0;
             const uint32_t room = (uint32_t)(SPL_COORD_MAX - (pos < 0 ? 0 : pos));
             uint32_t len = 0;
@@ -669,25 +727,12 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 k_next += (uint32_t)SPL_INLINE_OPS;
             }
             if (bad) atomicOr(p.err, SPL_DEV_ERR_RANGE);
-            bool to_queue = literal;
-            if (alive && rival) {
-                // one junction among <= SPL_INLINE_OPS ops, everything else aligned: rivals come from the junction table
-                int n_n = 0, n_b = 0;
-                int32_t jl = 0, jr = 0, blk_a[2] = {1, 1}, blk_b[2] = {0, 0};
-                bool simple = !p.combine_mode && n_ops <= (uint32_t)SPL_INLINE_OPS;
-#pragma unroll
-                for (int k = 0; k < SPL_INLINE_OPS; ++k) {
-                    const int32_t start = k ? cend[k - 1] : pos;
-                    if (kind[k] == 2u) { ++n_n; jl = start - 1; jr = cend[k] - 1; }
-                    else if (kind[k] == 3u) simple = false;
-                    else if (kind[k] == 1u) {
-                        if (n_b == 0) { blk_a[0] = start; blk_b[0] = cend[k] - 1; }
-                        else { blk_a[1] = start; blk_b[1] = cend[k] - 1; }
-                        ++n_b;
-                    }
-                }
-                simple = simple && n_n == 1 && n_b <= 2;
-                if (!simple || !rivals_inline<STRANDED, NARR>(p, lds, wbase, jl, jr, blk_a, blk_b, sidx)) to_queue = true;
+            // (a junction with rivals outside the once-spliced class -- soft clips, indels next to it, several junctions --
+            //  is the literal kernel's business)
+            bool to_queue = literal || (alive && rival);
+            if (to_queue && !literal && cls == SPL_RC_MNM && !p.combine_mode) { // a once-spliced read in a wave of mixed classes
+                s_q[SPL_CHUNK - 1u - atomicAdd(&s_rn, 1u)] = (uint16_t)(it * SPL_BLOCK + tid);
+                to_queue = false;
             }
             if (to_queue) s_q[atomicAdd(&s_qn, 1u)] = (uint16_t)(it * SPL_BLOCK + tid);
         }
@@ -697,6 +742,37 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
 #ifdef SPL_PHASE_TAIL
     SPL_PHASE(3); // with SPL_PHASE_TAIL slots 3 and 4 look inside the epilogue: barrier passed, queue handed over
 #endif
+    // Once-spliced reads with rivals, all lanes busy: the junction table says which sites of the read's window are
+    // affected and how (rivals_inline); what it cannot decide moves to the literal list -- after a barrier, because the
+    // front of s_q may by then reach into the part of the back list that is still being read.
+    {
+        const uint32_t rn = s_rn; // uniform
+        uint32_t undecided[SPL_RPT];
+#pragma unroll
+        for (int r = 0; r < SPL_RPT; ++r) {
+            undecided[r] = 0xffffffffu;
+            const uint32_t j = (uint32_t)(r * SPL_BLOCK + tid);
+            if (j < rn) {
+                const uint32_t slot = s_q[SPL_CHUNK - 1u - j];
+                const int64_t idx = chunk_base + slot;
+                const int32_t pos = p.r_pos[idx];
+                const uint32_t fn = p.r_fn[idx];
+                const uint32_t a = p.r_ops3[3 * idx] >> 4, d = p.r_ops3[3 * idx + 1] >> 4, b = p.r_ops3[3 * idx + 2] >> 4;
+                const int32_t c0 = pos + (int32_t)a, c1 = c0 + (int32_t)d, c2 = c1 + (int32_t)b;
+                uint32_t sidx = 0;
+                if (STRANDED) sidx = (spl_read_strand(fn & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
+                const int32_t blk_a[2] = {pos, c1}, blk_b[2] = {c0 - 1, c2 - 1};
+                if (!rivals_inline<STRANDED, NARR>(p, lds, wbase, c0 - 1, c1 - 1, blk_a, blk_b, sidx)) undecided[r] = slot;
+            }
+        }
+        if (rn) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < SPL_RPT; ++r)
+                if (undecided[r] != 0xffffffffu) s_q[atomicAdd(&s_qn, 1u)] = (uint16_t)undecided[r];
+            __syncthreads();
+        }
+    }
     // Hand the chunk's queue over: one returning atomic per workgroup on the counter of its XCD shard (8 counters, so
     // no single word sees more than a few reservations per microsecond), then a dense copy of packed indexes.
     // (Per-chunk regions without any atomic were tried: the range kernel gains 1 %, the literal kernel then has to walk
@@ -1020,12 +1096,12 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
             const int32_t pos = q.r_pos[idx];
             const uint32_t fn = q.r_fn[idx];
             const uint32_t flag = fn & 0xffffu;
-            uint32_t n_ops = fn >> 16;
+            uint32_t n_ops = (fn >> 16) & SPL_NOPS_SAT;
             const uint32_t *ops = q.r_ops3 + 3 * idx;
             if (n_ops > (uint32_t)SPL_INLINE_OPS) {
                 const uint32_t o0 = ops[2] - 2u;
                 ops = p.cigar + o0;
-                if (n_ops == 0xffffu) { // the packed count saturates: the true one from the BAM-native offsets
+                if (n_ops == SPL_NOPS_SAT) { // the packed count saturates: the true one from the BAM-native offsets
                     const int64_t i = (idx / SPL_CHUNK) * SPL_CHUNK + q.perm[idx];
                     n_ops = p.cig_off[i + 1] - o0;
                 }
@@ -1067,61 +1143,69 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
 // The range kernel's read layout, derived once per upload from the BAM-native arrays (one workgroup per chunk):
 //   * one word with flag and op count, three words with the first ops (or two ops and where the rest start), so that
 //     everything a typical read needs arrives in ONE memory trip without going through cig_off first;
-//   * inside each chunk the reads are stably partitioned into three runs: "simple" reads (exactly one aligned op,
-//     mapped, in range -- every unspliced short read), other reads of at most SPL_INLINE_OPS ops, wide reads.  Each run
-//     keeps coordinate order.  A wave of the range kernel then sees (almost always) one kind of read: simple ones take
-//     a path of their own on a wave-uniform branch, and only waves of wide reads walk further batches of ops.
+//   * inside each chunk the reads are stably partitioned into four runs (SPL_RC_*): simple reads (one aligned op,
+//     mapped, in range -- every unspliced short read), once-spliced reads (aligned, N, aligned), other reads of at most
+//     SPL_INLINE_OPS ops, wide reads; the class also rides in the top bits of the packed word.  Each run keeps
+//     coordinate order.  A wave of the range kernel then sees (almost always) one kind of read: the first two classes
+//     take paths of their own on wave-uniform branches, and only waves of wide reads walk further batches of ops.
 //   perm[] maps a packed slot back to the read's place in the chunk.
 __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_reads, const int32_t *pos, const uint16_t *flag,
                                                                    const uint32_t *cig_off, const uint32_t *cigar, int32_t *p_pos,
                                                                    uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm)
 {
     constexpr int NW = SPL_BLOCK / 64;
-    __shared__ uint32_t cnt[3][SPL_RPT][NW];
+    constexpr int NC = 4; // SPL_RC_*
+    __shared__ uint32_t cnt[NC][SPL_RPT][NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t cb = (int64_t)blockIdx.x * SPL_CHUNK;
     int32_t r_pos[SPL_RPT];
     uint32_t r_fn[SPL_RPT], w[SPL_RPT][3], rank[SPL_RPT];
-    int cls[SPL_RPT]; // 0 simple, 1 narrow, 2 wide, 3 past the end
+    int cls[SPL_RPT]; // SPL_RC_*, NC = past the end
 #pragma unroll
     for (int it = 0; it < SPL_RPT; ++it) {
         const int64_t i = cb + (int64_t)it * SPL_BLOCK + tid;
-        cls[it] = 3;
+        cls[it] = NC;
         r_pos[it] = 0; r_fn[it] = 0; w[it][0] = w[it][1] = w[it][2] = 0xfu;
         if (i < n_reads) {
             const uint32_t o0 = cig_off[i], n = cig_off[i + 1] - o0;
             r_pos[it] = pos[i];
-            r_fn[it] = (uint32_t)flag[i] | ((n < 0xffffu ? n : 0xffffu) << 16);
             if (n <= 3u) { for (uint32_t k = 0; k < n; ++k) w[it][k] = cigar[o0 + k]; }
             else { w[it][0] = cigar[o0]; w[it][1] = cigar[o0 + 1]; w[it][2] = o0 + 2u; }
-            const bool simple = n == 1u && ((SPL_KIND_TABLE >> (2u * (w[it][0] & 15u))) & 3u) == 1u && !(flag[i] & 4u) && r_pos[it] >= 0 &&
-                                (int64_t)r_pos[it] + (int64_t)(w[it][0] >> 4) <= (int64_t)SPL_COORD_MAX;
-            cls[it] = simple ? 0 : (n <= 3u ? 1 : 2);
+            auto kind = [](uint32_t op) { return (SPL_KIND_TABLE >> (2u * (op & 15u))) & 3u; };
+            const bool placed = !(flag[i] & 4u) && r_pos[it] >= 0;
+            const int64_t room = (int64_t)SPL_COORD_MAX - (int64_t)r_pos[it];
+            const bool simple = placed && n == 1u && kind(w[it][0]) == 1u && (int64_t)(w[it][0] >> 4) <= room;
+            const bool mnm = placed && n == 3u && kind(w[it][0]) == 1u && kind(w[it][1]) == 2u && kind(w[it][2]) == 1u &&
+                             (int64_t)(w[it][0] >> 4) + (int64_t)(w[it][1] >> 4) + (int64_t)(w[it][2] >> 4) <= room;
+            cls[it] = simple ? (int)SPL_RC_SIMPLE : mnm ? (int)SPL_RC_MNM : (n <= 3u ? (int)SPL_RC_NARROW : (int)SPL_RC_WIDE);
+            r_fn[it] = (uint32_t)flag[i] | ((n < SPL_NOPS_SAT ? n : SPL_NOPS_SAT) << 16) | ((uint32_t)cls[it] << 30);
         }
         const unsigned long long below = (1ull << lane) - 1ull;
         rank[it] = 0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const unsigned long long m = __ballot(cls[it] == c);
             if (cls[it] == c) rank[it] = (uint32_t)__popcll(m & below);
             if (lane == 0) cnt[c][it][wave] = (uint32_t)__popcll(m);
         }
     }
     __syncthreads();
-    uint32_t total[3] = {0, 0, 0};
+    uint32_t total[NC];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < NC; ++c) {
+        total[c] = 0;
         for (int it = 0; it < SPL_RPT; ++it)
             for (int wv = 0; wv < NW; ++wv) total[c] += cnt[c][it][wv];
+    }
 #pragma unroll
     for (int it = 0; it < SPL_RPT; ++it) {
-        if (cls[it] == 3) continue;
+        if (cls[it] == NC) continue;
         const int c = cls[it];
-        uint32_t before = c == 0 ? 0u : (c == 1 ? total[0] : total[0] + total[1]); // runs of the classes before mine
-        // reads of my class in earlier (it, wave) groups: chunk order is it-major, then wave, then lane
+        uint32_t before = 0; // the runs of the classes before mine, then reads of my class in earlier (it, wave) groups
+        for (int c2 = 0; c2 < NC; ++c2) before += (c2 < c) ? total[c2] : 0u;
         for (int it2 = 0; it2 <= it; ++it2)
             for (int wv = 0; wv < NW; ++wv)
-                if (it2 < it || wv < wave) before += cnt[c][it2][wv];
+                if (it2 < it || wv < wave) before += cnt[c][it2][wv]; // chunk order is it-major, then wave, then lane
         const int64_t dst = cb + before + rank[it];
         p_pos[dst] = r_pos[it];
         p_fn[dst] = r_fn[it];
