@@ -502,10 +502,29 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     constexpr bool AHEAD = SPL_BUCKET_AHEAD != 0;
     __shared__ int32_t lds_words[NARR * (SPL_WIN + 1)];
     spl_lds_i32 *const lds = (spl_lds_i32 *)lds_words;
-    // one array, two lists of chunk-relative packed slots: from the front the reads for the literal kernel, from the back
-    // the once-spliced reads whose junction has rivals (finished from the junction table after the loop, see below)
+    // Each wave owns one segment of s_q (as many entries as it has reads) with two lists of chunk-relative packed slots:
+    // from the front the reads for the literal kernel, from the back the once-spliced reads whose junction has rivals
+    // (finished from the junction table by the wave itself right after its loop, see below).  Only the owning wave touches a
+    // segment, so the fill counts are wave-uniform registers and slots are handed out by ballot, not by atomics.
+    constexpr int NWAVE = SPL_BLOCK / 64;
+    constexpr uint32_t SEG = 64u * SPL_RPT;
     __shared__ uint16_t s_q[SPL_CHUNK];
-    __shared__ uint32_t s_qn, s_rn, s_qbase;
+    __shared__ uint32_t s_qcnt[NWAVE], s_qbase;
+    const uint32_t seg0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * SEG; // wave-uniform, in an SGPR
+    uint32_t n_front = 0, n_back = 0;
+    auto rank_in = [](unsigned long long m) { // how many lanes below mine are in m (mbcnt: no per-lane mask to keep around)
+        return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
+    auto push_front = [&](bool want, uint32_t slot) {
+        const unsigned long long m = __ballot(want);
+        if (want) s_q[seg0 + n_front + rank_in(m)] = (uint16_t)slot;
+        n_front += (uint32_t)__popcll(m);
+    };
+    auto push_back = [&](bool want, uint32_t slot) {
+        const unsigned long long m = __ballot(want);
+        if (want) s_q[seg0 + SEG - 1u - n_back - rank_in(m)] = (uint16_t)slot;
+        n_back += (uint32_t)__popcll(m);
+    };
 
     const int tid = threadIdx.x;
     const uint32_t chunk = my_chunk();
@@ -549,7 +568,6 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     int32_t wbase = 0;
     { uint32_t nv; dbk_resolve(p, first_pos - 1, p.dbucket[dbk_slot(p, first_pos - 1)], wbase, nv); }
     for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) lds[j] = 0;
-    if (tid == 0) { s_qn = 0u; s_rn = 0u; }
     __syncthreads();
     SPL_PHASE(1);
 
@@ -654,9 +672,10 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                         commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | sidx, -1);
                     }
                 }
-                if (alive && (((nv1 & rv1) | (nv2 & rv2)) != 0u)) { // an end of the junction (c0 - 1, c1 - 1) has rivals
-                    if (p.combine_mode) s_q[atomicAdd(&s_qn, 1u)] = (uint16_t)(it * SPL_BLOCK + tid);
-                    else s_q[SPL_CHUNK - 1u - atomicAdd(&s_rn, 1u)] = (uint16_t)(it * SPL_BLOCK + tid);
+                const bool flagged = alive && (((nv1 & rv1) | (nv2 & rv2)) != 0u); // an end of the junction (c0 - 1, c1 - 1) has rivals
+                if (__any(flagged)) {
+                    push_front(flagged && p.combine_mode, (uint32_t)(it * SPL_BLOCK + tid));
+                    push_back(flagged && !p.combine_mode, (uint32_t)(it * SPL_BLOCK + tid));
                 }
                 continue;
             }
@@ -729,31 +748,22 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             if (bad) atomicOr(p.err, SPL_DEV_ERR_RANGE);
             // (a junction with rivals outside the once-spliced class -- soft clips, indels next to it, several junctions --
             //  is the literal kernel's business)
-            bool to_queue = literal || (alive && rival);
-            if (to_queue && !literal && cls == SPL_RC_MNM && !p.combine_mode) { // a once-spliced read in a wave of mixed classes
-                s_q[SPL_CHUNK - 1u - atomicAdd(&s_rn, 1u)] = (uint16_t)(it * SPL_BLOCK + tid);
-                to_queue = false;
+            const bool flagged = !literal && alive && rival;
+            const bool later = flagged && cls == SPL_RC_MNM && !p.combine_mode; // a once-spliced read in a wave of mixed classes
+            if (__any(literal || flagged)) {
+                push_front(literal || (flagged && !later), (uint32_t)(it * SPL_BLOCK + tid));
+                push_back(later, (uint32_t)(it * SPL_BLOCK + tid));
             }
-            if (to_queue) s_q[atomicAdd(&s_qn, 1u)] = (uint16_t)(it * SPL_BLOCK + tid);
         }
-    }
-    SPL_PHASE(6);
-    __syncthreads();
-#ifdef SPL_PHASE_TAIL
-    SPL_PHASE(3); // with SPL_PHASE_TAIL slots 3 and 4 look inside the epilogue: barrier passed, queue handed over
-#endif
-    // Once-spliced reads with rivals, all lanes busy: the junction table says which sites of the read's window are
-    // affected and how (rivals_inline); what it cannot decide moves to the literal list -- after a barrier, because the
-    // front of s_q may by then reach into the part of the back list that is still being read.
-    {
-        const uint32_t rn = s_rn; // uniform
-        uint32_t undecided[SPL_RPT];
-#pragma unroll
-        for (int r = 0; r < SPL_RPT; ++r) {
-            undecided[r] = 0xffffffffu;
-            const uint32_t j = (uint32_t)(r * SPL_BLOCK + tid);
-            if (j < rn) {
-                const uint32_t slot = s_q[SPL_CHUNK - 1u - j];
+        // Once-spliced reads with rivals, the wave's own, lanes dense: the junction table says which sites of the read's
+        // window are affected and how (rivals_inline); what it cannot decide joins the literal list.  The list is read
+        // from its growing end, so the front list can only ever grow into entries that are done with.
+        for (uint32_t r0 = 0; r0 < n_back; r0 += 64u) {
+            const uint32_t j = r0 + (uint32_t)(tid & 63);
+            bool undecided = false;
+            uint32_t slot = 0;
+            if (j < n_back) {
+                slot = s_q[seg0 + SEG - n_back + j];
                 const int64_t idx = chunk_base + slot;
                 const int32_t pos = p.r_pos[idx];
                 const uint32_t fn = p.r_fn[idx];
@@ -762,29 +772,41 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 uint32_t sidx = 0;
                 if (STRANDED) sidx = (spl_read_strand(fn & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
                 const int32_t blk_a[2] = {pos, c1}, blk_b[2] = {c0 - 1, c2 - 1};
-                if (!rivals_inline<STRANDED, NARR>(p, lds, wbase, c0 - 1, c1 - 1, blk_a, blk_b, sidx)) undecided[r] = slot;
+                undecided = !rivals_inline<STRANDED, NARR>(p, lds, wbase, c0 - 1, c1 - 1, blk_a, blk_b, sidx);
             }
-        }
-        if (rn) {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < SPL_RPT; ++r)
-                if (undecided[r] != 0xffffffffu) s_q[atomicAdd(&s_qn, 1u)] = (uint16_t)undecided[r];
-            __syncthreads();
+            if (__any(undecided)) push_front(undecided, slot);
         }
     }
+    if ((tid & 63) == 0) s_qcnt[tid >> 6] = n_front;
+    SPL_PHASE(6);
+    __syncthreads();
+#ifdef SPL_PHASE_TAIL
+    SPL_PHASE(3); // with SPL_PHASE_TAIL slots 3 and 4 look inside the epilogue: barrier passed, queue handed over
+#endif
     // Hand the chunk's queue over: one returning atomic per workgroup on the counter of its XCD shard (8 counters, so
     // no single word sees more than a few reservations per microsecond), then a dense copy of packed indexes.
     // (Per-chunk regions without any atomic were tried: the range kernel gains 1 %, the literal kernel then has to walk
     // regions of very uneven fill and loses far more.)
-    const uint32_t qn = s_qn; // uniform: read after the barrier above
+    uint32_t q_start[NWAVE + 1];
+    q_start[0] = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) q_start[w + 1] = q_start[w] + s_qcnt[w];
+    const uint32_t qn = q_start[NWAVE]; // uniform: read after the barrier above
     if (qn) {
         const uint32_t shard = blockIdx.x & 7u;
         if (tid == 0) s_qbase = atomicAdd(&p.queue_n[shard * SPL_COUNTER_STRIDE], qn); // a cache line per counter
         __syncthreads();
         uint32_t *dst = p.queue + (size_t)shard * p.queue_cap + s_qbase;
         const uint32_t first = (uint32_t)chunk_base;
-        for (uint32_t j = tid; j < qn; j += SPL_BLOCK) dst[j] = first + (uint32_t)s_q[j];
+        for (uint32_t j = tid; j < qn; j += SPL_BLOCK) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int k = 1; k < NWAVE; ++k) w += (j >= q_start[k]) ? 1u : 0u;
+            uint32_t base = 0;
+#pragma unroll
+            for (int k = 0; k < NWAVE; ++k) base = (w == (uint32_t)k) ? q_start[k] : base;
+            dst[j] = first + (uint32_t)s_q[w * SEG + (j - base)];
+        }
     }
 #ifdef SPL_PHASE_TAIL
     SPL_PHASE(4);
