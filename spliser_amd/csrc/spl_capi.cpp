@@ -99,6 +99,7 @@ struct spl_dreads {
     uint32_t *fn = nullptr, *ops3 = nullptr;       // the range kernel's own layout, packed on the device at upload
     int32_t *ppos = nullptr;
     uint16_t *perm = nullptr;
+    uint32_t *chunk_order = nullptr; // slot of an XCD slice -> chunk, longest first (holds the cost estimates during upload)
     uint32_t *queue = nullptr, *queue_n = nullptr; // reads the range kernel hands to the literal kernel
 };
 
@@ -555,6 +556,7 @@ static int upload_segments(spl_ctx *c, int n_seg, const spl_reads *segs, const i
     const size_t o_pos = take(4 * R), o_flag = take(2 * R), o_off = take(4 * (R + 1)), o_cig = take(4 * G);
     const size_t o_fn = take(4 * R), o_ops3 = take(12 * R), o_ppos = take(4 * R), o_perm = take(2 * R);
     const size_t n_chunks = (size_t)((R + SPL_CHUNK - 1) / SPL_CHUNK);
+    const size_t o_order = take(4 * (n_chunks ? n_chunks : 1));
     // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks
     const size_t shard_cap = ((n_chunks + 7) / 8) * SPL_CHUNK;
     const size_t o_queue = take(4 * 8 * shard_cap), o_qn = take(4 * 8 * SPL_COUNTER_STRIDE);
@@ -565,6 +567,7 @@ static int upload_segments(spl_ctx *c, int n_seg, const spl_reads *segs, const i
     d->queue = (uint32_t *)(d->slab + o_queue); d->queue_n = (uint32_t *)(d->slab + o_qn);
     d->fn = (uint32_t *)(d->slab + o_fn); d->ops3 = (uint32_t *)(d->slab + o_ops3);
     d->ppos = (int32_t *)(d->slab + o_ppos); d->perm = (uint16_t *)(d->slab + o_perm);
+    d->chunk_order = (uint32_t *)(d->slab + o_order);
     hipError_t q = hipSuccess;
     const uint32_t total_ops = (uint32_t)G; // lives until the synchronize below
     if (R) {
@@ -584,8 +587,21 @@ static int upload_segments(spl_ctx *c, int n_seg, const spl_reads *segs, const i
         }
         if (q == hipSuccess) q = hipMemcpyAsync(d->cig_off + R, &total_ops, 4, hipMemcpyHostToDevice, c->stream);
         // the range kernel's layout (flag + op count in one word, first ops inline) is derived on the device
-        if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack(R, d->pos, d->flag, d->cig_off, d->cigar, d->ppos, d->fn, d->ops3, d->perm, c->stream);
+        if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack(R, d->pos, d->flag, d->cig_off, d->cigar, d->ppos, d->fn, d->ops3, d->perm, d->chunk_order, c->stream);
         if (q == hipSuccess) q = hipStreamSynchronize(c->stream); // caller buffers are free to go after return
+        // chunk order of the range kernel: its workgroup b works on slot (b & 7) * per + (b >> 3) (one contiguous eighth of the
+        // reads per XCD, see my_chunk); inside every eighth the chunks go longest first
+        if (q == hipSuccess) {
+            std::vector<uint32_t> cost(n_chunks), order(n_chunks);
+            q = hipMemcpy(cost.data(), d->chunk_order, 4 * n_chunks, hipMemcpyDeviceToHost);
+            const size_t grid = (n_chunks + 7) / 8 * 8, per = grid / 8;
+            for (size_t x = 0; x < 8; ++x) {
+                const size_t lo = std::min(x * per, n_chunks), hi = std::min(lo + per, n_chunks);
+                for (size_t k = lo; k < hi; ++k) order[k] = (uint32_t)k;
+                std::stable_sort(order.begin() + (ptrdiff_t)lo, order.begin() + (ptrdiff_t)hi, [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+            }
+            if (q == hipSuccess) q = hipMemcpy(d->chunk_order, order.data(), 4 * n_chunks, hipMemcpyHostToDevice);
+        }
     }
     if (q != hipSuccess) { (void)hipFree(d->slab); delete d; return spl_set_error(SPL_ERR_HIP, "read set upload: %s", hipGetErrorString(q)); }
     *out = d;
@@ -638,7 +654,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.jhash = ds->jhash; p.jhash_mask = ds->jhash_mask; p.jrivals = ds->jrivals;
     spl_hot_params h;
     memset(&h, 0, sizeof(h));
-    h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos_orig = p.r_pos; h.r_pos = dr->ppos; h.perm = dr->perm; h.r_fn = dr->fn; h.r_ops3 = dr->ops3; h.cig_off = p.cig_off; h.cigar = p.cigar;
+    h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos_orig = p.r_pos; h.r_pos = dr->ppos; h.perm = dr->perm; h.chunk_order = dr->chunk_order; h.r_fn = dr->fn; h.r_ops3 = dr->ops3; h.cig_off = p.cig_off; h.cigar = p.cigar;
     h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.n_cigar = (uint32_t)dr->n_cigar;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = dr->queue; h.queue_n = dr->queue_n; h.err = c->d_err;

@@ -102,6 +102,7 @@ struct spl_hot_params {
     const int32_t *r_pos_orig;   // BAM-native order (window base of a chunk)
     const int32_t *r_pos;        // the arrays below are packed at upload, chunk-locally reordered (simple reads first)
     const uint16_t *perm;        // packed slot -> place of the read in its chunk
+    const uint32_t *chunk_order; // [n_chunks] slot of an XCD slice -> chunk, longest chunk first within every slice
     const uint32_t *r_fn;        // flag | min(n_ops, 65535) << 16
     const uint32_t *r_ops3;      // packed at upload, 3 words per read: the ops of a read with <= 3 ops (absent = 0xf);
                                  // for longer reads {op0, op1, index of op2 in cigar[]}
@@ -182,7 +183,7 @@ int spl_dev_launch_rebase(int32_t *pos, uint32_t *cig_off, int64_t n, int32_t sh
 int spl_dev_launch_clear(void *region, size_t bytes, int32_t *err, uint32_t *queue_n, void *stream);
 int spl_dev_launch_literal(const spl_count_params *p, const spl_queue_params *q, void *stream);
 int spl_dev_launch_pack(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar,
-                        int32_t *p_pos, uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm, void *stream);
+                        int32_t *p_pos, uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm, uint32_t *chunk_cost, void *stream);
 int spl_dev_launch_scan(const spl_scan_params *p, void *stream);
 int spl_dev_launch_sse(const spl_sse_params *p, void *stream);
 #ifdef __cplusplus

@@ -527,8 +527,11 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     };
 
     const int tid = threadIdx.x;
-    const uint32_t chunk = my_chunk();
-    const bool live = chunk < p.n_chunks;
+    // workgroup -> slot of its XCD slice (my_chunk) -> chunk: every slice is walked longest chunk first (chunk_order, built
+    // at upload from the pack kernel's cost estimate), so the workgroups that finish a launch are short ones
+    const uint32_t chunk_slot = my_chunk();
+    const bool live = chunk_slot < p.n_chunks;
+    const uint32_t chunk = live ? p.chunk_order[chunk_slot] : 0u;
     const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
     SPL_PHASE_DECL;
     SPL_PHASE(0);
@@ -1173,7 +1176,7 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
 //   perm[] maps a packed slot back to the read's place in the chunk.
 __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_reads, const int32_t *pos, const uint16_t *flag,
                                                                    const uint32_t *cig_off, const uint32_t *cigar, int32_t *p_pos,
-                                                                   uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm)
+                                                                   uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm, uint32_t *chunk_cost)
 {
     constexpr int NW = SPL_BLOCK / 64;
     constexpr int NC = 4; // SPL_RC_*
@@ -1219,6 +1222,9 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_rea
         for (int it = 0; it < SPL_RPT; ++it)
             for (int wv = 0; wv < NW; ++wv) total[c] += cnt[c][it][wv];
     }
+    // what the chunk will cost the range kernel, roughly (instructions per read of each class): the host orders the chunks of
+    // every XCD slice longest first, so that the last workgroups of a launch are the short ones
+    if (tid == 0) chunk_cost[blockIdx.x] = 2u * total[SPL_RC_SIMPLE] + 5u * total[SPL_RC_MNM] + 6u * total[SPL_RC_NARROW] + 14u * total[SPL_RC_WIDE];
 #pragma unroll
     for (int it = 0; it < SPL_RPT; ++it) {
         if (cls[it] == NC) continue;
@@ -1605,11 +1611,11 @@ extern "C" int spl_dev_launch_literal(const spl_count_params *p, const spl_queue
 }
 
 extern "C" int spl_dev_launch_pack(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar,
-                                   int32_t *p_pos, uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm, void *stream)
+                                   int32_t *p_pos, uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm, uint32_t *chunk_cost, void *stream)
 {
     if (n_reads <= 0) return 0;
     hipLaunchKernelGGL(spl_pack_reads_kernel, dim3((uint32_t)((n_reads + SPL_CHUNK - 1) / SPL_CHUNK)), dim3(SPL_BLOCK), 0, (hipStream_t)stream,
-                       n_reads, pos, flag, cig_off, cigar, p_pos, p_fn, p_ops3, perm);
+                       n_reads, pos, flag, cig_off, cigar, p_pos, p_fn, p_ops3, perm, chunk_cost);
     return (int)hipGetLastError();
 }
 
