@@ -76,6 +76,7 @@ struct RefReads {
     std::vector<uint32_t> cigar;
     int64_t max_end = 0;
     RefReads() { cig_off.push_back(0); }
+    void swap_into(RefReads &other) { pos.swap(other.pos); flag.swap(other.flag); cig_off.swap(other.cig_off); cigar.swap(other.cigar); }
 };
 
 // Inflate one BGZF block into dst (exactly b.isize bytes) and verify its CRC32.
@@ -156,12 +157,51 @@ const uint8_t *find_cg_tag(const uint8_t *aux, const uint8_t *end, uint32_t *n_o
 
 } // namespace
 
+// Large buffers ask for transparent huge pages (the usual system setting is "madvise"): a decode touches about a gigabyte
+// of fresh memory, and 4 KiB at a time that is a quarter of a million page faults contending for one address-space lock.
+static void *big_alloc(size_t bytes)
+{
+    const size_t huge = 2u << 20;
+    if (bytes < 4 * huge) return malloc(bytes ? bytes : 1);
+    void *p = nullptr;
+    if (posix_memalign(&p, huge, (bytes + huge - 1) / huge * huge) != 0) return nullptr;
+    (void)madvise(p, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
+    return p;
+}
+
+// What spl_bam_reads hands out: one exact-size allocation per array and reference, filled once after the last segment.
+struct RefFinal {
+    int64_t n = 0, n_cigar = 0, max_end = 0;
+    int32_t *pos = nullptr;
+    uint16_t *flag = nullptr;
+    uint32_t *cig_off = nullptr; // n + 1
+    uint32_t *cigar = nullptr;
+    RefFinal() = default;
+    RefFinal(const RefFinal &) = delete;
+    RefFinal &operator=(const RefFinal &) = delete;
+    ~RefFinal() { free(pos); free(flag); free(cig_off); free(cigar); }
+};
+
+struct PendingPart;
+
 struct spl_bam {
     std::vector<std::string> ref_names;
     std::vector<int64_t> ref_lengths;
-    std::vector<RefReads> refs;
+    std::vector<RefFinal> refs_storage; // (never resized after the header: RefFinal is not copyable)
+    RefFinal *refs = nullptr;
+    int n_refs = 0;
+    std::vector<PendingPart> *pending = nullptr; // the parse threads' output in file order, until assemble()
     int64_t n_records = 0;
+    ~spl_bam();
 };
+
+struct PendingPart {
+    int32_t tid = 0;
+    RefReads reads;
+    int64_t read_at = 0, op_at = 0; // where the part goes inside its reference
+};
+
+spl_bam::~spl_bam() { delete pending; }
 
 namespace {
 
@@ -188,6 +228,11 @@ const uint8_t *parse_records(const uint8_t *p, const uint8_t *end, const uint8_t
         const uint32_t bs = le32(p);
         if (bs < 32) { err = "corrupt record (block_size < 32)"; fatal = true; break; }
         if ((size_t)(end - p) < 4 + (size_t)bs) break;
+        // the walk is a pointer chase (the next record starts where this one ends); records of one library are about the
+        // same size, so the headers a few records ahead are probably where this record's size says
+        __builtin_prefetch(p + 3 * (4 + (size_t)bs));
+        __builtin_prefetch(p + 4 * (4 + (size_t)bs));
+        __builtin_prefetch(p + 4 * (4 + (size_t)bs) + 64);
         const uint8_t *r = p + 4;
         const int32_t tid = le32s(r);
         const int32_t pos0 = le32s(r + 4);
@@ -271,20 +316,70 @@ const uint8_t *find_record_start(const uint8_t *from, const uint8_t *end, int n_
     return end;
 }
 
+// The parse threads' parts are only queued while the file is being read (no copying, no growing destination on the
+// critical path); assemble() sizes every reference once and copies all parts in parallel.
 void merge_parts(spl_bam *bam, std::vector<Sink::Part> &parts)
 {
     for (Sink::Part &pt : parts) {
-        RefReads &dst = bam->refs[(size_t)pt.tid];
-        RefReads &src = pt.reads;
-        const uint32_t base = (uint32_t)dst.cigar.size();
-        dst.pos.insert(dst.pos.end(), src.pos.begin(), src.pos.end());
-        dst.flag.insert(dst.flag.end(), src.flag.begin(), src.flag.end());
-        dst.cigar.insert(dst.cigar.end(), src.cigar.begin(), src.cigar.end());
-        const size_t n0 = dst.cig_off.size();
-        dst.cig_off.resize(n0 + src.cig_off.size() - 1);
-        for (size_t k = 1; k < src.cig_off.size(); ++k) dst.cig_off[n0 + k - 1] = base + src.cig_off[k];
-        if (src.max_end > dst.max_end) dst.max_end = src.max_end;
+        bam->pending->emplace_back();
+        bam->pending->back().tid = pt.tid;
+        bam->pending->back().reads = std::move(pt.reads);
     }
+}
+
+bool assemble(spl_bam *bam, int n_threads, std::string &err)
+{
+    std::vector<PendingPart> &parts = *bam->pending;
+    const int n_ref = bam->n_refs;
+    std::vector<int64_t> n_reads((size_t)n_ref, 0), n_ops((size_t)n_ref, 0);
+    for (PendingPart &pt : parts) {
+        pt.read_at = n_reads[(size_t)pt.tid];
+        pt.op_at = n_ops[(size_t)pt.tid];
+        n_reads[(size_t)pt.tid] += (int64_t)pt.reads.pos.size();
+        n_ops[(size_t)pt.tid] += (int64_t)pt.reads.cigar.size();
+        RefFinal &dst = bam->refs[pt.tid];
+        if (pt.reads.max_end > dst.max_end) dst.max_end = pt.reads.max_end;
+    }
+    for (int t = 0; t < n_ref; ++t) {
+        RefFinal &dst = bam->refs[t];
+        dst.n = n_reads[(size_t)t];
+        dst.n_cigar = n_ops[(size_t)t];
+        if (dst.n_cigar > 0xfffffff0LL) { err = "more than 2^32 CIGAR operations on one reference"; return false; }
+        dst.pos = (int32_t *)big_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(dst.n, 1));
+        dst.flag = (uint16_t *)big_alloc(sizeof(uint16_t) * (size_t)std::max<int64_t>(dst.n, 1));
+        dst.cig_off = (uint32_t *)big_alloc(sizeof(uint32_t) * (size_t)(dst.n + 1));
+        dst.cigar = (uint32_t *)big_alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(dst.n_cigar, 1));
+        if (!dst.pos || !dst.flag || !dst.cig_off || !dst.cigar) { err = "out of host memory"; return false; }
+        dst.cig_off[0] = 0;
+    }
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= parts.size()) break;
+            PendingPart &pt = parts[i];
+            RefFinal &dst = bam->refs[pt.tid];
+            const RefReads &src = pt.reads;
+            const size_t n = src.pos.size();
+            if (n) {
+                memcpy(dst.pos + pt.read_at, src.pos.data(), sizeof(int32_t) * n);
+                memcpy(dst.flag + pt.read_at, src.flag.data(), sizeof(uint16_t) * n);
+                const uint32_t base = (uint32_t)pt.op_at;
+                uint32_t *off = dst.cig_off + pt.read_at; // entry k + 1 = end of read k
+                for (size_t k = 1; k <= n; ++k) off[k] = base + src.cig_off[k];
+                if (!src.cigar.empty()) memcpy(dst.cigar + pt.op_at, src.cigar.data(), sizeof(uint32_t) * src.cigar.size());
+            }
+            RefReads().swap_into(pt.reads); // give the part's memory back as soon as it is copied
+        }
+    };
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, parts.size()));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    parts.clear();
+    parts.shrink_to_fit();
+    return true;
 }
 
 // Parse the records of one inflated segment on several threads.  Thread t looks for the first record boundary at or
@@ -293,9 +388,9 @@ void merge_parts(spl_bam *bam, std::vector<Sink::Part> &parts)
 // true boundary at the segment start, every accepted start is then a true boundary.  Otherwise: one thread.
 const uint8_t *parse_segment_parallel(spl_bam *bam, const uint8_t *p, const uint8_t *end, int n_threads, std::string &err, bool &fatal)
 {
-    const int n_ref = (int)bam->refs.size();
+    const int n_ref = bam->n_refs;
     const size_t bytes = (size_t)(end - p);
-    int T = n_threads > 32 ? 32 : n_threads;
+    int T = n_threads > 16 ? 16 : n_threads; // the walk is latency-bound and short: more threads cost more to start than they save
     if (bytes < (size_t)(8u << 20) || T < 2) T = 1;
     std::vector<std::vector<Sink::Part>> parts((size_t)T);
     std::vector<const uint8_t *> start((size_t)T + 1), reached((size_t)T);
@@ -304,7 +399,10 @@ const uint8_t *parse_segment_parallel(spl_bam *bam, const uint8_t *p, const uint
     std::vector<char> fat((size_t)T, 0);
     start[0] = p;
     start[(size_t)T] = end;
+    std::vector<double> busy((size_t)T, 0.0);
+    auto clock_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto work = [&](int t) {
+        const double w0 = clock_now();
         const uint8_t *nominal_start = p + bytes / (size_t)T * (size_t)t;
         const uint8_t *nominal_end = (t + 1 == T) ? nullptr : p + bytes / (size_t)T * (size_t)(t + 1);
         if (t > 0) start[(size_t)t] = find_record_start(nominal_start, end, n_ref);
@@ -312,7 +410,9 @@ const uint8_t *parse_segment_parallel(spl_bam *bam, const uint8_t *p, const uint
         bool f = false;
         reached[(size_t)t] = parse_records(start[(size_t)t], end, nominal_end, n_ref, sink, nrec[(size_t)t], errs[(size_t)t], f);
         fat[(size_t)t] = f ? 1 : 0;
+        busy[(size_t)t] = clock_now() - w0;
     };
+    const double seg_t0 = clock_now();
     if (T > 1) {
         std::vector<std::thread> pool;
         for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
@@ -320,6 +420,12 @@ const uint8_t *parse_segment_parallel(spl_bam *bam, const uint8_t *p, const uint
         for (auto &th : pool) th.join();
     } else {
         work(0);
+    }
+    if (getenv("SPL_BAM_TIMING_DETAIL")) {
+        double mx = 0, sum = 0;
+        for (double b : busy) { mx = std::max(mx, b); sum += b; }
+        fprintf(stderr, "[parse segment] %zu MB, %d threads: wall %.4f s, slowest thread %.4f s, mean thread %.4f s\n", bytes >> 20, T,
+                clock_now() - seg_t0, mx, sum / T);
     }
     bool consistent = true;
     for (int t = 0; t + 1 < T; ++t) consistent &= (reached[(size_t)t] == start[(size_t)t + 1]) && !fat[(size_t)t];
@@ -370,7 +476,10 @@ struct Parser {
             }
             bam->ref_names.swap(names);
             bam->ref_lengths.swap(lens);
-            bam->refs.resize((size_t)n_ref);
+            bam->refs_storage = std::vector<RefFinal>((size_t)n_ref);
+            bam->refs = bam->refs_storage.data();
+            bam->n_refs = n_ref;
+            if (!bam->pending) bam->pending = new std::vector<PendingPart>();
             header_done = true;
             p = q;
         }
@@ -442,10 +551,25 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
 
     // 2. segments of blocks, double-buffered: while the records of segment k are being extracted (parse threads), the
     //    blocks of segment k+1 are already being inflated (inflate threads).
-    const size_t SEG_BLOCKS = 2048; // <= 128 MiB uncompressed
+    const size_t SEG_BLOCKS = 8192; // <= 512 MiB uncompressed (fewer, larger segments: thread start-up and stragglers are per segment)
     const size_t HEAD = 4u << 20;   // room in front of a segment for the incomplete record carried over from the previous one
     const size_t n_seg = (blocks.size() + SEG_BLOCKS - 1) / SEG_BLOCKS;
-    std::vector<uint8_t> bufs[2];
+    // two inflate buffers of the size of the largest segment: never zero-filled, huge pages where the system gives them
+    size_t seg_max = 0;
+    for (size_t sg = 0; sg < n_seg; ++sg) {
+        size_t bytes_in = 0;
+        for (size_t i = sg * SEG_BLOCKS; i < std::min(blocks.size(), (sg + 1) * SEG_BLOCKS); ++i) bytes_in += blocks[i].isize;
+        seg_max = std::max(seg_max, bytes_in);
+    }
+    struct RawBuf {
+        uint8_t *p = nullptr;
+        ~RawBuf() { free(p); }
+        uint8_t *data() { return p; }
+    } bufs[2];
+    for (int k = 0; k < 2; ++k) {
+        bufs[k].p = (uint8_t *)big_alloc(HEAD + seg_max + 64);
+        if (!bufs[k].p) { delete bam; munmap(map, fsize); return spl_set_error(SPL_ERR_NOMEM, "out of host memory for the inflate buffers"); }
+    }
     size_t seg_bytes[2] = {0, 0};
     std::atomic<bool> bad(false);
     const bool timing = getenv("SPL_BAM_TIMING") != nullptr;
@@ -456,8 +580,7 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
         std::vector<size_t> uoff(b1 - b0 + 1);
         uoff[0] = HEAD;
         for (size_t i = b0; i < b1; ++i) uoff[i - b0 + 1] = uoff[i - b0] + blocks[i].isize;
-        std::vector<uint8_t> &buf = bufs[seg & 1];
-        if (buf.size() < uoff[b1 - b0]) buf.resize(uoff[b1 - b0]);
+        RawBuf &buf = bufs[seg & 1];
         seg_bytes[seg & 1] = uoff[b1 - b0] - HEAD;
         std::atomic<size_t> next(b0);
         auto work = [&]() {
@@ -487,7 +610,7 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
         std::thread ahead;
         if (seg + 1 < n_seg) ahead = std::thread(inflate_segment, seg + 1);
         const double t0 = now();
-        std::vector<uint8_t> &buf = bufs[seg & 1];
+        RawBuf &buf = bufs[seg & 1];
         uint8_t *begin = buf.data() + HEAD;
         const size_t total = seg_bytes[seg & 1];
         std::vector<uint8_t> joined;
@@ -516,6 +639,9 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
     if (timing) fprintf(stderr, "[spl_bam_open] %zu blocks, %d threads: parse %.3f s, waiting for inflate %.3f s\n", blocks.size(), n_threads, t_parse, t_wait);
     if (fail.empty() && !parser.header_done) fail = "no BAM header found";
     if (fail.empty() && carry != 0) fail = "file ends inside a record (truncated)";
+    const double t_asm0 = now();
+    if (fail.empty() && !assemble(bam, n_threads, fail) && fail.empty()) fail = "assembling the per-reference arrays failed";
+    if (timing) fprintf(stderr, "[spl_bam_open] per-reference arrays assembled in %.3f s\n", now() - t_asm0);
     if (!fail.empty()) {
         delete bam;
         return spl_set_error(SPL_ERR_FORMAT, "%s: %s", path, fail.c_str());
@@ -525,7 +651,7 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
 }
 
 extern "C" void spl_bam_close(spl_bam *bam) { delete bam; }
-extern "C" int spl_bam_n_ref(const spl_bam *bam) { return bam ? (int)bam->refs.size() : 0; }
+extern "C" int spl_bam_n_ref(const spl_bam *bam) { return bam ? bam->n_refs : 0; }
 extern "C" const char *spl_bam_ref_name(const spl_bam *bam, int tid)
 {
     if (!bam || tid < 0 || (size_t)tid >= bam->ref_names.size()) return nullptr;
@@ -541,13 +667,13 @@ extern "C" int64_t spl_bam_n_records(const spl_bam *bam) { return bam ? bam->n_r
 extern "C" int spl_bam_reads(const spl_bam *bam, int tid, spl_reads *out, int64_t *max_end_out)
 {
     if (!bam || !out) return spl_set_error(SPL_ERR_ARG, "spl_bam_reads: null argument");
-    if (tid < 0 || (size_t)tid >= bam->refs.size()) return spl_set_error(SPL_ERR_ARG, "tid %d out of range", tid);
-    const RefReads &rr = bam->refs[(size_t)tid];
-    out->n_reads = (int64_t)rr.pos.size();
-    out->pos = rr.pos.data();
-    out->flag = rr.flag.data();
-    out->cig_off = rr.cig_off.data();
-    out->cigar = rr.cigar.data();
+    if (tid < 0 || tid >= bam->n_refs) return spl_set_error(SPL_ERR_ARG, "tid %d out of range", tid);
+    const RefFinal &rr = bam->refs[tid];
+    out->n_reads = rr.n;
+    out->pos = rr.pos;
+    out->flag = rr.flag;
+    out->cig_off = rr.cig_off;
+    out->cigar = rr.cigar;
     if (max_end_out) *max_end_out = rr.max_end;
     return SPL_OK;
 }
