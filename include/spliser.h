@@ -205,6 +205,17 @@ int spl_junctions_get(const spl_ctx *ctx, int32_t *left, int32_t *right, uint8_t
 int spl_gene_search(const int64_t *left, const int64_t *right, const uint8_t *gene_strand, int64_t n_genes,
                     const int64_t *q_pos, const uint8_t *q_strand, int64_t n_queries, int is_stranded, int32_t *out);
 
+/* ---- output (outputBedFile, SpliSER_v0_1_8.py:641-664) -------------------------------------------------------
+ * Appends the rows of one chromosome to a .SpliSER.tsv file (the caller writes the header line): 12 tab-separated
+ * columns, SSE as "%.3f", the two cryptic columns as an integer and "%.5f" or "NA NA" when cryptic == 0, Partners as
+ * Python's str(dict) "{pos: count, ...}" in partner order, Competitors as str(list).  Strand and gene texts come as one
+ * blob each with n_sites + 1 offsets.  No GPU involved. */
+int spl_tsv_append(const char *path, const char *chrom, int64_t n_sites, const int64_t *pos, const char *strand_blob,
+                   const uint32_t *strand_off, const char *gene_blob, const uint32_t *gene_off, const double *sse,
+                   const int64_t *alpha, const uint32_t *beta1, const int64_t *beta2_simple, int cryptic,
+                   const int64_t *beta2_cryptic, const double *beta2_weighted, const uint32_t *part_off,
+                   const int64_t *part_pos, const int64_t *edge_cnt, const uint32_t *comp_off, const int64_t *comp_pos);
+
 #ifdef __cplusplus
 }
 #endif

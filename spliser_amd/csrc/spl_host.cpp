@@ -1,5 +1,6 @@
 // Host-side helpers of the C ABI that need no GPU (include/spliser.h).
 #include <cstdint>
+#include <cstring>
 
 #include "../../include/spliser.h"
 #include "spl_error.h"
@@ -45,4 +46,60 @@ extern "C" int spl_gene_search(const int64_t *left, const int64_t *right, const 
         out[q] = found ? (int32_t)idx : -1;
     }
     return SPL_OK;
+}
+
+// ---- .SpliSER.tsv rows (outputBedFile, SpliSER_v0_1_8.py:641-664) -----------------------------------------------
+// One chromosome's rows appended to an open file: the same bytes spliser_amd/tsv.py formats -- "{0:.3f}" / "{0:.5f}" are
+// correctly rounded decimal conversions in CPython and in glibc's printf alike, str(dict) / str(list) of ints are
+// "{a: b, c: d}" / "[a, b]".  Strings come as one blob + offsets.
+#include <cinttypes>
+#include <cstdio>
+#include <string>
+
+extern "C" int spl_tsv_append(const char *path, const char *chrom, int64_t n_sites, const int64_t *pos, const char *strand_blob,
+                              const uint32_t *strand_off, const char *gene_blob, const uint32_t *gene_off, const double *sse,
+                              const int64_t *alpha, const uint32_t *beta1, const int64_t *beta2_simple, int cryptic,
+                              const int64_t *beta2_cryptic, const double *beta2_weighted, const uint32_t *part_off,
+                              const int64_t *part_pos, const int64_t *edge_cnt, const uint32_t *comp_off, const int64_t *comp_pos)
+{
+    if (!path || !chrom || n_sites < 0) return spl_set_error(SPL_ERR_ARG, "spl_tsv_append: bad argument");
+    if (n_sites && (!pos || !strand_blob || !strand_off || !gene_blob || !gene_off || !sse || !alpha || !beta1 || !beta2_simple ||
+                    !part_off || !comp_off || (cryptic && (!beta2_cryptic || !beta2_weighted))))
+        return spl_set_error(SPL_ERR_ARG, "spl_tsv_append: null array");
+    FILE *f = fopen(path, "ab");
+    if (!f) return spl_set_error(SPL_ERR_IO, "cannot open %s for appending", path);
+    std::string out;
+    out.reserve(1u << 20);
+    char num[64];
+    const size_t chrom_len = strlen(chrom);
+    bool ok = true;
+    for (int64_t i = 0; i < n_sites && ok; ++i) {
+        out.append(chrom, chrom_len);
+        out.push_back('\t');
+        out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64, pos[i]));
+        out.push_back('\t');
+        out.append(strand_blob + strand_off[i], strand_off[i + 1] - strand_off[i]);
+        out.push_back('\t');
+        out.append(gene_blob + gene_off[i], gene_off[i + 1] - gene_off[i]);
+        out.push_back('\t');
+        out.append(num, (size_t)snprintf(num, sizeof num, "%.3f", sse[i]));
+        out.append(num, (size_t)snprintf(num, sizeof num, "\t%" PRId64 "\t%u\t%" PRId64 "\t", alpha[i], beta1[i], beta2_simple[i]));
+        if (cryptic) out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64 "\t%.5f", beta2_cryptic[i], beta2_weighted[i]));
+        else out.append("NA\tNA");
+        out.append("\t{");
+        for (uint32_t e = part_off[i]; e < part_off[i + 1]; ++e) {
+            if (e != part_off[i]) out.append(", ");
+            out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64 ": %" PRId64, part_pos[e], edge_cnt[e]));
+        }
+        out.append("}\t[");
+        for (uint32_t e = comp_off[i]; e < comp_off[i + 1]; ++e) {
+            if (e != comp_off[i]) out.append(", ");
+            out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64, comp_pos[e]));
+        }
+        out.append("]\n");
+        if (out.size() > (1u << 20) - 4096) { ok = fwrite(out.data(), 1, out.size(), f) == out.size(); out.clear(); }
+    }
+    if (ok && !out.empty()) ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    if (fclose(f) != 0) ok = false;
+    return ok ? SPL_OK : spl_set_error(SPL_ERR_IO, "write error on %s", path);
 }

@@ -50,7 +50,7 @@ EXPORTS = [
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write",
-    "spl_gene_search", "spl_junctions", "spl_junctions_get",
+    "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append",
 ]
 
 _lib = None
@@ -325,6 +325,35 @@ def gene_search(g_left, g_right, g_strand, q_pos, q_strand, is_stranded):
     _check(lib().spl_gene_search(_ptr(g_left), _ptr(g_right), _ptr(g_strand), ctypes.c_int64(g_left.shape[0]), _ptr(q_pos),
                                  _ptr(q_strand), ctypes.c_int64(q_pos.shape[0]), ctypes.c_int(1 if is_stranded else 0), _ptr(out)))
     return out
+
+
+def _blob(texts):
+    """list of str -> (bytes, uint32 offsets[n + 1])."""
+    enc = [t.encode("utf-8") for t in texts]
+    off = np.zeros(len(enc) + 1, np.uint32)
+    if enc:
+        np.cumsum(np.fromiter((len(e) for e in enc), dtype=np.int64, count=len(enc)), out=off[1:])
+    return b"".join(enc), off
+
+
+def tsv_append(path, arr, res, cryptic):
+    """Rows of one chromosome appended to ``path`` by ``spl_tsv_append`` (same bytes as tsv.format_chrom)."""
+    strand_blob, strand_off = _blob(arr.strand_text)
+    gene_blob, gene_off = _blob(arr.genes)
+    c64 = lambda a: np.ascontiguousarray(a, np.int64)   # noqa: E731
+    pos, alpha = c64(arr.pos), c64(arr.alpha)
+    beta1 = np.ascontiguousarray(res["beta1"], np.uint32)
+    b2s = c64(res["beta2_simple"])
+    sse = np.ascontiguousarray(res["sse"], np.float64)
+    b2c = c64(res["beta2_cryptic"]) if cryptic else None
+    b2w = np.ascontiguousarray(res["beta2_weighted"], np.float64) if cryptic else None
+    part_off = np.ascontiguousarray(arr.part_off, np.uint32)
+    comp_off = np.ascontiguousarray(arr.comp_off, np.uint32)
+    part_pos, edge_cnt, comp_pos = c64(arr.part_pos), c64(arr.edge_cnt), c64(arr.comp_pos)
+    _check(lib().spl_tsv_append(os.fsencode(path), arr.chrom.encode("utf-8"), ctypes.c_int64(arr.n), _ptr(pos), strand_blob,
+                                _ptr(strand_off), gene_blob, _ptr(gene_off), _ptr(sse), _ptr(alpha), _ptr(beta1), _ptr(b2s),
+                                ctypes.c_int(1 if cryptic else 0), _ptr(b2c), _ptr(b2w), _ptr(part_off), _ptr(part_pos),
+                                _ptr(edge_cnt), _ptr(comp_off), _ptr(comp_pos)))
 
 
 def write_bam(path, ref_names, ref_lengths, read_sets, level=1, threads=0):

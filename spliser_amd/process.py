@@ -115,13 +115,15 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
 
 
 def write_tsv(output_path, table, results, is_beta2_cryptic):
-    """outputBedFile (SpliSER_v0_1_8.py:641-664)."""
-    with open(output_path + ".SpliSER.tsv", "w") as fh:
+    """outputBedFile (SpliSER_v0_1_8.py:641-664); the rows are formatted by the native library (tsv.format_chrom is the
+    Python statement of the same format and what the CPU tests compare it with)."""
+    path = output_path + ".SpliSER.tsv"
+    with open(path, "w") as fh:
         fh.write(tsv.HEADER)
-        for chrom in table.chrom_index:
-            if chrom in results:
-                arr, res = results[chrom]
-                fh.writelines(tsv.format_chrom(arr, res, is_beta2_cryptic))
+    for chrom in table.chrom_index:
+        if chrom in results:
+            arr, res = results[chrom]
+            native.tsv_append(path, arr, res, is_beta2_cryptic)
 
 
 def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0, annotationFile=None, aType="gene",
