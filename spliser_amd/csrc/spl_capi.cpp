@@ -554,8 +554,9 @@ static int upload_segments(spl_ctx *c, int n_seg, const spl_reads *segs, const i
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     const size_t o_pos = take(4 * R), o_flag = take(2 * R), o_off = take(4 * (R + 1)), o_cig = take(4 * G);
-    const size_t o_fn = take(4 * R), o_ops3 = take(12 * R), o_ppos = take(4 * R), o_perm = take(2 * R);
     const size_t n_chunks = (size_t)((R + SPL_CHUNK - 1) / SPL_CHUNK);
+    const size_t Rp = n_chunks * SPL_CHUNK; // the packed arrays cover whole chunks (the pack kernel pads the last one with inert reads)
+    const size_t o_fn = take(4 * Rp), o_ops3 = take(12 * Rp), o_ppos = take(4 * Rp), o_perm = take(2 * Rp);
     const size_t o_order = take(4 * (n_chunks ? n_chunks : 1));
     // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks
     const size_t shard_cap = ((n_chunks + 7) / 8) * SPL_CHUNK;

@@ -538,10 +538,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
 
     // Pipeline over the chunk's reads: while read `it` is worked on the packed words of the next read are in flight
     // (SPL_BUCKET_AHEAD: also its bucket entries, at the price of 25 more registers -- measured slower, occupancy 4).
-    const int64_t last_read = p.n_reads - 1;
     auto fetch_read = [&](int it, int32_t &f_pos, uint32_t &f_fn, uint32_t (&f_op)[SPL_INLINE_OPS]) {
-        const int64_t i = chunk_base + (int64_t)it * SPL_BLOCK + tid;
-        const int64_t ii = live ? (i <= last_read ? i : last_read) : 0;
+        const int64_t ii = live ? chunk_base + (int64_t)it * SPL_BLOCK + tid : 0; // (the packed arrays are padded to whole chunks)
         f_pos = p.r_pos[ii];                                                     // ---- trip 1: 20 bytes per read
         f_fn = p.r_fn[ii];
 #pragma unroll
@@ -584,9 +582,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             // Straight-line and branch-free up to the commits: out-of-range lanes re-read the last read and are masked
             // at the end, so all loads of a trip issue back to back.  Control flow is wave-uniform around every
             // commit_key (all 64 lanes reach it).
-            const int64_t i = chunk_base + (int64_t)it * SPL_BLOCK + tid;
-            bool alive = i <= last_read;
-            const int64_t ii = alive ? i : last_read;
+            const int64_t ii = chunk_base + (int64_t)it * SPL_BLOCK + tid;
+            bool alive = true; // every slot of a chunk holds a read (the pack kernel pads the last chunk with inert ones)
             const int32_t pos = cu_pos;
             const uint32_t fn = cu_fn;
             uint32_t op[SPL_INLINE_OPS];
@@ -609,7 +606,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 if (it + 1 < SPL_RPT) fetch_read(it + 1, cu_pos, cu_fn, cu_op); // next read's words
             }
             const uint32_t flag = fn & 0xffffu;
-            const uint32_t cls = fn >> 30; // lanes past the end repeat the last read of the chunk: same class, masked by `alive`
+            const uint32_t cls = fn >> 30;
             // ---- a wave of simple reads (one aligned op, mapped, in range: the pack kernel checked all that and put them
             //      first in the chunk) takes the short road: two boundaries, one range, nothing else can happen
             if (__all(cls == SPL_RC_SIMPLE)) {
@@ -1189,8 +1186,10 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_rea
 #pragma unroll
     for (int it = 0; it < SPL_RPT; ++it) {
         const int64_t i = cb + (int64_t)it * SPL_BLOCK + tid;
-        cls[it] = NC;
-        r_pos[it] = 0; r_fn[it] = 0; w[it][0] = w[it][1] = w[it][2] = 0xfu;
+        // a slot past the end of the read set becomes an inert read of the first class (one aligned op of length 0: an empty
+        // range, never queued), so that the range kernel needs no notion of "past the end" at all
+        cls[it] = (int)SPL_RC_SIMPLE;
+        r_pos[it] = 1; r_fn[it] = (1u << 16) | (SPL_RC_SIMPLE << 30); w[it][0] = 0u; w[it][1] = w[it][2] = 0xfu;
         if (i < n_reads) {
             const uint32_t o0 = cig_off[i], n = cig_off[i + 1] - o0;
             r_pos[it] = pos[i];
@@ -1227,7 +1226,6 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_rea
     if (tid == 0) chunk_cost[blockIdx.x] = 2u * total[SPL_RC_SIMPLE] + 5u * total[SPL_RC_MNM] + 6u * total[SPL_RC_NARROW] + 14u * total[SPL_RC_WIDE];
 #pragma unroll
     for (int it = 0; it < SPL_RPT; ++it) {
-        if (cls[it] == NC) continue;
         const int c = cls[it];
         uint32_t before = 0; // the runs of the classes before mine, then reads of my class in earlier (it, wave) groups
         for (int c2 = 0; c2 < NC; ++c2) before += (c2 < c) ? total[c2] : 0u;
