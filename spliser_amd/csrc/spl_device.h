@@ -29,7 +29,9 @@
 #define SPL_INLINE_OPS 3                 // CIGAR ops per read resolved in the straight-line part (M N M = 3)
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
 #define SPL_LITERAL_WAVES 8192           // one-wave workgroups of the literal kernel (grid-stride over the queue)
-#define SPL_SCAN_BLOCK 1024              // distinct positions per workgroup in the difference-array scan
+#ifndef SPL_SCAN_BLOCK
+#define SPL_SCAN_BLOCK 256               // distinct positions per workgroup of the scan kernels (a multiple of 256; 1024 left the chip half empty)
+#endif
 
 // Coordinates (read end, site position) must stay <= SPL_COORD_MAX so that t+1, cur and x - dbase never wrap int32.
 #define SPL_COORD_MAX 2147483581

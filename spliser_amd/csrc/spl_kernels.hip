@@ -1266,6 +1266,7 @@ __global__ __launch_bounds__(256) void spl_scan_apply_kernel(const spl_scan_para
     __shared__ int32_t wave_tot[4][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t base = blockIdx.x * SPL_SCAN_BLOCK;
+    constexpr int Q = SPL_SCAN_BLOCK / 256; // consecutive distinct positions per thread
     int32_t run[4] = {0, 0, 0, 0};
     // offset of this block = sum of the sums of all blocks before it
     for (int a = 0; a < p.n_arrays; ++a) {
@@ -1274,13 +1275,13 @@ __global__ __launch_bounds__(256) void spl_scan_apply_kernel(const spl_scan_para
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
         if (lane == 0) red[a][wave] = acc;
     }
-    // each thread owns 4 consecutive distinct positions
-    int32_t v[4][4];
-    const int32_t d0 = base + tid * 4;
+    // each thread owns Q consecutive distinct positions
+    int32_t v[4][Q];
+    const int32_t d0 = base + tid * Q;
     for (int a = 0; a < p.n_arrays; ++a) {
         const int32_t *d = p.diff + (int64_t)a * p.diff_stride;
         int32_t s = 0;
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < Q; ++q) {
             const int32_t r = d0 + q;
             s += (r < p.n_dpos) ? d[r] : 0;
             v[a][q] = s; // inclusive within the thread
@@ -1299,7 +1300,7 @@ __global__ __launch_bounds__(256) void spl_scan_apply_kernel(const spl_scan_para
         for (int w = 0; w < wave; ++w) off += wave_tot[a][w];
         run[a] += off;
     }
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < Q; ++q) {
         const int32_t d = d0 + q;
         if (d >= p.n_dpos) break;
         for (int32_t r = p.dpos_first_row[d]; r < p.dpos_first_row[d + 1]; ++r) { // the rows at this position
