@@ -13,6 +13,7 @@
                                          // line serialise the atomics of all XCDs: measured 11 ns per atomic, chip-wide)
 // Packed read word r_fn: flag (16 bits) | op count saturating at SPL_NOPS_SAT (14 bits) | class (2 bits), the class being
 // what the pack kernel partitions a chunk by: the range kernel branches on it wave-uniformly.
+#define SPL_PACK_SCAN_OPS 8              // CIGARs up to this many ops are packed without their non-consuming ops
 #define SPL_NOPS_SAT 0x3fffu
 #define SPL_RC_SIMPLE 0u                 // one aligned op, mapped, in range: every unspliced short read
 #define SPL_RC_MNM 1u                    // aligned, N, aligned; mapped, in range: every once-spliced short read

@@ -1191,11 +1191,24 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_rea
         cls[it] = (int)SPL_RC_SIMPLE;
         r_pos[it] = 1; r_fn[it] = (1u << 16) | (SPL_RC_SIMPLE << 30); w[it][0] = 0u; w[it][1] = w[it][2] = 0xfu;
         if (i < n_reads) {
-            const uint32_t o0 = cig_off[i], n = cig_off[i + 1] - o0;
+            const uint32_t o0 = cig_off[i], n_all = cig_off[i + 1] - o0;
             r_pos[it] = pos[i];
-            if (n <= 3u) { for (uint32_t k = 0; k < n; ++k) w[it][k] = cigar[o0 + k]; }
-            else { w[it][0] = cigar[o0]; w[it][1] = cigar[o0 + 1]; w[it][2] = o0 + 2u; }
             auto kind = [](uint32_t op) { return (SPL_KIND_TABLE >> (2u * (op & 15u))) & 3u; };
+            // Ops that do not consume the reference (S, H, I, P and undefined codes) change nothing for any path of checkBam
+            // (SpliSER_v0_1_8.py:457-464: no progress, no test): a short CIGAR is packed without them, so that a soft-clipped
+            // read is classified by what it aligns ("5S95M100N50M" is a once-spliced read).  Longer CIGARs stay as they are.
+            uint32_t n = n_all;
+            if (n_all <= (uint32_t)SPL_PACK_SCAN_OPS) {
+                uint32_t m = 0;
+                for (uint32_t k = 0; k < n_all; ++k) {
+                    const uint32_t op = cigar[o0 + k];
+                    if (kind(op) == 0u) continue;
+                    if (m < 3u) w[it][m] = op;
+                    ++m;
+                }
+                if (m <= 3u) n = m; // (the words beyond m keep their filler)
+            }
+            if (n > 3u) { w[it][0] = cigar[o0]; w[it][1] = cigar[o0 + 1]; w[it][2] = o0 + 2u; n = n_all; }
             const bool placed = !(flag[i] & 4u) && r_pos[it] >= 0;
             const int64_t room = (int64_t)SPL_COORD_MAX - (int64_t)r_pos[it];
             const bool simple = placed && n == 1u && kind(w[it][0]) == 1u && (int64_t)(w[it][0] >> 4) <= room;

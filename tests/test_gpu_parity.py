@@ -97,6 +97,53 @@ def test_gpu_matches_oracle_on_synthetic_genome(stranded, cryptic, kernel, ctx, 
     assert total > 10000
 
 
+def test_gpu_reads_with_non_consuming_ops(ctx, oracle_lib):
+    """Soft clips, hard clips, insertions and padding change nothing for checkBam; the pack kernel drops them from short
+    CIGARs (so that "5S95M100N50M" takes the once-spliced path).  Random decorations of spliced and unspliced reads on a
+    table with rivals, against the oracle, all kernels, all strand modes."""
+    rng = np.random.default_rng(17)
+    wl = synth.Workload("arabidopsis", scale=0.004, seed=31)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        import pathlib
+        table = _table_for(wl, pathlib.Path(tmp), True)
+    name = wl.genome.chrom_names[0]
+    arr, reads = table.chrom_arrays(name), wl.reads[0]
+    n = reads.n
+    cig_off = reads.cig_off.astype(np.int64)
+    new_ops, new_off = [], [0]
+    for i in range(n):
+        ops = reads.cigar[cig_off[i]:cig_off[i + 1]].tolist()
+        style = int(rng.integers(0, 8))
+        out = []
+        if style in (1, 3, 5):
+            out.append((int(rng.integers(1, 9)) << 4) | 5)          # leading hard clip
+        if style in (1, 2, 3):
+            out.append((int(rng.integers(1, 30)) << 4) | 4)         # leading soft clip
+        for k, op in enumerate(ops):
+            if style in (4, 5) and k == 0 and (op & 15) == 0 and (op >> 4) > 20:   # an insertion splits the first block
+                a = int(rng.integers(5, (op >> 4) - 5))
+                out += [(a << 4) | 0, (int(rng.integers(1, 4)) << 4) | 1, (((op >> 4) - a) << 4) | 0]
+            elif style == 6 and k == 0:
+                out += [op, (3 << 4) | 6]                            # padding after the first op
+            else:
+                out.append(op)
+        if style in (2, 3, 7):
+            out.append((int(rng.integers(1, 30)) << 4) | 4)         # trailing soft clip
+        new_ops += out
+        new_off.append(len(new_ops))
+    deco = native.ReadArrays(reads.pos, reads.flag, np.array(new_off, np.uint32), np.array(new_ops, np.uint32))
+    sites_c = native.SiteArrays.from_chrom(arr)
+    for stranded in (0, 1, 2):
+        want = oracle_lib.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos, deco.pos, deco.flag,
+                                    deco.cig_off, deco.cigar, stranded, 0)
+        for flags in KERNELS.values():
+            got = ctx.count(sites_c, deco, stranded, 0, flags)
+            for g, w in zip(got, want):
+                assert np.array_equal(g, w)
+    assert int(want[0].sum()) > 1000 and int(want[1].sum()) > 100
+
+
 def test_gpu_segment_upload_equals_packed_upload(ctx, tmp_path):
     """spl_reads_upload_segments (per-chromosome arrays shifted on the device) against the host-packed shard."""
     wl = synth.Workload("arabidopsis", scale=0.01, seed=77)
