@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--alt-fraction", type=float, default=None, help="(experiment) fraction of genes with alternative isoforms")
     ap.add_argument("--genes", type=int, default=None, help="(experiment) number of genes the reads are spread over: fewer genes = "
                     "deeper coverage per site")
+    ap.add_argument("--soft-clips", type=float, default=0.0, help="(experiment) fraction of reads that get leading / trailing "
+                    "soft clips, as a local aligner reports them")
     ap.add_argument("--cache", default=None, help="directory to cache the generated sample in (.npz); a cached "
                     "sample is loaded instead of regenerated (use under rocprofv3: no generator worker processes)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
@@ -73,6 +75,8 @@ def main():
                             workers=max(1, min(8, (os.cpu_count() or 1) // max(world, 1))))
         if cache:
             wl.save(cache)
+    if args.soft_clips > 0:
+        wl.reads = [synth.add_soft_clips(r, args.soft_clips, seed=100 + k) for k, r in enumerate(wl.reads)]
     tmp = tempfile.mkdtemp(prefix="spliser_bench_")
     bed = os.path.join(tmp, "junctions.bed")
     synth.write_bed(bed, wl.genome.chrom_names, wl.junctions)
@@ -194,7 +198,7 @@ def main():
         tfiles = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_traffic.json")))
         tpath = tfiles[-1] if tfiles else ""  # the newest committed measurement (file names sort by round and build)
         if (args.workload == "arabidopsis" and args.scale == 1.0 and args.kernel == "ranges" and not stranded
-                and args.alt_fraction is None and args.genes is None and os.path.exists(tpath)):
+                and args.alt_fraction is None and args.genes is None and args.soft_clips == 0 and os.path.exists(tpath)):
             with open(tpath) as fh:
                 traffic = json.load(fh)["hbm_bytes_per_launch"]
         k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")

@@ -390,6 +390,31 @@ class Workload(object):
         return prefix
 
 
+def add_soft_clips(reads, fraction, seed=0):
+    """A copy of ``reads`` in which ``fraction`` of the records carry a leading and / or trailing soft clip (the aligned part
+    and POS stay as they are: what a local aligner reports for reads with adapter or low-quality ends)."""
+    from .samio import ReadSet
+    rng = np.random.default_rng(seed)
+    n = reads.n
+    pick = rng.random(n) < fraction
+    side = rng.integers(1, 4, n)                      # 1 leading, 2 trailing, 3 both
+    lead = (pick & ((side & 1) != 0)).astype(np.int64)
+    trail = (pick & ((side & 2) != 0)).astype(np.int64)
+    off = reads.cig_off.astype(np.int64)
+    nops = np.diff(off)
+    new_off = np.zeros(n + 1, np.int64)
+    np.cumsum(nops + lead + trail, out=new_off[1:])
+    out = np.empty(int(new_off[-1]), np.uint32)
+    # original ops, shifted behind the leading clip of their read
+    owner = np.repeat(np.arange(n), nops)
+    within = np.arange(int(off[-1])) - np.repeat(off[:-1], nops)
+    out[new_off[:-1][owner] + lead[owner] + within] = reads.cigar
+    clip = ((rng.integers(1, 25, n).astype(np.uint32)) << 4) | 4
+    out[new_off[:-1][lead == 1]] = clip[lead == 1]
+    out[new_off[1:][trail == 1] - 1] = clip[trail == 1]
+    return ReadSet(reads.pos, reads.flag, new_off, out, reads.max_end)
+
+
 def _merge_sorted(parts):
     """Merge per-batch ReadSets of one chromosome into one coordinate-sorted ReadSet."""
     parts = [p for p in parts if p.n]
