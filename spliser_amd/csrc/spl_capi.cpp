@@ -655,7 +655,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.jhash = ds->jhash; p.jhash_mask = ds->jhash_mask; p.jrivals = ds->jrivals;
     spl_hot_params h;
     memset(&h, 0, sizeof(h));
-    h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos_orig = p.r_pos; h.r_pos = dr->ppos; h.perm = dr->perm; h.chunk_order = dr->chunk_order; h.r_fn = dr->fn; h.r_ops3 = dr->ops3; h.cig_off = p.cig_off; h.cigar = p.cigar;
+    h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos_orig = p.r_pos; h.r_pos = dr->ppos; h.perm = dr->perm; h.chunk_order = dr->chunk_order; h.part_pos = ds->part_pos; h.r_fn = dr->fn; h.r_ops3 = dr->ops3; h.cig_off = p.cig_off; h.cigar = p.cigar;
     h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.n_cigar = (uint32_t)dr->n_cigar;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = dr->queue; h.queue_n = dr->queue_n; h.err = c->d_err;

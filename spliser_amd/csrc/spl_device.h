@@ -11,14 +11,18 @@
 #endif
 #define SPL_COUNTER_STRIDE 64            // words between the 8 queue counters: a 256-byte line each (counters sharing a
                                          // line serialise the atomics of all XCDs: measured 11 ns per atomic, chip-wide)
-// Packed read word r_fn: flag (16 bits) | op count saturating at SPL_NOPS_SAT (14 bits) | class (2 bits), the class being
+// Packed read word r_fn: flag (16 bits) | op count saturating at SPL_NOPS_SAT (13 bits) | class (3 bits), the class being
 // what the pack kernel partitions a chunk by: the range kernel branches on it wave-uniformly.
 #define SPL_PACK_SCAN_OPS 8              // CIGARs up to this many ops are packed without their non-consuming ops
-#define SPL_NOPS_SAT 0x3fffu
+#define SPL_NOPS_SAT 0x1fffu
+#define SPL_RC_SHIFT 29
 #define SPL_RC_SIMPLE 0u                 // one aligned op, mapped, in range: every unspliced short read
 #define SPL_RC_MNM 1u                    // aligned, N, aligned; mapped, in range: every once-spliced short read
-#define SPL_RC_NARROW 2u                 // anything else of at most SPL_INLINE_OPS ops
-#define SPL_RC_WIDE 3u                   // more ops than that
+#define SPL_RC_M2 2u                     // aligned, N, aligned, N, aligned (aligned lengths < 4096, introns < 2^28): the packed words
+                                         // hold the five LENGTHS: w0 = a | b << 12 | (c & 255) << 24, w1 = c >> 8 | d1 << 4, w2 = d2
+#define SPL_RC_NARROW 3u                 // anything else of at most SPL_INLINE_OPS ops
+#define SPL_RC_WIDE 4u                   // more ops than that
+#define SPL_RC_COUNT 5
 #ifndef SPL_BUCKET_AHEAD
 #define SPL_BUCKET_AHEAD 0              // 1: prefetch the next read's bucket entries too (registers!)
 #endif
@@ -106,6 +110,7 @@ struct spl_hot_params {
     const int32_t *r_pos;        // the arrays below are packed at upload, chunk-locally reordered (simple reads first)
     const uint16_t *perm;        // packed slot -> place of the read in its chunk
     const uint32_t *chunk_order; // [n_chunks] slot of an XCD slice -> chunk, longest chunk first within every slice
+    const int32_t *part_pos;     // partner positions (CSR values): the twice-spliced junction-table pass scans a rival's list
     const uint32_t *r_fn;        // flag | min(n_ops, 65535) << 16
     const uint32_t *r_ops3;      // packed at upload, 3 words per read: the ops of a read with <= 3 ops (absent = 0xf);
                                  // for longer reads {op0, op1, index of op2 in cigar[]}

@@ -461,6 +461,82 @@ __device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, spl_lds_i
     return true;
 }
 
+// The same for a twice-spliced read (junctions jl/jr[0..1], aligned blocks blk[0..2]): the two-junction case of
+// rivals_table_path (see there for the rules: a rival is handled under the first junction that lists it, flanking needs
+// "inside that or a later intron", alpha reads and beta1-type reads take double counts on the rival's edges to any junction end
+// of the read except the partner used).  flagged[j]: an end of junction j carries a rival bit -- such a junction must be in
+// the table, or the read is the literal kernel's.  Point updates go to the LDS difference windows.
+template <bool STRANDED, int NARR>
+__device__ __forceinline__ bool rivals_inline2(const spl_hot_params &p, spl_lds_i32 *lds, int32_t wbase, const int32_t (&jl)[2],
+                                               const int32_t (&jr)[2], const bool (&flagged)[2], const int32_t (&blk_a)[3],
+                                               const int32_t (&blk_b)[3], uint32_t sidx)
+{
+    uint32_t r_off[2] = {0, 0}, r_n[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int32_t l = jl[j], r = jr[j];
+        uint32_t h = (uint32_t)l * 0x9E3779B1u ^ (uint32_t)r * 0x85EBCA77u;
+        h ^= h >> 15;
+        bool found = false;
+        uint4 ent = make_uint4(0, 0, 0, 0);
+        for (int probe = 0; probe < 8; ++probe) {
+            ent = p.jhash[2u * ((h + (uint32_t)probe) & p.jhash_mask)];
+            if ((int32_t)ent.x == l && (int32_t)ent.y == r) { found = true; break; }
+            if (ent.x == 0x80000000u) break;
+        }
+        if (found) {
+            if ((ent.w & SPL_JF_COMPLEX) || (ent.w & 0xffu) > 16u) return false;
+            if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) return false;
+            r_off[j] = ent.z;
+            r_n[j] = ent.w & 0xffu;
+        } else if (flagged[j]) return false;
+    }
+    const uint32_t want = sidx ? 2u : 1u;
+    const uint32_t a_b1 = sidx, a_me = (STRANDED ? 2u : 1u) + sidx;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        for (uint32_t i = 0; i < r_n[j]; ++i) {
+            const uint4 rv = p.jrivals[2u * (r_off[j] + i)];
+            bool earlier = false; // listed under the first junction too: handled there
+            if (j == 1) for (uint32_t i2 = 0; i2 < r_n[0]; ++i2) earlier |= (p.jrivals[2u * (r_off[0] + i2)].y == rv.y);
+            if (earlier) continue;
+            const int32_t t = (int32_t)rv.x;
+            const uint32_t td = rv.y & 0x3fffffffu;
+            const bool strand_ok = !STRANDED || (rv.y >> 30) == want;
+            int inside = -1;
+            bool cov = false, alpha = false;
+            int32_t pu = 0;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (t > jl[a] && t < jr[a]) inside = a;
+                if (jl[a] == t) { pu = jr[a]; alpha = true; } // :487-492, in op order
+                if (jr[a] == t) { pu = jl[a]; alpha = true; }
+            }
+#pragma unroll
+            for (int b = 0; b < 3; ++b) cov |= (blk_a[b] <= t) && (t + 1 <= blk_b[b]);
+            const bool beta1type = !alpha && inside < 0 && cov && strand_ok;
+            if (alpha || beta1type) {
+                const uint4 rx = p.jrivals[2u * (r_off[j] + i) + 1u]; // {row of t, its partner list offset, length, -}
+                for (uint32_t e2 = 0; e2 < rx.z; ++e2) {
+                    const int32_t pp = p.part_pos[rx.y + e2];
+                    const bool is_end = pp == jl[0] || pp == jr[0] || pp == jl[1] || pp == jr[1];
+                    if (is_end && !(alpha && pp == pu)) agg_add(&p.dbl[rx.y + e2], 1);
+                }
+                if (beta1type) {
+                    commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_b1, -1);
+                    commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_b1, 1);
+                    commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_me, 1);
+                    commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, -1);
+                }
+            } else if (inside >= j && strand_ok) { // flanking: the ME range counted it, `process` does not
+                commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_me, -1);
+                commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, 1);
+            }
+        }
+    }
+    return true;
+}
+
 } // namespace
 
 // The range kernel proper: one read per lane, straight-line, three batched memory trips per read --
@@ -548,7 +624,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     // ---- trip 2: bucket entries of the start boundary and of every inline op end (slots are clamped: always legal).
     //      The ends are recomputed when the read is worked on; for a read that turns out bad the entries go unused.
     auto fetch_buckets = [&](int32_t f_pos, uint32_t f_fn, const uint32_t (&f_op)[SPL_INLINE_OPS], uint4 (&f_e)[SPL_INLINE_OPS + 1]) {
-        const bool wide = (f_fn >> 30) == SPL_RC_WIDE;
+        const bool wide = (f_fn >> SPL_RC_SHIFT) == SPL_RC_WIDE;
         uint32_t len = 0;
         f_e[0] = p.dbucket[dbk_slot(p, f_pos - 1)];
 #pragma unroll
@@ -606,7 +682,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 if (it + 1 < SPL_RPT) fetch_read(it + 1, cu_pos, cu_fn, cu_op); // next read's words
             }
             const uint32_t flag = fn & 0xffffu;
-            const uint32_t cls = fn >> 30;
+            const uint32_t cls = fn >> SPL_RC_SHIFT;
             // ---- a wave of simple reads (one aligned op, mapped, in range: the pack kernel checked all that and put them
             //      first in the chunk) takes the short road: two boundaries, one range, nothing else can happen
             if (__all(cls == SPL_RC_SIMPLE)) {
@@ -678,6 +754,58 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                     push_back(flagged && !p.combine_mode, (uint32_t)(it * SPL_BLOCK + tid));
                 }
                 continue;
+            }
+            // ---- twice-spliced reads (aligned, N, aligned, N, aligned; the packed words hold the five lengths): six boundaries
+            //      in two trips, five ranges.  Unlike the two classes above this path takes the lanes of its class out of a
+            //      mixed wave too (the others idle through it): the general path below could not rebuild their ops.
+            const bool m2 = cls == SPL_RC_M2;
+            if (__any(m2)) {
+                const uint32_t la = op[0] & 0xfffu, lb = (op[0] >> 12) & 0xfffu, lc = (op[0] >> 24) | ((op[1] & 0xfu) << 8);
+                const uint32_t d1 = op[1] >> 4, d2 = op[2] & 0xfffffffu;
+                // (unsigned sums: for the lanes of other classes these are numbers without meaning; slots are clamped)
+                const int32_t c0 = (int32_t)((uint32_t)pos + la), c1 = (int32_t)((uint32_t)c0 + d1), c2 = (int32_t)((uint32_t)c1 + lb);
+                const int32_t c3 = (int32_t)((uint32_t)c2 + d2), c4 = (int32_t)((uint32_t)c3 + lc);
+                uint32_t sidx2 = 0;
+                if (STRANDED) sidx2 = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
+                const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx2;
+                uint4 f0 = p.dbucket[dbk_slot(p, pos - 1)], f1 = p.dbucket[dbk_slot(p, c0 - 1)];
+                uint4 f2 = p.dbucket[dbk_slot(p, c1 - 1)], f3 = p.dbucket[dbk_slot(p, c2 - 1)];
+                int32_t ua, ub; uint32_t nva, nvb, rva, rvb;
+                uint32_t fl1 = 0, fl2 = 0; // junction 1 / 2 has an end with rivals
+                auto range = [&](uint32_t arr) {
+                    const int32_t lo = ua + (int32_t)nva;
+                    const bool em = m2 && ub > lo;
+                    if (__any(em)) {
+                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | arr, 1);
+                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | arr, -1);
+                    }
+                    ua = ub; nva = nvb;
+                };
+                dbk_resolve(p, pos - 1, f0, ua, nva, rva);
+                dbk_resolve(p, c0 - 1, f1, ub, nvb, rvb);
+                range(sidx2);                       // block 1
+                fl1 |= nvb & rvb;
+                f0 = p.dbucket[dbk_slot(p, c3 - 1)]; // the second trip, under way while the first is worked off
+                f1 = p.dbucket[dbk_slot(p, c4 - 1)];
+                dbk_resolve(p, c1 - 1, f2, ub, nvb, rvb);
+                range(a_me);                        // intron 1
+                fl1 |= nvb & rvb;
+                dbk_resolve(p, c2 - 1, f3, ub, nvb, rvb);
+                range(sidx2);                       // block 2
+                fl2 |= nvb & rvb;
+                dbk_resolve(p, c3 - 1, f0, ub, nvb, rvb);
+                range(a_me);                        // intron 2
+                fl2 |= nvb & rvb;
+                dbk_resolve(p, c4 - 1, f1, ub, nvb, rvb);
+                range(sidx2);                       // block 3
+                const bool flagged = m2 && ((fl1 | fl2) != 0u);
+                if (__any(flagged)) {
+                    const uint32_t slot = (uint32_t)(it * SPL_BLOCK + tid);
+                    push_front(flagged && p.combine_mode, slot);
+                    push_back(flagged && !p.combine_mode, slot | (fl1 << 14) | (fl2 << 15)); // which junction must be in the table
+                }
+                if (__all(m2)) continue;
+                alive = alive && !m2;
             }
             uint32_t n_ops = (fn >> 16) & SPL_NOPS_SAT;
             uint32_t o0 = 0; // index of op 0 in cigar[]: known (and needed) only for reads with more than 3 ops
@@ -755,7 +883,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 push_back(later, (uint32_t)(it * SPL_BLOCK + tid));
             }
         }
-        // Once-spliced reads with rivals, the wave's own, lanes dense: the junction table says which sites of the read's
+        // Once- and twice-spliced reads with rivals, the wave's own, lanes dense: the junction table says which sites of the read's
         // window are affected and how (rivals_inline); what it cannot decide joins the literal list.  The list is read
         // from its growing end, so the front list can only ever grow into entries that are done with.
         for (uint32_t r0 = 0; r0 < n_back; r0 += 64u) {
@@ -763,16 +891,27 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             bool undecided = false;
             uint32_t slot = 0;
             if (j < n_back) {
-                slot = s_q[seg0 + SEG - n_back + j];
+                const uint32_t entry = s_q[seg0 + SEG - n_back + j];
+                slot = entry & 0x3fffu;
                 const int64_t idx = chunk_base + slot;
                 const int32_t pos = p.r_pos[idx];
                 const uint32_t fn = p.r_fn[idx];
-                const uint32_t a = p.r_ops3[3 * idx] >> 4, d = p.r_ops3[3 * idx + 1] >> 4, b = p.r_ops3[3 * idx + 2] >> 4;
-                const int32_t c0 = pos + (int32_t)a, c1 = c0 + (int32_t)d, c2 = c1 + (int32_t)b;
+                const uint32_t w0 = p.r_ops3[3 * idx], w1 = p.r_ops3[3 * idx + 1], w2 = p.r_ops3[3 * idx + 2];
                 uint32_t sidx = 0;
                 if (STRANDED) sidx = (spl_read_strand(fn & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
-                const int32_t blk_a[2] = {pos, c1}, blk_b[2] = {c0 - 1, c2 - 1};
-                undecided = !rivals_inline<STRANDED, NARR>(p, lds, wbase, c0 - 1, c1 - 1, blk_a, blk_b, sidx);
+                if ((fn >> SPL_RC_SHIFT) == SPL_RC_M2) {
+                    const uint32_t la = w0 & 0xfffu, lb = (w0 >> 12) & 0xfffu, lc = (w0 >> 24) | ((w1 & 0xfu) << 8);
+                    const int32_t c0 = pos + (int32_t)la, c1 = c0 + (int32_t)(w1 >> 4), c2 = c1 + (int32_t)lb;
+                    const int32_t c3 = c2 + (int32_t)(w2 & 0xfffffffu), c4 = c3 + (int32_t)lc;
+                    const int32_t jl[2] = {c0 - 1, c2 - 1}, jr[2] = {c1 - 1, c3 - 1};
+                    const bool jf[2] = {((entry >> 14) & 1u) != 0u, (entry >> 15) != 0u};
+                    const int32_t blk_a[3] = {pos, c1, c3}, blk_b[3] = {c0 - 1, c2 - 1, c4 - 1};
+                    undecided = !rivals_inline2<STRANDED, NARR>(p, lds, wbase, jl, jr, jf, blk_a, blk_b, sidx);
+                } else {
+                    const int32_t c0 = pos + (int32_t)(w0 >> 4), c1 = c0 + (int32_t)(w1 >> 4), c2 = c1 + (int32_t)(w2 >> 4);
+                    const int32_t blk_a[2] = {pos, c1}, blk_b[2] = {c0 - 1, c2 - 1};
+                    undecided = !rivals_inline<STRANDED, NARR>(p, lds, wbase, c0 - 1, c1 - 1, blk_a, blk_b, sidx);
+                }
             }
             if (__any(undecided)) push_front(undecided, slot);
         }
@@ -1095,6 +1234,7 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
 template <bool STRANDED>
 __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_params p, const spl_queue_params q)
 {
+    __shared__ uint32_t s_ops[64][5 + 1]; // rebuilt CIGARs of twice-spliced reads (+1: rows on different banks)
     // The 8 shard regions are walked as ONE index space (a wave must not pay the latency chain once per shard).
     // Entries are packed indexes: the read is taken from the range kernel's own arrays (one trip), its ops are inline
     // or start at the stored offset.
@@ -1120,7 +1260,17 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
             const uint32_t flag = fn & 0xffffu;
             uint32_t n_ops = (fn >> 16) & SPL_NOPS_SAT;
             const uint32_t *ops = q.r_ops3 + 3 * idx;
-            if (n_ops > (uint32_t)SPL_INLINE_OPS) {
+            if ((fn >> SPL_RC_SHIFT) == SPL_RC_M2) { // the packed words hold five lengths: the ops are rebuilt in the lane's row of LDS
+                const uint32_t w0 = ops[0], w1 = ops[1], w2 = ops[2];
+                uint32_t *row = s_ops[threadIdx.x];
+                row[0] = ((w0 & 0xfffu) << 4) | 0u;
+                row[1] = ((w1 >> 4) << 4) | (uint32_t)SPL_OP_N;
+                row[2] = (((w0 >> 12) & 0xfffu) << 4) | 0u;
+                row[3] = ((w2 & 0xfffffffu) << 4) | (uint32_t)SPL_OP_N;
+                row[4] = (((w0 >> 24) | ((w1 & 0xfu) << 8)) << 4) | 0u;
+                ops = row;
+                n_ops = 5u;
+            } else if (n_ops > (uint32_t)SPL_INLINE_OPS) {
                 const uint32_t o0 = ops[2] - 2u;
                 ops = p.cigar + o0;
                 if (n_ops == SPL_NOPS_SAT) { // the packed count saturates: the true one from the BAM-native offsets
@@ -1176,7 +1326,7 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_rea
                                                                    uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm, uint32_t *chunk_cost)
 {
     constexpr int NW = SPL_BLOCK / 64;
-    constexpr int NC = 4; // SPL_RC_*
+    constexpr int NC = SPL_RC_COUNT;
     __shared__ uint32_t cnt[NC][SPL_RPT][NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t cb = (int64_t)blockIdx.x * SPL_CHUNK;
@@ -1189,7 +1339,7 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_rea
         // a slot past the end of the read set becomes an inert read of the first class (one aligned op of length 0: an empty
         // range, never queued), so that the range kernel needs no notion of "past the end" at all
         cls[it] = (int)SPL_RC_SIMPLE;
-        r_pos[it] = 1; r_fn[it] = (1u << 16) | (SPL_RC_SIMPLE << 30); w[it][0] = 0u; w[it][1] = w[it][2] = 0xfu;
+        r_pos[it] = 1; r_fn[it] = (1u << 16) | (SPL_RC_SIMPLE << SPL_RC_SHIFT); w[it][0] = 0u; w[it][1] = w[it][2] = 0xfu;
         if (i < n_reads) {
             const uint32_t o0 = cig_off[i], n_all = cig_off[i + 1] - o0;
             r_pos[it] = pos[i];
@@ -1198,15 +1348,18 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_rea
             // (SpliSER_v0_1_8.py:457-464: no progress, no test): a short CIGAR is packed without them, so that a soft-clipped
             // read is classified by what it aligns ("5S95M100N50M" is a once-spliced read).  Longer CIGARs stay as they are.
             uint32_t n = n_all;
+            uint32_t c5[5] = {0xfu, 0xfu, 0xfu, 0xfu, 0xfu}; // the first five consuming ops
+            uint32_t m = 0xffffffffu;                          // their number, if the CIGAR was short enough to look
             if (n_all <= (uint32_t)SPL_PACK_SCAN_OPS) {
-                uint32_t m = 0;
+                m = 0;
                 for (uint32_t k = 0; k < n_all; ++k) {
                     const uint32_t op = cigar[o0 + k];
                     if (kind(op) == 0u) continue;
-                    if (m < 3u) w[it][m] = op;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) if (m == (uint32_t)q) c5[q] = op;
                     ++m;
                 }
-                if (m <= 3u) n = m; // (the words beyond m keep their filler)
+                if (m <= 3u) { n = m; w[it][0] = c5[0]; w[it][1] = c5[1]; w[it][2] = c5[2]; }
             }
             if (n > 3u) { w[it][0] = cigar[o0]; w[it][1] = cigar[o0 + 1]; w[it][2] = o0 + 2u; n = n_all; }
             const bool placed = !(flag[i] & 4u) && r_pos[it] >= 0;
@@ -1214,8 +1367,20 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_rea
             const bool simple = placed && n == 1u && kind(w[it][0]) == 1u && (int64_t)(w[it][0] >> 4) <= room;
             const bool mnm = placed && n == 3u && kind(w[it][0]) == 1u && kind(w[it][1]) == 2u && kind(w[it][2]) == 1u &&
                              (int64_t)(w[it][0] >> 4) + (int64_t)(w[it][1] >> 4) + (int64_t)(w[it][2] >> 4) <= room;
-            cls[it] = simple ? (int)SPL_RC_SIMPLE : mnm ? (int)SPL_RC_MNM : (n <= 3u ? (int)SPL_RC_NARROW : (int)SPL_RC_WIDE);
-            r_fn[it] = (uint32_t)flag[i] | ((n < SPL_NOPS_SAT ? n : SPL_NOPS_SAT) << 16) | ((uint32_t)cls[it] << 30);
+            // twice-spliced: the five lengths fit the three words (the literal paths rebuild the ops from them)
+            const uint32_t la = c5[0] >> 4, d1 = c5[1] >> 4, lb = c5[2] >> 4, d2 = c5[3] >> 4, lc = c5[4] >> 4;
+            const bool m2 = placed && m == 5u && kind(c5[0]) == 1u && kind(c5[1]) == 2u && kind(c5[2]) == 1u && kind(c5[3]) == 2u &&
+                            kind(c5[4]) == 1u && la < 4096u && lb < 4096u && lc < 4096u && d1 < (1u << 28) && d2 < (1u << 28) &&
+                            (int64_t)la + d1 + lb + d2 + lc <= room;
+            if (m2) {
+                w[it][0] = la | (lb << 12) | ((lc & 255u) << 24);
+                w[it][1] = (lc >> 8) | (d1 << 4);
+                w[it][2] = d2;
+                n = 5u;
+            }
+            cls[it] = simple ? (int)SPL_RC_SIMPLE : mnm ? (int)SPL_RC_MNM : m2 ? (int)SPL_RC_M2
+                                                  : (n <= 3u ? (int)SPL_RC_NARROW : (int)SPL_RC_WIDE);
+            r_fn[it] = (uint32_t)flag[i] | ((n < SPL_NOPS_SAT ? n : SPL_NOPS_SAT) << 16) | ((uint32_t)cls[it] << SPL_RC_SHIFT);
         }
         const unsigned long long below = (1ull << lane) - 1ull;
         rank[it] = 0;
@@ -1236,7 +1401,9 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_rea
     }
     // what the chunk will cost the range kernel, roughly (instructions per read of each class): the host orders the chunks of
     // every XCD slice longest first, so that the last workgroups of a launch are the short ones
-    if (tid == 0) chunk_cost[blockIdx.x] = 2u * total[SPL_RC_SIMPLE] + 5u * total[SPL_RC_MNM] + 6u * total[SPL_RC_NARROW] + 14u * total[SPL_RC_WIDE];
+    if (tid == 0)
+        chunk_cost[blockIdx.x] = 2u * total[SPL_RC_SIMPLE] + 5u * total[SPL_RC_MNM] + 9u * total[SPL_RC_M2] + 6u * total[SPL_RC_NARROW] +
+                                 14u * total[SPL_RC_WIDE];
 #pragma unroll
     for (int it = 0; it < SPL_RPT; ++it) {
         const int c = cls[it];
