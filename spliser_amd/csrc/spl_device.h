@@ -33,6 +33,9 @@
 #define SPL_WIN 1020                     // distinct site positions a workgroup privatises in LDS (4 arrays + queue: 8 workgroups in 160 KB)
 #define SPL_INLINE_OPS 3                 // CIGAR ops per read resolved in the straight-line part (M N M = 3)
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
+#ifndef SPL_AGG_ROUNDS
+#define SPL_AGG_ROUNDS 2                 // distinct addresses agg_add merges across the wave before it falls back to plain atomics
+#endif
 #define SPL_LITERAL_WAVES 8192           // one-wave workgroups of the literal kernel (grid-stride over the queue)
 #ifndef SPL_SCAN_BLOCK
 #define SPL_SCAN_BLOCK 256               // distinct positions per workgroup of the scan kernels (a multiple of 256; 1024 left the chip half empty)

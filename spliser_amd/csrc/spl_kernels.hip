@@ -393,7 +393,10 @@ __device__ __forceinline__ void agg_add(uint32_t *addr, int32_t delta)
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     unsigned long long todo = __ballot(1);
     const uint32_t lo = (uint32_t)(uintptr_t)addr, hi = (uint32_t)((uintptr_t)addr >> 32);
-    for (;;) {
+    // A hot counter is shared by many lanes and therefore shows up among the first few distinct addresses; when the lanes
+    // all differ there is nothing to merge, and electing 64 leaders one after the other costs far more than 64 plain
+    // atomics.  So: a few rounds of merging, then everybody left adds for himself.
+    for (int round = 0; round < SPL_AGG_ROUNDS; ++round) {
         const int leader = __ffsll((long long)todo) - 1;
         const bool same = (__shfl((int)lo, leader) == (int)lo) && (__shfl((int)hi, leader) == (int)hi);
         const unsigned long long grp = __ballot(same);
@@ -402,9 +405,10 @@ __device__ __forceinline__ void agg_add(uint32_t *addr, int32_t delta)
             const int32_t sum = 2 * (int32_t)__popcll(plus) - (int32_t)__popcll(grp);
             if (sum) atomicAdd(addr, (uint32_t)sum);
         }
-        if (same) break;
+        if (same) return;
         todo &= ~grp;
     }
+    atomicAdd(addr, (uint32_t)delta);
 }
 
 
@@ -1143,8 +1147,17 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
         }
     }
     if (n_j == 0) return true;
-    // pass 1: table entries of all junctions; everything that needs the literal walk bails out before any update
+    // pass 1: table entries of all junctions; everything that needs the literal walk bails out before any update.
+    // The first probe of every junction is issued before any of them is looked at (one trip for all junctions; at load 1/4
+    // the first probe almost always decides).
     uint32_t r_off[SPL_CF_JUNC], r_n[SPL_CF_JUNC];
+    uint4 first_probe[SPL_CF_JUNC];
+#pragma unroll
+    for (int j = 0; j < SPL_CF_JUNC; ++j) {
+        uint32_t h = (uint32_t)jl[j < n_j ? j : 0] * 0x9E3779B1u ^ (uint32_t)jr[j < n_j ? j : 0] * 0x85EBCA77u;
+        h ^= h >> 15;
+        first_probe[j] = p.jhash[2u * (h & p.jhash_mask)];
+    }
 #pragma unroll
     for (int j = 0; j < SPL_CF_JUNC; ++j) {
         r_off[j] = 0; r_n[j] = 0;
@@ -1153,9 +1166,9 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
         uint32_t h = (uint32_t)l * 0x9E3779B1u ^ (uint32_t)r * 0x85EBCA77u;
         h ^= h >> 15;
         bool found = false;
-        uint4 ent = make_uint4(0, 0, 0, 0);
+        uint4 ent = first_probe[j];
         for (int probe = 0; probe < 8; ++probe) {
-            ent = p.jhash[2u * ((h + (uint32_t)probe) & p.jhash_mask)];
+            if (probe) ent = p.jhash[2u * ((h + (uint32_t)probe) & p.jhash_mask)];
             if ((int32_t)ent.x == l && (int32_t)ent.y == r) { found = true; break; }
             if (ent.x == 0x80000000u) break;
         }
@@ -1182,6 +1195,7 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
     for (int j = 0; j < SPL_CF_JUNC; ++j) {
         for (uint32_t i = 0; i < r_n[j]; ++i) {
             const uint4 rv = p.jrivals[2u * (r_off[j] + i)];
+            const uint4 rx = p.jrivals[2u * (r_off[j] + i) + 1u]; // {row of t, its partner list offset, length, -}: same line, same trip
             bool earlier = false; // listed under an earlier junction of this read: handled there
 #pragma unroll
             for (int j2 = 0; j2 < SPL_CF_JUNC; ++j2)
@@ -1205,7 +1219,6 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
             const bool beta1type = !alpha && inside < 0 && cov && strand_ok;
             if (alpha || beta1type) {
                 // double counts: set(partners) & set(spliceSites), minus partnerUsed for the alpha case (:519-527, :544-551)
-                const uint4 rx = p.jrivals[2u * (r_off[j] + i) + 1u]; // {row of t, its partner list offset, length, -}
                 for (uint32_t e2 = 0; e2 < rx.z; ++e2) {
                     const int32_t pp = p.part_pos[rx.y + e2];
                     bool is_end = false;
