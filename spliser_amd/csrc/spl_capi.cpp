@@ -680,6 +680,8 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
         spl_queue_params lq;
         lq.queue = dr->queue; lq.queue_n = dr->queue_n; lq.queue_cap = h.queue_cap;
         lq.r_pos = dr->ppos; lq.r_fn = dr->fn; lq.r_ops3 = dr->ops3; lq.perm = dr->perm;
+        lq.diff = ds->diff; lq.block_sums = ds->block_sums; lq.diff_stride = ds->diff_stride; lq.n_dpos = ds->n_dpos;
+        lq.scan_blocks = ds->scan_blocks; lq.scan_arrays = o->stranded ? 4 : 2;
         rc = spl_dev_launch_literal(&p, &lq, c->stream);
         if (rc != 0) return spl_set_error(SPL_ERR_HIP, "literal kernel launch: %s", hipGetErrorString((hipError_t)rc));
         spl_scan_params q;

@@ -147,6 +147,10 @@ struct spl_queue_params {
     const uint32_t *r_fn;
     const uint32_t *r_ops3;
     const uint16_t *perm;
+    // the block sums of the difference arrays are taken by this launch too (see spl_count_literal_kernel)
+    const int32_t *diff;
+    int32_t *block_sums;         // [scan_arrays][scan_blocks]
+    int32_t diff_stride, n_dpos, scan_blocks, scan_arrays;
 };
 
 struct spl_scan_params {

@@ -1188,9 +1188,8 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
     }
     // pass 2: apply
     const uint32_t want = (spl_read_strand(flag, STRANDED ? p.stranded : 1) == (uint8_t)'-') ? 2u : 1u;
-    const uint32_t sidx = STRANDED ? (want - 1u) : 0u;
-    uint32_t *b1 = (uint32_t *)(p.diff + (int64_t)sidx * p.diff_stride);
-    uint32_t *me = (uint32_t *)(p.diff + (int64_t)((STRANDED ? 2u : 1u) + sidx) * p.diff_stride);
+    // (corrections go straight to the counters of the rival's row, not to the difference arrays: after the range kernel
+    //  nothing writes the difference arrays any more, so their block sums can be taken inside this very launch)
 #pragma unroll
     for (int j = 0; j < SPL_CF_JUNC; ++j) {
         for (uint32_t i = 0; i < r_n[j]; ++i) {
@@ -1202,7 +1201,6 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
                 if (j2 < j) for (uint32_t i2 = 0; i2 < r_n[j2]; ++i2) earlier |= (p.jrivals[2u * (r_off[j2] + i2)].y == rv.y);
             if (earlier) continue;
             const int32_t t = (int32_t)rv.x;
-            const uint32_t td = rv.y & 0x3fffffffu;
             const bool strand_ok = !STRANDED || (rv.y >> 30) == want;
             int inside = -1;
             bool cov = false, alpha = false;
@@ -1227,11 +1225,11 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
                     if (is_end && !(alpha && pp == pu)) agg_add(&p.dbl[rx.y + e2], 1);
                 }
                 if (beta1type) { // beta1-type (:544-556): the ranges counted it as beta1
-                    agg_add(&b1[td], -1); agg_add(&b1[td + 1u], 1);
-                    agg_add(&me[td], 1); agg_add(&me[td + 1u], -1);
+                    agg_add(&p.beta1[rx.x], -1);
+                    agg_add(&p.beta2s_reads[rx.x], 1);
                 }
             } else if (inside >= j && strand_ok) { // flanking (:503-505, :529): the ME range counted it, `process` does not
-                agg_add(&me[td], -1); agg_add(&me[td + 1u], 1);
+                agg_add(&p.beta2s_reads[rx.x], -1);
             }
         }
     }
@@ -1248,6 +1246,18 @@ template <bool STRANDED>
 __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_params p, const spl_queue_params q)
 {
     __shared__ uint32_t s_ops[64][5 + 1]; // rebuilt CIGARs of twice-spliced reads (+1: rows on different banks)
+    // First the block sums of the difference arrays for the scan that follows: the arrays are final once the range kernel
+    // is done (nothing in this kernel writes them), most of this kernel's waves have no queue entry to work on, and the few
+    // that have are a chain of dependent loads that this short streaming job overlaps with.
+    for (uint32_t b = blockIdx.x; b < (uint32_t)(q.scan_blocks * q.scan_arrays); b += gridDim.x) {
+        const uint32_t arr = b / (uint32_t)q.scan_blocks, blk = b - arr * (uint32_t)q.scan_blocks;
+        const int32_t *d = q.diff + (int64_t)arr * q.diff_stride;
+        const int32_t base = (int32_t)blk * SPL_SCAN_BLOCK;
+        int32_t acc = 0;
+        for (int j = (int)threadIdx.x; j < SPL_SCAN_BLOCK; j += 64) acc += (base + j < q.n_dpos) ? d[base + j] : 0;
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+        if (threadIdx.x == 0) q.block_sums[b] = acc;
+    }
     // The 8 shard regions are walked as ONE index space (a wave must not pay the latency chain once per shard).
     // Entries are packed indexes: the read is taken from the range kernel's own arrays (one trip), its ops are inline
     // or start at the stored offset.
@@ -1436,23 +1446,6 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_rea
 // =========================================================================================================
 // Difference arrays -> counters: two tiny launches (block sums, then offset + local inclusive scan).
 // =========================================================================================================
-__global__ __launch_bounds__(256) void spl_scan_sums_kernel(const spl_scan_params p)
-{
-    __shared__ int32_t red[4];
-    const int arr = blockIdx.y;
-    const int32_t base = blockIdx.x * SPL_SCAN_BLOCK;
-    const int32_t *d = p.diff + (int64_t)arr * p.diff_stride;
-    int32_t acc = 0;
-    for (int j = threadIdx.x; j < SPL_SCAN_BLOCK; j += 256) {
-        const int32_t r = base + j;
-        if (r < p.n_dpos) acc += d[r];
-    }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) p.block_sums[arr * p.n_blocks + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
 __global__ __launch_bounds__(256) void spl_scan_apply_kernel(const spl_scan_params p)
 {
     __shared__ int32_t red[4][4];   // [array][wave]
@@ -1815,7 +1808,7 @@ extern "C" int spl_dev_launch_scan(const spl_scan_params *p, void *stream)
 {
     if (p->n_dpos <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(spl_scan_sums_kernel, dim3(p->n_blocks, p->n_arrays), dim3(256), 0, st, *p);
+    // (the block sums were taken by the literal kernel's launch)
     hipLaunchKernelGGL(spl_scan_apply_kernel, dim3(p->n_blocks), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
