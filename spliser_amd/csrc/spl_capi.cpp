@@ -44,7 +44,8 @@ struct spl_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int32_t *d_err = nullptr;
+    int32_t *d_err = nullptr;               // error word of launches that are not counting passes (spl_junctions)
+    const uint32_t *last_queue_n = nullptr; // queue counters of the last counting pass (spl_literal_queue_size)
     int last_grid = 0, last_lds = 0, last_variant = 0;
     struct Junction { int32_t left, right; uint8_t strand; uint32_t count, anchor_left, anchor_right; };
     std::vector<Junction> junctions; // result of the last spl_junctions call, sorted
@@ -86,6 +87,12 @@ struct spl_dsites {
     // outputs
     uint32_t *beta1 = nullptr, *beta2s = nullptr, *dbl = nullptr; // contiguous: one memset clears all three
     size_t counter_bytes = 0;
+    // Everything a counting pass must find zero (counters, difference arrays, error word, queue counters) exists twice: a pass
+    // works on one copy while its literal kernel's idle waves clear the other for the next pass (alt_clean), so no pass starts
+    // with a clearing launch of its own.  The plain members always point into the copy in use.
+    uint32_t *alt_beta1 = nullptr, *alt_beta2s = nullptr, *alt_dbl = nullptr, *queue_n = nullptr, *alt_queue_n = nullptr;
+    int32_t *alt_diff = nullptr, *err = nullptr, *alt_err = nullptr;
+    bool alt_clean = false;
     int64_t *b2_simple = nullptr, *b2_cryptic = nullptr;
     double *b2_weighted = nullptr, *sse = nullptr;
 };
@@ -100,7 +107,7 @@ struct spl_dreads {
     int32_t *ppos = nullptr;
     uint16_t *perm = nullptr;
     uint32_t *chunk_order = nullptr; // slot of an XCD slice -> chunk, longest first (holds the cost estimates during upload)
-    uint32_t *queue = nullptr, *queue_n = nullptr; // reads the range kernel hands to the literal kernel
+    uint32_t *queue = nullptr; // reads the range kernel hands to the literal kernel (the counters are with the site table)
 };
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -473,7 +480,9 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     const size_t o_cnt = off;
     const size_t o_b1 = take(4 * S), o_b2 = take(4 * S), o_dbl = take(4 * P);
     const size_t o_diff = take(4 * 4 * (size_t)d->diff_stride);
+    const size_t o_ctl = take(4 * 8 * SPL_COUNTER_STRIDE + 256); // 8 queue counters (a cache line each), then the error word
     d->counter_bytes = off - o_cnt;
+    const size_t o_alt = take(d->counter_bytes);                // the second copy, same layout
     const size_t o_bsum = take(4 * 4 * (size_t)std::max(d->scan_blocks, 1));
     const size_t o_b2s = take(8 * S), o_b2c = take(8 * S), o_b2w = take(8 * S), o_sse = take(8 * S);
     d->slab_bytes = std::max<size_t>(off, 256);
@@ -488,6 +497,14 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     d->comp_pos = (int32_t *)(d->slab + o_cpos); d->alpha = (int64_t *)(d->slab + o_alpha); d->edge_cnt = (int64_t *)(d->slab + o_ecnt);
     d->bucket = (uint32_t *)(d->slab + o_bucket);
     d->beta1 = (uint32_t *)(d->slab + o_b1); d->beta2s = (uint32_t *)(d->slab + o_b2); d->dbl = (uint32_t *)(d->slab + o_dbl);
+    d->queue_n = (uint32_t *)(d->slab + o_ctl); d->err = (int32_t *)(d->slab + o_ctl + 4 * 8 * SPL_COUNTER_STRIDE);
+    {
+        const size_t shift = o_alt - o_cnt;
+        d->alt_beta1 = (uint32_t *)(d->slab + o_b1 + shift); d->alt_beta2s = (uint32_t *)(d->slab + o_b2 + shift);
+        d->alt_dbl = (uint32_t *)(d->slab + o_dbl + shift); d->alt_diff = (int32_t *)(d->slab + o_diff + shift);
+        d->alt_queue_n = (uint32_t *)(d->slab + o_ctl + shift); d->alt_err = (int32_t *)(d->slab + o_ctl + 4 * 8 * SPL_COUNTER_STRIDE + shift);
+        d->alt_clean = true; // the upload zeroes both copies
+    }
     d->b2_simple = (int64_t *)(d->slab + o_b2s); d->b2_cryptic = (int64_t *)(d->slab + o_b2c);
     d->b2_weighted = (double *)(d->slab + o_b2w); d->sse = (double *)(d->slab + o_sse);
 
@@ -560,12 +577,12 @@ static int upload_segments(spl_ctx *c, int n_seg, const spl_reads *segs, const i
     const size_t o_order = take(4 * (n_chunks ? n_chunks : 1));
     // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks
     const size_t shard_cap = ((n_chunks + 7) / 8) * SPL_CHUNK;
-    const size_t o_queue = take(4 * 8 * shard_cap), o_qn = take(4 * 8 * SPL_COUNTER_STRIDE);
+    const size_t o_queue = take(4 * 8 * shard_cap);
     hipError_t e = hipMalloc((void **)&d->slab, std::max<size_t>(off, 256));
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the read set: %s", off, hipGetErrorString(e)); }
     d->pos = (int32_t *)(d->slab + o_pos); d->flag = (uint16_t *)(d->slab + o_flag);
     d->cig_off = (uint32_t *)(d->slab + o_off); d->cigar = (uint32_t *)(d->slab + o_cig);
-    d->queue = (uint32_t *)(d->slab + o_queue); d->queue_n = (uint32_t *)(d->slab + o_qn);
+    d->queue = (uint32_t *)(d->slab + o_queue);
     d->fn = (uint32_t *)(d->slab + o_fn); d->ops3 = (uint32_t *)(d->slab + o_ops3);
     d->ppos = (int32_t *)(d->slab + o_ppos); d->perm = (uint16_t *)(d->slab + o_perm);
     d->chunk_order = (uint32_t *)(d->slab + o_order);
@@ -638,9 +655,15 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
         return spl_set_error(SPL_ERR_ARG, "stranded must be 0 (unstranded), 1 (fr) or 2 (rf); the reference raises "
                                           "UnboundLocalError for any other strandedType");
     HIP_TRY(hipSetDevice(c->device));
-    // counters, difference arrays, error word and queue counters start from zero: one launch for all of them
-    if (int rc0 = spl_dev_launch_clear(ds->beta1, ds->counter_bytes, c->d_err, dr->queue_n, c->stream))
+    // counters, difference arrays, error word and queue counters start from zero: the copy the previous pass cleared on the
+    // side, or -- first pass after a pair-kernel pass -- one clearing launch
+    if (ds->alt_clean) {
+        std::swap(ds->beta1, ds->alt_beta1); std::swap(ds->beta2s, ds->alt_beta2s); std::swap(ds->dbl, ds->alt_dbl);
+        std::swap(ds->diff, ds->alt_diff); std::swap(ds->queue_n, ds->alt_queue_n); std::swap(ds->err, ds->alt_err);
+        ds->alt_clean = false;
+    } else if (int rc0 = spl_dev_launch_clear(ds->beta1, ds->counter_bytes, c->stream))
         return spl_set_error(SPL_ERR_HIP, "clear kernel launch: %s", hipGetErrorString((hipError_t)rc0));
+    c->last_queue_n = ds->queue_n;
     spl_count_params p;
     memset(&p, 0, sizeof(p));
     p.n_reads = dr->n_reads;
@@ -658,13 +681,13 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos_orig = p.r_pos; h.r_pos = dr->ppos; h.perm = dr->perm; h.chunk_order = dr->chunk_order; h.part_pos = ds->part_pos; h.r_fn = dr->fn; h.r_ops3 = dr->ops3; h.cig_off = p.cig_off; h.cigar = p.cigar;
     h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.n_cigar = (uint32_t)dr->n_cigar;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
-    h.queue = dr->queue; h.queue_n = dr->queue_n; h.err = c->d_err;
+    h.queue = dr->queue; h.queue_n = ds->queue_n; h.err = ds->err;
     h.queue_cap = (uint32_t)(((p.n_chunks + 7u) / 8u) * SPL_CHUNK);
     h.jhash = ds->jhash; h.jhash_mask = ds->jhash_mask; h.jrivals = ds->jrivals; h.dbl = ds->dbl; h.combine_mode = o->combine_mode ? 1 : 0;
 
     p.bucket = ds->bucket; p.n_buckets = ds->n_buckets; p.bucket_base = ds->bucket_base; p.bucket_shift = ds->bucket_shift;
     p.stranded = o->stranded; p.combine_mode = o->combine_mode ? 1 : 0;
-    p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = c->d_err;
+    p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = ds->err;
     // range kernel whenever the table allows it; the literal pair kernel otherwise or on request
     const int variant = (!ds->mutual_links || (o->flags & SPL_OPT_PAIR_KERNEL)) ? 1 : ((o->flags & SPL_OPT_WAVE_AGGREGATION) ? 2 : 0);
     int grid = 0, lds = 0;
@@ -678,12 +701,14 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     if (rc != 0) return spl_set_error(SPL_ERR_HIP, "count kernel launch: %s", hipGetErrorString((hipError_t)rc));
     if (variant != 1 && grid > 0) { // queued reads through the literal kernel, then difference arrays -> counters
         spl_queue_params lq;
-        lq.queue = dr->queue; lq.queue_n = dr->queue_n; lq.queue_cap = h.queue_cap;
+        lq.queue = dr->queue; lq.queue_n = ds->queue_n; lq.queue_cap = h.queue_cap;
+        lq.clear_region = (uint4 *)ds->alt_beta1; lq.clear_n16 = ds->counter_bytes / 16; // the other copy, for the next pass
         lq.r_pos = dr->ppos; lq.r_fn = dr->fn; lq.r_ops3 = dr->ops3; lq.perm = dr->perm;
         lq.diff = ds->diff; lq.block_sums = ds->block_sums; lq.diff_stride = ds->diff_stride; lq.n_dpos = ds->n_dpos;
         lq.scan_blocks = ds->scan_blocks; lq.scan_arrays = o->stranded ? 4 : 2;
         rc = spl_dev_launch_literal(&p, &lq, c->stream);
         if (rc != 0) return spl_set_error(SPL_ERR_HIP, "literal kernel launch: %s", hipGetErrorString((hipError_t)rc));
+        ds->alt_clean = true;
         spl_scan_params q;
         memset(&q, 0, sizeof(q));
         q.n_dpos = ds->n_dpos; q.dpos_first_row = ds->dpos_first_row;
@@ -712,10 +737,10 @@ extern "C" int spl_sse_launch(spl_ctx *c, spl_dsites *ds, int cryptic)
     return SPL_OK;
 }
 
-static int check_device_error(spl_ctx *c)
+static int check_device_error(spl_ctx *c, const spl_dsites *ds)
 {
     int32_t err = 0;
-    HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(err), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&err, ds->err, sizeof(err), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (err & SPL_DEV_ERR_RANGE)
         return spl_set_error(SPL_ERR_RANGE, "a read starts below 0 or ends beyond coordinate %d: split the shard (spliser_amd/shard.py)", SPL_COORD_MAX);
@@ -729,7 +754,7 @@ extern "C" int spl_counters_download(spl_ctx *c, const spl_dsites *ds, uint32_t 
     if (beta1 && ds->n_sites) HIP_TRY(hipMemcpyAsync(beta1, ds->beta1, 4 * ds->n_sites, hipMemcpyDeviceToHost, c->stream));
     if (b2s && ds->n_sites) HIP_TRY(hipMemcpyAsync(b2s, ds->beta2s, 4 * ds->n_sites, hipMemcpyDeviceToHost, c->stream));
     if (dbl && ds->n_part) HIP_TRY(hipMemcpyAsync(dbl, ds->dbl, 4 * ds->n_part, hipMemcpyDeviceToHost, c->stream));
-    return check_device_error(c);
+    return check_device_error(c, ds);
 }
 
 extern "C" int spl_sse_download(spl_ctx *c, const spl_dsites *ds, int64_t *b2s, int64_t *b2c, double *b2w, double *sse)
@@ -836,7 +861,8 @@ extern "C" int spl_literal_queue_size(spl_ctx *c, const spl_dreads *dr, int64_t 
     if (!c || !dr || !n_out) return spl_set_error(SPL_ERR_ARG, "spl_literal_queue_size: null argument");
     HIP_TRY(hipSetDevice(c->device));
     std::vector<uint32_t> counts(8 * SPL_COUNTER_STRIDE);
-    HIP_TRY(hipMemcpyAsync(counts.data(), dr->queue_n, 4 * counts.size(), hipMemcpyDeviceToHost, c->stream));
+    if (!c->last_queue_n) { *n_out = 0; return SPL_OK; }
+    HIP_TRY(hipMemcpyAsync(counts.data(), c->last_queue_n, 4 * counts.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int64_t total = 0;
     for (int k = 0; k < 8; ++k) total += counts[(size_t)k * SPL_COUNTER_STRIDE];

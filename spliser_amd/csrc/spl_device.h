@@ -151,6 +151,9 @@ struct spl_queue_params {
     const int32_t *diff;
     int32_t *block_sums;         // [scan_arrays][scan_blocks]
     int32_t diff_stride, n_dpos, scan_blocks, scan_arrays;
+    // ... and the other copy of the counter region is cleared for the next counting pass
+    uint4 *clear_region;
+    size_t clear_n16;
 };
 
 struct spl_scan_params {
@@ -195,7 +198,7 @@ int spl_dev_launch_junctions(int64_t n_reads, const int32_t *pos, const uint16_t
                              uint32_t *vals, uint32_t n_slots, unsigned long long *out_keys,
                              uint32_t *out_vals, uint32_t *n_out, int32_t *err, void *stream);
 int spl_dev_launch_rebase(int32_t *pos, uint32_t *cig_off, int64_t n, int32_t shift, uint32_t cig_base, void *stream);
-int spl_dev_launch_clear(void *region, size_t bytes, int32_t *err, uint32_t *queue_n, void *stream);
+int spl_dev_launch_clear(void *region, size_t bytes, void *stream);
 int spl_dev_launch_literal(const spl_count_params *p, const spl_queue_params *q, void *stream);
 int spl_dev_launch_pack(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar,
                         int32_t *p_pos, uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm, uint32_t *chunk_cost, void *stream);

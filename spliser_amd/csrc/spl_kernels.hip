@@ -1246,7 +1246,9 @@ template <bool STRANDED>
 __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_params p, const spl_queue_params q)
 {
     __shared__ uint32_t s_ops[64][5 + 1]; // rebuilt CIGARs of twice-spliced reads (+1: rows on different banks)
-    // First the block sums of the difference arrays for the scan that follows: the arrays are final once the range kernel
+    // The other copy of the counter region, for the next counting pass (one 16-byte store per lane or so).
+    for (size_t j = (size_t)blockIdx.x * 64 + threadIdx.x; j < q.clear_n16; j += (size_t)gridDim.x * 64) q.clear_region[j] = make_uint4(0, 0, 0, 0);
+    // Then the block sums of the difference arrays for the scan that follows: the arrays are final once the range kernel
     // is done (nothing in this kernel writes them), most of this kernel's waves have no queue entry to work on, and the few
     // that have are a chain of dependent loads that this short streaming job overlaps with.
     for (uint32_t b = blockIdx.x; b < (uint32_t)(q.scan_blocks * q.scan_arrays); b += gridDim.x) {
@@ -1670,14 +1672,13 @@ __global__ __launch_bounds__(256) void spl_rebase_kernel(int32_t *pos, uint32_t 
     }
 }
 
-// Everything a counting pass starts from zero, in one launch: the counter / difference-array region of the site table
-// (16-byte aligned, a multiple of 16 bytes), the device error word and the queue counters.
-__global__ __launch_bounds__(256) void spl_clear_kernel(uint4 *region, size_t n16, int32_t *err, uint32_t *queue_n)
+// Everything a counting pass starts from zero (the counter region of the site table: counters, difference arrays, queue
+// counters, error word; 16-byte aligned, a multiple of 16 bytes).  Normally the literal kernel of the previous pass has
+// cleared the copy a pass starts on; this launch is for the passes that have no such predecessor.
+__global__ __launch_bounds__(256) void spl_clear_kernel(uint4 *region, size_t n16)
 {
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n16; j += stride) region[j] = make_uint4(0, 0, 0, 0);
-    if (blockIdx.x == 0 && threadIdx.x < 8) queue_n[threadIdx.x * SPL_COUNTER_STRIDE] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 8) *err = 0;
 }
 
 // ---- launchers (called from spl_capi.cpp through spl_device.h) ------------------------------------------
@@ -1709,12 +1710,12 @@ extern "C" int spl_dev_launch_rebase(int32_t *pos, uint32_t *cig_off, int64_t n,
     return (int)hipGetLastError();
 }
 
-extern "C" int spl_dev_launch_clear(void *region, size_t bytes, int32_t *err, uint32_t *queue_n, void *stream)
+extern "C" int spl_dev_launch_clear(void *region, size_t bytes, void *stream)
 {
     const size_t n16 = bytes / 16;
     size_t blocks = (n16 + 256 * 4 - 1) / (256 * 4); // four stores per thread
     blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-    hipLaunchKernelGGL(spl_clear_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, (uint4 *)region, n16, err, queue_n);
+    hipLaunchKernelGGL(spl_clear_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, (uint4 *)region, n16);
     return (int)hipGetLastError();
 }
 

@@ -144,6 +144,41 @@ def test_gpu_reads_with_non_consuming_ops(ctx, oracle_lib):
     assert int(want[0].sum()) > 1000 and int(want[1].sum()) > 100
 
 
+def test_gpu_back_to_back_passes_on_one_table(ctx, tmp_path, oracle_lib):
+    """The counter region of a device table exists twice and is cleared on the side by the previous pass (or by a clearing
+    launch after a pair-kernel pass): a sequence of passes with changing modes and kernels on ONE uploaded table and read set
+    must give the oracle's counters every time, and the device error word must not leak from one pass to the next."""
+    wl = synth.Workload("arabidopsis", scale=0.003, seed=41)
+    table = _table_for(wl, tmp_path, True)
+    name = wl.genome.chrom_names[1]
+    arr, reads = table.chrom_arrays(name), wl.reads[1]
+    sites_c = native.SiteArrays.from_chrom(arr)
+    reads_c = native.ReadArrays(reads.pos, reads.flag, reads.cig_off, reads.cigar)
+    ds, dr = ctx.upload_sites(sites_c), ctx.upload_reads(reads_c)
+    want = {}
+    for stranded in (0, 1, 2):
+        for combine in (0, 1):
+            want[(stranded, combine)] = oracle_lib.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos,
+                                                             reads.pos, reads.flag, reads.cig_off, reads.cigar, stranded, combine)
+    sequence = [(0, 0, "ranges"), (1, 0, "ranges"), (1, 0, "pairs"), (0, 0, "ranges"), (2, 1, "ranges"), (2, 1, "ranges_agg"),
+                (0, 1, "pairs"), (0, 1, "pairs"), (1, 1, "ranges"), (0, 0, "ranges_agg"), (0, 0, "ranges")]
+    for stranded, combine, kernel in sequence:
+        ctx.count_launch(ds, dr, stranded, combine, KERNELS[kernel])
+        for g, w in zip(ds.counters(), want[(stranded, combine)]):
+            assert np.array_equal(g, w), (stranded, combine, kernel)
+    # a pass that trips the range check, then a clean one on the same table
+    far = ctx.upload_reads(native.ReadArrays([2147483000], [0], [0, 1], [(1 << 20) << 4]))
+    ctx.count_launch(ds, far, 0, 0)
+    with pytest.raises(native.SpliserNativeError):
+        ds.counters()
+    far.free()
+    ctx.count_launch(ds, dr, 0, 0)
+    for g, w in zip(ds.counters(), want[(0, 0)]):
+        assert np.array_equal(g, w)
+    dr.free()
+    ds.free()
+
+
 def test_gpu_segment_upload_equals_packed_upload(ctx, tmp_path):
     """spl_reads_upload_segments (per-chromosome arrays shifted on the device) against the host-packed shard."""
     wl = synth.Workload("arabidopsis", scale=0.01, seed=77)
