@@ -95,6 +95,9 @@ struct spl_dsites {
     bool alt_clean = false;
     int64_t *b2_simple = nullptr, *b2_cryptic = nullptr;
     double *b2_weighted = nullptr, *sse = nullptr;
+    double *sse_cryptic = nullptr;      // SSE with --beta2Cryptic, written next to `sse` by the fused scan kernel
+    bool sse_fused = false;             // the last counting pass computed beta2 / SSE (both settings) already
+    const double *sse_view = nullptr;   // what spl_sse_download hands out
 };
 
 struct spl_dreads {
@@ -484,7 +487,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     d->counter_bytes = off - o_cnt;
     const size_t o_alt = take(d->counter_bytes);                // the second copy, same layout
     const size_t o_bsum = take(4 * 4 * (size_t)std::max(d->scan_blocks, 1));
-    const size_t o_b2s = take(8 * S), o_b2c = take(8 * S), o_b2w = take(8 * S), o_sse = take(8 * S);
+    const size_t o_b2s = take(8 * S), o_b2c = take(8 * S), o_b2w = take(8 * S), o_sse = take(8 * S), o_ssec = take(8 * S);
     d->slab_bytes = std::max<size_t>(off, 256);
     hipError_t e = hipMalloc((void **)&d->slab, d->slab_bytes);
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the site table: %s", d->slab_bytes, hipGetErrorString(e)); }
@@ -506,7 +509,8 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
         d->alt_clean = true; // the upload zeroes both copies
     }
     d->b2_simple = (int64_t *)(d->slab + o_b2s); d->b2_cryptic = (int64_t *)(d->slab + o_b2c);
-    d->b2_weighted = (double *)(d->slab + o_b2w); d->sse = (double *)(d->slab + o_sse);
+    d->b2_weighted = (double *)(d->slab + o_b2w); d->sse = (double *)(d->slab + o_sse); d->sse_cryptic = (double *)(d->slab + o_ssec);
+    d->sse_view = d->sse;
 
     auto up = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
         if (!bytes || !src) return hipSuccess;
@@ -664,6 +668,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     } else if (int rc0 = spl_dev_launch_clear(ds->beta1, ds->counter_bytes, c->stream))
         return spl_set_error(SPL_ERR_HIP, "clear kernel launch: %s", hipGetErrorString((hipError_t)rc0));
     c->last_queue_n = ds->queue_n;
+    ds->sse_fused = false;
     spl_count_params p;
     memset(&p, 0, sizeof(p));
     p.n_reads = dr->n_reads;
@@ -715,8 +720,16 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
         q.n_arrays = o->stranded ? 4 : 2; q.diff_stride = ds->diff_stride;
         q.n_blocks = ds->scan_blocks; q.diff = ds->diff; q.block_sums = ds->block_sums; q.site_flags = ds->flags;
         q.beta1 = ds->beta1; q.beta2s_reads = ds->beta2s;
+        q.with_sse = ds->has_sse_inputs ? 1 : 0;
+        if (q.with_sse) {
+            q.sse.n_sites = ds->n_sites; q.sse.site_pos = ds->pos; q.sse.part_off = ds->part_off; q.sse.part_pos = ds->part_pos;
+            q.sse.part_site = ds->part_site; q.sse.alpha = ds->alpha; q.sse.edge_cnt = ds->edge_cnt; q.sse.dbl = ds->dbl;
+            q.sse.beta2_simple = ds->b2_simple; q.sse.beta2_cryptic = ds->b2_cryptic; q.sse.beta2_weighted = ds->b2_weighted;
+            q.sse.sse = ds->sse; q.sse_with_cryptic = ds->sse_cryptic;
+        }
         rc = spl_dev_launch_scan(&q, c->stream);
         if (rc != 0) return spl_set_error(SPL_ERR_HIP, "scan kernel launch: %s", hipGetErrorString((hipError_t)rc));
+        ds->sse_fused = q.with_sse != 0;
     }
     return SPL_OK;
 }
@@ -726,6 +739,11 @@ extern "C" int spl_sse_launch(spl_ctx *c, spl_dsites *ds, int cryptic)
     if (!c || !ds) return spl_set_error(SPL_ERR_ARG, "spl_sse_launch: null argument");
     if (!ds->has_sse_inputs) return spl_set_error(SPL_ERR_ARG, "spl_sse needs sites->alpha, sites->edge_cnt and sites->part_site");
     HIP_TRY(hipSetDevice(c->device));
+    if (ds->sse_fused) { // the counting pass on these very counters computed both settings: pick one, nothing to launch
+        ds->sse_view = cryptic ? ds->sse_cryptic : ds->sse;
+        return SPL_OK;
+    }
+    ds->sse_view = ds->sse;
     spl_sse_params p;
     memset(&p, 0, sizeof(p));
     p.n_sites = ds->n_sites; p.site_pos = ds->pos; p.part_off = ds->part_off; p.part_pos = ds->part_pos; p.part_site = ds->part_site;
@@ -766,7 +784,7 @@ extern "C" int spl_sse_download(spl_ctx *c, const spl_dsites *ds, int64_t *b2s, 
         if (b2s) HIP_TRY(hipMemcpyAsync(b2s, ds->b2_simple, n, hipMemcpyDeviceToHost, c->stream));
         if (b2c) HIP_TRY(hipMemcpyAsync(b2c, ds->b2_cryptic, n, hipMemcpyDeviceToHost, c->stream));
         if (b2w) HIP_TRY(hipMemcpyAsync(b2w, ds->b2_weighted, n, hipMemcpyDeviceToHost, c->stream));
-        if (sse) HIP_TRY(hipMemcpyAsync(sse, ds->sse, n, hipMemcpyDeviceToHost, c->stream));
+        if (sse) HIP_TRY(hipMemcpyAsync(sse, ds->sse_view, n, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SPL_OK;

@@ -156,19 +156,6 @@ struct spl_queue_params {
     size_t clear_n16;
 };
 
-struct spl_scan_params {
-    int32_t n_dpos;
-    const int32_t *dpos_first_row; // [n_dpos + 1]
-    int32_t n_arrays;            // 2 unstranded {beta1, ME}; 4 stranded {beta1+, beta1-, ME+, ME-}
-    int32_t diff_stride;
-    int32_t n_blocks;
-    const int32_t *diff;
-    int32_t *block_sums;         // [n_arrays][n_blocks]
-    const uint8_t *site_flags;
-    uint32_t *beta1;
-    uint32_t *beta2s_reads;
-};
-
 struct spl_sse_params {
     int64_t n_sites;
     const int32_t *site_pos;
@@ -186,6 +173,23 @@ struct spl_sse_params {
     double *beta2_weighted;
     double *sse;
 };
+
+struct spl_scan_params {
+    int32_t n_dpos;
+    const int32_t *dpos_first_row; // [n_dpos + 1]
+    int32_t n_arrays;            // 2 unstranded {beta1, ME}; 4 stranded {beta1+, beta1-, ME+, ME-}
+    int32_t diff_stride;
+    int32_t n_blocks;
+    const int32_t *diff;
+    int32_t *block_sums;         // [n_arrays][n_blocks]
+    const uint8_t *site_flags;
+    uint32_t *beta1;
+    uint32_t *beta2s_reads;
+    int32_t with_sse;            // the table has the inputs of findBeta2Counts: compute beta2 / SSE of every row right here
+    spl_sse_params sse;          // (its beta1 / beta2s_reads / cryptic members are not used by the fused path)
+    double *sse_with_cryptic;    // SSE as --beta2Cryptic defines it; sse.sse holds the plain one
+};
+
 
 #ifdef __cplusplus
 extern "C" {

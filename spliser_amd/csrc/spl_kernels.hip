@@ -1448,6 +1448,78 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_rea
 // =========================================================================================================
 // Difference arrays -> counters: two tiny launches (block sums, then offset + local inclusive scan).
 // =========================================================================================================
+// =========================================================================================================
+// findBeta2Counts + calculateSSE, one site per lane.  IEEE binary64, compiled with -ffp-contract=off: every
+// operation below is one correctly rounded operation in the reference's order, so the doubles are the ones
+// CPython produces (int/int true division included for |values| < 2^53).
+// =========================================================================================================
+// findBeta2Counts for site s given its read-derived beta2Simple count (:581-623)
+__device__ __forceinline__ void sse_site_core(const spl_sse_params &p, int64_t s, uint32_t b2s_reads, int64_t &b2simple, int64_t &cryptic,
+                                              double &weighted)
+{
+    const int64_t t = p.site_pos[s];
+    b2simple = b2s_reads;
+    cryptic = 0;
+    weighted = 0.0;
+    const int64_t total_alpha = p.alpha[s];
+    const uint32_t e0 = p.part_off[s], e1 = p.part_off[s + 1];
+    for (uint32_t e = e0; e < e1; ++e) { // for pSite in Partners (:590)
+        const int32_t ps = p.part_site[e];
+        if (ps < 0) continue;
+        const int64_t ppos = p.site_pos[ps];
+        int64_t doubles = p.dbl[e];
+        bool have_key = doubles != 0;
+        const uint32_t f1 = p.part_off[ps + 1];
+        for (uint32_t f = p.part_off[ps]; f < f1; ++f) { // pSite.getPartnerCounts().items() (:592)
+            const int64_t cpos = p.part_pos[f];
+            if ((ppos > t && cpos < t) || (ppos < t && cpos > t)) { // junction (pSite, c) flanks t (:594-599)
+                const int64_t cnt = p.edge_cnt[f];
+                b2simple += cnt;
+                doubles += cnt;
+                have_key = true;
+            }
+        }
+        const int64_t shared = p.edge_cnt[e];          // PartnerCounts[pSite.pos] (:604)
+        int64_t b2 = p.alpha[ps] - shared;             // :606
+        if (have_key) { b2 -= doubles; if (b2 < 0) b2 = 0; } // :608-611 subIntNoNeg
+        cryptic += b2;                                 // :613
+        double w = 0.0;                                // trueDivCatchZero (:562-572)
+        if ((double)total_alpha > 0.0) w = (double)shared / (double)total_alpha;
+        const double wb2 = (double)b2 * w;             // :618
+        weighted = weighted + wb2;                     // :619
+    }
+}
+
+// calculateSSE (:626-639)
+__device__ __forceinline__ double sse_site_value(int64_t total_alpha, uint32_t beta1, int64_t b2simple, double weighted, bool with_cryptic)
+{
+    const int64_t betas_int = (int64_t)beta1 + b2simple; // :631
+    double value = 0.0;
+    if (with_cryptic) {
+        const double betas = (double)betas_int + weighted;     // :635
+        const double denom = (double)total_alpha + betas;      // :637
+        if (denom > 0.0) value = (double)total_alpha / denom;
+    } else {
+        const int64_t denom = total_alpha + betas_int;
+        if ((double)denom > 0.0) value = (double)total_alpha / (double)denom;
+    }
+    return value;
+}
+
+__global__ __launch_bounds__(256) void spl_sse_kernel(const spl_sse_params p)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= p.n_sites) return;
+    int64_t b2simple, cryptic;
+    double weighted;
+    sse_site_core(p, s, p.beta2s_reads[s], b2simple, cryptic, weighted);
+    p.beta2_simple[s] = b2simple;
+    p.beta2_cryptic[s] = cryptic;
+    p.beta2_weighted[s] = weighted;
+    p.sse[s] = sse_site_value(p.alpha[s], p.beta1[s], b2simple, weighted, p.cryptic != 0);
+}
+
+// Difference arrays -> counters (and, fused, findBeta2Counts + calculateSSE of every row)
 __global__ __launch_bounds__(256) void spl_scan_apply_kernel(const spl_scan_params p)
 {
     __shared__ int32_t red[4][4];   // [array][wave]
@@ -1500,66 +1572,24 @@ __global__ __launch_bounds__(256) void spl_scan_apply_kernel(const spl_scan_para
                 else if (f & SPL_SF_MINUS) { b1 = run[1] + v[1][q]; me = run[3] + v[3][q]; }
                 else { b1 = 0; me = 0; } // a row without strand matches no read in a stranded run (:406)
             }
-            if (b1) p.beta1[r] += (uint32_t)b1;
-            if (me) p.beta2s_reads[r] += (uint32_t)me;
-        }
-    }
-}
-
-// =========================================================================================================
-// findBeta2Counts + calculateSSE, one site per lane.  IEEE binary64, compiled with -ffp-contract=off: every
-// operation below is one correctly rounded operation in the reference's order, so the doubles are the ones
-// CPython produces (int/int true division included for |values| < 2^53).
-// =========================================================================================================
-__global__ __launch_bounds__(256) void spl_sse_kernel(const spl_sse_params p)
-{
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= p.n_sites) return;
-    const int64_t t = p.site_pos[s];
-    int64_t b2simple = p.beta2s_reads[s];
-    int64_t cryptic = 0;
-    double weighted = 0.0;
-    const int64_t total_alpha = p.alpha[s];
-    const uint32_t e0 = p.part_off[s], e1 = p.part_off[s + 1];
-    for (uint32_t e = e0; e < e1; ++e) { // for pSite in Partners (:590)
-        const int32_t ps = p.part_site[e];
-        if (ps < 0) continue;
-        const int64_t ppos = p.site_pos[ps];
-        int64_t doubles = p.dbl[e];
-        bool have_key = doubles != 0;
-        const uint32_t f1 = p.part_off[ps + 1];
-        for (uint32_t f = p.part_off[ps]; f < f1; ++f) { // pSite.getPartnerCounts().items() (:592)
-            const int64_t cpos = p.part_pos[f];
-            if ((ppos > t && cpos < t) || (ppos < t && cpos > t)) { // junction (pSite, c) flanks t (:594-599)
-                const int64_t cnt = p.edge_cnt[f];
-                b2simple += cnt;
-                doubles += cnt;
-                have_key = true;
+            // (the literal kernel may have left corrections in the counters: add, do not store)
+            const uint32_t v1 = p.beta1[r] + (uint32_t)b1, v2 = p.beta2s_reads[r] + (uint32_t)me;
+            if (b1) p.beta1[r] = v1;
+            if (me) p.beta2s_reads[r] = v2;
+            if (p.with_sse) { // findBeta2Counts + calculateSSE of the row while its counters are at hand, for both settings of
+                              // --beta2Cryptic (they differ in the last division only): no launch of its own for Step 3's tail
+                int64_t b2simple, cryptic;
+                double weighted;
+                sse_site_core(p.sse, r, v2, b2simple, cryptic, weighted);
+                p.sse.beta2_simple[r] = b2simple;
+                p.sse.beta2_cryptic[r] = cryptic;
+                p.sse.beta2_weighted[r] = weighted;
+                const int64_t total_alpha = p.sse.alpha[r];
+                p.sse.sse[r] = sse_site_value(total_alpha, v1, b2simple, weighted, false);
+                p.sse_with_cryptic[r] = sse_site_value(total_alpha, v1, b2simple, weighted, true);
             }
         }
-        const int64_t shared = p.edge_cnt[e];          // PartnerCounts[pSite.pos] (:604)
-        int64_t b2 = p.alpha[ps] - shared;             // :606
-        if (have_key) { b2 -= doubles; if (b2 < 0) b2 = 0; } // :608-611 subIntNoNeg
-        cryptic += b2;                                 // :613
-        double w = 0.0;                                // trueDivCatchZero (:562-572)
-        if ((double)total_alpha > 0.0) w = (double)shared / (double)total_alpha;
-        const double wb2 = (double)b2 * w;             // :618
-        weighted = weighted + wb2;                     // :619
     }
-    p.beta2_simple[s] = b2simple;
-    p.beta2_cryptic[s] = cryptic;
-    p.beta2_weighted[s] = weighted;
-    const int64_t betas_int = (int64_t)p.beta1[s] + b2simple; // :631
-    double value = 0.0;
-    if (p.cryptic) {
-        const double betas = (double)betas_int + weighted;     // :635
-        const double denom = (double)total_alpha + betas;      // :637
-        if (denom > 0.0) value = (double)total_alpha / denom;
-    } else {
-        const int64_t denom = total_alpha + betas_int;
-        if ((double)denom > 0.0) value = (double)total_alpha / (double)denom;
-    }
-    p.sse[s] = value;
 }
 
 // =========================================================================================================
