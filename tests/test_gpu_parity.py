@@ -144,6 +144,73 @@ def test_gpu_reads_with_non_consuming_ops(ctx, oracle_lib):
     assert int(want[0].sum()) > 1000 and int(want[1].sum()) > 100
 
 
+def test_gpu_twice_spliced_class_limits(ctx, oracle_lib):
+    """The twice-spliced class packs five lengths into three words (aligned < 4096, introns < 2^28): reads on and just beyond
+    those limits, with =/X blocks, soft clips, a deletion instead of an intron, in every neighbourhood (alone, in waves of
+    other classes), all modes, against the oracle."""
+    rng = np.random.default_rng(23)
+    # sites: junction ends of the reads below plus alternatives sharing ends (rivals), both strands
+    base = [1000, 1100, 1400, 1500, 5000, 5100, 5400, 5600, 9000, 9050, 300000000, 300000100]
+    SHIFT = 10000   # (room in front of the first site for the 4095-base blocks)
+    pos = np.array(sorted(set(base + [1050, 1450, 5050, 5500, 9020, 1000 + 4095, 1000 + 4096 + 50])), np.int64) + SHIFT
+    n = len(pos)
+    strand = np.where(np.arange(n) % 3 == 0, ord("-"), ord("+")).astype(np.uint8)
+    # partners: a ring of mutual links over neighbours two apart gives everybody competitors
+    part = [[] for _ in range(n)]
+    for i in range(n):
+        for j in (i + 1, i + 2):
+            if j < n:
+                part[i].append(j)
+                part[j].append(i)
+    part_off = np.zeros(n + 1, np.uint32)
+    np.cumsum([len(x) for x in part], out=part_off[1:])
+    part_site = np.array([j for x in part for j in x], np.int32)
+    part_pos = pos[part_site]
+    comp = [sorted({int(pos[c]) for p_ in x for c in part[p_] if c != i}) for i, x in enumerate(part)]
+    comp_off = np.zeros(n + 1, np.uint32)
+    np.cumsum([len(x) for x in comp], out=comp_off[1:])
+    comp_pos = np.array([c for x in comp for c in x], np.int64)
+    sites_c = native.SiteArrays(pos, strand, part_off, part_pos, comp_off, comp_pos, part_site=part_site)
+
+    def rec(flag, p, *ops):
+        return (flag, p, ops)
+    M, I, D, N, S, EQ, X = 0, 1, 2, 3, 4, 7, 8
+    shapes = [
+        rec(0, 951, (50, M), (100, N), (300, M), (100, N), (60, M)),                   # 1000|1100 .. 1400|1500 ends on sites
+        rec(16, 951, (50, EQ), (100, N), (300, X), (100, N), (60, EQ)),
+        rec(99, 951, (3, S), (50, M), (100, N), (300, M), (100, N), (60, M), (7, S)),   # soft clips: same class after compaction
+        rec(0, 951, (50, M), (100, N), (300, M), (100, D), (60, M)),                    # a deletion where the second intron was
+        rec(0, 951, (50, M), (100, N), (150, M), (2, I), (150, M), (100, N), (60, M)),  # insertion splits the middle block: wide
+        rec(0, 1000 - 4094, (4095, M), (100, N), (300, M), (100, N), (60, M)),          # longest block that fits 12 bits
+        rec(0, 1000 - 4095, (4096, M), (100, N), (300, M), (100, N), (60, M)),          # one more: wide
+        rec(0, 4951, (50, M), (100, N), (300, M), (200, N), (4095, M)),
+        rec(0, 8951, (50, M), (50, N), (30, M), ((1 << 28) - 1, N), (40, M)),         # the longest intron a BAM record can hold
+        rec(147, 8951, (50, M), (50, N), (0, M), (5, N), (40, M)),                    # an empty middle block
+        rec(0, 951, (50, M), (100, N), (300, M)), rec(0, 951, (150, M)), rec(4, 1000, (50, M), (100, N), (300, M), (100, N), (60, M)),
+    ]
+    recs = []
+    for k in range(3000):                        # every shape in every neighbourhood
+        recs.append(shapes[int(rng.integers(0, len(shapes)))])
+    recs += [shapes[0]] * 300 + [shapes[7]] * 200  # and whole waves of the class
+    recs.sort(key=lambda r: r[1])
+    rpos = np.array([r[1] for r in recs], np.int64) + SHIFT
+    rflag = np.array([r[0] for r in recs], np.uint16)
+    off = np.concatenate(([0], np.cumsum([len(r[2]) for r in recs])))
+    cig = np.array([(ln << 4) | code for r in recs for ln, code in r[2]], np.uint32)
+    reads_c = native.ReadArrays(rpos, rflag, off, cig)
+    seen = np.zeros(3, np.int64)
+    for stranded in (0, 1, 2):
+        for combine in (0, 1):
+            want = oracle_lib.check_bam(pos, strand, part_off, part_pos, comp_off, comp_pos, reads_c.pos, reads_c.flag, reads_c.cig_off,
+                                        reads_c.cigar, stranded, combine)
+            for name, flags in KERNELS.items():
+                got = ctx.count(sites_c, reads_c, stranded, combine, flags)
+                for g, w in zip(got, want):
+                    assert np.array_equal(g, w), (stranded, combine, name)
+            seen += [int(w.sum()) for w in want]
+    assert seen[0] > 1000 and seen[1] > 1000 and seen[2] > 0   # beta1, beta2Simple and double counts all exercised
+
+
 def test_gpu_back_to_back_passes_on_one_table(ctx, tmp_path, oracle_lib):
     """The counter region of a device table exists twice and is cleared on the side by the previous pass (or by a clearing
     launch after a pair-kernel pass): a sequence of passes with changing modes and kernels on ONE uploaded table and read set
