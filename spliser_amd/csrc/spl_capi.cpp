@@ -401,7 +401,6 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
             }
     // distinct positions ("dpos"), their 64 bp occupancy buckets and the rival bitmap
     std::vector<int32_t> dfirst;
-    std::vector<uint4> dbucket;
     std::vector<uint32_t> rbits;
     for (int64_t i = 0; i < S; ++i)
         if (i == 0 || s->pos[i] != s->pos[i - 1]) dfirst.push_back((int32_t)i);
@@ -413,28 +412,10 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
         // one empty bucket in front of the first site, one behind the last (first dpos = D): the kernels only clamp
         d->dbase = s->pos[0] >= 64 ? (int32_t)(s->pos[0] - 64) : -64;
         d->n_dbuckets = (uint32_t)(((int64_t)s->pos[S - 1] - (int64_t)d->dbase) >> 6) + 2;
-        dbucket.assign((size_t)d->n_dbuckets, make_uint4(0, 0, 0, 0));
-        int64_t di = 0;
-        for (uint32_t b = 0; b < d->n_dbuckets; ++b) {
-            const int64_t start = (int64_t)d->dbase + ((int64_t)b << 6);
-            while (di < D && (int64_t)s->pos[dfirst[(size_t)di]] < start) ++di;
-            unsigned long long mask = 0;
-            for (int64_t j = di; j < D && (int64_t)s->pos[dfirst[(size_t)j]] < start + 64; ++j)
-                mask |= 1ull << ((int64_t)s->pos[dfirst[(size_t)j]] - start);
-            dbucket[b] = make_uint4((uint32_t)di, 0u, (uint32_t)(mask & 0xffffffffu), (uint32_t)(mask >> 32));
-        }
+        // (the bucket entries themselves are built on the device, spl_build_dbuckets_kernel, once positions and rival bits are there)
         for (int64_t j = 0; j < D; ++j)
             for (int32_t r = dfirst[(size_t)j]; r < dfirst[(size_t)j + 1]; ++r)
                 if (flags[(size_t)r] & SPL_SF_RIVALS) rbits[(size_t)j >> 5] |= 1u << (j & 31);
-        // second word of a bucket entry: bit k = the k-th site position inside the bucket has a rival flag
-        for (uint32_t b = 0; b < d->n_dbuckets; ++b) {
-            const int64_t first = dbucket[b].x;
-            const int n_in = __builtin_popcountll((unsigned long long)dbucket[b].z | ((unsigned long long)dbucket[b].w << 32));
-            uint32_t rm = 0;
-            for (int k = 0; k < n_in && k < 32; ++k)
-                if ((rbits[(size_t)(first + k) >> 5] >> ((first + k) & 31)) & 1u) rm |= 1u << k;
-            dbucket[b].y = rm;
-        }
     }
     std::vector<uint4> jhash, jrivals;
     {
@@ -477,7 +458,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     const size_t o_pos = take(4 * S), o_strand = take(S), o_flags = take(S), o_meta = take(16 * S), o_poff = take(4 * (S + 1));
     const size_t o_ppos = take(4 * P), o_psite = take(4 * P), o_cpos = take(4 * C);
     const size_t o_alpha = take(8 * S), o_ecnt = take(8 * P), o_bucket = take(4 * bucket.size());
-    const size_t o_dfirst = take(4 * dfirst.size()), o_dbucket = take(16 * dbucket.size()), o_rbits = take(4 * rbits.size());
+    const size_t o_dfirst = take(4 * dfirst.size()), o_dbucket = take(16 * (size_t)d->n_dbuckets), o_rbits = take(4 * rbits.size());
     const size_t o_jhash = take(16 * jhash.size()), o_jriv = take(16 * jrivals.size());
     const size_t o_uoff = take(4 * ucl_off.size()), o_upos = take(4 * ucl_pos.size());
     const size_t o_cnt = off;
@@ -522,7 +503,6 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (r == hipSuccess) r = up(d->meta, meta.data(), 16 * S);
     if (r == hipSuccess) r = up(d->flags, flags.data(), S);
     if (r == hipSuccess) r = up(d->dpos_first_row, dfirst.data(), 4 * dfirst.size());
-    if (r == hipSuccess) r = up(d->dbucket, dbucket.data(), 16 * dbucket.size());
     if (r == hipSuccess) r = up(d->rival_bits, rbits.data(), 4 * rbits.size());
     if (r == hipSuccess) r = up(d->jhash, jhash.data(), 16 * jhash.size());
     if (r == hipSuccess) r = up(d->jrivals, jrivals.data(), 16 * jrivals.size());
@@ -536,6 +516,11 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (r == hipSuccess) r = up(d->edge_cnt, s->edge_cnt, 8 * P);
     if (r == hipSuccess) r = up(d->bucket, bucket.data(), 4 * bucket.size());
     if (r == hipSuccess) r = hipMemset(d->slab + o_cnt, 0, d->slab_bytes > o_cnt ? d->slab_bytes - o_cnt : 0);
+    if (r == hipSuccess && S > 0) {
+        r = (hipError_t)spl_dev_launch_build_dbuckets(d->pos, d->dpos_first_row, d->n_dpos, d->rival_bits, d->dbase, d->n_dbuckets, d->dbucket,
+                                                      c->stream);
+        if (r == hipSuccess) r = hipStreamSynchronize(c->stream);
+    }
     if (r != hipSuccess) { (void)hipFree(d->slab); delete d; return spl_set_error(SPL_ERR_HIP, "site table upload: %s", hipGetErrorString(r)); }
     *out = d;
     return SPL_OK;

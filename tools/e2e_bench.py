@@ -11,14 +11,16 @@ os.environ.setdefault("SPL_BAM_TIMING", "1")
 from spliser_amd import native, synth  # noqa: E402
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+workload = sys.argv[2] if len(sys.argv) > 2 else "arabidopsis"
+stranded = bool(synth.WORKLOADS[workload].get("paired"))
 t = time.time()
-wl = synth.Workload("arabidopsis", scale=scale)
+wl = synth.Workload(workload, scale=scale)
 print("generate %.1f s, %d reads" % (time.time() - t, wl.n_reads))
 d = tempfile.mkdtemp(prefix="spl_e2e_")
 prefix = os.path.join(d, "sample")
 t = time.time()
 native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=0)
-synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions)
+synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions, stranded=True)
 synth.write_gff(prefix + ".gff", wl.genome)
 print("write BAM %.1f s, %.1f MB" % (time.time() - t, os.path.getsize(prefix + ".bam") / 1e6))
 out = {"reads": wl.n_reads, "bam_mb": os.path.getsize(prefix + ".bam") / 1e6, "decode": {}}
@@ -32,14 +34,15 @@ for th in (1, 8, 32, 64, 0):
 from spliser_amd.process import process  # noqa: E402
 for rep in range(2):
     t = time.time()
-    timings = process(prefix + ".bam", prefix + ".bed", prefix + "_out", annotationFile=prefix + ".gff", log=lambda m: None)
+    timings = process(prefix + ".bam", prefix + ".bed", prefix + "_out", annotationFile=prefix + ".gff", log=lambda m: None,
+                      isStranded=stranded, strandedType="fr" if stranded else None, isbeta2Cryptic=stranded)
     dt = time.time() - t
     print("process wall %.2f s = %.1f M reads/s end to end; stages %s" % (dt, wl.n_reads / dt / 1e6, {k: round(v, 3) for k, v in timings.items()}))
     out["process_s"] = dt
     out["stages"] = timings
 from spliser_amd.junctions import junctions  # noqa: E402
 t = time.time()
-n_j = junctions(prefix + ".bam", prefix + "_junctions.bed", log=lambda m: None)
+n_j = junctions(prefix + ".bam", prefix + "_junctions.bed", log=lambda m: None, isStranded=stranded, strandedType="fr" if stranded else None)
 out["junctions_s"] = time.time() - t
 print("junctions CLI wall %.2f s, %d junctions" % (out["junctions_s"], n_j))
 b = native.BamFile(prefix + ".bam")
