@@ -590,6 +590,10 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     constexpr uint32_t SEG = 64u * SPL_RPT;
     __shared__ uint16_t s_q[SPL_CHUNK];
     __shared__ uint32_t s_qcnt[NWAVE], s_qbase;
+#ifdef SPL_PHASE_WAVES
+    __shared__ uint64_t s_wave_t[2 * NWAVE];
+    __shared__ uint32_t s_wave_n[NWAVE];
+#endif
     const uint32_t seg0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * SEG; // wave-uniform, in an SGPR
     uint32_t n_front = 0, n_back = 0;
     auto rank_in = [](unsigned long long m) { // how many lanes below mine are in m (mbcnt: no per-lane mask to keep around)
@@ -887,6 +891,12 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 push_back(later, (uint32_t)(it * SPL_BLOCK + tid));
             }
         }
+#ifdef SPL_PHASE_WAVES
+        if ((tid & 63) == 0) { // (development aid: when did each wave leave its loop, how long is its list)
+            s_wave_t[tid >> 6] = wall_clock64();
+            s_wave_n[tid >> 6] = n_back;
+        }
+#endif
         // Once- and twice-spliced reads with rivals, the wave's own, lanes dense: the junction table says which sites of the read's
         // window are affected and how (rivals_inline); what it cannot decide joins the literal list.  The list is read
         // from its growing end, so the front list can only ever grow into entries that are done with.
@@ -921,6 +931,9 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         }
     }
     if ((tid & 63) == 0) s_qcnt[tid >> 6] = n_front;
+#ifdef SPL_PHASE_WAVES
+    if ((tid & 63) == 0) s_wave_t[NWAVE + (tid >> 6)] = wall_clock64();
+#endif
     SPL_PHASE(6);
     __syncthreads();
 #ifdef SPL_PHASE_TAIL
@@ -962,6 +975,19 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         }
     }
     SPL_PHASE(7);
+#ifdef SPL_PHASE_WAVES
+    // slots 1, 3, 4, 5: earliest / latest loop end over the waves, latest list end, longest list
+    {
+        uint64_t lo = ~0ull, hi = 0, hi2 = 0, nmax = 0;
+        for (int w = 0; w < NWAVE; ++w) {
+            lo = s_wave_t[w] < lo ? s_wave_t[w] : lo;
+            hi = s_wave_t[w] > hi ? s_wave_t[w] : hi;
+            hi2 = s_wave_t[NWAVE + w] > hi2 ? s_wave_t[NWAVE + w] : hi2;
+            nmax = s_wave_n[w] > nmax ? s_wave_n[w] : nmax;
+        }
+        ph_[1] = lo; ph_[3] = hi; ph_[4] = hi2; ph_[5] = nmax;
+    }
+#endif
 #ifdef SPL_PHASE_TIMING
     ph_[2] = (uint64_t)__builtin_amdgcn_s_getreg(0xF804) | ((uint64_t)__builtin_amdgcn_s_getreg(0xF814) << 32); // HW_ID, XCC_ID
 #endif
