@@ -475,24 +475,37 @@ __device__ __forceinline__ bool rivals_inline2(const spl_hot_params &p, spl_lds_
                                                const int32_t (&jr)[2], const bool (&flagged)[2], const int32_t (&blk_a)[3],
                                                const int32_t (&blk_b)[3], uint32_t sidx)
 {
+    // the table slots of both junctions (each with its first rival record riding along) in one trip; at load 1/4 the
+    // first probe almost always decides
     uint32_t r_off[2] = {0, 0}, r_n[2] = {0, 0};
+    uint4 ent[2], first[2];
+    uint32_t h[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        h[j] = (uint32_t)jl[j] * 0x9E3779B1u ^ (uint32_t)jr[j] * 0x85EBCA77u;
+        h[j] ^= h[j] >> 15;
+        const uint4 *slot = p.jhash + 2u * (h[j] & p.jhash_mask);
+        ent[j] = slot[0];
+        first[j] = slot[1];
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int32_t l = jl[j], r = jr[j];
-        uint32_t h = (uint32_t)l * 0x9E3779B1u ^ (uint32_t)r * 0x85EBCA77u;
-        h ^= h >> 15;
         bool found = false;
-        uint4 ent = make_uint4(0, 0, 0, 0);
         for (int probe = 0; probe < 8; ++probe) {
-            ent = p.jhash[2u * ((h + (uint32_t)probe) & p.jhash_mask)];
-            if ((int32_t)ent.x == l && (int32_t)ent.y == r) { found = true; break; }
-            if (ent.x == 0x80000000u) break;
+            if (probe) {
+                const uint4 *slot = p.jhash + 2u * ((h[j] + (uint32_t)probe) & p.jhash_mask);
+                ent[j] = slot[0];
+                first[j] = slot[1];
+            }
+            if ((int32_t)ent[j].x == l && (int32_t)ent[j].y == r) { found = true; break; }
+            if (ent[j].x == 0x80000000u) break;
         }
         if (found) {
-            if ((ent.w & SPL_JF_COMPLEX) || (ent.w & 0xffu) > 16u) return false;
-            if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) return false;
-            r_off[j] = ent.z;
-            r_n[j] = ent.w & 0xffu;
+            if ((ent[j].w & SPL_JF_COMPLEX) || (ent[j].w & 0xffu) > 16u) return false;
+            if (!STRANDED && (ent[j].w & SPL_JF_MULTIROW)) return false;
+            r_off[j] = ent[j].z;
+            r_n[j] = ent[j].w & 0xffu;
         } else if (flagged[j]) return false;
     }
     const uint32_t want = sidx ? 2u : 1u;
@@ -500,9 +513,10 @@ __device__ __forceinline__ bool rivals_inline2(const spl_hot_params &p, spl_lds_
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         for (uint32_t i = 0; i < r_n[j]; ++i) {
-            const uint4 rv = p.jrivals[2u * (r_off[j] + i)];
+            const uint4 rv = i ? p.jrivals[2u * (r_off[j] + i)] : first[j];
             bool earlier = false; // listed under the first junction too: handled there
-            if (j == 1) for (uint32_t i2 = 0; i2 < r_n[0]; ++i2) earlier |= (p.jrivals[2u * (r_off[0] + i2)].y == rv.y);
+            if (j == 1)
+                for (uint32_t i2 = 0; i2 < r_n[0]; ++i2) earlier |= ((i2 ? p.jrivals[2u * (r_off[0] + i2)].y : first[0].y) == rv.y);
             if (earlier) continue;
             const int32_t t = (int32_t)rv.x;
             const uint32_t td = rv.y & 0x3fffffffu;
