@@ -1285,7 +1285,7 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
 template <bool STRANDED>
 __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_params p, const spl_queue_params q)
 {
-    __shared__ uint32_t s_ops[64][5 + 1]; // rebuilt CIGARs of twice-spliced reads (+1: rows on different banks)
+    __shared__ uint32_t s_ops[64][SPL_PACK_SCAN_OPS + 1]; // the lane's CIGAR: rebuilt (twice-spliced class) or fetched in one trip (+1: banks)
     // The other copy of the counter region, for the next counting pass (one 16-byte store per lane or so).
     for (size_t j = (size_t)blockIdx.x * 64 + threadIdx.x; j < q.clear_n16; j += (size_t)gridDim.x * 64) q.clear_region[j] = make_uint4(0, 0, 0, 0);
     // Then the block sums of the difference arrays for the scan that follows: the arrays are final once the range kernel
@@ -1341,6 +1341,15 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
                 if (n_ops == SPL_NOPS_SAT) { // the packed count saturates: the true one from the BAM-native offsets
                     const int64_t i = (idx / SPL_CHUNK) * SPL_CHUNK + q.perm[idx];
                     n_ops = p.cig_off[i + 1] - o0;
+                }
+                if (n_ops <= (uint32_t)SPL_PACK_SCAN_OPS) { // the ops are walked several times below: all of them in one trip, then LDS
+                    uint32_t w[SPL_PACK_SCAN_OPS];
+#pragma unroll
+                    for (int k = 0; k < SPL_PACK_SCAN_OPS; ++k) w[k] = ((uint32_t)k < n_ops) ? ops[k] : 0xfu;
+                    uint32_t *row = s_ops[threadIdx.x];
+#pragma unroll
+                    for (int k = 0; k < SPL_PACK_SCAN_OPS; ++k) row[k] = w[k];
+                    ops = row;
                 }
             }
 #ifdef SPL_PHASE_LITERAL
