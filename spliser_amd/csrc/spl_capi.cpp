@@ -321,18 +321,28 @@ static void build_junction_table(const spl_sites *s, const std::vector<uint8_t> 
     // a slot is two quads: {l, r, first rival record, count | flags} and a copy of the first rival's first quad, so that
     // the common one-rival junction costs the range kernel one memory trip instead of two
     jhash.assign(2 * cap, make_uint4(0x80000000u, 0, 0, 0));
+    size_t dropped = 0;
     for (const Junc &j : juncs) {
         uint32_t h = (uint32_t)j.l * 0x9E3779B1u ^ (uint32_t)j.r * 0x85EBCA77u;
         h ^= h >> 15;
+        bool placed = false;
         // the kernel gives up after 8 probes: an entry that cannot be placed within 8 is simply left out (-> literal kernel)
         for (uint32_t probe = 0; probe < 8; ++probe) {
             uint4 *slot = &jhash[2 * ((h + probe) & (cap - 1))];
             if (slot[0].x == 0x80000000u) {
                 slot[0] = make_uint4((uint32_t)j.l, (uint32_t)j.r, j.off, j.info);
                 slot[1] = (j.info & 0xffu) ? jrivals[2 * (size_t)j.off] : make_uint4(0, 0, 0xffffffffu, 0xffffffffu);
+                placed = true;
                 break;
             }
         }
+        if (!placed) ++dropped;
+    }
+    if (getenv("SPL_DEBUG_TABLE")) {
+        size_t complex = 0, multirow = 0, many = 0;
+        for (const Junc &j : juncs) { complex += (j.info & SPL_JF_COMPLEX) != 0; multirow += (j.info & SPL_JF_MULTIROW) != 0; many += (j.info & 0xffu) > 4; }
+        fprintf(stderr, "[junction table] %zu junctions with a flagged end, %zu slots, %zu not placed within 8 probes, %zu complex, %zu multirow, %zu with > 4 rivals\n",
+                juncs.size(), cap, dropped, complex, multirow, many);
     }
     if (jrivals.empty()) jrivals.assign(2, make_uint4(0, 0, 0xffffffffu, 0xffffffffu));
 }
