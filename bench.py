@@ -80,9 +80,12 @@ def main():
     tmp = tempfile.mkdtemp(prefix="spliser_bench_")
     bed = os.path.join(tmp, "junctions.bed")
     synth.write_bed(bed, wl.genome.chrom_names, wl.junctions)
-    table = sites.SiteTable(is_stranded=bool(stranded))
-    table.add_bed(bed)
-    table.find_competitors()
+    from spliser_amd import fast_sites
+    table = fast_sites.build(sites.GeneBins(), bool(stranded), bed)   # the same table `process` builds (Steps 1-2)
+    if table is None:
+        table = sites.SiteTable(is_stranded=bool(stranded))
+        table.add_bed(bed)
+        table.find_competitors()
     names = wl.genome.chrom_names
     items = []
     for i, c in enumerate(names):
