@@ -390,7 +390,8 @@ const uint8_t *parse_segment_parallel(spl_bam *bam, const uint8_t *p, const uint
 {
     const int n_ref = bam->n_refs;
     const size_t bytes = (size_t)(end - p);
-    int T = n_threads > 16 ? 16 : n_threads; // the walk is latency-bound and short: more threads cost more to start than they save
+    static const int cap = []() { const char *e = getenv("SPL_BAM_PARSE_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
+    int T = n_threads > cap ? cap : n_threads; // the walk is latency-bound and short: more threads cost more to start than they save
     if (bytes < (size_t)(8u << 20) || T < 2) T = 1;
     std::vector<std::vector<Sink::Part>> parts((size_t)T);
     std::vector<const uint8_t *> start((size_t)T + 1), reached((size_t)T);
