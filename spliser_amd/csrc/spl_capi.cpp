@@ -45,7 +45,6 @@ struct spl_ctx {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int32_t *d_err = nullptr;               // error word of launches that are not counting passes (spl_junctions)
-    const uint32_t *last_queue_n = nullptr; // queue counters of the last counting pass (spl_literal_queue_size)
     int last_grid = 0, last_lds = 0, last_variant = 0;
     struct Junction { int32_t left, right; uint8_t strand; uint32_t count, anchor_left, anchor_right; };
     std::vector<Junction> junctions; // result of the last spl_junctions call, sorted
@@ -111,6 +110,7 @@ struct spl_dreads {
     uint16_t *perm = nullptr;
     uint32_t *chunk_order = nullptr; // slot of an XCD slice -> chunk, longest first (holds the cost estimates during upload)
     uint32_t *queue = nullptr; // reads the range kernel hands to the literal kernel (the counters are with the site table)
+    mutable const uint32_t *last_queue_n = nullptr; // ... of the last counting pass over this read set (spl_literal_queue_size)
 };
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -662,7 +662,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
         ds->alt_clean = false;
     } else if (int rc0 = spl_dev_launch_clear(ds->beta1, ds->counter_bytes, c->stream))
         return spl_set_error(SPL_ERR_HIP, "clear kernel launch: %s", hipGetErrorString((hipError_t)rc0));
-    c->last_queue_n = ds->queue_n;
+    dr->last_queue_n = ds->queue_n;
     ds->sse_fused = false;
     spl_count_params p;
     memset(&p, 0, sizeof(p));
@@ -874,8 +874,8 @@ extern "C" int spl_literal_queue_size(spl_ctx *c, const spl_dreads *dr, int64_t 
     if (!c || !dr || !n_out) return spl_set_error(SPL_ERR_ARG, "spl_literal_queue_size: null argument");
     HIP_TRY(hipSetDevice(c->device));
     std::vector<uint32_t> counts(8 * SPL_COUNTER_STRIDE);
-    if (!c->last_queue_n) { *n_out = 0; return SPL_OK; }
-    HIP_TRY(hipMemcpyAsync(counts.data(), c->last_queue_n, 4 * counts.size(), hipMemcpyDeviceToHost, c->stream));
+    if (!dr->last_queue_n) { *n_out = 0; return SPL_OK; }
+    HIP_TRY(hipMemcpyAsync(counts.data(), dr->last_queue_n, 4 * counts.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int64_t total = 0;
     for (int k = 0; k < 8; ++k) total += counts[(size_t)k * SPL_COUNTER_STRIDE];
