@@ -23,6 +23,11 @@
 #define SPL_RC_NARROW 3u                 // anything else of at most SPL_INLINE_OPS ops
 #define SPL_RC_WIDE 4u                   // more ops than that
 #define SPL_RC_COUNT 5
+#ifndef SPL_W_SIMPLE                     // what a read of each class costs the range kernel, roughly (chunk order: longest first)
+#define SPL_W_SIMPLE 2u
+#define SPL_W_MNM 5u
+#define SPL_W_M2 9u
+#endif
 #ifndef SPL_BUCKET_AHEAD
 #define SPL_BUCKET_AHEAD 0              // 1: prefetch the next read's bucket entries too (registers!)
 #endif

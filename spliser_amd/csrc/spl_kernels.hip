@@ -1476,8 +1476,8 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_rea
     // what the chunk will cost the range kernel, roughly (instructions per read of each class): the host orders the chunks of
     // every XCD slice longest first, so that the last workgroups of a launch are the short ones
     if (tid == 0)
-        chunk_cost[blockIdx.x] = 2u * total[SPL_RC_SIMPLE] + 5u * total[SPL_RC_MNM] + 9u * total[SPL_RC_M2] + 6u * total[SPL_RC_NARROW] +
-                                 14u * total[SPL_RC_WIDE];
+        chunk_cost[blockIdx.x] = SPL_W_SIMPLE * total[SPL_RC_SIMPLE] + SPL_W_MNM * total[SPL_RC_MNM] + SPL_W_M2 * total[SPL_RC_M2] +
+                                 6u * total[SPL_RC_NARROW] + 14u * total[SPL_RC_WIDE];
 #pragma unroll
     for (int it = 0; it < SPL_RPT; ++it) {
         const int c = cls[it];
