@@ -74,7 +74,8 @@ struct spl_dsites {
     int32_t diff_stride = 0, scan_blocks = 0;
     int32_t n_dpos = 0;        // distinct site positions
     int32_t *dpos_first_row = nullptr; // [n_dpos + 1]
-    uint4 *dbucket = nullptr;  // 64 bp buckets {first dpos, -, occupancy mask}
+    uint2 *dbucket = nullptr;  // 32 bp buckets {first dpos, occupancy mask}
+    uint32_t *drival = nullptr; // per bucket: positions that are sites with rivals
     uint32_t n_dbuckets = 0;
     int32_t dbase = 0;         // coordinate of the first (empty) bucket
     uint32_t *rival_bits = nullptr;
@@ -421,7 +422,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (S > 0) {
         // one empty bucket in front of the first site, one behind the last (first dpos = D): the kernels only clamp
         d->dbase = s->pos[0] >= 64 ? (int32_t)(s->pos[0] - 64) : -64;
-        d->n_dbuckets = (uint32_t)(((int64_t)s->pos[S - 1] - (int64_t)d->dbase) >> 6) + 2;
+        d->n_dbuckets = (uint32_t)(((int64_t)s->pos[S - 1] - (int64_t)d->dbase) >> 5) + 2;
         // (the bucket entries themselves are built on the device, spl_build_dbuckets_kernel, once positions and rival bits are there)
         for (int64_t j = 0; j < D; ++j)
             for (int32_t r = dfirst[(size_t)j]; r < dfirst[(size_t)j + 1]; ++r)
@@ -468,7 +469,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     const size_t o_pos = take(4 * S), o_strand = take(S), o_flags = take(S), o_meta = take(16 * S), o_poff = take(4 * (S + 1));
     const size_t o_ppos = take(4 * P), o_psite = take(4 * P), o_cpos = take(4 * C);
     const size_t o_alpha = take(8 * S), o_ecnt = take(8 * P), o_bucket = take(4 * bucket.size());
-    const size_t o_dfirst = take(4 * dfirst.size()), o_dbucket = take(16 * (size_t)d->n_dbuckets), o_rbits = take(4 * rbits.size());
+    const size_t o_dfirst = take(4 * dfirst.size()), o_dbucket = take(8 * (size_t)d->n_dbuckets), o_drival = take(4 * (size_t)d->n_dbuckets), o_rbits = take(4 * rbits.size());
     const size_t o_jhash = take(16 * jhash.size()), o_jriv = take(16 * jrivals.size());
     const size_t o_uoff = take(4 * ucl_off.size()), o_upos = take(4 * ucl_pos.size());
     const size_t o_cnt = off;
@@ -484,7 +485,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the site table: %s", d->slab_bytes, hipGetErrorString(e)); }
     d->pos = (int32_t *)(d->slab + o_pos); d->strand = (uint8_t *)(d->slab + o_strand); d->meta = (uint4 *)(d->slab + o_meta);
     d->flags = (uint8_t *)(d->slab + o_flags); d->diff = (int32_t *)(d->slab + o_diff); d->block_sums = (int32_t *)(d->slab + o_bsum);
-    d->dpos_first_row = (int32_t *)(d->slab + o_dfirst); d->dbucket = (uint4 *)(d->slab + o_dbucket); d->rival_bits = (uint32_t *)(d->slab + o_rbits);
+    d->dpos_first_row = (int32_t *)(d->slab + o_dfirst); d->dbucket = (uint2 *)(d->slab + o_dbucket); d->drival = (uint32_t *)(d->slab + o_drival); d->rival_bits = (uint32_t *)(d->slab + o_rbits);
     d->jhash = (uint4 *)(d->slab + o_jhash); d->jrivals = (uint4 *)(d->slab + o_jriv);
     d->ucl_off = (uint32_t *)(d->slab + o_uoff); d->ucl_pos = (int32_t *)(d->slab + o_upos);
     d->part_off = (uint32_t *)(d->slab + o_poff); d->part_pos = (int32_t *)(d->slab + o_ppos); d->part_site = (int32_t *)(d->slab + o_psite);
@@ -527,7 +528,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (r == hipSuccess) r = up(d->bucket, bucket.data(), 4 * bucket.size());
     if (r == hipSuccess) r = hipMemset(d->slab + o_cnt, 0, d->slab_bytes > o_cnt ? d->slab_bytes - o_cnt : 0);
     if (r == hipSuccess && S > 0) {
-        r = (hipError_t)spl_dev_launch_build_dbuckets(d->pos, d->dpos_first_row, d->n_dpos, d->rival_bits, d->dbase, d->n_dbuckets, d->dbucket,
+        r = (hipError_t)spl_dev_launch_build_dbuckets(d->pos, d->dpos_first_row, d->n_dpos, d->rival_bits, d->dbase, d->n_dbuckets, d->dbucket, d->drival,
                                                       c->stream);
         if (r == hipSuccess) r = hipStreamSynchronize(c->stream);
     }
@@ -673,13 +674,13 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.site_pos = ds->pos; p.site_strand = ds->strand; p.site_flags = ds->flags; p.site_meta = ds->meta;
     p.part_pos = ds->part_pos; p.part_site = ds->part_site; p.comp_pos = ds->comp_pos;
     p.diff = ds->diff; p.diff_stride = ds->diff_stride;
-    p.dbucket = ds->dbucket; p.n_dbuckets = ds->n_dbuckets; p.dbase = ds->dbase; p.n_dpos = ds->n_dpos;
+    p.dbucket = ds->dbucket; p.drival = ds->drival; p.n_dbuckets = ds->n_dbuckets; p.dbase = ds->dbase; p.n_dpos = ds->n_dpos;
     p.rival_bits = ds->rival_bits; p.dpos_first_row = ds->dpos_first_row; p.ucl_off = ds->ucl_off; p.ucl_pos = ds->ucl_pos;
     p.jhash = ds->jhash; p.jhash_mask = ds->jhash_mask; p.jrivals = ds->jrivals;
     spl_hot_params h;
     memset(&h, 0, sizeof(h));
     h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos_orig = p.r_pos; h.r_pos = dr->ppos; h.perm = dr->perm; h.chunk_order = dr->chunk_order; h.part_pos = ds->part_pos; h.r_fn = dr->fn; h.r_ops3 = dr->ops3; h.cig_off = p.cig_off; h.cigar = p.cigar;
-    h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.n_cigar = (uint32_t)dr->n_cigar;
+    h.dbucket = p.dbucket; h.drival = p.drival; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.n_cigar = (uint32_t)dr->n_cigar;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = dr->queue; h.queue_n = ds->queue_n; h.err = ds->err;
     h.queue_cap = (uint32_t)(((p.n_chunks + 7u) / 8u) * SPL_CHUNK);

@@ -28,9 +28,6 @@
 #define SPL_W_MNM 5u
 #define SPL_W_M2 9u
 #endif
-#ifndef SPL_BUCKET_AHEAD
-#define SPL_BUCKET_AHEAD 0              // 1: prefetch the next read's bucket entries too (registers!)
-#endif
 #ifndef SPL_RPT
 #define SPL_RPT 8                        // reads per thread
 #endif
@@ -86,7 +83,8 @@ struct spl_count_params {
     int32_t bucket_base;
     int32_t bucket_shift;
     // position -> distinct-position index (range kernel): 64 bp buckets {first dpos, -, occupancy mask lo, hi}
-    const uint4 *dbucket;
+    const uint2 *dbucket;      // 32 bp buckets: {first dpos at or after the bucket start, occupancy mask}
+    const uint32_t *drival;    // per bucket: which of its positions are sites with rivals
     uint32_t n_dbuckets;
     int32_t dbase;
     int32_t n_dpos;
@@ -124,7 +122,8 @@ struct spl_hot_params {
                                  // for longer reads {op0, op1, index of op2 in cigar[]}
     const uint32_t *cig_off;     // only for reads with >= 65535 ops
     const uint32_t *cigar;
-    const uint4 *dbucket;
+    const uint2 *dbucket;      // 32 bp buckets: {first dpos at or after the bucket start, occupancy mask}
+    const uint32_t *drival;    // per bucket: which of its positions are sites with rivals
     uint32_t n_dbuckets;
     int32_t dbase;
     int32_t n_dpos;
@@ -207,7 +206,7 @@ int spl_dev_launch_junctions(int64_t n_reads, const int32_t *pos, const uint16_t
                              uint32_t *vals, uint32_t n_slots, unsigned long long *out_keys,
                              uint32_t *out_vals, uint32_t *n_out, int32_t *err, void *stream);
 int spl_dev_launch_build_dbuckets(const int32_t *site_pos, const int32_t *dpos_first_row, int32_t n_dpos, const uint32_t *rival_bits,
-                                  int32_t dbase, uint32_t n_dbuckets, uint4 *out, void *stream);
+                                  int32_t dbase, uint32_t n_dbuckets, uint2 *out, uint32_t *out_rival, void *stream);
 int spl_dev_launch_rebase(int32_t *pos, uint32_t *cig_off, int64_t n, int32_t shift, uint32_t cig_base, void *stream);
 int spl_dev_launch_clear(void *region, size_t bytes, void *stream);
 int spl_dev_launch_literal(const spl_count_params *p, const spl_queue_params *q, void *stream);

@@ -323,41 +323,38 @@ __device__ __forceinline__ void unmapped_read(const spl_count_params &p, int32_t
 }
 
 // Position -> distinct-position index ("dpos": rows sharing a position, e.g. the '+' and '-' site of a stranded
-// table, share one index).  64 bp buckets, one 16-byte entry each: {dpos of the first site at or after the bucket
-// start, unused, 64-bit occupancy mask}.  One load answers both "how many site positions are < x" and "is x a
-// site" with a popcount -- no dependent second access, so all boundaries of a read resolve in one memory trip.
+// table, share one index).  32 bp buckets, one 8-byte entry each: {dpos of the first site at or after the bucket
+// start, occupancy mask of the bucket's 32 positions}.  One load answers both "how many site positions are < x" and
+// "is x a site" with a popcount -- no dependent second access, so all boundaries of a read resolve in one memory
+// trip, in four instructions each (bit-field mask, and, counting add, bit-field extract).  Which of the bucket's
+// positions are sites WITH RIVALS is a second array of 32-bit masks, asked only for junction ends.
 template <class P>
 __device__ __forceinline__ uint32_t dbk_slot(const P &p, int32_t x)
 {
-    // the table starts one empty bucket before the first site (dbase >= -64) and ends with an empty bucket whose first
+    // the table starts with empty buckets before the first site (dbase >= -64) and ends with an empty bucket whose first
     // dpos is n_dpos, so clamping the index is all the range handling there is; x - dbase cannot wrap because
     // coordinates stay <= SPL_COORD_MAX = 2^31 - 67
-    int32_t b = (x - p.dbase) >> 6;
+    int32_t b = (x - p.dbase) >> 5;
     b = b < 0 ? 0 : b;
     const int32_t last = (int32_t)p.n_dbuckets - 1;
     return (uint32_t)(b > last ? last : b);
 }
 
-// e.y: bit j = the j-th site position of the bucket has a rival flag (conservatively all ones past 32 sites).
-// For x outside the table the clamped entry is an empty bucket: count 0, not a site, whatever `bit` says.
+// For x outside the table the clamped entry is an empty bucket: count 0, not a site, whatever the bit index says.
 template <class P>
-__device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint4 e, int32_t &u, uint32_t &nv, uint32_t &rv)
+__device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint2 e, int32_t &u, uint32_t &nv)
 {
-    const uint32_t bit = (uint32_t)(x - p.dbase) & 63u;
-    const bool upper = bit >= 32u;
-    const uint32_t sh = bit & 31u;
-    const uint32_t below = (1u << sh) - 1u;
-    const uint32_t cnt = __popc(e.z & (upper ? 0xffffffffu : below)) + __popc(e.w & (upper ? below : 0u));
-    u = (int32_t)(e.x + cnt);
-    nv = ((upper ? e.w : e.z) >> sh) & 1u;
-    rv = cnt < 32u ? ((e.y >> cnt) & 1u) : 1u;
+    const uint32_t bit = (uint32_t)(x - p.dbase) & 31u;
+    u = (int32_t)(e.x + (uint32_t)__popc(e.y & ((1u << bit) - 1u)));
+    nv = (e.y >> bit) & 1u;
 }
 
+// The same with the rival mask of the bucket: rv = x is a site that has rivals.
 template <class P>
-__device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint4 e, int32_t &u, uint32_t &nv)
+__device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint2 e, uint32_t rm, int32_t &u, uint32_t &nv, uint32_t &rv)
 {
-    uint32_t rv;
-    dbk_resolve(p, x, e, u, nv, rv);
+    dbk_resolve(p, x, e, u, nv);
+    rv = (rm >> ((uint32_t)(x - p.dbase) & 31u)) & 1u;
 }
 
 typedef __attribute__((address_space(3))) int32_t spl_lds_i32; // the difference windows, typed as what they are: LDS
@@ -600,7 +597,6 @@ template <bool STRANDED, bool AGG>
 __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ? 4 : 8, 8))) void spl_count_ranges_kernel(const spl_hot_params p)
 {
     constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
-    constexpr bool AHEAD = SPL_BUCKET_AHEAD != 0;
     __shared__ int32_t lds_words[NARR * (SPL_WIN + 1)];
     spl_lds_i32 *const lds = (spl_lds_i32 *)lds_words;
     // Each wave owns one segment of s_q (as many entries as it has reads) with two lists of chunk-relative packed slots:
@@ -642,7 +638,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     SPL_PHASE(0);
 
     // Pipeline over the chunk's reads: while read `it` is worked on the packed words of the next read are in flight
-    // (SPL_BUCKET_AHEAD: also its bucket entries, at the price of 25 more registers -- measured slower, occupancy 4).
+    // (its bucket entries too was tried: 25 more registers, occupancy 4, slower).
     auto fetch_read = [&](int it, int32_t &f_pos, uint32_t &f_fn, uint32_t (&f_op)[SPL_INLINE_OPS]) {
         const int64_t ii = live ? chunk_base + (int64_t)it * SPL_BLOCK + tid : 0; // (the packed arrays are padded to whole chunks)
         f_pos = ld_stream(&p.r_pos[ii]);                                         // ---- trip 1: 20 bytes per read
@@ -650,27 +646,10 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
 #pragma unroll
         for (int k = 0; k < SPL_INLINE_OPS; ++k) f_op[k] = ld_stream(&p.r_ops3[3 * ii + k]);
     };
-    // ---- trip 2: bucket entries of the start boundary and of every inline op end (slots are clamped: always legal).
-    //      The ends are recomputed when the read is worked on; for a read that turns out bad the entries go unused.
-    auto fetch_buckets = [&](int32_t f_pos, uint32_t f_fn, const uint32_t (&f_op)[SPL_INLINE_OPS], uint4 (&f_e)[SPL_INLINE_OPS + 1]) {
-        const bool wide = (f_fn >> SPL_RC_SHIFT) == SPL_RC_WIDE;
-        uint32_t len = 0;
-        f_e[0] = p.dbucket[dbk_slot(p, f_pos - 1)];
-#pragma unroll
-        for (int k = 0; k < SPL_INLINE_OPS; ++k) {
-            const uint32_t o = (k == 2 && wide) ? 0xfu : f_op[k];
-            const uint32_t kd = (SPL_KIND_TABLE >> (2u * (o & 15u))) & 3u;
-            len += kd ? (o >> 4) : 0u;
-            f_e[k + 1] = p.dbucket[dbk_slot(p, (int32_t)((uint32_t)f_pos + len) - 1)];
-        }
-    };
-    int32_t cu_pos, nx_pos = 0;
-    uint32_t cu_fn, nx_fn = 0, cu_op[SPL_INLINE_OPS], nx_op[SPL_INLINE_OPS];
-    uint4 cu_e[SPL_INLINE_OPS + 1];
+    int32_t cu_pos;
+    uint32_t cu_fn, cu_op[SPL_INLINE_OPS];
     fetch_read(0, cu_pos, cu_fn, cu_op);
-    if (AHEAD && SPL_RPT > 1) fetch_read(1, nx_pos, nx_fn, nx_op);
     const int32_t first_pos = p.r_pos_orig[live ? chunk_base : 0]; // wave-uniform: the window base of the chunk
-    if (AHEAD) fetch_buckets(cu_pos, cu_fn, cu_op, cu_e);
     int32_t wbase = 0;
     { uint32_t nv; dbk_resolve(p, first_pos - 1, p.dbucket[dbk_slot(p, first_pos - 1)], wbase, nv); }
     for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) lds[j] = 0;
@@ -692,34 +671,19 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             const int32_t pos = cu_pos;
             const uint32_t fn = cu_fn;
             uint32_t op[SPL_INLINE_OPS];
-            uint4 e0, ek[SPL_INLINE_OPS];
 #pragma unroll
             for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = cu_op[k];
-            if (AHEAD) {
-                e0 = cu_e[0];
-#pragma unroll
-                for (int k = 0; k < SPL_INLINE_OPS; ++k) ek[k] = cu_e[k + 1];
-                // next read's buckets, next-but-one read's words
-                if (it + 1 < SPL_RPT) {
-                    cu_pos = nx_pos; cu_fn = nx_fn;
-#pragma unroll
-                    for (int k = 0; k < SPL_INLINE_OPS; ++k) cu_op[k] = nx_op[k];
-                    fetch_buckets(cu_pos, cu_fn, cu_op, cu_e);
-                }
-                if (it + 2 < SPL_RPT) fetch_read(it + 2, nx_pos, nx_fn, nx_op);
-            } else {
-                if (it + 1 < SPL_RPT) fetch_read(it + 1, cu_pos, cu_fn, cu_op); // next read's words
-            }
+            if (it + 1 < SPL_RPT) fetch_read(it + 1, cu_pos, cu_fn, cu_op); // next read's words
             const uint32_t flag = fn & 0xffffu;
             const uint32_t cls = fn >> SPL_RC_SHIFT;
             // ---- a wave of simple reads (one aligned op, mapped, in range: the pack kernel checked all that and put them
             //      first in the chunk) takes the short road: two boundaries, one range, nothing else can happen
             if (__all(cls == SPL_RC_SIMPLE)) {
                 const int32_t c1 = pos + (int32_t)(op[0] >> 4);
-                if (!AHEAD) { e0 = p.dbucket[dbk_slot(p, pos - 1)]; ek[0] = p.dbucket[dbk_slot(p, c1 - 1)]; }
+                const uint2 e0 = p.dbucket[dbk_slot(p, pos - 1)], e1 = p.dbucket[dbk_slot(p, c1 - 1)]; // ---- trip 2
                 int32_t ua, ub; uint32_t nva, nvb;
                 dbk_resolve(p, pos - 1, e0, ua, nva);
-                dbk_resolve(p, c1 - 1, ek[0], ub, nvb);
+                dbk_resolve(p, c1 - 1, e1, ub, nvb);
                 const int32_t lo = ua + (int32_t)nva;
                 const bool emit = alive && ub > lo;
                 uint32_t arr = 0;
@@ -734,19 +698,16 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             //      and the junction-table look-up when an end of the junction has rivals
             if (__all(cls == SPL_RC_MNM)) {
                 const int32_t c0 = pos + (int32_t)(op[0] >> 4), c1 = c0 + (int32_t)(op[1] >> 4), c2 = c1 + (int32_t)(op[2] >> 4);
-                if (!AHEAD) {
-                    e0 = p.dbucket[dbk_slot(p, pos - 1)];
-                    ek[0] = p.dbucket[dbk_slot(p, c0 - 1)];
-                    ek[1] = p.dbucket[dbk_slot(p, c1 - 1)];
-                    ek[2] = p.dbucket[dbk_slot(p, c2 - 1)];
-                }
+                const uint32_t s1 = dbk_slot(p, c0 - 1), s2 = dbk_slot(p, c1 - 1);
+                const uint2 e0 = p.dbucket[dbk_slot(p, pos - 1)], e1 = p.dbucket[s1], e2 = p.dbucket[s2], e3 = p.dbucket[dbk_slot(p, c2 - 1)];
+                const uint32_t rm1 = p.drival[s1], rm2 = p.drival[s2]; // (the junction ends: which sites there have rivals)
                 uint32_t sidx = 0;
                 if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
                 const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx;
                 // boundary by boundary, so that a bucket entry dies as soon as it is resolved (the kernel lives on 64 VGPRs)
-                int32_t ua, ub; uint32_t nva, nvb, rva, rvb, nv1, rv1;
-                dbk_resolve(p, pos - 1, e0, ua, nva, rva);
-                dbk_resolve(p, c0 - 1, ek[0], ub, nvb, rvb);
+                int32_t ua, ub; uint32_t nva, nvb, rvb, nv1, rv1;
+                dbk_resolve(p, pos - 1, e0, ua, nva);
+                dbk_resolve(p, c0 - 1, e1, rm1, ub, nvb, rvb);
                 {
                     const int32_t lo = ua + (int32_t)nva;
                     const bool em = alive && ub > lo;
@@ -757,7 +718,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 }
                 nv1 = nvb; rv1 = rvb;
                 ua = ub; nva = nvb;
-                dbk_resolve(p, c1 - 1, ek[1], ub, nvb, rvb);
+                dbk_resolve(p, c1 - 1, e2, rm2, ub, nvb, rvb);
                 {
                     const int32_t lo = ua + (int32_t)nva;
                     const bool em = alive && ub > lo;
@@ -768,7 +729,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 }
                 const uint32_t nv2 = nvb, rv2 = rvb;
                 ua = ub; nva = nvb;
-                dbk_resolve(p, c2 - 1, ek[2], ub, nvb);
+                dbk_resolve(p, c2 - 1, e3, ub, nvb);
                 {
                     const int32_t lo = ua + (int32_t)nva;
                     const bool em = alive && ub > lo;
@@ -797,9 +758,11 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 uint32_t sidx2 = 0;
                 if (STRANDED) sidx2 = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
                 const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx2;
-                uint4 f0 = p.dbucket[dbk_slot(p, pos - 1)], f1 = p.dbucket[dbk_slot(p, c0 - 1)];
-                uint4 f2 = p.dbucket[dbk_slot(p, c1 - 1)], f3 = p.dbucket[dbk_slot(p, c2 - 1)];
-                int32_t ua, ub; uint32_t nva, nvb, rva, rvb;
+                const uint32_t s1 = dbk_slot(p, c0 - 1), s2 = dbk_slot(p, c1 - 1), s3 = dbk_slot(p, c2 - 1), s4 = dbk_slot(p, c3 - 1);
+                uint2 f0 = p.dbucket[dbk_slot(p, pos - 1)], f1 = p.dbucket[s1];
+                const uint2 f2 = p.dbucket[s2], f3 = p.dbucket[s3];
+                const uint32_t rm1 = p.drival[s1], rm2 = p.drival[s2], rm3 = p.drival[s3]; // (the junction ends)
+                int32_t ua, ub; uint32_t nva, nvb, rvb;
                 uint32_t fl1 = 0, fl2 = 0; // junction 1 / 2 has an end with rivals
                 auto range = [&](uint32_t arr) {
                     const int32_t lo = ua + (int32_t)nva;
@@ -810,22 +773,23 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                     }
                     ua = ub; nva = nvb;
                 };
-                dbk_resolve(p, pos - 1, f0, ua, nva, rva);
-                dbk_resolve(p, c0 - 1, f1, ub, nvb, rvb);
+                dbk_resolve(p, pos - 1, f0, ua, nva);
+                dbk_resolve(p, c0 - 1, f1, rm1, ub, nvb, rvb);
                 range(sidx2);                       // block 1
                 fl1 |= nvb & rvb;
-                f0 = p.dbucket[dbk_slot(p, c3 - 1)]; // the second trip, under way while the first is worked off
+                f0 = p.dbucket[s4];                  // the second trip, under way while the first is worked off
                 f1 = p.dbucket[dbk_slot(p, c4 - 1)];
-                dbk_resolve(p, c1 - 1, f2, ub, nvb, rvb);
+                const uint32_t rm4 = p.drival[s4];
+                dbk_resolve(p, c1 - 1, f2, rm2, ub, nvb, rvb);
                 range(a_me);                        // intron 1
                 fl1 |= nvb & rvb;
-                dbk_resolve(p, c2 - 1, f3, ub, nvb, rvb);
+                dbk_resolve(p, c2 - 1, f3, rm3, ub, nvb, rvb);
                 range(sidx2);                       // block 2
                 fl2 |= nvb & rvb;
-                dbk_resolve(p, c3 - 1, f0, ub, nvb, rvb);
+                dbk_resolve(p, c3 - 1, f0, rm4, ub, nvb, rvb);
                 range(a_me);                        // intron 2
                 fl2 |= nvb & rvb;
-                dbk_resolve(p, c4 - 1, f1, ub, nvb, rvb);
+                dbk_resolve(p, c4 - 1, f1, ub, nvb);
                 range(sidx2);                       // block 3
                 const bool flagged = m2 && ((fl1 | fl2) != 0u);
                 if (__any(flagged)) {
@@ -873,16 +837,16 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                         kind[k] = alive ? kd : 0u;
                     }
                 }
-                if (!AHEAD || !first) { // ---- trip 2 (see fetch_buckets)
-                    if (first) e0 = p.dbucket[dbk_slot(p, pos - 1)];
+                uint2 e0 = make_uint2(0, 0), ek[SPL_INLINE_OPS]; // ---- trip 2: the boundaries' bucket entries and rival masks
+                uint32_t r0 = 0, rk[SPL_INLINE_OPS];
+                if (first) { const uint32_t sl = dbk_slot(p, pos - 1); e0 = p.dbucket[sl]; r0 = p.drival[sl]; }
 #pragma unroll
-                    for (int k = 0; k < SPL_INLINE_OPS; ++k) ek[k] = p.dbucket[dbk_slot(p, cend[k] - 1)];
-                }
-                if (first) dbk_resolve(p, pos - 1, e0, pu, pnv, prv);
+                for (int k = 0; k < SPL_INLINE_OPS; ++k) { const uint32_t sl = dbk_slot(p, cend[k] - 1); ek[k] = p.dbucket[sl]; rk[k] = p.drival[sl]; }
+                if (first) dbk_resolve(p, pos - 1, e0, r0, pu, pnv, prv);
 #pragma unroll
                 for (int k = 0; k < SPL_INLINE_OPS; ++k) {
                     int32_t u; uint32_t nv, rv;
-                    dbk_resolve(p, cend[k] - 1, ek[k], u, nv, rv);
+                    dbk_resolve(p, cend[k] - 1, ek[k], rk[k], u, nv, rv);
                     const uint32_t kk = (first || mine) ? kind[k] : 0u;
                     const int32_t lo = pu + (int32_t)pnv; // first dpos at or after the op's first base
                     const bool emit = kk != 0u && kk != 3u && u > lo;
@@ -1226,10 +1190,10 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
             r_off[j] = ent.z; r_n[j] = ent.w & 0xffu;
         } else { // not a listed junction: fine only when neither end has a rival flag
             int32_t u; uint32_t nv, rv;
-            dbk_resolve(p, l, p.dbucket[dbk_slot(p, l)], u, nv, rv);
+            { const uint32_t sl = dbk_slot(p, l); dbk_resolve(p, l, p.dbucket[sl], p.drival[sl], u, nv, rv); }
             // a rival t would need this end in P_t and the other end in C_t: the union list of the end decides
             if ((nv & rv) && ucl_contains(p, u, r)) SPL_TP_FAIL(7);
-            dbk_resolve(p, r, p.dbucket[dbk_slot(p, r)], u, nv, rv);
+            { const uint32_t sl = dbk_slot(p, r); dbk_resolve(p, r, p.dbucket[sl], p.drival[sl], u, nv, rv); }
             if ((nv & rv) && ucl_contains(p, u, l)) SPL_TP_FAIL(7);
         }
     }
@@ -1753,30 +1717,30 @@ __global__ __launch_bounds__(256) void spl_junction_compact_kernel(const unsigne
     out_vals[3u * at + 2u] = vals[3u * j + 2u];
 }
 
-// The position index of a site table (see dbk_slot / dbk_resolve), built where it lives: one thread per 64 bp bucket finds the
-// first distinct position at or after the bucket start by bisection and collects occupancy and rival bits of the positions
-// inside.  (On the host this was a serial sweep over extent / 64 buckets: 0.3 s for a mammalian genome.)
+// The position index of a site table (see dbk_slot / dbk_resolve), built where it lives: one thread per 32 bp bucket finds the
+// first distinct position at or after the bucket start by bisection and collects occupancy and rival masks of the positions
+// inside.  (On the host this was a serial sweep over all buckets: 0.3 s for a mammalian genome.)
 __global__ __launch_bounds__(256) void spl_build_dbuckets_kernel(const int32_t *site_pos, const int32_t *dpos_first_row, int32_t n_dpos,
-                                                                 const uint32_t *rival_bits, int32_t dbase, uint32_t n_dbuckets, uint4 *out)
+                                                                 const uint32_t *rival_bits, int32_t dbase, uint32_t n_dbuckets, uint2 *out,
+                                                                 uint32_t *out_rival)
 {
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b >= n_dbuckets) return;
-    const int64_t start = (int64_t)dbase + ((int64_t)b << 6);
+    const int64_t start = (int64_t)dbase + ((int64_t)b << 5);
     int32_t lo = 0, hi = n_dpos;
     while (lo < hi) {
         const int32_t mid = lo + ((hi - lo) >> 1);
         if ((int64_t)site_pos[dpos_first_row[mid]] < start) lo = mid + 1; else hi = mid;
     }
-    unsigned long long mask = 0;
-    uint32_t rm = 0;
-    int k = 0;
-    for (int32_t j = lo; j < n_dpos; ++j, ++k) {
+    uint32_t mask = 0, rm = 0;
+    for (int32_t j = lo; j < n_dpos; ++j) {
         const int64_t pj = site_pos[dpos_first_row[j]];
-        if (pj >= start + 64) break;
-        mask |= 1ull << (pj - start);
-        if (k < 32 && ((rival_bits[j >> 5] >> (j & 31)) & 1u)) rm |= 1u << k; // bit k = the k-th position inside the bucket has rivals
+        if (pj >= start + 32) break;
+        mask |= 1u << (pj - start);
+        if ((rival_bits[j >> 5] >> (j & 31)) & 1u) rm |= 1u << (pj - start); // the site at this position has rivals
     }
-    out[b] = make_uint4((uint32_t)lo, rm, (uint32_t)(mask & 0xffffffffu), (uint32_t)(mask >> 32));
+    out[b] = make_uint2((uint32_t)lo, mask);
+    out_rival[b] = rm;
 }
 
 // A read segment (one chromosome of a shard) was copied into place as it is; this moves it into the shard's coordinate
@@ -1820,11 +1784,11 @@ extern "C" int spl_dev_launch_junctions(int64_t n_reads, const int32_t *pos, con
 }
 
 extern "C" int spl_dev_launch_build_dbuckets(const int32_t *site_pos, const int32_t *dpos_first_row, int32_t n_dpos, const uint32_t *rival_bits,
-                                             int32_t dbase, uint32_t n_dbuckets, uint4 *out, void *stream)
+                                             int32_t dbase, uint32_t n_dbuckets, uint2 *out, uint32_t *out_rival, void *stream)
 {
     if (n_dbuckets == 0) return 0;
     hipLaunchKernelGGL(spl_build_dbuckets_kernel, dim3((n_dbuckets + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, site_pos, dpos_first_row,
-                       n_dpos, rival_bits, dbase, n_dbuckets, out);
+                       n_dpos, rival_bits, dbase, n_dbuckets, out, out_rival);
     return (int)hipGetLastError();
 }
 
