@@ -673,7 +673,10 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             uint32_t op[SPL_INLINE_OPS];
 #pragma unroll
             for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = cu_op[k];
-            if (it + 1 < SPL_RPT) fetch_read(it + 1, cu_pos, cu_fn, cu_op); // next read's words
+            // (the next read's words are asked for right AFTER this read's bucket entries, in each path: memory operations
+            //  retire in order, and the entries must not wait for the stream; no branch around it -- the last read asks for
+            //  itself again -- so that the wait counts are the same on every way here)
+            auto fetch_next = [&]() { fetch_read(it + 1 < SPL_RPT ? it + 1 : it, cu_pos, cu_fn, cu_op); };
             const uint32_t flag = fn & 0xffffu;
             const uint32_t cls = fn >> SPL_RC_SHIFT;
             // ---- a wave of simple reads (one aligned op, mapped, in range: the pack kernel checked all that and put them
@@ -681,6 +684,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             if (__all(cls == SPL_RC_SIMPLE)) {
                 const int32_t c1 = pos + (int32_t)(op[0] >> 4);
                 const uint2 e0 = p.dbucket[dbk_slot(p, pos - 1)], e1 = p.dbucket[dbk_slot(p, c1 - 1)]; // ---- trip 2
+                fetch_next();
                 int32_t ua, ub; uint32_t nva, nvb;
                 dbk_resolve(p, pos - 1, e0, ua, nva);
                 dbk_resolve(p, c1 - 1, e1, ub, nvb);
@@ -701,6 +705,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 const uint32_t s1 = dbk_slot(p, c0 - 1), s2 = dbk_slot(p, c1 - 1);
                 const uint2 e0 = p.dbucket[dbk_slot(p, pos - 1)], e1 = p.dbucket[s1], e2 = p.dbucket[s2], e3 = p.dbucket[dbk_slot(p, c2 - 1)];
                 const uint32_t rm1 = p.drival[s1], rm2 = p.drival[s2]; // (the junction ends: which sites there have rivals)
+                fetch_next();
                 uint32_t sidx = 0;
                 if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
                 const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx;
@@ -762,6 +767,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 uint2 f0 = p.dbucket[dbk_slot(p, pos - 1)], f1 = p.dbucket[s1];
                 const uint2 f2 = p.dbucket[s2], f3 = p.dbucket[s3];
                 const uint32_t rm1 = p.drival[s1], rm2 = p.drival[s2], rm3 = p.drival[s3]; // (the junction ends)
+                if (__all(m2)) fetch_next();
                 int32_t ua, ub; uint32_t nva, nvb, rvb;
                 uint32_t fl1 = 0, fl2 = 0; // junction 1 / 2 has an end with rivals
                 auto range = [&](uint32_t arr) {
@@ -842,6 +848,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 if (first) { const uint32_t sl = dbk_slot(p, pos - 1); e0 = p.dbucket[sl]; r0 = p.drival[sl]; }
 #pragma unroll
                 for (int k = 0; k < SPL_INLINE_OPS; ++k) { const uint32_t sl = dbk_slot(p, cend[k] - 1); ek[k] = p.dbucket[sl]; rk[k] = p.drival[sl]; }
+                if (first) fetch_next();
                 if (first) dbk_resolve(p, pos - 1, e0, r0, pu, pnv, prv);
 #pragma unroll
                 for (int k = 0; k < SPL_INLINE_OPS; ++k) {
