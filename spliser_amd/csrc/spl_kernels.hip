@@ -27,10 +27,11 @@
 
 namespace {
 
-// A load of data that is read once per pass (the packed reads): marked non-temporal, so that these lines are the first to
-// leave the caches and the site-table structures (bucket entries, junction table), which every workgroup of the XCD comes
-// back to, stay.  Measured on the configs[1] sample: range kernel 0.1274 -> 0.1240 ms (the re-reads of the wave-local pass
-// after the loop are better off with plain loads: 0.1265 with both marked).
+// A load of data that is read once per pass, marked non-temporal: these lines are the first to leave the caches, and the
+// site-table structures (bucket entries, junction table), which every workgroup of the XCD comes back to, stay.  The range
+// kernel marks the three op words of a read (12 of its 20 bytes) and nothing else -- measured on the configs[1] sample:
+// all five words marked 0.120 ms, the op words only 0.110, the op words only for waves of simple reads 0.120, the position or
+// the flag word too 0.116, bucket entries too 0.112 (and with the older 64 bp index: nothing marked 0.127, all five 0.124).
 template <typename T>
 __device__ __forceinline__ T ld_stream(const T *addr) { return __builtin_nontemporal_load(addr); }
 
@@ -641,8 +642,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     // (its bucket entries too was tried: 25 more registers, occupancy 4, slower).
     auto fetch_read = [&](int it, int32_t &f_pos, uint32_t &f_fn, uint32_t (&f_op)[SPL_INLINE_OPS]) {
         const int64_t ii = live ? chunk_base + (int64_t)it * SPL_BLOCK + tid : 0; // (the packed arrays are padded to whole chunks)
-        f_pos = ld_stream(&p.r_pos[ii]);                                         // ---- trip 1: 20 bytes per read
-        f_fn = ld_stream(&p.r_fn[ii]);
+        f_pos = p.r_pos[ii];                                                     // ---- trip 1: 20 bytes per read
+        f_fn = p.r_fn[ii];
 #pragma unroll
         for (int k = 0; k < SPL_INLINE_OPS; ++k) f_op[k] = ld_stream(&p.r_ops3[3 * ii + k]);
     };
