@@ -47,6 +47,8 @@ def main():
                     "soft clips, as a local aligner reports them")
     ap.add_argument("--cache", default=None, help="directory to cache the generated sample in (.npz); a cached "
                     "sample is loaded instead of regenerated (use under rocprofv3: no generator worker processes)")
+    ap.add_argument("--copies", type=int, default=1, help="(experiment) device copies of the sample; step k works on copy "
+                    "k mod copies, so that nothing a step read can still be in a cache when it is read again")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -107,11 +109,14 @@ def main():
     scode = native.STRANDED_CODE[stranded]
     kflags = {"pairs": native.OPT_PAIR_KERNEL, "ranges_agg": native.OPT_WAVE_AGGREGATION, "ranges": 0}[args.kernel]
     ctx = native.Context(local_rank)
-    dev = [(ctx.upload_sites(sh.sites), ctx.upload_reads(sh.reads)) for sh in shards]
+    copies = [[(ctx.upload_sites(sh.sites), ctx.upload_reads(sh.reads)) for sh in shards] for _ in range(max(1, args.copies))]
+    dev = copies[0]
+    step_no = [0]
     alg_bytes = sum(native.algorithmic_bytes(ds, dr) for ds, dr in dev)
 
     def step():
-        for ds, dr in dev:
+        step_no[0] += 1
+        for ds, dr in copies[(args.steps + args.warmup - step_no[0]) % len(copies)]:   # (the last step works on copy 0)
             ctx.count_launch(ds, dr, scode, 0, kflags)
             ctx.sse_launch(ds, args.beta2Cryptic)
 

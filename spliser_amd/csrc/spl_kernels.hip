@@ -27,14 +27,6 @@
 
 namespace {
 
-// A load of data that is read once per pass, marked non-temporal: these lines are the first to leave the caches, and the
-// site-table structures (bucket entries, junction table), which every workgroup of the XCD comes back to, stay.  The range
-// kernel marks the three op words of a read (12 of its 20 bytes) and nothing else -- measured on the configs[1] sample:
-// all five words marked 0.120 ms, the op words only 0.110, the op words only for waves of simple reads 0.120, the position or
-// the flag word too 0.116, bucket entries too 0.112 (and with the older 64 bp index: nothing marked 0.127, all five 0.124).
-template <typename T>
-__device__ __forceinline__ T ld_stream(const T *addr) { return __builtin_nontemporal_load(addr); }
-
 // First table row whose position is >= pos: a direct-address bucket index (bucket b covers positions
 // [base + (b << shift), base + ((b+1) << shift))) narrows the search to the rows of one bucket, a short
 // binary search finishes it.  bucket[] has n_buckets + 1 entries; bucket[n_buckets] == n_sites.
@@ -642,10 +634,13 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     // (its bucket entries too was tried: 25 more registers, occupancy 4, slower).
     auto fetch_read = [&](int it, int32_t &f_pos, uint32_t &f_fn, uint32_t (&f_op)[SPL_INLINE_OPS]) {
         const int64_t ii = live ? chunk_base + (int64_t)it * SPL_BLOCK + tid : 0; // (the packed arrays are padded to whole chunks)
+        // (plain loads: marking the stream non-temporal looked 3...11 % faster in a benchmark that runs pass after pass
+        //  over one 400 MB sample -- position and flag words then survive in the 256 MB last-level cache from one pass to
+        //  the next -- and is 2...5 % SLOWER when every pass reads a different copy of the sample: DESIGN.md section 6)
         f_pos = p.r_pos[ii];                                                     // ---- trip 1: 20 bytes per read
         f_fn = p.r_fn[ii];
 #pragma unroll
-        for (int k = 0; k < SPL_INLINE_OPS; ++k) f_op[k] = ld_stream(&p.r_ops3[3 * ii + k]);
+        for (int k = 0; k < SPL_INLINE_OPS; ++k) f_op[k] = p.r_ops3[3 * ii + k];
     };
     int32_t cu_pos;
     uint32_t cu_fn, cu_op[SPL_INLINE_OPS];
