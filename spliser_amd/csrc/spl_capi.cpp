@@ -44,6 +44,17 @@ struct spl_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // The tail of a counting pass (literal kernel, scan + SSE) runs on a stream of its own, so that the range kernel of the
+    // NEXT pass -- of the next shard, sample or step -- starts as soon as this pass's range kernel is done: the tail is a
+    // few thousand waves waiting on memory and fits next to it.  Pass n's tail waits for ev_range[n % 4]; pass n's range
+    // kernel waits for ev_tail[(n - 2) % 4], the tail that last read the queue buffer and cleared the counter copy it is
+    // about to use (three counter copies per site table, two queue buffers per read set).  Opt-in (SPL_TAIL_STREAM=1 when the
+    // context is created): on this stack a cross-queue dependency costs ~20 us between two range kernels, which leaves
+    // 6 % of the 25 % there is to gain; the default is one stream.
+    hipStream_t tail = nullptr;
+    hipEvent_t ev_range[4] = {nullptr, nullptr, nullptr, nullptr}, ev_tail[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t n_pass = 0;       // counting passes with a tail launched so far
+    bool tail_pending = false; // the main stream has not been made to wait for the last tail yet
     int32_t *d_err = nullptr;               // error word of launches that are not counting passes (spl_junctions)
     int last_grid = 0, last_lds = 0, last_variant = 0;
     struct Junction { int32_t left, right; uint8_t strand; uint32_t count, anchor_left, anchor_right; };
@@ -87,12 +98,24 @@ struct spl_dsites {
     // outputs
     uint32_t *beta1 = nullptr, *beta2s = nullptr, *dbl = nullptr; // contiguous: one memset clears all three
     size_t counter_bytes = 0;
-    // Everything a counting pass must find zero (counters, difference arrays, error word, queue counters) exists twice: a pass
-    // works on one copy while its literal kernel's idle waves clear the other for the next pass (alt_clean), so no pass starts
-    // with a clearing launch of its own.  The plain members always point into the copy in use.
-    uint32_t *alt_beta1 = nullptr, *alt_beta2s = nullptr, *alt_dbl = nullptr, *queue_n = nullptr, *alt_queue_n = nullptr;
-    int32_t *alt_diff = nullptr, *err = nullptr, *alt_err = nullptr;
-    bool alt_clean = false;
+    // Everything a counting pass must find zero (counters, difference arrays, error word, queue counters) exists more than
+    // once: a pass works on one copy while its literal kernel's idle waves clear another for a later pass (region_clean), so
+    // no pass starts with a clearing launch of its own.  The plain members always point into the copy in use.
+    // (Three copies, in fact: with the tail of a pass on its own stream the copy that pass n's literal kernel clears is
+    // the one pass n + 2 will use -- pass n + 1 may already be running.)
+    uint32_t *queue_n = nullptr;
+    int32_t *err = nullptr;
+    char *region[3] = {nullptr, nullptr, nullptr}; // start of each copy (same layout: beta1, beta2s, dbl, diff, queue counters, error word)
+    size_t off_b2 = 0, off_dbl = 0, off_diff = 0, off_ctl = 0; // member offsets inside a copy
+    bool region_clean[3] = {false, false, false};
+    int cur = 2;                                   // the copy in use (the plain members point into it)
+    void point_at(int k)
+    {
+        cur = k;
+        beta1 = (uint32_t *)region[k]; beta2s = (uint32_t *)(region[k] + off_b2); dbl = (uint32_t *)(region[k] + off_dbl);
+        diff = (int32_t *)(region[k] + off_diff); queue_n = (uint32_t *)(region[k] + off_ctl);
+        err = (int32_t *)(region[k] + off_ctl + 4 * 8 * SPL_COUNTER_STRIDE);
+    }
     int64_t *b2_simple = nullptr, *b2_cryptic = nullptr;
     double *b2_weighted = nullptr, *sse = nullptr;
     double *sse_cryptic = nullptr;      // SSE with --beta2Cryptic, written next to `sse` by the fused scan kernel
@@ -111,6 +134,8 @@ struct spl_dreads {
     uint16_t *perm = nullptr;
     uint32_t *chunk_order = nullptr; // slot of an XCD slice -> chunk, longest first (holds the cost estimates during upload)
     uint32_t *queue = nullptr; // reads the range kernel hands to the literal kernel (the counters are with the site table)
+    uint32_t *queue_alt = nullptr;     // ... and the buffer the NEXT pass writes while this pass's literal kernel still reads
+    mutable int queue_turn = 0;        // which of the two the next pass takes
     mutable const uint32_t *last_queue_n = nullptr; // ... of the last counting pass over this read set (spl_literal_queue_size)
 };
 
@@ -152,6 +177,20 @@ static int create_ctx(int device_id, void *stream, bool use_given, spl_ctx **out
         if (se != hipSuccess) { delete c; return spl_set_error(SPL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
         c->own_stream = true;
     }
+    {
+        const char *want_tail = getenv("SPL_TAIL_STREAM");
+        if (want_tail && want_tail[0] == '1') {
+            bool ok = hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; i < 4 && ok; ++i)
+                // (no system-scope fences: what these events order is read on this device only)
+                ok = hipEventCreateWithFlags(&c->ev_range[i], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess &&
+                     hipEventCreateWithFlags(&c->ev_tail[i], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
+            if (!ok) { // one stream it is
+                if (c->tail) (void)hipStreamDestroy(c->tail);
+                c->tail = nullptr;
+            }
+        }
+    }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc((void **)&c->d_err, sizeof(int32_t)) != hipSuccess) {
         spl_destroy(c);
@@ -168,7 +207,13 @@ extern "C" void spl_destroy(spl_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->tail) (void)hipStreamSynchronize(c->tail);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 4; ++i) {
+        if (c->ev_range[i]) (void)hipEventDestroy(c->ev_range[i]);
+        if (c->ev_tail[i]) (void)hipEventDestroy(c->ev_tail[i]);
+    }
+    if (c->tail) (void)hipStreamDestroy(c->tail);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->k_ev) (void)hipEventDestroy(e);
@@ -177,10 +222,19 @@ extern "C" void spl_destroy(spl_ctx *c)
     delete c;
 }
 
+// Everything queued on the main stream after this call runs after the tails of all counting passes launched so far.
+static hipError_t join_tail(spl_ctx *c)
+{
+    if (!c->tail || !c->tail_pending) return hipSuccess;
+    c->tail_pending = false;
+    return hipStreamWaitEvent(c->stream, c->ev_tail[(c->n_pass - 1) % 4], 0);
+}
+
 extern "C" int spl_sync(spl_ctx *c)
 {
     if (!c) return spl_set_error(SPL_ERR_ARG, "spl_sync: null context");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(join_tail(c));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SPL_OK;
 }
@@ -197,6 +251,7 @@ extern "C" int spl_timer_end(spl_ctx *c, float *ms)
 {
     if (!c || !ms) return spl_set_error(SPL_ERR_ARG, "spl_timer_end: null argument");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(join_tail(c));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -477,7 +532,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     const size_t o_diff = take(4 * 4 * (size_t)d->diff_stride);
     const size_t o_ctl = take(4 * 8 * SPL_COUNTER_STRIDE + 256); // 8 queue counters (a cache line each), then the error word
     d->counter_bytes = off - o_cnt;
-    const size_t o_alt = take(d->counter_bytes);                // the second copy, same layout
+    const size_t o_alt = take(2 * d->counter_bytes);            // the second and third copy, same layout
     const size_t o_bsum = take(4 * 4 * (size_t)std::max(d->scan_blocks, 1));
     const size_t o_b2s = take(8 * S), o_b2c = take(8 * S), o_b2w = take(8 * S), o_sse = take(8 * S), o_ssec = take(8 * S);
     d->slab_bytes = std::max<size_t>(off, 256);
@@ -491,15 +546,11 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     d->part_off = (uint32_t *)(d->slab + o_poff); d->part_pos = (int32_t *)(d->slab + o_ppos); d->part_site = (int32_t *)(d->slab + o_psite);
     d->comp_pos = (int32_t *)(d->slab + o_cpos); d->alpha = (int64_t *)(d->slab + o_alpha); d->edge_cnt = (int64_t *)(d->slab + o_ecnt);
     d->bucket = (uint32_t *)(d->slab + o_bucket);
-    d->beta1 = (uint32_t *)(d->slab + o_b1); d->beta2s = (uint32_t *)(d->slab + o_b2); d->dbl = (uint32_t *)(d->slab + o_dbl);
-    d->queue_n = (uint32_t *)(d->slab + o_ctl); d->err = (int32_t *)(d->slab + o_ctl + 4 * 8 * SPL_COUNTER_STRIDE);
-    {
-        const size_t shift = o_alt - o_cnt;
-        d->alt_beta1 = (uint32_t *)(d->slab + o_b1 + shift); d->alt_beta2s = (uint32_t *)(d->slab + o_b2 + shift);
-        d->alt_dbl = (uint32_t *)(d->slab + o_dbl + shift); d->alt_diff = (int32_t *)(d->slab + o_diff + shift);
-        d->alt_queue_n = (uint32_t *)(d->slab + o_ctl + shift); d->alt_err = (int32_t *)(d->slab + o_ctl + 4 * 8 * SPL_COUNTER_STRIDE + shift);
-        d->alt_clean = true; // the upload zeroes both copies
-    }
+    static_cast<void>(o_b1); // (= o_cnt: beta1 opens a copy)
+    d->region[0] = d->slab + o_cnt; d->region[1] = d->slab + o_alt; d->region[2] = d->slab + o_alt + d->counter_bytes;
+    d->off_b2 = o_b2 - o_cnt; d->off_dbl = o_dbl - o_cnt; d->off_diff = o_diff - o_cnt; d->off_ctl = o_ctl - o_cnt;
+    d->region_clean[0] = d->region_clean[1] = d->region_clean[2] = true; // the upload zeroes all copies
+    d->point_at(2);                                                       // (the first pass moves on to copy 0)
     d->b2_simple = (int64_t *)(d->slab + o_b2s); d->b2_cryptic = (int64_t *)(d->slab + o_b2c);
     d->b2_weighted = (double *)(d->slab + o_b2w); d->sse = (double *)(d->slab + o_sse); d->sse_cryptic = (double *)(d->slab + o_ssec);
     d->sse_view = d->sse;
@@ -577,12 +628,13 @@ static int upload_segments(spl_ctx *c, int n_seg, const spl_reads *segs, const i
     const size_t o_order = take(4 * (n_chunks ? n_chunks : 1));
     // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks
     const size_t shard_cap = ((n_chunks + 7) / 8) * SPL_CHUNK;
-    const size_t o_queue = take(4 * 8 * shard_cap);
+    const size_t o_queue = take(4 * 8 * shard_cap), o_queue_alt = take(c->tail ? 4 * 8 * shard_cap : 0);
     hipError_t e = hipMalloc((void **)&d->slab, std::max<size_t>(off, 256));
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the read set: %s", off, hipGetErrorString(e)); }
     d->pos = (int32_t *)(d->slab + o_pos); d->flag = (uint16_t *)(d->slab + o_flag);
     d->cig_off = (uint32_t *)(d->slab + o_off); d->cigar = (uint32_t *)(d->slab + o_cig);
     d->queue = (uint32_t *)(d->slab + o_queue);
+    d->queue_alt = c->tail ? (uint32_t *)(d->slab + o_queue_alt) : d->queue;
     d->fn = (uint32_t *)(d->slab + o_fn); d->ops3 = (uint32_t *)(d->slab + o_ops3);
     d->ppos = (int32_t *)(d->slab + o_ppos); d->perm = (uint16_t *)(d->slab + o_perm);
     d->chunk_order = (uint32_t *)(d->slab + o_order);
@@ -657,12 +709,23 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     HIP_TRY(hipSetDevice(c->device));
     // counters, difference arrays, error word and queue counters start from zero: the copy the previous pass cleared on the
     // side, or -- first pass after a pair-kernel pass -- one clearing launch
-    if (ds->alt_clean) {
-        std::swap(ds->beta1, ds->alt_beta1); std::swap(ds->beta2s, ds->alt_beta2s); std::swap(ds->dbl, ds->alt_dbl);
-        std::swap(ds->diff, ds->alt_diff); std::swap(ds->queue_n, ds->alt_queue_n); std::swap(ds->err, ds->alt_err);
-        ds->alt_clean = false;
-    } else if (int rc0 = spl_dev_launch_clear(ds->beta1, ds->counter_bytes, c->stream))
+    // range kernel whenever the table allows it; the literal pair kernel otherwise or on request
+    const int variant = (!ds->mutual_links || (o->flags & SPL_OPT_PAIR_KERNEL)) ? 1 : ((o->flags & SPL_OPT_WAVE_AGGREGATION) ? 2 : 0);
+    const bool piped = c->tail != nullptr && variant != 1 && ds->region_clean[(ds->cur + 1) % 3];
+    if (piped) {
+        // the tail of the pass before the last one is the last thing that read the queue buffer and wrote the counter copy
+        // this pass takes (tails run in order on their stream): a wait that is over long before it is asked for
+        if (c->n_pass >= 2) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail[(c->n_pass - 2) % 4], 0));
+    } else
+        HIP_TRY(join_tail(c)); // (pair kernel, first pass after one, or one stream: everything in order on the main stream)
+    const int next = (ds->cur + 1) % 3;
+    if (ds->region_clean[next]) {
+        ds->point_at(next);
+        ds->region_clean[next] = false;
+    } else if (int rc0 = spl_dev_launch_clear(ds->beta1, ds->counter_bytes, c->stream)) // (in place: the copy in use)
         return spl_set_error(SPL_ERR_HIP, "clear kernel launch: %s", hipGetErrorString((hipError_t)rc0));
+    uint32_t *const queue = dr->queue_turn ? dr->queue_alt : dr->queue;
+    dr->queue_turn ^= 1;
     dr->last_queue_n = ds->queue_n;
     ds->sse_fused = false;
     spl_count_params p;
@@ -682,15 +745,13 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos_orig = p.r_pos; h.r_pos = dr->ppos; h.perm = dr->perm; h.chunk_order = dr->chunk_order; h.part_pos = ds->part_pos; h.r_fn = dr->fn; h.r_ops3 = dr->ops3; h.cig_off = p.cig_off; h.cigar = p.cigar;
     h.dbucket = p.dbucket; h.drival = p.drival; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.n_cigar = (uint32_t)dr->n_cigar;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
-    h.queue = dr->queue; h.queue_n = ds->queue_n; h.err = ds->err;
+    h.queue = queue; h.queue_n = ds->queue_n; h.err = ds->err;
     h.queue_cap = (uint32_t)(((p.n_chunks + 7u) / 8u) * SPL_CHUNK);
     h.jhash = ds->jhash; h.jhash_mask = ds->jhash_mask; h.jrivals = ds->jrivals; h.dbl = ds->dbl; h.combine_mode = o->combine_mode ? 1 : 0;
 
     p.bucket = ds->bucket; p.n_buckets = ds->n_buckets; p.bucket_base = ds->bucket_base; p.bucket_shift = ds->bucket_shift;
     p.stranded = o->stranded; p.combine_mode = o->combine_mode ? 1 : 0;
     p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = ds->err;
-    // range kernel whenever the table allows it; the literal pair kernel otherwise or on request
-    const int variant = (!ds->mutual_links || (o->flags & SPL_OPT_PAIR_KERNEL)) ? 1 : ((o->flags & SPL_OPT_WAVE_AGGREGATION) ? 2 : 0);
     int grid = 0, lds = 0;
     const bool timed = c->k_on && (size_t)(2 * c->k_used + 1) < c->k_ev.size();
     if (timed) HIP_TRY(hipEventRecord(c->k_ev[2 * c->k_used], c->stream));
@@ -701,15 +762,24 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     c->last_variant = variant;
     if (rc != 0) return spl_set_error(SPL_ERR_HIP, "count kernel launch: %s", hipGetErrorString((hipError_t)rc));
     if (variant != 1 && grid > 0) { // queued reads through the literal kernel, then difference arrays -> counters
+        hipStream_t ts = c->stream;
+        if (piped) {
+            HIP_TRY(hipEventRecord(c->ev_range[c->n_pass % 4], c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->tail, c->ev_range[c->n_pass % 4], 0));
+            ts = c->tail;
+        }
+        // the copy to clear: with the tail on its own stream the one after next (the next pass may be running by then),
+        // otherwise the next one
+        const int to_clear = piped ? (ds->cur + 2) % 3 : (ds->cur + 1) % 3;
         spl_queue_params lq;
-        lq.queue = dr->queue; lq.queue_n = ds->queue_n; lq.queue_cap = h.queue_cap;
-        lq.clear_region = (uint4 *)ds->alt_beta1; lq.clear_n16 = ds->counter_bytes / 16; // the other copy, for the next pass
+        lq.queue = queue; lq.queue_n = ds->queue_n; lq.queue_cap = h.queue_cap;
+        lq.clear_region = (uint4 *)ds->region[to_clear]; lq.clear_n16 = ds->counter_bytes / 16;
         lq.r_pos = dr->ppos; lq.r_fn = dr->fn; lq.r_ops3 = dr->ops3; lq.perm = dr->perm;
         lq.diff = ds->diff; lq.block_sums = ds->block_sums; lq.diff_stride = ds->diff_stride; lq.n_dpos = ds->n_dpos;
         lq.scan_blocks = ds->scan_blocks; lq.scan_arrays = o->stranded ? 4 : 2;
-        rc = spl_dev_launch_literal(&p, &lq, c->stream);
+        rc = spl_dev_launch_literal(&p, &lq, ts);
         if (rc != 0) return spl_set_error(SPL_ERR_HIP, "literal kernel launch: %s", hipGetErrorString((hipError_t)rc));
-        ds->alt_clean = true;
+        ds->region_clean[to_clear] = true;
         spl_scan_params q;
         memset(&q, 0, sizeof(q));
         q.n_dpos = ds->n_dpos; q.dpos_first_row = ds->dpos_first_row;
@@ -723,9 +793,14 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
             q.sse.beta2_simple = ds->b2_simple; q.sse.beta2_cryptic = ds->b2_cryptic; q.sse.beta2_weighted = ds->b2_weighted;
             q.sse.sse = ds->sse; q.sse_with_cryptic = ds->sse_cryptic;
         }
-        rc = spl_dev_launch_scan(&q, c->stream);
+        rc = spl_dev_launch_scan(&q, ts);
         if (rc != 0) return spl_set_error(SPL_ERR_HIP, "scan kernel launch: %s", hipGetErrorString((hipError_t)rc));
         ds->sse_fused = q.with_sse != 0;
+        if (piped) {
+            HIP_TRY(hipEventRecord(c->ev_tail[c->n_pass % 4], c->tail));
+            c->n_pass++;
+            c->tail_pending = true;
+        }
     }
     return SPL_OK;
 }
@@ -740,6 +815,7 @@ extern "C" int spl_sse_launch(spl_ctx *c, spl_dsites *ds, int cryptic)
         return SPL_OK;
     }
     ds->sse_view = ds->sse;
+    HIP_TRY(join_tail(c));
     spl_sse_params p;
     memset(&p, 0, sizeof(p));
     p.n_sites = ds->n_sites; p.site_pos = ds->pos; p.part_off = ds->part_off; p.part_pos = ds->part_pos; p.part_site = ds->part_site;
@@ -754,6 +830,7 @@ extern "C" int spl_sse_launch(spl_ctx *c, spl_dsites *ds, int cryptic)
 static int check_device_error(spl_ctx *c, const spl_dsites *ds)
 {
     int32_t err = 0;
+    HIP_TRY(join_tail(c));
     HIP_TRY(hipMemcpyAsync(&err, ds->err, sizeof(err), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (err & SPL_DEV_ERR_RANGE)
@@ -765,6 +842,7 @@ extern "C" int spl_counters_download(spl_ctx *c, const spl_dsites *ds, uint32_t 
 {
     if (!c || !ds) return spl_set_error(SPL_ERR_ARG, "spl_counters_download: null argument");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(join_tail(c));
     if (beta1 && ds->n_sites) HIP_TRY(hipMemcpyAsync(beta1, ds->beta1, 4 * ds->n_sites, hipMemcpyDeviceToHost, c->stream));
     if (b2s && ds->n_sites) HIP_TRY(hipMemcpyAsync(b2s, ds->beta2s, 4 * ds->n_sites, hipMemcpyDeviceToHost, c->stream));
     if (dbl && ds->n_part) HIP_TRY(hipMemcpyAsync(dbl, ds->dbl, 4 * ds->n_part, hipMemcpyDeviceToHost, c->stream));
@@ -776,6 +854,7 @@ extern "C" int spl_sse_download(spl_ctx *c, const spl_dsites *ds, int64_t *b2s, 
     if (!c || !ds) return spl_set_error(SPL_ERR_ARG, "spl_sse_download: null argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = 8 * (size_t)ds->n_sites;
+    HIP_TRY(join_tail(c));
     if (n) {
         if (b2s) HIP_TRY(hipMemcpyAsync(b2s, ds->b2_simple, n, hipMemcpyDeviceToHost, c->stream));
         if (b2c) HIP_TRY(hipMemcpyAsync(b2c, ds->b2_cryptic, n, hipMemcpyDeviceToHost, c->stream));
@@ -876,6 +955,7 @@ extern "C" int spl_literal_queue_size(spl_ctx *c, const spl_dreads *dr, int64_t 
     HIP_TRY(hipSetDevice(c->device));
     std::vector<uint32_t> counts(8 * SPL_COUNTER_STRIDE);
     if (!dr->last_queue_n) { *n_out = 0; return SPL_OK; }
+    HIP_TRY(join_tail(c));
     HIP_TRY(hipMemcpyAsync(counts.data(), dr->last_queue_n, 4 * counts.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int64_t total = 0;

@@ -246,6 +246,57 @@ def test_gpu_back_to_back_passes_on_one_table(ctx, tmp_path, oracle_lib):
     ds.free()
 
 
+def test_gpu_tail_stream_pipelined_passes(tmp_path, oracle_lib, monkeypatch):
+    """SPL_TAIL_STREAM=1: the literal kernel and the scan of a pass run on a stream of their own while the next pass's range
+    kernel is under way (three counter copies per table, two queue buffers per read set).  Passes launched back to back without
+    a download in between, on two tables and read sets taking turns, with changing modes and kernels: whatever is downloaded,
+    whenever, must be the oracle's result for the last pass on that table."""
+    monkeypatch.setenv("SPL_TAIL_STREAM", "1")
+    wl = synth.Workload("arabidopsis", scale=0.004, seed=43)
+    table = _table_for(wl, tmp_path, True)
+    with native.Context(0) as piped:
+        dev, want = [], []
+        for k in (0, 1):
+            name = wl.genome.chrom_names[k]
+            arr, reads = table.chrom_arrays(name), wl.reads[k]
+            dev.append((piped.upload_sites(native.SiteArrays.from_chrom(arr)),
+                        piped.upload_reads(native.ReadArrays(reads.pos, reads.flag, reads.cig_off, reads.cigar))))
+            want.append({(st, cb): (oracle_lib.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos,
+                                                         reads.pos, reads.flag, reads.cig_off, reads.cigar, st, cb), arr)
+                         for st in (0, 1, 2) for cb in (0, 1)})
+        def check(k, st, cb, cryptic):
+            ds = dev[k][0]
+            cnt, arr = want[k][(st, cb)]
+            for g, w in zip(ds.counters(), cnt):
+                assert np.array_equal(g, w), (k, st, cb)
+            piped.sse_launch(ds, cryptic)
+            w_sse = oracle_lib.beta2_sse(arr.pos, arr.part_off, arr.part_pos, arr.part_site, arr.alpha, arr.edge_cnt,
+                                         cnt[0], cnt[1], cnt[2], cryptic)
+            for g, w in zip(ds.sse_results(), w_sse):
+                assert np.array_equal(np.asarray(g), np.asarray(w)), (k, st, cb, "sse")
+        # bursts of passes, nothing read back until the end of a burst
+        for burst, (st, cb) in enumerate([(0, 0), (1, 0), (2, 1), (0, 1)]):
+            for rep in range(7):
+                for k in (0, 1):
+                    piped.count_launch(dev[k][0], dev[k][1], st, cb, 0)
+            check(1, st, cb, burst % 2 == 1)
+            check(0, st, cb, burst % 2 == 0)
+        # the other kernels in between (they run on the main stream alone), the tables and read sets crossed over
+        piped.count_launch(dev[0][0], dev[0][1], 1, 0, KERNELS["pairs"])
+        piped.count_launch(dev[1][0], dev[1][1], 1, 0, 0)
+        piped.count_launch(dev[0][0], dev[0][1], 2, 0, KERNELS["ranges_agg"])
+        piped.count_launch(dev[1][0], dev[1][1], 2, 0, 0)
+        check(0, 2, 0, False)
+        check(1, 2, 0, True)
+        for rep in range(5):
+            piped.count_launch(dev[0][0], dev[0][1], 0, 0, 0)
+        check(0, 0, 0, False)
+        assert dev[0][1].literal_queue_size() >= 0
+        for ds, dr in dev:
+            dr.free()
+            ds.free()
+
+
 def test_gpu_segment_upload_equals_packed_upload(ctx, tmp_path):
     """spl_reads_upload_segments (per-chromosome arrays shifted on the device) against the host-packed shard."""
     wl = synth.Workload("arabidopsis", scale=0.01, seed=77)
