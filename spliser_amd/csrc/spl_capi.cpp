@@ -754,9 +754,9 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = ds->err;
     int grid = 0, lds = 0;
     const bool timed = c->k_on && (size_t)(2 * c->k_used + 1) < c->k_ev.size();
-    if (timed) HIP_TRY(hipEventRecord(c->k_ev[2 * c->k_used], c->stream));
-    int rc = spl_dev_launch_count(&p, &h, variant, c->stream, &grid, &lds);
-    if (timed) { HIP_TRY(hipEventRecord(c->k_ev[2 * c->k_used + 1], c->stream)); c->k_used++; }
+    int rc = spl_dev_launch_count(&p, &h, variant, c->stream, &grid, &lds, timed ? (void *)c->k_ev[2 * c->k_used] : nullptr,
+                                  timed ? (void *)c->k_ev[2 * c->k_used + 1] : nullptr);
+    if (timed) c->k_used++;
     c->last_grid = grid;
     c->last_lds = lds;
     c->last_variant = variant;

@@ -17,6 +17,7 @@
 //
 // Integer / indexing work: no MFMA.  The roofline that bounds the count kernels is HBM.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
 #include <stdint.h>
@@ -1813,7 +1814,10 @@ extern "C" int spl_dev_launch_clear(void *region, size_t bytes, void *stream)
     return (int)hipGetLastError();
 }
 
-extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out)
+// ev_start / ev_stop (may be null): HIP events that take the kernel's own start and end time -- through hipExtLaunchKernelGGL,
+// i.e. without marker packets of their own in the queue (two hipEventRecord calls around a launch cost the step 3 us).
+extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out,
+                                    void *ev_start, void *ev_stop)
 {
     *grid_out = 0;
     *lds_out = 0;
@@ -1822,10 +1826,11 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
     const uint32_t grid = ((p->n_chunks + 7u) / 8u) * 8u;
     *grid_out = (int)grid;
     hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
     if (variant == 1) {
         *lds_out = 2 * SPL_WIN * 4 + 4;
-        if (p->stranded) hipLaunchKernelGGL(spl_count_pairs_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
-        else hipLaunchKernelGGL(spl_count_pairs_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, *p);
+        if (p->stranded) hipExtLaunchKernelGGL(spl_count_pairs_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *p);
+        else hipExtLaunchKernelGGL(spl_count_pairs_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *p);
     } else {
         *lds_out = (p->stranded ? 4 : 2) * (SPL_WIN + 1) * 4 + SPL_CHUNK * 2 + 8; // difference windows + the chunk's queue
         const bool agg = (variant & 2) != 0;
@@ -1840,11 +1845,11 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
         }
 #endif
         if (p->stranded) {
-            if (agg) hipLaunchKernelGGL((spl_count_ranges_kernel<true, true>), dim3(grid), dim3(SPL_BLOCK), 0, st, *h);
-            else hipLaunchKernelGGL((spl_count_ranges_kernel<true, false>), dim3(grid), dim3(SPL_BLOCK), 0, st, *h);
+            if (agg) hipExtLaunchKernelGGL((spl_count_ranges_kernel<true, true>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h);
+            else hipExtLaunchKernelGGL((spl_count_ranges_kernel<true, false>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h);
         } else {
-            if (agg) hipLaunchKernelGGL((spl_count_ranges_kernel<false, true>), dim3(grid), dim3(SPL_BLOCK), 0, st, *h);
-            else hipLaunchKernelGGL((spl_count_ranges_kernel<false, false>), dim3(grid), dim3(SPL_BLOCK), 0, st, *h);
+            if (agg) hipExtLaunchKernelGGL((spl_count_ranges_kernel<false, true>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h);
+            else hipExtLaunchKernelGGL((spl_count_ranges_kernel<false, false>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h);
         }
 #ifdef SPL_PHASE_TIMING
         if (const char *path = getenv("SPL_PHASE_DUMP")) {
