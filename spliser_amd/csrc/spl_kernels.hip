@@ -1289,7 +1289,11 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
     for (int sh = 0; sh < 8; ++sh) start[sh + 1] = start[sh] + q.queue_n[sh * SPL_COUNTER_STRIDE];
     const uint32_t total = start[8];
     {
-        for (uint32_t g = blockIdx.x * 64u + threadIdx.x; g < total; g += gridDim.x * 64u) {
+        // A short queue is spread thin, 16 entries per wave: a wave is as slow as its slowest lane (trips differ with the
+        // number of junctions and rivals), and there are far more waves than work (26 -> 22 us for 9 k reads).  A long one
+        // (combine mode: every flagged read) fills the waves.
+        const uint32_t lanes = total <= gridDim.x * 16u ? 16u : 64u;
+        for (uint32_t g = blockIdx.x * lanes + threadIdx.x; threadIdx.x < lanes && g < total; g += gridDim.x * lanes) {
             uint32_t shard = 0;
 #pragma unroll
             for (int sh = 1; sh < 8; ++sh) shard += (g >= start[sh]) ? 1u : 0u;
