@@ -229,7 +229,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "spl_count_%s_kernel" % args.kernel.split("_")[0], "kernel_ms_avg": k_avg_ms, "launches_timed": len(kernel_ms),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"]},
+                         "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"],
+                         "concurrent": (None if os.environ.get("SPL_TAIL_STREAM", "1")[:1] == "0" or args.kernel == "pairs" else
+                                        "the literal kernel and the scan of the launch before run beside this kernel on a stream of "
+                                        "their own: its duration includes what it yields to them (alone: SPL_TAIL_STREAM=0)")},
             "cpu_baseline": cpu,
             "parity": parity,
             "literal_kernel_reads": literal_reads,

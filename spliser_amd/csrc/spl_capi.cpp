@@ -48,9 +48,9 @@ struct spl_ctx {
     // NEXT pass -- of the next shard, sample or step -- starts as soon as this pass's range kernel is done: the tail is a
     // few thousand waves waiting on memory and fits next to it.  Pass n's tail waits for ev_range[n % 4]; pass n's range
     // kernel waits for ev_tail[(n - 2) % 4], the tail that last read the queue buffer and cleared the counter copy it is
-    // about to use (three counter copies per site table, two queue buffers per read set).  Opt-in (SPL_TAIL_STREAM=1 when the
-    // context is created): on this stack a cross-queue dependency costs ~20 us between two range kernels, which leaves
-    // 6 % of the 25 % there is to gain; the default is one stream.
+    // about to use (three counter copies per site table, two queue buffers per read set).  SPL_TAIL_STREAM=0 when the context
+    // is created: one stream.  (A cross-queue dependency still costs ~11 us between two range kernels on this stack, which
+    // leaves 4...9 % of the 20 % there is to gain: DESIGN.md section 6.)
     hipStream_t tail = nullptr;
     hipEvent_t ev_range[4] = {nullptr, nullptr, nullptr, nullptr}, ev_tail[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t n_pass = 0;       // counting passes with a tail launched so far
@@ -179,11 +179,11 @@ static int create_ctx(int device_id, void *stream, bool use_given, spl_ctx **out
     }
     {
         const char *want_tail = getenv("SPL_TAIL_STREAM");
-        if (want_tail && want_tail[0] == '1') {
+        if (!(want_tail && want_tail[0] == '0')) {
             bool ok = hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) == hipSuccess;
             for (int i = 0; i < 4 && ok; ++i)
                 // (no system-scope fences: what these events order is read on this device only)
-                ok = hipEventCreateWithFlags(&c->ev_range[i], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess &&
+                ok = hipEventCreate(&c->ev_range[i]) == hipSuccess && // (a kernel's stop event: hipExtLaunchKernelGGL)
                      hipEventCreateWithFlags(&c->ev_tail[i], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
             if (!ok) { // one stream it is
                 if (c->tail) (void)hipStreamDestroy(c->tail);
@@ -754,8 +754,10 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.beta1 = ds->beta1; p.beta2s_reads = ds->beta2s; p.dbl = ds->dbl; p.err = ds->err;
     int grid = 0, lds = 0;
     const bool timed = c->k_on && (size_t)(2 * c->k_used + 1) < c->k_ev.size();
-    int rc = spl_dev_launch_count(&p, &h, variant, c->stream, &grid, &lds, timed ? (void *)c->k_ev[2 * c->k_used] : nullptr,
-                                  timed ? (void *)c->k_ev[2 * c->k_used + 1] : nullptr);
+    // (with the tail on its own stream that stream waits for the range kernel's OWN stop event: a marker packet behind the
+    //  kernel -- hipEventRecord -- holds the main queue up for ~18 us when another queue depends on it)
+    hipEvent_t ev_stop = timed ? c->k_ev[2 * c->k_used + 1] : (piped ? c->ev_range[c->n_pass % 4] : nullptr);
+    int rc = spl_dev_launch_count(&p, &h, variant, c->stream, &grid, &lds, timed ? (void *)c->k_ev[2 * c->k_used] : nullptr, (void *)ev_stop);
     if (timed) c->k_used++;
     c->last_grid = grid;
     c->last_lds = lds;
@@ -764,8 +766,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     if (variant != 1 && grid > 0) { // queued reads through the literal kernel, then difference arrays -> counters
         hipStream_t ts = c->stream;
         if (piped) {
-            HIP_TRY(hipEventRecord(c->ev_range[c->n_pass % 4], c->stream));
-            HIP_TRY(hipStreamWaitEvent(c->tail, c->ev_range[c->n_pass % 4], 0));
+            HIP_TRY(hipStreamWaitEvent(c->tail, ev_stop, 0));
             ts = c->tail;
         }
         // the copy to clear: with the tail on its own stream the one after next (the next pass may be running by then),
