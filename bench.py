@@ -139,6 +139,15 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ctx.kernel_timing_collect(args.steps * len(dev) + 8)
+    # outside the timed region: the same kernel with nothing beside it (a sync after every launch, so that the tail of a pass is
+    # over before the next range kernel starts) -- what the tail stream costs the kernel it overlaps with
+    ctx.kernel_timing_begin(5 * len(dev))
+    for _ in range(5):
+        for ds, dr in dev:
+            ctx.count_launch(ds, dr, scode, 0, kflags)
+            ctx.sse_launch(ds, args.beta2Cryptic)
+            ctx.sync()
+    kernel_ms_alone = ctx.kernel_timing_collect(5 * len(dev) + 8)
     literal_reads = sum(dr.literal_queue_size() for _, dr in dev) if args.kernel != "pairs" else None
     info = ctx.launch_info()
 
@@ -230,6 +239,10 @@ def main():
                          "kernel": "spl_count_%s_kernel" % args.kernel.split("_")[0], "kernel_ms_avg": k_avg_ms, "launches_timed": len(kernel_ms),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"],
+                         "alone": (None if not kernel_ms_alone else
+                                   {"kernel_ms_avg": sum(kernel_ms_alone) / len(kernel_ms_alone),
+                                    "frac": bytes_per_launch / (sum(kernel_ms_alone) / len(kernel_ms_alone) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "how": "5 more launches after the timed region, each followed by a sync"}),
                          "concurrent": (None if os.environ.get("SPL_TAIL_STREAM", "1")[:1] == "0" or args.kernel == "pairs" else
                                         "the literal kernel and the scan of the launch before run beside this kernel on a stream of "
                                         "their own: its duration includes what it yields to them (alone: SPL_TAIL_STREAM=0)")},
