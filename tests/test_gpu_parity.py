@@ -293,6 +293,20 @@ def test_gpu_tail_stream_pipelined_passes(tmp_path, oracle_lib, monkeypatch, tai
             piped.count_launch(dev[0][0], dev[0][1], 0, 0, 0)
         check(0, 0, 0, False)
         assert dev[0][1].literal_queue_size() >= 0
+        # one table, two read sets taking turns (what `combine` does with a sample's gap-fill queries): the counter copies
+        # cycle with the table, the queue buffers with the read set
+        arr0, r1 = table.chrom_arrays(wl.genome.chrom_names[0]), wl.reads[1]
+        crossed = oracle_lib.check_bam(arr0.pos, arr0.strand, arr0.part_off, arr0.part_pos, arr0.comp_off, arr0.comp_pos,
+                                       r1.pos, r1.flag, r1.cig_off, r1.cigar, 1, 0)
+        for rep in range(5):
+            piped.count_launch(dev[0][0], dev[1][1], 1, 0, 0)
+            piped.count_launch(dev[0][0], dev[0][1], 1, 0, 0)
+        check(0, 1, 0, True)
+        for rep in range(4):
+            piped.count_launch(dev[0][0], dev[0][1], 1, 0, 0)
+            piped.count_launch(dev[0][0], dev[1][1], 1, 0, 0)
+        for g, w in zip(dev[0][0].counters(), crossed):
+            assert np.array_equal(g, w), "one table, the other read set"
         for ds, dr in dev:
             dr.free()
             ds.free()
