@@ -145,7 +145,12 @@ int spl_reads_upload(spl_ctx *ctx, const spl_reads *reads, spl_dreads **out);
  * (spliser_amd/shard.py packs several chromosomes into one launch that way).  Reads keep segment order. */
 int spl_reads_upload_segments(spl_ctx *ctx, int n_seg, const spl_reads *segs, const int32_t *pos_shift, spl_dreads **out);
 void spl_reads_free(spl_ctx *ctx, spl_dreads *dr);
-/* Zero the shard's counters and enqueue the classification kernel (asynchronous). */
+/* Enqueue one counting pass of dr over ds (asynchronous): the range kernel on the context's stream, then the literal kernel
+ * and the scan (which also computes beta2 / SSE when the table has the inputs) on a second stream the context owns, so that
+ * the range kernel of the NEXT launch -- next shard, sample or step -- starts as soon as this one's is done.  The counters
+ * start from zero (a clean copy of the counter region; the table keeps three).  spl_sync and the download calls wait for
+ * everything; a download returns the results of the LAST pass launched on that table.  SPL_TAIL_STREAM=0 in the environment
+ * when the context is created: one stream. */
 int spl_count_launch(spl_ctx *ctx, spl_dsites *ds, const spl_dreads *dr, const spl_opts *opts);
 /* Enqueue the beta2/SSE kernel on the counters currently held by ds (asynchronous). */
 int spl_sse_launch(spl_ctx *ctx, spl_dsites *ds, int beta2_cryptic);
