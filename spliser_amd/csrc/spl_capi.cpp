@@ -592,6 +592,8 @@ extern "C" void spl_sites_free(spl_ctx *c, spl_dsites *d)
 {
     if (!d) return;
     if (c) (void)hipSetDevice(c->device);
+    if (c && c->tail) (void)hipStreamSynchronize(c->tail); // (a tail may still be reading these buffers; hipFree itself waits
+    if (c && c->stream) (void)hipStreamSynchronize(c->stream); //  for the device, this makes it independent of that)
     if (d->slab) (void)hipFree(d->slab);
     delete d;
 }
@@ -695,6 +697,8 @@ extern "C" void spl_reads_free(spl_ctx *c, spl_dreads *d)
 {
     if (!d) return;
     if (c) (void)hipSetDevice(c->device);
+    if (c && c->tail) (void)hipStreamSynchronize(c->tail); // (a tail may still be reading these buffers; hipFree itself waits
+    if (c && c->stream) (void)hipStreamSynchronize(c->stream); //  for the device, this makes it independent of that)
     if (d->slab) (void)hipFree(d->slab);
     delete d;
 }
