@@ -149,8 +149,9 @@ void spl_reads_free(spl_ctx *ctx, spl_dreads *dr);
  * and the scan (which also computes beta2 / SSE when the table has the inputs) on a second stream the context owns, so that
  * the range kernel of the NEXT launch -- next shard, sample or step -- starts as soon as this one's is done.  The counters
  * start from zero (a clean copy of the counter region; the table keeps three).  spl_sync and the download calls wait for
- * everything; a download returns the results of the LAST pass launched on that table.  SPL_TAIL_STREAM=0 in the environment
- * when the context is created: one stream. */
+ * everything; a download returns the results of the LAST pass launched on that table.  Environment, read when the context
+ * is created: SPL_TAIL_STREAM=0 -- one stream; SPL_TAIL_HOST_WAIT=1 -- the call blocks while more than two passes are in
+ * flight instead of putting a wait into the queue (a few percent faster when the host keeps up, idle GPU when it does not). */
 int spl_count_launch(spl_ctx *ctx, spl_dsites *ds, const spl_dreads *dr, const spl_opts *opts);
 /* Enqueue the beta2/SSE kernel on the counters currently held by ds (asynchronous). */
 int spl_sse_launch(spl_ctx *ctx, spl_dsites *ds, int beta2_cryptic);

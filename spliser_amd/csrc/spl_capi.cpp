@@ -54,6 +54,7 @@ struct spl_ctx {
     hipStream_t tail = nullptr;
     hipEvent_t ev_range[4] = {nullptr, nullptr, nullptr, nullptr}, ev_tail[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t n_pass = 0;       // counting passes with a tail launched so far
+    bool tail_host_wait = false;
     bool tail_pending = false; // the main stream has not been made to wait for the last tail yet
     int32_t *d_err = nullptr;               // error word of launches that are not counting passes (spl_junctions)
     int last_grid = 0, last_lds = 0, last_variant = 0;
@@ -178,6 +179,8 @@ static int create_ctx(int device_id, void *stream, bool use_given, spl_ctx **out
         c->own_stream = true;
     }
     {
+        const char *hw = getenv("SPL_TAIL_HOST_WAIT");
+        c->tail_host_wait = hw && hw[0] == '1';
         const char *want_tail = getenv("SPL_TAIL_STREAM");
         if (!(want_tail && want_tail[0] == '0')) {
             bool ok = hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) == hipSuccess;
@@ -719,7 +722,13 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     if (piped) {
         // the tail of the pass before the last one is the last thing that read the queue buffer and wrote the counter copy
         // this pass takes (tails run in order on their stream): a wait that is over long before it is asked for
-        if (c->n_pass >= 2) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail[(c->n_pass - 2) % 4], 0));
+        // The wait packet in the main queue costs 6 us between two range kernels.  SPL_TAIL_HOST_WAIT=1: the HOST waits
+        // instead (the call then blocks while more than two passes are in flight) -- 4 % faster in bench.py, and one
+        // millisecond of host jitter is one millisecond of idle GPU (1 run in 12 lost 25 % that way): not the default.
+        if (c->n_pass >= 2) {
+            if (c->tail_host_wait) HIP_TRY(hipEventSynchronize(c->ev_tail[(c->n_pass - 2) % 4]));
+            else HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail[(c->n_pass - 2) % 4], 0));
+        }
     } else
         HIP_TRY(join_tail(c)); // (pair kernel, first pass after one, or one stream: everything in order on the main stream)
     const int next = (ds->cur + 1) % 3;

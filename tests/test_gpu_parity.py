@@ -246,13 +246,14 @@ def test_gpu_back_to_back_passes_on_one_table(ctx, tmp_path, oracle_lib):
     ds.free()
 
 
-@pytest.mark.parametrize("tail_stream", ["1", "0"])
+@pytest.mark.parametrize("tail_stream", ["1", "0", "host-wait"])
 def test_gpu_tail_stream_pipelined_passes(tmp_path, oracle_lib, monkeypatch, tail_stream):
     """The literal kernel and the scan of a pass run on a stream of their own while the next pass's range kernel is under way
     (three counter copies per table, two queue buffers per read set; SPL_TAIL_STREAM=0: everything on one stream).  Passes
     launched back to back without a download in between, on two tables and read sets taking turns, with changing modes and
     kernels: whatever is downloaded, whenever, must be the oracle's result for the last pass on that table."""
-    monkeypatch.setenv("SPL_TAIL_STREAM", tail_stream)
+    monkeypatch.setenv("SPL_TAIL_STREAM", "0" if tail_stream == "0" else "1")
+    monkeypatch.setenv("SPL_TAIL_HOST_WAIT", "1" if tail_stream == "host-wait" else "0")  # (who waits for the tail two passes back)
     wl = synth.Workload("arabidopsis", scale=0.004, seed=43)
     table = _table_for(wl, tmp_path, True)
     with native.Context(0) as piped:
