@@ -139,12 +139,28 @@ int spl_sse(spl_ctx *ctx, const spl_sites *sites, const uint32_t *beta1, const u
 /* ---- device-resident pipeline (bench.py, multi-shard overlap) ---------------------------------- */
 int spl_sites_upload(spl_ctx *ctx, const spl_sites *sites, spl_dsites **out);
 void spl_sites_free(spl_ctx *ctx, spl_dsites *ds);
+/* A read set on the device.  The kernels do not read the BAM-native arrays: on its way to the GPU every read set is packed,
+ * on host threads, into chunks of 2048 reads, each chunk partitioned by the kind of read (unspliced / once-spliced /
+ * twice-spliced / anything else) with records as wide as the kind needs (8 / 16 / 24 bytes; spliser_amd/csrc/spl_pack.h),
+ * piece by piece through a ring of page-locked staging buffers, the DMA of one piece running while the next is packed.
+ * The caller's arrays are not needed after the call returns. */
 int spl_reads_upload(spl_ctx *ctx, const spl_reads *reads, spl_dreads **out);
-/* Same, from n_seg host segments laid end to end -- e.g. the per-reference views of spl_bam_reads, uploaded straight
- * from the decoder's buffers: segment k is moved by pos_shift[k] into the shard's coordinate space on the device
+/* Same, from n_seg host segments laid end to end: segment k is moved by pos_shift[k] into the shard's coordinate space
  * (spliser_amd/shard.py packs several chromosomes into one launch that way).  Reads keep segment order. */
 int spl_reads_upload_segments(spl_ctx *ctx, int n_seg, const spl_reads *segs, const int32_t *pos_shift, spl_dreads **out);
+/* The same in steps, for segments that become available one after the other (the references of a BAM file while it is still
+ * being decoded): begin, add ... add, finish; counting passes need a finished read set.  spl_reads_add_bam takes the reads of
+ * reference `tid` straight from the decoder's buffers (waits until that reference is complete, spl_bam_wait_ref). */
+int spl_reads_begin(spl_ctx *ctx, spl_dreads **out);
+int spl_reads_add(spl_ctx *ctx, spl_dreads *dr, const spl_reads *reads, int32_t pos_shift);
+int spl_reads_add_bam(spl_ctx *ctx, spl_dreads *dr, spl_bam *bam, int tid, int32_t pos_shift);
+int spl_reads_finish(spl_ctx *ctx, spl_dreads *dr);
 void spl_reads_free(spl_ctx *ctx, spl_dreads *dr);
+/* The host packer alone (no GPU involved; diagnostic and test hook): sizes of what an upload of `reads` would send, and --
+ * into buffers of those sizes, when given -- the bytes: chunk descriptors (32 bytes each: record offset u64, wide-op offset
+ * u64, first POS i32, cost u32, reads per run u16[4]), the record blob, the wide ops. */
+int spl_pack_host(const spl_reads *reads, int n_threads, int64_t *n_chunks_out, int64_t *rec_bytes_out, int64_t *n_wide_out,
+                  void *chunk_desc, void *rec, uint32_t *wide);
 /* Enqueue one counting pass of dr over ds (asynchronous): the range kernel on the context's stream, then the literal kernel
  * and the scan (which also computes beta2 / SSE when the table has the inputs) on a second stream the context owns, so that
  * the range kernel of the NEXT launch -- next shard, sample or step -- starts as soon as this one's is done.  The counters
@@ -170,18 +186,27 @@ int spl_literal_queue_size(spl_ctx *ctx, const spl_dreads *dr, int64_t *n_out);
 int spl_last_launch_info(const spl_ctx *ctx, int32_t *grid_out, int32_t *block_out, int32_t *lds_bytes_out);
 
 /* ---- BAM ingest: replaces `samtools view` (SpliSER_v0_1_8.py:422) ------------------------------
- * spl_bam_open reads and inflates the whole BGZF file on n_threads host threads (0 = all cores)
- * and splits the alignment records per reference sequence into SoA buffers (page-locked when a
- * GPU is present).  Like `samtools view` without -F/-q it keeps EVERY record that has a reference
- * id (secondary, supplementary, duplicate, QC-fail, unmapped-but-placed ...). */
+ * The whole BGZF file is inflated and its alignment records are split per reference sequence on n_threads host threads
+ * (0 = all cores up to 32).  Like `samtools view` without -F/-q every record that has a reference id is kept (secondary,
+ * supplementary, duplicate, QC-fail, unmapped-but-placed ...).
+ * spl_bam_open_stream returns once the block directory and the header are read; the decode goes on on threads of its own.
+ * spl_bam_wait_ref waits until reference `tid` is complete -- in a file sorted by reference that is when a record of a later
+ * reference has been seen, long before the end of the file -- so that its reads can go to the GPU (spl_reads_add_bam) while
+ * the rest is still being inflated.  spl_bam_wait_all waits for the end of the file and says whether the file WAS sorted by
+ * reference (*sorted_out = 0: records of an earlier reference came after a later one; a consumer that took references early
+ * must then take them again).  spl_bam_open = open_stream + wait_all. */
 int spl_bam_open(const char *path, int n_threads, spl_bam **out);
+int spl_bam_open_stream(const char *path, int n_threads, spl_bam **out);
+int spl_bam_wait_ref(spl_bam *bam, int tid, int64_t *n_reads_out, int64_t *max_end_out);
+int spl_bam_wait_all(spl_bam *bam, int *sorted_out);
 void spl_bam_close(spl_bam *bam);
 int spl_bam_n_ref(const spl_bam *bam);
 const char *spl_bam_ref_name(const spl_bam *bam, int tid);
 int64_t spl_bam_ref_length(const spl_bam *bam, int tid);
 int64_t spl_bam_n_records(const spl_bam *bam); /* all records, including those without a reference */
-/* Borrowed view (valid until spl_bam_close) of the reads placed on reference `tid`;
- * *max_end_out = largest 1-based end coordinate any of them reaches (for shard packing). */
+/* Borrowed view (valid until spl_bam_close) of the reads placed on reference `tid` as BAM-native arrays, assembled on the
+ * first call (waits for the whole file); *max_end_out = largest 1-based end coordinate any of them reaches (for shard
+ * packing).  The GPU path does not need these arrays (spl_reads_add_bam). */
 int spl_bam_reads(const spl_bam *bam, int tid, spl_reads *out, int64_t *max_end_out);
 
 /* Test / synthetic-workload utility (no reference counterpart): write per-reference read sets as a coordinate-ordered

@@ -20,6 +20,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +32,7 @@
 #include <vector>
 
 #include "../../include/spliser.h"
+#include "spl_bam.h"
 #include "spl_error.h"
 
 namespace {
@@ -226,26 +229,49 @@ struct RefFinal {
     ~RefFinal() { free(pos); free(flag); free(cig_off); free(cigar); }
 };
 
-struct PendingPart;
-
-struct spl_bam {
-    std::vector<std::string> ref_names;
-    std::vector<int64_t> ref_lengths;
-    std::vector<RefFinal> refs_storage; // (never resized after the header: RefFinal is not copyable)
-    RefFinal *refs = nullptr;
-    int n_refs = 0;
-    std::vector<PendingPart> *pending = nullptr; // the parse threads' output in file order, until assemble()
-    int64_t n_records = 0;
-    ~spl_bam();
-};
-
 struct PendingPart {
     int32_t tid = 0;
     RefReads reads;
-    int64_t read_at = 0, op_at = 0; // where the part goes inside its reference
 };
 
-spl_bam::~spl_bam() { delete pending; }
+// A BAM file being decoded (or decoded).  The decode runs on a thread of its own (which drives the inflate and parse pools);
+// consumers wait per reference: in a coordinate-sorted file reference t is complete as soon as a record of a later reference
+// has been seen, so its reads can be packed and sent to the GPU while the rest of the file is still being inflated.
+struct spl_bam {
+    std::vector<std::string> ref_names;
+    std::vector<int64_t> ref_lengths;
+    int n_refs = 0;
+    // ---- filled by the decode thread, read under `mu` ----
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::vector<PendingPart *>> parts; // per reference, file order (owned)
+    std::vector<int64_t> ref_max_end, ref_reads;
+    int complete_upto = 0;      // every reference < this is complete -- if the file is sorted by reference
+    int max_tid_seen = -1;
+    bool out_of_order = false;  // a record of an earlier reference came after one of a later reference
+    bool done = false;
+    int err_code = 0;
+    std::string error;
+    int64_t n_records = 0;
+    // ---- BAM-native arrays per reference, assembled on demand (spl_bam_reads) ----
+    std::vector<RefFinal> refs_storage; // (never resized after the header: RefFinal is not copyable)
+    std::vector<char> assembled;
+    // ---- the decode thread and what it works on ----
+    std::thread worker;
+    void *map = nullptr;
+    size_t fsize = 0;
+    std::vector<Block> blocks;
+    int n_threads = 1;
+    std::string path;
+    ~spl_bam();
+};
+
+spl_bam::~spl_bam()
+{
+    if (worker.joinable()) worker.join();
+    for (auto &list : parts) for (PendingPart *p : list) delete p;
+    if (map) munmap(map, fsize);
+}
 
 namespace {
 
@@ -360,69 +386,69 @@ const uint8_t *find_record_start(const uint8_t *from, const uint8_t *end, int n_
     return end;
 }
 
-// The parse threads' parts are only queued while the file is being read (no copying, no growing destination on the
-// critical path); assemble() sizes every reference once and copies all parts in parallel.
+// The parse threads' parts, in file order, are handed to their references (nothing is copied); what is complete by now is
+// announced to the waiting consumers.
 void merge_parts(spl_bam *bam, std::vector<Sink::Part> &parts)
 {
+    std::lock_guard<std::mutex> lock(bam->mu);
     for (Sink::Part &pt : parts) {
-        bam->pending->emplace_back();
-        bam->pending->back().tid = pt.tid;
-        bam->pending->back().reads = std::move(pt.reads);
+        if (pt.reads.pos.empty()) continue;
+        if (pt.tid < bam->max_tid_seen) bam->out_of_order = true;
+        if (pt.tid > bam->max_tid_seen) bam->max_tid_seen = pt.tid;
+        PendingPart *pp = new PendingPart();
+        pp->tid = pt.tid;
+        pp->reads = std::move(pt.reads);
+        bam->ref_reads[(size_t)pt.tid] += (int64_t)pp->reads.pos.size();
+        if (pp->reads.max_end > bam->ref_max_end[(size_t)pt.tid]) bam->ref_max_end[(size_t)pt.tid] = pp->reads.max_end;
+        bam->parts[(size_t)pt.tid].push_back(pp);
     }
+    if (bam->max_tid_seen > bam->complete_upto) bam->complete_upto = bam->max_tid_seen;
+    bam->cv.notify_all();
 }
 
-bool assemble(spl_bam *bam, int n_threads, const NodeCpus &node, std::string &err)
+// BAM-native arrays of one reference (spl_bam_reads): one exact-size allocation per array, copied from the parts.
+bool assemble_ref(spl_bam *bam, int tid, std::string &err)
 {
-    std::vector<PendingPart> &parts = *bam->pending;
-    const int n_ref = bam->n_refs;
-    std::vector<int64_t> n_reads((size_t)n_ref, 0), n_ops((size_t)n_ref, 0);
-    for (PendingPart &pt : parts) {
-        pt.read_at = n_reads[(size_t)pt.tid];
-        pt.op_at = n_ops[(size_t)pt.tid];
-        n_reads[(size_t)pt.tid] += (int64_t)pt.reads.pos.size();
-        n_ops[(size_t)pt.tid] += (int64_t)pt.reads.cigar.size();
-        RefFinal &dst = bam->refs[pt.tid];
-        if (pt.reads.max_end > dst.max_end) dst.max_end = pt.reads.max_end;
-    }
-    for (int t = 0; t < n_ref; ++t) {
-        RefFinal &dst = bam->refs[t];
-        dst.n = n_reads[(size_t)t];
-        dst.n_cigar = n_ops[(size_t)t];
-        if (dst.n_cigar > 0xfffffff0LL) { err = "more than 2^32 CIGAR operations on one reference"; return false; }
-        dst.pos = (int32_t *)big_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(dst.n, 1));
-        dst.flag = (uint16_t *)big_alloc(sizeof(uint16_t) * (size_t)std::max<int64_t>(dst.n, 1));
-        dst.cig_off = (uint32_t *)big_alloc(sizeof(uint32_t) * (size_t)(dst.n + 1));
-        dst.cigar = (uint32_t *)big_alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(dst.n_cigar, 1));
-        if (!dst.pos || !dst.flag || !dst.cig_off || !dst.cigar) { err = "out of host memory"; return false; }
-        dst.cig_off[0] = 0;
+    RefFinal &dst = bam->refs_storage[(size_t)tid];
+    const std::vector<PendingPart *> &parts = bam->parts[(size_t)tid];
+    int64_t n = 0, g = 0;
+    for (const PendingPart *pt : parts) { n += (int64_t)pt->reads.pos.size(); g += (int64_t)pt->reads.cigar.size(); }
+    if (g > 0xfffffff0LL) { err = "more than 2^32 CIGAR operations on one reference"; return false; }
+    dst.n = n;
+    dst.n_cigar = g;
+    dst.max_end = bam->ref_max_end[(size_t)tid];
+    dst.pos = (int32_t *)big_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1));
+    dst.flag = (uint16_t *)big_alloc(sizeof(uint16_t) * (size_t)std::max<int64_t>(n, 1));
+    dst.cig_off = (uint32_t *)big_alloc(sizeof(uint32_t) * (size_t)(n + 1));
+    dst.cigar = (uint32_t *)big_alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(g, 1));
+    if (!dst.pos || !dst.flag || !dst.cig_off || !dst.cigar) { err = "out of host memory"; return false; }
+    dst.cig_off[0] = 0;
+    std::vector<int64_t> read_at(parts.size() + 1, 0), op_at(parts.size() + 1, 0);
+    for (size_t i = 0; i < parts.size(); ++i) {
+        read_at[i + 1] = read_at[i] + (int64_t)parts[i]->reads.pos.size();
+        op_at[i + 1] = op_at[i] + (int64_t)parts[i]->reads.cigar.size();
     }
     std::atomic<size_t> next(0);
     auto work = [&]() {
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= parts.size()) break;
-            PendingPart &pt = parts[i];
-            RefFinal &dst = bam->refs[pt.tid];
-            const RefReads &src = pt.reads;
-            const size_t n = src.pos.size();
-            if (n) {
-                memcpy(dst.pos + pt.read_at, src.pos.data(), sizeof(int32_t) * n);
-                memcpy(dst.flag + pt.read_at, src.flag.data(), sizeof(uint16_t) * n);
-                const uint32_t base = (uint32_t)pt.op_at;
-                uint32_t *off = dst.cig_off + pt.read_at; // entry k + 1 = end of read k
-                for (size_t k = 1; k <= n; ++k) off[k] = base + src.cig_off[k];
-                if (!src.cigar.empty()) memcpy(dst.cigar + pt.op_at, src.cigar.data(), sizeof(uint32_t) * src.cigar.size());
-            }
-            RefReads().swap_into(pt.reads); // give the part's memory back as soon as it is copied
+            const RefReads &src = parts[i]->reads;
+            const size_t k = src.pos.size();
+            if (!k) continue;
+            memcpy(dst.pos + read_at[i], src.pos.data(), sizeof(int32_t) * k);
+            memcpy(dst.flag + read_at[i], src.flag.data(), sizeof(uint16_t) * k);
+            const uint32_t base = (uint32_t)op_at[i];
+            uint32_t *off = dst.cig_off + read_at[i]; // entry j + 1 = end of read j
+            for (size_t j = 1; j <= k; ++j) off[j] = base + src.cig_off[j];
+            if (!src.cigar.empty()) memcpy(dst.cigar + op_at[i], src.cigar.data(), sizeof(uint32_t) * src.cigar.size());
         }
     };
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, parts.size()));
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::min(bam->n_threads, 16), parts.size()));
     std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back([&]() { node.pin_this_thread(); work(); });
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
     work();
     for (auto &th : pool) th.join();
-    parts.clear();
-    parts.shrink_to_fit();
     return true;
 }
 
@@ -494,6 +520,7 @@ struct Parser {
     const NodeCpus *node = nullptr;
     int n_threads = 1;
     bool header_done = false;
+    bool bam_header_set = false; // spl_bam already has names, lengths and per-reference state
     std::string err;
 
     // Consume as many complete items as possible from [p, end); returns bytes consumed.
@@ -521,12 +548,17 @@ struct Parser {
                 lens.push_back(le32(q + 4 + l_name));
                 q += 4 + l_name + 4;
             }
-            bam->ref_names.swap(names);
-            bam->ref_lengths.swap(lens);
-            bam->refs_storage = std::vector<RefFinal>((size_t)n_ref);
-            bam->refs = bam->refs_storage.data();
-            bam->n_refs = n_ref;
-            if (!bam->pending) bam->pending = new std::vector<PendingPart>();
+            if (!bam_header_set) { // (the opening call has parsed the header already: same bytes, same result)
+                std::lock_guard<std::mutex> lock(bam->mu);
+                bam->ref_names.swap(names);
+                bam->ref_lengths.swap(lens);
+                bam->refs_storage = std::vector<RefFinal>((size_t)n_ref);
+                bam->assembled.assign((size_t)n_ref, 0);
+                bam->parts.assign((size_t)n_ref, std::vector<PendingPart *>());
+                bam->ref_max_end.assign((size_t)n_ref, 0);
+                bam->ref_reads.assign((size_t)n_ref, 0);
+                bam->n_refs = n_ref;
+            }
             header_done = true;
             p = q;
         }
@@ -537,69 +569,19 @@ struct Parser {
 
 } // namespace
 
-extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
+namespace {
+
+// The decode proper, on the file's own thread: segments of blocks, double-buffered -- while the records of segment k are being
+// extracted (parse threads), the blocks of segment k+1 are already being inflated (inflate threads).  Ends by setting `done`
+// (and `error`).
+void decode_worker(spl_bam *bam)
 {
-    if (!path || !out) return spl_set_error(SPL_ERR_ARG, "spl_bam_open: null argument");
-    *out = nullptr;
-    const int fd = open(path, O_RDONLY);
-    if (fd < 0) return spl_set_error(SPL_ERR_IO, "cannot open %s", path);
-    struct stat st;
-    if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); return spl_set_error(SPL_ERR_IO, "cannot stat %s (or empty file)", path); }
-    const size_t fsize = (size_t)st.st_size;
-    void *map = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (map == MAP_FAILED) return spl_set_error(SPL_ERR_IO, "mmap failed for %s", path);
-    madvise(map, fsize, MADV_SEQUENTIAL);
-    const uint8_t *file = (const uint8_t *)map;
-
-    // 1. block directory (headers only)
-    std::vector<Block> blocks;
-    size_t off = 0;
-    int rc = SPL_OK;
-    while (off < fsize) {
-        if (fsize - off < 18 || file[off] != 0x1f || file[off + 1] != 0x8b || file[off + 2] != 8 || !(file[off + 3] & 4)) {
-            rc = spl_set_error(SPL_ERR_FORMAT, "%s: not BGZF at offset %zu (BAM files are BGZF-compressed)", path, off);
-            break;
-        }
-        const uint32_t xlen = le16(file + off + 10);
-        if (fsize - off < 12 + (size_t)xlen) { rc = spl_set_error(SPL_ERR_FORMAT, "%s: truncated BGZF header", path); break; }
-        uint32_t bsize = 0;
-        bool have = false;
-        for (size_t x = off + 12; x + 4 <= off + 12 + xlen;) {
-            const uint32_t slen = le16(file + x + 2);
-            if (file[x] == 'B' && file[x + 1] == 'C' && slen == 2) { bsize = (uint32_t)le16(file + x + 4) + 1; have = true; }
-            x += 4 + slen;
-        }
-        if (!have || bsize < 12 + xlen + 8 || fsize - off < bsize) {
-            rc = spl_set_error(SPL_ERR_FORMAT, "%s: corrupt or truncated BGZF block at offset %zu", path, off);
-            break;
-        }
-        Block b;
-        b.coff = off; b.csize = bsize; b.xlen = xlen; b.isize = le32(file + off + bsize - 4);
-        if (b.isize > 65536) { rc = spl_set_error(SPL_ERR_FORMAT, "%s: BGZF ISIZE > 64 KiB at offset %zu", path, off); break; }
-        blocks.push_back(b);
-        off += bsize;
-    }
-    if (rc != SPL_OK) { munmap(map, fsize); return rc; }
-    if (blocks.empty() || blocks.back().isize != 0) {
-        // htslib only warns about a missing EOF marker; a truncated file is far more likely than a writer
-        // that omits it, and silently counting fewer reads is the reference's worst failure mode: refuse.
-        munmap(map, fsize);
-        return spl_set_error(SPL_ERR_IO, "%s: BGZF EOF marker missing -- file is truncated", path);
-    }
-
-    spl_bam *bam = new (std::nothrow) spl_bam();
-    if (!bam) { munmap(map, fsize); return spl_set_error(SPL_ERR_NOMEM, "out of host memory"); }
-    if (n_threads <= 0) { // default: all cores up to 32 (beyond that thread start-up per segment costs more than it buys)
-        n_threads = (int)std::thread::hardware_concurrency();
-        if (n_threads > 32) n_threads = 32;
-    }
-    if (n_threads <= 0) n_threads = 1;
-
-    const NodeCpus node; // the caller's NUMA node: all worker threads stay there
-    // 2. segments of blocks, double-buffered: while the records of segment k are being extracted (parse threads), the
-    //    blocks of segment k+1 are already being inflated (inflate threads).
-    const size_t SEG_BLOCKS = 8192; // <= 512 MiB uncompressed (fewer, larger segments: thread start-up and stragglers are per segment)
+    const uint8_t *file = (const uint8_t *)bam->map;
+    const std::vector<Block> &blocks = bam->blocks;
+    const int n_threads = bam->n_threads;
+    const NodeCpus node; // the NUMA node this thread runs on (the opening thread's, inherited): all worker threads stay there
+    const size_t SEG_BLOCKS = []() { const char *e = getenv("SPL_BAM_SEG_BLOCKS"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)4096; }();
+    // (<= 256 MiB uncompressed per segment: a reference is announced complete at segment granularity)
     const size_t HEAD = 4u << 20;   // room in front of a segment for the incomplete record carried over from the previous one
     const size_t n_seg = (blocks.size() + SEG_BLOCKS - 1) / SEG_BLOCKS;
     // two inflate buffers of the size of the largest segment: never zero-filled, huge pages where the system gives them
@@ -609,6 +591,7 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
         for (size_t i = sg * SEG_BLOCKS; i < std::min(blocks.size(), (sg + 1) * SEG_BLOCKS); ++i) bytes_in += blocks[i].isize;
         seg_max = std::max(seg_max, bytes_in);
     }
+    std::string fail;
     struct RawBuf {
         uint8_t *p = nullptr;
         ~RawBuf() { free(p); }
@@ -616,7 +599,7 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
     } bufs[2];
     for (int k = 0; k < 2; ++k) {
         bufs[k].p = (uint8_t *)big_alloc(HEAD + seg_max + 64);
-        if (!bufs[k].p) { delete bam; munmap(map, fsize); return spl_set_error(SPL_ERR_NOMEM, "out of host memory for the inflate buffers"); }
+        if (!bufs[k].p) fail = "out of host memory for the inflate buffers";
     }
     size_t seg_bytes[2] = {0, 0};
     std::atomic<bool> bad(false);
@@ -650,10 +633,10 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
     parser.bam = bam;
     parser.node = &node;
     parser.n_threads = n_threads;
-    std::string fail;
+    parser.bam_header_set = true;
     std::vector<uint8_t> carry_bytes;
     size_t carry = 0;
-    inflate_segment(0);
+    if (fail.empty()) inflate_segment(0);
     for (size_t seg = 0; seg < n_seg && fail.empty(); ++seg) {
         if (bad.load()) { fail = "inflate or CRC32 failure in a BGZF block (corrupt file)"; break; }
         std::thread ahead;
@@ -684,19 +667,178 @@ extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
         t_wait += now() - t1;
     }
     if (fail.empty() && bad.load()) fail = "inflate or CRC32 failure in a BGZF block (corrupt file)";
-    munmap(map, fsize);
     if (timing) fprintf(stderr, "[spl_bam_open] %zu blocks, %d threads: parse %.3f s, waiting for inflate %.3f s\n", blocks.size(), n_threads, t_parse, t_wait);
     if (fail.empty() && !parser.header_done) fail = "no BAM header found";
     if (fail.empty() && carry != 0) fail = "file ends inside a record (truncated)";
-    const double t_asm0 = now();
-    if (fail.empty() && !assemble(bam, n_threads, node, fail) && fail.empty()) fail = "assembling the per-reference arrays failed";
-    if (timing) fprintf(stderr, "[spl_bam_open] per-reference arrays assembled in %.3f s\n", now() - t_asm0);
-    if (!fail.empty()) {
+    {
+        std::lock_guard<std::mutex> lock(bam->mu);
+        if (!fail.empty()) { bam->error = bam->path + ": " + fail; bam->err_code = SPL_ERR_FORMAT; }
+        bam->complete_upto = bam->n_refs;
+        bam->done = true;
+    }
+    bam->cv.notify_all();
+}
+
+// The BAM header (magic, text, reference dictionary) from the first blocks of the file, inflated one by one until it is whole.
+int read_header(spl_bam *bam, std::string &fail)
+{
+    const uint8_t *file = (const uint8_t *)bam->map;
+    std::vector<uint8_t> head;
+    void *ld = deflate_lib().ok ? deflate_lib().alloc() : nullptr;
+    int rc = 1; // 1 = need more, 0 = done, -1 = failed
+    for (size_t i = 0; i < bam->blocks.size() && rc == 1; ++i) {
+        const Block &b = bam->blocks[i];
+        const size_t at = head.size();
+        head.resize(at + b.isize);
+        if (!inflate_block(file, b, head.data() + at, ld)) { fail = "inflate or CRC32 failure in a BGZF block (corrupt file)"; rc = -1; break; }
+        const uint8_t *p = head.data(), *end = head.data() + head.size();
+        if (end - p < 12) continue;
+        if (memcmp(p, "BAM\1", 4) != 0) { fail = "not a BAM file (bad magic)"; rc = -1; break; }
+        const uint32_t l_text = le32(p + 4);
+        if ((size_t)(end - p) < 12 + (size_t)l_text) continue;
+        const uint8_t *q = p + 8 + l_text;
+        const int32_t n_ref = le32s(q);
+        q += 4;
+        if (n_ref < 0) { fail = "negative n_ref"; rc = -1; break; }
+        std::vector<std::string> names;
+        std::vector<int64_t> lens;
+        bool whole = true;
+        for (int32_t k = 0; k < n_ref; ++k) {
+            if (end - q < 4) { whole = false; break; }
+            const uint32_t l_name = le32(q);
+            if ((size_t)(end - q) < 4 + (size_t)l_name + 4) { whole = false; break; }
+            names.emplace_back((const char *)q + 4, l_name ? l_name - 1 : 0);
+            lens.push_back(le32(q + 4 + l_name));
+            q += 4 + l_name + 4;
+        }
+        if (!whole) continue;
+        bam->ref_names.swap(names);
+        bam->ref_lengths.swap(lens);
+        bam->refs_storage = std::vector<RefFinal>((size_t)n_ref);
+        bam->assembled.assign((size_t)n_ref, 0);
+        bam->parts.assign((size_t)n_ref, std::vector<PendingPart *>());
+        bam->ref_max_end.assign((size_t)n_ref, 0);
+        bam->ref_reads.assign((size_t)n_ref, 0);
+        bam->n_refs = n_ref;
+        rc = 0;
+    }
+    if (ld) deflate_lib().free_(ld);
+    if (rc == 1) fail = "no BAM header found";
+    return rc == 0 ? 0 : -1;
+}
+
+} // namespace
+
+// Opens the file, reads the block directory and the header, and starts the decode on a thread of its own.
+extern "C" int spl_bam_open_stream(const char *path, int n_threads, spl_bam **out)
+{
+    if (!path || !out) return spl_set_error(SPL_ERR_ARG, "spl_bam_open: null argument");
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return spl_set_error(SPL_ERR_IO, "cannot open %s", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); return spl_set_error(SPL_ERR_IO, "cannot stat %s (or empty file)", path); }
+    const size_t fsize = (size_t)st.st_size;
+    void *map = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return spl_set_error(SPL_ERR_IO, "mmap failed for %s", path);
+    madvise(map, fsize, MADV_SEQUENTIAL);
+    const uint8_t *file = (const uint8_t *)map;
+
+    // 1. block directory (headers only)
+    std::vector<Block> blocks;
+    size_t off = 0;
+    int rc = SPL_OK;
+    while (off < fsize) {
+        if (fsize - off < 18 || file[off] != 0x1f || file[off + 1] != 0x8b || file[off + 2] != 8 || !(file[off + 3] & 4)) {
+            rc = spl_set_error(SPL_ERR_FORMAT, "%s: not BGZF at offset %zu (BAM files are BGZF-compressed)", path, off);
+            break;
+        }
+        const uint32_t xlen = le16(file + off + 10);
+        if (fsize - off < 12 + (size_t)xlen) { rc = spl_set_error(SPL_ERR_FORMAT, "%s: truncated BGZF header", path); break; }
+        uint32_t bsize = 0;
+        bool have = false;
+        const size_t x_end = off + 12 + xlen;
+        for (size_t x = off + 12; x + 4 <= x_end;) {
+            const uint32_t slen = le16(file + x + 2);
+            if (x + 4 + (size_t)slen > x_end) break; // a subfield that runs past the extra area: corrupt, and not ours to read
+            if (file[x] == 'B' && file[x + 1] == 'C' && slen == 2) { bsize = (uint32_t)le16(file + x + 4) + 1; have = true; }
+            x += 4 + slen;
+        }
+        if (!have || bsize < 12 + xlen + 8 || fsize - off < bsize) {
+            rc = spl_set_error(SPL_ERR_FORMAT, "%s: corrupt or truncated BGZF block at offset %zu", path, off);
+            break;
+        }
+        Block b;
+        b.coff = off; b.csize = bsize; b.xlen = xlen; b.isize = le32(file + off + bsize - 4);
+        if (b.isize > 65536) { rc = spl_set_error(SPL_ERR_FORMAT, "%s: BGZF ISIZE > 64 KiB at offset %zu", path, off); break; }
+        blocks.push_back(b);
+        off += bsize;
+    }
+    if (rc != SPL_OK) { munmap(map, fsize); return rc; }
+    if (blocks.empty() || blocks.back().isize != 0) {
+        // htslib only warns about a missing EOF marker; a truncated file is far more likely than a writer
+        // that omits it, and silently counting fewer reads is the reference's worst failure mode: refuse.
+        munmap(map, fsize);
+        return spl_set_error(SPL_ERR_IO, "%s: BGZF EOF marker missing -- file is truncated", path);
+    }
+
+    spl_bam *bam = new (std::nothrow) spl_bam();
+    if (!bam) { munmap(map, fsize); return spl_set_error(SPL_ERR_NOMEM, "out of host memory"); }
+    bam->map = map;
+    bam->fsize = fsize;
+    bam->blocks.swap(blocks);
+    bam->path = path;
+    if (n_threads <= 0) { // default: all cores up to 32 (beyond that thread start-up per segment costs more than it buys)
+        n_threads = (int)std::thread::hardware_concurrency();
+        if (n_threads > 32) n_threads = 32;
+    }
+    bam->n_threads = n_threads > 0 ? n_threads : 1;
+    std::string fail;
+    if (read_header(bam, fail) != 0) {
         delete bam;
         return spl_set_error(SPL_ERR_FORMAT, "%s: %s", path, fail.c_str());
     }
+    bam->worker = std::thread(decode_worker, bam);
     *out = bam;
     return SPL_OK;
+}
+
+static int decode_status(spl_bam *bam) // (call with bam->mu held)
+{
+    if (bam->err_code) return spl_set_error(bam->err_code, "%s", bam->error.c_str());
+    return SPL_OK;
+}
+
+extern "C" int spl_bam_wait_ref(spl_bam *bam, int tid, int64_t *n_reads_out, int64_t *max_end_out)
+{
+    if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_wait_ref: null argument");
+    if (tid < 0 || tid >= bam->n_refs) return spl_set_error(SPL_ERR_ARG, "tid %d out of range", tid);
+    std::unique_lock<std::mutex> lock(bam->mu);
+    bam->cv.wait(lock, [&]() { return bam->done || tid < bam->complete_upto; });
+    const int rc = decode_status(bam);
+    if (rc) return rc;
+    if (n_reads_out) *n_reads_out = bam->ref_reads[(size_t)tid];
+    if (max_end_out) *max_end_out = bam->ref_max_end[(size_t)tid];
+    return SPL_OK;
+}
+
+extern "C" int spl_bam_wait_all(spl_bam *bam, int *sorted_out)
+{
+    if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_wait_all: null argument");
+    std::unique_lock<std::mutex> lock(bam->mu);
+    bam->cv.wait(lock, [&]() { return bam->done; });
+    if (sorted_out) *sorted_out = bam->out_of_order ? 0 : 1;
+    return decode_status(bam);
+}
+
+extern "C" int spl_bam_open(const char *path, int n_threads, spl_bam **out)
+{
+    int rc = spl_bam_open_stream(path, n_threads, out);
+    if (rc != SPL_OK) return rc;
+    rc = spl_bam_wait_all(*out, nullptr);
+    if (rc != SPL_OK) { delete *out; *out = nullptr; }
+    return rc;
 }
 
 extern "C" void spl_bam_close(spl_bam *bam) { delete bam; }
@@ -711,19 +853,49 @@ extern "C" int64_t spl_bam_ref_length(const spl_bam *bam, int tid)
     if (!bam || tid < 0 || (size_t)tid >= bam->ref_lengths.size()) return -1;
     return bam->ref_lengths[(size_t)tid];
 }
-extern "C" int64_t spl_bam_n_records(const spl_bam *bam) { return bam ? bam->n_records : 0; }
-
-extern "C" int spl_bam_reads(const spl_bam *bam, int tid, spl_reads *out, int64_t *max_end_out)
+extern "C" int64_t spl_bam_n_records(const spl_bam *bam)
 {
+    if (!bam) return 0;
+    spl_bam *b = const_cast<spl_bam *>(bam);
+    std::unique_lock<std::mutex> lock(b->mu);
+    b->cv.wait(lock, [&]() { return b->done; });
+    return b->n_records;
+}
+
+extern "C" int spl_bam_reads(const spl_bam *cbam, int tid, spl_reads *out, int64_t *max_end_out)
+{
+    spl_bam *bam = const_cast<spl_bam *>(cbam);
     if (!bam || !out) return spl_set_error(SPL_ERR_ARG, "spl_bam_reads: null argument");
     if (tid < 0 || tid >= bam->n_refs) return spl_set_error(SPL_ERR_ARG, "tid %d out of range", tid);
-    const RefFinal &rr = bam->refs[tid];
+    int rc = spl_bam_wait_all(bam, nullptr); // (the whole file: these arrays must hold every record of the reference, sorted file or not)
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(bam->mu);
+    if (!bam->assembled[(size_t)tid]) {
+        std::string err;
+        if (!assemble_ref(bam, tid, err)) return spl_set_error(SPL_ERR_NOMEM, "%s: %s", bam->path.c_str(), err.c_str());
+        bam->assembled[(size_t)tid] = 1;
+    }
+    const RefFinal &rr = bam->refs_storage[(size_t)tid];
     out->n_reads = rr.n;
     out->pos = rr.pos;
     out->flag = rr.flag;
     out->cig_off = rr.cig_off;
     out->cigar = rr.cigar;
     if (max_end_out) *max_end_out = rr.max_end;
+    return SPL_OK;
+}
+
+int spl_bam_source(spl_bam *bam, int tid, splpack::Source *out, int64_t *max_end_out)
+{
+    if (!bam || !out) return spl_set_error(SPL_ERR_ARG, "spl_bam_source: null argument");
+    int rc = spl_bam_wait_ref(bam, tid, nullptr, max_end_out);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(bam->mu);
+    for (const PendingPart *pt : bam->parts[(size_t)tid]) {
+        const RefReads &r = pt->reads;
+        if (r.pos.empty()) continue;
+        out->add(splpack::Part{r.pos.data(), r.flag.data(), r.cig_off.data(), r.cigar.data(), (int64_t)r.pos.size()});
+    }
     return SPL_OK;
 }
 

@@ -3,17 +3,22 @@
 #include <hip/hip_runtime_api.h>
 #include <hip/hip_vector_types.h>
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/spliser.h"
+#include "spl_bam.h"
 #include "spl_device.h"
 #include "spl_error.h"
+#include "spl_pack.h"
 
 // ---- error plumbing -------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
@@ -57,6 +62,16 @@ struct spl_ctx {
     bool tail_host_wait = false;
     bool tail_pending = false; // the main stream has not been made to wait for the last tail yet
     int32_t *d_err = nullptr;               // error word of launches that are not counting passes (spl_junctions)
+    // Read sets reach the device through a ring of page-locked staging buffers: the host packer (spl_pack.h) writes a piece of
+    // a segment's records into one of them while the DMA engine drains the others on a stream of their own.  Locked with
+    // hipHostRegister: on this stack that costs 0.7 ms per 32 MiB where hipHostMalloc costs 5 (tools/micro/hostmem.cpp), and
+    // copies run at 50...55 GB/s from pieces of this size (20 GB/s from 8 MiB pieces).
+    struct Stage { char *host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool busy = false, locked = false; };
+    std::vector<Stage> stage;
+    size_t stage_next = 0;
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_copy = nullptr;
+    int pack_threads = 1;
     int last_grid = 0, last_lds = 0, last_variant = 0;
     struct Junction { int32_t left, right; uint8_t strand; uint32_t count, anchor_left, anchor_right; };
     std::vector<Junction> junctions; // result of the last spl_junctions call, sorted
@@ -125,19 +140,29 @@ struct spl_dsites {
 };
 
 struct spl_dreads {
+    // A read set = segments (one reference of a BAM file, one caller array, ...) packed on the host into the chunked layout of
+    // spl_pack.h, each in a device allocation of its own with a coordinate shift of its own; the kernels see one flat list of
+    // chunk descriptors.
+    struct Segment {
+        char *slab = nullptr;       // records, then the wide ops
+        uint64_t rec_bytes = 0, n_wide = 0;
+        int64_t n_reads = 0, n_ops = 0;
+        int32_t shift = 0;
+        std::vector<splpack::ChunkDesc> chunks;
+    };
+    std::vector<Segment> segs;
     int64_t n_reads = 0, n_cigar = 0;
-    char *slab = nullptr;
-    int32_t *pos = nullptr;
-    uint16_t *flag = nullptr;
-    uint32_t *cig_off = nullptr, *cigar = nullptr;
-    uint32_t *fn = nullptr, *ops3 = nullptr;       // the range kernel's own layout, packed on the device at upload
-    int32_t *ppos = nullptr;
-    uint16_t *perm = nullptr;
-    uint32_t *chunk_order = nullptr; // slot of an XCD slice -> chunk, longest first (holds the cost estimates during upload)
+    uint32_t n_chunks = 0;
+    bool finished = false;
+    char *ctl = nullptr;            // chunk descriptors, chunk order, the queues (allocated by spl_reads_finish)
+    spl_chunk_meta *meta = nullptr;
+    uint32_t *chunk_order = nullptr; // slot of an XCD slice -> chunk, longest first
     uint32_t *queue = nullptr; // reads the range kernel hands to the literal kernel (the counters are with the site table)
     uint32_t *queue_alt = nullptr;     // ... and the buffer the NEXT pass writes while this pass's literal kernel still reads
+    uint32_t *queue_total = nullptr;   // entries the last pass queued (written by its literal kernel)
+    uint32_t queue_cap = 0;
     mutable int queue_turn = 0;        // which of the two the next pass takes
-    mutable const uint32_t *last_queue_n = nullptr; // ... of the last counting pass over this read set (spl_literal_queue_size)
+    mutable bool queued_pass = false;  // the last counting pass over this read set had a literal kernel
 };
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -206,6 +231,8 @@ static int create_ctx(int device_id, void *stream, bool use_given, spl_ctx **out
 extern "C" int spl_create(int device_id, spl_ctx **out) { return create_ctx(device_id, nullptr, false, out); }
 extern "C" int spl_create_on_stream(int device_id, void *hip_stream, spl_ctx **out) { return create_ctx(device_id, hip_stream, true, out); }
 
+static void free_stage(spl_ctx *c);
+
 extern "C" void spl_destroy(spl_ctx *c)
 {
     if (!c) return;
@@ -221,6 +248,7 @@ extern "C" void spl_destroy(spl_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->k_ev) (void)hipEventDestroy(e);
     if (c->d_err) (void)hipFree(c->d_err);
+    free_stage(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -602,83 +630,312 @@ extern "C" void spl_sites_free(spl_ctx *c, spl_dsites *d)
 }
 
 // ---- reads upload ---------------------------------------------------------------------------------------
-// One read set on the device from n_seg host segments laid end to end (segment k shifted by pos_shift[k]); a plain
-// spl_reads_upload is the one-segment case.
-static int upload_segments(spl_ctx *c, int n_seg, const spl_reads *segs, const int32_t *pos_shift, spl_dreads **out, const char *who)
+// The staging ring and the copy stream of a context (created at the first upload).
+static int ensure_stage(spl_ctx *c)
 {
-    *out = nullptr;
-    int64_t R = 0, G = 0;
-    for (int k = 0; k < n_seg; ++k) {
-        const spl_reads *r = &segs[k];
-        if (r->n_reads < 0) return spl_set_error(SPL_ERR_ARG, "%s: negative n_reads", who);
-        if (r->n_reads && (!r->pos || !r->flag || !r->cig_off)) return spl_set_error(SPL_ERR_ARG, "read set has null arrays");
-        if (r->n_reads && r->cig_off[0] != 0) return spl_set_error(SPL_ERR_ARG, "cig_off[0] must be 0");
-        const int64_t g = r->n_reads ? r->cig_off[r->n_reads] : 0;
-        if (g && !r->cigar) return spl_set_error(SPL_ERR_ARG, "cigar is null");
-        R += r->n_reads;
-        G += g;
+    if (!c->stage.empty()) return SPL_OK;
+    size_t mb = 32;
+    int n = 3;
+    if (const char *e = getenv("SPL_STAGE_MB")) { const long v = atol(e); if (v >= 1 && v <= 4096) mb = (size_t)v; }
+    if (const char *e = getenv("SPL_STAGE_BUFFERS")) { const int v = atoi(e); if (v >= 1 && v <= 16) n = v; }
+    {
+        int t = (int)std::thread::hardware_concurrency();
+        if (const char *e = getenv("SPL_PACK_THREADS")) { const int v = atoi(e); if (v > 0) t = v; }
+        else if (t > 32) t = 32;
+        c->pack_threads = t > 0 ? t : 1;
     }
-    if (R > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "n_reads out of range (counters are 32-bit)");
-    if (G > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops in one read set: use more shards");
-    HIP_TRY(hipSetDevice(c->device));
-    spl_dreads *d = new (std::nothrow) spl_dreads();
-    if (!d) return spl_set_error(SPL_ERR_NOMEM, "out of host memory");
-    d->n_reads = R; d->n_cigar = G;
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+    const size_t huge = 2u << 20, bytes = (mb << 20) / huge * huge < huge ? huge : (mb << 20) / huge * huge;
+    const bool want_lock = !(getenv("SPL_STAGE_PAGEABLE"));
+    for (int k = 0; k < n; ++k) {
+        spl_ctx::Stage st;
+        void *p = nullptr;
+        if (posix_memalign(&p, huge, bytes) != 0) return spl_set_error(SPL_ERR_NOMEM, "out of host memory for the staging buffers");
+        (void)madvise(p, bytes, MADV_HUGEPAGE);
+        memset(p, 0, bytes); // touch: the pages exist before they are locked
+        st.host = (char *)p;
+        st.bytes = bytes;
+        st.locked = want_lock && hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess; // (pageable works too, slower)
+        if (hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) { if (st.locked) (void)hipHostUnregister(p); free(p); return spl_set_error(SPL_ERR_HIP, "hipEventCreate failed"); }
+        c->stage.push_back(st);
+    }
+    return SPL_OK;
+}
+
+static void free_stage(spl_ctx *c)
+{
+    if (c->copy) (void)hipStreamSynchronize(c->copy);
+    for (spl_ctx::Stage &st : c->stage) {
+        if (st.done) (void)hipEventDestroy(st.done);
+        if (st.locked) (void)hipHostUnregister(st.host);
+        free(st.host);
+    }
+    c->stage.clear();
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->copy) (void)hipStreamDestroy(c->copy);
+    c->ev_copy = nullptr;
+    c->copy = nullptr;
+}
+
+namespace {
+struct EmitJob {
+    const splpack::Source *src;
+    const splpack::Plan *plan;
+    size_t c0, c1, per;
+    uint8_t *rec;
+    uint32_t *wide;
+};
+void emit_slice(size_t k, void *arg)
+{
+    const EmitJob &j = *(const EmitJob *)arg;
+    const size_t a = j.c0 + k * j.per, b = std::min(j.c1, a + j.per);
+    if (a >= b) return;
+    const splpack::ChunkDesc &d0 = j.plan->chunks[j.c0], &da = j.plan->chunks[a];
+    splpack::emit(*j.src, *j.plan, a, b, j.rec + (da.rec_off - d0.rec_off), j.wide + (da.wide_off - d0.wide_off));
+}
+} // namespace
+
+// One more segment of a read set under construction: packed on this host's threads piece by piece into the staging ring,
+// each piece on its way to the device while the next is packed.  The source arrays are not needed after return.
+static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, int32_t shift, int64_t max_end)
+{
+    if (d->finished) return spl_set_error(SPL_ERR_ARG, "the read set is finished: no more segments");
+    if (src.n_reads == 0) return SPL_OK;
+    if (d->n_reads + src.n_reads > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "n_reads out of range (counters are 32-bit)");
+    if (max_end >= 0 && max_end + (int64_t)shift > (int64_t)SPL_COORD_MAX)
+        return spl_set_error(SPL_ERR_RANGE, "a read ends beyond coordinate %d once its segment is moved by %d: split the shard (spliser_amd/shard.py)",
+                             SPL_COORD_MAX, shift);
+    int rc = ensure_stage(c);
+    if (rc) return rc;
+    splpack::Plan plan;
+    splpack::plan(src, plan, c->pack_threads);
+    if (plan.n_wide > 0xfffffff0ull) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops of wide reads in one segment: use more shards");
+    if ((uint64_t)d->n_chunks + plan.chunks.size() > (1ull << (32 - SPL_CHUNK_SHIFT)))
+        return spl_set_error(SPL_ERR_ARG, "too many reads in one read set: use more shards");
+    d->segs.emplace_back();
+    spl_dreads::Segment &seg = d->segs.back();
+    seg.rec_bytes = plan.rec_bytes; seg.n_wide = plan.n_wide; seg.n_reads = src.n_reads; seg.n_ops = src.n_ops; seg.shift = shift;
+    const size_t rec_al = align_up((size_t)plan.rec_bytes);
+    const size_t slab_bytes = rec_al + 4 * (size_t)plan.n_wide + 256;
+    hipError_t e = hipMalloc((void **)&seg.slab, slab_bytes);
+    if (e != hipSuccess) { d->segs.pop_back(); return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for a read segment: %s", slab_bytes, hipGetErrorString(e)); }
+    const size_t n_chunks = plan.chunks.size();
+    auto rec_end = [&](size_t k) { return k + 1 < n_chunks ? plan.chunks[k + 1].rec_off : plan.rec_bytes; };
+    auto wide_end = [&](size_t k) { return k + 1 < n_chunks ? plan.chunks[k + 1].wide_off : plan.n_wide; };
+    hipError_t q = hipSuccess;
+    for (size_t c0 = 0; c0 < n_chunks && q == hipSuccess;) {
+        spl_ctx::Stage &st = c->stage[c->stage_next];
+        c->stage_next = (c->stage_next + 1) % c->stage.size();
+        if (st.busy) { q = hipEventSynchronize(st.done); st.busy = false; if (q != hipSuccess) break; }
+        const uint64_t r0 = plan.chunks[c0].rec_off, w0 = plan.chunks[c0].wide_off;
+        size_t c1 = c0;
+        auto need = [&](size_t k) { return align_up((size_t)(rec_end(k) - r0)) + 4 * (size_t)(wide_end(k) - w0); };
+        while (c1 < n_chunks && need(c1) <= st.bytes) ++c1;
+        char *host = st.host;
+        std::vector<char> big; // a single chunk that does not fit a staging buffer (reads of a million ops): pageable, one at a time
+        if (c1 == c0) { c1 = c0 + 1; big.resize(need(c0)); host = big.data(); }
+        const size_t rec_span = (size_t)(rec_end(c1 - 1) - r0), wide_span = (size_t)(wide_end(c1 - 1) - w0);
+        EmitJob job{&src, &plan, c0, c1, 1, (uint8_t *)host, (uint32_t *)(host + align_up(rec_span))};
+        const size_t slices = std::min<size_t>((size_t)c->pack_threads * 4, c1 - c0);
+        job.per = (c1 - c0 + slices - 1) / slices;
+        splpack::parallel_for(slices, c->pack_threads, emit_slice, &job);
+        q = hipMemcpyAsync(seg.slab + r0, host, rec_span, hipMemcpyHostToDevice, c->copy);
+        if (q == hipSuccess && wide_span)
+            q = hipMemcpyAsync(seg.slab + rec_al + 4 * w0, host + align_up(rec_span), 4 * wide_span, hipMemcpyHostToDevice, c->copy);
+        if (q == hipSuccess && !big.empty()) q = hipStreamSynchronize(c->copy);
+        else if (q == hipSuccess) { q = hipEventRecord(st.done, c->copy); st.busy = true; }
+        c0 = c1;
+    }
+    if (q != hipSuccess) {
+        (void)hipStreamSynchronize(c->copy);
+        (void)hipFree(seg.slab);
+        d->segs.pop_back();
+        return spl_set_error(SPL_ERR_HIP, "read segment upload: %s", hipGetErrorString(q));
+    }
+    seg.chunks.swap(plan.chunks);
+    d->n_reads += src.n_reads;
+    d->n_cigar += src.n_ops;
+    d->n_chunks += (uint32_t)n_chunks;
+    return SPL_OK;
+}
+
+// The flat chunk list of a read set, the chunk order of the range kernel and the queues.
+static int finish_reads(spl_ctx *c, spl_dreads *d)
+{
+    if (d->finished) return SPL_OK;
+    if (d->n_cigar > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops in one read set: use more shards");
+    const size_t n = d->n_chunks;
+    std::vector<spl_chunk_meta> meta(n);
+    std::vector<uint32_t> cost(n), order(n);
+    size_t k = 0;
+    for (const spl_dreads::Segment &seg : d->segs) {
+        const uint64_t rec_al = align_up((size_t)seg.rec_bytes);
+        for (const splpack::ChunkDesc &cd : seg.chunks) {
+            spl_chunk_meta &m = meta[k];
+            m.rec = (uint64_t)(uintptr_t)seg.slab + cd.rec_off;
+            m.wide = (uint64_t)(uintptr_t)seg.slab + rec_al;
+            m.shift = seg.shift;
+            m.first_pos = cd.first_pos;
+            for (int r = 0; r < SPL_RC_RUNS; ++r) m.n[r] = cd.n[r];
+            cost[k++] = cd.cost;
+        }
+    }
+    // chunk order of the range kernel: its workgroup b works on slot (b & 7) * per + (b >> 3) (one contiguous eighth of the
+    // reads per XCD, see my_chunk); inside every eighth the chunks go longest first (stable counting sort on the cost)
+    {
+        const size_t grid = (n + 7) / 8 * 8, per = grid / 8;
+        const uint32_t max_cost = SPL_CHUNK * SPL_W_WIDE;
+        std::vector<uint32_t> bucket((size_t)max_cost + 2);
+        for (size_t x = 0; x < 8; ++x) {
+            const size_t lo = std::min(x * per, n), hi = std::min(lo + per, n);
+            if (lo >= hi) continue;
+            std::fill(bucket.begin(), bucket.end(), 0u);
+            for (size_t j = lo; j < hi; ++j) bucket[max_cost - std::min(cost[j], max_cost) + 1]++;
+            for (size_t b = 1; b < bucket.size(); ++b) bucket[b] += bucket[b - 1];
+            for (size_t j = lo; j < hi; ++j) order[lo + bucket[max_cost - std::min(cost[j], max_cost)]++] = (uint32_t)j;
+        }
+    }
+    // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks
+    const size_t shard_cap = ((n + 7) / 8) * SPL_CHUNK;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
-    const size_t o_pos = take(4 * R), o_flag = take(2 * R), o_off = take(4 * (R + 1)), o_cig = take(4 * G);
-    const size_t n_chunks = (size_t)((R + SPL_CHUNK - 1) / SPL_CHUNK);
-    const size_t Rp = n_chunks * SPL_CHUNK; // the packed arrays cover whole chunks (the pack kernel pads the last one with inert reads)
-    const size_t o_fn = take(4 * Rp), o_ops3 = take(12 * Rp), o_ppos = take(4 * Rp), o_perm = take(2 * Rp);
-    const size_t o_order = take(4 * (n_chunks ? n_chunks : 1));
-    // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks
-    const size_t shard_cap = ((n_chunks + 7) / 8) * SPL_CHUNK;
+    const size_t o_meta = take(sizeof(spl_chunk_meta) * std::max<size_t>(n, 1)), o_order = take(4 * std::max<size_t>(n, 1));
+    const size_t o_total = take(4);
     const size_t o_queue = take(4 * 8 * shard_cap), o_queue_alt = take(c->tail ? 4 * 8 * shard_cap : 0);
-    hipError_t e = hipMalloc((void **)&d->slab, std::max<size_t>(off, 256));
-    if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the read set: %s", off, hipGetErrorString(e)); }
-    d->pos = (int32_t *)(d->slab + o_pos); d->flag = (uint16_t *)(d->slab + o_flag);
-    d->cig_off = (uint32_t *)(d->slab + o_off); d->cigar = (uint32_t *)(d->slab + o_cig);
-    d->queue = (uint32_t *)(d->slab + o_queue);
-    d->queue_alt = c->tail ? (uint32_t *)(d->slab + o_queue_alt) : d->queue;
-    d->fn = (uint32_t *)(d->slab + o_fn); d->ops3 = (uint32_t *)(d->slab + o_ops3);
-    d->ppos = (int32_t *)(d->slab + o_ppos); d->perm = (uint16_t *)(d->slab + o_perm);
-    d->chunk_order = (uint32_t *)(d->slab + o_order);
+    hipError_t e = hipMalloc((void **)&d->ctl, std::max<size_t>(off, 256));
+    if (e != hipSuccess) return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the read set: %s", off, hipGetErrorString(e));
+    d->meta = (spl_chunk_meta *)(d->ctl + o_meta);
+    d->chunk_order = (uint32_t *)(d->ctl + o_order);
+    d->queue_total = (uint32_t *)(d->ctl + o_total);
+    d->queue = (uint32_t *)(d->ctl + o_queue);
+    d->queue_alt = c->tail ? (uint32_t *)(d->ctl + o_queue_alt) : d->queue;
+    d->queue_cap = (uint32_t)shard_cap;
     hipError_t q = hipSuccess;
-    const uint32_t total_ops = (uint32_t)G; // lives until the synchronize below
-    if (R) {
-        int64_t r0 = 0, g0 = 0;
-        for (int k = 0; k < n_seg && q == hipSuccess; ++k) {
-            const spl_reads *r = &segs[k];
-            const int64_t n = r->n_reads;
-            if (!n) continue;
-            const int64_t g = r->cig_off[n];
-            q = hipMemcpyAsync(d->pos + r0, r->pos, 4 * n, hipMemcpyHostToDevice, c->stream);
-            if (q == hipSuccess) q = hipMemcpyAsync(d->flag + r0, r->flag, 2 * n, hipMemcpyHostToDevice, c->stream);
-            if (q == hipSuccess) q = hipMemcpyAsync(d->cig_off + r0, r->cig_off, 4 * n, hipMemcpyHostToDevice, c->stream);
-            if (q == hipSuccess && g) q = hipMemcpyAsync(d->cigar + g0, r->cigar, 4 * g, hipMemcpyHostToDevice, c->stream);
-            if (q == hipSuccess) q = (hipError_t)spl_dev_launch_rebase(d->pos + r0, d->cig_off + r0, n, pos_shift ? pos_shift[k] : 0, (uint32_t)g0, c->stream);
-            r0 += n;
-            g0 += g;
-        }
-        if (q == hipSuccess) q = hipMemcpyAsync(d->cig_off + R, &total_ops, 4, hipMemcpyHostToDevice, c->stream);
-        // the range kernel's layout (flag + op count in one word, first ops inline) is derived on the device
-        if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack(R, d->pos, d->flag, d->cig_off, d->cigar, d->ppos, d->fn, d->ops3, d->perm, d->chunk_order, c->stream);
-        if (q == hipSuccess) q = hipStreamSynchronize(c->stream); // caller buffers are free to go after return
-        // chunk order of the range kernel: its workgroup b works on slot (b & 7) * per + (b >> 3) (one contiguous eighth of the
-        // reads per XCD, see my_chunk); inside every eighth the chunks go longest first
-        if (q == hipSuccess) {
-            std::vector<uint32_t> cost(n_chunks), order(n_chunks);
-            q = hipMemcpy(cost.data(), d->chunk_order, 4 * n_chunks, hipMemcpyDeviceToHost);
-            const size_t grid = (n_chunks + 7) / 8 * 8, per = grid / 8;
-            for (size_t x = 0; x < 8; ++x) {
-                const size_t lo = std::min(x * per, n_chunks), hi = std::min(lo + per, n_chunks);
-                for (size_t k = lo; k < hi; ++k) order[k] = (uint32_t)k;
-                std::stable_sort(order.begin() + (ptrdiff_t)lo, order.begin() + (ptrdiff_t)hi, [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-            }
-            if (q == hipSuccess) q = hipMemcpy(d->chunk_order, order.data(), 4 * n_chunks, hipMemcpyHostToDevice);
-        }
+    if (n) {
+        if (c->copy == nullptr) { int rc = ensure_stage(c); if (rc) return rc; }
+        q = hipMemcpyAsync(d->meta, meta.data(), sizeof(spl_chunk_meta) * n, hipMemcpyHostToDevice, c->copy);
+        if (q == hipSuccess) q = hipMemcpyAsync(d->chunk_order, order.data(), 4 * n, hipMemcpyHostToDevice, c->copy);
     }
-    if (q != hipSuccess) { (void)hipFree(d->slab); delete d; return spl_set_error(SPL_ERR_HIP, "read set upload: %s", hipGetErrorString(q)); }
+    // (everything the segments queued on the copy stream is over with this; the vectors above die at return)
+    if (q == hipSuccess && c->copy) q = hipStreamSynchronize(c->copy);
+    for (spl_ctx::Stage &st : c->stage) st.busy = false;
+    if (q != hipSuccess) return spl_set_error(SPL_ERR_HIP, "read set upload: %s", hipGetErrorString(q));
+    d->finished = true;
+    return SPL_OK;
+}
+
+static int source_of(const spl_reads *r, splpack::Source &src, int64_t *max_end, const char *who)
+{
+    if (r->n_reads < 0) return spl_set_error(SPL_ERR_ARG, "%s: negative n_reads", who);
+    if (r->n_reads && (!r->pos || !r->flag || !r->cig_off)) return spl_set_error(SPL_ERR_ARG, "read set has null arrays");
+    if (r->n_reads && r->cig_off[0] != 0) return spl_set_error(SPL_ERR_ARG, "cig_off[0] must be 0");
+    const int64_t g = r->n_reads ? r->cig_off[r->n_reads] : 0;
+    if (g && !r->cigar) return spl_set_error(SPL_ERR_ARG, "cigar is null");
+    if (r->n_reads) src.add(splpack::Part{r->pos, r->flag, r->cig_off, r->cigar, r->n_reads});
+    *max_end = -1; // not known: the general path of the kernels checks every read it cannot vouch for (see add_segment for shifts)
+    return SPL_OK;
+}
+
+extern "C" int spl_pack_host(const spl_reads *reads, int n_threads, int64_t *n_chunks_out, int64_t *rec_bytes_out, int64_t *n_wide_out,
+                             void *chunk_desc, void *rec, uint32_t *wide)
+{
+    if (!reads || !n_chunks_out || !rec_bytes_out || !n_wide_out) return spl_set_error(SPL_ERR_ARG, "spl_pack_host: null argument");
+    splpack::Source src;
+    int64_t max_end;
+    int rc = source_of(reads, src, &max_end, "spl_pack_host");
+    if (rc) return rc;
+    splpack::Plan plan;
+    splpack::plan(src, plan, n_threads > 0 ? n_threads : 1);
+    *n_chunks_out = (int64_t)plan.chunks.size();
+    *rec_bytes_out = (int64_t)plan.rec_bytes;
+    *n_wide_out = (int64_t)plan.n_wide;
+    static_assert(sizeof(splpack::ChunkDesc) == 32, "chunk descriptors are handed out as 32-byte records");
+    if (chunk_desc && !plan.chunks.empty()) memcpy(chunk_desc, plan.chunks.data(), sizeof(splpack::ChunkDesc) * plan.chunks.size());
+    if (rec && !plan.chunks.empty()) {
+        std::vector<uint32_t> no_wide((size_t)plan.n_wide + 1);
+        memset(rec, 0, (size_t)plan.rec_bytes); // (the padding between runs, so that two packings compare equal)
+        splpack::emit(src, plan, 0, plan.chunks.size(), (uint8_t *)rec, wide ? wide : no_wide.data());
+    }
+    return SPL_OK;
+}
+
+extern "C" int spl_reads_begin(spl_ctx *c, spl_dreads **out)
+{
+    if (!c || !out) return spl_set_error(SPL_ERR_ARG, "spl_reads_begin: null argument");
+    *out = new (std::nothrow) spl_dreads();
+    if (!*out) return spl_set_error(SPL_ERR_NOMEM, "out of host memory");
+    return SPL_OK;
+}
+
+// End (1-based, inclusive) of the last base any read of a caller's arrays covers; needed when the segment is moved.
+static int64_t max_end_of(const spl_reads *r)
+{
+    int64_t best = 0;
+    for (int64_t i = 0; i < r->n_reads; ++i) {
+        int64_t len = 0;
+        for (uint32_t k = r->cig_off[i]; k < r->cig_off[i + 1]; ++k) {
+            const uint32_t code = r->cigar[k] & 15u;
+            if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) len += r->cigar[k] >> 4;
+        }
+        const int64_t e = (int64_t)r->pos[i] + (len > 0 ? len : 1) - 1;
+        if (e > best && e <= (int64_t)SPL_COORD_MAX) best = e; // (reads out of range as they stand: the kernels report them)
+    }
+    return best;
+}
+
+extern "C" int spl_reads_add(spl_ctx *c, spl_dreads *d, const spl_reads *reads, int32_t pos_shift)
+{
+    if (!c || !d || !reads) return spl_set_error(SPL_ERR_ARG, "spl_reads_add: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    splpack::Source src;
+    int64_t max_end;
+    int rc = source_of(reads, src, &max_end, "spl_reads_add");
+    if (rc) return rc;
+    if (pos_shift != 0) max_end = max_end_of(reads);
+    return add_segment(c, d, src, pos_shift, max_end);
+}
+
+extern "C" int spl_reads_add_bam(spl_ctx *c, spl_dreads *d, spl_bam *bam, int tid, int32_t pos_shift)
+{
+    if (!c || !d || !bam) return spl_set_error(SPL_ERR_ARG, "spl_reads_add_bam: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    splpack::Source src;
+    int64_t max_end = 0;
+    int rc = spl_bam_source(bam, tid, &src, &max_end);
+    if (rc) return rc;
+    return add_segment(c, d, src, pos_shift, max_end);
+}
+
+extern "C" int spl_reads_finish(spl_ctx *c, spl_dreads *d)
+{
+    if (!c || !d) return spl_set_error(SPL_ERR_ARG, "spl_reads_finish: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return finish_reads(c, d);
+}
+
+extern "C" void spl_reads_free(spl_ctx *c, spl_dreads *d)
+{
+    if (!d) return;
+    if (c) (void)hipSetDevice(c->device);
+    if (c && c->copy) (void)hipStreamSynchronize(c->copy);
+    if (c && c->tail) (void)hipStreamSynchronize(c->tail); // (a tail may still be reading these buffers; hipFree itself waits
+    if (c && c->stream) (void)hipStreamSynchronize(c->stream); //  for the device, this makes it independent of that)
+    for (spl_dreads::Segment &seg : d->segs) if (seg.slab) (void)hipFree(seg.slab);
+    if (d->ctl) (void)hipFree(d->ctl);
+    delete d;
+}
+
+extern "C" int spl_reads_upload_segments(spl_ctx *c, int n_seg, const spl_reads *segs, const int32_t *pos_shift, spl_dreads **out)
+{
+    if (!c || !out || n_seg < 0 || (n_seg && (!segs || !pos_shift)))
+        return spl_set_error(SPL_ERR_ARG, "spl_reads_upload_segments: null argument");
+    *out = nullptr;
+    spl_dreads *d = nullptr;
+    int rc = spl_reads_begin(c, &d);
+    for (int k = 0; k < n_seg && rc == SPL_OK; ++k) rc = spl_reads_add(c, d, &segs[k], pos_shift[k]);
+    if (rc == SPL_OK) rc = spl_reads_finish(c, d);
+    if (rc != SPL_OK) { spl_reads_free(c, d); return rc; }
     *out = d;
     return SPL_OK;
 }
@@ -686,24 +943,8 @@ static int upload_segments(spl_ctx *c, int n_seg, const spl_reads *segs, const i
 extern "C" int spl_reads_upload(spl_ctx *c, const spl_reads *r, spl_dreads **out)
 {
     if (!c || !r || !out) return spl_set_error(SPL_ERR_ARG, "spl_reads_upload: null argument");
-    return upload_segments(c, 1, r, nullptr, out, "spl_reads_upload");
-}
-
-extern "C" int spl_reads_upload_segments(spl_ctx *c, int n_seg, const spl_reads *segs, const int32_t *pos_shift, spl_dreads **out)
-{
-    if (!c || !out || n_seg < 0 || (n_seg && (!segs || !pos_shift)))
-        return spl_set_error(SPL_ERR_ARG, "spl_reads_upload_segments: null argument");
-    return upload_segments(c, n_seg, segs, pos_shift, out, "spl_reads_upload_segments");
-}
-
-extern "C" void spl_reads_free(spl_ctx *c, spl_dreads *d)
-{
-    if (!d) return;
-    if (c) (void)hipSetDevice(c->device);
-    if (c && c->tail) (void)hipStreamSynchronize(c->tail); // (a tail may still be reading these buffers; hipFree itself waits
-    if (c && c->stream) (void)hipStreamSynchronize(c->stream); //  for the device, this makes it independent of that)
-    if (d->slab) (void)hipFree(d->slab);
-    delete d;
+    const int32_t zero = 0;
+    return spl_reads_upload_segments(c, 1, r, &zero, out);
 }
 
 // ---- launches -------------------------------------------------------------------------------------------
@@ -737,15 +978,16 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
         ds->region_clean[next] = false;
     } else if (int rc0 = spl_dev_launch_clear(ds->beta1, ds->counter_bytes, c->stream)) // (in place: the copy in use)
         return spl_set_error(SPL_ERR_HIP, "clear kernel launch: %s", hipGetErrorString((hipError_t)rc0));
+    if (!dr->finished) return spl_set_error(SPL_ERR_ARG, "spl_count_launch: the read set is not finished (spl_reads_finish)");
     uint32_t *const queue = dr->queue_turn ? dr->queue_alt : dr->queue;
     dr->queue_turn ^= 1;
-    dr->last_queue_n = ds->queue_n;
+    dr->queued_pass = false;
     ds->sse_fused = false;
     spl_count_params p;
     memset(&p, 0, sizeof(p));
     p.n_reads = dr->n_reads;
-    p.n_chunks = (uint32_t)((dr->n_reads + SPL_CHUNK - 1) / SPL_CHUNK);
-    p.r_pos = dr->pos; p.r_flag = dr->flag; p.cig_off = dr->cig_off; p.cigar = dr->cigar;
+    p.n_chunks = dr->n_chunks;
+    p.chunk_meta = dr->meta;
     p.n_sites = (int32_t)ds->n_sites;
     p.site_pos = ds->pos; p.site_strand = ds->strand; p.site_flags = ds->flags; p.site_meta = ds->meta;
     p.part_pos = ds->part_pos; p.part_site = ds->part_site; p.comp_pos = ds->comp_pos;
@@ -755,11 +997,11 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.jhash = ds->jhash; p.jhash_mask = ds->jhash_mask; p.jrivals = ds->jrivals;
     spl_hot_params h;
     memset(&h, 0, sizeof(h));
-    h.n_reads = p.n_reads; h.n_chunks = p.n_chunks; h.r_pos_orig = p.r_pos; h.r_pos = dr->ppos; h.perm = dr->perm; h.chunk_order = dr->chunk_order; h.part_pos = ds->part_pos; h.r_fn = dr->fn; h.r_ops3 = dr->ops3; h.cig_off = p.cig_off; h.cigar = p.cigar;
-    h.dbucket = p.dbucket; h.drival = p.drival; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos; h.n_cigar = (uint32_t)dr->n_cigar;
+    h.n_chunks = p.n_chunks; h.chunk_meta = dr->meta; h.chunk_order = dr->chunk_order; h.part_pos = ds->part_pos;
+    h.dbucket = p.dbucket; h.drival = p.drival; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = queue; h.queue_n = ds->queue_n; h.err = ds->err;
-    h.queue_cap = (uint32_t)(((p.n_chunks + 7u) / 8u) * SPL_CHUNK);
+    h.queue_cap = dr->queue_cap;
     h.jhash = ds->jhash; h.jhash_mask = ds->jhash_mask; h.jrivals = ds->jrivals; h.dbl = ds->dbl; h.combine_mode = o->combine_mode ? 1 : 0;
 
     p.bucket = ds->bucket; p.n_buckets = ds->n_buckets; p.bucket_base = ds->bucket_base; p.bucket_shift = ds->bucket_shift;
@@ -786,14 +1028,14 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
         // otherwise the next one
         const int to_clear = piped ? (ds->cur + 2) % 3 : (ds->cur + 1) % 3;
         spl_queue_params lq;
-        lq.queue = queue; lq.queue_n = ds->queue_n; lq.queue_cap = h.queue_cap;
+        lq.queue = queue; lq.queue_n = ds->queue_n; lq.queue_cap = h.queue_cap; lq.queue_total = dr->queue_total;
         lq.clear_region = (uint4 *)ds->region[to_clear]; lq.clear_n16 = ds->counter_bytes / 16;
-        lq.r_pos = dr->ppos; lq.r_fn = dr->fn; lq.r_ops3 = dr->ops3; lq.perm = dr->perm;
         lq.diff = ds->diff; lq.block_sums = ds->block_sums; lq.diff_stride = ds->diff_stride; lq.n_dpos = ds->n_dpos;
         lq.scan_blocks = ds->scan_blocks; lq.scan_arrays = o->stranded ? 4 : 2;
         rc = spl_dev_launch_literal(&p, &lq, ts);
         if (rc != 0) return spl_set_error(SPL_ERR_HIP, "literal kernel launch: %s", hipGetErrorString((hipError_t)rc));
         ds->region_clean[to_clear] = true;
+        dr->queued_pass = true;
         spl_scan_params q;
         memset(&q, 0, sizeof(q));
         q.n_dpos = ds->n_dpos; q.dpos_first_row = ds->dpos_first_row;
@@ -909,7 +1151,8 @@ extern "C" int spl_junctions(spl_ctx *c, const spl_dreads *dr, int stranded, int
     if (e != hipSuccess) return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the junction table: %s", bytes, hipGetErrorString(e));
     unsigned long long *keys = (unsigned long long *)buf, *out_keys = keys + slots;
     uint32_t *vals = (uint32_t *)(out_keys + slots), *out_vals = vals + 3 * slots, *n_dev = out_vals + 3 * slots;
-    int rc = spl_dev_launch_junctions(dr->n_reads, dr->pos, dr->flag, dr->cig_off, dr->cigar, stranded, (uint32_t)min_anchor, (uint32_t)min_intron,
+    if (!dr->finished) { (void)hipFree(buf); return spl_set_error(SPL_ERR_ARG, "spl_junctions: the read set is not finished (spl_reads_finish)"); }
+    int rc = spl_dev_launch_junctions(dr->meta, dr->n_chunks, stranded, (uint32_t)min_anchor, (uint32_t)min_intron,
                                       (uint32_t)max_intron, keys, vals, (uint32_t)slots, out_keys,
                                       out_vals, n_dev, c->d_err, c->stream);
     uint32_t n = 0;
@@ -967,13 +1210,12 @@ extern "C" int spl_literal_queue_size(spl_ctx *c, const spl_dreads *dr, int64_t 
 {
     if (!c || !dr || !n_out) return spl_set_error(SPL_ERR_ARG, "spl_literal_queue_size: null argument");
     HIP_TRY(hipSetDevice(c->device));
-    std::vector<uint32_t> counts(8 * SPL_COUNTER_STRIDE);
-    if (!dr->last_queue_n) { *n_out = 0; return SPL_OK; }
+    *n_out = 0;
+    if (!dr->queued_pass || !dr->queue_total) return SPL_OK;
+    uint32_t total = 0; // (a word of the read set's own, written by the literal kernel of its last pass)
     HIP_TRY(join_tail(c));
-    HIP_TRY(hipMemcpyAsync(counts.data(), dr->last_queue_n, 4 * counts.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&total, dr->queue_total, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    int64_t total = 0;
-    for (int k = 0; k < 8; ++k) total += counts[(size_t)k * SPL_COUNTER_STRIDE];
     *n_out = total;
     return SPL_OK;
 }

@@ -5,35 +5,21 @@
 #include <stdint.h>
 #include <hip/hip_vector_types.h>
 
+#include "spl_pack.h"
+
 // Launch geometry of the classification kernels (see DESIGN.md "Kernels").
 #ifndef SPL_BLOCK
 #define SPL_BLOCK 256                    // threads per workgroup = 4 waves
 #endif
 #define SPL_COUNTER_STRIDE 64            // words between the 8 queue counters: a 256-byte line each (counters sharing a
                                          // line serialise the atomics of all XCDs: measured 11 ns per atomic, chip-wide)
-// Packed read word r_fn: flag (16 bits) | op count saturating at SPL_NOPS_SAT (13 bits) | class (3 bits), the class being
-// what the pack kernel partitions a chunk by: the range kernel branches on it wave-uniformly.
-#define SPL_PACK_SCAN_OPS 8              // CIGARs up to this many ops are packed without their non-consuming ops
-#define SPL_NOPS_SAT 0x1fffu
-#define SPL_RC_SHIFT 29
-#define SPL_RC_SIMPLE 0u                 // one aligned op, mapped, in range: every unspliced short read
-#define SPL_RC_MNM 1u                    // aligned, N, aligned; mapped, in range: every once-spliced short read
-#define SPL_RC_M2 2u                     // aligned, N, aligned, N, aligned (aligned lengths < 4096, introns < 2^28): the packed words
-                                         // hold the five LENGTHS: w0 = a | b << 12 | (c & 255) << 24, w1 = c >> 8 | d1 << 4, w2 = d2
-#define SPL_RC_NARROW 3u                 // anything else of at most SPL_INLINE_OPS ops
-#define SPL_RC_WIDE 4u                   // more ops than that
-#define SPL_RC_COUNT 5
-#ifndef SPL_W_SIMPLE                     // what a read of each class costs the range kernel, roughly (chunk order: longest first)
-#define SPL_W_SIMPLE 2u
-#define SPL_W_MNM 5u
-#define SPL_W_M2 9u
-#endif
-#ifndef SPL_RPT
-#define SPL_RPT 8                        // reads per thread
-#endif
-#define SPL_CHUNK (SPL_BLOCK * SPL_RPT)  // consecutive reads per workgroup (chunk-relative slots travel as 16-bit numbers)
-#define SPL_WIN 1020                     // distinct site positions a workgroup privatises in LDS (4 arrays + queue: 8 workgroups in 160 KB)
-#define SPL_INLINE_OPS 3                 // CIGAR ops per read resolved in the straight-line part (M N M = 3)
+#define SPL_WAVES (SPL_BLOCK / 64)
+// The range kernel deals the wave-iterations of a chunk (64 reads of ONE run each; at most 32 + 3 of them: a run's last one may
+// be partial) round-robin to its waves: at most SPL_WAVE_ITERS per wave, and as many list entries (s_q) per wave.
+#define SPL_WAVE_ITERS 9
+#define SPL_WAVE_READS (64 * SPL_WAVE_ITERS)
+#define SPL_WIN 1020                     // distinct site positions a workgroup privatises in LDS (pair kernel; range kernel unstranded)
+#define SPL_WIN_STRANDED 988             // ... range kernel, stranded: 4 windows + the lists, 8 workgroups in 160 KB
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
 #ifndef SPL_AGG_ROUNDS
 #define SPL_AGG_ROUNDS 2                 // distinct addresses agg_add merges across the wave before it falls back to plain atomics
@@ -43,10 +29,6 @@
 #define SPL_SCAN_BLOCK 256               // distinct positions per workgroup of the scan kernels (a multiple of 256; 1024 left the chip half empty)
 #endif
 
-// Coordinates (read end, site position) must stay <= SPL_COORD_MAX so that t+1, cur and x - dbase never wrap int32.
-#define SPL_COORD_MAX 2147483581
-// op code -> 2-bit kind (see spl_count_ranges_kernel): M(0)=1 D(2)=3 N(3)=2 =(7)=1 X(8)=1, others 0
-#define SPL_KIND_TABLE ((1u << 0) | (3u << 4) | (2u << 6) | (1u << 14) | (1u << 16))
 
 #define SPL_DEV_ERR_RANGE 1
 #define SPL_DEV_ERR_TABLE 2
@@ -61,13 +43,10 @@
 #define SPL_SF_RIVALS 4u  // some partner of this row has competitors: a junction ending here may have rival sites
 
 struct spl_count_params {
-    // reads
+    // reads: the packed layout of spl_pack.h, one descriptor per chunk
     int64_t n_reads;
     uint32_t n_chunks;
-    const int32_t *r_pos;
-    const uint16_t *r_flag;
-    const uint32_t *cig_off;
-    const uint32_t *cigar;
+    const spl_chunk_meta *chunk_meta;
     // sites
     int32_t n_sites;
     const int32_t *site_pos;
@@ -109,19 +88,10 @@ struct spl_count_params {
 
 // Argument block of the range kernel: only what the straight-line path touches (keeps it out of SGPR spills).
 struct spl_hot_params {
-    int64_t n_reads;
     uint32_t n_chunks;
-    uint32_t n_cigar;
-    const int32_t *r_pos_orig;   // BAM-native order (window base of a chunk)
-    const int32_t *r_pos;        // the arrays below are packed at upload, chunk-locally reordered (simple reads first)
-    const uint16_t *perm;        // packed slot -> place of the read in its chunk
+    const spl_chunk_meta *chunk_meta; // [n_chunks] (spl_pack.h)
     const uint32_t *chunk_order; // [n_chunks] slot of an XCD slice -> chunk, longest chunk first within every slice
     const int32_t *part_pos;     // partner positions (CSR values): the twice-spliced junction-table pass scans a rival's list
-    const uint32_t *r_fn;        // flag | min(n_ops, 65535) << 16
-    const uint32_t *r_ops3;      // packed at upload, 3 words per read: the ops of a read with <= 3 ops (absent = 0xf);
-                                 // for longer reads {op0, op1, index of op2 in cigar[]}
-    const uint32_t *cig_off;     // only for reads with >= 65535 ops
-    const uint32_t *cigar;
     const uint2 *dbucket;      // 32 bp buckets: {first dpos at or after the bucket start, occupancy mask}
     const uint32_t *drival;    // per bucket: which of its positions are sites with rivals
     uint32_t n_dbuckets;
@@ -142,15 +112,12 @@ struct spl_hot_params {
     int32_t *err;
 };
 
-// the literal kernel's view of the queue and of the packed read arrays it indexes
+// the literal kernel's view of the queue (entries: chunk << SPL_CHUNK_SHIFT | slot of the read in its chunk, run order)
 struct spl_queue_params {
     const uint32_t *queue;       // 8 regions of queue_cap entries
     const uint32_t *queue_n;     // counter k at word k * SPL_COUNTER_STRIDE
     uint32_t queue_cap;
-    const int32_t *r_pos;        // packed (see spl_hot_params)
-    const uint32_t *r_fn;
-    const uint32_t *r_ops3;
-    const uint16_t *perm;
+    uint32_t *queue_total;       // the number of entries, for the host (diagnostic), written by this launch
     // the block sums of the difference arrays are taken by this launch too (see spl_count_literal_kernel)
     const int32_t *diff;
     int32_t *block_sums;         // [scan_arrays][scan_blocks]
@@ -201,17 +168,14 @@ extern "C" {
 // variant: 0 = range kernel (needs mutual partner links), 1 = pair kernel (any table), 2 = range kernel without
 // wave-level aggregation of LDS atomics (experiment)
 int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out, void *ev_start, void *ev_stop);
-int spl_dev_launch_junctions(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar,
+int spl_dev_launch_junctions(const spl_chunk_meta *chunk_meta, uint32_t n_chunks,
                              int stranded, uint32_t min_anchor, uint32_t min_intron, uint32_t max_intron, unsigned long long *keys,
                              uint32_t *vals, uint32_t n_slots, unsigned long long *out_keys,
                              uint32_t *out_vals, uint32_t *n_out, int32_t *err, void *stream);
 int spl_dev_launch_build_dbuckets(const int32_t *site_pos, const int32_t *dpos_first_row, int32_t n_dpos, const uint32_t *rival_bits,
                                   int32_t dbase, uint32_t n_dbuckets, uint2 *out, uint32_t *out_rival, void *stream);
-int spl_dev_launch_rebase(int32_t *pos, uint32_t *cig_off, int64_t n, int32_t shift, uint32_t cig_base, void *stream);
 int spl_dev_launch_clear(void *region, size_t bytes, void *stream);
 int spl_dev_launch_literal(const spl_count_params *p, const spl_queue_params *q, void *stream);
-int spl_dev_launch_pack(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar,
-                        int32_t *p_pos, uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm, uint32_t *chunk_cost, void *stream);
 int spl_dev_launch_scan(const spl_scan_params *p, void *stream);
 int spl_dev_launch_sse(const spl_sse_params *p, void *stream);
 #ifdef __cplusplus

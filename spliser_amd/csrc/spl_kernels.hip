@@ -56,6 +56,75 @@ __device__ __forceinline__ uint32_t my_chunk()
     return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
 }
 
+// ---- the packed read layout (spl_pack.h), device side ---------------------------------------------------
+
+// A chunk's descriptor as wave-uniform values (the index is uniform: scalar loads).
+struct ChunkView {
+    const char *rec;
+    const uint32_t *wide;
+    int32_t shift, first_pos;
+    uint32_t start[SPL_RC_RUNS + 1]; // slot (run order) of the first read of each run; start[4] = reads in the chunk
+    uint32_t off[SPL_RC_RUNS];       // byte offset of each run in the record area
+};
+
+__device__ __forceinline__ ChunkView chunk_view(const spl_chunk_meta *meta)
+{
+    const uint4 a = *(const uint4 *)meta, b = *((const uint4 *)meta + 1);
+    ChunkView v;
+    v.rec = (const char *)(((uint64_t)a.y << 32) | a.x);
+    v.wide = (const uint32_t *)(((uint64_t)a.w << 32) | a.z);
+    v.shift = (int32_t)b.x;
+    v.first_pos = (int32_t)b.y;
+    const uint32_t n0 = b.z & 0xffffu, n1 = b.z >> 16, n2 = b.w & 0xffffu, n3 = b.w >> 16;
+    v.start[0] = 0; v.start[1] = n0; v.start[2] = n0 + n1; v.start[3] = n0 + n1 + n2; v.start[4] = n0 + n1 + n2 + n3;
+    v.off[0] = 0;
+    v.off[1] = (n0 * SPL_REC_SIMPLE + 15u) & ~15u;
+    v.off[2] = v.off[1] + n1 * SPL_REC_MNM;
+    v.off[3] = v.off[2] + n2 * SPL_REC_M2;
+    return v;
+}
+
+// The read at `slot` (run order) of a chunk with its CIGAR in BAM form again -- for the literal formulations, which walk ops
+// (spl_classify.h).  Short CIGARs come back without their non-consuming ops (they change nothing for checkBam, :457-464), into
+// `row` (5 words the caller owns: LDS or private); a wide read's ops are where the packer put them, all of them.
+struct ReadView { int32_t pos; uint32_t flag, n_ops; const uint32_t *ops; bool neg; };
+
+__device__ __forceinline__ ReadView read_at(const ChunkView &cv, uint32_t slot, uint32_t *row)
+{
+    ReadView v;
+    v.ops = row;
+    int32_t pos0;
+    if (slot < cv.start[1]) {
+        const uint2 r = *(const uint2 *)(cv.rec + (size_t)(cv.off[0] + SPL_REC_SIMPLE * slot));
+        pos0 = (int32_t)r.x; v.flag = r.y & 0xffffu;
+        row[0] = (r.y >> 16) << 4;
+        v.n_ops = 1u;
+    } else if (slot < cv.start[2]) {
+        const uint4 r = *(const uint4 *)(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot - cv.start[1])));
+        pos0 = (int32_t)r.x; v.flag = r.y & 0xffffu;
+        row[0] = (r.y >> 16) << 4; row[1] = (r.z << 4) | (uint32_t)SPL_OP_N; row[2] = r.w << 4;
+        v.n_ops = 3u;
+    } else {
+        const bool m2 = slot < cv.start[3];
+        const uint2 *q = (const uint2 *)(cv.rec + (size_t)(m2 ? cv.off[2] + SPL_REC_M2 * (slot - cv.start[2])
+                                                                : cv.off[3] + SPL_REC_OTHER * (slot - cv.start[3])));
+        const uint2 r0 = q[0], r1 = q[1], r2 = q[2];
+        pos0 = (int32_t)r0.x; v.flag = r0.y & 0xffffu;
+        if (m2) {
+            row[0] = (r0.y >> 16) << 4; row[1] = (r1.x << 4) | (uint32_t)SPL_OP_N; row[2] = (r1.y & 0xffffu) << 4;
+            row[3] = (r2.x << 4) | (uint32_t)SPL_OP_N; row[4] = (r1.y >> 16) << 4;
+            v.n_ops = 5u;
+        } else {
+            v.n_ops = r2.y;
+            if ((r0.y >> SPL_RC_SHIFT) == SPL_RC_WIDE) v.ops = cv.wide + r2.x;
+            else { row[0] = r1.x; row[1] = r1.y; row[2] = r2.x; }
+        }
+    }
+    v.neg = pos0 < 0;
+    v.pos = pos0 + cv.shift;
+    return v;
+}
+
 // ---- literal (read, site) pair: shared by the pair kernel and by the slow paths of the range kernel ------
 
 // Counter updates of one classified pair, straight to HBM (SpliSER_v0_1_8.py:519-559).
@@ -120,75 +189,77 @@ template <bool STRANDED>
 __global__ __launch_bounds__(SPL_BLOCK) void spl_count_pairs_kernel(const spl_count_params p)
 {
     __shared__ uint32_t lds[2 * SPL_WIN]; // [0,WIN): beta1   [WIN,2WIN): beta2Simple (read-derived)
+    __shared__ uint32_t s_ops[SPL_BLOCK][5]; // a lane's short CIGAR, rebuilt from its packed record
     __shared__ int32_t s_wbase;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t chunk = my_chunk();
     const bool live = chunk < p.n_chunks;
-    const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
+    const ChunkView cv = chunk_view(p.chunk_meta + (live ? chunk : 0u));
+    const uint32_t n_here = live ? cv.start[SPL_RC_RUNS] : 0u;
 
     for (int j = tid; j < 2 * SPL_WIN; j += SPL_BLOCK) lds[j] = 0u;
-    if (tid == 0) s_wbase = live ? first_site_at_or_after(p, p.r_pos[chunk_base]) : 0;
+    if (tid == 0) s_wbase = live ? first_site_at_or_after(p, cv.first_pos + cv.shift) : 0;
     __syncthreads();
     const int32_t wbase = s_wbase;
     const int32_t n_sites = p.n_sites;
 
-    if (live) {
-        for (int it = 0; it < SPL_RPT; ++it) {
-            const int64_t i = chunk_base + (int64_t)it * SPL_BLOCK + tid;
-            bool valid = i < p.n_reads;
-            int32_t pos = 0, end = -1, s = n_sites;
-            uint32_t flag = 0, o0 = 0, n_ops = 0;
-            bool has_n = false;
-            uint8_t rstrand = 0;
-            if (valid) {
-                pos = p.r_pos[i];
-                flag = p.r_flag[i];
-                o0 = p.cig_off[i];
-                n_ops = p.cig_off[i + 1] - o0;
-                int64_t ref_len;
-                spl_read_extent(p.cigar + o0, n_ops, &ref_len, &has_n);
-                const int64_t end64 = (int64_t)pos + spl_fetch_len(flag, ref_len) - 1;
-                // the CIGAR walk runs in int32: the whole read must fit, not only its fetch window
-                if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX || pos < 0) {
-                    atomicOr(p.err, SPL_DEV_ERR_RANGE);
-                    valid = false;
-                } else {
-                    end = (int32_t)end64;
-                    s = first_site_at_or_after(p, pos);
-                    if (STRANDED) rstrand = spl_read_strand(flag, p.stranded);
-                }
+    for (uint32_t base = 0; base < n_here; base += SPL_BLOCK) {
+        const uint32_t slot = base + (uint32_t)tid;
+        bool valid = slot < n_here;
+        int32_t pos = 0, end = -1, s = n_sites;
+        uint32_t flag = 0, n_ops = 0;
+        const uint32_t *ops = s_ops[tid];
+        bool has_n = false;
+        uint8_t rstrand = 0;
+        if (valid) {
+            const ReadView rv = read_at(cv, slot, s_ops[tid]);
+            pos = rv.pos; flag = rv.flag; n_ops = rv.n_ops; ops = rv.ops;
+            int64_t ref_len;
+            spl_read_extent(ops, n_ops, &ref_len, &has_n);
+            const int64_t end64 = (int64_t)pos + spl_fetch_len(flag, ref_len) - 1;
+            // the CIGAR walk runs in int32: the whole read must fit, not only its fetch window
+            if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX || rv.neg) {
+                atomicOr(p.err, SPL_DEV_ERR_RANGE);
+                valid = false;
+            } else {
+                end = (int32_t)end64;
+                s = first_site_at_or_after(p, pos);
+                if (STRANDED) rstrand = spl_read_strand(flag, p.stranded);
             }
-            // lane-serial part: the first few sites of this lane's read
-            int served = 0;
-            while (valid && s < n_sites && served < SPL_SERIAL_MAX) {
-                const int32_t t = p.site_pos[s];
-                if (t > end) break;
-                do_pair<STRANDED>(p, lds, wbase, s, t, pos, p.cigar + o0, n_ops, has_n, rstrand);
-                ++s;
-                ++served;
-            }
-            // reads that span many sites (long introns) are finished by the whole wave, one site per lane
-            const bool heavy = valid && s < n_sites && p.site_pos[s] <= end;
-            unsigned long long todo = __ballot(heavy);
-            while (todo) {
-                const int src = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                const int32_t b_pos = __shfl(pos, src);
-                const int32_t b_end = __shfl(end, src);
-                const int32_t b_s = __shfl(s, src);
-                const uint32_t b_o0 = __shfl(o0, src);
-                const uint32_t b_nops = __shfl(n_ops, src);
-                const bool b_has_n = __shfl((int)has_n, src) != 0;
-                const uint8_t b_rs = (uint8_t)__shfl((int)rstrand, src);
-                for (int32_t s0 = b_s;; s0 += 64) {
-                    const int32_t my = s0 + lane;
-                    int32_t t = 0;
-                    const bool in = my < n_sites && (t = p.site_pos[my]) <= b_end;
-                    if (in) do_pair<STRANDED>(p, lds, wbase, my, t, b_pos, p.cigar + b_o0, b_nops, b_has_n, b_rs);
-                    if (__ballot(in) != ~0ull) break; // rows are sorted: a lane out of range ends the read
-                }
+        }
+        // lane-serial part: the first few sites of this lane's read
+        int served = 0;
+        while (valid && s < n_sites && served < SPL_SERIAL_MAX) {
+            const int32_t t = p.site_pos[s];
+            if (t > end) break;
+            do_pair<STRANDED>(p, lds, wbase, s, t, pos, ops, n_ops, has_n, rstrand);
+            ++s;
+            ++served;
+        }
+        // reads that span many sites (long introns) are finished by the whole wave, one site per lane
+        const bool heavy = valid && s < n_sites && p.site_pos[s] <= end;
+        unsigned long long todo = __ballot(heavy);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const int32_t b_pos = __shfl(pos, src);
+            const int32_t b_end = __shfl(end, src);
+            const int32_t b_s = __shfl(s, src);
+            const uint32_t b_nops = __shfl(n_ops, src);
+            const bool b_has_n = __shfl((int)has_n, src) != 0;
+            const uint8_t b_rs = (uint8_t)__shfl((int)rstrand, src);
+            // (a generic pointer: the source lane's row in LDS or its stretch of the wide-op array)
+            const uintptr_t op_addr = (uintptr_t)ops;
+            const uint32_t *b_ops = (const uint32_t *)(((uintptr_t)(uint32_t)__shfl((int)(uint32_t)(op_addr >> 32), src) << 32) |
+                                                       (uintptr_t)(uint32_t)__shfl((int)(uint32_t)op_addr, src));
+            for (int32_t s0 = b_s;; s0 += 64) {
+                const int32_t my = s0 + lane;
+                int32_t t = 0;
+                const bool in = my < n_sites && (t = p.site_pos[my]) <= b_end;
+                if (in) do_pair<STRANDED>(p, lds, wbase, my, t, b_pos, b_ops, b_nops, b_has_n, b_rs);
+                if (__ballot(in) != ~0ull) break; // rows are sorted: a lane out of range ends the read
             }
         }
     }
@@ -375,11 +446,12 @@ __device__ __forceinline__ void commit_key(const spl_hot_params &p, spl_lds_i32 
         go = head;
     }
     if (go) {
+        constexpr int WIN = NARR == 4 ? SPL_WIN_STRANDED : SPL_WIN;
         const int arr = (int)(key & 3u);
         const int32_t d = (int32_t)(key >> 2);
         const uint32_t loc = (uint32_t)(d - wbase);
         // (an LDS-typed pointer: ds_add on one side, a global atomic on the other, never a flat atomic on a selected address)
-        if (loc <= (uint32_t)SPL_WIN) __hip_atomic_fetch_add(lds + (arr * (SPL_WIN + 1) + (int)loc), amount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (loc <= (uint32_t)WIN) __hip_atomic_fetch_add(lds + (arr * (WIN + 1) + (int)loc), amount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + d], amount);
     }
 }
@@ -555,16 +627,16 @@ __device__ __forceinline__ bool rivals_inline2(const spl_hot_params &p, spl_lds_
 
 } // namespace
 
-// The range kernel proper: one read per lane, straight-line, three batched memory trips per read --
-//   trip 1  pos, flag, cig_off[i], cig_off[i+1]                       (coalesced)
-//   trip 2  the read's first SPL_INLINE_OPS CIGAR ops                   (neighbouring lanes, neighbouring words)
-//   trip 3  one bucket entry per boundary (read start + end of every reference-consuming op), all independent
-// then popcounts turn boundaries into dpos ranges and adjacent lanes that start or end a range on the same dpos
-// share one LDS atomic.  No LDS staging, no barriers inside the loop, few registers and a small argument block
-// (everything the literal paths need lives in spl_count_literal_kernel): reads that need a literal decision --
-// unmapped-but-placed records and reads with a junction end that has rival sites -- are appended to a queue.
-// Reads with more than SPL_INLINE_OPS ops continue one op at a time (long-read CIGARs work, they just are not
-// the tuned case).
+// The range kernel proper: one workgroup per chunk, one read per lane per wave-iteration, straight-line, two batched memory
+// trips per read --
+//   trip 1  the read's record (8, 16 or 24 bytes by run; asked for one iteration ahead)
+//   trip 2  one bucket entry per boundary (read start + end of every reference-consuming op), all independent
+// then popcounts turn boundaries into dpos ranges.  A chunk's reads come as four runs (spl_pack.h): a wave-iteration takes 64
+// reads of ONE run, so every wave runs one code path at a time on a branch that is decided by scalar arithmetic on the
+// chunk's descriptor, not by loaded data; the wave-iterations of a chunk (32 + at most 3 partial ones) are dealt round-robin
+// to the four waves.  No LDS staging, no barriers inside the loop, few registers and a small argument block (everything the
+// literal paths need lives in spl_count_literal_kernel): reads that need a literal decision -- unmapped-but-placed records and
+// reads with a junction end that has rival sites the junction table cannot settle -- are appended to a queue.
 // Development aid, compiled out of the product (make EXTRA=-DSPL_PHASE_TIMING): wave 0 of every workgroup stamps the
 // 100 MHz wall clock at the phase borders of the range kernel; tools/phase_report.py turns the dump into a timeline.
 #if defined(SPL_PHASE_TIMING) || defined(SPL_PHASE_LITERAL)
@@ -591,21 +663,23 @@ template <bool STRANDED, bool AGG>
 __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ? 4 : 8, 8))) void spl_count_ranges_kernel(const spl_hot_params p)
 {
     constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
-    __shared__ int32_t lds_words[NARR * (SPL_WIN + 1)];
+    constexpr int WIN = STRANDED ? SPL_WIN_STRANDED : SPL_WIN;
+    __shared__ int32_t lds_words[NARR * (WIN + 1)];
     spl_lds_i32 *const lds = (spl_lds_i32 *)lds_words;
-    // Each wave owns one segment of s_q (as many entries as it has reads) with two lists of chunk-relative packed slots:
-    // from the front the reads for the literal kernel, from the back the once-spliced reads whose junction has rivals
+    // Each wave owns one segment of s_q (as many entries as it can have reads) with two lists of chunk-relative slots:
+    // from the front the reads for the literal kernel, from the back the once- and twice-spliced reads whose junction has rivals
     // (finished from the junction table by the wave itself right after its loop, see below).  Only the owning wave touches a
     // segment, so the fill counts are wave-uniform registers and slots are handed out by ballot, not by atomics.
-    constexpr int NWAVE = SPL_BLOCK / 64;
-    constexpr uint32_t SEG = 64u * SPL_RPT;
-    __shared__ uint16_t s_q[SPL_CHUNK];
+    constexpr int NWAVE = SPL_WAVES;
+    constexpr uint32_t SEG = SPL_WAVE_READS;
+    __shared__ uint16_t s_q[NWAVE * SEG];
     __shared__ uint32_t s_qcnt[NWAVE], s_qbase;
 #ifdef SPL_PHASE_WAVES
     __shared__ uint64_t s_wave_t[2 * NWAVE];
     __shared__ uint32_t s_wave_n[NWAVE];
 #endif
-    const uint32_t seg0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * SEG; // wave-uniform, in an SGPR
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, in an SGPR
+    const uint32_t seg0 = wave * SEG;
     uint32_t n_front = 0, n_back = 0;
     auto rank_in = [](unsigned long long m) { // how many lanes below mine are in m (mbcnt: no per-lane mask to keep around)
         return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -622,64 +696,77 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     };
 
     const int tid = threadIdx.x;
+    const uint32_t lane = (uint32_t)tid & 63u;
     // workgroup -> slot of its XCD slice (my_chunk) -> chunk: every slice is walked longest chunk first (chunk_order, built
-    // at upload from the pack kernel's cost estimate), so the workgroups that finish a launch are short ones
+    // at upload from the packer's cost estimate), so the workgroups that finish a launch are short ones
     const uint32_t chunk_slot = my_chunk();
     const bool live = chunk_slot < p.n_chunks;
     const uint32_t chunk = live ? p.chunk_order[chunk_slot] : 0u;
-    const int64_t chunk_base = (int64_t)chunk * SPL_CHUNK;
+    const ChunkView cv = chunk_view(p.chunk_meta + chunk);
     SPL_PHASE_DECL;
     SPL_PHASE(0);
-
-    // Pipeline over the chunk's reads: while read `it` is worked on the packed words of the next read are in flight
-    // (its bucket entries too was tried: 25 more registers, occupancy 4, slower).
-    auto fetch_read = [&](int it, int32_t &f_pos, uint32_t &f_fn, uint32_t (&f_op)[SPL_INLINE_OPS]) {
-        const int64_t ii = live ? chunk_base + (int64_t)it * SPL_BLOCK + tid : 0; // (the packed arrays are padded to whole chunks)
-        // (plain loads: marking the stream non-temporal looked 3...11 % faster in a benchmark that runs pass after pass
-        //  over one 400 MB sample -- position and flag words then survive in the 256 MB last-level cache from one pass to
-        //  the next -- and is 2...5 % SLOWER when every pass reads a different copy of the sample: DESIGN.md section 6)
-        f_pos = p.r_pos[ii];                                                     // ---- trip 1: 20 bytes per read
-        f_fn = p.r_fn[ii];
+    // wave-iterations of the chunk: run r has iters[r] of them, the first being number g_start[r] of the chunk
+    uint32_t g_start[SPL_RC_RUNS + 1];
+    g_start[0] = 0;
 #pragma unroll
-        for (int k = 0; k < SPL_INLINE_OPS; ++k) f_op[k] = p.r_ops3[3 * ii + k];
+    for (int r = 0; r < SPL_RC_RUNS; ++r) g_start[r + 1] = g_start[r] + ((cv.start[r + 1] - cv.start[r] + 63u) >> 6);
+    const uint32_t g_total = live ? g_start[SPL_RC_RUNS] : 0u;
+    // where wave-iteration g is: its run, the slot of this lane's read in the chunk (clamped into the run: lanes past the end
+    // of a partial iteration re-read the run's last record and are masked), the byte offset of that record
+    // (select chains, no indexing by `run`: the descriptor stays in scalar registers)
+    auto locate = [&](uint32_t g, uint32_t &run, uint32_t &slot, bool &valid, uint32_t &byte_off) {
+        run = (g >= g_start[1] ? 1u : 0u) + (g >= g_start[2] ? 1u : 0u) + (g >= g_start[3] ? 1u : 0u);
+        uint32_t gs = 0, s0 = 0, n_run = cv.start[1], off = 0, size = SPL_REC_SIMPLE;
+        if (run == 1u) { gs = g_start[1]; s0 = cv.start[1]; n_run = cv.start[2] - cv.start[1]; off = cv.off[1]; size = SPL_REC_MNM; }
+        if (run == 2u) { gs = g_start[2]; s0 = cv.start[2]; n_run = cv.start[3] - cv.start[2]; off = cv.off[2]; size = SPL_REC_M2; }
+        if (run == 3u) { gs = g_start[3]; s0 = cv.start[3]; n_run = cv.start[4] - cv.start[3]; off = cv.off[3]; size = SPL_REC_OTHER; }
+        const uint32_t i = ((g - gs) << 6) + lane;
+        valid = i < n_run;
+        const uint32_t idx = valid ? i : n_run - 1u;
+        slot = s0 + idx;
+        byte_off = off + idx * size;
     };
-    int32_t cu_pos;
-    uint32_t cu_fn, cu_op[SPL_INLINE_OPS];
-    fetch_read(0, cu_pos, cu_fn, cu_op);
-    const int32_t first_pos = p.r_pos_orig[live ? chunk_base : 0]; // wave-uniform: the window base of the chunk
+    // Pipeline over the wave's iterations: while one is worked on the records of the next are in flight
+    // (its bucket entries too was tried: 25 more registers, occupancy 4, slower).
+    // (plain loads: marking the stream non-temporal looked 3...11 % faster in a benchmark that runs pass after pass
+    //  over one 400 MB sample -- the words then survive in the 256 MB last-level cache from one pass to
+    //  the next -- and is 2...5 % SLOWER when every pass reads a different copy of the sample: DESIGN.md section 6)
+    uint2 cu_a = make_uint2(0, 0), cu_b = make_uint2(0, 0), cu_c = make_uint2(0, 0); // ---- trip 1: 8, 16 or 24 bytes per read
+    uint32_t cu_run = 0, cu_slot = 0;
+    bool cu_valid = false;
+    auto fetch = [&](uint32_t g) {
+        uint32_t off;
+        locate(g, cu_run, cu_slot, cu_valid, off);
+        const char *r = cv.rec + (size_t)off;
+        if (cu_run == 0u) cu_a = *(const uint2 *)r;
+        else if (cu_run == 1u) { const uint4 q = *(const uint4 *)r; cu_a = make_uint2(q.x, q.y); cu_b = make_uint2(q.z, q.w); }
+        else { cu_a = *(const uint2 *)r; const uint4 q = *(const uint4 *)(r + 8); cu_b = make_uint2(q.x, q.y); cu_c = make_uint2(q.z, q.w); }
+    };
+    if (wave < g_total) fetch(wave);
     int32_t wbase = 0;
-    { uint32_t nv; dbk_resolve(p, first_pos - 1, p.dbucket[dbk_slot(p, first_pos - 1)], wbase, nv); }
-    for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) lds[j] = 0;
+    { const int32_t fp = cv.first_pos + cv.shift; uint32_t nv; dbk_resolve(p, fp - 1, p.dbucket[dbk_slot(p, fp - 1)], wbase, nv); }
+    for (int j = tid; j < NARR * (WIN + 1); j += SPL_BLOCK) lds[j] = 0;
     __syncthreads();
     SPL_PHASE(1);
 
-    if (live) {
-        for (int it = 0; it < SPL_RPT; ++it) {
-#ifndef SPL_PHASE_TAIL
-            if (it == 1) SPL_PHASE(3); // reads 1..3 of the chunk get a stamp each (read 0 starts at stamp 1)
-            if (it == 2) SPL_PHASE(4);
-            if (it == 3) SPL_PHASE(5);
-#endif
-            // Straight-line and branch-free up to the commits: out-of-range lanes re-read the last read and are masked
-            // at the end, so all loads of a trip issue back to back.  Control flow is wave-uniform around every
-            // commit_key (all 64 lanes reach it).
-            const int64_t ii = chunk_base + (int64_t)it * SPL_BLOCK + tid;
-            bool alive = true; // every slot of a chunk holds a read (the pack kernel pads the last chunk with inert ones)
-            const int32_t pos = cu_pos;
-            const uint32_t fn = cu_fn;
-            uint32_t op[SPL_INLINE_OPS];
-#pragma unroll
-            for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = cu_op[k];
-            // (the next read's words are asked for right AFTER this read's bucket entries, in each path: memory operations
-            //  retire in order, and the entries must not wait for the stream; no branch around it -- the last read asks for
-            //  itself again -- so that the wait counts are the same on every way here)
-            auto fetch_next = [&]() { fetch_read(it + 1 < SPL_RPT ? it + 1 : it, cu_pos, cu_fn, cu_op); };
-            const uint32_t flag = fn & 0xffffu;
-            const uint32_t cls = fn >> SPL_RC_SHIFT;
-            // ---- a wave of simple reads (one aligned op, mapped, in range: the pack kernel checked all that and put them
-            //      first in the chunk) takes the short road: two boundaries, one range, nothing else can happen
-            if (__all(cls == SPL_RC_SIMPLE)) {
-                const int32_t c1 = pos + (int32_t)(op[0] >> 4);
+    {
+        for (uint32_t g = wave; g < g_total; g += NWAVE) {
+            // Straight-line up to the commits: lanes past the end of a run re-read its last read and are masked, so all
+            // loads of a trip issue back to back.  Control flow is wave-uniform around every commit_key (all 64 lanes
+            // reach it).
+            const uint32_t run = cu_run;
+            const uint32_t slot = cu_slot;                  // of the read in its chunk, run order
+            bool alive = cu_valid;
+            const uint2 ra = cu_a, rb = cu_b, rc = cu_c;
+            const int32_t pos = (int32_t)ra.x + cv.shift;
+            const uint32_t flag = ra.y & 0xffffu;
+            // (the next iteration's records are asked for right AFTER this read's bucket entries, in each path: memory
+            //  operations retire in order, and the entries must not wait for the stream)
+            auto fetch_next = [&]() { if (g + NWAVE < g_total) fetch(g + NWAVE); };
+            // ---- simple reads (one aligned op, mapped, in range: the packer checked all that): two boundaries, one range,
+            //      nothing else can happen
+            if (run == SPL_RC_SIMPLE) {
+                const int32_t c1 = pos + (int32_t)(ra.y >> 16);
                 const uint2 e0 = p.dbucket[dbk_slot(p, pos - 1)], e1 = p.dbucket[dbk_slot(p, c1 - 1)]; // ---- trip 2
                 fetch_next();
                 int32_t ua, ub; uint32_t nva, nvb;
@@ -695,10 +782,10 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 }
                 continue;
             }
-            // ---- a wave of once-spliced reads (aligned, N, aligned): the kinds are known, so are the arrays; three ranges
+            // ---- once-spliced reads (aligned, N, aligned): the kinds are known, so are the arrays; three ranges
             //      and the junction-table look-up when an end of the junction has rivals
-            if (__all(cls == SPL_RC_MNM)) {
-                const int32_t c0 = pos + (int32_t)(op[0] >> 4), c1 = c0 + (int32_t)(op[1] >> 4), c2 = c1 + (int32_t)(op[2] >> 4);
+            if (run == SPL_RC_MNM) {
+                const int32_t c0 = pos + (int32_t)(ra.y >> 16), c1 = c0 + (int32_t)rb.x, c2 = c1 + (int32_t)rb.y;
                 const uint32_t s1 = dbk_slot(p, c0 - 1), s2 = dbk_slot(p, c1 - 1);
                 const uint2 e0 = p.dbucket[dbk_slot(p, pos - 1)], e1 = p.dbucket[s1], e2 = p.dbucket[s2], e3 = p.dbucket[dbk_slot(p, c2 - 1)];
                 const uint32_t rm1 = p.drival[s1], rm2 = p.drival[s2]; // (the junction ends: which sites there have rivals)
@@ -742,21 +829,17 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 }
                 const bool flagged = alive && (((nv1 & rv1) | (nv2 & rv2)) != 0u); // an end of the junction (c0 - 1, c1 - 1) has rivals
                 if (__any(flagged)) {
-                    push_front(flagged && p.combine_mode, (uint32_t)(it * SPL_BLOCK + tid));
-                    push_back(flagged && !p.combine_mode, (uint32_t)(it * SPL_BLOCK + tid));
+                    push_front(flagged && p.combine_mode, slot);
+                    push_back(flagged && !p.combine_mode, slot);
                 }
                 continue;
             }
-            // ---- twice-spliced reads (aligned, N, aligned, N, aligned; the packed words hold the five lengths): six boundaries
-            //      in two trips, five ranges.  Unlike the two classes above this path takes the lanes of its class out of a
-            //      mixed wave too (the others idle through it): the general path below could not rebuild their ops.
-            const bool m2 = cls == SPL_RC_M2;
-            if (__any(m2)) {
-                const uint32_t la = op[0] & 0xfffu, lb = (op[0] >> 12) & 0xfffu, lc = (op[0] >> 24) | ((op[1] & 0xfu) << 8);
-                const uint32_t d1 = op[1] >> 4, d2 = op[2] & 0xfffffffu;
-                // (unsigned sums: for the lanes of other classes these are numbers without meaning; slots are clamped)
-                const int32_t c0 = (int32_t)((uint32_t)pos + la), c1 = (int32_t)((uint32_t)c0 + d1), c2 = (int32_t)((uint32_t)c1 + lb);
-                const int32_t c3 = (int32_t)((uint32_t)c2 + d2), c4 = (int32_t)((uint32_t)c3 + lc);
+            // ---- twice-spliced reads (aligned, N, aligned, N, aligned; the record holds the five lengths): six boundaries
+            //      in two trips, five ranges
+            if (run == SPL_RC_M2) {
+                const uint32_t la = ra.y >> 16, d1 = rb.x, lb = rb.y & 0xffffu, lc = rb.y >> 16, d2 = rc.x;
+                const int32_t c0 = pos + (int32_t)la, c1 = c0 + (int32_t)d1, c2 = c1 + (int32_t)lb;
+                const int32_t c3 = c2 + (int32_t)d2, c4 = c3 + (int32_t)lc;
                 uint32_t sidx2 = 0;
                 if (STRANDED) sidx2 = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
                 const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx2;
@@ -764,12 +847,12 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 uint2 f0 = p.dbucket[dbk_slot(p, pos - 1)], f1 = p.dbucket[s1];
                 const uint2 f2 = p.dbucket[s2], f3 = p.dbucket[s3];
                 const uint32_t rm1 = p.drival[s1], rm2 = p.drival[s2], rm3 = p.drival[s3]; // (the junction ends)
-                if (__all(m2)) fetch_next();
+                fetch_next();
                 int32_t ua, ub; uint32_t nva, nvb, rvb;
                 uint32_t fl1 = 0, fl2 = 0; // junction 1 / 2 has an end with rivals
                 auto range = [&](uint32_t arr) {
                     const int32_t lo = ua + (int32_t)nva;
-                    const bool em = m2 && ub > lo;
+                    const bool em = alive && ub > lo;
                     if (__any(em)) {
                         commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | arr, 1);
                         commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | arr, -1);
@@ -794,38 +877,37 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 fl2 |= nvb & rvb;
                 dbk_resolve(p, c4 - 1, f1, ub, nvb);
                 range(sidx2);                       // block 3
-                const bool flagged = m2 && ((fl1 | fl2) != 0u);
+                const bool flagged = alive && ((fl1 | fl2) != 0u);
                 if (__any(flagged)) {
-                    const uint32_t slot = (uint32_t)(it * SPL_BLOCK + tid);
                     push_front(flagged && p.combine_mode, slot);
                     push_back(flagged && !p.combine_mode, slot | (fl1 << 14) | (fl2 << 15)); // which junction must be in the table
                 }
-                if (__all(m2)) continue;
-                alive = alive && !m2;
+                continue;
             }
-            uint32_t n_ops = (fn >> 16) & SPL_NOPS_SAT;
-            uint32_t o0 = 0; // index of op 0 in cigar[]: known (and needed) only for reads with more than 3 ops
-            if (n_ops > (uint32_t)SPL_INLINE_OPS) {
-                o0 = op[2] - 2u;
-                op[2] = 0xfu; // the third word was the pointer: ops 2.. are walked one at a time below
+            // ---- everything else: {pos, fn, op0, op1, op2 | index of op 0 among the segment's wide ops, number of ops}
+            const uint32_t fn = ra.y;
+            uint32_t op[SPL_INLINE_OPS] = {rb.x, rb.y, rc.x};
+            uint32_t n_ops = rc.y;
+            const bool wide = (fn >> SPL_RC_SHIFT) == SPL_RC_WIDE;
+            uint32_t o0 = 0; // index of op 0 in the wide ops: known (and needed) only for wide reads
+            if (wide) {
+                o0 = op[2];
+                op[2] = 0xfu; // the third word was the index: ops 2.. are walked in batches below
             }
-            const uint32_t n_inline = n_ops > (uint32_t)SPL_INLINE_OPS ? 2u : n_ops;
-            bool bad = alive && pos < 0;
+            const uint32_t n_inline = wide ? 2u : n_ops;
+            bool bad = alive && (int32_t)ra.x < 0;
             const bool literal = alive && !bad && (flag & 4u); // fetched as a 1-base record: literal kernel
             alive = alive && !bad && !literal;
             uint32_t sidx = 0;
             if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
-            const bool wide = n_ops > (uint32_t)SPL_INLINE_OPS;
-            if (n_ops == SPL_NOPS_SAT) // the packed word saturates: the true count is with the read's own place in the input
-                n_ops = p.cig_off[chunk_base + p.perm[ii] + 1] - o0;
             const uint32_t room = (uint32_t)(SPL_COORD_MAX - (pos < 0 ? 0 : pos));
             uint32_t len = 0;
             int32_t cend[SPL_INLINE_OPS];
             uint32_t kind[SPL_INLINE_OPS]; // 0 none, 1 aligned, 2 N, 3 D
             int32_t pu = 0; uint32_t pnv = 0, prv = 0; // the dpos AT the previous boundary's last base (if pnv) and its rival bit
             bool rival = false;
-            // The ops go through in batches of SPL_INLINE_OPS: the first batch is the packed words (every read of a typical
-            // short-read library ends there), further batches of a wide read cost two memory trips each (ops, then buckets).
+            // The ops go through in batches of SPL_INLINE_OPS: the first batch is the record's words (every narrow read
+            // ends there), further batches of a wide read cost two memory trips each (ops, then buckets).
             uint32_t k_next = n_inline;
             bool mine = true; // this lane has ops in the batch (a narrow read in a wave of wide ones sits the later batches out)
             for (bool first = true;; first = false) {
@@ -835,7 +917,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                     const uint32_t kd = alive ? ((SPL_KIND_TABLE >> (2u * (op[k] & 15u))) & 3u) : 0u;
                     len += kd ? (op[k] >> 4) : 0u;                 // len <= 2^31 before, three lengths < 2^28: no wrap
                     if (kd && len > room) { bad = true; alive = false; }
-                    if (first || mine) { // keeps the first batch's summary intact for the junction-table path below
+                    if (first || mine) {
                         cend[k] = pos + (int32_t)len;
                         kind[k] = alive ? kd : 0u;
                     }
@@ -867,18 +949,14 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 if (!__any(more)) break;
                 mine = more;
 #pragma unroll
-                for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = (more && k_next + (uint32_t)k < n_ops) ? p.cigar[o0 + k_next + (uint32_t)k] : 0xfu;
+                for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = (more && k_next + (uint32_t)k < n_ops) ? cv.wide[o0 + k_next + (uint32_t)k] : 0xfu;
                 k_next += (uint32_t)SPL_INLINE_OPS;
             }
             if (bad) atomicOr(p.err, SPL_DEV_ERR_RANGE);
-            // (a junction with rivals outside the once-spliced class -- soft clips, indels next to it, several junctions --
-            //  is the literal kernel's business)
+            // (a junction with rivals outside the spliced classes -- indels next to it, three and more junctions -- is the
+            //  literal kernel's business)
             const bool flagged = !literal && alive && rival;
-            const bool later = flagged && cls == SPL_RC_MNM && !p.combine_mode; // a once-spliced read in a wave of mixed classes
-            if (__any(literal || flagged)) {
-                push_front(literal || (flagged && !later), (uint32_t)(it * SPL_BLOCK + tid));
-                push_back(later, (uint32_t)(it * SPL_BLOCK + tid));
-            }
+            if (__any(literal || flagged)) push_front(literal || flagged, slot);
         }
 #ifdef SPL_PHASE_WAVES
         if ((tid & 63) == 0) { // (development aid: when did each wave leave its loop, how long is its list)
@@ -890,28 +968,30 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         // window are affected and how (rivals_inline); what it cannot decide joins the literal list.  The list is read
         // from its growing end, so the front list can only ever grow into entries that are done with.
         for (uint32_t r0 = 0; r0 < n_back; r0 += 64u) {
-            const uint32_t j = r0 + (uint32_t)(tid & 63);
+            const uint32_t j = r0 + lane;
             bool undecided = false;
             uint32_t slot = 0;
             if (j < n_back) {
                 const uint32_t entry = s_q[seg0 + SEG - n_back + j];
                 slot = entry & 0x3fffu;
-                const int64_t idx = chunk_base + slot;
-                const int32_t pos = p.r_pos[idx];
-                const uint32_t fn = p.r_fn[idx];
-                const uint32_t w0 = p.r_ops3[3 * idx], w1 = p.r_ops3[3 * idx + 1], w2 = p.r_ops3[3 * idx + 2];
-                uint32_t sidx = 0;
-                if (STRANDED) sidx = (spl_read_strand(fn & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
-                if ((fn >> SPL_RC_SHIFT) == SPL_RC_M2) {
-                    const uint32_t la = w0 & 0xfffu, lb = (w0 >> 12) & 0xfffu, lc = (w0 >> 24) | ((w1 & 0xfu) << 8);
-                    const int32_t c0 = pos + (int32_t)la, c1 = c0 + (int32_t)(w1 >> 4), c2 = c1 + (int32_t)lb;
-                    const int32_t c3 = c2 + (int32_t)(w2 & 0xfffffffu), c4 = c3 + (int32_t)lc;
+                if (slot >= cv.start[SPL_RC_M2]) {
+                    const uint2 *q = (const uint2 *)(cv.rec + (size_t)(cv.off[2] + SPL_REC_M2 * (slot - cv.start[2])));
+                    const uint2 ra = q[0], rb = q[1], rc = q[2];
+                    const int32_t pos = (int32_t)ra.x + cv.shift;
+                    uint32_t sidx = 0;
+                    if (STRANDED) sidx = (spl_read_strand(ra.y & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
+                    const int32_t c0 = pos + (int32_t)(ra.y >> 16), c1 = c0 + (int32_t)rb.x, c2 = c1 + (int32_t)(rb.y & 0xffffu);
+                    const int32_t c3 = c2 + (int32_t)rc.x, c4 = c3 + (int32_t)(rb.y >> 16);
                     const int32_t jl[2] = {c0 - 1, c2 - 1}, jr[2] = {c1 - 1, c3 - 1};
                     const bool jf[2] = {((entry >> 14) & 1u) != 0u, (entry >> 15) != 0u};
                     const int32_t blk_a[3] = {pos, c1, c3}, blk_b[3] = {c0 - 1, c2 - 1, c4 - 1};
                     undecided = !rivals_inline2<STRANDED, NARR>(p, lds, wbase, jl, jr, jf, blk_a, blk_b, sidx);
                 } else {
-                    const int32_t c0 = pos + (int32_t)(w0 >> 4), c1 = c0 + (int32_t)(w1 >> 4), c2 = c1 + (int32_t)(w2 >> 4);
+                    const uint4 r = *(const uint4 *)(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot - cv.start[1])));
+                    const int32_t pos = (int32_t)r.x + cv.shift;
+                    uint32_t sidx = 0;
+                    if (STRANDED) sidx = (spl_read_strand(r.y & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
+                    const int32_t c0 = pos + (int32_t)(r.y >> 16), c1 = c0 + (int32_t)r.z, c2 = c1 + (int32_t)r.w;
                     const int32_t blk_a[2] = {pos, c1}, blk_b[2] = {c0 - 1, c2 - 1};
                     undecided = !rivals_inline<STRANDED, NARR>(p, lds, wbase, c0 - 1, c1 - 1, blk_a, blk_b, sidx);
                 }
@@ -942,7 +1022,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         if (tid == 0) s_qbase = atomicAdd(&p.queue_n[shard * SPL_COUNTER_STRIDE], qn); // a cache line per counter
         __syncthreads();
         uint32_t *dst = p.queue + (size_t)shard * p.queue_cap + s_qbase;
-        const uint32_t first = (uint32_t)chunk_base;
+        const uint32_t first = chunk << SPL_CHUNK_SHIFT;
         for (uint32_t j = tid; j < qn; j += SPL_BLOCK) {
             uint32_t w = 0;
 #pragma unroll
@@ -950,16 +1030,16 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             uint32_t base = 0;
 #pragma unroll
             for (int k = 0; k < NWAVE; ++k) base = (w == (uint32_t)k) ? q_start[k] : base;
-            dst[j] = first + (uint32_t)s_q[w * SEG + (j - base)];
+            dst[j] = first | (uint32_t)s_q[w * SEG + (j - base)];
         }
     }
 #ifdef SPL_PHASE_TAIL
     SPL_PHASE(4);
 #endif
-    for (int j = tid; j < NARR * (SPL_WIN + 1); j += SPL_BLOCK) {
+    for (int j = tid; j < NARR * (WIN + 1); j += SPL_BLOCK) {
         const int32_t v = lds[j];
         if (v) {
-            const int arr = j / (SPL_WIN + 1), loc = j - arr * (SPL_WIN + 1);
+            const int arr = j / (WIN + 1), loc = j - arr * (WIN + 1);
             atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + wbase + loc], v);
         }
     }
@@ -1260,7 +1340,7 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
 template <bool STRANDED>
 __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_params p, const spl_queue_params q)
 {
-    __shared__ uint32_t s_ops[64][SPL_PACK_SCAN_OPS + 1]; // the lane's CIGAR: rebuilt (twice-spliced class) or fetched in one trip (+1: banks)
+    __shared__ uint32_t s_ops[64][SPL_PACK_SCAN_OPS + 1]; // the lane's CIGAR: rebuilt from its record or fetched in one trip (+1: banks)
     // The other copy of the counter region, for the next counting pass (one 16-byte store per lane or so).
     for (size_t j = (size_t)blockIdx.x * 64 + threadIdx.x; j < q.clear_n16; j += (size_t)gridDim.x * 64) q.clear_region[j] = make_uint4(0, 0, 0, 0);
     // Then the block sums of the difference arrays for the scan that follows: the arrays are final once the range kernel
@@ -1288,6 +1368,7 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
 #pragma unroll
     for (int sh = 0; sh < 8; ++sh) start[sh + 1] = start[sh] + q.queue_n[sh * SPL_COUNTER_STRIDE];
     const uint32_t total = start[8];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *q.queue_total = total;
     {
         // A short queue is spread thin, 16 entries per wave: a wave is as slow as its slowest lane (trips differ with the
         // number of junctions and rivals), and there are far more waves than work (26 -> 22 us for 9 k reads).  A long one
@@ -1300,41 +1381,25 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
             uint32_t base = 0;
 #pragma unroll
             for (int sh = 0; sh < 8; ++sh) base = (shard == (uint32_t)sh) ? start[sh] : base;
-            const int64_t idx = q.queue[(size_t)shard * q.queue_cap + (g - base)];
-            const int32_t pos = q.r_pos[idx];
-            const uint32_t fn = q.r_fn[idx];
-            const uint32_t flag = fn & 0xffffu;
-            uint32_t n_ops = (fn >> 16) & SPL_NOPS_SAT;
-            const uint32_t *ops = q.r_ops3 + 3 * idx;
-            if ((fn >> SPL_RC_SHIFT) == SPL_RC_M2) { // the packed words hold five lengths: the ops are rebuilt in the lane's row of LDS
-                const uint32_t w0 = ops[0], w1 = ops[1], w2 = ops[2];
-                uint32_t *row = s_ops[threadIdx.x];
-                row[0] = ((w0 & 0xfffu) << 4) | 0u;
-                row[1] = ((w1 >> 4) << 4) | (uint32_t)SPL_OP_N;
-                row[2] = (((w0 >> 12) & 0xfffu) << 4) | 0u;
-                row[3] = ((w2 & 0xfffffffu) << 4) | (uint32_t)SPL_OP_N;
-                row[4] = (((w0 >> 24) | ((w1 & 0xfu) << 8)) << 4) | 0u;
+            const uint32_t entry = q.queue[(size_t)shard * q.queue_cap + (g - base)]; // chunk << SPL_CHUNK_SHIFT | slot
+            const ChunkView cv = chunk_view(p.chunk_meta + (entry >> SPL_CHUNK_SHIFT));
+            uint32_t *row = s_ops[threadIdx.x];
+            const ReadView rv = read_at(cv, entry & (SPL_CHUNK - 1u), row);
+            const int32_t pos = rv.pos;
+            const uint32_t flag = rv.flag;
+            uint32_t n_ops = rv.n_ops;
+            const uint32_t *ops = rv.ops;
+            if (ops != row && n_ops <= (uint32_t)SPL_PACK_SCAN_OPS) { // a wide read's ops are walked several times below: all of them in one trip, then LDS
+                uint32_t w[SPL_PACK_SCAN_OPS];
+#pragma unroll
+                for (int k = 0; k < SPL_PACK_SCAN_OPS; ++k) w[k] = ((uint32_t)k < n_ops) ? ops[k] : 0xfu;
+#pragma unroll
+                for (int k = 0; k < SPL_PACK_SCAN_OPS; ++k) row[k] = w[k];
                 ops = row;
-                n_ops = 5u;
-            } else if (n_ops > (uint32_t)SPL_INLINE_OPS) {
-                const uint32_t o0 = ops[2] - 2u;
-                ops = p.cigar + o0;
-                if (n_ops == SPL_NOPS_SAT) { // the packed count saturates: the true one from the BAM-native offsets
-                    const int64_t i = (idx / SPL_CHUNK) * SPL_CHUNK + q.perm[idx];
-                    n_ops = p.cig_off[i + 1] - o0;
-                }
-                if (n_ops <= (uint32_t)SPL_PACK_SCAN_OPS) { // the ops are walked several times below: all of them in one trip, then LDS
-                    uint32_t w[SPL_PACK_SCAN_OPS];
-#pragma unroll
-                    for (int k = 0; k < SPL_PACK_SCAN_OPS; ++k) w[k] = ((uint32_t)k < n_ops) ? ops[k] : 0xfu;
-                    uint32_t *row = s_ops[threadIdx.x];
-#pragma unroll
-                    for (int k = 0; k < SPL_PACK_SCAN_OPS; ++k) row[k] = w[k];
-                    ops = row;
-                }
             }
+            if (rv.neg) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
 #ifdef SPL_PHASE_LITERAL
-            asm volatile("s_nop 0" ::"v"(pos), "v"(fn));
+            asm volatile("s_nop 0" ::"v"(pos), "v"(flag));
             lt_[1] = wall_clock64(); // after the read's words arrived
 #endif
             int64_t ref_len; bool hn;
@@ -1365,114 +1430,6 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
     if (threadIdx.x == 0) for (int k_ = 0; k_ < 4; ++k_) g_phase[(size_t)blockIdx.x * 8 + k_] = lt_[k_];
     if (threadIdx.x == 0) g_phase[(size_t)blockIdx.x * 8 + 7] = (uint64_t)__popcll(__ballot(1)) + 1; // marks the row as written
 #endif
-}
-
-// The range kernel's read layout, derived once per upload from the BAM-native arrays (one workgroup per chunk):
-//   * one word with flag and op count, three words with the first ops (or two ops and where the rest start), so that
-//     everything a typical read needs arrives in ONE memory trip without going through cig_off first;
-//   * inside each chunk the reads are stably partitioned into four runs (SPL_RC_*): simple reads (one aligned op,
-//     mapped, in range -- every unspliced short read), once-spliced reads (aligned, N, aligned), other reads of at most
-//     SPL_INLINE_OPS ops, wide reads; the class also rides in the top bits of the packed word.  Each run keeps
-//     coordinate order.  A wave of the range kernel then sees (almost always) one kind of read: the first two classes
-//     take paths of their own on wave-uniform branches, and only waves of wide reads walk further batches of ops.
-//   perm[] maps a packed slot back to the read's place in the chunk.
-__global__ __launch_bounds__(SPL_BLOCK) void spl_pack_reads_kernel(int64_t n_reads, const int32_t *pos, const uint16_t *flag,
-                                                                   const uint32_t *cig_off, const uint32_t *cigar, int32_t *p_pos,
-                                                                   uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm, uint32_t *chunk_cost)
-{
-    constexpr int NW = SPL_BLOCK / 64;
-    constexpr int NC = SPL_RC_COUNT;
-    __shared__ uint32_t cnt[NC][SPL_RPT][NW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t cb = (int64_t)blockIdx.x * SPL_CHUNK;
-    int32_t r_pos[SPL_RPT];
-    uint32_t r_fn[SPL_RPT], w[SPL_RPT][3], rank[SPL_RPT];
-    int cls[SPL_RPT]; // SPL_RC_*, NC = past the end
-#pragma unroll
-    for (int it = 0; it < SPL_RPT; ++it) {
-        const int64_t i = cb + (int64_t)it * SPL_BLOCK + tid;
-        // a slot past the end of the read set becomes an inert read of the first class (one aligned op of length 0: an empty
-        // range, never queued), so that the range kernel needs no notion of "past the end" at all
-        cls[it] = (int)SPL_RC_SIMPLE;
-        r_pos[it] = 1; r_fn[it] = (1u << 16) | (SPL_RC_SIMPLE << SPL_RC_SHIFT); w[it][0] = 0u; w[it][1] = w[it][2] = 0xfu;
-        if (i < n_reads) {
-            const uint32_t o0 = cig_off[i], n_all = cig_off[i + 1] - o0;
-            r_pos[it] = pos[i];
-            auto kind = [](uint32_t op) { return (SPL_KIND_TABLE >> (2u * (op & 15u))) & 3u; };
-            // Ops that do not consume the reference (S, H, I, P and undefined codes) change nothing for any path of checkBam
-            // (SpliSER_v0_1_8.py:457-464: no progress, no test): a short CIGAR is packed without them, so that a soft-clipped
-            // read is classified by what it aligns ("5S95M100N50M" is a once-spliced read).  Longer CIGARs stay as they are.
-            uint32_t n = n_all;
-            uint32_t c5[5] = {0xfu, 0xfu, 0xfu, 0xfu, 0xfu}; // the first five consuming ops
-            uint32_t m = 0xffffffffu;                          // their number, if the CIGAR was short enough to look
-            if (n_all <= (uint32_t)SPL_PACK_SCAN_OPS) {
-                m = 0;
-                for (uint32_t k = 0; k < n_all; ++k) {
-                    const uint32_t op = cigar[o0 + k];
-                    if (kind(op) == 0u) continue;
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) if (m == (uint32_t)q) c5[q] = op;
-                    ++m;
-                }
-                if (m <= 3u) { n = m; w[it][0] = c5[0]; w[it][1] = c5[1]; w[it][2] = c5[2]; }
-            }
-            if (n > 3u) { w[it][0] = cigar[o0]; w[it][1] = cigar[o0 + 1]; w[it][2] = o0 + 2u; n = n_all; }
-            const bool placed = !(flag[i] & 4u) && r_pos[it] >= 0;
-            const int64_t room = (int64_t)SPL_COORD_MAX - (int64_t)r_pos[it];
-            const bool simple = placed && n == 1u && kind(w[it][0]) == 1u && (int64_t)(w[it][0] >> 4) <= room;
-            const bool mnm = placed && n == 3u && kind(w[it][0]) == 1u && kind(w[it][1]) == 2u && kind(w[it][2]) == 1u &&
-                             (int64_t)(w[it][0] >> 4) + (int64_t)(w[it][1] >> 4) + (int64_t)(w[it][2] >> 4) <= room;
-            // twice-spliced: the five lengths fit the three words (the literal paths rebuild the ops from them)
-            const uint32_t la = c5[0] >> 4, d1 = c5[1] >> 4, lb = c5[2] >> 4, d2 = c5[3] >> 4, lc = c5[4] >> 4;
-            const bool m2 = placed && m == 5u && kind(c5[0]) == 1u && kind(c5[1]) == 2u && kind(c5[2]) == 1u && kind(c5[3]) == 2u &&
-                            kind(c5[4]) == 1u && la < 4096u && lb < 4096u && lc < 4096u && d1 < (1u << 28) && d2 < (1u << 28) &&
-                            (int64_t)la + d1 + lb + d2 + lc <= room;
-            if (m2) {
-                w[it][0] = la | (lb << 12) | ((lc & 255u) << 24);
-                w[it][1] = (lc >> 8) | (d1 << 4);
-                w[it][2] = d2;
-                n = 5u;
-            }
-            cls[it] = simple ? (int)SPL_RC_SIMPLE : mnm ? (int)SPL_RC_MNM : m2 ? (int)SPL_RC_M2
-                                                  : (n <= 3u ? (int)SPL_RC_NARROW : (int)SPL_RC_WIDE);
-            r_fn[it] = (uint32_t)flag[i] | ((n < SPL_NOPS_SAT ? n : SPL_NOPS_SAT) << 16) | ((uint32_t)cls[it] << SPL_RC_SHIFT);
-        }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        rank[it] = 0;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const unsigned long long m = __ballot(cls[it] == c);
-            if (cls[it] == c) rank[it] = (uint32_t)__popcll(m & below);
-            if (lane == 0) cnt[c][it][wave] = (uint32_t)__popcll(m);
-        }
-    }
-    __syncthreads();
-    uint32_t total[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        total[c] = 0;
-        for (int it = 0; it < SPL_RPT; ++it)
-            for (int wv = 0; wv < NW; ++wv) total[c] += cnt[c][it][wv];
-    }
-    // what the chunk will cost the range kernel, roughly (instructions per read of each class): the host orders the chunks of
-    // every XCD slice longest first, so that the last workgroups of a launch are the short ones
-    if (tid == 0)
-        chunk_cost[blockIdx.x] = SPL_W_SIMPLE * total[SPL_RC_SIMPLE] + SPL_W_MNM * total[SPL_RC_MNM] + SPL_W_M2 * total[SPL_RC_M2] +
-                                 6u * total[SPL_RC_NARROW] + 14u * total[SPL_RC_WIDE];
-#pragma unroll
-    for (int it = 0; it < SPL_RPT; ++it) {
-        const int c = cls[it];
-        uint32_t before = 0; // the runs of the classes before mine, then reads of my class in earlier (it, wave) groups
-        for (int c2 = 0; c2 < NC; ++c2) before += (c2 < c) ? total[c2] : 0u;
-        for (int it2 = 0; it2 <= it; ++it2)
-            for (int wv = 0; wv < NW; ++wv)
-                if (it2 < it || wv < wave) before += cnt[c][it2][wv]; // chunk order is it-major, then wave, then lane
-        const int64_t dst = cb + before + rank[it];
-        p_pos[dst] = r_pos[it];
-        p_fn[dst] = r_fn[it];
-        p_ops3[3 * dst] = w[it][0]; p_ops3[3 * dst + 1] = w[it][1]; p_ops3[3 * dst + 2] = w[it][2];
-        perm[dst] = (uint16_t)(it * SPL_BLOCK + tid);
-    }
 }
 
 // =========================================================================================================
@@ -1633,17 +1590,21 @@ __global__ __launch_bounds__(256) void spl_scan_apply_kernel(const spl_scan_para
 // of reads carrying it and the longest anchors seen on either side (reference bases of the read between the junction and
 // the previous / next N op or read end -- the block sizes of a BED12 junction line).  Open addressing on a 64-bit key,
 // one insert per N op; lanes of a wave that insert the same key (neighbours in a sorted file) merge first.
-__global__ __launch_bounds__(256) void spl_junction_kernel(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off,
-                                                           const uint32_t *cigar, int stranded, uint32_t min_anchor, uint32_t min_intron,
+__global__ __launch_bounds__(256) void spl_junction_kernel(const spl_chunk_meta *chunk_meta, int stranded, uint32_t min_anchor, uint32_t min_intron,
                                                            uint32_t max_intron, unsigned long long *keys, uint32_t *vals, uint32_t mask,
                                                            int32_t *err)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = i < n_reads;
-    uint32_t o = 0, n_ops = 0, fl = 0;
+    __shared__ uint32_t s_ops[256][5]; // a lane's short CIGAR, rebuilt from its packed record
+    const ChunkView cv = chunk_view(chunk_meta + blockIdx.x); // one workgroup per chunk
+  for (uint32_t base = 0; base < cv.start[SPL_RC_RUNS]; base += 256u) {
+    const uint32_t slot = base + threadIdx.x;
+    const bool valid = slot < cv.start[SPL_RC_RUNS];
+    uint32_t n_ops = 0, fl = 0;
     int32_t cur = 0;
-    if (valid) { o = cig_off[i]; n_ops = cig_off[i + 1] - o; cur = pos[i]; fl = flag[i]; }
-    const bool skip = !valid || (fl & 4u) || cur < 0; // unmapped records carry no junctions
+    const uint32_t *ops = s_ops[threadIdx.x];
+    bool neg = false;
+    if (valid) { const ReadView rv = read_at(cv, slot, s_ops[threadIdx.x]); n_ops = rv.n_ops; cur = rv.pos; fl = rv.flag; ops = rv.ops; neg = rv.neg; }
+    const bool skip = !valid || (fl & 4u) || neg; // unmapped records carry no junctions
     const unsigned long long sbit = (stranded && spl_read_strand(fl, stranded) == (uint8_t)'-') ? 1ull : 0ull;
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     uint32_t k = 0;
@@ -1654,7 +1615,7 @@ __global__ __launch_bounds__(256) void spl_junction_kernel(int64_t n_reads, cons
         unsigned long long key = ~0ull;
         uint32_t a_left = 0, a_right = 0;
         while (!skip && k < n_ops && !have) {
-            const uint32_t op = cigar[o + k];
+            const uint32_t op = ops[k];
             const uint32_t code = op & 15u, d = op >> 4;
             ++k;
             if (!((SPL_PROG_MASK >> code) & 1u)) continue;
@@ -1664,7 +1625,7 @@ __global__ __launch_bounds__(256) void spl_junction_kernel(int64_t n_reads, cons
             // anchor on the right: reference bases up to the next N op or the end of the read
             uint32_t after = 0;
             for (uint32_t k2 = k; k2 < n_ops; ++k2) {
-                const uint32_t op2 = cigar[o + k2];
+                const uint32_t op2 = ops[k2];
                 const uint32_t c2 = op2 & 15u;
                 if (c2 == SPL_OP_N) break;
                 if ((SPL_PROG_MASK >> c2) & 1u) after += op2 >> 4;
@@ -1708,6 +1669,7 @@ __global__ __launch_bounds__(256) void spl_junction_kernel(int64_t n_reads, cons
             todo &= ~grp;
         }
     }
+  }
 }
 
 // Non-empty slots -> dense arrays (order arbitrary; the host sorts).
@@ -1751,17 +1713,6 @@ __global__ __launch_bounds__(256) void spl_build_dbuckets_kernel(const int32_t *
     out_rival[b] = rm;
 }
 
-// A read segment (one chromosome of a shard) was copied into place as it is; this moves it into the shard's coordinate
-// space and makes its CIGAR offsets global.
-__global__ __launch_bounds__(256) void spl_rebase_kernel(int32_t *pos, uint32_t *cig_off, int64_t n, int32_t shift, uint32_t cig_base)
-{
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
-        pos[j] += shift;
-        cig_off[j] += cig_base;
-    }
-}
-
 // Everything a counting pass starts from zero (the counter region of the site table: counters, difference arrays, queue
 // counters, error word; 16-byte aligned, a multiple of 16 bytes).  Normally the literal kernel of the previous pass has
 // cleared the copy a pass starts on; this launch is for the passes that have no such predecessor.
@@ -1773,7 +1724,7 @@ __global__ __launch_bounds__(256) void spl_clear_kernel(uint4 *region, size_t n1
 
 // ---- launchers (called from spl_capi.cpp through spl_device.h) ------------------------------------------
 
-extern "C" int spl_dev_launch_junctions(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar,
+extern "C" int spl_dev_launch_junctions(const spl_chunk_meta *chunk_meta, uint32_t n_chunks,
                                         int stranded, uint32_t min_anchor, uint32_t min_intron, uint32_t max_intron,
                                         unsigned long long *keys, uint32_t *vals, uint32_t n_slots,
                                         unsigned long long *out_keys, uint32_t *out_vals, uint32_t *n_out, int32_t *err, void *stream)
@@ -1784,9 +1735,9 @@ extern "C" int spl_dev_launch_junctions(int64_t n_reads, const int32_t *pos, con
     if (e == hipSuccess) e = hipMemsetAsync(n_out, 0, 4, st);
     if (e == hipSuccess) e = hipMemsetAsync(err, 0, 4, st);
     if (e != hipSuccess) return (int)e;
-    if (n_reads > 0)
-        hipLaunchKernelGGL(spl_junction_kernel, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, n_reads, pos, flag, cig_off, cigar,
-                           stranded, min_anchor, min_intron, max_intron, keys, vals, n_slots - 1u, err);
+    if (n_chunks > 0)
+        hipLaunchKernelGGL(spl_junction_kernel, dim3(n_chunks), dim3(256), 0, st, chunk_meta, stranded, min_anchor, min_intron, max_intron, keys,
+                           vals, n_slots - 1u, err);
     hipLaunchKernelGGL(spl_junction_compact_kernel, dim3((n_slots + 255u) / 256u), dim3(256), 0, st, keys, vals, n_slots, out_keys, out_vals, n_out);
     return (int)hipGetLastError();
 }
@@ -1797,15 +1748,6 @@ extern "C" int spl_dev_launch_build_dbuckets(const int32_t *site_pos, const int3
     if (n_dbuckets == 0) return 0;
     hipLaunchKernelGGL(spl_build_dbuckets_kernel, dim3((n_dbuckets + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, site_pos, dpos_first_row,
                        n_dpos, rival_bits, dbase, n_dbuckets, out, out_rival);
-    return (int)hipGetLastError();
-}
-
-extern "C" int spl_dev_launch_rebase(int32_t *pos, uint32_t *cig_off, int64_t n, int32_t shift, uint32_t cig_base, void *stream)
-{
-    if (n <= 0 || (shift == 0 && cig_base == 0)) return 0;
-    int64_t blocks = (n + 1023) / 1024;
-    blocks = blocks > 8192 ? 8192 : blocks;
-    hipLaunchKernelGGL(spl_rebase_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, pos, cig_off, n, shift, cig_base);
     return (int)hipGetLastError();
 }
 
@@ -1832,11 +1774,11 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
     if (variant == 1) {
-        *lds_out = 2 * SPL_WIN * 4 + 4;
+        *lds_out = 2 * SPL_WIN * 4 + SPL_BLOCK * 5 * 4 + 4;
         if (p->stranded) hipExtLaunchKernelGGL(spl_count_pairs_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *p);
         else hipExtLaunchKernelGGL(spl_count_pairs_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *p);
     } else {
-        *lds_out = (p->stranded ? 4 : 2) * (SPL_WIN + 1) * 4 + SPL_CHUNK * 2 + 8; // difference windows + the chunk's queue
+        *lds_out = (p->stranded ? 4 * (SPL_WIN_STRANDED + 1) : 2 * (SPL_WIN + 1)) * 4 + SPL_WAVES * SPL_WAVE_READS * 2 + 4 * SPL_WAVES + 4; // difference windows + the waves' lists
         const bool agg = (variant & 2) != 0;
 #ifdef SPL_PHASE_TIMING
         static uint64_t *phase_buf = nullptr;
@@ -1896,15 +1838,6 @@ extern "C" int spl_dev_launch_literal(const spl_count_params *p, const spl_queue
                 why[1], why[2], why[3], why[4], why[5], why[6], why[7]);
     }
 #endif
-    return (int)hipGetLastError();
-}
-
-extern "C" int spl_dev_launch_pack(int64_t n_reads, const int32_t *pos, const uint16_t *flag, const uint32_t *cig_off, const uint32_t *cigar,
-                                   int32_t *p_pos, uint32_t *p_fn, uint32_t *p_ops3, uint16_t *perm, uint32_t *chunk_cost, void *stream)
-{
-    if (n_reads <= 0) return 0;
-    hipLaunchKernelGGL(spl_pack_reads_kernel, dim3((uint32_t)((n_reads + SPL_CHUNK - 1) / SPL_CHUNK)), dim3(SPL_BLOCK), 0, (hipStream_t)stream,
-                       n_reads, pos, flag, cig_off, cigar, p_pos, p_fn, p_ops3, perm, chunk_cost);
     return (int)hipGetLastError();
 }
 

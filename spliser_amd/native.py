@@ -47,8 +47,9 @@ OPT_WAVE_AGGREGATION = 2
 EXPORTS = [
     "spl_abi_version", "spl_last_error", "spl_device_count", "spl_create", "spl_create_on_stream", "spl_destroy",
     "spl_sync", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
-    "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
-    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_close",
+    "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
+    "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
+    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write",
     "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append",
 ]
@@ -208,6 +209,12 @@ class Context(object):
         _check(lib().spl_reads_upload(self._h, ctypes.byref(reads.c), ctypes.byref(h)))
         return DeviceReads(self, h, reads.n)
 
+    def begin_reads(self):
+        """A read set to which segments are added one by one (``DeviceReads.add`` / ``add_bam``), then ``finish()``."""
+        h = ctypes.c_void_p()
+        _check(lib().spl_reads_begin(self._h, ctypes.byref(h)))
+        return DeviceReads(self, h, 0)
+
     def upload_read_segments(self, segments):
         """segments: [(ReadArrays-like with .c, position shift)] laid end to end as ONE device read set, copied straight
         from where they are (``spl_reads_upload_segments``)."""
@@ -260,6 +267,12 @@ class DeviceSites(object):
     def __init__(self, ctx, h, n, n_part):
         self.ctx, self._h, self.n, self.n_part = ctx, h, n, n_part
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
     def counters(self):
         beta1 = np.zeros(max(self.n, 1), np.uint32)
         b2s = np.zeros(max(self.n, 1), np.uint32)
@@ -283,6 +296,30 @@ class DeviceSites(object):
 class DeviceReads(object):
     def __init__(self, ctx, h, n):
         self.ctx, self._h, self.n = ctx, h, n
+
+    def add(self, reads, shift=0):
+        """One more segment from host arrays (``ReadArrays``), moved by ``shift`` into the shard's coordinate space."""
+        _check(lib().spl_reads_add(self.ctx._h, self._h, ctypes.byref(reads.c), ctypes.c_int32(int(shift))))
+        self.n += reads.n
+
+    def add_bam(self, bam, chrom, shift=0):
+        """One more segment: the reads of reference ``chrom`` straight from the decoder's buffers (waits for that reference
+        to be complete; the rest of the file may still be decoding).  -> number of reads added."""
+        tid = bam._tid[chrom]
+        n_reads, _ = bam.wait_ref(chrom)
+        _check(lib().spl_reads_add_bam(self.ctx._h, self._h, bam._h, ctypes.c_int(tid), ctypes.c_int32(int(shift))))
+        self.n += n_reads
+        return n_reads
+
+    def finish(self):
+        _check(lib().spl_reads_finish(self.ctx._h, self._h))
+        return self
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
 
     def literal_queue_size(self):
         out = ctypes.c_int64(0)
@@ -371,32 +408,59 @@ def write_bam(path, ref_names, ref_lengths, read_sets, level=1, threads=0):
 
 
 class BamFile(object):
-    """Whole-file BAM decode on host threads (``spl_bam_*``); replaces ``samtools view`` per site."""
+    """BAM decode on host threads (``spl_bam_*``); replaces ``samtools view`` per site.
 
-    def __init__(self, path, threads=0):
+    ``stream=True``: the constructor returns once the header is read and the decode goes on in the background; ``wait_ref``
+    blocks until one reference is complete, ``DeviceReads.add_bam`` sends its reads to the GPU from the decoder's own buffers,
+    ``wait_all`` ends the decode and tells whether the file was sorted by reference (if not, references taken early were
+    incomplete)."""
+
+    def __init__(self, path, threads=0, stream=False):
         self._h = ctypes.c_void_p()
-        _check(lib().spl_bam_open(os.fsencode(path), ctypes.c_int(threads), ctypes.byref(self._h)))
+        opener = lib().spl_bam_open_stream if stream else lib().spl_bam_open
+        _check(opener(os.fsencode(path), ctypes.c_int(threads), ctypes.byref(self._h)))
         self.ref_names = [lib().spl_bam_ref_name(self._h, i).decode("ascii") for i in range(lib().spl_bam_n_ref(self._h))]
         self.ref_lengths = [lib().spl_bam_ref_length(self._h, i) for i in range(len(self.ref_names))]
-        self.n_records = lib().spl_bam_n_records(self._h)
         self._tid = {n: i for i, n in enumerate(self.ref_names)}
+        self._views = {}
+
+    @property
+    def n_records(self):
+        return lib().spl_bam_n_records(self._h)     # (waits for the end of the decode)
+
+    def wait_ref(self, chrom):
+        """-> (reads on that reference, largest end coordinate) once the reference is complete."""
+        n, me = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(lib().spl_bam_wait_ref(self._h, ctypes.c_int(self._tid[chrom]), ctypes.byref(n), ctypes.byref(me)))
+        return n.value, me.value
+
+    def wait_all(self):
+        """Waits for the end of the decode (raises its error, if any).  -> True when the file was sorted by reference."""
+        ok = ctypes.c_int(0)
+        _check(lib().spl_bam_wait_all(self._h, ctypes.byref(ok)))
+        return bool(ok.value)
 
     def reads(self, chrom):
-        """-> samio.ReadSet-compatible views (borrowed from the native object) or None when the file has
-        no such reference (the reference's samtools call would print an error and yield nothing)."""
+        """-> samio.ReadSet-compatible views of the BAM-native arrays (borrowed from the native object, which every view
+        keeps alive) or None when the file has no such reference (the reference's samtools call would print an error and
+        yield nothing).  Waits for the whole file."""
         from .samio import ReadSet
         tid = self._tid.get(chrom)
         if tid is None:
             return None
+        if chrom in self._views:
+            return self._views[chrom]
         r = spl_reads()
         me = ctypes.c_int64(0)
         _check(lib().spl_bam_reads(self._h, ctypes.c_int(tid), ctypes.byref(r), ctypes.byref(me)))
         n = r.n_reads
         if n == 0:
             return ReadSet.empty()
+        owner = _BamHandle(self)
 
         def view(ptr, count, dt):
             buf = (ctypes.c_char * (count * np.dtype(dt).itemsize)).from_address(ptr)
+            buf._owner = owner      # the array's base object keeps the native decoder alive
             return np.frombuffer(buf, dtype=dt, count=count)
         cig_off = view(r.cig_off, n + 1, np.uint32)
         n_cig = int(cig_off[-1])
@@ -406,18 +470,57 @@ class BamFile(object):
         rs.cig_off = cig_off
         rs.cigar = view(r.cigar, n_cig, np.uint32) if n_cig else np.zeros(0, np.uint32)
         rs.max_end = me.value
-        rs_owner = self  # keep the native object alive as long as the views
-        setattr(self, "_views", getattr(self, "_views", []) + [rs])
-        del rs_owner
+        self._views[chrom] = rs
         return rs
 
     def close(self):
-        if self._h:
-            lib().spl_bam_close(self._h)
-            self._h = ctypes.c_void_p()
+        """Closes the native decoder -- unless views of its arrays are still alive: then their owner closes it."""
+        h, self._h = self._h, ctypes.c_void_p()
+        views, self._views = self._views, {}
+        if h and not views:
+            lib().spl_bam_close(h)
+        elif h:
+            _BamHandle.release(h, views)
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+
+class _BamHandle(object):
+    """Shared ownership of a native decoder between a BamFile and the numpy views handed out from it."""
+    _parked = {}
+
+    def __init__(self, bam):
+        self._bam = bam          # a view keeps its BamFile (and so the native object) alive
+
+    @classmethod
+    def release(cls, handle, views):
+        # BamFile.close() with live views: the native object is closed when the last view is gone
+        import weakref
+        key = handle.value
+        cls._parked[key] = handle
+        left = [len(views)]
+
+        def gone(_):
+            left[0] -= 1
+            if left[0] == 0:
+                lib().spl_bam_close(cls._parked.pop(key))
+        for rs in views.values():
+            weakref.finalize(rs.pos, gone, None)
+
+
+def pack_host(reads, threads=1):
+    """The host packer alone (``spl_pack_host``): -> (chunk descriptors as a structured array, record blob uint8, wide ops)."""
+    nc, rb, nw = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    _check(lib().spl_pack_host(ctypes.byref(reads.c), ctypes.c_int(threads), ctypes.byref(nc), ctypes.byref(rb), ctypes.byref(nw),
+                               None, None, None))
+    desc = np.zeros(max(nc.value, 1), np.dtype([("rec_off", "<u8"), ("wide_off", "<u8"), ("first_pos", "<i4"), ("cost", "<u4"),
+                                                 ("n", "<u2", (4,))]))
+    rec = np.zeros(max(rb.value, 1), np.uint8)
+    wide = np.zeros(max(nw.value, 1), np.uint32)
+    _check(lib().spl_pack_host(ctypes.byref(reads.c), ctypes.c_int(threads), ctypes.byref(nc), ctypes.byref(rb), ctypes.byref(nw),
+                               _ptr(desc), _ptr(rec), _ptr(wide)))
+    return desc[:nc.value], rec[:rb.value], wide[:nw.value]
