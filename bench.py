@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the SpliSER `process` hot path (Step 3) on MI355X.
 
-One "step" = one pass of the hot path over one synthetic sample whose SoA is already resident in HBM:
-spl_count_kernel (the checkBam loop, SpliSER_v0_1_8.py:408-559) + spl_sse_kernel (findBeta2Counts +
-calculateSSE, :581-639) for every shard of the sample.  Default workload = BASELINE.json configs[1]
-("A. thaliana whole-genome process, ~20M 150 bp reads, 1 MI355X"), synthesised from a seed
-(spliser_amd/synth.py) because there is no network and the reference ships no data.
+One "step" = ONE pass of the hot path over one synthetic sample whose reads are resident in HBM in the form every read set has
+when it gets there (packed by the host on the way, spliser_amd/csrc/spl_pack.h): for every shard of the sample the range
+kernel (the checkBam loop, SpliSER_v0_1_8.py:408-559), the literal kernel and the scan with findBeta2Counts + calculateSSE
+(:581-639).  A step ends with a device-side barrier: the next step's first kernel does not start before this step's last one
+has finished, as in a `process` run, which counts a read set once (``--pipelined`` drops the barrier: many samples in a row).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards with no exchange step, so
-every rank processes its own sample of the same shape (weak scaling, seed + rank); the only collectives
-are the timing barrier and the MAX reduction of the elapsed time.
+Default workload = BASELINE.json configs[2], the largest single-GPU configuration ("synthetic human-scale: 200 M reads x 300 k
+splice sites, HBM-roofline run"), synthesised from a seed (spliser_amd/synth.py) because there is no network and the reference
+ships no data.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards with no exchange step.  ``--scaling weak``
+(default): every rank processes its own sample of the same shape (seed + rank).  ``--scaling strong``: ONE sample, its
+chromosomes dealt to the ranks by read count (the partition of `process --gpus N`); the line then reports the imbalance.  The
+only collectives are the timing barrier and the reductions of the report.
+
+Besides the resident-step figure the line carries (rank 0, N = 1): the parity of the last timed step against the oracle on the
+whole workload; a CPU baseline (the oracle on 1 thread and on all cores of this host); and ``e2e`` -- BAM file -> native
+decode -> host packing -> H2D -> kernels -> .SpliSER.tsv through spliser_amd.process, with stage times.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
 import sys
 import tempfile
 import time
@@ -28,16 +39,157 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def build_inputs(args, rank, world):
+    """-> (workload, table, items [(chrom, ChromArrays, ReadSet)], stranded)"""
+    from spliser_amd import fast_sites, sites, synth
+    cfg = synth.WORKLOADS[args.workload]
+    stranded = args.stranded or ("fr" if cfg.get("paired") else None)
+    seed = cfg["seed"] + (rank if args.scaling == "weak" else 0)
+    cache = None
+    if args.cache:
+        os.makedirs(args.cache, exist_ok=True)
+        cache = os.path.join(args.cache, "%s_s%g_seed%d%s.npz" % (args.workload, args.scale, seed,
+                                                                   "" if args.genes is None else "_g%d" % args.genes))
+    if cache and os.path.exists(cache):
+        wl = synth.Workload.load(cache, args.workload)
+    else:
+        over = {} if args.alt_fraction is None else {"alt_fraction": args.alt_fraction}
+        if args.genes is not None:
+            over["n_genes"] = args.genes
+        wl = synth.Workload(args.workload, scale=args.scale, seed=seed, **over,
+                            workers=max(1, min(32, (os.cpu_count() or 1) // max(world, 1))))
+        if cache:
+            wl.save(cache)
+    if args.soft_clips > 0:
+        wl.reads = [synth.add_soft_clips(r, args.soft_clips, seed=100 + k) for k, r in enumerate(wl.reads)]
+    tmp = tempfile.mkdtemp(prefix="spliser_bench_")
+    bed = os.path.join(tmp, "junctions.bed")
+    synth.write_bed(bed, wl.genome.chrom_names, wl.junctions)
+    table = fast_sites.build(sites.GeneBins(), bool(stranded), bed)   # the same table `process` builds (Steps 1-2)
+    if table is None:
+        table = sites.SiteTable(is_stranded=bool(stranded))
+        table.add_bed(bed)
+        table.find_competitors()
+    shutil.rmtree(tmp, ignore_errors=True)
+    items = []
+    for i, c in enumerate(wl.genome.chrom_names):
+        arr = table.chrom_arrays(c)
+        if arr.n:
+            items.append((c, arr, wl.reads[i]))
+    return wl, table, items, stranded
+
+
+def lib_sha16():
+    from spliser_amd import native
+    h = hashlib.sha256()
+    with open(native.LIB_PATH, "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def run_oracle(items, scode, cryptic, threads):
+    """The oracle over the whole workload.  -> (seconds, {chrom: (counters, sse results)})"""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    outer = 1 if threads <= 1 else min(len(items), 8)
+    oracle.set_threads(max(1, threads // outer))
+
+    def one(item):
+        c, arr, rd = item
+        cnt = oracle.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos,
+                               rd.pos, rd.flag, rd.cig_off, rd.cigar, scode, 0)
+        sse = oracle.beta2_sse(arr.pos, arr.part_off, arr.part_pos, arr.part_site, arr.alpha, arr.edge_cnt,
+                               cnt[0], cnt[1], cnt[2], cryptic)
+        return c, (cnt, sse)
+    t = time.perf_counter()
+    if outer == 1:
+        res = dict(one(it) for it in items)
+    else:  # (ctypes releases the GIL: chromosomes side by side, the site loop of each on its share of the cores)
+        with ThreadPoolExecutor(outer) as pool:
+            res = dict(pool.map(one, sorted(items, key=lambda it: -it[2].n)))
+    dt = time.perf_counter() - t
+    oracle.set_threads(1)
+    return dt, res
+
+
+def e2e_leg(name, wl, table_items, stranded, cryptic, seq_mode, reps, want_rows):
+    """BAM + BED + GFF files of one workload -> spliser_amd.process.process (the CLI's function), timed.  The .SpliSER.tsv is
+    compared, row by row, with the counts the oracle gave for the same sample."""
+    from spliser_amd import native, process, synth
+    tmp = tempfile.mkdtemp(prefix="spliser_e2e_")
+    out = {"workload": name}
+    try:
+        prefix = os.path.join(tmp, name)
+        t = time.perf_counter()
+        synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions)
+        synth.write_gff(prefix + ".gff", wl.genome)
+        native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=0,
+                         seq_mode=seq_mode)
+        out["files_written_s"] = time.perf_counter() - t
+        out["bam_bytes"] = os.path.getsize(prefix + ".bam")
+        out["bam_seq_qual"] = ("constant bytes (deflate to almost nothing)" if seq_mode == 0 else
+                               "pseudo-random bases, binned qualities in runs (deflate like a real library)")
+        n_reads = sum(r.n for r in wl.reads)
+        runs = []
+        for k in range(reps):
+            t = time.perf_counter()
+            tm = process.process(prefix + ".bam", prefix + ".bed", prefix + ".out%d" % k, annotationFile=prefix + ".gff",
+                                 isStranded=bool(stranded), strandedType=stranded, isbeta2Cryptic=cryptic, log=lambda m: None)
+            wall = time.perf_counter() - t
+            runs.append(dict(wall_s=wall, reads_per_sec=n_reads / wall, stages={k2: round(v, 4) for k2, v in tm.items()}))
+        best = min(runs, key=lambda r: r["wall_s"])
+        out.update(reads=n_reads, reads_per_sec=best["reads_per_sec"], wall_s=best["wall_s"], stages=best["stages"],
+                   first_call_wall_s=runs[0]["wall_s"], runs=len(runs),
+                   what="process(): open BAM + BED/GFF -> Steps 0-2 on the host while the BAM decodes -> per chromosome: host "
+                        "packing, H2D through the staging ring, range + literal + scan/SSE kernels, D2H -> .SpliSER.tsv written "
+                        "while later chromosomes decode; wall clock of the whole call in a process whose GPU context exists "
+                        "(first_call_wall_s: the call that creates it)")
+        # parity of the file: Site, alpha, beta1, beta2Simple and SSE text of every row against the oracle's numbers
+        ok, rows = True, 0
+        with open(prefix + ".out%d.SpliSER.tsv" % (reps - 1)) as fh:
+            next(fh)
+            for line in fh:
+                v = line.split("\t")
+                w = want_rows.get((v[0], int(v[1]), v[2]))
+                ok &= w is not None and (v[4], v[5], v[6], v[7]) == w
+                rows += 1
+        out["tsv_rows"] = rows
+        out["tsv_matches_oracle"] = bool(ok and rows == len(want_rows))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def oracle_rows(items, want, cryptic):
+    """{(chrom, pos, strand text): (SSE text, alpha, beta1, beta2Simple)} as the .SpliSER.tsv prints them."""
+    rows = {}
+    for c, arr, _ in items:
+        (b1, _, _), (b2s, _, _, sse) = want[c]
+        for i in range(arr.n):
+            rows[(c, int(arr.pos[i]), arr.strand_text[i])] = ("{0:.3f}".format(sse[i]), str(int(arr.alpha[i])), str(int(b1[i])),
+                                                              str(int(b2s[i])))
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="arabidopsis", choices=["arabidopsis", "human", "mouse_stranded", "single_gene"])
+    ap.add_argument("--workload", default="human", choices=["arabidopsis", "human", "mouse_stranded", "single_gene"])
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the workload's read count (debug)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = a sample per rank; strong = one sample, chromosomes dealt to the ranks")
     ap.add_argument("--stranded", default=None, choices=[None, "fr", "rf"])
     ap.add_argument("--beta2Cryptic", action="store_true")
+    ap.add_argument("--pipelined", action="store_true", help="no barrier between steps: the tail of a step runs beside the "
+                    "first range kernel of the next (many samples in a row)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e", default="auto", choices=["auto", "off"], help="auto: the decode-inclusive leg for this workload "
+                    "(and for arabidopsis when the workload is human)")
+    ap.add_argument("--e2e-seq-mode", type=int, default=0, choices=[0, 1], help="SEQ / QUAL of the e2e BAM: 0 constant bytes, "
+                    "1 pseudo-random bases + binned qualities (10x the file)")
+    ap.add_argument("--e2e-reps", type=int, default=3)
     ap.add_argument("--kernel", default="ranges", choices=["ranges", "ranges_agg", "pairs"],
                     help="ranges = default product path; pairs = the literal per-(read, site) kernel")
     ap.add_argument("--alt-fraction", type=float, default=None, help="(experiment) fraction of genes with alternative isoforms")
@@ -49,54 +201,30 @@ def main():
                     "sample is loaded instead of regenerated (use under rocprofv3: no generator worker processes)")
     ap.add_argument("--copies", type=int, default=1, help="(experiment) device copies of the sample; step k works on copy "
                     "k mod copies, so that nothing a step read can still be in a cache when it is read again")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    from spliser_amd import native, shard, sites, synth
+    from spliser_amd import native, shard, synth
 
     # ---- synthetic sample of this rank (generated BEFORE the GPU is touched: the generator forks) -----
     t_gen = time.perf_counter()
-    cfg = synth.WORKLOADS[args.workload]
-    stranded = args.stranded or ("fr" if cfg.get("paired") else None)
-    cache = None
-    if args.cache:
-        os.makedirs(args.cache, exist_ok=True)
-        cache = os.path.join(args.cache, "%s_s%g_seed%d%s.npz" % (args.workload, args.scale, cfg["seed"] + rank,
-                                                                   "" if args.genes is None else "_g%d" % args.genes))
-    if cache and os.path.exists(cache):
-        wl = synth.Workload.load(cache, args.workload)
-    else:
-        over = {} if args.alt_fraction is None else {"alt_fraction": args.alt_fraction}
-        if args.genes is not None:
-            over["n_genes"] = args.genes
-        wl = synth.Workload(args.workload, scale=args.scale, seed=cfg["seed"] + rank, **over,
-                            workers=max(1, min(8, (os.cpu_count() or 1) // max(world, 1))))
-        if cache:
-            wl.save(cache)
-    if args.soft_clips > 0:
-        wl.reads = [synth.add_soft_clips(r, args.soft_clips, seed=100 + k) for k, r in enumerate(wl.reads)]
-    tmp = tempfile.mkdtemp(prefix="spliser_bench_")
-    bed = os.path.join(tmp, "junctions.bed")
-    synth.write_bed(bed, wl.genome.chrom_names, wl.junctions)
-    from spliser_amd import fast_sites
-    table = fast_sites.build(sites.GeneBins(), bool(stranded), bed)   # the same table `process` builds (Steps 1-2)
-    if table is None:
-        table = sites.SiteTable(is_stranded=bool(stranded))
-        table.add_bed(bed)
-        table.find_competitors()
-    names = wl.genome.chrom_names
-    items = []
-    for i, c in enumerate(names):
-        arr = table.chrom_arrays(c)
-        if arr.n:
-            items.append((c, arr, wl.reads[i]))
-    shards = shard.pack(items)
-    n_reads = sum(sh.reads.n for sh in shards)
-    n_sites = sum(sh.sites.n for sh in shards)
+    wl, table, items, stranded = build_inputs(args, rank, world)
+    all_items = items
+    if args.scaling == "strong" and world > 1:   # `process --gpus N`: chromosomes by read count, longest first (shard.assign)
+        mine = set(shard.assign({c: rd.n + arr.n for c, arr, rd in items}, world)[rank])
+        items = [it for it in items if it[0] in mine]
+    # the e2e leg of the smaller configuration wants a sample of its own: generated now, for the same reason
+    wl_small = None
+    if args.e2e == "auto" and rank == 0 and world == 1 and args.workload == "human" and args.scale == 1.0:
+        small = argparse.Namespace(**vars(args))
+        small.workload, small.cache = "arabidopsis", None
+        wl_small = build_inputs(small, 0, 1)
+    shards = shard.pack(items, concat_reads=False)
+    n_reads = sum(rd.n for _, _, rd in items)
+    n_sites = sum(arr.n for _, arr, _ in items)
     t_gen = time.perf_counter() - t_gen
 
     import torch
@@ -109,7 +237,11 @@ def main():
     scode = native.STRANDED_CODE[stranded]
     kflags = {"pairs": native.OPT_PAIR_KERNEL, "ranges_agg": native.OPT_WAVE_AGGREGATION, "ranges": 0}[args.kernel]
     ctx = native.Context(local_rank)
-    copies = [[(ctx.upload_sites(sh.sites), ctx.upload_reads(sh.reads)) for sh in shards] for _ in range(max(1, args.copies))]
+    t_up = time.perf_counter()
+    copies = [[(ctx.upload_sites(sh.sites), ctx.upload_read_segments(sh.read_segments)) for sh in shards]
+              for _ in range(max(1, args.copies))]
+    ctx.sync()
+    t_up = time.perf_counter() - t_up
     dev = copies[0]
     step_no = [0]
     alg_bytes = sum(native.algorithmic_bytes(ds, dr) for ds, dr in dev)
@@ -119,6 +251,8 @@ def main():
         for ds, dr in copies[(args.steps + args.warmup - step_no[0]) % len(copies)]:   # (the last step works on copy 0)
             ctx.count_launch(ds, dr, scode, 0, kflags)
             ctx.sse_launch(ds, args.beta2Cryptic)
+        if not args.pipelined:
+            ctx.pass_barrier()
 
     def fence():
         ctx.sync()
@@ -139,8 +273,12 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ctx.kernel_timing_collect(args.steps * len(dev) + 8)
-    # outside the timed region: the same kernel with nothing beside it (a sync after every launch, so that the tail of a pass is
-    # over before the next range kernel starts) -- what the tail stream costs the kernel it overlaps with
+    # the results of the LAST TIMED step, taken before anything else is launched: what the parity field below compares
+    gpu_counts = [ds.counters() for ds, _ in dev]
+    gpu_sse = [ds.sse_results() for ds, _ in dev]
+    literal_reads = sum(dr.literal_queue_size() for _, dr in dev) if args.kernel != "pairs" else None
+    # outside the timed region: the range kernel with nothing beside it (a sync after every launch, so that the tail of a pass
+    # is over before the next range kernel starts)
     ctx.kernel_timing_begin(5 * len(dev))
     for _ in range(5):
         for ds, dr in dev:
@@ -148,10 +286,15 @@ def main():
             ctx.sse_launch(ds, args.beta2Cryptic)
             ctx.sync()
     kernel_ms_alone = ctx.kernel_timing_collect(5 * len(dev) + 8)
-    literal_reads = sum(dr.literal_queue_size() for _, dr in dev) if args.kernel != "pairs" else None
     info = ctx.launch_info()
+    for cp in copies:
+        for ds, dr in cp:
+            dr.free()
+            ds.free()
 
     tot_reads, tot_sites = float(n_reads), float(n_sites)
+    imbalance = None
+    my_elapsed = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -159,83 +302,90 @@ def main():
         c = torch.tensor([tot_reads, tot_sites], dtype=torch.float64, device="cuda")
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         tot_reads, tot_sites = float(c[0].item()), float(c[1].item())
+        per = torch.zeros(world, 2, dtype=torch.float64, device="cuda")
+        per[rank, 0], per[rank, 1] = float(n_reads), my_elapsed
+        dist.all_reduce(per, op=dist.ReduceOp.SUM)
+        imbalance = {"reads_per_rank": [int(v) for v in per[:, 0].tolist()],
+                     "seconds_per_rank": [round(float(v), 6) for v in per[:, 1].tolist()],
+                     "max_over_mean_reads": float(per[:, 0].max() / per[:, 0].mean())}
 
     # ---- whole-workload parity check + CPU baseline (rank 0; the baseline only at N = 1) -------------
-    # The oracle is the checker here, never the thing measured as "value".  It is so much faster than the
-    # Python reference (tens of M reads/s on one core) that the bounded sample is the ENTIRE workload,
-    # repeated until ~cpu-seconds of CPU work have been timed.
+    # The oracle is the checker here, never the thing measured as "value".
     cpu = None
     parity = None
+    e2e = None
     if rank == 0:
-        from oracle import oracle
-        gpu_counts = [ds.counters() for ds, _ in dev]          # results of the last timed step
-        gpu_sse = [ds.sse_results() for ds, _ in dev]
-
-        def run_oracle():
-            res = {}
-            t = time.perf_counter()
-            for c, arr, rd in items:
-                cnt = oracle.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos,
-                                       rd.pos, rd.flag, rd.cig_off, rd.cigar, scode, 0)
-                sse = oracle.beta2_sse(arr.pos, arr.part_off, arr.part_pos, arr.part_site, arr.alpha, arr.edge_cnt,
-                                       cnt[0], cnt[1], cnt[2], args.beta2Cryptic)
-                res[c] = (cnt, sse)
-            return time.perf_counter() - t, res
-
-        t_cpu, want = run_oracle()
+        t_cpu1, want = run_oracle(items, scode, args.beta2Cryptic, 1)
         exact = True
         for sh, cnts, sses in zip(shards, gpu_counts, gpu_sse):
             for chrom, (r0, r1), (e0, e1) in zip(sh.chroms, sh.site_rows, sh.edge_rows):
                 (w1, w2, w3), wsse = want[chrom]
                 exact &= np.array_equal(cnts[0][r0:r1], w1) and np.array_equal(cnts[1][r0:r1], w2) and np.array_equal(cnts[2][e0:e1], w3)
                 exact &= all(np.array_equal(g[r0:r1], w) for g, w in zip(sses, wsse))
-        parity = {"reads": n_reads, "sites": n_sites, "bit_exact_vs_oracle": bool(exact),
+        parity = {"reads": n_reads, "sites": n_sites, "bit_exact_vs_oracle": bool(exact), "of": "the last timed step",
                   "checked": "beta1, beta2Simple(reads), double counts, beta2Simple, beta2Cryptic, beta2Weighted, SSE"}
         if world == 1 and not args.no_cpu_baseline:
-            times = [t_cpu]
-            while sum(times) < args.cpu_seconds and len(times) < 50:
-                times.append(run_oracle()[0])
-            best = min(times)
-            cpu = {"value": n_sites / best, "unit": "splice sites/s", "reads_per_sec": n_reads / best, "cores": 1,
+            nproc = os.cpu_count() or 1
+            t_all, want_all = run_oracle(items, scode, args.beta2Cryptic, nproc)
+            same = all(all(np.array_equal(a, b) for a, b in zip(want[c][0], want_all[c][0])) for c in want)
+            pairs = int(sum(int(w[0].sum()) + int(w[1].sum()) for w, _ in want.values()))
+            cpu = {"value": n_sites / t_cpu1, "unit": "splice sites/s", "reads_per_sec": n_reads / t_cpu1, "cores": 1,
                    "kind": "port",
-                   "sample": "the whole workload (%d reads x %d sites), oracle/spliser_oracle.c site-centric C "
-                             "restatement on 1 thread, best of %d passes (%.2f s each, %.1f s total)"
-                             % (n_reads, n_sites, len(times), best, sum(times))}
-
-    for ds, dr in dev:
-        dr.free()
-        ds.free()
+                   "sample": "the whole workload (%d reads x %d sites), one pass (%.1f s) of oracle/spliser_oracle.c, the "
+                             "site-centric C restatement of checkBam + findBeta2Counts + calculateSSE, on 1 thread" % (n_reads, n_sites, t_cpu1),
+                   "all_cores": {"value": n_sites / t_all, "reads_per_sec": n_reads / t_all, "nproc": nproc,
+                                 "threads": "up to 8 chromosomes side by side, the site loop of each on nproc/8 OpenMP threads",
+                                 "seconds": t_all, "same_counts_as_1_thread": bool(same)},
+                   "reference_cost_model": {"estimate_seconds": n_sites * 1.7e-3 + pairs * 7.1e-6,
+                                            "label": "ESTIMATE, not a measurement: S*1.7 ms (one samtools spawn per site) + P*7.1 us "
+                                                     "(Python per counted (read, site) pair, P >= %d) for SpliSER v0.1.8 on one core "
+                                                     "(BASELINE.md; SpliSER_v0_1_8.py:422, :427-559)" % pairs}}
+        if world == 1 and args.e2e == "auto":
+            e2e = [e2e_leg(args.workload, wl, items, stranded, args.beta2Cryptic, args.e2e_seq_mode, args.e2e_reps,
+                           oracle_rows(items, want, args.beta2Cryptic))]
+            if wl_small is not None:
+                wl2, _, items2, stranded2 = wl_small
+                _, want2 = run_oracle(items2, native.STRANDED_CODE[stranded2], args.beta2Cryptic, os.cpu_count() or 1)
+                e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, args.e2e_seq_mode, args.e2e_reps,
+                                   oracle_rows(items2, want2, args.beta2Cryptic)))
     ctx.close()
 
     if rank == 0:
-        # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from the committed
-        # rocprofv3 --pmc passes of the same command (profiles/), and only for the exact workload they were measured on.
-        traffic = None
+        # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from a committed
+        # rocprofv3 --pmc run of this command (profiles/*_traffic.json, made by tools/prof_pmc.sh) and are quoted only for the
+        # workload AND the library build they were measured with.
+        traffic, traffic_from = None, None
         import glob
-        tfiles = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_traffic.json")))
-        tpath = tfiles[-1] if tfiles else ""  # the newest committed measurement (file names sort by round and build)
-        if (args.workload == "arabidopsis" and args.scale == 1.0 and args.kernel == "ranges" and not stranded
-                and args.alt_fraction is None and args.genes is None and args.soft_clips == 0 and os.path.exists(tpath)):
+        sha = lib_sha16()
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_traffic.json")), reverse=True):
             with open(tpath) as fh:
-                traffic = json.load(fh)["hbm_bytes_per_launch"]
+                tj = json.load(fh)
+            if tj.get("lib_sha16") == sha and tj.get("workload") == args.workload and args.scale == 1.0 and args.kernel == "ranges":
+                traffic, traffic_from = tj["hbm_bytes_per_launch"], os.path.basename(tpath)
+                break
         k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         # one step = len(dev) launches; bytes per launch and time per launch are both averaged over launches
         bytes_per_launch = alg_bytes / max(len(dev), 1)
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9 if kernel_ms else float("nan")
+        ms_per_step = elapsed / args.steps * 1e3
+        path_gbs = alg_bytes / (my_elapsed / args.steps) / 1e9
         out = {
             "metric": "splice sites/sec (+ reads/sec) processed",
             "value": tot_sites * args.steps / elapsed,
             "unit": "splice sites/s",
             "reads_per_sec": tot_reads * args.steps / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "int32/u32 counters, f64 SSE", "data": "synthetic",
-            "config": {"workload": "%s: %d reads x %d splice sites per GPU, %d chromosomes in %d shard(s), 150 bp, %s"
-                                   % (args.workload, n_reads, n_sites, len(items), len(dev), stranded or "unstranded"),
-                       "scale": args.scale, "parallelism": "chromosome/sample shards, no collectives", "seed": cfg["seed"]},
+            "config": {"workload": "%s: %d reads x %d splice sites%s, %d chromosomes in %d shard(s) on rank 0, 150 bp, %s"
+                                   % (args.workload, int(tot_reads), int(tot_sites), " per GPU" if args.scaling == "weak" and world > 1 else "",
+                                      len(items), len(dev), stranded or "unstranded"),
+                       "scale": args.scale, "parallelism": "chromosome/sample shards, no collectives", "seed": synth.WORKLOADS[args.workload]["seed"],
+                       "step": "one pass per resident read set: range + literal + scan/SSE kernels of every shard, %s"
+                               % ("no barrier between steps (pipelined)" if args.pipelined else "device-side barrier between steps")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
                          "kernel": "spl_count_%s_kernel" % args.kernel.split("_")[0], "kernel_ms_avg": k_avg_ms, "launches_timed": len(kernel_ms),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"],
@@ -243,13 +393,15 @@ def main():
                                    {"kernel_ms_avg": sum(kernel_ms_alone) / len(kernel_ms_alone),
                                     "frac": bytes_per_launch / (sum(kernel_ms_alone) / len(kernel_ms_alone) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "how": "5 more launches after the timed region, each followed by a sync"}),
-                         "concurrent": (None if os.environ.get("SPL_TAIL_STREAM", "1")[:1] == "0" or args.kernel == "pairs" else
-                                        "the literal kernel and the scan of the launch before run beside this kernel on a stream of "
-                                        "their own: its duration includes what it yields to them (alone: SPL_TAIL_STREAM=0)")},
+                         "path": {"what": "algorithmic bytes of a step / time of a step: every kernel of the pass and the gaps between them",
+                                  "achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS},
+                         "lib_sha16": sha},
             "cpu_baseline": cpu,
             "parity": parity,
+            "e2e": e2e,
+            "imbalance": imbalance,
             "literal_kernel_reads": literal_reads,
-            "gen_seconds": t_gen,
+            "gen_seconds": t_gen, "upload_seconds": t_up,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -110,6 +110,9 @@ int spl_create(int device_id, spl_ctx **out);
 int spl_create_on_stream(int device_id, void *hip_stream, spl_ctx **out);
 void spl_destroy(spl_ctx *ctx);
 int spl_sync(spl_ctx *ctx);
+/* Device-side barrier: what is launched on the context after this call starts after everything launched before it has
+ * finished (the tails of counting passes, which run on a second stream, included).  The host does not wait. */
+int spl_pass_barrier(spl_ctx *ctx);
 /* HIP-event stopwatch on the context's stream (what bench.py times the kernels with). */
 int spl_timer_begin(spl_ctx *ctx);
 int spl_timer_end(spl_ctx *ctx, float *elapsed_ms_out);
@@ -213,6 +216,10 @@ int spl_bam_reads(const spl_bam *bam, int tid, spl_reads *out, int64_t *max_end_
  * BAM with dummy names, SEQ and QUAL of the query length, BGZF blocks deflated on n_threads (0 = all cores). */
 int spl_bam_write(const char *path, int n_ref, const char *const *ref_names, const int64_t *ref_lengths,
                   const spl_reads *per_ref, int level, int n_threads);
+/* Same with a choice of what SEQ / QUAL hold: seq_mode 0 = constant bytes (spl_bam_write: a file that deflates to a few bytes
+ * per record), 1 = pseudo-random bases and binned qualities in runs (deflates about 4x, like a real library). */
+int spl_bam_write2(const char *path, int n_ref, const char *const *ref_names, const int64_t *ref_lengths,
+                   const spl_reads *per_ref, int level, int n_threads, int seq_mode);
 
 /* ---- junction table of a read set (what the pipeline otherwise takes from `regtools junctions extract`) --------------
  * Every N op of every mapped read is a junction (left, right) in SpliSER's site convention (left = last base before the

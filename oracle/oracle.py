@@ -34,6 +34,12 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def set_threads(n):
+    """Threads for the site loop of ``check_bam`` (default 1, like the reference).  Only bench.py's all-cores CPU baseline
+    asks for more."""
+    lib().orc_set_threads(ctypes.c_int(int(n)))
+
+
 def _c(a, dt):
     return np.ascontiguousarray(a, dtype=dt)
 

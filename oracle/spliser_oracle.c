@@ -28,6 +28,11 @@
  * read fetch: what `samtools view BAM chr:t-(t+1)` hands to checkBam (SpliSER_v0_1_8.py:422-435)
  * ---------------------------------------------------------------------------------------------- */
 
+/* Threads for the site loop of orc_check_bam and the index build (default 1: the reference is single-threaded,
+ * SpliSER_v0_1_8.py:681-692).  Only the all-cores CPU baseline of bench.py asks for more. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+
 typedef struct {
     int64_t n;
     int64_t *order;   /* read indices sorted by pos (stable)                 */
@@ -71,11 +76,14 @@ static int fetch_index_build(fetch_index *fi, int64_t n, const int32_t *r_pos, c
     int64_t *key = (int64_t *)malloc(sizeof(int64_t) * n);
     if (!fi->order || !fi->pos0 || !fi->pmaxend || !fi->endpos0 || !key) return -1;
     int sorted = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads > 0 ? g_threads : 1) reduction(&& : sorted)
+#endif
     for (int64_t i = 0; i < n; ++i) {
         key[i] = (int64_t)r_pos[i] - 1;
         fi->order[i] = i;
         fi->endpos0[i] = bam_endpos0(key[i], r_flag[i], cigar + cig_off[i], cig_off[i + 1] - cig_off[i]);
-        if (i && key[i] < key[i - 1]) sorted = 0;
+        if (i && (int64_t)r_pos[i] < (int64_t)r_pos[i - 1]) sorted = 0;
     }
     if (!sorted) {
         g_sort_key = key;
@@ -232,6 +240,11 @@ int orc_check_bam(int64_t n_sites, const int32_t *site_pos, const uint8_t *site_
     memset(beta2s_reads, 0, sizeof(uint32_t) * (size_t)n_sites);
     if (n_sites > 0) memset(dbl, 0, sizeof(uint32_t) * (size_t)part_off[n_sites]);
 
+    /* The CPU-baseline leg of bench.py may ask for several threads (orc_set_threads): the sites of a chromosome are
+     * independent of each other (every output below belongs to one site), so the loop is simply shared out. */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 128) num_threads(g_threads > 0 ? g_threads : 1)
+#endif
     for (int64_t s = 0; s < n_sites; ++s) {
         const int64_t t = site_pos[s];
         /* region chr:t-(t+1)  ->  0-based half-open [t-1, t+1) */

@@ -86,7 +86,10 @@ struct Deflate {
     int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
     void (*free_)(void *) = nullptr;
     uint32_t (*crc32)(uint32_t, const void *, size_t) = nullptr;
-    bool ok = false;
+    void *(*calloc_)(int) = nullptr;                                           // compressor (the BAM writer)
+    size_t (*compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+    void (*cfree)(void *) = nullptr;
+    bool ok = false, cok = false;
     Deflate()
     {
         if (getenv("SPL_BAM_NO_LIBDEFLATE")) return;
@@ -97,6 +100,10 @@ struct Deflate {
         free_ = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
         crc32 = (uint32_t(*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
         ok = alloc && decompress && free_ && crc32;
+        calloc_ = (void *(*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        compress = (size_t(*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_deflate_compress");
+        cfree = (void (*)(void *))dlsym(h, "libdeflate_free_compressor");
+        cok = ok && calloc_ && compress && cfree;
     }
 };
 const Deflate &deflate_lib()
@@ -901,118 +908,169 @@ int spl_bam_source(spl_bam *bam, int tid, splpack::Source *out, int64_t *max_end
 
 // ---- BAM writer (synthetic workloads, tests): the inverse of the reader above -------------------------------------
 // Records carry a dummy read name, SEQ and QUAL of the query length so that the file has the size and block structure
-// of a real BAM; BGZF blocks are deflated in parallel.  Only what spl_bam_open reads back is meaningful.
+// of a real BAM.  The reads are cut into slices; a slice is formatted and deflated into BGZF blocks of its own by one
+// thread (concatenated BGZF blocks are a BGZF file, wherever the records are cut).  Only what spl_bam_open reads back is
+// meaningful.
 namespace {
-
-struct OutBlock { std::vector<uint8_t> raw, comp; };
 
 void put32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
 void put16(std::vector<uint8_t> &v, uint32_t x) { v.push_back((uint8_t)x); v.push_back((uint8_t)(x >> 8)); }
 
-bool deflate_block(OutBlock &b, int level)
+// raw[0..n) -> one BGZF block appended to out.  ld: a libdeflate compressor or null (zlib).
+bool deflate_block(const uint8_t *raw, size_t n, int level, void *ld, std::vector<uint8_t> &out)
 {
-    const size_t n = b.raw.size();
-    b.comp.resize(n + n / 8 + 64);
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-    zs.next_in = b.raw.data(); zs.avail_in = (uInt)n;
-    zs.next_out = b.comp.data() + 18; zs.avail_out = (uInt)(b.comp.size() - 18 - 8);
-    const int rc = deflate(&zs, Z_FINISH);
-    const size_t clen = zs.total_out;
-    deflateEnd(&zs);
-    if (rc != Z_STREAM_END) return false;
+    const size_t at = out.size();
+    out.resize(at + 18 + n + n / 8 + 64 + 8);
+    uint8_t *dst = out.data() + at;
+    size_t clen = 0;
+    if (ld) {
+        clen = deflate_lib().compress(ld, raw, n, dst + 18, n + n / 8 + 64);
+        if (clen == 0) return false;
+    } else {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        zs.next_in = const_cast<Bytef *>(raw); zs.avail_in = (uInt)n;
+        zs.next_out = dst + 18; zs.avail_out = (uInt)(n + n / 8 + 64);
+        const int rc = deflate(&zs, Z_FINISH);
+        clen = zs.total_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END) return false;
+    }
     const size_t bsize = 18 + clen + 8;
     if (bsize > 65536) return false;
     static const uint8_t head[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
-    memcpy(b.comp.data(), head, 12);
-    b.comp[12] = 'B'; b.comp[13] = 'C'; b.comp[14] = 2; b.comp[15] = 0;
-    b.comp[16] = (uint8_t)((bsize - 1) & 0xff); b.comp[17] = (uint8_t)((bsize - 1) >> 8);
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), b.raw.data(), (uInt)n);
-    uint8_t *t = b.comp.data() + 18 + clen;
+    memcpy(dst, head, 12);
+    dst[12] = 'B'; dst[13] = 'C'; dst[14] = 2; dst[15] = 0;
+    dst[16] = (uint8_t)((bsize - 1) & 0xff); dst[17] = (uint8_t)((bsize - 1) >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), raw, (uInt)n);
+    uint8_t *t = dst + 18 + clen;
     for (int i = 0; i < 4; ++i) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i)); }
-    b.comp.resize(bsize);
+    out.resize(at + bsize);
+    return true;
+}
+
+bool deflate_all(const std::vector<uint8_t> &raw, int level, void *ld, std::vector<uint8_t> &out)
+{
+    const size_t BLOCK = 0xff00;
+    for (size_t at = 0; at < raw.size(); at += BLOCK)
+        if (!deflate_block(raw.data() + at, std::min(BLOCK, raw.size() - at), level, ld, out)) return false;
     return true;
 }
 
 } // namespace
 
-extern "C" int spl_bam_write(const char *path, int n_ref, const char *const *ref_names, const int64_t *ref_lengths,
-                             const spl_reads *per_ref, int level, int n_threads)
+// seq_mode 0: constant SEQ / QUAL bytes (a file that deflates to a few bytes per record); 1: pseudo-random bases and binned
+// qualities in runs, so that records deflate about as well as those of a real library (~4x).
+extern "C" int spl_bam_write2(const char *path, int n_ref, const char *const *ref_names, const int64_t *ref_lengths,
+                              const spl_reads *per_ref, int level, int n_threads, int seq_mode)
 {
     if (!path || n_ref < 0 || (n_ref && (!ref_names || !ref_lengths || !per_ref))) return spl_set_error(SPL_ERR_ARG, "spl_bam_write: bad argument");
     FILE *fh = fopen(path, "wb");
     if (!fh) return spl_set_error(SPL_ERR_IO, "cannot create %s", path);
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads <= 0) n_threads = 1;
-    const size_t BLOCK = 0xff00, BATCH = 2048;
-    std::vector<OutBlock> batch;
-    std::vector<uint8_t> cur;
-    cur.reserve(BLOCK + 1024);
+    if (n_threads > 64) n_threads = 64;
     int rc = SPL_OK;
-    auto flush_batch = [&]() {
-        std::atomic<size_t> next(0);
-        std::atomic<bool> bad(false);
-        auto work = [&]() { for (;;) { size_t i = next.fetch_add(1); if (i >= batch.size()) break; if (!deflate_block(batch[i], level)) bad.store(true); } };
+    // header
+    {
+        std::vector<uint8_t> cur, out;
+        std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+        for (int i = 0; i < n_ref; ++i) text += std::string("@SQ\tSN:") + ref_names[i] + "\tLN:" + std::to_string((long long)ref_lengths[i]) + "\n";
+        cur.insert(cur.end(), {'B', 'A', 'M', 1});
+        put32(cur, (uint32_t)text.size());
+        cur.insert(cur.end(), text.begin(), text.end());
+        put32(cur, (uint32_t)n_ref);
+        for (int i = 0; i < n_ref; ++i) {
+            const size_t ln = strlen(ref_names[i]) + 1;
+            put32(cur, (uint32_t)ln);
+            cur.insert(cur.end(), ref_names[i], ref_names[i] + ln);
+            put32(cur, (uint32_t)ref_lengths[i]);
+        }
+        if (!deflate_all(cur, level, nullptr, out)) rc = spl_set_error(SPL_ERR_IO, "deflate failed while writing %s", path);
+        else if (fwrite(out.data(), 1, out.size(), fh) != out.size()) rc = spl_set_error(SPL_ERR_IO, "short write to %s", path);
+    }
+    struct Slice { int tid; int64_t k0, k1; uint64_t serial; std::vector<uint8_t> out; bool bad = false; };
+    std::vector<Slice> slices;
+    const int64_t SLICE = 16384;
+    uint64_t serial = 0;
+    for (int tid = 0; tid < n_ref; ++tid)
+        for (int64_t k = 0; k < per_ref[tid].n_reads; k += SLICE) {
+            Slice sl;
+            sl.tid = tid; sl.k0 = k; sl.k1 = std::min(per_ref[tid].n_reads, k + SLICE); sl.serial = serial;
+            serial += (uint64_t)(sl.k1 - sl.k0);
+            slices.push_back(std::move(sl));
+        }
+    const size_t WAVE = (size_t)n_threads * 4;
+    for (size_t w0 = 0; w0 < slices.size() && rc == SPL_OK; w0 += WAVE) {
+        const size_t w1 = std::min(slices.size(), w0 + WAVE);
+        std::atomic<size_t> next(w0);
+        auto work = [&]() {
+            void *ld = deflate_lib().cok ? deflate_lib().calloc_(level < 1 ? 1 : (level > 12 ? 12 : level)) : nullptr;
+            std::vector<uint8_t> cur;
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= w1) break;
+                Slice &sl = slices[i];
+                const spl_reads &r = per_ref[sl.tid];
+                cur.clear();
+                uint64_t lcg = 0x9E3779B97F4A7C15ull * (sl.serial + 1);
+                for (int64_t k = sl.k0; k < sl.k1; ++k) {
+                    const uint32_t o0 = r.cig_off[k], n_ops = r.cig_off[k + 1] - o0;
+                    uint32_t qlen = 0;
+                    for (uint32_t j = 0; j < n_ops; ++j) { const uint32_t c = r.cigar[o0 + j] & 15u; if (c == 0 || c == 1 || c == 4 || c == 7 || c == 8) qlen += r.cigar[o0 + j] >> 4; }
+                    char name[24];
+                    const int l_name = snprintf(name, sizeof(name), "r%llu", (unsigned long long)(sl.serial + (uint64_t)(k - sl.k0))) + 1;
+                    const uint32_t bs = 32 + (uint32_t)l_name + 4 * n_ops + (qlen + 1) / 2 + qlen;
+                    put32(cur, bs);
+                    put32(cur, (uint32_t)sl.tid);
+                    put32(cur, (uint32_t)(r.pos[k] - 1));
+                    cur.push_back((uint8_t)l_name); cur.push_back(60);
+                    put16(cur, 4680); put16(cur, n_ops); put16(cur, r.flag[k]);
+                    put32(cur, qlen); put32(cur, 0xffffffffu); put32(cur, 0xffffffffu); put32(cur, 0);
+                    cur.insert(cur.end(), name, name + l_name);
+                    for (uint32_t j = 0; j < n_ops; ++j) put32(cur, r.cigar[o0 + j]);
+                    if (seq_mode == 0) {
+                        cur.insert(cur.end(), (qlen + 1) / 2, (uint8_t)0x12);
+                        cur.insert(cur.end(), qlen, (uint8_t)30);
+                    } else {
+                        static const uint8_t base[4] = {1, 2, 4, 8};
+                        static const uint8_t qbin[4] = {37, 37, 25, 11};
+                        for (uint32_t j = 0; j < (qlen + 1) / 2; ++j) {
+                            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                            cur.push_back((uint8_t)((base[(lcg >> 60) & 3] << 4) | base[(lcg >> 58) & 3]));
+                        }
+                        for (uint32_t j = 0; j < qlen;) { // binned qualities in runs
+                            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                            const uint32_t run = 1u + (uint32_t)((lcg >> 40) % 24u);
+                            const uint8_t q = qbin[(lcg >> 62) & 3];
+                            for (uint32_t x = 0; x < run && j < qlen; ++x, ++j) cur.push_back(q);
+                        }
+                    }
+                }
+                if (!deflate_all(cur, level, ld, sl.out)) sl.bad = true;
+            }
+            if (ld) deflate_lib().cfree(ld);
+        };
         std::vector<std::thread> pool;
-        const int nt = (int)std::min<size_t>((size_t)n_threads, batch.size());
+        const int nt = (int)std::min<size_t>((size_t)n_threads, w1 - w0);
         for (int t = 1; t < nt; ++t) pool.emplace_back(work);
         work();
         for (auto &t : pool) t.join();
-        if (bad.load()) { rc = spl_set_error(SPL_ERR_IO, "deflate failed while writing %s", path); }
-        for (auto &b : batch) if (rc == SPL_OK && fwrite(b.comp.data(), 1, b.comp.size(), fh) != b.comp.size()) rc = spl_set_error(SPL_ERR_IO, "short write to %s", path);
-        batch.clear();
-    };
-    auto cut = [&](bool force) {
-        while (cur.size() >= BLOCK || (force && !cur.empty())) {
-            OutBlock b;
-            const size_t n = std::min(cur.size(), BLOCK);
-            b.raw.assign(cur.begin(), cur.begin() + n);
-            cur.erase(cur.begin(), cur.begin() + n);
-            batch.push_back(std::move(b));
-            if (batch.size() >= BATCH) flush_batch();
-        }
-    };
-    // header
-    std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
-    for (int i = 0; i < n_ref; ++i) text += std::string("@SQ\tSN:") + ref_names[i] + "\tLN:" + std::to_string((long long)ref_lengths[i]) + "\n";
-    cur.insert(cur.end(), {'B', 'A', 'M', 1});
-    put32(cur, (uint32_t)text.size());
-    cur.insert(cur.end(), text.begin(), text.end());
-    put32(cur, (uint32_t)n_ref);
-    for (int i = 0; i < n_ref; ++i) {
-        const size_t ln = strlen(ref_names[i]) + 1;
-        put32(cur, (uint32_t)ln);
-        cur.insert(cur.end(), ref_names[i], ref_names[i] + ln);
-        put32(cur, (uint32_t)ref_lengths[i]);
-    }
-    uint64_t serial = 0;
-    for (int tid = 0; tid < n_ref && rc == SPL_OK; ++tid) {
-        const spl_reads &r = per_ref[tid];
-        for (int64_t k = 0; k < r.n_reads && rc == SPL_OK; ++k) {
-            const uint32_t o0 = r.cig_off[k], n_ops = r.cig_off[k + 1] - o0;
-            uint32_t qlen = 0;
-            for (uint32_t j = 0; j < n_ops; ++j) { const uint32_t c = r.cigar[o0 + j] & 15u; if (c == 0 || c == 1 || c == 4 || c == 7 || c == 8) qlen += r.cigar[o0 + j] >> 4; }
-            char name[24];
-            const int l_name = snprintf(name, sizeof(name), "r%llu", (unsigned long long)serial++) + 1;
-            const uint32_t bs = 32 + (uint32_t)l_name + 4 * n_ops + (qlen + 1) / 2 + qlen;
-            put32(cur, bs);
-            put32(cur, (uint32_t)tid);
-            put32(cur, (uint32_t)(r.pos[k] - 1));
-            cur.push_back((uint8_t)l_name); cur.push_back(60);
-            put16(cur, 4680); put16(cur, n_ops); put16(cur, r.flag[k]);
-            put32(cur, qlen); put32(cur, 0xffffffffu); put32(cur, 0xffffffffu); put32(cur, 0);
-            cur.insert(cur.end(), name, name + l_name);
-            for (uint32_t j = 0; j < n_ops; ++j) put32(cur, r.cigar[o0 + j]);
-            cur.insert(cur.end(), (qlen + 1) / 2, (uint8_t)0x12);
-            cur.insert(cur.end(), qlen, (uint8_t)30);
-            if (cur.size() >= BLOCK) cut(false);
+        for (size_t i = w0; i < w1 && rc == SPL_OK; ++i) {
+            if (slices[i].bad) rc = spl_set_error(SPL_ERR_IO, "deflate failed while writing %s", path);
+            else if (fwrite(slices[i].out.data(), 1, slices[i].out.size(), fh) != slices[i].out.size()) rc = spl_set_error(SPL_ERR_IO, "short write to %s", path);
+            std::vector<uint8_t>().swap(slices[i].out);
         }
     }
-    cut(true);
-    if (!batch.empty()) flush_batch();
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (rc == SPL_OK && fwrite(eof, 1, 28, fh) != 28) rc = spl_set_error(SPL_ERR_IO, "short write to %s", path);
     fclose(fh);
     return rc;
+}
+
+extern "C" int spl_bam_write(const char *path, int n_ref, const char *const *ref_names, const int64_t *ref_lengths,
+                             const spl_reads *per_ref, int level, int n_threads)
+{
+    return spl_bam_write2(path, n_ref, ref_names, ref_lengths, per_ref, level, n_threads, 0);
 }

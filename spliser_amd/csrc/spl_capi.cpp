@@ -270,6 +270,16 @@ extern "C" int spl_sync(spl_ctx *c)
     return SPL_OK;
 }
 
+// Device-side barrier between passes: whatever is launched on this context after the call starts after everything launched
+// before it -- the tails of counting passes on the context's second stream included -- has finished.  The host does not wait.
+extern "C" int spl_pass_barrier(spl_ctx *c)
+{
+    if (!c) return spl_set_error(SPL_ERR_ARG, "spl_pass_barrier: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(join_tail(c));
+    return SPL_OK;
+}
+
 extern "C" int spl_timer_begin(spl_ctx *c)
 {
     if (!c) return spl_set_error(SPL_ERR_ARG, "spl_timer_begin: null context");

@@ -52,9 +52,13 @@ extern "C" int spl_gene_search(const int64_t *left, const int64_t *right, const 
 // One chromosome's rows appended to an open file: the same bytes spliser_amd/tsv.py formats -- "{0:.3f}" / "{0:.5f}" are
 // correctly rounded decimal conversions in CPython and in glibc's printf alike, str(dict) / str(list) of ints are
 // "{a: b, c: d}" / "[a, b]".  Strings come as one blob + offsets.
+#include <algorithm>
+#include <atomic>
 #include <cinttypes>
 #include <cstdio>
 #include <string>
+#include <thread>
+#include <vector>
 
 extern "C" int spl_tsv_append(const char *path, const char *chrom, int64_t n_sites, const int64_t *pos, const char *strand_blob,
                               const uint32_t *strand_off, const char *gene_blob, const uint32_t *gene_off, const double *sse,
@@ -68,38 +72,60 @@ extern "C" int spl_tsv_append(const char *path, const char *chrom, int64_t n_sit
         return spl_set_error(SPL_ERR_ARG, "spl_tsv_append: null array");
     FILE *f = fopen(path, "ab");
     if (!f) return spl_set_error(SPL_ERR_IO, "cannot open %s for appending", path);
-    std::string out;
-    out.reserve(1u << 20);
-    char num[64];
     const size_t chrom_len = strlen(chrom);
-    bool ok = true;
-    for (int64_t i = 0; i < n_sites && ok; ++i) {
-        out.append(chrom, chrom_len);
-        out.push_back('\t');
-        out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64, pos[i]));
-        out.push_back('\t');
-        out.append(strand_blob + strand_off[i], strand_off[i + 1] - strand_off[i]);
-        out.push_back('\t');
-        out.append(gene_blob + gene_off[i], gene_off[i + 1] - gene_off[i]);
-        out.push_back('\t');
-        out.append(num, (size_t)snprintf(num, sizeof num, "%.3f", sse[i]));
-        out.append(num, (size_t)snprintf(num, sizeof num, "\t%" PRId64 "\t%u\t%" PRId64 "\t", alpha[i], beta1[i], beta2_simple[i]));
-        if (cryptic) out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64 "\t%.5f", beta2_cryptic[i], beta2_weighted[i]));
-        else out.append("NA\tNA");
-        out.append("\t{");
-        for (uint32_t e = part_off[i]; e < part_off[i + 1]; ++e) {
-            if (e != part_off[i]) out.append(", ");
-            out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64 ": %" PRId64, part_pos[e], edge_cnt[e]));
+    // rows [a, b) as text
+    auto format = [&](int64_t a, int64_t b, std::string &out) {
+        char num[64];
+        out.reserve((size_t)(b - a) * 96);
+        for (int64_t i = a; i < b; ++i) {
+            out.append(chrom, chrom_len);
+            out.push_back('\t');
+            out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64, pos[i]));
+            out.push_back('\t');
+            out.append(strand_blob + strand_off[i], strand_off[i + 1] - strand_off[i]);
+            out.push_back('\t');
+            out.append(gene_blob + gene_off[i], gene_off[i + 1] - gene_off[i]);
+            out.push_back('\t');
+            out.append(num, (size_t)snprintf(num, sizeof num, "%.3f", sse[i]));
+            out.append(num, (size_t)snprintf(num, sizeof num, "\t%" PRId64 "\t%u\t%" PRId64 "\t", alpha[i], beta1[i], beta2_simple[i]));
+            if (cryptic) out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64 "\t%.5f", beta2_cryptic[i], beta2_weighted[i]));
+            else out.append("NA\tNA");
+            out.append("\t{");
+            for (uint32_t e = part_off[i]; e < part_off[i + 1]; ++e) {
+                if (e != part_off[i]) out.append(", ");
+                out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64 ": %" PRId64, part_pos[e], edge_cnt[e]));
+            }
+            out.append("}\t[");
+            for (uint32_t e = comp_off[i]; e < comp_off[i + 1]; ++e) {
+                if (e != comp_off[i]) out.append(", ");
+                out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64, comp_pos[e]));
+            }
+            out.append("]\n");
         }
-        out.append("}\t[");
-        for (uint32_t e = comp_off[i]; e < comp_off[i + 1]; ++e) {
-            if (e != comp_off[i]) out.append(", ");
-            out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64, comp_pos[e]));
-        }
-        out.append("]\n");
-        if (out.size() > (1u << 20) - 4096) { ok = fwrite(out.data(), 1, out.size(), f) == out.size(); out.clear(); }
+    };
+    // slices of rows formatted on a few threads (snprintf of a quarter of a million rows is 80 ms on one), written in order
+    const int64_t SLICE = 8192;
+    const size_t n_slices = (size_t)((n_sites + SLICE - 1) / SLICE);
+    std::vector<std::string> text(n_slices);
+    {
+        std::atomic<size_t> next(0);
+        auto work = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= n_slices) break;
+                format((int64_t)k * SLICE, std::min<int64_t>(n_sites, (int64_t)(k + 1) * SLICE), text[k]);
+            }
+        };
+        int nt = (int)std::thread::hardware_concurrency();
+        nt = nt > 16 ? 16 : (nt < 1 ? 1 : nt);
+        nt = (int)std::min<size_t>((size_t)nt, n_slices);
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
     }
-    if (ok && !out.empty()) ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    bool ok = true;
+    for (size_t k = 0; k < n_slices && ok; ++k) ok = fwrite(text[k].data(), 1, text[k].size(), f) == text[k].size();
     if (fclose(f) != 0) ok = false;
     return ok ? SPL_OK : spl_set_error(SPL_ERR_IO, "write error on %s", path);
 }

@@ -46,11 +46,11 @@ OPT_WAVE_AGGREGATION = 2
 
 EXPORTS = [
     "spl_abi_version", "spl_last_error", "spl_device_count", "spl_create", "spl_create_on_stream", "spl_destroy",
-    "spl_sync", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
+    "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
-    "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write",
+    "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
     "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append",
 ]
 
@@ -240,6 +240,10 @@ class Context(object):
     def sync(self):
         _check(lib().spl_sync(self._h))
 
+    def pass_barrier(self):
+        """Later launches start after all earlier ones (tails of counting passes included) are done; the host does not wait."""
+        _check(lib().spl_pass_barrier(self._h))
+
     def timer_begin(self):
         _check(lib().spl_timer_begin(self._h))
 
@@ -393,8 +397,9 @@ def tsv_append(path, arr, res, cryptic):
                                 _ptr(edge_cnt), _ptr(comp_off), _ptr(comp_pos)))
 
 
-def write_bam(path, ref_names, ref_lengths, read_sets, level=1, threads=0):
-    """Fast native BAM writer for synthetic workloads: read_sets[i] = samio.ReadSet of reference i."""
+def write_bam(path, ref_names, ref_lengths, read_sets, level=1, threads=0, seq_mode=0):
+    """Fast native BAM writer for synthetic workloads: read_sets[i] = samio.ReadSet of reference i.  ``seq_mode`` 0: constant
+    SEQ / QUAL bytes (deflates to a few bytes per record); 1: pseudo-random bases, binned qualities (deflates ~4x)."""
     n = len(ref_names)
     names = (ctypes.c_char_p * n)(*[s.encode("ascii") for s in ref_names])
     lens = (ctypes.c_int64 * n)(*[int(v) for v in ref_lengths])
@@ -404,7 +409,8 @@ def write_bam(path, ref_names, ref_lengths, read_sets, level=1, threads=0):
         ra = ReadArrays(rs.pos, rs.flag, rs.cig_off, rs.cigar)
         keep.append(ra)
         arr[i] = ra.c
-    _check(lib().spl_bam_write(os.fsencode(path), ctypes.c_int(n), names, lens, arr, ctypes.c_int(level), ctypes.c_int(threads)))
+    _check(lib().spl_bam_write2(os.fsencode(path), ctypes.c_int(n), names, lens, arr, ctypes.c_int(level), ctypes.c_int(threads),
+                                ctypes.c_int(seq_mode)))
 
 
 class BamFile(object):

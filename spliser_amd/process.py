@@ -33,20 +33,30 @@ class _SamSource(object):
         return self._sets.get(chrom)
 
 
-def open_alignments(path, threads=0):
-    """BAM (BGZF) through the native decoder; plain SAM text through the Python reader."""
+def open_alignments(path, threads=0, stream=False):
+    """BAM (BGZF) through the native decoder; plain SAM text through the Python reader.  ``stream=True``: the BAM decoder
+    returns after the header and decodes in the background (``native.BamFile``)."""
     with open(path, "rb") as fh:
         magic = fh.read(4)
     if magic[:2] == b"\x1f\x8b":
-        return native.BamFile(path, threads=threads)
+        return native.BamFile(path, threads=threads, stream=stream)
     if magic[:1] == b"@" or b"\t" in open(path, "rb").readline():
         return _SamSource(path)
     raise native.SpliserNativeError(-5, "%s is neither BGZF/BAM nor SAM text" % path)
 
 
+class _Replan(Exception):
+    """A read reaches beyond the room its chromosome was given in the shard (planned from the BAM header)."""
+
+
 def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_cryptic, devices=(0,), combine_mode=0,
-                  log=_log, timings=None):
-    """processSites (SpliSER_v0_1_8.py:681-692) for every chromosome at once.
+                  log=_log, timings=None, on_result=None):
+    """processSites (SpliSER_v0_1_8.py:681-692) for every chromosome.
+
+    One thread and one context per device; the chromosomes of a device share ONE site table in one coordinate space
+    (``shard.pack``) and are counted one after the other AS THEIR READS BECOME AVAILABLE: with a BAM file that is still being
+    decoded a chromosome's reads go to the GPU (packed by the host, through the page-locked staging ring) as soon as the decoder
+    has seen the first record of the next one, and its results are handed to ``on_result`` while later chromosomes decode.
 
     -> {chrom: (ChromArrays, results dict)} with results keys beta1, beta2_simple, beta2_cryptic,
     beta2_weighted, sse (numpy arrays in table row order).
@@ -54,6 +64,7 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
     stranded = native.STRANDED_CODE[stranded_type] if is_stranded else 0
     if is_stranded and stranded == 0:
         raise ValueError("strandedType must be 'fr' or 'rf' for a stranded analysis")
+    is_bam = isinstance(source, native.BamFile)
     items = {}
     for chrom in table.chrom_index:
         log("Processing region " + str(chrom))
@@ -62,11 +73,18 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
         arr = table.chrom_arrays(chrom)
         if arr.n == 0:
             continue
-        reads = source.reads(chrom)
-        if reads is None:
+        if is_bam:
+            reads = None
+            present = chrom in source._tid
+        else:
+            reads = source.reads(chrom)
+            present = reads is not None
+        if not present:
             log("  (no reference named %s in the alignment file: all beta counts are 0)" % chrom)
-        items[chrom] = (arr, reads)
-    weights = {c: (r.n if r is not None else 0) + a.n for c, (a, r) in items.items()}
+        items[chrom] = (arr, reads, present)
+    # Which device takes which chromosome is decided before the reads are known (they may still be on their way): the junction
+    # read counts of the BED file say where the spliced reads are.
+    weights = {c: (r.n if r is not None else int(a.alpha.sum())) + a.n for c, (a, r, _) in items.items()}
     plan = shard.assign(weights, len(devices))
     out, errors = {}, []
     lock = threading.Lock()
@@ -77,32 +95,54 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                 return
             t0 = time.perf_counter()
             order = [c for c in table.chrom_index if c in chroms]
-            shards = shard.pack([(c, items[c][0], items[c][1]) for c in order], concat_reads=False)
-            t1 = time.perf_counter()
-            with native.Context(device) as ctx:
-                for sh in shards:
-                    ds = ctx.upload_sites(sh.sites)
-                    dr = ctx.upload_read_segments(sh.read_segments)  # straight from the decoder's buffers
-                    ctx.count_launch(ds, dr, stranded, combine_mode)
-                    ctx.sse_launch(ds, is_beta2_cryptic)
-                    beta1, _, _ = ds.counters()
-                    b2s, b2c, b2w, sse = ds.sse_results()
-                    dr.free()
-                    ds.free()
-                    with lock:
-                        for chrom, (r0, r1) in zip(sh.chroms, sh.site_rows):
-                            out[chrom] = (items[chrom][0], dict(beta1=beta1[r0:r1], beta2_simple=b2s[r0:r1],
-                                                                beta2_cryptic=b2c[r0:r1], beta2_weighted=b2w[r0:r1],
-                                                                sse=sse[r0:r1]))
+            if is_bam:      # the order of the file: a chromosome is complete when the next one begins
+                order.sort(key=lambda c: source._tid.get(c, 1 << 30))
+            for exact in ((False, True) if is_bam else (True,)):
+                extents = None
+                if is_bam and not exact:    # room by the header's reference lengths
+                    extents = {c: (1, source.ref_lengths[source._tid[c]]) for c in order if c in source._tid}
+                elif is_bam:                # ... or, should a read reach beyond that, by what the decoder has seen (whole file)
+                    source.wait_all()
+                    extents = {c: (1, max(1, source.wait_ref(c)[1])) for c in order if c in source._tid}
+                shards = shard.pack([(c, items[c][0], items[c][1]) for c in order], concat_reads=False, extents=extents)
+                try:
+                    _count_shards(device, shards)
+                    break
+                except _Replan:
+                    if exact:
+                        raise
             if timings is not None:
                 with lock:
-                    timings.setdefault("pack_s", 0.0)
-                    timings["pack_s"] += t1 - t0
-                    timings.setdefault("gpu_s", 0.0)
-                    timings["gpu_s"] += time.perf_counter() - t1
+                    timings["gpu_s"] = timings.get("gpu_s", 0.0) + time.perf_counter() - t0
         except Exception as exc:  # surfaced after join
             with lock:
                 errors.append(exc)
+
+    def _count_shards(device, shards):
+        with native.Context(device) as ctx:
+            for sh in shards:
+                with ctx.upload_sites(sh.sites) as ds:
+                    for chrom, off, limit, (r0, r1) in zip(sh.chroms, sh.offsets, sh.limits, sh.site_rows):
+                        with ctx.begin_reads() as dr:
+                            if is_bam and items[chrom][2]:
+                                _, max_end = source.wait_ref(chrom)
+                                if max_end > limit:
+                                    raise _Replan()
+                                dr.add_bam(source, chrom, off)
+                            elif items[chrom][1] is not None and items[chrom][1].n:
+                                rs = items[chrom][1]
+                                dr.add(native.ReadArrays(rs.pos, rs.flag, rs.cig_off, rs.cigar), off)
+                            dr.finish()
+                            ctx.count_launch(ds, dr, stranded, combine_mode)
+                            ctx.sse_launch(ds, is_beta2_cryptic)
+                            beta1, _, _ = ds.counters()
+                            b2s, b2c, b2w, sse = ds.sse_results()
+                        res = dict(beta1=beta1[r0:r1].copy(), beta2_simple=b2s[r0:r1].copy(), beta2_cryptic=b2c[r0:r1].copy(),
+                                   beta2_weighted=b2w[r0:r1].copy(), sse=sse[r0:r1].copy())
+                        with lock:
+                            out[chrom] = (items[chrom][0], res)
+                        if on_result is not None:
+                            on_result(chrom, items[chrom][0], res)
 
     threads = [threading.Thread(target=run, args=(dev, chroms)) for dev, chroms in zip(devices, plan)]
     for t in threads:
@@ -114,16 +154,54 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
     return out
 
 
+class _TsvWriter(object):
+    """outputBedFile (SpliSER_v0_1_8.py:641-664) while Step 3 is still running: chromosomes arrive in any order (one device
+    thread each, the order of the BAM file), the file gets them in the table's order; the rows are formatted by the native
+    library (tsv.format_chrom is the Python statement of the same format and what the CPU tests compare it with)."""
+
+    def __init__(self, output_path, table, cryptic):
+        self.path = output_path + ".SpliSER.tsv"
+        self.order = list(table.chrom_index)
+        self.cryptic = cryptic
+        self.ready = {}
+        self.next = 0
+        self.lock = threading.Lock()
+        self.seconds = 0.0
+        with open(self.path, "w") as fh:
+            fh.write(tsv.HEADER)
+
+    def add(self, chrom, arr, res):
+        with self.lock:      # (one writer at a time: the file is appended to in order)
+            self.ready[chrom] = (arr, res)
+            self._drain(final=False)
+
+    def _drain(self, final):
+        t = time.perf_counter()
+        while self.next < len(self.order):
+            chrom = self.order[self.next]
+            if chrom in self.ready:
+                arr, res = self.ready.pop(chrom)
+                native.tsv_append(self.path, arr, res, self.cryptic)
+            elif not final:
+                break
+            self.next += 1
+        self.seconds += time.perf_counter() - t
+
+    def close(self, expected):
+        """Chromosomes that never got a result (no sites, other -c) are skipped; everything in ``expected`` must be there."""
+        with self.lock:
+            missing = [c for c in expected if c not in self.ready and self.order.index(c) >= self.next]
+            if missing:
+                raise RuntimeError("no results for %s" % missing)
+            self._drain(final=True)
+
+
 def write_tsv(output_path, table, results, is_beta2_cryptic):
-    """outputBedFile (SpliSER_v0_1_8.py:641-664); the rows are formatted by the native library (tsv.format_chrom is the
-    Python statement of the same format and what the CPU tests compare it with)."""
-    path = output_path + ".SpliSER.tsv"
-    with open(path, "w") as fh:
-        fh.write(tsv.HEADER)
-    for chrom in table.chrom_index:
-        if chrom in results:
-            arr, res = results[chrom]
-            native.tsv_append(path, arr, res, is_beta2_cryptic)
+    """outputBedFile for a finished result set."""
+    w = _TsvWriter(output_path, table, is_beta2_cryptic)
+    for chrom, (arr, res) in results.items():
+        w.ready[chrom] = (arr, res)
+    w.close(list(results))
 
 
 def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0, annotationFile=None, aType="gene",
@@ -131,39 +209,35 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
     """SpliSER_v0_1_8.py:695-720, keyword-compatible with the reference's argparse dests."""
     timings = {}
     t0 = time.perf_counter()
-    # The alignment file does not depend on Steps 0-2: it is decoded on native threads (GIL released) while the site table
-    # is built here.  Its outcome -- reads or an error -- is picked up where the reference's Step 3 begins.
-    opened = {}
-
-    def _open():
-        t = time.perf_counter()
-        try:
-            opened["source"] = open_alignments(inBAM, threads=threads)
-        except BaseException as exc:  # re-raised on the main thread below
-            opened["error"] = exc
-        opened["seconds"] = time.perf_counter() - t
-    opener = threading.Thread(target=_open, name="spliser-bam-decode")
-    opener.start()
+    # The alignment file does not depend on Steps 0-2: it is decoded on native threads while the site table is built here, and
+    # goes on decoding while Step 3 counts the chromosomes that are complete.  An unreadable file is an error here already
+    # (block directory and header are read by the opening call).
+    source = open_alignments(inBAM, threads=threads, stream=True)
     try:
+        t_open = time.perf_counter()
         table = _site_table(inBed, qGene, qChrom, maxIntronSize, annotationFile, aType, isStranded, strandedType, log)
-    except BaseException:
-        opener.join()
-        raise
-    t1 = time.perf_counter()
-    log("\n\nStep 3: Finding Beta reads")
-    log("Processing sample 1 out of 1")
-    opener.join()
-    if "error" in opened:
-        raise opened["error"]
-    source = opened["source"]
-    t2 = time.perf_counter()
-    results = process_sites(table, source, qChrom, isStranded, strandedType, isbeta2Cryptic, devices=devices, log=log,
-                            timings=timings)
-    t3 = time.perf_counter()
-    log("\nOutputting .tsv file")
-    write_tsv(outputPath, table, results, isbeta2Cryptic)
-    t4 = time.perf_counter()
-    timings.update(site_table_s=t1 - t0, decode_s=opened["seconds"], decode_wait_s=t2 - t1, step3_s=t3 - t2, write_s=t4 - t3)
+        t1 = time.perf_counter()
+        log("\n\nStep 3: Finding Beta reads")
+        log("Processing sample 1 out of 1")
+        writer = _TsvWriter(outputPath, table, isbeta2Cryptic)
+        results = process_sites(table, source, qChrom, isStranded, strandedType, isbeta2Cryptic, devices=devices, log=log,
+                                timings=timings, on_result=writer.add)
+        if isinstance(source, native.BamFile) and not source.wait_all():
+            # records of an earlier reference after a later one: chromosomes were counted before they were complete.  (samtools
+            # cannot index such a file, the reference could not have processed it at all.)  Everything is decoded by now: again.
+            log("  (the alignment file is not sorted by reference: counting again from the complete decode)")
+            writer = _TsvWriter(outputPath, table, isbeta2Cryptic)
+            results = process_sites(table, source, qChrom, isStranded, strandedType, isbeta2Cryptic, devices=devices, log=lambda m: None,
+                                    timings=timings, on_result=writer.add)
+        t3 = time.perf_counter()
+        log("\nOutputting .tsv file")
+        writer.close(list(results))
+        t4 = time.perf_counter()
+    finally:
+        if hasattr(source, "close"):
+            source.close()
+    timings.update(open_s=t_open - t0, site_table_s=t1 - t_open, step3_s=t3 - t1, write_tail_s=t4 - t3, write_s=writer.seconds,
+                   total_s=t4 - t0)
     return timings
 
 

@@ -38,6 +38,7 @@ class Shard(object):
     def __init__(self):
         self.chroms = []       # chromosome names, in packing order
         self.offsets = []      # coordinate shift per chromosome
+        self.limits = []       # largest coordinate (unshifted) the chromosome's slot has room for
         self.site_rows = []    # (row_begin, row_end) per chromosome in the packed table
         self.edge_rows = []    # (edge_begin, edge_end) per chromosome in the packed partner CSR
         self.sites = None      # native.SiteArrays
@@ -56,22 +57,28 @@ def _extent(arr, reads):
     return lo, hi
 
 
-def pack(items, concat_reads=True):
+def pack(items, concat_reads=True, extents=None):
     """items: list of (chrom, ChromArrays, ReadSet-or-None).  -> list of Shard (usually one).
 
     ``concat_reads=False`` skips building the shard-wide read arrays on the host: the per-chromosome arrays stay where they
-    are (e.g. in the BAM decoder's buffers) and ``read_segments`` tells the device where to put them."""
+    are (e.g. in the BAM decoder's buffers) and ``read_segments`` tells the device where to put them.
+
+    ``extents``: {chrom: (lo, hi)} coordinate range to reserve for a chromosome whose reads are not known yet (a BAM file
+    still being decoded: the caller plans with the reference length of the header and checks the reads against it when
+    they arrive); the sites are always looked at."""
     shards, cur, cursor = [], [], 0
     groups = []
     for chrom, arr, reads in items:
         lo, hi = _extent(arr, reads)
+        if extents is not None and chrom in extents:
+            lo, hi = min(lo, int(extents[chrom][0])), max(hi, int(extents[chrom][1]))
         span = hi - lo + 1 + GAP
         if span > COORD_MAX:
             raise native.SpliserNativeError(-6, "chromosome %s spans more than the int32 coordinate space" % chrom)
         if cur and cursor + span > COORD_MAX:
             groups.append(cur)
             cur, cursor = [], 0
-        cur.append((chrom, arr, reads, cursor - lo + 1))
+        cur.append((chrom, arr, reads, cursor - lo + 1, hi))
         cursor += span
     if cur:
         groups.append(cur)
@@ -81,9 +88,10 @@ def pack(items, concat_reads=True):
         part_deg, comp_deg = [], []
         r_pos, r_flag, r_ops, r_nops = [], [], [], []
         row = edge = 0
-        for chrom, arr, reads, off in group:
+        for chrom, arr, reads, off, hi in group:
             sh.chroms.append(chrom)
             sh.offsets.append(off)
+            sh.limits.append(hi)
             sh.site_rows.append((row, row + arr.n))
             n_edge = int(arr.part_off[-1]) if arr.n else 0
             sh.edge_rows.append((edge, edge + n_edge))

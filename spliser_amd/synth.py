@@ -29,7 +29,7 @@ WORKLOADS = {
     # name: chroms, genes, reads, intron (median, min, max), exons mean, seed, paired/stranded flags
     "single_gene": dict(chroms=[("Chr1", 200000)], n_genes=12, n_reads=2000, intron=(100, 70, 6000), seed=1),
     "arabidopsis": dict(chroms=ARABIDOPSIS, n_genes=27000, n_reads=20_000_000, intron=(100, 70, 6000), seed=2),
-    "human": dict(chroms=HG38, n_genes=30000, n_reads=200_000_000, intron=(1500, 70, 500000), seed=3),
+    "human": dict(chroms=HG38, n_genes=36500, n_reads=200_000_000, intron=(1500, 70, 500000), seed=3),
     "mouse_stranded": dict(chroms=MM39, n_genes=28000, n_reads=100_000_000, intron=(1200, 70, 400000), seed=5, paired=True),
 }
 
