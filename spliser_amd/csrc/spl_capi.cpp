@@ -95,7 +95,6 @@ struct spl_dsites {
     uint32_t n_buckets = 0;
     int32_t bucket_base = 0, bucket_shift = 0;
     bool has_sse_inputs = false;
-    bool mutual_links = false; // every partner edge has its reverse edge: the range kernel is applicable
     int32_t *diff = nullptr;   // 4 difference arrays of diff_stride int32 over distinct positions (range kernel)
     int32_t *block_sums = nullptr;
     int32_t diff_stride = 0, scan_blocks = 0;
@@ -105,9 +104,7 @@ struct spl_dsites {
     uint32_t *drival = nullptr; // per bucket: positions that are sites with rivals
     uint32_t n_dbuckets = 0;
     int32_t dbase = 0;         // coordinate of the first (empty) bucket
-    uint32_t *rival_bits = nullptr;
-    uint32_t *ucl_off = nullptr; // per distinct position: competitor positions of the partners of its rows (flagged rows only)
-    int32_t *ucl_pos = nullptr;
+    int32_t *flag_pos = nullptr; // ends of the junctions that have rivals (sorted; input of the bucket build)
     uint4 *jhash = nullptr;    // junction table (see build_junction_table)
     uint32_t jhash_mask = 0;
     uint4 *jrivals = nullptr;
@@ -344,102 +341,96 @@ static int validate_sites(const spl_sites *s)
     return SPL_OK;
 }
 
-// Junction table for the range kernel: every BED junction (l, r) -- a partner edge of the table -- with a flagged end,
-// mapped to the sites t for which checkBam's compSplicing test (SpliSER_v0_1_8.py:494-501) succeeds given that
-// junction alone:  (l in P_t and r in C_t) or (r in P_t and l in C_t), evaluated literally on the table's own lists.
-// Candidates are the partners of the rows at l and at r (partner links are mutual).  Open-addressing hash on (l, r).
+// Junction table: every junction (l, r) that can make checkBam's compSplicing test (SpliSER_v0_1_8.py:494-501) succeed for
+// SOME site of the table, with the sites ("rivals") it succeeds for.  The test for site t given a read junction (l, r) is
+//     (l in P_t and r in C_t) or (r in P_t and l in C_t)        P_t = partner positions, C_t = competitor positions of t
+// so the junctions are exactly the pairs (p, c), p in P_t, c in C_t, smaller coordinate first -- enumerated here from each
+// row's own lists.  Nothing else about the table is assumed (partner links need not be mutual, partners and competitors need
+// not be rows: the query tables of `combine` qualify), and the table is COMPLETE: a read junction that is not in it has no
+// rival anywhere.  The ends of the table's junctions are the "flagged" positions (a bit per position next to the position
+// index, see spl_build_dbuckets_kernel): only a read junction with a flagged end is ever looked up.
+// Open-addressing hash on (l, r), at most 8 probes; the table grows until every junction is placed.
 static void build_junction_table(const spl_sites *s, const std::vector<uint8_t> &flags, const std::vector<int32_t> &dfirst,
-                                 const std::vector<int32_t> &row_dpos, std::vector<uint4> &jhash, std::vector<uint4> &jrivals)
+                                 const std::vector<int32_t> &row_dpos, std::vector<uint4> &jhash, std::vector<uint4> &jrivals,
+                                 std::vector<int32_t> &flag_pos)
 {
     const int64_t S = s->n_sites;
-    auto in_list = [](const int32_t *list, uint32_t a, uint32_t b, int32_t v) { for (uint32_t i = a; i < b; ++i) if (list[i] == v) return true; return false; };
-    auto rows_at = [&](int32_t row, int32_t &r0, int32_t &r1) { const int32_t d = row_dpos[(size_t)row]; r0 = dfirst[(size_t)d]; r1 = dfirst[(size_t)d + 1]; };
+    struct Trip { int32_t l, r, t; };
+    std::vector<Trip> trips;
+    for (int64_t t = 0; t < S; ++t) {
+        const uint32_t pa = s->part_off[t], pb = s->part_off[t + 1], ca = s->comp_off[t], cb = s->comp_off[t + 1];
+        for (uint32_t e = pa; e < pb; ++e)
+            for (uint32_t f = ca; f < cb; ++f) {
+                const int32_t p = s->part_pos[e], c = s->comp_pos[f];
+                trips.push_back(p <= c ? Trip{p, c, (int32_t)t} : Trip{c, p, (int32_t)t});
+            }
+    }
+    std::sort(trips.begin(), trips.end(), [](const Trip &a, const Trip &b) { return a.l != b.l ? a.l < b.l : (a.r != b.r ? a.r < b.r : a.t < b.t); });
+    trips.erase(std::unique(trips.begin(), trips.end(), [](const Trip &a, const Trip &b) { return a.l == b.l && a.r == b.r && a.t == b.t; }), trips.end());
     struct Junc { int32_t l, r; uint32_t off, info; };
     std::vector<Junc> juncs;
-    for (int64_t a = 0; a < S; ++a) {
-        const int32_t l = s->pos[a];
-        for (uint32_t e = s->part_off[a]; e < s->part_off[a + 1]; ++e) {
-            const int32_t q = s->part_site[e];
-            const int32_t r = s->part_pos[e];
-            if (q < 0 || !(l < r)) continue; // every junction is seen from both ends: keep the (left, right) view
-            int32_t l0, l1, r0, r1;
-            rows_at((int32_t)a, l0, l1);
-            rows_at(q, r0, r1);
-            bool flagged = false;
-            for (int32_t x = l0; x < l1; ++x) flagged |= (flags[(size_t)x] & SPL_SF_RIVALS) != 0;
-            for (int32_t x = r0; x < r1; ++x) flagged |= (flags[(size_t)x] & SPL_SF_RIVALS) != 0;
-            if (!flagged) continue;
-            bool seen = false; // the same junction listed by an earlier row at l (other strand, duplicate edge)
-            for (int32_t x = l0; x < l1 && !seen; ++x)
-                for (uint32_t e2 = s->part_off[x]; e2 < s->part_off[x + 1]; ++e2)
-                    if (s->part_pos[e2] == r && ((int64_t)x < a || ((int64_t)x == a && e2 < e))) { seen = true; break; }
-            if (seen) continue;
-            Junc j;
-            j.l = l; j.r = r; j.off = (uint32_t)(jrivals.size() / 2); j.info = 0;
-            std::vector<int32_t> done;
-            for (int side = 0; side < 2; ++side) {
-                const int32_t x0 = side ? r0 : l0, x1 = side ? r1 : l1;
-                for (int32_t x = x0; x < x1; ++x)
-                    for (uint32_t e2 = s->part_off[x]; e2 < s->part_off[x + 1]; ++e2) {
-                        const int32_t t = s->part_site[e2];
-                        if (t < 0 || std::find(done.begin(), done.end(), t) != done.end()) continue;
-                        done.push_back(t);
-                        const uint32_t pa = s->part_off[t], pb = s->part_off[t + 1], ca = s->comp_off[t], cb = s->comp_off[t + 1];
-                        const bool comp = (in_list(s->part_pos, pa, pb, l) && in_list(s->comp_pos, ca, cb, r)) ||
-                                          (in_list(s->part_pos, pa, pb, r) && in_list(s->comp_pos, ca, cb, l));
-                        if (!comp) continue;
-                        const int32_t tpos = s->pos[t];
-                        if (tpos == l || tpos == r) j.info |= SPL_JF_COMPLEX; // alpha read with compSplicing: literal
-                        int32_t t0, t1;
-                        rows_at(t, t0, t1);
-                        if (t1 - t0 > 1) {
-                            j.info |= SPL_JF_MULTIROW;
-                            for (int32_t y = t0; y < t1; ++y)
-                                if (y != t && (flags[(size_t)y] & 3u) == (flags[(size_t)t] & 3u)) j.info |= SPL_JF_COMPLEX;
-                        }
-                        uint32_t edges[2] = {0xffffffffu, 0xffffffffu};
-                        int ne = 0;
-                        for (uint32_t e3 = pa; e3 < pb; ++e3)
-                            if (s->part_pos[e3] == l || s->part_pos[e3] == r) { if (ne < 2) edges[ne] = e3; ++ne; }
-                        if (ne > 2) j.info |= SPL_JF_COMPLEX;
-                        const uint32_t scode = (flags[(size_t)t] & SPL_SF_PLUS) ? 1u : ((flags[(size_t)t] & SPL_SF_MINUS) ? 2u : 0u);
-                        jrivals.push_back(make_uint4((uint32_t)tpos, (uint32_t)row_dpos[(size_t)t] | (scode << 30), edges[0], edges[1]));
-                        jrivals.push_back(make_uint4((uint32_t)t, pa, pb - pa, 0u));
-                    }
+    for (size_t i = 0; i < trips.size();) {
+        size_t k = i;
+        while (k < trips.size() && trips[k].l == trips[i].l && trips[k].r == trips[i].r) ++k;
+        Junc j;
+        j.l = trips[i].l; j.r = trips[i].r; j.off = (uint32_t)(jrivals.size() / 2); j.info = 0;
+        for (size_t x = i; x < k; ++x) {
+            const int32_t t = trips[x].t;
+            const uint32_t pa = s->part_off[t], pb = s->part_off[t + 1];
+            const int32_t tpos = s->pos[t];
+            if (tpos == j.l || tpos == j.r) j.info |= SPL_JF_COMPLEX; // alpha read with compSplicing: literal
+            const int32_t d = row_dpos[(size_t)t], t0 = dfirst[(size_t)d], t1 = dfirst[(size_t)d + 1];
+            if (t1 - t0 > 1) {
+                j.info |= SPL_JF_MULTIROW;
+                for (int32_t y = t0; y < t1; ++y)
+                    if (y != t && (flags[(size_t)y] & 3u) == (flags[(size_t)t] & 3u)) j.info |= SPL_JF_COMPLEX;
             }
-            const uint32_t n = (uint32_t)(jrivals.size() / 2) - j.off;
-            if (n > 255u) { j.info |= SPL_JF_COMPLEX; }
-            j.info |= (n > 255u ? 255u : n);
-            juncs.push_back(j);
+            uint32_t edges[2] = {0xffffffffu, 0xffffffffu};
+            int ne = 0;
+            for (uint32_t e3 = pa; e3 < pb; ++e3)
+                if (s->part_pos[e3] == j.l || s->part_pos[e3] == j.r) { if (ne < 2) edges[ne] = e3; ++ne; }
+            if (ne > 2) j.info |= SPL_JF_COMPLEX;
+            const uint32_t scode = (flags[(size_t)t] & SPL_SF_PLUS) ? 1u : ((flags[(size_t)t] & SPL_SF_MINUS) ? 2u : 0u);
+            jrivals.push_back(make_uint4((uint32_t)tpos, (uint32_t)d | (scode << 30), edges[0], edges[1]));
+            jrivals.push_back(make_uint4((uint32_t)t, pa, pb - pa, 0u));
         }
+        const size_t n = k - i;
+        j.info |= (uint32_t)std::min<size_t>(n, SPL_JF_COUNT_MASK);
+        if (n > SPL_JF_COUNT_MASK) j.info |= SPL_JF_COMPLEX; // (cannot happen below 16 M rivals of one junction; the literal path would stop short)
+        juncs.push_back(j);
+        flag_pos.push_back(j.l);
+        flag_pos.push_back(j.r);
+        i = k;
     }
-    size_t cap = 16;
-    while (cap < 4 * juncs.size() + 1) cap <<= 1; // load <= 1/4: at 1/2 one junction in a hundred missed its 8 probes and its reads paid the literal walk
+    std::sort(flag_pos.begin(), flag_pos.end());
+    flag_pos.erase(std::unique(flag_pos.begin(), flag_pos.end()), flag_pos.end());
     // a slot is two quads: {l, r, first rival record, count | flags} and a copy of the first rival's first quad, so that
     // the common one-rival junction costs the range kernel one memory trip instead of two
-    jhash.assign(2 * cap, make_uint4(0x80000000u, 0, 0, 0));
-    size_t dropped = 0;
-    for (const Junc &j : juncs) {
-        uint32_t h = (uint32_t)j.l * 0x9E3779B1u ^ (uint32_t)j.r * 0x85EBCA77u;
-        h ^= h >> 15;
-        bool placed = false;
-        // the kernel gives up after 8 probes: an entry that cannot be placed within 8 is simply left out (-> literal kernel)
-        for (uint32_t probe = 0; probe < 8; ++probe) {
-            uint4 *slot = &jhash[2 * ((h + probe) & (cap - 1))];
-            if (slot[0].x == 0x80000000u) {
+    size_t cap = 16;
+    while (cap < 4 * juncs.size() + 1) cap <<= 1; // load <= 1/4
+    for (;; cap <<= 1) {
+        jhash.assign(2 * cap, make_uint4(0x80000000u, 0, 0, 0));
+        bool all = true;
+        for (const Junc &j : juncs) {
+            uint32_t h = (uint32_t)j.l * 0x9E3779B1u ^ (uint32_t)j.r * 0x85EBCA77u;
+            h ^= h >> 15;
+            bool placed = false;
+            for (uint32_t probe = 0; probe < 8 && !placed; ++probe) { // (the kernels give up after 8 probes)
+                uint4 *slot = &jhash[2 * ((h + probe) & (cap - 1))];
+                if (slot[0].x != 0x80000000u) continue;
                 slot[0] = make_uint4((uint32_t)j.l, (uint32_t)j.r, j.off, j.info);
-                slot[1] = (j.info & 0xffu) ? jrivals[2 * (size_t)j.off] : make_uint4(0, 0, 0xffffffffu, 0xffffffffu);
+                slot[1] = jrivals[2 * (size_t)j.off];
                 placed = true;
-                break;
             }
+            if (!placed) { all = false; break; }
         }
-        if (!placed) ++dropped;
+        if (all) break; // (otherwise: the table must be complete -- twice the slots and again)
     }
     if (getenv("SPL_DEBUG_TABLE")) {
         size_t complex = 0, multirow = 0, many = 0;
-        for (const Junc &j : juncs) { complex += (j.info & SPL_JF_COMPLEX) != 0; multirow += (j.info & SPL_JF_MULTIROW) != 0; many += (j.info & 0xffu) > 4; }
-        fprintf(stderr, "[junction table] %zu junctions with a flagged end, %zu slots, %zu not placed within 8 probes, %zu complex, %zu multirow, %zu with > 4 rivals\n",
-                juncs.size(), cap, dropped, complex, multirow, many);
+        for (const Junc &j : juncs) { complex += (j.info & SPL_JF_COMPLEX) != 0; multirow += (j.info & SPL_JF_MULTIROW) != 0; many += (j.info & SPL_JF_COUNT_MASK) > 4; }
+        fprintf(stderr, "[junction table] %zu junctions with rivals (%zu flagged positions), %zu slots, %zu complex, %zu multirow, %zu with > 4 rivals\n",
+                juncs.size(), flag_pos.size(), cap, complex, multirow, many);
     }
     if (jrivals.empty()) jrivals.assign(2, make_uint4(0, 0, 0xffffffffu, 0xffffffffu));
 }
@@ -483,79 +474,34 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
         meta[(size_t)i] = make_uint4(s->part_off[i], np, s->comp_off[i], s->comp_off[i + 1] - s->comp_off[i]);
         flags[(size_t)i] = (uint8_t)((s->strand[i] == '+' ? SPL_SF_PLUS : 0u) | (s->strand[i] == '-' ? SPL_SF_MINUS : 0u));
     }
-    // The range kernel finds the sites whose outcome depends on their own partner / competitor lists by walking
-    // the partner edges of the rows at a read's junction ends; that needs every edge s -> p to exist as p -> s
-    // (true for tables built like findAlphaCounts does, SpliSER_v0_1_8.py:352-355).  Otherwise: pair kernel.
-    d->mutual_links = s->part_site != nullptr || P == 0;
-    for (int64_t i = 0; i < S && d->mutual_links; ++i) {
-        for (uint32_t e = s->part_off[i]; e < s->part_off[i + 1] && d->mutual_links; ++e) {
-            const int32_t q = s->part_site[e];
-            bool ok = q >= 0 && q < S && s->pos[q] == s->part_pos[e];
-            if (ok) {
-                ok = false;
-                for (uint32_t f = s->part_off[q]; f < s->part_off[q + 1]; ++f) ok |= (s->part_site[f] == (int32_t)i);
-            }
-            if (!ok) d->mutual_links = false;
-        }
-    }
-    // SPL_SF_RIVALS: a partner of this row has competitors, i.e. for a read whose junction ends on this row there
-    // may be sites whose compSplicing test (:494-501) can succeed.  Rows without the flag keep reads on the fast path.
-    if (d->mutual_links && s->part_site)
-        for (int64_t i = 0; i < S; ++i)
-            for (uint32_t e = s->part_off[i]; e < s->part_off[i + 1]; ++e) {
-                const int32_t q = s->part_site[e];
-                if (s->comp_off[q + 1] != s->comp_off[q]) { flags[(size_t)i] |= SPL_SF_RIVALS; break; }
-            }
-    // distinct positions ("dpos"), their 64 bp occupancy buckets and the rival bitmap
+    // distinct positions ("dpos"): rows sharing a position share one index
     std::vector<int32_t> dfirst;
-    std::vector<uint32_t> rbits;
     for (int64_t i = 0; i < S; ++i)
         if (i == 0 || s->pos[i] != s->pos[i - 1]) dfirst.push_back((int32_t)i);
     const int64_t D = (int64_t)dfirst.size();
     dfirst.push_back((int32_t)S);
     d->n_dpos = (int32_t)D;
-    rbits.assign((size_t)(D + 31) / 32 + 1, 0u);
-    if (S > 0) {
-        // one empty bucket in front of the first site, one behind the last (first dpos = D): the kernels only clamp
-        d->dbase = s->pos[0] >= 64 ? (int32_t)(s->pos[0] - 64) : -64;
-        d->n_dbuckets = (uint32_t)(((int64_t)s->pos[S - 1] - (int64_t)d->dbase) >> 5) + 2;
-        // (the bucket entries themselves are built on the device, spl_build_dbuckets_kernel, once positions and rival bits are there)
-        for (int64_t j = 0; j < D; ++j)
-            for (int32_t r = dfirst[(size_t)j]; r < dfirst[(size_t)j + 1]; ++r)
-                if (flags[(size_t)r] & SPL_SF_RIVALS) rbits[(size_t)j >> 5] |= 1u << (j & 31);
-    }
     std::vector<uint4> jhash, jrivals;
+    std::vector<int32_t> flag_pos; // ends of the junctions that have rivals, sorted (not necessarily site positions)
     {
         std::vector<int32_t> row_dpos((size_t)S);
         for (int64_t j = 0; j < D; ++j)
             for (int32_t r = dfirst[(size_t)j]; r < dfirst[(size_t)j + 1]; ++r) row_dpos[(size_t)r] = (int32_t)j;
-        if (d->mutual_links && s->part_site) build_junction_table(s, flags, dfirst, row_dpos, jhash, jrivals);
+        if (S > 0) build_junction_table(s, flags, dfirst, row_dpos, jhash, jrivals, flag_pos);
         if (jhash.empty()) { jhash.assign(32, make_uint4(0x80000000u, 0, 0, 0)); jrivals.assign(2, make_uint4(0, 0, 0xffffffffu, 0xffffffffu)); }
     }
+    for (int32_t x : flag_pos)
+        if (x < 0 || x > SPL_COORD_MAX) { delete d; return spl_set_error(SPL_ERR_RANGE, "partner / competitor position outside [0, %d]", SPL_COORD_MAX); }
     d->jhash_mask = (uint32_t)(jhash.size() / 2) - 1u;
-    // For a read junction that is NOT an edge of the table but ends on a flagged position x, a rival t needs x in P_t and
-    // the other end in C_t (:494-501).  With mutual links such t are partners of the rows at x, so the union of their
-    // competitor lists decides in one short scan whether the literal walk is needed at all (it almost never is).
-    std::vector<uint32_t> ucl_off((size_t)D + 1, 0u);
-    std::vector<int32_t> ucl_pos;
-    if (d->mutual_links && s->part_site) {
-        std::vector<int32_t> tmp;
-        for (int64_t j = 0; j < D; ++j) {
-            ucl_off[(size_t)j] = (uint32_t)ucl_pos.size();
-            if (!((rbits[(size_t)j >> 5] >> (j & 31)) & 1u)) continue;
-            tmp.clear();
-            for (int32_t x = dfirst[(size_t)j]; x < dfirst[(size_t)j + 1]; ++x)
-                for (uint32_t e = s->part_off[x]; e < s->part_off[x + 1]; ++e) {
-                    const int32_t t = s->part_site[e];
-                    if (t < 0) continue;
-                    for (uint32_t f = s->comp_off[t]; f < s->comp_off[t + 1]; ++f) tmp.push_back(s->comp_pos[f]);
-                }
-            std::sort(tmp.begin(), tmp.end());
-            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-            ucl_pos.insert(ucl_pos.end(), tmp.begin(), tmp.end());
-        }
+    if (S > 0) {
+        // the position index covers sites and flagged positions alike, with one empty bucket in front of the first and one
+        // behind the last of them (first dpos = D there): the kernels only clamp
+        const int64_t lo = flag_pos.empty() ? s->pos[0] : std::min<int64_t>(s->pos[0], flag_pos.front());
+        const int64_t hi = flag_pos.empty() ? s->pos[S - 1] : std::max<int64_t>(s->pos[S - 1], flag_pos.back());
+        d->dbase = lo >= 64 ? (int32_t)(lo - 64) : -64;
+        d->n_dbuckets = (uint32_t)((hi - (int64_t)d->dbase) >> 5) + 2;
+        // (the bucket entries themselves are built on the device, spl_build_dbuckets_kernel, once the positions are there)
     }
-    ucl_off[(size_t)D] = (uint32_t)ucl_pos.size();
     d->diff_stride = (int32_t)align_up((size_t)D + 2, 64);
     d->scan_blocks = (int32_t)((D + SPL_SCAN_BLOCK - 1) / SPL_SCAN_BLOCK);
 
@@ -565,9 +511,8 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     const size_t o_pos = take(4 * S), o_strand = take(S), o_flags = take(S), o_meta = take(16 * S), o_poff = take(4 * (S + 1));
     const size_t o_ppos = take(4 * P), o_psite = take(4 * P), o_cpos = take(4 * C);
     const size_t o_alpha = take(8 * S), o_ecnt = take(8 * P), o_bucket = take(4 * bucket.size());
-    const size_t o_dfirst = take(4 * dfirst.size()), o_dbucket = take(8 * (size_t)d->n_dbuckets), o_drival = take(4 * (size_t)d->n_dbuckets), o_rbits = take(4 * rbits.size());
+    const size_t o_dfirst = take(4 * dfirst.size()), o_dbucket = take(8 * (size_t)d->n_dbuckets), o_drival = take(4 * (size_t)d->n_dbuckets), o_fpos = take(4 * flag_pos.size());
     const size_t o_jhash = take(16 * jhash.size()), o_jriv = take(16 * jrivals.size());
-    const size_t o_uoff = take(4 * ucl_off.size()), o_upos = take(4 * ucl_pos.size());
     const size_t o_cnt = off;
     const size_t o_b1 = take(4 * S), o_b2 = take(4 * S), o_dbl = take(4 * P);
     const size_t o_diff = take(4 * 4 * (size_t)d->diff_stride);
@@ -581,9 +526,8 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the site table: %s", d->slab_bytes, hipGetErrorString(e)); }
     d->pos = (int32_t *)(d->slab + o_pos); d->strand = (uint8_t *)(d->slab + o_strand); d->meta = (uint4 *)(d->slab + o_meta);
     d->flags = (uint8_t *)(d->slab + o_flags); d->diff = (int32_t *)(d->slab + o_diff); d->block_sums = (int32_t *)(d->slab + o_bsum);
-    d->dpos_first_row = (int32_t *)(d->slab + o_dfirst); d->dbucket = (uint2 *)(d->slab + o_dbucket); d->drival = (uint32_t *)(d->slab + o_drival); d->rival_bits = (uint32_t *)(d->slab + o_rbits);
+    d->dpos_first_row = (int32_t *)(d->slab + o_dfirst); d->dbucket = (uint2 *)(d->slab + o_dbucket); d->drival = (uint32_t *)(d->slab + o_drival); d->flag_pos = (int32_t *)(d->slab + o_fpos);
     d->jhash = (uint4 *)(d->slab + o_jhash); d->jrivals = (uint4 *)(d->slab + o_jriv);
-    d->ucl_off = (uint32_t *)(d->slab + o_uoff); d->ucl_pos = (int32_t *)(d->slab + o_upos);
     d->part_off = (uint32_t *)(d->slab + o_poff); d->part_pos = (int32_t *)(d->slab + o_ppos); d->part_site = (int32_t *)(d->slab + o_psite);
     d->comp_pos = (int32_t *)(d->slab + o_cpos); d->alpha = (int64_t *)(d->slab + o_alpha); d->edge_cnt = (int64_t *)(d->slab + o_ecnt);
     d->bucket = (uint32_t *)(d->slab + o_bucket);
@@ -606,11 +550,9 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (r == hipSuccess) r = up(d->meta, meta.data(), 16 * S);
     if (r == hipSuccess) r = up(d->flags, flags.data(), S);
     if (r == hipSuccess) r = up(d->dpos_first_row, dfirst.data(), 4 * dfirst.size());
-    if (r == hipSuccess) r = up(d->rival_bits, rbits.data(), 4 * rbits.size());
+    if (r == hipSuccess) r = up(d->flag_pos, flag_pos.data(), 4 * flag_pos.size());
     if (r == hipSuccess) r = up(d->jhash, jhash.data(), 16 * jhash.size());
     if (r == hipSuccess) r = up(d->jrivals, jrivals.data(), 16 * jrivals.size());
-    if (r == hipSuccess) r = up(d->ucl_off, ucl_off.data(), 4 * ucl_off.size());
-    if (r == hipSuccess) r = up(d->ucl_pos, ucl_pos.data(), 4 * ucl_pos.size());
     if (r == hipSuccess) r = up(d->part_off, s->part_off, S ? 4 * (S + 1) : 0);
     if (r == hipSuccess) r = up(d->part_pos, s->part_pos, 4 * P);
     if (r == hipSuccess) r = up(d->part_site, s->part_site, 4 * P);
@@ -620,7 +562,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (r == hipSuccess) r = up(d->bucket, bucket.data(), 4 * bucket.size());
     if (r == hipSuccess) r = hipMemset(d->slab + o_cnt, 0, d->slab_bytes > o_cnt ? d->slab_bytes - o_cnt : 0);
     if (r == hipSuccess && S > 0) {
-        r = (hipError_t)spl_dev_launch_build_dbuckets(d->pos, d->dpos_first_row, d->n_dpos, d->rival_bits, d->dbase, d->n_dbuckets, d->dbucket, d->drival,
+        r = (hipError_t)spl_dev_launch_build_dbuckets(d->pos, d->dpos_first_row, d->n_dpos, d->flag_pos, (int32_t)flag_pos.size(), d->dbase, d->n_dbuckets, d->dbucket, d->drival,
                                                       c->stream);
         if (r == hipSuccess) r = hipStreamSynchronize(c->stream);
     }
@@ -968,7 +910,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     // counters, difference arrays, error word and queue counters start from zero: the copy the previous pass cleared on the
     // side, or -- first pass after a pair-kernel pass -- one clearing launch
     // range kernel whenever the table allows it; the literal pair kernel otherwise or on request
-    const int variant = (!ds->mutual_links || (o->flags & SPL_OPT_PAIR_KERNEL)) ? 1 : ((o->flags & SPL_OPT_WAVE_AGGREGATION) ? 2 : 0);
+    const int variant = (o->flags & SPL_OPT_PAIR_KERNEL) ? 1 : ((o->flags & SPL_OPT_WAVE_AGGREGATION) ? 2 : 0);
     const bool piped = c->tail != nullptr && variant != 1 && ds->region_clean[(ds->cur + 1) % 3];
     if (piped) {
         // the tail of the pass before the last one is the last thing that read the queue buffer and wrote the counter copy
@@ -1003,7 +945,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.part_pos = ds->part_pos; p.part_site = ds->part_site; p.comp_pos = ds->comp_pos;
     p.diff = ds->diff; p.diff_stride = ds->diff_stride;
     p.dbucket = ds->dbucket; p.drival = ds->drival; p.n_dbuckets = ds->n_dbuckets; p.dbase = ds->dbase; p.n_dpos = ds->n_dpos;
-    p.rival_bits = ds->rival_bits; p.dpos_first_row = ds->dpos_first_row; p.ucl_off = ds->ucl_off; p.ucl_pos = ds->ucl_pos;
+    p.dpos_first_row = ds->dpos_first_row;
     p.jhash = ds->jhash; p.jhash_mask = ds->jhash_mask; p.jrivals = ds->jrivals;
     spl_hot_params h;
     memset(&h, 0, sizeof(h));

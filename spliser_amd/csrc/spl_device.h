@@ -33,14 +33,14 @@
 #define SPL_DEV_ERR_RANGE 1
 #define SPL_DEV_ERR_TABLE 2
 
-// junction table entry flags (word 3, above the 8-bit rival count)
-#define SPL_JF_COMPLEX 0x100u   // needs the literal kernel (a rival is a junction end, too many rivals, ...)
-#define SPL_JF_MULTIROW 0x200u  // a rival shares its position with another row: unstranded runs cannot address it by dpos
+// junction table entry, word 3: flags above ...
+#define SPL_JF_COUNT_MASK 0x00ffffffu // ... the number of rivals
+#define SPL_JF_COMPLEX 0x40000000u  // needs the literal walk (a rival is a junction end itself, duplicate partner edges, ...)
+#define SPL_JF_MULTIROW 0x80000000u // a rival shares its position with another row: unstranded runs cannot address it by dpos
 
 // per-row flag byte (built at upload)
 #define SPL_SF_PLUS 1u    // Site.strand == '+'
 #define SPL_SF_MINUS 2u   // Site.strand == '-'
-#define SPL_SF_RIVALS 4u  // some partner of this row has competitors: a junction ending here may have rival sites
 
 struct spl_count_params {
     // reads: the packed layout of spl_pack.h, one descriptor per chunk
@@ -67,9 +67,6 @@ struct spl_count_params {
     uint32_t n_dbuckets;
     int32_t dbase;
     int32_t n_dpos;
-    const uint32_t *rival_bits;  // bit d: some row at distinct position d carries SPL_SF_RIVALS
-    const uint32_t *ucl_off;     // [n_dpos + 1] per distinct position: the competitor positions of all partners of its rows
-    const int32_t *ucl_pos;      //   (sorted, unique) -- a junction from there to anywhere else cannot make a rival
     const int32_t *dpos_first_row;
     const uint4 *jhash;          // junction table (see spl_hot_params)
     uint32_t jhash_mask;
@@ -172,8 +169,8 @@ int spl_dev_launch_junctions(const spl_chunk_meta *chunk_meta, uint32_t n_chunks
                              int stranded, uint32_t min_anchor, uint32_t min_intron, uint32_t max_intron, unsigned long long *keys,
                              uint32_t *vals, uint32_t n_slots, unsigned long long *out_keys,
                              uint32_t *out_vals, uint32_t *n_out, int32_t *err, void *stream);
-int spl_dev_launch_build_dbuckets(const int32_t *site_pos, const int32_t *dpos_first_row, int32_t n_dpos, const uint32_t *rival_bits,
-                                  int32_t dbase, uint32_t n_dbuckets, uint2 *out, uint32_t *out_rival, void *stream);
+int spl_dev_launch_build_dbuckets(const int32_t *site_pos, const int32_t *dpos_first_row, int32_t n_dpos, const int32_t *flag_pos,
+                                  int32_t n_flag, int32_t dbase, uint32_t n_dbuckets, uint2 *out, uint32_t *out_rival, void *stream);
 int spl_dev_launch_clear(void *region, size_t bytes, void *stream);
 int spl_dev_launch_literal(const spl_count_params *p, const spl_queue_params *q, void *stream);
 int spl_dev_launch_scan(const spl_scan_params *p, void *stream);

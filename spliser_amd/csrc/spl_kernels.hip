@@ -293,71 +293,30 @@ __global__ __launch_bounds__(SPL_BLOCK) void spl_count_pairs_kernel(const spl_co
 // =========================================================================================================
 namespace {
 
-// Is any junction end of the read that comes before (stop_op, stop_side) -- in lSite, rSite order per N op --
-// a member of `part`?  Used to visit a rival exactly once.
-__device__ __forceinline__ bool earlier_end_in(int32_t pos, const uint32_t *ops, uint32_t stop_op, int stop_side,
-                                               const int32_t *part, uint32_t n_part)
+__device__ __forceinline__ void agg_add(uint32_t *addr, int32_t delta);
+
+// Look (l, r) up in the junction table (spl_capi.cpp, build_junction_table).  The table is complete: a junction that is not in it
+// cannot make compSplicing true for any site.
+__device__ __forceinline__ bool jt_find(const uint4 *jhash, uint32_t jhash_mask, int32_t l, int32_t r, uint4 &ent)
 {
-    int32_t cur = pos;
-    for (uint32_t k = 0; k <= stop_op; ++k) {
-        const uint32_t op = ops[k];
-        const uint32_t code = op & 15u;
-        if (!((SPL_PROG_MASK >> code) & 1u)) continue;
-        const int32_t d = (int32_t)(op >> 4);
-        cur += d;
-        if (code != SPL_OP_N) continue;
-        const int32_t l = cur - d - 1, r = cur - 1;
-        if (k < stop_op) {
-            if (spl_contains(part, n_part, l) || spl_contains(part, n_part, r)) return true;
-        } else if (stop_side == 1) {
-            if (spl_contains(part, n_part, l)) return true;
-        }
+    uint32_t h = (uint32_t)l * 0x9E3779B1u ^ (uint32_t)r * 0x85EBCA77u;
+    h ^= h >> 15;
+    for (int probe = 0; probe < 8; ++probe) {
+        ent = jhash[2u * ((h + (uint32_t)probe) & jhash_mask)];
+        if ((int32_t)ent.x == l && (int32_t)ent.y == r) return true;
+        if (ent.x == 0x80000000u) return false;
     }
     return false;
 }
 
+// The literal walk for one read, any CIGAR, any table, both modes: the sites whose compSplicing test (:494-501) can succeed for
+// the read are the rivals the junction table lists under the read's junctions; each of them inside the read's fetch window is
+// classified with the literal state machine (spl_classify.h), with and without its lists -- where the two outcomes differ,
+// what the ranges counted for that row is taken back and the literal outcome applied.  A rival listed under several junctions
+// of the read is handled under the first of them.
 template <bool STRANDED>
-__device__ __forceinline__ void rivals_of_end(const spl_count_params &p, int32_t pos, uint32_t flag, const uint32_t *ops,
-                                           uint32_t n_ops, int32_t end_fetch, uint32_t k_op, int side, int32_t x)
-{
-    const int32_t n_sites = p.n_sites;
-    const int32_t r0 = first_site_at_or_after(p, x);
-    for (int32_t row = r0; row < n_sites && p.site_pos[row] == x; ++row) {
-        const uint4 m = p.site_meta[row];
-        for (uint32_t e = 0; e < m.y; ++e) {
-            const int32_t trow = p.part_site[m.x + e];
-            if (trow < 0) continue;
-            const int32_t t = p.site_pos[trow];
-            if (t < pos || t > end_fetch) continue;
-            const uint4 mt = p.site_meta[trow];
-            if (mt.w == 0u) continue; // no competitors: compSplicing impossible
-            const int32_t *part = p.part_pos + mt.x;
-            const int32_t *comp = p.comp_pos + mt.z;
-            // visit once: skip when an earlier junction end of this read also leads here, or an earlier row at x does
-            if (earlier_end_in(pos, ops, k_op, side, part, mt.y)) continue;
-            bool dup = false;
-            for (int32_t row2 = r0; row2 < row && !dup; ++row2) {
-                const uint4 m2 = p.site_meta[row2];
-                for (uint32_t e2 = 0; e2 < m2.y; ++e2) dup |= (p.part_site[m2.x + e2] == trow);
-            }
-            for (uint32_t e2 = 0; e2 < e; ++e2) dup |= (p.part_site[m.x + e2] == trow);
-            if (dup) continue;
-            bool strand_ok = true;
-            if (STRANDED) strand_ok = (p.site_strand[trow] == spl_read_strand(flag, p.stranded));
-            const spl_pair full = spl_classify_pair(pos, ops, n_ops, t, part, mt.y, comp, mt.w, strand_ok);
-            const spl_pair base = spl_classify_pair(pos, ops, n_ops, t, nullptr, 0u, nullptr, 0u, strand_ok);
-            if (full.cls == base.cls) continue;
-            // take back what the ranges counted for this row, apply the literal outcome
-            if (base.cls == SPL_CLS_BETA1) atomicAdd(&p.beta1[trow], 0xffffffffu);
-            else if (base.cls == SPL_CLS_ME) atomicAdd(&p.beta2s_reads[trow], 0xffffffffu);
-            apply_pair_global(p, full, trow, pos, ops, n_ops, part, mt.y, mt.x);
-        }
-    }
-}
-
-template <bool STRANDED>
-__device__ __forceinline__ void rivals_pass(const spl_count_params &p, int32_t pos, uint32_t flag, const uint32_t *ops,
-                                         uint32_t n_ops, int32_t end_fetch)
+__device__ __forceinline__ void rivals_literal(const spl_count_params &p, int32_t pos, uint32_t flag, const uint32_t *ops,
+                                               uint32_t n_ops, int32_t end_fetch)
 {
     int32_t cur = pos;
     for (uint32_t k = 0; k < n_ops; ++k) {
@@ -367,8 +326,54 @@ __device__ __forceinline__ void rivals_pass(const spl_count_params &p, int32_t p
         const int32_t d = (int32_t)(op >> 4);
         cur += d;
         if (code != SPL_OP_N) continue;
-        rivals_of_end<STRANDED>(p, pos, flag, ops, n_ops, end_fetch, k, 0, cur - d - 1);
-        rivals_of_end<STRANDED>(p, pos, flag, ops, n_ops, end_fetch, k, 1, cur - 1);
+        const int32_t l = cur - d - 1, r = cur - 1;
+        uint4 ent;
+        if (!jt_find(p.jhash, p.jhash_mask, l, r, ent)) continue;
+        {   // the same junction earlier in the read (0N ops, repeats): its rivals are done
+            bool repeat = false;
+            int32_t c2 = pos;
+            for (uint32_t k2 = 0; k2 < k; ++k2) {
+                const uint32_t op2 = ops[k2];
+                if (!((SPL_PROG_MASK >> (op2 & 15u)) & 1u)) continue;
+                const int32_t d2 = (int32_t)(op2 >> 4);
+                c2 += d2;
+                repeat |= (op2 & 15u) == SPL_OP_N && c2 - d2 - 1 == l && c2 - 1 == r;
+            }
+            if (repeat) continue;
+        }
+        const uint32_t n_riv = ent.w & SPL_JF_COUNT_MASK;
+        for (uint32_t i = 0; i < n_riv; ++i) {
+            const uint4 rx = p.jrivals[2u * (ent.z + i) + 1u]; // {row of t, its partner list offset, length, -}
+            const int32_t trow = (int32_t)rx.x;
+            const int32_t t = p.site_pos[trow];
+            if (t < pos || t > end_fetch) continue;
+            // listed under an earlier junction of this read too?  (compSplicing became true there: handled there)
+            bool earlier = false;
+            int32_t c2 = pos;
+            for (uint32_t k2 = 0; k2 < k && !earlier; ++k2) {
+                const uint32_t op2 = ops[k2];
+                if (!((SPL_PROG_MASK >> (op2 & 15u)) & 1u)) continue;
+                const int32_t d2 = (int32_t)(op2 >> 4);
+                c2 += d2;
+                if ((op2 & 15u) != SPL_OP_N) continue;
+                uint4 e2;
+                if (!jt_find(p.jhash, p.jhash_mask, c2 - d2 - 1, c2 - 1, e2)) continue;
+                for (uint32_t i2 = 0; i2 < (e2.w & SPL_JF_COUNT_MASK); ++i2) earlier |= p.jrivals[2u * (e2.z + i2) + 1u].x == rx.x;
+            }
+            if (earlier) continue;
+            const uint4 mt = p.site_meta[trow];
+            const int32_t *part = p.part_pos + mt.x;
+            const int32_t *comp = p.comp_pos + mt.z;
+            bool strand_ok = true;
+            if (STRANDED) strand_ok = (p.site_strand[trow] == spl_read_strand(flag, p.stranded));
+            const spl_pair full = spl_classify_pair(pos, ops, n_ops, t, part, mt.y, comp, mt.w, strand_ok);
+            const spl_pair base = spl_classify_pair(pos, ops, n_ops, t, nullptr, 0u, nullptr, 0u, strand_ok);
+            if (full.cls == base.cls) continue;
+            // take back what the ranges counted for this row, apply the literal outcome
+            if (base.cls == SPL_CLS_BETA1) agg_add(&p.beta1[trow], -1);
+            else if (base.cls == SPL_CLS_ME) agg_add(&p.beta2s_reads[trow], -1);
+            apply_pair_global(p, full, trow, pos, ops, n_ops, part, mt.y, mt.x);
+        }
     }
 }
 
@@ -505,8 +510,8 @@ __device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, spl_lds_i
         if ((int32_t)ent.x == l && (int32_t)ent.y == r) { found = true; break; }
         if (ent.x == 0x80000000u) break; // empty slot: not a BED junction with flagged ends
     }
-    if (!found) return false;
-    const uint32_t n_riv = ent.w & 0xffu;
+    if (!found) return true; // the table is complete: no site anywhere has this junction as a rival's
+    const uint32_t n_riv = ent.w & SPL_JF_COUNT_MASK;
     if ((ent.w & SPL_JF_COMPLEX) || n_riv > 4u) return false;
     if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) return false; // several rows share a rival's position: per-row only
     for (uint32_t i = 0; i < n_riv; ++i) {
@@ -572,11 +577,11 @@ __device__ __forceinline__ bool rivals_inline2(const spl_hot_params &p, spl_lds_
             if (ent[j].x == 0x80000000u) break;
         }
         if (found) {
-            if ((ent[j].w & SPL_JF_COMPLEX) || (ent[j].w & 0xffu) > 16u) return false;
+            if ((ent[j].w & SPL_JF_COMPLEX) || (ent[j].w & SPL_JF_COUNT_MASK) > 16u) return false;
             if (!STRANDED && (ent[j].w & SPL_JF_MULTIROW)) return false;
             r_off[j] = ent[j].z;
-            r_n[j] = ent[j].w & 0xffu;
-        } else if (flagged[j]) return false;
+            r_n[j] = ent[j].w & SPL_JF_COUNT_MASK;
+        } // (not in the table: the table is complete, the junction has no rivals)
     }
     const uint32_t want = sidx ? 2u : 1u;
     const uint32_t a_b1 = sidx, a_me = (STRANDED ? 2u : 1u) + sidx;
@@ -794,7 +799,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
                 const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx;
                 // boundary by boundary, so that a bucket entry dies as soon as it is resolved (the kernel lives on 64 VGPRs)
-                int32_t ua, ub; uint32_t nva, nvb, rvb, nv1, rv1;
+                int32_t ua, ub; uint32_t nva, nvb, rvb, rv1;
                 dbk_resolve(p, pos - 1, e0, ua, nva);
                 dbk_resolve(p, c0 - 1, e1, rm1, ub, nvb, rvb);
                 {
@@ -805,7 +810,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                         commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | sidx, -1);
                     }
                 }
-                nv1 = nvb; rv1 = rvb;
+                rv1 = rvb;
                 ua = ub; nva = nvb;
                 dbk_resolve(p, c1 - 1, e2, rm2, ub, nvb, rvb);
                 {
@@ -816,7 +821,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                         commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | a_me, -1);
                     }
                 }
-                const uint32_t nv2 = nvb, rv2 = rvb;
+                const uint32_t rv2 = rvb;
                 ua = ub; nva = nvb;
                 dbk_resolve(p, c2 - 1, e3, ub, nvb);
                 {
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                         commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | sidx, -1);
                     }
                 }
-                const bool flagged = alive && (((nv1 & rv1) | (nv2 & rv2)) != 0u); // an end of the junction (c0 - 1, c1 - 1) has rivals
+                const bool flagged = alive && ((rv1 | rv2) != 0u); // an end of the junction (c0 - 1, c1 - 1) is an end of a junction with rivals
                 if (__any(flagged)) {
                     push_front(flagged && p.combine_mode, slot);
                     push_back(flagged && !p.combine_mode, slot);
@@ -862,19 +867,19 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 dbk_resolve(p, pos - 1, f0, ua, nva);
                 dbk_resolve(p, c0 - 1, f1, rm1, ub, nvb, rvb);
                 range(sidx2);                       // block 1
-                fl1 |= nvb & rvb;
+                fl1 |= rvb;
                 f0 = p.dbucket[s4];                  // the second trip, under way while the first is worked off
                 f1 = p.dbucket[dbk_slot(p, c4 - 1)];
                 const uint32_t rm4 = p.drival[s4];
                 dbk_resolve(p, c1 - 1, f2, rm2, ub, nvb, rvb);
                 range(a_me);                        // intron 1
-                fl1 |= nvb & rvb;
+                fl1 |= rvb;
                 dbk_resolve(p, c2 - 1, f3, rm3, ub, nvb, rvb);
                 range(sidx2);                       // block 2
-                fl2 |= nvb & rvb;
+                fl2 |= rvb;
                 dbk_resolve(p, c3 - 1, f0, rm4, ub, nvb, rvb);
                 range(a_me);                        // intron 2
-                fl2 |= nvb & rvb;
+                fl2 |= rvb;
                 dbk_resolve(p, c4 - 1, f1, ub, nvb);
                 range(sidx2);                       // block 3
                 const bool flagged = alive && ((fl1 | fl2) != 0u);
@@ -938,7 +943,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                     const bool emit = kk != 0u && kk != 3u && u > lo;
                     const uint32_t arr = (kk == 2u ? (STRANDED ? 2u : 1u) : 0u) + sidx;
                     // junction ends: lSite is the previous boundary's position, rSite this one's
-                    rival |= (kk == 2u) & (((pnv & prv) | (nv & rv)) != 0u);
+                    rival |= (kk == 2u) & ((prv | rv) != 0u);
                     if (__any(emit)) {
                         commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
                         commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)u << 2) | arr, -1);
@@ -1065,135 +1070,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
 
 namespace {
 
-// Rivals of a short read (at most SPL_CF_JUNC N ops and SPL_CF_BLK aligned blocks: every short-read CIGAR) in closed
-// form.  With the read's junctions (l_j, r_j) and aligned blocks in registers, the CIGAR walk of checkBam for a rival
-// site t collapses to: alpha/comp prefix flags per junction, "t strictly inside junction j", "a block covers t and
-// t+1" -- evaluated in junction order so that the stickiness of compSplicing and alpha_read (:487-512) is kept.
-// Returns false (nothing done) when the read does not fit; the caller then takes the general walk.
 #define SPL_CF_JUNC 4
 #define SPL_CF_BLK 5
-template <bool STRANDED>
-__device__ __forceinline__ bool rivals_closed_form(const spl_count_params &p, int32_t pos, uint32_t flag,
-                                                   const uint32_t *ops, uint32_t n_ops)
-{
-    int32_t blk_a[SPL_CF_BLK], blk_b[SPL_CF_BLK], jl[SPL_CF_JUNC], jr[SPL_CF_JUNC];
-    int n_blk = 0, n_j = 0;
-    int32_t cur = pos;
-    int64_t ref_len = 0;
-    for (uint32_t k = 0; k < n_ops; ++k) {
-        const uint32_t op = ops[k];
-        const uint32_t code = op & 15u;
-        if (!((SPL_PROG_MASK >> code) & 1u)) continue;
-        const int32_t d = (int32_t)(op >> 4);
-        const int32_t start = cur;
-        cur += d;
-        ref_len += d;
-        if (code == SPL_OP_N) {
-            if (n_j == SPL_CF_JUNC) return false;
-#pragma unroll
-            for (int j = 0; j < SPL_CF_JUNC; ++j) if (j == n_j) { jl[j] = start - 1; jr[j] = cur - 1; }
-            ++n_j;
-        } else if (code != SPL_OP_D && d >= 2) { // an aligned block that can hold t and t+1
-            if (n_blk == SPL_CF_BLK) return false;
-#pragma unroll
-            for (int j = 0; j < SPL_CF_BLK; ++j) if (j == n_blk) { blk_a[j] = start; blk_b[j] = cur - 1; }
-            ++n_blk;
-        }
-    }
-    if (n_j == 0) return true; // no junction: nothing can set compSplicing
-    const int32_t end_fetch = (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1);
-    uint8_t rstrand = 0;
-    if (STRANDED) rstrand = spl_read_strand(flag, p.stranded);
-#pragma unroll
-    for (int q = 0; q < 2 * SPL_CF_JUNC; ++q) {
-        if (q >= 2 * n_j) break;
-        const int32_t x = (q & 1) ? jr[q >> 1] : jl[q >> 1];
-        bool repeat = false; // the same position earlier in the list (0N, back-to-back N ops): rows already done
-#pragma unroll
-        for (int q2 = 0; q2 < q; ++q2) repeat |= (((q2 & 1) ? jr[q2 >> 1] : jl[q2 >> 1]) == x);
-        if (repeat) continue;
-        // rows at this junction end (checkBam's order: lSite_1, rSite_1, lSite_2, ...)
-        int32_t xu; uint32_t xnv;
-        dbk_resolve(p, x, p.dbucket[dbk_slot(p, x)], xu, xnv);
-        if (!xnv) continue;
-        const int32_t row_first = p.dpos_first_row[xu], row_end = p.dpos_first_row[xu + 1];
-        for (int32_t row = row_first; row < row_end; ++row) {
-            const uint4 m = p.site_meta[row];
-            for (uint32_t e = 0; e < m.y; ++e) {
-                const int32_t t = p.part_pos[m.x + e];
-                if (t < pos || t > end_fetch) continue;
-                bool touches = false;
-#pragma unroll
-                for (int j = 0; j < SPL_CF_JUNC; ++j) touches |= (j < n_j) && (t >= jl[j]) && (t <= jr[j]);
-                bool cov = false;
-#pragma unroll
-                for (int j = 0; j < SPL_CF_BLK; ++j) cov |= (j < n_blk) && (blk_a[j] <= t) && (t + 1 <= blk_b[j]);
-                if (!(touches || cov)) continue; // neither alpha, inside an intron nor beta1: no counter can change
-                const int32_t trow = p.part_site[m.x + e];
-                if (trow < 0) continue;
-                const uint4 mt = p.site_meta[trow];
-                if (mt.w == 0u) continue;
-                const int32_t *part = p.part_pos + mt.x;
-                const int32_t *comp = p.comp_pos + mt.z;
-                bool seen = false; // reachable from an earlier junction end: handled there
-#pragma unroll
-                for (int q2 = 0; q2 < q; ++q2) seen |= spl_contains(part, mt.y, (q2 & 1) ? jr[q2 >> 1] : jl[q2 >> 1]);
-                if (seen) continue;
-                bool dup = false; // listed by an earlier row at this position too?
-                for (int32_t row2 = row_first; row2 < row; ++row2) {
-                    const uint4 m2 = p.site_meta[row2];
-                    for (uint32_t e2 = 0; e2 < m2.y; ++e2) dup |= (p.part_site[m2.x + e2] == trow);
-                }
-                if (dup) continue;
-                bool dup_edge = false;
-                for (uint32_t e2 = 0; e2 < e; ++e2) dup_edge |= (p.part_site[m.x + e2] == trow);
-                if (dup_edge) continue;
-                bool strand_ok = true;
-                if (STRANDED) strand_ok = (p.site_strand[trow] == rstrand);
-                // the CIGAR walk, junction by junction (:480-512)
-                bool alpha = false, comp_spl = false, flank = false, me = false, me_base = false, has_pu = false;
-                int32_t pu = 0;
-#pragma unroll
-                for (int j = 0; j < SPL_CF_JUNC; ++j) {
-                    if (j >= n_j) break;
-                    const int32_t l = jl[j], r = jr[j];
-                    if (l == t) { pu = r; has_pu = true; alpha = true; }
-                    if (r == t) { pu = l; has_pu = true; alpha = true; }
-                    if (spl_contains(comp, mt.w, r) && spl_contains(part, mt.y, l)) comp_spl = true;
-                    if (spl_contains(comp, mt.w, l) && spl_contains(part, mt.y, r)) comp_spl = true;
-                    const bool inside = (t > l) && (t < r);
-                    if (comp_spl && inside) flank = true;
-                    if (!alpha && !comp_spl && inside && strand_ok) me = true;
-                    if (!alpha && inside && strand_ok) me_base = true; // what the ranges assumed: compSplicing false
-                }
-                if (!comp_spl) continue; // the ranges were right
-                const bool beta1 = cov && strand_ok;
-                const int base = me_base ? SPL_CLS_ME : (beta1 ? SPL_CLS_BETA1 : SPL_CLS_NONE);
-                const int full = (alpha && comp_spl) ? SPL_CLS_ALPHA_COMP : flank ? SPL_CLS_FLANK : me ? SPL_CLS_ME
-                                 : beta1 ? SPL_CLS_B1TYPE : SPL_CLS_NONE;
-                if (full == base) continue;
-                if (base == SPL_CLS_ME) agg_add(&p.beta2s_reads[trow], -1);
-                else if (base == SPL_CLS_BETA1) agg_add(&p.beta1[trow], -1);
-                if (full == SPL_CLS_ME) agg_add(&p.beta2s_reads[trow], 1);
-                else if (full == SPL_CLS_FLANK) { if (p.combine_mode) agg_add(&p.beta2s_reads[trow], 1); }
-                else if (full == SPL_CLS_B1TYPE || full == SPL_CLS_ALPHA_COMP) {
-                    if (full == SPL_CLS_B1TYPE) agg_add(&p.beta2s_reads[trow], 1);
-                    for (uint32_t e2 = 0; e2 < mt.y; ++e2) { // set(partners) & set(spliceSites) (:519-527, :544-551)
-                        const int32_t pp = part[e2];
-                        bool is_end = false;
-#pragma unroll
-                        for (int j = 0; j < SPL_CF_JUNC; ++j) is_end |= (j < n_j) && (pp == jl[j] || pp == jr[j]);
-                        if (!is_end) continue;
-                        if (full == SPL_CLS_ALPHA_COMP && has_pu && pp == pu) continue;
-                        agg_add(&p.dbl[mt.x + e2], 1);
-                    }
-                }
-            }
-        }
-    }
-    return true;
-}
-
 // The same junction table the range kernel uses for single-junction reads, applied to reads with up to SPL_CF_JUNC
 // junctions: compSplicing of junction j for site t is "t is listed under (l_j, r_j)", so no partner / competitor list is
 // scanned.  A rival is handled under the FIRST junction that lists it (that is where compSplicing becomes true and
@@ -1201,14 +1079,6 @@ __device__ __forceinline__ bool rivals_closed_form(const spl_count_params &p, in
 // covered with t+1 by an aligned block -> beta1-type.  Anything the table cannot decide exactly (a junction that is not
 // in the BED file but touches flagged sites, a rival that is itself a junction end of the read, entries marked complex,
 // combine mode) returns false and the read takes rivals_closed_form.  Updates go to the global difference arrays.
-// Is position x among the competitor positions of any partner of the rows at distinct position d?  (built at upload)
-__device__ __forceinline__ bool ucl_contains(const spl_count_params &p, int32_t d, int32_t x)
-{
-    bool hit = false;
-    for (uint32_t k = p.ucl_off[d], e = p.ucl_off[d + 1]; k < e; ++k) hit |= (p.ucl_pos[k] == x);
-    return hit;
-}
-
 #ifdef SPL_PHASE_LITERAL
 __device__ unsigned long long g_tp_fail[8]; // why reads leave the table path (development aid)
 #define SPL_TP_FAIL(code) do { atomicAdd(&g_tp_fail[code], 1ull); return false; } while (0)
@@ -1269,17 +1139,10 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
         }
         if (found) {
             if (ent.w & SPL_JF_COMPLEX) SPL_TP_FAIL(4);
-            if ((ent.w & 0xffu) > 16u) SPL_TP_FAIL(5);
+            if ((ent.w & SPL_JF_COUNT_MASK) > 16u) SPL_TP_FAIL(5);
             if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) SPL_TP_FAIL(6);
-            r_off[j] = ent.z; r_n[j] = ent.w & 0xffu;
-        } else { // not a listed junction: fine only when neither end has a rival flag
-            int32_t u; uint32_t nv, rv;
-            { const uint32_t sl = dbk_slot(p, l); dbk_resolve(p, l, p.dbucket[sl], p.drival[sl], u, nv, rv); }
-            // a rival t would need this end in P_t and the other end in C_t: the union list of the end decides
-            if ((nv & rv) && ucl_contains(p, u, r)) SPL_TP_FAIL(7);
-            { const uint32_t sl = dbk_slot(p, r); dbk_resolve(p, r, p.dbucket[sl], p.drival[sl], u, nv, rv); }
-            if ((nv & rv) && ucl_contains(p, u, l)) SPL_TP_FAIL(7);
-        }
+            r_off[j] = ent.z; r_n[j] = ent.w & SPL_JF_COUNT_MASK;
+        } // (not in the table: no site has this junction as a rival's -- the table is complete)
     }
     // pass 2: apply
     const uint32_t want = (spl_read_strand(flag, STRANDED ? p.stranded : 1) == (uint8_t)'-') ? 2u : 1u;
@@ -1412,17 +1275,13 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
             if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
 #ifdef SPL_PHASE_LITERAL
             const bool tp_ = rivals_table_path<STRANDED>(p, pos, flag, ops, n_ops);
-            bool cf_ = false;
-            if (!tp_) cf_ = rivals_closed_form<STRANDED>(p, pos, flag, ops, n_ops);
-            if (!tp_ && !cf_) rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
+            if (!tp_) rivals_literal<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
             atomicAdd((unsigned long long *)&g_phase[(size_t)blockIdx.x * 8 + 4], tp_ ? 1ull : 0ull);
-            atomicAdd((unsigned long long *)&g_phase[(size_t)blockIdx.x * 8 + 5], cf_ ? 1ull : 0ull);
-            atomicAdd((unsigned long long *)&g_phase[(size_t)blockIdx.x * 8 + 6], (!tp_ && !cf_) ? 1ull : 0ull);
+            atomicAdd((unsigned long long *)&g_phase[(size_t)blockIdx.x * 8 + 6], !tp_ ? 1ull : 0ull);
             continue;
 #endif
             if (rivals_table_path<STRANDED>(p, pos, flag, ops, n_ops)) continue;
-            if (rivals_closed_form<STRANDED>(p, pos, flag, ops, n_ops)) continue;
-            rivals_pass<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
+            rivals_literal<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
         }
     }
 #ifdef SPL_PHASE_LITERAL
@@ -1688,11 +1547,12 @@ __global__ __launch_bounds__(256) void spl_junction_compact_kernel(const unsigne
 }
 
 // The position index of a site table (see dbk_slot / dbk_resolve), built where it lives: one thread per 32 bp bucket finds the
-// first distinct position at or after the bucket start by bisection and collects occupancy and rival masks of the positions
-// inside.  (On the host this was a serial sweep over all buckets: 0.3 s for a mammalian genome.)
+// first distinct position at or after the bucket start by bisection and collects the occupancy mask of the positions inside;
+// the same for the flagged positions (ends of junctions that have rivals: sorted, not necessarily sites) and their mask.
+// (On the host this was a serial sweep over all buckets: 0.3 s for a mammalian genome.)
 __global__ __launch_bounds__(256) void spl_build_dbuckets_kernel(const int32_t *site_pos, const int32_t *dpos_first_row, int32_t n_dpos,
-                                                                 const uint32_t *rival_bits, int32_t dbase, uint32_t n_dbuckets, uint2 *out,
-                                                                 uint32_t *out_rival)
+                                                                 const int32_t *flag_pos, int32_t n_flag, int32_t dbase, uint32_t n_dbuckets,
+                                                                 uint2 *out, uint32_t *out_rival)
 {
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b >= n_dbuckets) return;
@@ -1707,7 +1567,16 @@ __global__ __launch_bounds__(256) void spl_build_dbuckets_kernel(const int32_t *
         const int64_t pj = site_pos[dpos_first_row[j]];
         if (pj >= start + 32) break;
         mask |= 1u << (pj - start);
-        if ((rival_bits[j >> 5] >> (j & 31)) & 1u) rm |= 1u << (pj - start); // the site at this position has rivals
+    }
+    int32_t fl = 0, fh = n_flag;
+    while (fl < fh) {
+        const int32_t mid = fl + ((fh - fl) >> 1);
+        if ((int64_t)flag_pos[mid] < start) fl = mid + 1; else fh = mid;
+    }
+    for (int32_t j = fl; j < n_flag; ++j) {
+        const int64_t pj = flag_pos[j];
+        if (pj >= start + 32) break;
+        rm |= 1u << (pj - start);
     }
     out[b] = make_uint2((uint32_t)lo, mask);
     out_rival[b] = rm;
@@ -1742,12 +1611,12 @@ extern "C" int spl_dev_launch_junctions(const spl_chunk_meta *chunk_meta, uint32
     return (int)hipGetLastError();
 }
 
-extern "C" int spl_dev_launch_build_dbuckets(const int32_t *site_pos, const int32_t *dpos_first_row, int32_t n_dpos, const uint32_t *rival_bits,
-                                             int32_t dbase, uint32_t n_dbuckets, uint2 *out, uint32_t *out_rival, void *stream)
+extern "C" int spl_dev_launch_build_dbuckets(const int32_t *site_pos, const int32_t *dpos_first_row, int32_t n_dpos, const int32_t *flag_pos,
+                                             int32_t n_flag, int32_t dbase, uint32_t n_dbuckets, uint2 *out, uint32_t *out_rival, void *stream)
 {
     if (n_dbuckets == 0) return 0;
     hipLaunchKernelGGL(spl_build_dbuckets_kernel, dim3((n_dbuckets + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, site_pos, dpos_first_row,
-                       n_dpos, rival_bits, dbase, n_dbuckets, out, out_rival);
+                       n_dpos, flag_pos, n_flag, dbase, n_dbuckets, out, out_rival);
     return (int)hipGetLastError();
 }
 

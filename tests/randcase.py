@@ -80,3 +80,29 @@ def make_case(seed, stranded):
             recs.append((flag, start, "".join(ops)))
     recs.sort(key=lambda r: r[1])
     return arr, samio.ReadSet.from_records(recs)
+
+
+def query_table(arr, seed):
+    """A table as `combine` asks about it (SpliSER_v0_1_8.py:869-904): some of the rows of ``arr``, each with the strand,
+    partners and competitors "as they stand" when only some samples have contributed -- a random part of its lists, possibly
+    none, possibly no strand -- and no links between rows.  -> dict of arrays (pos, strand, part_off, part_pos, comp_off,
+    comp_pos)."""
+    rng = np.random.default_rng(seed + 977)
+    keep = np.nonzero(rng.random(arr.n) < 0.7)[0]
+    pos, strand, part_off, part_pos, comp_off, comp_pos = [], [], [0], [], [0], []
+    for i in keep:
+        pos.append(int(arr.pos[i]))
+        strand.append(int(arr.strand[i]) if rng.random() < 0.85 else 0)
+        p = arr.part_pos[int(arr.part_off[i]):int(arr.part_off[i + 1])].tolist()
+        c = arr.comp_pos[int(arr.comp_off[i]):int(arr.comp_off[i + 1])].tolist()
+        p = p[:int(rng.integers(0, len(p) + 1))]
+        c = [x for x in c if rng.random() < 0.7]
+        if rng.random() < 0.15 and len(arr.pos):      # a partner / competitor that is no row of the table at all
+            (p if rng.random() < 0.5 else c).append(int(arr.pos[int(rng.integers(0, arr.n))]) + int(rng.choice([-1, 1, 3])))
+            c = sorted(set(c))
+        part_pos.extend(p)
+        comp_pos.extend(c)
+        part_off.append(len(part_pos))
+        comp_off.append(len(comp_pos))
+    return dict(pos=np.asarray(pos, np.int64), strand=np.asarray(strand, np.uint8), part_off=np.asarray(part_off, np.uint32),
+                part_pos=np.asarray(part_pos, np.int64), comp_off=np.asarray(comp_off, np.uint32), comp_pos=np.asarray(comp_pos, np.int64))

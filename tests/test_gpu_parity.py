@@ -476,3 +476,25 @@ def test_process_cli_end_to_end_bam(ctx, tmp_path, oracle_lib):
         assert cli.main(argv) == 0
         got = open(str(tmp_path / case) + ".SpliSER.tsv").read()
         assert got == helpers.expected(case, variant)[0]
+
+
+@pytest.mark.parametrize("seed", range(0, 24))
+@pytest.mark.parametrize("stranded", [0, 1, 2])
+def test_gpu_query_tables_like_combine(seed, stranded, ctx, oracle_lib):
+    """Tables as `combine` asks about them: rows without links between them, partial partner / competitor lists, partners
+    that are no rows, rows without strand.  The range kernel's junction table is built from each row's own lists, so these
+    take the same path as `process` tables; both modes, against the oracle (and the pair kernel)."""
+    import randcase
+    arr, rs = randcase.make_case(seed + 300, bool(stranded))
+    q = randcase.query_table(arr, seed)
+    if not len(q["pos"]) or rs.n == 0:
+        pytest.skip("empty case")
+    sq = native.SiteArrays(q["pos"], q["strand"], q["part_off"], q["part_pos"], q["comp_off"], q["comp_pos"],
+                           part_site=np.full(len(q["part_pos"]), -1, np.int32))
+    r = native.ReadArrays(rs.pos, rs.flag, rs.cig_off, rs.cigar)
+    for combine in (0, 1):
+        want = oracle_lib.check_bam(q["pos"], q["strand"], q["part_off"], q["part_pos"], q["comp_off"], q["comp_pos"], rs.pos, rs.flag,
+                                    rs.cig_off, rs.cigar, stranded, combine)
+        for flags in KERNELS.values():
+            for w, g in zip(want, ctx.count(sq, r, stranded, combine, flags)):
+                assert np.array_equal(w, g)

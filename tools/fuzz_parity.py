@@ -58,4 +58,21 @@ with native.Context(0) as ctx:
                     n_reads += reads.n
                 dr.free()
             ds.free()
+            # the same reads against a query table as `combine` builds them (rows without links, partial lists)
+            q = randcase.query_table(arr, seed)
+            if len(q["pos"]):
+                sq = native.SiteArrays(q["pos"], q["strand"], q["part_off"], q["part_pos"], q["comp_off"], q["comp_pos"],
+                                       part_site=np.full(len(q["part_pos"]), -1, np.int32))
+                for reads in variants:
+                    r = native.ReadArrays(reads.pos, reads.flag, reads.cig_off, reads.cigar)
+                    for combine in (0, 1):
+                        want = oracle.check_bam(q["pos"], q["strand"], q["part_off"], q["part_pos"], q["comp_off"], q["comp_pos"], reads.pos,
+                                                reads.flag, reads.cig_off, reads.cigar, stranded, combine)
+                        got = ctx.count(sq, r, stranded, combine, 0)
+                        for name, w, g in zip(("beta1", "beta2s", "dbl"), want, got):
+                            if not np.array_equal(w, g):
+                                print("MISMATCH (query table) seed %d stranded %d combine %d reads %d: %s" % (seed, stranded, combine, reads.n, name))
+                                sys.exit(1)
+                        n_cases += 1
+                        n_reads += reads.n
 print("fuzz ok: seeds %d..%d, %d (case, mode) runs, %d reads, %.0f s" % (first, last, n_cases, n_reads, time.time() - t0))
