@@ -19,8 +19,7 @@ from ast import literal_eval
 
 import numpy as np
 
-from . import native, samio, shard
-from .process import open_alignments
+from . import native
 
 HEADER = ("Sample\tRegion\tSite\tStrand\tGene\tSSE\talpha_count\tbeta1_count\tbeta2Simple_count\tbeta2Cryptic_count\t"
           "beta2_weighted\tPartners\tCompetitors\n")
@@ -200,44 +199,60 @@ def gap_queries(merged):
     return per_sample
 
 
-def query_shards(queries, source):
-    """Pack one sample's queries with that sample's reads.  -> (shards, rows, absent) where rows[k] lists, for
-    shard k, (chrom, [site index per table row]) and ``absent`` the site indices on references the BAM lacks."""
-    by_chrom = {}
-    for q in queries:
-        by_chrom.setdefault(q[1], []).append(q)
-    items, keep, absent = [], {}, []
-    for chrom, qs in by_chrom.items():
-        reads = source.reads(chrom)
-        if reads is None or reads.n == 0:
-            absent.extend(q[0] for q in qs)
-            continue
-        qs.sort(key=lambda q: q[2])
-        items.append((chrom, _query_arrays(chrom, qs), reads))
-        keep[chrom] = [q[0] for q in qs]
-    shards = shard.pack(items) if items else []
-    rows = [[(chrom, keep[chrom]) for chrom in sh.chroms] for sh in shards]
-    return shards, rows, absent
+class _QueryTable(object):
+    """One sample's gap-fill queries in the shape ``process.process_sites`` counts: a table per chromosome (rows sorted by
+    position; strand, partners and competitors of a row as the walk had them when it reached that sample), and for every row
+    the index of the merged site it answers."""
+
+    def __init__(self, queries):
+        by_chrom = {}
+        for q in queries:
+            by_chrom.setdefault(q[1], []).append(q)
+        self.chrom_index = list(by_chrom)
+        self._arrays, self.site_index = {}, {}
+        for chrom, qs in by_chrom.items():
+            qs.sort(key=lambda q: q[2])
+            self._arrays[chrom] = _query_arrays(chrom, qs)
+            self.site_index[chrom] = [q[0] for q in qs]
+
+    def chrom_arrays(self, chrom):
+        return self._arrays[chrom]
 
 
 def fill_gaps(merged, bam_paths, is_stranded, stranded_type, devices=(0,), threads=0, log=_log):
-    """Answer every (site, sample) query on the GPU: each sample's BAM is decoded once, one combine-mode launch per
-    shard (``spl_count`` with ``combine_mode = 1``).  -> {(site index, sample idx): (beta1, beta2Simple)}"""
-    stranded = native.STRANDED_CODE[stranded_type] if is_stranded else 0
+    """Answer every (site, sample) query on the GPUs.  Each sample's BAM is decoded once, in the background; its chromosomes are
+    dealt to the devices (``process.process_sites``: one context per device, a chromosome goes to its GPU as soon as the decoder
+    has it complete) and counted in ``combine_mode`` (a flanking read counts toward beta2Simple, :529-536); several samples are
+    in flight at a time, each starting on another device.  -> {(site index, sample idx): (beta1, beta2Simple)}"""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import process as _process
+    per_sample = gap_queries(merged)
     results = {}
-    with native.Context(devices[0]) as ctx:
-        for idx, queries in sorted(gap_queries(merged).items()):
-            source = open_alignments(bam_paths[idx], threads=threads)
-            shards, rows, absent = query_shards(queries, source)
-            for si in absent:
-                results[(si, idx)] = (0, 0)
-            for sh, sh_rows in zip(shards, rows):
-                beta1, b2s, _ = ctx.count(sh.sites, sh.reads, stranded, 1)
-                for (chrom, sis), (r0, r1) in zip(sh_rows, sh.site_rows):
-                    for k, si in enumerate(sis):
-                        results[(si, idx)] = (int(beta1[r0 + k]), int(b2s[r0 + k]))
+    devices = tuple(devices)
+
+    def one(idx):
+        table = _QueryTable(per_sample[idx])
+        source = _process.open_alignments(bam_paths[idx], threads=threads, stream=True)
+        try:
+            devs = devices[idx % len(devices):] + devices[:idx % len(devices)]
+            out = _process.process_sites(table, source, "All", is_stranded, stranded_type, False, devices=devs, combine_mode=1,
+                                         log=lambda m: None)
+            if isinstance(source, native.BamFile) and not source.wait_all():   # not sorted by reference: again, from the whole decode
+                out = _process.process_sites(table, source, "All", is_stranded, stranded_type, False, devices=devs, combine_mode=1,
+                                             log=lambda m: None)
+        finally:
             if hasattr(source, "close"):
                 source.close()
+        res = {}
+        for chrom, (_, r) in out.items():
+            for k, si in enumerate(table.site_index[chrom]):
+                res[(si, idx)] = (int(r["beta1"][k]), int(r["beta2s_reads"][k]))
+        return res
+
+    order = sorted(per_sample)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(order), max(2, len(devices))))) as pool:
+        for res in pool.map(one, order):
+            results.update(res)
     return results
 
 

@@ -31,20 +31,57 @@ def junctions(inBAM, outputPath, isStranded=False, strandedType=None, minAnchor=
     stranded = native.STRANDED_CODE[strandedType] if isStranded else 0
     if isStranded and stranded == 0:
         raise ValueError("strandedType must be 'fr' or 'rf' for a stranded library")
-    source = _process.open_alignments(inBAM, threads=threads)
+    import threading
+    from . import shard
+    source = _process.open_alignments(inBAM, threads=threads, stream=True)
+    is_bam = isinstance(source, native.BamFile)
+    chroms = [c for c in source.ref_names if qChrom == c or qChrom == "All"]
+    lengths = dict(zip(source.ref_names, source.ref_lengths)) if is_bam else {c: (source.reads(c).n if source.reads(c) is not None else 0) for c in chroms}
+    plan = shard.assign({c: int(lengths.get(c, 1)) for c in chroms}, len(devices))   # chromosomes over the devices, longest first
+    tables, errors, lock = {}, [], threading.Lock()
+
+    def run(device, mine):
+        try:
+            with native.Context(device) as ctx:
+                for chrom in [c for c in chroms if c in mine]:     # (file order: a chromosome is complete when the next begins)
+                    with ctx.begin_reads() as dr:
+                        if is_bam:
+                            n = dr.add_bam(source, chrom)
+                        else:
+                            rs = source.reads(chrom)
+                            n = rs.n if rs is not None else 0
+                            if n:
+                                dr.add(native.ReadArrays(rs.pos, rs.flag, rs.cig_off, rs.cigar))
+                        if n == 0:
+                            continue
+                        dr.finish()
+                        table = dr.junctions(stranded, minAnchor, minIntron, maxIntron)
+                    with lock:
+                        tables[chrom] = (n, table)
+        except Exception as exc:
+            with lock:
+                errors.append(exc)
+    workers = [threading.Thread(target=run, args=(dev, set(mine))) for dev, mine in zip(devices, plan)]
+    for w in workers:
+        w.start()
+    for w in workers:
+        w.join()
+    try:
+        if errors:
+            raise errors[0]
+        if is_bam and not source.wait_all():
+            raise native.SpliserNativeError(-5, "%s is not sorted by reference: sort it (samtools sort) first" % inBAM)
+    finally:
+        if hasattr(source, "close"):
+            source.close()
     total = 0
-    with native.Context(devices[0]) as ctx, open(outputPath, "w") as out:
+    with open(outputPath, "w") as out:
         out.write('track name=junctions description="spliser_amd junctions (a>=%d, %d<=intron<=%d)"\n' % (minAnchor, minIntron, maxIntron))
-        for chrom in source.ref_names:
-            if not (qChrom == chrom or qChrom == "All"):
+        for chrom in chroms:
+            if chrom not in tables:
                 continue
-            reads = source.reads(chrom)
-            if reads is None or reads.n == 0:
-                continue
-            dr = ctx.upload_reads(native.ReadArrays(reads.pos, reads.flag, reads.cig_off, reads.cigar))
-            table = dr.junctions(stranded, minAnchor, minIntron, maxIntron)
-            dr.free()
+            n, table = tables[chrom]
             total += write_junction_bed(out, chrom, table, total + 1)
-            log("%s: %d reads, %d junctions" % (chrom, reads.n, len(table["left"])))
+            log("%s: %d reads, %d junctions" % (chrom, n, len(table["left"])))
     log("Junctions written:\t%d" % total)
     return total

@@ -135,10 +135,10 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                             dr.finish()
                             ctx.count_launch(ds, dr, stranded, combine_mode)
                             ctx.sse_launch(ds, is_beta2_cryptic)
-                            beta1, _, _ = ds.counters()
+                            beta1, b2r, _ = ds.counters()
                             b2s, b2c, b2w, sse = ds.sse_results()
                         res = dict(beta1=beta1[r0:r1].copy(), beta2_simple=b2s[r0:r1].copy(), beta2_cryptic=b2c[r0:r1].copy(),
-                                   beta2_weighted=b2w[r0:r1].copy(), sse=sse[r0:r1].copy())
+                                   beta2_weighted=b2w[r0:r1].copy(), sse=sse[r0:r1].copy(), beta2s_reads=b2r[r0:r1].copy())
                         with lock:
                             out[chrom] = (items[chrom][0], res)
                         if on_result is not None:

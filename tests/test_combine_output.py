@@ -52,16 +52,16 @@ def test_combine_host_walk_with_oracle_gap_fill(variant, tmp_path, oracle_lib):
     results = {}
     for idx, queries in cmb.gap_queries(merged).items():
         source = proc.open_alignments(bams[idx])
-        shards, srows, absent = cmb.query_shards(queries, source)
-        for si in absent:
-            results[(si, idx)] = (0, 0)
-        for sh, sh_rows in zip(shards, srows):
-            s, r = sh.sites, sh.reads
-            b1, b2, _ = oracle_lib.check_bam(s.pos, s.strand, s.part_off, s.part_pos, s.comp_off, s.comp_pos,
-                                             r.pos, r.flag, r.cig_off, r.cigar, stranded, 1)
-            for (chrom, sis), (r0, r1) in zip(sh_rows, sh.site_rows):
-                for k, si in enumerate(sis):
-                    results[(si, idx)] = (int(b1[r0 + k]), int(b2[r0 + k]))
+        table = cmb._QueryTable(queries)
+        for chrom in table.chrom_index:
+            s, r = table.chrom_arrays(chrom), source.reads(chrom)
+            if r is None or r.n == 0:
+                b1 = b2 = [0] * s.n
+            else:
+                b1, b2, _ = oracle_lib.check_bam(s.pos, s.strand, s.part_off, s.part_pos, s.comp_off, s.comp_pos,
+                                                 r.pos, r.flag, r.cig_off, r.cigar, stranded, 1)
+            for k, si in enumerate(table.site_index[chrom]):
+                results[(si, idx)] = (int(b1[k]), int(b2[k]))
     out = str(tmp_path / "all.combined.tsv")
     cmb.write_combined(out, merged, titles, results, f["cryptic"])
     assert open(out).read() == open(os.path.join(CASE, "expected.%s.combined.tsv" % variant)).read()
