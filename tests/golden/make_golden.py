@@ -380,6 +380,22 @@ def build_combine(outroot, name="combine_a", seed=21):
         json.dump({"n_samples": len(samples), "variants": manifest}, fh, indent=1, sort_keys=True)
 
 
+def diff_tree(fresh, committed, label):
+    """Every file of a regenerated case against the committed one, sub-directories included.  -> number of differences."""
+    bad = 0
+    cmp = filecmp.dircmp(fresh, committed)
+    if cmp.diff_files or cmp.left_only or cmp.right_only or cmp.funny_files:
+        print("MISMATCH", label, cmp.diff_files, cmp.left_only, cmp.right_only)
+        bad += 1
+    for f in cmp.common_files:      # (dircmp compares by stat signature first: make sure of the bytes)
+        if open(os.path.join(fresh, f), "rb").read() != open(os.path.join(committed, f), "rb").read():
+            print("MISMATCH", label, f)
+            bad += 1
+    for sub in cmp.common_dirs:
+        bad += diff_tree(os.path.join(fresh, sub), os.path.join(committed, sub), label + "/" + sub)
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -390,13 +406,14 @@ def main():
     if a.check:
         tmp = tempfile.mkdtemp()
         try:
-            build(tmp, a.names, cross_check=False)
+            names = [n for n in a.names if n != "combine_a"]
+            if names or not a.names:
+                build(tmp, names or None, cross_check=False)
+            if not a.names or "combine_a" in a.names:
+                build_combine(tmp)          # process x 3 samples -> combine / combineShallow x 7 variants -> output x 2
             bad = 0
             for name in sorted(os.listdir(tmp)):
-                cmp = filecmp.dircmp(os.path.join(tmp, name), os.path.join(HERE, name))
-                if cmp.diff_files or cmp.left_only or cmp.right_only:
-                    print("MISMATCH", name, cmp.diff_files, cmp.left_only, cmp.right_only)
-                    bad += 1
+                bad += diff_tree(os.path.join(tmp, name), os.path.join(HERE, name), name)
             sys.exit(1 if bad else 0)
         finally:
             shutil.rmtree(tmp)

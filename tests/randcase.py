@@ -9,7 +9,9 @@ import numpy as np
 from spliser_amd import samio, sites
 
 
-def make_case(seed, stranded):
+def make_case(seed, stranded, dirpath=None):
+    """-> (ChromArrays of the table built from the case's BED file, ReadSet).  With ``dirpath`` the inputs are also left there as
+    ``junctions.bed`` and ``reads.sam`` (what the reference takes)."""
     rng = np.random.default_rng(seed)
     n_pos = int(rng.integers(6, 18))
     positions = np.sort(rng.choice(np.arange(100, 100 + 40 * n_pos), n_pos, replace=False))
@@ -20,8 +22,8 @@ def make_case(seed, stranded):
         if not stranded and rng.random() < 0.3:
             strand = "?"
         juncs.append(("c1", int(positions[a]), int(positions[b]), int(rng.integers(0, 9)), strand))
-    tmp = tempfile.mkdtemp(prefix="spl_rand_")
-    bed = os.path.join(tmp, "j.bed")
+    tmp = dirpath or tempfile.mkdtemp(prefix="spl_rand_")
+    bed = os.path.join(tmp, "junctions.bed" if dirpath else "j.bed")
     with open(bed, "w") as fh:
         for (c, l, r, sc, st) in juncs:
             fh.write("%s\t%d\t%d\tJ\t%d\t%s\t%d\t%d\t0\t2\t10,10\t0,%d\n" % (c, l - 10, r + 10, sc, st, l - 10, r + 10, r - l + 10))
@@ -79,6 +81,11 @@ def make_case(seed, stranded):
             ops.append("%dM" % int(rng.integers(0, 60)))
             recs.append((flag, start, "".join(ops)))
     recs.sort(key=lambda r: r[1])
+    if dirpath:
+        with open(os.path.join(dirpath, "reads.sam"), "w") as fh:
+            fh.write("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c1\tLN:100000000\n")
+            for i, (flag, start, cig) in enumerate(recs):
+                fh.write("r%d\t%d\tc1\t%d\t60\t%s\t*\t0\t0\t*\t*\n" % (i, flag, start, cig))
     return arr, samio.ReadSet.from_records(recs)
 
 

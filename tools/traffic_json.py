@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch of the range kernel from the FETCH_SIZE / WRITE_SIZE passes of tools/prof_pmc.sh, as the JSON bench.py
+quotes in roofline.traffic (only for the workload and the library build it was measured with).
+   tools/traffic_json.py <tag> [the bench.py arguments of the profiled command]"""
+import collections
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, args = sys.argv[1], sys.argv[2:]
+
+
+def mean(counter, sub):
+    vals = collections.defaultdict(list)
+    for path in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, sub), "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter and "spl_count_ranges_kernel" in r["Kernel_Name"]:
+                vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    if not vals:
+        return None, 0
+    name = max(vals, key=lambda k: len(vals[k]))
+    return sum(vals[name]) / len(vals[name]), len(vals[name])
+
+
+fetch, n = mean("FETCH_SIZE", "fetch")
+write, _ = mean("WRITE_SIZE", "write")
+h = hashlib.sha256(open(os.path.join(ROOT, "spliser_amd", "libspliser_hip.so"), "rb").read()).hexdigest()[:16]
+workload = args[args.index("--workload") + 1] if "--workload" in args else "human"
+out = {"workload": workload, "bench_args": args, "lib_sha16": h, "kernel": "spl_count_ranges_kernel", "dispatches": n,
+       "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof_pmc.sh), means per dispatch",
+       "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+       "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read (MI355X_MICROARCH.md, HBM): x 2 for the "
+                     "record stream; this kernel's mix of 8 / 16 / 24-byte record loads and 8-byte gathers was calibrated at 1.927 on a "
+                     "stream of known size (profiles/r01e_traffic.json), which is what is applied; WRITE_SIZE is exact",
+       "hbm_bytes_per_launch": None if fetch is None else int(fetch * 1024 * 1.927 + (write or 0) * 1024)}
+print(json.dumps(out, indent=1))
