@@ -100,8 +100,7 @@ struct spl_dsites {
     int32_t diff_stride = 0, scan_blocks = 0;
     int32_t n_dpos = 0;        // distinct site positions
     int32_t *dpos_first_row = nullptr; // [n_dpos + 1]
-    uint2 *dbucket = nullptr;  // 32 bp buckets {first dpos, occupancy mask}
-    uint32_t *drival = nullptr; // per bucket: positions that are sites with rivals
+    spl_dbk *dbucket = nullptr; // 32 bp buckets {first dpos, occupancy mask, mask of flagged positions}
     uint32_t n_dbuckets = 0;
     int32_t dbase = 0;         // coordinate of the first (empty) bucket
     int32_t *flag_pos = nullptr; // ends of the junctions that have rivals (sorted; input of the bucket build)
@@ -511,7 +510,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     const size_t o_pos = take(4 * S), o_strand = take(S), o_flags = take(S), o_meta = take(16 * S), o_poff = take(4 * (S + 1));
     const size_t o_ppos = take(4 * P), o_psite = take(4 * P), o_cpos = take(4 * C);
     const size_t o_alpha = take(8 * S), o_ecnt = take(8 * P), o_bucket = take(4 * bucket.size());
-    const size_t o_dfirst = take(4 * dfirst.size()), o_dbucket = take(8 * (size_t)d->n_dbuckets), o_drival = take(4 * (size_t)d->n_dbuckets), o_fpos = take(4 * flag_pos.size());
+    const size_t o_dfirst = take(4 * dfirst.size()), o_dbucket = take(sizeof(spl_dbk) * (size_t)d->n_dbuckets), o_fpos = take(4 * flag_pos.size());
     const size_t o_jhash = take(16 * jhash.size()), o_jriv = take(16 * jrivals.size());
     const size_t o_cnt = off;
     const size_t o_b1 = take(4 * S), o_b2 = take(4 * S), o_dbl = take(4 * P);
@@ -526,7 +525,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the site table: %s", d->slab_bytes, hipGetErrorString(e)); }
     d->pos = (int32_t *)(d->slab + o_pos); d->strand = (uint8_t *)(d->slab + o_strand); d->meta = (uint4 *)(d->slab + o_meta);
     d->flags = (uint8_t *)(d->slab + o_flags); d->diff = (int32_t *)(d->slab + o_diff); d->block_sums = (int32_t *)(d->slab + o_bsum);
-    d->dpos_first_row = (int32_t *)(d->slab + o_dfirst); d->dbucket = (uint2 *)(d->slab + o_dbucket); d->drival = (uint32_t *)(d->slab + o_drival); d->flag_pos = (int32_t *)(d->slab + o_fpos);
+    d->dpos_first_row = (int32_t *)(d->slab + o_dfirst); d->dbucket = (spl_dbk *)(d->slab + o_dbucket); d->flag_pos = (int32_t *)(d->slab + o_fpos);
     d->jhash = (uint4 *)(d->slab + o_jhash); d->jrivals = (uint4 *)(d->slab + o_jriv);
     d->part_off = (uint32_t *)(d->slab + o_poff); d->part_pos = (int32_t *)(d->slab + o_ppos); d->part_site = (int32_t *)(d->slab + o_psite);
     d->comp_pos = (int32_t *)(d->slab + o_cpos); d->alpha = (int64_t *)(d->slab + o_alpha); d->edge_cnt = (int64_t *)(d->slab + o_ecnt);
@@ -562,7 +561,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (r == hipSuccess) r = up(d->bucket, bucket.data(), 4 * bucket.size());
     if (r == hipSuccess) r = hipMemset(d->slab + o_cnt, 0, d->slab_bytes > o_cnt ? d->slab_bytes - o_cnt : 0);
     if (r == hipSuccess && S > 0) {
-        r = (hipError_t)spl_dev_launch_build_dbuckets(d->pos, d->dpos_first_row, d->n_dpos, d->flag_pos, (int32_t)flag_pos.size(), d->dbase, d->n_dbuckets, d->dbucket, d->drival,
+        r = (hipError_t)spl_dev_launch_build_dbuckets(d->pos, d->dpos_first_row, d->n_dpos, d->flag_pos, (int32_t)flag_pos.size(), d->dbase, d->n_dbuckets, d->dbucket,
                                                       c->stream);
         if (r == hipSuccess) r = hipStreamSynchronize(c->stream);
     }
@@ -944,13 +943,13 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.site_pos = ds->pos; p.site_strand = ds->strand; p.site_flags = ds->flags; p.site_meta = ds->meta;
     p.part_pos = ds->part_pos; p.part_site = ds->part_site; p.comp_pos = ds->comp_pos;
     p.diff = ds->diff; p.diff_stride = ds->diff_stride;
-    p.dbucket = ds->dbucket; p.drival = ds->drival; p.n_dbuckets = ds->n_dbuckets; p.dbase = ds->dbase; p.n_dpos = ds->n_dpos;
+    p.dbucket = ds->dbucket; p.n_dbuckets = ds->n_dbuckets; p.dbase = ds->dbase; p.n_dpos = ds->n_dpos;
     p.dpos_first_row = ds->dpos_first_row;
     p.jhash = ds->jhash; p.jhash_mask = ds->jhash_mask; p.jrivals = ds->jrivals;
     spl_hot_params h;
     memset(&h, 0, sizeof(h));
     h.n_chunks = p.n_chunks; h.chunk_meta = dr->meta; h.chunk_order = dr->chunk_order; h.part_pos = ds->part_pos;
-    h.dbucket = p.dbucket; h.drival = p.drival; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos;
+    h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = queue; h.queue_n = ds->queue_n; h.err = ds->err;
     h.queue_cap = dr->queue_cap;

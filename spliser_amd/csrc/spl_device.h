@@ -42,6 +42,13 @@
 #define SPL_SF_PLUS 1u    // Site.strand == '+'
 #define SPL_SF_MINUS 2u   // Site.strand == '-'
 
+// Position index entry: one per 32 bp bucket of the shard's coordinate space.
+struct spl_dbk {
+    uint32_t first;  // distinct-position index ("dpos") of the first site at or after the bucket start
+    uint32_t occ;    // which of the bucket's 32 positions are sites
+    uint32_t rival;  // ... are ends of junctions that have rivals (not necessarily sites)
+};
+
 struct spl_count_params {
     // reads: the packed layout of spl_pack.h, one descriptor per chunk
     int64_t n_reads;
@@ -62,8 +69,7 @@ struct spl_count_params {
     int32_t bucket_base;
     int32_t bucket_shift;
     // position -> distinct-position index (range kernel): 64 bp buckets {first dpos, -, occupancy mask lo, hi}
-    const uint2 *dbucket;      // 32 bp buckets: {first dpos at or after the bucket start, occupancy mask}
-    const uint32_t *drival;    // per bucket: which of its positions are sites with rivals
+    const spl_dbk *dbucket;    // 32 bp buckets
     uint32_t n_dbuckets;
     int32_t dbase;
     int32_t n_dpos;
@@ -89,8 +95,7 @@ struct spl_hot_params {
     const spl_chunk_meta *chunk_meta; // [n_chunks] (spl_pack.h)
     const uint32_t *chunk_order; // [n_chunks] slot of an XCD slice -> chunk, longest chunk first within every slice
     const int32_t *part_pos;     // partner positions (CSR values): the twice-spliced junction-table pass scans a rival's list
-    const uint2 *dbucket;      // 32 bp buckets: {first dpos at or after the bucket start, occupancy mask}
-    const uint32_t *drival;    // per bucket: which of its positions are sites with rivals
+    const spl_dbk *dbucket;    // 32 bp buckets
     uint32_t n_dbuckets;
     int32_t dbase;
     int32_t n_dpos;
@@ -170,7 +175,7 @@ int spl_dev_launch_junctions(const spl_chunk_meta *chunk_meta, uint32_t n_chunks
                              uint32_t *vals, uint32_t n_slots, unsigned long long *out_keys,
                              uint32_t *out_vals, uint32_t *n_out, int32_t *err, void *stream);
 int spl_dev_launch_build_dbuckets(const int32_t *site_pos, const int32_t *dpos_first_row, int32_t n_dpos, const int32_t *flag_pos,
-                                  int32_t n_flag, int32_t dbase, uint32_t n_dbuckets, uint2 *out, uint32_t *out_rival, void *stream);
+                                  int32_t n_flag, int32_t dbase, uint32_t n_dbuckets, spl_dbk *out, void *stream);
 int spl_dev_launch_clear(void *region, size_t bytes, void *stream);
 int spl_dev_launch_literal(const spl_count_params *p, const spl_queue_params *q, void *stream);
 int spl_dev_launch_scan(const spl_scan_params *p, void *stream);

@@ -410,21 +410,44 @@ __device__ __forceinline__ uint32_t dbk_slot(const P &p, int32_t x)
     return (uint32_t)(b > last ? last : b);
 }
 
-// For x outside the table the clamped entry is an empty bucket: count 0, not a site, whatever the bit index says.
+// For x outside the table the clamped entry is an empty bucket: count 0, not a site, not flagged, whatever the bit index says.
 template <class P>
-__device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint2 e, int32_t &u, uint32_t &nv)
+__device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const spl_dbk &e, int32_t &u, uint32_t &nv)
 {
     const uint32_t bit = (uint32_t)(x - p.dbase) & 31u;
-    u = (int32_t)(e.x + (uint32_t)__popc(e.y & ((1u << bit) - 1u)));
-    nv = (e.y >> bit) & 1u;
+    u = (int32_t)(e.first + (uint32_t)__popc(e.occ & ((1u << bit) - 1u)));
+    nv = (e.occ >> bit) & 1u;
 }
 
-// The same with the rival mask of the bucket: rv = x is a site that has rivals.
+// The same with the bucket's mask of flagged positions: rv = x is an end of a junction that has rivals.
 template <class P>
-__device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const uint2 e, uint32_t rm, int32_t &u, uint32_t &nv, uint32_t &rv)
+__device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const spl_dbk &e, int32_t &u, uint32_t &nv, uint32_t &rv)
 {
     dbk_resolve(p, x, e, u, nv);
-    rv = (rm >> ((uint32_t)(x - p.dbase) & 31u)) & 1u;
+    rv = (e.rival >> ((uint32_t)(x - p.dbase) & 31u)) & 1u;
+}
+
+// Neighbouring reads of a sorted file cross the same buckets: instead of one gather per boundary (a vector memory instruction
+// each, 64 addresses through the address unit: the unit this kernel keeps busiest), a wave whose boundaries of one kind all
+// fall within 64 buckets of lane 0's loads those 64 entries ONCE, coalesced, lane i taking bucket base + i, and every lane then
+// picks its entries out of the wave's registers (ds_bpermute).  Lanes ahead of lane 0's bucket or more than 63 behind make the
+// wave fall back to gathers (unsorted input, sparse regions).
+__device__ __forceinline__ uint32_t lane_id() { return (uint32_t)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+template <class P>
+__device__ __forceinline__ spl_dbk coop_load(const P &p, uint32_t base)
+{
+    const uint32_t last = p.n_dbuckets - 1u, s = base + lane_id();
+    return p.dbucket[s > last ? last : s];
+}
+
+__device__ __forceinline__ spl_dbk coop_get(const spl_dbk &ent, uint32_t rel, bool with_rival)
+{
+    spl_dbk e;
+    e.first = (uint32_t)__shfl((int)ent.first, (int)rel);
+    e.occ = (uint32_t)__shfl((int)ent.occ, (int)rel);
+    e.rival = with_rival ? (uint32_t)__shfl((int)ent.rival, (int)rel) : 0u;
+    return e;
 }
 
 typedef __attribute__((address_space(3))) int32_t spl_lds_i32; // the difference windows, typed as what they are: LDS
@@ -749,7 +772,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     };
     if (wave < g_total) fetch(wave);
     int32_t wbase = 0;
-    { const int32_t fp = cv.first_pos + cv.shift; uint32_t nv; dbk_resolve(p, fp - 1, p.dbucket[dbk_slot(p, fp - 1)], wbase, nv); }
+    { const int32_t fp = cv.first_pos + cv.shift; uint32_t nv; const spl_dbk e = p.dbucket[dbk_slot(p, fp - 1)]; dbk_resolve(p, fp - 1, e, wbase, nv); }
     for (int j = tid; j < NARR * (WIN + 1); j += SPL_BLOCK) lds[j] = 0;
     __syncthreads();
     SPL_PHASE(1);
@@ -772,8 +795,18 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             //      nothing else can happen
             if (run == SPL_RC_SIMPLE) {
                 const int32_t c1 = pos + (int32_t)(ra.y >> 16);
-                const uint2 e0 = p.dbucket[dbk_slot(p, pos - 1)], e1 = p.dbucket[dbk_slot(p, c1 - 1)]; // ---- trip 2
-                fetch_next();
+                const uint32_t s0 = dbk_slot(p, pos - 1), s1 = dbk_slot(p, c1 - 1);
+                const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0);
+                spl_dbk e0, e1;
+                if (__all((s0 - base) < 64u && (s1 - base) < 64u)) {                                    // ---- trip 2, one load for the wave
+                    const spl_dbk ent = coop_load(p, base);
+                    fetch_next();
+                    e0 = coop_get(ent, s0 - base, false);
+                    e1 = coop_get(ent, s1 - base, false);
+                } else {
+                    e0 = p.dbucket[s0]; e1 = p.dbucket[s1];                                              // ---- trip 2, gathers
+                    fetch_next();
+                }
                 int32_t ua, ub; uint32_t nva, nvb;
                 dbk_resolve(p, pos - 1, e0, ua, nva);
                 dbk_resolve(p, c1 - 1, e1, ub, nvb);
@@ -791,47 +824,40 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             //      and the junction-table look-up when an end of the junction has rivals
             if (run == SPL_RC_MNM) {
                 const int32_t c0 = pos + (int32_t)(ra.y >> 16), c1 = c0 + (int32_t)rb.x, c2 = c1 + (int32_t)rb.y;
-                const uint32_t s1 = dbk_slot(p, c0 - 1), s2 = dbk_slot(p, c1 - 1);
-                const uint2 e0 = p.dbucket[dbk_slot(p, pos - 1)], e1 = p.dbucket[s1], e2 = p.dbucket[s2], e3 = p.dbucket[dbk_slot(p, c2 - 1)];
-                const uint32_t rm1 = p.drival[s1], rm2 = p.drival[s2]; // (the junction ends: which sites there have rivals)
+                const uint32_t s0 = dbk_slot(p, pos - 1), s1 = dbk_slot(p, c0 - 1), s2 = dbk_slot(p, c1 - 1), s3 = dbk_slot(p, c2 - 1);
+                // two groups of boundaries: around the read's start (pos - 1, c0 - 1) and beyond its intron (c1 - 1, c2 - 1)
+                const uint32_t base_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0), base_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s2);
+                const bool coop_a = __all((s0 - base_a) < 64u && (s1 - base_a) < 64u), coop_b = __all((s2 - base_b) < 64u && (s3 - base_b) < 64u);
+                // (registers: the shared loads of both groups go out at once; a group that cannot share one gathers its two
+                //  entries when its turn comes and pays the trip -- rare in sorted input)
+                spl_dbk ea, eb, ent_a = {0u, 0u, 0u}, ent_b = {0u, 0u, 0u};
+                if (coop_a) ent_a = coop_load(p, base_a);
+                if (coop_b) ent_b = coop_load(p, base_b);
                 fetch_next();
                 uint32_t sidx = 0;
                 if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
                 const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx;
-                // boundary by boundary, so that a bucket entry dies as soon as it is resolved (the kernel lives on 64 VGPRs)
-                int32_t ua, ub; uint32_t nva, nvb, rvb, rv1;
-                dbk_resolve(p, pos - 1, e0, ua, nva);
-                dbk_resolve(p, c0 - 1, e1, rm1, ub, nvb, rvb);
-                {
+                int32_t ua, ub; uint32_t nva, nvb, rv1, rv2;
+                auto range = [&](uint32_t arr) {
                     const int32_t lo = ua + (int32_t)nva;
                     const bool em = alive && ub > lo;
                     if (__any(em)) {
-                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | sidx, 1);
-                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | sidx, -1);
+                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | arr, 1);
+                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | arr, -1);
                     }
-                }
-                rv1 = rvb;
-                ua = ub; nva = nvb;
-                dbk_resolve(p, c1 - 1, e2, rm2, ub, nvb, rvb);
-                {
-                    const int32_t lo = ua + (int32_t)nva;
-                    const bool em = alive && ub > lo;
-                    if (__any(em)) {
-                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | a_me, 1);
-                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | a_me, -1);
-                    }
-                }
-                const uint32_t rv2 = rvb;
-                ua = ub; nva = nvb;
-                dbk_resolve(p, c2 - 1, e3, ub, nvb);
-                {
-                    const int32_t lo = ua + (int32_t)nva;
-                    const bool em = alive && ub > lo;
-                    if (__any(em)) {
-                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | sidx, 1);
-                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | sidx, -1);
-                    }
-                }
+                    ua = ub; nva = nvb;
+                };
+                if (coop_a) { ea = coop_get(ent_a, s0 - base_a, false); eb = coop_get(ent_a, s1 - base_a, true); }
+                else { ea = p.dbucket[s0]; eb = p.dbucket[s1]; }
+                dbk_resolve(p, pos - 1, ea, ua, nva);
+                dbk_resolve(p, c0 - 1, eb, ub, nvb, rv1);
+                range(sidx);                        // block 1
+                if (coop_b) { ea = coop_get(ent_b, s2 - base_b, true); eb = coop_get(ent_b, s3 - base_b, false); }
+                else { ea = p.dbucket[s2]; eb = p.dbucket[s3]; }
+                dbk_resolve(p, c1 - 1, ea, ub, nvb, rv2);
+                range(a_me);                        // the intron
+                dbk_resolve(p, c2 - 1, eb, ub, nvb);
+                range(sidx);                        // block 2
                 const bool flagged = alive && ((rv1 | rv2) != 0u); // an end of the junction (c0 - 1, c1 - 1) is an end of a junction with rivals
                 if (__any(flagged)) {
                     push_front(flagged && p.combine_mode, slot);
@@ -848,10 +874,19 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 uint32_t sidx2 = 0;
                 if (STRANDED) sidx2 = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
                 const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx2;
-                const uint32_t s1 = dbk_slot(p, c0 - 1), s2 = dbk_slot(p, c1 - 1), s3 = dbk_slot(p, c2 - 1), s4 = dbk_slot(p, c3 - 1);
-                uint2 f0 = p.dbucket[dbk_slot(p, pos - 1)], f1 = p.dbucket[s1];
-                const uint2 f2 = p.dbucket[s2], f3 = p.dbucket[s3];
-                const uint32_t rm1 = p.drival[s1], rm2 = p.drival[s2], rm3 = p.drival[s3]; // (the junction ends)
+                const uint32_t s0 = dbk_slot(p, pos - 1), s1 = dbk_slot(p, c0 - 1), s2 = dbk_slot(p, c1 - 1), s3 = dbk_slot(p, c2 - 1);
+                const uint32_t s4 = dbk_slot(p, c3 - 1), s5 = dbk_slot(p, c4 - 1);
+                // three groups of boundaries, one per aligned block
+                const uint32_t base_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0), base_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s2);
+                const uint32_t base_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)s4);
+                const bool coop_a = __all((s0 - base_a) < 64u && (s1 - base_a) < 64u), coop_b = __all((s2 - base_b) < 64u && (s3 - base_b) < 64u);
+                const bool coop_c = __all((s4 - base_c) < 64u && (s5 - base_c) < 64u);
+                // (registers: the shared loads of all three groups go out at once; a group that cannot share one gathers its
+                //  two entries when its turn comes and pays the trip -- rare in sorted input)
+                spl_dbk fa, fb, ent_a = {0u, 0u, 0u}, ent_b = {0u, 0u, 0u}, ent_c = {0u, 0u, 0u};
+                if (coop_a) ent_a = coop_load(p, base_a);
+                if (coop_b) ent_b = coop_load(p, base_b);
+                if (coop_c) ent_c = coop_load(p, base_c);
                 fetch_next();
                 int32_t ua, ub; uint32_t nva, nvb, rvb;
                 uint32_t fl1 = 0, fl2 = 0; // junction 1 / 2 has an end with rivals
@@ -864,23 +899,26 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                     }
                     ua = ub; nva = nvb;
                 };
-                dbk_resolve(p, pos - 1, f0, ua, nva);
-                dbk_resolve(p, c0 - 1, f1, rm1, ub, nvb, rvb);
+                if (coop_a) { fa = coop_get(ent_a, s0 - base_a, false); fb = coop_get(ent_a, s1 - base_a, true); }
+                else { fa = p.dbucket[s0]; fb = p.dbucket[s1]; }
+                dbk_resolve(p, pos - 1, fa, ua, nva);
+                dbk_resolve(p, c0 - 1, fb, ub, nvb, rvb);
                 range(sidx2);                       // block 1
                 fl1 |= rvb;
-                f0 = p.dbucket[s4];                  // the second trip, under way while the first is worked off
-                f1 = p.dbucket[dbk_slot(p, c4 - 1)];
-                const uint32_t rm4 = p.drival[s4];
-                dbk_resolve(p, c1 - 1, f2, rm2, ub, nvb, rvb);
+                if (coop_b) { fa = coop_get(ent_b, s2 - base_b, true); fb = coop_get(ent_b, s3 - base_b, true); }
+                else { fa = p.dbucket[s2]; fb = p.dbucket[s3]; }
+                dbk_resolve(p, c1 - 1, fa, ub, nvb, rvb);
                 range(a_me);                        // intron 1
                 fl1 |= rvb;
-                dbk_resolve(p, c2 - 1, f3, rm3, ub, nvb, rvb);
+                dbk_resolve(p, c2 - 1, fb, ub, nvb, rvb);
                 range(sidx2);                       // block 2
                 fl2 |= rvb;
-                dbk_resolve(p, c3 - 1, f0, rm4, ub, nvb, rvb);
+                if (coop_c) { fa = coop_get(ent_c, s4 - base_c, true); fb = coop_get(ent_c, s5 - base_c, false); }
+                else { fa = p.dbucket[s4]; fb = p.dbucket[s5]; }
+                dbk_resolve(p, c3 - 1, fa, ub, nvb, rvb);
                 range(a_me);                        // intron 2
                 fl2 |= rvb;
-                dbk_resolve(p, c4 - 1, f1, ub, nvb);
+                dbk_resolve(p, c4 - 1, fb, ub, nvb);
                 range(sidx2);                       // block 3
                 const bool flagged = alive && ((fl1 | fl2) != 0u);
                 if (__any(flagged)) {
@@ -927,17 +965,15 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                         kind[k] = alive ? kd : 0u;
                     }
                 }
-                uint2 e0 = make_uint2(0, 0), ek[SPL_INLINE_OPS]; // ---- trip 2: the boundaries' bucket entries and rival masks
-                uint32_t r0 = 0, rk[SPL_INLINE_OPS];
-                if (first) { const uint32_t sl = dbk_slot(p, pos - 1); e0 = p.dbucket[sl]; r0 = p.drival[sl]; }
+                spl_dbk e0 = {0u, 0u, 0u}, ek[SPL_INLINE_OPS]; // ---- trip 2: the boundaries' bucket entries
+                if (first) e0 = p.dbucket[dbk_slot(p, pos - 1)];
 #pragma unroll
-                for (int k = 0; k < SPL_INLINE_OPS; ++k) { const uint32_t sl = dbk_slot(p, cend[k] - 1); ek[k] = p.dbucket[sl]; rk[k] = p.drival[sl]; }
-                if (first) fetch_next();
-                if (first) dbk_resolve(p, pos - 1, e0, r0, pu, pnv, prv);
+                for (int k = 0; k < SPL_INLINE_OPS; ++k) ek[k] = p.dbucket[dbk_slot(p, cend[k] - 1)];
+                if (first) dbk_resolve(p, pos - 1, e0, pu, pnv, prv);
 #pragma unroll
                 for (int k = 0; k < SPL_INLINE_OPS; ++k) {
                     int32_t u; uint32_t nv, rv;
-                    dbk_resolve(p, cend[k] - 1, ek[k], rk[k], u, nv, rv);
+                    dbk_resolve(p, cend[k] - 1, ek[k], u, nv, rv);
                     const uint32_t kk = (first || mine) ? kind[k] : 0u;
                     const int32_t lo = pu + (int32_t)pnv; // first dpos at or after the op's first base
                     const bool emit = kk != 0u && kk != 3u && u > lo;
@@ -957,6 +993,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 for (int k = 0; k < SPL_INLINE_OPS; ++k) op[k] = (more && k_next + (uint32_t)k < n_ops) ? cv.wide[o0 + k_next + (uint32_t)k] : 0xfu;
                 k_next += (uint32_t)SPL_INLINE_OPS;
             }
+            fetch_next(); // (this path asks late: its batches of bucket entries need the registers, and it is the rare one)
             if (bad) atomicOr(p.err, SPL_DEV_ERR_RANGE);
             // (a junction with rivals outside the spliced classes -- indels next to it, three and more junctions -- is the
             //  literal kernel's business)
@@ -1552,7 +1589,7 @@ __global__ __launch_bounds__(256) void spl_junction_compact_kernel(const unsigne
 // (On the host this was a serial sweep over all buckets: 0.3 s for a mammalian genome.)
 __global__ __launch_bounds__(256) void spl_build_dbuckets_kernel(const int32_t *site_pos, const int32_t *dpos_first_row, int32_t n_dpos,
                                                                  const int32_t *flag_pos, int32_t n_flag, int32_t dbase, uint32_t n_dbuckets,
-                                                                 uint2 *out, uint32_t *out_rival)
+                                                                 spl_dbk *out)
 {
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b >= n_dbuckets) return;
@@ -1578,8 +1615,9 @@ __global__ __launch_bounds__(256) void spl_build_dbuckets_kernel(const int32_t *
         if (pj >= start + 32) break;
         rm |= 1u << (pj - start);
     }
-    out[b] = make_uint2((uint32_t)lo, mask);
-    out_rival[b] = rm;
+    spl_dbk e;
+    e.first = (uint32_t)lo; e.occ = mask; e.rival = rm;
+    out[b] = e;
 }
 
 // Everything a counting pass starts from zero (the counter region of the site table: counters, difference arrays, queue
@@ -1612,11 +1650,11 @@ extern "C" int spl_dev_launch_junctions(const spl_chunk_meta *chunk_meta, uint32
 }
 
 extern "C" int spl_dev_launch_build_dbuckets(const int32_t *site_pos, const int32_t *dpos_first_row, int32_t n_dpos, const int32_t *flag_pos,
-                                             int32_t n_flag, int32_t dbase, uint32_t n_dbuckets, uint2 *out, uint32_t *out_rival, void *stream)
+                                             int32_t n_flag, int32_t dbase, uint32_t n_dbuckets, spl_dbk *out, void *stream)
 {
     if (n_dbuckets == 0) return 0;
     hipLaunchKernelGGL(spl_build_dbuckets_kernel, dim3((n_dbuckets + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, site_pos, dpos_first_row,
-                       n_dpos, flag_pos, n_flag, dbase, n_dbuckets, out, out_rival);
+                       n_dpos, flag_pos, n_flag, dbase, n_dbuckets, out);
     return (int)hipGetLastError();
 }
 
