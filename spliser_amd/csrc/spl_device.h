@@ -17,6 +17,10 @@
 // The range kernel deals the wave-iterations of a chunk (64 reads of ONE run each; at most 32 + 3 of them: a run's last one may
 // be partial) round-robin to its waves: at most SPL_WAVE_ITERS per wave, and as many list entries (s_q) per wave.
 #define SPL_WAVE_ITERS 9
+#ifndef SPL_K_SIMPLE
+#define SPL_K_SIMPLE 4                   // reads per lane and wave-iteration: simple reads (8-byte records)
+#define SPL_K_MNM 2                      // ... once-spliced reads (16-byte records)
+#endif
 #define SPL_WAVE_READS (64 * SPL_WAVE_ITERS)
 #define SPL_WIN 1020                     // distinct site positions a workgroup privatises in LDS (pair kernel; range kernel unstranded)
 #define SPL_WIN_STRANDED 988             // ... range kernel, stranded: 4 windows + the lists, 8 workgroups in 160 KB

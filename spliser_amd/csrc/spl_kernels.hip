@@ -59,9 +59,14 @@ __device__ __forceinline__ uint32_t my_chunk()
 // ---- the packed read layout (spl_pack.h), device side ---------------------------------------------------
 
 // A chunk's descriptor as wave-uniform values (the index is uniform: scalar loads).
+// (the addresses arrive as integers: typed as GLOBAL pointers, or every load through them is a flat_load -- and a wave with a
+//  flat load outstanding can only ever wait for ALL its memory operations, which is the end of any prefetching)
+#define SPL_GLOBAL __attribute__((address_space(1)))
+typedef SPL_GLOBAL const char spl_gchar;
+typedef SPL_GLOBAL const uint32_t spl_gu32;
 struct ChunkView {
-    const char *rec;
-    const uint32_t *wide;
+    spl_gchar *rec;
+    spl_gu32 *wide;
     int32_t shift, first_pos;
     uint32_t start[SPL_RC_RUNS + 1]; // slot (run order) of the first read of each run; start[4] = reads in the chunk
     uint32_t off[SPL_RC_RUNS];       // byte offset of each run in the record area
@@ -71,8 +76,8 @@ __device__ __forceinline__ ChunkView chunk_view(const spl_chunk_meta *meta)
 {
     const uint4 a = *(const uint4 *)meta, b = *((const uint4 *)meta + 1);
     ChunkView v;
-    v.rec = (const char *)(((uint64_t)a.y << 32) | a.x);
-    v.wide = (const uint32_t *)(((uint64_t)a.w << 32) | a.z);
+    v.rec = (spl_gchar *)(((uint64_t)a.y << 32) | a.x);
+    v.wide = (spl_gu32 *)(((uint64_t)a.w << 32) | a.z);
     v.shift = (int32_t)b.x;
     v.first_pos = (int32_t)b.y;
     const uint32_t n0 = b.z & 0xffffu, n1 = b.z >> 16, n2 = b.w & 0xffffu, n3 = b.w >> 16;
@@ -95,18 +100,18 @@ __device__ __forceinline__ ReadView read_at(const ChunkView &cv, uint32_t slot, 
     v.ops = row;
     int32_t pos0;
     if (slot < cv.start[1]) {
-        const uint2 r = *(const uint2 *)(cv.rec + (size_t)(cv.off[0] + SPL_REC_SIMPLE * slot));
+        const uint2 r = *(SPL_GLOBAL const uint2 *)(cv.rec + (size_t)(cv.off[0] + SPL_REC_SIMPLE * slot));
         pos0 = (int32_t)r.x; v.flag = r.y & 0xffffu;
         row[0] = (r.y >> 16) << 4;
         v.n_ops = 1u;
     } else if (slot < cv.start[2]) {
-        const uint4 r = *(const uint4 *)(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot - cv.start[1])));
+        const uint4 r = *(SPL_GLOBAL const uint4 *)(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot - cv.start[1])));
         pos0 = (int32_t)r.x; v.flag = r.y & 0xffffu;
         row[0] = (r.y >> 16) << 4; row[1] = (r.z << 4) | (uint32_t)SPL_OP_N; row[2] = r.w << 4;
         v.n_ops = 3u;
     } else {
         const bool m2 = slot < cv.start[3];
-        const uint2 *q = (const uint2 *)(cv.rec + (size_t)(m2 ? cv.off[2] + SPL_REC_M2 * (slot - cv.start[2])
+        SPL_GLOBAL const uint2 *q = (SPL_GLOBAL const uint2 *)(cv.rec + (size_t)(m2 ? cv.off[2] + SPL_REC_M2 * (slot - cv.start[2])
                                                                 : cv.off[3] + SPL_REC_OTHER * (slot - cv.start[3])));
         const uint2 r0 = q[0], r1 = q[1], r2 = q[2];
         pos0 = (int32_t)r0.x; v.flag = r0.y & 0xffffu;
@@ -116,7 +121,7 @@ __device__ __forceinline__ ReadView read_at(const ChunkView &cv, uint32_t slot, 
             v.n_ops = 5u;
         } else {
             v.n_ops = r2.y;
-            if ((r0.y >> SPL_RC_SHIFT) == SPL_RC_WIDE) v.ops = cv.wide + r2.x;
+            if ((r0.y >> SPL_RC_SHIFT) == SPL_RC_WIDE) v.ops = (const uint32_t *)(cv.wide + r2.x);
             else { row[0] = r1.x; row[1] = r1.y; row[2] = r2.x; }
         }
     }
@@ -427,29 +432,6 @@ __device__ __forceinline__ void dbk_resolve(const P &p, int32_t x, const spl_dbk
     rv = (e.rival >> ((uint32_t)(x - p.dbase) & 31u)) & 1u;
 }
 
-// Neighbouring reads of a sorted file cross the same buckets: instead of one gather per boundary (a vector memory instruction
-// each, 64 addresses through the address unit: the unit this kernel keeps busiest), a wave whose boundaries of one kind all
-// fall within 64 buckets of lane 0's loads those 64 entries ONCE, coalesced, lane i taking bucket base + i, and every lane then
-// picks its entries out of the wave's registers (ds_bpermute).  Lanes ahead of lane 0's bucket or more than 63 behind make the
-// wave fall back to gathers (unsorted input, sparse regions).
-__device__ __forceinline__ uint32_t lane_id() { return (uint32_t)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
-template <class P>
-__device__ __forceinline__ spl_dbk coop_load(const P &p, uint32_t base)
-{
-    const uint32_t last = p.n_dbuckets - 1u, s = base + lane_id();
-    return p.dbucket[s > last ? last : s];
-}
-
-__device__ __forceinline__ spl_dbk coop_get(const spl_dbk &ent, uint32_t rel, bool with_rival)
-{
-    spl_dbk e;
-    e.first = (uint32_t)__shfl((int)ent.first, (int)rel);
-    e.occ = (uint32_t)__shfl((int)ent.occ, (int)rel);
-    e.rival = with_rival ? (uint32_t)__shfl((int)ent.rival, (int)rel) : 0u;
-    return e;
-}
-
 typedef __attribute__((address_space(3))) int32_t spl_lds_i32; // the difference windows, typed as what they are: LDS
 
 // All 64 lanes call this together.  Lanes that add `sign` to the same key = (dpos << 2 | array) and sit next to each
@@ -733,42 +715,47 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     const ChunkView cv = chunk_view(p.chunk_meta + chunk);
     SPL_PHASE_DECL;
     SPL_PHASE(0);
-    // wave-iterations of the chunk: run r has iters[r] of them, the first being number g_start[r] of the chunk
+    // Wave-iterations of the chunk.  A wave-iteration takes 64 * K consecutive reads of ONE run, K per lane: K = 4 for simple reads
+    // (32 bytes of records per lane), 2 for once-spliced ones (32 bytes), 1 for the rest (24 bytes).  Run r has iters[r]
+    // wave-iterations, the first being number g_start[r] of the chunk.
+    // Why several reads per lane: vector-memory results come back in order, so waiting for this iteration's bucket entries also
+    // waits for the next iteration's records -- a wave never has more than ONE load of the stream in flight across that wait, and
+    // every iteration costs a round trip to HBM.  What can grow is the size of that one load: 2 KB per wave instead of 512 bytes.
+    constexpr uint32_t KS = SPL_K_SIMPLE, KM = SPL_K_MNM;
     uint32_t g_start[SPL_RC_RUNS + 1];
     g_start[0] = 0;
-#pragma unroll
-    for (int r = 0; r < SPL_RC_RUNS; ++r) g_start[r + 1] = g_start[r] + ((cv.start[r + 1] - cv.start[r] + 63u) >> 6);
+    g_start[1] = (cv.start[1] + 64u * KS - 1u) / (64u * KS);
+    g_start[2] = g_start[1] + (cv.start[2] - cv.start[1] + 64u * KM - 1u) / (64u * KM);
+    g_start[3] = g_start[2] + ((cv.start[3] - cv.start[2] + 63u) >> 6);
+    g_start[4] = g_start[3] + ((cv.start[4] - cv.start[3] + 63u) >> 6);
     const uint32_t g_total = live ? g_start[SPL_RC_RUNS] : 0u;
-    // where wave-iteration g is: its run, the slot of this lane's read in the chunk (clamped into the run: lanes past the end
-    // of a partial iteration re-read the run's last record and are masked), the byte offset of that record
-    // (select chains, no indexing by `run`: the descriptor stays in scalar registers)
-    auto locate = [&](uint32_t g, uint32_t &run, uint32_t &slot, bool &valid, uint32_t &byte_off) {
-        run = (g >= g_start[1] ? 1u : 0u) + (g >= g_start[2] ? 1u : 0u) + (g >= g_start[3] ? 1u : 0u);
-        uint32_t gs = 0, s0 = 0, n_run = cv.start[1], off = 0, size = SPL_REC_SIMPLE;
-        if (run == 1u) { gs = g_start[1]; s0 = cv.start[1]; n_run = cv.start[2] - cv.start[1]; off = cv.off[1]; size = SPL_REC_MNM; }
-        if (run == 2u) { gs = g_start[2]; s0 = cv.start[2]; n_run = cv.start[3] - cv.start[2]; off = cv.off[2]; size = SPL_REC_M2; }
-        if (run == 3u) { gs = g_start[3]; s0 = cv.start[3]; n_run = cv.start[4] - cv.start[3]; off = cv.off[3]; size = SPL_REC_OTHER; }
-        const uint32_t i = ((g - gs) << 6) + lane;
-        valid = i < n_run;
-        const uint32_t idx = valid ? i : n_run - 1u;
-        slot = s0 + idx;
-        byte_off = off + idx * size;
-    };
     // Pipeline over the wave's iterations: while one is worked on the records of the next are in flight
     // (its bucket entries too was tried: 25 more registers, occupancy 4, slower).
     // (plain loads: marking the stream non-temporal looked 3...11 % faster in a benchmark that runs pass after pass
     //  over one 400 MB sample -- the words then survive in the 256 MB last-level cache from one pass to
     //  the next -- and is 2...5 % SLOWER when every pass reads a different copy of the sample: DESIGN.md section 6)
-    uint2 cu_a = make_uint2(0, 0), cu_b = make_uint2(0, 0), cu_c = make_uint2(0, 0); // ---- trip 1: 8, 16 or 24 bytes per read
-    uint32_t cu_run = 0, cu_slot = 0;
-    bool cu_valid = false;
+    struct alignas(8) W4 { uint32_t x, y, z, w; };
+    W4 cu0 = {0, 0, 0, 0}, cu1 = {0, 0, 0, 0};       // ---- trip 1: 32 or 24 bytes of records per lane
+    uint32_t cu_i0 = 0;                               // the index, in its run, of the lane's first read
+    // (select chains, no indexing by `run`: the descriptor stays in scalar registers)
     auto fetch = [&](uint32_t g) {
-        uint32_t off;
-        locate(g, cu_run, cu_slot, cu_valid, off);
-        const char *r = cv.rec + (size_t)off;
-        if (cu_run == 0u) cu_a = *(const uint2 *)r;
-        else if (cu_run == 1u) { const uint4 q = *(const uint4 *)r; cu_a = make_uint2(q.x, q.y); cu_b = make_uint2(q.z, q.w); }
-        else { cu_a = *(const uint2 *)r; const uint4 q = *(const uint4 *)(r + 8); cu_b = make_uint2(q.x, q.y); cu_c = make_uint2(q.z, q.w); }
+        const uint32_t run = (g >= g_start[1] ? 1u : 0u) + (g >= g_start[2] ? 1u : 0u) + (g >= g_start[3] ? 1u : 0u);
+        uint32_t gs = 0, n_run = cv.start[1], off = 0, size = SPL_REC_SIMPLE, per = KS;
+        if (run == 1u) { gs = g_start[1]; n_run = cv.start[2] - cv.start[1]; off = cv.off[1]; size = SPL_REC_MNM; per = KM; }
+        if (run == 2u) { gs = g_start[2]; n_run = cv.start[3] - cv.start[2]; off = cv.off[2]; size = SPL_REC_M2; per = 1u; }
+        if (run == 3u) { gs = g_start[3]; n_run = cv.start[4] - cv.start[3]; off = cv.off[3]; size = SPL_REC_OTHER; per = 1u; }
+        const uint32_t i0 = (((g - gs) << 6) + lane) * per;
+
+        cu_i0 = i0;
+        // (a lane wholly past the end of the run reads the run's first records and is masked; a lane whose LAST reads are past
+        //  the end reads at most 24 bytes beyond the run: other runs, or the padding every segment's allocation ends with)
+        // Always the same two 16-byte loads, no branch anywhere in here: the compiler counts outstanding loads statically, and
+        // only if every way through the loop body issues the same number after the bucket loads can the wait for the bucket
+        // entries leave these two in flight (a branch here turns that wait into "wait for everything").  A 24-byte record's
+        // second load takes 8 bytes of its neighbour along.
+        spl_gchar *r = cv.rec + (size_t)(off + (i0 < n_run ? i0 : 0u) * size);
+        cu0 = *(SPL_GLOBAL const W4 *)r;
+        cu1 = *(SPL_GLOBAL const W4 *)(r + 16);
     };
     if (wave < g_total) fetch(wave);
     int32_t wbase = 0;
@@ -776,66 +763,74 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     for (int j = tid; j < NARR * (WIN + 1); j += SPL_BLOCK) lds[j] = 0;
     __syncthreads();
     SPL_PHASE(1);
+    // (the first two words of a bucket entry: all a boundary needs that is no junction end)
+    auto dbk2 = [&](uint32_t s) { const uint32_t *q = (const uint32_t *)(p.dbucket + s); spl_dbk e; e.first = q[0]; e.occ = q[1]; e.rival = 0u; return e; };
 
     {
-        for (uint32_t g = wave; g < g_total; g += NWAVE) {
-            // Straight-line up to the commits: lanes past the end of a run re-read its last read and are masked, so all
-            // loads of a trip issue back to back.  Control flow is wave-uniform around every commit_key (all 64 lanes
-            // reach it).
-            const uint32_t run = cu_run;
-            const uint32_t slot = cu_slot;                  // of the read in its chunk, run order
-            bool alive = cu_valid;
-            const uint2 ra = cu_a, rb = cu_b, rc = cu_c;
-            const int32_t pos = (int32_t)ra.x + cv.shift;
-            const uint32_t flag = ra.y & 0xffffu;
-            // (the next iteration's records are asked for right AFTER this read's bucket entries, in each path: memory
-            //  operations retire in order, and the entries must not wait for the stream)
-            auto fetch_next = [&]() { if (g + NWAVE < g_total) fetch(g + NWAVE); };
-            // ---- simple reads (one aligned op, mapped, in range: the packer checked all that): two boundaries, one range,
-            //      nothing else can happen
-            if (run == SPL_RC_SIMPLE) {
-                const int32_t c1 = pos + (int32_t)(ra.y >> 16);
-                const uint32_t s0 = dbk_slot(p, pos - 1), s1 = dbk_slot(p, c1 - 1);
-                const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0);
-                spl_dbk e0, e1;
-                if (__all((s0 - base) < 64u && (s1 - base) < 64u)) {                                    // ---- trip 2, one load for the wave
-                    const spl_dbk ent = coop_load(p, base);
-                    fetch_next();
-                    e0 = coop_get(ent, s0 - base, false);
-                    e1 = coop_get(ent, s1 - base, false);
-                } else {
-                    e0 = p.dbucket[s0]; e1 = p.dbucket[s1];                                              // ---- trip 2, gathers
-                    fetch_next();
-                }
+        // One loop per run, the wave's iterations g = wave, wave + 4, ... running through all of them; the records of the NEXT
+        // iteration -- of this run or the next -- are asked for right AFTER this iteration's bucket entries (memory operations
+        // retire in order, and the entries must not wait for the stream), in straight-line code: one place per loop body, so
+        // that no pass of the compiler finds common code to move to the end of the iteration.
+        // Straight-line up to the commits: lanes past the end of a run are masked, all loads of a trip issue back to
+        // back.  Control flow is wave-uniform around every commit_key (all 64 lanes reach it).
+        uint32_t g = wave;
+        auto fetch_next = [&]() { fetch(g + NWAVE < g_total ? g + NWAVE : g); }; // (the last iteration asks for itself again)
+        // ---- simple reads (one aligned op, mapped, in range: the packer checked all that): two boundaries, one range,
+        //      nothing else can happen.  Four of them per lane.
+        for (; g < g_start[1]; g += NWAVE) {
+            const uint32_t i0 = cu_i0;
+            const W4 r0 = cu0, r1 = cu1;
+            const uint32_t n_run = cv.start[1];
+            const uint32_t w[2 * KS] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            int32_t pos[KS], c1[KS];
+            spl_dbk e0[KS], e1[KS];
+#pragma unroll
+            for (uint32_t j = 0; j < KS; ++j) {
+                pos[j] = (int32_t)w[2 * j] + cv.shift;
+                c1[j] = pos[j] + (int32_t)(w[2 * j + 1] >> 16);
+                e0[j] = dbk2(dbk_slot(p, pos[j] - 1));                                               // ---- trip 2
+                e1[j] = dbk2(dbk_slot(p, c1[j] - 1));
+            }
+            fetch_next();
+#pragma unroll
+            for (uint32_t j = 0; j < KS; ++j) {
                 int32_t ua, ub; uint32_t nva, nvb;
-                dbk_resolve(p, pos - 1, e0, ua, nva);
-                dbk_resolve(p, c1 - 1, e1, ub, nvb);
+                dbk_resolve(p, pos[j] - 1, e0[j], ua, nva);
+                dbk_resolve(p, c1[j] - 1, e1[j], ub, nvb);
                 const int32_t lo = ua + (int32_t)nva;
-                const bool emit = alive && ub > lo;
+                const bool emit = i0 + j < n_run && ub > lo;
                 uint32_t arr = 0;
-                if (STRANDED) arr = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
+                if (STRANDED) arr = (spl_read_strand(w[2 * j + 1] & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
                 if (__any(emit)) {
                     commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
                     commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)ub << 2) | arr, -1);
                 }
-                continue;
             }
-            // ---- once-spliced reads (aligned, N, aligned): the kinds are known, so are the arrays; three ranges
-            //      and the junction-table look-up when an end of the junction has rivals
-            if (run == SPL_RC_MNM) {
-                const int32_t c0 = pos + (int32_t)(ra.y >> 16), c1 = c0 + (int32_t)rb.x, c2 = c1 + (int32_t)rb.y;
-                const uint32_t s0 = dbk_slot(p, pos - 1), s1 = dbk_slot(p, c0 - 1), s2 = dbk_slot(p, c1 - 1), s3 = dbk_slot(p, c2 - 1);
-                // two groups of boundaries: around the read's start (pos - 1, c0 - 1) and beyond its intron (c1 - 1, c2 - 1)
-                const uint32_t base_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0), base_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s2);
-                const bool coop_a = __all((s0 - base_a) < 64u && (s1 - base_a) < 64u), coop_b = __all((s2 - base_b) < 64u && (s3 - base_b) < 64u);
-                // (registers: the shared loads of both groups go out at once; a group that cannot share one gathers its two
-                //  entries when its turn comes and pays the trip -- rare in sorted input)
-                spl_dbk ea, eb, ent_a = {0u, 0u, 0u}, ent_b = {0u, 0u, 0u};
-                if (coop_a) ent_a = coop_load(p, base_a);
-                if (coop_b) ent_b = coop_load(p, base_b);
-                fetch_next();
+        }
+        // ---- once-spliced reads (aligned, N, aligned): the kinds are known, so are the arrays; three ranges
+        //      and the junction-table look-up when an end of the junction has rivals.  Two of them per lane.
+        for (; g < g_start[2]; g += NWAVE) {
+            const uint32_t i0 = cu_i0;
+            const W4 r0 = cu0, r1 = cu1;
+            const uint32_t n_run = cv.start[2] - cv.start[1];
+            const uint32_t w[4 * KM] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            int32_t pos[KM], c0[KM], c1[KM], c2[KM];
+            spl_dbk ea[KM], eb[KM], ec[KM], ed[KM];
+#pragma unroll
+            for (uint32_t j = 0; j < KM; ++j) {
+                pos[j] = (int32_t)w[4 * j] + cv.shift;
+                c0[j] = pos[j] + (int32_t)(w[4 * j + 1] >> 16); c1[j] = c0[j] + (int32_t)w[4 * j + 2]; c2[j] = c1[j] + (int32_t)w[4 * j + 3];
+                ea[j] = dbk2(dbk_slot(p, pos[j] - 1));                                               // ---- trip 2
+                eb[j] = p.dbucket[dbk_slot(p, c0[j] - 1)];   // (the junction ends: with the mask of flagged positions)
+                ec[j] = p.dbucket[dbk_slot(p, c1[j] - 1)];
+                ed[j] = dbk2(dbk_slot(p, c2[j] - 1));
+            }
+            fetch_next();
+#pragma unroll
+            for (uint32_t j = 0; j < KM; ++j) {
+                const bool alive = i0 + j < n_run;
                 uint32_t sidx = 0;
-                if (STRANDED) sidx = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
+                if (STRANDED) sidx = (spl_read_strand(w[4 * j + 1] & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
                 const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx;
                 int32_t ua, ub; uint32_t nva, nvb, rv1, rv2;
                 auto range = [&](uint32_t arr) {
@@ -847,86 +842,80 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                     }
                     ua = ub; nva = nvb;
                 };
-                if (coop_a) { ea = coop_get(ent_a, s0 - base_a, false); eb = coop_get(ent_a, s1 - base_a, true); }
-                else { ea = p.dbucket[s0]; eb = p.dbucket[s1]; }
-                dbk_resolve(p, pos - 1, ea, ua, nva);
-                dbk_resolve(p, c0 - 1, eb, ub, nvb, rv1);
+                dbk_resolve(p, pos[j] - 1, ea[j], ua, nva);
+                dbk_resolve(p, c0[j] - 1, eb[j], ub, nvb, rv1);
                 range(sidx);                        // block 1
-                if (coop_b) { ea = coop_get(ent_b, s2 - base_b, true); eb = coop_get(ent_b, s3 - base_b, false); }
-                else { ea = p.dbucket[s2]; eb = p.dbucket[s3]; }
-                dbk_resolve(p, c1 - 1, ea, ub, nvb, rv2);
+                dbk_resolve(p, c1[j] - 1, ec[j], ub, nvb, rv2);
                 range(a_me);                        // the intron
-                dbk_resolve(p, c2 - 1, eb, ub, nvb);
+                dbk_resolve(p, c2[j] - 1, ed[j], ub, nvb);
                 range(sidx);                        // block 2
                 const bool flagged = alive && ((rv1 | rv2) != 0u); // an end of the junction (c0 - 1, c1 - 1) is an end of a junction with rivals
                 if (__any(flagged)) {
+                    const uint32_t slot = cv.start[1] + i0 + j;
                     push_front(flagged && p.combine_mode, slot);
                     push_back(flagged && !p.combine_mode, slot);
                 }
-                continue;
             }
-            // ---- twice-spliced reads (aligned, N, aligned, N, aligned; the record holds the five lengths): six boundaries
-            //      in two trips, five ranges
-            if (run == SPL_RC_M2) {
-                const uint32_t la = ra.y >> 16, d1 = rb.x, lb = rb.y & 0xffffu, lc = rb.y >> 16, d2 = rc.x;
-                const int32_t c0 = pos + (int32_t)la, c1 = c0 + (int32_t)d1, c2 = c1 + (int32_t)lb;
-                const int32_t c3 = c2 + (int32_t)d2, c4 = c3 + (int32_t)lc;
-                uint32_t sidx2 = 0;
-                if (STRANDED) sidx2 = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
-                const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx2;
-                const uint32_t s0 = dbk_slot(p, pos - 1), s1 = dbk_slot(p, c0 - 1), s2 = dbk_slot(p, c1 - 1), s3 = dbk_slot(p, c2 - 1);
-                const uint32_t s4 = dbk_slot(p, c3 - 1), s5 = dbk_slot(p, c4 - 1);
-                // three groups of boundaries, one per aligned block
-                const uint32_t base_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0), base_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s2);
-                const uint32_t base_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)s4);
-                const bool coop_a = __all((s0 - base_a) < 64u && (s1 - base_a) < 64u), coop_b = __all((s2 - base_b) < 64u && (s3 - base_b) < 64u);
-                const bool coop_c = __all((s4 - base_c) < 64u && (s5 - base_c) < 64u);
-                // (registers: the shared loads of all three groups go out at once; a group that cannot share one gathers its
-                //  two entries when its turn comes and pays the trip -- rare in sorted input)
-                spl_dbk fa, fb, ent_a = {0u, 0u, 0u}, ent_b = {0u, 0u, 0u}, ent_c = {0u, 0u, 0u};
-                if (coop_a) ent_a = coop_load(p, base_a);
-                if (coop_b) ent_b = coop_load(p, base_b);
-                if (coop_c) ent_c = coop_load(p, base_c);
-                fetch_next();
-                int32_t ua, ub; uint32_t nva, nvb, rvb;
-                uint32_t fl1 = 0, fl2 = 0; // junction 1 / 2 has an end with rivals
-                auto range = [&](uint32_t arr) {
-                    const int32_t lo = ua + (int32_t)nva;
-                    const bool em = alive && ub > lo;
-                    if (__any(em)) {
-                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | arr, 1);
-                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | arr, -1);
-                    }
-                    ua = ub; nva = nvb;
-                };
-                if (coop_a) { fa = coop_get(ent_a, s0 - base_a, false); fb = coop_get(ent_a, s1 - base_a, true); }
-                else { fa = p.dbucket[s0]; fb = p.dbucket[s1]; }
-                dbk_resolve(p, pos - 1, fa, ua, nva);
-                dbk_resolve(p, c0 - 1, fb, ub, nvb, rvb);
-                range(sidx2);                       // block 1
-                fl1 |= rvb;
-                if (coop_b) { fa = coop_get(ent_b, s2 - base_b, true); fb = coop_get(ent_b, s3 - base_b, true); }
-                else { fa = p.dbucket[s2]; fb = p.dbucket[s3]; }
-                dbk_resolve(p, c1 - 1, fa, ub, nvb, rvb);
-                range(a_me);                        // intron 1
-                fl1 |= rvb;
-                dbk_resolve(p, c2 - 1, fb, ub, nvb, rvb);
-                range(sidx2);                       // block 2
-                fl2 |= rvb;
-                if (coop_c) { fa = coop_get(ent_c, s4 - base_c, true); fb = coop_get(ent_c, s5 - base_c, false); }
-                else { fa = p.dbucket[s4]; fb = p.dbucket[s5]; }
-                dbk_resolve(p, c3 - 1, fa, ub, nvb, rvb);
-                range(a_me);                        // intron 2
-                fl2 |= rvb;
-                dbk_resolve(p, c4 - 1, fb, ub, nvb);
-                range(sidx2);                       // block 3
-                const bool flagged = alive && ((fl1 | fl2) != 0u);
-                if (__any(flagged)) {
-                    push_front(flagged && p.combine_mode, slot);
-                    push_back(flagged && !p.combine_mode, slot | (fl1 << 14) | (fl2 << 15)); // which junction must be in the table
+        }
+        // ---- twice-spliced reads (aligned, N, aligned, N, aligned; the record holds the five lengths): six boundaries,
+        //      five ranges.  One read per lane.
+        for (; g < g_start[3]; g += NWAVE) {
+            const uint32_t i0 = cu_i0;
+            const W4 r0 = cu0, r1 = cu1;
+            const uint32_t slot = cv.start[2] + i0;     // of the read in its chunk, run order
+            const bool alive = i0 < cv.start[3] - cv.start[2];
+            const uint2 ra = make_uint2(r0.x, r0.y), rb = make_uint2(r0.z, r0.w), rc = make_uint2(r1.x, r1.y);
+            const int32_t pos = (int32_t)ra.x + cv.shift;
+            const uint32_t flag = ra.y & 0xffffu;
+            const uint32_t la = ra.y >> 16, d1 = rb.x, lb = rb.y & 0xffffu, lc = rb.y >> 16, d2 = rc.x;
+            const int32_t c0 = pos + (int32_t)la, c1 = c0 + (int32_t)d1, c2 = c1 + (int32_t)lb;
+            const int32_t c3 = c2 + (int32_t)d2, c4 = c3 + (int32_t)lc;
+            uint32_t sidx2 = 0;
+            if (STRANDED) sidx2 = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
+            const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx2;
+            const spl_dbk f0 = dbk2(dbk_slot(p, pos - 1)), f1 = p.dbucket[dbk_slot(p, c0 - 1)], f2 = p.dbucket[dbk_slot(p, c1 - 1)]; // ---- trip 2
+            const spl_dbk f3 = p.dbucket[dbk_slot(p, c2 - 1)], f4 = p.dbucket[dbk_slot(p, c3 - 1)], f5 = dbk2(dbk_slot(p, c4 - 1));
+            fetch_next();
+            int32_t ua, ub; uint32_t nva, nvb, rvb;
+            uint32_t fl1 = 0, fl2 = 0; // junction 1 / 2 has an end with rivals
+            auto range = [&](uint32_t arr) {
+                const int32_t lo = ua + (int32_t)nva;
+                const bool em = alive && ub > lo;
+                if (__any(em)) {
+                    commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | arr, 1);
+                    commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | arr, -1);
                 }
-                continue;
+                ua = ub; nva = nvb;
+            };
+            dbk_resolve(p, pos - 1, f0, ua, nva);
+            dbk_resolve(p, c0 - 1, f1, ub, nvb, rvb);
+            range(sidx2);                       // block 1
+            fl1 |= rvb;
+            dbk_resolve(p, c1 - 1, f2, ub, nvb, rvb);
+            range(a_me);                        // intron 1
+            fl1 |= rvb;
+            dbk_resolve(p, c2 - 1, f3, ub, nvb, rvb);
+            range(sidx2);                       // block 2
+            fl2 |= rvb;
+            dbk_resolve(p, c3 - 1, f4, ub, nvb, rvb);
+            range(a_me);                        // intron 2
+            fl2 |= rvb;
+            dbk_resolve(p, c4 - 1, f5, ub, nvb);
+            range(sidx2);                       // block 3
+            const bool flagged = alive && ((fl1 | fl2) != 0u);
+            if (__any(flagged)) {
+                push_front(flagged && p.combine_mode, slot);
+                push_back(flagged && !p.combine_mode, slot | (fl1 << 14) | (fl2 << 15)); // which junction must be in the table
             }
+        }
+        for (; g < g_total; g += NWAVE) {
+            const uint32_t i0 = cu_i0;
+            const W4 r0 = cu0, r1 = cu1;
+            const uint32_t slot = cv.start[3] + i0;     // of the read in its chunk, run order
+            bool alive = i0 < cv.start[4] - cv.start[3];
+            const uint2 ra = make_uint2(r0.x, r0.y), rb = make_uint2(r0.z, r0.w), rc = make_uint2(r1.x, r1.y);
+            const int32_t pos = (int32_t)ra.x + cv.shift;
+            const uint32_t flag = ra.y & 0xffffu;
             // ---- everything else: {pos, fn, op0, op1, op2 | index of op 0 among the segment's wide ops, number of ops}
             const uint32_t fn = ra.y;
             uint32_t op[SPL_INLINE_OPS] = {rb.x, rb.y, rc.x};
@@ -1017,7 +1006,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 const uint32_t entry = s_q[seg0 + SEG - n_back + j];
                 slot = entry & 0x3fffu;
                 if (slot >= cv.start[SPL_RC_M2]) {
-                    const uint2 *q = (const uint2 *)(cv.rec + (size_t)(cv.off[2] + SPL_REC_M2 * (slot - cv.start[2])));
+                    SPL_GLOBAL const uint2 *q = (SPL_GLOBAL const uint2 *)(cv.rec + (size_t)(cv.off[2] + SPL_REC_M2 * (slot - cv.start[2])));
                     const uint2 ra = q[0], rb = q[1], rc = q[2];
                     const int32_t pos = (int32_t)ra.x + cv.shift;
                     uint32_t sidx = 0;
@@ -1029,7 +1018,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                     const int32_t blk_a[3] = {pos, c1, c3}, blk_b[3] = {c0 - 1, c2 - 1, c4 - 1};
                     undecided = !rivals_inline2<STRANDED, NARR>(p, lds, wbase, jl, jr, jf, blk_a, blk_b, sidx);
                 } else {
-                    const uint4 r = *(const uint4 *)(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot - cv.start[1])));
+                    const uint4 r = *(SPL_GLOBAL const uint4 *)(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot - cv.start[1])));
                     const int32_t pos = (int32_t)r.x + cv.shift;
                     uint32_t sidx = 0;
                     if (STRANDED) sidx = (spl_read_strand(r.y & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
