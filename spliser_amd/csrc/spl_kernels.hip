@@ -64,6 +64,10 @@ __device__ __forceinline__ uint32_t my_chunk()
 #define SPL_GLOBAL __attribute__((address_space(1)))
 typedef SPL_GLOBAL const char spl_gchar;
 typedef SPL_GLOBAL const uint32_t spl_gu32;
+typedef uint32_t spl_u32x2 __attribute__((ext_vector_type(2))); // (built-in vectors: loadable from any address space)
+typedef uint32_t spl_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 ld_g2(spl_gchar *p) { const spl_u32x2 v = *(SPL_GLOBAL const spl_u32x2 *)p; return make_uint2(v.x, v.y); }
+__device__ __forceinline__ uint4 ld_g4(spl_gchar *p) { const spl_u32x4 v = *(SPL_GLOBAL const spl_u32x4 *)p; return make_uint4(v.x, v.y, v.z, v.w); }
 struct ChunkView {
     spl_gchar *rec;
     spl_gu32 *wide;
@@ -100,20 +104,19 @@ __device__ __forceinline__ ReadView read_at(const ChunkView &cv, uint32_t slot, 
     v.ops = row;
     int32_t pos0;
     if (slot < cv.start[1]) {
-        const uint2 r = *(SPL_GLOBAL const uint2 *)(cv.rec + (size_t)(cv.off[0] + SPL_REC_SIMPLE * slot));
+        const uint2 r = ld_g2(cv.rec + (size_t)(cv.off[0] + SPL_REC_SIMPLE * slot));
         pos0 = (int32_t)r.x; v.flag = r.y & 0xffffu;
         row[0] = (r.y >> 16) << 4;
         v.n_ops = 1u;
     } else if (slot < cv.start[2]) {
-        const uint4 r = *(SPL_GLOBAL const uint4 *)(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot - cv.start[1])));
+        const uint4 r = ld_g4(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot - cv.start[1])));
         pos0 = (int32_t)r.x; v.flag = r.y & 0xffffu;
         row[0] = (r.y >> 16) << 4; row[1] = (r.z << 4) | (uint32_t)SPL_OP_N; row[2] = r.w << 4;
         v.n_ops = 3u;
     } else {
         const bool m2 = slot < cv.start[3];
-        SPL_GLOBAL const uint2 *q = (SPL_GLOBAL const uint2 *)(cv.rec + (size_t)(m2 ? cv.off[2] + SPL_REC_M2 * (slot - cv.start[2])
-                                                                : cv.off[3] + SPL_REC_OTHER * (slot - cv.start[3])));
-        const uint2 r0 = q[0], r1 = q[1], r2 = q[2];
+        spl_gchar *q = cv.rec + (size_t)(m2 ? cv.off[2] + SPL_REC_M2 * (slot - cv.start[2]) : cv.off[3] + SPL_REC_OTHER * (slot - cv.start[3]));
+        const uint2 r0 = ld_g2(q), r1 = ld_g2(q + 8), r2 = ld_g2(q + 16);
         pos0 = (int32_t)r0.x; v.flag = r0.y & 0xffffu;
         if (m2) {
             row[0] = (r0.y >> 16) << 4; row[1] = (r1.x << 4) | (uint32_t)SPL_OP_N; row[2] = (r1.y & 0xffffu) << 4;
@@ -734,8 +737,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     // (plain loads: marking the stream non-temporal looked 3...11 % faster in a benchmark that runs pass after pass
     //  over one 400 MB sample -- the words then survive in the 256 MB last-level cache from one pass to
     //  the next -- and is 2...5 % SLOWER when every pass reads a different copy of the sample: DESIGN.md section 6)
-    struct alignas(8) W4 { uint32_t x, y, z, w; };
-    W4 cu0 = {0, 0, 0, 0}, cu1 = {0, 0, 0, 0};       // ---- trip 1: 32 or 24 bytes of records per lane
+    typedef uint4 W4;
+    W4 cu0 = make_uint4(0, 0, 0, 0), cu1 = make_uint4(0, 0, 0, 0); // ---- trip 1: 32 or 24 bytes of records per lane
     uint32_t cu_i0 = 0;                               // the index, in its run, of the lane's first read
     // (select chains, no indexing by `run`: the descriptor stays in scalar registers)
     auto fetch = [&](uint32_t g) {
@@ -754,8 +757,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         // entries leave these two in flight (a branch here turns that wait into "wait for everything").  A 24-byte record's
         // second load takes 8 bytes of its neighbour along.
         spl_gchar *r = cv.rec + (size_t)(off + (i0 < n_run ? i0 : 0u) * size);
-        cu0 = *(SPL_GLOBAL const W4 *)r;
-        cu1 = *(SPL_GLOBAL const W4 *)(r + 16);
+        cu0 = ld_g4(r);
+        cu1 = ld_g4(r + 16);
     };
     if (wave < g_total) fetch(wave);
     int32_t wbase = 0;
@@ -1006,8 +1009,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 const uint32_t entry = s_q[seg0 + SEG - n_back + j];
                 slot = entry & 0x3fffu;
                 if (slot >= cv.start[SPL_RC_M2]) {
-                    SPL_GLOBAL const uint2 *q = (SPL_GLOBAL const uint2 *)(cv.rec + (size_t)(cv.off[2] + SPL_REC_M2 * (slot - cv.start[2])));
-                    const uint2 ra = q[0], rb = q[1], rc = q[2];
+                    spl_gchar *q = cv.rec + (size_t)(cv.off[2] + SPL_REC_M2 * (slot - cv.start[2]));
+                    const uint2 ra = ld_g2(q), rb = ld_g2(q + 8), rc = ld_g2(q + 16);
                     const int32_t pos = (int32_t)ra.x + cv.shift;
                     uint32_t sidx = 0;
                     if (STRANDED) sidx = (spl_read_strand(ra.y & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
@@ -1018,7 +1021,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                     const int32_t blk_a[3] = {pos, c1, c3}, blk_b[3] = {c0 - 1, c2 - 1, c4 - 1};
                     undecided = !rivals_inline2<STRANDED, NARR>(p, lds, wbase, jl, jr, jf, blk_a, blk_b, sidx);
                 } else {
-                    const uint4 r = *(SPL_GLOBAL const uint4 *)(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot - cv.start[1])));
+                    const uint4 r = ld_g4(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot - cv.start[1])));
                     const int32_t pos = (int32_t)r.x + cv.shift;
                     uint32_t sidx = 0;
                     if (STRANDED) sidx = (spl_read_strand(r.y & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
