@@ -61,7 +61,11 @@ __device__ __forceinline__ uint32_t my_chunk()
 // A chunk's descriptor as wave-uniform values (the index is uniform: scalar loads).
 // (the addresses arrive as integers: typed as GLOBAL pointers, or every load through them is a flat_load -- and a wave with a
 //  flat load outstanding can only ever wait for ALL its memory operations, which is the end of any prefetching)
+#ifdef SPL_NO_GLOBAL
+#define SPL_GLOBAL
+#else
 #define SPL_GLOBAL __attribute__((address_space(1)))
+#endif
 typedef SPL_GLOBAL const char spl_gchar;
 typedef SPL_GLOBAL const uint32_t spl_gu32;
 typedef uint32_t spl_u32x2 __attribute__((ext_vector_type(2))); // (built-in vectors: loadable from any address space)
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         // that no pass of the compiler finds common code to move to the end of the iteration.
         // Straight-line up to the commits: lanes past the end of a run are masked, all loads of a trip issue back to
         // back.  Control flow is wave-uniform around every commit_key (all 64 lanes reach it).
-        uint32_t g = wave;
+        uint32_t g = live ? wave : g_start[SPL_RC_RUNS]; // (a workgroup without a chunk has chunk 0's descriptor and no iteration at all)
         auto fetch_next = [&]() { fetch(g + NWAVE < g_total ? g + NWAVE : g); }; // (the last iteration asks for itself again)
         // ---- simple reads (one aligned op, mapped, in range: the packer checked all that): two boundaries, one range,
         //      nothing else can happen.  Four of them per lane.
@@ -784,7 +788,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t n_run = cv.start[1];
-            const uint32_t w[2 * KS] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
             int32_t pos[KS], c1[KS];
             spl_dbk e0[KS], e1[KS];
 #pragma unroll
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t n_run = cv.start[2] - cv.start[1];
-            const uint32_t w[4 * KM] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
             int32_t pos[KM], c0[KM], c1[KM], c2[KM];
             spl_dbk ea[KM], eb[KM], ec[KM], ed[KM];
 #pragma unroll
