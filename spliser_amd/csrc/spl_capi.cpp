@@ -1040,6 +1040,7 @@ static int check_device_error(spl_ctx *c, const spl_dsites *ds)
     HIP_TRY(join_tail(c));
     HIP_TRY(hipMemcpyAsync(&err, ds->err, sizeof(err), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err & SPL_DEV_ERR_TABLE) return spl_set_error(SPL_ERR_HIP, "a wave's list of reads overflowed in the range kernel (internal error: results discarded)");
     if (err & SPL_DEV_ERR_RANGE)
         return spl_set_error(SPL_ERR_RANGE, "a read starts below 0 or ends beyond coordinate %d: split the shard (spliser_amd/shard.py)", SPL_COORD_MAX);
     return SPL_OK;

@@ -14,16 +14,18 @@
 #define SPL_COUNTER_STRIDE 64            // words between the 8 queue counters: a 256-byte line each (counters sharing a
                                          // line serialise the atomics of all XCDs: measured 11 ns per atomic, chip-wide)
 #define SPL_WAVES (SPL_BLOCK / 64)
-// The range kernel deals the wave-iterations of a chunk (64 reads of ONE run each; at most 32 + 3 of them: a run's last one may
-// be partial) round-robin to its waves: at most SPL_WAVE_ITERS per wave, and as many list entries (s_q) per wave.
-#define SPL_WAVE_ITERS 9
+// The range kernel deals the wave-iterations of a chunk (64 * K reads of ONE run each, K = 4 / 2 / 1 / 1 by run; a run's last one
+// may be partial) round-robin to its four waves.  Simple reads are never listed; of the others a wave can get at most
+// 128 + 8 * 64 = 640 (one full once-spliced iteration and eight of the rest: 33 iterations at most carry listable reads): as
+// many list entries (s_q) per wave.
 #ifndef SPL_K_SIMPLE
 #define SPL_K_SIMPLE 4                   // reads per lane and wave-iteration: simple reads (8-byte records)
 #define SPL_K_MNM 2                      // ... once-spliced reads (16-byte records)
 #endif
+#define SPL_WAVE_ITERS 10
 #define SPL_WAVE_READS (64 * SPL_WAVE_ITERS)
 #define SPL_WIN 1020                     // distinct site positions a workgroup privatises in LDS (pair kernel; range kernel unstranded)
-#define SPL_WIN_STRANDED 988             // ... range kernel, stranded: 4 windows + the lists, 8 workgroups in 160 KB
+#define SPL_WIN_STRANDED 956             // ... range kernel, stranded: 4 windows + the lists, 8 workgroups in 160 KB
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
 #ifndef SPL_AGG_ROUNDS
 #define SPL_AGG_ROUNDS 2                 // distinct addresses agg_add merges across the wave before it falls back to plain atomics

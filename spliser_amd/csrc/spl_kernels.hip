@@ -697,23 +697,29 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
 #endif
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, in an SGPR
     const uint32_t seg0 = wave * SEG;
-    uint32_t n_front = 0, n_back = 0;
+    const uint32_t lane = (uint32_t)threadIdx.x & 63u;
+    uint32_t n_front = 0, n_back = 0, back_done = 0; // (back_done: entries of the back list the list pass is through with)
     auto rank_in = [](unsigned long long m) { // how many lanes below mine are in m (mbcnt: no per-lane mask to keep around)
         return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     };
+    // (a segment cannot overflow -- see SPL_WAVE_ITERS -- but if that reasoning were ever wrong the launch must say so, not
+    //  count some reads twice: an entry that does not fit is dropped and the error word set)
     auto push_front = [&](bool want, uint32_t slot) {
         const unsigned long long m = __ballot(want);
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (n_front + n_back - back_done + n > SEG) { if (lane == 0) atomicOr(p.err, SPL_DEV_ERR_TABLE); return; }
         if (want) s_q[seg0 + n_front + rank_in(m)] = (uint16_t)slot;
-        n_front += (uint32_t)__popcll(m);
+        n_front += n;
     };
     auto push_back = [&](bool want, uint32_t slot) {
         const unsigned long long m = __ballot(want);
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (n_front + n_back + n > SEG) { if (lane == 0) atomicOr(p.err, SPL_DEV_ERR_TABLE); return; }
         if (want) s_q[seg0 + SEG - 1u - n_back - rank_in(m)] = (uint16_t)slot;
-        n_back += (uint32_t)__popcll(m);
+        n_back += n;
     };
 
     const int tid = threadIdx.x;
-    const uint32_t lane = (uint32_t)tid & 63u;
     // workgroup -> slot of its XCD slice (my_chunk) -> chunk: every slice is walked longest chunk first (chunk_order, built
     // at upload from the packer's cost estimate), so the workgroups that finish a launch are short ones
     const uint32_t chunk_slot = my_chunk();
@@ -1034,6 +1040,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                     undecided = !rivals_inline<STRANDED, NARR>(p, lds, wbase, c0 - 1, c1 - 1, blk_a, blk_b, sidx);
                 }
             }
+            back_done = r0 + 64u < n_back ? r0 + 64u : n_back;
             if (__any(undecided)) push_front(undecided, slot);
         }
     }

@@ -7,6 +7,7 @@ from oracle import oracle
 from spliser_amd import native, samio
 oracle.build()
 seed, stranded = int(sys.argv[1]), int(sys.argv[2])
+combine = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 arr, rs = randcase.make_case(seed, bool(stranded))
 s = native.SiteArrays.from_chrom(arr)
 
@@ -21,8 +22,8 @@ def subset(idx):
 
 def ok(reads, ctx):
     r = native.ReadArrays(reads.pos, reads.flag, reads.cig_off, reads.cigar)
-    want = oracle.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos, reads.pos, reads.flag, reads.cig_off, reads.cigar, stranded, 0)
-    got = ctx.count(s, r, stranded, 0, 0)
+    want = oracle.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos, reads.pos, reads.flag, reads.cig_off, reads.cigar, stranded, combine)
+    got = ctx.count(s, r, stranded, combine, 0)
     d, _, _ = native.pack_host(r)
     return all(np.array_equal(w, g) for w, g in zip(want, got)), d["n"].sum(axis=0).tolist() if len(d) else []
 
@@ -39,6 +40,6 @@ with native.Context(0) as ctx:
     for n in (64, 65, 128, 192, 193, 256, 257, 300):
         reads = subset(np.repeat([i], n))
         r = native.ReadArrays(reads.pos, reads.flag, reads.cig_off, reads.cigar)
-        want = oracle.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos, reads.pos, reads.flag, reads.cig_off, reads.cigar, stranded, 0)
-        got = ctx.count(s, r, stranded, 0, 0)
+        want = oracle.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos, reads.pos, reads.flag, reads.cig_off, reads.cigar, stranded, combine)
+        got = ctx.count(s, r, stranded, combine, 0)
         print("read %d x%d" % (i, n), [(g.astype(int) - w.astype(int)).tolist() for g, w in zip(got, want)])
