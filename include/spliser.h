@@ -243,6 +243,25 @@ int spl_junctions_get(const spl_ctx *ctx, int32_t *left, int32_t *right, uint8_t
 int spl_gene_search(const int64_t *left, const int64_t *right, const uint8_t *gene_strand, int64_t n_genes,
                     const int64_t *q_pos, const uint8_t *q_strand, int64_t n_queries, int is_stranded, int32_t *out);
 
+/* ---- host helpers of Steps 0-1: the text inputs as columns ----------------------------------------------------------------
+ * spl_bed_open: every line of exactly 12 tab-separated columns of a BED12 junction file as findAlphaCounts reads it
+ * (SpliSER_v0_1_8.py:257-277): chromosome (index into the file's chromosome names, first-appearance order), left = chromStart +
+ * blockSizes[0], right = chromEnd - blockSizes[1], alpha = score, strand byte (0 = empty column).  spl_gff_open: every `gene`
+ * line of a GFF / GTF file as createGenes keeps it (:81-87, HTSeq conventions): chromosome, left = column 4 - 1, right = column 5,
+ * strand byte, name = value of the first attribute.  Both fail with SPL_ERR_FORMAT on anything they are not sure to read the way
+ * the reference's Python would (the caller then reads line by line).  No GPU involved. */
+typedef struct spl_textfile spl_textfile;
+int spl_bed_open(const char *path, spl_textfile **out);
+int spl_gff_open(const char *path, spl_textfile **out);
+void spl_text_close(spl_textfile *t);
+int64_t spl_text_rows(const spl_textfile *t);
+int32_t spl_text_n_chrom(const spl_textfile *t);
+const char *spl_text_chrom_name(const spl_textfile *t, int32_t k);
+const int32_t *spl_text_chrom(const spl_textfile *t);                 /* [rows] */
+const int64_t *spl_text_i64(const spl_textfile *t, int which);        /* [rows] which: 0 left, 1 right, 2 alpha (BED) */
+const uint8_t *spl_text_strand(const spl_textfile *t);                /* [rows] */
+const char *spl_text_names(const spl_textfile *t, const uint32_t **off_out); /* GFF: gene names, one blob + rows + 1 offsets */
+
 /* ---- output (outputBedFile, SpliSER_v0_1_8.py:641-664) -------------------------------------------------------
  * Appends the rows of one chromosome to a .SpliSER.tsv file (the caller writes the header line): 12 tab-separated
  * columns, SSE as "%.3f", the two cryptic columns as an integer and "%.5f" or "NA NA" when cryptic == 0, Partners as

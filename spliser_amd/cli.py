@@ -36,6 +36,9 @@ def build_parser():
                    help='optional: strand specificity of the library, "rf" (first-strand) or "fr" (second-strand)')
     p.add_argument("--beta2Cryptic", dest="isbeta2Cryptic", default=False, action="store_true",
                    help="optional: weight the utilisation of competing splice sites into SSE (legacy)")
+    p.add_argument("--checkJunctions", dest="checkJunctions", default=False, action="store_true",
+                   help="(this build only) also count every junction in the BAM on the GPU and write <outputPath>.junctionCheck.tsv: "
+                        "BED alpha against reads in the BAM; changes no result")
     _engine_flags(p)
     c = sub.add_parser("combine")
     c.add_argument("-S", "--samplesFile", dest="samplesFile", required=True,

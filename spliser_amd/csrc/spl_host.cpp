@@ -129,3 +129,206 @@ extern "C" int spl_tsv_append(const char *path, const char *chrom, int64_t n_sit
     if (fclose(f) != 0) ok = false;
     return ok ? SPL_OK : spl_set_error(SPL_ERR_IO, "write error on %s", path);
 }
+
+// ---- Steps 0-1 text input: the BED12 junction file and the gene lines of the annotation, as columns ---------------------
+// What findAlphaCounts reads from a line (SpliSER_v0_1_8.py:257-277) and what createGenes keeps of a gene line (:81-87, with
+// HTSeq's conventions: start = column 4 - 1, end = column 5, name = value of the first attribute).  Files of this kind have
+// 10^5 lines; line by line in Python that is a fifth of a second, here it is a few milliseconds.  Anything these parsers are
+// not sure to read the way Python's str.split / int() would -- a number that is not a plain decimal integer, a strand
+// column longer than one byte, a lone carriage return, bytes outside ASCII where they would matter -- makes the call fail with
+// SPL_ERR_FORMAT, and the caller takes its line-by-line path, which then says what Python says.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <map>
+
+struct spl_textfile {
+    std::vector<int32_t> chrom;
+    std::vector<int64_t> a, b, c;      // BED: left, right, alpha;  GFF: left, right, -
+    std::vector<uint8_t> strand;
+    std::string name_blob;             // GFF: gene names
+    std::vector<uint32_t> name_off;
+    std::vector<std::string> chrom_names;
+};
+
+namespace {
+
+struct Mapped {
+    const char *p = nullptr;
+    size_t n = 0;
+    bool ok = false;
+    explicit Mapped(const char *path)
+    {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        if (fstat(fd, &st) == 0) {
+            n = (size_t)st.st_size;
+            if (n == 0) ok = true;
+            else {
+                void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) { p = (const char *)m; ok = true; }
+            }
+        }
+        close(fd);
+    }
+    ~Mapped() { if (p) munmap((void *)p, n); }
+};
+
+inline bool is_space(char ch) { return ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r' || ch == '\v' || ch == '\f'; }
+
+// Python's int(text) for the texts that occur in these files: optional blanks, optional sign, decimal digits, optional blanks.
+bool py_int(const char *s, const char *e, int64_t *out)
+{
+    while (s < e && is_space(*s)) ++s;
+    while (e > s && is_space(e[-1])) --e;
+    bool neg = false;
+    if (s < e && (*s == '+' || *s == '-')) { neg = *s == '-'; ++s; }
+    if (s >= e || e - s > 18) return false;
+    int64_t v = 0;
+    for (; s < e; ++s) {
+        if (*s < '0' || *s > '9') return false;
+        v = v * 10 + (*s - '0');
+    }
+    *out = neg ? -v : v;
+    return true;
+}
+
+int32_t chrom_id(spl_textfile *t, std::map<std::string, int32_t> &ids, const char *s, const char *e)
+{
+    std::string key(s, e);
+    auto it = ids.find(key);
+    if (it != ids.end()) return it->second;
+    const int32_t id = (int32_t)t->chrom_names.size();
+    ids.emplace(key, id);
+    t->chrom_names.push_back(key);
+    return id;
+}
+
+} // namespace
+
+extern "C" int spl_bed_open(const char *path, spl_textfile **out)
+{
+    if (!path || !out) return spl_set_error(SPL_ERR_ARG, "spl_bed_open: null argument");
+    *out = nullptr;
+    Mapped f(path);
+    if (!f.ok) return spl_set_error(SPL_ERR_IO, "cannot read %s", path);
+    spl_textfile *t = new spl_textfile();
+    std::map<std::string, int32_t> ids;
+    const char *p = f.p, *end = f.p + f.n;
+    int64_t line_no = 0;
+    while (p < end) {
+        ++line_no;
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;             // the line without its newline
+        if (le > p && le[-1] == '\r') --le;         // (text mode turns "\r\n" into "\n")
+        if (memchr(p, '\r', (size_t)(le - p))) { delete t; return spl_set_error(SPL_ERR_FORMAT, "%s: carriage return inside line %lld", path, (long long)line_no); }
+        const char *field[13];
+        int n_field = 0;
+        field[0] = p;
+        for (const char *q = p; q < le && n_field < 12; ++q)
+            if (*q == '\t') field[++n_field] = q + 1;
+        // (n_field = tabs seen, capped at 12: twelve columns = eleven tabs)
+        if (n_field == 11) {
+            field[12] = le + 1;
+            auto fe = [&](int k) { return field[k + 1] - 1; }; // end of column k
+            int64_t start, stop, score, b0, b1;
+            const char *blocks = field[10], *be = fe(10);
+            const char *c1 = (const char *)memchr(blocks, ',', (size_t)(be - blocks));
+            if (!c1) { delete t; return spl_set_error(SPL_ERR_FORMAT, "%s: line %lld has one block size", path, (long long)line_no); }
+            const char *c2 = (const char *)memchr(c1 + 1, ',', (size_t)(be - c1 - 1));
+            if (!py_int(field[1], fe(1), &start) || !py_int(field[2], fe(2), &stop) || !py_int(field[4], fe(4), &score) ||
+                !py_int(blocks, c1, &b0) || !py_int(c1 + 1, c2 ? c2 : be, &b1)) {
+                delete t;
+                return spl_set_error(SPL_ERR_FORMAT, "%s: line %lld holds a number that is not a plain integer", path, (long long)line_no);
+            }
+            const size_t sl = (size_t)(fe(5) - field[5]);
+            if (sl > 1 || (sl == 1 && (unsigned char)field[5][0] >= 128)) { delete t; return spl_set_error(SPL_ERR_FORMAT, "%s: line %lld has a strand column of more than one character", path, (long long)line_no); }
+            t->chrom.push_back(chrom_id(t, ids, field[0], fe(0)));
+            t->a.push_back(start + b0);   // :275
+            t->b.push_back(stop - b1);    // :276
+            t->c.push_back(score);        // :277
+            t->strand.push_back(sl ? (uint8_t)field[5][0] : 0);
+        }
+        if (!nl) break;
+        p = nl + 1;
+    }
+    *out = t;
+    return SPL_OK;
+}
+
+extern "C" int spl_gff_open(const char *path, spl_textfile **out)
+{
+    if (!path || !out) return spl_set_error(SPL_ERR_ARG, "spl_gff_open: null argument");
+    *out = nullptr;
+    Mapped f(path);
+    if (!f.ok) return spl_set_error(SPL_ERR_IO, "cannot read %s", path);
+    spl_textfile *t = new spl_textfile();
+    t->name_off.push_back(0);
+    std::map<std::string, int32_t> ids;
+    const char *p = f.p, *end = f.p + f.n;
+    int64_t line_no = 0;
+    auto fail = [&](const char *what) { delete t; return spl_set_error(SPL_ERR_FORMAT, "%s: line %lld %s", path, (long long)line_no, what); };
+    while (p < end) {
+        ++line_no;
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        if (le > p && le[-1] == '\r') --le;
+        if (memchr(p, '\r', (size_t)(le - p))) return fail("holds a carriage return");
+        bool blank = true;
+        for (const char *q = p; q < le && blank; ++q) blank = is_space(*q);
+        if (!(le == p || *p == '#' || blank)) {
+            std::vector<const char *> field;
+            field.push_back(p);
+            for (const char *q = p; q < le; ++q) if (*q == '\t') field.push_back(q + 1);
+            field.push_back(le + 1);
+            const size_t n_col = field.size() - 1;
+            auto fe = [&](size_t k) { return field[k + 1] - 1; };
+            if (n_col >= 9 && fe(2) - field[2] == 4 && memcmp(field[2], "gene", 4) == 0) {
+                int64_t c4, c5;
+                if (!py_int(field[3], fe(3), &c4) || !py_int(field[4], fe(4), &c5)) return fail("holds a coordinate that is not a plain integer");
+                const size_t sl = (size_t)(fe(6) - field[6]);
+                if (sl != 1 || (unsigned char)field[6][0] >= 128) return fail("has a strand column that is not one character");
+                // name = value of the first attribute (HTSeq), quotes stripped: sites.py _first_attribute
+                const char *s = field[8], *e = fe(8);
+                for (const char *q = s; q < e; ++q) if ((unsigned char)*q >= 128) return fail("has non-ASCII attributes");
+                while (s < e && is_space(*s)) ++s;
+                while (e > s && is_space(e[-1])) --e;
+                const char *semi = (const char *)memchr(s, ';', (size_t)(e - s));
+                if (semi) e = semi;
+                while (s < e && is_space(*s)) ++s;
+                while (e > s && is_space(e[-1])) --e;
+                const char *eq = (const char *)memchr(s, '=', (size_t)(e - s));
+                const char *sp = (const char *)memchr(s, ' ', (size_t)(e - s));
+                if (eq) s = eq + 1;
+                else if (sp) s = sp + 1;
+                while (s < e && is_space(*s)) ++s;
+                while (e > s && is_space(e[-1])) --e;
+                while (s < e && *s == '"') ++s;
+                while (e > s && e[-1] == '"') --e;
+                t->chrom.push_back(chrom_id(t, ids, field[0], fe(0)));
+                t->a.push_back(c4 - 1);
+                t->b.push_back(c5);
+                t->strand.push_back((uint8_t)field[6][0]);
+                t->name_blob.append(s, e);
+                t->name_off.push_back((uint32_t)t->name_blob.size());
+            }
+        }
+        if (!nl) break;
+        p = nl + 1;
+    }
+    *out = t;
+    return SPL_OK;
+}
+
+extern "C" void spl_text_close(spl_textfile *t) { delete t; }
+extern "C" int64_t spl_text_rows(const spl_textfile *t) { return t ? (int64_t)t->chrom.size() : 0; }
+extern "C" int32_t spl_text_n_chrom(const spl_textfile *t) { return t ? (int32_t)t->chrom_names.size() : 0; }
+extern "C" const char *spl_text_chrom_name(const spl_textfile *t, int32_t k) { return (t && k >= 0 && (size_t)k < t->chrom_names.size()) ? t->chrom_names[(size_t)k].c_str() : nullptr; }
+extern "C" const int32_t *spl_text_chrom(const spl_textfile *t) { return t ? t->chrom.data() : nullptr; }
+// which: 0 = left, 1 = right, 2 = alpha (BED only)
+extern "C" const int64_t *spl_text_i64(const spl_textfile *t, int which) { return !t ? nullptr : (which == 0 ? t->a.data() : (which == 1 ? t->b.data() : t->c.data())); }
+extern "C" const uint8_t *spl_text_strand(const spl_textfile *t) { return t ? t->strand.data() : nullptr; }
+extern "C" const char *spl_text_names(const spl_textfile *t, const uint32_t **off_out) { if (!t) return nullptr; if (off_out) *off_out = t->name_off.data(); return t->name_blob.data(); }

@@ -61,6 +61,7 @@ def _empty(chrom):
 
 
 def _strand_code(s):
+    """What spl_gene_search compares: '+' and '-' as they are, anything else 0."""
     return 43 if s == "+" else (45 if s == "-" else 0)
 
 
@@ -68,50 +69,34 @@ def build(bins, is_stranded, bed_path, q_chrom="All", q_gene="All", max_intron=0
     """-> FastSiteTable, or None when the line-by-line builder has to be used."""
     if q_gene != "All":
         return None
+    cols = native.read_bed_columns(bed_path)     # the 12-column lines as findAlphaCounts reads them (:257-277), natively
+    if cols is None:
+        return None                               # (a line the native reader will not vouch for)
     table = FastSiteTable(bins, is_stranded)
-    per_chrom = {}   # chrom -> (left, right, strand text, alpha) lists in line order
-    known = set(bins.genes)
-    with open(bed_path, "r") as handle:
-        for line in handle:
-            values = line.split("\t")
-            if len(values) != 12:                       # :259
-                continue
-            chrom = values[0]
-            if chrom not in known:                      # :265-268 (also for chromosomes the -c filter drops)
-                bins.ensure_chrom(chrom)
-                known.add(chrom)
-            if not (q_chrom == chrom or q_chrom == "All"):
-                continue
-            flank = values[10].split(",")
-            rec = per_chrom.get(chrom)
-            if rec is None:
-                rec = per_chrom[chrom] = ([], [], [], [])
-            rec[0].append(int(values[1]) + int(flank[0]))   # :275
-            rec[1].append(int(values[2]) - int(flank[1]))   # :276
-            rec[2].append(values[5])
-            rec[3].append(int(values[4]))                   # :277
-    for chrom, (left, right, strands, alpha) in per_chrom.items():
-        arr = _chrom(table, chrom, left, right, strands, alpha)
+    for chrom in cols.chrom_names:                # :265-268 (also for chromosomes the -c filter drops)
+        bins.ensure_chrom(chrom)
+    for k, chrom in enumerate(cols.chrom_names):
+        if not (q_chrom == chrom or q_chrom == "All"):
+            continue
+        rows = np.flatnonzero(cols.chrom == k)    # line order
+        arr = _chrom(table, chrom, cols.left[rows], cols.right[rows], cols.strand[rows], cols.alpha[rows])
         if arr is None:
             return None
         table._arrays[chrom] = arr
     return table
 
 
-def _chrom(table, chrom, left, right, strands, alpha):
+def _chrom(table, chrom, left, right, strand, alpha):
+    """One chromosome from its lines (arrays in line order; ``strand`` = the strand column's byte, 0 when empty)."""
     is_stranded = table.is_stranded
-    k = len(left)
-    left = np.asarray(left, np.int64)
-    right = np.asarray(right, np.int64)
-    alpha = np.asarray(alpha, np.int64)
-    uniq_strands = set(strands)
-    if is_stranded and not uniq_strands <= {"+", "-"}:
+    k = left.shape[0]
+    if is_stranded and bool(((strand != 43) & (strand != 45)).any()):
         return None          # strand-free look-ups depend on what has been inserted so far: line by line
     if k and (min(int(left.min()), int(right.min())) < 0 or max(int(left.max()), int(right.max())) >= (1 << 61)):
         return None
     if bool((left == right).any()):
         return None          # both look-ups precede both insertions (:291-292): such a line creates TWO sites at one position
-    minus = np.fromiter((s == "-" for s in strands), dtype=bool, count=k)
+    minus = strand == 45
     # junction ends in the order the reference looks them up: line 0 left, line 0 right, line 1 left, ...
     pos = np.empty(2 * k, np.int64)
     pos[0::2], pos[1::2] = left, right
@@ -125,19 +110,15 @@ def _chrom(table, chrom, left, right, strands, alpha):
     out.chrom, out.n = chrom, n
     out.pos = (ukey >> 1) if is_stranded else ukey.copy()
     creator = line[first]                                   # the line whose look-up created the site
-    out.strand_text = [strands[i] for i in creator.tolist()]
-    out.strand = np.fromiter((ord(s[0]) if s else 0 for s in out.strand_text), dtype=np.uint8, count=n)
+    out.strand = strand[creator].astype(np.uint8)           # (first byte of the creating line's strand column, 0 = empty)
+    out.strand_text = [chr(c) if c else "" for c in out.strand.tolist()]
     out.alpha = np.zeros(n, np.int64)
     np.add.at(out.alpha, inv, np.repeat(alpha, 2))           # :341
     # genes (:313): one bisection per created site, with the creating line's strand
-    genes = table.bins.genes.get(chrom, [])
-    if genes and n:
-        g_left = np.fromiter((g.left for g in genes), dtype=np.int64, count=len(genes))
-        g_right = np.fromiter((g.right for g in genes), dtype=np.int64, count=len(genes))
-        g_strand = np.fromiter((_strand_code(g.strand) for g in genes), dtype=np.uint8, count=len(genes))
-        q_strand = np.fromiter((_strand_code(s) for s in out.strand_text), dtype=np.uint8, count=n)
+    g_left, g_right, g_strand, names = table.bins.gene_arrays(chrom)
+    if len(names) and n:
+        q_strand = np.where((out.strand == 43) | (out.strand == 45), out.strand, 0).astype(np.uint8)
         gi = native.gene_search(g_left, g_right, g_strand, out.pos, q_strand, is_stranded)
-        names = [g.name for g in genes]
         out.genes = [names[i] if i >= 0 else "NA" for i in gi.tolist()]
         table.assigned += int((gi >= 0).sum())
     else:

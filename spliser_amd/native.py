@@ -52,6 +52,8 @@ EXPORTS = [
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
     "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append",
+    "spl_bed_open", "spl_gff_open", "spl_text_close", "spl_text_rows", "spl_text_n_chrom", "spl_text_chrom_name", "spl_text_chrom",
+    "spl_text_i64", "spl_text_strand", "spl_text_names",
 ]
 
 _lib = None
@@ -76,8 +78,12 @@ def lib():
         L.spl_bam_ref_name.restype = ctypes.c_char_p
         L.spl_bam_ref_length.restype = ctypes.c_int64
         L.spl_bam_n_records.restype = ctypes.c_int64
-        for name in ("spl_destroy", "spl_sites_free", "spl_reads_free", "spl_bam_close"):
+        for name in ("spl_destroy", "spl_sites_free", "spl_reads_free", "spl_bam_close", "spl_text_close"):
             getattr(L, name).restype = None
+        L.spl_text_rows.restype = ctypes.c_int64
+        L.spl_text_chrom_name.restype = ctypes.c_char_p
+        for name in ("spl_text_chrom", "spl_text_i64", "spl_text_strand", "spl_text_names"):
+            getattr(L, name).restype = ctypes.c_void_p
         if L.spl_abi_version() != 1:
             raise SpliserNativeError(-1, "ABI version mismatch")
         _lib = L
@@ -530,3 +536,53 @@ def pack_host(reads, threads=1):
     _check(lib().spl_pack_host(ctypes.byref(reads.c), ctypes.c_int(threads), ctypes.byref(nc), ctypes.byref(rb), ctypes.byref(nw),
                                _ptr(desc), _ptr(rec), _ptr(wide)))
     return desc[:nc.value], rec[:rb.value], wide[:nw.value]
+
+
+class TextColumns(object):
+    """A BED12 junction file or the gene lines of an annotation as columns (``spl_bed_open`` / ``spl_gff_open``)."""
+    __slots__ = ("chrom_names", "chrom", "left", "right", "alpha", "strand", "names")
+
+
+def _text_columns(opener, path, with_alpha, with_names):
+    h = ctypes.c_void_p()
+    rc = opener(os.fsencode(path), ctypes.byref(h))
+    if rc == -5:
+        return None           # something the native reader will not vouch for: the caller reads line by line
+    _check(rc)
+    try:
+        L = lib()
+        rows = L.spl_text_rows(h)
+
+        def col(ptr, dt):
+            if not rows:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(rows,)).copy()
+        out = TextColumns()
+        out.chrom_names = [L.spl_text_chrom_name(h, k).decode("utf-8") for k in range(L.spl_text_n_chrom(h))]
+        out.chrom = col(L.spl_text_chrom(h), np.int32)
+        out.left = col(L.spl_text_i64(h, 0), np.int64)
+        out.right = col(L.spl_text_i64(h, 1), np.int64)
+        out.alpha = col(L.spl_text_i64(h, 2), np.int64) if with_alpha else None
+        out.strand = col(L.spl_text_strand(h), np.uint8)
+        out.names = None
+        if with_names:
+            off_p = ctypes.c_void_p()
+            blob_p = L.spl_text_names(h, ctypes.byref(off_p))
+            off = np.ctypeslib.as_array(ctypes.cast(off_p, ctypes.POINTER(ctypes.c_uint32)), shape=(rows + 1,)).tolist()
+            blob = ctypes.string_at(blob_p, off[-1]) if rows and off[-1] else b""
+            out.names = [blob[off[i]:off[i + 1]].decode("ascii") for i in range(rows)]
+        return out
+    except UnicodeDecodeError:
+        return None
+    finally:
+        lib().spl_text_close(h)
+
+
+def read_bed_columns(path):
+    """-> TextColumns of the 12-column lines of a BED file, or None when the file must be read line by line."""
+    return _text_columns(lib().spl_bed_open, path, True, False)
+
+
+def read_gff_genes(path):
+    """-> TextColumns of the ``gene`` lines of a GFF / GTF file, or None when the file must be read line by line."""
+    return _text_columns(lib().spl_gff_open, path, False, True)

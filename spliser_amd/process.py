@@ -49,8 +49,31 @@ class _Replan(Exception):
     """A read reaches beyond the room its chromosome was given in the shard (planned from the BAM header)."""
 
 
+def junction_consistency(arr, junctions, offset, is_stranded):
+    """The junctions of the BED file (each partner edge of the table seen from its left end: position, partner position, alpha,
+    SpliSER_v0_1_8.py:275-277, :341-355) against the junctions the reads themselves carry (``spl_junctions`` over the same read
+    set: one count per N op, no anchor or intron-length filter).  -> list of (left, right, strand, BED alpha, reads in the BAM);
+    regtools-style files filter by anchor length, so BED <= BAM is the normal case and BED > BAM means the two files do not
+    belong together."""
+    import numpy as np
+    bam = {}
+    for l, r, st, n in zip(junctions["left"].tolist(), junctions["right"].tolist(), junctions["strand"].tolist(), junctions["count"].tolist()):
+        bam[(l - offset, r - offset, chr(st) if is_stranded else "?")] = n
+    rows, seen = [], set()
+    pos, off, ppos, cnt = arr.pos.tolist(), arr.part_off.tolist(), arr.part_pos.tolist(), arr.edge_cnt.tolist()
+    for i in range(arr.n):
+        st = arr.strand_text[i] if is_stranded else "?"
+        for e in range(off[i], off[i + 1]):
+            if ppos[e] > pos[i]:
+                key = (pos[i], ppos[e], st)
+                seen.add(key)
+                rows.append(key + (cnt[e], bam.get(key, 0)))
+    rows.extend(key + (0, n) for key, n in sorted(bam.items()) if key not in seen)
+    return rows
+
+
 def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_cryptic, devices=(0,), combine_mode=0,
-                  log=_log, timings=None, on_result=None):
+                  log=_log, timings=None, on_result=None, on_junctions=None):
     """processSites (SpliSER_v0_1_8.py:681-692) for every chromosome.
 
     One thread and one context per device; the chromosomes of a device share ONE site table in one coordinate space
@@ -137,6 +160,8 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                             ctx.sse_launch(ds, is_beta2_cryptic)
                             beta1, b2r, _ = ds.counters()
                             b2s, b2c, b2w, sse = ds.sse_results()
+                            if on_junctions is not None and dr.n:
+                                on_junctions(chrom, junction_consistency(items[chrom][0], dr.junctions(stranded), off, bool(stranded)))
                         res = dict(beta1=beta1[r0:r1].copy(), beta2_simple=b2s[r0:r1].copy(), beta2_cryptic=b2c[r0:r1].copy(),
                                    beta2_weighted=b2w[r0:r1].copy(), sse=sse[r0:r1].copy(), beta2s_reads=b2r[r0:r1].copy())
                         with lock:
@@ -205,8 +230,12 @@ def write_tsv(output_path, table, results, is_beta2_cryptic):
 
 
 def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0, annotationFile=None, aType="gene",
-            isStranded=False, strandedType=None, isbeta2Cryptic=False, devices=(0,), threads=0, log=_log):
-    """SpliSER_v0_1_8.py:695-720, keyword-compatible with the reference's argparse dests."""
+            isStranded=False, strandedType=None, isbeta2Cryptic=False, devices=(0,), threads=0, log=_log, checkJunctions=False):
+    """SpliSER_v0_1_8.py:695-720, keyword-compatible with the reference's argparse dests.
+
+    ``checkJunctions`` (this build only; changes no result): also derive every chromosome's junction table from the reads on
+    the GPU and write ``<outputPath>.junctionCheck.tsv`` -- BED alpha against reads in the BAM per junction -- with a warning
+    for every junction the BED file gives MORE reads than the BAM holds (the two files do not belong together)."""
     timings = {}
     t0 = time.perf_counter()
     # The alignment file does not depend on Steps 0-2: it is decoded on native threads while the site table is built here, and
@@ -220,18 +249,33 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
         log("\n\nStep 3: Finding Beta reads")
         log("Processing sample 1 out of 1")
         writer = _TsvWriter(outputPath, table, isbeta2Cryptic)
+        jrows = {}
         results = process_sites(table, source, qChrom, isStranded, strandedType, isbeta2Cryptic, devices=devices, log=log,
-                                timings=timings, on_result=writer.add)
+                                timings=timings, on_result=writer.add,
+                                on_junctions=(lambda c, rows: jrows.__setitem__(c, rows)) if checkJunctions else None)
         if isinstance(source, native.BamFile) and not source.wait_all():
             # records of an earlier reference after a later one: chromosomes were counted before they were complete.  (samtools
             # cannot index such a file, the reference could not have processed it at all.)  Everything is decoded by now: again.
             log("  (the alignment file is not sorted by reference: counting again from the complete decode)")
             writer = _TsvWriter(outputPath, table, isbeta2Cryptic)
+            jrows = {}
             results = process_sites(table, source, qChrom, isStranded, strandedType, isbeta2Cryptic, devices=devices, log=lambda m: None,
-                                    timings=timings, on_result=writer.add)
+                                    timings=timings, on_result=writer.add,
+                                    on_junctions=(lambda c, rows: jrows.__setitem__(c, rows)) if checkJunctions else None)
         t3 = time.perf_counter()
         log("\nOutputting .tsv file")
         writer.close(list(results))
+        if checkJunctions:
+            n_more = 0
+            with open(outputPath + ".junctionCheck.tsv", "w") as fh:
+                fh.write("Region\tLeft\tRight\tStrand\tBED_alpha\tBAM_reads\tStatus\n")
+                for chrom in table.chrom_index:
+                    for (l, r, st, a, b) in jrows.get(chrom, ()):
+                        status = "equal" if a == b else ("bam_only" if a == 0 else ("bed_only" if b == 0 else ("bed<bam" if a < b else "bed>bam")))
+                        n_more += a > b
+                        fh.write("%s\t%d\t%d\t%s\t%d\t%d\t%s\n" % (chrom, l, r, st, a, b, status))
+            if n_more:
+                log("WARNING: %d junction(s) of %s carry more reads than %s holds for them -- do the two files belong together?" % (n_more, inBed, inBAM))
         t4 = time.perf_counter()
     finally:
         if hasattr(source, "close"):

@@ -34,6 +34,7 @@ class Gene(object):
 
 
 NA_GENE = Gene("NA", -1, -1, None)  # SpliSER_v0_1_8.py:40-47
+USE_NATIVE_TEXT = True              # tests switch it off to hold the native readers to the line-by-line ones
 
 
 def _first_attribute(field):
@@ -51,20 +52,53 @@ def _first_attribute(field):
 
 class GeneBins(object):
     """Per-chromosome gene lists ordered by left boundary (bisect.insort on Gene.__lt__,
-    Gene_Site_Iter_Graph_v0_1_8.py:27-28), plus the chromosome order they induce."""
+    Gene_Site_Iter_Graph_v0_1_8.py:27-28), plus the chromosome order they induce.
+
+    Two forms of the same lists: ``genes`` (Gene objects: what the line-by-line builders walk) and ``gene_arrays`` (columns:
+    what the array-at-a-time builder bisects natively).  An annotation read by the native reader starts out as columns and
+    grows its objects only if somebody asks for them."""
 
     def __init__(self):
         self.chrom_index = []   # SpliSER_v0_1_8.py:23
-        self.genes = {}         # chrom -> list[Gene]      (gene2D_array, :24)
+        self._genes = {}        # chrom -> list[Gene]      (gene2D_array, :24)
         self._lefts = {}        # chrom -> list[int] parallel to genes[chrom], for insort
+        self._columns = None    # chrom -> (left, right, strand code, names) in list order, when read natively
+        self._chroms = set()
         self.query_gene = None  # QUERY_gene, :39
         self.n_created = 0
 
+    @property
+    def genes(self):
+        if self._columns is not None:      # objects on demand
+            for chrom, (left, right, strand, names) in self._columns.items():
+                self._genes[chrom] = [Gene(n, l, r, chr(s)) for n, l, r, s in zip(names, left.tolist(), right.tolist(), strand.tolist())]
+                self._lefts[chrom] = left.tolist()
+            self._columns = None
+        return self._genes
+
+    def has_chrom(self, chrom):
+        return chrom in self._chroms
+
     def ensure_chrom(self, chrom):
-        if chrom not in self.genes:
+        if chrom not in self._chroms:
+            self._chroms.add(chrom)
             self.chrom_index.append(chrom)
-            self.genes[chrom] = []
-            self._lefts[chrom] = []
+            if self._columns is not None:
+                self._columns[chrom] = (np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.uint8), [])
+            else:
+                self._genes[chrom] = []
+                self._lefts[chrom] = []
+
+    def gene_arrays(self, chrom):
+        """-> (left, right, strand code ('+' 43, '-' 45, anything else 0), names) of a chromosome's genes, list order."""
+        if self._columns is not None:
+            left, right, strand, names = self._columns.get(chrom, (np.zeros(0, np.int64),) * 2 + (np.zeros(0, np.uint8), []))
+            return left, right, np.where((strand == 43) | (strand == 45), strand, 0).astype(np.uint8), names
+        genes = self._genes.get(chrom, [])
+        k = len(genes)
+        return (np.fromiter((g.left for g in genes), dtype=np.int64, count=k), np.fromiter((g.right for g in genes), dtype=np.int64, count=k),
+                np.fromiter((43 if g.strand == "+" else (45 if g.strand == "-" else 0) for g in genes), dtype=np.uint8, count=k),
+                [g.name for g in genes])
 
     @classmethod
     def from_annotation(cls, path, a_type="gene", q_gene="All", log=None):
@@ -72,6 +106,25 @@ class GeneBins(object):
         (it tests ``line.type == 'gene'`` literally, SpliSER_v0_1_8.py:82).  Coordinates follow
         HTSeq.GFF_Reader: start = column4 - 1, end = column5 (0-based, half-open)."""
         bins = cls()
+        if q_gene == "All" and USE_NATIVE_TEXT:
+            cols = None
+            try:
+                from . import native
+                cols = native.read_gff_genes(path)
+            except Exception:
+                cols = None
+            if cols is not None:
+                bins._columns = {}
+                for k, chrom in enumerate(cols.chrom_names):
+                    rows = np.flatnonzero(cols.chrom == k)
+                    order = rows[np.argsort(cols.left[rows], kind="stable")]   # = bisect.insort by left, later lines after equal ones
+                    bins._chroms.add(chrom)
+                    bins.chrom_index.append(chrom)
+                    bins._columns[chrom] = (cols.left[order], cols.right[order], cols.strand[order], [cols.names[i] for i in order.tolist()])
+                bins.n_created = int(cols.chrom.shape[0])
+                if log:
+                    log("%d Genes created in %d bins" % (bins.n_created, len(bins.chrom_index)))
+                return bins
         with open(path, "r") as handle:
             for raw in handle:
                 if raw.startswith("#") or not raw.strip():
@@ -86,12 +139,12 @@ class GeneBins(object):
                     bins.n_created += 1
                     at = bisect.bisect_right(bins._lefts[chrom], gene.left)
                     bins._lefts[chrom].insert(at, gene.left)
-                    bins.genes[chrom].insert(at, gene)
+                    bins._genes[chrom].insert(at, gene)
                 elif gene.name == q_gene:
                     if log:
                         log("Query Gene found")
                     bins.query_gene = gene
-                    bins.genes[chrom].append(gene)
+                    bins._genes[chrom].append(gene)
                     bins._lefts[chrom].append(gene.left)
         if log:
             log("%d Genes created in %d bins" % (bins.n_created, len(bins.chrom_index)))

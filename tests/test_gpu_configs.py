@@ -171,3 +171,30 @@ def test_process_reads_beyond_the_reference_length(tmp_path, oracle_lib):
     native.write_bam(prefix + ".bam", wl.genome.chrom_names, [1000] * 5, wl.reads, level=1, threads=2)   # every reference "1 kb long"
     assert cli.main(["process", "-B", prefix + ".bam", "-b", prefix + ".bed", "-o", prefix]) == 0
     assert open(prefix + ".SpliSER.tsv").read() == _oracle_tsv(oracle_lib, prefix + ".bed", wl, None, False)
+
+
+def test_process_check_junctions(tmp_path, capsys):
+    """--checkJunctions: the junction table of the BAM (device) against the BED file's alpha.  A BED file made from the very
+    reads agrees junction by junction; one that claims more reads than the BAM holds is called out."""
+    wl = synth.Workload("arabidopsis", scale=0.005, seed=12, workers=2)
+    prefix = str(tmp_path / "j")
+    _files(wl, prefix)
+    assert cli.main(["process", "-B", prefix + ".bam", "-b", prefix + ".bed", "-o", prefix, "--checkJunctions"]) == 0
+    rows = [l.rstrip("\n").split("\t") for l in open(prefix + ".junctionCheck.tsv")][1:]
+    assert len(rows) == len(wl.junctions[0]) and all(r[6] == "equal" and r[4] == r[5] for r in rows)
+    plain = open(prefix + ".SpliSER.tsv").read()
+    # tamper: the first junction gets 5 more reads in the BED file than the BAM has, the last one is dropped
+    lines = open(prefix + ".bed").read().split("\n")
+    f = lines[1].split("\t")
+    f[4] = str(int(f[4]) + 5)
+    lines[1] = "\t".join(f)
+    with open(prefix + ".2.bed", "w") as fh:
+        fh.write("\n".join(lines[:-2]) + "\n")
+    capsys.readouterr()
+    assert cli.main(["process", "-B", prefix + ".bam", "-b", prefix + ".2.bed", "-o", prefix + "2", "--checkJunctions"]) == 0
+    assert "WARNING: 1 junction(s)" in capsys.readouterr().out
+    status = [l.rstrip("\n").split("\t")[6] for l in open(prefix + "2.junctionCheck.tsv")][1:]
+    assert status.count("bed>bam") == 1 and status.count("bam_only") == 1 and status.count("equal") == len(rows) - 2
+    # and the flag changes nothing in the product's own output
+    assert cli.main(["process", "-B", prefix + ".bam", "-b", prefix + ".bed", "-o", prefix + "3"]) == 0
+    assert open(prefix + "3.SpliSER.tsv").read() == plain
