@@ -207,6 +207,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
+    # torch first: it brings a HIP runtime of its own, and whichever libamdhip64 a process loads first is the one everything
+    # else in it gets -- libspliser_hip.so (loaded by the host helpers below, long before a GPU is touched) would otherwise pull
+    # in the system's, and torch's other libraries do not work with that one.  (Importing does not initialise the GPU.)
+    import torch
     from spliser_amd import native, shard, synth
 
     # ---- synthetic sample of this rank (generated BEFORE the GPU is touched: the generator forks) -----
@@ -227,7 +231,6 @@ def main():
     n_sites = sum(arr.n for _, arr, _ in items)
     t_gen = time.perf_counter() - t_gen
 
-    import torch
     dist = None
     torch.cuda.set_device(local_rank)
     if world > 1:
