@@ -467,6 +467,11 @@ __device__ __forceinline__ void commit_key(const spl_hot_params &p, spl_lds_i32 
         const int arr = (int)(key & 3u);
         const int32_t d = (int32_t)(key >> 2);
         const uint32_t loc = (uint32_t)(d - wbase);
+#ifdef SPL_EXP_FLAT_COMMIT
+        // (experiment, never in the product: every lane adds to a word of its own -- what the kernel would cost if no two lanes
+        //  of an LDS atomic ever met in a bank; results are wrong by construction)
+        { const uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); __hip_atomic_fetch_add(lds + ln, amount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
+#endif
         // (an LDS-typed pointer: ds_add on one side, a global atomic on the other, never a flat atomic on a selected address)
         if (loc <= (uint32_t)WIN) __hip_atomic_fetch_add(lds + (arr * (WIN + 1) + (int)loc), amount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + d], amount);
@@ -1011,6 +1016,9 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         // Once- and twice-spliced reads with rivals, the wave's own, lanes dense: the junction table says which sites of the read's
         // window are affected and how (rivals_inline); what it cannot decide joins the literal list.  The list is read
         // from its growing end, so the front list can only ever grow into entries that are done with.
+#ifdef SPL_EXP_NO_LIST
+        n_back = 0; // (experiment, never in the product: what the list pass costs -- 28 % of the kernel on config 2)
+#endif
         for (uint32_t r0 = 0; r0 < n_back; r0 += 64u) {
             const uint32_t j = r0 + lane;
             bool undecided = false;

@@ -10,7 +10,8 @@ while [ $# -ge 2 ]; do
   /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread $flags -c spl_capi.cpp -o $tmp/c.o
   g++ -O3 -std=c++17 -fPIC -pthread -c bam_reader.cpp -o $tmp/b.o
   g++ -O3 -std=c++17 -fPIC -pthread -c spl_host.cpp -o $tmp/h.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build/exp/$name.so $tmp/k.o $tmp/c.o $tmp/b.o $tmp/h.o -lz -ldl -lpthread
+  g++ -O3 -std=c++17 -fPIC -pthread -c spl_pack.cpp -o $tmp/p.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build/exp/$name.so $tmp/k.o $tmp/c.o $tmp/b.o $tmp/h.o $tmp/p.o -lz -ldl -lpthread
   rm -rf $tmp
   echo built build/exp/$name.so
 done
