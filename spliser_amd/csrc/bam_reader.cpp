@@ -123,14 +123,41 @@ struct Block {
     uint32_t isize; // uncompressed payload
 };
 
+// The reads one batch found for one reference, BAM-native: exact-size arrays carved out of the extracting thread's arena.
 struct RefReads {
-    std::vector<int32_t> pos;
-    std::vector<uint16_t> flag;
-    std::vector<uint32_t> cig_off; // n + 1
-    std::vector<uint32_t> cigar;
+    int32_t *pos = nullptr;
+    uint16_t *flag = nullptr;
+    uint32_t *cig_off = nullptr; // n + 1 entries, cig_off[0] = 0: ops of read k are cigar[cig_off[k] .. cig_off[k + 1])
+    uint32_t *cigar = nullptr;
+    size_t n = 0, n_ops = 0;
     int64_t max_end = 0;
-    RefReads() { cig_off.push_back(0); }
-    void swap_into(RefReads &other) { pos.swap(other.pos); flag.swap(other.flag); cig_off.swap(other.cig_off); cigar.swap(other.cigar); }
+};
+
+// Bump allocation out of large slabs (2 MiB-aligned, huge pages asked for).  What the decoder extracts lives until the file
+// is closed, a decode produces gigabytes of it in pieces of a few hundred kilobytes, and malloc serves pieces of that size
+// with an mmap and an munmap each: on 64 threads the address-space lock and the TLB shoot-downs of those calls were the
+// decode's ceiling.  A slab is never given back before spl_bam_close.
+struct Arena {
+    std::vector<void *> slabs;
+    uint8_t *cur = nullptr, *end = nullptr;
+    bool failed = false;
+    void *take(size_t bytes)
+    {
+        bytes = (bytes + 63) & ~(size_t)63;
+        if ((size_t)(end - cur) < bytes) {
+            const size_t huge = 2u << 20, want = std::max<size_t>(bytes, (size_t)16 << 20);
+            const size_t size = (want + huge - 1) / huge * huge;
+            void *slab = nullptr;
+            if (posix_memalign(&slab, huge, size) != 0) { failed = true; return nullptr; }
+            (void)madvise(slab, size, MADV_HUGEPAGE);
+            slabs.push_back(slab);
+            cur = (uint8_t *)slab;
+            end = cur + size;
+        }
+        void *out = cur;
+        cur += bytes;
+        return out;
+    }
 };
 
 // Inflate one BGZF block into dst (exactly b.isize bytes) and verify its CRC32.
@@ -251,7 +278,8 @@ struct spl_bam {
     // ---- filled by the decode thread, read under `mu` ----
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<std::vector<PendingPart *>> parts; // per reference, file order (owned)
+    std::vector<std::vector<PendingPart *>> parts; // per reference, file order (owned; their arrays live in `slabs`)
+    std::vector<void *> slabs;
     std::vector<int64_t> ref_max_end, ref_reads;
     int complete_upto = 0;      // every reference < this is complete -- if the file is sorted by reference
     int max_tid_seen = -1;
@@ -269,6 +297,7 @@ struct spl_bam {
     size_t fsize = 0;
     std::vector<Block> blocks;
     int n_threads = 1;
+    uint64_t header_bytes = 0; // magic, text and reference dictionary: the first record starts here in the inflated stream
     std::string path;
     ~spl_bam();
 };
@@ -277,78 +306,113 @@ spl_bam::~spl_bam()
 {
     if (worker.joinable()) worker.join();
     for (auto &list : parts) for (PendingPart *p : list) delete p;
+    for (void *slab : slabs) free(slab);
     if (map) munmap(map, fsize);
 }
 
 namespace {
 
 
-// Where a parsing thread puts what it extracts: (reference id, reads) parts in file order.  A coordinate-sorted BAM
-// changes reference rarely, so "same tid as the last part" is the common case.
-struct Sink {
-    struct Part { int32_t tid; RefReads reads; };
-    std::vector<Part> &parts;
-    explicit Sink(std::vector<Part> &p) : parts(p) {}
-    RefReads &at(int32_t tid)
-    {
-        if (parts.empty() || parts.back().tid != tid) { parts.emplace_back(); parts.back().tid = tid; }
-        return parts.back().reads;
-    }
-};
+// What a thread extracts: (reference id, reads) parts in file order.  A coordinate-sorted BAM changes reference rarely, so a
+// stretch of records usually is one part.
+struct Part { int32_t tid; RefReads reads; };
 
-// Parse alignment records starting at p, which MUST be a record boundary.  Stops at the first boundary >= stop_at
-// (when given) or at the last complete record.  Returns the position reached (a record boundary).
-const uint8_t *parse_records(const uint8_t *p, const uint8_t *end, const uint8_t *stop_at, int n_ref, Sink &sink, int64_t &n_records,
-                             std::string &err, bool &fatal)
+// The CIGAR of the record whose fixed fields start at r (block_size bs, `need` = fixed + name + cigar + seq + qual bytes):
+// the record's own ops, or the real ones parked in a CG tag (htslib bam_tag2cigar).
+inline const uint8_t *record_cigar(const uint8_t *r, uint32_t bs, size_t need, uint32_t l_name, uint32_t l_seq, uint32_t &n_cig)
 {
-    while (end - p >= 4 && (!stop_at || p < stop_at)) {
-        const uint32_t bs = le32(p);
+    const uint8_t *cig = r + 32 + l_name;
+    if (n_cig > 0 && (le32(cig) & 15u) == 4u && (le32(cig) >> 4) == l_seq) {
+        uint32_t n_real = 0;
+        const uint8_t *cg = find_cg_tag(r + need, r + bs, &n_real);
+        if (cg && n_real >= n_cig && n_real < (1u << 29)) { cig = cg; n_cig = n_real; }
+    }
+    return cig;
+}
+
+// Extract the alignment records in [p, end); p MUST be a record boundary.  Stops at the last complete record and returns
+// the position reached (a record boundary).  Two walks: the first checks every record and sizes the parts, the second fills
+// arrays of exactly that size -- the bytes are in the caller's cache both times.
+const uint8_t *extract_records(const uint8_t *p, const uint8_t *end, int n_ref, Arena &arena, std::vector<Part> &parts, int64_t &n_records,
+                               std::string &err, bool &fatal)
+{
+    struct Run { int32_t tid; size_t n, ops; const uint8_t *begin; };
+    Run few[4];
+    std::vector<Run> many; // (more than four changes of reference in one stretch: an unsorted file)
+    size_t n_runs = 0;
+    auto run_at = [&](size_t k) -> Run & { return k < 4 ? few[k] : many[k - 4]; };
+    const uint8_t *q = p;
+    while (end - q >= 4) {
+        const uint32_t bs = le32(q);
         if (bs < 32) { err = "corrupt record (block_size < 32)"; fatal = true; break; }
-        if ((size_t)(end - p) < 4 + (size_t)bs) break;
+        if ((size_t)(end - q) < 4 + (size_t)bs) break;
         // the walk is a pointer chase (the next record starts where this one ends); records of one library are about the
         // same size, so the headers a few records ahead are probably where this record's size says
-        __builtin_prefetch(p + 3 * (4 + (size_t)bs));
-        __builtin_prefetch(p + 4 * (4 + (size_t)bs));
-        __builtin_prefetch(p + 4 * (4 + (size_t)bs) + 64);
-        const uint8_t *r = p + 4;
-        const int32_t tid = le32s(r);
-        const int32_t pos0 = le32s(r + 4);
-        const uint32_t l_name = r[8];
+        __builtin_prefetch(q + 3 * (4 + (size_t)bs));
+        __builtin_prefetch(q + 4 * (4 + (size_t)bs));
+        __builtin_prefetch(q + 4 * (4 + (size_t)bs) + 64);
+        const uint8_t *r = q + 4;
+        const int32_t tid = le32s(r), pos0 = le32s(r + 4);
+        const uint32_t l_name = r[8], l_seq = le32(r + 16);
         uint32_t n_cig = le16(r + 12);
-        const uint16_t flag = le16(r + 14);
-        const uint32_t l_seq = le32(r + 16);
-        const size_t fixed = 32;
-        const size_t need = fixed + l_name + 4ull * n_cig + ((size_t)l_seq + 1) / 2 + l_seq;
+        const size_t need = 32 + (size_t)l_name + 4ull * n_cig + ((size_t)l_seq + 1) / 2 + l_seq;
         if (need > bs) { err = "corrupt record (fields exceed block_size)"; fatal = true; break; }
         n_records++;
         if (tid >= 0 && tid < n_ref && pos0 >= 0) {
-            const uint8_t *cig = r + fixed + l_name;
-            // real CIGAR parked in a CG tag? (htslib bam_tag2cigar)
-            if (n_cig > 0 && (le32(cig) & 15u) == 4u && (le32(cig) >> 4) == l_seq) {
-                uint32_t n_real = 0;
-                const uint8_t *cg = find_cg_tag(r + need, r + bs, &n_real);
-                if (cg && n_real >= n_cig && n_real < (1u << 29)) { cig = cg; n_cig = n_real; }
+            (void)record_cigar(r, bs, need, l_name, l_seq, n_cig);
+            if (n_runs == 0 || run_at(n_runs - 1).tid != tid) {
+                const Run fresh = {tid, 0, 0, q};
+                if (n_runs < 4) few[n_runs] = fresh; else many.push_back(fresh);
+                ++n_runs;
             }
-            RefReads &rr = sink.at(tid);
+            Run &run = run_at(n_runs - 1);
+            run.n++;
+            run.ops += n_cig;
+        }
+        q += 4 + (size_t)bs;
+    }
+    const uint8_t *reached = q;
+    for (size_t k = 0; k < n_runs; ++k) {
+        const Run &run = run_at(k);
+        if (run.ops > 0xfffffff0ull) { err = "more than 2^32 CIGAR operations in one stretch of records"; fatal = true; return reached; }
+        RefReads rr;
+        rr.n = run.n;
+        rr.n_ops = run.ops;
+        rr.pos = (int32_t *)arena.take(sizeof(int32_t) * run.n);
+        rr.flag = (uint16_t *)arena.take(sizeof(uint16_t) * run.n);
+        rr.cig_off = (uint32_t *)arena.take(sizeof(uint32_t) * (run.n + 1));
+        rr.cigar = (uint32_t *)arena.take(sizeof(uint32_t) * std::max<size_t>(run.ops, 1));
+        if (!rr.pos || !rr.flag || !rr.cig_off || !rr.cigar) { err = "out of host memory"; fatal = true; return reached; }
+        rr.cig_off[0] = 0;
+        size_t i = 0, at = 0;
+        for (q = run.begin; i < run.n; q += 4 + (size_t)le32(q)) {
+            const uint32_t bs = le32(q);
+            __builtin_prefetch(q + 3 * (4 + (size_t)bs));
+            const uint8_t *r = q + 4;
+            const int32_t tid = le32s(r), pos0 = le32s(r + 4);
+            if (tid != run.tid || pos0 < 0) continue; // (an unplaced record inside the run)
+            const uint32_t l_name = r[8], l_seq = le32(r + 16);
+            uint32_t n_cig = le16(r + 12);
+            const size_t need = 32 + (size_t)l_name + 4ull * n_cig + ((size_t)l_seq + 1) / 2 + l_seq;
+            const uint8_t *cig = record_cigar(r, bs, need, l_name, l_seq, n_cig);
             int64_t ref_len = 0;
-            const size_t base = rr.cigar.size();
-            rr.cigar.resize(base + n_cig);
-            uint32_t *dst = rr.cigar.data() + base;
-            for (uint32_t k = 0; k < n_cig; ++k) {
-                const uint32_t op = le32(cig + 4ull * k);
-                dst[k] = op;
+            uint32_t *dst = rr.cigar + at;
+            for (uint32_t c = 0; c < n_cig; ++c) {
+                const uint32_t op = le32(cig + 4ull * c);
+                dst[c] = op;
                 const uint32_t code = op & 15u;
                 if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) ref_len += op >> 4;
             }
-            rr.pos.push_back(pos0 + 1);
-            rr.flag.push_back(flag);
-            rr.cig_off.push_back((uint32_t)rr.cigar.size());
+            at += n_cig;
+            rr.pos[i] = pos0 + 1;
+            rr.flag[i] = le16(r + 14);
+            rr.cig_off[++i] = (uint32_t)at;
             const int64_t e = (int64_t)pos0 + 1 + (ref_len > 0 ? ref_len : 1) - 1;
             if (e > rr.max_end) rr.max_end = e;
         }
-        p += 4 + (size_t)bs;
+        parts.push_back(Part{run.tid, rr});
     }
-    return p;
+    return reached;
 }
 
 // Does a record plausibly start at c?  Every fixed field is checked against the BAM specification; the caller also
@@ -395,22 +459,24 @@ const uint8_t *find_record_start(const uint8_t *from, const uint8_t *end, int n_
 
 // The parse threads' parts, in file order, are handed to their references (nothing is copied); what is complete by now is
 // announced to the waiting consumers.
-void merge_parts(spl_bam *bam, std::vector<Sink::Part> &parts)
+void merge_parts(spl_bam *bam, std::vector<Part> &parts)
 {
     std::lock_guard<std::mutex> lock(bam->mu);
-    for (Sink::Part &pt : parts) {
-        if (pt.reads.pos.empty()) continue;
+    const int before = bam->complete_upto;
+    for (Part &pt : parts) {
+        if (pt.reads.n == 0) continue;
         if (pt.tid < bam->max_tid_seen) bam->out_of_order = true;
         if (pt.tid > bam->max_tid_seen) bam->max_tid_seen = pt.tid;
+        std::vector<PendingPart *> &list = bam->parts[(size_t)pt.tid];
+        bam->ref_reads[(size_t)pt.tid] += (int64_t)pt.reads.n;
+        if (pt.reads.max_end > bam->ref_max_end[(size_t)pt.tid]) bam->ref_max_end[(size_t)pt.tid] = pt.reads.max_end;
         PendingPart *pp = new PendingPart();
         pp->tid = pt.tid;
-        pp->reads = std::move(pt.reads);
-        bam->ref_reads[(size_t)pt.tid] += (int64_t)pp->reads.pos.size();
-        if (pp->reads.max_end > bam->ref_max_end[(size_t)pt.tid]) bam->ref_max_end[(size_t)pt.tid] = pp->reads.max_end;
-        bam->parts[(size_t)pt.tid].push_back(pp);
+        pp->reads = pt.reads;
+        list.push_back(pp);
     }
     if (bam->max_tid_seen > bam->complete_upto) bam->complete_upto = bam->max_tid_seen;
-    bam->cv.notify_all();
+    if (bam->complete_upto != before) bam->cv.notify_all();
 }
 
 // BAM-native arrays of one reference (spl_bam_reads): one exact-size allocation per array, copied from the parts.
@@ -419,7 +485,7 @@ bool assemble_ref(spl_bam *bam, int tid, std::string &err)
     RefFinal &dst = bam->refs_storage[(size_t)tid];
     const std::vector<PendingPart *> &parts = bam->parts[(size_t)tid];
     int64_t n = 0, g = 0;
-    for (const PendingPart *pt : parts) { n += (int64_t)pt->reads.pos.size(); g += (int64_t)pt->reads.cigar.size(); }
+    for (const PendingPart *pt : parts) { n += (int64_t)pt->reads.n; g += (int64_t)pt->reads.n_ops; }
     if (g > 0xfffffff0LL) { err = "more than 2^32 CIGAR operations on one reference"; return false; }
     dst.n = n;
     dst.n_cigar = g;
@@ -432,8 +498,8 @@ bool assemble_ref(spl_bam *bam, int tid, std::string &err)
     dst.cig_off[0] = 0;
     std::vector<int64_t> read_at(parts.size() + 1, 0), op_at(parts.size() + 1, 0);
     for (size_t i = 0; i < parts.size(); ++i) {
-        read_at[i + 1] = read_at[i] + (int64_t)parts[i]->reads.pos.size();
-        op_at[i + 1] = op_at[i] + (int64_t)parts[i]->reads.cigar.size();
+        read_at[i + 1] = read_at[i] + (int64_t)parts[i]->reads.n;
+        op_at[i + 1] = op_at[i] + (int64_t)parts[i]->reads.n_ops;
     }
     std::atomic<size_t> next(0);
     auto work = [&]() {
@@ -441,14 +507,14 @@ bool assemble_ref(spl_bam *bam, int tid, std::string &err)
             const size_t i = next.fetch_add(1);
             if (i >= parts.size()) break;
             const RefReads &src = parts[i]->reads;
-            const size_t k = src.pos.size();
+            const size_t k = src.n;
             if (!k) continue;
-            memcpy(dst.pos + read_at[i], src.pos.data(), sizeof(int32_t) * k);
-            memcpy(dst.flag + read_at[i], src.flag.data(), sizeof(uint16_t) * k);
+            memcpy(dst.pos + read_at[i], src.pos, sizeof(int32_t) * k);
+            memcpy(dst.flag + read_at[i], src.flag, sizeof(uint16_t) * k);
             const uint32_t base = (uint32_t)op_at[i];
             uint32_t *off = dst.cig_off + read_at[i]; // entry j + 1 = end of read j
             for (size_t j = 1; j <= k; ++j) off[j] = base + src.cig_off[j];
-            if (!src.cigar.empty()) memcpy(dst.cigar + op_at[i], src.cigar.data(), sizeof(uint32_t) * src.cigar.size());
+            if (src.n_ops) memcpy(dst.cigar + op_at[i], src.cigar, sizeof(uint32_t) * src.n_ops);
         }
     };
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::min(bam->n_threads, 16), parts.size()));
@@ -459,224 +525,204 @@ bool assemble_ref(spl_bam *bam, int tid, std::string &err)
     return true;
 }
 
-// Parse the records of one inflated segment on several threads.  Thread t looks for the first record boundary at or
-// after its nominal start (plausibility + chaining), parses to the first boundary at or after its nominal end, and
-// the results are accepted only if every walk ends exactly where the next one started -- by induction from the known
-// true boundary at the segment start, every accepted start is then a true boundary.  Otherwise: one thread.
-const uint8_t *parse_segment_parallel(spl_bam *bam, const uint8_t *p, const uint8_t *end, int n_threads, const NodeCpus &node, std::string &err,
-                                      bool &fatal)
-{
-    const int n_ref = bam->n_refs;
-    const size_t bytes = (size_t)(end - p);
-    static const int cap = []() { const char *e = getenv("SPL_BAM_PARSE_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
-    int T = n_threads > cap ? cap : n_threads; // the walk is latency-bound and short: more threads cost more to start than they save
-    if (bytes < (size_t)(8u << 20) || T < 2) T = 1;
-    std::vector<std::vector<Sink::Part>> parts((size_t)T);
-    std::vector<const uint8_t *> start((size_t)T + 1), reached((size_t)T);
-    std::vector<int64_t> nrec((size_t)T, 0);
-    std::vector<std::string> errs((size_t)T);
-    std::vector<char> fat((size_t)T, 0);
-    start[0] = p;
-    start[(size_t)T] = end;
-    std::vector<double> busy((size_t)T, 0.0);
-    auto clock_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    auto work = [&](int t) {
-        const double w0 = clock_now();
-        const uint8_t *nominal_start = p + bytes / (size_t)T * (size_t)t;
-        const uint8_t *nominal_end = (t + 1 == T) ? nullptr : p + bytes / (size_t)T * (size_t)(t + 1);
-        if (t > 0) start[(size_t)t] = find_record_start(nominal_start, end, n_ref);
-        Sink sink(parts[(size_t)t]);
-        bool f = false;
-        reached[(size_t)t] = parse_records(start[(size_t)t], end, nominal_end, n_ref, sink, nrec[(size_t)t], errs[(size_t)t], f);
-        fat[(size_t)t] = f ? 1 : 0;
-        busy[(size_t)t] = clock_now() - w0;
-    };
-    const double seg_t0 = clock_now();
-    if (T > 1) {
-        std::vector<std::thread> pool;
-        for (int t = 1; t < T; ++t) pool.emplace_back([&, t]() { node.pin_this_thread(); work(t); });
-        work(0);
-        for (auto &th : pool) th.join();
-    } else {
-        work(0);
-    }
-    if (getenv("SPL_BAM_TIMING_DETAIL")) {
-        double mx = 0, sum = 0;
-        for (double b : busy) { mx = std::max(mx, b); sum += b; }
-        fprintf(stderr, "[parse segment] %zu MB, %d threads: wall %.4f s, slowest thread %.4f s, mean thread %.4f s\n", bytes >> 20, T,
-                clock_now() - seg_t0, mx, sum / T);
-    }
-    bool consistent = true;
-    for (int t = 0; t + 1 < T; ++t) consistent &= (reached[(size_t)t] == start[(size_t)t + 1]) && !fat[(size_t)t];
-    if (!consistent) { // a guessed boundary was wrong (or the data is corrupt): redo sequentially, authoritative
-        std::vector<Sink::Part> seq;
-        Sink sink(seq);
-        int64_t n = 0;
-        const uint8_t *r = parse_records(p, end, nullptr, n_ref, sink, n, err, fatal);
-        merge_parts(bam, seq);
-        bam->n_records += n;
-        return r;
-    }
-    if (fat[(size_t)T - 1]) { err = errs[(size_t)T - 1]; fatal = true; }
-    for (int t = 0; t < T; ++t) { merge_parts(bam, parts[(size_t)t]); bam->n_records += nrec[(size_t)t]; }
-    return reached[(size_t)T - 1];
-}
-
-struct Parser {
-    spl_bam *bam;
-    const NodeCpus *node = nullptr;
-    int n_threads = 1;
-    bool header_done = false;
-    bool bam_header_set = false; // spl_bam already has names, lengths and per-reference state
-    std::string err;
-
-    // Consume as many complete items as possible from [p, end); returns bytes consumed.
-    size_t feed(const uint8_t *p, const uint8_t *end, bool &fatal)
-    {
-        const uint8_t *start = p;
-        fatal = false;
-        if (!header_done) {
-            // magic, l_text, text, n_ref, then per ref: l_name, name, l_ref -- needs to be complete in the buffer
-            if (end - p < 12) return 0;
-            if (memcmp(p, "BAM\1", 4) != 0) { err = "not a BAM file (bad magic)"; fatal = true; return 0; }
-            const uint32_t l_text = le32(p + 4);
-            if ((size_t)(end - p) < 12 + (size_t)l_text) return 0;
-            const uint8_t *q = p + 8 + l_text;
-            const int32_t n_ref = le32s(q);
-            q += 4;
-            if (n_ref < 0) { err = "negative n_ref"; fatal = true; return 0; }
-            std::vector<std::string> names;
-            std::vector<int64_t> lens;
-            for (int32_t i = 0; i < n_ref; ++i) {
-                if (end - q < 4) return 0;
-                const uint32_t l_name = le32(q);
-                if ((size_t)(end - q) < 4 + (size_t)l_name + 4) return 0;
-                names.emplace_back((const char *)q + 4, l_name ? l_name - 1 : 0);
-                lens.push_back(le32(q + 4 + l_name));
-                q += 4 + l_name + 4;
-            }
-            if (!bam_header_set) { // (the opening call has parsed the header already: same bytes, same result)
-                std::lock_guard<std::mutex> lock(bam->mu);
-                bam->ref_names.swap(names);
-                bam->ref_lengths.swap(lens);
-                bam->refs_storage = std::vector<RefFinal>((size_t)n_ref);
-                bam->assembled.assign((size_t)n_ref, 0);
-                bam->parts.assign((size_t)n_ref, std::vector<PendingPart *>());
-                bam->ref_max_end.assign((size_t)n_ref, 0);
-                bam->ref_reads.assign((size_t)n_ref, 0);
-                bam->n_refs = n_ref;
-            }
-            header_done = true;
-            p = q;
-        }
-        p = parse_segment_parallel(bam, p, end, n_threads, *node, err, fatal);
-        return (size_t)(p - start);
-    }
+// The decode proper, on the file's own thread.  The blocks are dealt out in BATCHES of a few consecutive blocks (two
+// megabytes inflated); a worker thread inflates a batch into a buffer of its own and extracts the records right there, while the
+// bytes are still in its cache -- the inflated stream is never written out to memory and read back, and every thread does both
+// halves of the work.  Where the first record of a batch starts is not known when the batch is taken (records straddle blocks and
+// batches freely): the worker GUESSES the first boundary (a plausible record header whose successors chain, find_record_start)
+// and keeps a copy of the bytes in front of it (`head`) and of the incomplete record at the end (`tail`).  This thread commits
+// the batches in file order and accepts a batch only if the bytes carried over from its predecessors plus its head are whole
+// records, i.e. if a sequential walk from the last known boundary arrives exactly at the guessed start -- by induction from the
+// end of the header every accepted start is a true boundary, whatever the guess was based on.  A batch that fails the test is
+// inflated again and walked sequentially from the known boundary (never seen on a well-formed file; the tests force it).
+struct BatchOut {
+    std::vector<Part> parts;
+    std::vector<uint8_t> head, tail;
+    size_t len = 0, start = 0;
+    int64_t nrec = 0;
+    bool inflate_bad = false, parse_bad = false;
+    std::atomic<int> state{0}; // 0 = the worker's, 1 = ready to commit
 };
 
-} // namespace
-
-namespace {
-
-// The decode proper, on the file's own thread: segments of blocks, double-buffered -- while the records of segment k are being
-// extracted (parse threads), the blocks of segment k+1 are already being inflated (inflate threads).  Ends by setting `done`
-// (and `error`).
 void decode_worker(spl_bam *bam)
 {
     const uint8_t *file = (const uint8_t *)bam->map;
     const std::vector<Block> &blocks = bam->blocks;
-    const int n_threads = bam->n_threads;
+    const int n_ref = bam->n_refs;
     const NodeCpus node; // the NUMA node this thread runs on (the opening thread's, inherited): all worker threads stay there
-    const size_t SEG_BLOCKS = []() { const char *e = getenv("SPL_BAM_SEG_BLOCKS"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)4096; }();
-    // (<= 256 MiB uncompressed per segment: a reference is announced complete at segment granularity)
-    const size_t HEAD = 4u << 20;   // room in front of a segment for the incomplete record carried over from the previous one
-    const size_t n_seg = (blocks.size() + SEG_BLOCKS - 1) / SEG_BLOCKS;
-    // two inflate buffers of the size of the largest segment: never zero-filled, huge pages where the system gives them
-    size_t seg_max = 0;
-    for (size_t sg = 0; sg < n_seg; ++sg) {
-        size_t bytes_in = 0;
-        for (size_t i = sg * SEG_BLOCKS; i < std::min(blocks.size(), (sg + 1) * SEG_BLOCKS); ++i) bytes_in += blocks[i].isize;
-        seg_max = std::max(seg_max, bytes_in);
-    }
-    std::string fail;
-    struct RawBuf {
-        uint8_t *p = nullptr;
-        ~RawBuf() { free(p); }
-        uint8_t *data() { return p; }
-    } bufs[2];
-    for (int k = 0; k < 2; ++k) {
-        bufs[k].p = (uint8_t *)big_alloc(HEAD + seg_max + 64);
-        if (!bufs[k].p) fail = "out of host memory for the inflate buffers";
-    }
-    size_t seg_bytes[2] = {0, 0};
-    std::atomic<bool> bad(false);
+    auto env_num = [](const char *name, long dflt) { const char *e = getenv(name); const long v = e ? atol(e) : 0; return v > 0 ? v : dflt; };
+    const size_t BATCH = (size_t)env_num("SPL_BAM_BATCH_BLOCKS", 32);
+    const bool force_slow = getenv("SPL_BAM_FORCE_RESYNC") != nullptr; // (tests: every batch takes the sequential path)
     const bool timing = getenv("SPL_BAM_TIMING") != nullptr;
-    double t_wait = 0, t_parse = 0;
-    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    auto inflate_segment = [&](size_t seg) {
-        const size_t b0 = seg * SEG_BLOCKS, b1 = std::min(blocks.size(), b0 + SEG_BLOCKS);
-        std::vector<size_t> uoff(b1 - b0 + 1);
-        uoff[0] = HEAD;
-        for (size_t i = b0; i < b1; ++i) uoff[i - b0 + 1] = uoff[i - b0] + blocks[i].isize;
-        RawBuf &buf = bufs[seg & 1];
-        seg_bytes[seg & 1] = uoff[b1 - b0] - HEAD;
-        std::atomic<size_t> next(b0);
-        auto work = [&]() {
-            void *ld = deflate_lib().ok ? deflate_lib().alloc() : nullptr;
-            for (;;) {
-                const size_t i = next.fetch_add(1);
-                if (i >= b1) break;
-                if (!inflate_block(file, blocks[i], buf.data() + uoff[i - b0], ld)) bad.store(true);
-            }
-            if (ld) deflate_lib().free_(ld);
-        };
-        const int nt = (int)std::min<size_t>((size_t)n_threads, b1 - b0);
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back([&]() { node.pin_this_thread(); work(); });
-        work();
-        for (auto &t : pool) t.join();
+    const size_t n_batches = (blocks.size() + BATCH - 1) / BATCH;
+    std::vector<uint64_t> u0(n_batches + 1, 0); // offset of each batch in the inflated stream
+    for (size_t b = 0; b < n_batches; ++b) {
+        uint64_t bytes = 0;
+        for (size_t i = b * BATCH; i < std::min(blocks.size(), (b + 1) * BATCH); ++i) bytes += blocks[i].isize;
+        u0[b + 1] = u0[b] + bytes;
+    }
+    const uint64_t H = bam->header_bytes; // the first record starts here
+    std::string fail;
+    if (H > u0[n_batches]) fail = "no BAM header found";
+    size_t first_batch = 0;
+    while (first_batch < n_batches && u0[first_batch + 1] <= H) ++first_batch; // (batches of header bytes only, and empty ones)
+    const int n_workers = (int)std::max<size_t>(1, std::min<size_t>((size_t)bam->n_threads, n_batches - std::min(n_batches, first_batch)));
+    const size_t W = 4 * (size_t)n_workers; // batches in flight: finished but not yet committed, or being worked on
+    std::vector<BatchOut> ring(W);
+    // No lock anywhere on the batches' way: a slot is handed over by its state word, room in the ring is the frontier counter.
+    // (Condition variables were tried first: with 64 workers every commit woke the lot of them, 6 of 9 seconds went into that.)
+    std::atomic<size_t> frontier(first_batch); // the next batch to commit; slot b % W is free for batch b once frontier > b - W
+    std::atomic<bool> stop(false);
+    std::atomic<size_t> next(first_batch);
+    auto nap = [](int &spins) { // wait a little: busy first (the other side is usually microseconds away), then off the core
+        if (++spins < 2000) { __builtin_ia32_pause(); return; }
+        std::this_thread::sleep_for(std::chrono::microseconds(spins < 4000 ? 20 : 200));
     };
-    Parser parser;
-    parser.bam = bam;
-    parser.node = &node;
-    parser.n_threads = n_threads;
-    parser.bam_header_set = true;
-    std::vector<uint8_t> carry_bytes;
-    size_t carry = 0;
-    if (fail.empty()) inflate_segment(0);
-    for (size_t seg = 0; seg < n_seg && fail.empty(); ++seg) {
-        if (bad.load()) { fail = "inflate or CRC32 failure in a BGZF block (corrupt file)"; break; }
-        std::thread ahead;
-        if (seg + 1 < n_seg) ahead = std::thread([&, seg]() { node.pin_this_thread(); inflate_segment(seg + 1); });
-        const double t0 = now();
-        RawBuf &buf = bufs[seg & 1];
-        uint8_t *begin = buf.data() + HEAD;
-        const size_t total = seg_bytes[seg & 1];
-        std::vector<uint8_t> joined;
-        const uint8_t *p0 = begin, *p1 = begin + total;
-        if (carry) {
-            if (carry <= HEAD) { memcpy(begin - carry, carry_bytes.data(), carry); p0 = begin - carry; }
-            else { // a record larger than the head room: splice into a fresh buffer
-                joined.resize(carry + total);
-                memcpy(joined.data(), carry_bytes.data(), carry);
-                memcpy(joined.data() + carry, begin, total);
-                p0 = joined.data(); p1 = joined.data() + joined.size();
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+
+    double sum_inflate = 0, sum_extract = 0; // (SPL_BAM_TIMING: thread-seconds)
+    auto keep_slabs = [&](Arena &a) { // (the file owns what its parts point into)
+        std::lock_guard<std::mutex> lock(bam->mu);
+        bam->slabs.insert(bam->slabs.end(), a.slabs.begin(), a.slabs.end());
+        a.slabs.clear();
+    };
+    auto inflate_batch = [&](size_t b, uint8_t *buf, void *ld) {
+        size_t at = 0;
+        bool ok = true;
+        for (size_t i = b * BATCH; i < std::min(blocks.size(), (b + 1) * BATCH); ++i) {
+            ok = inflate_block(file, blocks[i], buf + at, ld) && ok;
+            at += blocks[i].isize;
+        }
+        return ok;
+    };
+    auto work = [&]() {
+        void *ld = deflate_lib().ok ? deflate_lib().alloc() : nullptr;
+        std::vector<uint8_t> store(BATCH * 65536 + 64);
+        uint8_t *buf = store.data();
+        Arena arena;
+        double my_inflate = 0, my_extract = 0;
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= n_batches) break;
+            for (int spins = 0; !stop.load(std::memory_order_acquire) && b >= frontier.load(std::memory_order_acquire) + W;) nap(spins);
+            if (stop.load(std::memory_order_acquire)) break;
+            BatchOut &o = ring[b % W];
+            o.len = (size_t)(u0[b + 1] - u0[b]);
+            const double w0 = timing ? now() : 0.0;
+            o.inflate_bad = !inflate_batch(b, buf, ld);
+            const double w1 = timing ? now() : 0.0;
+            o.start = o.len;
+            size_t reached = o.len;
+            if (!o.inflate_bad) {
+                const uint8_t *end = buf + o.len;
+                const uint8_t *p = (b == first_batch) ? buf + (size_t)(H - u0[b]) : find_record_start(buf, end, n_ref);
+                o.start = (size_t)(p - buf);
+                std::string err;
+                bool fatal = false;
+                reached = (size_t)(extract_records(p, end, n_ref, arena, o.parts, o.nrec, err, fatal) - buf);
+                o.parse_bad = fatal;
+                if (b != first_batch) o.head.assign((const uint8_t *)buf, (const uint8_t *)buf + o.start);
+                o.tail.assign((const uint8_t *)buf + reached, end);
+            }
+            o.state.store(1, std::memory_order_release);
+            if (timing) { const double w2 = now(); my_inflate += w1 - w0; my_extract += w2 - w1; }
+        }
+        if (timing) { std::lock_guard<std::mutex> lock(bam->mu); sum_inflate += my_inflate; sum_extract += my_extract; }
+        keep_slabs(arena);
+        if (ld) deflate_lib().free_(ld);
+    };
+    std::vector<std::thread> pool;
+    if (fail.empty())
+        for (int t = 0; t < n_workers; ++t) pool.emplace_back([&]() { node.pin_this_thread(); work(); });
+
+    // ---- commit, in file order
+    std::vector<uint8_t> carry, joined, again; // carry: the bytes between the last committed record and the frontier batch
+    void *ld_mine = nullptr;
+    Arena arena_mine;
+    double t_wait = 0, t_bridge = 0, t_merge = 0, t_release = 0;
+    size_t n_resync = 0;
+    auto walk = [&](const uint8_t *p0, const uint8_t *p1, bool &fatal) { // sequential, authoritative: commits what it parses
+        std::vector<Part> seq;
+        int64_t n = 0;
+        const uint8_t *r = extract_records(p0, p1, n_ref, arena_mine, seq, n, fail, fatal);
+        merge_parts(bam, seq);
+        bam->n_records += n;
+        return r;
+    };
+    for (size_t b = first_batch; b < n_batches && fail.empty(); ++b) {
+        BatchOut &o = ring[b % W];
+        if (o.state.load(std::memory_order_acquire) != 1) {
+            const double w0 = now();
+            for (int spins = 0; o.state.load(std::memory_order_acquire) != 1;) nap(spins);
+            t_wait += now() - w0;
+        }
+        const double c0 = now();
+        if (o.inflate_bad) { fail = "inflate or CRC32 failure in a BGZF block (corrupt file)"; break; }
+        bool accept = !o.parse_bad && !force_slow;
+        bool fatal = false, handled = false;
+        if (accept && (!carry.empty() || !o.head.empty())) {
+            joined.assign(carry.begin(), carry.end());
+            joined.insert(joined.end(), o.head.begin(), o.head.end());
+            // (peek first: nothing may be committed from a walk that turns out not to arrive at the guessed start)
+            const uint8_t *q = joined.data(), *qe = joined.data() + joined.size();
+            while (qe - q >= 4) {
+                const uint32_t bs = le32(q);
+                if (bs < 32 || (size_t)(qe - q) < 4 + (size_t)bs) break;
+                q += 4 + (size_t)bs;
+            }
+            if (q == qe) {
+                const uint8_t *r = walk(joined.data(), qe, fatal);
+                if (fatal) break;
+                accept = (r == qe);
+                carry.clear();
+            } else if (o.start == o.len) { // no record starts in this batch: one record spans it (or the file ends inside one)
+                const uint8_t *r = walk(joined.data(), q, fatal);
+                if (fatal) break;
+                carry.assign(r, qe);
+                handled = true;
+            } else {
+                accept = false;
             }
         }
-        bool fatal = false;
-        const size_t used = parser.feed(p0, p1, fatal);
-        if (fatal) fail = parser.err;
-        carry = (size_t)(p1 - p0) - used;
-        carry_bytes.assign(p0 + used, p1);
-        const double t1 = now();
-        if (ahead.joinable()) ahead.join();
-        t_parse += t1 - t0;
-        t_wait += now() - t1;
+        const double c1 = now();
+        t_bridge += c1 - c0;
+        if (handled) {
+        } else if (accept) {
+            merge_parts(bam, o.parts);
+            bam->n_records += o.nrec;
+            carry.swap(o.tail);
+        } else { // the guess did not hold: this batch again, sequentially, from the known boundary
+            ++n_resync;
+            if (!ld_mine && deflate_lib().ok) ld_mine = deflate_lib().alloc();
+            again.resize(carry.size() + o.len + 64);
+            if (!carry.empty()) memcpy(again.data(), carry.data(), carry.size());
+            if (!inflate_batch(b, again.data() + carry.size(), ld_mine)) { fail = "inflate or CRC32 failure in a BGZF block (corrupt file)"; break; }
+            const uint8_t *p0 = again.data(), *p1 = again.data() + carry.size() + o.len;
+            if (b == first_batch) p0 += (size_t)(H - u0[b]);
+            const uint8_t *r = walk(p0, p1, fatal);
+            if (fatal) break;
+            carry.assign(r, p1);
+        }
+        o.parts.clear();
+        o.head.clear();
+        o.tail.clear();
+        o.nrec = 0;
+        const double c2 = now();
+        t_merge += c2 - c1;
+        o.state.store(0, std::memory_order_relaxed);
+        frontier.store(b + 1, std::memory_order_release);
+        t_release += now() - c2;
     }
-    if (fail.empty() && bad.load()) fail = "inflate or CRC32 failure in a BGZF block (corrupt file)";
-    if (timing) fprintf(stderr, "[spl_bam_open] %zu blocks, %d threads: parse %.3f s, waiting for inflate %.3f s\n", blocks.size(), n_threads, t_parse, t_wait);
-    if (fail.empty() && !parser.header_done) fail = "no BAM header found";
-    if (fail.empty() && carry != 0) fail = "file ends inside a record (truncated)";
+    stop.store(true, std::memory_order_release);
+    for (auto &t : pool) t.join();
+    keep_slabs(arena_mine);
+    if (ld_mine) deflate_lib().free_(ld_mine);
+    if (timing)
+        fprintf(stderr, "[spl_bam_open] %zu blocks in %zu batches, %d threads: %.3f s, the committing thread waited %.3f s of that (straddling records %.3f s, hand-over %.3f s, "
+                "ring %.3f s), %zu batches re-walked; workers: inflate + CRC %.2f thread-s, records %.2f thread-s\n", blocks.size(), n_batches, n_workers,
+                now() - t_begin, t_wait, t_bridge, t_merge, t_release, n_resync, sum_inflate, sum_extract);
+    if (fail.empty() && !carry.empty()) fail = "file ends inside a record (truncated)";
     {
         std::lock_guard<std::mutex> lock(bam->mu);
         if (!fail.empty()) { bam->error = bam->path + ": " + fail; bam->err_code = SPL_ERR_FORMAT; }
@@ -727,6 +773,7 @@ int read_header(spl_bam *bam, std::string &fail)
         bam->ref_max_end.assign((size_t)n_ref, 0);
         bam->ref_reads.assign((size_t)n_ref, 0);
         bam->n_refs = n_ref;
+        bam->header_bytes = (uint64_t)(q - p);
         rc = 0;
     }
     if (ld) deflate_lib().free_(ld);
@@ -753,6 +800,7 @@ extern "C" int spl_bam_open_stream(const char *path, int n_threads, spl_bam **ou
     const uint8_t *file = (const uint8_t *)map;
 
     // 1. block directory (headers only)
+    const auto t_dir = std::chrono::steady_clock::now();
     std::vector<Block> blocks;
     size_t off = 0;
     int rc = SPL_OK;
@@ -783,6 +831,9 @@ extern "C" int spl_bam_open_stream(const char *path, int n_threads, spl_bam **ou
         off += bsize;
     }
     if (rc != SPL_OK) { munmap(map, fsize); return rc; }
+    if (getenv("SPL_BAM_TIMING"))
+        fprintf(stderr, "[spl_bam_open] block directory: %zu blocks of %.1f MB in %.3f s\n", blocks.size(), fsize / 1e6,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dir).count());
     if (blocks.empty() || blocks.back().isize != 0) {
         // htslib only warns about a missing EOF marker; a truncated file is far more likely than a writer
         // that omits it, and silently counting fewer reads is the reference's worst failure mode: refuse.
@@ -796,9 +847,11 @@ extern "C" int spl_bam_open_stream(const char *path, int n_threads, spl_bam **ou
     bam->fsize = fsize;
     bam->blocks.swap(blocks);
     bam->path = path;
-    if (n_threads <= 0) { // default: all cores up to 32 (beyond that thread start-up per segment costs more than it buys)
+    if (n_threads <= 0) { // default: all hardware threads up to SPL_BAM_THREADS (32 unless the environment says otherwise)
+        const char *e = getenv("SPL_BAM_THREADS");
+        const int cap = e && atoi(e) > 0 ? atoi(e) : 32;
         n_threads = (int)std::thread::hardware_concurrency();
-        if (n_threads > 32) n_threads = 32;
+        if (n_threads > cap) n_threads = cap;
     }
     bam->n_threads = n_threads > 0 ? n_threads : 1;
     std::string fail;
@@ -900,8 +953,8 @@ int spl_bam_source(spl_bam *bam, int tid, splpack::Source *out, int64_t *max_end
     std::lock_guard<std::mutex> lock(bam->mu);
     for (const PendingPart *pt : bam->parts[(size_t)tid]) {
         const RefReads &r = pt->reads;
-        if (r.pos.empty()) continue;
-        out->add(splpack::Part{r.pos.data(), r.flag.data(), r.cig_off.data(), r.cigar.data(), (int64_t)r.pos.size()});
+        if (r.n == 0) continue;
+        out->add(splpack::Part{r.pos, r.flag, r.cig_off, r.cigar, (int64_t)r.n});
     }
     return SPL_OK;
 }

@@ -1,0 +1,98 @@
+"""The BAM decoder's batch scheme (bam_reader.cpp, decode_worker): records straddle blocks and batches, first record boundaries are
+guessed per batch and accepted only when the sequential walk arrives there.  Every way through it must give back exactly the
+records that were written: default batches, one block per batch (nearly every batch starts inside a record), the forced
+sequential path, records larger than a batch, one thread and many."""
+import numpy as np
+import pytest
+
+from spliser_amd import native, samio
+
+
+@pytest.fixture(scope="module")
+def built():
+    native.build()
+    return native.lib()
+
+
+def _same(got, want):
+    assert got.n == want.n
+    assert np.array_equal(got.pos, want.pos) and np.array_equal(got.flag, want.flag)
+    assert np.array_equal(got.cig_off, want.cig_off) and np.array_equal(got.cigar, want.cigar)
+    assert got.max_end == want.max_end
+
+
+def _random_sets(seed, n_per_ref, n_ref):
+    rng = np.random.default_rng(seed)
+    names = ["c%d" % k for k in range(n_ref)]
+    sets = {}
+    for c in names:
+        n = int(n_per_ref * rng.uniform(0.5, 1.5))
+        pos = np.sort(rng.integers(1, 5_000_000, n)).astype(np.int32)
+        n_ops = rng.choice([1, 3, 5, 7, 2], size=n, p=[0.6, 0.25, 0.08, 0.02, 0.05])
+        cig_off = np.concatenate(([0], np.cumsum(n_ops))).astype(np.uint32)
+        cigar = np.empty(int(cig_off[-1]), np.uint32)
+        k = 0
+        for i in range(n):
+            m = int(n_ops[i])
+            for j in range(m):
+                if m == 2:
+                    code, length = (4, 5) if j == 0 else (0, 70)
+                else:
+                    code, length = (0, int(rng.integers(10, 80))) if j % 2 == 0 else (3, int(rng.integers(70, 4000)))
+                cigar[k] = (length << 4) | code
+                k += 1
+        flag = rng.choice([0, 16, 99, 147, 83, 163, 256, 1024], size=n).astype(np.uint16)
+        sets[c] = samio.ReadSet(pos, flag, cig_off, cigar)
+    return names, sets
+
+
+@pytest.mark.parametrize("env", [dict(), dict(SPL_BAM_BATCH_BLOCKS="1"), dict(SPL_BAM_BATCH_BLOCKS="3"), dict(SPL_BAM_FORCE_RESYNC="1"),
+                                 dict(SPL_BAM_BATCH_BLOCKS="2", SPL_BAM_FORCE_RESYNC="1")])
+@pytest.mark.parametrize("seq_mode", [0, 1])
+def test_many_batches(built, tmp_path, monkeypatch, env, seq_mode):
+    names, sets = _random_sets(11 + seq_mode, 60_000, 3)
+    path = str(tmp_path / "m.bam")
+    native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=3, seq_mode=seq_mode)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for threads in (1, 3, 8):
+        with_stream = threads == 3
+        bam = native.BamFile(path, threads=threads, stream=with_stream)
+        assert bam.n_records == sum(s.n for s in sets.values())
+        for c in names:
+            _same(bam.reads(c), sets[c])
+        bam.close()
+
+
+@pytest.mark.parametrize("blocks", ["1", "2", "8"])
+def test_records_larger_than_a_batch(built, tmp_path, monkeypatch, blocks):
+    # reads of 300 000 and 700 000 bases with SEQ and QUAL: records of 450 KB and over a megabyte between ordinary ones
+    pos = np.array([10, 20, 30, 40, 50, 60], np.int32)
+    ops = [[(50 << 4) | 0], [(300_000 << 4) | 0], [(20 << 4) | 0, (100 << 4) | 3, (30 << 4) | 0], [(700_000 << 4) | 0],
+           [(700_000 << 4) | 0], [(75 << 4) | 0]]
+    cig_off = np.concatenate(([0], np.cumsum([len(o) for o in ops]))).astype(np.uint32)
+    cigar = np.array([x for o in ops for x in o], np.uint32)
+    want = samio.ReadSet(pos, np.array([0, 16, 0, 0, 16, 0], np.uint16), cig_off, cigar)
+    path = str(tmp_path / "big.bam")
+    samio.write_bam(path, ["c0"], [10 ** 8], [("c0", want)], with_seq=True)
+    monkeypatch.setenv("SPL_BAM_BATCH_BLOCKS", blocks)
+    for threads in (1, 4):
+        bam = native.BamFile(path, threads=threads)
+        assert bam.n_records == 6
+        _same(bam.reads("c0"), want)
+        bam.close()
+
+
+def test_truncation_inside_a_late_batch_is_reported(built, tmp_path, monkeypatch):
+    names, sets = _random_sets(5, 40_000, 2)
+    path = str(tmp_path / "t.bam")
+    native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=2, seq_mode=1)
+    data = open(path, "rb").read()
+    # drop a whole block from the middle (the directory stays well-formed): the record that straddles it cannot chain
+    bam = native.BamFile(path, threads=2)
+    bam.close()
+    eof = data[-28:]
+    cut = str(tmp_path / "cut.bam")
+    open(cut, "wb").write(data[:len(data) // 2] + eof)   # (ends mid-block: the directory scan refuses it)
+    with pytest.raises(native.SpliserNativeError):
+        native.BamFile(cut, threads=2)
