@@ -273,6 +273,11 @@ int spl_tsv_append(const char *path, const char *chrom, int64_t n_sites, const i
                    const int64_t *beta2_cryptic, const double *beta2_weighted, const uint32_t *part_off,
                    const int64_t *part_pos, const int64_t *edge_cnt, const uint32_t *comp_off, const int64_t *comp_pos);
 
+/* The writer's "%.3f" / "%.5f": x >= 0 with `digits` (0..6) decimals into out64 (NUL-terminated), correctly rounded from the
+ * double's exact value, ties to even -- what Python's "{0:.3f}".format gives (SpliSER_v0_1_8.py:655-660).  Exported so that the
+ * tests can hold it against Python over many values. */
+int spl_fmt_fixed(double x, int digits, char *out64);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,11 +117,83 @@ inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1]
 inline int32_t le32s(const uint8_t *p) { return (int32_t)le32(p); }
 
 struct Block {
-    size_t coff;   // offset of the block in the file
+    size_t coff;    // offset of the block in the file
+    uint64_t uoff;  // offset of its payload in the inflated stream
     uint32_t csize; // whole block
     uint32_t xlen;
     uint32_t isize; // uncompressed payload
 };
+
+// The file's BGZF blocks, found by walking the block headers from the start (each header says where the next block begins).
+// The walk is one thread's pointer chase over the whole file -- a tenth of a second per gigabyte -- so only the blocks of the
+// BAM header are walked by the opening call; the rest is walked beside the decode, which takes the blocks as they are
+// announced.  Blocks live in chunks that never move: readers index below n_ready without a lock.
+struct BlockDir {
+    static constexpr size_t CHUNK = (size_t)1 << 15;
+    std::vector<Block *> chunks;        // sized for the worst case when the file is opened, filled by the walk
+    std::atomic<size_t> n_ready{0};     // blocks [0, n_ready) are final
+    std::atomic<int> state{0};          // 0 = being walked, 1 = complete, -1 = failed (`error`, `err_code`)
+    std::string error;
+    int err_code = 0;
+    size_t off = 0;                     // the walk's position in the file
+    uint64_t uoff = 0;                  // ... and in the inflated stream
+    const Block &at(size_t i) const { return chunks[i / CHUNK][i % CHUNK]; }
+    ~BlockDir() { for (Block *c : chunks) free(c); }
+};
+
+// Walk up to max_blocks further block headers (0 = to the end of the file).  Returns false when the walk has failed.
+bool walk_blocks(BlockDir &dir, const uint8_t *file, size_t fsize, const char *path, size_t max_blocks)
+{
+    auto failed = [&](int code, const char *what, size_t where) {
+        char text[512];
+        snprintf(text, sizeof text, "%s: %s at offset %zu", path, what, where);
+        dir.error = text;
+        dir.err_code = code;
+        dir.state.store(-1, std::memory_order_release);
+        return false;
+    };
+    size_t n = dir.n_ready.load(std::memory_order_relaxed), done = 0;
+    size_t off = dir.off;
+    while (off < fsize && (max_blocks == 0 || done < max_blocks)) {
+        if (fsize - off < 18 || file[off] != 0x1f || file[off + 1] != 0x8b || file[off + 2] != 8 || !(file[off + 3] & 4))
+            return failed(SPL_ERR_FORMAT, "not BGZF (BAM files are BGZF-compressed)", off);
+        const uint32_t xlen = le16(file + off + 10);
+        if (fsize - off < 12 + (size_t)xlen) return failed(SPL_ERR_FORMAT, "truncated BGZF header", off);
+        uint32_t bsize = 0;
+        bool have = false;
+        const size_t x_end = off + 12 + xlen;
+        for (size_t x = off + 12; x + 4 <= x_end;) {
+            const uint32_t slen = le16(file + x + 2);
+            if (x + 4 + (size_t)slen > x_end) break; // a subfield that runs past the extra area: corrupt, and not ours to read
+            if (file[x] == 'B' && file[x + 1] == 'C' && slen == 2) { bsize = (uint32_t)le16(file + x + 4) + 1; have = true; }
+            x += 4 + slen;
+        }
+        if (!have || bsize < 12 + xlen + 8 || fsize - off < bsize) return failed(SPL_ERR_FORMAT, "corrupt or truncated BGZF block", off);
+        Block b;
+        b.coff = off; b.uoff = dir.uoff; b.csize = bsize; b.xlen = xlen; b.isize = le32(file + off + bsize - 4);
+        if (b.isize > 65536) return failed(SPL_ERR_FORMAT, "BGZF ISIZE > 64 KiB", off);
+        if (n / BlockDir::CHUNK >= dir.chunks.size()) return failed(SPL_ERR_FORMAT, "more BGZF blocks than the file has room for", off);
+        Block *&chunk = dir.chunks[n / BlockDir::CHUNK];
+        if (!chunk) chunk = (Block *)malloc(sizeof(Block) * BlockDir::CHUNK);
+        if (!chunk) return failed(SPL_ERR_NOMEM, "out of host memory for the block directory", off);
+        chunk[n % BlockDir::CHUNK] = b;
+        ++n;
+        ++done;
+        off += bsize;
+        dir.uoff += b.isize;
+        if ((n & 255u) == 0) dir.n_ready.store(n, std::memory_order_release);
+    }
+    dir.off = off;
+    dir.n_ready.store(n, std::memory_order_release);
+    if (off >= fsize) {
+        // htslib only warns about a missing EOF marker; a truncated file is far more likely than a writer that omits it, and
+        // silently counting fewer reads is the reference's worst failure mode: refuse.  (The opening call has looked at the
+        // file's last 28 bytes already; this is the same statement about the walked blocks.)
+        if (n == 0 || dir.at(n - 1).isize != 0) return failed(SPL_ERR_IO, "BGZF EOF marker missing -- file is truncated", off);
+        dir.state.store(1, std::memory_order_release);
+    }
+    return true;
+}
 
 // The reads one batch found for one reference, BAM-native: exact-size arrays carved out of the extracting thread's arena.
 struct RefReads {
@@ -295,7 +367,7 @@ struct spl_bam {
     std::thread worker;
     void *map = nullptr;
     size_t fsize = 0;
-    std::vector<Block> blocks;
+    BlockDir dir;
     int n_threads = 1;
     uint64_t header_bytes = 0; // magic, text and reference dictionary: the first record starts here in the inflated stream
     std::string path;
@@ -538,42 +610,36 @@ bool assemble_ref(spl_bam *bam, int tid, std::string &err)
 struct BatchOut {
     std::vector<Part> parts;
     std::vector<uint8_t> head, tail;
-    size_t len = 0, start = 0;
+    size_t len = 0, start = 0, i0 = 0, i1 = 0; // bytes inflated, guessed first boundary; the batch's blocks
+    uint64_t u0 = 0;                            // offset of the batch in the inflated stream
     int64_t nrec = 0;
     bool inflate_bad = false, parse_bad = false;
+    bool known = false;                         // the first boundary is the end of the BAM header, not a guess
+    bool skip = false;                          // nothing but BAM header in it
     std::atomic<int> state{0}; // 0 = the worker's, 1 = ready to commit
 };
 
 void decode_worker(spl_bam *bam)
 {
     const uint8_t *file = (const uint8_t *)bam->map;
-    const std::vector<Block> &blocks = bam->blocks;
+    BlockDir &dir = bam->dir;
     const int n_ref = bam->n_refs;
     const NodeCpus node; // the NUMA node this thread runs on (the opening thread's, inherited): all worker threads stay there
     auto env_num = [](const char *name, long dflt) { const char *e = getenv(name); const long v = e ? atol(e) : 0; return v > 0 ? v : dflt; };
     const size_t BATCH = (size_t)env_num("SPL_BAM_BATCH_BLOCKS", 32);
     const bool force_slow = getenv("SPL_BAM_FORCE_RESYNC") != nullptr; // (tests: every batch takes the sequential path)
     const bool timing = getenv("SPL_BAM_TIMING") != nullptr;
-    const size_t n_batches = (blocks.size() + BATCH - 1) / BATCH;
-    std::vector<uint64_t> u0(n_batches + 1, 0); // offset of each batch in the inflated stream
-    for (size_t b = 0; b < n_batches; ++b) {
-        uint64_t bytes = 0;
-        for (size_t i = b * BATCH; i < std::min(blocks.size(), (b + 1) * BATCH); ++i) bytes += blocks[i].isize;
-        u0[b + 1] = u0[b] + bytes;
-    }
     const uint64_t H = bam->header_bytes; // the first record starts here
     std::string fail;
-    if (H > u0[n_batches]) fail = "no BAM header found";
-    size_t first_batch = 0;
-    while (first_batch < n_batches && u0[first_batch + 1] <= H) ++first_batch; // (batches of header bytes only, and empty ones)
-    const int n_workers = (int)std::max<size_t>(1, std::min<size_t>((size_t)bam->n_threads, n_batches - std::min(n_batches, first_batch)));
+    // (a batch of real data is a few hundred kilobytes of file: no more workers than the file can have batches)
+    const int n_workers = (int)std::max<size_t>(1, std::min<size_t>((size_t)bam->n_threads, bam->fsize / 65536 + 1));
     const size_t W = 4 * (size_t)n_workers; // batches in flight: finished but not yet committed, or being worked on
     std::vector<BatchOut> ring(W);
     // No lock anywhere on the batches' way: a slot is handed over by its state word, room in the ring is the frontier counter.
     // (Condition variables were tried first: with 64 workers every commit woke the lot of them, 6 of 9 seconds went into that.)
-    std::atomic<size_t> frontier(first_batch); // the next batch to commit; slot b % W is free for batch b once frontier > b - W
+    std::atomic<size_t> frontier(0); // the next batch to commit; slot b % W is free for batch b once frontier > b - W
     std::atomic<bool> stop(false);
-    std::atomic<size_t> next(first_batch);
+    std::atomic<size_t> next(0);
     auto nap = [](int &spins) { // wait a little: busy first (the other side is usually microseconds away), then off the core
         if (++spins < 2000) { __builtin_ia32_pause(); return; }
         std::this_thread::sleep_for(std::chrono::microseconds(spins < 4000 ? 20 : 200));
@@ -587,12 +653,25 @@ void decode_worker(spl_bam *bam)
         bam->slabs.insert(bam->slabs.end(), a.slabs.begin(), a.slabs.end());
         a.slabs.clear();
     };
-    auto inflate_batch = [&](size_t b, uint8_t *buf, void *ld) {
+    // Blocks [i0, i1) of batch b, once the directory has them; false = there is no batch b (the file has ended, or its walk failed).
+    auto batch_blocks = [&](size_t b, size_t &i0, size_t &i1) {
+        i0 = b * BATCH;
+        for (int spins = 0;;) {
+            const int st = dir.state.load(std::memory_order_acquire);
+            const size_t n = dir.n_ready.load(std::memory_order_acquire);
+            if (n >= i0 + BATCH) { i1 = i0 + BATCH; return true; }
+            if (st != 0) { i1 = n; return n > i0; }
+            if (stop.load(std::memory_order_acquire)) return false;
+            nap(spins);
+        }
+    };
+    auto inflate_batch = [&](size_t i0, size_t i1, uint8_t *buf, void *ld) {
         size_t at = 0;
         bool ok = true;
-        for (size_t i = b * BATCH; i < std::min(blocks.size(), (b + 1) * BATCH); ++i) {
-            ok = inflate_block(file, blocks[i], buf + at, ld) && ok;
-            at += blocks[i].isize;
+        for (size_t i = i0; i < i1; ++i) {
+            const Block &blk = dir.at(i);
+            ok = inflate_block(file, blk, buf + at, ld) && ok;
+            at += blk.isize;
         }
         return ok;
     };
@@ -604,25 +683,35 @@ void decode_worker(spl_bam *bam)
         double my_inflate = 0, my_extract = 0;
         for (;;) {
             const size_t b = next.fetch_add(1);
-            if (b >= n_batches) break;
+            size_t i0, i1;
+            if (!batch_blocks(b, i0, i1)) break;
             for (int spins = 0; !stop.load(std::memory_order_acquire) && b >= frontier.load(std::memory_order_acquire) + W;) nap(spins);
             if (stop.load(std::memory_order_acquire)) break;
             BatchOut &o = ring[b % W];
-            o.len = (size_t)(u0[b + 1] - u0[b]);
-            const double w0 = timing ? now() : 0.0;
-            o.inflate_bad = !inflate_batch(b, buf, ld);
-            const double w1 = timing ? now() : 0.0;
+            o.i0 = i0;
+            o.i1 = i1;
+            o.u0 = dir.at(i0).uoff;
+            const uint64_t u1 = dir.at(i1 - 1).uoff + dir.at(i1 - 1).isize;
+            o.len = (size_t)(u1 - o.u0);
             o.start = o.len;
+            o.known = false;
+            o.skip = u1 <= H && u1 > o.u0;   // BAM header bytes only
+            o.inflate_bad = o.parse_bad = false;
+            if (o.skip) { o.state.store(1, std::memory_order_release); continue; }
+            const double w0 = timing ? now() : 0.0;
+            o.inflate_bad = !inflate_batch(i0, i1, buf, ld);
+            const double w1 = timing ? now() : 0.0;
             size_t reached = o.len;
             if (!o.inflate_bad) {
                 const uint8_t *end = buf + o.len;
-                const uint8_t *p = (b == first_batch) ? buf + (size_t)(H - u0[b]) : find_record_start(buf, end, n_ref);
+                o.known = o.u0 <= H; // the batch the header ends in: the first record starts right there
+                const uint8_t *p = o.known ? buf + (size_t)(H - o.u0) : find_record_start(buf, end, n_ref);
                 o.start = (size_t)(p - buf);
                 std::string err;
                 bool fatal = false;
                 reached = (size_t)(extract_records(p, end, n_ref, arena, o.parts, o.nrec, err, fatal) - buf);
                 o.parse_bad = fatal;
-                if (b != first_batch) o.head.assign((const uint8_t *)buf, (const uint8_t *)buf + o.start);
+                if (!o.known) o.head.assign((const uint8_t *)buf, (const uint8_t *)buf + o.start);
                 o.tail.assign((const uint8_t *)buf + reached, end);
             }
             o.state.store(1, std::memory_order_release);
@@ -632,9 +721,10 @@ void decode_worker(spl_bam *bam)
         keep_slabs(arena);
         if (ld) deflate_lib().free_(ld);
     };
+    // the rest of the block directory, beside the decode
+    std::thread walker([&]() { node.pin_this_thread(); walk_blocks(dir, file, bam->fsize, bam->path.c_str(), 0); });
     std::vector<std::thread> pool;
-    if (fail.empty())
-        for (int t = 0; t < n_workers; ++t) pool.emplace_back([&]() { node.pin_this_thread(); work(); });
+    for (int t = 0; t < n_workers; ++t) pool.emplace_back([&]() { node.pin_this_thread(); work(); });
 
     // ---- commit, in file order
     std::vector<uint8_t> carry, joined, again; // carry: the bytes between the last committed record and the frontier batch
@@ -650,12 +740,25 @@ void decode_worker(spl_bam *bam)
         bam->n_records += n;
         return r;
     };
-    for (size_t b = first_batch; b < n_batches && fail.empty(); ++b) {
+    size_t n_batches = 0;
+    for (size_t b = 0; fail.empty(); ++b) {
         BatchOut &o = ring[b % W];
         if (o.state.load(std::memory_order_acquire) != 1) {
             const double w0 = now();
-            for (int spins = 0; o.state.load(std::memory_order_acquire) != 1;) nap(spins);
+            bool ended = false;
+            for (int spins = 0; o.state.load(std::memory_order_acquire) != 1 && !ended;) {
+                // (no batch b: the directory is final and ends before it -- a worker that takes b finds the same and leaves)
+                ended = dir.state.load(std::memory_order_acquire) != 0 && dir.n_ready.load(std::memory_order_acquire) <= b * BATCH;
+                if (!ended) nap(spins);
+            }
             t_wait += now() - w0;
+            if (ended) break;
+        }
+        n_batches = b + 1;
+        if (o.skip) {
+            o.state.store(0, std::memory_order_relaxed);
+            frontier.store(b + 1, std::memory_order_release);
+            continue;
         }
         const double c0 = now();
         if (o.inflate_bad) { fail = "inflate or CRC32 failure in a BGZF block (corrupt file)"; break; }
@@ -697,9 +800,9 @@ void decode_worker(spl_bam *bam)
             if (!ld_mine && deflate_lib().ok) ld_mine = deflate_lib().alloc();
             again.resize(carry.size() + o.len + 64);
             if (!carry.empty()) memcpy(again.data(), carry.data(), carry.size());
-            if (!inflate_batch(b, again.data() + carry.size(), ld_mine)) { fail = "inflate or CRC32 failure in a BGZF block (corrupt file)"; break; }
+            if (!inflate_batch(o.i0, o.i1, again.data() + carry.size(), ld_mine)) { fail = "inflate or CRC32 failure in a BGZF block (corrupt file)"; break; }
             const uint8_t *p0 = again.data(), *p1 = again.data() + carry.size() + o.len;
-            if (b == first_batch) p0 += (size_t)(H - u0[b]);
+            if (o.known) p0 += (size_t)(H - o.u0);
             const uint8_t *r = walk(p0, p1, fatal);
             if (fatal) break;
             carry.assign(r, p1);
@@ -716,16 +819,25 @@ void decode_worker(spl_bam *bam)
     }
     stop.store(true, std::memory_order_release);
     for (auto &t : pool) t.join();
+    walker.join();
+    if (dir.state.load() < 0) { // the walk's own words (and error class) for what is wrong with the file
+        std::lock_guard<std::mutex> lock(bam->mu);
+        bam->error = dir.error;
+        bam->err_code = dir.err_code;
+        fail.clear();
+    } else if (fail.empty() && H > dir.uoff) {
+        fail = "no BAM header found";
+    }
     keep_slabs(arena_mine);
     if (ld_mine) deflate_lib().free_(ld_mine);
     if (timing)
         fprintf(stderr, "[spl_bam_open] %zu blocks in %zu batches, %d threads: %.3f s, the committing thread waited %.3f s of that (straddling records %.3f s, hand-over %.3f s, "
-                "ring %.3f s), %zu batches re-walked; workers: inflate + CRC %.2f thread-s, records %.2f thread-s\n", blocks.size(), n_batches, n_workers,
+                "ring %.3f s), %zu batches re-walked; workers: inflate + CRC %.2f thread-s, records %.2f thread-s\n", dir.n_ready.load(), n_batches, n_workers,
                 now() - t_begin, t_wait, t_bridge, t_merge, t_release, n_resync, sum_inflate, sum_extract);
-    if (fail.empty() && !carry.empty()) fail = "file ends inside a record (truncated)";
+    if (fail.empty() && !carry.empty() && dir.state.load() > 0) fail = "file ends inside a record (truncated)";
     {
         std::lock_guard<std::mutex> lock(bam->mu);
-        if (!fail.empty()) { bam->error = bam->path + ": " + fail; bam->err_code = SPL_ERR_FORMAT; }
+        if (!fail.empty() && !bam->err_code) { bam->error = bam->path + ": " + fail; bam->err_code = SPL_ERR_FORMAT; }
         bam->complete_upto = bam->n_refs;
         bam->done = true;
     }
@@ -733,14 +845,18 @@ void decode_worker(spl_bam *bam)
 }
 
 // The BAM header (magic, text, reference dictionary) from the first blocks of the file, inflated one by one until it is whole.
-int read_header(spl_bam *bam, std::string &fail)
+int read_header(spl_bam *bam, std::string &fail, int &code)
 {
+    code = SPL_ERR_FORMAT;
     const uint8_t *file = (const uint8_t *)bam->map;
     std::vector<uint8_t> head;
     void *ld = deflate_lib().ok ? deflate_lib().alloc() : nullptr;
     int rc = 1; // 1 = need more, 0 = done, -1 = failed
-    for (size_t i = 0; i < bam->blocks.size() && rc == 1; ++i) {
-        const Block &b = bam->blocks[i];
+    for (size_t i = 0; rc == 1; ++i) {
+        if (i >= bam->dir.n_ready.load() && bam->dir.state.load() == 0) walk_blocks(bam->dir, file, bam->fsize, bam->path.c_str(), 1);
+        if (bam->dir.state.load() < 0) { fail = bam->dir.error; code = bam->dir.err_code; rc = -1; break; }
+        if (i >= bam->dir.n_ready.load()) break;
+        const Block &b = bam->dir.at(i);
         const size_t at = head.size();
         head.resize(at + b.isize);
         if (!inflate_block(file, b, head.data() + at, ld)) { fail = "inflate or CRC32 failure in a BGZF block (corrupt file)"; rc = -1; break; }
@@ -799,54 +915,29 @@ extern "C" int spl_bam_open_stream(const char *path, int n_threads, spl_bam **ou
     madvise(map, fsize, MADV_SEQUENTIAL);
     const uint8_t *file = (const uint8_t *)map;
 
-    // 1. block directory (headers only)
-    const auto t_dir = std::chrono::steady_clock::now();
-    std::vector<Block> blocks;
-    size_t off = 0;
-    int rc = SPL_OK;
-    while (off < fsize) {
-        if (fsize - off < 18 || file[off] != 0x1f || file[off + 1] != 0x8b || file[off + 2] != 8 || !(file[off + 3] & 4)) {
-            rc = spl_set_error(SPL_ERR_FORMAT, "%s: not BGZF at offset %zu (BAM files are BGZF-compressed)", path, off);
-            break;
+    // The end of the file first: a BGZF file ends with an empty block (htslib's 28-byte EOF marker).
+    static const uint8_t eof_marker[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool bgzf = fsize >= 18 && file[0] == 0x1f && file[1] == 0x8b && file[2] == 8 && (file[3] & 4);
+    if (bgzf && (fsize < 28 || memcmp(file + fsize - 28, eof_marker, 28) != 0)) {
+        // Not the standard marker: a truncated file, or (legal, unusual) an empty last block written with other header fields.
+        // The caller must not be handed results of a truncated file chromosome by chromosome before anybody notices: walk
+        // all blocks here and now -- the one case that pays for the walk up front.
+        BlockDir probe;
+        probe.chunks.assign(fsize / 28 / BlockDir::CHUNK + 2, nullptr);
+        walk_blocks(probe, file, fsize, path, 0);
+        if (probe.state.load() < 0) {
+            const int code = probe.err_code;
+            const std::string text = probe.error;
+            munmap(map, fsize);
+            return spl_set_error(code, "%s", text.c_str());
         }
-        const uint32_t xlen = le16(file + off + 10);
-        if (fsize - off < 12 + (size_t)xlen) { rc = spl_set_error(SPL_ERR_FORMAT, "%s: truncated BGZF header", path); break; }
-        uint32_t bsize = 0;
-        bool have = false;
-        const size_t x_end = off + 12 + xlen;
-        for (size_t x = off + 12; x + 4 <= x_end;) {
-            const uint32_t slen = le16(file + x + 2);
-            if (x + 4 + (size_t)slen > x_end) break; // a subfield that runs past the extra area: corrupt, and not ours to read
-            if (file[x] == 'B' && file[x + 1] == 'C' && slen == 2) { bsize = (uint32_t)le16(file + x + 4) + 1; have = true; }
-            x += 4 + slen;
-        }
-        if (!have || bsize < 12 + xlen + 8 || fsize - off < bsize) {
-            rc = spl_set_error(SPL_ERR_FORMAT, "%s: corrupt or truncated BGZF block at offset %zu", path, off);
-            break;
-        }
-        Block b;
-        b.coff = off; b.csize = bsize; b.xlen = xlen; b.isize = le32(file + off + bsize - 4);
-        if (b.isize > 65536) { rc = spl_set_error(SPL_ERR_FORMAT, "%s: BGZF ISIZE > 64 KiB at offset %zu", path, off); break; }
-        blocks.push_back(b);
-        off += bsize;
     }
-    if (rc != SPL_OK) { munmap(map, fsize); return rc; }
-    if (getenv("SPL_BAM_TIMING"))
-        fprintf(stderr, "[spl_bam_open] block directory: %zu blocks of %.1f MB in %.3f s\n", blocks.size(), fsize / 1e6,
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dir).count());
-    if (blocks.empty() || blocks.back().isize != 0) {
-        // htslib only warns about a missing EOF marker; a truncated file is far more likely than a writer
-        // that omits it, and silently counting fewer reads is the reference's worst failure mode: refuse.
-        munmap(map, fsize);
-        return spl_set_error(SPL_ERR_IO, "%s: BGZF EOF marker missing -- file is truncated", path);
-    }
-
     spl_bam *bam = new (std::nothrow) spl_bam();
     if (!bam) { munmap(map, fsize); return spl_set_error(SPL_ERR_NOMEM, "out of host memory"); }
     bam->map = map;
     bam->fsize = fsize;
-    bam->blocks.swap(blocks);
     bam->path = path;
+    bam->dir.chunks.assign(fsize / 28 / BlockDir::CHUNK + 2, nullptr); // (a block is at least 28 bytes)
     if (n_threads <= 0) { // default: all hardware threads up to SPL_BAM_THREADS (32 unless the environment says otherwise)
         const char *e = getenv("SPL_BAM_THREADS");
         const int cap = e && atoi(e) > 0 ? atoi(e) : 32;
@@ -855,9 +946,11 @@ extern "C" int spl_bam_open_stream(const char *path, int n_threads, spl_bam **ou
     }
     bam->n_threads = n_threads > 0 ? n_threads : 1;
     std::string fail;
-    if (read_header(bam, fail) != 0) {
+    int code = SPL_ERR_FORMAT;
+    if (read_header(bam, fail, code) != 0) {
         delete bam;
-        return spl_set_error(SPL_ERR_FORMAT, "%s: %s", path, fail.c_str());
+        if (fail.compare(0, strlen(path), path) == 0) return spl_set_error(code, "%s", fail.c_str()); // (the walk's message names the file already)
+        return spl_set_error(code, "%s: %s", path, fail.c_str());
     }
     bam->worker = std::thread(decode_worker, bam);
     *out = bam;

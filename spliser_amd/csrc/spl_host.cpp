@@ -55,10 +55,69 @@ extern "C" int spl_gene_search(const int64_t *left, const int64_t *right, const 
 #include <algorithm>
 #include <atomic>
 #include <cinttypes>
+#include <cmath>
 #include <cstdio>
 #include <string>
 #include <thread>
 #include <vector>
+
+namespace {
+
+// "%d" of v into out; returns the length.
+inline size_t fmt_int(char *out, int64_t v)
+{
+    char tmp[24];
+    int n = 0;
+    uint64_t u = v < 0 ? 0ull - (uint64_t)v : (uint64_t)v;
+    do { tmp[n++] = (char)('0' + u % 10u); u /= 10u; } while (u);
+    size_t k = 0;
+    if (v < 0) out[k++] = '-';
+    while (n) out[k++] = tmp[--n];
+    return k;
+}
+
+// "%.<digits>f" of x (digits <= 6) into out, exactly as printf and Python's format() round: to the nearest decimal of the
+// double's EXACT binary value, ties to even.  x = m * 2^e with an integer m: m * 10^digits is split at the binary point with
+// integer arithmetic, nothing is ever rounded before the one decision that matters.  Values this does not cover (negative,
+// not finite, 2^63 / 10^digits and beyond) go to snprintf.
+inline size_t fmt_fixed(char *out, double x, int digits)
+{
+    static const uint64_t pow10[7] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull};
+    if (!(x >= 0.0) || !(x < 9.0e12) || digits > 6) return (size_t)snprintf(out, 64, "%.*f", digits, x);
+    int e = 0;
+    const double f = frexp(x, &e);                    // x = f * 2^e, f in [0.5, 1) (or 0)
+    const uint64_t m = (uint64_t)ldexp(f, 53);         // 53-bit integer, exact
+    const int sh = 53 - e;                             // x = m / 2^sh
+    unsigned __int128 v = (unsigned __int128)m * pow10[digits];
+    uint64_t q;
+    if (sh <= 0) {
+        q = (uint64_t)(v << (-sh));                    // an integer already (x < 9e12: fits)
+    } else if (sh >= 120) {
+        q = 0;                                         // far below half a unit in the last place
+    } else {
+        const unsigned __int128 one = (unsigned __int128)1 << sh;
+        const unsigned __int128 rem = v & (one - 1), half = one >> 1;
+        q = (uint64_t)(v >> sh);
+        if (rem > half || (rem == half && (q & 1u))) ++q;
+    }
+    const uint64_t ip = q / pow10[digits], fp = q % pow10[digits];
+    size_t k = fmt_int(out, (int64_t)ip);
+    if (digits) {
+        out[k++] = '.';
+        for (int d = digits - 1; d >= 0; --d) out[k++] = (char)('0' + (fp / pow10[d]) % 10u);
+    }
+    return k;
+}
+
+} // namespace
+
+// (test hook: the formatter above against printf / Python over many values -- tests/test_tsv_native.py)
+extern "C" int spl_fmt_fixed(double x, int digits, char *out64)
+{
+    if (!out64) return spl_set_error(SPL_ERR_ARG, "spl_fmt_fixed: null argument");
+    out64[fmt_fixed(out64, x, digits)] = 0;
+    return SPL_OK;
+}
 
 extern "C" int spl_tsv_append(const char *path, const char *chrom, int64_t n_sites, const int64_t *pos, const char *strand_blob,
                               const uint32_t *strand_off, const char *gene_blob, const uint32_t *gene_off, const double *sse,
@@ -73,32 +132,46 @@ extern "C" int spl_tsv_append(const char *path, const char *chrom, int64_t n_sit
     FILE *f = fopen(path, "ab");
     if (!f) return spl_set_error(SPL_ERR_IO, "cannot open %s for appending", path);
     const size_t chrom_len = strlen(chrom);
-    // rows [a, b) as text
+    // rows [a, b) as text.  Numbers are written by hand (fmt_int, fmt_fixed below: the digits printf would give, at a tenth of
+    // printf's cost -- a row has seven to ten numbers and a table a few hundred thousand rows).
     auto format = [&](int64_t a, int64_t b, std::string &out) {
-        char num[64];
+        char num[96];
         out.reserve((size_t)(b - a) * 96);
         for (int64_t i = a; i < b; ++i) {
             out.append(chrom, chrom_len);
             out.push_back('\t');
-            out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64, pos[i]));
+            out.append(num, fmt_int(num, pos[i]));
             out.push_back('\t');
             out.append(strand_blob + strand_off[i], strand_off[i + 1] - strand_off[i]);
             out.push_back('\t');
             out.append(gene_blob + gene_off[i], gene_off[i + 1] - gene_off[i]);
             out.push_back('\t');
-            out.append(num, (size_t)snprintf(num, sizeof num, "%.3f", sse[i]));
-            out.append(num, (size_t)snprintf(num, sizeof num, "\t%" PRId64 "\t%u\t%" PRId64 "\t", alpha[i], beta1[i], beta2_simple[i]));
-            if (cryptic) out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64 "\t%.5f", beta2_cryptic[i], beta2_weighted[i]));
-            else out.append("NA\tNA");
+            out.append(num, fmt_fixed(num, sse[i], 3));
+            out.push_back('\t');
+            out.append(num, fmt_int(num, alpha[i]));
+            out.push_back('\t');
+            out.append(num, fmt_int(num, (int64_t)beta1[i]));
+            out.push_back('\t');
+            out.append(num, fmt_int(num, beta2_simple[i]));
+            out.push_back('\t');
+            if (cryptic) {
+                out.append(num, fmt_int(num, beta2_cryptic[i]));
+                out.push_back('\t');
+                out.append(num, fmt_fixed(num, beta2_weighted[i], 5));
+            } else {
+                out.append("NA\tNA");
+            }
             out.append("\t{");
             for (uint32_t e = part_off[i]; e < part_off[i + 1]; ++e) {
                 if (e != part_off[i]) out.append(", ");
-                out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64 ": %" PRId64, part_pos[e], edge_cnt[e]));
+                out.append(num, fmt_int(num, part_pos[e]));
+                out.append(": ");
+                out.append(num, fmt_int(num, edge_cnt[e]));
             }
             out.append("}\t[");
             for (uint32_t e = comp_off[i]; e < comp_off[i + 1]; ++e) {
                 if (e != comp_off[i]) out.append(", ");
-                out.append(num, (size_t)snprintf(num, sizeof num, "%" PRId64, comp_pos[e]));
+                out.append(num, fmt_int(num, comp_pos[e]));
             }
             out.append("]\n");
         }

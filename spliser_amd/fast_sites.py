@@ -50,7 +50,7 @@ def _empty(chrom):
     out.pos = np.zeros(0, np.int64)
     out.strand = np.zeros(0, np.uint8)
     out.alpha = np.zeros(0, np.int64)
-    out.genes, out.strand_text = [], []
+    out.gene_idx, out.gene_names = np.zeros(0, np.int64), []
     out.part_off = np.zeros(1, np.uint32)
     out.part_pos = np.zeros(0, np.int64)
     out.part_site = np.zeros(0, np.int32)
@@ -110,8 +110,8 @@ def _chrom(table, chrom, left, right, strand, alpha):
     out.chrom, out.n = chrom, n
     out.pos = (ukey >> 1) if is_stranded else ukey.copy()
     creator = line[first]                                   # the line whose look-up created the site
-    out.strand = strand[creator].astype(np.uint8)           # (first byte of the creating line's strand column, 0 = empty)
-    out.strand_text = [chr(c) if c else "" for c in out.strand.tolist()]
+    out.strand = strand[creator].astype(np.uint8)           # (first byte of the creating line's strand column, 0 = empty;
+    #                                                          strand_text follows from it when somebody asks)
     out.alpha = np.zeros(n, np.int64)
     np.add.at(out.alpha, inv, np.repeat(alpha, 2))           # :341
     # genes (:313): one bisection per created site, with the creating line's strand
@@ -119,10 +119,10 @@ def _chrom(table, chrom, left, right, strand, alpha):
     if len(names) and n:
         q_strand = np.where((out.strand == 43) | (out.strand == 45), out.strand, 0).astype(np.uint8)
         gi = native.gene_search(g_left, g_right, g_strand, out.pos, q_strand, is_stranded)
-        out.genes = [names[i] if i >= 0 else "NA" for i in gi.tolist()]
         table.assigned += int((gi >= 0).sum())
     else:
-        out.genes = ["NA"] * n
+        gi = np.full(n, -1, np.int64)
+    out.gene_idx, out.gene_names = np.asarray(gi, np.int64), names   # (the Gene column; a list of str only on demand)
     # partner edges (:352-355): site of an end -> position of the other end, summed per (site, position), listed in
     # first-appearance order
     src = inv

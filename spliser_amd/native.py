@@ -51,7 +51,7 @@ EXPORTS = [
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
-    "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append",
+    "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append", "spl_fmt_fixed",
     "spl_bed_open", "spl_gff_open", "spl_text_close", "spl_text_rows", "spl_text_n_chrom", "spl_text_chrom_name", "spl_text_chrom",
     "spl_text_i64", "spl_text_strand", "spl_text_names",
 ]
@@ -385,8 +385,25 @@ def _blob(texts):
 
 def tsv_append(path, arr, res, cryptic):
     """Rows of one chromosome appended to ``path`` by ``spl_tsv_append`` (same bytes as tsv.format_chrom)."""
-    strand_blob, strand_off = _blob(arr.strand_text)
-    gene_blob, gene_off = _blob(arr.genes)
+    if getattr(arr, "_strand_text", 0) is None:      # (a table built from arrays: the texts follow from the arrays, no list of str)
+        codes = np.ascontiguousarray(arr.strand, np.uint8)
+        there = codes != 0
+        strand_blob = codes[there].tobytes()
+        strand_off = np.zeros(arr.n + 1, np.uint32)
+        np.cumsum(there, out=strand_off[1:])
+    else:
+        strand_blob, strand_off = _blob(arr.strand_text)
+    if getattr(arr, "_genes", 0) is None and arr.gene_idx is not None:
+        names_blob, names_off = _blob(list(arr.gene_names) + ["NA"])
+        gi = np.where(arr.gene_idx >= 0, arr.gene_idx, len(arr.gene_names)).astype(np.int64)
+        first = names_off[:-1].astype(np.int64)[gi]
+        length = np.diff(names_off.astype(np.int64))[gi]
+        gene_off = np.zeros(arr.n + 1, np.uint32)
+        np.cumsum(length, out=gene_off[1:])
+        take = np.repeat(first - gene_off[:-1].astype(np.int64), length) + np.arange(int(gene_off[-1]), dtype=np.int64)
+        gene_blob = np.frombuffer(names_blob, np.uint8)[take].tobytes() if arr.n else b""
+    else:
+        gene_blob, gene_off = _blob(arr.genes)
     c64 = lambda a: np.ascontiguousarray(a, np.int64)   # noqa: E731
     pos, alpha = c64(arr.pos), c64(arr.alpha)
     beta1 = np.ascontiguousarray(res["beta1"], np.uint32)

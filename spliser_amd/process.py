@@ -182,50 +182,77 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
 class _TsvWriter(object):
     """outputBedFile (SpliSER_v0_1_8.py:641-664) while Step 3 is still running: chromosomes arrive in any order (one device
     thread each, the order of the BAM file), the file gets them in the table's order; the rows are formatted by the native
-    library (tsv.format_chrom is the Python statement of the same format and what the CPU tests compare it with)."""
+    library (tsv.format_chrom is the Python statement of the same format and what the CPU tests compare it with) on a thread
+    of the writer's own -- the device threads hand a chromosome over and go on with the next one."""
 
     def __init__(self, output_path, table, cryptic):
         self.path = output_path + ".SpliSER.tsv"
         self.order = list(table.chrom_index)
         self.cryptic = cryptic
         self.ready = {}
+        self.taken = set()     # chromosomes handed to the writing thread
         self.next = 0
-        self.lock = threading.Lock()
+        self.cond = threading.Condition()
+        self.closing = False
+        self.error = None
         self.seconds = 0.0
         with open(self.path, "w") as fh:
             fh.write(tsv.HEADER)
+        self.thread = threading.Thread(target=self._run)
+        self.thread.start()
 
     def add(self, chrom, arr, res):
-        with self.lock:      # (one writer at a time: the file is appended to in order)
+        with self.cond:
             self.ready[chrom] = (arr, res)
-            self._drain(final=False)
+            self.cond.notify()
 
-    def _drain(self, final):
-        t = time.perf_counter()
-        while self.next < len(self.order):
-            chrom = self.order[self.next]
-            if chrom in self.ready:
-                arr, res = self.ready.pop(chrom)
-                native.tsv_append(self.path, arr, res, self.cryptic)
-            elif not final:
-                break
-            self.next += 1
-        self.seconds += time.perf_counter() - t
+    def _run(self):
+        try:
+            while True:
+                with self.cond:
+                    while True:
+                        while self.next < len(self.order) and self.closing and self.order[self.next] not in self.ready:
+                            self.next += 1      # (closing: a chromosome without a result has no rows)
+                        if self.next >= len(self.order):
+                            return
+                        if self.order[self.next] in self.ready:
+                            arr, res = self.ready.pop(self.order[self.next])
+                            self.taken.add(self.order[self.next])
+                            break
+                        self.cond.wait()
+                t = time.perf_counter()
+                native.tsv_append(self.path, arr, res, self.cryptic)   # (the file is appended to in order, by this thread only)
+                self.seconds += time.perf_counter() - t
+                self.next += 1
+        except BaseException as exc:   # surfaced by close()
+            self.error = exc
 
     def close(self, expected):
         """Chromosomes that never got a result (no sites, other -c) are skipped; everything in ``expected`` must be there."""
-        with self.lock:
-            missing = [c for c in expected if c not in self.ready and self.order.index(c) >= self.next]
-            if missing:
-                raise RuntimeError("no results for %s" % missing)
-            self._drain(final=True)
+        with self.cond:
+            missing = [c for c in expected if c not in self.ready and c not in self.taken]
+            self.closing = True
+            self.cond.notify()
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+        if missing:
+            raise RuntimeError("no results for %s" % missing)
+
+    def abandon(self):
+        """Stop without writing what is left (an error elsewhere)."""
+        with self.cond:
+            self.order = self.order[:self.next]
+            self.closing = True
+            self.cond.notify()
+        self.thread.join()
 
 
 def write_tsv(output_path, table, results, is_beta2_cryptic):
     """outputBedFile for a finished result set."""
     w = _TsvWriter(output_path, table, is_beta2_cryptic)
     for chrom, (arr, res) in results.items():
-        w.ready[chrom] = (arr, res)
+        w.add(chrom, arr, res)
     w.close(list(results))
 
 
@@ -250,18 +277,23 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
         log("Processing sample 1 out of 1")
         writer = _TsvWriter(outputPath, table, isbeta2Cryptic)
         jrows = {}
-        results = process_sites(table, source, qChrom, isStranded, strandedType, isbeta2Cryptic, devices=devices, log=log,
-                                timings=timings, on_result=writer.add,
-                                on_junctions=(lambda c, rows: jrows.__setitem__(c, rows)) if checkJunctions else None)
-        if isinstance(source, native.BamFile) and not source.wait_all():
-            # records of an earlier reference after a later one: chromosomes were counted before they were complete.  (samtools
-            # cannot index such a file, the reference could not have processed it at all.)  Everything is decoded by now: again.
-            log("  (the alignment file is not sorted by reference: counting again from the complete decode)")
-            writer = _TsvWriter(outputPath, table, isbeta2Cryptic)
-            jrows = {}
-            results = process_sites(table, source, qChrom, isStranded, strandedType, isbeta2Cryptic, devices=devices, log=lambda m: None,
+        try:
+            results = process_sites(table, source, qChrom, isStranded, strandedType, isbeta2Cryptic, devices=devices, log=log,
                                     timings=timings, on_result=writer.add,
                                     on_junctions=(lambda c, rows: jrows.__setitem__(c, rows)) if checkJunctions else None)
+            if isinstance(source, native.BamFile) and not source.wait_all():
+                # records of an earlier reference after a later one: chromosomes were counted before they were complete.  (samtools
+                # cannot index such a file, the reference could not have processed it at all.)  Everything is decoded by now: again.
+                log("  (the alignment file is not sorted by reference: counting again from the complete decode)")
+                writer.abandon()
+                writer = _TsvWriter(outputPath, table, isbeta2Cryptic)
+                jrows = {}
+                results = process_sites(table, source, qChrom, isStranded, strandedType, isbeta2Cryptic, devices=devices, log=lambda m: None,
+                                        timings=timings, on_result=writer.add,
+                                        on_junctions=(lambda c, rows: jrows.__setitem__(c, rows)) if checkJunctions else None)
+        except BaseException:
+            writer.abandon()
+            raise
         t3 = time.perf_counter()
         log("\nOutputting .tsv file")
         writer.close(list(results))
@@ -279,9 +311,11 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
         t4 = time.perf_counter()
     finally:
         if hasattr(source, "close"):
-            source.close()
+            # (closing a decoded BAM gives gigabytes of read arrays back to the system -- a tenth of a second for 200 M reads --
+            #  and nobody is waiting for that: on a thread of its own)
+            threading.Thread(target=source.close).start()
     timings.update(open_s=t_open - t0, site_table_s=t1 - t_open, step3_s=t3 - t1, write_tail_s=t4 - t3, write_s=writer.seconds,
-                   total_s=t4 - t0)
+                   close_s=time.perf_counter() - t4, total_s=time.perf_counter() - t0)
     return timings
 
 

@@ -216,9 +216,37 @@ _STRAND_RANK = {"+": 0, "-": 1}
 
 
 class ChromArrays(object):
-    """SoA + CSR view of one chromosome's sites (the payload of ``spl_sites``)."""
+    """SoA + CSR view of one chromosome's sites (the payload of ``spl_sites``).
+
+    ``genes`` / ``strand_text`` (one str per row, what the Gene and Strand columns print) are lists when the line-by-line
+    builder made the table; the array builder (fast_sites) leaves ``gene_idx`` (row -> index into ``gene_names``, -1 = NA) and
+    the strand bytes instead, and the lists come into being only if somebody asks for them."""
     __slots__ = ("chrom", "n", "pos", "strand", "part_off", "part_pos", "part_site", "edge_cnt",
-                 "comp_off", "comp_pos", "alpha", "genes", "strand_text")
+                 "comp_off", "comp_pos", "alpha", "_genes", "_strand_text", "gene_idx", "gene_names")
+
+    def __init__(self):
+        self._genes = self._strand_text = self.gene_idx = self.gene_names = None
+
+    @property
+    def genes(self):
+        if self._genes is None and self.gene_idx is not None:
+            names = self.gene_names
+            self._genes = [names[i] if i >= 0 else "NA" for i in self.gene_idx.tolist()]
+        return self._genes
+
+    @genes.setter
+    def genes(self, value):
+        self._genes = value
+
+    @property
+    def strand_text(self):
+        if self._strand_text is None and self.strand is not None:
+            self._strand_text = [chr(c) if c else "" for c in self.strand.tolist()]
+        return self._strand_text
+
+    @strand_text.setter
+    def strand_text(self, value):
+        self._strand_text = value
 
 
 class SiteTable(object):

@@ -83,16 +83,31 @@ def test_records_larger_than_a_batch(built, tmp_path, monkeypatch, blocks):
         bam.close()
 
 
-def test_truncation_inside_a_late_batch_is_reported(built, tmp_path, monkeypatch):
+def test_broken_directory_behind_a_good_start_is_reported(built, tmp_path):
+    """The blocks are walked beside the decode: a file whose first blocks and EOF marker are fine and whose middle is not must
+    fail the decode (every way of waiting for it), not end early."""
     names, sets = _random_sets(5, 40_000, 2)
     path = str(tmp_path / "t.bam")
     native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=2, seq_mode=1)
-    data = open(path, "rb").read()
-    # drop a whole block from the middle (the directory stays well-formed): the record that straddles it cannot chain
-    bam = native.BamFile(path, threads=2)
-    bam.close()
-    eof = data[-28:]
-    cut = str(tmp_path / "cut.bam")
-    open(cut, "wb").write(data[:len(data) // 2] + eof)   # (ends mid-block: the directory scan refuses it)
+    data = bytearray(open(path, "rb").read())
+    # find a block header in the second half and break its magic
+    at = data.find(b"\x1f\x8b\x08\x04", len(data) // 2)
+    assert at > 0
+    data[at + 1] = 0
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(data))
+    with pytest.raises(native.SpliserNativeError) as e1:
+        native.BamFile(bad, threads=2)
+    assert "not BGZF" in str(e1.value)
+    bam = native.BamFile(bad, threads=2, stream=True)      # the header is fine: the opening call succeeds
     with pytest.raises(native.SpliserNativeError):
-        native.BamFile(cut, threads=2)
+        bam.wait_all()
+    with pytest.raises(native.SpliserNativeError):
+        bam.wait_ref(names[-1])
+    bam.close()
+    # the end cut off in the middle of a block: refused by the opening call itself
+    cut = str(tmp_path / "cut.bam")
+    open(cut, "wb").write(bytes(open(path, "rb").read()[:-5000]))
+    with pytest.raises(native.SpliserNativeError) as e2:
+        native.BamFile(cut, threads=2, stream=True)
+    assert "truncated" in str(e2.value) or "corrupt" in str(e2.value)

@@ -71,3 +71,58 @@ def test_native_rows_on_adversarial_numbers(tmp_path):
     for cryptic in (False, True):
         want = tsv.HEADER + "".join(tsv.format_chrom(arr, res, cryptic))
         assert _native_text(tmp_path, [(arr, res)], cryptic) == want
+
+
+def test_fixed_point_text_matches_python_format():
+    """spl_fmt_fixed (the writer's "%.3f" / "%.5f") against Python's format over ratios of small integers (what SSE values are --
+    exact ties like 1/16 included), random doubles, powers of two, tiny and large values."""
+    import ctypes
+    import random
+    lib = native.lib()
+    lib.spl_fmt_fixed.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_char_p]
+    buf = ctypes.create_string_buffer(64)
+
+    def got(x, d):
+        assert lib.spl_fmt_fixed(x, d, buf) == 0
+        return buf.value.decode()
+
+    rnd = random.Random(7)
+    values = [0.0, 1.0, 0.5, 0.0625, 0.1875, 0.0005, 0.00049999999999999, 0.9995, 0.99949999999999994, 2.5e-5, 5e-324, 1e-310,
+              123456789.123456, 8.9e12, 4503599627370496.0, 1e40, 0.000005, 0.0000049999]
+    values += [2.0 ** -k for k in range(0, 80)] + [(2 * k + 1) / 2.0 ** 12 for k in range(0, 2048, 7)]
+    values += [a / b for a in range(0, 60) for b in range(1, 60)]
+    values += [rnd.random() for _ in range(20000)] + [rnd.random() * 10 ** rnd.randint(-8, 12) for _ in range(20000)]
+    values += [rnd.randint(0, 10 ** 6) / 10 ** rnd.randint(1, 7) for _ in range(20000)]   # decimal-looking values next to ties
+    for x in values:
+        for d in (3, 5, 0, 6):
+            assert got(x, d) == ("{0:.%df}" % d).format(x), (x, d)
+    assert got(-1.5, 3) == "-1.500" and got(float("inf"), 3) == "inf"
+
+
+@pytest.mark.parametrize("stranded", [False, True])
+def test_rows_of_an_array_built_table(tmp_path, stranded):
+    """fast_sites leaves the Gene and Strand columns as arrays (gene index, strand byte): the writer's own way from those to the
+    text columns must give what the lists give (tsv.format_chrom asks for the lists)."""
+    import os
+    from spliser_amd import fast_sites, synth
+    wl = synth.Workload("arabidopsis", scale=0.002, seed=4)
+    bed, gff = str(tmp_path / "j.bed"), str(tmp_path / "g.gff")
+    synth.write_bed(bed, wl.genome.chrom_names, wl.junctions, stranded=stranded)
+    synth.write_gff(gff, wl.genome)
+    bins = sites.GeneBins.from_annotation(gff, "gene", "All", log=lambda m: None)
+    table = fast_sites.build(bins, stranded, bed)
+    assert table is not None
+    rng = np.random.default_rng(1)
+    chunks, want = [], tsv.HEADER
+    for chrom in table.chrom_index:
+        arr = table.chrom_arrays(chrom)
+        if arr.n == 0:
+            continue
+        assert arr._genes is None and arr._strand_text is None
+        res = dict(beta1=rng.integers(0, 50, arr.n).astype(np.uint32), beta2_simple=rng.integers(0, 50, arr.n), sse=rng.random(arr.n),
+                   beta2_cryptic=rng.integers(0, 9, arr.n), beta2_weighted=rng.random(arr.n) * 7)
+        chunks.append((arr, res))
+    got = _native_text(tmp_path, chunks, True)     # (before anything asks for the lists)
+    for arr, res in chunks:
+        want += "".join(tsv.format_chrom(arr, res, True))
+    assert any(g != "NA" for arr, _ in chunks for g in arr.genes) and got == want
