@@ -1,6 +1,7 @@
-"""The hot path with the hand-over included (run on the GPU box): host arrays -> spl_reads_upload (H2D copies + the pack kernel) ->
-one counting pass + beta2 / SSE -> results back on the host.  bench.py's `value` starts with the data resident in HBM; this is
-the rate a caller sees who hands over host buffers every time.   tools/pcie_rate.py [repeats]"""
+"""The hot path with the hand-over included (run on the GPU box): caller's host arrays -> spl_reads_upload (host packing into the
+page-locked staging ring, H2D copies on the copy stream) -> one counting pass + beta2 / SSE -> results back on the host.
+bench.py's `value` starts with the data resident in HBM; this is the rate a caller sees who hands over host buffers every time.
+tools/pcie_rate.py [repeats]"""
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spliser_amd import fast_sites, native, shard, sites, synth  # noqa: E402
@@ -29,7 +30,7 @@ for rep in range(reps):
         res = ds.sse_results()
         dr.free()
     t2 = time.perf_counter()
-    print("pass %d: upload + pack %.4f s, count + SSE + download %.4f s, total %.4f s = %.1f M reads/s (%.1f GB/s of host arrays)"
+    print("pass %d: pack + upload %.4f s, count + SSE + download %.4f s, total %.4f s = %.1f M reads/s (%.1f GB/s of host arrays)"
           % (rep, t1 - t0, t2 - t1, t2 - t0, n_reads / (t2 - t0) / 1e6, host_bytes / (t2 - t0) / 1e9))
     best = min(best or 1e9, t2 - t0)
 print("best: %.4f s = %.1f M reads/s for %d reads, %.1f MB of host arrays" % (best, n_reads / best / 1e6, n_reads, host_bytes / 1e6))

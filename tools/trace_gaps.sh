@@ -3,9 +3,9 @@
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p /tmp/wl
-cd $R && python bench.py --cache /tmp/wl --no-cpu-baseline --steps 2 > /dev/null 2>&1
+cd $R && python bench.py --cache /tmp/wl --no-cpu-baseline --e2e off --steps 2 "$@" > /dev/null 2>&1   # (same arguments: same cache key, nothing generated under the profiler)
 cd /tmp && rm -rf /tmp/tr
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 $R/bench.py --cache /tmp/wl --steps 8 --warmup 2 --no-cpu-baseline "$@" > /tmp/tr.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 $R/bench.py --cache /tmp/wl --steps 8 --warmup 2 --no-cpu-baseline --e2e off "$@" > /tmp/tr.log 2>&1
 find /tmp/tr -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 -c "
 import csv
 rows=[r for r in csv.DictReader(open('{}')) if 'spl_' in r['Kernel_Name'] and 'pack' not in r['Kernel_Name'] and 'dbuckets' not in r['Kernel_Name']]
