@@ -87,6 +87,30 @@ def lib_sha16():
     return h.hexdigest()[:16]
 
 
+def cpu_budget():
+    """-> (hardware threads this process may run on, CPU-time quota of its cgroup in cores or None).  A box of this pool shows
+    256 hardware threads and grants 16 cores' worth of CPU time: threads beyond the quota only get throttled."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                 # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = float(fh.read()), float(fp.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    return n, quota
+
+
 def run_oracle(items, scode, cryptic, threads):
     """The oracle over the whole workload.  -> (seconds, {chrom: (counters, sse results)})"""
     from concurrent.futures import ThreadPoolExecutor
@@ -138,6 +162,10 @@ def e2e_leg(name, wl, table_items, stranded, cryptic, seq_mode, reps, want_rows)
             wall = time.perf_counter() - t
             runs.append(dict(wall_s=wall, reads_per_sec=n_reads / wall, stages={k2: round(v, 4) for k2, v in tm.items()}))
         best = min(runs, key=lambda r: r["wall_s"])
+        nproc, quota = cpu_budget()
+        out["host_cpu"] = {"nproc": nproc, "cpu_quota_cores": quota,
+                           "note": "the call is host-bound (BGZF inflate + CRC, record extraction, packing): the GPU is idle for "
+                                   "nine tenths of it, see profiles/*_e2e_*_timeline.txt"}
         out.update(reads=n_reads, reads_per_sec=best["reads_per_sec"], wall_s=best["wall_s"], stages=best["stages"],
                    first_call_wall_s=runs[0]["wall_s"], runs=len(runs),
                    what="process(): open BAM + BED/GFF -> Steps 0-2 on the host while the BAM decodes -> per chromosome: host "
@@ -328,8 +356,9 @@ def main():
         parity = {"reads": n_reads, "sites": n_sites, "bit_exact_vs_oracle": bool(exact), "of": "the last timed step",
                   "checked": "beta1, beta2Simple(reads), double counts, beta2Simple, beta2Cryptic, beta2Weighted, SSE"}
         if world == 1 and not args.no_cpu_baseline:
-            nproc = os.cpu_count() or 1
-            t_all, want_all = run_oracle(items, scode, args.beta2Cryptic, nproc)
+            nproc, quota = cpu_budget()
+            n_threads = max(1, min(nproc, int(round(quota)) if quota else nproc))
+            t_all, want_all = run_oracle(items, scode, args.beta2Cryptic, n_threads)
             same = all(all(np.array_equal(a, b) for a, b in zip(want[c][0], want_all[c][0])) for c in want)
             pairs = int(sum(int(w[0].sum()) + int(w[1].sum()) for w, _ in want.values()))
             cpu = {"value": n_sites / t_cpu1, "unit": "splice sites/s", "reads_per_sec": n_reads / t_cpu1, "cores": 1,
@@ -337,7 +366,9 @@ def main():
                    "sample": "the whole workload (%d reads x %d sites), one pass (%.1f s) of oracle/spliser_oracle.c, the "
                              "site-centric C restatement of checkBam + findBeta2Counts + calculateSSE, on 1 thread" % (n_reads, n_sites, t_cpu1),
                    "all_cores": {"value": n_sites / t_all, "reads_per_sec": n_reads / t_all, "nproc": nproc,
-                                 "threads": "up to 8 chromosomes side by side, the site loop of each on nproc/8 OpenMP threads",
+                                 "cpu_quota_cores": quota, "threads_used": n_threads,
+                                 "threads": "min(nproc, the cgroup's CPU quota) threads: up to 8 chromosomes side by side, the site "
+                                            "loop of each on its share of them (OpenMP)",
                                  "seconds": t_all, "same_counts_as_1_thread": bool(same)},
                    "reference_cost_model": {"estimate_seconds": n_sites * 1.7e-3 + pairs * 7.1e-6,
                                             "label": "ESTIMATE, not a measurement: S*1.7 ms (one samtools spawn per site) + P*7.1 us "

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -72,6 +73,12 @@ struct spl_ctx {
     hipStream_t copy = nullptr;
     hipEvent_t ev_copy = nullptr;
     int pack_threads = 1;
+    // SPL_STAGE_TIMING=1 (diagnostic: every piece is waited for, so packing and copying no longer overlap): what the pieces of a
+    // read set took to pack and to copy, printed when the read set is finished
+    bool stage_timing = false;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    double tm_plan_s = 0, tm_emit_s = 0, tm_copy_ms = 0;
+    size_t tm_bytes = 0, tm_pieces = 0;
     int last_grid = 0, last_lds = 0, last_variant = 0;
     struct Junction { int32_t left, right; uint8_t strand; uint32_t count, anchor_left, anchor_right; };
     std::vector<Junction> junctions; // result of the last spl_junctions call, sorted
@@ -434,6 +441,8 @@ static void build_junction_table(const spl_sites *s, const std::vector<uint8_t> 
     if (jrivals.empty()) jrivals.assign(2, make_uint4(0, 0, 0xffffffffu, 0xffffffffu));
 }
 
+static int ensure_stage(spl_ctx *c);
+
 extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out)
 {
     if (!c || !out) return spl_set_error(SPL_ERR_ARG, "spl_sites_upload: null argument");
@@ -441,6 +450,10 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     int rc = validate_sites(s);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    const bool stamps = getenv("SPL_DEBUG_TABLE") != nullptr;
+    auto host_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = host_now();
+    auto stamp = [&](const char *what) { if (stamps) { const double t = host_now(); fprintf(stderr, "[spl_sites_upload] %-28s %.4f s\n", what, t - t_mark); t_mark = t; } };
     const int64_t S = s->n_sites;
     const int64_t P = S ? s->part_off[S] : 0, C = S ? s->comp_off[S] : 0;
     spl_dsites *d = new (std::nothrow) spl_dsites();
@@ -466,6 +479,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
         }
         bucket[d->n_buckets] = (uint32_t)S;
     }
+    stamp("row buckets");
     std::vector<uint4> meta((size_t)S);
     std::vector<uint8_t> flags((size_t)S);
     for (int64_t i = 0; i < S; ++i) {
@@ -489,6 +503,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
         if (S > 0) build_junction_table(s, flags, dfirst, row_dpos, jhash, jrivals, flag_pos);
         if (jhash.empty()) { jhash.assign(32, make_uint4(0x80000000u, 0, 0, 0)); jrivals.assign(2, make_uint4(0, 0, 0xffffffffu, 0xffffffffu)); }
     }
+    stamp("junction table");
     for (int32_t x : flag_pos)
         if (x < 0 || x > SPL_COORD_MAX) { delete d; return spl_set_error(SPL_ERR_RANGE, "partner / competitor position outside [0, %d]", SPL_COORD_MAX); }
     d->jhash_mask = (uint32_t)(jhash.size() / 2) - 1u;
@@ -523,6 +538,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     d->slab_bytes = std::max<size_t>(off, 256);
     hipError_t e = hipMalloc((void **)&d->slab, d->slab_bytes);
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the site table: %s", d->slab_bytes, hipGetErrorString(e)); }
+    stamp("hipMalloc");
     d->pos = (int32_t *)(d->slab + o_pos); d->strand = (uint8_t *)(d->slab + o_strand); d->meta = (uint4 *)(d->slab + o_meta);
     d->flags = (uint8_t *)(d->slab + o_flags); d->diff = (int32_t *)(d->slab + o_diff); d->block_sums = (int32_t *)(d->slab + o_bsum);
     d->dpos_first_row = (int32_t *)(d->slab + o_dfirst); d->dbucket = (spl_dbk *)(d->slab + o_dbucket); d->flag_pos = (int32_t *)(d->slab + o_fpos);
@@ -539,11 +555,43 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     d->b2_weighted = (double *)(d->slab + o_b2w); d->sse = (double *)(d->slab + o_sse); d->sse_cryptic = (double *)(d->slab + o_ssec);
     d->sse_view = d->sse;
 
+    // The table's arrays go up through the context's page-locked staging ring, packed end to end into its buffers: fifteen
+    // arrays, 25 MB for 200 k sites -- as fifteen synchronous copies out of pageable memory that took 8...20 ms (most of the
+    // call), this way the copy engine runs at its 50 GB/s while the next buffer is being filled.
+    hipError_t r = hipSuccess;
+    if (ensure_stage(c) != SPL_OK) r = hipErrorOutOfMemory;
+    size_t fill = 0;        // bytes used of the current staging buffer
+    bool open_buf = false;  // the current buffer has copies in flight that no event covers yet
+    auto next_buffer = [&]() -> hipError_t {
+        hipError_t q = hipSuccess;
+        if (open_buf) {
+            spl_ctx::Stage &cur = c->stage[c->stage_next];
+            q = hipEventRecord(cur.done, c->copy);
+            cur.busy = true;
+            c->stage_next = (c->stage_next + 1) % c->stage.size();
+            open_buf = false;
+        }
+        fill = 0;
+        return q;
+    };
     auto up = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
         if (!bytes || !src) return hipSuccess;
-        return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); // synchronous: host vectors above die at return
+        const char *from = (const char *)src;
+        char *to = (char *)dst;
+        while (bytes) {
+            spl_ctx::Stage *st = &c->stage[c->stage_next];
+            if (fill + 64 > st->bytes) { const hipError_t q = next_buffer(); if (q != hipSuccess) return q; st = &c->stage[c->stage_next]; }
+            if (fill == 0 && st->busy) { const hipError_t q = hipEventSynchronize(st->done); st->busy = false; if (q != hipSuccess) return q; }
+            const size_t n = std::min(bytes, st->bytes - fill);
+            memcpy(st->host + fill, from, n);
+            const hipError_t q = hipMemcpyAsync(to, st->host + fill, n, hipMemcpyHostToDevice, c->copy);
+            if (q != hipSuccess) return q;
+            open_buf = true;
+            fill = (fill + n + 63) & ~(size_t)63;
+            from += n; to += n; bytes -= n;
+        }
+        return hipSuccess;
     };
-    hipError_t r = hipSuccess;
     if (r == hipSuccess) r = up(d->pos, s->pos, 4 * S);
     if (r == hipSuccess) r = up(d->strand, s->strand, S);
     if (r == hipSuccess) r = up(d->meta, meta.data(), 16 * S);
@@ -559,12 +607,17 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     if (r == hipSuccess) r = up(d->alpha, s->alpha, 8 * S);
     if (r == hipSuccess) r = up(d->edge_cnt, s->edge_cnt, 8 * P);
     if (r == hipSuccess) r = up(d->bucket, bucket.data(), 4 * bucket.size());
+    if (r == hipSuccess) r = next_buffer();
+    if (r == hipSuccess) r = hipStreamSynchronize(c->copy); // (the arrays are on the device before anything is launched on them)
+    stamp("copies");
     if (r == hipSuccess) r = hipMemset(d->slab + o_cnt, 0, d->slab_bytes > o_cnt ? d->slab_bytes - o_cnt : 0);
+    stamp("memset");
     if (r == hipSuccess && S > 0) {
         r = (hipError_t)spl_dev_launch_build_dbuckets(d->pos, d->dpos_first_row, d->n_dpos, d->flag_pos, (int32_t)flag_pos.size(), d->dbase, d->n_dbuckets, d->dbucket,
                                                       c->stream);
         if (r == hipSuccess) r = hipStreamSynchronize(c->stream);
     }
+    stamp("position index kernel");
     if (r != hipSuccess) { (void)hipFree(d->slab); delete d; return spl_set_error(SPL_ERR_HIP, "site table upload: %s", hipGetErrorString(r)); }
     *out = d;
     return SPL_OK;
@@ -597,6 +650,11 @@ static int ensure_stage(spl_ctx *c)
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+    if (getenv("SPL_STAGE_TIMING")) {
+        HIP_TRY(hipEventCreate(&c->ev_t0));
+        HIP_TRY(hipEventCreate(&c->ev_t1));
+        c->stage_timing = true;
+    }
     const size_t huge = 2u << 20, bytes = (mb << 20) / huge * huge < huge ? huge : (mb << 20) / huge * huge;
     const bool want_lock = !(getenv("SPL_STAGE_PAGEABLE"));
     for (int k = 0; k < n; ++k) {
@@ -624,8 +682,10 @@ static void free_stage(spl_ctx *c)
     }
     c->stage.clear();
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
+    if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->copy) (void)hipStreamDestroy(c->copy);
-    c->ev_copy = nullptr;
+    c->ev_copy = c->ev_t0 = c->ev_t1 = nullptr;
     c->copy = nullptr;
 }
 
@@ -659,8 +719,11 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
                              SPL_COORD_MAX, shift);
     int rc = ensure_stage(c);
     if (rc) return rc;
+    auto host_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tp0 = c->stage_timing ? host_now() : 0.0;
     splpack::Plan plan;
     splpack::plan(src, plan, c->pack_threads);
+    if (c->stage_timing) c->tm_plan_s += host_now() - tp0;
     if (plan.n_wide > 0xfffffff0ull) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops of wide reads in one segment: use more shards");
     if ((uint64_t)d->n_chunks + plan.chunks.size() > (1ull << (32 - SPL_CHUNK_SHIFT)))
         return spl_set_error(SPL_ERR_ARG, "too many reads in one read set: use more shards");
@@ -690,12 +753,20 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
         EmitJob job{&src, &plan, c0, c1, 1, (uint8_t *)host, (uint32_t *)(host + align_up(rec_span))};
         const size_t slices = std::min<size_t>((size_t)c->pack_threads * 4, c1 - c0);
         job.per = (c1 - c0 + slices - 1) / slices;
+        const double te0 = c->stage_timing ? host_now() : 0.0;
         splpack::parallel_for(slices, c->pack_threads, emit_slice, &job);
+        if (c->stage_timing) { c->tm_emit_s += host_now() - te0; (void)hipEventRecord(c->ev_t0, c->copy); }
         q = hipMemcpyAsync(seg.slab + r0, host, rec_span, hipMemcpyHostToDevice, c->copy);
         if (q == hipSuccess && wide_span)
             q = hipMemcpyAsync(seg.slab + rec_al + 4 * w0, host + align_up(rec_span), 4 * wide_span, hipMemcpyHostToDevice, c->copy);
         if (q == hipSuccess && !big.empty()) q = hipStreamSynchronize(c->copy);
         else if (q == hipSuccess) { q = hipEventRecord(st.done, c->copy); st.busy = true; }
+        if (q == hipSuccess && c->stage_timing) {
+            float ms = 0;
+            (void)hipEventRecord(c->ev_t1, c->copy);
+            (void)hipEventSynchronize(c->ev_t1);
+            if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) == hipSuccess) { c->tm_copy_ms += ms; c->tm_bytes += rec_span + 4 * wide_span; ++c->tm_pieces; }
+        }
         c0 = c1;
     }
     if (q != hipSuccess) {
@@ -715,6 +786,13 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
 static int finish_reads(spl_ctx *c, spl_dreads *d)
 {
     if (d->finished) return SPL_OK;
+    if (c->stage_timing && c->tm_pieces) {
+        fprintf(stderr, "[spl_reads] %lld reads: classify %.4f s, write records %.4f s (host, %d threads); H2D %zu pieces, %.1f MB, %.3f ms in the copies = %.1f GB/s\n",
+                (long long)d->n_reads, c->tm_plan_s, c->tm_emit_s, c->pack_threads, c->tm_pieces, c->tm_bytes / 1e6, c->tm_copy_ms,
+                c->tm_copy_ms > 0 ? c->tm_bytes / 1e6 / c->tm_copy_ms : 0.0);
+        c->tm_plan_s = c->tm_emit_s = c->tm_copy_ms = 0;
+        c->tm_bytes = c->tm_pieces = 0;
+    }
     if (d->n_cigar > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops in one read set: use more shards");
     const size_t n = d->n_chunks;
     std::vector<spl_chunk_meta> meta(n);

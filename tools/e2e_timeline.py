@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 --kernel-trace --memory-copy-trace directory of tools/e2e_profile.py: the LAST `process` call's copies and
-kernels on one time axis.   tools/e2e_timeline.py <dir>"""
+"""Summarise a rocprofv3 --kernel-trace --memory-copy-trace directory of tools/e2e_profile.py --runs 1: the copies and kernels of
+the `process` call on one time axis.   tools/e2e_timeline.py <dir>"""
 import csv
 import glob
 import sys
@@ -29,12 +29,7 @@ kernels.sort()
 copies.sort()
 if not kernels:
     sys.exit("no kernels in the trace")
-# the last call = everything after the longest pause between two kernel launches
-gaps = [(kernels[i + 1][0] - kernels[i][1], i) for i in range(len(kernels) - 1)]
-cut = kernels[max(gaps)[1] + 1][0] if gaps else kernels[0][0]
-first_spl = min(k[0] for k in kernels if k[0] >= cut)
-copies = [c for c in copies if c[0] >= first_spl - 50_000_000]   # (the site table goes up just before the first kernel)
-kernels = [k for k in kernels if k[0] >= cut]
+# (tools/e2e_timeline.sh traces a process that makes ONE call: everything in the trace belongs to it)
 t0 = min([k[0] for k in kernels] + [c[0] for c in copies])
 t1 = max([k[1] for k in kernels] + [c[1] for c in copies])
 
@@ -69,7 +64,7 @@ h2d = [c for c in copies if "HOST_TO_DEVICE" in c[2].upper() or "H2D" in c[2].up
 d2h = [c for c in copies if c not in h2d]
 hu = union([(a, b) for a, b, _, _ in h2d])
 busy = lambda u: sum(b - a for a, b in u)
-print("last process() call on the device: %.1f ms from the first copy/kernel to the last" % ((t1 - t0) / 1e6))
+print("process() on the device: %.1f ms from the first copy/kernel to the last" % ((t1 - t0) / 1e6))
 print("kernels: %d launches, %.2f ms busy (union)" % (len(kernels), busy(ku) / 1e6))
 by = {}
 for a, b, n in kernels:
@@ -80,12 +75,11 @@ for n, (c, t) in sorted(by.items(), key=lambda kv: -kv[1][1]):
     print("    %-40s %5d x %9.1f us = %8.2f ms" % (n[:40], c, t / c / 1e3, t / 1e6))
 print("H2D copies: %d, %.1f MB, %.2f ms busy (union); D2H/other copies: %d, %.1f MB" % (
     len(h2d), sum(c[3] for c in h2d) / 1e6, busy(hu) / 1e6, len(d2h), sum(c[3] for c in d2h) / 1e6))
-big = [c for c in h2d if c[3] >= (8 << 20)]
-if big:
-    rates = sorted(c[3] / (c[1] - c[0]) for c in big)
-    print("H2D pieces >= 8 MiB as they ran: %d, rate min / median / max = %.1f / %.1f / %.1f GB/s (%.1f MB in %.2f ms = %.1f GB/s overall)" % (
-        len(big), rates[0], rates[len(rates) // 2], rates[-1], sum(c[3] for c in big) / 1e6, sum(c[1] - c[0] for c in big) / 1e6,
-        sum(c[3] for c in big) / sum(c[1] - c[0] for c in big)))
+long_ = sorted(c[1] - c[0] for c in h2d if c[1] - c[0] >= 300_000)
+if long_:
+    print("H2D copies of 0.3 ms and more (the staging ring's 32 MiB pieces; this trace format has no sizes): %d, duration min / median / max "
+          "= %.2f / %.2f / %.2f ms -- a full piece at the median = %.1f GB/s (SPL_STAGE_TIMING=1 prints exact rates)" % (
+              len(long_), long_[0] / 1e6, long_[len(long_) // 2] / 1e6, long_[-1] / 1e6, (32 << 20) / long_[len(long_) // 2]))
 print("copy time with a kernel running beside it: %.2f ms of %.2f ms H2D (%.0f %%); kernel time under a copy: %.0f %%" % (
     overlap(hu, ku) / 1e6, busy(hu) / 1e6, 100.0 * overlap(hu, ku) / max(busy(hu), 1), 100.0 * overlap(hu, ku) / max(busy(ku), 1)))
 both = union([(a, b) for a, b in ku] + [(a, b) for a, b in hu] + [(a, b) for a, b, _, _ in d2h])
