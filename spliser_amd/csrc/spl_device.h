@@ -173,8 +173,8 @@ struct spl_scan_params {
 #ifdef __cplusplus
 extern "C" {
 #endif
-// variant: 0 = range kernel (needs mutual partner links), 1 = pair kernel (any table), 2 = range kernel without
-// wave-level aggregation of LDS atomics (experiment)
+// variant: 0 = range kernel (any table: the junction table is built from each row's own lists), 1 = pair kernel (the
+// literal cross-check), 2 = range kernel WITH wave-level aggregation of LDS atomics (SPL_OPT_WAVE_AGGREGATION)
 int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out, void *ev_start, void *ev_stop);
 int spl_dev_launch_junctions(const spl_chunk_meta *chunk_meta, uint32_t n_chunks,
                              int stranded, uint32_t min_anchor, uint32_t min_intron, uint32_t max_intron, unsigned long long *keys,

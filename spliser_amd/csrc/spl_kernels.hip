@@ -6,14 +6,19 @@
 //                            t+1) a beta1 read, an N op makes every row strictly inside it a
 //                            mutually-exclusive (beta2Simple) read -- recorded as +1/-1 in LDS-privatised
 //                            difference arrays.  Cost per read is O(ops), whatever the number of sites a
-//                            500 kb intron spans.  Only the sites whose outcome can depend on their own
-//                            partner / competitor lists (rivals of the read's junction ends) are classified
-//                            one by one with the literal state machine (spl_classify.h) and corrected.
-//   spl_scan_*_kernel        prefix sums that turn the difference arrays into beta1 / beta2Simple counters.
-//   spl_count_pairs_kernel   the literal formulation: every (read, site) pair through spl_classify_pair.
-//                            Used for tables whose partner links are not mutual (combine gap-fill queries)
-//                            and as an on-device cross-check of the range kernel in the tests.
-//   spl_sse_kernel           findBeta2Counts + calculateSSE (SpliSER_v0_1_8.py:581-639), one site per lane.
+//                            500 kb intron spans.  Reads come as per-class records laid out by the host
+//                            (spl_pack.h).  Only the sites whose outcome can depend on their own partner /
+//                            competitor lists (rivals of the read's junction: the junction table) are
+//                            corrected one by one, by the wave itself for once- and twice-spliced reads.
+//   spl_count_literal_kernel the reads the range kernel queues (odd CIGAR shapes with a flagged junction end,
+//                            records with flag 0x4, combine mode): table-driven walk, or the literal state machine
+//                            (spl_classify.h).  Also clears the spare counter copy and takes the scan's block sums.
+//   spl_scan_apply_kernel    prefix sums that turn the difference arrays into beta1 / beta2Simple counters, then
+//                            findBeta2Counts + calculateSSE of every row (SpliSER_v0_1_8.py:581-639).
+//   spl_count_pairs_kernel   the literal formulation: every (read, site) pair through spl_classify_pair.  An
+//                            on-device cross-check of the range kernel in the tests; the product never selects it.
+//   spl_junction_kernel      the junction table of a read set (what the README asks regtools for).
+//   spl_sse_kernel           findBeta2Counts + calculateSSE alone, one site per lane (spl_sse on caller's counters).
 //
 // Integer / indexing work: no MFMA.  The roofline that bounds the count kernels is HBM.
 #include <hip/hip_runtime.h>
