@@ -22,6 +22,9 @@
 #define SPL_K_SIMPLE 4                   // reads per lane and wave-iteration: simple reads (8-byte records)
 #define SPL_K_MNM 2                      // ... once-spliced reads (16-byte records)
 #endif
+#ifndef SPL_LIST_K
+#define SPL_LIST_K 2                     // entries per lane and round of the range kernel's list pass (3: spills 2 registers, 4: 17)
+#endif
 #define SPL_WAVE_ITERS 10
 #define SPL_WAVE_READS (64 * SPL_WAVE_ITERS)
 #define SPL_WIN 1020                     // distinct site positions a workgroup privatises in LDS (pair kernel; range kernel unstranded)

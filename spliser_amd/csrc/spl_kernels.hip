@@ -517,18 +517,25 @@ __device__ __forceinline__ void agg_add(uint32_t *addr, int32_t delta)
 //   an aligned block covers t,t+1 -> beta1-type read: -1 beta1, +1 beta2Simple, +1 double count per listed edge.
 // Point updates go to the same LDS difference arrays as the ranges.  Returns false when the read must take the
 // literal kernel instead (junction not in the table = not a BED junction, table entry marked complex, ...).
-template <bool STRANDED, int NARR>
-__device__ __forceinline__ bool rivals_inline(const spl_hot_params &p, spl_lds_i32 *lds, int32_t wbase, int32_t l, int32_t r,
-                                              const int32_t *blk_a, const int32_t *blk_b, uint32_t sidx)
+__device__ __forceinline__ uint32_t junction_hash(int32_t l, int32_t r)
 {
     uint32_t h = (uint32_t)l * 0x9E3779B1u ^ (uint32_t)r * 0x85EBCA77u;
-    h ^= h >> 15;
-    uint4 ent = make_uint4(0, 0, 0, 0), first = make_uint4(0, 0, 0, 0);
+    return h ^ (h >> 15);
+}
+
+// (ent, first) = the two quads of slot h & mask, already loaded by the caller -- who may have asked for several reads' slots in
+// one trip -- further probes and further rival records are fetched here.
+template <bool STRANDED, int NARR>
+__device__ __forceinline__ bool rivals_inline_from(const spl_hot_params &p, spl_lds_i32 *lds, int32_t wbase, int32_t l, int32_t r, uint32_t h,
+                                                   uint4 ent, uint4 first, const int32_t *blk_a, const int32_t *blk_b, uint32_t sidx)
+{
     bool found = false;
     for (int probe = 0; probe < 8; ++probe) {
-        const uint4 *slot = p.jhash + 2u * ((h + (uint32_t)probe) & p.jhash_mask);
-        ent = slot[0];
-        first = slot[1]; // the first rival's record rides along: one trip for the usual one-rival junction
+        if (probe) {
+            const uint4 *slot = p.jhash + 2u * ((h + (uint32_t)probe) & p.jhash_mask);
+            ent = slot[0];
+            first = slot[1]; // the first rival's record rides along: one trip for the usual one-rival junction
+        }
         if ((int32_t)ent.x == l && (int32_t)ent.y == r) { found = true; break; }
         if (ent.x == 0x80000000u) break; // empty slot: not a BED junction with flagged ends
     }
@@ -880,6 +887,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 }
             }
         }
+        const uint32_t n_back_mnm = n_back; // (the list so far: once-spliced reads; what follows is twice-spliced)
         // ---- twice-spliced reads (aligned, N, aligned, N, aligned; the record holds the five lengths): six boundaries,
         //      five ranges.  One read per lane.
         for (; g < g_start[3]; g += NWAVE) {
@@ -1024,37 +1032,72 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
 #ifdef SPL_EXP_NO_LIST
         n_back = 0; // (experiment, never in the product: what the list pass costs -- 28 % of the kernel on config 2)
 #endif
-        for (uint32_t r0 = 0; r0 < n_back; r0 += 64u) {
+        // (the list is read from its growing end: entries [0, n_m2) are the twice-spliced reads, [n_m2, n_back) the once-spliced)
+        const uint32_t n_m2 = n_back - (n_back ? n_back_mnm : 0u);
+        for (uint32_t r0 = 0; r0 < n_m2; r0 += 64u) {
             const uint32_t j = r0 + lane;
             bool undecided = false;
             uint32_t slot = 0;
-            if (j < n_back) {
+            if (j < n_m2) {
                 const uint32_t entry = s_q[seg0 + SEG - n_back + j];
                 slot = entry & 0x3fffu;
-                if (slot >= cv.start[SPL_RC_M2]) {
-                    spl_gchar *q = cv.rec + (size_t)(cv.off[2] + SPL_REC_M2 * (slot - cv.start[2]));
-                    const uint2 ra = ld_g2(q), rb = ld_g2(q + 8), rc = ld_g2(q + 16);
-                    const int32_t pos = (int32_t)ra.x + cv.shift;
+                spl_gchar *q = cv.rec + (size_t)(cv.off[2] + SPL_REC_M2 * (slot - cv.start[2]));
+                const uint2 ra = ld_g2(q), rb = ld_g2(q + 8), rc = ld_g2(q + 16);
+                const int32_t pos = (int32_t)ra.x + cv.shift;
+                uint32_t sidx = 0;
+                if (STRANDED) sidx = (spl_read_strand(ra.y & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
+                const int32_t c0 = pos + (int32_t)(ra.y >> 16), c1 = c0 + (int32_t)rb.x, c2 = c1 + (int32_t)(rb.y & 0xffffu);
+                const int32_t c3 = c2 + (int32_t)rc.x, c4 = c3 + (int32_t)(rb.y >> 16);
+                const int32_t jl[2] = {c0 - 1, c2 - 1}, jr[2] = {c1 - 1, c3 - 1};
+                const bool jf[2] = {((entry >> 14) & 1u) != 0u, (entry >> 15) != 0u};
+                const int32_t blk_a[3] = {pos, c1, c3}, blk_b[3] = {c0 - 1, c2 - 1, c4 - 1};
+                undecided = !rivals_inline2<STRANDED, NARR>(p, lds, wbase, jl, jr, jf, blk_a, blk_b, sidx);
+            }
+            back_done = r0 + 64u < n_m2 ? r0 + 64u : n_m2;
+            if (__any(undecided)) push_front(undecided, slot);
+        }
+        // Once-spliced reads, SPL_LIST_K list entries per lane and round: a round is a chain of dependent trips (record, table
+        // slot, sometimes more), and what a wave pays for is the number of rounds -- all the entries' records are asked for
+        // together, then all their slots.  Straight-line up to there: lanes without an entry read the run's first record and
+        // are masked.
+        constexpr int LK = SPL_LIST_K;
+        for (uint32_t r0 = n_m2; r0 < n_back; r0 += 64u * LK) {
+            bool live[LK], undecided[LK];
+            uint32_t slot[LK];
+            uint4 rec[LK];
+#pragma unroll
+            for (int k = 0; k < LK; ++k) {
+                const uint32_t j = r0 + 64u * (uint32_t)k + lane;
+                live[k] = j < n_back;
+                undecided[k] = false;
+                slot[k] = live[k] ? ((uint32_t)s_q[seg0 + SEG - n_back + j] & 0x3fffu) : cv.start[1];
+                rec[k] = ld_g4(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot[k] - cv.start[1])));
+            }
+            int32_t pos[LK], c0[LK], c1[LK], c2[LK];
+            uint32_t h[LK];
+            uint4 ent[LK], first[LK];
+#pragma unroll
+            for (int k = 0; k < LK; ++k) {
+                pos[k] = (int32_t)rec[k].x + cv.shift;
+                c0[k] = pos[k] + (int32_t)(rec[k].y >> 16); c1[k] = c0[k] + (int32_t)rec[k].z; c2[k] = c1[k] + (int32_t)rec[k].w;
+                h[k] = junction_hash(c0[k] - 1, c1[k] - 1);
+                const uint4 *hslot = p.jhash + 2u * (h[k] & p.jhash_mask);
+                ent[k] = hslot[0];
+                first[k] = hslot[1];
+            }
+#pragma unroll
+            for (int k = 0; k < LK; ++k) {
+                if (live[k]) {
                     uint32_t sidx = 0;
-                    if (STRANDED) sidx = (spl_read_strand(ra.y & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
-                    const int32_t c0 = pos + (int32_t)(ra.y >> 16), c1 = c0 + (int32_t)rb.x, c2 = c1 + (int32_t)(rb.y & 0xffffu);
-                    const int32_t c3 = c2 + (int32_t)rc.x, c4 = c3 + (int32_t)(rb.y >> 16);
-                    const int32_t jl[2] = {c0 - 1, c2 - 1}, jr[2] = {c1 - 1, c3 - 1};
-                    const bool jf[2] = {((entry >> 14) & 1u) != 0u, (entry >> 15) != 0u};
-                    const int32_t blk_a[3] = {pos, c1, c3}, blk_b[3] = {c0 - 1, c2 - 1, c4 - 1};
-                    undecided = !rivals_inline2<STRANDED, NARR>(p, lds, wbase, jl, jr, jf, blk_a, blk_b, sidx);
-                } else {
-                    const uint4 r = ld_g4(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot - cv.start[1])));
-                    const int32_t pos = (int32_t)r.x + cv.shift;
-                    uint32_t sidx = 0;
-                    if (STRANDED) sidx = (spl_read_strand(r.y & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
-                    const int32_t c0 = pos + (int32_t)(r.y >> 16), c1 = c0 + (int32_t)r.z, c2 = c1 + (int32_t)r.w;
-                    const int32_t blk_a[2] = {pos, c1}, blk_b[2] = {c0 - 1, c2 - 1};
-                    undecided = !rivals_inline<STRANDED, NARR>(p, lds, wbase, c0 - 1, c1 - 1, blk_a, blk_b, sidx);
+                    if (STRANDED) sidx = (spl_read_strand(rec[k].y & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
+                    const int32_t blk_a[2] = {pos[k], c1[k]}, blk_b[2] = {c0[k] - 1, c2[k] - 1};
+                    undecided[k] = !rivals_inline_from<STRANDED, NARR>(p, lds, wbase, c0[k] - 1, c1[k] - 1, h[k], ent[k], first[k], blk_a, blk_b, sidx);
                 }
             }
-            back_done = r0 + 64u < n_back ? r0 + 64u : n_back;
-            if (__any(undecided)) push_front(undecided, slot);
+            back_done = r0 + 64u * LK < n_back ? r0 + 64u * LK : n_back;
+#pragma unroll
+            for (int k = 0; k < LK; ++k)
+                if (__any(undecided[k])) push_front(undecided[k], slot[k]);
         }
     }
     if ((tid & 63) == 0) s_qcnt[tid >> 6] = n_front;
