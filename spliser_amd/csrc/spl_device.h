@@ -25,7 +25,9 @@
 #ifndef SPL_LIST_K
 #define SPL_LIST_K 2                     // entries per lane and round of the range kernel's list pass (3: spills 2 registers, 4: 17)
 #endif
+#ifndef SPL_WAVE_ITERS
 #define SPL_WAVE_ITERS 10
+#endif
 #define SPL_WAVE_READS (64 * SPL_WAVE_ITERS)
 #define SPL_WIN 1020                     // distinct site positions a workgroup privatises in LDS (pair kernel; range kernel unstranded)
 #define SPL_WIN_STRANDED 956             // ... range kernel, stranded: 4 windows + the lists, 8 workgroups in 160 KB

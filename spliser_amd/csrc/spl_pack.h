@@ -30,8 +30,10 @@
 
 #include <stdint.h>
 
+#ifndef SPL_CHUNK
 #define SPL_CHUNK 2048                   // consecutive reads per chunk = per workgroup of the range kernel
 #define SPL_CHUNK_SHIFT 11
+#endif
 #define SPL_PACK_SCAN_OPS 8              // CIGARs up to this many ops are packed without their non-consuming ops
 #define SPL_NOPS_SAT 0x1fffu
 #define SPL_RC_SHIFT 29
