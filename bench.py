@@ -87,6 +87,19 @@ def lib_sha16():
     return h.hexdigest()[:16]
 
 
+KERNEL_SOURCES = ("spl_kernels.hip", "spl_device.h", "spl_pack.h", "spl_classify.h", "spl_pack.cpp")
+
+
+def kernel_src_sha16():
+    """What the HBM traffic of the range kernel depends on: the kernel's sources and the packer that lays out what it reads
+    (tools/traffic_json.py stamps a measurement with the same hash).  Host-side changes elsewhere in the library leave it alone."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "spliser_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_budget():
     """-> (hardware threads this process may run on, CPU-time quota of its cgroup in cores or None).  A box of this pool shows
     256 hardware threads and grants 16 cores' worth of CPU time: threads beyond the quota only get throttled."""
@@ -387,14 +400,14 @@ def main():
     if rank == 0:
         # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from a committed
         # rocprofv3 --pmc run of this command (profiles/*_traffic.json, made by tools/prof_pmc.sh) and are quoted only for the
-        # workload AND the library build they were measured with.
+        # workload AND the kernel sources (kernel + packer) they were measured with.
         traffic, traffic_from = None, None
         import glob
-        sha = lib_sha16()
+        sha, ksha = lib_sha16(), kernel_src_sha16()
         for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_traffic.json")), reverse=True):
             with open(tpath) as fh:
                 tj = json.load(fh)
-            if tj.get("lib_sha16") == sha and tj.get("workload") == args.workload and args.scale == 1.0 and args.kernel == "ranges":
+            if tj.get("kernel_src_sha16") == ksha and tj.get("workload") == args.workload and args.scale == 1.0 and args.kernel == "ranges":
                 traffic, traffic_from = tj["hbm_bytes_per_launch"], os.path.basename(tpath)
                 break
         k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
@@ -429,7 +442,7 @@ def main():
                                     "how": "5 more launches after the timed region, each followed by a sync"}),
                          "path": {"what": "algorithmic bytes of a step / time of a step: every kernel of the pass and the gaps between them",
                                   "achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS},
-                         "lib_sha16": sha},
+                         "lib_sha16": sha, "kernel_src_sha16": ksha},
             "cpu_baseline": cpu,
             "parity": parity,
             "e2e": e2e,

@@ -12,6 +12,7 @@
 #include <new>
 #include <string>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -634,6 +635,10 @@ extern "C" void spl_sites_free(spl_ctx *c, spl_dsites *d)
 }
 
 // ---- reads upload ---------------------------------------------------------------------------------------
+struct PooledStage { int device; spl_ctx::Stage st; };
+static std::mutex &stage_pool_mu() { static std::mutex m; return m; }
+static std::vector<PooledStage> &stage_pool() { static std::vector<PooledStage> *p = new std::vector<PooledStage>(); return *p; } // (never destroyed: no order-of-exit games with the HIP runtime)
+
 // The staging ring and the copy stream of a context (created at the first upload).
 static int ensure_stage(spl_ctx *c)
 {
@@ -657,7 +662,16 @@ static int ensure_stage(spl_ctx *c)
     }
     const size_t huge = 2u << 20, bytes = (mb << 20) / huge * huge < huge ? huge : (mb << 20) / huge * huge;
     const bool want_lock = !(getenv("SPL_STAGE_PAGEABLE"));
-    for (int k = 0; k < n; ++k) {
+    {   // buffers a destroyed context of this process left behind (same device, same size): page-locking 96 MiB anew costs 12 ms
+        std::lock_guard<std::mutex> lock(stage_pool_mu());
+        std::vector<PooledStage> &pool = stage_pool();
+        for (size_t k = pool.size(); k-- > 0 && (int)c->stage.size() < n;) {
+            if (pool[k].device != c->device || pool[k].st.bytes != bytes || pool[k].st.locked != want_lock) continue;
+            c->stage.push_back(pool[k].st);
+            pool.erase(pool.begin() + (long)k);
+        }
+    }
+    for (int k = (int)c->stage.size(); k < n; ++k) {
         spl_ctx::Stage st;
         void *p = nullptr;
         if (posix_memalign(&p, huge, bytes) != 0) return spl_set_error(SPL_ERR_NOMEM, "out of host memory for the staging buffers");
@@ -675,10 +689,16 @@ static int ensure_stage(spl_ctx *c)
 static void free_stage(spl_ctx *c)
 {
     if (c->copy) (void)hipStreamSynchronize(c->copy);
-    for (spl_ctx::Stage &st : c->stage) {
-        if (st.done) (void)hipEventDestroy(st.done);
-        if (st.locked) (void)hipHostUnregister(st.host);
-        free(st.host);
+    {   // the buffers (idle now) stay with the process for the next context on this device; a handful at most are kept
+        std::lock_guard<std::mutex> lock(stage_pool_mu());
+        std::vector<PooledStage> &pool = stage_pool();
+        for (spl_ctx::Stage &st : c->stage) {
+            st.busy = false;
+            if (pool.size() < 8) { pool.push_back(PooledStage{c->device, st}); continue; }
+            if (st.done) (void)hipEventDestroy(st.done);
+            if (st.locked) (void)hipHostUnregister(st.host);
+            free(st.host);
+        }
     }
     c->stage.clear();
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HBM bytes per launch of the range kernel from the FETCH_SIZE / WRITE_SIZE passes of tools/prof_pmc.sh, as the JSON bench.py
-quotes in roofline.traffic (only for the workload and the library build it was measured with).
+quotes in roofline.traffic (only for the workload and the kernel sources it was measured with).
    tools/traffic_json.py <tag> [the bench.py arguments of the profiled command]"""
 import collections
 import csv
@@ -29,8 +29,11 @@ def mean(counter, sub):
 fetch, n = mean("FETCH_SIZE", "fetch")
 write, _ = mean("WRITE_SIZE", "write")
 h = hashlib.sha256(open(os.path.join(ROOT, "spliser_amd", "libspliser_hip.so"), "rb").read()).hexdigest()[:16]
+kh = hashlib.sha256()
+for name in ("spl_kernels.hip", "spl_device.h", "spl_pack.h", "spl_classify.h", "spl_pack.cpp"):   # (= bench.py KERNEL_SOURCES)
+    kh.update(open(os.path.join(ROOT, "spliser_amd", "csrc", name), "rb").read())
 workload = args[args.index("--workload") + 1] if "--workload" in args else "human"
-out = {"workload": workload, "bench_args": args, "lib_sha16": h, "kernel": "spl_count_ranges_kernel", "dispatches": n,
+out = {"workload": workload, "bench_args": args, "lib_sha16": h, "kernel_src_sha16": kh.hexdigest()[:16], "kernel": "spl_count_ranges_kernel", "dispatches": n,
        "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof_pmc.sh), means per dispatch",
        "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
        "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read (MI355X_MICROARCH.md, HBM): x 2 for the "
