@@ -392,9 +392,13 @@ def main():
                            oracle_rows(items, want, args.beta2Cryptic))]
             if wl_small is not None:
                 wl2, _, items2, stranded2 = wl_small
-                _, want2 = run_oracle(items2, native.STRANDED_CODE[stranded2], args.beta2Cryptic, os.cpu_count() or 1)
-                e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, args.e2e_seq_mode, args.e2e_reps,
-                                   oracle_rows(items2, want2, args.beta2Cryptic)))
+                _, want2 = run_oracle(items2, native.STRANDED_CODE[stranded2], args.beta2Cryptic, max(1, int(round(cpu_budget()[1] or 8))))
+                rows2 = oracle_rows(items2, want2, args.beta2Cryptic)
+                e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, args.e2e_seq_mode, args.e2e_reps, rows2))
+                if args.e2e_seq_mode == 0:
+                    # ... and once with SEQ / QUAL bytes that deflate like a real library's (1.4 GB for these 20 M reads): the
+                    # files above inflate at memset speed, a real one makes BGZF inflate the whole cost of the call
+                    e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, 1, args.e2e_reps, rows2))
     ctx.close()
 
     if rank == 0:
