@@ -200,6 +200,14 @@ int spl_last_launch_info(const spl_ctx *ctx, int32_t *grid_out, int32_t *block_o
  * must then take them again).  spl_bam_open = open_stream + wait_all. */
 int spl_bam_open(const char *path, int n_threads, spl_bam **out);
 int spl_bam_open_stream(const char *path, int n_threads, spl_bam **out);
+/* Decode on the DEVICE instead: spl_bam_open_deferred reads the header and starts nothing; spl_bam_decode_device then sends the
+ * file to the GPU as it is, inflates its BGZF blocks there (one block per lane, CRC32 checked), finds and extracts the alignment
+ * records there, and brings back only what checkBam reads (POS, FLAG, CIGAR: a fifteenth of the inflated bytes); every
+ * reference is complete when it returns.  *on_device_out = 0: the file is one the device path does not take (not sorted by
+ * reference, CIGARs parked in CG tags, anything malformed) and the host threads have been started on it instead -- results and
+ * error reporting are the host decoder's either way.  Waiting on a deferred file nobody decoded starts the host decode. */
+int spl_bam_open_deferred(const char *path, int n_threads, spl_bam **out);
+int spl_bam_decode_device(spl_ctx *ctx, spl_bam *bam, int *on_device_out);
 int spl_bam_wait_ref(spl_bam *bam, int tid, int64_t *n_reads_out, int64_t *max_end_out);
 int spl_bam_wait_all(spl_bam *bam, int *sorted_out);
 void spl_bam_close(spl_bam *bam);

@@ -369,6 +369,7 @@ struct spl_bam {
     size_t fsize = 0;
     BlockDir dir;
     int n_threads = 1;
+    bool started = false;      // a decode has been started (host worker) or its result adopted (device decoder)
     uint64_t header_bytes = 0; // magic, text and reference dictionary: the first record starts here in the inflated stream
     std::string path;
     ~spl_bam();
@@ -585,8 +586,9 @@ bool assemble_ref(spl_bam *bam, int tid, std::string &err)
             memcpy(dst.flag + read_at[i], src.flag, sizeof(uint16_t) * k);
             const uint32_t base = (uint32_t)op_at[i];
             uint32_t *off = dst.cig_off + read_at[i]; // entry j + 1 = end of read j
-            for (size_t j = 1; j <= k; ++j) off[j] = base + src.cig_off[j];
-            if (src.n_ops) memcpy(dst.cigar + op_at[i], src.cigar, sizeof(uint32_t) * src.n_ops);
+            const uint32_t c0 = src.cig_off[0]; // (0 for the host decoder's parts; a file-wide offset for adopted arrays)
+            for (size_t j = 1; j <= k; ++j) off[j] = base + (src.cig_off[j] - c0);
+            if (src.n_ops) memcpy(dst.cigar + op_at[i], src.cigar + c0, sizeof(uint32_t) * src.n_ops);
         }
     };
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::min(bam->n_threads, 16), parts.size()));
@@ -900,7 +902,7 @@ int read_header(spl_bam *bam, std::string &fail, int &code)
 } // namespace
 
 // Opens the file, reads the block directory and the header, and starts the decode on a thread of its own.
-extern "C" int spl_bam_open_stream(const char *path, int n_threads, spl_bam **out)
+static int open_file(const char *path, int n_threads, bool start_now, spl_bam **out)
 {
     if (!path || !out) return spl_set_error(SPL_ERR_ARG, "spl_bam_open: null argument");
     *out = nullptr;
@@ -952,8 +954,71 @@ extern "C" int spl_bam_open_stream(const char *path, int n_threads, spl_bam **ou
         if (fail.compare(0, strlen(path), path) == 0) return spl_set_error(code, "%s", fail.c_str()); // (the walk's message names the file already)
         return spl_set_error(code, "%s: %s", path, fail.c_str());
     }
-    bam->worker = std::thread(decode_worker, bam);
+    if (start_now) { bam->started = true; bam->worker = std::thread(decode_worker, bam); }
     *out = bam;
+    return SPL_OK;
+}
+
+extern "C" int spl_bam_open_stream(const char *path, int n_threads, spl_bam **out) { return open_file(path, n_threads, true, out); }
+extern "C" int spl_bam_open_deferred(const char *path, int n_threads, spl_bam **out) { return open_file(path, n_threads, false, out); }
+
+int spl_bam_start_host(spl_bam *bam)
+{
+    if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_start_host: null argument");
+    std::lock_guard<std::mutex> lock(bam->mu);
+    if (!bam->started) { bam->started = true; bam->worker = std::thread(decode_worker, bam); }
+    return SPL_OK;
+}
+
+int spl_bam_walk_all(spl_bam *bam)
+{
+    if (bam->dir.state.load() == 0) walk_blocks(bam->dir, (const uint8_t *)bam->map, bam->fsize, bam->path.c_str(), 0);
+    if (bam->dir.state.load() < 0) return spl_set_error(bam->dir.err_code, "%s", bam->dir.error.c_str());
+    return SPL_OK;
+}
+size_t spl_bam_block_count(const spl_bam *bam) { return bam->dir.n_ready.load(); }
+void spl_bam_block_get(const spl_bam *bam, size_t i, spl_bam_block_info *out)
+{
+    const Block &b = bam->dir.at(i);
+    const uint8_t *file = (const uint8_t *)bam->map;
+    out->data_off = b.coff + 12 + b.xlen;
+    out->data_len = b.csize - 12 - b.xlen - 8;
+    out->uoff = b.uoff;
+    out->isize = b.isize;
+    out->crc = le32(file + b.coff + b.csize - 8);
+}
+const uint8_t *spl_bam_image(const spl_bam *bam, size_t *fsize_out) { if (fsize_out) *fsize_out = bam->fsize; return (const uint8_t *)bam->map; }
+uint64_t spl_bam_header_end(const spl_bam *bam) { return bam->header_bytes; }
+int spl_bam_thread_count(const spl_bam *bam) { return bam->n_threads; }
+
+int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off, uint32_t *cigar, const int64_t *ref_first, const int64_t *ref_n,
+                  const int64_t *ref_max_end, int64_t n_records_total)
+{
+    std::lock_guard<std::mutex> lock(bam->mu);
+    if (bam->started) return spl_set_error(SPL_ERR_ARG, "spl_bam_adopt: the host decode of this file is running already");
+    bam->started = true;
+    bam->slabs.push_back(pos); bam->slabs.push_back(flag); bam->slabs.push_back(cig_off); bam->slabs.push_back(cigar);
+    for (int t = 0; t < bam->n_refs; ++t) {
+        if (ref_n[t] <= 0) continue;
+        PendingPart *pp = new PendingPart();
+        pp->tid = t;
+        RefReads &r = pp->reads;
+        r.pos = pos + ref_first[t];
+        r.flag = flag + ref_first[t];
+        r.cig_off = cig_off + ref_first[t]; // (offsets into the file-wide op array: cig_off[0] of a part need not be 0)
+        r.cigar = cigar;
+        r.n = (size_t)ref_n[t];
+        r.n_ops = (size_t)(r.cig_off[r.n] - r.cig_off[0]);
+        r.max_end = ref_max_end[t];
+        bam->parts[(size_t)t].push_back(pp);
+        bam->ref_reads[(size_t)t] = ref_n[t];
+        bam->ref_max_end[(size_t)t] = ref_max_end[t];
+    }
+    bam->n_records = n_records_total;
+    bam->max_tid_seen = bam->n_refs - 1;
+    bam->complete_upto = bam->n_refs;
+    bam->done = true;
+    bam->cv.notify_all();
     return SPL_OK;
 }
 
@@ -967,6 +1032,7 @@ extern "C" int spl_bam_wait_ref(spl_bam *bam, int tid, int64_t *n_reads_out, int
 {
     if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_wait_ref: null argument");
     if (tid < 0 || tid >= bam->n_refs) return spl_set_error(SPL_ERR_ARG, "tid %d out of range", tid);
+    (void)spl_bam_start_host(bam); // (a deferred file nobody has decoded yet: on the host then)
     std::unique_lock<std::mutex> lock(bam->mu);
     bam->cv.wait(lock, [&]() { return bam->done || tid < bam->complete_upto; });
     const int rc = decode_status(bam);
@@ -979,6 +1045,7 @@ extern "C" int spl_bam_wait_ref(spl_bam *bam, int tid, int64_t *n_reads_out, int
 extern "C" int spl_bam_wait_all(spl_bam *bam, int *sorted_out)
 {
     if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_wait_all: null argument");
+    (void)spl_bam_start_host(bam);
     std::unique_lock<std::mutex> lock(bam->mu);
     bam->cv.wait(lock, [&]() { return bam->done; });
     if (sorted_out) *sorted_out = bam->out_of_order ? 0 : 1;
@@ -1010,6 +1077,7 @@ extern "C" int64_t spl_bam_n_records(const spl_bam *bam)
 {
     if (!bam) return 0;
     spl_bam *b = const_cast<spl_bam *>(bam);
+    (void)spl_bam_start_host(b);
     std::unique_lock<std::mutex> lock(b->mu);
     b->cv.wait(lock, [&]() { return b->done; });
     return b->n_records;

@@ -9,4 +9,20 @@
 // reference is complete (spl_bam_wait_ref).  The views stay valid until spl_bam_release_ref(tid) or spl_bam_close.
 int spl_bam_source(spl_bam *bam, int tid, splpack::Source *out, int64_t *max_end_out);
 
+// ---- for the device decoder (spl_capi.cpp: spl_bam_decode_device) -------------------------------------------------------
+// A file opened with spl_bam_open_deferred has its header read and nothing else started: the caller then either hands the decode
+// to the host threads (spl_bam_start_host) or does it elsewhere and gives the result back (spl_bam_adopt).
+struct spl_bam_block_info { uint64_t data_off; uint64_t uoff; uint32_t data_len, isize, crc; };
+int spl_bam_walk_all(spl_bam *bam);                       // the whole block directory, now (SPL_OK or the file's error)
+size_t spl_bam_block_count(const spl_bam *bam);
+void spl_bam_block_get(const spl_bam *bam, size_t i, spl_bam_block_info *out);
+const uint8_t *spl_bam_image(const spl_bam *bam, size_t *fsize_out);
+uint64_t spl_bam_header_end(const spl_bam *bam);           // where the first record starts in the inflated stream
+int spl_bam_thread_count(const spl_bam *bam);
+// The placed records of the whole file in file order as four malloc'ed arrays (the file takes them over and frees them with
+// free()); reference t has records [ref_first[t], ref_first[t] + ref_n[t]), cig_off holds n_total + 1 offsets into cigar.
+int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off, uint32_t *cigar, const int64_t *ref_first, const int64_t *ref_n,
+                  const int64_t *ref_max_end, int64_t n_records_total);
+int spl_bam_start_host(spl_bam *bam);                      // decode on the host's threads after all (idempotent)
+
 #endif

@@ -18,6 +18,7 @@
 
 #include "../../include/spliser.h"
 #include "spl_bam.h"
+#include "spl_inflate.h"
 #include "spl_device.h"
 #include "spl_error.h"
 #include "spl_pack.h"
@@ -799,6 +800,212 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
     d->n_reads += src.n_reads;
     d->n_cigar += src.n_ops;
     d->n_chunks += (uint32_t)n_chunks;
+    return SPL_OK;
+}
+
+// ---- BAM decode on the device ----------------------------------------------------------------------------------------
+// The file image goes up through the staging ring (filled by the packing threads from the page cache), then: inflate + CRC32
+// (spl_inflate.hip), scan of the inflated stream for records (a guess per BGZF block, verified as a chain on the host), prefix
+// sums on the host, extraction of POS / FLAG / CIGAR into file-wide arrays, and those come back into page-locked host arrays
+// that the spl_bam adopts, one part per reference.
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t get(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T *as() const { return (T *)p; }
+};
+struct CopyJob { char *dst; const char *src; size_t n, per; };
+void copy_slice(size_t k, void *arg)
+{
+    const CopyJob &j = *(const CopyJob *)arg;
+    const size_t a = k * j.per, b = std::min(j.n, a + j.per);
+    if (a < b) memcpy(j.dst + a, j.src + a, b - a);
+}
+} // namespace
+
+extern "C" int spl_bam_decode_device(spl_ctx *c, spl_bam *bam, int *on_device_out)
+{
+    if (!c || !bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_decode_device: null argument");
+    if (on_device_out) *on_device_out = 0;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool timing = getenv("SPL_BAM_TIMING") != nullptr;
+    auto host_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = host_now();
+    const double t_begin = t_mark;
+    auto stamp = [&](const char *what) { if (timing) { const double t = host_now(); fprintf(stderr, "[spl_bam_decode_device] %-34s %.4f s\n", what, t - t_mark); t_mark = t; } };
+    auto to_host = [&](const char *why) { // not a file for this path: the host threads take it (and find the words for what is wrong with it)
+        if (timing) fprintf(stderr, "[spl_bam_decode_device] handing the file to the host decoder: %s\n", why);
+        return spl_bam_start_host(bam);
+    };
+    int rc = spl_bam_walk_all(bam);
+    if (rc) return to_host("block directory");
+    const size_t n_blocks = spl_bam_block_count(bam);
+    size_t fsize = 0;
+    const uint8_t *image = spl_bam_image(bam, &fsize);
+    const int n_ref = spl_bam_n_ref(bam);
+    if (n_blocks == 0 || n_blocks > 0xfffffff0ull) return to_host("no blocks");
+    std::vector<spl_zblock> blocks(n_blocks);
+    uint64_t stream_len = 0;
+    for (size_t i = 0; i < n_blocks; ++i) {
+        spl_bam_block_info bi;
+        spl_bam_block_get(bam, i, &bi);
+        blocks[i].in = bi.data_off; blocks[i].out = bi.uoff; blocks[i].in_len = bi.data_len; blocks[i].out_len = bi.isize; blocks[i].crc = bi.crc; blocks[i].pad = 0;
+        stream_len = bi.uoff + bi.isize;
+    }
+    stamp("block directory");
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if ((double)fsize + (double)stream_len * 1.2 + (double)(1u << 30) > (double)free_b) return to_host("not enough device memory for the inflated stream");
+    rc = ensure_stage(c);
+    if (rc) return rc;
+    DevBuf d_image, d_stream, d_blocks, d_status, d_scan;
+    HIP_TRY(d_image.get(fsize + 64));
+    HIP_TRY(d_stream.get(stream_len + 64));
+    HIP_TRY(d_blocks.get(sizeof(spl_zblock) * n_blocks));
+    HIP_TRY(d_status.get(4 * n_blocks));
+    HIP_TRY(d_scan.get(sizeof(spl_bscan) * n_blocks));
+    HIP_TRY(hipMemsetAsync(d_image.as<char>() + fsize, 0, 64, c->copy));
+    // the file image: page cache -> staging buffer (all packing threads) -> device, piece by piece
+    for (size_t off = 0; off < fsize;) {
+        spl_ctx::Stage &st = c->stage[c->stage_next];
+        c->stage_next = (c->stage_next + 1) % c->stage.size();
+        if (st.busy) { HIP_TRY(hipEventSynchronize(st.done)); st.busy = false; }
+        const size_t n = std::min(st.bytes, fsize - off);
+        CopyJob job{st.host, (const char *)image + off, n, 0};
+        const size_t slices = (size_t)std::max(1, c->pack_threads);
+        job.per = (n + slices - 1) / slices;
+        splpack::parallel_for(slices, c->pack_threads, copy_slice, &job);
+        HIP_TRY(hipMemcpyAsync(d_image.as<char>() + off, st.host, n, hipMemcpyHostToDevice, c->copy));
+        HIP_TRY(hipEventRecord(st.done, c->copy));
+        st.busy = true;
+        off += n;
+    }
+    HIP_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), sizeof(spl_zblock) * n_blocks, hipMemcpyHostToDevice, c->copy));
+    HIP_TRY(hipMemsetAsync(d_status.p, 0xff, 4 * n_blocks, c->copy));
+    HIP_TRY(hipStreamSynchronize(c->copy));
+    stamp("file image to the device");
+    HIP_TRY((hipError_t)spl_dev_launch_inflate(d_image.as<uint8_t>(), d_blocks.as<spl_zblock>(), (uint32_t)n_blocks, d_stream.as<uint8_t>(), d_status.as<uint32_t>(), c->copy));
+    HIP_TRY((hipError_t)spl_dev_launch_crc32(d_stream.as<uint8_t>(), d_blocks.as<spl_zblock>(), (uint32_t)n_blocks, d_status.as<uint32_t>(), c->copy));
+    HIP_TRY((hipError_t)spl_dev_launch_bam_scan(d_stream.as<uint8_t>(), stream_len, spl_bam_header_end(bam), n_ref, d_blocks.as<spl_zblock>(), (uint32_t)n_blocks,
+                                                d_scan.as<spl_bscan>(), c->copy));
+    std::vector<uint32_t> status(n_blocks);
+    std::vector<spl_bscan> scan(n_blocks);
+    HIP_TRY(hipMemcpyAsync(status.data(), d_status.p, 4 * n_blocks, hipMemcpyDeviceToHost, c->copy));
+    HIP_TRY(hipMemcpyAsync(scan.data(), d_scan.p, sizeof(spl_bscan) * n_blocks, hipMemcpyDeviceToHost, c->copy));
+    HIP_TRY(hipStreamSynchronize(c->copy));
+    stamp("inflate + CRC32 + record scan");
+    for (size_t i = 0; i < n_blocks; ++i)
+        if (status[i] != SPL_Z_OK) return to_host("a block did not inflate (or its CRC32 is wrong)");
+    // the chain of boundaries, from the end of the BAM header to the end of the stream
+    const uint64_t H = spl_bam_header_end(bam);
+    if (H > stream_len) return to_host("no BAM header");
+    size_t first = 0;
+    while (first < n_blocks && blocks[first].out + blocks[first].out_len <= H && !(blocks[first].out + blocks[first].out_len == H && first + 1 == n_blocks)) ++first;
+    std::vector<uint64_t> rec_off(n_blocks + 1, 0), op_off(n_blocks + 1, 0);
+    int64_t n_all = 0;
+    {
+        uint64_t expect = H;
+        int32_t last_tid = -1;
+        for (size_t b = first; b < n_blocks; ++b) {
+            const spl_bscan &sc = scan[b];
+            if (sc.flags & SPL_BS_CORRUPT) return to_host("a record contradicts itself");
+            if (sc.flags & SPL_BS_NO_START) return to_host("no record boundary found near a block");
+            if (sc.flags & SPL_BS_NEEDS_HOST) return to_host("a CIGAR parked in a CG tag");
+            if (sc.flags & SPL_BS_UNSORTED) return to_host("not sorted by reference");
+            if (sc.start != expect) return to_host("a guessed record boundary did not hold");
+            if (sc.n_placed) {
+                if (sc.tid_first < last_tid) return to_host("not sorted by reference");
+                last_tid = sc.tid_last;
+            }
+            expect = sc.reached;
+            n_all += sc.n_all;
+        }
+        if (expect != stream_len) return to_host("the file ends inside a record");
+    }
+    for (size_t b = 0; b < n_blocks; ++b) {
+        const bool live = b >= first;
+        rec_off[b + 1] = rec_off[b] + (live ? scan[b].n_placed : 0u);
+        op_off[b + 1] = op_off[b] + (live ? scan[b].n_ops : 0u);
+        if (!live) scan[b].n_placed = 0; // (the extraction skips header blocks)
+    }
+    const uint64_t n_rec = rec_off[n_blocks], n_ops = op_off[n_blocks];
+    if (n_ops > 0xfffffff0ull) return to_host("more than 2^32 CIGAR operations");
+    stamp("boundary chain + prefix sums");
+    DevBuf d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
+    HIP_TRY(d_recoff.get(8 * (n_blocks + 1)));
+    HIP_TRY(d_opoff.get(8 * (n_blocks + 1)));
+    HIP_TRY(d_pos.get(4 * n_rec));
+    HIP_TRY(d_flag.get(2 * n_rec));
+    HIP_TRY(d_cigoff.get(4 * (n_rec + 1)));
+    HIP_TRY(d_cigar.get(4 * n_ops));
+    HIP_TRY(d_tid.get(4 * n_rec));
+    HIP_TRY(d_maxend.get(8 * (size_t)std::max(n_ref, 1)));
+    const uint32_t cap = (uint32_t)std::max(n_ref, 1) * 4u + 64u;
+    HIP_TRY(d_bounds.get(16 * (size_t)cap));
+    HIP_TRY(d_nbounds.get(4));
+    HIP_TRY(hipMemcpyAsync(d_recoff.p, rec_off.data(), 8 * (n_blocks + 1), hipMemcpyHostToDevice, c->copy));
+    HIP_TRY(hipMemcpyAsync(d_opoff.p, op_off.data(), 8 * (n_blocks + 1), hipMemcpyHostToDevice, c->copy));
+    HIP_TRY(hipMemcpyAsync(d_scan.p, scan.data(), sizeof(spl_bscan) * n_blocks, hipMemcpyHostToDevice, c->copy));
+    HIP_TRY(hipMemsetAsync(d_maxend.p, 0, 8 * (size_t)std::max(n_ref, 1), c->copy));
+    HIP_TRY(hipMemsetAsync(d_nbounds.p, 0, 4, c->copy));
+    HIP_TRY(hipMemsetAsync(d_cigoff.p, 0, 4, c->copy));
+    HIP_TRY((hipError_t)spl_dev_launch_bam_extract(d_stream.as<uint8_t>(), stream_len, n_ref, d_blocks.as<spl_zblock>(), (uint32_t)n_blocks, d_scan.as<spl_bscan>(),
+                                                   d_recoff.as<uint64_t>(), d_opoff.as<uint64_t>(), d_pos.as<int32_t>(), d_flag.as<uint16_t>(), d_cigoff.as<uint32_t>(),
+                                                   d_cigar.as<uint32_t>(), d_tid.as<int32_t>(), d_maxend.as<unsigned long long>(), c->copy));
+    HIP_TRY((hipError_t)spl_dev_launch_bam_bounds(d_tid.as<int32_t>(), n_rec, d_bounds.as<uint64_t>(), d_nbounds.as<uint32_t>(), cap, c->copy));
+    // results into page-locked host arrays (registered for the copy, released again: the file keeps them as ordinary memory)
+    auto host_array = [&](size_t bytes) -> void * {
+        const size_t huge = 2u << 20, size = (std::max<size_t>(bytes, 64) + huge - 1) / huge * huge;
+        void *p = nullptr;
+        if (posix_memalign(&p, huge, size) != 0) return nullptr;
+        (void)madvise(p, size, MADV_HUGEPAGE);
+        return p;
+    };
+    int32_t *h_pos = (int32_t *)host_array(4 * n_rec);
+    uint16_t *h_flag = (uint16_t *)host_array(2 * n_rec);
+    uint32_t *h_cigoff = (uint32_t *)host_array(4 * (n_rec + 1));
+    uint32_t *h_cigar = (uint32_t *)host_array(4 * n_ops);
+    struct Pin { void *p; size_t n; bool on; } pins[4] = {{h_pos, 4 * n_rec, false}, {h_flag, 2 * n_rec, false}, {h_cigoff, 4 * (n_rec + 1), false}, {h_cigar, 4 * n_ops, false}};
+    auto release = [&](bool free_too) {
+        for (Pin &pn : pins) { if (pn.on) (void)hipHostUnregister(pn.p); pn.on = false; if (free_too) free(pn.p); }
+    };
+    if (!h_pos || !h_flag || !h_cigoff || !h_cigar) { release(true); return spl_set_error(SPL_ERR_NOMEM, "out of host memory for the decoded reads"); }
+    for (Pin &pn : pins) {
+        if (pn.n >= (1u << 20)) { memset(pn.p, 0, pn.n); pn.on = hipHostRegister(pn.p, pn.n, hipHostRegisterDefault) == hipSuccess; } // (touched, then locked)
+    }
+    std::vector<unsigned long long> maxend((size_t)std::max(n_ref, 1));
+    std::vector<uint64_t> bounds(2 * (size_t)cap);
+    uint32_t n_bounds = 0;
+    hipError_t q = hipSuccess;
+    if (n_rec) q = hipMemcpyAsync(h_pos, d_pos.p, 4 * n_rec, hipMemcpyDeviceToHost, c->copy);
+    if (q == hipSuccess && n_rec) q = hipMemcpyAsync(h_flag, d_flag.p, 2 * n_rec, hipMemcpyDeviceToHost, c->copy);
+    if (q == hipSuccess) q = hipMemcpyAsync(h_cigoff, d_cigoff.p, 4 * (n_rec + 1), hipMemcpyDeviceToHost, c->copy);
+    if (q == hipSuccess && n_ops) q = hipMemcpyAsync(h_cigar, d_cigar.p, 4 * n_ops, hipMemcpyDeviceToHost, c->copy);
+    if (q == hipSuccess) q = hipMemcpyAsync(maxend.data(), d_maxend.p, 8 * maxend.size(), hipMemcpyDeviceToHost, c->copy);
+    if (q == hipSuccess) q = hipMemcpyAsync(bounds.data(), d_bounds.p, 16 * (size_t)cap, hipMemcpyDeviceToHost, c->copy);
+    if (q == hipSuccess) q = hipMemcpyAsync(&n_bounds, d_nbounds.p, 4, hipMemcpyDeviceToHost, c->copy);
+    if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
+    release(false);
+    if (q != hipSuccess) { release(true); return spl_set_error(SPL_ERR_HIP, "BAM decode on the device: %s", hipGetErrorString(q)); }
+    stamp("extraction + results to the host");
+    if (n_bounds > cap) { release(true); return to_host("not sorted by reference"); }
+    std::vector<std::pair<uint64_t, int32_t>> runs;
+    for (uint32_t k = 0; k < n_bounds; ++k) runs.emplace_back(bounds[2 * k], (int32_t)(uint32_t)bounds[2 * k + 1]);
+    std::sort(runs.begin(), runs.end());
+    std::vector<int64_t> ref_first((size_t)std::max(n_ref, 1), 0), ref_n((size_t)std::max(n_ref, 1), 0), ref_max((size_t)std::max(n_ref, 1), 0);
+    for (size_t k = 0; k < runs.size(); ++k) {
+        const int32_t t = runs[k].second;
+        if (t < 0 || t >= n_ref || (k && t <= runs[k - 1].second)) { release(true); return to_host("not sorted by reference"); }
+        ref_first[(size_t)t] = (int64_t)runs[k].first;
+        ref_n[(size_t)t] = (int64_t)((k + 1 < runs.size() ? runs[k + 1].first : n_rec) - runs[k].first);
+        ref_max[(size_t)t] = (int64_t)maxend[(size_t)t];
+    }
+    rc = spl_bam_adopt(bam, h_pos, h_flag, h_cigoff, h_cigar, ref_first.data(), ref_n.data(), ref_max.data(), n_all);
+    if (rc) { release(true); return rc; }
+    if (on_device_out) *on_device_out = 1;
+    if (timing) fprintf(stderr, "[spl_bam_decode_device] %zu blocks, %.1f MB -> %.1f MB inflated, %llu placed records of %lld: %.4f s\n", n_blocks, fsize / 1e6,
+                        stream_len / 1e6, (unsigned long long)n_rec, (long long)n_all, host_now() - t_begin);
     return SPL_OK;
 }
 

@@ -33,9 +33,38 @@ struct spl_zblock {
 #define SPL_Z_SHORT 7u
 #define SPL_Z_BAD_CRC 8u
 
+// ---- BAM records out of the inflated stream, one BGZF block per lane ------------------------------------------------
+// What a lane reports about the records that START in its block (spl_bam_scan_kernel).  `start` = the first record boundary at
+// or after the block's first byte -- GUESSED from the bytes (a header that satisfies the BAM specification and whose
+// successors chain), except in the block the BAM header ends in; `reached` = the first boundary at or after the block's end,
+// by walking the records from `start`.  The host accepts the lot only if reached[b] == start[b + 1] for every b: by induction
+// from the end of the BAM header every boundary is then a true one (the same argument as the host decoder's, bam_reader.cpp).
+struct spl_bscan {
+    uint64_t start, reached;
+    uint32_t n_all;      // records starting in the block
+    uint32_t n_placed;   // ... with a reference and a position: the ones that are extracted
+    uint32_t n_ops;      // CIGAR ops of those
+    uint32_t flags;      // SPL_BS_*
+    int32_t tid_first, tid_last; // of the placed records (tid_first = -1: none)
+};
+#define SPL_BS_CORRUPT 1u     // a record that contradicts itself (block_size < 32, fields beyond block_size, stream ends inside it)
+#define SPL_BS_NEEDS_HOST 2u  // a CIGAR parked in a CG tag (more than 65535 ops): the host decoder's business
+#define SPL_BS_UNSORTED 4u    // reference ids go down inside the block
+#define SPL_BS_NO_START 8u    // no plausible record start found within reach of the block
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+// stream_len = bytes of the inflated stream; header_end = where the first record starts; blocks[b].out / out_len say where block b lies
+int spl_dev_launch_bam_scan(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks,
+                            spl_bscan *scan, void *stream_handle);
+// rec_off[b] / op_off[b]: index of the block's first placed record / first op in the output arrays.  cig_off gets n + 1 entries
+// (the caller sets entry 0); ref_max_end[tid] = largest last base of a read of the reference (atomicMax; zero it first).
+int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream_len, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks, const spl_bscan *scan,
+                               const uint64_t *rec_off, const uint64_t *op_off, int32_t *pos, uint16_t *flag, uint32_t *cig_off, uint32_t *cigar,
+                               int32_t *tid, unsigned long long *ref_max_end, void *stream_handle);
+// where the reference id changes along the placed records: (index of the first record of a run, its tid) pairs, unordered
+int spl_dev_launch_bam_bounds(const int32_t *tid, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap, void *stream_handle);
 // image: the whole file in device memory, padded with 8 readable bytes.  stream: the stream to launch on.
 int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *stream);
 int spl_dev_launch_crc32(const uint8_t *out, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *stream);

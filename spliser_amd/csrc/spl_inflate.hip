@@ -7,10 +7,11 @@
 namespace {
 
 struct BitReader {
-    const uint32_t *p;   // next aligned word of the image
+    const uint32_t *p;   // the word after `ahead`
     const uint8_t *end;  // one past the block's DEFLATE data
     uint64_t buf;
     uint32_t cnt;        // valid bits in buf
+    uint32_t ahead;      // the next word of the image, asked for when the previous one was taken: a refill never waits for memory
     __device__ __forceinline__ void init(const uint8_t *at, const uint8_t *e)
     {
         end = e;
@@ -19,16 +20,17 @@ struct BitReader {
         const uint32_t skip = (uint32_t)(a & 3u) * 8u;
         buf = (uint64_t)(*p++) >> skip;
         cnt = 32u - skip;
+        ahead = *p++;
     }
     __device__ __forceinline__ void refill()
     {
-        if (cnt <= 32u) { buf |= (uint64_t)(*p++) << cnt; cnt += 32u; }
+        if (cnt <= 32u) { buf |= (uint64_t)ahead << cnt; cnt += 32u; ahead = *p++; }
     }
     __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
     __device__ __forceinline__ void drop(uint32_t n) { buf >>= n; cnt -= n; }
     __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
-    // bytes of the block consumed so far (whole bytes still in the buffer given back)
-    __device__ __forceinline__ const uint8_t *pos() const { return (const uint8_t *)p - (cnt >> 3); }
+    // bytes of the block consumed so far (whole bytes still in the buffer, and the word read ahead, given back)
+    __device__ __forceinline__ const uint8_t *pos() const { return (const uint8_t *)(p - 1) - (cnt >> 3); }
 };
 
 // A canonical Huffman table: how many codes of each length (1..15), packed two per word so that the decode loop's fixed
@@ -37,8 +39,15 @@ struct Counts {
     uint32_t w[8]; // count[len] = (w[len >> 1] >> (16 * (len & 1))) & 0xffff
 };
 
-template <int MAXSYM>
-__device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Counts &c, uint16_t *symbol)
+// The symbols of a lane's tables live in LDS, entry-major (entry e of lane l at [e * 64 + l]): a look-up is one ds_read instead
+// of a trip to the lane's scratch -- the look-up sits on the dependent chain of every symbol.
+struct LdsSyms {
+    uint16_t *base; // &lds[lane]
+    __device__ __forceinline__ uint16_t get(int e) const { return base[e * 64]; }
+    __device__ __forceinline__ void set(int e, uint16_t v) const { base[e * 64] = v; }
+};
+
+__device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Counts &c, const LdsSyms &symbol)
 {
     uint16_t count[16], offs[16];
 #pragma unroll
@@ -57,7 +66,7 @@ __device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Count
 #pragma unroll
     for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
     for (int s = 0; s < n; ++s)
-        if (lengths[s]) symbol[offs[lengths[s]]++] = (uint16_t)s;
+        if (lengths[s]) symbol.set(offs[lengths[s]]++, (uint16_t)s);
 #pragma unroll
     for (int k = 0; k < 8; ++k) c.w[k] = (uint32_t)count[2 * k] | ((uint32_t)count[2 * k + 1] << 16);
     c.w[0] &= 0xffff0000u; // (codes of length 0 do not exist)
@@ -65,7 +74,7 @@ __device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Count
 }
 
 // One symbol.  -1: no code matches (corrupt data, or an incomplete table was asked for a code it does not have).
-__device__ __forceinline__ int decode_symbol(BitReader &br, const Counts &c, const uint16_t *symbol)
+__device__ __forceinline__ int decode_symbol(BitReader &br, const Counts &c, const LdsSyms &symbol)
 {
     br.refill();
     uint32_t bits = (uint32_t)br.buf;
@@ -77,7 +86,7 @@ __device__ __forceinline__ int decode_symbol(BitReader &br, const Counts &c, con
         const int count = (int)((c.w[len >> 1] >> (16 * (len & 1))) & 0xffffu);
         if (code - count < first) {
             br.drop((uint32_t)len);
-            return (int)symbol[index + (code - first)];
+            return (int)symbol.get(index + (code - first));
         }
         index += count;
         first += count;
@@ -98,6 +107,15 @@ __constant__ uint8_t k_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4
 __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status)
 {
     const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+    // lane-interleaved symbol tables: literal/length (288), distance (32); the code-length code's 19 symbols borrow the
+    // distance table's place while the lengths are being read
+    __shared__ uint16_t s_sym[(288 + 30) * 64]; // (4 workgroups of these in a CU's 160 KB)
+    __shared__ uint16_t s_base[64]; // length and distance bases / extra bits: {len_base[29], dist_base[30]} packed below
+    __shared__ uint8_t s_extra[64];
+    if (threadIdx.x < 29) { s_base[threadIdx.x] = k_len_base[threadIdx.x]; s_extra[threadIdx.x] = k_len_extra[threadIdx.x]; }
+    if (threadIdx.x >= 32 && threadIdx.x < 62) { s_base[threadIdx.x] = k_dist_base[threadIdx.x - 32]; s_extra[threadIdx.x] = k_dist_extra[threadIdx.x - 32]; }
+    __syncthreads();
+    const LdsSyms lsym{s_sym + threadIdx.x}, dsym{s_sym + 288 * 64 + threadIdx.x};
     if (b >= n_blocks) return;
     const spl_zblock zb = blocks[b];
     uint8_t *const out = out_all + zb.out;
@@ -107,9 +125,9 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
     if (out_len == 0) { status[b] = SPL_Z_OK; return; } // (the EOF marker and other empty blocks: nothing to decode into)
     BitReader br;
     br.init(image + zb.in, image + zb.in + zb.in_len);
-    uint16_t lsym[288], dsym[32];
     uint8_t lengths[320];
     Counts lc, dc;
+    uint64_t window = 0; // the last eight bytes of the output, the most recent one on top
     for (int last = 0; !last && err == SPL_Z_OK;) {
         br.refill();
         last = (int)br.take(1);
@@ -123,7 +141,7 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
             if ((len ^ 0xffffu) != nlen) { err = SPL_Z_BAD_STORED; break; }
             const uint8_t *src = br.pos();
             if (src + len > br.end || at + len > out_len) { err = SPL_Z_OVERRUN; break; }
-            for (uint32_t i = 0; i < len; ++i) out[at + i] = src[i];
+            for (uint32_t i = 0; i < len; ++i) { out[at + i] = src[i]; window = (window >> 8) | ((uint64_t)src[i] << 56); }
             at += len;
             br.init(src + len, br.end);
             continue;
@@ -135,9 +153,9 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
             for (; s < 256; ++s) lengths[s] = 9;
             for (; s < 280; ++s) lengths[s] = 7;
             for (; s < 288; ++s) lengths[s] = 8;
-            build_table<288>(lengths, 288, lc, lsym);
+            build_table(lengths, 288, lc, lsym);
             for (s = 0; s < 30; ++s) lengths[s] = 5;
-            build_table<32>(lengths, 30, dc, dsym);
+            build_table(lengths, 30, dc, dsym);
         } else { // dynamic codes
             br.refill();
             const int nlen = (int)br.take(5) + 257, ndist = (int)br.take(5) + 1, ncode = (int)br.take(4) + 4;
@@ -147,8 +165,8 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
             for (int i = 0; i < 19; ++i) cl[i] = 0;
             for (int i = 0; i < ncode; ++i) { br.refill(); cl[k_clen_order[i]] = (uint8_t)br.take(3); }
             Counts cc;
-            uint16_t csym[19];
-            if (!build_table<19>(cl, 19, cc, csym)) { err = SPL_Z_BAD_LENGTHS; break; }
+            const LdsSyms csym = dsym;
+            if (!build_table(cl, 19, cc, csym)) { err = SPL_Z_BAD_LENGTHS; break; }
             int idx = 0;
             while (idx < nlen + ndist) {
                 const int sym = decode_symbol(br, cc, csym);
@@ -170,32 +188,83 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
             }
             if (err != SPL_Z_OK) break;
             if (lengths[256] == 0) { err = SPL_Z_BAD_LENGTHS; break; } // no end-of-block code
-            if (!build_table<288>(lengths, nlen, lc, lsym)) { err = SPL_Z_BAD_LENGTHS; break; }
-            if (!build_table<32>(lengths + nlen, ndist, dc, dsym)) { err = SPL_Z_BAD_LENGTHS; break; }
+            if (!build_table(lengths, nlen, lc, lsym)) { err = SPL_Z_BAD_LENGTHS; break; }
+            if (!build_table(lengths + nlen, ndist, dc, dsym)) { err = SPL_Z_BAD_LENGTHS; break; }
         }
-        // the symbols of the block
-        for (;;) {
-            if (br.pos() > br.end + 8) { err = SPL_Z_OVERRUN; break; }
+        // The symbols of the block, as a state machine that does ONE small thing per turn -- a literal/length symbol, a distance
+        // symbol, or eight bytes of a pending copy.  The 64 lanes of a wave take their turns together: a loop that finished a
+        // 258-byte copy before looking at the next symbol would make 63 lanes wait for the longest copy among them at every
+        // step (that version ran at a twelfth of this one's speed).  `window` = the last eight bytes written: a copy at a distance
+        // of eight or less is made from it without reading anything back.
+        uint32_t copy_left = 0, copy_dist = 0;
+        int want_dist = 0;
+        for (uint32_t turns = 0;; ++turns) {
+            if (turns > 2u * out_len + 4096u || br.pos() > br.end + 12) { err = SPL_Z_OVERRUN; break; }
+            if (copy_left) {
+                if (copy_dist >= 32u && copy_left >= 32u) {
+                    // far enough back and long enough: 32 bytes a turn, four independent loads, then four stores (a turn costs
+                    // a round trip to the L2 for what this lane wrote earlier -- make the trip carry more)
+                    uint64_t w[4];
+                    const uint8_t *src = out + at - copy_dist;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) __builtin_memcpy(&w[k], src + 8 * k, 8);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) __builtin_memcpy(out + at + 8 * k, &w[k], 8);
+                    window = w[3];
+                    at += 32u;
+                    copy_left -= 32u;
+                    continue;
+                }
+                const uint32_t n = copy_left < 8u ? copy_left : 8u;
+                uint64_t rep;
+                if (copy_dist <= 8u) {
+                    // the next bytes repeat the last copy_dist ones: double the pattern until it covers eight bytes
+                    rep = copy_dist == 8u ? window : (window >> (8u * (8u - copy_dist)));
+                    if (copy_dist < 8u) rep &= (1ull << (8u * copy_dist)) - 1ull;
+                    if (copy_dist < 2u) rep |= rep << 8;
+                    if (copy_dist < 3u) rep |= rep << 16;
+                    else if (copy_dist == 3u) rep |= rep << 24;
+                    if (copy_dist < 5u) { if (copy_dist == 3u) rep |= rep << 48; else rep |= rep << 32; }
+                    else if (copy_dist < 8u) rep |= rep << (8u * copy_dist);
+                } else {
+                    __builtin_memcpy(&rep, out + at - copy_dist, 8); // (one unaligned 8-byte load: all eight bytes are behind `at`)
+                }
+                if (n == 8u) {
+                    __builtin_memcpy(out + at, &rep, 8);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k)
+                        if ((uint32_t)k < n) out[at + (uint32_t)k] = (uint8_t)(rep >> (8 * k));
+                }
+                window = n == 8u ? rep : ((window >> (8u * n)) | (rep << (8u * (8u - n))));
+                at += n;
+                copy_left -= n;
+                continue;
+            }
+            if (want_dist) {
+                const int ds = decode_symbol(br, dc, dsym);
+                if (ds < 0 || ds >= 30) { err = SPL_Z_BAD_CODE; break; }
+                br.refill();
+                copy_dist = (uint32_t)s_base[32 + ds] + br.take(s_extra[32 + ds]);
+                if (copy_dist > at) { err = SPL_Z_BAD_DISTANCE; break; }
+                copy_left = (uint32_t)want_dist;
+                if (at + copy_left > out_len) { err = SPL_Z_OVERRUN; break; }
+                want_dist = 0;
+                continue;
+            }
             int sym = decode_symbol(br, lc, lsym);
             if (sym < 0) { err = SPL_Z_BAD_CODE; break; }
             if (sym < 256) {
                 if (at >= out_len) { err = SPL_Z_OVERRUN; break; }
                 out[at++] = (uint8_t)sym;
+                window = (window >> 8) | ((uint64_t)sym << 56);
                 continue;
             }
             if (sym == 256) break;
             sym -= 257;
             if (sym >= 29) { err = SPL_Z_BAD_CODE; break; }
             br.refill();
-            const uint32_t len = (uint32_t)k_len_base[sym] + br.take(k_len_extra[sym]);
-            const int ds = decode_symbol(br, dc, dsym);
-            if (ds < 0 || ds >= 30) { err = SPL_Z_BAD_CODE; break; }
-            br.refill();
-            const uint32_t dist = (uint32_t)k_dist_base[ds] + br.take(k_dist_extra[ds]);
-            if (dist > at) { err = SPL_Z_BAD_DISTANCE; break; }
-            if (at + len > out_len) { err = SPL_Z_OVERRUN; break; }
-            for (uint32_t i = 0; i < len; ++i) out[at + i] = out[at + i - dist];
-            at += len;
+            want_dist = (int)((uint32_t)s_base[sym] + br.take(s_extra[sym])); // (the length, 3..258: a distance symbol follows)
         }
     }
     if (err == SPL_Z_OK && at != out_len) err = SPL_Z_SHORT;
@@ -221,6 +290,184 @@ __global__ __launch_bounds__(64) void spl_crc32_kernel(const uint8_t *out_all, c
     uint32_t c = 0xffffffffu;
     for (uint32_t i = 0; i < zb.out_len; ++i) c = table[(c ^ p[i]) & 0xffu] ^ (c >> 8);
     if ((c ^ 0xffffffffu) != zb.crc) status[b] = SPL_Z_BAD_CRC;
+}
+
+// ---- BAM records ---------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+// Does a record plausibly start at c?  (bam_reader.cpp, plausible_record: the same checks.)  len = the record's size with its
+// length word.
+__device__ __forceinline__ bool plausible_record(const uint8_t *c, const uint8_t *end, int32_t n_ref, uint64_t &len)
+{
+    if (end - c < 36) return false;
+    const uint32_t bs = ld32(c);
+    if (bs < 33u || bs > (1u << 29)) return false;
+    const uint8_t *r = c + 4;
+    const int32_t tid = (int32_t)ld32(r), pos0 = (int32_t)ld32(r + 4);
+    const uint32_t l_name = r[8], n_cig = ld16(r + 12);
+    const int32_t l_seq = (int32_t)ld32(r + 16), next_tid = (int32_t)ld32(r + 20), next_pos = (int32_t)ld32(r + 24);
+    if (tid < -1 || tid >= n_ref || next_tid < -1 || next_tid >= n_ref || pos0 < -1 || next_pos < -1 || l_seq < 0 || l_name < 1u) return false;
+    const uint64_t need = 32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1ull) / 2ull + (uint64_t)l_seq;
+    if (need > bs) return false;
+    if ((uint64_t)(end - c) >= 4ull + 32ull + l_name) {
+        const uint8_t *name = r + 32;
+        if (name[l_name - 1u] != 0) return false;
+        for (uint32_t i = 0; i + 1u < l_name; ++i)
+            if (name[i] < 33 || name[i] > 126) return false;
+    }
+    len = 4ull + bs;
+    return true;
+}
+
+} // namespace
+
+__global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref,
+                                                           const spl_zblock *blocks, uint32_t n_blocks, spl_bscan *scan)
+{
+    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint64_t u0 = blocks[b].out, u1 = u0 + blocks[b].out_len;
+    const uint8_t *const end = stream + stream_len;
+    spl_bscan out;
+    out.start = out.reached = u1;
+    out.n_all = out.n_placed = out.n_ops = 0;
+    out.flags = 0;
+    out.tid_first = out.tid_last = -1;
+    if (u1 <= header_end && !(u1 == header_end && u0 == u1)) { // BAM header bytes only (or an empty block inside them)
+        out.start = out.reached = u1 < header_end ? u1 : header_end;
+        scan[b] = out;
+        return;
+    }
+    uint64_t at = u0;
+    if (u0 <= header_end) {
+        at = header_end; // the first record of the file: known, not guessed
+    } else {
+        // the first plausible start at or after u0 whose next three records chain; the search may run past the block (a record
+        // larger than a block) but not for ever
+        const uint64_t limit = u0 + (1ull << 20) < stream_len ? u0 + (1ull << 20) : stream_len;
+        bool found = false;
+        for (; at + 36 <= limit; ++at) {
+            uint64_t len = 0;
+            if (!plausible_record(stream + at, end, n_ref, len)) continue;
+            uint64_t q = at + len;
+            bool ok = true;
+            for (int k = 0; k < 3 && ok && q + 36 <= stream_len; ++k) {
+                uint64_t l2 = 0;
+                ok = plausible_record(stream + q, end, n_ref, l2);
+                q += l2;
+            }
+            if (ok) { found = true; break; }
+        }
+        if (!found) {
+            if (limit == stream_len) at = stream_len; // (the tail of the last record of the file)
+            else out.flags |= SPL_BS_NO_START;
+        }
+    }
+    out.start = at;
+    // the records that start before the block's end
+    int32_t last_tid = -1;
+    while (at < u1 && !(out.flags & (SPL_BS_CORRUPT | SPL_BS_NO_START))) {
+        if (stream_len - at < 4) { out.flags |= SPL_BS_CORRUPT; break; }
+        const uint32_t bs = ld32(stream + at);
+        if (bs < 32u || stream_len - at < 4ull + bs) { out.flags |= SPL_BS_CORRUPT; break; }
+        const uint8_t *r = stream + at + 4;
+        const int32_t tid = (int32_t)ld32(r), pos0 = (int32_t)ld32(r + 4);
+        const uint32_t l_name = r[8], n_cig = ld16(r + 12), l_seq = ld32(r + 16);
+        const uint64_t need = 32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1ull) / 2ull + (uint64_t)l_seq;
+        if (need > bs) { out.flags |= SPL_BS_CORRUPT; break; }
+        out.n_all++;
+        if (tid >= 0 && tid < n_ref && pos0 >= 0) {
+            if (n_cig > 0) {
+                const uint32_t op0 = ld32(r + 32 + l_name);
+                if ((op0 & 15u) == 4u && (op0 >> 4) == l_seq && bs > need) out.flags |= SPL_BS_NEEDS_HOST; // maybe a CG tag behind it
+            }
+            if (out.tid_first < 0) out.tid_first = tid;
+            if (tid < last_tid) out.flags |= SPL_BS_UNSORTED;
+            last_tid = tid;
+            out.tid_last = tid;
+            out.n_placed++;
+            out.n_ops += n_cig;
+        }
+        at += 4ull + bs;
+    }
+    out.reached = at;
+    scan[b] = out;
+}
+
+__global__ __launch_bounds__(64) void spl_bam_extract_kernel(const uint8_t *stream, uint64_t stream_len, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks,
+                                                              const spl_bscan *scan, const uint64_t *rec_off, const uint64_t *op_off, int32_t *pos_out,
+                                                              uint16_t *flag_out, uint32_t *cig_off, uint32_t *cigar, int32_t *tid_out,
+                                                              unsigned long long *ref_max_end)
+{
+    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+    if (b >= n_blocks) return;
+    const spl_bscan sc = scan[b];
+    if (sc.n_placed == 0) return;
+    const uint64_t u1 = blocks[b].out + blocks[b].out_len;
+    uint64_t at = sc.start, i = rec_off[b], o = op_off[b];
+    while (at < u1) {
+        const uint32_t bs = ld32(stream + at);
+        const uint8_t *r = stream + at + 4;
+        const int32_t tid = (int32_t)ld32(r), pos0 = (int32_t)ld32(r + 4);
+        if (tid >= 0 && tid < n_ref && pos0 >= 0) {
+            const uint32_t l_name = r[8], n_cig = ld16(r + 12);
+            const uint8_t *cig = r + 32 + l_name;
+            long long ref_len = 0;
+            for (uint32_t k = 0; k < n_cig; ++k) {
+                const uint32_t op = ld32(cig + 4ull * k);
+                cigar[o + k] = op;
+                const uint32_t code = op & 15u;
+                if (code == 0u || code == 2u || code == 3u || code == 7u || code == 8u) ref_len += (long long)(op >> 4);
+            }
+            o += n_cig;
+            pos_out[i] = pos0 + 1;
+            flag_out[i] = (uint16_t)ld16(r + 14);
+            tid_out[i] = tid;
+            cig_off[i + 1] = (uint32_t)o;
+            const long long e = (long long)pos0 + 1 + (ref_len > 0 ? ref_len : 1) - 1;
+            atomicMax(&ref_max_end[tid], (unsigned long long)e);
+            ++i;
+        }
+        at += 4ull + bs;
+    }
+}
+
+__global__ __launch_bounds__(256) void spl_bam_bounds_kernel(const int32_t *tid, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0 || tid[i] != tid[i - 1]) {
+        const uint32_t k = atomicAdd(n_bounds, 1u);
+        if (k < cap) { bounds[2 * k] = i; bounds[2 * k + 1] = (uint64_t)(uint32_t)tid[i]; }
+    }
+}
+
+extern "C" int spl_dev_launch_bam_scan(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks,
+                                       spl_bscan *scan, void *st)
+{
+    if (n_blocks == 0) return 0;
+    hipLaunchKernelGGL(spl_bam_scan_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)st, stream, stream_len, header_end, n_ref, blocks, n_blocks, scan);
+    return (int)hipGetLastError();
+}
+
+extern "C" int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream_len, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks, const spl_bscan *scan,
+                                          const uint64_t *rec_off, const uint64_t *op_off, int32_t *pos, uint16_t *flag, uint32_t *cig_off, uint32_t *cigar,
+                                          int32_t *tid, unsigned long long *ref_max_end, void *st)
+{
+    if (n_blocks == 0) return 0;
+    hipLaunchKernelGGL(spl_bam_extract_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)st, stream, stream_len, n_ref, blocks, n_blocks, scan, rec_off,
+                       op_off, pos, flag, cig_off, cigar, tid, ref_max_end);
+    return (int)hipGetLastError();
+}
+
+extern "C" int spl_dev_launch_bam_bounds(const int32_t *tid, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap, void *st)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(spl_bam_bounds_kernel, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, (hipStream_t)st, tid, n, bounds, n_bounds, cap);
+    return (int)hipGetLastError();
 }
 
 extern "C" int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *stream)

@@ -49,7 +49,7 @@ EXPORTS = [
     "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
-    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
+    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
     "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append", "spl_fmt_fixed",
     "spl_bed_open", "spl_gff_open", "spl_text_close", "spl_text_rows", "spl_text_n_chrom", "spl_text_chrom_name", "spl_text_chrom",
@@ -444,14 +444,24 @@ class BamFile(object):
     ``wait_all`` ends the decode and tells whether the file was sorted by reference (if not, references taken early were
     incomplete)."""
 
-    def __init__(self, path, threads=0, stream=False):
+    def __init__(self, path, threads=0, stream=False, defer=False):
         self._h = ctypes.c_void_p()
-        opener = lib().spl_bam_open_stream if stream else lib().spl_bam_open
+        opener = lib().spl_bam_open_deferred if defer else (lib().spl_bam_open_stream if stream else lib().spl_bam_open)
         _check(opener(os.fsencode(path), ctypes.c_int(threads), ctypes.byref(self._h)))
+        self.on_device = None    # (defer=True: set by decode_on_device)
         self.ref_names = [lib().spl_bam_ref_name(self._h, i).decode("ascii") for i in range(lib().spl_bam_n_ref(self._h))]
         self.ref_lengths = [lib().spl_bam_ref_length(self._h, i) for i in range(len(self.ref_names))]
         self._tid = {n: i for i, n in enumerate(self.ref_names)}
         self._views = {}
+
+    def decode_on_device(self, ctx):
+        """A file opened with ``defer=True``: inflate it and extract its records on the GPU of ``ctx`` (every reference is
+        complete on return).  -> True; False when the file is not one for the device path (unsorted, CG-tag CIGARs, malformed)
+        and the host threads have been started on it instead.  Without this call the first wait starts the host decode."""
+        flag = ctypes.c_int(0)
+        _check(lib().spl_bam_decode_device(ctx._h, self._h, ctypes.byref(flag)))
+        self.on_device = bool(flag.value)
+        return self.on_device
 
     @property
     def n_records(self):

@@ -1,0 +1,91 @@
+"""BAM decode on the device (spl_bam_decode_device: BGZF inflate, CRC32, record scan and extraction as HIP kernels) against the
+host decoder on the same files: identical arrays per reference, identical record counts -- and the files the device path does
+not take (unsorted, CG-tag CIGARs, damaged) end up with the host decoder, whose results and errors are the contract."""
+import numpy as np
+import pytest
+
+from spliser_amd import native, samio
+from test_bam_decode import _random_sets, _same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    native.build()
+    with native.Context(0) as c:
+        yield c
+
+
+def _both(path, ctx, names):
+    host = native.BamFile(path, threads=4)
+    dev = native.BamFile(path, threads=4, defer=True)
+    took = dev.decode_on_device(ctx)
+    assert dev.n_records == host.n_records
+    for c in names:
+        a, b = dev.reads(c), host.reads(c)
+        _same(a, b)
+        assert dev.wait_ref(c) == host.wait_ref(c)
+    host.close()
+    dev.close()
+    return took
+
+
+@pytest.mark.parametrize("seq_mode,level", [(0, 1), (1, 1), (1, 6), (1, 0)])
+def test_device_decode_matches_host(ctx, tmp_path, seq_mode, level):
+    names, sets = _random_sets(21 + seq_mode + level, 50_000, 4)
+    path = str(tmp_path / "d.bam")
+    native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=level, threads=3, seq_mode=seq_mode)
+    assert _both(path, ctx, names) is True
+
+
+def test_python_writer_files_unplaced_and_empty_references(ctx, tmp_path):
+    import os
+    from helpers import ROOT  # noqa: F401
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names, sets = samio.read_sam(os.path.join(root, "tests", "golden", "random_b", "reads.sam"))
+    path = str(tmp_path / "x.bam")
+    samio.write_bam(path, names + ["empty_ref"], [10 ** 8] * (len(names) + 1), [(c, sets[c]) for c in names if c in sets], with_seq=True, unplaced=5)
+    assert _both(path, ctx, names + ["empty_ref"]) is True
+
+
+def test_files_the_device_path_hands_to_the_host(ctx, tmp_path):
+    names, sets = _random_sets(4, 20_000, 3)
+    # records of an earlier reference after a later one
+    path = str(tmp_path / "unsorted.bam")
+    native.write_bam(path, names, [10 ** 8] * 3, [sets[names[0]], sets[names[1]], sets[names[2]]], level=1, threads=2, seq_mode=1)
+    shuffled = str(tmp_path / "shuffled.bam")
+    samio.write_bam(shuffled, names, [10 ** 8] * 3, [(names[1], sets[names[1]]), (names[0], sets[names[0]])], with_seq=True)
+    dev = native.BamFile(shuffled, threads=2, defer=True)
+    assert dev.decode_on_device(ctx) is False
+    assert dev.wait_all() is False          # (the host decoder's verdict: not sorted by reference)
+    dev.close()
+    # CIGARs parked in CG tags
+    tagged = str(tmp_path / "cg.bam")
+    samio.write_bam(tagged, names, [10 ** 8] * 3, [(c, sets[c]) for c in names], with_seq=True, long_cigar_tag=True)
+    assert _both(tagged, ctx, names) is False
+    # a flipped byte in the middle: the device notices (inflate or CRC), the host decoder reports
+    data = bytearray(open(path, "rb").read())
+    data[len(data) // 2] ^= 0xFF
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(data))
+    dev = native.BamFile(bad, threads=2, defer=True)
+    assert dev.decode_on_device(ctx) is False
+    with pytest.raises(native.SpliserNativeError):
+        dev.wait_all()
+    dev.close()
+
+
+def test_records_larger_than_a_block_on_the_device(ctx, tmp_path):
+    pos = np.array([10, 20, 30, 40, 50, 60], np.int32)
+    ops = [[(50 << 4) | 0], [(300_000 << 4) | 0], [(20 << 4) | 0, (100 << 4) | 3, (30 << 4) | 0], [(700_000 << 4) | 0],
+           [(700_000 << 4) | 0], [(75 << 4) | 0]]
+    cig_off = np.concatenate(([0], np.cumsum([len(o) for o in ops]))).astype(np.uint32)
+    cigar = np.array([x for o in ops for x in o], np.uint32)
+    want = samio.ReadSet(pos, np.array([0, 16, 0, 0, 16, 0], np.uint16), cig_off, cigar)
+    path = str(tmp_path / "big.bam")
+    samio.write_bam(path, ["c0"], [10 ** 8], [("c0", want)], with_seq=True)
+    dev = native.BamFile(path, threads=2, defer=True)
+    dev.decode_on_device(ctx)               # (either path may take it: the result is what counts)
+    _same(dev.reads("c0"), want)
+    dev.close()

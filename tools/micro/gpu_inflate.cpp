@@ -24,7 +24,7 @@ int main(int argc, char **argv)
     fseek(f, 0, SEEK_END);
     const size_t fsize = (size_t)ftell(f);
     fseek(f, 0, SEEK_SET);
-    std::vector<uint8_t> file(fsize + 16, 0);
+    std::vector<uint8_t> file(fsize + 32, 0);
     if (fread(file.data(), 1, fsize, f) != fsize) return 1;
     fclose(f);
     std::vector<spl_zblock> blocks;
@@ -54,11 +54,11 @@ int main(int argc, char **argv)
     uint8_t *d_img = nullptr, *d_out = nullptr;
     spl_zblock *d_blocks = nullptr;
     uint32_t *d_status = nullptr;
-    CK(hipMalloc(&d_img, fsize + 16));
+    CK(hipMalloc(&d_img, fsize + 32));
     CK(hipMalloc(&d_out, uoff + 64));
     CK(hipMalloc(&d_blocks, sizeof(spl_zblock) * n));
     CK(hipMalloc(&d_status, 4 * n));
-    CK(hipMemcpy(d_img, file.data(), fsize + 16, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_img, file.data(), fsize + 32, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_blocks, blocks.data(), sizeof(spl_zblock) * n, hipMemcpyHostToDevice));
     CK(hipMemset(d_status, 0xff, 4 * n));
     for (int rep = 0; rep < 3; ++rep) {
