@@ -39,6 +39,9 @@ def build_parser():
     p.add_argument("--checkJunctions", dest="checkJunctions", default=False, action="store_true",
                    help="(this build only) also count every junction in the BAM on the GPU and write <outputPath>.junctionCheck.tsv: "
                         "BED alpha against reads in the BAM; changes no result")
+    p.add_argument("--gpuDecode", dest="gpuDecode", default=False, action="store_true",
+                   help="(this build only) inflate the BAM's BGZF blocks and extract its records on the GPU instead of on host "
+                        "threads; changes no result")
     _engine_flags(p)
     c = sub.add_parser("combine")
     c.add_argument("-S", "--samplesFile", dest="samplesFile", required=True,

@@ -369,7 +369,7 @@ struct spl_bam {
     size_t fsize = 0;
     BlockDir dir;
     int n_threads = 1;
-    bool started = false;      // a decode has been started (host worker) or its result adopted (device decoder)
+    int claim = 0;             // 0 = nobody decodes yet (deferred open), 1 = the device decoder is at it, 2 = host worker started / arrays adopted
     uint64_t header_bytes = 0; // magic, text and reference dictionary: the first record starts here in the inflated stream
     std::string path;
     ~spl_bam();
@@ -954,7 +954,7 @@ static int open_file(const char *path, int n_threads, bool start_now, spl_bam **
         if (fail.compare(0, strlen(path), path) == 0) return spl_set_error(code, "%s", fail.c_str()); // (the walk's message names the file already)
         return spl_set_error(code, "%s: %s", path, fail.c_str());
     }
-    if (start_now) { bam->started = true; bam->worker = std::thread(decode_worker, bam); }
+    if (start_now) { bam->claim = 2; bam->worker = std::thread(decode_worker, bam); }
     *out = bam;
     return SPL_OK;
 }
@@ -962,11 +962,27 @@ static int open_file(const char *path, int n_threads, bool start_now, spl_bam **
 extern "C" int spl_bam_open_stream(const char *path, int n_threads, spl_bam **out) { return open_file(path, n_threads, true, out); }
 extern "C" int spl_bam_open_deferred(const char *path, int n_threads, spl_bam **out) { return open_file(path, n_threads, false, out); }
 
+// Decode on the host's threads unless somebody is decoding already (waits on a deferred file come through here).
 int spl_bam_start_host(spl_bam *bam)
 {
     if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_start_host: null argument");
     std::lock_guard<std::mutex> lock(bam->mu);
-    if (!bam->started) { bam->started = true; bam->worker = std::thread(decode_worker, bam); }
+    if (bam->claim == 0) { bam->claim = 2; bam->worker = std::thread(decode_worker, bam); }
+    return SPL_OK;
+}
+
+// The device decoder takes the file (false: somebody else has it) / gives it to the host threads after all.
+bool spl_bam_claim_for_device(spl_bam *bam)
+{
+    std::lock_guard<std::mutex> lock(bam->mu);
+    if (bam->claim != 0) return false;
+    bam->claim = 1;
+    return true;
+}
+int spl_bam_device_gives_up(spl_bam *bam)
+{
+    std::lock_guard<std::mutex> lock(bam->mu);
+    if (bam->claim == 1) { bam->claim = 2; bam->worker = std::thread(decode_worker, bam); }
     return SPL_OK;
 }
 
@@ -995,8 +1011,8 @@ int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off,
                   const int64_t *ref_max_end, int64_t n_records_total)
 {
     std::lock_guard<std::mutex> lock(bam->mu);
-    if (bam->started) return spl_set_error(SPL_ERR_ARG, "spl_bam_adopt: the host decode of this file is running already");
-    bam->started = true;
+    if (bam->claim != 1) return spl_set_error(SPL_ERR_ARG, "spl_bam_adopt: the file is not claimed by the device decoder");
+    bam->claim = 2;
     bam->slabs.push_back(pos); bam->slabs.push_back(flag); bam->slabs.push_back(cig_off); bam->slabs.push_back(cigar);
     for (int t = 0; t < bam->n_refs; ++t) {
         if (ref_n[t] <= 0) continue;

@@ -23,6 +23,8 @@ int spl_bam_thread_count(const spl_bam *bam);
 // free()); reference t has records [ref_first[t], ref_first[t] + ref_n[t]), cig_off holds n_total + 1 offsets into cigar.
 int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off, uint32_t *cigar, const int64_t *ref_first, const int64_t *ref_n,
                   const int64_t *ref_max_end, int64_t n_records_total);
-int spl_bam_start_host(spl_bam *bam);                      // decode on the host's threads after all (idempotent)
+int spl_bam_start_host(spl_bam *bam);                      // decode on the host's threads unless somebody decodes already
+bool spl_bam_claim_for_device(spl_bam *bam);               // the device decoder takes the file (false: it is taken)
+int spl_bam_device_gives_up(spl_bam *bam);                 // ... and hands it to the host threads after all
 
 #endif

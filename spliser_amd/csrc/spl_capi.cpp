@@ -824,10 +824,23 @@ void copy_slice(size_t k, void *arg)
 }
 } // namespace
 
+static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out);
+
 extern "C" int spl_bam_decode_device(spl_ctx *c, spl_bam *bam, int *on_device_out)
 {
     if (!c || !bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_decode_device: null argument");
     if (on_device_out) *on_device_out = 0;
+    if (!spl_bam_claim_for_device(bam)) return SPL_OK; // (being decoded already, by whoever asked first: nothing to do here)
+    const int rc = decode_device_claimed(c, bam, on_device_out);
+    // whatever went wrong on the way (device memory, a HIP error): the file must not be left without a decoder -- the host
+    // threads take it (a no-op when the arrays were adopted or the host was started already); spl_last_error keeps the reason
+    (void)spl_bam_device_gives_up(bam);
+    if (rc != SPL_OK && getenv("SPL_BAM_TIMING")) fprintf(stderr, "[spl_bam_decode_device] failed (%s): host decoder instead\n", spl_last_error());
+    return SPL_OK;
+}
+
+static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
+{
     HIP_TRY(hipSetDevice(c->device));
     const bool timing = getenv("SPL_BAM_TIMING") != nullptr;
     auto host_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -836,7 +849,7 @@ extern "C" int spl_bam_decode_device(spl_ctx *c, spl_bam *bam, int *on_device_ou
     auto stamp = [&](const char *what) { if (timing) { const double t = host_now(); fprintf(stderr, "[spl_bam_decode_device] %-34s %.4f s\n", what, t - t_mark); t_mark = t; } };
     auto to_host = [&](const char *why) { // not a file for this path: the host threads take it (and find the words for what is wrong with it)
         if (timing) fprintf(stderr, "[spl_bam_decode_device] handing the file to the host decoder: %s\n", why);
-        return spl_bam_start_host(bam);
+        return spl_bam_device_gives_up(bam);
     };
     int rc = spl_bam_walk_all(bam);
     if (rc) return to_host("block directory");

@@ -33,13 +33,14 @@ class _SamSource(object):
         return self._sets.get(chrom)
 
 
-def open_alignments(path, threads=0, stream=False):
+def open_alignments(path, threads=0, stream=False, defer=False):
     """BAM (BGZF) through the native decoder; plain SAM text through the Python reader.  ``stream=True``: the BAM decoder
-    returns after the header and decodes in the background (``native.BamFile``)."""
+    returns after the header and decodes in the background (``native.BamFile``); ``defer=True``: nothing is decoded until
+    somebody asks (``BamFile.decode_on_device``, or the first wait: host threads)."""
     with open(path, "rb") as fh:
         magic = fh.read(4)
     if magic[:2] == b"\x1f\x8b":
-        return native.BamFile(path, threads=threads, stream=stream)
+        return native.BamFile(path, threads=threads, stream=stream, defer=defer)
     if magic[:1] == b"@" or b"\t" in open(path, "rb").readline():
         return _SamSource(path)
     raise native.SpliserNativeError(-5, "%s is neither BGZF/BAM nor SAM text" % path)
@@ -143,6 +144,10 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
 
     def _count_shards(device, shards):
         with native.Context(device) as ctx:
+            if is_bam and getattr(source, "on_device", 0) is None:
+                # a file opened for the device decoder: whichever device thread gets here first inflates it and extracts its
+                # records on its GPU (the others find it taken and wait for the references as usual)
+                source.decode_on_device(ctx)
             for sh in shards:
                 with ctx.upload_sites(sh.sites) as ds:
                     for chrom, off, limit, (r0, r1) in zip(sh.chroms, sh.offsets, sh.limits, sh.site_rows):
@@ -257,18 +262,23 @@ def write_tsv(output_path, table, results, is_beta2_cryptic):
 
 
 def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0, annotationFile=None, aType="gene",
-            isStranded=False, strandedType=None, isbeta2Cryptic=False, devices=(0,), threads=0, log=_log, checkJunctions=False):
+            isStranded=False, strandedType=None, isbeta2Cryptic=False, devices=(0,), threads=0, log=_log, checkJunctions=False,
+            gpuDecode=False):
     """SpliSER_v0_1_8.py:695-720, keyword-compatible with the reference's argparse dests.
 
     ``checkJunctions`` (this build only; changes no result): also derive every chromosome's junction table from the reads on
     the GPU and write ``<outputPath>.junctionCheck.tsv`` -- BED alpha against reads in the BAM per junction -- with a warning
-    for every junction the BED file gives MORE reads than the BAM holds (the two files do not belong together)."""
+    for every junction the BED file gives MORE reads than the BAM holds (the two files do not belong together).
+
+    ``gpuDecode`` (this build only; changes no result): the BAM goes to the GPU as it is -- BGZF inflate, CRC32 and the
+    extraction of POS / FLAG / CIGAR happen there (``spl_bam_decode_device``); files that path does not take (unsorted, CG-tag
+    CIGARs, damaged) are decoded by the host threads as without the option."""
     timings = {}
     t0 = time.perf_counter()
     # The alignment file does not depend on Steps 0-2: it is decoded on native threads while the site table is built here, and
     # goes on decoding while Step 3 counts the chromosomes that are complete.  An unreadable file is an error here already
     # (block directory and header are read by the opening call).
-    source = open_alignments(inBAM, threads=threads, stream=True)
+    source = open_alignments(inBAM, threads=threads, stream=True, defer=bool(gpuDecode))
     try:
         t_open = time.perf_counter()
         table = _site_table(inBed, qGene, qChrom, maxIntronSize, annotationFile, aType, isStranded, strandedType, log)

@@ -41,7 +41,6 @@ def test_device_decode_matches_host(ctx, tmp_path, seq_mode, level):
 
 def test_python_writer_files_unplaced_and_empty_references(ctx, tmp_path):
     import os
-    from helpers import ROOT  # noqa: F401
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     names, sets = samio.read_sam(os.path.join(root, "tests", "golden", "random_b", "reads.sam"))
     path = str(tmp_path / "x.bam")
