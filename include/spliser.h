@@ -208,6 +208,10 @@ int spl_bam_open_stream(const char *path, int n_threads, spl_bam **out);
  * error reporting are the host decoder's either way.  Waiting on a deferred file nobody decoded starts the host decode. */
 int spl_bam_open_deferred(const char *path, int n_threads, spl_bam **out);
 int spl_bam_decode_device(spl_ctx *ctx, spl_bam *bam, int *on_device_out);
+/* For a caller that will call spl_bam_decode_device from another thread in a moment while others may already wait for
+ * references: the file is marked as taken by the device decoder now, so that those waits wait instead of starting the host
+ * decode.  The promise must be kept (spl_bam_decode_device), or the waits never end. */
+int spl_bam_reserve_device(spl_bam *bam);
 int spl_bam_wait_ref(spl_bam *bam, int tid, int64_t *n_reads_out, int64_t *max_end_out);
 int spl_bam_wait_all(spl_bam *bam, int *sorted_out);
 void spl_bam_close(spl_bam *bam);

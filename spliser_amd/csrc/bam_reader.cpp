@@ -369,6 +369,7 @@ struct spl_bam {
     size_t fsize = 0;
     BlockDir dir;
     int n_threads = 1;
+    bool reserved = false;     // claim == 1 on behalf of a spl_bam_decode_device call that is still to come
     int claim = 0;             // 0 = nobody decodes yet (deferred open), 1 = the device decoder is at it, 2 = host worker started / arrays adopted
     uint64_t header_bytes = 0; // magic, text and reference dictionary: the first record starts here in the inflated stream
     std::string path;
@@ -975,9 +976,20 @@ int spl_bam_start_host(spl_bam *bam)
 bool spl_bam_claim_for_device(spl_bam *bam)
 {
     std::lock_guard<std::mutex> lock(bam->mu);
+    if (bam->claim == 1 && bam->reserved) { bam->reserved = false; return true; } // (reserved earlier for exactly this call)
     if (bam->claim != 0) return false;
     bam->claim = 1;
     return true;
+}
+
+extern "C" int spl_bam_reserve_device(spl_bam *bam)
+{
+    if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_reserve_device: null argument");
+    std::lock_guard<std::mutex> lock(bam->mu);
+    if (bam->claim != 0) return spl_set_error(SPL_ERR_ARG, "spl_bam_reserve_device: the file is being decoded already");
+    bam->claim = 1;
+    bam->reserved = true;
+    return SPL_OK;
 }
 int spl_bam_device_gives_up(spl_bam *bam)
 {

@@ -879,7 +879,11 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
     HIP_TRY(d_status.get(4 * n_blocks));
     HIP_TRY(d_scan.get(sizeof(spl_bscan) * n_blocks));
     HIP_TRY(hipMemsetAsync(d_image.as<char>() + fsize, 0, 64, c->copy));
-    // the file image: page cache -> staging buffer (all packing threads) -> device, piece by piece
+    HIP_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), sizeof(spl_zblock) * n_blocks, hipMemcpyHostToDevice, c->copy));
+    HIP_TRY(hipMemsetAsync(d_status.p, 0xff, 4 * n_blocks, c->copy));
+    // the file image: page cache -> staging buffer (all packing threads) -> device, piece by piece; the blocks that are whole on
+    // the device after a piece are inflated behind it on the same stream, while the host fills the next buffer
+    size_t next_block = 0;
     for (size_t off = 0; off < fsize;) {
         spl_ctx::Stage &st = c->stage[c->stage_next];
         c->stage_next = (c->stage_next + 1) % c->stage.size();
@@ -893,12 +897,15 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
         HIP_TRY(hipEventRecord(st.done, c->copy));
         st.busy = true;
         off += n;
+        size_t b1 = next_block; // (the bit reader looks a few words ahead: a block counts as whole with 16 bytes behind it, or at the end of the file)
+        while (b1 < n_blocks && (blocks[b1].in + blocks[b1].in_len + 16 <= off || off == fsize)) ++b1;
+        if (b1 > next_block) {
+            HIP_TRY((hipError_t)spl_dev_launch_inflate(d_image.as<uint8_t>(), d_blocks.as<spl_zblock>() + next_block, (uint32_t)(b1 - next_block), d_stream.as<uint8_t>(),
+                                                       d_status.as<uint32_t>() + next_block, c->copy));
+            next_block = b1;
+        }
     }
-    HIP_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), sizeof(spl_zblock) * n_blocks, hipMemcpyHostToDevice, c->copy));
-    HIP_TRY(hipMemsetAsync(d_status.p, 0xff, 4 * n_blocks, c->copy));
-    HIP_TRY(hipStreamSynchronize(c->copy));
-    stamp("file image to the device");
-    HIP_TRY((hipError_t)spl_dev_launch_inflate(d_image.as<uint8_t>(), d_blocks.as<spl_zblock>(), (uint32_t)n_blocks, d_stream.as<uint8_t>(), d_status.as<uint32_t>(), c->copy));
+    if (timing) { HIP_TRY(hipStreamSynchronize(c->copy)); stamp("file image to the device + inflate"); }
     HIP_TRY((hipError_t)spl_dev_launch_crc32(d_stream.as<uint8_t>(), d_blocks.as<spl_zblock>(), (uint32_t)n_blocks, d_status.as<uint32_t>(), c->copy));
     HIP_TRY((hipError_t)spl_dev_launch_bam_scan(d_stream.as<uint8_t>(), stream_len, spl_bam_header_end(bam), n_ref, d_blocks.as<spl_zblock>(), (uint32_t)n_blocks,
                                                 d_scan.as<spl_bscan>(), c->copy));
@@ -907,7 +914,7 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
     HIP_TRY(hipMemcpyAsync(status.data(), d_status.p, 4 * n_blocks, hipMemcpyDeviceToHost, c->copy));
     HIP_TRY(hipMemcpyAsync(scan.data(), d_scan.p, sizeof(spl_bscan) * n_blocks, hipMemcpyDeviceToHost, c->copy));
     HIP_TRY(hipStreamSynchronize(c->copy));
-    stamp("inflate + CRC32 + record scan");
+    stamp("CRC32 + record scan");
     for (size_t i = 0; i < n_blocks; ++i)
         if (status[i] != SPL_Z_OK) return to_host("a block did not inflate (or its CRC32 is wrong)");
     // the chain of boundaries, from the end of the BAM header to the end of the stream
@@ -967,6 +974,7 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
                                                    d_recoff.as<uint64_t>(), d_opoff.as<uint64_t>(), d_pos.as<int32_t>(), d_flag.as<uint16_t>(), d_cigoff.as<uint32_t>(),
                                                    d_cigar.as<uint32_t>(), d_tid.as<int32_t>(), d_maxend.as<unsigned long long>(), c->copy));
     HIP_TRY((hipError_t)spl_dev_launch_bam_bounds(d_tid.as<int32_t>(), n_rec, d_bounds.as<uint64_t>(), d_nbounds.as<uint32_t>(), cap, c->copy));
+    if (timing) { HIP_TRY(hipStreamSynchronize(c->copy)); stamp("extraction kernels"); }
     // results into page-locked host arrays (registered for the copy, released again: the file keeps them as ordinary memory)
     auto host_array = [&](size_t bytes) -> void * {
         const size_t huge = 2u << 20, size = (std::max<size_t>(bytes, 64) + huge - 1) / huge * huge;
@@ -985,8 +993,9 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
     };
     if (!h_pos || !h_flag || !h_cigoff || !h_cigar) { release(true); return spl_set_error(SPL_ERR_NOMEM, "out of host memory for the decoded reads"); }
     for (Pin &pn : pins) {
-        if (pn.n >= (1u << 20)) { memset(pn.p, 0, pn.n); pn.on = hipHostRegister(pn.p, pn.n, hipHostRegisterDefault) == hipSuccess; } // (touched, then locked)
+        if (pn.n >= (1u << 20)) pn.on = hipHostRegister(pn.p, pn.n, hipHostRegisterDefault) == hipSuccess; // (locking faults the pages in)
     }
+    stamp("host arrays allocated and locked");
     std::vector<unsigned long long> maxend((size_t)std::max(n_ref, 1));
     std::vector<uint64_t> bounds(2 * (size_t)cap);
     uint32_t n_bounds = 0;
@@ -1001,7 +1010,7 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
     if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
     release(false);
     if (q != hipSuccess) { release(true); return spl_set_error(SPL_ERR_HIP, "BAM decode on the device: %s", hipGetErrorString(q)); }
-    stamp("extraction + results to the host");
+    stamp("results to the host");
     if (n_bounds > cap) { release(true); return to_host("not sorted by reference"); }
     std::vector<std::pair<uint64_t, int32_t>> runs;
     for (uint32_t k = 0; k < n_bounds; ++k) runs.emplace_back(bounds[2 * k], (int32_t)(uint32_t)bounds[2 * k + 1]);

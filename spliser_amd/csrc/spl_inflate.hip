@@ -39,12 +39,26 @@ struct Counts {
     uint32_t w[8]; // count[len] = (w[len >> 1] >> (16 * (len & 1))) & 0xffff
 };
 
-// The symbols of a lane's tables live in LDS, entry-major (entry e of lane l at [e * 64 + l]): a look-up is one ds_read instead
-// of a trip to the lane's scratch -- the look-up sits on the dependent chain of every symbol.
+// The symbols of a lane's tables live in LDS, entry-major (entry e of lane l at [e * 64 + l]): a look-up is a ds_read instead
+// of a trip to the lane's scratch -- the look-up sits on the dependent chain of every symbol.  A byte per symbol plus, for the
+// literal/length table, a bit per entry for "256 and above": 354 bytes per lane, seven workgroups in a CU's 160 KB.
 struct LdsSyms {
-    uint16_t *base; // &lds[lane]
-    __device__ __forceinline__ uint16_t get(int e) const { return base[e * 64]; }
-    __device__ __forceinline__ void set(int e, uint16_t v) const { base[e * 64] = v; }
+    uint8_t *lo;   // &bytes[lane]
+    uint32_t *hi;  // &bits[lane] (word w of lane l at [w * 64 + l]) or nullptr for tables whose symbols fit a byte
+    __device__ __forceinline__ int get(int e) const
+    {
+        int v = lo[e * 64];
+        if (hi) v |= (int)((hi[(e >> 5) * 64] >> (e & 31)) & 1u) << 8;
+        return v;
+    }
+    __device__ __forceinline__ void set(int e, int v) const
+    {
+        lo[e * 64] = (uint8_t)v;
+        if (hi) {
+            uint32_t &w = hi[(e >> 5) * 64];
+            w = (w & ~(1u << (e & 31))) | ((uint32_t)(v >> 8) << (e & 31));
+        }
+    }
 };
 
 __device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Counts &c, const LdsSyms &symbol)
@@ -66,7 +80,7 @@ __device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Count
 #pragma unroll
     for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
     for (int s = 0; s < n; ++s)
-        if (lengths[s]) symbol.set(offs[lengths[s]]++, (uint16_t)s);
+        if (lengths[s]) symbol.set(offs[lengths[s]]++, s);
 #pragma unroll
     for (int k = 0; k < 8; ++k) c.w[k] = (uint32_t)count[2 * k] | ((uint32_t)count[2 * k + 1] << 16);
     c.w[0] &= 0xffff0000u; // (codes of length 0 do not exist)
@@ -86,7 +100,7 @@ __device__ __forceinline__ int decode_symbol(BitReader &br, const Counts &c, con
         const int count = (int)((c.w[len >> 1] >> (16 * (len & 1))) & 0xffffu);
         if (code - count < first) {
             br.drop((uint32_t)len);
-            return (int)symbol.get(index + (code - first));
+            return symbol.get(index + (code - first));
         }
         index += count;
         first += count;
@@ -109,13 +123,14 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
     const uint32_t b = blockIdx.x * 64u + threadIdx.x;
     // lane-interleaved symbol tables: literal/length (288), distance (32); the code-length code's 19 symbols borrow the
     // distance table's place while the lengths are being read
-    __shared__ uint16_t s_sym[(288 + 30) * 64]; // (4 workgroups of these in a CU's 160 KB)
+    __shared__ uint8_t s_sym[(288 + 32) * 64];
+    __shared__ uint32_t s_hi[9 * 64];
     __shared__ uint16_t s_base[64]; // length and distance bases / extra bits: {len_base[29], dist_base[30]} packed below
     __shared__ uint8_t s_extra[64];
     if (threadIdx.x < 29) { s_base[threadIdx.x] = k_len_base[threadIdx.x]; s_extra[threadIdx.x] = k_len_extra[threadIdx.x]; }
     if (threadIdx.x >= 32 && threadIdx.x < 62) { s_base[threadIdx.x] = k_dist_base[threadIdx.x - 32]; s_extra[threadIdx.x] = k_dist_extra[threadIdx.x - 32]; }
     __syncthreads();
-    const LdsSyms lsym{s_sym + threadIdx.x}, dsym{s_sym + 288 * 64 + threadIdx.x};
+    const LdsSyms lsym{s_sym + threadIdx.x, s_hi + threadIdx.x}, dsym{s_sym + 288 * 64 + threadIdx.x, nullptr};
     if (b >= n_blocks) return;
     const spl_zblock zb = blocks[b];
     uint8_t *const out = out_all + zb.out;
@@ -408,6 +423,8 @@ __global__ __launch_bounds__(64) void spl_bam_extract_kernel(const uint8_t *stre
     if (sc.n_placed == 0) return;
     const uint64_t u1 = blocks[b].out + blocks[b].out_len;
     uint64_t at = sc.start, i = rec_off[b], o = op_off[b];
+    int32_t run_tid = -1;     // the reference of the records seen last and the largest end among them: one atomic per run
+    long long run_end = 0;    // (one per record was 20 M atomics on five words: most of the kernel's time)
     while (at < u1) {
         const uint32_t bs = ld32(stream + at);
         const uint8_t *r = stream + at + 4;
@@ -428,11 +445,18 @@ __global__ __launch_bounds__(64) void spl_bam_extract_kernel(const uint8_t *stre
             tid_out[i] = tid;
             cig_off[i + 1] = (uint32_t)o;
             const long long e = (long long)pos0 + 1 + (ref_len > 0 ? ref_len : 1) - 1;
-            atomicMax(&ref_max_end[tid], (unsigned long long)e);
+            if (tid != run_tid) {
+                if (run_tid >= 0) atomicMax(&ref_max_end[run_tid], (unsigned long long)run_end);
+                run_tid = tid;
+                run_end = e;
+            } else if (e > run_end) {
+                run_end = e;
+            }
             ++i;
         }
         at += 4ull + bs;
     }
+    if (run_tid >= 0) atomicMax(&ref_max_end[run_tid], (unsigned long long)run_end);
 }
 
 __global__ __launch_bounds__(256) void spl_bam_bounds_kernel(const int32_t *tid, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap)

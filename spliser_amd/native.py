@@ -49,7 +49,7 @@ EXPORTS = [
     "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
-    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
+    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
     "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append", "spl_fmt_fixed",
     "spl_bed_open", "spl_gff_open", "spl_text_close", "spl_text_rows", "spl_text_n_chrom", "spl_text_chrom_name", "spl_text_chrom",
@@ -454,6 +454,24 @@ class BamFile(object):
         self._tid = {n: i for i, n in enumerate(self.ref_names)}
         self._views = {}
 
+    def decode_on_device_async(self, device=0):
+        """``decode_on_device`` on a thread and a context of its own, started now: the caller goes on (Steps 0-2), anybody who
+        waits for a reference meanwhile waits for this decode.  -> the thread (join it before closing the file)."""
+        import threading
+        _check(lib().spl_bam_reserve_device(self._h))
+        self.on_device = False
+
+        def run():
+            try:
+                with Context(device) as ctx:
+                    self.decode_on_device(ctx)
+            except BaseException as exc:   # (the C side never leaves the file without a decoder; keep the reason)
+                self.device_error = exc
+        t = threading.Thread(target=run)
+        t.start()
+        self._device_thread = t
+        return t
+
     def decode_on_device(self, ctx):
         """A file opened with ``defer=True``: inflate it and extract its records on the GPU of ``ctx`` (every reference is
         complete on return).  -> True; False when the file is not one for the device path (unsorted, CG-tag CIGARs, malformed)
@@ -514,6 +532,10 @@ class BamFile(object):
 
     def close(self):
         """Closes the native decoder -- unless views of its arrays are still alive: then their owner closes it."""
+        t = getattr(self, "_device_thread", None)
+        if t is not None:
+            t.join()                 # (the device decoder works on the native object: not under its feet)
+            self._device_thread = None
         h, self._h = self._h, ctypes.c_void_p()
         views, self._views = self._views, {}
         if h and not views:

@@ -144,10 +144,6 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
 
     def _count_shards(device, shards):
         with native.Context(device) as ctx:
-            if is_bam and getattr(source, "on_device", 0) is None:
-                # a file opened for the device decoder: whichever device thread gets here first inflates it and extracts its
-                # records on its GPU (the others find it taken and wait for the references as usual)
-                source.decode_on_device(ctx)
             for sh in shards:
                 with ctx.upload_sites(sh.sites) as ds:
                     for chrom, off, limit, (r0, r1) in zip(sh.chroms, sh.offsets, sh.limits, sh.site_rows):
@@ -279,6 +275,8 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
     # goes on decoding while Step 3 counts the chromosomes that are complete.  An unreadable file is an error here already
     # (block directory and header are read by the opening call).
     source = open_alignments(inBAM, threads=threads, stream=True, defer=bool(gpuDecode))
+    if gpuDecode and isinstance(source, native.BamFile):
+        source.decode_on_device_async(devices[0])     # (runs beside Steps 0-2, like the host decode would)
     try:
         t_open = time.perf_counter()
         table = _site_table(inBed, qGene, qChrom, maxIntronSize, annotationFile, aType, isStranded, strandedType, log)
