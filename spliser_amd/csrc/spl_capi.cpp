@@ -809,10 +809,13 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
 // sums on the host, extraction of POS / FLAG / CIGAR into file-wide arrays, and those come back into page-locked host arrays
 // that the spl_bam adopts, one part per reference.
 namespace {
+// Device memory of the decode.  (Stream-ordered allocation -- hipMallocAsync / hipFreeAsync on the copy stream -- was tried so
+// that freeing 18 GB would not wait for the device: the frees turned out to cost 20 ms, and with the pool the decode became
+// flaky on this stack -- stale tids in one run of four -- so: plain hipMalloc / hipFree.)
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t get(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    hipError_t get(size_t bytes, hipStream_t) { return hipMalloc(&p, bytes ? bytes : 16); }
     template <class T> T *as() const { return (T *)p; }
 };
 struct CopyJob { char *dst; const char *src; size_t n, per; };
@@ -851,39 +854,24 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
         if (timing) fprintf(stderr, "[spl_bam_decode_device] handing the file to the host decoder: %s\n", why);
         return spl_bam_device_gives_up(bam);
     };
-    int rc = spl_bam_walk_all(bam);
-    if (rc) return to_host("block directory");
-    const size_t n_blocks = spl_bam_block_count(bam);
     size_t fsize = 0;
     const uint8_t *image = spl_bam_image(bam, &fsize);
     const int n_ref = spl_bam_n_ref(bam);
-    if (n_blocks == 0 || n_blocks > 0xfffffff0ull) return to_host("no blocks");
-    std::vector<spl_zblock> blocks(n_blocks);
-    uint64_t stream_len = 0;
-    for (size_t i = 0; i < n_blocks; ++i) {
-        spl_bam_block_info bi;
-        spl_bam_block_get(bam, i, &bi);
-        blocks[i].in = bi.data_off; blocks[i].out = bi.uoff; blocks[i].in_len = bi.data_len; blocks[i].out_len = bi.isize; blocks[i].crc = bi.crc; blocks[i].pad = 0;
-        stream_len = bi.uoff + bi.isize;
-    }
-    stamp("block directory");
+    int rc = ensure_stage(c);
+    if (rc) return rc;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    if ((double)fsize + (double)stream_len * 1.2 + (double)(1u << 30) > (double)free_b) return to_host("not enough device memory for the inflated stream");
-    rc = ensure_stage(c);
-    if (rc) return rc;
+    if ((double)fsize * 8.0 + (double)(1u << 30) > (double)free_b) return to_host("not enough device memory");
+    // the block directory (one thread's walk over the file's block headers) beside the upload of the file image
+    int walk_rc = SPL_OK;
+    std::thread walker([&]() { walk_rc = spl_bam_walk_all(bam); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{walker};
     DevBuf d_image, d_stream, d_blocks, d_status, d_scan;
-    HIP_TRY(d_image.get(fsize + 64));
-    HIP_TRY(d_stream.get(stream_len + 64));
-    HIP_TRY(d_blocks.get(sizeof(spl_zblock) * n_blocks));
-    HIP_TRY(d_status.get(4 * n_blocks));
-    HIP_TRY(d_scan.get(sizeof(spl_bscan) * n_blocks));
+    HIP_TRY(d_image.get(fsize + 64, c->copy));
     HIP_TRY(hipMemsetAsync(d_image.as<char>() + fsize, 0, 64, c->copy));
-    HIP_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), sizeof(spl_zblock) * n_blocks, hipMemcpyHostToDevice, c->copy));
-    HIP_TRY(hipMemsetAsync(d_status.p, 0xff, 4 * n_blocks, c->copy));
-    // the file image: page cache -> staging buffer (all packing threads) -> device, piece by piece; the blocks that are whole on
-    // the device after a piece are inflated behind it on the same stream, while the host fills the next buffer
-    size_t next_block = 0;
+    // the file image: page cache -> staging buffer (all packing threads) -> device, piece by piece.  (Inflating the blocks of a
+    // piece right behind it was tried: a launch of this kernel takes as long as ONE lane needs for its block whatever the
+    // number of blocks, and 44 such launches in a row took 4 s where one launch over everything takes 0.15.)
     for (size_t off = 0; off < fsize;) {
         spl_ctx::Stage &st = c->stage[c->stage_next];
         c->stage_next = (c->stage_next + 1) % c->stage.size();
@@ -897,15 +885,30 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
         HIP_TRY(hipEventRecord(st.done, c->copy));
         st.busy = true;
         off += n;
-        size_t b1 = next_block; // (the bit reader looks a few words ahead: a block counts as whole with 16 bytes behind it, or at the end of the file)
-        while (b1 < n_blocks && (blocks[b1].in + blocks[b1].in_len + 16 <= off || off == fsize)) ++b1;
-        if (b1 > next_block) {
-            HIP_TRY((hipError_t)spl_dev_launch_inflate(d_image.as<uint8_t>(), d_blocks.as<spl_zblock>() + next_block, (uint32_t)(b1 - next_block), d_stream.as<uint8_t>(),
-                                                       d_status.as<uint32_t>() + next_block, c->copy));
-            next_block = b1;
-        }
     }
-    if (timing) { HIP_TRY(hipStreamSynchronize(c->copy)); stamp("file image to the device + inflate"); }
+    walker.join();
+    if (walk_rc) return to_host("block directory");
+    const size_t n_blocks = spl_bam_block_count(bam);
+    if (n_blocks == 0 || n_blocks > 0xfffffff0ull) return to_host("no blocks");
+    std::vector<spl_zblock> blocks(n_blocks);
+    uint64_t stream_len = 0;
+    for (size_t i = 0; i < n_blocks; ++i) {
+        spl_bam_block_info bi;
+        spl_bam_block_get(bam, i, &bi);
+        blocks[i].in = bi.data_off; blocks[i].out = bi.uoff; blocks[i].in_len = bi.data_len; blocks[i].out_len = bi.isize; blocks[i].crc = bi.crc; blocks[i].pad = 0;
+        stream_len = bi.uoff + bi.isize;
+    }
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if ((double)stream_len * 1.2 + (double)(1u << 30) > (double)free_b) return to_host("not enough device memory for the inflated stream");
+    HIP_TRY(d_stream.get(stream_len + 64, c->copy));
+    HIP_TRY(d_blocks.get(sizeof(spl_zblock) * n_blocks, c->copy));
+    HIP_TRY(d_status.get(4 * n_blocks, c->copy));
+    HIP_TRY(d_scan.get(sizeof(spl_bscan) * n_blocks, c->copy));
+    HIP_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), sizeof(spl_zblock) * n_blocks, hipMemcpyHostToDevice, c->copy));
+    HIP_TRY(hipMemsetAsync(d_status.p, 0xff, 4 * n_blocks, c->copy));
+    if (timing) { HIP_TRY(hipStreamSynchronize(c->copy)); stamp("file image to the device (block directory beside it)"); }
+    HIP_TRY((hipError_t)spl_dev_launch_inflate(d_image.as<uint8_t>(), d_blocks.as<spl_zblock>(), (uint32_t)n_blocks, d_stream.as<uint8_t>(), d_status.as<uint32_t>(), c->copy));
+    if (timing) { HIP_TRY(hipStreamSynchronize(c->copy)); stamp("inflate"); }
     HIP_TRY((hipError_t)spl_dev_launch_crc32(d_stream.as<uint8_t>(), d_blocks.as<spl_zblock>(), (uint32_t)n_blocks, d_status.as<uint32_t>(), c->copy));
     HIP_TRY((hipError_t)spl_dev_launch_bam_scan(d_stream.as<uint8_t>(), stream_len, spl_bam_header_end(bam), n_ref, d_blocks.as<spl_zblock>(), (uint32_t)n_blocks,
                                                 d_scan.as<spl_bscan>(), c->copy));
@@ -953,17 +956,17 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
     if (n_ops > 0xfffffff0ull) return to_host("more than 2^32 CIGAR operations");
     stamp("boundary chain + prefix sums");
     DevBuf d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
-    HIP_TRY(d_recoff.get(8 * (n_blocks + 1)));
-    HIP_TRY(d_opoff.get(8 * (n_blocks + 1)));
-    HIP_TRY(d_pos.get(4 * n_rec));
-    HIP_TRY(d_flag.get(2 * n_rec));
-    HIP_TRY(d_cigoff.get(4 * (n_rec + 1)));
-    HIP_TRY(d_cigar.get(4 * n_ops));
-    HIP_TRY(d_tid.get(4 * n_rec));
-    HIP_TRY(d_maxend.get(8 * (size_t)std::max(n_ref, 1)));
+    HIP_TRY(d_recoff.get(8 * (n_blocks + 1), c->copy));
+    HIP_TRY(d_opoff.get(8 * (n_blocks + 1), c->copy));
+    HIP_TRY(d_pos.get(4 * n_rec, c->copy));
+    HIP_TRY(d_flag.get(2 * n_rec, c->copy));
+    HIP_TRY(d_cigoff.get(4 * (n_rec + 1), c->copy));
+    HIP_TRY(d_cigar.get(4 * n_ops, c->copy));
+    HIP_TRY(d_tid.get(4 * n_rec, c->copy));
+    HIP_TRY(d_maxend.get(8 * (size_t)std::max(n_ref, 1), c->copy));
     const uint32_t cap = (uint32_t)std::max(n_ref, 1) * 4u + 64u;
-    HIP_TRY(d_bounds.get(16 * (size_t)cap));
-    HIP_TRY(d_nbounds.get(4));
+    HIP_TRY(d_bounds.get(16 * (size_t)cap, c->copy));
+    HIP_TRY(d_nbounds.get(4, c->copy));
     HIP_TRY(hipMemcpyAsync(d_recoff.p, rec_off.data(), 8 * (n_blocks + 1), hipMemcpyHostToDevice, c->copy));
     HIP_TRY(hipMemcpyAsync(d_opoff.p, op_off.data(), 8 * (n_blocks + 1), hipMemcpyHostToDevice, c->copy));
     HIP_TRY(hipMemcpyAsync(d_scan.p, scan.data(), sizeof(spl_bscan) * n_blocks, hipMemcpyHostToDevice, c->copy));

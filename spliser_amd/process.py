@@ -143,9 +143,36 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                 errors.append(exc)
 
     def _count_shards(device, shards):
+        whole = False
+        if is_bam and getattr(source, "_device_thread", None) is not None and on_junctions is None:
+            # the device decoder (process --gpuDecode) delivers every reference at once: nothing to stream chromosome by
+            # chromosome, so all chromosomes of a shard go up as ONE read set and are counted in one pass
+            source._device_thread.join()
+            whole = bool(source.on_device)
         with native.Context(device) as ctx:
             for sh in shards:
                 with ctx.upload_sites(sh.sites) as ds:
+                    if whole:
+                        with ctx.begin_reads() as dr:
+                            for chrom, off, limit in zip(sh.chroms, sh.offsets, sh.limits):
+                                if items[chrom][2]:
+                                    _, max_end = source.wait_ref(chrom)
+                                    if max_end > limit:
+                                        raise _Replan()
+                                    dr.add_bam(source, chrom, off)
+                            dr.finish()
+                            ctx.count_launch(ds, dr, stranded, combine_mode)
+                            ctx.sse_launch(ds, is_beta2_cryptic)
+                            beta1, b2r, _ = ds.counters()
+                            b2s, b2c, b2w, sse = ds.sse_results()
+                        for chrom, (r0, r1) in zip(sh.chroms, sh.site_rows):
+                            res = dict(beta1=beta1[r0:r1].copy(), beta2_simple=b2s[r0:r1].copy(), beta2_cryptic=b2c[r0:r1].copy(),
+                                       beta2_weighted=b2w[r0:r1].copy(), sse=sse[r0:r1].copy(), beta2s_reads=b2r[r0:r1].copy())
+                            with lock:
+                                out[chrom] = (items[chrom][0], res)
+                            if on_result is not None:
+                                on_result(chrom, items[chrom][0], res)
+                        continue
                     for chrom, off, limit, (r0, r1) in zip(sh.chroms, sh.offsets, sh.limits, sh.site_rows):
                         with ctx.begin_reads() as dr:
                             if is_bam and items[chrom][2]:

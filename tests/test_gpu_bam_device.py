@@ -17,13 +17,16 @@ def ctx():
         yield c
 
 
-def _both(path, ctx, names):
+def _both(path, ctx, names, truth=None):
     host = native.BamFile(path, threads=4)
     dev = native.BamFile(path, threads=4, defer=True)
     took = dev.decode_on_device(ctx)
     assert dev.n_records == host.n_records
     for c in names:
         a, b = dev.reads(c), host.reads(c)
+        if truth is not None:
+            _same(b, truth[c])      # (the host decoder against what was written ...)
+            _same(a, truth[c])      # (... and the device decoder)
         _same(a, b)
         assert dev.wait_ref(c) == host.wait_ref(c)
     host.close()
@@ -36,7 +39,7 @@ def test_device_decode_matches_host(ctx, tmp_path, seq_mode, level):
     names, sets = _random_sets(21 + seq_mode + level, 50_000, 4)
     path = str(tmp_path / "d.bam")
     native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=level, threads=3, seq_mode=seq_mode)
-    assert _both(path, ctx, names) is True
+    assert _both(path, ctx, names, sets) is True
 
 
 def test_python_writer_files_unplaced_and_empty_references(ctx, tmp_path):
@@ -88,3 +91,22 @@ def test_records_larger_than_a_block_on_the_device(ctx, tmp_path):
     dev.decode_on_device(ctx)               # (either path may take it: the result is what counts)
     _same(dev.reads("c0"), want)
     dev.close()
+
+
+@pytest.mark.parametrize("stranded", [None, "fr"])
+def test_process_with_gpu_decode_writes_the_same_file(tmp_path, stranded):
+    from spliser_amd import synth
+    from spliser_amd.process import process
+    name = "mouse_stranded" if stranded else "arabidopsis"
+    wl = synth.Workload(name, scale=0.01, seed=9)
+    prefix = str(tmp_path / "s")
+    synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions, stranded=bool(stranded))
+    synth.write_gff(prefix + ".gff", wl.genome)
+    native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=2, seq_mode=1)
+    texts = []
+    for gpu in (False, True):
+        out = prefix + (".gpu" if gpu else ".host")
+        process(prefix + ".bam", prefix + ".bed", out, annotationFile=prefix + ".gff", isStranded=bool(stranded), strandedType=stranded,
+                isbeta2Cryptic=bool(stranded), log=lambda m: None, gpuDecode=gpu)
+        texts.append(open(out + ".SpliSER.tsv").read())
+    assert texts[0] == texts[1] and texts[0].count("\n") > 100
