@@ -149,7 +149,7 @@ def run_oracle(items, scode, cryptic, threads):
     return dt, res
 
 
-def e2e_leg(name, wl, table_items, stranded, cryptic, seq_mode, reps, want_rows):
+def e2e_leg(name, wl, table_items, stranded, cryptic, seq_mode, reps, want_rows, gpu_decode=False):
     """BAM + BED + GFF files of one workload -> spliser_amd.process.process (the CLI's function), timed.  The .SpliSER.tsv is
     compared, row by row, with the counts the oracle gave for the same sample."""
     from spliser_amd import native, process, synth
@@ -163,6 +163,8 @@ def e2e_leg(name, wl, table_items, stranded, cryptic, seq_mode, reps, want_rows)
         native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=0,
                          seq_mode=seq_mode)
         out["files_written_s"] = time.perf_counter() - t
+        out["bam_decode"] = ("on the GPU (process --gpuDecode: BGZF inflate, CRC32, record extraction as kernels)" if gpu_decode else
+                             "on host threads (the default)")
         out["bam_bytes"] = os.path.getsize(prefix + ".bam")
         out["bam_seq_qual"] = ("constant bytes (deflate to almost nothing)" if seq_mode == 0 else
                                "pseudo-random bases, binned qualities in runs (deflate like a real library)")
@@ -171,7 +173,8 @@ def e2e_leg(name, wl, table_items, stranded, cryptic, seq_mode, reps, want_rows)
         for k in range(reps):
             t = time.perf_counter()
             tm = process.process(prefix + ".bam", prefix + ".bed", prefix + ".out%d" % k, annotationFile=prefix + ".gff",
-                                 isStranded=bool(stranded), strandedType=stranded, isbeta2Cryptic=cryptic, log=lambda m: None)
+                                 isStranded=bool(stranded), strandedType=stranded, isbeta2Cryptic=cryptic, log=lambda m: None,
+                                 gpuDecode=gpu_decode)
             wall = time.perf_counter() - t
             runs.append(dict(wall_s=wall, reads_per_sec=n_reads / wall, stages={k2: round(v, 4) for k2, v in tm.items()}))
         best = min(runs, key=lambda r: r["wall_s"])
@@ -399,6 +402,8 @@ def main():
                     # ... and once with SEQ / QUAL bytes that deflate like a real library's (1.4 GB for these 20 M reads): the
                     # files above inflate at memset speed, a real one makes BGZF inflate the whole cost of the call
                     e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, 1, args.e2e_reps, rows2))
+                    # ... and that file with the decode on the GPU (process --gpuDecode)
+                    e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, 1, args.e2e_reps, rows2, gpu_decode=True))
     ctx.close()
 
     if rank == 0:

@@ -815,7 +815,14 @@ namespace {
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t get(size_t bytes, hipStream_t) { return hipMalloc(&p, bytes ? bytes : 16); }
+    hipError_t get(size_t bytes, hipStream_t st)
+    {
+        const hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        // (tests: fresh device memory is zero-filled on this stack, which would hide a read of something never written)
+        static const bool poison = getenv("SPL_DEV_POISON") != nullptr;
+        if (e == hipSuccess && poison) return hipMemsetAsync(p, 0xA5, bytes ? bytes : 16, st);
+        return e;
+    }
     template <class T> T *as() const { return (T *)p; }
 };
 struct CopyJob { char *dst; const char *src; size_t n, per; };
