@@ -33,18 +33,22 @@ struct BitReader {
     __device__ __forceinline__ const uint8_t *pos() const { return (const uint8_t *)(p - 1) - (cnt >> 3); }
 };
 
-// A canonical Huffman table: how many codes of each length (1..15), packed two per word so that the decode loop's fixed
-// indices keep them in registers, and the symbols in order of code (the caller's scratch array).
+// A canonical Huffman table, decoded without a loop over code lengths: limit[len] = the first 15-bit left-justified code value
+// that is NOT a code of `len` bits or fewer (non-decreasing in len), so the length of the code at the head of the bit buffer is
+// 1 + the number of limits its left-justified value has reached -- fourteen compares, no branch; the symbol then sits at
+// base[len] + (value >> (15 - len)) in the table's symbol array (base[len] = index of the first symbol of that length minus the
+// first code of that length).  The limits live in registers (two per word), bases and symbols in the lane's LDS.
 struct Counts {
-    uint32_t w[8]; // count[len] = (w[len >> 1] >> (16 * (len & 1))) & 0xffff
+    uint32_t w[8]; // limit[len] = (w[len >> 1] >> (16 * (len & 1))) & 0xffff, len = 1..15
 };
 
 // The symbols of a lane's tables live in LDS, entry-major (entry e of lane l at [e * 64 + l]): a look-up is a ds_read instead
 // of a trip to the lane's scratch -- the look-up sits on the dependent chain of every symbol.  A byte per symbol plus, for the
-// literal/length table, a bit per entry for "256 and above": 354 bytes per lane, seven workgroups in a CU's 160 KB.
+// literal/length table, a bit per entry for "256 and above"; sixteen 16-bit bases per table.
 struct LdsSyms {
     uint8_t *lo;   // &bytes[lane]
     uint32_t *hi;  // &bits[lane] (word w of lane l at [w * 64 + l]) or nullptr for tables whose symbols fit a byte
+    int16_t *base; // &bases[lane] (base of length len at [len * 64])
     __device__ __forceinline__ int get(int e) const
     {
         int v = lo[e * 64];
@@ -63,12 +67,13 @@ struct LdsSyms {
 
 __device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Counts &c, const LdsSyms &symbol)
 {
-    uint16_t count[16], offs[16];
+    uint16_t count[16], offs[16], limit[16];
 #pragma unroll
     for (int l = 0; l < 16; ++l) count[l] = 0;
     for (int s = 0; s < n; ++s) count[lengths[s]]++;
-    // over-subscribed sets are an error; incomplete ones are legal only in the cases RFC 1951 allows, which the decode loop
-    // handles by failing to find a code
+    count[0] = 0;
+    // over-subscribed sets are an error; incomplete ones are legal only in the cases RFC 1951 allows, which the decode
+    // handles by finding no code
     int left = 1;
 #pragma unroll
     for (int l = 1; l < 16; ++l) {
@@ -79,11 +84,19 @@ __device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Count
     offs[1] = 0;
 #pragma unroll
     for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
+    int code = 0;
+    limit[0] = 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+        symbol.base[l * 64] = (int16_t)((int)offs[l] - code);
+        code += (int)count[l];
+        limit[l] = (uint16_t)(code << (15 - l)); // (<= 0x8000: the set is not over-subscribed)
+        code <<= 1;
+    }
     for (int s = 0; s < n; ++s)
         if (lengths[s]) symbol.set(offs[lengths[s]]++, s);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) c.w[k] = (uint32_t)count[2 * k] | ((uint32_t)count[2 * k + 1] << 16);
-    c.w[0] &= 0xffff0000u; // (codes of length 0 do not exist)
+    for (int k = 0; k < 8; ++k) c.w[k] = (uint32_t)limit[2 * k] | ((uint32_t)limit[2 * k + 1] << 16);
     return true;
 }
 
@@ -91,23 +104,13 @@ __device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Count
 __device__ __forceinline__ int decode_symbol(BitReader &br, const Counts &c, const LdsSyms &symbol)
 {
     br.refill();
-    uint32_t bits = (uint32_t)br.buf;
-    int code = 0, first = 0, index = 0;
+    const uint32_t v = __brev((uint32_t)br.buf) >> 17; // the next 15 bits, first bit on top: codes are packed from their top bit
+    int len = 1;
 #pragma unroll
-    for (int len = 1; len <= 15; ++len) {
-        code |= (int)(bits & 1u);
-        bits >>= 1;
-        const int count = (int)((c.w[len >> 1] >> (16 * (len & 1))) & 0xffffu);
-        if (code - count < first) {
-            br.drop((uint32_t)len);
-            return symbol.get(index + (code - first));
-        }
-        index += count;
-        first += count;
-        first <<= 1;
-        code <<= 1;
-    }
-    return -1;
+    for (int l = 1; l <= 14; ++l) len += v >= ((c.w[l >> 1] >> (16 * (l & 1))) & 0xffffu) ? 1 : 0;
+    if (v >= ((c.w[7] >> 16) & 0xffffu)) return -1;
+    br.drop((uint32_t)len);
+    return symbol.get((int)symbol.base[len * 64] + (int)(v >> (15 - len)));
 }
 
 __constant__ uint16_t k_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -125,12 +128,13 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
     // distance table's place while the lengths are being read
     __shared__ uint8_t s_sym[(288 + 32) * 64];
     __shared__ uint32_t s_hi[9 * 64];
+    __shared__ int16_t s_lbase[16 * 64], s_dbase[16 * 64];
     __shared__ uint16_t s_base[64]; // length and distance bases / extra bits: {len_base[29], dist_base[30]} packed below
     __shared__ uint8_t s_extra[64];
     if (threadIdx.x < 29) { s_base[threadIdx.x] = k_len_base[threadIdx.x]; s_extra[threadIdx.x] = k_len_extra[threadIdx.x]; }
     if (threadIdx.x >= 32 && threadIdx.x < 62) { s_base[threadIdx.x] = k_dist_base[threadIdx.x - 32]; s_extra[threadIdx.x] = k_dist_extra[threadIdx.x - 32]; }
     __syncthreads();
-    const LdsSyms lsym{s_sym + threadIdx.x, s_hi + threadIdx.x}, dsym{s_sym + 288 * 64 + threadIdx.x, nullptr};
+    const LdsSyms lsym{s_sym + threadIdx.x, s_hi + threadIdx.x, s_lbase + threadIdx.x}, dsym{s_sym + 288 * 64 + threadIdx.x, nullptr, s_dbase + threadIdx.x};
     if (b >= n_blocks) return;
     const spl_zblock zb = blocks[b];
     uint8_t *const out = out_all + zb.out;
