@@ -35,20 +35,20 @@ struct BitReader {
 
 // A canonical Huffman table, decoded without a loop over code lengths: limit[len] = the first 15-bit left-justified code value
 // that is NOT a code of `len` bits or fewer (non-decreasing in len), so the length of the code at the head of the bit buffer is
-// 1 + the number of limits its left-justified value has reached -- fourteen compares, no branch; the symbol then sits at
-// base[len] + (value >> (15 - len)) in the table's symbol array (base[len] = index of the first symbol of that length minus the
-// first code of that length).  The limits live in registers (two per word), bases and symbols in the lane's LDS.
+// 1 + the number of limits its left-justified value has reached -- fourteen compares, no branch.  The same compares collect the
+// largest limit reached (= the first code of the found length, left-justified) and the number of symbols with shorter codes:
+// the symbol's place in the table's array follows without a look-up.  Limits and counts live in registers, two per word.
 struct Counts {
     uint32_t w[8]; // limit[len] = (w[len >> 1] >> (16 * (len & 1))) & 0xffff, len = 1..15
+    uint32_t n[8]; // count[len], packed the same way
 };
 
 // The symbols of a lane's tables live in LDS, entry-major (entry e of lane l at [e * 64 + l]): a look-up is a ds_read instead
 // of a trip to the lane's scratch -- the look-up sits on the dependent chain of every symbol.  A byte per symbol plus, for the
-// literal/length table, a bit per entry for "256 and above"; sixteen 16-bit bases per table.
+// literal/length table, a bit per entry for "256 and above": 354 bytes per lane, seven workgroups in a CU's 160 KB.
 struct LdsSyms {
     uint8_t *lo;   // &bytes[lane]
     uint32_t *hi;  // &bits[lane] (word w of lane l at [w * 64 + l]) or nullptr for tables whose symbols fit a byte
-    int16_t *base; // &bases[lane] (base of length len at [len * 64])
     __device__ __forceinline__ int get(int e) const
     {
         int v = lo[e * 64];
@@ -88,11 +88,12 @@ __device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Count
     limit[0] = 0;
 #pragma unroll
     for (int l = 1; l < 16; ++l) {
-        symbol.base[l * 64] = (int16_t)((int)offs[l] - code);
         code += (int)count[l];
         limit[l] = (uint16_t)(code << (15 - l)); // (<= 0x8000: the set is not over-subscribed)
         code <<= 1;
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c.n[k] = (uint32_t)count[2 * k] | ((uint32_t)count[2 * k + 1] << 16);
     for (int s = 0; s < n; ++s)
         if (lengths[s]) symbol.set(offs[lengths[s]]++, s);
 #pragma unroll
@@ -105,12 +106,18 @@ __device__ __forceinline__ int decode_symbol(BitReader &br, const Counts &c, con
 {
     br.refill();
     const uint32_t v = __brev((uint32_t)br.buf) >> 17; // the next 15 bits, first bit on top: codes are packed from their top bit
-    int len = 1;
+    uint32_t len = 1, below = 0, shorter = 0; // below = limit[len - 1], shorter = symbols with codes shorter than len
 #pragma unroll
-    for (int l = 1; l <= 14; ++l) len += v >= ((c.w[l >> 1] >> (16 * (l & 1))) & 0xffffu) ? 1 : 0;
+    for (int l = 1; l <= 14; ++l) {
+        const uint32_t lim = (c.w[l >> 1] >> (16 * (l & 1))) & 0xffffu, cnt = (c.n[l >> 1] >> (16 * (l & 1))) & 0xffffu;
+        const bool ge = v >= lim;
+        len += ge ? 1u : 0u;
+        below = ge ? lim : below;
+        shorter += ge ? cnt : 0u;
+    }
     if (v >= ((c.w[7] >> 16) & 0xffffu)) return -1;
-    br.drop((uint32_t)len);
-    return symbol.get((int)symbol.base[len * 64] + (int)(v >> (15 - len)));
+    br.drop(len);
+    return symbol.get((int)(shorter + ((v - below) >> (15u - len))));
 }
 
 __constant__ uint16_t k_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -128,13 +135,12 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
     // distance table's place while the lengths are being read
     __shared__ uint8_t s_sym[(288 + 32) * 64];
     __shared__ uint32_t s_hi[9 * 64];
-    __shared__ int16_t s_lbase[16 * 64], s_dbase[16 * 64];
     __shared__ uint16_t s_base[64]; // length and distance bases / extra bits: {len_base[29], dist_base[30]} packed below
     __shared__ uint8_t s_extra[64];
     if (threadIdx.x < 29) { s_base[threadIdx.x] = k_len_base[threadIdx.x]; s_extra[threadIdx.x] = k_len_extra[threadIdx.x]; }
     if (threadIdx.x >= 32 && threadIdx.x < 62) { s_base[threadIdx.x] = k_dist_base[threadIdx.x - 32]; s_extra[threadIdx.x] = k_dist_extra[threadIdx.x - 32]; }
     __syncthreads();
-    const LdsSyms lsym{s_sym + threadIdx.x, s_hi + threadIdx.x, s_lbase + threadIdx.x}, dsym{s_sym + 288 * 64 + threadIdx.x, nullptr, s_dbase + threadIdx.x};
+    const LdsSyms lsym{s_sym + threadIdx.x, s_hi + threadIdx.x}, dsym{s_sym + 288 * 64 + threadIdx.x, nullptr};
     if (b >= n_blocks) return;
     const spl_zblock zb = blocks[b];
     uint8_t *const out = out_all + zb.out;
