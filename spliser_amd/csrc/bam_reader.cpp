@@ -367,6 +367,7 @@ struct spl_bam {
     std::thread worker;
     void *map = nullptr;
     size_t fsize = 0;
+    int fd = -1;               // kept open for readers that want the bytes without the mapping (spl_bam_decode_device)
     BlockDir dir;
     int n_threads = 1;
     bool reserved = false;     // claim == 1 on behalf of a spl_bam_decode_device call that is still to come
@@ -382,6 +383,7 @@ spl_bam::~spl_bam()
     for (auto &list : parts) for (PendingPart *p : list) delete p;
     for (void *slab : slabs) free(slab);
     if (map) munmap(map, fsize);
+    if (fd >= 0) close(fd);
 }
 
 namespace {
@@ -913,8 +915,8 @@ static int open_file(const char *path, int n_threads, bool start_now, spl_bam **
     if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); return spl_set_error(SPL_ERR_IO, "cannot stat %s (or empty file)", path); }
     const size_t fsize = (size_t)st.st_size;
     void *map = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (map == MAP_FAILED) return spl_set_error(SPL_ERR_IO, "mmap failed for %s", path);
+    if (map == MAP_FAILED) { close(fd); return spl_set_error(SPL_ERR_IO, "mmap failed for %s", path); }
+    struct FdGuard { int fd; ~FdGuard() { if (fd >= 0) close(fd); } } fd_guard{fd}; // (handed to the spl_bam below, or closed on the way out)
     madvise(map, fsize, MADV_SEQUENTIAL);
     const uint8_t *file = (const uint8_t *)map;
 
@@ -940,6 +942,8 @@ static int open_file(const char *path, int n_threads, bool start_now, spl_bam **
     bam->map = map;
     bam->fsize = fsize;
     bam->path = path;
+    bam->fd = fd_guard.fd;
+    fd_guard.fd = -1;
     bam->dir.chunks.assign(fsize / 28 / BlockDir::CHUNK + 2, nullptr); // (a block is at least 28 bytes)
     if (n_threads <= 0) { // default: all hardware threads up to SPL_BAM_THREADS (32 unless the environment says otherwise)
         const char *e = getenv("SPL_BAM_THREADS");
@@ -1016,6 +1020,7 @@ void spl_bam_block_get(const spl_bam *bam, size_t i, spl_bam_block_info *out)
     out->crc = le32(file + b.coff + b.csize - 8);
 }
 const uint8_t *spl_bam_image(const spl_bam *bam, size_t *fsize_out) { if (fsize_out) *fsize_out = bam->fsize; return (const uint8_t *)bam->map; }
+int spl_bam_fd(const spl_bam *bam) { return bam->fd; }
 uint64_t spl_bam_header_end(const spl_bam *bam) { return bam->header_bytes; }
 int spl_bam_thread_count(const spl_bam *bam) { return bam->n_threads; }
 

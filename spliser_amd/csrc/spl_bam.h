@@ -17,6 +17,7 @@ int spl_bam_walk_all(spl_bam *bam);                       // the whole block dir
 size_t spl_bam_block_count(const spl_bam *bam);
 void spl_bam_block_get(const spl_bam *bam, size_t i, spl_bam_block_info *out);
 const uint8_t *spl_bam_image(const spl_bam *bam, size_t *fsize_out);
+int spl_bam_fd(const spl_bam *bam);                        // the open file (pread: bytes without touching the mapping's page tables)
 uint64_t spl_bam_header_end(const spl_bam *bam);           // where the first record starts in the inflated stream
 int spl_bam_thread_count(const spl_bam *bam);
 // The placed records of the whole file in file order as four malloc'ed arrays (the file takes them over and frees them with
