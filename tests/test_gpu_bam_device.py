@@ -110,3 +110,33 @@ def test_process_with_gpu_decode_writes_the_same_file(tmp_path, stranded):
                 isbeta2Cryptic=bool(stranded), log=lambda m: None, gpuDecode=gpu)
         texts.append(open(out + ".SpliSER.tsv").read())
     assert texts[0] == texts[1] and texts[0].count("\n") > 100
+
+
+def test_many_small_files_all_block_kinds(ctx, tmp_path):
+    """Small files through the Python writer at every zlib level: stored blocks (level 0), fixed-code blocks (a handful of
+    records), dynamic blocks, blocks of a few bytes, files of one record -- device decode against what was written."""
+    rng = np.random.default_rng(77)
+    taken = 0
+    for k in range(36):
+        n = int(rng.choice([1, 2, 5, 40, 300, 3000]))
+        pos = np.sort(rng.integers(1, 100000, n)).astype(np.int32)
+        n_ops = rng.choice([1, 3, 5], size=n)
+        cig_off = np.concatenate(([0], np.cumsum(n_ops))).astype(np.uint32)
+        cigar = np.empty(int(cig_off[-1]), np.uint32)
+        j = 0
+        for i in range(n):
+            for q in range(int(n_ops[i])):
+                cigar[j] = (int(rng.integers(1, 200)) << 4) | (0 if q % 2 == 0 else 3)
+                j += 1
+        want = samio.ReadSet(pos, rng.choice([0, 16, 99, 147], size=n).astype(np.uint16), cig_off, cigar)
+        path = str(tmp_path / ("f%d.bam" % k))
+        samio.write_bam(path, ["a", "b"], [10 ** 6, 10 ** 6], [("b" if k % 3 == 0 else "a", want)], level=k % 10, with_seq=bool(k % 2),
+                        unplaced=k % 4)
+        dev = native.BamFile(path, threads=2, defer=True)
+        taken += bool(dev.decode_on_device(ctx))
+        ref = "b" if k % 3 == 0 else "a"
+        _same(dev.reads(ref), want)
+        assert dev.reads("a" if ref == "b" else "b").n == 0
+        assert dev.n_records == n + k % 4
+        dev.close()
+    assert taken == 36
