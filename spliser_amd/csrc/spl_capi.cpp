@@ -810,18 +810,57 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
 // sums on the host, extraction of POS / FLAG / CIGAR into file-wide arrays, and those come back into page-locked host arrays
 // that the spl_bam adopts, one part per reference.
 namespace {
-// Device memory of the decode.  (Stream-ordered allocation -- hipMallocAsync / hipFreeAsync on the copy stream -- was tried so
-// that freeing 18 GB would not wait for the device: the frees turned out to cost 20 ms, and with the pool the decode became
-// flaky on this stack -- stale tids in one run of four -- so: plain hipMalloc / hipFree.)
+// Device memory of the decode.  The large buffers (file image, inflated stream: 18 GB for a 50 M-read file) are kept by the
+// process for the next decode on the same device instead of being freed: freed VRAM is scrubbed by the copy engines, and a
+// decode that started while 18 GB of the previous one were being scrubbed had its upload run at 4 GB/s instead of 35 (every
+// other call of a loop took 0.4...0.7 s longer).  At most two buffers per device are kept, the rest is freed as before.
+// (Stream-ordered allocation -- hipMallocAsync / hipFreeAsync -- was tried first: with the pool the decode became flaky on
+// this stack, stale tids in one run of four.)
+struct CachedDev { int device; void *p; size_t bytes; };
+static std::mutex &dev_cache_mu() { static std::mutex m; return m; }
+static std::vector<CachedDev> &dev_cache() { static std::vector<CachedDev> *v = new std::vector<CachedDev>(); return *v; }
+
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    size_t cap = 0;
+    int device = -1;
+    ~DevBuf()
+    {
+        if (!p) return;
+        if (cap >= ((size_t)256 << 20)) {
+            std::lock_guard<std::mutex> lock(dev_cache_mu());
+            std::vector<CachedDev> &cache = dev_cache();
+            size_t mine = 0;
+            for (const CachedDev &e : cache) mine += e.device == device ? 1 : 0;
+            if (mine < 2) { cache.push_back(CachedDev{device, p, cap}); return; }
+        }
+        (void)hipFree(p);
+    }
     hipError_t get(size_t bytes, hipStream_t st)
     {
-        const hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        bytes = bytes ? bytes : 16;
+        (void)hipGetDevice(&device);
+        if (bytes >= ((size_t)256 << 20)) {
+            std::lock_guard<std::mutex> lock(dev_cache_mu());
+            std::vector<CachedDev> &cache = dev_cache();
+            size_t best = cache.size();
+            for (size_t k = 0; k < cache.size(); ++k)
+                if (cache[k].device == device && cache[k].bytes >= bytes && (best == cache.size() || cache[k].bytes < cache[best].bytes)) best = k;
+            if (best < cache.size()) {
+                p = cache[best].p;
+                cap = cache[best].bytes;
+                cache.erase(cache.begin() + (long)best);
+                return hipSuccess;
+            }
+            // nothing large enough: what is cached for this device and too small only stands in the way
+            for (size_t k = cache.size(); k-- > 0;)
+                if (cache[k].device == device) { (void)hipFree(cache[k].p); cache.erase(cache.begin() + (long)k); }
+        }
+        cap = bytes;
+        const hipError_t e = hipMalloc(&p, bytes);
         // (tests: fresh device memory is zero-filled on this stack, which would hide a read of something never written)
         static const bool poison = getenv("SPL_DEV_POISON") != nullptr;
-        if (e == hipSuccess && poison) return hipMemsetAsync(p, 0xA5, bytes ? bytes : 16, st);
+        if (e == hipSuccess && poison) return hipMemsetAsync(p, 0xA5, bytes, st);
         return e;
     }
     template <class T> T *as() const { return (T *)p; }
@@ -881,7 +920,8 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
     if ((double)fsize * 8.0 + (double)(1u << 30) > (double)free_b) return to_host("not enough device memory");
     // the block directory (one thread's walk over the file's block headers) beside the upload of the file image
     int walk_rc = SPL_OK;
-    std::thread walker([&]() { walk_rc = spl_bam_walk_all(bam); });
+    double t_walk = 0;
+    std::thread walker([&]() { const double w0 = host_now(); walk_rc = spl_bam_walk_all(bam); t_walk = host_now() - w0; });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{walker};
     DevBuf d_image, d_stream, d_blocks, d_status, d_scan;
     HIP_TRY(d_image.get(fsize + 64, c->copy));
@@ -904,7 +944,9 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
         st.busy = true;
         off += n;
     }
+    const double t_loop_end = host_now();
     walker.join();
+    if (timing) fprintf(stderr, "[spl_bam_decode_device] (upload loop done after %.4f s; the directory walk took %.4f s)\n", t_loop_end - t_begin, t_walk);
     if (walk_rc) return to_host("block directory");
     const size_t n_blocks = spl_bam_block_count(bam);
     if (n_blocks == 0 || n_blocks > 0xfffffff0ull) return to_host("no blocks");

@@ -266,9 +266,19 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
                 copy_left -= n;
                 continue;
             }
-            if (want_dist) {
-                const int ds = decode_symbol(br, dc, dsym);
-                if (ds < 0 || ds >= 30) { err = SPL_Z_BAD_CODE; break; }
+            // one decode per turn whichever table the lane is at (a length is followed by a distance): the lanes that want a
+            // distance symbol and those that want a literal/length symbol go through the same instructions with their own
+            // limits, counts and symbol arrays -- two decode blocks in a row cost every turn twice
+            const bool is_dist = want_dist != 0;
+            Counts tc;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { tc.w[k] = is_dist ? dc.w[k] : lc.w[k]; tc.n[k] = is_dist ? dc.n[k] : lc.n[k]; }
+            const LdsSyms ts{is_dist ? dsym.lo : lsym.lo, lsym.hi};
+            int sym = decode_symbol(br, tc, ts);
+            if (sym < 0) { err = SPL_Z_BAD_CODE; break; }
+            if (is_dist) {
+                const int ds = sym & 0xff; // (the high bit belongs to the literal/length table: meaningless here)
+                if (ds >= 30) { err = SPL_Z_BAD_CODE; break; }
                 br.refill();
                 copy_dist = (uint32_t)s_base[32 + ds] + br.take(s_extra[32 + ds]);
                 if (copy_dist > at) { err = SPL_Z_BAD_DISTANCE; break; }
@@ -277,8 +287,6 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
                 want_dist = 0;
                 continue;
             }
-            int sym = decode_symbol(br, lc, lsym);
-            if (sym < 0) { err = SPL_Z_BAD_CODE; break; }
             if (sym < 256) {
                 if (at >= out_len) { err = SPL_Z_OVERRUN; break; }
                 out[at++] = (uint8_t)sym;
