@@ -159,6 +159,7 @@ struct spl_dreads {
     std::vector<Segment> segs;
     int64_t n_reads = 0, n_cigar = 0;
     uint32_t n_chunks = 0;
+    uint32_t chunk_shift = SPL_CHUNK_SHIFT; // reads per chunk of this set (fixed when it is begun: spl_reads_begin_sized)
     bool finished = false;
     char *ctl = nullptr;            // chunk descriptors, chunk order, the queues (allocated by spl_reads_finish)
     spl_chunk_meta *meta = nullptr;
@@ -744,10 +745,11 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
     auto host_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tp0 = c->stage_timing ? host_now() : 0.0;
     splpack::Plan plan;
+    plan.chunk = 1u << d->chunk_shift;
     splpack::plan(src, plan, c->pack_threads);
     if (c->stage_timing) c->tm_plan_s += host_now() - tp0;
     if (plan.n_wide > 0xfffffff0ull) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops of wide reads in one segment: use more shards");
-    if ((uint64_t)d->n_chunks + plan.chunks.size() > (1ull << (32 - SPL_CHUNK_SHIFT)))
+    if ((uint64_t)d->n_chunks + plan.chunks.size() > (1ull << (32 - d->chunk_shift)))
         return spl_set_error(SPL_ERR_ARG, "too many reads in one read set: use more shards");
     d->segs.emplace_back();
     spl_dreads::Segment &seg = d->segs.back();
@@ -1126,7 +1128,7 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
     // reads per XCD, see my_chunk); inside every eighth the chunks go longest first (stable counting sort on the cost)
     {
         const size_t grid = (n + 7) / 8 * 8, per = grid / 8;
-        const uint32_t max_cost = SPL_CHUNK * SPL_W_WIDE;
+        const uint32_t max_cost = (1u << d->chunk_shift) * SPL_W_WIDE;
         std::vector<uint32_t> bucket((size_t)max_cost + 2);
         for (size_t x = 0; x < 8; ++x) {
             const size_t lo = std::min(x * per, n), hi = std::min(lo + per, n);
@@ -1138,7 +1140,7 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
         }
     }
     // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks
-    const size_t shard_cap = ((n + 7) / 8) * SPL_CHUNK;
+    const size_t shard_cap = ((n + 7) / 8) << d->chunk_shift;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     const size_t o_meta = take(sizeof(spl_chunk_meta) * std::max<size_t>(n, 1)), o_order = take(4 * std::max<size_t>(n, 1));
@@ -1201,13 +1203,19 @@ extern "C" int spl_pack_host(const spl_reads *reads, int n_threads, int64_t *n_c
     return SPL_OK;
 }
 
-extern "C" int spl_reads_begin(spl_ctx *c, spl_dreads **out)
+extern "C" int spl_reads_begin_sized(spl_ctx *c, int64_t expected_reads, spl_dreads **out)
 {
     if (!c || !out) return spl_set_error(SPL_ERR_ARG, "spl_reads_begin: null argument");
     *out = new (std::nothrow) spl_dreads();
     if (!*out) return spl_set_error(SPL_ERR_NOMEM, "out of host memory");
+    // large sets in chunks of twice the size (spl_pack.h); SPL_FORCE_CHUNK=<reads per chunk> overrides (tests)
+    bool big = expected_reads >= SPL_BIG_SET_READS;
+    if (const char *e = getenv("SPL_FORCE_CHUNK")) big = atol(e) == SPL_CHUNK_BIG;
+    (*out)->chunk_shift = big ? SPL_CHUNK_BIG_SHIFT : SPL_CHUNK_SHIFT;
     return SPL_OK;
 }
+
+extern "C" int spl_reads_begin(spl_ctx *c, spl_dreads **out) { return spl_reads_begin_sized(c, 0, out); }
 
 // End (1-based, inclusive) of the last base any read of a caller's arrays covers; needed when the segment is moved.
 static int64_t max_end_of(const spl_reads *r)
@@ -1273,7 +1281,9 @@ extern "C" int spl_reads_upload_segments(spl_ctx *c, int n_seg, const spl_reads 
         return spl_set_error(SPL_ERR_ARG, "spl_reads_upload_segments: null argument");
     *out = nullptr;
     spl_dreads *d = nullptr;
-    int rc = spl_reads_begin(c, &d);
+    int64_t total = 0;
+    for (int k = 0; k < n_seg; ++k) total += segs[k].n_reads > 0 ? segs[k].n_reads : 0;
+    int rc = spl_reads_begin_sized(c, total, &d);
     for (int k = 0; k < n_seg && rc == SPL_OK; ++k) rc = spl_reads_add(c, d, &segs[k], pos_shift[k]);
     if (rc == SPL_OK) rc = spl_reads_finish(c, d);
     if (rc != SPL_OK) { spl_reads_free(c, d); return rc; }
@@ -1338,7 +1348,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.jhash = ds->jhash; p.jhash_mask = ds->jhash_mask; p.jrivals = ds->jrivals;
     spl_hot_params h;
     memset(&h, 0, sizeof(h));
-    h.n_chunks = p.n_chunks; h.chunk_meta = dr->meta; h.chunk_order = dr->chunk_order; h.part_pos = ds->part_pos;
+    h.n_chunks = p.n_chunks; h.chunk_shift = dr->chunk_shift; h.chunk_meta = dr->meta; h.chunk_order = dr->chunk_order; h.part_pos = ds->part_pos;
     h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = queue; h.queue_n = ds->queue_n; h.err = ds->err;
@@ -1369,7 +1379,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
         // otherwise the next one
         const int to_clear = piped ? (ds->cur + 2) % 3 : (ds->cur + 1) % 3;
         spl_queue_params lq;
-        lq.queue = queue; lq.queue_n = ds->queue_n; lq.queue_cap = h.queue_cap; lq.queue_total = dr->queue_total;
+        lq.queue = queue; lq.queue_n = ds->queue_n; lq.queue_cap = h.queue_cap; lq.chunk_shift = dr->chunk_shift; lq.queue_total = dr->queue_total;
         lq.clear_region = (uint4 *)ds->region[to_clear]; lq.clear_n16 = ds->counter_bytes / 16;
         lq.diff = ds->diff; lq.block_sums = ds->block_sums; lq.diff_stride = ds->diff_stride; lq.n_dpos = ds->n_dpos;
         lq.scan_blocks = ds->scan_blocks; lq.scan_arrays = o->stranded ? 4 : 2;

@@ -29,6 +29,7 @@
 #define SPL_WAVE_ITERS 10
 #endif
 #define SPL_WAVE_READS (64 * SPL_WAVE_ITERS)
+#define SPL_WAVE_READS_BIG (64 * (2 * SPL_WAVE_ITERS - 2)) // chunks of SPL_CHUNK_BIG: 8 once-spliced iterations of 128 per wave at most, and the partial ones
 #define SPL_WIN 1020                     // distinct site positions a workgroup privatises in LDS (pair kernel; range kernel unstranded)
 #define SPL_WIN_STRANDED 956             // ... range kernel, stranded: 4 windows + the lists, 8 workgroups in 160 KB
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
@@ -103,6 +104,7 @@ struct spl_count_params {
 // Argument block of the range kernel: only what the straight-line path touches (keeps it out of SGPR spills).
 struct spl_hot_params {
     uint32_t n_chunks;
+    uint32_t chunk_shift;        // log2 of the reads per chunk of this read set (SPL_CHUNK_SHIFT or SPL_CHUNK_BIG_SHIFT)
     const spl_chunk_meta *chunk_meta; // [n_chunks] (spl_pack.h)
     const uint32_t *chunk_order; // [n_chunks] slot of an XCD slice -> chunk, longest chunk first within every slice
     const int32_t *part_pos;     // partner positions (CSR values): the twice-spliced junction-table pass scans a rival's list
@@ -130,6 +132,7 @@ struct spl_queue_params {
     const uint32_t *queue;       // 8 regions of queue_cap entries
     const uint32_t *queue_n;     // counter k at word k * SPL_COUNTER_STRIDE
     uint32_t queue_cap;
+    uint32_t chunk_shift;        // (how to take an entry apart)
     uint32_t *queue_total;       // the number of entries, for the host (diagnostic), written by this launch
     // the block sums of the difference arrays are taken by this launch too (see spl_count_literal_kernel)
     const int32_t *diff;
@@ -180,7 +183,7 @@ extern "C" {
 #endif
 // variant: 0 = range kernel (any table: the junction table is built from each row's own lists), 1 = pair kernel (the
 // literal cross-check), 2 = range kernel WITH wave-level aggregation of LDS atomics (SPL_OPT_WAVE_AGGREGATION)
-int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out, void *ev_start, void *ev_stop);
+int spl_dev_launch_count(const spl_count_params *p, const spl_hot_params *h, int variant, void *stream, int *grid_out, int *lds_out, void *ev_start, void *ev_stop); // (h->chunk_shift picks the instantiation)
 int spl_dev_launch_junctions(const spl_chunk_meta *chunk_meta, uint32_t n_chunks,
                              int stranded, uint32_t min_anchor, uint32_t min_intron, uint32_t max_intron, unsigned long long *keys,
                              uint32_t *vals, uint32_t n_slots, unsigned long long *out_keys,

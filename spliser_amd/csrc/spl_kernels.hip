@@ -693,7 +693,7 @@ __device__ uint64_t *g_phase;
 // cover each other's memory trips and barriers; the register cap costs nothing -- no scratch).  Merging the atomics of
 // neighbouring lanes first (AGG, SPL_OPT_WAVE_AGGREGATION) needs a few more registers than that cap allows and was
 // never faster in measurements, not even at 8000 reads per site; it stays as a variant for parity tests.
-template <bool STRANDED, bool AGG>
+template <bool STRANDED, bool AGG, bool BIG>
 __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ? 4 : 8, 8))) void spl_count_ranges_kernel(const spl_hot_params p)
 {
     constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     // (finished from the junction table by the wave itself right after its loop, see below).  Only the owning wave touches a
     // segment, so the fill counts are wave-uniform registers and slots are handed out by ballot, not by atomics.
     constexpr int NWAVE = SPL_WAVES;
-    constexpr uint32_t SEG = SPL_WAVE_READS;
+    constexpr uint32_t SEG = BIG ? SPL_WAVE_READS_BIG : SPL_WAVE_READS;
     __shared__ uint16_t s_q[NWAVE * SEG];
     __shared__ uint32_t s_qcnt[NWAVE], s_qbase;
 #ifdef SPL_PHASE_WAVES
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         if (tid == 0) s_qbase = atomicAdd(&p.queue_n[shard * SPL_COUNTER_STRIDE], qn); // a cache line per counter
         __syncthreads();
         uint32_t *dst = p.queue + (size_t)shard * p.queue_cap + s_qbase;
-        const uint32_t first = chunk << SPL_CHUNK_SHIFT;
+        const uint32_t first = chunk << (BIG ? SPL_CHUNK_BIG_SHIFT : SPL_CHUNK_SHIFT);
         for (uint32_t j = tid; j < qn; j += SPL_BLOCK) {
             uint32_t w = 0;
 #pragma unroll
@@ -1341,9 +1341,9 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
 #pragma unroll
             for (int sh = 0; sh < 8; ++sh) base = (shard == (uint32_t)sh) ? start[sh] : base;
             const uint32_t entry = q.queue[(size_t)shard * q.queue_cap + (g - base)]; // chunk << SPL_CHUNK_SHIFT | slot
-            const ChunkView cv = chunk_view(p.chunk_meta + (entry >> SPL_CHUNK_SHIFT));
+            const ChunkView cv = chunk_view(p.chunk_meta + (entry >> q.chunk_shift));
             uint32_t *row = s_ops[threadIdx.x];
-            const ReadView rv = read_at(cv, entry & (SPL_CHUNK - 1u), row);
+            const ReadView rv = read_at(cv, entry & ((1u << q.chunk_shift) - 1u), row);
             const int32_t pos = rv.pos;
             const uint32_t flag = rv.flag;
             uint32_t n_ops = rv.n_ops;
@@ -1744,7 +1744,8 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
         if (p->stranded) hipExtLaunchKernelGGL(spl_count_pairs_kernel<true>, dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *p);
         else hipExtLaunchKernelGGL(spl_count_pairs_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *p);
     } else {
-        *lds_out = (p->stranded ? 4 * (SPL_WIN_STRANDED + 1) : 2 * (SPL_WIN + 1)) * 4 + SPL_WAVES * SPL_WAVE_READS * 2 + 4 * SPL_WAVES + 4; // difference windows + the waves' lists
+        const bool big = h->chunk_shift == SPL_CHUNK_BIG_SHIFT;
+        *lds_out = (p->stranded ? 4 * (SPL_WIN_STRANDED + 1) : 2 * (SPL_WIN + 1)) * 4 + SPL_WAVES * (big ? SPL_WAVE_READS_BIG : SPL_WAVE_READS) * 2 + 4 * SPL_WAVES + 4; // difference windows + the waves' lists
         const bool agg = (variant & 2) != 0;
 #ifdef SPL_PHASE_TIMING
         static uint64_t *phase_buf = nullptr;
@@ -1756,13 +1757,15 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), &phase_buf, sizeof(phase_buf));
         }
 #endif
+#define SPL_LAUNCH_RANGES(S, A, B) hipExtLaunchKernelGGL((spl_count_ranges_kernel<S, A, B>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h)
         if (p->stranded) {
-            if (agg) hipExtLaunchKernelGGL((spl_count_ranges_kernel<true, true>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h);
-            else hipExtLaunchKernelGGL((spl_count_ranges_kernel<true, false>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h);
+            if (agg) { if (big) SPL_LAUNCH_RANGES(true, true, true); else SPL_LAUNCH_RANGES(true, true, false); }
+            else { if (big) SPL_LAUNCH_RANGES(true, false, true); else SPL_LAUNCH_RANGES(true, false, false); }
         } else {
-            if (agg) hipExtLaunchKernelGGL((spl_count_ranges_kernel<false, true>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h);
-            else hipExtLaunchKernelGGL((spl_count_ranges_kernel<false, false>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h);
+            if (agg) { if (big) SPL_LAUNCH_RANGES(false, true, true); else SPL_LAUNCH_RANGES(false, true, false); }
+            else { if (big) SPL_LAUNCH_RANGES(false, false, true); else SPL_LAUNCH_RANGES(false, false, false); }
         }
+#undef SPL_LAUNCH_RANGES
 #ifdef SPL_PHASE_TIMING
         if (const char *path = getenv("SPL_PHASE_DUMP")) {
             (void)hipStreamSynchronize(st);

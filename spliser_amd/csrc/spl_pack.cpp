@@ -111,7 +111,8 @@ void plan_chunk(size_t c, void *arg)
     const PlanJob &job = *(const PlanJob *)arg;
     const Source &src = *job.src;
     ChunkDesc &d = job.plan->chunks[c];
-    const int64_t i0 = (int64_t)c * SPL_CHUNK, i1 = std::min<int64_t>(src.n_reads, i0 + SPL_CHUNK);
+    const int64_t chunk = (int64_t)job.plan->chunk;
+    const int64_t i0 = (int64_t)c * chunk, i1 = std::min<int64_t>(src.n_reads, i0 + chunk);
     uint32_t n[SPL_RC_RUNS] = {0, 0, 0, 0}, cost = 0;
     uint64_t wide = 0;
     bool first = true;
@@ -156,7 +157,7 @@ void parallel_for(size_t n, int n_threads, void (*fn)(size_t, void *), void *arg
 
 void plan(const Source &src, Plan &out, int n_threads)
 {
-    const size_t n_chunks = (size_t)((src.n_reads + SPL_CHUNK - 1) / SPL_CHUNK);
+    const size_t n_chunks = (size_t)((src.n_reads + out.chunk - 1) / out.chunk);
     out.chunks.assign(n_chunks, ChunkDesc());
     PlanJob job{&src, &out};
     parallel_for(n_chunks, n_threads, plan_chunk, &job);
@@ -184,7 +185,7 @@ void emit(const Source &src, const Plan &plan, size_t c0, size_t c1, uint8_t *re
         uint64_t wide_at = d.wide_off;
         uint32_t *wdst = wide_dst + (d.wide_off - plan.chunks[c0].wide_off);
         static const uint32_t rec_size[SPL_RC_RUNS] = {SPL_REC_SIMPLE, SPL_REC_MNM, SPL_REC_M2, SPL_REC_OTHER};
-        const int64_t i0 = (int64_t)c * SPL_CHUNK, i1 = std::min<int64_t>(src.n_reads, i0 + SPL_CHUNK);
+        const int64_t i0 = (int64_t)c * (int64_t)plan.chunk, i1 = std::min<int64_t>(src.n_reads, i0 + (int64_t)plan.chunk);
         for_reads(src, i0, i1, [&](int32_t pos, uint32_t flag, const uint32_t *ops, uint32_t n_ops) {
             classify(pos, flag, ops, n_ops, (uint32_t)wide_at, r);
             memcpy(run[r.run], r.w, rec_size[r.run]);

@@ -47,7 +47,7 @@ OPT_WAVE_AGGREGATION = 2
 EXPORTS = [
     "spl_abi_version", "spl_last_error", "spl_device_count", "spl_create", "spl_create_on_stream", "spl_destroy",
     "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
-    "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
+    "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
@@ -215,10 +215,11 @@ class Context(object):
         _check(lib().spl_reads_upload(self._h, ctypes.byref(reads.c), ctypes.byref(h)))
         return DeviceReads(self, h, reads.n)
 
-    def begin_reads(self):
-        """A read set to which segments are added one by one (``DeviceReads.add`` / ``add_bam``), then ``finish()``."""
+    def begin_reads(self, expected_reads=0):
+        """A read set to which segments are added one by one (``DeviceReads.add`` / ``add_bam``), then ``finish()``.
+        ``expected_reads``: how many reads are going to be added, when known (sets of 64 M and more get larger chunks)."""
         h = ctypes.c_void_p()
-        _check(lib().spl_reads_begin(self._h, ctypes.byref(h)))
+        _check(lib().spl_reads_begin_sized(self._h, ctypes.c_int64(int(expected_reads)), ctypes.byref(h)))
         return DeviceReads(self, h, 0)
 
     def upload_read_segments(self, segments):

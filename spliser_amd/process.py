@@ -153,7 +153,8 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
             for sh in shards:
                 with ctx.upload_sites(sh.sites) as ds:
                     if whole:
-                        with ctx.begin_reads() as dr:
+                        n_expected = sum(source.wait_ref(c)[0] for c in sh.chroms if items[c][2])
+                        with ctx.begin_reads(n_expected) as dr:
                             for chrom, off, limit in zip(sh.chroms, sh.offsets, sh.limits):
                                 if items[chrom][2]:
                                     _, max_end = source.wait_ref(chrom)

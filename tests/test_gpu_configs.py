@@ -54,6 +54,22 @@ def test_config3_human_scale_process(devices, tmp_path, oracle_lib):
     assert open(prefix + ".SpliSER.tsv").read() == _oracle_tsv(oracle_lib, prefix + ".bed", wl, None, False, prefix + ".gff")
 
 
+@pytest.mark.parametrize("gpu_decode", [False, True])
+@pytest.mark.parametrize("stranded", [None, "fr"])
+def test_large_read_set_chunks(tmp_path, oracle_lib, monkeypatch, stranded, gpu_decode):
+    """Read sets of 64 M reads and more are cut into chunks of 4096 reads (other instantiations of the range kernel, longer
+    per-wave lists, another queue entry format): forced here on a sample a test can afford, host and device decode."""
+    monkeypatch.setenv("SPL_FORCE_CHUNK", "4096")
+    wl = synth.Workload("mouse_stranded" if stranded else "human", scale=0.01, workers=4)
+    prefix = str(tmp_path / "b")
+    _files(wl, prefix, seq_mode=1)
+    argv = ["process", "-B", prefix + ".bam", "-b", prefix + ".bed", "-o", prefix]
+    argv += ["--isStranded", "-s", "fr", "--beta2Cryptic"] if stranded else []
+    argv += ["--gpuDecode"] if gpu_decode else []
+    assert cli.main(argv) == 0
+    assert open(prefix + ".SpliSER.tsv").read() == _oracle_tsv(oracle_lib, prefix + ".bed", wl, stranded, bool(stranded))
+
+
 @pytest.mark.parametrize("devices", ["0", "0,0"])
 def test_config5_mouse_stranded_cryptic_process(devices, tmp_path, oracle_lib):
     wl = synth.Workload("mouse_stranded", scale=0.02, workers=4)    # 2 M reads with flags 99/147/83/163
