@@ -91,13 +91,22 @@ KERNEL_SOURCES = ("spl_kernels.hip", "spl_device.h", "spl_pack.h", "spl_classify
 
 
 def kernel_src_sha16():
-    """What the HBM traffic of the range kernel depends on: the kernel's sources and the packer that lays out what it reads
-    (tools/traffic_json.py stamps a measurement with the same hash).  Host-side changes elsewhere in the library leave it alone."""
+    """What the HBM traffic of the range kernel depends on: the kernel's sources and the packer that lays out what it reads,
+    comments and white space aside (tools/traffic_json.py stamps a measurement with the same hash).  Host-side changes elsewhere
+    in the library, and comments, leave it alone."""
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
         with open(os.path.join(ROOT, "spliser_amd", "csrc", name), "rb") as fh:
-            h.update(fh.read())
+            h.update(strip_source(fh.read().decode("utf-8", "replace")).encode("utf-8"))
     return h.hexdigest()[:16]
+
+
+def strip_source(text):
+    """C / C++ source without comments, every run of white space one blank (string literals of these files hold no '//')."""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return re.sub(r"\s+", " ", text).strip()
 
 
 def cpu_budget():

@@ -15,9 +15,10 @@
                                          // line serialise the atomics of all XCDs: measured 11 ns per atomic, chip-wide)
 #define SPL_WAVES (SPL_BLOCK / 64)
 // The range kernel deals the wave-iterations of a chunk (64 * K reads of ONE run each, K = 4 / 2 / 1 / 1 by run; a run's last one
-// may be partial) round-robin to its four waves.  Simple reads are never listed; of the others a wave can get at most
-// 128 + 8 * 64 = 640 (one full once-spliced iteration and eight of the rest: 33 iterations at most carry listable reads): as
-// many list entries (s_q) per wave.
+// may be partial) round-robin to its four waves.  Simple reads are never listed; of the others a wave can get a quarter of the
+// chunk plus what the alignment of the runs' partial iterations adds: at most 577 of a 2048-read chunk and 1089 of a 4096-read one
+// (enumerated over the run sizes); s_q has 640 / 1152 entries per wave, and a launch that ever needed more says so
+// (SPL_DEV_ERR_TABLE) instead of dropping a read.
 #ifndef SPL_K_SIMPLE
 #define SPL_K_SIMPLE 4                   // reads per lane and wave-iteration: simple reads (8-byte records)
 #define SPL_K_MNM 2                      // ... once-spliced reads (16-byte records)

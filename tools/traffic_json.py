@@ -29,9 +29,18 @@ def mean(counter, sub):
 fetch, n = mean("FETCH_SIZE", "fetch")
 write, _ = mean("WRITE_SIZE", "write")
 h = hashlib.sha256(open(os.path.join(ROOT, "spliser_amd", "libspliser_hip.so"), "rb").read()).hexdigest()[:16]
+import re
+
+
+def strip_source(text):   # (= bench.py strip_source: comments and white space do not count)
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return re.sub(r"\s+", " ", text).strip()
+
+
 kh = hashlib.sha256()
 for name in ("spl_kernels.hip", "spl_device.h", "spl_pack.h", "spl_classify.h", "spl_pack.cpp"):   # (= bench.py KERNEL_SOURCES)
-    kh.update(open(os.path.join(ROOT, "spliser_amd", "csrc", name), "rb").read())
+    kh.update(strip_source(open(os.path.join(ROOT, "spliser_amd", "csrc", name), "rb").read().decode("utf-8", "replace")).encode("utf-8"))
 workload = args[args.index("--workload") + 1] if "--workload" in args else "human"
 out = {"workload": workload, "bench_args": args, "lib_sha16": h, "kernel_src_sha16": kh.hexdigest()[:16], "kernel": "spl_count_ranges_kernel", "dispatches": n,
        "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof_pmc.sh), means per dispatch",
