@@ -215,6 +215,12 @@ int spl_bam_decode_device(spl_ctx *ctx, spl_bam *bam, int *on_device_out);
  * references: the file is marked as taken by the device decoder now, so that those waits wait instead of starting the host
  * decode.  The promise must be kept (spl_bam_decode_device), or the waits never end. */
 int spl_bam_reserve_device(spl_bam *bam);
+/* A deferred file's other option, said out loud: decode on the host's threads, starting now. */
+int spl_bam_start(spl_bam *bam);
+/* Inflated bytes per file byte over the first record blocks of a deferred file (0 = cannot tell): BGZF inflate is what a decode
+ * costs, and which side inflates faster depends on this number -- a real library's file (3...4) is twice as fast on the GPU, a
+ * file that inflates at memset speed (synthetic data: 50) is faster on the host.  `process` decides by it unless told otherwise. */
+int spl_bam_compression_ratio(spl_bam *bam, double *ratio_out);
 int spl_bam_wait_ref(spl_bam *bam, int tid, int64_t *n_reads_out, int64_t *max_end_out);
 int spl_bam_wait_all(spl_bam *bam, int *sorted_out);
 void spl_bam_close(spl_bam *bam);

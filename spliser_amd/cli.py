@@ -39,9 +39,12 @@ def build_parser():
     p.add_argument("--checkJunctions", dest="checkJunctions", default=False, action="store_true",
                    help="(this build only) also count every junction in the BAM on the GPU and write <outputPath>.junctionCheck.tsv: "
                         "BED alpha against reads in the BAM; changes no result")
-    p.add_argument("--gpuDecode", dest="gpuDecode", default=False, action="store_true",
-                   help="(this build only) inflate the BAM's BGZF blocks and extract its records on the GPU instead of on host "
-                        "threads; changes no result")
+    p.add_argument("--gpuDecode", dest="gpuDecode", default=None, action="store_true",
+                   help="(this build only) inflate the BAM's BGZF blocks and extract its records on the GPU whatever the file "
+                        "looks like (default: the GPU for files that compress like real libraries, host threads for files that "
+                        "inflate at memset speed); changes no result")
+    p.add_argument("--hostDecode", dest="gpuDecode", action="store_false",
+                   help="(this build only) decode the BAM on host threads whatever the file looks like")
     _engine_flags(p)
     c = sub.add_parser("combine")
     c.add_argument("-S", "--samplesFile", dest="samplesFile", required=True,

@@ -1002,6 +1002,36 @@ int spl_bam_device_gives_up(spl_bam *bam)
     return SPL_OK;
 }
 
+// Decode on the host's threads (public face of spl_bam_start_host: a deferred file whose caller has made up his mind).
+extern "C" int spl_bam_start(spl_bam *bam) { return spl_bam_start_host(bam); }
+
+// How well the file's first blocks behind the BAM header are compressed (inflated bytes per file byte, over up to 256 blocks):
+// what decides whether the host's inflate or the GPU's is the faster one for this file.  Deferred files only (nobody else may be
+// walking the block directory).  0 = could not tell (no record blocks among the first, or the directory is not walkable).
+extern "C" int spl_bam_compression_ratio(spl_bam *bam, double *ratio_out)
+{
+    if (!bam || !ratio_out) return spl_set_error(SPL_ERR_ARG, "spl_bam_compression_ratio: null argument");
+    *ratio_out = 0.0;
+    {
+        std::lock_guard<std::mutex> lock(bam->mu);
+        if (bam->claim != 0) return SPL_OK;
+    }
+    const size_t want = 256;
+    if (bam->dir.state.load() == 0 && bam->dir.n_ready.load() < want)
+        walk_blocks(bam->dir, (const uint8_t *)bam->map, bam->fsize, bam->path.c_str(), want - bam->dir.n_ready.load());
+    if (bam->dir.state.load() < 0) return SPL_OK; // (the decoder will report what is wrong with the file)
+    uint64_t in = 0, out = 0;
+    const size_t n = std::min(want, bam->dir.n_ready.load());
+    for (size_t i = 0; i < n; ++i) {
+        const Block &b = bam->dir.at(i);
+        if (b.uoff < bam->header_bytes || b.isize == 0) continue;
+        in += b.csize;
+        out += b.isize;
+    }
+    if (in) *ratio_out = (double)out / (double)in;
+    return SPL_OK;
+}
+
 int spl_bam_walk_all(spl_bam *bam)
 {
     if (bam->dir.state.load() == 0) walk_blocks(bam->dir, (const uint8_t *)bam->map, bam->fsize, bam->path.c_str(), 0);

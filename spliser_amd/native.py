@@ -49,7 +49,7 @@ EXPORTS = [
     "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
-    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
+    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
     "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append", "spl_fmt_fixed",
     "spl_bed_open", "spl_gff_open", "spl_text_close", "spl_text_rows", "spl_text_n_chrom", "spl_text_chrom_name", "spl_text_chrom",
@@ -454,6 +454,17 @@ class BamFile(object):
         self.ref_lengths = [lib().spl_bam_ref_length(self._h, i) for i in range(len(self.ref_names))]
         self._tid = {n: i for i, n in enumerate(self.ref_names)}
         self._views = {}
+
+    def start_host_decode(self):
+        """A file opened with ``defer=True``: decode on the host's threads, from now on in the background."""
+        _check(lib().spl_bam_start(self._h))
+        self.on_device = False
+
+    def compression_ratio(self):
+        """Inflated bytes per file byte over the first record blocks (0.0 = cannot tell); ``defer=True`` files only."""
+        r = ctypes.c_double(0.0)
+        _check(lib().spl_bam_compression_ratio(self._h, ctypes.byref(r)))
+        return r.value
 
     def decode_on_device_async(self, device=0):
         """``decode_on_device`` on a thread and a context of its own, started now: the caller goes on (Steps 0-2), anybody who

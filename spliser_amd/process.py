@@ -46,6 +46,9 @@ def open_alignments(path, threads=0, stream=False, defer=False):
     raise native.SpliserNativeError(-5, "%s is neither BGZF/BAM nor SAM text" % path)
 
 
+GPU_DECODE_BELOW = 10.0     # inflated bytes per file byte below which `process` inflates on the GPU (measured cross-over: 10...20)
+
+
 class _Replan(Exception):
     """A read reaches beyond the room its chromosome was given in the shard (planned from the BAM header)."""
 
@@ -287,24 +290,31 @@ def write_tsv(output_path, table, results, is_beta2_cryptic):
 
 def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0, annotationFile=None, aType="gene",
             isStranded=False, strandedType=None, isbeta2Cryptic=False, devices=(0,), threads=0, log=_log, checkJunctions=False,
-            gpuDecode=False):
+            gpuDecode=None):
     """SpliSER_v0_1_8.py:695-720, keyword-compatible with the reference's argparse dests.
 
     ``checkJunctions`` (this build only; changes no result): also derive every chromosome's junction table from the reads on
     the GPU and write ``<outputPath>.junctionCheck.tsv`` -- BED alpha against reads in the BAM per junction -- with a warning
     for every junction the BED file gives MORE reads than the BAM holds (the two files do not belong together).
 
-    ``gpuDecode`` (this build only; changes no result): the BAM goes to the GPU as it is -- BGZF inflate, CRC32 and the
+    ``gpuDecode`` (this build only; changes no result): True = the BAM goes to the GPU as it is -- BGZF inflate, CRC32 and the
     extraction of POS / FLAG / CIGAR happen there (``spl_bam_decode_device``); files that path does not take (unsorted, CG-tag
-    CIGARs, damaged) are decoded by the host threads as without the option."""
+    CIGARs, damaged) are decoded by the host threads all the same.  False = host threads.  None (default) = by the file: on the
+    GPU when its first blocks inflate to less than GPU_DECODE_BELOW times their size (a real library's file: 3-4x, twice as fast
+    on the GPU), on the host when they inflate at memset speed (synthetic data)."""
     timings = {}
     t0 = time.perf_counter()
     # The alignment file does not depend on Steps 0-2: it is decoded on native threads while the site table is built here, and
     # goes on decoding while Step 3 counts the chromosomes that are complete.  An unreadable file is an error here already
     # (block directory and header are read by the opening call).
-    source = open_alignments(inBAM, threads=threads, stream=True, defer=bool(gpuDecode))
-    if gpuDecode and isinstance(source, native.BamFile):
-        source.decode_on_device_async(devices[0])     # (runs beside Steps 0-2, like the host decode would)
+    source = open_alignments(inBAM, threads=threads, stream=True, defer=gpuDecode is not False)
+    if isinstance(source, native.BamFile) and gpuDecode is not False:
+        # where to inflate: told by the caller, or by how the file's first blocks are compressed (GPU_DECODE_BELOW)
+        on_gpu = bool(gpuDecode) if gpuDecode is not None else 0.0 < source.compression_ratio() < GPU_DECODE_BELOW
+        if on_gpu:
+            source.decode_on_device_async(devices[0])     # (runs beside Steps 0-2, like the host decode does)
+        else:
+            source.start_host_decode()
     try:
         t_open = time.perf_counter()
         table = _site_table(inBed, qGene, qChrom, maxIntronSize, annotationFile, aType, isStranded, strandedType, log)
@@ -350,6 +360,7 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
             # (closing a decoded BAM gives gigabytes of read arrays back to the system -- a tenth of a second for 200 M reads --
             #  and nobody is waiting for that: on a thread of its own)
             threading.Thread(target=source.close).start()
+    timings["bam_decode"] = "device" if getattr(source, "on_device", False) else "host"
     timings.update(open_s=t_open - t0, site_table_s=t1 - t_open, step3_s=t3 - t1, write_tail_s=t4 - t3, write_s=writer.seconds,
                    close_s=time.perf_counter() - t4, total_s=time.perf_counter() - t0)
     return timings

@@ -37,7 +37,7 @@ for rep in range(2):
     timings = process(prefix + ".bam", prefix + ".bed", prefix + "_out", annotationFile=prefix + ".gff", log=lambda m: None,
                       isStranded=stranded, strandedType="fr" if stranded else None, isbeta2Cryptic=stranded)
     dt = time.time() - t
-    print("process wall %.2f s = %.1f M reads/s end to end; stages %s" % (dt, wl.n_reads / dt / 1e6, {k: round(v, 3) for k, v in timings.items()}))
+    print("process wall %.2f s = %.1f M reads/s end to end; stages %s" % (dt, wl.n_reads / dt / 1e6, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in timings.items()}))
     out["process_s"] = dt
     out["stages"] = timings
 from spliser_amd.junctions import junctions  # noqa: E402

@@ -24,6 +24,7 @@ ap.add_argument("--files", default="/tmp/wl_files")
 ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--devices", default="0", help="e.g. 0,0 = two contexts (and host threads) on GPU 0")
 ap.add_argument("--gpu-decode", action="store_true", help="BGZF inflate and record extraction on the GPU (process(gpuDecode=True))")
+ap.add_argument("--auto-decode", action="store_true", help="process(gpuDecode=None): by the file's compression (the product's default)")
 args = ap.parse_args()
 cfg = synth.WORKLOADS[args.workload]
 stranded = "fr" if cfg.get("paired") else None
@@ -51,7 +52,7 @@ for k in range(args.runs):
     t = time.perf_counter()
     tm = process.process(prefix + ".bam", prefix + ".bed", prefix + ".out", annotationFile=prefix + ".gff", isStranded=bool(stranded),
                          strandedType=stranded, isbeta2Cryptic=bool(stranded), log=lambda m: None,
-                         devices=tuple(int(d) for d in args.devices.split(",")), gpuDecode=args.gpu_decode)
+                         devices=tuple(int(d) for d in args.devices.split(",")), gpuDecode=None if args.auto_decode else args.gpu_decode)
     wall = time.perf_counter() - t
     print(json.dumps(dict(run=k, workload=args.workload, reads=n_reads, wall_s=round(wall, 4), reads_per_sec=round(n_reads / wall),
-                          bam_bytes=os.path.getsize(prefix + ".bam"), gpu_decode=args.gpu_decode, stages={a: round(b, 4) for a, b in tm.items()})), flush=True)
+                          bam_bytes=os.path.getsize(prefix + ".bam"), gpu_decode="auto" if args.auto_decode else args.gpu_decode, decoder=tm.pop("bam_decode", None), stages={a: round(b, 4) for a, b in tm.items()})), flush=True)
