@@ -140,3 +140,27 @@ def test_many_small_files_all_block_kinds(ctx, tmp_path):
         assert dev.n_records == n + k % 4
         dev.close()
     assert taken == 36
+
+
+@pytest.mark.parametrize("strategy", ["filtered", "huffman_only", "rle", "fixed"])
+def test_deflate_strategies(ctx, tmp_path, monkeypatch, strategy):
+    """The same records deflated the ways zlib can be told to: Huffman codes only (no matches at all), run-length matches only
+    (every distance is 1), fixed codes throughout, the 'filtered' heuristics -- block shapes an aligner's BAM never has and a
+    DEFLATE decoder must read all the same."""
+    import struct
+    import zlib
+    strat = {"filtered": zlib.Z_FILTERED, "huffman_only": zlib.Z_HUFFMAN_ONLY, "rle": zlib.Z_RLE, "fixed": zlib.Z_FIXED}[strategy]
+
+    def block(payload, level):
+        comp = zlib.compressobj(6, zlib.DEFLATED, -15, 8, strat)
+        data = comp.compress(payload) + comp.flush()
+        if len(data) + 26 > 0x10000:      # (Huffman-only output of incompressible bytes can outgrow a block: store it instead)
+            comp = zlib.compressobj(0, zlib.DEFLATED, -15)
+            data = comp.compress(payload) + comp.flush()
+        header = struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 0x42, 0x43, 2, len(data) + 25)
+        return header + data + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload) & 0xFFFFFFFF)
+    monkeypatch.setattr(samio, "_bgzf_block", block)
+    names, sets = _random_sets(31, 6_000, 2)
+    path = str(tmp_path / "s.bam")
+    samio.write_bam(path, names, [10 ** 8] * 2, [(c, sets[c]) for c in names], with_seq=True)
+    assert _both(path, ctx, names, sets) is True
