@@ -832,9 +832,18 @@ struct DevBuf {
         if (cap >= ((size_t)256 << 20)) {
             std::lock_guard<std::mutex> lock(dev_cache_mu());
             std::vector<CachedDev> &cache = dev_cache();
-            size_t mine = 0;
-            for (const CachedDev &e : cache) mine += e.device == device ? 1 : 0;
+            size_t mine = 0, smallest = cache.size();
+            for (size_t k = 0; k < cache.size(); ++k) {
+                if (cache[k].device != device) continue;
+                ++mine;
+                if (smallest == cache.size() || cache[k].bytes < cache[smallest].bytes) smallest = k;
+            }
             if (mine < 2) { cache.push_back(CachedDev{device, p, cap}); return; }
+            if (cache[smallest].bytes < cap) { // keep the two LARGEST (the image and the inflated stream): the smaller one goes
+                void *old = cache[smallest].p;
+                cache[smallest] = CachedDev{device, p, cap};
+                p = old;
+            }
         }
         (void)hipFree(p);
     }
@@ -928,23 +937,36 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
     DevBuf d_image, d_stream, d_blocks, d_status, d_scan;
     HIP_TRY(d_image.get(fsize + 64, c->copy));
     HIP_TRY(hipMemsetAsync(d_image.as<char>() + fsize, 0, 64, c->copy));
-    // the file image: page cache -> staging buffer (all packing threads) -> device, piece by piece.  (Inflating the blocks of a
-    // piece right behind it was tried: a launch of this kernel takes as long as ONE lane needs for its block whatever the
-    // number of blocks, and 44 such launches in a row took 4 s where one launch over everything takes 0.15.)
-    for (size_t off = 0; off < fsize;) {
-        spl_ctx::Stage &st = c->stage[c->stage_next];
-        c->stage_next = (c->stage_next + 1) % c->stage.size();
-        if (st.busy) { HIP_TRY(hipEventSynchronize(st.done)); st.busy = false; }
-        const size_t n = std::min(st.bytes, fsize - off);
-        CopyJob job{st.host, (const char *)image + off, n, 0, spl_bam_fd(bam), off};
-        const int copiers = std::max(1, std::min(c->pack_threads, 8)); // (memory-bound: eight threads fill a buffer as fast as 32, and leave the CPU quota alone)
-        const size_t slices = (size_t)copiers;
-        job.per = (n + slices - 1) / slices;
-        splpack::parallel_for(slices, copiers, copy_slice, &job);
-        HIP_TRY(hipMemcpyAsync(d_image.as<char>() + off, st.host, n, hipMemcpyHostToDevice, c->copy));
-        HIP_TRY(hipEventRecord(st.done, c->copy));
-        st.busy = true;
-        off += n;
+    // The file image: page cache -> staging buffer -> device.  One reader thread per staging buffer: it preads its pieces of
+    // the file (a piece = a buffer's size, dealt round-robin) and sends each on its way itself; three readers keep the copy
+    // engine busy where a loop that filled one buffer at a time with eight short-lived threads reached a third of that on a
+    // 14 GB file.  (Inflating the blocks of a piece right behind it was tried: a launch of the inflate kernel takes as long as
+    // ONE lane needs for its block whatever the number of blocks, and 44 such launches in a row took 4 s where one launch over
+    // everything takes 0.15.)
+    {
+        const size_t n_stage = c->stage.size();
+        const size_t piece = c->stage[0].bytes;
+        const size_t n_pieces = (fsize + piece - 1) / piece;
+        std::vector<hipError_t> errs(n_stage, hipSuccess);
+        const int fd = spl_bam_fd(bam);
+        char *const d_img = d_image.as<char>();
+        auto reader = [&](size_t t) {
+            if (hipSetDevice(c->device) != hipSuccess) { errs[t] = hipErrorInvalidDevice; return; }
+            spl_ctx::Stage &st = c->stage[t];
+            for (size_t k = t; k < n_pieces && errs[t] == hipSuccess; k += n_stage) {
+                if (st.busy) { errs[t] = hipEventSynchronize(st.done); st.busy = false; if (errs[t] != hipSuccess) break; }
+                const size_t off = k * piece, n = std::min(piece, fsize - off);
+                CopyJob job{st.host, (const char *)image + off, n, n, fd, off};
+                copy_slice(0, &job);
+                errs[t] = hipMemcpyAsync(d_img + off, st.host, n, hipMemcpyHostToDevice, c->copy);
+                if (errs[t] == hipSuccess) { errs[t] = hipEventRecord(st.done, c->copy); st.busy = true; }
+            }
+        };
+        std::vector<std::thread> readers;
+        for (size_t t = 1; t < n_stage; ++t) readers.emplace_back(reader, t);
+        reader(0);
+        for (std::thread &th : readers) th.join();
+        for (hipError_t e : errs) HIP_TRY(e);
     }
     const double t_loop_end = host_now();
     walker.join();
