@@ -370,6 +370,12 @@ struct spl_bam {
     int fd = -1;               // kept open for readers that want the bytes without the mapping (spl_bam_decode_device)
     BlockDir dir;
     int n_threads = 1;
+    // reads adopted from the device decoder without their host copies: fetched (dev_fetch) when somebody wants to read them
+    bool lazy = false;
+    int (*dev_fetch)(void *, int32_t **, uint16_t **, uint32_t **, uint32_t **) = nullptr;
+    std::vector<int64_t> lazy_first;       // first record of every reference in the file-wide arrays
+    void *dev_handle = nullptr;            // what the device decoder left in device memory for the device packer (spl_capi.cpp)
+    void (*dev_free)(void *) = nullptr;    // ... and how to give it back
     bool reserved = false;     // claim == 1 on behalf of a spl_bam_decode_device call that is still to come
     int claim = 0;             // 0 = nobody decodes yet (deferred open), 1 = the device decoder is at it, 2 = host worker started / arrays adopted
     uint64_t header_bytes = 0; // magic, text and reference dictionary: the first record starts here in the inflated stream
@@ -380,6 +386,7 @@ struct spl_bam {
 spl_bam::~spl_bam()
 {
     if (worker.joinable()) worker.join();
+    if (dev_handle && dev_free) dev_free(dev_handle);
     for (auto &list : parts) for (PendingPart *p : list) delete p;
     for (void *slab : slabs) free(slab);
     if (map) munmap(map, fsize);
@@ -1049,6 +1056,18 @@ void spl_bam_block_get(const spl_bam *bam, size_t i, spl_bam_block_info *out)
     out->isize = b.isize;
     out->crc = le32(file + b.coff + b.csize - 8);
 }
+void spl_bam_set_device_reads(spl_bam *bam, void *handle, void (*free_fn)(void *))
+{
+    std::lock_guard<std::mutex> lock(bam->mu);
+    if (bam->dev_handle && bam->dev_free) bam->dev_free(bam->dev_handle);
+    bam->dev_handle = handle;
+    bam->dev_free = free_fn;
+}
+void *spl_bam_device_reads(spl_bam *bam)
+{
+    std::lock_guard<std::mutex> lock(bam->mu);
+    return bam->dev_handle;
+}
 const uint8_t *spl_bam_image(const spl_bam *bam, size_t *fsize_out) { if (fsize_out) *fsize_out = bam->fsize; return (const uint8_t *)bam->map; }
 int spl_bam_fd(const spl_bam *bam) { return bam->fd; }
 uint64_t spl_bam_header_end(const spl_bam *bam) { return bam->header_bytes; }
@@ -1060,18 +1079,23 @@ int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off,
     std::lock_guard<std::mutex> lock(bam->mu);
     if (bam->claim != 1) return spl_set_error(SPL_ERR_ARG, "spl_bam_adopt: the file is not claimed by the device decoder");
     bam->claim = 2;
-    bam->slabs.push_back(pos); bam->slabs.push_back(flag); bam->slabs.push_back(cig_off); bam->slabs.push_back(cigar);
+    const bool have = pos != nullptr; // (nullptr: the arrays stay on the device until somebody asks, spl_bam_set_fetch)
+    if (have) { bam->slabs.push_back(pos); bam->slabs.push_back(flag); bam->slabs.push_back(cig_off); bam->slabs.push_back(cigar); }
+    bam->lazy = !have;
+    bam->lazy_first.assign(ref_first, ref_first + bam->n_refs);
     for (int t = 0; t < bam->n_refs; ++t) {
         if (ref_n[t] <= 0) continue;
         PendingPart *pp = new PendingPart();
         pp->tid = t;
         RefReads &r = pp->reads;
-        r.pos = pos + ref_first[t];
-        r.flag = flag + ref_first[t];
-        r.cig_off = cig_off + ref_first[t]; // (offsets into the file-wide op array: cig_off[0] of a part need not be 0)
-        r.cigar = cigar;
         r.n = (size_t)ref_n[t];
-        r.n_ops = (size_t)(r.cig_off[r.n] - r.cig_off[0]);
+        if (have) {
+            r.pos = pos + ref_first[t];
+            r.flag = flag + ref_first[t];
+            r.cig_off = cig_off + ref_first[t]; // (offsets into the file-wide op array: cig_off[0] of a part need not be 0)
+            r.cigar = cigar;
+            r.n_ops = (size_t)(r.cig_off[r.n] - r.cig_off[0]);
+        }
         r.max_end = ref_max_end[t];
         bam->parts[(size_t)t].push_back(pp);
         bam->ref_reads[(size_t)t] = ref_n[t];
@@ -1082,6 +1106,36 @@ int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off,
     bam->complete_upto = bam->n_refs;
     bam->done = true;
     bam->cv.notify_all();
+    return SPL_OK;
+}
+
+void spl_bam_set_fetch(spl_bam *bam, int (*fetch)(void *, int32_t **, uint16_t **, uint32_t **, uint32_t **))
+{
+    std::lock_guard<std::mutex> lock(bam->mu);
+    bam->dev_fetch = fetch;
+}
+
+// The host copies of reads that were adopted without them (call with bam->mu held).
+static int fetch_lazy(spl_bam *bam)
+{
+    if (!bam->lazy) return SPL_OK;
+    if (!bam->dev_fetch || !bam->dev_handle) return spl_set_error(SPL_ERR_ARG, "%s: decoded reads are neither on the host nor fetchable", bam->path.c_str());
+    int32_t *pos = nullptr; uint16_t *flag = nullptr; uint32_t *cig_off = nullptr, *cigar = nullptr;
+    const int rc = bam->dev_fetch(bam->dev_handle, &pos, &flag, &cig_off, &cigar);
+    if (rc) return rc;
+    bam->slabs.push_back(pos); bam->slabs.push_back(flag); bam->slabs.push_back(cig_off); bam->slabs.push_back(cigar);
+    for (int t = 0; t < bam->n_refs; ++t) {
+        for (PendingPart *pp : bam->parts[(size_t)t]) {
+            RefReads &r = pp->reads;
+            const int64_t first = bam->lazy_first[(size_t)t];
+            r.pos = pos + first;
+            r.flag = flag + first;
+            r.cig_off = cig_off + first;
+            r.cigar = cigar;
+            r.n_ops = (size_t)(r.cig_off[r.n] - r.cig_off[0]);
+        }
+    }
+    bam->lazy = false;
     return SPL_OK;
 }
 
@@ -1154,6 +1208,8 @@ extern "C" int spl_bam_reads(const spl_bam *cbam, int tid, spl_reads *out, int64
     int rc = spl_bam_wait_all(bam, nullptr); // (the whole file: these arrays must hold every record of the reference, sorted file or not)
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(bam->mu);
+    rc = fetch_lazy(bam);
+    if (rc) return rc;
     if (!bam->assembled[(size_t)tid]) {
         std::string err;
         if (!assemble_ref(bam, tid, err)) return spl_set_error(SPL_ERR_NOMEM, "%s: %s", bam->path.c_str(), err.c_str());
@@ -1175,6 +1231,8 @@ int spl_bam_source(spl_bam *bam, int tid, splpack::Source *out, int64_t *max_end
     int rc = spl_bam_wait_ref(bam, tid, nullptr, max_end_out);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(bam->mu);
+    rc = fetch_lazy(bam);
+    if (rc) return rc;
     for (const PendingPart *pt : bam->parts[(size_t)tid]) {
         const RefReads &r = pt->reads;
         if (r.n == 0) continue;

@@ -24,6 +24,12 @@ int spl_bam_thread_count(const spl_bam *bam);
 // free()); reference t has records [ref_first[t], ref_first[t] + ref_n[t]), cig_off holds n_total + 1 offsets into cigar.
 int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off, uint32_t *cigar, const int64_t *ref_first, const int64_t *ref_n,
                   const int64_t *ref_max_end, int64_t n_records_total);
+// what the device decoder keeps in device memory for the device packer: an opaque handle, freed with the file
+void spl_bam_set_device_reads(spl_bam *bam, void *handle, void (*free_fn)(void *));
+void *spl_bam_device_reads(spl_bam *bam);
+// spl_bam_adopt with null arrays = the reads stay on the device; `fetch(handle, ...)` brings malloc'ed host copies when a host-side
+// reader asks for them (spl_bam_source, spl_bam_reads)
+void spl_bam_set_fetch(spl_bam *bam, int (*fetch)(void *, int32_t **, uint16_t **, uint32_t **, uint32_t **));
 int spl_bam_start_host(spl_bam *bam);                      // decode on the host's threads unless somebody decodes already
 bool spl_bam_claim_for_device(spl_bam *bam);               // the device decoder takes the file (false: it is taken)
 int spl_bam_device_gives_up(spl_bam *bam);                 // ... and hands it to the host threads after all

@@ -20,6 +20,7 @@
 #include "../../include/spliser.h"
 #include "spl_bam.h"
 #include "spl_inflate.h"
+#include "spl_devpack.h"
 #include "spl_device.h"
 #include "spl_error.h"
 #include "spl_pack.h"
@@ -894,6 +895,119 @@ void copy_slice(size_t k, void *arg)
 }
 } // namespace
 
+// What spl_bam_decode_device leaves on the device: the file's placed records, BAM-native, and where each reference's are.
+struct DeviceReads {
+    int device = 0;
+    void *pos = nullptr, *flag = nullptr, *cig_off = nullptr, *cigar = nullptr;
+    int64_t n_rec = 0, n_ops = 0;
+    std::vector<int64_t> ref_first, ref_n, ref_max, ref_ops;
+};
+static void free_device_reads(void *h)
+{
+    DeviceReads *r = (DeviceReads *)h;
+    if (!r) return;
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    (void)hipSetDevice(r->device);
+    (void)hipFree(r->pos); (void)hipFree(r->flag); (void)hipFree(r->cig_off); (void)hipFree(r->cigar);
+    if (have) (void)hipSetDevice(cur);
+    delete r;
+}
+
+static void *host_array(size_t bytes) // (2 MiB-aligned, huge pages asked for: tens to hundreds of MB that are written once, front to back)
+{
+    const size_t huge = 2u << 20, size = (std::max<size_t>(bytes, 64) + huge - 1) / huge * huge;
+    void *p = nullptr;
+    if (posix_memalign(&p, huge, size) != 0) return nullptr;
+    (void)madvise(p, size, MADV_HUGEPAGE);
+    return p;
+}
+
+// Host copies of the reads a device decode left on the device (malloc'ed: the caller owns them), page-locked for the copy only.
+// Nobody asks for them while the reads are counted on the device they were decoded on; a reader on the host (spl_bam_reads) or
+// a read set on another device does, through the file (spl_bam_set_fetch), once.
+static int fetch_device_reads(void *h, int32_t **pos_out, uint16_t **flag_out, uint32_t **cigoff_out, uint32_t **cigar_out)
+{
+    const DeviceReads *r = (const DeviceReads *)h;
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    const size_t n_rec = (size_t)r->n_rec, n_ops = (size_t)r->n_ops;
+    struct Arr { void *host; const void *dev; size_t bytes; bool pinned; } arr[4] = {
+        {nullptr, r->pos, 4 * n_rec, false}, {nullptr, r->flag, 2 * n_rec, false}, {nullptr, r->cig_off, 4 * (n_rec + 1), false}, {nullptr, r->cigar, 4 * n_ops, false}};
+    bool ok = true;
+    for (Arr &a : arr) { a.host = host_array(a.bytes); ok = ok && a.host; }
+    hipError_t q = ok ? hipSetDevice(r->device) : hipSuccess;
+    hipStream_t st = nullptr;
+    if (ok && q == hipSuccess) q = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (ok && q == hipSuccess) {
+        for (Arr &a : arr) if (a.bytes >= (1u << 20)) a.pinned = hipHostRegister(a.host, a.bytes, hipHostRegisterDefault) == hipSuccess; // (locking faults the pages in)
+        for (Arr &a : arr) if (q == hipSuccess && a.bytes) q = hipMemcpyAsync(a.host, a.dev, a.bytes, hipMemcpyDeviceToHost, st);
+        if (q == hipSuccess) q = hipStreamSynchronize(st);
+        for (Arr &a : arr) if (a.pinned) (void)hipHostUnregister(a.host);
+    }
+    if (st) (void)hipStreamDestroy(st);
+    if (have) (void)hipSetDevice(cur);
+    if (!ok || q != hipSuccess) {
+        for (Arr &a : arr) free(a.host);
+        return ok ? spl_set_error(SPL_ERR_HIP, "decoded reads back to the host: %s", hipGetErrorString(q)) : spl_set_error(SPL_ERR_NOMEM, "out of host memory for the decoded reads");
+    }
+    *pos_out = (int32_t *)arr[0].host; *flag_out = (uint16_t *)arr[1].host; *cigoff_out = (uint32_t *)arr[2].host; *cigar_out = (uint32_t *)arr[3].host;
+    return SPL_OK;
+}
+
+// One more segment of a read set, packed ON THE DEVICE from reads that are there already (add_segment is the host's version).
+static int add_segment_device(spl_ctx *c, spl_dreads *d, const DeviceReads &dev, int64_t first, int64_t n_reads, int64_t n_ops, int32_t shift, int64_t max_end)
+{
+    if (d->finished) return spl_set_error(SPL_ERR_ARG, "the read set is finished: no more segments");
+    if (n_reads == 0) return SPL_OK;
+    if (d->n_reads + n_reads > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "n_reads out of range (counters are 32-bit)");
+    if (max_end >= 0 && max_end + (int64_t)shift > (int64_t)SPL_COORD_MAX)
+        return spl_set_error(SPL_ERR_RANGE, "a read ends beyond coordinate %d once its segment is moved by %d: split the shard (spliser_amd/shard.py)",
+                             SPL_COORD_MAX, shift);
+    int rc = ensure_stage(c);
+    if (rc) return rc;
+    const uint32_t chunk = 1u << d->chunk_shift;
+    const size_t n_chunks = (size_t)((n_reads + chunk - 1) / chunk);
+    if ((uint64_t)d->n_chunks + n_chunks > (1ull << (32 - d->chunk_shift))) return spl_set_error(SPL_ERR_ARG, "too many reads in one read set: use more shards");
+    const spl_devreads src{(const int32_t *)dev.pos, (const uint16_t *)dev.flag, (const uint32_t *)dev.cig_off, (const uint32_t *)dev.cigar};
+    splpack::ChunkDesc *d_descs = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_descs, sizeof(splpack::ChunkDesc) * n_chunks));
+    std::vector<splpack::ChunkDesc> descs(n_chunks);
+    hipError_t q = (hipError_t)spl_dev_launch_pack_count(&src, first, n_reads, chunk, d_descs, c->copy);
+    if (q == hipSuccess) q = hipMemcpyAsync(descs.data(), d_descs, sizeof(splpack::ChunkDesc) * n_chunks, hipMemcpyDeviceToHost, c->copy);
+    if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
+    if (q != hipSuccess) { (void)hipFree(d_descs); return spl_set_error(SPL_ERR_HIP, "device packer (sizes): %s", hipGetErrorString(q)); }
+    uint64_t rec = 0, wide = 0; // sizes -> offsets, as splpack::plan does
+    for (splpack::ChunkDesc &cd : descs) {
+        const uint64_t bytes = cd.rec_off, ops = cd.wide_off;
+        cd.rec_off = rec;
+        cd.wide_off = wide;
+        rec += bytes;
+        wide += ops;
+    }
+    if (wide > 0xfffffff0ull) { (void)hipFree(d_descs); return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops of wide reads in one segment: use more shards"); }
+    d->segs.emplace_back();
+    spl_dreads::Segment &seg = d->segs.back();
+    seg.rec_bytes = rec; seg.n_wide = wide; seg.n_reads = n_reads; seg.n_ops = n_ops; seg.shift = shift;
+    const size_t rec_al = align_up((size_t)rec);
+    const size_t slab_bytes = rec_al + 4 * (size_t)wide + 256;
+    q = hipMalloc((void **)&seg.slab, slab_bytes);
+    if (q == hipSuccess) q = hipMemcpyAsync(d_descs, descs.data(), sizeof(splpack::ChunkDesc) * n_chunks, hipMemcpyHostToDevice, c->copy);
+    if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack_emit(&src, first, n_reads, chunk, d_descs, seg.slab, seg.slab + rec_al, c->copy);
+    if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
+    (void)hipFree(d_descs);
+    if (q != hipSuccess) {
+        if (seg.slab) (void)hipFree(seg.slab);
+        d->segs.pop_back();
+        return spl_set_error(SPL_ERR_HIP, "device packer: %s", hipGetErrorString(q));
+    }
+    seg.chunks.swap(descs);
+    d->n_reads += n_reads;
+    d->n_cigar += n_ops;
+    d->n_chunks += (uint32_t)n_chunks;
+    return SPL_OK;
+}
+
 static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out);
 
 extern "C" int spl_bam_decode_device(spl_ctx *c, spl_bam *bam, int *on_device_out)
@@ -1060,58 +1174,57 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
     HIP_TRY((hipError_t)spl_dev_launch_bam_extract(d_stream.as<uint8_t>(), stream_len, n_ref, d_blocks.as<spl_zblock>(), (uint32_t)n_blocks, d_scan.as<spl_bscan>(),
                                                    d_recoff.as<uint64_t>(), d_opoff.as<uint64_t>(), d_pos.as<int32_t>(), d_flag.as<uint16_t>(), d_cigoff.as<uint32_t>(),
                                                    d_cigar.as<uint32_t>(), d_tid.as<int32_t>(), d_maxend.as<unsigned long long>(), c->copy));
-    HIP_TRY((hipError_t)spl_dev_launch_bam_bounds(d_tid.as<int32_t>(), n_rec, d_bounds.as<uint64_t>(), d_nbounds.as<uint32_t>(), cap, c->copy));
+    HIP_TRY((hipError_t)spl_dev_launch_bam_bounds(d_tid.as<int32_t>(), d_cigoff.as<uint32_t>(), n_rec, d_bounds.as<uint64_t>(), d_nbounds.as<uint32_t>(), cap, c->copy));
     if (timing) { HIP_TRY(hipStreamSynchronize(c->copy)); stamp("extraction kernels"); }
-    // results into page-locked host arrays (registered for the copy, released again: the file keeps them as ordinary memory)
-    auto host_array = [&](size_t bytes) -> void * {
-        const size_t huge = 2u << 20, size = (std::max<size_t>(bytes, 64) + huge - 1) / huge * huge;
-        void *p = nullptr;
-        if (posix_memalign(&p, huge, size) != 0) return nullptr;
-        (void)madvise(p, size, MADV_HUGEPAGE);
-        return p;
-    };
-    int32_t *h_pos = (int32_t *)host_array(4 * n_rec);
-    uint16_t *h_flag = (uint16_t *)host_array(2 * n_rec);
-    uint32_t *h_cigoff = (uint32_t *)host_array(4 * (n_rec + 1));
-    uint32_t *h_cigar = (uint32_t *)host_array(4 * n_ops);
-    struct Pin { void *p; size_t n; bool on; } pins[4] = {{h_pos, 4 * n_rec, false}, {h_flag, 2 * n_rec, false}, {h_cigoff, 4 * (n_rec + 1), false}, {h_cigar, 4 * n_ops, false}};
-    auto release = [&](bool free_too) {
-        for (Pin &pn : pins) { if (pn.on) (void)hipHostUnregister(pn.p); pn.on = false; if (free_too) free(pn.p); }
-    };
-    if (!h_pos || !h_flag || !h_cigoff || !h_cigar) { release(true); return spl_set_error(SPL_ERR_NOMEM, "out of host memory for the decoded reads"); }
-    for (Pin &pn : pins) {
-        if (pn.n >= (1u << 20)) pn.on = hipHostRegister(pn.p, pn.n, hipHostRegisterDefault) == hipSuccess; // (locking faults the pages in)
-    }
-    stamp("host arrays allocated and locked");
     std::vector<unsigned long long> maxend((size_t)std::max(n_ref, 1));
     std::vector<uint64_t> bounds(2 * (size_t)cap);
     uint32_t n_bounds = 0;
-    hipError_t q = hipSuccess;
-    if (n_rec) q = hipMemcpyAsync(h_pos, d_pos.p, 4 * n_rec, hipMemcpyDeviceToHost, c->copy);
-    if (q == hipSuccess && n_rec) q = hipMemcpyAsync(h_flag, d_flag.p, 2 * n_rec, hipMemcpyDeviceToHost, c->copy);
-    if (q == hipSuccess) q = hipMemcpyAsync(h_cigoff, d_cigoff.p, 4 * (n_rec + 1), hipMemcpyDeviceToHost, c->copy);
-    if (q == hipSuccess && n_ops) q = hipMemcpyAsync(h_cigar, d_cigar.p, 4 * n_ops, hipMemcpyDeviceToHost, c->copy);
-    if (q == hipSuccess) q = hipMemcpyAsync(maxend.data(), d_maxend.p, 8 * maxend.size(), hipMemcpyDeviceToHost, c->copy);
-    if (q == hipSuccess) q = hipMemcpyAsync(bounds.data(), d_bounds.p, 16 * (size_t)cap, hipMemcpyDeviceToHost, c->copy);
-    if (q == hipSuccess) q = hipMemcpyAsync(&n_bounds, d_nbounds.p, 4, hipMemcpyDeviceToHost, c->copy);
-    if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
-    release(false);
-    if (q != hipSuccess) { release(true); return spl_set_error(SPL_ERR_HIP, "BAM decode on the device: %s", hipGetErrorString(q)); }
-    stamp("results to the host");
-    if (n_bounds > cap) { release(true); return to_host("not sorted by reference"); }
-    std::vector<std::pair<uint64_t, int32_t>> runs;
-    for (uint32_t k = 0; k < n_bounds; ++k) runs.emplace_back(bounds[2 * k], (int32_t)(uint32_t)bounds[2 * k + 1]);
-    std::sort(runs.begin(), runs.end());
-    std::vector<int64_t> ref_first((size_t)std::max(n_ref, 1), 0), ref_n((size_t)std::max(n_ref, 1), 0), ref_max((size_t)std::max(n_ref, 1), 0);
+    HIP_TRY(hipMemcpyAsync(maxend.data(), d_maxend.p, 8 * maxend.size(), hipMemcpyDeviceToHost, c->copy));
+    HIP_TRY(hipMemcpyAsync(bounds.data(), d_bounds.p, 16 * (size_t)cap, hipMemcpyDeviceToHost, c->copy));
+    HIP_TRY(hipMemcpyAsync(&n_bounds, d_nbounds.p, 4, hipMemcpyDeviceToHost, c->copy));
+    HIP_TRY(hipStreamSynchronize(c->copy));
+    stamp("reference boundaries to the host");
+    if (n_bounds > cap) return to_host("not sorted by reference");
+    struct Run { uint64_t first; int32_t tid; uint32_t op; };
+    std::vector<Run> runs;
+    for (uint32_t k = 0; k < n_bounds; ++k) runs.push_back(Run{bounds[2 * k], (int32_t)(uint32_t)bounds[2 * k + 1], (uint32_t)(bounds[2 * k + 1] >> 32)});
+    std::sort(runs.begin(), runs.end(), [](const Run &a, const Run &b) { return a.first < b.first; });
+    const size_t nr = (size_t)std::max(n_ref, 1);
+    // The records stay where they are, BAM-native in device memory: a read set on this device is laid out from them by kernels
+    // (spl_devpack.hip), and the host gets copies only if somebody asks the file for them (fetch_device_reads).
+    DeviceReads *keep = new (std::nothrow) DeviceReads();
+    if (!keep) return spl_set_error(SPL_ERR_NOMEM, "out of host memory");
+    keep->device = c->device;
+    keep->n_rec = (int64_t)n_rec; keep->n_ops = (int64_t)n_ops;
+    keep->ref_first.assign(nr, 0); keep->ref_n.assign(nr, 0); keep->ref_max.assign(nr, 0); keep->ref_ops.assign(nr, 0);
     for (size_t k = 0; k < runs.size(); ++k) {
-        const int32_t t = runs[k].second;
-        if (t < 0 || t >= n_ref || (k && t <= runs[k - 1].second)) { release(true); return to_host("not sorted by reference"); }
-        ref_first[(size_t)t] = (int64_t)runs[k].first;
-        ref_n[(size_t)t] = (int64_t)((k + 1 < runs.size() ? runs[k + 1].first : n_rec) - runs[k].first);
-        ref_max[(size_t)t] = (int64_t)maxend[(size_t)t];
+        const int32_t t = runs[k].tid;
+        if (t < 0 || t >= n_ref || (k && t <= runs[k - 1].tid)) { delete keep; return to_host("not sorted by reference"); }
+        const bool last = k + 1 == runs.size();
+        keep->ref_first[(size_t)t] = (int64_t)runs[k].first;
+        keep->ref_n[(size_t)t] = (int64_t)((last ? n_rec : runs[k + 1].first) - runs[k].first);
+        keep->ref_ops[(size_t)t] = (int64_t)((last ? n_ops : (uint64_t)runs[k + 1].op) - runs[k].op);
+        keep->ref_max[(size_t)t] = (int64_t)maxend[(size_t)t];
     }
-    rc = spl_bam_adopt(bam, h_pos, h_flag, h_cigoff, h_cigar, ref_first.data(), ref_n.data(), ref_max.data(), n_all);
-    if (rc) { release(true); return rc; }
+    const bool eager = getenv("SPL_NO_DEVICE_PACK") != nullptr; // (the round-trip this replaces, for A/B: host copies now, nothing kept here)
+    keep->pos = d_pos.p; keep->flag = d_flag.p; keep->cig_off = d_cigoff.p; keep->cigar = d_cigar.p;
+    if (eager) {
+        int32_t *h_pos = nullptr; uint16_t *h_flag = nullptr; uint32_t *h_cigoff = nullptr, *h_cigar = nullptr;
+        rc = fetch_device_reads(keep, &h_pos, &h_flag, &h_cigoff, &h_cigar);
+        if (rc == SPL_OK) {
+            stamp("results to the host");
+            rc = spl_bam_adopt(bam, h_pos, h_flag, h_cigoff, h_cigar, keep->ref_first.data(), keep->ref_n.data(), keep->ref_max.data(), n_all);
+            if (rc) { free(h_pos); free(h_flag); free(h_cigoff); free(h_cigar); }
+        }
+        delete keep; // (the device arrays go back with the DevBufs)
+        if (rc) return rc;
+    } else {
+        d_pos.p = d_flag.p = d_cigoff.p = d_cigar.p = nullptr; // (the file owns them from here)
+        spl_bam_set_device_reads(bam, keep, free_device_reads);
+        spl_bam_set_fetch(bam, fetch_device_reads);
+        rc = spl_bam_adopt(bam, nullptr, nullptr, nullptr, nullptr, keep->ref_first.data(), keep->ref_n.data(), keep->ref_max.data(), n_all);
+        if (rc) { spl_bam_set_device_reads(bam, nullptr, nullptr); return rc; }
+    }
     if (on_device_out) *on_device_out = 1;
     if (timing) fprintf(stderr, "[spl_bam_decode_device] %zu blocks, %.1f MB -> %.1f MB inflated, %llu placed records of %lld: %.4f s\n", n_blocks, fsize / 1e6,
                         stream_len / 1e6, (unsigned long long)n_rec, (long long)n_all, host_now() - t_begin);
@@ -1271,9 +1384,18 @@ extern "C" int spl_reads_add_bam(spl_ctx *c, spl_dreads *d, spl_bam *bam, int ti
 {
     if (!c || !d || !bam) return spl_set_error(SPL_ERR_ARG, "spl_reads_add_bam: null argument");
     HIP_TRY(hipSetDevice(c->device));
+    int rc = spl_bam_wait_ref(bam, tid, nullptr, nullptr);
+    if (rc) return rc;
+    if (const DeviceReads *dev = (const DeviceReads *)spl_bam_device_reads(bam)) {
+        // decoded on this device, and the arrays are still there: laid out there, nothing crosses PCIe
+        if (dev->device == c->device && tid >= 0 && (size_t)tid < dev->ref_n.size()) {
+            const size_t t = (size_t)tid;
+            return add_segment_device(c, d, *dev, dev->ref_first[t], dev->ref_n[t], dev->ref_ops[t], pos_shift, dev->ref_n[t] ? dev->ref_max[t] : -1);
+        }
+    }
     splpack::Source src;
     int64_t max_end = 0;
-    int rc = spl_bam_source(bam, tid, &src, &max_end);
+    rc = spl_bam_source(bam, tid, &src, &max_end); // (the views are what the host packer reads; reads that stayed on another device come to the host here)
     if (rc) return rc;
     return add_segment(c, d, src, pos_shift, max_end);
 }

@@ -64,7 +64,7 @@ int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream_len, int32
                                const uint64_t *rec_off, const uint64_t *op_off, int32_t *pos, uint16_t *flag, uint32_t *cig_off, uint32_t *cigar,
                                int32_t *tid, unsigned long long *ref_max_end, void *stream_handle);
 // where the reference id changes along the placed records: (index of the first record of a run, its tid) pairs, unordered
-int spl_dev_launch_bam_bounds(const int32_t *tid, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap, void *stream_handle);
+int spl_dev_launch_bam_bounds(const int32_t *tid, const uint32_t *cig_off, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap, void *stream_handle);
 // image: the whole file in device memory, padded with 8 readable bytes.  stream: the stream to launch on.
 int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *stream);
 int spl_dev_launch_crc32(const uint8_t *out, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *stream);

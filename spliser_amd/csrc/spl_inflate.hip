@@ -477,13 +477,14 @@ __global__ __launch_bounds__(64) void spl_bam_extract_kernel(const uint8_t *stre
     if (run_tid >= 0) atomicMax(&ref_max_end[run_tid], (unsigned long long)run_end);
 }
 
-__global__ __launch_bounds__(256) void spl_bam_bounds_kernel(const int32_t *tid, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap)
+// Where every reference's records begin: (first record, tid | first CIGAR op << 32) per run of equal tids, in no particular order.
+__global__ __launch_bounds__(256) void spl_bam_bounds_kernel(const int32_t *tid, const uint32_t *cig_off, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     if (i == 0 || tid[i] != tid[i - 1]) {
         const uint32_t k = atomicAdd(n_bounds, 1u);
-        if (k < cap) { bounds[2 * k] = i; bounds[2 * k + 1] = (uint64_t)(uint32_t)tid[i]; }
+        if (k < cap) { bounds[2 * k] = i; bounds[2 * k + 1] = (uint64_t)(uint32_t)tid[i] | ((uint64_t)cig_off[i] << 32); }
     }
 }
 
@@ -505,10 +506,10 @@ extern "C" int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream
     return (int)hipGetLastError();
 }
 
-extern "C" int spl_dev_launch_bam_bounds(const int32_t *tid, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap, void *st)
+extern "C" int spl_dev_launch_bam_bounds(const int32_t *tid, const uint32_t *cig_off, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap, void *st)
 {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(spl_bam_bounds_kernel, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, (hipStream_t)st, tid, n, bounds, n_bounds, cap);
+    hipLaunchKernelGGL(spl_bam_bounds_kernel, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, (hipStream_t)st, tid, cig_off, n, bounds, n_bounds, cap);
     return (int)hipGetLastError();
 }
 

@@ -96,6 +96,85 @@ struct spl_chunk_meta {
     uint16_t n[SPL_RC_RUNS];
 };
 
+// One read -> its record: shared by the host packer (spl_pack.cpp) and the device packer (spl_devpack.hip), so that a read set
+// packed on either side is the same bytes.
+namespace splrec {
+SPL_PACK_HD uint32_t kind_of(uint32_t op) { return (SPL_KIND_TABLE >> (2u * (op & 15u))) & 3u; }
+
+struct Rec {
+    uint32_t run;   // SPL_RC_SIMPLE .. SPL_RC_OTHER
+    uint32_t w[6];  // the record's words (as many as the run's record size says)
+    uint32_t n_wide; // ops that go to the wide array (WIDE reads: all of them)
+    uint32_t weight;
+};
+
+// What checkBam's walk depends on (:436-559), in the form the range kernel wants it.  One read.
+SPL_PACK_HD void classify(int32_t pos, uint32_t flag, const uint32_t *ops, uint32_t n_all, uint32_t wide_index, Rec &r)
+{
+    uint32_t n = n_all;
+    uint32_t c5[5] = {0xfu, 0xfu, 0xfu, 0xfu, 0xfu}; // the first five reference-consuming ops
+    uint32_t m = 0xffffffffu;                        // their number, if the CIGAR was short enough to look
+    uint32_t w0 = 0xfu, w1 = 0xfu, w2 = 0xfu;
+    if (n_all <= (uint32_t)SPL_PACK_SCAN_OPS) {
+        m = 0;
+        for (uint32_t k = 0; k < n_all; ++k) {
+            const uint32_t op = ops[k];
+            if (kind_of(op) == 0u) continue;
+            if (m < 5u) c5[m] = op;
+            ++m;
+        }
+        if (m <= 3u) { n = m; w0 = c5[0]; w1 = c5[1]; w2 = c5[2]; }
+    }
+    const bool wide = n > 3u;
+    if (wide) { w0 = ops[0]; w1 = ops[1]; w2 = wide_index; n = n_all; }
+    const bool placed = !(flag & 4u) && pos >= 0;
+    const int64_t room = (int64_t)SPL_COORD_MAX - (int64_t)pos;
+    r.n_wide = 0;
+    if (placed && !wide) {
+        if (n == 1u && kind_of(w0) == 1u && (w0 >> 4) < 65536u && (int64_t)(w0 >> 4) <= room) {
+            r.run = SPL_RC_SIMPLE;
+            r.w[0] = (uint32_t)pos;
+            r.w[1] = flag | ((w0 >> 4) << 16);
+            r.weight = SPL_W_SIMPLE;
+            return;
+        }
+        if (n == 3u && kind_of(w0) == 1u && kind_of(w1) == 2u && kind_of(w2) == 1u && (w0 >> 4) < 65536u &&
+            (int64_t)(w0 >> 4) + (int64_t)(w1 >> 4) + (int64_t)(w2 >> 4) <= room) {
+            r.run = SPL_RC_MNM;
+            r.w[0] = (uint32_t)pos;
+            r.w[1] = flag | ((w0 >> 4) << 16);
+            r.w[2] = w1 >> 4;
+            r.w[3] = w2 >> 4;
+            r.weight = SPL_W_MNM;
+            return;
+        }
+    }
+    if (placed && m == 5u) { // twice-spliced: five lengths
+        const uint32_t la = c5[0] >> 4, d1 = c5[1] >> 4, lb = c5[2] >> 4, d2 = c5[3] >> 4, lc = c5[4] >> 4;
+        if (kind_of(c5[0]) == 1u && kind_of(c5[1]) == 2u && kind_of(c5[2]) == 1u && kind_of(c5[3]) == 2u && kind_of(c5[4]) == 1u &&
+            la < 65536u && lb < 65536u && lc < 65536u && (int64_t)la + d1 + lb + d2 + lc <= room) {
+            r.run = SPL_RC_M2;
+            r.w[0] = (uint32_t)pos;
+            r.w[1] = flag | (la << 16);
+            r.w[2] = d1;
+            r.w[3] = lb | (lc << 16);
+            r.w[4] = d2;
+            r.w[5] = 0u;
+            r.weight = SPL_W_M2;
+            return;
+        }
+    }
+    r.run = SPL_RC_OTHER;
+    r.w[0] = (uint32_t)pos;
+    r.w[1] = flag | ((n < SPL_NOPS_SAT ? n : SPL_NOPS_SAT) << 16) | ((wide ? SPL_RC_WIDE : SPL_RC_NARROW) << SPL_RC_SHIFT);
+    r.w[2] = w0; r.w[3] = w1; r.w[4] = w2;
+    r.w[5] = n;
+    r.n_wide = wide ? n_all : 0u;
+    r.weight = wide ? SPL_W_WIDE : SPL_W_NARROW;
+}
+
+} // namespace splrec
+
 #include <stddef.h>
 
 #include <vector>
