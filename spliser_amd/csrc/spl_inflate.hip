@@ -6,8 +6,15 @@
 
 namespace {
 
+// (pointers into the file image say "global memory" in their type: the image's address goes through an integer to be aligned,
+// after which the compiler no longer knows, and a FLAT load counts as an LDS operation too -- every wait for a table look-up
+// would then wait for the read-ahead word as well, a trip to memory on the dependent chain of the symbols)
+typedef const __attribute__((address_space(1))) uint32_t *gptr32;
+typedef const __attribute__((address_space(1))) uint8_t *gptr8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 struct BitReader {
-    const uint32_t *p;   // the word after `ahead`
+    gptr32 p;            // the word after `ahead`
     const uint8_t *end;  // one past the block's DEFLATE data
     uint64_t buf;
     uint32_t cnt;        // valid bits in buf
@@ -16,7 +23,7 @@ struct BitReader {
     {
         end = e;
         const uintptr_t a = (uintptr_t)at;
-        p = (const uint32_t *)(a & ~(uintptr_t)3);
+        p = (gptr32)(a & ~(uintptr_t)3);
         const uint32_t skip = (uint32_t)(a & 3u) * 8u;
         buf = (uint64_t)(*p++) >> skip;
         cnt = 32u - skip;
@@ -34,13 +41,15 @@ struct BitReader {
 };
 
 // A canonical Huffman table, decoded without a loop over code lengths: limit[len] = the first 15-bit left-justified code value
-// that is NOT a code of `len` bits or fewer (non-decreasing in len), so the length of the code at the head of the bit buffer is
-// 1 + the number of limits its left-justified value has reached -- fourteen compares, no branch.  The same compares collect the
-// largest limit reached (= the first code of the found length, left-justified) and the number of symbols with shorter codes:
-// the symbol's place in the table's array follows without a look-up.  Limits and counts live in registers, two per word.
-struct Counts {
-    uint32_t w[8]; // limit[len] = (w[len >> 1] >> (16 * (len & 1))) & 0xffff, len = 1..15
-    uint32_t n[8]; // count[len], packed the same way
+// that is NOT a code of `len` bits or fewer (non-decreasing in len, limit[0] = 0), so the length of the code at the head of the
+// bit buffer is the number of limits its left-justified value has reached.  Two limits to a word, both compared by ONE
+// subtraction: with v < 0x8000 and limits <= 0x8000, (0x8000 + v - limit) has bit 15 set exactly when v >= limit and never
+// borrows from its neighbour -- eight subtractions, eight masked population counts.  The symbol's place in the table's array
+// is base[len] + (v >> (15 - len)), base[len] = (symbols with shorter codes) - (first code of that length): one value per
+// length, picked from eight more registers.
+struct Table {
+    uint32_t w[8]; // limit[len] = (w[len >> 1] >> (16 * (len & 1))) & 0xffff, len = 0..15
+    uint32_t b[8]; // base[len] as int16, packed the same way
 };
 
 // The symbols of a lane's tables live in LDS, entry-major (entry e of lane l at [e * 64 + l]): a look-up is a ds_read instead
@@ -65,9 +74,9 @@ struct LdsSyms {
     }
 };
 
-__device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Counts &c, const LdsSyms &symbol)
+__device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Table &c, const LdsSyms &symbol)
 {
-    uint16_t count[16], offs[16], limit[16];
+    uint16_t count[16], offs[16], limit[16], base[16];
 #pragma unroll
     for (int l = 0; l < 16; ++l) count[l] = 0;
     for (int s = 0; s < n; ++s) count[lengths[s]]++;
@@ -86,14 +95,16 @@ __device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Count
     for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
     int code = 0;
     limit[0] = 0;
+    base[0] = 0;
 #pragma unroll
     for (int l = 1; l < 16; ++l) {
+        base[l] = (uint16_t)((int)offs[l] - code); // (code = the first code of length l)
         code += (int)count[l];
         limit[l] = (uint16_t)(code << (15 - l)); // (<= 0x8000: the set is not over-subscribed)
         code <<= 1;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) c.n[k] = (uint32_t)count[2 * k] | ((uint32_t)count[2 * k + 1] << 16);
+    for (int k = 0; k < 8; ++k) c.b[k] = (uint32_t)base[2 * k] | ((uint32_t)base[2 * k + 1] << 16);
     for (int s = 0; s < n; ++s)
         if (lengths[s]) symbol.set(offs[lengths[s]]++, s);
 #pragma unroll
@@ -101,29 +112,38 @@ __device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Count
     return true;
 }
 
-// One symbol.  -1: no code matches (corrupt data, or an incomplete table was asked for a code it does not have).
-__device__ __forceinline__ int decode_symbol(BitReader &br, const Counts &c, const LdsSyms &symbol)
+// One symbol from the bits in the buffer (the caller has refilled it: 15 bits at most).  -1: no code matches (corrupt data,
+// or an incomplete table was asked for a code it does not have).
+__device__ __forceinline__ int decode_symbol(BitReader &br, const Table &c, const LdsSyms &symbol)
 {
-    br.refill();
     const uint32_t v = __brev((uint32_t)br.buf) >> 17; // the next 15 bits, first bit on top: codes are packed from their top bit
-    uint32_t len = 1, below = 0, shorter = 0; // below = limit[len - 1], shorter = symbols with codes shorter than len
+    const uint32_t vv = v * 0x10001u + 0x80008000u;
+    uint32_t len = 0;
 #pragma unroll
-    for (int l = 1; l <= 14; ++l) {
-        const uint32_t lim = (c.w[l >> 1] >> (16 * (l & 1))) & 0xffffu, cnt = (c.n[l >> 1] >> (16 * (l & 1))) & 0xffffu;
-        const bool ge = v >= lim;
-        len += ge ? 1u : 0u;
-        below = ge ? lim : below;
-        shorter += ge ? cnt : 0u;
-    }
-    if (v >= ((c.w[7] >> 16) & 0xffffu)) return -1;
+    for (int k = 0; k < 8; ++k) len += (uint32_t)__popc((vv - c.w[k]) & 0x80008000u);
+    if (len > 15u) return -1; // (v >= limit[15])
+    const uint32_t i = len >> 1;
+    const uint32_t x0 = (i & 1u) ? c.b[1] : c.b[0], x1 = (i & 1u) ? c.b[3] : c.b[2], x2 = (i & 1u) ? c.b[5] : c.b[4], x3 = (i & 1u) ? c.b[7] : c.b[6];
+    const uint32_t y0 = (i & 2u) ? x1 : x0, y1 = (i & 2u) ? x3 : x2;
+    const uint32_t z = (i & 4u) ? y1 : y0;
+    const int base = (int)(int16_t)(uint16_t)(z >> (16u * (len & 1u)));
     br.drop(len);
-    return symbol.get((int)(shorter + ((v - below) >> (15u - len))));
+    return symbol.get(base + (int)(v >> (15u - len)));
 }
 
-__constant__ uint16_t k_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t k_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t k_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t k_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+// Length symbol 257 + i -> (base, extra bits); distance symbol -> the same (RFC 1951, 3.2.5), by arithmetic: the tables would be
+// a trip to LDS on the symbol's dependent chain.
+__device__ __forceinline__ void length_code(uint32_t i, uint32_t &base, uint32_t &extra)
+{
+    extra = i < 8u || i == 28u ? 0u : (i >> 2) - 1u;
+    base = i < 4u ? 3u + i : (i == 28u ? 258u : 3u + ((4u + (i & 3u)) << extra));
+}
+__device__ __forceinline__ void distance_code(uint32_t i, uint32_t &base, uint32_t &extra)
+{
+    extra = i < 4u ? 0u : (i >> 1) - 1u;
+    base = i < 2u ? 1u + i : 1u + ((2u + (i & 1u)) << extra);
+}
+
 __constant__ uint8_t k_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 } // namespace
@@ -135,11 +155,6 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
     // distance table's place while the lengths are being read
     __shared__ uint8_t s_sym[(288 + 32) * 64];
     __shared__ uint32_t s_hi[9 * 64];
-    __shared__ uint16_t s_base[64]; // length and distance bases / extra bits: {len_base[29], dist_base[30]} packed below
-    __shared__ uint8_t s_extra[64];
-    if (threadIdx.x < 29) { s_base[threadIdx.x] = k_len_base[threadIdx.x]; s_extra[threadIdx.x] = k_len_extra[threadIdx.x]; }
-    if (threadIdx.x >= 32 && threadIdx.x < 62) { s_base[threadIdx.x] = k_dist_base[threadIdx.x - 32]; s_extra[threadIdx.x] = k_dist_extra[threadIdx.x - 32]; }
-    __syncthreads();
     const LdsSyms lsym{s_sym + threadIdx.x, s_hi + threadIdx.x}, dsym{s_sym + 288 * 64 + threadIdx.x, nullptr};
     if (b >= n_blocks) return;
     const spl_zblock zb = blocks[b];
@@ -151,7 +166,7 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
     BitReader br;
     br.init(image + zb.in, image + zb.in + zb.in_len);
     uint8_t lengths[320];
-    Counts lc, dc;
+    Table lc, dc;
     uint64_t window = 0; // the last eight bytes of the output, the most recent one on top
     for (int last = 0; !last && err == SPL_Z_OK;) {
         br.refill();
@@ -189,11 +204,12 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
 #pragma unroll
             for (int i = 0; i < 19; ++i) cl[i] = 0;
             for (int i = 0; i < ncode; ++i) { br.refill(); cl[k_clen_order[i]] = (uint8_t)br.take(3); }
-            Counts cc;
+            Table cc;
             const LdsSyms csym = dsym;
             if (!build_table(cl, 19, cc, csym)) { err = SPL_Z_BAD_LENGTHS; break; }
             int idx = 0;
             while (idx < nlen + ndist) {
+                br.refill();
                 const int sym = decode_symbol(br, cc, csym);
                 if (sym < 0) { err = SPL_Z_BAD_CODE; break; }
                 if (sym < 16) { lengths[idx++] = (uint8_t)sym; continue; }
@@ -217,87 +233,123 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
             if (!build_table(lengths + nlen, ndist, dc, dsym)) { err = SPL_Z_BAD_LENGTHS; break; }
         }
         // The symbols of the block, as a state machine that does ONE small thing per turn -- a literal/length symbol, a distance
-        // symbol, or eight bytes of a pending copy.  The 64 lanes of a wave take their turns together: a loop that finished a
+        // symbol, or a piece of a pending copy.  The 64 lanes of a wave take their turns together: a loop that finished a
         // 258-byte copy before looking at the next symbol would make 63 lanes wait for the longest copy among them at every
-        // step (that version ran at a twelfth of this one's speed).  `window` = the last eight bytes written: a copy at a distance
-        // of eight or less is made from it without reading anything back.
-        uint32_t copy_left = 0, copy_dist = 0;
-        int want_dist = 0;
+        // step (that version ran at a twelfth of this one's speed).
+        //
+        // A turn has a memory half and a decoding half, and nothing in a turn waits for memory it has asked for itself:
+        // what the memory half asks for -- the next word of the block, the source bytes of a copy -- is used by the memory
+        // half of the NEXT turn, and what the decoding half produces -- a literal -- is stored by the next turn's memory half.
+        // The wave's one wait per turn is then for operations issued a whole symbol decode earlier, instead of a round trip to
+        // the L2 after every load and an acknowledged store before every refill (62 % of the kernel's time, by SQ_WAIT_ANY).
+        // `window` = the last eight bytes of the output: a copy at a distance of eight or less is made from it, no load at all.
+        uint32_t copy_left = 0, copy_dist = 0, want_dist = 0;
+        uint32_t lit = 0;
+        bool lit_pending = false, loaded = false, wide = false;
+        uint64_t w0 = 0; // eight source bytes of a copy, or
+        u32x4 wa = {0, 0, 0, 0}, wb = {0, 0, 0, 0}; // thirty-two
+        const gptr8 stop = (gptr8)(br.end + 24); // (the read-ahead runs 12 bytes past what has been consumed: beyond this, the data is corrupt)
         for (uint32_t turns = 0;; ++turns) {
-            if (turns > 2u * out_len + 4096u || br.pos() > br.end + 12) { err = SPL_Z_OVERRUN; break; }
+            // the turn's one wait for memory: everything the previous turn asked for, asked for before its decoding half.
+            // (Said to the compiler as a use of all of it, here: left to itself it waits where each value is first touched, for
+            // everything in flight at that point -- this turn's stores and loads included.)
+            asm volatile("" : "+v"(w0), "+v"(wa), "+v"(wb), "+v"(br.ahead));
+            if (turns > 2u * out_len + 4096u || (gptr8)br.p > stop) { err = SPL_Z_OVERRUN; break; }
+            br.refill(); // (33 bits or more after this: a symbol and its extra bits are 28 at most)
+            // ---- the memory half: stores first (they may be what the loads after them read), then the loads
+            if (lit_pending) { out[at - 1u] = (uint8_t)lit; lit_pending = false; }
             if (copy_left) {
-                if (copy_dist >= 32u && copy_left >= 32u) {
-                    // far enough back and long enough: 32 bytes a turn, four independent loads, then four stores (a turn costs
-                    // a round trip to the L2 for what this lane wrote earlier -- make the trip carry more)
-                    uint64_t w[4];
-                    const uint8_t *src = out + at - copy_dist;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) __builtin_memcpy(&w[k], src + 8 * k, 8);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) __builtin_memcpy(out + at + 8 * k, &w[k], 8);
-                    window = w[3];
-                    at += 32u;
-                    copy_left -= 32u;
-                    continue;
-                }
-                const uint32_t n = copy_left < 8u ? copy_left : 8u;
-                uint64_t rep;
+                uint64_t bytes = 0;
+                bool narrow = false;
                 if (copy_dist <= 8u) {
                     // the next bytes repeat the last copy_dist ones: double the pattern until it covers eight bytes
-                    rep = copy_dist == 8u ? window : (window >> (8u * (8u - copy_dist)));
+                    uint64_t rep = copy_dist == 8u ? window : (window >> (8u * (8u - copy_dist)));
                     if (copy_dist < 8u) rep &= (1ull << (8u * copy_dist)) - 1ull;
                     if (copy_dist < 2u) rep |= rep << 8;
                     if (copy_dist < 3u) rep |= rep << 16;
                     else if (copy_dist == 3u) rep |= rep << 24;
                     if (copy_dist < 5u) { if (copy_dist == 3u) rep |= rep << 48; else rep |= rep << 32; }
                     else if (copy_dist < 8u) rep |= rep << (8u * copy_dist);
-                } else {
-                    __builtin_memcpy(&rep, out + at - copy_dist, 8); // (one unaligned 8-byte load: all eight bytes are behind `at`)
+                    bytes = rep;
+                    narrow = true;
+                } else if (loaded) {
+                    if (wide) {
+                        __builtin_memcpy(out + at, &wa, 16);
+                        __builtin_memcpy(out + at + 16, &wb, 16);
+                        window = (uint64_t)wb.z | ((uint64_t)wb.w << 32);
+                        at += 32u;
+                        copy_left -= 32u;
+                    } else {
+                        bytes = w0;
+                        narrow = true;
+                    }
+                    loaded = false;
                 }
-                if (n == 8u) {
-                    __builtin_memcpy(out + at, &rep, 8);
-                } else {
+                if (narrow) {
+                    // eight bytes at out + at, the first n of them meant: stored whole when the ones beyond are this lane's to
+                    // overwrite later (all but the last seven bytes of a block)
+                    const uint32_t n = copy_left < 8u ? copy_left : 8u;
+                    if (at + 8u <= out_len) {
+                        __builtin_memcpy(out + at, &bytes, 8);
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 7; ++k)
-                        if ((uint32_t)k < n) out[at + (uint32_t)k] = (uint8_t)(rep >> (8 * k));
+                        for (int k = 0; k < 8; ++k)
+                            if ((uint32_t)k < n) out[at + (uint32_t)k] = (uint8_t)(bytes >> (8 * k));
+                    }
+                    window = n == 8u ? bytes : ((window >> (8u * n)) | (bytes << (8u * (8u - n))));
+                    at += n;
+                    copy_left -= n;
                 }
-                window = n == 8u ? rep : ((window >> (8u * n)) | (rep << (8u * (8u - n))));
-                at += n;
-                copy_left -= n;
-                continue;
+                if (copy_left && copy_dist > 8u) {
+                    // the next piece's source: behind `at` in full (the distance is more than its length), stored already
+                    const uint8_t *src = out + at - copy_dist;
+                    wide = copy_dist >= 32u && copy_left >= 32u;
+                    if (wide) {
+                        __builtin_memcpy(&wa, src, 16);
+                        __builtin_memcpy(&wb, src + 16, 16);
+                    } else {
+                        __builtin_memcpy(&w0, src, 8);
+                    }
+                    loaded = true;
+                }
             }
-            // one decode per turn whichever table the lane is at (a length is followed by a distance): the lanes that want a
-            // distance symbol and those that want a literal/length symbol go through the same instructions with their own
-            // limits, counts and symbol arrays -- two decode blocks in a row cost every turn twice
-            const bool is_dist = want_dist != 0;
-            Counts tc;
+            if (copy_left) continue;
+            // ---- the decoding half.  One decode per turn whichever table the lane is at (a length is followed by a distance):
+            // the lanes that want a distance symbol and those that want a literal/length symbol go through the same
+            // instructions with their own limits, bases and symbol arrays -- two decode blocks in a row cost every turn twice
+            const bool is_dist = want_dist != 0u;
+            Table tc;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { tc.w[k] = is_dist ? dc.w[k] : lc.w[k]; tc.n[k] = is_dist ? dc.n[k] : lc.n[k]; }
+            for (int k = 0; k < 8; ++k) { tc.w[k] = is_dist ? dc.w[k] : lc.w[k]; tc.b[k] = is_dist ? dc.b[k] : lc.b[k]; }
             const LdsSyms ts{is_dist ? dsym.lo : lsym.lo, lsym.hi};
             int sym = decode_symbol(br, tc, ts);
             if (sym < 0) { err = SPL_Z_BAD_CODE; break; }
             if (is_dist) {
-                const int ds = sym & 0xff; // (the high bit belongs to the literal/length table: meaningless here)
-                if (ds >= 30) { err = SPL_Z_BAD_CODE; break; }
-                br.refill();
-                copy_dist = (uint32_t)s_base[32 + ds] + br.take(s_extra[32 + ds]);
+                const uint32_t ds = (uint32_t)sym & 0xffu; // (the high bit belongs to the literal/length table: meaningless here)
+                if (ds >= 30u) { err = SPL_Z_BAD_CODE; break; }
+                uint32_t base, extra;
+                distance_code(ds, base, extra);
+                copy_dist = base + br.take(extra);
                 if (copy_dist > at) { err = SPL_Z_BAD_DISTANCE; break; }
-                copy_left = (uint32_t)want_dist;
+                copy_left = want_dist;
                 if (at + copy_left > out_len) { err = SPL_Z_OVERRUN; break; }
                 want_dist = 0;
                 continue;
             }
             if (sym < 256) {
                 if (at >= out_len) { err = SPL_Z_OVERRUN; break; }
-                out[at++] = (uint8_t)sym;
+                lit = (uint32_t)sym;
+                lit_pending = true; // (stored by the next turn, at out[at - 1])
+                ++at;
                 window = (window >> 8) | ((uint64_t)sym << 56);
                 continue;
             }
             if (sym == 256) break;
-            sym -= 257;
-            if (sym >= 29) { err = SPL_Z_BAD_CODE; break; }
-            br.refill();
-            want_dist = (int)((uint32_t)s_base[sym] + br.take(s_extra[sym])); // (the length, 3..258: a distance symbol follows)
+            const uint32_t ls = (uint32_t)sym - 257u;
+            if (ls >= 29u) { err = SPL_Z_BAD_CODE; break; }
+            uint32_t base, extra;
+            length_code(ls, base, extra);
+            want_dist = base + br.take(extra); // (the length, 3..258: a distance symbol follows)
         }
     }
     if (err == SPL_Z_OK && at != out_len) err = SPL_Z_SHORT;
