@@ -244,8 +244,8 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
         // the L2 after every load and an acknowledged store before every refill (62 % of the kernel's time, by SQ_WAIT_ANY).
         // `window` = the last eight bytes of the output: a copy at a distance of eight or less is made from it, no load at all.
         uint32_t copy_left = 0, copy_dist = 0, want_dist = 0;
-        uint32_t lit = 0;
-        bool lit_pending = false, loaded = false, wide = false;
+        uint32_t lit = 0, n_lit = 0; // literals of the last turn (two at most), not yet stored
+        bool eob = false, loaded = false, wide = false;
         uint64_t w0 = 0; // eight source bytes of a copy, or
         u32x4 wa = {0, 0, 0, 0}, wb = {0, 0, 0, 0}; // thirty-two
         const gptr8 stop = (gptr8)(br.end + 24); // (the read-ahead runs 12 bytes past what has been consumed: beyond this, the data is corrupt)
@@ -257,7 +257,12 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
             if (turns > 2u * out_len + 4096u || (gptr8)br.p > stop) { err = SPL_Z_OVERRUN; break; }
             br.refill(); // (33 bits or more after this: a symbol and its extra bits are 28 at most)
             // ---- the memory half: stores first (they may be what the loads after them read), then the loads
-            if (lit_pending) { out[at - 1u] = (uint8_t)lit; lit_pending = false; }
+            if (n_lit) {
+                if (n_lit == 2u) { const uint16_t two = (uint16_t)lit; __builtin_memcpy(out + at - 2u, &two, 2); }
+                else out[at - 1u] = (uint8_t)lit;
+                n_lit = 0;
+            }
+            if (eob) break; // (seen behind a literal in the last turn)
             if (copy_left) {
                 uint64_t bytes = 0;
                 bool narrow = false;
@@ -339,9 +344,30 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
             if (sym < 256) {
                 if (at >= out_len) { err = SPL_Z_OVERRUN; break; }
                 lit = (uint32_t)sym;
-                lit_pending = true; // (stored by the next turn, at out[at - 1])
+                n_lit = 1; // (stored by the next turn, behind `at`)
                 ++at;
                 window = (window >> 8) | ((uint64_t)sym << 56);
+                // a second symbol in the same turn when the bits are there (a code and a length's extra bits: 20 at most):
+                // most symbols are literals, and the turn's memory half, its wait and its bookkeeping are then paid once for two
+                if (br.cnt >= 20u) {
+                    const int s2 = decode_symbol(br, lc, lsym);
+                    if (s2 < 0) { err = SPL_Z_BAD_CODE; break; }
+                    if (s2 < 256) {
+                        if (at >= out_len) { err = SPL_Z_OVERRUN; break; }
+                        lit |= (uint32_t)s2 << 8;
+                        n_lit = 2;
+                        ++at;
+                        window = (window >> 8) | ((uint64_t)s2 << 56);
+                    } else if (s2 == 256) {
+                        eob = true; // (the literal is still to be stored: the next turn does that and leaves)
+                    } else {
+                        const uint32_t l2 = (uint32_t)s2 - 257u;
+                        if (l2 >= 29u) { err = SPL_Z_BAD_CODE; break; }
+                        uint32_t base, extra;
+                        length_code(l2, base, extra);
+                        want_dist = base + br.take(extra);
+                    }
+                }
                 continue;
             }
             if (sym == 256) break;
