@@ -1116,7 +1116,7 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
     // it has, so launches queued on ONE stream take a multiple of one launch over everything) -- and the default is ONE stretch,
     // the whole file: with kernels running beside it the upload of a 3.6 GB file took 0.26 s instead of 0.09-0.12 (the kernel's
     // scattered byte stores and the copy's writes meet in the memory system), 0.32 s for upload + inflate against 0.21 one after
-    // the other.
+    // the other.  (Streams restricted to 7/8 or 1/2 of the CUs left the upload alone but took 0.16-0.18 s for what was left behind it.)
     struct Lanes {
         std::vector<hipStream_t> streams;
         std::vector<hipEvent_t> events;
