@@ -172,7 +172,7 @@ def e2e_leg(name, wl, table_items, stranded, cryptic, seq_mode, reps, want_rows,
         native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=0,
                          seq_mode=seq_mode)
         out["files_written_s"] = time.perf_counter() - t
-        out["bam_decode_asked"] = {None: "default (by the file's compression)", False: "host threads (process --hostDecode)",
+        out["bam_decode_asked"] = {None: "default (one device: on the GPU)", False: "host threads (process --hostDecode)",
                                    True: "GPU (process --gpuDecode)"}[gpu_decode]
         out["bam_bytes"] = os.path.getsize(prefix + ".bam")
         out["bam_seq_qual"] = ("constant bytes (deflate to almost nothing)" if seq_mode == 0 else
@@ -190,15 +190,16 @@ def e2e_leg(name, wl, table_items, stranded, cryptic, seq_mode, reps, want_rows,
         best = min(runs, key=lambda r: r["wall_s"])
         nproc, quota = cpu_budget()
         out["host_cpu"] = {"nproc": nproc, "cpu_quota_cores": quota,
-                           "note": "the call is host-bound (BGZF inflate + CRC, record extraction, packing): the GPU is idle for "
-                                   "nine tenths of it, see profiles/*_e2e_*_timeline.txt"}
+                           "note": "with the host decoder the call is host-bound (BGZF inflate + CRC, record extraction, packing) and the "
+                                   "GPU idle for nine tenths of it; with the decode on the GPU the clock is the file's way there "
+                                   "(page cache -> staging -> PCIe) and the inflate kernel, see profiles/*_gpu_decode.txt"}
         out["bam_decode"] = {"host": "on host threads", "device": "on the GPU (BGZF inflate, CRC32, record extraction as kernels)"}[best["bam_decode"]]
         out.update(reads=n_reads, reads_per_sec=best["reads_per_sec"], wall_s=best["wall_s"], stages=best["stages"],
                    first_call_wall_s=runs[0]["wall_s"], runs=len(runs),
-                   what="process(): open BAM + BED/GFF -> Steps 0-2 on the host while the BAM decodes -> per chromosome: host "
-                        "packing, H2D through the staging ring, range + literal + scan/SSE kernels, D2H -> .SpliSER.tsv written "
-                        "while later chromosomes decode; wall clock of the whole call in a process whose GPU context exists "
-                        "(first_call_wall_s: the call that creates it)")
+                   what="process(): open BAM + BED/GFF -> Steps 0-2 on the host while the BAM decodes (GPU: file image up, inflate, "
+                        "CRC32, record extraction, reads laid out by kernels; host: threads, packing, H2D through the staging "
+                        "ring) -> range + literal + scan/SSE kernels, D2H -> .SpliSER.tsv; wall clock of the whole call in a "
+                        "process whose GPU context exists (first_call_wall_s: the call that creates it)")
         # parity of the file: Site, alpha, beta1, beta2Simple and SSE text of every row against the oracle's numbers
         ok, rows = True, 0
         with open(prefix + ".out%d.SpliSER.tsv" % (reps - 1)) as fh:

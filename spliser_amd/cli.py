@@ -41,10 +41,10 @@ def build_parser():
                         "BED alpha against reads in the BAM; changes no result")
     p.add_argument("--gpuDecode", dest="gpuDecode", default=None, action="store_true",
                    help="(this build only) inflate the BAM's BGZF blocks and extract its records on the GPU whatever the file "
-                        "looks like (default: the GPU for files that compress like real libraries, host threads for files that "
-                        "inflate at memset speed); changes no result")
+                        "looks like (the default with one GPU; with several, only files that compress like real libraries go "
+                        "that way); changes no result")
     p.add_argument("--hostDecode", dest="gpuDecode", action="store_false",
-                   help="(this build only) decode the BAM on host threads whatever the file looks like")
+                   help="(this build only) decode the BAM on host threads")
     _engine_flags(p)
     c = sub.add_parser("combine")
     c.add_argument("-S", "--samplesFile", dest="samplesFile", required=True,

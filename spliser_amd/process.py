@@ -46,7 +46,11 @@ def open_alignments(path, threads=0, stream=False, defer=False):
     raise native.SpliserNativeError(-5, "%s is neither BGZF/BAM nor SAM text" % path)
 
 
-GPU_DECODE_BELOW = 10.0     # inflated bytes per file byte below which `process` inflates on the GPU (measured cross-over: 10...20)
+# With ONE device `process` inflates every BAM on the GPU (3.6x file: 195 M reads/s against 45 M on the 16 host cores of the
+# bench box; a file of constant bytes that inflates 49x: 350 M against 190 M).  With several devices the decoded reads stay on the
+# decoding device and the others get theirs by way of the host, which only pays for files below this ratio (inflated bytes per
+# file byte, measured with the round trip in place: twice as fast at 3.6x, slower at 49x).
+GPU_DECODE_BELOW = 10.0
 
 
 class _Replan(Exception):
@@ -299,9 +303,9 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
 
     ``gpuDecode`` (this build only; changes no result): True = the BAM goes to the GPU as it is -- BGZF inflate, CRC32 and the
     extraction of POS / FLAG / CIGAR happen there (``spl_bam_decode_device``); files that path does not take (unsorted, CG-tag
-    CIGARs, damaged) are decoded by the host threads all the same.  False = host threads.  None (default) = by the file: on the
-    GPU when its first blocks inflate to less than GPU_DECODE_BELOW times their size (a real library's file: 3-4x, twice as fast
-    on the GPU), on the host when they inflate at memset speed (synthetic data)."""
+    CIGARs, damaged) are decoded by the host threads all the same.  False = host threads.  None (default) = the GPU when the call
+    uses one device; with several, by the file: on the GPU when its first blocks inflate to less than GPU_DECODE_BELOW times
+    their size (see there)."""
     timings = {}
     t0 = time.perf_counter()
     # The alignment file does not depend on Steps 0-2: it is decoded on native threads while the site table is built here, and
@@ -309,8 +313,11 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
     # (block directory and header are read by the opening call).
     source = open_alignments(inBAM, threads=threads, stream=True, defer=gpuDecode is not False)
     if isinstance(source, native.BamFile) and gpuDecode is not False:
-        # where to inflate: told by the caller, or by how the file's first blocks are compressed (GPU_DECODE_BELOW)
-        on_gpu = bool(gpuDecode) if gpuDecode is not None else 0.0 < source.compression_ratio() < GPU_DECODE_BELOW
+        # where to inflate: told by the caller, or the GPU (with several devices: by how the file's first blocks are compressed)
+        if gpuDecode is not None:
+            on_gpu = bool(gpuDecode)
+        else:
+            on_gpu = len(set(devices)) == 1 or 0.0 < source.compression_ratio() < GPU_DECODE_BELOW
         if on_gpu:
             source.decode_on_device_async(devices[0])     # (runs beside Steps 0-2, like the host decode does)
         else:

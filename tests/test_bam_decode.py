@@ -111,3 +111,56 @@ def test_broken_directory_behind_a_good_start_is_reported(built, tmp_path):
     with pytest.raises(native.SpliserNativeError) as e2:
         native.BamFile(cut, threads=2, stream=True)
     assert "truncated" in str(e2.value) or "corrupt" in str(e2.value)
+
+
+def _directory(path, monkeypatch, one_thread, least=None, threads=4):
+    """The whole block directory of a file, as the device decoder asks for it (internal entry points, by their C++ names)."""
+    import ctypes
+    lib = native.lib()
+    walk = getattr(lib, "_Z16spl_bam_walk_allP7spl_bam")
+    count = getattr(lib, "_Z19spl_bam_block_countPK7spl_bam")
+    get = getattr(lib, "_Z17spl_bam_block_getPK7spl_bammP18spl_bam_block_info")
+    count.restype = ctypes.c_size_t
+
+    class Info(ctypes.Structure):
+        _fields_ = [("data_off", ctypes.c_uint64), ("uoff", ctypes.c_uint64), ("data_len", ctypes.c_uint32), ("isize", ctypes.c_uint32),
+                    ("crc", ctypes.c_uint32)]
+    if one_thread:
+        monkeypatch.setenv("SPL_WALK_ONE_THREAD", "1")
+    else:
+        monkeypatch.delenv("SPL_WALK_ONE_THREAD", raising=False)
+        monkeypatch.setenv("SPL_WALK_PARALLEL_MIN", str(least))
+    bam = native.BamFile(path, threads=threads, defer=True)
+    try:
+        rc = walk(bam._h)
+        if rc:
+            return rc, lib.spl_last_error().decode()
+        out = []
+        info = Info()
+        for i in range(count(bam._h)):
+            get(bam._h, ctypes.c_size_t(i), ctypes.byref(info))
+            out.append((info.data_off, info.uoff, info.data_len, info.isize, info.crc))
+        return 0, out
+    finally:
+        bam.close()
+
+
+@pytest.mark.parametrize("least", [4096, 100_000, 1 << 20])
+def test_directory_by_several_threads_is_the_one_thread_directory(built, tmp_path, monkeypatch, least):
+    names, sets = _random_sets(11, 60_000, 3)
+    path = str(tmp_path / "t.bam")
+    native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=2, seq_mode=1)
+    rc, want = _directory(path, monkeypatch, True)
+    assert rc == 0 and len(want) > 50
+    for threads in (2, 8):
+        rc, got = _directory(path, monkeypatch, False, least, threads)
+        assert rc == 0 and got == want
+    # a file that is not what it says in its second half: the same refusal, in the same words, either way
+    data = bytearray(open(path, "rb").read())
+    at = data.find(b"\x1f\x8b\x08\x04", len(data) // 2)
+    data[at + 1] = 0
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(data))
+    rc1, text1 = _directory(bad, monkeypatch, True)
+    rc2, text2 = _directory(bad, monkeypatch, False, least)
+    assert rc1 != 0 and (rc1, text1) == (rc2, text2) and "not BGZF" in text1
