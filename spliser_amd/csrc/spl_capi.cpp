@@ -49,6 +49,111 @@ int spl_set_error(int code, const char *fmt, ...)
 extern "C" const char *spl_last_error(void) { return g_last_error.c_str(); }
 extern "C" int spl_abi_version(void) { return SPL_ABI_VERSION; }
 
+// ---- device memory ---------------------------------------------------------------------------------------
+// Device memory handed out here is kept by the process when it is given back, for whoever asks next on the same device: fresh
+// VRAM costs 30 ms per GB on this stack (cleared on its way out: hipMalloc of the 56 GB a 200 M-read file inflates to takes
+// 1.8 s in a new process) and freed VRAM is scrubbed by the copy engines at the next upload's expense (a decode that started
+// while 18 GB of the previous one were being scrubbed had its upload run at 4 GB/s instead of 35).  A second `process` call of
+// the same process -- `combine`'s samples, a service -- finds its read sets', decoded arrays' and inflated stream's memory
+// where the first left it.  Best fit, at most twice what was asked for; buffers below 8 MiB are not worth keeping; the pool
+// holds at most SPL_DEV_CACHE_GB (default 128) per device and lets its smallest buffers go first; when the device runs out,
+// everything held is given back before the request fails.  put() waits for the device like the hipFree it stands in for.
+// (Stream-ordered allocation -- hipMallocAsync / hipFreeAsync -- was tried first: with that pool the BAM decode became flaky
+// on this stack, stale reference ids in one run of four.)
+// SPL_DEV_POISON=1 (tests): every buffer is filled with 0xA5 when handed out -- fresh device memory is zero on this stack and
+// reused memory is not, and nothing may depend on either.
+namespace devmem {
+struct Held { int device; void *p; size_t bytes; };
+static std::mutex &mu() { static std::mutex m; return m; }
+static std::vector<Held> &held() { static std::vector<Held> *v = new std::vector<Held>(); return *v; }
+static std::vector<Held> &lent() { static std::vector<Held> *v = new std::vector<Held>(); return *v; }
+static size_t limit()
+{
+    static const size_t v = []() { const char *e = getenv("SPL_DEV_CACHE_GB"); return (size_t)(e ? std::max(0, atoi(e)) : 128) << 30; }();
+    return v;
+}
+static size_t held_bytes(int device)
+{
+    std::lock_guard<std::mutex> lock(mu());
+    size_t n = 0;
+    for (const Held &h : held()) if (h.device == device) n += h.bytes;
+    return n;
+}
+static void flush(int device)
+{
+    std::vector<Held> go;
+    {
+        std::lock_guard<std::mutex> lock(mu());
+        std::vector<Held> &v = held();
+        for (size_t k = v.size(); k-- > 0;)
+            if (v[k].device == device) { go.push_back(v[k]); v.erase(v.begin() + (long)k); }
+    }
+    for (const Held &h : go) (void)hipFree(h.p);
+}
+static hipError_t get(void **out, size_t bytes)
+{
+    static const bool poison = getenv("SPL_DEV_POISON") != nullptr;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    const size_t gran = (size_t)2 << 20;
+    bytes = (std::max<size_t>(bytes, 1) + gran - 1) / gran * gran;
+    void *p = nullptr;
+    size_t cap = bytes;
+    {
+        std::lock_guard<std::mutex> lock(mu());
+        std::vector<Held> &v = held();
+        size_t best = v.size();
+        for (size_t k = 0; k < v.size(); ++k)
+            if (v[k].device == device && v[k].bytes >= bytes && v[k].bytes <= 2 * bytes && (best == v.size() || v[k].bytes < v[best].bytes)) best = k;
+        if (best < v.size()) { p = v[best].p; cap = v[best].bytes; v.erase(v.begin() + (long)best); }
+    }
+    if (!p) {
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); flush(device); e = hipMalloc(&p, bytes); }
+        if (e != hipSuccess) return e;
+    }
+    { std::lock_guard<std::mutex> lock(mu()); lent().push_back(Held{device, p, cap}); }
+    if (poison) { e = hipMemset(p, 0xA5, cap); if (e != hipSuccess) return e; }
+    *out = p;
+    return hipSuccess;
+}
+static void put(void *p)
+{
+    if (!p) return;
+    Held h{-1, p, 0};
+    std::vector<Held> go;
+    {
+        std::lock_guard<std::mutex> lock(mu());
+        std::vector<Held> &l = lent();
+        for (size_t k = 0; k < l.size(); ++k)
+            if (l[k].p == p) { h = l[k]; l.erase(l.begin() + (long)k); break; }
+    }
+    if (h.device < 0 || h.bytes < ((size_t)8 << 20) || h.bytes > limit()) { (void)hipFree(p); return; }
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    if (have && cur != h.device) (void)hipSetDevice(h.device);
+    (void)hipDeviceSynchronize(); // (nothing in flight may still be using it when the next owner gets it)
+    if (have && cur != h.device) (void)hipSetDevice(cur);
+    {
+        std::lock_guard<std::mutex> lock(mu());
+        std::vector<Held> &v = held();
+        v.push_back(h);
+        size_t total = 0;
+        for (const Held &x : v) if (x.device == h.device) total += x.bytes;
+        while (total > limit()) { // the smallest go first: the large ones are the expensive ones
+            size_t s = v.size();
+            for (size_t k = 0; k < v.size(); ++k)
+                if (v[k].device == h.device && (s == v.size() || v[k].bytes < v[s].bytes)) s = k;
+            total -= v[s].bytes;
+            go.push_back(v[s]);
+            v.erase(v.begin() + (long)s);
+        }
+    }
+    for (const Held &x : go) (void)hipFree(x.p);
+}
+} // namespace devmem
+
 // ---- objects --------------------------------------------------------------------------------------------
 struct spl_ctx {
     int device = -1;
@@ -542,7 +647,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     const size_t o_bsum = take(4 * 4 * (size_t)std::max(d->scan_blocks, 1));
     const size_t o_b2s = take(8 * S), o_b2c = take(8 * S), o_b2w = take(8 * S), o_sse = take(8 * S), o_ssec = take(8 * S);
     d->slab_bytes = std::max<size_t>(off, 256);
-    hipError_t e = hipMalloc((void **)&d->slab, d->slab_bytes);
+    hipError_t e = devmem::get((void **)&d->slab, d->slab_bytes);
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the site table: %s", d->slab_bytes, hipGetErrorString(e)); }
     stamp("hipMalloc");
     d->pos = (int32_t *)(d->slab + o_pos); d->strand = (uint8_t *)(d->slab + o_strand); d->meta = (uint4 *)(d->slab + o_meta);
@@ -624,7 +729,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
         if (r == hipSuccess) r = hipStreamSynchronize(c->stream);
     }
     stamp("position index kernel");
-    if (r != hipSuccess) { (void)hipFree(d->slab); delete d; return spl_set_error(SPL_ERR_HIP, "site table upload: %s", hipGetErrorString(r)); }
+    if (r != hipSuccess) { devmem::put(d->slab); delete d; return spl_set_error(SPL_ERR_HIP, "site table upload: %s", hipGetErrorString(r)); }
     *out = d;
     return SPL_OK;
 }
@@ -635,7 +740,7 @@ extern "C" void spl_sites_free(spl_ctx *c, spl_dsites *d)
     if (c) (void)hipSetDevice(c->device);
     if (c && c->tail) (void)hipStreamSynchronize(c->tail); // (a tail may still be reading these buffers; hipFree itself waits
     if (c && c->stream) (void)hipStreamSynchronize(c->stream); //  for the device, this makes it independent of that)
-    if (d->slab) (void)hipFree(d->slab);
+    devmem::put(d->slab);
     delete d;
 }
 
@@ -758,7 +863,7 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
     seg.rec_bytes = plan.rec_bytes; seg.n_wide = plan.n_wide; seg.n_reads = src.n_reads; seg.n_ops = src.n_ops; seg.shift = shift;
     const size_t rec_al = align_up((size_t)plan.rec_bytes);
     const size_t slab_bytes = rec_al + 4 * (size_t)plan.n_wide + 256;
-    hipError_t e = hipMalloc((void **)&seg.slab, slab_bytes);
+    hipError_t e = devmem::get((void **)&seg.slab, slab_bytes);
     if (e != hipSuccess) { d->segs.pop_back(); return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for a read segment: %s", slab_bytes, hipGetErrorString(e)); }
     const size_t n_chunks = plan.chunks.size();
     auto rec_end = [&](size_t k) { return k + 1 < n_chunks ? plan.chunks[k + 1].rec_off : plan.rec_bytes; };
@@ -797,7 +902,7 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
     }
     if (q != hipSuccess) {
         (void)hipStreamSynchronize(c->copy);
-        (void)hipFree(seg.slab);
+        devmem::put(seg.slab);
         d->segs.pop_back();
         return spl_set_error(SPL_ERR_HIP, "read segment upload: %s", hipGetErrorString(q));
     }
@@ -814,68 +919,11 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
 // sums on the host, extraction of POS / FLAG / CIGAR into file-wide arrays, and those come back into page-locked host arrays
 // that the spl_bam adopts, one part per reference.
 namespace {
-// Device memory of the decode.  The large buffers (file image, inflated stream: 18 GB for a 50 M-read file) are kept by the
-// process for the next decode on the same device instead of being freed: freed VRAM is scrubbed by the copy engines, and a
-// decode that started while 18 GB of the previous one were being scrubbed had its upload run at 4 GB/s instead of 35 (every
-// other call of a loop took 0.4...0.7 s longer).  At most two buffers per device are kept, the rest is freed as before.
-// (Stream-ordered allocation -- hipMallocAsync / hipFreeAsync -- was tried first: with the pool the decode became flaky on
-// this stack, stale tids in one run of four.)
-struct CachedDev { int device; void *p; size_t bytes; };
-static std::mutex &dev_cache_mu() { static std::mutex m; return m; }
-static std::vector<CachedDev> &dev_cache() { static std::vector<CachedDev> *v = new std::vector<CachedDev>(); return *v; }
-
+// Device memory of the decode (devmem above: the file image and the inflated stream are the buffers that made it necessary).
 struct DevBuf {
     void *p = nullptr;
-    size_t cap = 0;
-    int device = -1;
-    ~DevBuf()
-    {
-        if (!p) return;
-        if (cap >= ((size_t)256 << 20)) {
-            std::lock_guard<std::mutex> lock(dev_cache_mu());
-            std::vector<CachedDev> &cache = dev_cache();
-            size_t mine = 0, smallest = cache.size();
-            for (size_t k = 0; k < cache.size(); ++k) {
-                if (cache[k].device != device) continue;
-                ++mine;
-                if (smallest == cache.size() || cache[k].bytes < cache[smallest].bytes) smallest = k;
-            }
-            if (mine < 2) { cache.push_back(CachedDev{device, p, cap}); return; }
-            if (cache[smallest].bytes < cap) { // keep the two LARGEST (the image and the inflated stream): the smaller one goes
-                void *old = cache[smallest].p;
-                cache[smallest] = CachedDev{device, p, cap};
-                p = old;
-            }
-        }
-        (void)hipFree(p);
-    }
-    hipError_t get(size_t bytes, hipStream_t st)
-    {
-        bytes = bytes ? bytes : 16;
-        (void)hipGetDevice(&device);
-        if (bytes >= ((size_t)256 << 20)) {
-            std::lock_guard<std::mutex> lock(dev_cache_mu());
-            std::vector<CachedDev> &cache = dev_cache();
-            size_t best = cache.size();
-            for (size_t k = 0; k < cache.size(); ++k)
-                if (cache[k].device == device && cache[k].bytes >= bytes && (best == cache.size() || cache[k].bytes < cache[best].bytes)) best = k;
-            if (best < cache.size()) {
-                p = cache[best].p;
-                cap = cache[best].bytes;
-                cache.erase(cache.begin() + (long)best);
-                return hipSuccess;
-            }
-            // nothing large enough: what is cached for this device and too small only stands in the way
-            for (size_t k = cache.size(); k-- > 0;)
-                if (cache[k].device == device) { (void)hipFree(cache[k].p); cache.erase(cache.begin() + (long)k); }
-        }
-        cap = bytes;
-        const hipError_t e = hipMalloc(&p, bytes);
-        // (tests: fresh device memory is zero-filled on this stack, which would hide a read of something never written)
-        static const bool poison = getenv("SPL_DEV_POISON") != nullptr;
-        if (e == hipSuccess && poison) return hipMemsetAsync(p, 0xA5, bytes, st);
-        return e;
-    }
+    ~DevBuf() { devmem::put(p); }
+    hipError_t get(size_t bytes, hipStream_t) { return devmem::get(&p, bytes ? bytes : 16); }
     template <class T> T *as() const { return (T *)p; }
 };
 // A stretch of the file into a staging buffer: pread when the file is open (the page cache's bytes straight into the pinned
@@ -910,7 +958,7 @@ static void free_device_reads(void *h)
     int cur = 0;
     const bool have = hipGetDevice(&cur) == hipSuccess;
     (void)hipSetDevice(r->device);
-    (void)hipFree(r->pos); (void)hipFree(r->flag); (void)hipFree(r->cig_off); (void)hipFree(r->cigar);
+    devmem::put(r->pos); devmem::put(r->flag); devmem::put(r->cig_off); devmem::put(r->cigar);
     if (have) (void)hipSetDevice(cur);
     delete r;
 }
@@ -972,12 +1020,12 @@ static int add_segment_device(spl_ctx *c, spl_dreads *d, const DeviceReads &dev,
     if ((uint64_t)d->n_chunks + n_chunks > (1ull << (32 - d->chunk_shift))) return spl_set_error(SPL_ERR_ARG, "too many reads in one read set: use more shards");
     const spl_devreads src{(const int32_t *)dev.pos, (const uint16_t *)dev.flag, (const uint32_t *)dev.cig_off, (const uint32_t *)dev.cigar};
     splpack::ChunkDesc *d_descs = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_descs, sizeof(splpack::ChunkDesc) * n_chunks));
+    HIP_TRY(devmem::get((void **)&d_descs, sizeof(splpack::ChunkDesc) * n_chunks));
     std::vector<splpack::ChunkDesc> descs(n_chunks);
     hipError_t q = (hipError_t)spl_dev_launch_pack_count(&src, first, n_reads, chunk, d_descs, c->copy);
     if (q == hipSuccess) q = hipMemcpyAsync(descs.data(), d_descs, sizeof(splpack::ChunkDesc) * n_chunks, hipMemcpyDeviceToHost, c->copy);
     if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
-    if (q != hipSuccess) { (void)hipFree(d_descs); return spl_set_error(SPL_ERR_HIP, "device packer (sizes): %s", hipGetErrorString(q)); }
+    if (q != hipSuccess) { devmem::put(d_descs); return spl_set_error(SPL_ERR_HIP, "device packer (sizes): %s", hipGetErrorString(q)); }
     uint64_t rec = 0, wide = 0; // sizes -> offsets, as splpack::plan does
     for (splpack::ChunkDesc &cd : descs) {
         const uint64_t bytes = cd.rec_off, ops = cd.wide_off;
@@ -986,19 +1034,19 @@ static int add_segment_device(spl_ctx *c, spl_dreads *d, const DeviceReads &dev,
         rec += bytes;
         wide += ops;
     }
-    if (wide > 0xfffffff0ull) { (void)hipFree(d_descs); return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops of wide reads in one segment: use more shards"); }
+    if (wide > 0xfffffff0ull) { devmem::put(d_descs); return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops of wide reads in one segment: use more shards"); }
     d->segs.emplace_back();
     spl_dreads::Segment &seg = d->segs.back();
     seg.rec_bytes = rec; seg.n_wide = wide; seg.n_reads = n_reads; seg.n_ops = n_ops; seg.shift = shift;
     const size_t rec_al = align_up((size_t)rec);
     const size_t slab_bytes = rec_al + 4 * (size_t)wide + 256;
-    q = hipMalloc((void **)&seg.slab, slab_bytes);
+    q = devmem::get((void **)&seg.slab, slab_bytes);
     if (q == hipSuccess) q = hipMemcpyAsync(d_descs, descs.data(), sizeof(splpack::ChunkDesc) * n_chunks, hipMemcpyHostToDevice, c->copy);
     if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack_emit(&src, first, n_reads, chunk, d_descs, seg.slab, seg.slab + rec_al, c->copy);
     if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
-    (void)hipFree(d_descs);
+    devmem::put(d_descs);
     if (q != hipSuccess) {
-        if (seg.slab) (void)hipFree(seg.slab);
+        devmem::put(seg.slab);
         d->segs.pop_back();
         return spl_set_error(SPL_ERR_HIP, "device packer: %s", hipGetErrorString(q));
     }
@@ -1043,6 +1091,7 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
     if (rc) return rc;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    free_b += devmem::held_bytes(c->device); // (given back before a request fails)
     if ((double)fsize * 8.0 + (double)(1u << 30) > (double)free_b) return to_host("not enough device memory");
     // The block directory (one thread's walk over the file's block headers) beside the upload of the file image, and, once the
     // directory is there, the blocks of every stretch of the file inflated as soon as the stretch has arrived.
@@ -1102,6 +1151,7 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
         stream_len = bi.uoff + bi.isize;
     }
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    free_b += devmem::held_bytes(c->device);
     if ((double)stream_len * 1.2 + (double)(1u << 30) > (double)free_b) return to_host("not enough device memory for the inflated stream");
     // (everything from here to the record scan runs on streams other than the copy stream, whose queue is full of file pieces)
     HIP_TRY(d_stream.get(stream_len + 64, c->stream));
@@ -1344,7 +1394,7 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
     const size_t o_meta = take(sizeof(spl_chunk_meta) * std::max<size_t>(n, 1)), o_order = take(4 * std::max<size_t>(n, 1));
     const size_t o_total = take(4);
     const size_t o_queue = take(4 * 8 * shard_cap), o_queue_alt = take(c->tail ? 4 * 8 * shard_cap : 0);
-    hipError_t e = hipMalloc((void **)&d->ctl, std::max<size_t>(off, 256));
+    hipError_t e = devmem::get((void **)&d->ctl, std::max<size_t>(off, 256));
     if (e != hipSuccess) return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the read set: %s", off, hipGetErrorString(e));
     d->meta = (spl_chunk_meta *)(d->ctl + o_meta);
     d->chunk_order = (uint32_t *)(d->ctl + o_order);
@@ -1477,8 +1527,8 @@ extern "C" void spl_reads_free(spl_ctx *c, spl_dreads *d)
     if (c && c->copy) (void)hipStreamSynchronize(c->copy);
     if (c && c->tail) (void)hipStreamSynchronize(c->tail); // (a tail may still be reading these buffers; hipFree itself waits
     if (c && c->stream) (void)hipStreamSynchronize(c->stream); //  for the device, this makes it independent of that)
-    for (spl_dreads::Segment &seg : d->segs) if (seg.slab) (void)hipFree(seg.slab);
-    if (d->ctl) (void)hipFree(d->ctl);
+    for (spl_dreads::Segment &seg : d->segs) devmem::put(seg.slab);
+    devmem::put(d->ctl);
     delete d;
 }
 
