@@ -90,9 +90,10 @@ static void flush(int device)
     }
     for (const Held &h : go) (void)hipFree(h.p);
 }
-static hipError_t get(void **out, size_t bytes)
+static hipError_t get(void **out, size_t bytes, char tag = 'x')
 {
-    static const bool poison = getenv("SPL_DEV_POISON") != nullptr;
+    static const char *const poison_env = getenv("SPL_DEV_POISON");
+    const bool poison = poison_env && (poison_env[0] == '1' || strchr(poison_env, tag));
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
@@ -114,7 +115,11 @@ static hipError_t get(void **out, size_t bytes)
         if (e != hipSuccess) return e;
     }
     { std::lock_guard<std::mutex> lock(mu()); lent().push_back(Held{device, p, cap}); }
-    if (poison) { e = hipMemset(p, 0xA5, cap); if (e != hipSuccess) return e; }
+    if (poison) { // (and done before anybody's stream touches the buffer: a memset on the null stream does not wait for, or hold up, the others)
+        e = hipMemset(p, 0xA5, cap);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) return e;
+    }
     *out = p;
     return hipSuccess;
 }
@@ -647,7 +652,7 @@ extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out
     const size_t o_bsum = take(4 * 4 * (size_t)std::max(d->scan_blocks, 1));
     const size_t o_b2s = take(8 * S), o_b2c = take(8 * S), o_b2w = take(8 * S), o_sse = take(8 * S), o_ssec = take(8 * S);
     d->slab_bytes = std::max<size_t>(off, 256);
-    hipError_t e = devmem::get((void **)&d->slab, d->slab_bytes);
+    hipError_t e = devmem::get((void **)&d->slab, d->slab_bytes, 's');
     if (e != hipSuccess) { delete d; return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the site table: %s", d->slab_bytes, hipGetErrorString(e)); }
     stamp("hipMalloc");
     d->pos = (int32_t *)(d->slab + o_pos); d->strand = (uint8_t *)(d->slab + o_strand); d->meta = (uint4 *)(d->slab + o_meta);
@@ -863,7 +868,7 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
     seg.rec_bytes = plan.rec_bytes; seg.n_wide = plan.n_wide; seg.n_reads = src.n_reads; seg.n_ops = src.n_ops; seg.shift = shift;
     const size_t rec_al = align_up((size_t)plan.rec_bytes);
     const size_t slab_bytes = rec_al + 4 * (size_t)plan.n_wide + 256;
-    hipError_t e = devmem::get((void **)&seg.slab, slab_bytes);
+    hipError_t e = devmem::get((void **)&seg.slab, slab_bytes, 'r');
     if (e != hipSuccess) { d->segs.pop_back(); return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for a read segment: %s", slab_bytes, hipGetErrorString(e)); }
     const size_t n_chunks = plan.chunks.size();
     auto rec_end = [&](size_t k) { return k + 1 < n_chunks ? plan.chunks[k + 1].rec_off : plan.rec_bytes; };
@@ -923,7 +928,7 @@ namespace {
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { devmem::put(p); }
-    hipError_t get(size_t bytes, hipStream_t) { return devmem::get(&p, bytes ? bytes : 16); }
+    hipError_t get(size_t bytes, hipStream_t) { return devmem::get(&p, bytes ? bytes : 16, 'b'); }
     template <class T> T *as() const { return (T *)p; }
 };
 // A stretch of the file into a staging buffer: pread when the file is open (the page cache's bytes straight into the pinned
@@ -1020,7 +1025,7 @@ static int add_segment_device(spl_ctx *c, spl_dreads *d, const DeviceReads &dev,
     if ((uint64_t)d->n_chunks + n_chunks > (1ull << (32 - d->chunk_shift))) return spl_set_error(SPL_ERR_ARG, "too many reads in one read set: use more shards");
     const spl_devreads src{(const int32_t *)dev.pos, (const uint16_t *)dev.flag, (const uint32_t *)dev.cig_off, (const uint32_t *)dev.cigar};
     splpack::ChunkDesc *d_descs = nullptr;
-    HIP_TRY(devmem::get((void **)&d_descs, sizeof(splpack::ChunkDesc) * n_chunks));
+    HIP_TRY(devmem::get((void **)&d_descs, sizeof(splpack::ChunkDesc) * n_chunks, 'd'));
     std::vector<splpack::ChunkDesc> descs(n_chunks);
     hipError_t q = (hipError_t)spl_dev_launch_pack_count(&src, first, n_reads, chunk, d_descs, c->copy);
     if (q == hipSuccess) q = hipMemcpyAsync(descs.data(), d_descs, sizeof(splpack::ChunkDesc) * n_chunks, hipMemcpyDeviceToHost, c->copy);
@@ -1040,7 +1045,7 @@ static int add_segment_device(spl_ctx *c, spl_dreads *d, const DeviceReads &dev,
     seg.rec_bytes = rec; seg.n_wide = wide; seg.n_reads = n_reads; seg.n_ops = n_ops; seg.shift = shift;
     const size_t rec_al = align_up((size_t)rec);
     const size_t slab_bytes = rec_al + 4 * (size_t)wide + 256;
-    q = devmem::get((void **)&seg.slab, slab_bytes);
+    q = devmem::get((void **)&seg.slab, slab_bytes, 'R');
     if (q == hipSuccess) q = hipMemcpyAsync(d_descs, descs.data(), sizeof(splpack::ChunkDesc) * n_chunks, hipMemcpyHostToDevice, c->copy);
     if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack_emit(&src, first, n_reads, chunk, d_descs, seg.slab, seg.slab + rec_al, c->copy);
     if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
@@ -1394,7 +1399,7 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
     const size_t o_meta = take(sizeof(spl_chunk_meta) * std::max<size_t>(n, 1)), o_order = take(4 * std::max<size_t>(n, 1));
     const size_t o_total = take(4);
     const size_t o_queue = take(4 * 8 * shard_cap), o_queue_alt = take(c->tail ? 4 * 8 * shard_cap : 0);
-    hipError_t e = devmem::get((void **)&d->ctl, std::max<size_t>(off, 256));
+    hipError_t e = devmem::get((void **)&d->ctl, std::max<size_t>(off, 256), 'c');
     if (e != hipSuccess) return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the read set: %s", off, hipGetErrorString(e));
     d->meta = (spl_chunk_meta *)(d->ctl + o_meta);
     d->chunk_order = (uint32_t *)(d->ctl + o_order);
