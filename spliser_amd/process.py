@@ -11,6 +11,7 @@ Deliberate deviations from the reference, all on the failure side (SURVEY.md sec
   * ``-g GENE`` with a gene that is not in the annotation is an error here; the reference crashes with
     AttributeError at :283.
 """
+import os
 import sys
 import threading
 import time
@@ -156,9 +157,17 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
             # chromosome, so all chromosomes of a shard go up as ONE read set and are counted in one pass
             source._device_thread.join()
             whole = bool(source.on_device)
+        stamps = [] if os.environ.get("SPL_PROCESS_TIMING") else None   # (where a device thread's time goes, on stderr)
+
+        def stamp(what):
+            if stamps is not None:
+                stamps.append((what, time.perf_counter()))
+        stamp("decoder joined")
         with native.Context(device) as ctx:
+            stamp("context")
             for sh in shards:
                 with ctx.upload_sites(sh.sites) as ds:
+                    stamp("site table up")
                     if whole:
                         n_expected = sum(source.wait_ref(c)[0] for c in sh.chroms if items[c][2])
                         with ctx.begin_reads(n_expected) as dr:
@@ -168,11 +177,15 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                                     if max_end > limit:
                                         raise _Replan()
                                     dr.add_bam(source, chrom, off)
+                            stamp("reads laid out")
                             dr.finish()
+                            stamp("read set finished")
                             ctx.count_launch(ds, dr, stranded, combine_mode)
                             ctx.sse_launch(ds, is_beta2_cryptic)
                             beta1, b2r, _ = ds.counters()
                             b2s, b2c, b2w, sse = ds.sse_results()
+                            stamp("counted, results down")
+                        stamp("read set freed")
                         for chrom, (r0, r1) in zip(sh.chroms, sh.site_rows):
                             res = dict(beta1=beta1[r0:r1].copy(), beta2_simple=b2s[r0:r1].copy(), beta2_cryptic=b2c[r0:r1].copy(),
                                        beta2_weighted=b2w[r0:r1].copy(), sse=sse[r0:r1].copy(), beta2s_reads=b2r[r0:r1].copy())
@@ -180,6 +193,10 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                                 out[chrom] = (items[chrom][0], res)
                             if on_result is not None:
                                 on_result(chrom, items[chrom][0], res)
+                        stamp("rows handed over")
+                        if stamps is not None and sh is shards[-1]:
+                            sys.stderr.write("[process] device %d: %s\n" % (device, ", ".join(
+                                "%s +%.4f" % (w, t - stamps[k - 1][1]) for k, (w, t) in enumerate(stamps) if k)))
                         continue
                     for chrom, off, limit, (r0, r1) in zip(sh.chroms, sh.offsets, sh.limits, sh.site_rows):
                         with ctx.begin_reads() as dr:
