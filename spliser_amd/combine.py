@@ -220,9 +220,9 @@ class _QueryTable(object):
 
 
 def fill_gaps(merged, bam_paths, is_stranded, stranded_type, devices=(0,), threads=0, log=_log):
-    """Answer every (site, sample) query on the GPUs.  Each sample's BAM is decoded once, in the background; its chromosomes are
-    dealt to the devices (``process.process_sites``: one context per device, a chromosome goes to its GPU as soon as the decoder
-    has it complete) and counted in ``combine_mode`` (a flanking read counts toward beta2Simple, :529-536); several samples are
+    """Answer every (site, sample) query on the GPUs.  Each sample's BAM is decoded once, in the background (on the GPU when the
+    call has one device, like ``process``); its chromosomes are dealt to the devices (``process.process_sites``: one context per
+    device, a chromosome goes to its GPU as soon as the decoder has it complete) and counted in ``combine_mode`` (a flanking read counts toward beta2Simple, :529-536); several samples are
     in flight at a time, each starting on another device.  -> {(site index, sample idx): (beta1, beta2Simple)}"""
     from concurrent.futures import ThreadPoolExecutor
     from . import process as _process
@@ -232,9 +232,9 @@ def fill_gaps(merged, bam_paths, is_stranded, stranded_type, devices=(0,), threa
 
     def one(idx):
         table = _QueryTable(per_sample[idx])
-        source = _process.open_alignments(bam_paths[idx], threads=threads, stream=True)
+        devs = devices[idx % len(devices):] + devices[:idx % len(devices)]
+        source = _process.open_and_decode(bam_paths[idx], devs, None, threads)   # (on the sample's first device when it has one device)
         try:
-            devs = devices[idx % len(devices):] + devices[:idx % len(devices)]
             out = _process.process_sites(table, source, "All", is_stranded, stranded_type, False, devices=devs, combine_mode=1,
                                          log=lambda m: None)
             if isinstance(source, native.BamFile) and not source.wait_all():   # not sorted by reference: again, from the whole decode

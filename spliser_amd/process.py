@@ -54,6 +54,23 @@ def open_alignments(path, threads=0, stream=False, defer=False):
 GPU_DECODE_BELOW = 10.0
 
 
+def open_and_decode(path, devices, gpuDecode=None, threads=0):
+    """The alignment file opened and its decode started: on the GPU (``devices[0]``) or on host threads -- told by the caller
+    (``gpuDecode`` True / False) or, None, chosen here: the GPU when the call uses one device, by the file's compression when it
+    uses several (GPU_DECODE_BELOW).  SAM text has one reader."""
+    source = open_alignments(path, threads=threads, stream=True, defer=gpuDecode is not False)
+    if isinstance(source, native.BamFile) and gpuDecode is not False:
+        if gpuDecode is not None:
+            on_gpu = bool(gpuDecode)
+        else:
+            on_gpu = len(set(devices)) == 1 or 0.0 < source.compression_ratio() < GPU_DECODE_BELOW
+        if on_gpu:
+            source.decode_on_device_async(devices[0])
+        else:
+            source.start_host_decode()
+    return source
+
+
 class _Replan(Exception):
     """A read reaches beyond the room its chromosome was given in the shard (planned from the BAM header)."""
 
@@ -328,17 +345,7 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
     # The alignment file does not depend on Steps 0-2: it is decoded on native threads while the site table is built here, and
     # goes on decoding while Step 3 counts the chromosomes that are complete.  An unreadable file is an error here already
     # (block directory and header are read by the opening call).
-    source = open_alignments(inBAM, threads=threads, stream=True, defer=gpuDecode is not False)
-    if isinstance(source, native.BamFile) and gpuDecode is not False:
-        # where to inflate: told by the caller, or the GPU (with several devices: by how the file's first blocks are compressed)
-        if gpuDecode is not None:
-            on_gpu = bool(gpuDecode)
-        else:
-            on_gpu = len(set(devices)) == 1 or 0.0 < source.compression_ratio() < GPU_DECODE_BELOW
-        if on_gpu:
-            source.decode_on_device_async(devices[0])     # (runs beside Steps 0-2, like the host decode does)
-        else:
-            source.start_host_decode()
+    source = open_and_decode(inBAM, devices, gpuDecode, threads)     # (the decode runs beside Steps 0-2, wherever it runs)
     try:
         t_open = time.perf_counter()
         table = _site_table(inBed, qGene, qChrom, maxIntronSize, annotationFile, aType, isStranded, strandedType, log)
