@@ -164,3 +164,40 @@ def test_deflate_strategies(ctx, tmp_path, monkeypatch, strategy):
     path = str(tmp_path / "s.bam")
     samio.write_bam(path, names, [10 ** 8] * 2, [(c, sets[c]) for c in names], with_seq=True)
     assert _both(path, ctx, names, sets) is True
+
+
+@pytest.mark.parametrize("seed", range(0, 10))
+@pytest.mark.parametrize("stranded", [0, 1, 2])
+def test_reads_laid_out_on_the_device_count_like_the_oracle(seed, stranded, ctx, oracle_lib, tmp_path, monkeypatch):
+    """The device packer (spl_devpack.hip) on what the host packer's tests use: adversarial reads -- 0N ops, adjacent N ops,
+    clipped / indel / = / X CIGARs, unmapped-but-placed records, reads of every class -- each repeated so that runs of every
+    class cross thread, wave and chunk boundaries of the layout kernels.  BAM -> device decode -> device layout -> counting
+    kernels, against the oracle on the arrays that were written; both chunk sizes."""
+    import helpers
+    import randcase
+    arr, rs = randcase.make_case(seed + 700, bool(stranded))
+    if arr.n == 0 or rs.n == 0:
+        pytest.skip("empty case")
+    times = 61
+    n_ops = np.diff(rs.cig_off.astype(np.int64))
+    keep = np.repeat(np.arange(rs.n), times)
+    op_idx = np.concatenate([np.arange(rs.cig_off[i], rs.cig_off[i + 1]) for i in keep]) if rs.n else np.zeros(0, np.int64)
+    big = samio.ReadSet(rs.pos[keep], rs.flag[keep], np.concatenate(([0], np.cumsum(n_ops[keep]))).astype(np.uint32),
+                        rs.cigar[op_idx.astype(np.int64)])
+    path = str(tmp_path / "adv.bam")
+    samio.write_bam(path, ["c1"], [10 ** 8], [("c1", big)], level=6)
+    ocount, _ = helpers.oracle_engine(oracle_lib)
+    want = ocount(arr, big, stranded, 0)
+    for chunk in ("2048", "4096"):
+        monkeypatch.setenv("SPL_FORCE_CHUNK", chunk)
+        bam = native.BamFile(path, threads=2, defer=True)
+        assert bam.decode_on_device(ctx)
+        with ctx.upload_sites(native.SiteArrays.from_chrom(arr)) as ds:
+            with ctx.begin_reads() as dr:
+                dr.add_bam(bam, "c1", 0)
+                dr.finish()
+                ctx.count_launch(ds, dr, stranded, 0)
+                got = ds.counters()
+        bam.close()
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g)
