@@ -1155,145 +1155,154 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
         blocks[i].in = bi.data_off; blocks[i].out = bi.uoff; blocks[i].in_len = bi.data_len; blocks[i].out_len = bi.isize; blocks[i].crc = bi.crc; blocks[i].pad = 0;
         stream_len = bi.uoff + bi.isize;
     }
+    // The inflated stream is never there as a whole: it is made, scanned and emptied of its records a WINDOW at a time -- a
+    // device-ful of blocks, one per lane of as many workgroups as the inflate kernel fits on the device (7 per CU for its tables
+    // in LDS: 114 688 blocks, 7.5 GB of stream) -- in one buffer.  A launch of the inflate kernel takes as long as ONE lane needs
+    // for its block however few blocks it has, so a window of a device-ful costs what its share of one launch over everything
+    // would; and fresh device memory costs 30 ms per GB here (56 GB of stream for a 200 M-read file: 1.8 s of hipMalloc in a
+    // new process, in the way of the upload it shares the copy engines with).  SPL_INFLATE_WINDOW_BLOCKS overrides (tests).
+    size_t win_blocks = (size_t)7 * 256 * 64;
+    if (const char *e = getenv("SPL_INFLATE_WINDOW_BLOCKS")) win_blocks = (size_t)std::max(2, atoi(e));
+    win_blocks = std::min(win_blocks, n_blocks);
+    uint64_t win_cap = 0; // the longest stretch of the stream that win_blocks consecutive blocks hold
+    for (size_t i = 0; i + win_blocks <= n_blocks; i += std::max<size_t>(1, win_blocks / 64))
+        win_cap = std::max(win_cap, blocks[i + win_blocks - 1].out + blocks[i + win_blocks - 1].out_len - blocks[i].out);
+    win_cap = std::min<uint64_t>(stream_len, std::max<uint64_t>(win_cap, 1) + (uint64_t)win_blocks / 64 * 65536 + 65536);
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     free_b += devmem::held_bytes(c->device);
-    if ((double)stream_len * 1.2 + (double)(1u << 30) > (double)free_b) return to_host("not enough device memory for the inflated stream");
-    // (everything from here to the record scan runs on streams other than the copy stream, whose queue is full of file pieces)
-    HIP_TRY(d_stream.get(stream_len + 64, c->stream));
-    HIP_TRY(d_blocks.get(sizeof(spl_zblock) * n_blocks, c->stream));
-    HIP_TRY(d_status.get(4 * n_blocks, c->stream));
-    HIP_TRY(d_scan.get(sizeof(spl_bscan) * n_blocks, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), sizeof(spl_zblock) * n_blocks, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(d_status.p, 0xff, 4 * n_blocks, c->stream));
-    // Inflate + CRC32 of the blocks, released by an event behind the file's pieces in the copy stream's queue.  The machinery takes
-    // the file in stretches of SPL_INFLATE_STRETCH pieces, each stretch's blocks launched on one of a few streams of its own as
-    // soon as the stretch has arrived (side by side: a launch takes as long as one lane needs for its block however few blocks
-    // it has, so launches queued on ONE stream take a multiple of one launch over everything) -- and the default is ONE stretch,
-    // the whole file: with kernels running beside it the upload of a 3.6 GB file took 0.26 s instead of 0.09-0.12 (the kernel's
-    // scattered byte stores and the copy's writes meet in the memory system), 0.32 s for upload + inflate against 0.21 one after
-    // the other.  (Streams restricted to 7/8 or 1/2 of the CUs left the upload alone but took 0.16-0.18 s for what was left behind it.)
-    struct Lanes {
-        std::vector<hipStream_t> streams;
-        std::vector<hipEvent_t> events;
-        ~Lanes() { for (hipEvent_t e : events) (void)hipEventDestroy(e); for (hipStream_t st : streams) (void)hipStreamDestroy(st); }
-    } lanes;
-    size_t stretch = 0;
-    if (const char *e = getenv("SPL_INFLATE_STRETCH")) stretch = (size_t)std::max(0, atoi(e));
-    if (stretch == 0) stretch = n_pieces;
-    const size_t n_stretch = (n_pieces + stretch - 1) / stretch;
-    const size_t n_lanes = std::min<size_t>(4, n_stretch);
-    for (size_t k = 0; k < n_lanes; ++k) {
-        hipStream_t st = nullptr;
-        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        lanes.streams.push_back(st);
-    }
-    auto new_event = [&](hipEvent_t *out) -> hipError_t {
-        hipError_t q = hipEventCreateWithFlags(out, hipEventDisableTiming);
-        if (q == hipSuccess) lanes.events.push_back(*out);
-        return q;
-    };
-    hipEvent_t ev_tables = nullptr; // the block table and the status words are where the lanes' kernels expect them
-    HIP_TRY(new_event(&ev_tables));
-    HIP_TRY(hipEventRecord(ev_tables, c->stream));
-    for (hipStream_t st : lanes.streams) HIP_TRY(hipStreamWaitEvent(st, ev_tables, 0));
-    size_t b0 = 0;
-    for (size_t g = 0; g < n_stretch; ++g) {
-        const size_t k1 = std::min(n_pieces, (g + 1) * stretch);
-        for (size_t k = g * stretch; k < k1; ++k)
-            while (!sent[k].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
-        if (reader_failed.load(std::memory_order_acquire)) break;
-        const uint64_t end_off = std::min<uint64_t>((uint64_t)fsize, (uint64_t)k1 * piece);
-        size_t b1 = b0;
-        while (b1 < n_blocks && blocks[b1].in + blocks[b1].in_len + 8 <= end_off) ++b1; // (+ 8: the trailer, not needed, but whole blocks are simpler to reason about)
-        if (k1 == n_pieces) b1 = n_blocks;
-        if (b1 == b0) continue;
-        hipEvent_t ev = nullptr;
-        HIP_TRY(new_event(&ev));
-        HIP_TRY(hipEventRecord(ev, c->copy));
-        hipStream_t st = lanes.streams[g % n_lanes];
-        HIP_TRY(hipStreamWaitEvent(st, ev, 0));
-        HIP_TRY((hipError_t)spl_dev_launch_inflate(d_image.as<uint8_t>(), d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), d_stream.as<uint8_t>(), d_status.as<uint32_t>() + b0, st));
-        HIP_TRY((hipError_t)spl_dev_launch_crc32(d_stream.as<uint8_t>(), d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), d_status.as<uint32_t>() + b0, st));
-        b0 = b1;
-    }
+    if ((double)win_cap + (double)stream_len * 0.2 + (double)(1u << 30) > (double)free_b) return to_host("not enough device memory for the inflated stream");
+    HIP_TRY(d_stream.get(win_cap + 128, c->copy));
+    HIP_TRY(d_blocks.get(sizeof(spl_zblock) * n_blocks, c->copy));
+    HIP_TRY(d_status.get(4 * n_blocks, c->copy));
+    HIP_TRY(d_scan.get(sizeof(spl_bscan) * n_blocks, c->copy));
     crew.join();
     for (hipError_t e : errs) HIP_TRY(e);
+    // (everything below is queued on the copy stream behind the file's pieces.  Inflating stretches of the file on streams of
+    // their own while the rest was still on its way was measured and is not done: with kernels running beside it the upload of
+    // a 3.6 GB file took 0.24-0.26 s instead of 0.09-0.12 -- the kernel's scattered byte stores and the copy's writes meet in
+    // the memory system -- 0.32 s for upload + inflate against 0.21 s one after the other; with the kernels kept off 1/8 or 1/2
+    // of the CUs the upload was left alone and what was left behind it took 0.16-0.18 s.)
+    HIP_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), sizeof(spl_zblock) * n_blocks, hipMemcpyHostToDevice, c->copy));
+    HIP_TRY(hipMemsetAsync(d_status.p, 0xff, 4 * n_blocks, c->copy));
     if (timing) { HIP_TRY(hipStreamSynchronize(c->copy)); stamp("file image to the device"); }
-    for (hipStream_t st : lanes.streams) {
-        hipEvent_t ev = nullptr;
-        HIP_TRY(new_event(&ev));
-        HIP_TRY(hipEventRecord(ev, st));
-        HIP_TRY(hipStreamWaitEvent(c->copy, ev, 0));
-    }
-    if (timing) { HIP_TRY(hipStreamSynchronize(c->copy)); stamp("inflate + CRC32 still to do behind it"); }
-    HIP_TRY((hipError_t)spl_dev_launch_bam_scan(d_stream.as<uint8_t>(), stream_len, spl_bam_header_end(bam), n_ref, d_blocks.as<spl_zblock>(), (uint32_t)n_blocks,
-                                                d_scan.as<spl_bscan>(), c->copy));
-    std::vector<uint32_t> status(n_blocks);
-    std::vector<spl_bscan> scan(n_blocks);
-    HIP_TRY(hipMemcpyAsync(status.data(), d_status.p, 4 * n_blocks, hipMemcpyDeviceToHost, c->copy));
-    HIP_TRY(hipMemcpyAsync(scan.data(), d_scan.p, sizeof(spl_bscan) * n_blocks, hipMemcpyDeviceToHost, c->copy));
-    HIP_TRY(hipStreamSynchronize(c->copy));
-    stamp("record scan");
-    for (size_t i = 0; i < n_blocks; ++i)
-        if (status[i] != SPL_Z_OK) return to_host("a block did not inflate (or its CRC32 is wrong)");
-    // the chain of boundaries, from the end of the BAM header to the end of the stream
     const uint64_t H = spl_bam_header_end(bam);
     if (H > stream_len) return to_host("no BAM header");
-    size_t first = 0;
+    size_t first = 0; // the first block that holds more than BAM header
     while (first < n_blocks && blocks[first].out + blocks[first].out_len <= H && !(blocks[first].out + blocks[first].out_len == H && first + 1 == n_blocks)) ++first;
+    std::vector<uint32_t> status(n_blocks);
+    std::vector<spl_bscan> scan(n_blocks);
     std::vector<uint64_t> rec_off(n_blocks + 1, 0), op_off(n_blocks + 1, 0);
-    int64_t n_all = 0;
-    {
-        uint64_t expect = H;
-        int32_t last_tid = -1;
-        for (size_t b = first; b < n_blocks; ++b) {
-            const spl_bscan &sc = scan[b];
-            if (sc.flags & SPL_BS_CORRUPT) return to_host("a record contradicts itself");
-            if (sc.flags & SPL_BS_NO_START) return to_host("no record boundary found near a block");
-            if (sc.flags & SPL_BS_NEEDS_HOST) return to_host("a CIGAR parked in a CG tag");
-            if (sc.flags & SPL_BS_UNSORTED) return to_host("not sorted by reference");
-            if (sc.start != expect) return to_host("a guessed record boundary did not hold");
-            if (sc.n_placed) {
-                if (sc.tid_first < last_tid) return to_host("not sorted by reference");
-                last_tid = sc.tid_last;
-            }
-            expect = sc.reached;
-            n_all += sc.n_all;
-        }
-        if (expect != stream_len) return to_host("the file ends inside a record");
-    }
-    for (size_t b = 0; b < n_blocks; ++b) {
-        const bool live = b >= first;
-        rec_off[b + 1] = rec_off[b] + (live ? scan[b].n_placed : 0u);
-        op_off[b + 1] = op_off[b] + (live ? scan[b].n_ops : 0u);
-        if (!live) scan[b].n_placed = 0; // (the extraction skips header blocks)
-    }
-    const uint64_t n_rec = rec_off[n_blocks], n_ops = op_off[n_blocks];
-    if (n_ops > 0xfffffff0ull) return to_host("more than 2^32 CIGAR operations");
-    stamp("boundary chain + prefix sums");
     DevBuf d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
     HIP_TRY(d_recoff.get(8 * (n_blocks + 1), c->copy));
     HIP_TRY(d_opoff.get(8 * (n_blocks + 1), c->copy));
-    HIP_TRY(d_pos.get(4 * n_rec, c->copy));
-    HIP_TRY(d_flag.get(2 * n_rec, c->copy));
-    HIP_TRY(d_cigoff.get(4 * (n_rec + 1), c->copy));
-    HIP_TRY(d_cigar.get(4 * n_ops, c->copy));
-    HIP_TRY(d_tid.get(4 * n_rec, c->copy));
     HIP_TRY(d_maxend.get(8 * (size_t)std::max(n_ref, 1), c->copy));
     const uint32_t cap = (uint32_t)std::max(n_ref, 1) * 4u + 64u;
     HIP_TRY(d_bounds.get(16 * (size_t)cap, c->copy));
     HIP_TRY(d_nbounds.get(4, c->copy));
-    HIP_TRY(hipMemcpyAsync(d_recoff.p, rec_off.data(), 8 * (n_blocks + 1), hipMemcpyHostToDevice, c->copy));
-    HIP_TRY(hipMemcpyAsync(d_opoff.p, op_off.data(), 8 * (n_blocks + 1), hipMemcpyHostToDevice, c->copy));
-    HIP_TRY(hipMemcpyAsync(d_scan.p, scan.data(), sizeof(spl_bscan) * n_blocks, hipMemcpyHostToDevice, c->copy));
     HIP_TRY(hipMemsetAsync(d_maxend.p, 0, 8 * (size_t)std::max(n_ref, 1), c->copy));
     HIP_TRY(hipMemsetAsync(d_nbounds.p, 0, 4, c->copy));
-    HIP_TRY(hipMemsetAsync(d_cigoff.p, 0, 4, c->copy));
-    HIP_TRY((hipError_t)spl_dev_launch_bam_extract(d_stream.as<uint8_t>(), stream_len, n_ref, d_blocks.as<spl_zblock>(), (uint32_t)n_blocks, d_scan.as<spl_bscan>(),
-                                                   d_recoff.as<uint64_t>(), d_opoff.as<uint64_t>(), d_pos.as<int32_t>(), d_flag.as<uint16_t>(), d_cigoff.as<uint32_t>(),
-                                                   d_cigar.as<uint32_t>(), d_tid.as<int32_t>(), d_maxend.as<unsigned long long>(), c->copy));
+    // the extracted arrays: as large as the first window says the file will need and a tenth more, larger when that was wrong
+    uint64_t cap_rec = 0, cap_ops = 0, n_rec = 0, n_ops = 0;
+    auto make_room = [&](uint64_t need_rec, uint64_t need_ops, double part_done) -> int {
+        if (need_rec <= cap_rec && need_ops <= cap_ops && cap_rec) return SPL_OK;
+        const double scale = 1.1 / std::max(part_done, 1e-6);
+        const uint64_t want_rec = std::max<uint64_t>(need_rec, (uint64_t)((double)need_rec * scale)) + 1024;
+        const uint64_t want_ops = std::max<uint64_t>(need_ops, (uint64_t)((double)need_ops * scale)) + 1024;
+        DevBuf pos2, flag2, cigoff2, cigar2, tid2;
+        HIP_TRY(pos2.get(4 * want_rec, c->copy));
+        HIP_TRY(flag2.get(2 * want_rec, c->copy));
+        HIP_TRY(cigoff2.get(4 * (want_rec + 1), c->copy));
+        HIP_TRY(cigar2.get(4 * want_ops, c->copy));
+        HIP_TRY(tid2.get(4 * want_rec, c->copy));
+        if (cap_rec) { // what the windows so far have left (n_rec records, n_ops ops) moves
+            HIP_TRY(hipMemcpyAsync(pos2.p, d_pos.p, 4 * n_rec, hipMemcpyDeviceToDevice, c->copy));
+            HIP_TRY(hipMemcpyAsync(flag2.p, d_flag.p, 2 * n_rec, hipMemcpyDeviceToDevice, c->copy));
+            HIP_TRY(hipMemcpyAsync(cigoff2.p, d_cigoff.p, 4 * (n_rec + 1), hipMemcpyDeviceToDevice, c->copy));
+            HIP_TRY(hipMemcpyAsync(cigar2.p, d_cigar.p, 4 * n_ops, hipMemcpyDeviceToDevice, c->copy));
+            HIP_TRY(hipMemcpyAsync(tid2.p, d_tid.p, 4 * n_rec, hipMemcpyDeviceToDevice, c->copy));
+            HIP_TRY(hipStreamSynchronize(c->copy));
+        } else {
+            HIP_TRY(hipMemsetAsync(cigoff2.p, 0, 4, c->copy));
+        }
+        std::swap(d_pos.p, pos2.p); std::swap(d_flag.p, flag2.p); std::swap(d_cigoff.p, cigoff2.p); std::swap(d_cigar.p, cigar2.p); std::swap(d_tid.p, tid2.p);
+        cap_rec = want_rec;
+        cap_ops = want_ops;
+        return SPL_OK;
+    };
+    int64_t n_all = 0;
+    uint64_t expect = H; // the chain of boundaries, from the end of the BAM header to the end of the stream
+    int32_t last_tid = -1;
+    size_t n_windows = 0;
+    for (size_t b0 = 0; b0 < n_blocks; ++n_windows) {
+        size_t b1 = std::min(n_blocks, b0 + win_blocks);
+        while (b1 > b0 + 1 && blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out > win_cap) --b1;
+        const bool more = b1 < n_blocks;
+        const uint32_t nb = (uint32_t)(b1 - b0);
+        const uint64_t base = blocks[b0].out, win_end = blocks[b1 - 1].out + blocks[b1 - 1].out_len;
+        if (win_end - base > win_cap) return to_host("a block larger than the inflate window");
+        uint8_t *const stream0 = d_stream.as<uint8_t>() - base; // (indexed with offsets into the whole stream, from `base` on)
+        HIP_TRY((hipError_t)spl_dev_launch_inflate(d_image.as<uint8_t>(), d_blocks.as<spl_zblock>() + b0, nb, stream0, d_status.as<uint32_t>() + b0, c->copy));
+        HIP_TRY((hipError_t)spl_dev_launch_crc32(stream0, d_blocks.as<spl_zblock>() + b0, nb, d_status.as<uint32_t>() + b0, c->copy));
+        HIP_TRY((hipError_t)spl_dev_launch_bam_scan(stream0, win_end, H, n_ref, d_blocks.as<spl_zblock>() + b0, nb, d_scan.as<spl_bscan>() + b0, more ? 1 : 0, c->copy));
+        HIP_TRY(hipMemcpyAsync(status.data() + b0, d_status.as<uint32_t>() + b0, 4 * (size_t)nb, hipMemcpyDeviceToHost, c->copy));
+        HIP_TRY(hipMemcpyAsync(scan.data() + b0, d_scan.as<spl_bscan>() + b0, sizeof(spl_bscan) * nb, hipMemcpyDeviceToHost, c->copy));
+        HIP_TRY(hipStreamSynchronize(c->copy));
+        for (size_t i = b0; i < b1; ++i)
+            if (status[i] != SPL_Z_OK) return to_host("a block did not inflate (or its CRC32 is wrong)");
+        // Which of the window's blocks are done with: all whose records end inside it.  A block near the window's end may have
+        // looked for its first record, or walked its last one, into bytes that are not there yet: it is told by its flag, or
+        // -- within reach of the end -- by anything being wrong with it, and is the first block of the next window.
+        const uint64_t reach = std::min<uint64_t>((win_end - base) / 2, ((uint64_t)5 << 18));
+        size_t b_done = b1;
+        for (size_t b = b0; b < b1; ++b) {
+            spl_bscan &sc = scan[b];
+            if (b < first) { // (BAM header only: nothing to extract)
+                sc.n_placed = 0;
+                rec_off[b + 1] = rec_off[b];
+                op_off[b + 1] = op_off[b];
+                continue;
+            }
+            const char *wrong = nullptr;
+            if (sc.flags & SPL_BS_CORRUPT) wrong = "a record contradicts itself";
+            else if (sc.flags & SPL_BS_NO_START) wrong = "no record boundary found near a block";
+            else if (sc.flags & SPL_BS_NEEDS_HOST) wrong = "a CIGAR parked in a CG tag";
+            else if (sc.flags & SPL_BS_UNSORTED) wrong = "not sorted by reference";
+            else if (sc.start != expect) wrong = "a guessed record boundary did not hold";
+            else if (sc.n_placed && sc.tid_first < last_tid) wrong = "not sorted by reference";
+            if ((sc.flags & SPL_BS_INCOMPLETE) || (wrong && more && blocks[b].out + reach >= win_end)) { b_done = b; break; }
+            if (wrong) return to_host(wrong);
+            if (sc.n_placed) last_tid = sc.tid_last;
+            expect = sc.reached;
+            n_all += sc.n_all;
+            rec_off[b + 1] = rec_off[b] + sc.n_placed;
+            op_off[b + 1] = op_off[b] + sc.n_ops;
+        }
+        if (b_done == b0) return to_host("a record larger than the inflate window");
+        const uint64_t had_rec = n_rec, had_ops = n_ops;
+        if (op_off[b_done] > 0xfffffff0ull) return to_host("more than 2^32 CIGAR operations");
+        rc = make_room(rec_off[b_done], op_off[b_done], (double)(blocks[b_done - 1].out + blocks[b_done - 1].out_len) / (double)std::max<uint64_t>(stream_len, 1));
+        if (rc) return rc;
+        (void)had_rec; (void)had_ops;
+        n_rec = rec_off[b_done];
+        n_ops = op_off[b_done];
+        const size_t nd = b_done - b0;
+        HIP_TRY(hipMemcpyAsync(d_recoff.as<uint64_t>() + b0, rec_off.data() + b0, 8 * nd, hipMemcpyHostToDevice, c->copy));
+        HIP_TRY(hipMemcpyAsync(d_opoff.as<uint64_t>() + b0, op_off.data() + b0, 8 * nd, hipMemcpyHostToDevice, c->copy));
+        HIP_TRY(hipMemcpyAsync(d_scan.as<spl_bscan>() + b0, scan.data() + b0, sizeof(spl_bscan) * nd, hipMemcpyHostToDevice, c->copy));
+        HIP_TRY((hipError_t)spl_dev_launch_bam_extract(stream0, win_end, n_ref, d_blocks.as<spl_zblock>() + b0, (uint32_t)nd, d_scan.as<spl_bscan>() + b0,
+                                                       d_recoff.as<uint64_t>() + b0, d_opoff.as<uint64_t>() + b0, d_pos.as<int32_t>(), d_flag.as<uint16_t>(),
+                                                       d_cigoff.as<uint32_t>(), d_cigar.as<uint32_t>(), d_tid.as<int32_t>(), d_maxend.as<unsigned long long>(), c->copy));
+        b0 = b_done;
+    }
+    if (expect != stream_len) return to_host("the file ends inside a record");
+    if (!cap_rec) { rc = make_room(0, 0, 1.0); if (rc) return rc; } // (a file without a block behind its header)
     HIP_TRY((hipError_t)spl_dev_launch_bam_bounds(d_tid.as<int32_t>(), d_cigoff.as<uint32_t>(), n_rec, d_bounds.as<uint64_t>(), d_nbounds.as<uint32_t>(), cap, c->copy));
-    if (timing) { HIP_TRY(hipStreamSynchronize(c->copy)); stamp("extraction kernels"); }
+    if (timing) {
+        HIP_TRY(hipStreamSynchronize(c->copy));
+        char what[96];
+        snprintf(what, sizeof what, "inflate, CRC32, scan, extraction: %zu window%s", n_windows, n_windows == 1 ? "" : "s");
+        stamp(what);
+    }
     std::vector<unsigned long long> maxend((size_t)std::max(n_ref, 1));
     std::vector<uint64_t> bounds(2 * (size_t)cap);
     uint32_t n_bounds = 0;

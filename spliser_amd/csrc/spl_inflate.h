@@ -51,13 +51,16 @@ struct spl_bscan {
 #define SPL_BS_NEEDS_HOST 2u  // a CIGAR parked in a CG tag (more than 65535 ops): the host decoder's business
 #define SPL_BS_UNSORTED 4u    // reference ids go down inside the block
 #define SPL_BS_NO_START 8u    // no plausible record start found within reach of the block
+#define SPL_BS_INCOMPLETE 16u  // a record of the block runs past the end of what is inflated at the moment (a window of the stream)
 
 #ifdef __cplusplus
 extern "C" {
 #endif
-// stream_len = bytes of the inflated stream; header_end = where the first record starts; blocks[b].out / out_len say where block b lies
+// stream_len = bytes of the inflated stream; header_end = where the first record starts; blocks[b].out / out_len say where block b lies.
+// The stream may be there in part only: `stream` is indexed with offsets into the WHOLE stream all the same (the caller passes
+// the window's address minus the window's offset), stream_len = where the window ends, more = the stream goes on behind it.
 int spl_dev_launch_bam_scan(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks,
-                            spl_bscan *scan, void *stream_handle);
+                            spl_bscan *scan, int more, void *stream_handle);
 // rec_off[b] / op_off[b]: index of the block's first placed record / first op in the output arrays.  cig_off gets n + 1 entries
 // (the caller sets entry 0); ref_max_end[tid] = largest last base of a read of the reference (atomicMax; zero it first).
 int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream_len, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks, const spl_bscan *scan,

@@ -460,8 +460,10 @@ __device__ __forceinline__ bool plausible_record(const uint8_t *c, const uint8_t
 
 } // namespace
 
+// `stream_len` = where the inflated bytes end: the stream's end, or (more != 0) the end of the window that is inflated at the
+// moment -- a record that runs past it is then no damage but something for the next window (SPL_BS_INCOMPLETE).
 __global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref,
-                                                           const spl_zblock *blocks, uint32_t n_blocks, spl_bscan *scan)
+                                                           const spl_zblock *blocks, uint32_t n_blocks, spl_bscan *scan, uint32_t more)
 {
     const uint32_t b = blockIdx.x * 64u + threadIdx.x;
     if (b >= n_blocks) return;
@@ -498,17 +500,19 @@ __global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream,
             if (ok) { found = true; break; }
         }
         if (!found) {
-            if (limit == stream_len) at = stream_len; // (the tail of the last record of the file)
+            if (limit == stream_len && more) out.flags |= SPL_BS_INCOMPLETE | SPL_BS_NO_START; // (whatever starts here ends beyond the window)
+            else if (limit == stream_len) at = stream_len; // (the tail of the last record of the file)
             else out.flags |= SPL_BS_NO_START;
         }
     }
     out.start = at;
     // the records that start before the block's end
     int32_t last_tid = -1;
-    while (at < u1 && !(out.flags & (SPL_BS_CORRUPT | SPL_BS_NO_START))) {
-        if (stream_len - at < 4) { out.flags |= SPL_BS_CORRUPT; break; }
+    while (at < u1 && !(out.flags & (SPL_BS_CORRUPT | SPL_BS_NO_START | SPL_BS_INCOMPLETE))) {
+        if (stream_len - at < 4) { out.flags |= more ? SPL_BS_INCOMPLETE : SPL_BS_CORRUPT; break; }
         const uint32_t bs = ld32(stream + at);
-        if (bs < 32u || stream_len - at < 4ull + bs) { out.flags |= SPL_BS_CORRUPT; break; }
+        if (bs < 32u) { out.flags |= SPL_BS_CORRUPT; break; }
+        if (stream_len - at < 4ull + bs) { out.flags |= more ? SPL_BS_INCOMPLETE : SPL_BS_CORRUPT; break; }
         const uint8_t *r = stream + at + 4;
         const int32_t tid = (int32_t)ld32(r), pos0 = (int32_t)ld32(r + 4);
         const uint32_t l_name = r[8], n_cig = ld16(r + 12), l_seq = ld32(r + 16);
@@ -597,10 +601,10 @@ __global__ __launch_bounds__(256) void spl_bam_bounds_kernel(const int32_t *tid,
 }
 
 extern "C" int spl_dev_launch_bam_scan(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks,
-                                       spl_bscan *scan, void *st)
+                                       spl_bscan *scan, int more, void *st)
 {
     if (n_blocks == 0) return 0;
-    hipLaunchKernelGGL(spl_bam_scan_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)st, stream, stream_len, header_end, n_ref, blocks, n_blocks, scan);
+    hipLaunchKernelGGL(spl_bam_scan_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)st, stream, stream_len, header_end, n_ref, blocks, n_blocks, scan, more ? 1u : 0u);
     return (int)hipGetLastError();
 }
 

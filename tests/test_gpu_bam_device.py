@@ -201,3 +201,31 @@ def test_reads_laid_out_on_the_device_count_like_the_oracle(seed, stranded, ctx,
         bam.close()
         for w, g in zip(want, got):
             assert np.array_equal(w, g)
+
+
+@pytest.mark.parametrize("window", ["2", "3", "7", "40"])
+def test_inflate_windows_of_a_few_blocks(ctx, tmp_path, monkeypatch, window):
+    """The stream is inflated, scanned and emptied of its records a window at a time (114 688 blocks in production): windows of
+    a few blocks on files of a few hundred -- every window ends in the middle of a record, blocks near a window's end are done
+    again by the next, the extracted arrays grow as they go -- must give what the host decoder gives; records larger than a
+    window are the host decoder's."""
+    monkeypatch.setenv("SPL_INFLATE_WINDOW_BLOCKS", window)
+    for seq_mode, level, seed in ((1, 1, 31), (1, 6, 32), (0, 1, 33), (1, 0, 34)):
+        names, sets = _random_sets(seed, 30_000, 3)
+        path = str(tmp_path / ("w%d.bam" % seed))
+        native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=level, threads=3, seq_mode=seq_mode)
+        assert _both(path, ctx, names, sets) is True
+    # reads of 300 000 and 700 000 bases with SEQ and QUAL (records of 450 KB and a megabyte) between ordinary ones
+    pos = np.array([10, 20, 30, 40, 50, 60], np.int32)
+    ops = [[(50 << 4) | 0], [(300_000 << 4) | 0], [(20 << 4) | 0, (100 << 4) | 3, (30 << 4) | 0], [(700_000 << 4) | 0],
+           [(700_000 << 4) | 0], [(75 << 4) | 0]]
+    cig_off = np.concatenate(([0], np.cumsum([len(o) for o in ops]))).astype(np.uint32)
+    want = samio.ReadSet(pos, np.array([0, 16, 0, 0, 16, 0], np.uint16), cig_off, np.array([x for o in ops for x in o], np.uint32))
+    path = str(tmp_path / "big.bam")
+    samio.write_bam(path, ["c0"], [10 ** 8], [("c0", want)], with_seq=True)
+    dev = native.BamFile(path, threads=2, defer=True)
+    took = dev.decode_on_device(ctx)
+    assert not (took and int(window) < 17)  # (a megabyte is 17 blocks: the small windows cannot hold such a record; either way the
+                                            #  result is what counts)
+    _same(dev.reads("c0"), want)
+    dev.close()
