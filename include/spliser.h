@@ -213,9 +213,10 @@ int spl_bam_open_deferred(const char *path, int n_threads, spl_bam **out);
 int spl_bam_decode_device(spl_ctx *ctx, spl_bam *bam, int *on_device_out);
 /* For a caller that will call spl_bam_decode_device from another thread in a moment while others may already wait for
  * references: the file is marked as taken by the device decoder now, so that those waits wait instead of starting the host
- * decode.  The promise must be kept (spl_bam_decode_device), or the waits never end. */
+ * decode.  The promise must be kept (spl_bam_decode_device) or taken back (spl_bam_start), or the waits never end. */
 int spl_bam_reserve_device(spl_bam *bam);
-/* A deferred file's other option, said out loud: decode on the host's threads, starting now. */
+/* A deferred file's other option, said out loud: decode on the host's threads, starting now.  Also ends a reservation that
+ * nobody has taken up (its maker failed before it could call spl_bam_decode_device). */
 int spl_bam_start(spl_bam *bam);
 /* Inflated bytes per file byte over the first record blocks of a deferred file (0 = cannot tell): BGZF inflate is what a decode
  * costs, and which side inflates faster depends on this number -- a real library's file (3...4) is twice as fast on the GPU, a

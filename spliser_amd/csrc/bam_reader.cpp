@@ -1120,8 +1120,18 @@ int spl_bam_device_gives_up(spl_bam *bam)
     return SPL_OK;
 }
 
-// Decode on the host's threads (public face of spl_bam_start_host: a deferred file whose caller has made up his mind).
-extern "C" int spl_bam_start(spl_bam *bam) { return spl_bam_start_host(bam); }
+// Decode on the host's threads (public face of spl_bam_start_host: a deferred file whose caller has made up his mind).  A
+// reservation nobody has taken up (spl_bam_reserve_device, and then no spl_bam_decode_device: its caller failed on the way
+// there) ends here -- the file must not be left waiting for a decoder that will not come.
+extern "C" int spl_bam_start(spl_bam *bam)
+{
+    if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_start: null argument");
+    {
+        std::lock_guard<std::mutex> lock(bam->mu);
+        if (bam->claim == 1 && bam->reserved) { bam->reserved = false; bam->claim = 0; }
+    }
+    return spl_bam_start_host(bam);
+}
 
 // How well the file's first blocks behind the BAM header are compressed (inflated bytes per file byte, over up to 256 blocks):
 // what decides whether the host's inflate or the GPU's is the faster one for this file.  Deferred files only (nobody else may be

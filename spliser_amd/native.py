@@ -479,6 +479,10 @@ class BamFile(object):
                     self.decode_on_device(ctx)
             except BaseException as exc:   # (the C side never leaves the file without a decoder; keep the reason)
                 self.device_error = exc
+                try:                       # (... and if it never got as far as the C side -- no context -- the reservation must
+                    lib().spl_bam_start(self._h)   #  not outlive this thread: the host threads take the file)
+                except Exception:
+                    pass
         t = threading.Thread(target=run)
         t.start()
         self._device_thread = t

@@ -164,3 +164,25 @@ def test_directory_by_several_threads_is_the_one_thread_directory(built, tmp_pat
     rc1, text1 = _directory(bad, monkeypatch, True)
     rc2, text2 = _directory(bad, monkeypatch, False, least)
     assert rc1 != 0 and (rc1, text1) == (rc2, text2) and "not BGZF" in text1
+
+
+def test_a_reservation_nobody_takes_up_ends_with_the_host_decoder(built, tmp_path):
+    """decode_on_device_async reserves the file for the device decoder before its thread has a context; when that thread fails
+    on the way (no device, no memory) the file must not wait for ever for a decoder that will not come."""
+    names, sets = _random_sets(3, 5_000, 2)
+    path = str(tmp_path / "r.bam")
+    native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=2, seq_mode=1)
+    bam = native.BamFile(path, threads=2, defer=True)
+    assert native.lib().spl_bam_reserve_device(bam._h) == 0
+    bam.start_host_decode()
+    for c in names:
+        _same(bam.reads(c), sets[c])
+    bam.close()
+    # ... and through the thread that decode_on_device_async starts, with a device that does not exist
+    bam = native.BamFile(path, threads=2, defer=True)
+    t = bam.decode_on_device_async(device=4096)
+    t.join()
+    assert bam.device_error is not None and not bam.on_device
+    for c in names:
+        _same(bam.reads(c), sets[c])
+    bam.close()
