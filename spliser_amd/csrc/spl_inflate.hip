@@ -245,15 +245,16 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
         // `window` = the last eight bytes of the output: a copy at a distance of eight or less is made from it, no load at all.
         uint32_t copy_left = 0, copy_dist = 0, want_dist = 0;
         uint32_t lit = 0, n_lit = 0; // literals of the last turn (two at most), not yet stored
-        bool eob = false, loaded = false, wide = false;
+        bool eob = false, loaded = false;
+        uint32_t wide = 0; // what has been asked for: 0 = eight bytes, 1 = 32, 2 = 64
         uint64_t w0 = 0; // eight source bytes of a copy, or
-        u32x4 wa = {0, 0, 0, 0}, wb = {0, 0, 0, 0}; // thirty-two
+        u32x4 wa = {0, 0, 0, 0}, wb = {0, 0, 0, 0}, wc = {0, 0, 0, 0}, wd = {0, 0, 0, 0}; // thirty-two (wa, wb) or sixty-four
         const gptr8 stop = (gptr8)(br.end + 24); // (the read-ahead runs 12 bytes past what has been consumed: beyond this, the data is corrupt)
         for (uint32_t turns = 0;; ++turns) {
             // the turn's one wait for memory: everything the previous turn asked for, asked for before its decoding half.
             // (Said to the compiler as a use of all of it, here: left to itself it waits where each value is first touched, for
             // everything in flight at that point -- this turn's stores and loads included.)
-            asm volatile("" : "+v"(w0), "+v"(wa), "+v"(wb), "+v"(br.ahead));
+            asm volatile("" : "+v"(w0), "+v"(wa), "+v"(wb), "+v"(wc), "+v"(wd), "+v"(br.ahead));
             if (turns > 2u * out_len + 4096u || (gptr8)br.p > stop) { err = SPL_Z_OVERRUN; break; }
             br.refill(); // (33 bits or more after this: a symbol and its extra bits are 28 at most)
             // ---- the memory half: stores first (they may be what the loads after them read), then the loads
@@ -278,7 +279,15 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
                     bytes = rep;
                     narrow = true;
                 } else if (loaded) {
-                    if (wide) {
+                    if (wide == 2u) {
+                        __builtin_memcpy(out + at, &wa, 16);
+                        __builtin_memcpy(out + at + 16, &wb, 16);
+                        __builtin_memcpy(out + at + 32, &wc, 16);
+                        __builtin_memcpy(out + at + 48, &wd, 16);
+                        window = (uint64_t)wd.z | ((uint64_t)wd.w << 32);
+                        at += 64u;
+                        copy_left -= 64u;
+                    } else if (wide == 1u) {
                         __builtin_memcpy(out + at, &wa, 16);
                         __builtin_memcpy(out + at + 16, &wb, 16);
                         window = (uint64_t)wb.z | ((uint64_t)wb.w << 32);
@@ -308,10 +317,14 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
                 if (copy_left && copy_dist > 8u) {
                     // the next piece's source: behind `at` in full (the distance is more than its length), stored already
                     const uint8_t *src = out + at - copy_dist;
-                    wide = copy_dist >= 32u && copy_left >= 32u;
+                    wide = copy_dist >= 64u && copy_left >= 64u ? 2u : (copy_dist >= 32u && copy_left >= 32u ? 1u : 0u);
                     if (wide) {
                         __builtin_memcpy(&wa, src, 16);
                         __builtin_memcpy(&wb, src + 16, 16);
+                        if (wide == 2u) {
+                            __builtin_memcpy(&wc, src + 32, 16);
+                            __builtin_memcpy(&wd, src + 48, 16);
+                        }
                     } else {
                         __builtin_memcpy(&w0, src, 8);
                     }
