@@ -16,6 +16,10 @@ from oracle import oracle  # noqa: E402
 from spliser_amd import native, samio  # noqa: E402
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
+device_path = "--device-path" in sys.argv
+import tempfile  # noqa: E402
+tmpdir = tempfile.mkdtemp(prefix="spl_fuzz_")
+n_device = 0
 oracle.build()
 t0 = time.time()
 n_cases = n_reads = 0
@@ -57,6 +61,31 @@ with native.Context(0) as ctx:
                     n_cases += 1
                     n_reads += reads.n
                 dr.free()
+            if device_path:
+                reads = variants[-1]
+                path = os.path.join(tmpdir, "f.bam")
+                samio.write_bam(path, ["c1"], [10 ** 8], [("c1", reads)], level=1 + seed % 9)
+                os.environ["SPL_INFLATE_WINDOW_BLOCKS"] = "3" if seed % 2 else "114688"
+                os.environ["SPL_FORCE_CHUNK"] = "4096" if seed % 3 == 0 else "2048"
+                bam = native.BamFile(path, threads=2, defer=True)
+                if not bam.decode_on_device(ctx):
+                    print("device decoder did not take the file of seed %d" % seed)
+                    sys.exit(1)
+                for combine in (0, 1):
+                    want = oracle.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos, reads.pos,
+                                            reads.flag, reads.cig_off, reads.cigar, stranded, combine)
+                    with ctx.begin_reads() as dr2:
+                        dr2.add_bam(bam, "c1", 0)
+                        dr2.finish()
+                        ctx.count_launch(ds, dr2, stranded, combine)
+                        got = ds.counters()
+                    for name, w, g in zip(("beta1", "beta2s", "dbl"), want, got):
+                        if not np.array_equal(w, g):
+                            print("MISMATCH (device path) seed %d stranded %d combine %d reads %d: %s" % (seed, stranded, combine, reads.n, name))
+                            sys.exit(1)
+                    n_device += 1
+                bam.close()
+                del os.environ["SPL_FORCE_CHUNK"]
             ds.free()
             # the same reads against a query table as `combine` builds them (rows without links, partial lists)
             q = randcase.query_table(arr, seed)
@@ -75,4 +104,4 @@ with native.Context(0) as ctx:
                                 sys.exit(1)
                         n_cases += 1
                         n_reads += reads.n
-print("fuzz ok: seeds %d..%d, %d (case, mode) runs, %d reads, %.0f s" % (first, last, n_cases, n_reads, time.time() - t0))
+print("fuzz ok: seeds %d..%d, %d (case, mode) runs, %d of them more through the device decoder and layout, %d reads, %.0f s" % (first, last, n_cases, n_device, n_reads, time.time() - t0))
