@@ -114,6 +114,7 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
     if is_stranded and stranded == 0:
         raise ValueError("strandedType must be 'fr' or 'rf' for a stranded analysis")
     is_bam = isinstance(source, native.BamFile)
+    t_enter = time.perf_counter()
     items = {}
     for chrom in table.chrom_index:
         log("Processing region " + str(chrom))
@@ -148,12 +149,15 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                 order.sort(key=lambda c: source._tid.get(c, 1 << 30))
             for exact in ((False, True) if is_bam else (True,)):
                 extents = None
-                if is_bam and not exact:    # room by the header's reference lengths
-                    extents = {c: (1, source.ref_lengths[source._tid[c]]) for c in order if c in source._tid}
+                if is_bam and not exact:    # room by the header's reference lengths, and a little more: a read that hangs over
+                    # the end of its reference (soft ends, simulated data) is no reason to plan again
+                    extents = {c: (1, source.ref_lengths[source._tid[c]] + (1 << 20)) for c in order if c in source._tid}
                 elif is_bam:                # ... or, should a read reach beyond that, by what the decoder has seen (whole file)
                     source.wait_all()
                     extents = {c: (1, max(1, source.wait_ref(c)[1])) for c in order if c in source._tid}
                 shards = shard.pack([(c, items[c][0], items[c][1]) for c in order], concat_reads=False, extents=extents)
+                if os.environ.get("SPL_PROCESS_TIMING"):
+                    sys.stderr.write("[process] device %d: %s plan %.4f s after Step 3 began\n" % (device, "exact" if exact else "first", time.perf_counter() - t_enter))
                 try:
                     _count_shards(device, shards)
                     break
@@ -168,23 +172,27 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                 errors.append(exc)
 
     def _count_shards(device, shards):
-        whole = False
-        if is_bam and getattr(source, "_device_thread", None) is not None and on_junctions is None:
-            # the device decoder (process --gpuDecode) delivers every reference at once: nothing to stream chromosome by
-            # chromosome, so all chromosomes of a shard go up as ONE read set and are counted in one pass
-            source._device_thread.join()
-            whole = bool(source.on_device)
+        # the device decoder delivers every reference at once: nothing to stream chromosome by chromosome, so all chromosomes of
+        # a shard are laid out as ONE read set and counted in one pass.  (Whether it did is asked when the first site table is
+        # up: context and table take 10 ms that the decode's last kernels can run beside.)
+        device_decode = is_bam and getattr(source, "_device_thread", None) is not None and on_junctions is None
+        whole = None
         stamps = [] if os.environ.get("SPL_PROCESS_TIMING") else None   # (where a device thread's time goes, on stderr)
 
         def stamp(what):
             if stamps is not None:
                 stamps.append((what, time.perf_counter()))
-        stamp("decoder joined")
+        stamp("start")
         with native.Context(device) as ctx:
             stamp("context")
             for sh in shards:
                 with ctx.upload_sites(sh.sites) as ds:
                     stamp("site table up")
+                    if whole is None:
+                        if device_decode:
+                            source._device_thread.join()
+                        whole = bool(device_decode and source.on_device)
+                        stamp("decoder joined")
                     if whole:
                         n_expected = sum(source.wait_ref(c)[0] for c in sh.chroms if items[c][2])
                         with ctx.begin_reads(n_expected) as dr:
@@ -212,7 +220,7 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                                 on_result(chrom, items[chrom][0], res)
                         stamp("rows handed over")
                         if stamps is not None and sh is shards[-1]:
-                            sys.stderr.write("[process] device %d: %s\n" % (device, ", ".join(
+                            sys.stderr.write("[process] device %d: its shards %.4f s after Step 3 began, then %s\n" % (device, stamps[0][1] - t_enter, ", ".join(
                                 "%s +%.4f" % (w, t - stamps[k - 1][1]) for k, (w, t) in enumerate(stamps) if k)))
                         continue
                     for chrom, off, limit, (r0, r1) in zip(sh.chroms, sh.offsets, sh.limits, sh.site_rows):
