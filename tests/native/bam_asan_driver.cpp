@@ -10,6 +10,10 @@
 
 #include "../../include/spliser.h"
 
+// (internal entry points of bam_reader.cpp, as spl_bam.h declares them: the device decoder's way to the whole block directory)
+int spl_bam_walk_all(spl_bam *bam);
+size_t spl_bam_block_count(const spl_bam *bam);
+
 static std::string g_err;
 int spl_set_error(int code, const char *fmt, ...) { g_err = fmt; return code; }
 
@@ -55,6 +59,18 @@ int main(int argc, char **argv)
         }
         spl_bam_close(b);
     }
+    // the whole block directory at once, by several threads on stretches of the file and by one thread: the same blocks
+    size_t n_blocks[2] = {0, 0};
+    for (int one = 0; one < 2; ++one) {
+        if (one) setenv("SPL_WALK_ONE_THREAD", "1", 1); else { unsetenv("SPL_WALK_ONE_THREAD"); setenv("SPL_WALK_PARALLEL_MIN", "65536", 1); }
+        spl_bam *b = nullptr;
+        if (spl_bam_open_deferred(path.c_str(), 8, &b) != 0) { fprintf(stderr, "deferred open failed: %s\n", g_err.c_str()); return 1; }
+        if (spl_bam_walk_all(b) != 0) { fprintf(stderr, "walk failed: %s\n", g_err.c_str()); return 1; }
+        n_blocks[one] = spl_bam_block_count(b);
+        spl_bam_close(b);
+    }
+    unsetenv("SPL_WALK_ONE_THREAD");
+    if (n_blocks[0] != n_blocks[1] || n_blocks[0] < 4) { fprintf(stderr, "directories differ: %zu blocks by several threads, %zu by one\n", n_blocks[0], n_blocks[1]); return 1; }
     // damaged copies: every one must fail cleanly (no crash, no sanitizer report)
     FILE *fh = fopen(path.c_str(), "rb");
     std::vector<unsigned char> data;
@@ -71,6 +87,8 @@ int main(int argc, char **argv)
         fh = fopen(bp.c_str(), "wb"); fwrite(bad.data(), 1, bad.size(), fh); fclose(fh);
         spl_bam *b = nullptr;
         if (spl_bam_open(bp.c_str(), 4, &b) == 0) { ++accepted; spl_bam_close(b); } else ++rejected;
+        b = nullptr;
+        if (spl_bam_open_deferred(bp.c_str(), 4, &b) == 0) { (void)spl_bam_walk_all(b); spl_bam_close(b); } // (the stretch-wise walk on the same damage)
     }
     printf("ok: round trip on 3 thread counts; damaged copies rejected %d, accepted %d (a flipped bit inside an unused byte of the\n"
            "gzip header cannot be noticed; every payload bit is covered by CRC32)\n", rejected, accepted);
