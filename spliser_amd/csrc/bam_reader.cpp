@@ -203,7 +203,6 @@ bool walk_blocks(BlockDir &dir, const uint8_t *file, size_t fsize, const char *p
 // stretch's walk must end exactly where the next one's began, and by induction from the first every block is then one the
 // one-thread walk would have found.  Anything else (a stretch without a block start, a header that does not hold, ends that do
 // not meet) and nothing is kept: the one-thread walk does the file, and finds the words for what is wrong with it.
-namespace {
 
 bool block_at(const uint8_t *file, size_t fsize, size_t off, Block &b)
 {
@@ -303,8 +302,6 @@ bool walk_rest_in_parallel(BlockDir &dir, const uint8_t *file, size_t fsize, int
     dir.state.store(1, std::memory_order_release);
     return true;
 }
-
-} // namespace
 
 // The reads one batch found for one reference, BAM-native: exact-size arrays carved out of the extracting thread's arena.
 struct RefReads {

@@ -1278,11 +1278,9 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
             op_off[b + 1] = op_off[b] + sc.n_ops;
         }
         if (b_done == b0) return to_host("a record larger than the inflate window");
-        const uint64_t had_rec = n_rec, had_ops = n_ops;
         if (op_off[b_done] > 0xfffffff0ull) return to_host("more than 2^32 CIGAR operations");
         rc = make_room(rec_off[b_done], op_off[b_done], (double)(blocks[b_done - 1].out + blocks[b_done - 1].out_len) / (double)std::max<uint64_t>(stream_len, 1));
         if (rc) return rc;
-        (void)had_rec; (void)had_ops;
         n_rec = rec_off[b_done];
         n_ops = op_off[b_done];
         const size_t nd = b_done - b0;
