@@ -33,7 +33,7 @@ def junctions(inBAM, outputPath, isStranded=False, strandedType=None, minAnchor=
         raise ValueError("strandedType must be 'fr' or 'rf' for a stranded library")
     import threading
     from . import shard
-    source = _process.open_alignments(inBAM, threads=threads, stream=True)
+    source = _process.open_and_decode(inBAM, tuple(devices), None, threads)   # (on the GPU with one device, like `process`)
     is_bam = isinstance(source, native.BamFile)
     chroms = [c for c in source.ref_names if qChrom == c or qChrom == "All"]
     lengths = dict(zip(source.ref_names, source.ref_lengths)) if is_bam else {c: (source.reads(c).n if source.reads(c) is not None else 0) for c in chroms}
