@@ -186,3 +186,25 @@ def test_a_reservation_nobody_takes_up_ends_with_the_host_decoder(built, tmp_pat
     for c in names:
         _same(bam.reads(c), sets[c])
     bam.close()
+
+
+def test_where_process_decodes(built, tmp_path, monkeypatch):
+    """open_and_decode: told by the caller, or chosen -- the GPU with one device, by the file's compression with several."""
+    from spliser_amd import process
+    names, sets = _random_sets(8, 3_000, 2)
+    path = str(tmp_path / "p.bam")
+    native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=2, seq_mode=1)
+    calls = []
+    monkeypatch.setattr(native.BamFile, "decode_on_device_async", lambda self, device=0: calls.append(("device", device)))
+    real_start = native.BamFile.start_host_decode
+    monkeypatch.setattr(native.BamFile, "start_host_decode", lambda self: (calls.append(("host",)), real_start(self))[1])
+    for devices, asked, ratio, want in (((0,), None, 49.0, ("device", 0)), ((3,), None, 3.6, ("device", 3)), ((0, 1), None, 3.6, ("device", 0)),
+                                        ((1, 0), None, 49.0, ("host",)), ((0, 0), None, 49.0, ("device", 0)), ((0,), False, 3.6, None),
+                                        ((0, 1), True, 49.0, ("device", 0)), ((0, 1), None, 0.0, ("host",))):
+        del calls[:]
+        monkeypatch.setattr(native.BamFile, "compression_ratio", lambda self, r=ratio: r)
+        source = process.open_and_decode(path, devices, asked, 2)
+        assert calls == ([want] if want else []), (devices, asked, ratio, calls)
+        if want != ("device", devices[0]):       # (whoever was not handed to the fake device decoder decodes on the host)
+            _same(source.reads(names[0]), sets[names[0]])
+        source.close()
