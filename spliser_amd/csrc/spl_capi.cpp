@@ -919,10 +919,11 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
 }
 
 // ---- BAM decode on the device ----------------------------------------------------------------------------------------
-// The file image goes up through the staging ring (filled by the packing threads from the page cache), then: inflate + CRC32
-// (spl_inflate.hip), scan of the inflated stream for records (a guess per BGZF block, verified as a chain on the host), prefix
-// sums on the host, extraction of POS / FLAG / CIGAR into file-wide arrays, and those come back into page-locked host arrays
-// that the spl_bam adopts, one part per reference.
+// The file image goes up through the staging ring (one reader thread per buffer, from the page cache), then, a window of the
+// inflated stream at a time: inflate + CRC32 (spl_inflate.hip), scan of the window for records (a guess per BGZF block,
+// verified as a chain on the host), prefix sums on the host, extraction of POS / FLAG / CIGAR into file-wide arrays -- which
+// stay in device memory, owned by the spl_bam (DeviceReads): read sets on this device are laid out from them by kernels
+// (spl_devpack.hip, add_segment_device), the host gets copies only when it asks (fetch_device_reads).
 namespace {
 // Device memory of the decode (devmem above: the file image and the inflated stream are the buffers that made it necessary).
 struct DevBuf {

@@ -2,13 +2,13 @@
 //
 // A BGZF block is a gzip member of its own holding at most 64 KiB: a BAM file is hundreds of thousands of independent
 // DEFLATE streams, which is all the parallelism a GPU needs -- no cooperation inside a stream.  Each lane decodes its block
-// from the copy of the file in device memory straight to its place in the inflated stream.  Canonical Huffman decoding by
-// code length (count-per-length tables: the fifteen counts of a table live in registers, the symbols in the lane's scratch),
-// bits from a 64-bit buffer refilled by aligned 32-bit loads.  Every loop is bounded by the block's own sizes: a corrupt block
-// ends with an error code in its status word, never with a hang.
+// from the copy of the file in device memory straight to its place in the inflated stream (or in the window of it that is
+// being worked on).  Canonical Huffman decoding by code length (per-length limits and bases in registers, compared two at a
+// time; the symbols in LDS), bits from a 64-bit buffer refilled by aligned 32-bit loads asked for a turn ahead.  Every loop is
+// bounded by the block's own sizes: a corrupt block ends with an error code in its status word, never with a hang.
 //
-// The inflate and CRC kernels are what `process --gpuDecode` replaces the host's libdeflate + CRC32 threads with
-// (bam_reader.cpp, decode_worker); replaces SpliSER_v0_1_8.py:422 (samtools view) all the same.
+// The inflate and CRC kernels are what `process` replaces the host's libdeflate + CRC32 threads with (bam_reader.cpp,
+// decode_worker; `--hostDecode` keeps those); replaces SpliSER_v0_1_8.py:422 (samtools view) all the same.
 #ifndef SPL_INFLATE_H
 #define SPL_INFLATE_H
 #include <stdint.h>
