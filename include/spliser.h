@@ -153,7 +153,8 @@ int spl_reads_upload(spl_ctx *ctx, const spl_reads *reads, spl_dreads **out);
 int spl_reads_upload_segments(spl_ctx *ctx, int n_seg, const spl_reads *segs, const int32_t *pos_shift, spl_dreads **out);
 /* The same in steps, for segments that become available one after the other (the references of a BAM file while it is still
  * being decoded): begin, add ... add, finish; counting passes need a finished read set.  spl_reads_add_bam takes the reads of
- * reference `tid` straight from the decoder's buffers (waits until that reference is complete, spl_bam_wait_ref). */
+ * reference `tid` straight from the decoder's buffers -- host memory, or the device's own after spl_bam_decode_device -- and
+ * waits until that reference is complete (spl_bam_wait_ref). */
 int spl_reads_begin(spl_ctx *ctx, spl_dreads **out);
 /* ... with the number of reads that are going to be added, if the caller knows it (0 = no idea): sets of 64 M reads and more are
  * cut into chunks of 4096 instead of 2048 reads, which suits launches of that size (3.5 % on 100 M reads) and no others. */
@@ -204,9 +205,11 @@ int spl_last_launch_info(const spl_ctx *ctx, int32_t *grid_out, int32_t *block_o
 int spl_bam_open(const char *path, int n_threads, spl_bam **out);
 int spl_bam_open_stream(const char *path, int n_threads, spl_bam **out);
 /* Decode on the DEVICE instead: spl_bam_open_deferred reads the header and starts nothing; spl_bam_decode_device then sends the
- * file to the GPU as it is, inflates its BGZF blocks there (one block per lane, CRC32 checked), finds and extracts the alignment
- * records there, and brings back only what checkBam reads (POS, FLAG, CIGAR: a fifteenth of the inflated bytes); every
- * reference is complete when it returns.  *on_device_out = 0: the file is one the device path does not take (not sorted by
+ * file to the GPU as it is, inflates its BGZF blocks there (one block per lane, CRC32 checked, a window of the stream at a
+ * time), finds and extracts the alignment records there, and keeps what checkBam reads (POS, FLAG, CIGAR: a fifteenth of the
+ * inflated bytes) in device memory: spl_reads_add_bam on a context of the same device lays a reference's reads out for the
+ * counting kernels with kernels, nothing crosses PCIe again; spl_bam_reads (or a context on another device) makes the host
+ * copies, once.  Every reference is complete when the call returns.  *on_device_out = 0: the file is one the device path does not take (not sorted by
  * reference, CIGARs parked in CG tags, anything malformed) and the host threads have been started on it instead -- results and
  * error reporting are the host decoder's either way.  Waiting on a deferred file nobody decoded starts the host decode. */
 int spl_bam_open_deferred(const char *path, int n_threads, spl_bam **out);
