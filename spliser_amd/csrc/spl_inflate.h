@@ -22,6 +22,11 @@ struct spl_zblock {
     uint32_t pad;
 };
 
+// The file image must be readable for this many bytes past the end of any block's DEFLATE data (inside the file that is the
+// next block; behind the last one the caller pads), and the inflated stream writable for 16 bytes past its end: the wave kernel
+// moves 16 bytes at a time.
+#define SPL_Z_IMAGE_PAD 64u
+
 // status codes written per block (0 = fine)
 #define SPL_Z_OK 0u
 #define SPL_Z_BAD_BLOCK_TYPE 1u

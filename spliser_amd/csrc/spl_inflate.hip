@@ -1,8 +1,22 @@
 // spl_inflate.hip -- see spl_inflate.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "spl_inflate.h"
+#include "spl_wave.h"
+#include "spl_inflate_wave.h"
+
+// One BGZF block per WAVE (spl_inflate_wave.h has the method, and is what the host tests run through the wave emulator).
+__global__ __launch_bounds__(64) void spl_inflate_wave_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status)
+{
+    __shared__ splz::Shared sh;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const spl_zblock zb = blocks[b];
+    const uint32_t st = splz::inflate_block(sh, image, zb, out_all);
+    if (threadIdx.x == 0) status[b] = st;
+}
 
 namespace {
 
@@ -641,7 +655,9 @@ extern "C" int spl_dev_launch_bam_bounds(const int32_t *tid, const uint32_t *cig
 extern "C" int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *stream)
 {
     if (n_blocks == 0) return 0;
-    hipLaunchKernelGGL(spl_inflate_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status);
+    static const bool per_lane = getenv("SPL_INFLATE_PER_LANE") != nullptr; // (round 2's kernel, a block per lane: kept for comparison)
+    if (per_lane) hipLaunchKernelGGL(spl_inflate_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status);
+    else hipLaunchKernelGGL(spl_inflate_wave_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status);
     return (int)hipGetLastError();
 }
 

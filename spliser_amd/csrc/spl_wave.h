@@ -1,0 +1,54 @@
+// spl_wave.h -- the handful of wave-level primitives the wave-cooperative kernels are written against (spl_inflate_wave.h, ...).
+//
+// On the device they are the gfx950 operations themselves (one wave = 64 lanes = one workgroup, so a workgroup barrier is the
+// wave's own).  tests/hostsim/wave_emul.h provides the same names on the host, 64 fibers taking turns, so that the kernel
+// bodies -- the very same source -- run and are checked on a CPU (tests/test_inflate_wave_host.py): there is no GPU where this
+// is built.  Rules the bodies keep, and the emulator enforces: every primitive below is called by all 64 lanes from wave-uniform
+// control flow, and data goes from lane to lane through shared memory only across a wv_sync().
+#ifndef SPL_WAVE_H
+#define SPL_WAVE_H
+
+#ifndef SPL_WAVE_EMUL
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WV_DEV __device__ __forceinline__
+#define WV_SHARED_PTR(T) T *
+
+namespace wv {
+WV_DEV uint32_t lane() { return threadIdx.x & 63u; }
+WV_DEV uint64_t ballot(bool p) { return __ballot(p); }
+WV_DEV bool any(bool p) { return __ballot(p) != 0ull; }
+WV_DEV uint32_t shfl(uint32_t v, uint32_t src_lane) { return (uint32_t)__shfl((int)v, (int)src_lane, 64); }
+WV_DEV uint32_t shfl_up(uint32_t v, uint32_t delta) { return (uint32_t)__shfl_up((int)v, delta, 64); }
+// a value every lane holds alike, said to the compiler (scalar registers, scalar branches)
+WV_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+WV_DEV uint32_t readlane(uint32_t v, uint32_t uniform_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)uniform_lane)); }
+// shared memory written before it is readable by every lane after it (the workgroup is one wave: its barrier costs nothing to wait for)
+WV_DEV void sync() { __syncthreads(); }
+WV_DEV uint32_t lds_max(uint32_t *p, uint32_t v) { return atomicMax(p, v); }
+WV_DEV uint32_t lds_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
+WV_DEV uint32_t popc64(uint64_t m) { return (uint32_t)__popcll(m); }
+WV_DEV uint32_t ffs64(uint64_t m) { return (uint32_t)__ffsll((long long)m) - 1u; } // index of the lowest set bit (m != 0)
+WV_DEV uint32_t brev32(uint32_t v) { return __brev(v); }
+// inclusive prefix sum over the lanes
+WV_DEV uint32_t scan_add(uint32_t v)
+{
+    const uint32_t l = lane();
+#pragma unroll
+    for (uint32_t s = 1; s < 64u; s <<= 1) {
+        const uint32_t up = shfl_up(v, s);
+        if (l >= s) v += up;
+    }
+    return v;
+}
+// unaligned accesses to global memory (the hardware takes them: the compiler is told the alignment is 1)
+WV_DEV uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+WV_DEV uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+WV_DEV void st16(uint8_t *p, uint32_t v) { const uint16_t x = (uint16_t)v; __builtin_memcpy(p, &x, 2); }
+WV_DEV void st32(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+WV_DEV void st64(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+} // namespace wv
+#endif // !SPL_WAVE_EMUL
+
+#endif

@@ -1,0 +1,68 @@
+// inflate_wave_host.cpp -- the body of spl_inflate_wave_kernel (spliser_amd/csrc/spl_inflate_wave.h) run on the host, a wave of
+// 64 fibers per BGZF block (wave_emul.h): what tests/test_inflate_wave_host.py loads, and a command line over a whole .bam:
+//   g++ -O1 -g -o /tmp/iw tests/hostsim/inflate_wave_host.cpp -lz && /tmp/iw file.bam [max_blocks]
+#include <zlib.h>
+
+#include <vector>
+
+#define WAVE_EMUL_IMPLEMENTATION
+#include "wave_emul.h"
+#include "../../spliser_amd/csrc/spl_inflate_wave.h"
+
+extern "C" int emul_inflate_blocks(const uint8_t *image, const spl_zblock *blocks, uint32_t n, uint8_t *out, uint32_t *status)
+{
+    static splz::Shared sh;
+    for (uint32_t b = 0; b < n; ++b) {
+        memset(&sh, 0xEE, sizeof sh); // (nothing may depend on what the wave before left)
+        const bool ok = wv::run_wave([&]() {
+            const uint32_t st = splz::inflate_block(sh, image, blocks[b], out);
+            if (wv::lane() == 0) status[b] = st;
+        });
+        if (!ok) return -1 - (int)b;
+    }
+    return 0;
+}
+
+#ifndef EMUL_NO_MAIN
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: %s file.bam [max_blocks]\n", argv[0]); return 2; }
+    const size_t max_blocks = argc > 2 ? (size_t)atoll(argv[2]) : (size_t)-1;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) { perror(argv[1]); return 1; }
+    fseek(f, 0, SEEK_END);
+    const size_t fsize = (size_t)ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> file(fsize + 64, 0);
+    if (fread(file.data(), 1, fsize, f) != fsize) return 1;
+    fclose(f);
+    size_t at = 0, nb = 0, bad = 0;
+    while (at + 18 <= fsize && nb < max_blocks) {
+        const uint8_t *h = file.data() + at;
+        if (h[0] != 0x1f || h[1] != 0x8b) { fprintf(stderr, "not a BGZF block at %zu\n", at); return 1; }
+        const size_t bsize = (size_t)(h[16] | h[17] << 8) + 1;
+        const uint32_t isize = (uint32_t)h[bsize - 4] | (uint32_t)h[bsize - 3] << 8 | (uint32_t)h[bsize - 2] << 16 | (uint32_t)h[bsize - 1] << 24;
+        spl_zblock zb{(uint64_t)at + 18, 0, (uint32_t)(bsize - 26), isize, 0, 0};
+        std::vector<uint8_t> want(isize + 1), got(isize + 64, 0xA5);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        inflateInit2(&zs, -15);
+        zs.next_in = const_cast<Bytef *>(h + 18); zs.avail_in = (uInt)(bsize - 26); zs.next_out = want.data(); zs.avail_out = isize + 1;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END) { fprintf(stderr, "zlib: block %zu does not inflate\n", nb); return 1; }
+        uint32_t status = 99;
+        const int er = emul_inflate_blocks(file.data(), &zb, 1, got.data(), &status);
+        if (er || status != 0 || memcmp(got.data(), want.data(), isize) != 0 || got[isize] != 0xA5) {
+            size_t k = 0;
+            while (k < isize && got[k] == want[k]) ++k;
+            fprintf(stderr, "block %zu (at %zu, %zu -> %u bytes): emulator %d, status %u, first difference at %zu\n", nb, at, bsize - 26, isize, er, status, k);
+            if (++bad > 5) return 1;
+        }
+        at += bsize;
+        nb++;
+    }
+    printf("%zu blocks, %zu bad\n", nb, bad);
+    return bad ? 1 : 0;
+}
+#endif
