@@ -205,9 +205,10 @@ int spl_last_launch_info(const spl_ctx *ctx, int32_t *grid_out, int32_t *block_o
 int spl_bam_open(const char *path, int n_threads, spl_bam **out);
 int spl_bam_open_stream(const char *path, int n_threads, spl_bam **out);
 /* Decode on the DEVICE instead: spl_bam_open_deferred reads the header and starts nothing; spl_bam_decode_device then sends the
- * file to the GPU as it is, inflates its BGZF blocks there (one block per lane, CRC32 checked, a window of the stream at a
- * time), finds and extracts the alignment records there, and keeps what checkBam reads (POS, FLAG, CIGAR: a fifteenth of the
- * inflated bytes) in device memory: spl_reads_add_bam on a context of the same device lays a reference's reads out for the
+ * file to the GPU as it is, inflates its BGZF blocks there (Huffman decoding a wave per block, the copies it leaves a lane per
+ * block, CRC32 checked; a window of the stream at a time, the next window's decoding beside this window's checks and the upload
+ * beside both), finds and extracts the alignment records there, and keeps what checkBam reads (POS, FLAG, CIGAR: a fifteenth of
+ * the inflated bytes) in device memory: spl_reads_add_bam on a context of the same device lays a reference's reads out for the
  * counting kernels with kernels, nothing crosses PCIe again; spl_bam_reads (or a context on another device) makes the host
  * copies, once.  Every reference is complete when the call returns.  *on_device_out = 0: the file is one the device path does not take (not sorted by
  * reference, CIGARs parked in CG tags, anything malformed) and the host threads have been started on it instead -- results and
@@ -218,6 +219,20 @@ int spl_bam_decode_device(spl_ctx *ctx, spl_bam *bam, int *on_device_out);
  * references: the file is marked as taken by the device decoder now, so that those waits wait instead of starting the host
  * decode.  The promise must be kept (spl_bam_decode_device) or taken back (spl_bam_start), or the waits never end. */
 int spl_bam_reserve_device(spl_bam *bam);
+/* The same decode in SHARES, one per device (replaces SpliSER_v0_1_8.py:422 per chromosome shard): a BAM
+ * file is sorted by reference and its BGZF blocks are independent, so every device can take the stretch of the file where its own
+ * references' records begin -- over its own PCIe link, into its own memory, no exchange.  spl_bam_share_plan cuts the file into up
+ * to n_shares stretches of about equal size at reference boundaries (block directory, then a bisection that inflates one block
+ * per probe on the host) and says how many it made (*n_out; fewer than asked when the file has few references);
+ * spl_bam_share_range says which references share k holds (tid_lo <= tid < tid_hi; the last share also holds the records without
+ * a reference).  The file is then reserved (spl_bam_reserve_device) and EVERY share decoded by a
+ * spl_bam_decode_device_share call, each on the context of the device that is to count its references; the file is complete
+ * when the last of them returns.  Should any share not be decodable on its device, all of them are dropped and the host threads
+ * decode the file (*on_device_out = 0 from that share's call; spl_bam_decoded_on_device says how it ended). */
+int spl_bam_share_plan(spl_bam *bam, int n_shares, int *n_out);
+int spl_bam_share_range(spl_bam *bam, int k, int *tid_lo_out, int *tid_hi_out);
+int spl_bam_decode_device_share(spl_ctx *ctx, spl_bam *bam, int k, int *on_device_out);
+int spl_bam_decoded_on_device(spl_bam *bam, int *on_device_out);
 /* A deferred file's other option, said out loud: decode on the host's threads, starting now.  Also ends a reservation that
  * nobody has taken up (its maker failed before it could call spl_bam_decode_device). */
 int spl_bam_start(spl_bam *bam);

@@ -16,6 +16,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <math.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -481,9 +482,16 @@ struct spl_bam {
     // reads adopted from the device decoder without their host copies: fetched (dev_fetch) when somebody wants to read them
     bool lazy = false;
     int (*dev_fetch)(void *, int32_t **, uint16_t **, uint32_t **, uint32_t **) = nullptr;
-    std::vector<int64_t> lazy_first;       // first record of every reference in the file-wide arrays
-    void *dev_handle = nullptr;            // what the device decoder left in device memory for the device packer (spl_capi.cpp)
-    void (*dev_free)(void *) = nullptr;    // ... and how to give it back
+    std::vector<int64_t> lazy_first;       // first record of every reference in the arrays of the share that holds it
+    // what the device decoder(s) left in device memory for the device packer (spl_capi.cpp), and how to give it back: one handle
+    // for a whole-file decode, one per share otherwise
+    struct DevShare { void *handle = nullptr; void (*free_fn)(void *) = nullptr; int32_t tid_lo = 0, tid_hi = 0; bool fetched = false; };
+    std::vector<DevShare> dev_shares;
+    // a decode in shares (spl_bam_share_plan): the plan, and what the shares' decoders have reported so far
+    std::vector<spl_bam_share> shares;
+    struct ShareResult { bool reported = false, failed = false; void *handle = nullptr; void (*free_fn)(void *) = nullptr; std::vector<int64_t> first, n, max_end; int64_t n_records = 0; };
+    std::vector<ShareResult> share_results;
+    bool shares_on_device = false;
     bool reserved = false;     // claim == 1 on behalf of a spl_bam_decode_device call that is still to come
     int claim = 0;             // 0 = nobody decodes yet (deferred open), 1 = the device decoder is at it, 2 = host worker started / arrays adopted
     uint64_t header_bytes = 0; // magic, text and reference dictionary: the first record starts here in the inflated stream
@@ -494,7 +502,8 @@ struct spl_bam {
 spl_bam::~spl_bam()
 {
     if (worker.joinable()) worker.join();
-    if (dev_handle && dev_free) dev_free(dev_handle);
+    for (DevShare &d : dev_shares) if (d.handle && d.free_fn) d.free_fn(d.handle);
+    for (ShareResult &r : share_results) if (r.handle && r.free_fn) r.free_fn(r.handle);
     for (auto &list : parts) for (PendingPart *p : list) delete p;
     for (void *slab : slabs) free(slab);
     if (map) munmap(map, fsize);
@@ -1178,14 +1187,15 @@ void spl_bam_block_get(const spl_bam *bam, size_t i, spl_bam_block_info *out)
 void spl_bam_set_device_reads(spl_bam *bam, void *handle, void (*free_fn)(void *))
 {
     std::lock_guard<std::mutex> lock(bam->mu);
-    if (bam->dev_handle && bam->dev_free) bam->dev_free(bam->dev_handle);
-    bam->dev_handle = handle;
-    bam->dev_free = free_fn;
+    for (spl_bam::DevShare &d : bam->dev_shares) if (d.handle && d.free_fn) d.free_fn(d.handle);
+    bam->dev_shares.clear();
+    if (handle) { spl_bam::DevShare d; d.handle = handle; d.free_fn = free_fn; d.tid_lo = 0; d.tid_hi = bam->n_refs + 1; bam->dev_shares.push_back(d); }
 }
-void *spl_bam_device_reads(spl_bam *bam)
+void *spl_bam_device_reads(spl_bam *bam, int tid)
 {
     std::lock_guard<std::mutex> lock(bam->mu);
-    return bam->dev_handle;
+    for (const spl_bam::DevShare &d : bam->dev_shares) if (tid >= d.tid_lo && tid < d.tid_hi) return d.handle;
+    return nullptr;
 }
 const uint8_t *spl_bam_image(const spl_bam *bam, size_t *fsize_out) { if (fsize_out) *fsize_out = bam->fsize; return (const uint8_t *)bam->map; }
 int spl_bam_fd(const spl_bam *bam) { return bam->fd; }
@@ -1228,31 +1238,244 @@ int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off,
     return SPL_OK;
 }
 
+// ---- a decode in shares ------------------------------------------------------------------------------------------------
+namespace {
+// The reference (records without one: n_refs) of the last record that begins in block b -- or, when none does, of the first
+// record behind it -- by inflating the block and a few behind it.  -2: cannot tell.
+int last_tid_of_block(spl_bam *bam, size_t b, void *ld, std::vector<uint8_t> &buf)
+{
+    const uint8_t *file = (const uint8_t *)bam->map;
+    const size_t n_blocks = bam->dir.n_ready.load();
+    for (int hop = 0; hop < 64 && b < n_blocks; ++hop, ++b) {
+        const Block &blk = bam->dir.at(b);
+        if (blk.uoff + blk.isize <= bam->header_bytes) continue; // (BAM header only)
+        size_t len = 0, nb = 0;
+        for (size_t k = b; k < n_blocks && nb < 6; ++k, ++nb) len += bam->dir.at(k).isize;
+        buf.resize(len + 64);
+        size_t at = 0;
+        for (size_t k = b; k < b + nb; ++k) {
+            if (!inflate_block(file, bam->dir.at(k), buf.data() + at, ld)) return -2;
+            at += bam->dir.at(k).isize;
+        }
+        const uint8_t *const end = buf.data() + len;
+        const size_t u1 = blk.isize;
+        size_t start;
+        if (blk.uoff <= bam->header_bytes) start = (size_t)(bam->header_bytes - blk.uoff);
+        else start = (size_t)(find_record_start(buf.data(), end, bam->n_refs) - buf.data());
+        int last = -2;
+        size_t p = start;
+        while (p + 36 <= len) {
+            const int32_t tid = le32s(buf.data() + p + 4);
+            const uint32_t bs = le32(buf.data() + p);
+            if (bs < 32) return -2;
+            const int eff = tid < 0 || tid >= bam->n_refs ? bam->n_refs : tid;
+            if (p >= u1) { if (last == -2) last = eff; break; } // (nothing began in the block: the first record behind it)
+            last = eff;
+            p += 4 + (size_t)bs;
+        }
+        if (last != -2) return last;
+    }
+    return b >= n_blocks ? bam->n_refs : -2; // (behind the last record: behind every reference)
+}
+} // namespace
+
+extern "C" int spl_bam_share_plan(spl_bam *bam, int n_shares, int *n_out)
+{
+    if (!bam || n_shares < 1) return spl_set_error(SPL_ERR_ARG, "spl_bam_share_plan: bad argument");
+    {
+        std::lock_guard<std::mutex> lock(bam->mu);
+        if (!bam->shares.empty()) { if (n_out) *n_out = (int)bam->shares.size(); return SPL_OK; }
+    }
+    int rc = spl_bam_walk_all(bam);
+    if (rc) return rc;
+    const size_t n_blocks = bam->dir.n_ready.load();
+    std::vector<spl_bam_share> plan;
+    const int32_t all = bam->n_refs + 1;
+    auto whole = [&]() { plan.clear(); plan.push_back(spl_bam_share{0, n_blocks, 0, all}); };
+    whole();
+    if (n_shares > 1 && n_blocks > 8 && bam->n_refs > 1) {
+        void *ld = deflate_lib().ok ? deflate_lib().alloc() : nullptr;
+        std::vector<uint8_t> buf;
+        bool ok = true;
+        const bool dbg = getenv("SPL_BAM_TIMING") != nullptr;
+        auto g = [&](size_t b) { const int t = last_tid_of_block(bam, b, ld, buf); if (t == -2) ok = false; if (dbg) fprintf(stderr, "[share plan] block %zu: reference %d\n", b, t); return t; };
+        auto first_block_with = [&](int32_t tid) { // the first block b with g(b) >= tid (g does not decrease in a sorted file)
+            size_t lo = 0, hi = n_blocks; // (g(hi) >= tid: everything is below the end)
+            while (lo < hi && ok) {
+                const size_t mid = lo + (hi - lo) / 2;
+                if (g(mid) >= tid) hi = mid; else lo = mid + 1;
+            }
+            return lo;
+        };
+        std::vector<int32_t> cut_tid{0};
+        std::vector<size_t> cut_block{0};
+        for (int k = 1; k < n_shares && ok; ++k) {
+            const size_t target = (size_t)((double)bam->fsize * k / n_shares);
+            size_t lo = 0, hi = n_blocks; // the block at the target offset
+            while (lo + 1 < hi) { const size_t mid = lo + (hi - lo) / 2; if (bam->dir.at(mid).coff <= target) lo = mid; else hi = mid; }
+            const int t = g(lo);
+            if (!ok) break;
+            // the reference there begins at or before the target, the next one behind it: the nearer of the two
+            const int32_t cands[2] = {(int32_t)t, (int32_t)t + 1};
+            int32_t best_tid = -1; size_t best_block = 0; double best_d = 0;
+            for (int32_t c : cands) {
+                if (c <= cut_tid.back() || c >= bam->n_refs) continue; // (no share of its own for the records without a reference)
+                const size_t bb = first_block_with(c);
+                if (!ok) break;
+                const double d = fabs((double)(bb < n_blocks ? bam->dir.at(bb).coff : bam->fsize) - (double)target);
+                if (best_tid < 0 || d < best_d) { best_tid = c; best_block = bb; best_d = d; }
+            }
+            if (ok && best_tid >= 0 && best_block < n_blocks) { cut_tid.push_back(best_tid); cut_block.push_back(best_block); }
+        }
+        if (ld) deflate_lib().free_(ld);
+        if (ok && cut_tid.size() > 1) {
+            plan.clear();
+            for (size_t k = 0; k < cut_tid.size(); ++k) {
+                const bool last = k + 1 == cut_tid.size();
+                spl_bam_share sh;
+                sh.tid_lo = cut_tid[k];
+                sh.tid_hi = last ? all : cut_tid[k + 1];
+                sh.block_lo = cut_block[k];
+                sh.block_hi = last ? n_blocks : std::min(n_blocks, cut_block[k + 1] + 1); // (the block the next reference begins in holds the last of ours)
+                plan.push_back(sh);
+            }
+        }
+    }
+    std::lock_guard<std::mutex> lock(bam->mu);
+    if (bam->shares.empty()) { bam->shares = plan; bam->share_results.assign(plan.size(), spl_bam::ShareResult()); }
+    if (n_out) *n_out = (int)bam->shares.size();
+    return SPL_OK;
+}
+
+int spl_bam_share_get(spl_bam *bam, int k, spl_bam_share *out)
+{
+    std::lock_guard<std::mutex> lock(bam->mu);
+    if (!bam || k < 0 || (size_t)k >= bam->shares.size() || !out) return spl_set_error(SPL_ERR_ARG, "spl_bam_share_get: no such share");
+    *out = bam->shares[(size_t)k];
+    return SPL_OK;
+}
+
+int spl_bam_share_done(spl_bam *bam, int k, void *handle, void (*free_fn)(void *), const int64_t *ref_first, const int64_t *ref_n,
+                       const int64_t *ref_max_end, int64_t n_records, int failed)
+{
+    std::unique_lock<std::mutex> lock(bam->mu);
+    if (k < 0 || (size_t)k >= bam->share_results.size() || bam->share_results[(size_t)k].reported) {
+        lock.unlock();
+        if (handle && free_fn) free_fn(handle);
+        return spl_set_error(SPL_ERR_ARG, "spl_bam_share_done: no such share, or reported twice");
+    }
+    spl_bam::ShareResult &r = bam->share_results[(size_t)k];
+    r.reported = true;
+    r.failed = failed != 0;
+    r.handle = handle;
+    r.free_fn = free_fn;
+    r.n_records = n_records;
+    if (!r.failed) {
+        r.first.assign(ref_first, ref_first + bam->n_refs);
+        r.n.assign(ref_n, ref_n + bam->n_refs);
+        r.max_end.assign(ref_max_end, ref_max_end + bam->n_refs);
+    }
+    bool all = true, any_failed = false;
+    for (const spl_bam::ShareResult &x : bam->share_results) { all = all && x.reported; any_failed = any_failed || x.failed; }
+    if (!all) return SPL_OK;
+    if (bam->claim != 1) return SPL_OK; // (somebody gave the file to the host threads meanwhile)
+    bam->claim = 2;
+    if (any_failed) { // everything the devices have is dropped: the host threads decode the file
+        std::vector<spl_bam::ShareResult> drop;
+        drop.swap(bam->share_results);
+        bam->share_results.assign(drop.size(), spl_bam::ShareResult());
+        for (spl_bam::ShareResult &x : bam->share_results) x.reported = true;
+        bam->worker = std::thread(decode_worker, bam);
+        lock.unlock();
+        for (spl_bam::ShareResult &x : drop) if (x.handle && x.free_fn) x.free_fn(x.handle);
+        return SPL_OK;
+    }
+    bam->lazy = true;
+    bam->lazy_first.assign((size_t)bam->n_refs, 0);
+    int64_t n_all = 0;
+    for (size_t s = 0; s < bam->share_results.size(); ++s) {
+        spl_bam::ShareResult &x = bam->share_results[s];
+        const spl_bam_share &sh = bam->shares[s];
+        spl_bam::DevShare d;
+        d.handle = x.handle; d.free_fn = x.free_fn; d.tid_lo = sh.tid_lo; d.tid_hi = sh.tid_hi;
+        x.handle = nullptr;
+        bam->dev_shares.push_back(d);
+        n_all += x.n_records;
+        for (int t = std::max(0, (int)sh.tid_lo); t < bam->n_refs && t < sh.tid_hi; ++t) {
+            if (x.n[(size_t)t] <= 0) continue;
+            PendingPart *pp = new PendingPart();
+            pp->tid = t;
+            pp->reads.n = (size_t)x.n[(size_t)t];
+            pp->reads.max_end = x.max_end[(size_t)t];
+            bam->parts[(size_t)t].push_back(pp);
+            bam->ref_reads[(size_t)t] = x.n[(size_t)t];
+            bam->ref_max_end[(size_t)t] = x.max_end[(size_t)t];
+            bam->lazy_first[(size_t)t] = x.first[(size_t)t];
+        }
+    }
+    bam->n_records = n_all;
+    bam->max_tid_seen = bam->n_refs - 1;
+    bam->complete_upto = bam->n_refs;
+    bam->shares_on_device = true;
+    bam->done = true;
+    bam->cv.notify_all();
+    return SPL_OK;
+}
+
+extern "C" int spl_bam_share_range(spl_bam *bam, int k, int *tid_lo_out, int *tid_hi_out)
+{
+    if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_share_range: null argument");
+    spl_bam_share sh;
+    const int rc = spl_bam_share_get(bam, k, &sh);
+    if (rc) return rc;
+    if (tid_lo_out) *tid_lo_out = sh.tid_lo;
+    if (tid_hi_out) *tid_hi_out = sh.tid_hi;
+    return SPL_OK;
+}
+
+extern "C" int spl_bam_decoded_on_device(spl_bam *bam, int *on_device_out)
+{
+    if (!bam || !on_device_out) return spl_set_error(SPL_ERR_ARG, "spl_bam_decoded_on_device: null argument");
+    std::lock_guard<std::mutex> lock(bam->mu);
+    *on_device_out = (bam->shares_on_device || (bam->done && !bam->dev_shares.empty())) ? 1 : 0;
+    return SPL_OK;
+}
+
+int spl_bam_shares_on_device(spl_bam *bam)
+{
+    std::lock_guard<std::mutex> lock(bam->mu);
+    return bam->shares_on_device ? 1 : 0;
+}
+
 void spl_bam_set_fetch(spl_bam *bam, int (*fetch)(void *, int32_t **, uint16_t **, uint32_t **, uint32_t **))
 {
     std::lock_guard<std::mutex> lock(bam->mu);
     bam->dev_fetch = fetch;
 }
 
-// The host copies of reads that were adopted without them (call with bam->mu held).
+// The host copies of reads that were adopted without them (call with bam->mu held): of every share that has not brought its yet.
 static int fetch_lazy(spl_bam *bam)
 {
     if (!bam->lazy) return SPL_OK;
-    if (!bam->dev_fetch || !bam->dev_handle) return spl_set_error(SPL_ERR_ARG, "%s: decoded reads are neither on the host nor fetchable", bam->path.c_str());
-    int32_t *pos = nullptr; uint16_t *flag = nullptr; uint32_t *cig_off = nullptr, *cigar = nullptr;
-    const int rc = bam->dev_fetch(bam->dev_handle, &pos, &flag, &cig_off, &cigar);
-    if (rc) return rc;
-    bam->slabs.push_back(pos); bam->slabs.push_back(flag); bam->slabs.push_back(cig_off); bam->slabs.push_back(cigar);
-    for (int t = 0; t < bam->n_refs; ++t) {
-        for (PendingPart *pp : bam->parts[(size_t)t]) {
-            RefReads &r = pp->reads;
-            const int64_t first = bam->lazy_first[(size_t)t];
-            r.pos = pos + first;
-            r.flag = flag + first;
-            r.cig_off = cig_off + first;
-            r.cigar = cigar;
-            r.n_ops = (size_t)(r.cig_off[r.n] - r.cig_off[0]);
+    if (!bam->dev_fetch || bam->dev_shares.empty()) return spl_set_error(SPL_ERR_ARG, "%s: decoded reads are neither on the host nor fetchable", bam->path.c_str());
+    for (spl_bam::DevShare &d : bam->dev_shares) {
+        if (d.fetched) continue;
+        int32_t *pos = nullptr; uint16_t *flag = nullptr; uint32_t *cig_off = nullptr, *cigar = nullptr;
+        const int rc = bam->dev_fetch(d.handle, &pos, &flag, &cig_off, &cigar);
+        if (rc) return rc;
+        bam->slabs.push_back(pos); bam->slabs.push_back(flag); bam->slabs.push_back(cig_off); bam->slabs.push_back(cigar);
+        for (int t = std::max(0, (int)d.tid_lo); t < bam->n_refs && t < d.tid_hi; ++t) {
+            for (PendingPart *pp : bam->parts[(size_t)t]) {
+                RefReads &r = pp->reads;
+                const int64_t first = bam->lazy_first[(size_t)t];
+                r.pos = pos + first;
+                r.flag = flag + first;
+                r.cig_off = cig_off + first;
+                r.cigar = cigar;
+                r.n_ops = (size_t)(r.cig_off[r.n] - r.cig_off[0]);
+            }
         }
+        d.fetched = true;
     }
     bam->lazy = false;
     return SPL_OK;

@@ -26,7 +26,20 @@ int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off,
                   const int64_t *ref_max_end, int64_t n_records_total);
 // what the device decoder keeps in device memory for the device packer: an opaque handle, freed with the file
 void spl_bam_set_device_reads(spl_bam *bam, void *handle, void (*free_fn)(void *));
-void *spl_bam_device_reads(spl_bam *bam);
+void *spl_bam_device_reads(spl_bam *bam, int tid);          // the handle that holds reference `tid` (several after a decode in shares)
+
+// ---- a decode in SHARES: each device takes the stretch of the file where its references' records begin ----------------
+// BGZF blocks [block_lo, block_hi) and the references tid_lo <= tid < tid_hi (records without a reference count as n_ref).
+// Both ends of a stretch may hold records of a neighbour's references: they are skipped, not decoded twice.
+struct spl_bam_share { uint64_t block_lo, block_hi; int32_t tid_lo, tid_hi; };
+// Cuts the file into up to n_shares stretches of about equal size at reference boundaries (found by inflating a block per probe
+// on the host).  The whole block directory is walked first.  Once per file; later calls return the first plan.
+int spl_bam_share_get(spl_bam *bam, int k, spl_bam_share *out);
+// A share's decoder is done: `handle` holds its references (share-local first record per reference in ref_first), or failed != 0.
+// When the last share has reported the file is complete -- or, if one failed, everything is dropped and the host threads decode.
+int spl_bam_share_done(spl_bam *bam, int k, void *handle, void (*free_fn)(void *), const int64_t *ref_first, const int64_t *ref_n,
+                       const int64_t *ref_max_end, int64_t n_records, int failed);
+int spl_bam_shares_on_device(spl_bam *bam);                  // 1: all shares reported and none failed
 // spl_bam_adopt with null arrays = the reads stay on the device; `fetch(handle, ...)` brings malloc'ed host copies when a host-side
 // reader asks for them (spl_bam_source, spl_bam_reads)
 void spl_bam_set_fetch(spl_bam *bam, int (*fetch)(void *, int32_t **, uint16_t **, uint32_t **, uint32_t **));

@@ -1063,58 +1063,158 @@ static int add_segment_device(spl_ctx *c, spl_dreads *d, const DeviceReads &dev,
     return SPL_OK;
 }
 
-static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out);
+// ---- the decode itself: a share of the file (or all of it) on one device -----------------------------------------------
+// A pipeline over WINDOWS of the share's BGZF blocks (a fixed number of blocks each, two buffers of inflated stream):
+//   copy stream   the file's bytes, piece by piece through the staging ring (one reader thread per staging buffer)
+//   stream A      Huffman decoding of window k + 1 (spl_inflate_decode_kernel, a wave per block) as soon as its bytes have arrived
+//   stream B      window k: the copies the decoding left (a lane per block), CRC32, the scan for records, -- host: the chain of
+//                 record boundaries, prefix sums -- extraction
+// The kernels of stream B are lanes waiting for memory, the one of stream A is arithmetic: they share the device well.  A record
+// that straddles two windows: the bytes from the first block that is not done with to the window's end are copied in front of the
+// next window's buffer (its head room), so that scan and extraction see them in one piece; the blocks are not inflated twice.
+namespace {
+struct ShareOut { DeviceReads *reads = nullptr; int64_t n_all = 0; bool to_host = false; };
+}
+static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, ShareOut &res);
+
+static void fill_whole(spl_bam *bam, spl_bam_share &sh) { sh.block_lo = 0; sh.block_hi = spl_bam_block_count(bam); sh.tid_lo = 0; sh.tid_hi = spl_bam_n_ref(bam) + 1; }
 
 extern "C" int spl_bam_decode_device(spl_ctx *c, spl_bam *bam, int *on_device_out)
 {
     if (!c || !bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_decode_device: null argument");
     if (on_device_out) *on_device_out = 0;
     if (!spl_bam_claim_for_device(bam)) return SPL_OK; // (being decoded already, by whoever asked first: nothing to do here)
-    const int rc = decode_device_claimed(c, bam, on_device_out);
-    // whatever went wrong on the way (device memory, a HIP error): the file must not be left without a decoder -- the host
-    // threads take it (a no-op when the arrays were adopted or the host was started already); spl_last_error keeps the reason
+    ShareOut res;
+    int rc = decode_share(c, bam, nullptr, res);
+    if (rc == SPL_OK && !res.to_host && res.reads) {
+        DeviceReads *keep = res.reads;
+        const bool eager = getenv("SPL_NO_DEVICE_PACK") != nullptr; // (the round-trip over the host, for A/B: host copies now, nothing kept here)
+        if (eager) {
+            int32_t *h_pos = nullptr; uint16_t *h_flag = nullptr; uint32_t *h_cigoff = nullptr, *h_cigar = nullptr;
+            rc = fetch_device_reads(keep, &h_pos, &h_flag, &h_cigoff, &h_cigar);
+            if (rc == SPL_OK) {
+                rc = spl_bam_adopt(bam, h_pos, h_flag, h_cigoff, h_cigar, keep->ref_first.data(), keep->ref_n.data(), keep->ref_max.data(), res.n_all);
+                if (rc) { free(h_pos); free(h_flag); free(h_cigoff); free(h_cigar); }
+            }
+            free_device_reads(keep);
+        } else {
+            spl_bam_set_device_reads(bam, keep, free_device_reads);
+            spl_bam_set_fetch(bam, fetch_device_reads);
+            rc = spl_bam_adopt(bam, nullptr, nullptr, nullptr, nullptr, keep->ref_first.data(), keep->ref_n.data(), keep->ref_max.data(), res.n_all);
+            if (rc) spl_bam_set_device_reads(bam, nullptr, nullptr);
+        }
+        if (rc == SPL_OK && on_device_out) *on_device_out = 1;
+    }
+    // whatever went wrong on the way (device memory, a HIP error, a file this path does not take): the file must not be left
+    // without a decoder -- the host threads take it (a no-op when the arrays were adopted); spl_last_error keeps the reason
     (void)spl_bam_device_gives_up(bam);
     if (rc != SPL_OK && getenv("SPL_BAM_TIMING")) fprintf(stderr, "[spl_bam_decode_device] failed (%s): host decoder instead\n", spl_last_error());
     return SPL_OK;
 }
 
-static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
+// Share k of the file's plan (spl_bam_share_plan) on this context's device.  The file must have been reserved for the device
+// decoders (spl_bam_reserve_device) and every share must be decoded by somebody: the last one to finish makes the file complete
+// -- or, if any share could not be done on its device, hands the whole file to the host threads.
+extern "C" int spl_bam_decode_device_share(spl_ctx *c, spl_bam *bam, int k, int *on_device_out)
+{
+    if (!c || !bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_decode_device_share: null argument");
+    if (on_device_out) *on_device_out = 0;
+    spl_bam_share sh;
+    int rc = spl_bam_share_get(bam, k, &sh);
+    if (rc) return rc;
+    ShareOut res;
+    rc = decode_share(c, bam, &sh, res);
+    const bool failed = rc != SPL_OK || res.to_host || !res.reads;
+    if (failed && getenv("SPL_BAM_TIMING")) fprintf(stderr, "[spl_bam_decode_device] share %d not done on its device (%s)\n", k, rc ? spl_last_error() : "handed to the host");
+    if (failed && res.reads) { free_device_reads(res.reads); res.reads = nullptr; }
+    if (!failed) spl_bam_set_fetch(bam, fetch_device_reads);
+    rc = spl_bam_share_done(bam, k, res.reads, free_device_reads, failed ? nullptr : res.reads->ref_first.data(), failed ? nullptr : res.reads->ref_n.data(),
+                            failed ? nullptr : res.reads->ref_max.data(), res.n_all, failed ? 1 : 0);
+    if (rc == SPL_OK && !failed && on_device_out) *on_device_out = 1;
+    return rc;
+}
+
+static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, ShareOut &res)
 {
     HIP_TRY(hipSetDevice(c->device));
     const bool timing = getenv("SPL_BAM_TIMING") != nullptr;
     auto host_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_mark = host_now();
-    const double t_begin = t_mark;
-    auto stamp = [&](const char *what) { if (timing) { const double t = host_now(); fprintf(stderr, "[spl_bam_decode_device] %-34s %.4f s\n", what, t - t_mark); t_mark = t; } };
+    const double t_begin = host_now();
     auto to_host = [&](const char *why) { // not a file for this path: the host threads take it (and find the words for what is wrong with it)
         if (timing) fprintf(stderr, "[spl_bam_decode_device] handing the file to the host decoder: %s\n", why);
-        return spl_bam_device_gives_up(bam);
+        res.to_host = true;
+        return SPL_OK;
     };
     size_t fsize = 0;
     const uint8_t *image = spl_bam_image(bam, &fsize);
     const int n_ref = spl_bam_n_ref(bam);
     int rc = ensure_stage(c);
     if (rc) return rc;
+    // ---- everything the streams touch is declared before them: what is declared last goes first, and that is the guard that waits
+    DevBuf d_image, d_stream[2], d_zwork[2], d_blocks, d_status, d_scan, d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
+    std::vector<spl_zblock> blocks;
+    std::vector<uint32_t> status;
+    std::vector<spl_bscan> scan;
+    std::vector<uint64_t> rec_off, op_off;
+    std::vector<unsigned long long> maxend;
+    std::vector<uint64_t> bounds;
+    uint32_t n_bounds = 0;
+    struct Pipe { // stream A, stream B, their events; waits for everything on the way out, whichever way that is
+        spl_ctx *c;
+        hipStream_t a = nullptr, b = nullptr;
+        hipEvent_t k1[2] = {nullptr, nullptr}, freed[2] = {nullptr, nullptr}, setup = nullptr;
+        std::vector<hipEvent_t> piece;
+        explicit Pipe(spl_ctx *ctx) : c(ctx) {}
+        hipError_t make(size_t n_pieces)
+        {
+            hipError_t e = hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
+            for (int k = 0; k < 2 && e == hipSuccess; ++k) { e = hipEventCreateWithFlags(&k1[k], hipEventDisableTiming); if (e == hipSuccess) e = hipEventCreateWithFlags(&freed[k], hipEventDisableTiming); }
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&setup, hipEventDisableTiming);
+            piece.assign(n_pieces, nullptr);
+            for (size_t k = 0; k < n_pieces && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&piece[k], hipEventDisableTiming);
+            return e;
+        }
+        ~Pipe()
+        {
+            if (a) (void)hipStreamSynchronize(a);
+            if (b) (void)hipStreamSynchronize(b);
+            if (c->copy) (void)hipStreamSynchronize(c->copy);
+            for (hipEvent_t e : piece) if (e) (void)hipEventDestroy(e);
+            for (int k = 0; k < 2; ++k) { if (k1[k]) (void)hipEventDestroy(k1[k]); if (freed[k]) (void)hipEventDestroy(freed[k]); }
+            if (setup) (void)hipEventDestroy(setup);
+            if (a) (void)hipStreamDestroy(a);
+            if (b) (void)hipStreamDestroy(b);
+        }
+    } pipe(c);
+    // ---- the share: which blocks, which bytes of the file
+    int walk_rc = SPL_OK;
+    double t_walk = 0;
+    spl_bam_share sh;
+    size_t byte_lo = 0, byte_hi = fsize;
+    if (share) {
+        sh = *share; // (its plan walked the directory)
+        spl_bam_block_info b0, b1;
+        spl_bam_block_get(bam, (size_t)sh.block_lo, &b0);
+        spl_bam_block_get(bam, (size_t)sh.block_hi - 1, &b1);
+        byte_lo = (size_t)b0.data_off;
+        byte_hi = std::min(fsize, (size_t)b1.data_off + b1.data_len + 8);
+    }
+    const size_t n_bytes = byte_hi - byte_lo;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     free_b += devmem::held_bytes(c->device); // (given back before a request fails)
-    if ((double)fsize * 8.0 + (double)(1u << 30) > (double)free_b) return to_host("not enough device memory");
-    // The block directory (one thread's walk over the file's block headers) beside the upload of the file image, and, once the
-    // directory is there, the blocks of every stretch of the file inflated as soon as the stretch has arrived.
-    int walk_rc = SPL_OK;
-    double t_walk = 0;
-    DevBuf d_image, d_stream, d_blocks, d_status, d_scan;
-    HIP_TRY(d_image.get(fsize + 64, c->copy));
-    HIP_TRY(hipMemsetAsync(d_image.as<char>() + fsize, 0, 64, c->copy));
-    // The file image: page cache -> staging buffer -> device.  One reader thread per staging buffer: it preads its pieces of
-    // the file (a piece = a buffer's size, dealt round-robin) and sends each on its way itself; three readers keep the copy
-    // engine busy where a loop that filled one buffer at a time with eight short-lived threads reached a third of that on a
-    // 14 GB file.
+    if ((double)n_bytes * 2.5 + (double)((size_t)12 << 30) > (double)free_b) return to_host("not enough device memory");
+    HIP_TRY(d_image.get(n_bytes + SPL_Z_IMAGE_PAD, c->copy));
+    HIP_TRY(hipMemsetAsync(d_image.as<char>() + n_bytes, 0, SPL_Z_IMAGE_PAD, c->copy));
+    // The file's bytes: page cache -> staging buffer -> device.  One reader thread per staging buffer: it preads its pieces (a
+    // piece = a buffer's size, dealt round-robin), sends each on its way itself and records the piece's event behind it.
     const size_t n_stage = c->stage.size();
     const size_t piece = c->stage[0].bytes;
-    const size_t n_pieces = (fsize + piece - 1) / piece;
+    const size_t n_pieces = (n_bytes + piece - 1) / piece;
+    HIP_TRY(pipe.make(n_pieces));
     std::vector<hipError_t> errs(n_stage, hipSuccess);
-    std::vector<std::atomic<int>> sent(n_pieces); // piece k's copy is in the copy stream's queue (or will never be: errs)
+    std::vector<std::atomic<int>> sent(n_pieces); // piece k's copy and event are in the copy stream's queue (or will never be: errs)
     for (auto &f : sent) f.store(0, std::memory_order_relaxed);
     std::atomic<int> reader_failed(0);
     const int fd = spl_bam_fd(bam);
@@ -1125,84 +1225,89 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
         for (size_t k = t; k < n_pieces; k += n_stage) {
             if (errs[t] == hipSuccess && st.busy) { errs[t] = hipEventSynchronize(st.done); st.busy = false; }
             if (errs[t] == hipSuccess) {
-                const size_t off = k * piece, n = std::min(piece, fsize - off);
-                CopyJob job{st.host, (const char *)image + off, n, n, fd, off};
+                const size_t off = k * piece, n = std::min(piece, n_bytes - off);
+                CopyJob job{st.host, (const char *)image + byte_lo + off, n, n, fd, byte_lo + off};
                 copy_slice(0, &job);
                 errs[t] = hipMemcpyAsync(d_img + off, st.host, n, hipMemcpyHostToDevice, c->copy);
                 if (errs[t] == hipSuccess) { errs[t] = hipEventRecord(st.done, c->copy); st.busy = true; }
+                if (errs[t] == hipSuccess) errs[t] = hipEventRecord(pipe.piece[k], c->copy);
             }
             if (errs[t] != hipSuccess) reader_failed.store(1, std::memory_order_release);
             sent[k].store(1, std::memory_order_release);
         }
     };
-    // (declared behind everything its threads touch: joined before any of that goes away, on every way out)
-    struct Crew {
+    struct Crew { // (declared behind everything its threads touch: joined before any of that goes away, on every way out)
         std::vector<std::thread> threads;
         void join() { for (std::thread &t : threads) if (t.joinable()) t.join(); }
         ~Crew() { join(); }
     } crew;
-    crew.threads.emplace_back([&]() { const double w0 = host_now(); walk_rc = spl_bam_walk_all(bam); t_walk = host_now() - w0; });
+    if (!share) crew.threads.emplace_back([&]() { const double w0 = host_now(); walk_rc = spl_bam_walk_all(bam); t_walk = host_now() - w0; });
     for (size_t t = 0; t < n_stage; ++t) crew.threads.emplace_back(reader, t);
-    crew.threads[0].join(); // the walk
-    if (timing) fprintf(stderr, "[spl_bam_decode_device] (the directory walk took %.4f s)\n", t_walk);
-    if (walk_rc) return to_host("block directory");
-    const size_t n_blocks = spl_bam_block_count(bam);
+    if (!share) {
+        crew.threads[0].join(); // the walk
+        if (timing) fprintf(stderr, "[spl_bam_decode_device] (the directory walk took %.4f s)\n", t_walk);
+        if (walk_rc) return to_host("block directory");
+        fill_whole(bam, sh);
+    }
+    const size_t n_blocks_file = spl_bam_block_count(bam);
+    const size_t lo = (size_t)sh.block_lo, hi = (size_t)sh.block_hi, n_blocks = hi - lo;
     if (n_blocks == 0 || n_blocks > 0xfffffff0ull) return to_host("no blocks");
-    std::vector<spl_zblock> blocks(n_blocks);
-    uint64_t stream_len = 0;
+    const bool last_share = hi == n_blocks_file, first_share = lo == 0;
+    blocks.resize(n_blocks);
     for (size_t i = 0; i < n_blocks; ++i) {
         spl_bam_block_info bi;
-        spl_bam_block_get(bam, i, &bi);
+        spl_bam_block_get(bam, lo + i, &bi);
         blocks[i].in = bi.data_off; blocks[i].out = bi.uoff; blocks[i].in_len = bi.data_len; blocks[i].out_len = bi.isize; blocks[i].crc = bi.crc; blocks[i].pad = 0;
-        stream_len = bi.uoff + bi.isize;
     }
-    // The inflated stream is never there as a whole: it is made, scanned and emptied of its records a WINDOW at a time -- a
-    // device-ful of blocks, one per lane of as many workgroups as the inflate kernel fits on the device (7 per CU for its tables
-    // in LDS: 114 688 blocks, 7.5 GB of stream) -- in one buffer.  A launch of the inflate kernel takes as long as ONE lane needs
-    // for its block however few blocks it has, so a window of a device-ful costs what its share of one launch over everything
-    // would; and fresh device memory costs 30 ms per GB here (56 GB of stream for a 200 M-read file: 1.8 s of hipMalloc in a
-    // new process, in the way of the upload it shares the copy engines with).  SPL_INFLATE_WINDOW_BLOCKS overrides (tests).
-    size_t win_blocks = (size_t)7 * 256 * 64;
+    const uint64_t stream_begin = blocks[0].out, stream_len = blocks[n_blocks - 1].out + blocks[n_blocks - 1].out_len; // (of the share; offsets are the file's)
+    // ---- windows
+    size_t win_blocks = (size_t)49152;
     if (const char *e = getenv("SPL_INFLATE_WINDOW_BLOCKS")) win_blocks = (size_t)std::max(2, atoi(e));
     win_blocks = std::min(win_blocks, n_blocks);
-    uint64_t win_cap = 0; // the longest stretch of the stream that win_blocks consecutive blocks hold
-    for (size_t i = 0; i + win_blocks <= n_blocks; i += std::max<size_t>(1, win_blocks / 64))
-        win_cap = std::max(win_cap, blocks[i + win_blocks - 1].out + blocks[i + win_blocks - 1].out_len - blocks[i].out);
-    win_cap = std::min<uint64_t>(stream_len, std::max<uint64_t>(win_cap, 1) + (uint64_t)win_blocks / 64 * 65536 + 65536);
+    const size_t n_win = (n_blocks + win_blocks - 1) / win_blocks;
+    const uint64_t HEAD = (uint64_t)8 << 20; // room in front of a window's bytes for what the window before left unfinished
+    uint64_t win_cap = 0;
+    for (size_t k = 0; k < n_win; ++k) {
+        const size_t b0 = k * win_blocks, b1 = std::min(n_blocks, b0 + win_blocks);
+        win_cap = std::max(win_cap, blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out);
+    }
+    uint32_t match_stride = 0;
+    if (const char *e = getenv("SPL_INFLATE_MATCH_STRIDE")) match_stride = (uint32_t)std::max(8, atoi(e)); // (tests: lists that overflow)
+    const size_t work_bytes = spl_dev_inflate_work_bytes((uint32_t)win_blocks, match_stride);
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     free_b += devmem::held_bytes(c->device);
-    if ((double)win_cap + (double)stream_len * 0.2 + (double)(1u << 30) > (double)free_b) return to_host("not enough device memory for the inflated stream");
-    HIP_TRY(d_stream.get(win_cap + 128, c->copy));
+    const int n_buf = n_win > 1 ? 2 : 1;
+    if ((double)n_buf * ((double)win_cap + (double)HEAD + (double)work_bytes) + (double)(stream_len - stream_begin) * 0.2 + (double)((size_t)1 << 30) > (double)free_b)
+        return to_host("not enough device memory for the inflated stream");
+    for (int k = 0; k < n_buf; ++k) {
+        HIP_TRY(d_stream[k].get(HEAD + win_cap + 256, c->copy));
+        HIP_TRY(d_zwork[k].get(work_bytes, c->copy));
+    }
     HIP_TRY(d_blocks.get(sizeof(spl_zblock) * n_blocks, c->copy));
     HIP_TRY(d_status.get(4 * n_blocks, c->copy));
     HIP_TRY(d_scan.get(sizeof(spl_bscan) * n_blocks, c->copy));
-    crew.join();
-    for (hipError_t e : errs) HIP_TRY(e);
-    // (everything below is queued on the copy stream behind the file's pieces.  Inflating stretches of the file on streams of
-    // their own while the rest was still on its way was measured and is not done: with kernels running beside it the upload of
-    // a 3.6 GB file took 0.24-0.26 s instead of 0.09-0.12 -- the kernel's scattered byte stores and the copy's writes meet in
-    // the memory system -- 0.32 s for upload + inflate against 0.21 s one after the other; with the kernels kept off 1/8 or 1/2
-    // of the CUs the upload was left alone and what was left behind it took 0.16-0.18 s.)
-    HIP_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), sizeof(spl_zblock) * n_blocks, hipMemcpyHostToDevice, c->copy));
-    HIP_TRY(hipMemsetAsync(d_status.p, 0xff, 4 * n_blocks, c->copy));
-    if (timing) { HIP_TRY(hipStreamSynchronize(c->copy)); stamp("file image to the device"); }
-    const uint64_t H = spl_bam_header_end(bam);
-    if (H > stream_len) return to_host("no BAM header");
-    size_t first = 0; // the first block that holds more than BAM header
-    while (first < n_blocks && blocks[first].out + blocks[first].out_len <= H && !(blocks[first].out + blocks[first].out_len == H && first + 1 == n_blocks)) ++first;
-    std::vector<uint32_t> status(n_blocks);
-    std::vector<spl_bscan> scan(n_blocks);
-    std::vector<uint64_t> rec_off(n_blocks + 1, 0), op_off(n_blocks + 1, 0);
-    DevBuf d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
     HIP_TRY(d_recoff.get(8 * (n_blocks + 1), c->copy));
     HIP_TRY(d_opoff.get(8 * (n_blocks + 1), c->copy));
     HIP_TRY(d_maxend.get(8 * (size_t)std::max(n_ref, 1), c->copy));
     const uint32_t cap = (uint32_t)std::max(n_ref, 1) * 4u + 64u;
     HIP_TRY(d_bounds.get(16 * (size_t)cap, c->copy));
     HIP_TRY(d_nbounds.get(4, c->copy));
-    HIP_TRY(hipMemsetAsync(d_maxend.p, 0, 8 * (size_t)std::max(n_ref, 1), c->copy));
-    HIP_TRY(hipMemsetAsync(d_nbounds.p, 0, 4, c->copy));
-    // the extracted arrays: as large as the first window says the file will need and a tenth more, larger when that was wrong
+    status.assign(n_blocks, 0);
+    scan.resize(n_blocks);
+    rec_off.assign(n_blocks + 1, 0);
+    op_off.assign(n_blocks + 1, 0);
+    HIP_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), sizeof(spl_zblock) * n_blocks, hipMemcpyHostToDevice, pipe.b));
+    HIP_TRY(hipMemsetAsync(d_status.p, 0xff, 4 * n_blocks, pipe.b));
+    HIP_TRY(hipMemsetAsync(d_maxend.p, 0, 8 * (size_t)std::max(n_ref, 1), pipe.b));
+    HIP_TRY(hipMemsetAsync(d_nbounds.p, 0, 4, pipe.b));
+    HIP_TRY(hipEventRecord(pipe.setup, pipe.b));
+    HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.setup, 0));
+    const uint64_t H = spl_bam_header_end(bam);
+    if (first_share && H > stream_len) return to_host("no BAM header");
+    size_t first = 0; // the first block that holds more than BAM header
+    if (first_share)
+        while (first < n_blocks && blocks[first].out + blocks[first].out_len <= H && !(blocks[first].out + blocks[first].out_len == H && first + 1 == n_blocks)) ++first;
+    // the extracted arrays: as large as the first window says the share will need and a tenth more, larger when that was wrong
     uint64_t cap_rec = 0, cap_ops = 0, n_rec = 0, n_ops = 0;
     auto make_room = [&](uint64_t need_rec, uint64_t need_ops, double part_done) -> int {
         if (need_rec <= cap_rec && need_ops <= cap_ops && cap_rec) return SPL_OK;
@@ -1210,106 +1315,141 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
         const uint64_t want_rec = std::max<uint64_t>(need_rec, (uint64_t)((double)need_rec * scale)) + 1024;
         const uint64_t want_ops = std::max<uint64_t>(need_ops, (uint64_t)((double)need_ops * scale)) + 1024;
         DevBuf pos2, flag2, cigoff2, cigar2, tid2;
-        HIP_TRY(pos2.get(4 * want_rec, c->copy));
-        HIP_TRY(flag2.get(2 * want_rec, c->copy));
-        HIP_TRY(cigoff2.get(4 * (want_rec + 1), c->copy));
-        HIP_TRY(cigar2.get(4 * want_ops, c->copy));
-        HIP_TRY(tid2.get(4 * want_rec, c->copy));
+        HIP_TRY(pos2.get(4 * want_rec, pipe.b));
+        HIP_TRY(flag2.get(2 * want_rec, pipe.b));
+        HIP_TRY(cigoff2.get(4 * (want_rec + 1), pipe.b));
+        HIP_TRY(cigar2.get(4 * want_ops, pipe.b));
+        HIP_TRY(tid2.get(4 * want_rec, pipe.b));
         if (cap_rec) { // what the windows so far have left (n_rec records, n_ops ops) moves
-            HIP_TRY(hipMemcpyAsync(pos2.p, d_pos.p, 4 * n_rec, hipMemcpyDeviceToDevice, c->copy));
-            HIP_TRY(hipMemcpyAsync(flag2.p, d_flag.p, 2 * n_rec, hipMemcpyDeviceToDevice, c->copy));
-            HIP_TRY(hipMemcpyAsync(cigoff2.p, d_cigoff.p, 4 * (n_rec + 1), hipMemcpyDeviceToDevice, c->copy));
-            HIP_TRY(hipMemcpyAsync(cigar2.p, d_cigar.p, 4 * n_ops, hipMemcpyDeviceToDevice, c->copy));
-            HIP_TRY(hipMemcpyAsync(tid2.p, d_tid.p, 4 * n_rec, hipMemcpyDeviceToDevice, c->copy));
-            HIP_TRY(hipStreamSynchronize(c->copy));
+            HIP_TRY(hipMemcpyAsync(pos2.p, d_pos.p, 4 * n_rec, hipMemcpyDeviceToDevice, pipe.b));
+            HIP_TRY(hipMemcpyAsync(flag2.p, d_flag.p, 2 * n_rec, hipMemcpyDeviceToDevice, pipe.b));
+            HIP_TRY(hipMemcpyAsync(cigoff2.p, d_cigoff.p, 4 * (n_rec + 1), hipMemcpyDeviceToDevice, pipe.b));
+            HIP_TRY(hipMemcpyAsync(cigar2.p, d_cigar.p, 4 * n_ops, hipMemcpyDeviceToDevice, pipe.b));
+            HIP_TRY(hipMemcpyAsync(tid2.p, d_tid.p, 4 * n_rec, hipMemcpyDeviceToDevice, pipe.b));
+            HIP_TRY(hipStreamSynchronize(pipe.b));
         } else {
-            HIP_TRY(hipMemsetAsync(cigoff2.p, 0, 4, c->copy));
+            HIP_TRY(hipMemsetAsync(cigoff2.p, 0, 4, pipe.b));
         }
         std::swap(d_pos.p, pos2.p); std::swap(d_flag.p, flag2.p); std::swap(d_cigoff.p, cigoff2.p); std::swap(d_cigar.p, cigar2.p); std::swap(d_tid.p, tid2.p);
         cap_rec = want_rec;
         cap_ops = want_ops;
         return SPL_OK;
     };
+    // the Huffman decoding of window k on stream A, behind the pieces of the file it reads and behind whoever last used its buffer
+    const uint8_t *const image0 = d_image.as<uint8_t>() - byte_lo; // (indexed with offsets into the file)
+    size_t pieces_waited = 0;
+    auto win_range = [&](size_t k, size_t &b0, size_t &b1) { b0 = k * win_blocks; b1 = std::min(n_blocks, b0 + win_blocks); };
+    auto stream0_of = [&](size_t k) { size_t b0, b1; win_range(k, b0, b1); return d_stream[k % (size_t)n_buf].as<uint8_t>() + HEAD - blocks[b0].out; }; // (indexed with offsets into the whole stream)
+    auto launch_decode = [&](size_t k) -> int {
+        size_t b0, b1;
+        win_range(k, b0, b1);
+        const size_t last_byte = (size_t)(blocks[b1 - 1].in + blocks[b1 - 1].in_len + 8) - byte_lo;
+        const size_t need = std::min(n_pieces, last_byte / piece + 1);
+        for (; pieces_waited < need; ++pieces_waited) {
+            while (!sent[pieces_waited].load(std::memory_order_acquire)) std::this_thread::yield();
+            if (reader_failed.load(std::memory_order_acquire)) { for (hipError_t e : errs) HIP_TRY(e); }
+            HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.piece[pieces_waited], 0));
+        }
+        if (k >= (size_t)n_buf) HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.freed[k % (size_t)n_buf], 0));
+        HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k), d_status.as<uint32_t>() + b0,
+                                                          d_zwork[k % (size_t)n_buf].p, match_stride, pipe.a));
+        HIP_TRY(hipEventRecord(pipe.k1[k % (size_t)n_buf], pipe.a));
+        return SPL_OK;
+    };
     int64_t n_all = 0;
-    uint64_t expect = H; // the chain of boundaries, from the end of the BAM header to the end of the stream
+    uint64_t expect = first_share ? H : 0; // the chain of boundaries, from the end of the BAM header (a later share: from its first block's guess)
+    bool expect_known = first_share;
     int32_t last_tid = -1;
-    size_t n_windows = 0;
-    for (size_t b0 = 0; b0 < n_blocks; ++n_windows) {
-        size_t b1 = std::min(n_blocks, b0 + win_blocks);
-        while (b1 > b0 + 1 && blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out > win_cap) --b1;
-        const bool more = b1 < n_blocks;
+    size_t carry = 0; // the first block whose records are not all extracted yet
+    rc = launch_decode(0);
+    if (rc) return rc;
+    for (size_t k = 0; k < n_win; ++k) {
+        size_t b0, b1;
+        win_range(k, b0, b1);
+        if (k + 1 < n_win) { rc = launch_decode(k + 1); if (rc) return rc; }
+        const size_t slot = k % (size_t)n_buf;
+        const bool more = b1 < n_blocks || !last_share;
         const uint32_t nb = (uint32_t)(b1 - b0);
-        const uint64_t base = blocks[b0].out, win_end = blocks[b1 - 1].out + blocks[b1 - 1].out_len;
-        if (win_end - base > win_cap) return to_host("a block larger than the inflate window");
-        uint8_t *const stream0 = d_stream.as<uint8_t>() - base; // (indexed with offsets into the whole stream, from `base` on)
-        HIP_TRY((hipError_t)spl_dev_launch_inflate(d_image.as<uint8_t>(), d_blocks.as<spl_zblock>() + b0, nb, stream0, d_status.as<uint32_t>() + b0, c->copy));
-        HIP_TRY((hipError_t)spl_dev_launch_crc32(stream0, d_blocks.as<spl_zblock>() + b0, nb, d_status.as<uint32_t>() + b0, c->copy));
-        HIP_TRY((hipError_t)spl_dev_launch_bam_scan(stream0, win_end, H, n_ref, d_blocks.as<spl_zblock>() + b0, nb, d_scan.as<spl_bscan>() + b0, more ? 1 : 0, c->copy));
-        HIP_TRY(hipMemcpyAsync(status.data() + b0, d_status.as<uint32_t>() + b0, 4 * (size_t)nb, hipMemcpyDeviceToHost, c->copy));
-        HIP_TRY(hipMemcpyAsync(scan.data() + b0, d_scan.as<spl_bscan>() + b0, sizeof(spl_bscan) * nb, hipMemcpyDeviceToHost, c->copy));
-        HIP_TRY(hipStreamSynchronize(c->copy));
+        const uint64_t win_end = blocks[b1 - 1].out + blocks[b1 - 1].out_len;
+        uint8_t *const stream0 = stream0_of(k);
+        const size_t s0 = k == 0 ? b0 : carry; // scan and extraction begin with what the window before left
+        HIP_TRY(hipStreamWaitEvent(pipe.b, pipe.k1[slot], 0));
+        HIP_TRY((hipError_t)spl_dev_launch_inflate_copy(d_blocks.as<spl_zblock>() + b0, nb, stream0, d_zwork[slot].p, match_stride, pipe.b));
+        HIP_TRY((hipError_t)spl_dev_launch_crc32(stream0, d_blocks.as<spl_zblock>() + b0, nb, d_status.as<uint32_t>() + b0, pipe.b));
+        HIP_TRY((hipError_t)spl_dev_launch_bam_scan(stream0, win_end, H, n_ref, sh.tid_lo, sh.tid_hi, d_blocks.as<spl_zblock>() + s0, (uint32_t)(b1 - s0), d_scan.as<spl_bscan>() + s0,
+                                                    more ? 1 : 0, pipe.b));
+        HIP_TRY(hipMemcpyAsync(status.data() + b0, d_status.as<uint32_t>() + b0, 4 * (size_t)nb, hipMemcpyDeviceToHost, pipe.b));
+        HIP_TRY(hipMemcpyAsync(scan.data() + s0, d_scan.as<spl_bscan>() + s0, sizeof(spl_bscan) * (b1 - s0), hipMemcpyDeviceToHost, pipe.b));
+        HIP_TRY(hipStreamSynchronize(pipe.b));
         for (size_t i = b0; i < b1; ++i)
             if (status[i] != SPL_Z_OK) return to_host("a block did not inflate (or its CRC32 is wrong)");
         // Which of the window's blocks are done with: all whose records end inside it.  A block near the window's end may have
         // looked for its first record, or walked its last one, into bytes that are not there yet: it is told by its flag, or
-        // -- within reach of the end -- by anything being wrong with it, and is the first block of the next window.
-        const uint64_t reach = std::min<uint64_t>((win_end - base) / 2, ((uint64_t)5 << 18));
+        // -- within reach of the end -- by anything being wrong with it, and is looked at again with the next window.
+        const uint64_t reach = std::min<uint64_t>((win_end - blocks[s0].out) / 2, ((uint64_t)5 << 18));
         size_t b_done = b1;
-        for (size_t b = b0; b < b1; ++b) {
+        for (size_t b = s0; b < b1; ++b) {
             spl_bscan &sc = scan[b];
-            if (b < first) { // (BAM header only: nothing to extract)
+            if (first_share && b < first) { // (BAM header only: nothing to extract)
                 sc.n_placed = 0;
                 rec_off[b + 1] = rec_off[b];
                 op_off[b + 1] = op_off[b];
                 continue;
             }
+            const bool share_edge = !(lo + b >= (size_t)sh.block_lo + 2 && lo + b + 2 < (size_t)sh.block_hi); // (the neighbours' records may lie here)
             const char *wrong = nullptr;
             if (sc.flags & SPL_BS_CORRUPT) wrong = "a record contradicts itself";
             else if (sc.flags & SPL_BS_NO_START) wrong = "no record boundary found near a block";
             else if (sc.flags & SPL_BS_NEEDS_HOST) wrong = "a CIGAR parked in a CG tag";
             else if (sc.flags & SPL_BS_UNSORTED) wrong = "not sorted by reference";
-            else if (sc.start != expect) wrong = "a guessed record boundary did not hold";
+            else if (expect_known && sc.start != expect) wrong = "a guessed record boundary did not hold";
             else if (sc.n_placed && sc.tid_first < last_tid) wrong = "not sorted by reference";
-            if ((sc.flags & SPL_BS_INCOMPLETE) || (wrong && more && blocks[b].out + reach >= win_end)) { b_done = b; break; }
+            else if (sc.n_foreign && !share_edge) wrong = "not sorted by reference";
+            if (!last_share && b1 == n_blocks && (sc.flags & SPL_BS_INCOMPLETE) && b + 1 >= b1 && !wrong) {
+                // the last block of a share that is not the file's last: the record that runs on is the next share's
+                sc.flags &= ~SPL_BS_INCOMPLETE;
+            }
+            if ((sc.flags & SPL_BS_INCOMPLETE) || (wrong && more && blocks[b].out + reach >= win_end && b1 < n_blocks)) { b_done = b; break; }
             if (wrong) return to_host(wrong);
             if (sc.n_placed) last_tid = sc.tid_last;
             expect = sc.reached;
+            expect_known = true;
             n_all += sc.n_all;
             rec_off[b + 1] = rec_off[b] + sc.n_placed;
             op_off[b + 1] = op_off[b] + sc.n_ops;
         }
-        if (b_done == b0) return to_host("a record larger than the inflate window");
+        if (b_done < b1 && b1 == n_blocks) return to_host(last_share ? "the file ends inside a record" : "a record runs past the share's last block");
+        if (b_done < b1 && win_end - blocks[b_done].out > HEAD) return to_host("a record larger than the room between two windows");
         if (op_off[b_done] > 0xfffffff0ull) return to_host("more than 2^32 CIGAR operations");
-        rc = make_room(rec_off[b_done], op_off[b_done], (double)(blocks[b_done - 1].out + blocks[b_done - 1].out_len) / (double)std::max<uint64_t>(stream_len, 1));
-        if (rc) return rc;
-        n_rec = rec_off[b_done];
-        n_ops = op_off[b_done];
-        const size_t nd = b_done - b0;
-        HIP_TRY(hipMemcpyAsync(d_recoff.as<uint64_t>() + b0, rec_off.data() + b0, 8 * nd, hipMemcpyHostToDevice, c->copy));
-        HIP_TRY(hipMemcpyAsync(d_opoff.as<uint64_t>() + b0, op_off.data() + b0, 8 * nd, hipMemcpyHostToDevice, c->copy));
-        HIP_TRY(hipMemcpyAsync(d_scan.as<spl_bscan>() + b0, scan.data() + b0, sizeof(spl_bscan) * nd, hipMemcpyHostToDevice, c->copy));
-        HIP_TRY((hipError_t)spl_dev_launch_bam_extract(stream0, win_end, n_ref, d_blocks.as<spl_zblock>() + b0, (uint32_t)nd, d_scan.as<spl_bscan>() + b0,
-                                                       d_recoff.as<uint64_t>() + b0, d_opoff.as<uint64_t>() + b0, d_pos.as<int32_t>(), d_flag.as<uint16_t>(),
-                                                       d_cigoff.as<uint32_t>(), d_cigar.as<uint32_t>(), d_tid.as<int32_t>(), d_maxend.as<unsigned long long>(), c->copy));
-        b0 = b_done;
+        if (b_done > s0) {
+            rc = make_room(rec_off[b_done], op_off[b_done], (double)(blocks[b_done - 1].out + blocks[b_done - 1].out_len - stream_begin) / (double)std::max<uint64_t>(stream_len - stream_begin, 1));
+            if (rc) return rc;
+            n_rec = rec_off[b_done];
+            n_ops = op_off[b_done];
+            const size_t nd = b_done - s0;
+            HIP_TRY(hipMemcpyAsync(d_recoff.as<uint64_t>() + s0, rec_off.data() + s0, 8 * nd, hipMemcpyHostToDevice, pipe.b));
+            HIP_TRY(hipMemcpyAsync(d_opoff.as<uint64_t>() + s0, op_off.data() + s0, 8 * nd, hipMemcpyHostToDevice, pipe.b));
+            HIP_TRY(hipMemcpyAsync(d_scan.as<spl_bscan>() + s0, scan.data() + s0, sizeof(spl_bscan) * nd, hipMemcpyHostToDevice, pipe.b));
+            HIP_TRY((hipError_t)spl_dev_launch_bam_extract(stream0, win_end, n_ref, sh.tid_lo, sh.tid_hi, d_blocks.as<spl_zblock>() + s0, (uint32_t)nd, d_scan.as<spl_bscan>() + s0,
+                                                           d_recoff.as<uint64_t>() + s0, d_opoff.as<uint64_t>() + s0, d_pos.as<int32_t>(), d_flag.as<uint16_t>(),
+                                                           d_cigoff.as<uint32_t>(), d_cigar.as<uint32_t>(), d_tid.as<int32_t>(), d_maxend.as<unsigned long long>(), pipe.b));
+        }
+        if (b_done < b1 && k + 1 < n_win) // what is left of this window: in front of the next one's bytes
+            HIP_TRY(hipMemcpyAsync(stream0_of(k + 1) + blocks[b_done].out, stream0 + blocks[b_done].out, (size_t)(win_end - blocks[b_done].out), hipMemcpyDeviceToDevice, pipe.b));
+        HIP_TRY(hipEventRecord(pipe.freed[slot], pipe.b));
+        carry = b_done;
     }
-    if (expect != stream_len) return to_host("the file ends inside a record");
-    if (!cap_rec) { rc = make_room(0, 0, 1.0); if (rc) return rc; } // (a file without a block behind its header)
-    HIP_TRY((hipError_t)spl_dev_launch_bam_bounds(d_tid.as<int32_t>(), d_cigoff.as<uint32_t>(), n_rec, d_bounds.as<uint64_t>(), d_nbounds.as<uint32_t>(), cap, c->copy));
-    if (timing) {
-        HIP_TRY(hipStreamSynchronize(c->copy));
-        char what[96];
-        snprintf(what, sizeof what, "inflate, CRC32, scan, extraction: %zu window%s", n_windows, n_windows == 1 ? "" : "s");
-        stamp(what);
-    }
-    std::vector<unsigned long long> maxend((size_t)std::max(n_ref, 1));
-    std::vector<uint64_t> bounds(2 * (size_t)cap);
-    uint32_t n_bounds = 0;
-    HIP_TRY(hipMemcpyAsync(maxend.data(), d_maxend.p, 8 * maxend.size(), hipMemcpyDeviceToHost, c->copy));
-    HIP_TRY(hipMemcpyAsync(bounds.data(), d_bounds.p, 16 * (size_t)cap, hipMemcpyDeviceToHost, c->copy));
-    HIP_TRY(hipMemcpyAsync(&n_bounds, d_nbounds.p, 4, hipMemcpyDeviceToHost, c->copy));
-    HIP_TRY(hipStreamSynchronize(c->copy));
-    stamp("reference boundaries to the host");
+    if (last_share && expect_known && expect != stream_len) return to_host("the file ends inside a record");
+    if (!cap_rec) { rc = make_room(0, 0, 1.0); if (rc) return rc; } // (a share without a record of its own)
+    HIP_TRY((hipError_t)spl_dev_launch_bam_bounds(d_tid.as<int32_t>(), d_cigoff.as<uint32_t>(), n_rec, d_bounds.as<uint64_t>(), d_nbounds.as<uint32_t>(), cap, pipe.b));
+    maxend.assign((size_t)std::max(n_ref, 1), 0);
+    bounds.assign(2 * (size_t)cap, 0);
+    HIP_TRY(hipMemcpyAsync(maxend.data(), d_maxend.p, 8 * maxend.size(), hipMemcpyDeviceToHost, pipe.b));
+    HIP_TRY(hipMemcpyAsync(bounds.data(), d_bounds.p, 16 * (size_t)cap, hipMemcpyDeviceToHost, pipe.b));
+    HIP_TRY(hipMemcpyAsync(&n_bounds, d_nbounds.p, 4, hipMemcpyDeviceToHost, pipe.b));
+    HIP_TRY(hipStreamSynchronize(pipe.b));
+    crew.join();
+    for (hipError_t e : errs) HIP_TRY(e);
     if (n_bounds > cap) return to_host("not sorted by reference");
     struct Run { uint64_t first; int32_t tid; uint32_t op; };
     std::vector<Run> runs;
@@ -1332,28 +1472,12 @@ static int decode_device_claimed(spl_ctx *c, spl_bam *bam, int *on_device_out)
         keep->ref_ops[(size_t)t] = (int64_t)((last ? n_ops : (uint64_t)runs[k + 1].op) - runs[k].op);
         keep->ref_max[(size_t)t] = (int64_t)maxend[(size_t)t];
     }
-    const bool eager = getenv("SPL_NO_DEVICE_PACK") != nullptr; // (the round-trip this replaces, for A/B: host copies now, nothing kept here)
     keep->pos = d_pos.p; keep->flag = d_flag.p; keep->cig_off = d_cigoff.p; keep->cigar = d_cigar.p;
-    if (eager) {
-        int32_t *h_pos = nullptr; uint16_t *h_flag = nullptr; uint32_t *h_cigoff = nullptr, *h_cigar = nullptr;
-        rc = fetch_device_reads(keep, &h_pos, &h_flag, &h_cigoff, &h_cigar);
-        if (rc == SPL_OK) {
-            stamp("results to the host");
-            rc = spl_bam_adopt(bam, h_pos, h_flag, h_cigoff, h_cigar, keep->ref_first.data(), keep->ref_n.data(), keep->ref_max.data(), n_all);
-            if (rc) { free(h_pos); free(h_flag); free(h_cigoff); free(h_cigar); }
-        }
-        delete keep; // (the device arrays go back with the DevBufs)
-        if (rc) return rc;
-    } else {
-        d_pos.p = d_flag.p = d_cigoff.p = d_cigar.p = nullptr; // (the file owns them from here)
-        spl_bam_set_device_reads(bam, keep, free_device_reads);
-        spl_bam_set_fetch(bam, fetch_device_reads);
-        rc = spl_bam_adopt(bam, nullptr, nullptr, nullptr, nullptr, keep->ref_first.data(), keep->ref_n.data(), keep->ref_max.data(), n_all);
-        if (rc) { spl_bam_set_device_reads(bam, nullptr, nullptr); return rc; }
-    }
-    if (on_device_out) *on_device_out = 1;
-    if (timing) fprintf(stderr, "[spl_bam_decode_device] %zu blocks, %.1f MB -> %.1f MB inflated, %llu placed records of %lld: %.4f s\n", n_blocks, fsize / 1e6,
-                        stream_len / 1e6, (unsigned long long)n_rec, (long long)n_all, host_now() - t_begin);
+    d_pos.p = d_flag.p = d_cigoff.p = d_cigar.p = nullptr; // (the caller owns them from here)
+    res.reads = keep;
+    res.n_all = n_all;
+    if (timing) fprintf(stderr, "[spl_bam_decode_device] device %d: blocks %zu..%zu, %.1f MB -> %.1f MB inflated in %zu window%s, %llu placed records of %lld: %.4f s\n", c->device, lo, hi,
+                        n_bytes / 1e6, (stream_len - stream_begin) / 1e6, n_win, n_win == 1 ? "" : "s", (unsigned long long)n_rec, (long long)n_all, host_now() - t_begin);
     return SPL_OK;
 }
 
@@ -1512,7 +1636,7 @@ extern "C" int spl_reads_add_bam(spl_ctx *c, spl_dreads *d, spl_bam *bam, int ti
     HIP_TRY(hipSetDevice(c->device));
     int rc = spl_bam_wait_ref(bam, tid, nullptr, nullptr);
     if (rc) return rc;
-    if (const DeviceReads *dev = (const DeviceReads *)spl_bam_device_reads(bam)) {
+    if (const DeviceReads *dev = (const DeviceReads *)spl_bam_device_reads(bam, tid)) {
         // decoded on this device, and the arrays are still there: laid out there, nothing crosses PCIe
         if (dev->device == c->device && tid >= 0 && (size_t)tid < dev->ref_n.size()) {
             const size_t t = (size_t)tid;

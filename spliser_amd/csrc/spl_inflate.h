@@ -11,6 +11,7 @@
 // decode_worker; `--hostDecode` keeps those); replaces SpliSER_v0_1_8.py:422 (samtools view) all the same.
 #ifndef SPL_INFLATE_H
 #define SPL_INFLATE_H
+#include <stddef.h>
 #include <stdint.h>
 
 struct spl_zblock {
@@ -26,6 +27,12 @@ struct spl_zblock {
 // next block; behind the last one the caller pads), and the inflated stream writable for 16 bytes past its end: the wave kernel
 // moves 16 bytes at a time.
 #define SPL_Z_IMAGE_PAD 64u
+// The decoding kernel leaves every block's matches to the copying kernel as a list of their places in the block (no match is
+// shorter than three bytes: a block has at most 65536 / 3 of them), one list of this many half-words per block.
+#define SPL_Z_MATCH_STRIDE_MAX 21848u
+// ... or fewer (the caller's choice: memory): a block with more matches than its list holds gets SPL_Z_TOO_MANY from the
+// decoding kernel and is then done by round 2's one-lane-per-block decoder, which needs no list.
+#define SPL_Z_MATCH_STRIDE 12288u
 
 // status codes written per block (0 = fine)
 #define SPL_Z_OK 0u
@@ -37,6 +44,7 @@ struct spl_zblock {
 #define SPL_Z_OVERRUN 6u
 #define SPL_Z_SHORT 7u
 #define SPL_Z_BAD_CRC 8u
+#define SPL_Z_TOO_MANY 9u   // (between the kernels of spl_dev_launch_inflate only)
 
 // ---- BAM records out of the inflated stream, one BGZF block per lane ------------------------------------------------
 // What a lane reports about the records that START in its block (spl_bam_scan_kernel).  `start` = the first record boundary at
@@ -51,6 +59,8 @@ struct spl_bscan {
     uint32_t n_ops;      // CIGAR ops of those
     uint32_t flags;      // SPL_BS_*
     int32_t tid_first, tid_last; // of the placed records (tid_first = -1: none)
+    uint32_t n_foreign;  // records starting in the block that belong to references outside [tid_lo, tid_hi): another device's
+    uint32_t pad;
 };
 #define SPL_BS_CORRUPT 1u     // a record that contradicts itself (block_size < 32, fields beyond block_size, stream ends inside it)
 #define SPL_BS_NEEDS_HOST 2u  // a CIGAR parked in a CG tag (more than 65535 ops): the host decoder's business
@@ -64,17 +74,27 @@ extern "C" {
 // stream_len = bytes of the inflated stream; header_end = where the first record starts; blocks[b].out / out_len say where block b lies.
 // The stream may be there in part only: `stream` is indexed with offsets into the WHOLE stream all the same (the caller passes
 // the window's address minus the window's offset), stream_len = where the window ends, more = the stream goes on behind it.
-int spl_dev_launch_bam_scan(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks,
-                            spl_bscan *scan, int more, void *stream_handle);
+// Only records of references tid_lo <= tid < tid_hi count (records without a reference count as reference n_ref): a device that
+// decodes a stretch of the file takes the references that begin there.
+int spl_dev_launch_bam_scan(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref, int32_t tid_lo, int32_t tid_hi, const spl_zblock *blocks,
+                            uint32_t n_blocks, spl_bscan *scan, int more, void *stream_handle);
 // rec_off[b] / op_off[b]: index of the block's first placed record / first op in the output arrays.  cig_off gets n + 1 entries
 // (the caller sets entry 0); ref_max_end[tid] = largest last base of a read of the reference (atomicMax; zero it first).
-int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream_len, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks, const spl_bscan *scan,
+int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream_len, int32_t n_ref, int32_t tid_lo, int32_t tid_hi, const spl_zblock *blocks, uint32_t n_blocks, const spl_bscan *scan,
                                const uint64_t *rec_off, const uint64_t *op_off, int32_t *pos, uint16_t *flag, uint32_t *cig_off, uint32_t *cigar,
                                int32_t *tid, unsigned long long *ref_max_end, void *stream_handle);
 // where the reference id changes along the placed records: (index of the first record of a run, its tid) pairs, unordered
 int spl_dev_launch_bam_bounds(const int32_t *tid, const uint32_t *cig_off, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap, void *stream_handle);
-// image: the whole file in device memory, padded with 8 readable bytes.  stream: the stream to launch on.
-int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *stream);
+// image: the whole file in device memory, readable SPL_Z_IMAGE_PAD bytes past its end; out: writable 16 bytes past the last block.
+// work: spl_dev_inflate_work_bytes(n_blocks) bytes of device memory (the blocks' lists of matches between the two kernels), or
+// null for round 2's one-kernel decoder.  stream: the stream to launch on.
+// match_stride: places per block's list (0 = SPL_Z_MATCH_STRIDE; at most SPL_Z_MATCH_STRIDE_MAX; a multiple of 8).
+size_t spl_dev_inflate_work_bytes(uint32_t n_blocks, uint32_t match_stride);
+int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t match_stride, void *stream);
+// ... in two halves, for callers that put them on different streams: the Huffman decoding (and the fallback for blocks whose
+// lists overflow), then the copies
+int spl_dev_launch_inflate_decode(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t match_stride, void *stream);
+int spl_dev_launch_inflate_copy(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, void *work, uint32_t match_stride, void *stream);
 int spl_dev_launch_crc32(const uint8_t *out, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *stream);
 #ifdef __cplusplus
 }

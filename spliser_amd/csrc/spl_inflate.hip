@@ -7,15 +7,25 @@
 #include "spl_wave.h"
 #include "spl_inflate_wave.h"
 
-// One BGZF block per WAVE (spl_inflate_wave.h has the method, and is what the host tests run through the wave emulator).
-__global__ __launch_bounds__(64) void spl_inflate_wave_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status)
+// The Huffman decoding, one BGZF block per WAVE, and the copies it leaves to be made, one block per LANE (spl_inflate_wave.h has
+// the method, and is what the host tests run through the wave emulator).
+__global__ __launch_bounds__(64) void spl_inflate_decode_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status,
+                                                                uint16_t *midx_all, uint32_t stride, uint32_t *n_match)
 {
     __shared__ splz::Shared sh;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
     const spl_zblock zb = blocks[b];
-    const uint32_t st = splz::inflate_block(sh, image, zb, out_all);
-    if (threadIdx.x == 0) status[b] = st;
+    uint32_t n = 0;
+    const uint32_t st = splz::decode_block(sh, image, zb, out_all, midx_all + (size_t)b * stride, stride, n);
+    if (threadIdx.x == 0) { status[b] = st; n_match[b] = st == SPL_Z_OK ? n : 0u; }
+}
+
+__global__ __launch_bounds__(64) void spl_inflate_copy_kernel(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, const uint16_t *midx_all, uint32_t stride, const uint32_t *n_match)
+{
+    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+    if (b >= n_blocks) return;
+    splz::copy_block(out_all + blocks[b].out, midx_all + (size_t)b * stride, n_match[b]);
 }
 
 namespace {
@@ -162,7 +172,8 @@ __constant__ uint8_t k_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4
 
 } // namespace
 
-__global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status)
+// `only`: null, or a status: then only the blocks that have it are done (the others' lanes leave at once).
+__global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status, uint32_t only)
 {
     const uint32_t b = blockIdx.x * 64u + threadIdx.x;
     // lane-interleaved symbol tables: literal/length (288), distance (32); the code-length code's 19 symbols borrow the
@@ -171,6 +182,7 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
     __shared__ uint32_t s_hi[9 * 64];
     const LdsSyms lsym{s_sym + threadIdx.x, s_hi + threadIdx.x}, dsym{s_sym + 288 * 64 + threadIdx.x, nullptr};
     if (b >= n_blocks) return;
+    if (only != 0u && status[b] != only) return;
     const spl_zblock zb = blocks[b];
     uint8_t *const out = out_all + zb.out;
     const uint32_t out_len = zb.out_len;
@@ -489,7 +501,7 @@ __device__ __forceinline__ bool plausible_record(const uint8_t *c, const uint8_t
 
 // `stream_len` = where the inflated bytes end: the stream's end, or (more != 0) the end of the window that is inflated at the
 // moment -- a record that runs past it is then no damage but something for the next window (SPL_BS_INCOMPLETE).
-__global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref,
+__global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref, int32_t tid_lo, int32_t tid_hi,
                                                            const spl_zblock *blocks, uint32_t n_blocks, spl_bscan *scan, uint32_t more)
 {
     const uint32_t b = blockIdx.x * 64u + threadIdx.x;
@@ -499,6 +511,7 @@ __global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream,
     spl_bscan out;
     out.start = out.reached = u1;
     out.n_all = out.n_placed = out.n_ops = 0;
+    out.n_foreign = out.pad = 0;
     out.flags = 0;
     out.tid_first = out.tid_last = -1;
     if (u1 <= header_end && !(u1 == header_end && u0 == u1)) { // BAM header bytes only (or an empty block inside them)
@@ -545,6 +558,8 @@ __global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream,
         const uint32_t l_name = r[8], n_cig = ld16(r + 12), l_seq = ld32(r + 16);
         const uint64_t need = 32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1ull) / 2ull + (uint64_t)l_seq;
         if (need > bs) { out.flags |= SPL_BS_CORRUPT; break; }
+        const int32_t tid_eff = tid < 0 || tid >= n_ref ? n_ref : tid; // (records without a reference: behind all others)
+        if (tid_eff < tid_lo || tid_eff >= tid_hi) { out.n_foreign++; at += 4ull + bs; continue; }
         out.n_all++;
         if (tid >= 0 && tid < n_ref && pos0 >= 0) {
             if (n_cig > 0) {
@@ -564,7 +579,7 @@ __global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream,
     scan[b] = out;
 }
 
-__global__ __launch_bounds__(64) void spl_bam_extract_kernel(const uint8_t *stream, uint64_t stream_len, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks,
+__global__ __launch_bounds__(64) void spl_bam_extract_kernel(const uint8_t *stream, uint64_t stream_len, int32_t n_ref, int32_t tid_lo, int32_t tid_hi, const spl_zblock *blocks, uint32_t n_blocks,
                                                               const spl_bscan *scan, const uint64_t *rec_off, const uint64_t *op_off, int32_t *pos_out,
                                                               uint16_t *flag_out, uint32_t *cig_off, uint32_t *cigar, int32_t *tid_out,
                                                               unsigned long long *ref_max_end)
@@ -589,7 +604,7 @@ __global__ __launch_bounds__(64) void spl_bam_extract_kernel(const uint8_t *stre
         const uint8_t *cig = stream + at + 36 + l_name;
         at += 4ull + bs;
         if (at < u1) { __builtin_memcpy(&h0, stream + at, 16); __builtin_memcpy(&h1, stream + at + 16, 16); }
-        if (tid >= 0 && tid < n_ref && pos0 >= 0) {
+        if (tid >= 0 && tid < n_ref && pos0 >= 0 && tid >= tid_lo && tid < tid_hi) {
             long long ref_len = 0;
             for (uint32_t k = 0; k < n_cig; ++k) {
                 const uint32_t op = ld32(cig + 4ull * k);
@@ -627,20 +642,20 @@ __global__ __launch_bounds__(256) void spl_bam_bounds_kernel(const int32_t *tid,
     }
 }
 
-extern "C" int spl_dev_launch_bam_scan(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks,
-                                       spl_bscan *scan, int more, void *st)
+extern "C" int spl_dev_launch_bam_scan(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref, int32_t tid_lo, int32_t tid_hi, const spl_zblock *blocks,
+                                       uint32_t n_blocks, spl_bscan *scan, int more, void *st)
 {
     if (n_blocks == 0) return 0;
-    hipLaunchKernelGGL(spl_bam_scan_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)st, stream, stream_len, header_end, n_ref, blocks, n_blocks, scan, more ? 1u : 0u);
+    hipLaunchKernelGGL(spl_bam_scan_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)st, stream, stream_len, header_end, n_ref, tid_lo, tid_hi, blocks, n_blocks, scan, more ? 1u : 0u);
     return (int)hipGetLastError();
 }
 
-extern "C" int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream_len, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks, const spl_bscan *scan,
+extern "C" int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream_len, int32_t n_ref, int32_t tid_lo, int32_t tid_hi, const spl_zblock *blocks, uint32_t n_blocks, const spl_bscan *scan,
                                           const uint64_t *rec_off, const uint64_t *op_off, int32_t *pos, uint16_t *flag, uint32_t *cig_off, uint32_t *cigar,
                                           int32_t *tid, unsigned long long *ref_max_end, void *st)
 {
     if (n_blocks == 0) return 0;
-    hipLaunchKernelGGL(spl_bam_extract_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)st, stream, stream_len, n_ref, blocks, n_blocks, scan, rec_off,
+    hipLaunchKernelGGL(spl_bam_extract_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)st, stream, stream_len, n_ref, tid_lo, tid_hi, blocks, n_blocks, scan, rec_off,
                        op_off, pos, flag, cig_off, cigar, tid, ref_max_end);
     return (int)hipGetLastError();
 }
@@ -652,13 +667,44 @@ extern "C" int spl_dev_launch_bam_bounds(const int32_t *tid, const uint32_t *cig
     return (int)hipGetLastError();
 }
 
-extern "C" int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *stream)
+static uint32_t stride_of(uint32_t match_stride)
+{
+    uint32_t st = match_stride ? match_stride : SPL_Z_MATCH_STRIDE;
+    if (st > SPL_Z_MATCH_STRIDE_MAX) st = SPL_Z_MATCH_STRIDE_MAX;
+    return (st + 7u) & ~7u;
+}
+extern "C" size_t spl_dev_inflate_work_bytes(uint32_t n_blocks, uint32_t match_stride) { return 256 + ((size_t)n_blocks * 4 + 255) / 256 * 256 + (size_t)n_blocks * stride_of(match_stride) * 2; }
+
+extern "C" int spl_dev_launch_inflate_decode(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t match_stride, void *stream)
 {
     if (n_blocks == 0) return 0;
-    static const bool per_lane = getenv("SPL_INFLATE_PER_LANE") != nullptr; // (round 2's kernel, a block per lane: kept for comparison)
-    if (per_lane) hipLaunchKernelGGL(spl_inflate_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status);
-    else hipLaunchKernelGGL(spl_inflate_wave_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status);
+    static const bool per_lane = getenv("SPL_INFLATE_PER_LANE") != nullptr; // (round 2's kernel, a block per lane for everything: kept for comparison)
+    if (per_lane || !work) {
+        hipLaunchKernelGGL(spl_inflate_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status, 0u);
+        return (int)hipGetLastError();
+    }
+    uint32_t *const n_match = (uint32_t *)work;
+    uint16_t *const midx = (uint16_t *)((char *)work + ((size_t)n_blocks * 4 + 255) / 256 * 256);
+    hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status, midx, stride_of(match_stride), n_match);
+    // blocks with more matches than their list holds: by the decoder that needs none
+    hipLaunchKernelGGL(spl_inflate_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status, SPL_Z_TOO_MANY);
     return (int)hipGetLastError();
+}
+
+extern "C" int spl_dev_launch_inflate_copy(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, void *work, uint32_t match_stride, void *stream)
+{
+    static const bool per_lane = getenv("SPL_INFLATE_PER_LANE") != nullptr;
+    if (n_blocks == 0 || per_lane || !work) return 0;
+    const uint32_t *const n_match = (const uint32_t *)work;
+    const uint16_t *const midx = (const uint16_t *)((const char *)work + ((size_t)n_blocks * 4 + 255) / 256 * 256);
+    hipLaunchKernelGGL(spl_inflate_copy_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, blocks, n_blocks, out, midx, stride_of(match_stride), n_match);
+    return (int)hipGetLastError();
+}
+
+extern "C" int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t match_stride, void *stream)
+{
+    const int rc = spl_dev_launch_inflate_decode(image, blocks, n_blocks, out, status, work, match_stride, stream);
+    return rc ? rc : spl_dev_launch_inflate_copy(blocks, n_blocks, out, work, match_stride, stream);
 }
 
 extern "C" int spl_dev_launch_crc32(const uint8_t *out, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *stream)

@@ -1,22 +1,27 @@
-// spl_inflate_wave.h -- DEFLATE (RFC 1951) with one BGZF block per WAVE: the body of spl_inflate_wave_kernel (spl_inflate.hip),
-// written against the primitives of spl_wave.h so that the same source runs on the host under tests/hostsim/wave_emul.h.
+// spl_inflate_wave.h -- DEFLATE (RFC 1951) on the device in two kernels (spl_inflate.hip launches them; the bodies are here,
+// written against the primitives of spl_wave.h so that the same source runs on the host under tests/hostsim/wave_emul.h):
 //
-// Why a wave per block (round 2 gave every lane a block of its own): a lane's Huffman tables were 356 bytes of LDS and thirty-odd
-// registers -- 1.75 waves per SIMD -- and 64 lanes in 64 different blocks meant 64 cache lines per memory instruction.  Here the
-// 64 lanes share ONE pair of tables (two-level look-up tables in LDS, 2.9 KB), read the compressed bytes from a tile of them
-// staged in LDS by coalesced loads, and write one block's 64 KB.
+//   decode_block   one BGZF block per WAVE: the Huffman decoding.  Literals go to their places in the inflated stream; a match
+//                  (length, distance) is left as three bytes at ITS place -- distance - 1 | (length - 3) << 15, it has room for
+//                  them: no match is shorter -- and its place is appended to the block's list of matches.
+//   copy_block     one BGZF block per LANE: the list's matches made one after the other, each a copy of bytes that are there.
 //
-// Huffman codes have no markers, so where a lane should start is not known: it is FOUND.  The data of a DEFLATE block is worked
-// off in tiles of 64 subsequences of SUB_BITS bits, one per lane.  Every lane decodes from a guessed start (the beginning of its
-// subsequence; lane 0 from the true position) to the first symbol boundary at or past its subsequence's end, counting what it
-// would produce; then every lane takes its predecessor's end as its start and decodes again if that differs, until nothing
-// changes.  Wrongly started decoders fall into step with the true sequence of symbols within a few symbols almost always, so two or
-// three passes do; lane k is right after pass k + 1 whatever the data.  A prefix sum over the lanes' byte counts places every lane
-// in the output, and a last pass decodes once more for good: literals are stored where they belong, matches (length, distance) are
-// queued in LDS in output order.  The queue is then worked off by 64 lanes at a time, a lane per match, under one rule: a match may
-// be copied when its source lies below the first byte still to be written -- the destination of the oldest match not yet made --
-// and the oldest one always may; matches longer than COOP_MIN bytes are copied by the whole wave, a byte per lane, when they are
-// the oldest (a copy that overlaps its own destination has a period, and every lane knows which byte of the period is its).
+// Why the split.  Round 2 gave every lane a block of its own for everything: a lane's Huffman tables were 356 bytes of LDS and
+// thirty-odd registers (1.75 waves per SIMD), every turn of the 64 lanes ran through all the decoder's branches (330 vector
+// instructions a turn).  Decoding is what a wave can share: here 64 lanes use ONE pair of tables (two-level look-up tables in
+// LDS, 2.9 KB) and read the compressed bytes from a tile of them staged in LDS by coalesced loads.  Copying is what it cannot: a
+// BAM record's matches copy from the record before, whose matches copy from the one before that -- measured with
+// tools/inflate_sim.cpp: about 2 000 dependent steps per block, a dozen copies ready at any time -- so 64 lanes on one block's
+// copies idle (built and measured: 33 of the kernel's 58 ms, profiles/r03_inflate_wave_account.md), while 64 lanes on 64 blocks'
+// copies are all busy and need no tables.
+//
+// Huffman codes have no markers, so where a lane should start decoding is not known: it is FOUND.  The data of a DEFLATE block
+// is worked off in tiles of 64 subsequences of SUB_BITS bits, one per lane.  Every lane decodes from a guessed start (the beginning
+// of its subsequence; lane 0 from the true position) to the first symbol boundary at or past its subsequence's end, counting what
+// it would produce; then every lane takes its predecessor's end as its start and decodes again if that differs, until nothing
+// changes.  Wrongly started decoders fall into step with the true sequence of symbols sooner or later, so a few passes do; lane k
+// is right after pass k + 1 whatever the data.  A prefix sum over the lanes' byte counts places every lane in the output, and a last
+// pass decodes once more for good.
 //
 // Replaces what SpliSER_v0_1_8.py:422 (samtools view) does to every BGZF block it touches.
 #ifndef SPL_INFLATE_WAVE_H
@@ -28,29 +33,22 @@ namespace splz {
 
 constexpr uint32_t ROOT_L = 9, ROOT_D = 6, ROOT_C = 7;
 constexpr uint32_t LUT_L = 852, LUT_D = 592; // entries: root table + the most sub-tables a valid code can need (zlib's ENOUGH_LENS / ENOUGH_DISTS for these roots)
-constexpr uint32_t SUB_BITS = 128;           // bits of DEFLATE data per lane and tile
+constexpr uint32_t SUB_BITS = 256;           // bits of DEFLATE data per lane and tile
 constexpr uint32_t TILE_WORDS = 64u * SUB_BITS / 32u;
 constexpr uint32_t TILE_PAD = 16;            // words behind the tile: a symbol that begins in the last subsequence ends there
-constexpr uint32_t OUT_CAP = 4096;           // bytes of a tile's output that are put together in shared memory
-constexpr uint32_t QCAP = 512;               // matches per tile (a tile with more is cut short) ...
-constexpr uint32_t QCAP_G = 640;             // ... when its output is put together in device memory instead (the queue then lies where the output would)
-constexpr uint32_t COOP_MIN = 32;            // matches longer than this are copied by the whole wave
+constexpr uint32_t QCAP = 704;               // matches per tile (a tile with more is cut short)
 constexpr uint32_t FL_OK = 0, FL_EOB = 1, FL_ERR = 2;
 constexpr uint32_t SYM_EOB = 256, SYM_MATCH = 257, SYM_BAD = 0xffffffffu;
 
-// One wave's shared memory: 9128 bytes (17 waves on a CU's 160 KB).
+// One wave's shared memory: 6408 bytes.
 struct Shared {
     uint16_t lut_l[LUT_L];                // literal/length code.  Entry: symbol << 4 | bits; 0x8000 | offset << 4 | sub-table bits; 0 = no such code
     uint16_t lut_d[LUT_D];                // distance code
-    uint32_t tile[TILE_WORDS + TILE_PAD]; // the compressed bytes being worked on (while a header is read: the code-length code's table)
-    uint16_t q_dest[QCAP];                // where the tile's matches go, in output order (while a header is read: the code lengths)
-    // The tile's output: literals stored, matches first as three bytes of (distance - 1 | (length - 3) << 15) at their own place,
-    // then copied; written to device memory in one piece.  (While tables are built: work space.  For a tile whose output is too
-    // large: the queue of its matches, distance - 1 | (length - 3) << 16 in words, then their places in half-words.)
-    uint32_t out[OUT_CAP / 4 + 8];
+    uint32_t tile[TILE_WORDS + TILE_PAD]; // the compressed bytes being worked on (while tables are built: work space)
+    uint16_t q_dest[QCAP];                // where the tile's matches go, in output order (while a header is read: code lengths, the code-length code's table)
 };
-static_assert(SUB_BITS == 128u, "the tile is staged sixteen bytes a lane");
-static_assert(QCAP_G * 6u <= OUT_CAP + 32u, "the queue of the large-output path lies in the output tile");
+static_assert(SUB_BITS == 256u, "the tile is staged thirty-two bytes a lane");
+static_assert(QCAP * 2u >= 352u + 256u, "code lengths and the code-length code's table lie in q_dest while a header is read");
 
 // the order in which a dynamic header lists the lengths of the code-length code (RFC 1951, 3.2.7), five bits a place
 constexpr uint64_t pack5(const int *v, int n) { uint64_t r = 0; for (int i = 0; i < n; ++i) r |= (uint64_t)v[i] << (5 * i); return r; }
@@ -225,153 +223,18 @@ WV_DEV Count count_from(const Shared &sh, uint32_t base, uint32_t start, uint32_
 // n bytes (1..16) of (lo, hi) to p
 WV_DEV void store_n(uint8_t *p, uint64_t lo, uint64_t hi, uint32_t n)
 {
-    if (n == 16u) { wv::st64(p, lo); wv::st64(p + 8, hi); return; }
+    if (n == 16u) { wv::st128(p, lo, hi); return; }
     if (n & 8u) { wv::st64(p, lo); p += 8; lo = hi; }
     if (n & 4u) { wv::st32(p, (uint32_t)lo); p += 4; lo >>= 32; }
     if (n & 2u) { wv::st16(p, (uint32_t)lo); p += 2; lo >>= 16; }
     if (n & 1u) *p = (uint8_t)lo;
 }
 
-// The queued matches of a tile made in output order, 64 at a time, a lane per match.  A match may be copied when its source lies
-// below the first byte still to be written (`hwm`: where the oldest match not yet made is at); the oldest always may.  One longer
-// than COOP_MIN bytes waits until it is the oldest and is then copied by the whole wave, a byte per lane: byte i of it is byte
-// i mod distance of the bytes before it.
-//
-// ... with the tile's output in shared memory.  tout: the tile (positions in it: 0 = the first byte of the tile); before: the
-// same place in device memory, for sources in front of the tile (all there: earlier tiles are complete).
-WV_DEV void resolve_in_tile(uint8_t *tout, const uint16_t *q_dest, uint32_t n_q, const uint8_t *before)
+// The block `zb` of the file image, by one wave.  midx: room for `stride` places of matches; n_match_out: how many were written.  Returns the block's status (every lane the same).
+WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock &zb, uint8_t *out_all, uint16_t *midx, uint32_t stride, uint32_t &n_match_out)
 {
-    const uint32_t l = wv::lane();
-    for (uint32_t b0 = 0; b0 < n_q; b0 += 64u) {
-        const uint32_t t = b0 + l;
-        bool pend = t < n_q;
-        uint32_t d = 0, left = 0, dist = 1;
-        if (pend) {
-            d = q_dest[t];
-            const uint32_t tok = (uint32_t)tout[d] | (uint32_t)tout[d + 1u] << 8 | (uint32_t)tout[d + 2u] << 16;
-            dist = (tok & 0x7fffu) + 1u;
-            left = (tok >> 15) + 3u;
-        }
-        for (;;) {
-            const uint64_t m = wv::ballot(pend);
-            if (m == 0ull) break;
-            const uint32_t f = wv::ffs64(m);
-            const uint32_t hwm = wv::readlane(d, f), f_left = wv::readlane(left, f), f_dist = wv::readlane(dist, f);
-            if (f_left > COOP_MIN) {
-                const int32_t s0 = (int32_t)hwm - (int32_t)f_dist;
-                uint8_t v[5];
-#pragma unroll
-                for (uint32_t k = 0; k < 5u; ++k) {
-                    const uint32_t i = k * 64u + l;
-                    const int32_t si = s0 + (int32_t)(f_dist >= f_left ? i : i % f_dist);
-                    v[k] = i < f_left ? (si < 0 ? before[si] : tout[si]) : (uint8_t)0;
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < 5u; ++k) {
-                    const uint32_t i = k * 64u + l;
-                    if (i < f_left) tout[hwm + i] = v[k];
-                }
-                if (l == f) { pend = false; left = 0; }
-                wv::sync();
-                continue;
-            }
-            if (pend && left <= COOP_MIN) {
-                const int32_t s = (int32_t)d - (int32_t)dist;
-                uint32_t n = left < 16u ? left : 16u;
-                if (s < 0) n = n < (uint32_t)-s ? n : (uint32_t)-s;  // (the part of the source in front of the tile first: plain bytes)
-                else if (dist < 8u) n = n < 8u ? n : 8u;             // (made from the period, below)
-                else if (dist < n) n = dist;                         // (only what is there already)
-                const uint32_t s_end = (uint32_t)((int32_t)d - (int32_t)dist) + (n < dist ? n : dist); // (s < 0: below any hwm)
-                if (l == f || s < 0 || s_end <= hwm) {
-                    uint64_t lo, hi = 0;
-                    if (s < 0) {
-                        lo = wv::ld64(before + s);
-                        if (n > 8u) hi = wv::ld64(before + s + 8);
-                    } else {
-                        lo = wv::ld64(tout + s);
-                        if (n > 8u) hi = wv::ld64(tout + s + 8);
-                        if (dist < 8u) { // the bytes repeat with a period shorter than the piece: the period, as often as it fits
-                            lo &= (1ull << (8u * dist)) - 1ull;
-                            lo |= lo << (8u * dist);
-                            if (dist < 4u) lo |= lo << (16u * dist);
-                            if (dist < 2u) lo |= lo << 32;
-                        }
-                    }
-                    store_n(tout + d, lo, hi, n);
-                    d += n;
-                    left -= n;
-                    if (left == 0u) pend = false;
-                }
-            }
-            wv::sync();
-        }
-    }
-}
-
-// ... with the output in device memory (out: the block's first byte; places in the queue count from there).
-WV_DEV void resolve_in_memory(const uint32_t *q_ld, const uint16_t *q_to, uint32_t n_q, uint8_t *out)
-{
-    const uint32_t l = wv::lane();
-    for (uint32_t b0 = 0; b0 < n_q; b0 += 64u) {
-        const uint32_t t = b0 + l;
-        bool pend = t < n_q;
-        uint32_t d = 0, left = 0, dist = 1;
-        if (pend) {
-            const uint32_t ld = q_ld[t];
-            dist = (ld & 0xffffu) + 1u;
-            left = (ld >> 16) + 3u;
-            d = q_to[t];
-        }
-        for (;;) {
-            const uint64_t m = wv::ballot(pend);
-            if (m == 0ull) break;
-            const uint32_t f = wv::ffs64(m);
-            const uint32_t hwm = wv::readlane(d, f), f_left = wv::readlane(left, f), f_dist = wv::readlane(dist, f);
-            if (f_left > COOP_MIN) {
-                // the oldest match by the whole wave: byte i of it is byte i mod distance of the bytes before it
-                const uint8_t *const src = out + hwm - f_dist;
-                uint8_t v[5];
-#pragma unroll
-                for (uint32_t k = 0; k < 5u; ++k) {
-                    const uint32_t i = k * 64u + l;
-                    v[k] = i < f_left ? src[f_dist >= f_left ? i : i % f_dist] : (uint8_t)0;
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < 5u; ++k) {
-                    const uint32_t i = k * 64u + l;
-                    if (i < f_left) out[hwm + i] = v[k];
-                }
-                if (l == f) { pend = false; left = 0; }
-                continue;
-            }
-            if (pend && left <= COOP_MIN) {
-                uint32_t n = left < 16u ? left : 16u;
-                if (dist < 8u) n = n < 8u ? n : 8u;      // (made from the period, below)
-                else if (dist < n) n = dist;             // (only what is there already)
-                const uint32_t s_end = d - dist + (n < dist ? n : dist);
-                if (l == f || s_end <= hwm) {
-                    const uint8_t *const src = out + d - dist;
-                    uint64_t lo = wv::ld64(src), hi = 0;
-                    if (n > 8u) hi = wv::ld64(src + 8);
-                    if (dist < 8u) { // the bytes repeat with a period shorter than the piece: the period, as often as it fits
-                        lo &= (1ull << (8u * dist)) - 1ull;
-                        lo |= lo << (8u * dist);
-                        if (dist < 4u) lo |= lo << (16u * dist);
-                        if (dist < 2u) lo |= lo << 32;
-                    }
-                    store_n(out + d, lo, hi, n);
-                    d += n;
-                    left -= n;
-                    if (left == 0u) pend = false;
-                }
-            }
-        }
-    }
-}
-
-// The block `zb` of the file image, by one wave.  Returns the block's status (every lane the same).
-WV_DEV uint32_t inflate_block(Shared &sh, const uint8_t *image, const spl_zblock &zb, uint8_t *out_all)
-{
+    n_match_out = 0;
+    uint32_t n_match = 0;
     const uint32_t l = wv::lane();
     const uint8_t *const in = image + zb.in;
     uint8_t *const out = out_all + zb.out;
@@ -379,7 +242,7 @@ WV_DEV uint32_t inflate_block(Shared &sh, const uint8_t *image, const spl_zblock
     if (out_len == 0u) return SPL_Z_OK; // (the EOF marker and other empty blocks: nothing to decode into)
     if (out_len > 65536u || in_len > 65536u) return SPL_Z_OVERRUN; // (not a BGZF block)
     uint8_t *const lens = (uint8_t *)sh.q_dest; // 352 code lengths while a header is read
-    uint32_t *const work = sh.out;
+    uint32_t *const work = sh.tile;
     uint32_t pos = 0, at = 0;
     for (uint32_t last = 0; !last;) {
         if (pos + 3u > end_bits) return SPL_Z_OVERRUN;
@@ -421,7 +284,7 @@ WV_DEV uint32_t inflate_block(Shared &sh, const uint8_t *image, const spl_zblock
             if (l < n_code) lens[clen_order(l)] = (uint8_t)(gbits(in, pos + 3u * l) & 7u);
             pos += 3u * n_code;
             wv::sync();
-            uint16_t *const lut_c = (uint16_t *)sh.tile;
+            uint16_t *const lut_c = sh.q_dest + 176;
             if (!build_lut(lens, 19u, ROOT_C, lut_c, 1u << ROOT_C, work)) return SPL_Z_BAD_LENGTHS;
             // the lengths of the two codes, a run-length code of its own: one after the other (every lane does the same)
             const uint32_t n_all = n_lit + n_dist;
@@ -463,11 +326,13 @@ WV_DEV uint32_t inflate_block(Shared &sh, const uint8_t *image, const spl_zblock
             // the tile: 32 bytes per lane, and the words behind it (what lies beyond the block's data is never used: zeros will do,
             // and the image is readable for SPL_Z_IMAGE_PAD bytes past any block)
             {
-                const uint32_t o = byte0 + (SUB_BITS / 8u) * l;
-                uint64_t a = 0, b = 0;
+                const uint32_t o = byte0 + 32u * l;
+                uint64_t a = 0, b = 0, c = 0, d = 0;
                 if (o + 16u <= in_len + SPL_Z_IMAGE_PAD) { a = wv::ld64(in + o); b = wv::ld64(in + o + 8u); }
-                uint32_t *t = sh.tile + (SUB_BITS / 32u) * l;
+                if (o + 32u <= in_len + SPL_Z_IMAGE_PAD) { c = wv::ld64(in + o + 16u); d = wv::ld64(in + o + 24u); }
+                uint32_t *t = sh.tile + 8u * l;
                 t[0] = (uint32_t)a; t[1] = (uint32_t)(a >> 32); t[2] = (uint32_t)b; t[3] = (uint32_t)(b >> 32);
+                t[4] = (uint32_t)c; t[5] = (uint32_t)(c >> 32); t[6] = (uint32_t)d; t[7] = (uint32_t)(d >> 32);
                 if (l < TILE_PAD / 4u) {
                     const uint32_t o2 = byte0 + TILE_WORDS * 4u + 16u * l;
                     uint64_t e = 0, f = 0;
@@ -496,84 +361,86 @@ WV_DEV uint32_t inflate_block(Shared &sh, const uint8_t *image, const spl_zblock
                     if (!dead) c = count_from(sh, base, start, sub_end);
                 }
             }
-            // The lanes that count: all that are alive (a suffix of the lanes is dead), short of the one whose matches overflow the
-            // queue.  Where the tile's output is put together: in shared memory when at least half of those lanes' output fits
-            // there (the others are left to the next tile), in device memory otherwise (what deflates to almost nothing).
-            const uint32_t cum_m = wv::scan_add(dead ? 0u : c.n_match), cum_all = wv::scan_add(dead ? 0u : c.n_out);
-            const uint64_t m_live = wv::ballot(!dead), m_fit = wv::ballot(!dead && cum_all <= OUT_CAP && cum_m <= QCAP), m_big = wv::ballot(!dead && cum_m <= QCAP_G);
-            const uint32_t n_live = ~m_live ? wv::ffs64(~m_live) : 64u, n_fit = ~m_fit ? wv::ffs64(~m_fit) : 64u, n_big = ~m_big ? wv::ffs64(~m_big) : 64u;
-            const bool in_lds = n_fit * 2u >= n_live;
-            const uint32_t n_valid = in_lds ? n_fit : n_big;
+            // the lanes that count: all that are alive (a suffix of the lanes is dead), short of the one whose matches overflow the queue
+            const uint32_t cum_m = wv::scan_add(dead ? 0u : c.n_match), cum_o = wv::scan_add(dead ? 0u : c.n_out);
+            const uint64_t m_ok = wv::ballot(!dead && cum_m <= QCAP);
+            const uint32_t n_valid = ~m_ok ? wv::ffs64(~m_ok) : 64u; // (the low run of ones)
             if (n_valid == 0u) return SPL_Z_OVERRUN;
             const bool valid = l < n_valid;
             if (wv::any(valid && c.flag == FL_ERR)) return SPL_Z_BAD_CODE;
             eob = wv::any(valid && c.flag == FL_EOB);
-            const uint32_t total = wv::readlane(cum_all, n_valid - 1u), n_q = wv::readlane(cum_m, n_valid - 1u);
+            const uint32_t total = wv::readlane(cum_o, n_valid - 1u), n_q = wv::readlane(cum_m, n_valid - 1u);
             if (at + total > out_len) return SPL_Z_OVERRUN;
+            if (n_match + n_q > stride) return SPL_Z_TOO_MANY;
+            // ---- the writing pass: literals to their places, matches as three bytes at theirs and their places to the list
             bool bad_dist = false;
-            if (in_lds) {
-                uint8_t *const tout = (uint8_t *)sh.out;
-                // ---- the writing pass: literals to their places in the tile, matches as three bytes at theirs
 #ifndef SPL_EXP_NO_WRITE
-                if (valid) {
-                    uint32_t p = start, wr = cum_all - c.n_out, qi = cum_m - c.n_match;
-                    while (p < sub_end) {
-                        uint32_t len = 0, dist = 0;
-                        const uint32_t s = decode(sh, base, p, len, dist);
-                        if (s < 256u) { tout[wr++] = (uint8_t)s; continue; }
-                        if (s != SYM_MATCH) break; // (the end of the block; errors were seen by the counting pass)
-                        if (dist > at + wr) { bad_dist = true; break; }
-                        const uint32_t tok = (dist - 1u) | (len - 3u) << 15;
-                        tout[wr] = (uint8_t)tok; tout[wr + 1u] = (uint8_t)(tok >> 8); tout[wr + 2u] = (uint8_t)(tok >> 16);
-                        sh.q_dest[qi++] = (uint16_t)wr;
-                        wr += len;
-                    }
+            if (valid) {
+                uint32_t p = start, wr = at + cum_o - c.n_out, qi = cum_m - c.n_match;
+                while (p < sub_end) {
+                    uint32_t len = 0, dist = 0;
+                    const uint32_t s = decode(sh, base, p, len, dist);
+                    if (s < 256u) { out[wr++] = (uint8_t)s; continue; }
+                    if (s != SYM_MATCH) break; // (the end of the block; errors were seen by the counting pass)
+                    if (dist > wr) { bad_dist = true; break; }
+                    const uint32_t tok = (dist - 1u) | (len - 3u) << 15;
+                    out[wr] = (uint8_t)tok; out[wr + 1u] = (uint8_t)(tok >> 8); out[wr + 2u] = (uint8_t)(tok >> 16);
+                    sh.q_dest[qi++] = (uint16_t)wr;
+                    wr += len;
                 }
-#endif
-                if (wv::any(bad_dist)) return SPL_Z_BAD_DISTANCE;
-                wv::sync();
-#ifndef SPL_EXP_NO_ROUNDS
-                resolve_in_tile(tout, sh.q_dest, n_q, out + at);
-#endif
-                wv::sync();
-                // ---- the tile to its place in the stream
-                for (uint32_t o = l * 16u; o < total; o += 1024u) {
-                    const uint64_t lo = (uint64_t)sh.out[o / 4u] | (uint64_t)sh.out[o / 4u + 1u] << 32, hi = (uint64_t)sh.out[o / 4u + 2u] | (uint64_t)sh.out[o / 4u + 3u] << 32;
-                    store_n(out + at + o, lo, hi, total - o < 16u ? total - o : 16u);
-                }
-            } else {
-                uint32_t *const q_ld = sh.out;
-                uint16_t *const q_to = (uint16_t *)(sh.out + QCAP_G);
-                const uint32_t cum_o = cum_all;
-                // ---- the writing pass: literals to their places, matches to the queue
-#ifndef SPL_EXP_NO_WRITE
-                if (valid) {
-                    uint32_t p = start, wr = at + cum_o - c.n_out, qi = cum_m - c.n_match;
-                    while (p < sub_end) {
-                        uint32_t len = 0, dist = 0;
-                        const uint32_t s = decode(sh, base, p, len, dist);
-                        if (s < 256u) { out[wr++] = (uint8_t)s; continue; }
-                        if (s != SYM_MATCH) break;
-                        if (dist > wr) { bad_dist = true; break; }
-                        q_ld[qi] = (dist - 1u) | (len - 3u) << 16;
-                        q_to[qi] = (uint16_t)wr;
-                        ++qi;
-                        wr += len;
-                    }
-                }
-#endif
-                if (wv::any(bad_dist)) return SPL_Z_BAD_DISTANCE;
-                wv::sync();
-#ifndef SPL_EXP_NO_ROUNDS
-                resolve_in_memory(q_ld, q_to, n_q, out);
-#endif
             }
+#endif
+            if (wv::any(bad_dist)) return SPL_Z_BAD_DISTANCE;
+            wv::sync();
+            for (uint32_t t = l; t < n_q; t += 64u) midx[n_match + t] = sh.q_dest[t];
+            n_match += n_q;
             wv::sync();
             at += total;
             pos = wv::readlane(c.end, n_valid - 1u);
         }
     }
-    return at == out_len ? SPL_Z_OK : SPL_Z_SHORT;
+    if (at != out_len) return SPL_Z_SHORT;
+    n_match_out = n_match;
+    return SPL_Z_OK;
+}
+
+// The matches of a block made in the order of its list: every one a copy of bytes that are there by then (literals, and the
+// matches before it).  One lane's work; 64 blocks to a wave, 64 different cache lines to every memory instruction -- what this
+// kernel costs is the NUMBER of its memory requests, so it makes few: the places of eight matches in one 16-byte load, a
+// match's three bytes asked for a match ahead, a piece of up to 16 bytes in one load and one store.
+WV_DEV void copy_block(uint8_t *out, const uint16_t *midx, uint32_t n)
+{
+    if (n == 0u) return;
+    uint64_t w_lo, w_hi; // the places of matches i .. (eight to a load; midx + 8k is 16-byte aligned)
+    wv::ld128((const uint8_t *)midx, w_lo, w_hi);
+    uint32_t i = 0, d = 0, left = 0, dist = 1;
+    uint32_t tok = wv::ld32(out + (uint32_t)(w_lo & 0xffffu)) & 0xffffffu; // of match i
+    for (;;) {
+        if (left == 0u) {
+            if (i >= n) break;
+            d = (uint32_t)(w_lo & 0xffffu);
+            dist = (tok & 0x7fffu) + 1u;
+            left = (tok >> 15) + 3u;
+            ++i;
+            if ((i & 7u) == 0u) { if (i < n) wv::ld128((const uint8_t *)(midx + i), w_lo, w_hi); }
+            else { w_lo = w_lo >> 16 | w_hi << 48; w_hi >>= 16; }
+            if (i < n) tok = wv::ld32(out + (uint32_t)(w_lo & 0xffffu)) & 0xffffffu; // (nobody writes there before that match is made)
+        }
+        uint32_t k = left < 16u ? left : 16u;
+        if (dist < 8u) k = k < 8u ? k : 8u;      // (made from the period, below)
+        else if (dist < k) k = dist;             // (only what is there already)
+        uint64_t lo, hi;
+        wv::ld128(out + d - dist, lo, hi);
+        if (dist < 8u) { // the bytes repeat with a period shorter than the piece: the period, as often as it fits
+            lo &= (1ull << (8u * dist)) - 1ull;
+            lo |= lo << (8u * dist);
+            if (dist < 4u) lo |= lo << (16u * dist);
+            if (dist < 2u) lo |= lo << 32;
+        }
+        store_n(out + d, lo, hi, k);
+        d += k;
+        left -= k;
+    }
 }
 
 } // namespace splz

@@ -45,6 +45,9 @@ WV_DEV uint32_t scan_add(uint32_t v)
 // unaligned accesses to global memory (the hardware takes them: the compiler is told the alignment is 1)
 WV_DEV uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 WV_DEV uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+struct alignas(4) u128 { uint32_t w[4]; };
+WV_DEV void ld128(const uint8_t *p, uint64_t &lo, uint64_t &hi) { u128 v; __builtin_memcpy(&v, p, 16); lo = (uint64_t)v.w[0] | (uint64_t)v.w[1] << 32; hi = (uint64_t)v.w[2] | (uint64_t)v.w[3] << 32; }
+WV_DEV void st128(uint8_t *p, uint64_t lo, uint64_t hi) { u128 v; v.w[0] = (uint32_t)lo; v.w[1] = (uint32_t)(lo >> 32); v.w[2] = (uint32_t)hi; v.w[3] = (uint32_t)(hi >> 32); __builtin_memcpy(p, &v, 16); }
 WV_DEV void st16(uint8_t *p, uint32_t v) { const uint16_t x = (uint16_t)v; __builtin_memcpy(p, &x, 2); }
 WV_DEV void st32(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 WV_DEV void st64(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }

@@ -49,7 +49,7 @@ EXPORTS = [
     "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
-    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
+    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
     "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append", "spl_fmt_fixed",
     "spl_bed_open", "spl_gff_open", "spl_text_close", "spl_text_rows", "spl_text_n_chrom", "spl_text_chrom_name", "spl_text_chrom",
@@ -488,6 +488,52 @@ class BamFile(object):
         self._device_thread = t
         return t
 
+    def decode_on_devices_async(self, devices):
+        """The decode in SHARES, one per entry of ``devices`` (a device may appear more than once: a context each): the file is
+        cut at reference boundaries into stretches of about equal size, and every device inflates and extracts its own stretch
+        -- the references that begin there -- over its own PCIe link.  -> [(device, [reference names])], the plan: whoever counts
+        a reference should do it on the device that holds its reads (``shares``).  Threads in ``_device_threads``."""
+        import threading
+        n = ctypes.c_int(0)
+        _check(lib().spl_bam_share_plan(self._h, ctypes.c_int(len(devices)), ctypes.byref(n)))
+        _check(lib().spl_bam_reserve_device(self._h))
+        self.on_device = False
+        plan = []
+        for k in range(n.value):
+            lo, hi = ctypes.c_int(0), ctypes.c_int(0)
+            _check(lib().spl_bam_share_range(self._h, ctypes.c_int(k), ctypes.byref(lo), ctypes.byref(hi)))
+            plan.append((devices[k], [self.ref_names[t] for t in range(lo.value, min(hi.value, len(self.ref_names)))]))
+        self.shares = plan
+        self._share_errors = []
+
+        def run(k, device):
+            flag = ctypes.c_int(0)
+            try:
+                with Context(device) as ctx:
+                    _check(lib().spl_bam_decode_device_share(ctx._h, self._h, ctypes.c_int(k), ctypes.byref(flag)))
+            except BaseException as exc:   # (no context, or the call itself failed: the share must still be reported, or the
+                self._share_errors.append(exc)   # file waits for ever -- the host threads take all of it then)
+                try:
+                    lib().spl_bam_start(self._h)
+                except Exception:
+                    pass
+        self._device_threads = [threading.Thread(target=run, args=(k, dev)) for k, (dev, _) in enumerate(plan)]
+        for t in self._device_threads:
+            t.start()
+        self._device_thread = self._device_threads[0]
+        return plan
+
+    def join_decoders(self):
+        """Waits for the device decoders started by ``decode_on_device_async`` / ``decode_on_devices_async``; -> True when the
+        reads are on the device(s)."""
+        for t in getattr(self, "_device_threads", None) or ([self._device_thread] if getattr(self, "_device_thread", None) is not None else []):
+            t.join()
+        if getattr(self, "_device_threads", None):
+            flag = ctypes.c_int(0)
+            _check(lib().spl_bam_decoded_on_device(self._h, ctypes.byref(flag)))
+            self.on_device = bool(flag.value)
+        return bool(self.on_device)
+
     def decode_on_device(self, ctx):
         """A file opened with ``defer=True``: inflate it and extract its records on the GPU of ``ctx`` (every reference is
         complete on return).  -> True; False when the file is not one for the device path (unsorted, CG-tag CIGARs, malformed)
@@ -548,10 +594,10 @@ class BamFile(object):
 
     def close(self):
         """Closes the native decoder -- unless views of its arrays are still alive: then their owner closes it."""
-        t = getattr(self, "_device_thread", None)
-        if t is not None:
-            t.join()                 # (the device decoder works on the native object: not under its feet)
-            self._device_thread = None
+        for t in (getattr(self, "_device_threads", None) or []) + ([self._device_thread] if getattr(self, "_device_thread", None) is not None else []):
+            t.join()                 # (the device decoders work on the native object: not under their feet)
+        self._device_thread = None
+        self._device_threads = None
         h, self._h = self._h, ctypes.c_void_p()
         views, self._views = self._views, {}
         if h and not views:

@@ -47,27 +47,16 @@ def open_alignments(path, threads=0, stream=False, defer=False):
     raise native.SpliserNativeError(-5, "%s is neither BGZF/BAM nor SAM text" % path)
 
 
-# With ONE device `process` inflates every BAM on the GPU (3.6x file: 195 M reads/s against 45 M on the 16 host cores of the
-# bench box; a file of constant bytes that inflates 49x: 350 M against 190 M).  With several devices the decoded reads stay on the
-# decoding device and the others get theirs by way of the host, which only pays for files below this ratio (inflated bytes per
-# file byte, measured with the round trip in place: twice as fast at 3.6x, slower at 49x).
-GPU_DECODE_BELOW = 10.0
-
-
 def open_and_decode(path, devices, gpuDecode=None, threads=0):
-    """The alignment file opened and its decode started: on the GPU (``devices[0]``) or on host threads -- told by the caller
-    (``gpuDecode`` True / False) or, None, chosen here: the GPU when the call uses one device, by the file's compression when it
-    uses several (GPU_DECODE_BELOW).  SAM text has one reader."""
+    """The alignment file opened and its decode started: on the GPU(s) -- with several devices every one inflates and extracts
+    the stretch of the file that holds its own references (``BamFile.decode_on_devices_async``), and counts them -- or, told so
+    (``gpuDecode=False``), on host threads.  SAM text has one reader."""
     source = open_alignments(path, threads=threads, stream=True, defer=gpuDecode is not False)
     if isinstance(source, native.BamFile) and gpuDecode is not False:
-        if gpuDecode is not None:
-            on_gpu = bool(gpuDecode)
+        if len(devices) > 1:
+            source.decode_on_devices_async(list(devices))
         else:
-            on_gpu = len(set(devices)) == 1 or 0.0 < source.compression_ratio() < GPU_DECODE_BELOW
-        if on_gpu:
             source.decode_on_device_async(devices[0])
-        else:
-            source.start_host_decode()
     return source
 
 
@@ -135,7 +124,15 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
     # Which device takes which chromosome is decided before the reads are known (they may still be on their way): the junction
     # read counts of the BED file say where the spliced reads are.
     weights = {c: (r.n if r is not None else int(a.alpha.sum())) + a.n for c, (a, r, _) in items.items()}
-    plan = shard.assign(weights, len(devices))
+    shares = getattr(source, "shares", None) if is_bam else None
+    if shares and len(devices) >= len(shares) and [d for d, _ in shares] == list(devices[:len(shares)]):
+        # the file is being decoded in shares, a device each: a chromosome is counted where its reads are (the others, if any, by the first)
+        where = {c: k for k, (_, names) in enumerate(shares) for c in names}
+        plan = [[] for _ in devices]
+        for c in items:
+            plan[where.get(c, 0)].append(c)
+    else:
+        plan = shard.assign(weights, len(devices))
     out, errors = {}, []
     lock = threading.Lock()
 
@@ -175,7 +172,7 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
         # the device decoder delivers every reference at once: nothing to stream chromosome by chromosome, so all chromosomes of
         # a shard are laid out as ONE read set and counted in one pass.  (Whether it did is asked when the first site table is
         # up: context and table take 10 ms that the decode's last kernels can run beside.)
-        device_decode = is_bam and getattr(source, "_device_thread", None) is not None and on_junctions is None
+        device_decode = is_bam and (getattr(source, "_device_thread", None) is not None or getattr(source, "_device_threads", None)) and on_junctions is None
         whole = None
         stamps = [] if os.environ.get("SPL_PROCESS_TIMING") else None   # (where a device thread's time goes, on stderr)
 
@@ -189,9 +186,7 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                 with ctx.upload_sites(sh.sites) as ds:
                     stamp("site table up")
                     if whole is None:
-                        if device_decode:
-                            source._device_thread.join()
-                        whole = bool(device_decode and source.on_device)
+                        whole = bool(device_decode and source.join_decoders())
                         stamp("decoder joined")
                     if whole:
                         n_expected = sum(source.wait_ref(c)[0] for c in sh.chroms if items[c][2])
@@ -345,9 +340,8 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
 
     ``gpuDecode`` (this build only; changes no result): True = the BAM goes to the GPU as it is -- BGZF inflate, CRC32 and the
     extraction of POS / FLAG / CIGAR happen there (``spl_bam_decode_device``); files that path does not take (unsorted, CG-tag
-    CIGARs, damaged) are decoded by the host threads all the same.  False = host threads.  None (default) = the GPU when the call
-    uses one device; with several, by the file: on the GPU when its first blocks inflate to less than GPU_DECODE_BELOW times
-    their size (see there)."""
+    CIGARs, damaged) are decoded by the host threads all the same.  False = host threads.  None (default) = the GPU: with several
+    devices every one decodes the stretch of the file that holds the references it then counts (``open_and_decode``)."""
     timings = {}
     t0 = time.perf_counter()
     # The alignment file does not depend on Steps 0-2: it is decoded on native threads while the site table is built here, and

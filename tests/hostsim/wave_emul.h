@@ -178,6 +178,8 @@ inline uint32_t scan_add(uint32_t v, WV_SITE)
 }
 inline uint32_t ld32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 inline uint64_t ld64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+inline void ld128(const uint8_t *p, uint64_t &lo, uint64_t &hi) { memcpy(&lo, p, 8); memcpy(&hi, p + 8, 8); }
+inline void st128(uint8_t *p, uint64_t lo, uint64_t hi) { memcpy(p, &lo, 8); memcpy(p + 8, &hi, 8); }
 inline void st16(uint8_t *p, uint32_t v) { const uint16_t x = (uint16_t)v; memcpy(p, &x, 2); }
 inline void st32(uint8_t *p, uint32_t v) { memcpy(p, &v, 4); }
 inline void st64(uint8_t *p, uint64_t v) { memcpy(p, &v, 8); }

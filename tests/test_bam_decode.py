@@ -189,22 +189,43 @@ def test_a_reservation_nobody_takes_up_ends_with_the_host_decoder(built, tmp_pat
 
 
 def test_where_process_decodes(built, tmp_path, monkeypatch):
-    """open_and_decode: told by the caller, or chosen -- the GPU with one device, by the file's compression with several."""
+    """open_and_decode: on the GPU -- one decoder with one device, a share of the file per device with several -- unless told
+    to use the host's threads."""
     from spliser_amd import process
     names, sets = _random_sets(8, 3_000, 2)
     path = str(tmp_path / "p.bam")
     native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=2, seq_mode=1)
     calls = []
     monkeypatch.setattr(native.BamFile, "decode_on_device_async", lambda self, device=0: calls.append(("device", device)))
-    real_start = native.BamFile.start_host_decode
-    monkeypatch.setattr(native.BamFile, "start_host_decode", lambda self: (calls.append(("host",)), real_start(self))[1])
-    for devices, asked, ratio, want in (((0,), None, 49.0, ("device", 0)), ((3,), None, 3.6, ("device", 3)), ((0, 1), None, 3.6, ("device", 0)),
-                                        ((1, 0), None, 49.0, ("host",)), ((0, 0), None, 49.0, ("device", 0)), ((0,), False, 3.6, None),
-                                        ((0, 1), True, 49.0, ("device", 0)), ((0, 1), None, 0.0, ("host",))):
+    monkeypatch.setattr(native.BamFile, "decode_on_devices_async", lambda self, devices: calls.append(("shares", tuple(devices))))
+    for devices, asked, want in (((0,), None, ("device", 0)), ((3,), None, ("device", 3)), ((0, 1), None, ("shares", (0, 1))),
+                                 ((0, 0), True, ("shares", (0, 0))), ((0,), False, None), ((0, 1), False, None)):
         del calls[:]
-        monkeypatch.setattr(native.BamFile, "compression_ratio", lambda self, r=ratio: r)
         source = process.open_and_decode(path, devices, asked, 2)
-        assert calls == ([want] if want else []), (devices, asked, ratio, calls)
-        if want != ("device", devices[0]):       # (whoever was not handed to the fake device decoder decodes on the host)
+        assert calls == ([want] if want else []), (devices, asked, calls)
+        if want is None:       # (whoever was not handed to the fake device decoders decodes on the host)
             _same(source.reads(names[0]), sets[names[0]])
         source.close()
+
+
+def test_share_plan_cuts_at_reference_boundaries(built, tmp_path):
+    """spl_bam_share_plan: stretches of the file at reference boundaries, every reference in exactly one share, in file order."""
+    import ctypes
+    names, sets = _random_sets(9, 30_000, 5)
+    path = str(tmp_path / "s.bam")
+    native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=2, seq_mode=1)
+    for want in (1, 2, 3, 8):
+        bam = native.BamFile(path, defer=True)
+        n = ctypes.c_int(0)
+        assert native.lib().spl_bam_share_plan(bam._h, ctypes.c_int(want), ctypes.byref(n)) == 0
+        assert 1 <= n.value <= min(want, len(names))
+        seen = []
+        for k in range(n.value):
+            lo, hi = ctypes.c_int(0), ctypes.c_int(0)
+            assert native.lib().spl_bam_share_range(bam._h, ctypes.c_int(k), ctypes.byref(lo), ctypes.byref(hi)) == 0
+            assert lo.value < hi.value
+            seen.extend(range(lo.value, hi.value))
+        assert seen == list(range(len(names) + 1))     # (the last share also takes the records without a reference)
+        if want >= 2:
+            assert n.value >= 2                          # (five references of equal size: there is a cut to be found)
+        bam.close()

@@ -224,8 +224,45 @@ def test_inflate_windows_of_a_few_blocks(ctx, tmp_path, monkeypatch, window):
     path = str(tmp_path / "big.bam")
     samio.write_bam(path, ["c0"], [10 ** 8], [("c0", want)], with_seq=True)
     dev = native.BamFile(path, threads=2, defer=True)
-    took = dev.decode_on_device(ctx)
-    assert not (took and int(window) < 17)  # (a megabyte is 17 blocks: the small windows cannot hold such a record; either way the
-                                            #  result is what counts)
-    _same(dev.reads("c0"), want)
+    dev.decode_on_device(ctx)      # (a megabyte is 17 blocks: the record's bytes travel from window to window in the room in
+    _same(dev.reads("c0"), want)   #  front of each; what counts is the result)
     dev.close()
+
+
+@pytest.mark.parametrize("window", [None, "5"])
+@pytest.mark.parametrize("devices", [(0, 0), (0, 0, 0, 0)])
+def test_process_decodes_in_shares(tmp_path, monkeypatch, devices, window):
+    """Several contexts (here on one GPU): the file is cut at reference boundaries, every context inflates and extracts its own
+    stretch and counts the chromosomes that begin there -- the .SpliSER.tsv is the one the host decoder's reads give."""
+    from spliser_amd import synth
+    from spliser_amd.process import process
+    wl = synth.Workload("arabidopsis", scale=0.02, seed=12)
+    prefix = str(tmp_path / "s")
+    synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions)
+    synth.write_gff(prefix + ".gff", wl.genome)
+    native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=2, seq_mode=1)
+    process(prefix + ".bam", prefix + ".bed", prefix + ".host", annotationFile=prefix + ".gff", log=lambda m: None, gpuDecode=False)
+    if window:
+        monkeypatch.setenv("SPL_INFLATE_WINDOW_BLOCKS", window)
+    seen = {}
+    real = native.BamFile.decode_on_devices_async
+    monkeypatch.setattr(native.BamFile, "decode_on_devices_async", lambda self, devs: seen.setdefault("plan", real(self, devs)))
+    tm = process(prefix + ".bam", prefix + ".bed", prefix + ".dev", annotationFile=prefix + ".gff", log=lambda m: None, devices=devices)
+    assert tm["bam_decode"] == "device"
+    plan = seen["plan"]
+    assert len(plan) == min(len(devices), len(wl.genome.chrom_names)) and sorted(c for _, names in plan for c in names) == sorted(wl.genome.chrom_names)
+    assert open(prefix + ".dev.SpliSER.tsv").read() == open(prefix + ".host.SpliSER.tsv").read()
+
+
+def test_reads_of_every_share_come_back_to_the_host(tmp_path):
+    """A decode in shares keeps every share's reads on its device; a reader on the host (``BamFile.reads``) gets copies from all
+    of them, each reference from the share that holds it."""
+    names, sets = _random_sets(41, 20_000, 4)
+    path = str(tmp_path / "u.bam")
+    native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=2, seq_mode=1)
+    bam = native.BamFile(path, defer=True)
+    plan = bam.decode_on_devices_async([0, 0, 0])
+    assert bam.join_decoders() is True and len(plan) == 3
+    for c in names:
+        _same(bam.reads(c), sets[c])
+    bam.close()

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 cd $R
 python tools/e2e_profile.py human --seq-mode 1 --scale $SCALE --auto-decode --runs 1 > gpurun_out/${TAG}_warm.log 2>&1
 F=/tmp/wl_files/human_s${SCALE}_q1.bam
-for V in FULL NO_ROUNDS NO_WRITE; do
+for V in FULL NO_WRITE; do
   X=""; [ $V = NO_ROUNDS ] && X="-DSPL_EXP_NO_ROUNDS"; [ $V = NO_WRITE ] && X="-DSPL_EXP_NO_ROUNDS -DSPL_EXP_NO_WRITE"
   (cd spliser_amd/csrc && touch spl_inflate.hip && make EXTRA="$X" > /dev/null 2>&1)
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_$V -- python3 $R/tools/gpu_decode_steps.py $F > $R/gpurun_out/${TAG}_$V.log 2>&1)
