@@ -27,8 +27,9 @@ struct spl_zblock {
 // next block; behind the last one the caller pads), and the inflated stream writable for 16 bytes past its end: the wave kernel
 // moves 16 bytes at a time.
 #define SPL_Z_IMAGE_PAD 64u
-// The decoding kernel leaves every block's matches to the copying kernel as a list of their places in the block (no match is
-// shorter than three bytes: a block has at most 65536 / 3 of them), one list of this many half-words per block.
+// The decoding kernel leaves every block's matches to the copying kernel as a list of (place in the block | distance - 1 << 16 |
+// (length - 3) << 32), eight bytes each, in output order (no match is shorter than three bytes: a block has at most 65536 / 3
+// of them), one list of this many entries per block.
 #define SPL_Z_MATCH_STRIDE_MAX 21848u
 // ... or fewer (the caller's choice: memory): a block with more matches than its list holds gets SPL_Z_TOO_MANY from the
 // decoding kernel and is then done by round 2's one-lane-per-block decoder, which needs no list.

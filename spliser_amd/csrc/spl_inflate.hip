@@ -10,7 +10,7 @@
 // The Huffman decoding, one BGZF block per WAVE, and the copies it leaves to be made, one block per LANE (spl_inflate_wave.h has
 // the method, and is what the host tests run through the wave emulator).
 __global__ __launch_bounds__(64) void spl_inflate_decode_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status,
-                                                                uint16_t *midx_all, uint32_t stride, uint32_t *n_match)
+                                                                uint64_t *midx_all, uint32_t stride, uint32_t *n_match)
 {
     __shared__ splz::Shared sh;
     const uint32_t b = blockIdx.x;
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(64) void spl_inflate_decode_kernel(const uint8_t *i
     if (threadIdx.x == 0) { status[b] = st; n_match[b] = st == SPL_Z_OK ? n : 0u; }
 }
 
-__global__ __launch_bounds__(64) void spl_inflate_copy_kernel(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, const uint16_t *midx_all, uint32_t stride, const uint32_t *n_match)
+__global__ __launch_bounds__(64) void spl_inflate_copy_kernel(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, const uint64_t *midx_all, uint32_t stride, const uint32_t *n_match)
 {
     const uint32_t b = blockIdx.x * 64u + threadIdx.x;
     if (b >= n_blocks) return;
@@ -673,7 +673,7 @@ static uint32_t stride_of(uint32_t match_stride)
     if (st > SPL_Z_MATCH_STRIDE_MAX) st = SPL_Z_MATCH_STRIDE_MAX;
     return (st + 7u) & ~7u;
 }
-extern "C" size_t spl_dev_inflate_work_bytes(uint32_t n_blocks, uint32_t match_stride) { return 256 + ((size_t)n_blocks * 4 + 255) / 256 * 256 + (size_t)n_blocks * stride_of(match_stride) * 2; }
+extern "C" size_t spl_dev_inflate_work_bytes(uint32_t n_blocks, uint32_t match_stride) { return 256 + ((size_t)n_blocks * 4 + 255) / 256 * 256 + (size_t)n_blocks * stride_of(match_stride) * 8; }
 
 extern "C" int spl_dev_launch_inflate_decode(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t match_stride, void *stream)
 {
@@ -684,7 +684,7 @@ extern "C" int spl_dev_launch_inflate_decode(const uint8_t *image, const spl_zbl
         return (int)hipGetLastError();
     }
     uint32_t *const n_match = (uint32_t *)work;
-    uint16_t *const midx = (uint16_t *)((char *)work + ((size_t)n_blocks * 4 + 255) / 256 * 256);
+    uint64_t *const midx = (uint64_t *)((char *)work + ((size_t)n_blocks * 4 + 255) / 256 * 256);
     hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status, midx, stride_of(match_stride), n_match);
     // blocks with more matches than their list holds: by the decoder that needs none
     hipLaunchKernelGGL(spl_inflate_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status, SPL_Z_TOO_MANY);
@@ -696,7 +696,7 @@ extern "C" int spl_dev_launch_inflate_copy(const spl_zblock *blocks, uint32_t n_
     static const bool per_lane = getenv("SPL_INFLATE_PER_LANE") != nullptr;
     if (n_blocks == 0 || per_lane || !work) return 0;
     const uint32_t *const n_match = (const uint32_t *)work;
-    const uint16_t *const midx = (const uint16_t *)((const char *)work + ((size_t)n_blocks * 4 + 255) / 256 * 256);
+    const uint64_t *const midx = (const uint64_t *)((const char *)work + ((size_t)n_blocks * 4 + 255) / 256 * 256);
     hipLaunchKernelGGL(spl_inflate_copy_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, blocks, n_blocks, out, midx, stride_of(match_stride), n_match);
     return (int)hipGetLastError();
 }

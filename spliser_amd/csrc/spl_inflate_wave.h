@@ -2,8 +2,7 @@
 // written against the primitives of spl_wave.h so that the same source runs on the host under tests/hostsim/wave_emul.h):
 //
 //   decode_block   one BGZF block per WAVE: the Huffman decoding.  Literals go to their places in the inflated stream; a match
-//                  (length, distance) is left as three bytes at ITS place -- distance - 1 | (length - 3) << 15, it has room for
-//                  them: no match is shorter -- and its place is appended to the block's list of matches.
+//                  is appended to the block's list of matches: where it goes, distance, length, eight bytes.
 //   copy_block     one BGZF block per LANE: the list's matches made one after the other, each a copy of bytes that are there.
 //
 // Why the split.  Round 2 gave every lane a block of its own for everything: a lane's Huffman tables were 356 bytes of LDS and
@@ -36,19 +35,19 @@ constexpr uint32_t LUT_L = 852, LUT_D = 592; // entries: root table + the most s
 constexpr uint32_t SUB_BITS = 256;           // bits of DEFLATE data per lane and tile
 constexpr uint32_t TILE_WORDS = 64u * SUB_BITS / 32u;
 constexpr uint32_t TILE_PAD = 16;            // words behind the tile: a symbol that begins in the last subsequence ends there
-constexpr uint32_t QCAP = 704;               // matches per tile (a tile with more is cut short)
+constexpr uint32_t QCAP = 640;               // matches per tile (a tile with more is cut short)
 constexpr uint32_t FL_OK = 0, FL_EOB = 1, FL_ERR = 2;
 constexpr uint32_t SYM_EOB = 256, SYM_MATCH = 257, SYM_BAD = 0xffffffffu;
 
-// One wave's shared memory: 6408 bytes.
+// One wave's shared memory: 10120 bytes (16 waves on a CU's 160 KB).
 struct Shared {
     uint16_t lut_l[LUT_L];                // literal/length code.  Entry: symbol << 4 | bits; 0x8000 | offset << 4 | sub-table bits; 0 = no such code
     uint16_t lut_d[LUT_D];                // distance code
     uint32_t tile[TILE_WORDS + TILE_PAD]; // the compressed bytes being worked on (while tables are built: work space)
-    uint16_t q_dest[QCAP];                // where the tile's matches go, in output order (while a header is read: code lengths, the code-length code's table)
+    uint64_t q[QCAP];                     // the tile's matches in output order (while a header is read: code lengths, the code-length code's table)
 };
 static_assert(SUB_BITS == 256u, "the tile is staged thirty-two bytes a lane");
-static_assert(QCAP * 2u >= 352u + 256u, "code lengths and the code-length code's table lie in q_dest while a header is read");
+static_assert(QCAP * 8u >= 352u + 256u, "code lengths and the code-length code's table lie in q while a header is read");
 
 // the order in which a dynamic header lists the lengths of the code-length code (RFC 1951, 3.2.7), five bits a place
 constexpr uint64_t pack5(const int *v, int n) { uint64_t r = 0; for (int i = 0; i < n; ++i) r |= (uint64_t)v[i] << (5 * i); return r; }
@@ -231,7 +230,7 @@ WV_DEV void store_n(uint8_t *p, uint64_t lo, uint64_t hi, uint32_t n)
 }
 
 // The block `zb` of the file image, by one wave.  midx: room for `stride` places of matches; n_match_out: how many were written.  Returns the block's status (every lane the same).
-WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock &zb, uint8_t *out_all, uint16_t *midx, uint32_t stride, uint32_t &n_match_out)
+WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock &zb, uint8_t *out_all, uint64_t *midx, uint32_t stride, uint32_t &n_match_out)
 {
     n_match_out = 0;
     uint32_t n_match = 0;
@@ -241,7 +240,7 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
     const uint32_t in_len = zb.in_len, out_len = zb.out_len, end_bits = in_len * 8u;
     if (out_len == 0u) return SPL_Z_OK; // (the EOF marker and other empty blocks: nothing to decode into)
     if (out_len > 65536u || in_len > 65536u) return SPL_Z_OVERRUN; // (not a BGZF block)
-    uint8_t *const lens = (uint8_t *)sh.q_dest; // 352 code lengths while a header is read
+    uint8_t *const lens = (uint8_t *)sh.q; // 352 code lengths while a header is read
     uint32_t *const work = sh.tile;
     uint32_t pos = 0, at = 0;
     for (uint32_t last = 0; !last;) {
@@ -284,7 +283,7 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             if (l < n_code) lens[clen_order(l)] = (uint8_t)(gbits(in, pos + 3u * l) & 7u);
             pos += 3u * n_code;
             wv::sync();
-            uint16_t *const lut_c = sh.q_dest + 176;
+            uint16_t *const lut_c = (uint16_t *)sh.q + 176;
             if (!build_lut(lens, 19u, ROOT_C, lut_c, 1u << ROOT_C, work)) return SPL_Z_BAD_LENGTHS;
             // the lengths of the two codes, a run-length code of its own: one after the other (every lane does the same)
             const uint32_t n_all = n_lit + n_dist;
@@ -372,7 +371,7 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             const uint32_t total = wv::readlane(cum_o, n_valid - 1u), n_q = wv::readlane(cum_m, n_valid - 1u);
             if (at + total > out_len) return SPL_Z_OVERRUN;
             if (n_match + n_q > stride) return SPL_Z_TOO_MANY;
-            // ---- the writing pass: literals to their places, matches as three bytes at theirs and their places to the list
+            // ---- the writing pass: literals to their places, matches to the list
             bool bad_dist = false;
 #ifndef SPL_EXP_NO_WRITE
             if (valid) {
@@ -383,16 +382,14 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
                     if (s < 256u) { out[wr++] = (uint8_t)s; continue; }
                     if (s != SYM_MATCH) break; // (the end of the block; errors were seen by the counting pass)
                     if (dist > wr) { bad_dist = true; break; }
-                    const uint32_t tok = (dist - 1u) | (len - 3u) << 15;
-                    out[wr] = (uint8_t)tok; out[wr + 1u] = (uint8_t)(tok >> 8); out[wr + 2u] = (uint8_t)(tok >> 16);
-                    sh.q_dest[qi++] = (uint16_t)wr;
+                    sh.q[qi++] = (uint64_t)(wr | (dist - 1u) << 16) | (uint64_t)(len - 3u) << 32;
                     wr += len;
                 }
             }
 #endif
             if (wv::any(bad_dist)) return SPL_Z_BAD_DISTANCE;
             wv::sync();
-            for (uint32_t t = l; t < n_q; t += 64u) midx[n_match + t] = sh.q_dest[t];
+            for (uint32_t t = l; t < n_q; t += 64u) midx[n_match + t] = sh.q[t];
             n_match += n_q;
             wv::sync();
             at += total;
@@ -405,26 +402,25 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
 }
 
 // The matches of a block made in the order of its list: every one a copy of bytes that are there by then (literals, and the
-// matches before it).  One lane's work; 64 blocks to a wave, 64 different cache lines to every memory instruction -- what this
-// kernel costs is the NUMBER of its memory requests, so it makes few: the places of eight matches in one 16-byte load, a
-// match's three bytes asked for a match ahead, a piece of up to 16 bytes in one load and one store.
-WV_DEV void copy_block(uint8_t *out, const uint16_t *midx, uint32_t n)
+// matches before it).  One lane's work; 64 blocks to a wave, 64 different cache lines to every memory instruction: two matches'
+// entries in one 16-byte load, a piece of up to 16 bytes in one load and at most two stores (the second overlaps the first: a
+// piece of 11 bytes is bytes 0..7 and bytes 3..10).  (Asking for the next piece's bytes before this piece is stored -- two loads
+// on their way -- was built and is slower, 22.5 ms against 19.6 per window of 49 152 blocks.)
+WV_DEV void copy_block(uint8_t *out, const uint64_t *midx, uint32_t n)
 {
     if (n == 0u) return;
-    uint64_t w_lo, w_hi; // the places of matches i .. (eight to a load; midx + 8k is 16-byte aligned)
-    wv::ld128((const uint8_t *)midx, w_lo, w_hi);
+    uint64_t e0, e1; // entries i (and i + 1 when i is even): two to a load; midx + 2k is 16-byte aligned
+    wv::ld128((const uint8_t *)midx, e0, e1);
     uint32_t i = 0, d = 0, left = 0, dist = 1;
-    uint32_t tok = wv::ld32(out + (uint32_t)(w_lo & 0xffffu)) & 0xffffffu; // of match i
     for (;;) {
         if (left == 0u) {
             if (i >= n) break;
-            d = (uint32_t)(w_lo & 0xffffu);
-            dist = (tok & 0x7fffu) + 1u;
-            left = (tok >> 15) + 3u;
+            d = (uint32_t)e0 & 0xffffu;
+            dist = ((uint32_t)e0 >> 16) + 1u;
+            left = (uint32_t)(e0 >> 32) + 3u;
             ++i;
-            if ((i & 7u) == 0u) { if (i < n) wv::ld128((const uint8_t *)(midx + i), w_lo, w_hi); }
-            else { w_lo = w_lo >> 16 | w_hi << 48; w_hi >>= 16; }
-            if (i < n) tok = wv::ld32(out + (uint32_t)(w_lo & 0xffffu)) & 0xffffffu; // (nobody writes there before that match is made)
+            if (i & 1u) e0 = e1;
+            else if (i < n) wv::ld128((const uint8_t *)(midx + i), e0, e1);
         }
         uint32_t k = left < 16u ? left : 16u;
         if (dist < 8u) k = k < 8u ? k : 8u;      // (made from the period, below)
@@ -437,7 +433,19 @@ WV_DEV void copy_block(uint8_t *out, const uint16_t *midx, uint32_t n)
             if (dist < 4u) lo |= lo << (16u * dist);
             if (dist < 2u) lo |= lo << 32;
         }
-        store_n(out + d, lo, hi, k);
+        uint8_t *const p = out + d;
+        if (k == 16u) wv::st128(p, lo, hi);
+        else if (k >= 8u) { // bytes 0..7, then the last eight (they overlap when k < 16)
+            wv::st64(p, lo);
+            const uint32_t sh8 = 8u * (k - 8u);
+            if (k > 8u) wv::st64(p + k - 8u, sh8 ? lo >> sh8 | hi << (64u - sh8) : lo);
+        } else if (k >= 4u) {
+            wv::st32(p, (uint32_t)lo);
+            if (k > 4u) wv::st32(p + k - 4u, (uint32_t)(lo >> (8u * (k - 4u))));
+        } else {
+            if (k & 2u) wv::st16(p, (uint32_t)lo);
+            if (k & 1u) p[k - 1u] = (uint8_t)(lo >> (8u * (k - 1u)));
+        }
         d += k;
         left -= k;
     }

@@ -14,11 +14,11 @@ extern "C" int emul_inflate_blocks(const uint8_t *image, const spl_zblock *block
     static splz::Shared sh;
     for (uint32_t b = 0; b < n; ++b) {
         memset(&sh, 0xEE, sizeof sh); // (nothing may depend on what the wave before left)
-        static std::vector<uint16_t> midx(SPL_Z_MATCH_STRIDE);
+        static std::vector<uint64_t> midx(SPL_Z_MATCH_STRIDE_MAX + 8);
         uint32_t n_match = 0;
         const bool ok = wv::run_wave([&]() {
             uint32_t n = 0;
-            const uint32_t st = splz::decode_block(sh, image, blocks[b], out, midx.data(), n);
+            const uint32_t st = splz::decode_block(sh, image, blocks[b], out, midx.data(), SPL_Z_MATCH_STRIDE_MAX, n);
             if (wv::lane() == 0) { status[b] = st; n_match = st == SPL_Z_OK ? n : 0u; }
         });
         if (!ok) return -1 - (int)b;

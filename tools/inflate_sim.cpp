@@ -134,7 +134,7 @@ static Sym decode_one(const Bits &b, const Lut &L, const Lut &D, uint64_t &pos, 
 
 struct Stats {
     uint64_t blocks = 0, dblocks = 0, tiles = 0, passes = 0, count_steps = 0, turns = 0, ideal_turns = 0, stalls = 0, lane_turns = 0, symbols = 0, literals = 0,
-             matches = 0, match_bytes = 0, out_bytes = 0, in_bytes = 0, header_syms = 0, lanes_used = 0, searches = 0, max_passes = 0, short_dist = 0, stored = 0, rounds = 0, copy_rounds = 0, coop = 0, coop_steps = 0, active = 0, max_queue = 0, self_resolved = 0, self_pieces = 0, merged = 0, unmerged = 0;
+             matches = 0, match_bytes = 0, out_bytes = 0, in_bytes = 0, header_syms = 0, lanes_used = 0, searches = 0, max_passes = 0, short_dist = 0, stored = 0, rounds = 0, copy_rounds = 0, coop = 0, coop_steps = 0, active = 0, max_queue = 0, self_resolved = 0, self_pieces = 0, merged = 0, unmerged = 0, fwd_iters = 0;
     uint64_t pass_hist[66] = {0};
 };
 
@@ -143,6 +143,7 @@ static int coop_min = 16;
 static int exact_dep = 0;
 static int WIN = 64;
 static int self_resolve = 0;
+static int FWD = 0; // forward a match's source through the matches it copies from, before the copies are made
 static int MERGE_K = 0; // 0 = plain re-decode; else two-pointer merge with the lane's previous chain for up to K steps
 static int MERGE_FROM = 2; // first pass (1-based) that uses it
 static bool wave_inflate(const uint8_t *data, size_t n, const std::vector<uint8_t> &want, Stats &st, int piece_max)
@@ -325,7 +326,7 @@ static bool wave_inflate(const uint8_t *data, size_t n, const std::vector<uint8_
             // its matches; then the matches of the tile are made in output order by a window of 64 of them (one per lane, token k
             // in lane k % 64): a match may be made when its source lies below the first byte that is still to be written (the
             // destination of the oldest match not made yet), the oldest one always; long ones by the whole wave together.
-            struct Tok { uint64_t dest; uint32_t len, dist; };
+            struct Tok { uint64_t dest; uint32_t len, dist; int64_t src; bool fin; };
             std::vector<Tok> q;
             uint32_t ideal = 0;
             for (int l = 0; l < n_valid; ++l) {
@@ -347,7 +348,7 @@ static bool wave_inflate(const uint8_t *data, size_t n, const std::vector<uint8_
                         w += y.len;
                         continue;
                     }
-                    q.push_back(Tok{w, y.len, y.dist});
+                    q.push_back(Tok{w, y.len, y.dist, (int64_t)w - (int64_t)y.dist, false});
                     w += y.len;
                     taint_end = w;
                 }
@@ -359,6 +360,32 @@ static bool wave_inflate(const uint8_t *data, size_t n, const std::vector<uint8_
             {
                 const size_t nq = q.size();
                 std::vector<uint8_t> written_before;
+                if (FWD) {
+                    // a match whose source lies inside ONE earlier match of the tile that does not overlap itself copies from that
+                    // match's source instead; all matches at once, until nothing moves
+                    int it = 0;
+                    for (;; ++it) {
+                        bool moved = false;
+                        std::vector<int64_t> ns(nq);
+                        for (size_t t = 0; t < nq; ++t) {
+                            ns[t] = q[t].src;
+                            if (q[t].fin || q[t].dist < q[t].len) continue; // (periodic copies keep their source)
+                            const int64_t s0 = q[t].src, s1 = s0 + q[t].len;
+                            if (s1 <= (int64_t)reg[0]) { q[t].fin = true; continue; }
+                            // the earlier match that holds s0
+                            size_t lo = 0, hi = t;
+                            while (lo < hi) { const size_t mid = (lo + hi) / 2; if ((int64_t)(q[mid].dest + q[mid].len) <= s0) lo = mid + 1; else hi = mid; }
+                            if (lo < t && (int64_t)q[lo].dest <= s0 && s1 <= (int64_t)(q[lo].dest + q[lo].len) && q[lo].dist >= q[lo].len) {
+                                ns[t] = q[lo].src + (s0 - (int64_t)q[lo].dest);
+                                moved = true;
+                            } else q[t].fin = true;
+                        }
+                        for (size_t t = 0; t < nq; ++t) q[t].src = ns[t];
+                        if (!moved) break;
+                    }
+                    st.fwd_iters += it + 1;
+                    for (size_t t = 0; t < nq; ++t) q[t].dist = (uint32_t)((int64_t)q[t].dest - q[t].src);
+                }
                 std::vector<size_t> tok(WIN);
                 std::vector<uint32_t> left(WIN);
                 std::vector<char> pend(WIN);
@@ -430,6 +457,7 @@ int main(int argc, char **argv)
     if (getenv("WIN")) WIN = atoi(getenv("WIN"));
     if (getenv("SELF")) self_resolve = atoi(getenv("SELF"));
     if (getenv("MERGE_K")) MERGE_K = atoi(getenv("MERGE_K"));
+    if (getenv("FWD")) FWD = atoi(getenv("FWD"));
     if (getenv("MERGE_FROM")) MERGE_FROM = atoi(getenv("MERGE_FROM"));
     FILE *f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 1; }
@@ -476,6 +504,7 @@ int main(int argc, char **argv)
            st.copy_rounds ? (double)st.active / st.copy_rounds : 0.0, (double)st.coop / st.tiles, st.coop ? (double)st.coop_steps / st.coop : 0.0);
     printf("self-resolved in the decode pass: %.1f %% of matches (%.2f pieces each)\n", st.matches ? 100.0 * st.self_resolved / st.matches : 0.0, st.self_resolved ? (double)st.self_pieces / st.self_resolved : 0.0);
     printf("wave-steps per block: search %.0f + decode-and-store %.0f + copy rounds %.0f\n", (double)st.count_steps / st.blocks, (double)st.turns / st.blocks, (double)st.rounds / st.blocks);
+    printf("source forwarding: %.2f iterations per tile\n", (double)st.fwd_iters / st.tiles);
     printf("recounts that merged with the lane's earlier chain: %llu, that did not: %llu\n", (unsigned long long)st.merged, (unsigned long long)st.unmerged);
     printf("passes histogram:");
     for (int i = 1; i < 66; ++i) if (st.pass_hist[i]) printf(" %d:%llu", i, (unsigned long long)st.pass_hist[i]);
