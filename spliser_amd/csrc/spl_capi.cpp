@@ -267,6 +267,10 @@ struct spl_dreads {
         int64_t n_reads = 0, n_ops = 0;
         int32_t shift = 0;
         std::vector<splpack::ChunkDesc> chunks;
+        // a segment laid out by the device packer: its chunk descriptors are still on the device (n_dev of them, then two words
+        // of totals) until the read set is finished -- nothing waits for the packer's kernels before that
+        splpack::ChunkDesc *d_descs = nullptr;
+        size_t n_dev = 0;
     };
     std::vector<Segment> segs;
     int64_t n_reads = 0, n_cigar = 0;
@@ -1011,6 +1015,8 @@ static int fetch_device_reads(void *h, int32_t **pos_out, uint16_t **flag_out, u
 }
 
 // One more segment of a read set, packed ON THE DEVICE from reads that are there already (add_segment is the host's version).
+// Three launches on the copy stream and no wait: room for the records is taken for the worst case (24 bytes a read: 288 GB are
+// there to be used), the chunk descriptors come to the host when the read set is finished.
 static int add_segment_device(spl_ctx *c, spl_dreads *d, const DeviceReads &dev, int64_t first, int64_t n_reads, int64_t n_ops, int32_t shift, int64_t max_end)
 {
     if (d->finished) return spl_set_error(SPL_ERR_ARG, "the read set is finished: no more segments");
@@ -1019,44 +1025,32 @@ static int add_segment_device(spl_ctx *c, spl_dreads *d, const DeviceReads &dev,
     if (max_end >= 0 && max_end + (int64_t)shift > (int64_t)SPL_COORD_MAX)
         return spl_set_error(SPL_ERR_RANGE, "a read ends beyond coordinate %d once its segment is moved by %d: split the shard (spliser_amd/shard.py)",
                              SPL_COORD_MAX, shift);
+    if (n_ops > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops in one segment: use more shards");
     int rc = ensure_stage(c);
     if (rc) return rc;
     const uint32_t chunk = 1u << d->chunk_shift;
     const size_t n_chunks = (size_t)((n_reads + chunk - 1) / chunk);
     if ((uint64_t)d->n_chunks + n_chunks > (1ull << (32 - d->chunk_shift))) return spl_set_error(SPL_ERR_ARG, "too many reads in one read set: use more shards");
     const spl_devreads src{(const int32_t *)dev.pos, (const uint16_t *)dev.flag, (const uint32_t *)dev.cig_off, (const uint32_t *)dev.cigar};
-    splpack::ChunkDesc *d_descs = nullptr;
-    HIP_TRY(devmem::get((void **)&d_descs, sizeof(splpack::ChunkDesc) * n_chunks, 'd'));
-    std::vector<splpack::ChunkDesc> descs(n_chunks);
-    hipError_t q = (hipError_t)spl_dev_launch_pack_count(&src, first, n_reads, chunk, d_descs, c->copy);
-    if (q == hipSuccess) q = hipMemcpyAsync(descs.data(), d_descs, sizeof(splpack::ChunkDesc) * n_chunks, hipMemcpyDeviceToHost, c->copy);
-    if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
-    if (q != hipSuccess) { devmem::put(d_descs); return spl_set_error(SPL_ERR_HIP, "device packer (sizes): %s", hipGetErrorString(q)); }
-    uint64_t rec = 0, wide = 0; // sizes -> offsets, as splpack::plan does
-    for (splpack::ChunkDesc &cd : descs) {
-        const uint64_t bytes = cd.rec_off, ops = cd.wide_off;
-        cd.rec_off = rec;
-        cd.wide_off = wide;
-        rec += bytes;
-        wide += ops;
-    }
-    if (wide > 0xfffffff0ull) { devmem::put(d_descs); return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops of wide reads in one segment: use more shards"); }
     d->segs.emplace_back();
     spl_dreads::Segment &seg = d->segs.back();
-    seg.rec_bytes = rec; seg.n_wide = wide; seg.n_reads = n_reads; seg.n_ops = n_ops; seg.shift = shift;
-    const size_t rec_al = align_up((size_t)rec);
-    const size_t slab_bytes = rec_al + 4 * (size_t)wide + 256;
-    q = devmem::get((void **)&seg.slab, slab_bytes, 'R');
-    if (q == hipSuccess) q = hipMemcpyAsync(d_descs, descs.data(), sizeof(splpack::ChunkDesc) * n_chunks, hipMemcpyHostToDevice, c->copy);
-    if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack_emit(&src, first, n_reads, chunk, d_descs, seg.slab, seg.slab + rec_al, c->copy);
-    if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
-    devmem::put(d_descs);
+    const size_t rec_al = align_up((size_t)n_reads * SPL_REC_OTHER + n_chunks * 32);
+    const size_t slab_bytes = rec_al + 4 * (size_t)n_ops + 256;
+    hipError_t q = devmem::get((void **)&seg.d_descs, sizeof(splpack::ChunkDesc) * n_chunks + 16, 'd');
+    if (q == hipSuccess) q = devmem::get((void **)&seg.slab, slab_bytes, 'R');
+    if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack_count(&src, first, n_reads, chunk, seg.d_descs, c->copy);
+    if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack_offsets(seg.d_descs, (uint32_t)n_chunks, seg.d_descs + n_chunks, c->copy);
+    if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack_emit(&src, first, n_reads, chunk, seg.d_descs, seg.slab, seg.slab + rec_al, c->copy);
     if (q != hipSuccess) {
+        (void)hipStreamSynchronize(c->copy);
+        devmem::put(seg.d_descs);
         devmem::put(seg.slab);
         d->segs.pop_back();
         return spl_set_error(SPL_ERR_HIP, "device packer: %s", hipGetErrorString(q));
     }
-    seg.chunks.swap(descs);
+    seg.n_dev = n_chunks;
+    seg.rec_bytes = rec_al; seg.n_wide = (uint64_t)n_ops; // (upper bounds: what finish_reads makes the wide ops' address from)
+    seg.n_reads = n_reads; seg.n_ops = n_ops; seg.shift = shift;
     d->n_reads += n_reads;
     d->n_cigar += n_ops;
     d->n_chunks += (uint32_t)n_chunks;
@@ -1506,6 +1500,21 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
         c->tm_bytes = c->tm_pieces = 0;
     }
     if (d->n_cigar > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops in one read set: use more shards");
+    { // the chunk descriptors of segments the device packer laid out: to the host now (the packer's kernels are done by then)
+        hipError_t q = hipSuccess;
+        bool any = false;
+        for (spl_dreads::Segment &seg : d->segs)
+            if (seg.d_descs) {
+                seg.chunks.resize(seg.n_dev);
+                if (q == hipSuccess) q = hipMemcpyAsync(seg.chunks.data(), seg.d_descs, sizeof(splpack::ChunkDesc) * seg.n_dev, hipMemcpyDeviceToHost, c->copy);
+                any = true;
+            }
+        if (any) {
+            if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
+            for (spl_dreads::Segment &seg : d->segs) { devmem::put(seg.d_descs); seg.d_descs = nullptr; }
+            if (q != hipSuccess) return spl_set_error(SPL_ERR_HIP, "device packer: %s", hipGetErrorString(q));
+        }
+    }
     const size_t n = d->n_chunks;
     std::vector<spl_chunk_meta> meta(n);
     std::vector<uint32_t> cost(n), order(n);
@@ -1677,7 +1686,7 @@ extern "C" void spl_reads_free(spl_ctx *c, spl_dreads *d)
     if (c && c->copy) (void)hipStreamSynchronize(c->copy);
     if (c && c->tail) (void)hipStreamSynchronize(c->tail); // (a tail may still be reading these buffers; hipFree itself waits
     if (c && c->stream) (void)hipStreamSynchronize(c->stream); //  for the device, this makes it independent of that)
-    for (spl_dreads::Segment &seg : d->segs) devmem::put(seg.slab);
+    for (spl_dreads::Segment &seg : d->segs) { devmem::put(seg.slab); devmem::put(seg.d_descs); }
     devmem::put(d->ctl);
     delete d;
 }

@@ -11,4 +11,7 @@ P() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/
 P insts SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT
 P cycles SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS
 P cache TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum
-cd $R && python tools/pmc_summary.py gpurun_out/pmc_${TAG}_insts gpurun_out/pmc_${TAG}_cycles gpurun_out/pmc_${TAG}_cache | grep -i "inflate\|crc\|bam_" | tee gpurun_out/pmc_${TAG}_summary.txt
+P fetch FETCH_SIZE
+P write WRITE_SIZE
+P ta TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE
+cd $R && python tools/pmc_summary.py gpurun_out/pmc_${TAG}_insts gpurun_out/pmc_${TAG}_cycles gpurun_out/pmc_${TAG}_cache gpurun_out/pmc_${TAG}_fetch gpurun_out/pmc_${TAG}_write gpurun_out/pmc_${TAG}_ta | grep -i "inflate\|crc\|bam_" | tee gpurun_out/pmc_${TAG}_summary.txt
