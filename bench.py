@@ -11,14 +11,18 @@ Default workload = BASELINE.json configs[2], the largest single-GPU configuratio
 splice sites, HBM-roofline run"), synthesised from a seed (spliser_amd/synth.py) because there is no network and the reference
 ships no data.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards with no exchange step.  ``--scaling weak``
-(default): every rank processes its own sample of the same shape (seed + rank).  ``--scaling strong``: ONE sample, its
-chromosomes dealt to the ranks by read count (the partition of `process --gpus N`); the line then reports the imbalance.  The
-only collectives are the timing barrier and the reductions of the report.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards with no exchange step.  ``--scaling strong`` (the
+default for N > 1): ONE sample, its chromosomes dealt to the ranks by read count; the line then reports the imbalance.
+``--scaling weak`` (N = 1, or asked for): every rank processes its own sample of the same shape (seed + rank).  The only
+collectives are the timing barrier and the reductions of the report.
 
-Besides the resident-step figure the line carries (rank 0, N = 1): the parity of the last timed step against the oracle on the
-whole workload; a CPU baseline (the oracle on 1 thread and on all cores of this host); and ``e2e`` -- BAM file -> native
-decode -> host packing -> H2D -> kernels -> .SpliSER.tsv through spliser_amd.process, with stage times.
+Besides the resident-step figure the line carries (rank 0): the parity of the last timed step against the oracle on the whole
+workload; a CPU baseline (the oracle on 1 thread and on all cores of this host; N = 1); and ``e2e`` -- the PRODUCT: BAM file ->
+decode on the GPU(s) -> reads laid out -> kernels -> .SpliSER.tsv through spliser_amd.process, wall clock of the whole call, on
+a file of constant SEQ / QUAL bytes and on one that deflates like a real library's, each with a table of the kernels' times from
+the library's own events, the whole file text checked against the oracle, and the same work on the host's cores beside it
+(``cpu_e2e``).  With N > 1 the legs call process(devices=range(N)): every GPU decodes and counts its own stretch of ONE file --
+strong scaling of the product -- next to the same call on one GPU.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
 """
@@ -101,6 +105,18 @@ def kernel_src_sha16():
     return h.hexdigest()[:16]
 
 
+INGEST_SOURCES = ("spl_inflate.hip", "spl_inflate_wave.h", "spl_wave.h", "spl_inflate.h", "spl_devpack.hip", "spl_devpack.h")
+
+
+def ingest_src_sha16():
+    """The sources of the device decode and the device packer (what the end-to-end legs run besides the counting kernels)."""
+    h = hashlib.sha256()
+    for name in INGEST_SOURCES:
+        with open(os.path.join(ROOT, "spliser_amd", "csrc", name), "rb") as fh:
+            h.update(strip_source(fh.read().decode("utf-8", "replace")).encode("utf-8"))
+    return h.hexdigest()[:16]
+
+
 def strip_source(text):
     """C / C++ source without comments, every run of white space one blank (string literals of these files hold no '//')."""
     import re
@@ -158,73 +174,103 @@ def run_oracle(items, scode, cryptic, threads):
     return dt, res
 
 
-def e2e_leg(name, wl, table_items, stranded, cryptic, seq_mode, reps, want_rows, gpu_decode=None):
+def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode=None, devices=(0,), cpu_e2e=False, compare_devices=None):
     """BAM + BED + GFF files of one workload -> spliser_amd.process.process (the CLI's function), timed.  The .SpliSER.tsv is
-    compared, row by row, with the counts the oracle gave for the same sample."""
-    from spliser_amd import native, process, synth
+    compared, byte for byte, with the text the oracle's numbers give for the same sample (``want``: run_oracle's results)."""
+    import statistics
+    from spliser_amd import native, process, synth, tsv
     tmp = tempfile.mkdtemp(prefix="spliser_e2e_")
     out = {"workload": name}
+    noop = lambda m: None   # noqa: E731
     try:
         prefix = os.path.join(tmp, name)
         t = time.perf_counter()
-        synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions)
+        synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions, stranded=bool(stranded))
         synth.write_gff(prefix + ".gff", wl.genome)
         native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=0,
                          seq_mode=seq_mode)
         out["files_written_s"] = time.perf_counter() - t
-        out["bam_decode_asked"] = {None: "default (one device: on the GPU)", False: "host threads (process --hostDecode)",
+        out["devices"] = list(devices)
+        out["bam_decode_asked"] = {None: "default (on the GPU: every device its own stretch of the file)", False: "host threads (process --hostDecode)",
                                    True: "GPU (process --gpuDecode)"}[gpu_decode]
         out["bam_bytes"] = os.path.getsize(prefix + ".bam")
         out["bam_seq_qual"] = ("constant bytes (deflate to almost nothing)" if seq_mode == 0 else
                                "pseudo-random bases, binned qualities in runs (deflate like a real library)")
         n_reads = sum(r.n for r in wl.reads)
-        runs = []
-        for k in range(reps):
-            t = time.perf_counter()
-            tm = process.process(prefix + ".bam", prefix + ".bed", prefix + ".out%d" % k, annotationFile=prefix + ".gff",
-                                 isStranded=bool(stranded), strandedType=stranded, isbeta2Cryptic=cryptic, log=lambda m: None,
-                                 gpuDecode=gpu_decode)
-            wall = time.perf_counter() - t
-            runs.append(dict(wall_s=wall, reads_per_sec=n_reads / wall, bam_decode=tm.pop("bam_decode", "host"),
-                             stages={k2: round(v, 4) for k2, v in tm.items()}))
+
+        def call(tag, devs):
+            t0 = time.perf_counter()
+            tm = process.process(prefix + ".bam", prefix + ".bed", prefix + ".out" + tag, annotationFile=prefix + ".gff",
+                                 isStranded=bool(stranded), strandedType=stranded, isbeta2Cryptic=cryptic, log=noop,
+                                 gpuDecode=gpu_decode, devices=tuple(devs))
+            wall = time.perf_counter() - t0
+            return dict(wall_s=wall, reads_per_sec=n_reads / wall, bam_decode=tm.pop("bam_decode", "host"),
+                        stages={k2: round(v, 4) for k2, v in tm.items()})
+        runs = [call("%d" % k, devices) for k in range(reps)]
         best = min(runs, key=lambda r: r["wall_s"])
+        med = statistics.median(r["wall_s"] for r in runs)
         nproc, quota = cpu_budget()
-        out["host_cpu"] = {"nproc": nproc, "cpu_quota_cores": quota,
-                           "note": "with the host decoder the call is host-bound (BGZF inflate + CRC, record extraction, packing) and the "
-                                   "GPU idle for nine tenths of it; with the decode on the GPU the clock is the file's way there "
-                                   "(page cache -> staging -> PCIe) and the inflate kernel, see profiles/*_gpu_decode.txt"}
+        out["host_cpu"] = {"nproc": nproc, "cpu_quota_cores": quota}
         out["bam_decode"] = {"host": "on host threads", "device": "on the GPU (BGZF inflate, CRC32, record extraction as kernels)"}[best["bam_decode"]]
         out.update(reads=n_reads, reads_per_sec=best["reads_per_sec"], wall_s=best["wall_s"], stages=best["stages"],
+                   median_wall_s=med, median_reads_per_sec=n_reads / med, all_wall_s=[round(r["wall_s"], 4) for r in runs],
                    first_call_wall_s=runs[0]["wall_s"], runs=len(runs),
-                   what="process(): open BAM + BED/GFF -> Steps 0-2 on the host while the BAM decodes (GPU: file image up, inflate, "
-                        "CRC32, record extraction, reads laid out by kernels; host: threads, packing, H2D through the staging "
-                        "ring) -> range + literal + scan/SSE kernels, D2H -> .SpliSER.tsv; wall clock of the whole call in a "
-                        "process whose GPU context exists (first_call_wall_s: the call that creates it)")
-        # parity of the file: Site, alpha, beta1, beta2Simple and SSE text of every row against the oracle's numbers
-        ok, rows = True, 0
+                   what="process(): open BAM + BED/GFF -> Steps 0-2 on the host while the BAM decodes (GPU: the file's bytes up, Huffman "
+                        "decoding, copies, CRC32, record extraction, reads laid out by kernels, a window of the stream at a time; host: "
+                        "threads, packing, H2D through the staging ring) -> range + literal + scan/SSE kernels, D2H -> .SpliSER.tsv; wall "
+                        "clock of the whole call in a process whose GPU context exists (first_call_wall_s: the call that creates it); "
+                        "reads_per_sec / wall_s: the best of `runs` calls, median_*: their median")
+        if compare_devices is not None:     # the same call on fewer devices: what the others bought
+            one = [call("c%d" % k, compare_devices) for k in range(max(2, reps - 1))]
+            b1 = min(r["wall_s"] for r in one)
+            out["compared_with"] = {"devices": list(compare_devices), "wall_s": b1, "reads_per_sec": n_reads / b1,
+                                    "median_wall_s": statistics.median(r["wall_s"] for r in one),
+                                    "speedup_of_this_leg": b1 / best["wall_s"]}
+        # one more call under the library's own stopwatch: where the device's time goes (never one of the timed calls)
+        native.prof_enable(True)
+        prof_run = call("p", devices)
+        table = native.prof_report()
+        native.prof_enable(False)
+        for row in table:
+            row["GBps"] = row["bytes"] / (row["ms"] * 1e-3) / 1e9 if row["ms"] > 0 else None
+            row["frac_of_hbm_peak"] = row["GBps"] / HBM_PEAK_GBS if row["GBps"] is not None else None
+        out["kernels"] = {"what": "every kernel launch of one more process() call between two events on its own stream (spl_prof_*): "
+                                  "calls, summed ms, the bytes it was given to work on (algorithmic: its stretch of the inflated stream, "
+                                  "its reads) and that as a rate against the 8 TB/s HBM peak; kernels of different streams overlap, "
+                                  "so the ms do not add up to the call",
+                          "wall_s_of_that_call": prof_run["wall_s"], "kernel_ms_sum": sum(r["ms"] for r in table), "table": table}
+        # parity of the FILE: its whole text against the rows the oracle's numbers give (same table, same format statement)
+        tab = process._site_table(prefix + ".bed", "All", "All", 0, prefix + ".gff", "gene", bool(stranded), stranded, noop)
+        text = [tsv.HEADER]
+        for chrom in tab.chrom_index:
+            if chrom not in want:
+                continue
+            (b1c, _, _), (b2s, b2c, b2w, sse) = want[chrom]
+            text.extend(tsv.format_chrom(tab.chrom_arrays(chrom), dict(beta1=b1c, beta2_simple=b2s, beta2_cryptic=b2c, beta2_weighted=b2w, sse=sse), cryptic))
+        expected = "".join(text)
         with open(prefix + ".out%d.SpliSER.tsv" % (reps - 1)) as fh:
-            next(fh)
-            for line in fh:
-                v = line.split("\t")
-                w = want_rows.get((v[0], int(v[1]), v[2]))
-                ok &= w is not None and (v[4], v[5], v[6], v[7]) == w
-                rows += 1
-        out["tsv_rows"] = rows
-        out["tsv_matches_oracle"] = bool(ok and rows == len(want_rows))
+            got = fh.read()
+        out["tsv_rows"] = got.count("\n") - 1
+        out["tsv_matches_oracle"] = bool(got == expected)
+        out["tsv_compared"] = "the whole file, byte for byte, against tsv.format_chrom over the oracle's counters and doubles"
+        if cpu_e2e:     # the same work on the host's cores: decode (threads, libdeflate) + the oracle on all of them
+            scode = native.STRANDED_CODE[stranded]
+            n_threads = max(1, min(nproc, int(round(quota)) if quota else nproc))
+            t0 = time.perf_counter()
+            bam = native.BamFile(prefix + ".bam", threads=0)
+            cpu_items = [(c, arr, bam.reads(c)) for c, arr, _ in items]
+            t_dec = time.perf_counter() - t0
+            t_or, got_cpu = run_oracle(cpu_items, scode, cryptic, n_threads)
+            same = all(all(np.array_equal(x, y) for x, y in zip(got_cpu[c][0], want[c][0])) for c in want)
+            del cpu_items
+            bam.close()
+            out["cpu_e2e"] = {"what": "the same file on the host alone: BGZF inflate + record extraction on the host's threads (libdeflate), then "
+                                      "the oracle (oracle/spliser_oracle.c) on %d threads; no TSV" % n_threads,
+                              "decode_s": t_dec, "oracle_s": t_or, "wall_s": t_dec + t_or, "reads_per_sec": n_reads / (t_dec + t_or),
+                              "threads": n_threads, "same_counts": bool(same), "gpu_over_cpu": (t_dec + t_or) / best["wall_s"]}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out
-
-
-def oracle_rows(items, want, cryptic):
-    """{(chrom, pos, strand text): (SSE text, alpha, beta1, beta2Simple)} as the .SpliSER.tsv prints them."""
-    rows = {}
-    for c, arr, _ in items:
-        (b1, _, _), (b2s, _, _, sse) = want[c]
-        for i in range(arr.n):
-            rows[(c, int(arr.pos[i]), arr.strand_text[i])] = ("{0:.3f}".format(sse[i]), str(int(arr.alpha[i])), str(int(b1[i])),
-                                                              str(int(b2s[i])))
-    return rows
 
 
 def main():
@@ -234,8 +280,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="human", choices=["arabidopsis", "human", "mouse_stranded", "single_gene"])
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the workload's read count (debug)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = a sample per rank; strong = one sample, chromosomes dealt to the ranks")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1: strong (default) = one sample, chromosomes dealt to the ranks; weak = a sample per rank")
     ap.add_argument("--stranded", default=None, choices=[None, "fr", "rf"])
     ap.add_argument("--beta2Cryptic", action="store_true")
     ap.add_argument("--pipelined", action="store_true", help="no barrier between steps: the tail of a step runs beside the "
@@ -243,9 +289,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", default="auto", choices=["auto", "off"], help="auto: the decode-inclusive leg for this workload "
                     "(and for arabidopsis when the workload is human)")
-    ap.add_argument("--e2e-seq-mode", type=int, default=0, choices=[0, 1], help="SEQ / QUAL of the e2e BAM: 0 constant bytes, "
-                    "1 pseudo-random bases + binned qualities (10x the file)")
+    ap.add_argument("--e2e-seq-mode", type=int, default=None, choices=[0, 1], help="SEQ / QUAL of the e2e BAMs: 0 constant bytes, "
+                    "1 pseudo-random bases + binned qualities (10x the file); default: both")
     ap.add_argument("--e2e-reps", type=int, default=3)
+    ap.add_argument("--no-small-leg", action="store_true", help="no A. thaliana end-to-end legs beside the human-scale ones")
     ap.add_argument("--kernel", default="ranges", choices=["ranges", "ranges_agg", "pairs"],
                     help="ranges = default product path; pairs = the literal per-(read, site) kernel")
     ap.add_argument("--alt-fraction", type=float, default=None, help="(experiment) fraction of genes with alternative isoforms")
@@ -262,6 +309,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
 
     # torch first: it brings a HIP runtime of its own, and whichever libamdhip64 a process loads first is the one everything
     # else in it gets -- libspliser_hip.so (loaded by the host helpers below, long before a GPU is touched) would otherwise pull
@@ -278,7 +327,7 @@ def main():
         items = [it for it in items if it[0] in mine]
     # the e2e leg of the smaller configuration wants a sample of its own: generated now, for the same reason
     wl_small = None
-    if args.e2e == "auto" and rank == 0 and world == 1 and args.workload == "human" and args.scale == 1.0:
+    if args.e2e == "auto" and rank == 0 and world == 1 and args.workload == "human" and args.scale == 1.0 and not args.no_small_leg:
         small = argparse.Namespace(**vars(args))
         small.workload, small.cache = "arabidopsis", None
         wl_small = build_inputs(small, 0, 1)
@@ -367,6 +416,14 @@ def main():
         imbalance = {"reads_per_rank": [int(v) for v in per[:, 0].tolist()],
                      "seconds_per_rank": [round(float(v), 6) for v in per[:, 1].tolist()],
                      "max_over_mean_reads": float(per[:, 0].max() / per[:, 0].mean())}
+        # the collectives are over: what follows (parity, the end-to-end legs over ALL the node's GPUs) is rank 0's alone, the other
+        # ranks give their GPUs back
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
+        if rank != 0:
+            ctx.close()
+            return
 
     # ---- whole-workload parity check + CPU baseline (rank 0; the baseline only at N = 1) -------------
     # The oracle is the checker here, never the thing measured as "value".
@@ -402,20 +459,23 @@ def main():
                                             "label": "ESTIMATE, not a measurement: S*1.7 ms (one samtools spawn per site) + P*7.1 us "
                                                      "(Python per counted (read, site) pair, P >= %d) for SpliSER v0.1.8 on one core "
                                                      "(BASELINE.md; SpliSER_v0_1_8.py:422, :427-559)" % pairs}}
-        if world == 1 and args.e2e == "auto":
-            e2e = [e2e_leg(args.workload, wl, items, stranded, args.beta2Cryptic, args.e2e_seq_mode, args.e2e_reps,
-                           oracle_rows(items, want, args.beta2Cryptic))]
+        if args.e2e == "auto":
+            nproc, quota = cpu_budget()
+            n_threads = max(1, min(nproc, int(round(quota)) if quota else nproc))
+            want_all = want if len(all_items) == len(items) else run_oracle(all_items, scode, args.beta2Cryptic, n_threads)[1]
+            modes = [args.e2e_seq_mode] if args.e2e_seq_mode is not None else [1, 0]
+            devs = tuple(range(world))
+            e2e = []
+            for q in modes:     # (first the file that deflates like a real library's: the leg that says what the product does)
+                e2e.append(e2e_leg(args.workload, wl, all_items, stranded, args.beta2Cryptic, q, args.e2e_reps, want_all, devices=devs,
+                                   cpu_e2e=(world == 1 and q == 1 and not args.no_cpu_baseline), compare_devices=(0,) if world > 1 else None))
             if wl_small is not None:
                 wl2, _, items2, stranded2 = wl_small
-                _, want2 = run_oracle(items2, native.STRANDED_CODE[stranded2], args.beta2Cryptic, max(1, int(round(cpu_budget()[1] or 8))))
-                rows2 = oracle_rows(items2, want2, args.beta2Cryptic)
-                e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, args.e2e_seq_mode, args.e2e_reps, rows2))
-                if args.e2e_seq_mode == 0:
-                    # ... and once with SEQ / QUAL bytes that deflate like a real library's (1.4 GB for these 20 M reads): the
-                    # files above inflate at memset speed, a real one makes BGZF inflate the whole cost of the call
-                    # (by default `process` inflates such a file on the GPU; once with the host decoder asked for)
-                    e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, 1, args.e2e_reps, rows2))
-                    e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, 1, args.e2e_reps, rows2, gpu_decode=False))
+                _, want2 = run_oracle(items2, native.STRANDED_CODE[stranded2], args.beta2Cryptic, n_threads)
+                for q in modes:
+                    e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, q, args.e2e_reps, want2, cpu_e2e=(q == 1 and not args.no_cpu_baseline)))
+                if 1 in modes:  # ... and once with the host decoder asked for
+                    e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, 1, args.e2e_reps, want2, gpu_decode=False))
     ctx.close()
 
     if rank == 0:
@@ -463,7 +523,11 @@ def main():
                                     "how": "5 more launches after the timed region, each followed by a sync"}),
                          "path": {"what": "algorithmic bytes of a step / time of a step: every kernel of the pass and the gaps between them",
                                   "achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS},
-                         "lib_sha16": sha, "kernel_src_sha16": ksha},
+                         "hbm_actual": (None if not traffic or not kernel_ms else
+                                        {"what": "HBM bytes per launch by the PMC counters (traffic) / the kernel's time: what the memory system "
+                                                 "really moved, beside the algorithmic rate above",
+                                         "GBps": traffic / (k_avg_ms * 1e-3) / 1e9, "frac": traffic / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}),
+                         "lib_sha16": sha, "kernel_src_sha16": ksha, "ingest_src_sha16": ingest_src_sha16()},
             "cpu_baseline": cpu,
             "parity": parity,
             "e2e": e2e,

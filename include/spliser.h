@@ -122,6 +122,13 @@ int spl_timer_end(spl_ctx *ctx, float *elapsed_ms_out);
  * launches; collect() synchronises and returns their durations in launch order. */
 int spl_kernel_timing_begin(spl_ctx *ctx, int max_records);
 int spl_kernel_timing_collect(spl_ctx *ctx, float *ms_out, int capacity, int *n_out);
+/* The library's own stopwatch over ALL its kernels (process-wide): spl_prof_enable(1) clears what was recorded and brackets every
+ * kernel launch from then on -- the device decode's, the device packer's, the counting passes' -- with two events on its stream;
+ * spl_prof_report waits for the devices and writes JSON text, [{"kernel", "calls", "ms", "bytes"}, ...] most time first, `bytes`
+ * being what the kernel was given to work on (the stretch of the inflated stream, the reads: algorithmic, not fetched).  Returns
+ * the length the text needs.  What bench.py's end-to-end legs quote as their `kernels` table. */
+int spl_prof_enable(int on);
+int spl_prof_report(char *buf, int cap);
 
 /* ---- one-shot entry points on host buffers (what the `process` driver calls per shard) ---------
  * spl_count  == the checkBam loop of processSites (SpliSER_v0_1_8.py:686-688) for all sites at once.

@@ -159,6 +159,93 @@ static void put(void *p)
 }
 } // namespace devmem
 
+struct spl_dsites;
+struct spl_dreads;
+extern "C" int spl_count_algorithmic_bytes(const spl_dsites *ds, const spl_dreads *dr, int64_t *out);
+
+// ---- the library's own stopwatch over its kernels -----------------------------------------------------------------------
+// spl_prof_enable(1): from then on every kernel launch of the ingest path (device decode, device packer) and every counting pass
+// is bracketed by two events on its stream; spl_prof_report sums them by name.  What bench.py's end-to-end legs quote as their
+// `kernels` table: durations measured where the kernels run, with the bytes each is given to work on (algorithmic: the stretch
+// of the stream, or the reads, it is responsible for -- not what it happens to fetch).
+namespace splprof {
+struct Rec { const char *name; int device; hipEvent_t a, b; double bytes; };
+static std::atomic<int> g_on{0};
+static std::mutex &mu() { static std::mutex m; return m; }
+static std::vector<Rec> &recs() { static std::vector<Rec> *v = new std::vector<Rec>(); return *v; }
+static std::vector<std::pair<int, hipEvent_t>> &pool() { static std::vector<std::pair<int, hipEvent_t>> *v = new std::vector<std::pair<int, hipEvent_t>>(); return *v; }
+static hipEvent_t take(int device)
+{
+    {
+        std::lock_guard<std::mutex> lock(mu());
+        std::vector<std::pair<int, hipEvent_t>> &p = pool();
+        for (size_t k = 0; k < p.size(); ++k)
+            if (p[k].first == device) { hipEvent_t e = p[k].second; p.erase(p.begin() + (long)k); return e; }
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+struct Scope { // (the current device is the stream's)
+    const char *name; hipStream_t st; double bytes; hipEvent_t a = nullptr, b = nullptr; int device = 0;
+    Scope(const char *n, hipStream_t s, double by) : name(n), st(s), bytes(by)
+    {
+        if (!g_on.load(std::memory_order_relaxed)) return;
+        if (hipGetDevice(&device) != hipSuccess) return;
+        a = take(device); b = take(device);
+        if (a && b) (void)hipEventRecord(a, st);
+    }
+    ~Scope()
+    {
+        if (!a || !b) return;
+        (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> lock(mu());
+        recs().push_back(Rec{name, device, a, b, bytes});
+    }
+};
+} // namespace splprof
+
+extern "C" int spl_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lock(splprof::mu());
+    for (const splprof::Rec &r : splprof::recs()) { splprof::pool().push_back({r.device, r.a}); splprof::pool().push_back({r.device, r.b}); }
+    splprof::recs().clear();
+    splprof::g_on.store(on ? 1 : 0);
+    return SPL_OK;
+}
+
+// JSON text: [{"kernel": ..., "calls": n, "ms": sum, "bytes": sum}, ...] (most time first).  Waits for the devices.  Returns the
+// length the text needs (it is cut to cap - 1 characters).
+extern "C" int spl_prof_report(char *buf, int cap)
+{
+    std::vector<splprof::Rec> recs;
+    { std::lock_guard<std::mutex> lock(splprof::mu()); recs = splprof::recs(); }
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    struct Sum { std::string name; int calls; double ms, bytes; };
+    std::vector<Sum> sums;
+    for (const splprof::Rec &r : recs) {
+        (void)hipSetDevice(r.device);
+        float ms = 0;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { (void)hipGetLastError(); continue; }
+        size_t k = 0;
+        while (k < sums.size() && sums[k].name != r.name) ++k;
+        if (k == sums.size()) sums.push_back(Sum{r.name, 0, 0, 0});
+        sums[k].calls++; sums[k].ms += ms; sums[k].bytes += r.bytes;
+    }
+    if (have) (void)hipSetDevice(cur);
+    std::sort(sums.begin(), sums.end(), [](const Sum &a, const Sum &b) { return a.ms > b.ms; });
+    std::string out = "[";
+    for (size_t k = 0; k < sums.size(); ++k) {
+        char line[256];
+        snprintf(line, sizeof line, "%s{\"kernel\": \"%s\", \"calls\": %d, \"ms\": %.4f, \"bytes\": %.0f}", k ? ", " : "", sums[k].name.c_str(), sums[k].calls, sums[k].ms, sums[k].bytes);
+        out += line;
+    }
+    out += "]";
+    if (buf && cap > 0) { strncpy(buf, out.c_str(), (size_t)cap - 1); buf[cap - 1] = 0; }
+    return (int)out.size() + 1;
+}
+
 // ---- objects --------------------------------------------------------------------------------------------
 struct spl_ctx {
     int device = -1;
@@ -1038,9 +1125,10 @@ static int add_segment_device(spl_ctx *c, spl_dreads *d, const DeviceReads &dev,
     const size_t slab_bytes = rec_al + 4 * (size_t)n_ops + 256;
     hipError_t q = devmem::get((void **)&seg.d_descs, sizeof(splpack::ChunkDesc) * n_chunks + 16, 'd');
     if (q == hipSuccess) q = devmem::get((void **)&seg.slab, slab_bytes, 'R');
-    if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack_count(&src, first, n_reads, chunk, seg.d_descs, c->copy);
-    if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack_offsets(seg.d_descs, (uint32_t)n_chunks, seg.d_descs + n_chunks, c->copy);
-    if (q == hipSuccess) q = (hipError_t)spl_dev_launch_pack_emit(&src, first, n_reads, chunk, seg.d_descs, seg.slab, seg.slab + rec_al, c->copy);
+    const double in_bytes = 10.0 * (double)n_reads + 4.0 * (double)n_ops;
+    if (q == hipSuccess) { splprof::Scope p("spl_devpack_count_kernel", c->copy, in_bytes); q = (hipError_t)spl_dev_launch_pack_count(&src, first, n_reads, chunk, seg.d_descs, c->copy); }
+    if (q == hipSuccess) { splprof::Scope p("spl_devpack_offsets_kernel", c->copy, 32.0 * (double)n_chunks); q = (hipError_t)spl_dev_launch_pack_offsets(seg.d_descs, (uint32_t)n_chunks, seg.d_descs + n_chunks, c->copy); }
+    if (q == hipSuccess) { splprof::Scope p("spl_devpack_emit_kernel", c->copy, in_bytes + 8.0 * (double)n_reads + 4.0 * (double)n_ops); q = (hipError_t)spl_dev_launch_pack_emit(&src, first, n_reads, chunk, seg.d_descs, seg.slab, seg.slab + rec_al, c->copy); }
     if (q != hipSuccess) {
         (void)hipStreamSynchronize(c->copy);
         devmem::put(seg.d_descs);
@@ -1146,7 +1234,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     int rc = ensure_stage(c);
     if (rc) return rc;
     // ---- everything the streams touch is declared before them: what is declared last goes first, and that is the guard that waits
-    constexpr int NBUF = 2, NCOPY = 1; // (measured: four buffers with two windows' copies side by side take longer, 0.80 s against 0.58 s for a 14 GB file)
+    constexpr int NBUF = 2, NCOPY = 1; // (measured twice: four buffers with two windows' copies side by side take longer, 0.68-0.80 s against 0.51-0.58 s for a 14 GB file -- two copying kernels at once get in each other's way in the memory system)
     DevBuf d_image, d_stream[NBUF], d_zwork[NBUF], d_blocks, d_status, d_scan, d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
     std::vector<spl_zblock> blocks;
     std::vector<uint32_t> status;
@@ -1344,24 +1432,35 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     size_t pieces_waited = 0;
     auto win_range = [&](size_t k, size_t &b0, size_t &b1) { b0 = k * win_blocks; b1 = std::min(n_blocks, b0 + win_blocks); };
     auto stream0_of = [&](size_t k) { size_t b0, b1; win_range(k, b0, b1); return d_stream[k % (size_t)n_buf].as<uint8_t>() + HEAD - blocks[b0].out; }; // (indexed with offsets into the whole stream)
-    auto launch_decode = [&](size_t k) -> int {
+    auto launch_decode = [&](size_t k, bool wait, bool &launched_it) -> int {
         size_t b0, b1;
         win_range(k, b0, b1);
+        launched_it = false;
         const size_t last_byte = (size_t)(blocks[b1 - 1].in + blocks[b1 - 1].in_len + 8) - byte_lo;
         const size_t need = std::min(n_pieces, last_byte / piece + 1);
+        if (!wait) // (a window ahead of the one the host is at: only if its bytes are on their way already)
+            for (size_t q = pieces_waited; q < need; ++q) if (!sent[q].load(std::memory_order_acquire)) return SPL_OK;
         for (; pieces_waited < need; ++pieces_waited) {
             while (!sent[pieces_waited].load(std::memory_order_acquire)) std::this_thread::yield();
             if (reader_failed.load(std::memory_order_acquire)) { for (hipError_t e : errs) HIP_TRY(e); }
             HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.piece[pieces_waited], 0));
         }
         if (k >= (size_t)n_buf) HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.freed[k % (size_t)n_buf], 0));
-        HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k), d_status.as<uint32_t>() + b0,
-                                                          d_zwork[k % (size_t)n_buf].p, match_stride, pipe.a));
+        const double w_in = (double)(blocks[b1 - 1].in + blocks[b1 - 1].in_len - blocks[b0].in), w_out = (double)(blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out);
+        {
+            splprof::Scope p("spl_inflate_decode_kernel", pipe.a, w_in + w_out);
+            HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k), d_status.as<uint32_t>() + b0,
+                                                              d_zwork[k % (size_t)n_buf].p, match_stride, pipe.a));
+        }
         HIP_TRY(hipEventRecord(pipe.k1[k % (size_t)n_buf], pipe.a));
         hipStream_t cs = pipe.cp[k % (size_t)NCOPY];
         HIP_TRY(hipStreamWaitEvent(cs, pipe.k1[k % (size_t)n_buf], 0));
-        HIP_TRY((hipError_t)spl_dev_launch_inflate_copy(d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k), d_zwork[k % (size_t)n_buf].p, match_stride, cs));
+        {
+            splprof::Scope p("spl_inflate_copy_kernel", cs, w_out);
+            HIP_TRY((hipError_t)spl_dev_launch_inflate_copy(d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k), d_zwork[k % (size_t)n_buf].p, match_stride, cs));
+        }
         HIP_TRY(hipEventRecord(pipe.k2[k % (size_t)n_buf], cs));
+        launched_it = true;
         return SPL_OK;
     };
     int64_t n_all = 0;
@@ -1374,7 +1473,13 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         size_t b0, b1;
         win_range(k, b0, b1);
         // (a window's buffer is free again when the extraction of the window that had it is on stream B: windows k .. k + n_buf - 1 fit)
-        for (; launched < n_win && launched < k + (size_t)n_buf; ++launched) { rc = launch_decode(launched); if (rc) return rc; }
+        while (launched < n_win && launched < k + (size_t)n_buf) {
+            bool did = false;
+            rc = launch_decode(launched, launched == k, did);
+            if (rc) return rc;
+            if (!did) break;
+            ++launched;
+        }
         const size_t slot = k % (size_t)n_buf;
         const bool more = b1 < n_blocks || !last_share;
         const uint32_t nb = (uint32_t)(b1 - b0);
@@ -1382,9 +1487,13 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         uint8_t *const stream0 = stream0_of(k);
         const size_t s0 = k == 0 ? b0 : carry; // scan and extraction begin with what the window before left
         HIP_TRY(hipStreamWaitEvent(pipe.b, pipe.k2[slot], 0));
-        HIP_TRY((hipError_t)spl_dev_launch_crc32(stream0, d_blocks.as<spl_zblock>() + b0, nb, d_status.as<uint32_t>() + b0, pipe.b));
-        HIP_TRY((hipError_t)spl_dev_launch_bam_scan(stream0, win_end, H, n_ref, sh.tid_lo, sh.tid_hi, d_blocks.as<spl_zblock>() + s0, (uint32_t)(b1 - s0), d_scan.as<spl_bscan>() + s0,
-                                                    more ? 1 : 0, pipe.b));
+        const double win_out = (double)(win_end - blocks[b0].out);
+        { splprof::Scope p("spl_crc32_kernel", pipe.b, win_out); HIP_TRY((hipError_t)spl_dev_launch_crc32(stream0, d_blocks.as<spl_zblock>() + b0, nb, d_status.as<uint32_t>() + b0, pipe.b)); }
+        {
+            splprof::Scope p("spl_bam_scan_kernel", pipe.b, (double)(win_end - blocks[s0].out));
+            HIP_TRY((hipError_t)spl_dev_launch_bam_scan(stream0, win_end, H, n_ref, sh.tid_lo, sh.tid_hi, d_blocks.as<spl_zblock>() + s0, (uint32_t)(b1 - s0), d_scan.as<spl_bscan>() + s0,
+                                                        more ? 1 : 0, pipe.b));
+        }
         HIP_TRY(hipMemcpyAsync(status.data() + b0, d_status.as<uint32_t>() + b0, 4 * (size_t)nb, hipMemcpyDeviceToHost, pipe.b));
         HIP_TRY(hipMemcpyAsync(scan.data() + s0, d_scan.as<spl_bscan>() + s0, sizeof(spl_bscan) * (b1 - s0), hipMemcpyDeviceToHost, pipe.b));
         HIP_TRY(hipStreamSynchronize(pipe.b));
@@ -1437,6 +1546,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             HIP_TRY(hipMemcpyAsync(d_recoff.as<uint64_t>() + s0, rec_off.data() + s0, 8 * nd, hipMemcpyHostToDevice, pipe.b));
             HIP_TRY(hipMemcpyAsync(d_opoff.as<uint64_t>() + s0, op_off.data() + s0, 8 * nd, hipMemcpyHostToDevice, pipe.b));
             HIP_TRY(hipMemcpyAsync(d_scan.as<spl_bscan>() + s0, scan.data() + s0, sizeof(spl_bscan) * nd, hipMemcpyHostToDevice, pipe.b));
+            splprof::Scope p("spl_bam_extract_kernel", pipe.b, (double)(blocks[b_done - 1].out + blocks[b_done - 1].out_len - blocks[s0].out));
             HIP_TRY((hipError_t)spl_dev_launch_bam_extract(stream0, win_end, n_ref, sh.tid_lo, sh.tid_hi, d_blocks.as<spl_zblock>() + s0, (uint32_t)nd, d_scan.as<spl_bscan>() + s0,
                                                            d_recoff.as<uint64_t>() + s0, d_opoff.as<uint64_t>() + s0, d_pos.as<int32_t>(), d_flag.as<uint16_t>(),
                                                            d_cigoff.as<uint32_t>(), d_cigar.as<uint32_t>(), d_tid.as<int32_t>(), d_maxend.as<unsigned long long>(), pipe.b));
@@ -1779,7 +1889,10 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     // (with the tail on its own stream that stream waits for the range kernel's OWN stop event: a marker packet behind the
     //  kernel -- hipEventRecord -- holds the main queue up for ~18 us when another queue depends on it)
     hipEvent_t ev_stop = timed ? c->k_ev[2 * c->k_used + 1] : (piped ? c->ev_range[c->n_pass % 4] : nullptr);
-    int rc = spl_dev_launch_count(&p, &h, variant, c->stream, &grid, &lds, timed ? (void *)c->k_ev[2 * c->k_used] : nullptr, (void *)ev_stop);
+    int64_t alg = 0;
+    if (splprof::g_on.load(std::memory_order_relaxed)) (void)spl_count_algorithmic_bytes(ds, dr, &alg);
+    int rc;
+    { splprof::Scope prof("spl_count_ranges_kernel", c->stream, (double)alg); rc = spl_dev_launch_count(&p, &h, variant, c->stream, &grid, &lds, timed ? (void *)c->k_ev[2 * c->k_used] : nullptr, (void *)ev_stop); }
     if (timed) c->k_used++;
     c->last_grid = grid;
     c->last_lds = lds;

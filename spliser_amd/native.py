@@ -46,7 +46,7 @@ OPT_WAVE_AGGREGATION = 2
 
 EXPORTS = [
     "spl_abi_version", "spl_last_error", "spl_device_count", "spl_create", "spl_create_on_stream", "spl_destroy",
-    "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
+    "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_prof_enable", "spl_prof_report", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_close",
@@ -435,6 +435,20 @@ def write_bam(path, ref_names, ref_lengths, read_sets, level=1, threads=0, seq_m
         arr[i] = ra.c
     _check(lib().spl_bam_write2(os.fsencode(path), ctypes.c_int(n), names, lens, arr, ctypes.c_int(level), ctypes.c_int(threads),
                                 ctypes.c_int(seq_mode)))
+
+
+def prof_enable(on=True):
+    """The library's own stopwatch over all its kernels, process-wide (``spl_prof_enable``): clears what was recorded."""
+    _check(lib().spl_prof_enable(ctypes.c_int(1 if on else 0)))
+
+
+def prof_report():
+    """-> [{"kernel", "calls", "ms", "bytes"}, ...] of the launches since ``prof_enable`` (waits for the devices)."""
+    import json
+    need = lib().spl_prof_report(None, ctypes.c_int(0))
+    buf = ctypes.create_string_buffer(need + 16)
+    lib().spl_prof_report(buf, ctypes.c_int(need + 16))
+    return json.loads(buf.value.decode("ascii"))
 
 
 class BamFile(object):
