@@ -65,9 +65,9 @@ typedef struct spl_sites {
     const uint8_t *strand;     /* [n_sites]   Site.strand as ASCII ('+', '-', anything else = none)  */
     const uint32_t *part_off;  /* [n_sites+1] CSR offsets into part_*                                */
     const int32_t *part_pos;   /* [n_part]    keys of Site.PartnerCounts, insertion order            */
-    const int32_t *part_site;  /* [n_part]    row of that partner in this table, -1 when absent; when
-                                              NULL spl_count falls back to the pair kernel and spl_sse
-                                              is unavailable                                        */
+    const int32_t *part_site;  /* [n_part]    row of that partner in this table, -1 when absent (the
+                                              one-way lists of combine's query tables); NULL: spl_sse
+                                              is unavailable.  The range kernel takes either.        */
     const uint32_t *comp_off;  /* [n_sites+1] CSR offsets into comp_pos                              */
     const int32_t *comp_pos;   /* [n_comp]    Site.CompetitorPos (sorted unique)                     */
     const int64_t *alpha;      /* [n_sites]   Site.alphaCounts[sample]; may be NULL for spl_count    */
@@ -93,9 +93,9 @@ typedef struct spl_opts {
     int32_t flags;        /* SPL_OPT_* bits                                                            */
 } spl_opts;
 
-/* Force the literal per-(read, site) kernel.  By default spl_count uses the range kernel whenever every
- * partner edge of the table has its reverse edge (tables built like findAlphaCounts builds them), and the
- * pair kernel otherwise (e.g. combine gap-fill queries); both give identical counters. */
+/* Force the literal per-(read, site) kernel: an on-device cross-check (tests).  Nothing in the product selects it -- the
+ * range kernel takes every table, combine's query tables with their one-way partner lists included (its junction table is
+ * built from each row's own lists); both give identical counters. */
 #define SPL_OPT_PAIR_KERNEL 1
 /* Variant of the range kernel that merges the LDS atomics of neighbouring lanes before issuing them (same results;
  * measured never faster than the plain atomics the default uses -- kept for parity tests and experiments). */
@@ -105,6 +105,10 @@ typedef struct spl_opts {
 int spl_abi_version(void);
 const char *spl_last_error(void);
 int spl_device_count(int *n_out);
+/* The library keeps device memory it was given back (read sets, site tables, the buffers of a device decode) for its next call
+ * in the same process -- fresh device memory costs 30 ms per GB on this stack -- up to half of what was free on the device when it
+ * first asked (SPL_DEV_CACHE_GB overrides).  spl_trim returns all of it to the driver: device_id, or -1 for every device. */
+int spl_trim(int device_id);
 int spl_create(int device_id, spl_ctx **out);
 /* Same, but work is enqueued on a caller-provided hipStream_t (e.g. torch's current stream). */
 int spl_create_on_stream(int device_id, void *hip_stream, spl_ctx **out);

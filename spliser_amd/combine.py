@@ -273,7 +273,7 @@ def _query_arrays(chrom, qs):
     np.cumsum(cdeg, out=a.comp_off[1:])
     a.part_pos = np.array([p for q in qs for p in q[4]], np.int64)
     a.comp_pos = np.array([c for q in qs for c in q[5]], np.int64)
-    a.part_site = np.full(a.part_pos.shape[0], -1, np.int32)     # one-way lists: the library takes its pair kernel
+    a.part_site = np.full(a.part_pos.shape[0], -1, np.int32)     # one-way lists (the range kernel takes them: its junction table is built per row)
     a.edge_cnt = np.zeros(a.part_pos.shape[0], np.int64)
     a.alpha = np.zeros(a.n, np.int64)
     return a

@@ -56,8 +56,10 @@ extern "C" int spl_abi_version(void) { return SPL_ABI_VERSION; }
 // while 18 GB of the previous one were being scrubbed had its upload run at 4 GB/s instead of 35).  A second `process` call of
 // the same process -- `combine`'s samples, a service -- finds its read sets', decoded arrays' and inflated stream's memory
 // where the first left it.  Best fit, at most twice what was asked for; buffers below 8 MiB are not worth keeping; the pool
-// holds at most SPL_DEV_CACHE_GB (default 128) per device and lets its smallest buffers go first; when the device runs out,
-// everything held is given back before the request fails.  put() waits for the device like the hipFree it stands in for.
+// holds at most half of what was free on the device when it was first asked (SPL_DEV_CACHE_GB overrides, 0 = keep nothing) and
+// lets its smallest buffers go first; when the device runs out, everything held is given back before the request fails;
+// spl_trim() gives it all back on request (a service between two jobs).  put() waits for the device like the hipFree it stands
+// in for.
 // (Stream-ordered allocation -- hipMallocAsync / hipFreeAsync -- was tried first: with that pool the BAM decode became flaky
 // on this stack, stale reference ids in one run of four.)
 // SPL_DEV_POISON=1 (tests): every buffer is filled with 0xA5 when handed out -- fresh device memory is zero on this stack and
@@ -67,10 +69,24 @@ struct Held { int device; void *p; size_t bytes; };
 static std::mutex &mu() { static std::mutex m; return m; }
 static std::vector<Held> &held() { static std::vector<Held> *v = new std::vector<Held>(); return *v; }
 static std::vector<Held> &lent() { static std::vector<Held> *v = new std::vector<Held>(); return *v; }
-static size_t limit()
+static size_t limit(int device)
 {
-    static const size_t v = []() { const char *e = getenv("SPL_DEV_CACHE_GB"); return (size_t)(e ? std::max(0, atoi(e)) : 128) << 30; }();
-    return v;
+    static const long long env = []() { const char *e = getenv("SPL_DEV_CACHE_GB"); return e ? (long long)std::max(0, atoi(e)) << 30 : -1LL; }();
+    if (env >= 0) return (size_t)env;
+    static std::mutex m;
+    static std::vector<size_t> per; // by device: half of what was free when the pool was first asked there
+    std::lock_guard<std::mutex> lock(m);
+    if ((size_t)device >= per.size()) per.resize((size_t)device + 1, 0);
+    if (per[(size_t)device] == 0) {
+        size_t free_b = 0, total_b = 0;
+        int cur = 0;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        if (have && cur != device) (void)hipSetDevice(device);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)64 << 30; }
+        if (have && cur != device) (void)hipSetDevice(cur);
+        per[(size_t)device] = std::max<size_t>(free_b / 2, (size_t)1 << 30);
+    }
+    return per[(size_t)device];
 }
 static size_t held_bytes(int device)
 {
@@ -134,7 +150,7 @@ static void put(void *p)
         for (size_t k = 0; k < l.size(); ++k)
             if (l[k].p == p) { h = l[k]; l.erase(l.begin() + (long)k); break; }
     }
-    if (h.device < 0 || h.bytes < ((size_t)8 << 20) || h.bytes > limit()) { (void)hipFree(p); return; }
+    if (h.device < 0 || h.bytes < ((size_t)8 << 20) || h.bytes > limit(h.device)) { (void)hipFree(p); return; }
     int cur = 0;
     const bool have = hipGetDevice(&cur) == hipSuccess;
     if (have && cur != h.device) (void)hipSetDevice(h.device);
@@ -146,7 +162,8 @@ static void put(void *p)
         v.push_back(h);
         size_t total = 0;
         for (const Held &x : v) if (x.device == h.device) total += x.bytes;
-        while (total > limit()) { // the smallest go first: the large ones are the expensive ones
+        const size_t lim = limit(h.device);
+        while (total > lim) { // the smallest go first: the large ones are the expensive ones
             size_t s = v.size();
             for (size_t k = 0; k < v.size(); ++k)
                 if (v[k].device == h.device && (s == v.size() || v[k].bytes < v[s].bytes)) s = k;
@@ -158,6 +175,19 @@ static void put(void *p)
     for (const Held &x : go) (void)hipFree(x.p);
 }
 } // namespace devmem
+
+// Device memory the process keeps for its next call (devmem above) goes back to the driver: device_id, or -1 for every device.
+extern "C" int spl_trim(int device_id)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return SPL_OK; }
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (int d = 0; d < n; ++d)
+        if (device_id < 0 || d == device_id) { (void)hipSetDevice(d); devmem::flush(d); }
+    if (have) (void)hipSetDevice(cur);
+    return SPL_OK;
+}
 
 struct spl_dsites;
 struct spl_dreads;

@@ -1,11 +1,13 @@
-// spl_inflate.h -- DEFLATE (RFC 1951) on the device, one BGZF block per lane.
+// spl_inflate.h -- DEFLATE (RFC 1951) on the device: the launchers of spl_inflate.hip and what they exchange with the host.
 //
-// A BGZF block is a gzip member of its own holding at most 64 KiB: a BAM file is hundreds of thousands of independent
-// DEFLATE streams, which is all the parallelism a GPU needs -- no cooperation inside a stream.  Each lane decodes its block
-// from the copy of the file in device memory straight to its place in the inflated stream (or in the window of it that is
-// being worked on).  Canonical Huffman decoding by code length (per-length limits and bases in registers, compared two at a
-// time; the symbols in LDS), bits from a 64-bit buffer refilled by aligned 32-bit loads asked for a turn ahead.  Every loop is
-// bounded by the block's own sizes: a corrupt block ends with an error code in its status word, never with a hang.
+// A BGZF block is a gzip member of its own holding at most 64 KiB: a BAM file is hundreds of thousands of independent DEFLATE
+// streams.  Two kernels inflate them (spl_inflate_wave.h has the method): the Huffman decoding, a WAVE per block -- 64 lanes
+// share one pair of look-up tables in LDS and find their places in the block's bits by decoding from guessed starts until the
+// guesses agree -- writes the literals and a list of the matches; the copies the matches stand for, a LANE per block, are made
+// from that list.  Round 2's decoder, a lane per block for everything (canonical Huffman decoding by code length, tables per
+// lane), remains as spl_inflate_kernel: it takes the blocks whose match lists overflow, and all of them under
+// SPL_INFLATE_PER_LANE=1.  Every loop of either is bounded by the block's own sizes: a corrupt block ends with an error code in
+// its status word, never with a hang or a read beyond the image's padding.
 //
 // The inflate and CRC kernels are what `process` replaces the host's libdeflate + CRC32 threads with (bam_reader.cpp,
 // decode_worker; `--hostDecode` keeps those); replaces SpliSER_v0_1_8.py:422 (samtools view) all the same.

@@ -229,12 +229,17 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
             uint8_t cl[19];
 #pragma unroll
             for (int i = 0; i < 19; ++i) cl[i] = 0;
-            for (int i = 0; i < ncode; ++i) { br.refill(); cl[k_clen_order[i]] = (uint8_t)br.take(3); }
+            // (a header is bounded by the block's own bytes like everything else: the read-ahead runs 12 bytes past what has been
+            //  consumed, the image is readable SPL_Z_IMAGE_PAD bytes past any block -- beyond end + 24 the data is corrupt)
+            const gptr8 stop_h = (gptr8)(br.end + 24);
+            for (int i = 0; i < ncode && (gptr8)br.p <= stop_h; ++i) { br.refill(); cl[k_clen_order[i]] = (uint8_t)br.take(3); }
+            if ((gptr8)br.p > stop_h) { err = SPL_Z_OVERRUN; break; }
             Table cc;
             const LdsSyms csym = dsym;
             if (!build_table(cl, 19, cc, csym)) { err = SPL_Z_BAD_LENGTHS; break; }
             int idx = 0;
             while (idx < nlen + ndist) {
+                if ((gptr8)br.p > stop_h) { err = SPL_Z_OVERRUN; break; }
                 br.refill();
                 const int sym = decode_symbol(br, cc, csym);
                 if (sym < 0) { err = SPL_Z_BAD_CODE; break; }

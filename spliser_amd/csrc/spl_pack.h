@@ -69,7 +69,7 @@
 // op code -> 2-bit kind: M(0)=1 D(2)=3 N(3)=2 =(7)=1 X(8)=1, others 0 (does not consume the reference)
 #define SPL_KIND_TABLE ((1u << 0) | (3u << 4) | (2u << 6) | (1u << 14) | (1u << 16))
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SPL_PACK_HD __host__ __device__ inline
 #else
 #define SPL_PACK_HD inline

@@ -45,7 +45,7 @@ OPT_WAVE_AGGREGATION = 2
 
 
 EXPORTS = [
-    "spl_abi_version", "spl_last_error", "spl_device_count", "spl_create", "spl_create_on_stream", "spl_destroy",
+    "spl_abi_version", "spl_last_error", "spl_device_count", "spl_trim", "spl_create", "spl_create_on_stream", "spl_destroy",
     "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_prof_enable", "spl_prof_report", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
@@ -435,6 +435,11 @@ def write_bam(path, ref_names, ref_lengths, read_sets, level=1, threads=0, seq_m
         arr[i] = ra.c
     _check(lib().spl_bam_write2(os.fsencode(path), ctypes.c_int(n), names, lens, arr, ctypes.c_int(level), ctypes.c_int(threads),
                                 ctypes.c_int(seq_mode)))
+
+
+def trim(device=-1):
+    """Device memory the library keeps for its next call goes back to the driver (``spl_trim``)."""
+    _check(lib().spl_trim(ctypes.c_int(device)))
 
 
 def prof_enable(on=True):

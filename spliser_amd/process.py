@@ -1,9 +1,10 @@
 """``process`` -- the SpliSER sub-command whose Step 3 is the MI355X hot path.
 
 Same call signature, same stdout banners (loosely), same ``<outputPath>.SpliSER.tsv`` as
-SpliSER_v0_1_8.py:695-720.  Steps 0-2 run on the host (``sites.py``); Step 3 -- the per-site
-``checkBam`` loop plus ``findBeta2Counts`` / ``calculateSSE`` (``processSites``, :681-692) -- is one
-``spl_count`` + one ``spl_sse`` launch per shard on each GPU (``native.py`` -> libspliser_hip.so).
+SpliSER_v0_1_8.py:695-720.  Steps 0-2 run on the host (``sites.py`` / ``fast_sites.py``) while the BAM file is decoded on the
+GPU(s) -- every device the stretch of the file that holds its own chromosomes; Step 3 -- the per-site ``checkBam`` loop plus
+``findBeta2Counts`` / ``calculateSSE`` (``processSites``, :681-692) -- is one counting pass (range, literal, scan + SSE
+kernels) per shard on each GPU, over reads that never left it (``native.py`` -> libspliser_hip.so).
 
 Deliberate deviations from the reference, all on the failure side:
   * an unreadable / truncated / non-BAM alignment file is an error here; the reference ignores samtools'
