@@ -253,6 +253,10 @@ int spl_bam_start(spl_bam *bam);
 int spl_bam_compression_ratio(spl_bam *bam, double *ratio_out);
 int spl_bam_wait_ref(spl_bam *bam, int tid, int64_t *n_reads_out, int64_t *max_end_out);
 int spl_bam_wait_all(spl_bam *bam, int *sorted_out);
+/* spl_bam_close waits for a decode in progress to END.  A caller who only wants to leave (something else failed) says so first:
+ * after spl_bam_cancel the decoders stop at their next batch (host) or window (device), a decode that has not begun never
+ * does, and waiting calls return with an error. */
+void spl_bam_cancel(spl_bam *bam);
 void spl_bam_close(spl_bam *bam);
 int spl_bam_n_ref(const spl_bam *bam);
 const char *spl_bam_ref_name(const spl_bam *bam, int tid);

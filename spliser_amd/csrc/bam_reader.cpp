@@ -481,6 +481,7 @@ struct spl_bam {
     int n_threads = 1;
     // reads adopted from the device decoder without their host copies: fetched (dev_fetch) when somebody wants to read them
     bool lazy = false;
+    bool fetching = false;     // somebody is copying a share's reads to the host right now (fetch_lazy)
     int (*dev_fetch)(void *, int32_t **, uint16_t **, uint32_t **, uint32_t **) = nullptr;
     std::vector<int64_t> lazy_first;       // first record of every reference in the arrays of the share that holds it
     // what the device decoder(s) left in device memory for the device packer (spl_capi.cpp), and how to give it back: one handle
@@ -492,6 +493,7 @@ struct spl_bam {
     struct ShareResult { bool reported = false, failed = false; void *handle = nullptr; void (*free_fn)(void *) = nullptr; std::vector<int64_t> first, n, max_end; int64_t n_records = 0; };
     std::vector<ShareResult> share_results;
     bool shares_on_device = false;
+    std::atomic<bool> cancel{false};       // spl_bam_cancel: whoever decodes stops at the next batch / window; nobody starts
     bool reserved = false;     // claim == 1 on behalf of a spl_bam_decode_device call that is still to come
     int claim = 0;             // 0 = nobody decodes yet (deferred open), 1 = the device decoder is at it, 2 = host worker started / arrays adopted
     uint64_t header_bytes = 0; // magic, text and reference dictionary: the first record starts here in the inflated stream
@@ -871,6 +873,7 @@ void decode_worker(spl_bam *bam)
     };
     size_t n_batches = 0;
     for (size_t b = 0; fail.empty(); ++b) {
+        if (bam->cancel.load(std::memory_order_acquire)) { fail = "the file was closed while it was being decoded"; break; }
         BatchOut &o = ring[b % W];
         if (o.state.load(std::memory_order_acquire) != 1) {
             const double w0 = now();
@@ -1091,12 +1094,26 @@ static int open_file(const char *path, int n_threads, bool start_now, spl_bam **
 extern "C" int spl_bam_open_stream(const char *path, int n_threads, spl_bam **out) { return open_file(path, n_threads, true, out); }
 extern "C" int spl_bam_open_deferred(const char *path, int n_threads, spl_bam **out) { return open_file(path, n_threads, false, out); }
 
+// (call with bam->mu held) nobody will decode a file that is being closed: whoever waits is told so
+static bool cancelled_locked(spl_bam *bam)
+{
+    if (!bam->cancel.load(std::memory_order_acquire)) return false;
+    if (!bam->done) {
+        bam->claim = 2;
+        bam->err_code = SPL_ERR_IO;
+        bam->error = bam->path + ": closed before it was decoded";
+        bam->done = true;
+        bam->cv.notify_all();
+    }
+    return true;
+}
+
 // Decode on the host's threads unless somebody is decoding already (waits on a deferred file come through here).
 int spl_bam_start_host(spl_bam *bam)
 {
     if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_start_host: null argument");
     std::lock_guard<std::mutex> lock(bam->mu);
-    if (bam->claim == 0) { bam->claim = 2; bam->worker = std::thread(decode_worker, bam); }
+    if (bam->claim == 0 && !cancelled_locked(bam)) { bam->claim = 2; bam->worker = std::thread(decode_worker, bam); }
     return SPL_OK;
 }
 
@@ -1122,9 +1139,21 @@ extern "C" int spl_bam_reserve_device(spl_bam *bam)
 int spl_bam_device_gives_up(spl_bam *bam)
 {
     std::lock_guard<std::mutex> lock(bam->mu);
-    if (bam->claim == 1) { bam->claim = 2; bam->worker = std::thread(decode_worker, bam); }
+    if (bam->claim == 1 && !cancelled_locked(bam)) { bam->claim = 2; bam->worker = std::thread(decode_worker, bam); }
     return SPL_OK;
 }
+
+// The file is about to be closed: a decode in progress stops at its next batch (host threads) or window (device), a decode that
+// has not begun never does.  Waiting calls return with an error.  (spl_bam_close alone waits for the decode to END: minutes on a
+// large file when the caller only wants to leave, because something else failed.)
+extern "C" void spl_bam_cancel(spl_bam *bam)
+{
+    if (!bam) return;
+    bam->cancel.store(true, std::memory_order_release);
+    std::lock_guard<std::mutex> lock(bam->mu);
+    if (bam->claim == 0) (void)cancelled_locked(bam);
+}
+bool spl_bam_cancelled(const spl_bam *bam) { return bam->cancel.load(std::memory_order_acquire); }
 
 // Decode on the host's threads (public face of spl_bam_start_host: a deferred file whose caller has made up his mind).  A
 // reservation nobody has taken up (spl_bam_reserve_device, and then no spl_bam_decode_device: its caller failed on the way
@@ -1385,7 +1414,7 @@ int spl_bam_share_done(spl_bam *bam, int k, void *handle, void (*free_fn)(void *
         drop.swap(bam->share_results);
         bam->share_results.assign(drop.size(), spl_bam::ShareResult());
         for (spl_bam::ShareResult &x : bam->share_results) x.reported = true;
-        bam->worker = std::thread(decode_worker, bam);
+        if (!cancelled_locked(bam)) bam->worker = std::thread(decode_worker, bam);
         lock.unlock();
         for (spl_bam::ShareResult &x : drop) if (x.handle && x.free_fn) x.free_fn(x.handle);
         return SPL_OK;
@@ -1453,18 +1482,29 @@ void spl_bam_set_fetch(spl_bam *bam, int (*fetch)(void *, int32_t **, uint16_t *
     bam->dev_fetch = fetch;
 }
 
-// The host copies of reads that were adopted without them (call with bam->mu held): of every share that has not brought its yet.
-static int fetch_lazy(spl_bam *bam)
+// The host copies of reads that were adopted without them: of every share that has not brought its yet.  Called with bam->mu
+// held; the copy itself (gigabytes over PCIe) runs WITHOUT it -- whoever else wants a reference that is there already, or wants
+// to wait for one, is not kept out -- and a second caller waits for the first one's copy instead of making its own.
+static int fetch_lazy(spl_bam *bam, std::unique_lock<std::mutex> &lock)
 {
-    if (!bam->lazy) return SPL_OK;
-    if (!bam->dev_fetch || bam->dev_shares.empty()) return spl_set_error(SPL_ERR_ARG, "%s: decoded reads are neither on the host nor fetchable", bam->path.c_str());
-    for (spl_bam::DevShare &d : bam->dev_shares) {
-        if (d.fetched) continue;
+    for (;;) {
+        if (!bam->lazy) return SPL_OK;
+        if (!bam->dev_fetch || bam->dev_shares.empty()) return spl_set_error(SPL_ERR_ARG, "%s: decoded reads are neither on the host nor fetchable", bam->path.c_str());
+        if (bam->fetching) { bam->cv.wait(lock, [&]() { return !bam->fetching; }); continue; }
+        size_t k = 0;
+        while (k < bam->dev_shares.size() && bam->dev_shares[k].fetched) ++k;
+        if (k == bam->dev_shares.size()) { bam->lazy = false; return SPL_OK; }
+        bam->fetching = true;
+        void *const handle = bam->dev_shares[k].handle;
+        const int32_t tid_lo = bam->dev_shares[k].tid_lo, tid_hi = bam->dev_shares[k].tid_hi;
         int32_t *pos = nullptr; uint16_t *flag = nullptr; uint32_t *cig_off = nullptr, *cigar = nullptr;
-        const int rc = bam->dev_fetch(d.handle, &pos, &flag, &cig_off, &cigar);
-        if (rc) return rc;
+        lock.unlock();
+        const int rc = bam->dev_fetch(handle, &pos, &flag, &cig_off, &cigar);
+        lock.lock();
+        bam->fetching = false;
+        if (rc) { bam->cv.notify_all(); return rc; }
         bam->slabs.push_back(pos); bam->slabs.push_back(flag); bam->slabs.push_back(cig_off); bam->slabs.push_back(cigar);
-        for (int t = std::max(0, (int)d.tid_lo); t < bam->n_refs && t < d.tid_hi; ++t) {
+        for (int t = std::max(0, (int)tid_lo); t < bam->n_refs && t < tid_hi; ++t) {
             for (PendingPart *pp : bam->parts[(size_t)t]) {
                 RefReads &r = pp->reads;
                 const int64_t first = bam->lazy_first[(size_t)t];
@@ -1475,10 +1515,9 @@ static int fetch_lazy(spl_bam *bam)
                 r.n_ops = (size_t)(r.cig_off[r.n] - r.cig_off[0]);
             }
         }
-        d.fetched = true;
+        bam->dev_shares[k].fetched = true;
+        bam->cv.notify_all();
     }
-    bam->lazy = false;
-    return SPL_OK;
 }
 
 static int decode_status(spl_bam *bam) // (call with bam->mu held)
@@ -1549,8 +1588,8 @@ extern "C" int spl_bam_reads(const spl_bam *cbam, int tid, spl_reads *out, int64
     if (tid < 0 || tid >= bam->n_refs) return spl_set_error(SPL_ERR_ARG, "tid %d out of range", tid);
     int rc = spl_bam_wait_all(bam, nullptr); // (the whole file: these arrays must hold every record of the reference, sorted file or not)
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(bam->mu);
-    rc = fetch_lazy(bam);
+    std::unique_lock<std::mutex> lock(bam->mu);
+    rc = fetch_lazy(bam, lock);
     if (rc) return rc;
     if (!bam->assembled[(size_t)tid]) {
         std::string err;
@@ -1572,8 +1611,8 @@ int spl_bam_source(spl_bam *bam, int tid, splpack::Source *out, int64_t *max_end
     if (!bam || !out) return spl_set_error(SPL_ERR_ARG, "spl_bam_source: null argument");
     int rc = spl_bam_wait_ref(bam, tid, nullptr, max_end_out);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(bam->mu);
-    rc = fetch_lazy(bam);
+    std::unique_lock<std::mutex> lock(bam->mu);
+    rc = fetch_lazy(bam, lock);
     if (rc) return rc;
     for (const PendingPart *pt : bam->parts[(size_t)tid]) {
         const RefReads &r = pt->reads;

@@ -39,7 +39,8 @@ int spl_bam_share_get(spl_bam *bam, int k, spl_bam_share *out);
 // When the last share has reported the file is complete -- or, if one failed, everything is dropped and the host threads decode.
 int spl_bam_share_done(spl_bam *bam, int k, void *handle, void (*free_fn)(void *), const int64_t *ref_first, const int64_t *ref_n,
                        const int64_t *ref_max_end, int64_t n_records, int failed);
-int spl_bam_shares_on_device(spl_bam *bam);                  // 1: all shares reported and none failed
+int spl_bam_shares_on_device(spl_bam *bam);
+bool spl_bam_cancelled(const spl_bam *bam);                   // spl_bam_cancel was called: stop at the next window                  // 1: all shares reported and none failed
 // spl_bam_adopt with null arrays = the reads stay on the device; `fetch(handle, ...)` brings malloc'ed host copies when a host-side
 // reader asks for them (spl_bam_source, spl_bam_reads)
 void spl_bam_set_fetch(spl_bam *bam, int (*fetch)(void *, int32_t **, uint16_t **, uint32_t **, uint32_t **));

@@ -1502,6 +1502,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     for (size_t k = 0; k < n_win; ++k) {
         size_t b0, b1;
         win_range(k, b0, b1);
+        if (spl_bam_cancelled(bam)) return to_host("the file is being closed");
         // (a window's buffer is free again when the extraction of the window that had it is on stream B: windows k .. k + n_buf - 1 fit)
         while (launched < n_win && launched < k + (size_t)n_buf) {
             bool did = false;

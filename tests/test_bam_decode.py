@@ -229,3 +229,22 @@ def test_share_plan_cuts_at_reference_boundaries(built, tmp_path):
         if want >= 2:
             assert n.value >= 2                          # (five references of equal size: there is a cut to be found)
         bam.close()
+
+
+def test_close_does_not_wait_for_the_rest_of_the_file(built, tmp_path):
+    """Closing a file whose decode has only begun (the caller failed elsewhere) stops the decoders at their next batch
+    (spl_bam_cancel) instead of waiting for the whole file; a file nobody began to decode never is."""
+    import time
+    names, sets = _random_sets(3, 120_000, 2)
+    path = str(tmp_path / "c.bam")
+    native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=2, seq_mode=1)
+    t = time.perf_counter()
+    whole = native.BamFile(path, threads=1)
+    whole.close()
+    t_whole = time.perf_counter() - t
+    t = time.perf_counter()
+    bam = native.BamFile(path, threads=1, stream=True)
+    bam.close()
+    assert time.perf_counter() - t < max(0.05, 0.6 * t_whole)
+    late = native.BamFile(path, defer=True)
+    late.close()
