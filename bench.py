@@ -125,6 +125,27 @@ def strip_source(text):
     return re.sub(r"\s+", " ", text).strip()
 
 
+def reference_measured():
+    """What the REAL reference took in the build container (tools/time_reference.py, committed under profiles/): it cannot
+    travel to the GPU box, so its `Total runtime (s)` is quoted from there -- indicative only: samtools is a SAM-text shim."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_time_reference.txt")))
+    if not paths:
+        return None
+    try:
+        with open(paths[-1]) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    return {"label": "INDICATIVE, measured in the build container (not on this box): the unmodified SpliSER_v0_1_8.py process, one "
+                     "core; `samtools view` per site served by a SAM-text shim (oracle/refharness/samtools)",
+            "from": os.path.basename(paths[-1]), "host": doc.get("host"),
+            "cases": [{"name": c["name"], "reads": c["reads"],
+                       "total_runtime_s_child_process_per_site": c["child process per site (samtools shim)"]["total_runtime_s"],
+                       "total_runtime_s_in_process_replay": c["in-process replay"]["total_runtime_s"], "rows": c["in-process replay"]["rows"]}
+                      for c in doc.get("cases", [])]}
+
+
 def cpu_budget():
     """-> (hardware threads this process may run on, CPU-time quota of its cgroup in cores or None).  A box of this pool shows
     256 hardware threads and grants 16 cores' worth of CPU time: threads beyond the quota only get throttled."""
@@ -458,7 +479,8 @@ def main():
                    "reference_cost_model": {"estimate_seconds": n_sites * 1.7e-3 + pairs * 7.1e-6,
                                             "label": "ESTIMATE, not a measurement: S*1.7 ms (one samtools spawn per site) + P*7.1 us "
                                                      "(Python per counted (read, site) pair, P >= %d) for SpliSER v0.1.8 on one core "
-                                                     "(BASELINE.md; SpliSER_v0_1_8.py:422, :427-559)" % pairs}}
+                                                     "(BASELINE.md; SpliSER_v0_1_8.py:422, :427-559)" % pairs},
+                   "reference_measured": reference_measured()}
         if args.e2e == "auto":
             nproc, quota = cpu_budget()
             n_threads = max(1, min(nproc, int(round(quota)) if quota else nproc))

@@ -83,14 +83,15 @@ def beta2_sse(site_pos, part_off, part_pos, part_site, alpha, edge_cnt, beta1, b
     return b2s, b2c, b2w, sse
 
 
-def junction_table(r_pos, r_flag, cig_off, cigar, stranded=0):
+def junction_table(r_pos, r_flag, cig_off, cigar, stranded=0, min_anchor=0, min_intron=0, max_intron=0):
     """Plain-Python restatement of the junction table (checker for spl_junctions; small inputs only).
 
     Walks every read like checkBam walks its CIGAR (SpliSER_v0_1_8.py:457-483): M,=,X,D,N advance the cursor, an N op of
     length d ending at ``cur`` is the junction (cur-d-1, cur-1).  Records flagged unmapped (0x4) carry none.  Read strand
     by check_strand's rule (:374-406) when ``stranded`` is 1 (fr) or 2 (rf).  -> sorted list of
     (left, right, strand byte, count, anchor_left, anchor_right); anchors = reference bases of the read between the
-    junction and the neighbouring N op / read end, maximum over the reads.
+    junction and the neighbouring N op / read end, maximum over the reads.  ``min_anchor`` / ``min_intron`` / ``max_intron`` (0 =
+    no limit): a read counts for a junction only if both its anchors and the N op's length pass (regtools' -a / -m / -M).
     """
     table = {}
     for i in range(len(r_pos)):
@@ -120,8 +121,9 @@ def junction_table(r_pos, r_flag, cig_off, cigar, stranded=0):
                     break
                 if code2 in (0, 2, 7, 8):
                     after += d2
-            key = (cur - d - 1, cur - 1, strand)
-            c, a, b = table.get(key, (0, 0, 0))
-            table[key] = (c + 1, max(a, before), max(b, after))
+            if before >= min_anchor and after >= min_anchor and d >= min_intron and (max_intron == 0 or d <= max_intron):
+                key = (cur - d - 1, cur - 1, strand)
+                c, a, b = table.get(key, (0, 0, 0))
+                table[key] = (c + 1, max(a, before), max(b, after))
             before = 0
     return [k + table[k] for k in sorted(table)]

@@ -380,6 +380,60 @@ def build_combine(outroot, name="combine_a", seed=21):
         json.dump({"n_samples": len(samples), "variants": manifest}, fh, indent=1, sort_keys=True)
 
 
+# --------------------------------------------------------------------------------------
+# junction goldens: the BED12 file is the one the build's own `junctions` command wrote ON THE GPU from
+# the reads of another case (there is no regtools here to hold it against) -- what pins it is the real reference: its
+# findAlphaCounts must read that file (SpliSER_v0_1_8.py:259-277) into the sites, alpha counts and partners the build's table has.
+#   stage 1 (GPU box):   python tests/golden/make_golden.py --junction-beds gpurun_out/junction_beds
+#   stage 2 (container): copy each <case>.bed to tests/golden/<case>/junctions.bed, then the usual run (names: junctions_u junctions_fr)
+JUNCTION_CASES = {
+    "junctions_u": dict(reads_of="random_b", junctions={}, variants={"unstranded": {}, "cryptic": {"cryptic": True}}),
+    "junctions_fr": dict(reads_of="multichrom", junctions=dict(isStranded=True, strandedType="fr"),
+                         variants={"fr": {"stranded": "fr"}, "fr_cryptic": {"stranded": "fr", "cryptic": True}}),
+}
+JUNCTION_KNOBS = dict(minAnchor=1, minIntron=1, maxIntron=10 ** 9)   # (every N op: the goldens' reads are short)
+
+
+def write_junction_beds(outdir):
+    """Stage 1, on the GPU box: the `junctions` command on the reads of the source cases."""
+    sys.path.insert(0, ROOT)
+    from spliser_amd.junctions import junctions
+    os.makedirs(outdir, exist_ok=True)
+    for name, case in JUNCTION_CASES.items():
+        n = junctions(os.path.join(HERE, case["reads_of"], "reads.sam"), os.path.join(outdir, name + ".bed"), log=lambda m: None,
+                      **dict(JUNCTION_KNOBS, **case["junctions"]))
+        print("%s: %d junctions from the reads of %s" % (name, n, case["reads_of"]))
+
+
+def build_junction_cases(outroot, names=None):
+    manifest = {}
+    for name, case in JUNCTION_CASES.items():
+        if names and name not in names:
+            continue
+        bed = os.path.join(HERE, name, "junctions.bed")
+        if not os.path.exists(bed):
+            print("junction case %s: no junctions.bed yet (stage 1 runs on the GPU box)" % name)
+            continue
+        d = os.path.join(outroot, name)
+        os.makedirs(d, exist_ok=True)
+        if os.path.abspath(d) != os.path.abspath(os.path.join(HERE, name)):
+            shutil.copy(bed, os.path.join(d, "junctions.bed"))
+        shutil.copy(os.path.join(HERE, case["reads_of"], "reads.sam"), os.path.join(d, "reads.sam"))
+        manifest[name] = {}
+        for vname, v in case["variants"].items():
+            tmp = tempfile.mkdtemp()
+            try:
+                text, _ = run_reference.run_process(os.path.join(d, "reads.sam"), os.path.join(d, "junctions.bed"), os.path.join(tmp, "out"), inprocess=True,
+                                                    dump_json=os.path.join(d, "expected.%s.json" % vname), stranded=v.get("stranded"), cryptic=v.get("cryptic", False))
+            finally:
+                shutil.rmtree(tmp)
+            with open(os.path.join(d, "expected.%s.tsv" % vname), "w") as fh:
+                fh.write(text)
+            manifest[name][vname] = dict(v)
+            print("golden %-22s %-22s %4d rows" % (name, vname, text.count("\n") - 1))
+    return manifest
+
+
 def diff_tree(fresh, committed, label):
     """Every file of a regenerated case against the committed one, sub-directories included.  -> number of differences."""
     bad = 0
@@ -399,8 +453,12 @@ def diff_tree(fresh, committed, label):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--junction-beds", metavar="DIR", help="stage 1 of the junction goldens: run on the GPU box, writes <case>.bed into DIR")
     ap.add_argument("names", nargs="*")
     a = ap.parse_args()
+    if a.junction_beds:
+        write_junction_beds(a.junction_beds)
+        return
     if not run_reference.reference_available():
         sys.exit("reference not available at %s" % run_reference.REFERENCE_DIR)
     if a.check:
@@ -409,6 +467,7 @@ def main():
             names = [n for n in a.names if n != "combine_a"]
             if names or not a.names:
                 build(tmp, names or None, cross_check=False)
+                build_junction_cases(tmp, names or None)
             if not a.names or "combine_a" in a.names:
                 build_combine(tmp)          # process x 3 samples -> combine / combineShallow x 7 variants -> output x 2
             bad = 0
@@ -422,6 +481,7 @@ def main():
         if a.names == ["combine_a"]:
             return
     manifest = build(HERE, [n for n in a.names if n != "combine_a"] or None)
+    manifest.update(build_junction_cases(HERE, [n for n in a.names if n != "combine_a"] or None))
     mpath = os.path.join(HERE, "manifest.json")
     old = {}
     if a.names and os.path.exists(mpath):

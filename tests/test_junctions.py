@@ -95,3 +95,16 @@ def test_junctions_cli_feeds_process(ctx, tmp_path, oracle_lib):
     got = dr.junctions(0, 20, 0, 0)
     dr.free()
     assert len(got["left"]) <= len(want) and int(got["anchor_left"].min()) >= 20 and int(got["anchor_right"].min()) >= 20
+
+
+def test_junctions_command_writes_the_golden_beds(tmp_path):
+    """The BED12 files the REAL reference was run on (tests/golden/junctions_*: its findAlphaCounts read them into the sites and
+    alpha counts of expected.*.tsv) are what the `junctions` command writes from the same reads today, byte for byte."""
+    import sys
+    sys.path.insert(0, helpers.GOLDEN)
+    from make_golden import JUNCTION_CASES, JUNCTION_KNOBS
+    from spliser_amd.junctions import junctions
+    for name, case in JUNCTION_CASES.items():
+        out = str(tmp_path / (name + ".bed"))
+        junctions(os.path.join(helpers.GOLDEN, case["reads_of"], "reads.sam"), out, log=lambda m: None, **dict(JUNCTION_KNOBS, **case["junctions"]))
+        assert open(out).read() == open(os.path.join(helpers.GOLDEN, name, "junctions.bed")).read()

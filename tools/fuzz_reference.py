@@ -9,6 +9,12 @@ same files: TSV byte for byte, counters equal, doubles bit-identical.
 
     python tools/fuzz_reference.py FIRST LAST [--jobs N]      -> a summary line; exit 1 on the first mismatch
 
+``--combine``: 2-4 random samples per seed (tests/golden/make_golden.py's generator: one gene model, sample-specific junctions and
+reads) through the real reference's `process`, then its `combine` and `combineShallow` (random -m / -r / -e), for {unstranded, fr,
+rf} -- against the product's host walk over the same per-sample files (spliser_amd.combine: region order, lock-step merge with
+its order dependence, SpliSER_v0_1_8.py:869-904, query snapshots, writers) with the oracle answering the gap-fill queries:
+.combined.tsv byte for byte.
+
 Needs /root/reference: never runs on the GPU box; nothing of the reference is copied anywhere (inputs are synthesised, outputs
 compared and dropped).
 """
@@ -90,11 +96,74 @@ def one_seed(seed):
     return (runs, reads)
 
 
+def one_combine_seed(seed):
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    import run_reference
+    from oracle import oracle
+    from spliser_amd import combine as cmb
+    from spliser_amd import process as proc
+    rng = random.Random(seed * 31 + 5)
+    n_samples = rng.randint(2, 4)
+    samples, gff = make_golden.combine_case(seed, n_samples)
+    runs = 0
+    tmp = tempfile.mkdtemp(prefix="spl_fuzzcmb_")
+    try:
+        for k, (reads, juncs) in enumerate(samples):
+            make_golden.write_case(os.path.join(tmp, "sample%d" % k), reads, juncs, gff=gff)
+        for stype in (None, "fr", "rf"):
+            cryptic = bool(stype) and rng.random() < 0.5
+            lines = []
+            for k in range(n_samples):
+                sd = os.path.join(tmp, "sample%d" % k)
+                run_reference.run_process(os.path.join(sd, "reads.sam"), os.path.join(sd, "junctions.bed"), os.path.join(tmp, "s%d_%s" % (k, stype)),
+                                          inprocess=True, stranded=stype, cryptic=cryptic)
+                lines.append("S%d\t%s\t%s\n" % (k, os.path.join(tmp, "s%d_%s.SpliSER.tsv" % (k, stype)), os.path.join(sd, "reads.sam")))
+            sfile = os.path.join(tmp, "samples_%s.tsv" % stype)
+            with open(sfile, "w") as fh:
+                fh.writelines(lines)
+            base = (["--isStranded", "-s", stype] if stype else []) + (["--beta2Cryptic"] if cryptic else [])
+            m, r, e = rng.randint(0, n_samples), rng.randint(0, 6), rng.choice([0.0, 0.1, 0.3])
+            for command, extra, shallow in (("combine", [], None), ("combineShallow", ["-m", str(m), "-r", str(r), "-e", str(e)], (m, r, e))):
+                out_ref = os.path.join(tmp, "ref_%s_%s" % (stype, command))
+                rc, log = run_reference.run_cli([command, "-S", sfile, "-o", out_ref] + base + extra, inprocess=True)
+                if rc != 0:
+                    return "reference %s failed, seed %d: %s" % (command, seed, log[-400:])
+                titles, tsvs, bams = cmb.read_samples_file(sfile)
+                rows = [cmb._parse_tsv(p) for p in tsvs]
+                chroms = cmb.region_order(rows)
+                merged = cmb.merge_sites(rows, chroms, len(titles), bool(stype), "All", shallow=shallow)
+                scode = {None: 0, "fr": 1, "rf": 2}[stype]
+                results = {}
+                for idx, queries in cmb.gap_queries(merged).items():
+                    source = proc.open_alignments(bams[idx])
+                    table = cmb._QueryTable(queries)
+                    for chrom in table.chrom_index:
+                        st, rd = table.chrom_arrays(chrom), source.reads(chrom)
+                        if rd is None or rd.n == 0:
+                            b1 = b2 = [0] * st.n
+                        else:
+                            b1, b2, _ = oracle.check_bam(st.pos, st.strand, st.part_off, st.part_pos, st.comp_off, st.comp_pos, rd.pos, rd.flag,
+                                                         rd.cig_off, rd.cigar, scode, 1)
+                        for j, si in enumerate(table.site_index[chrom]):
+                            results[(si, idx)] = (int(b1[j]), int(b2[j]))
+                mine = os.path.join(tmp, "mine_%s_%s.combined.tsv" % (stype, command))
+                cmb.write_combined(mine, merged, titles, results, cryptic)
+                if open(mine).read() != open(out_ref + ".combined.tsv").read():
+                    return "MISMATCH (%s) seed %d stranded %s cryptic %s shallow %r, %d samples" % (command, seed, stype, cryptic, shallow, n_samples)
+                runs += 1
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return (runs, n_samples)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("first", type=int)
     ap.add_argument("last", type=int)
     ap.add_argument("--jobs", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--combine", action="store_true", help="the real reference's combine / combineShallow against the product's host walk")
     a = ap.parse_args()
     import run_reference
     if not run_reference.reference_available():
@@ -104,6 +173,20 @@ def main():
     t0 = time.time()
     import multiprocessing
     runs = reads = 0
+    if a.combine:
+        samples = 0
+        with multiprocessing.get_context("fork").Pool(a.jobs) as pool:
+            for res in pool.imap_unordered(one_combine_seed, range(a.first, a.last), chunksize=2):
+                if isinstance(res, str):
+                    print(res)
+                    pool.terminate()
+                    sys.exit(1)
+                runs += res[0]
+                samples += res[1]
+        print("reference combine fuzz ok: seeds %d..%d x {unstranded, fr, rf} x {combine, combineShallow with random -m -r -e}: %d runs of "
+              "SpliSER_v0_1_8.py combine / combineShallow over %d samples (2-4 per seed, each through the reference's process first), "
+              ".combined.tsv byte-identical to spliser_amd.combine's host walk with the oracle's gap fill, %.0f s" % (a.first, a.last, runs, samples, time.time() - t0))
+        return
     with multiprocessing.get_context("fork").Pool(a.jobs) as pool:
         for res in pool.imap_unordered(one_seed, range(a.first, a.last), chunksize=4):
             if isinstance(res, str):
