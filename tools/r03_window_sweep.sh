@@ -7,6 +7,7 @@ cd $R
 python tools/e2e_profile.py human --seq-mode 1 --scale $SCALE --auto-decode --runs 1 > gpurun_out/${TAG}_warm.log 2>&1
 F=/tmp/wl_files/human_s${SCALE}_q1.bam
 for W in "$@"; do
+  rm -rf /tmp/ws_$W
   (cd /tmp && SPL_INFLATE_WINDOW_BLOCKS=$W rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ws_$W -- python3 $R/tools/gpu_decode_steps.py $F > $R/gpurun_out/${TAG}_W$W.log 2>&1)
   python3 - $W $(find /tmp/ws_$W -name '*kernel_stats.csv' | head -1) <<'PY'
 import csv, sys
