@@ -123,6 +123,7 @@ struct Block {
     uint32_t csize; // whole block
     uint32_t xlen;
     uint32_t isize; // uncompressed payload
+    uint32_t crc;   // of the payload, as the block's trailer says (read with ISIZE: whoever wants it later would miss the cache again)
 };
 
 // The file's BGZF blocks, found by walking the block headers from the start (each header says where the next block begins).
@@ -171,7 +172,7 @@ bool walk_blocks(BlockDir &dir, const uint8_t *file, size_t fsize, const char *p
         }
         if (!have || bsize < 12 + xlen + 8 || fsize - off < bsize) return failed(SPL_ERR_FORMAT, "corrupt or truncated BGZF block", off);
         Block b;
-        b.coff = off; b.uoff = dir.uoff; b.csize = bsize; b.xlen = xlen; b.isize = le32(file + off + bsize - 4);
+        b.coff = off; b.uoff = dir.uoff; b.csize = bsize; b.xlen = xlen; b.isize = le32(file + off + bsize - 4); b.crc = le32(file + off + bsize - 8);
         if (b.isize > 65536) return failed(SPL_ERR_FORMAT, "BGZF ISIZE > 64 KiB", off);
         if (n / BlockDir::CHUNK >= dir.chunks.size()) return failed(SPL_ERR_FORMAT, "more BGZF blocks than the file has room for", off);
         Block *&chunk = dir.chunks[n / BlockDir::CHUNK];
@@ -220,7 +221,7 @@ bool block_at(const uint8_t *file, size_t fsize, size_t off, Block &b)
         x += 4 + slen;
     }
     if (!have || bsize < 12 + xlen + 8 || fsize - off < bsize) return false;
-    b.coff = off; b.uoff = 0; b.csize = bsize; b.xlen = xlen; b.isize = le32(file + off + bsize - 4);
+    b.coff = off; b.uoff = 0; b.csize = bsize; b.xlen = xlen; b.isize = le32(file + off + bsize - 4); b.crc = le32(file + off + bsize - 8);
     return b.isize <= 65536;
 }
 
@@ -267,7 +268,7 @@ bool walk_rest_in_parallel(BlockDir &dir, const uint8_t *file, size_t fsize, int
     size_t least = (size_t)64 << 20; // (below this the one-thread walk is done before the threads have started)
     if (const char *e = getenv("SPL_WALK_PARALLEL_MIN")) least = (size_t)std::max(4096ll, atoll(e));
     if (dir.state.load() != 0 || from >= fsize || fsize - from < least) return false;
-    const size_t T = std::min<size_t>((size_t)std::max(2, std::min(n_threads, 8)), (fsize - from) / (least / 4));
+    const size_t T = std::min<size_t>((size_t)std::max(2, std::min(n_threads, 32)), (fsize - from) / (least / 4));
     if (T < 2) return false;
     std::vector<Stretch> st(T);
     const size_t span = (fsize - from + T - 1) / T;
@@ -1206,12 +1207,11 @@ size_t spl_bam_block_count(const spl_bam *bam) { return bam->dir.n_ready.load();
 void spl_bam_block_get(const spl_bam *bam, size_t i, spl_bam_block_info *out)
 {
     const Block &b = bam->dir.at(i);
-    const uint8_t *file = (const uint8_t *)bam->map;
     out->data_off = b.coff + 12 + b.xlen;
     out->data_len = b.csize - 12 - b.xlen - 8;
     out->uoff = b.uoff;
     out->isize = b.isize;
-    out->crc = le32(file + b.coff + b.csize - 8);
+    out->crc = b.crc;
 }
 void spl_bam_set_device_reads(spl_bam *bam, void *handle, void (*free_fn)(void *))
 {

@@ -14,6 +14,7 @@
 #include <new>
 #include <string>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -1267,9 +1268,9 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     constexpr int NBUF = 2, NCOPY = 1; // (measured twice: four buffers with two windows' copies side by side take longer, 0.68-0.80 s against 0.51-0.58 s for a 14 GB file -- two copying kernels at once get in each other's way in the memory system)
     DevBuf d_image, d_stream[NBUF], d_zwork[NBUF], d_blocks, d_status, d_scan, d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
     std::vector<spl_zblock> blocks;
-    std::vector<uint32_t> status;
-    std::vector<spl_bscan> scan;
-    std::vector<uint64_t> rec_off, op_off;
+    std::unique_ptr<uint32_t[]> status;
+    std::unique_ptr<spl_bscan[]> scan;
+    std::unique_ptr<uint64_t[]> rec_off, op_off;
     std::vector<unsigned long long> maxend;
     std::vector<uint64_t> bounds;
     uint32_t n_bounds = 0;
@@ -1370,6 +1371,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         if (walk_rc) return to_host("block directory");
         fill_whole(bam, sh);
     }
+    const double t_walked = host_now() - t_begin;
     const size_t n_blocks_file = spl_bam_block_count(bam);
     const size_t lo = (size_t)sh.block_lo, hi = (size_t)sh.block_hi, n_blocks = hi - lo;
     if (n_blocks == 0 || n_blocks > 0xfffffff0ull) return to_host("no blocks");
@@ -1380,16 +1382,23 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         spl_bam_block_get(bam, lo + i, &bi);
         blocks[i].in = bi.data_off; blocks[i].out = bi.uoff; blocks[i].in_len = bi.data_len; blocks[i].out_len = bi.isize; blocks[i].crc = bi.crc; blocks[i].pad = 0;
     }
+    const double t_blocks = host_now() - t_begin;
     const uint64_t stream_begin = blocks[0].out, stream_len = blocks[n_blocks - 1].out + blocks[n_blocks - 1].out_len; // (of the share; offsets are the file's)
     // ---- windows
     size_t win_blocks = (size_t)49152;
     if (const char *e = getenv("SPL_INFLATE_WINDOW_BLOCKS")) win_blocks = (size_t)std::max(2, atoi(e));
     win_blocks = std::min(win_blocks, n_blocks);
-    const size_t n_win = (n_blocks + win_blocks - 1) / win_blocks;
+    // The first windows are short ones: nothing runs behind the first window's decoding kernel until it is through, nor behind
+    // its copying kernel, so the pipeline is filled with an eighth, a quarter and a half of a window before the whole ones.
+    std::vector<size_t> win_at(1, 0);
+    if (win_blocks >= 8 && !getenv("SPL_INFLATE_NO_RAMP"))
+        for (size_t part = win_blocks / 8; part < win_blocks && win_at.back() + part + win_blocks < n_blocks; part *= 2) win_at.push_back(win_at.back() + part);
+    while (win_at.back() < n_blocks) win_at.push_back(std::min(n_blocks, win_at.back() + win_blocks));
+    const size_t n_win = win_at.size() - 1;
     const uint64_t HEAD = (uint64_t)8 << 20; // room in front of a window's bytes for what the window before left unfinished
     uint64_t win_cap = 0;
     for (size_t k = 0; k < n_win; ++k) {
-        const size_t b0 = k * win_blocks, b1 = std::min(n_blocks, b0 + win_blocks);
+        const size_t b0 = win_at[k], b1 = win_at[k + 1];
         win_cap = std::max(win_cap, blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out);
     }
     uint32_t match_stride = 0;
@@ -1413,10 +1422,13 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     const uint32_t cap = (uint32_t)std::max(n_ref, 1) * 4u + 64u;
     HIP_TRY(d_bounds.get(16 * (size_t)cap, c->copy));
     HIP_TRY(d_nbounds.get(4, c->copy));
-    status.assign(n_blocks, 0);
-    scan.resize(n_blocks);
-    rec_off.assign(n_blocks + 1, 0);
-    op_off.assign(n_blocks + 1, 0);
+    const double t_bufs = host_now() - t_begin;
+    status.reset(new (std::nothrow) uint32_t[n_blocks]); // (four arrays the device fills window by window: not zeroed first, that was 10 ms of a large file's start)
+    scan.reset(new (std::nothrow) spl_bscan[n_blocks]);
+    rec_off.reset(new (std::nothrow) uint64_t[n_blocks + 1]);
+    op_off.reset(new (std::nothrow) uint64_t[n_blocks + 1]);
+    if (!status || !scan || !rec_off || !op_off) return spl_set_error(SPL_ERR_NOMEM, "out of host memory");
+    rec_off[0] = op_off[0] = 0;
     HIP_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), sizeof(spl_zblock) * n_blocks, hipMemcpyHostToDevice, pipe.b));
     HIP_TRY(hipMemsetAsync(d_status.p, 0xff, 4 * n_blocks, pipe.b));
     HIP_TRY(hipMemsetAsync(d_maxend.p, 0, 8 * (size_t)std::max(n_ref, 1), pipe.b));
@@ -1460,7 +1472,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     // the Huffman decoding of window k on stream A, behind the pieces of the file it reads and behind whoever last used its buffer
     const uint8_t *const image0 = d_image.as<uint8_t>() - byte_lo; // (indexed with offsets into the file)
     size_t pieces_waited = 0;
-    auto win_range = [&](size_t k, size_t &b0, size_t &b1) { b0 = k * win_blocks; b1 = std::min(n_blocks, b0 + win_blocks); };
+    auto win_range = [&](size_t k, size_t &b0, size_t &b1) { b0 = win_at[k]; b1 = win_at[k + 1]; };
     auto stream0_of = [&](size_t k) { size_t b0, b1; win_range(k, b0, b1); return d_stream[k % (size_t)n_buf].as<uint8_t>() + HEAD - blocks[b0].out; }; // (indexed with offsets into the whole stream)
     auto launch_decode = [&](size_t k, bool wait, bool &launched_it) -> int {
         size_t b0, b1;
@@ -1499,6 +1511,8 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     int32_t last_tid = -1;
     size_t carry = 0; // the first block whose records are not all extracted yet
     size_t launched = 0; // windows whose decoding has been put on its streams
+    std::vector<double> t_win; // (SPL_BAM_TIMING: when each window's scan was back on the host)
+    const double t_setup = host_now() - t_begin;
     for (size_t k = 0; k < n_win; ++k) {
         size_t b0, b1;
         win_range(k, b0, b1);
@@ -1525,9 +1539,10 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             HIP_TRY((hipError_t)spl_dev_launch_bam_scan(stream0, win_end, H, n_ref, sh.tid_lo, sh.tid_hi, d_blocks.as<spl_zblock>() + s0, (uint32_t)(b1 - s0), d_scan.as<spl_bscan>() + s0,
                                                         more ? 1 : 0, pipe.b));
         }
-        HIP_TRY(hipMemcpyAsync(status.data() + b0, d_status.as<uint32_t>() + b0, 4 * (size_t)nb, hipMemcpyDeviceToHost, pipe.b));
-        HIP_TRY(hipMemcpyAsync(scan.data() + s0, d_scan.as<spl_bscan>() + s0, sizeof(spl_bscan) * (b1 - s0), hipMemcpyDeviceToHost, pipe.b));
+        HIP_TRY(hipMemcpyAsync(status.get() + b0, d_status.as<uint32_t>() + b0, 4 * (size_t)nb, hipMemcpyDeviceToHost, pipe.b));
+        HIP_TRY(hipMemcpyAsync(scan.get() + s0, d_scan.as<spl_bscan>() + s0, sizeof(spl_bscan) * (b1 - s0), hipMemcpyDeviceToHost, pipe.b));
         HIP_TRY(hipStreamSynchronize(pipe.b));
+        if (timing) t_win.push_back(host_now() - t_begin);
         for (size_t i = b0; i < b1; ++i)
             if (status[i] != SPL_Z_OK) return to_host("a block did not inflate (or its CRC32 is wrong)");
         // Which of the window's blocks are done with: all whose records end inside it.  A block near the window's end may have
@@ -1574,9 +1589,9 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             n_rec = rec_off[b_done];
             n_ops = op_off[b_done];
             const size_t nd = b_done - s0;
-            HIP_TRY(hipMemcpyAsync(d_recoff.as<uint64_t>() + s0, rec_off.data() + s0, 8 * nd, hipMemcpyHostToDevice, pipe.b));
-            HIP_TRY(hipMemcpyAsync(d_opoff.as<uint64_t>() + s0, op_off.data() + s0, 8 * nd, hipMemcpyHostToDevice, pipe.b));
-            HIP_TRY(hipMemcpyAsync(d_scan.as<spl_bscan>() + s0, scan.data() + s0, sizeof(spl_bscan) * nd, hipMemcpyHostToDevice, pipe.b));
+            HIP_TRY(hipMemcpyAsync(d_recoff.as<uint64_t>() + s0, rec_off.get() + s0, 8 * nd, hipMemcpyHostToDevice, pipe.b));
+            HIP_TRY(hipMemcpyAsync(d_opoff.as<uint64_t>() + s0, op_off.get() + s0, 8 * nd, hipMemcpyHostToDevice, pipe.b));
+            HIP_TRY(hipMemcpyAsync(d_scan.as<spl_bscan>() + s0, scan.get() + s0, sizeof(spl_bscan) * nd, hipMemcpyHostToDevice, pipe.b));
             splprof::Scope p("spl_bam_extract_kernel", pipe.b, (double)(blocks[b_done - 1].out + blocks[b_done - 1].out_len - blocks[s0].out));
             HIP_TRY((hipError_t)spl_dev_launch_bam_extract(stream0, win_end, n_ref, sh.tid_lo, sh.tid_hi, d_blocks.as<spl_zblock>() + s0, (uint32_t)nd, d_scan.as<spl_bscan>() + s0,
                                                            d_recoff.as<uint64_t>() + s0, d_opoff.as<uint64_t>() + s0, d_pos.as<int32_t>(), d_flag.as<uint16_t>(),
@@ -1626,6 +1641,11 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     res.n_all = n_all;
     if (timing) fprintf(stderr, "[spl_bam_decode_device] device %d: blocks %zu..%zu, %.1f MB -> %.1f MB inflated in %zu window%s, %llu placed records of %lld: %.4f s\n", c->device, lo, hi,
                         n_bytes / 1e6, (stream_len - stream_begin) / 1e6, n_win, n_win == 1 ? "" : "s", (unsigned long long)n_rec, (long long)n_all, host_now() - t_begin);
+    if (timing) {
+        fprintf(stderr, "[spl_bam_decode_device] device %d: directory at %.4f s, block list %.4f, buffers %.4f, set up %.4f; windows scanned at", c->device, t_walked, t_blocks, t_bufs, t_setup);
+        for (double t : t_win) fprintf(stderr, " %.3f", t);
+        fprintf(stderr, " s\n");
+    }
     return SPL_OK;
 }
 

@@ -384,8 +384,13 @@ def _blob(texts):
     return b"".join(enc), off
 
 
-def tsv_append(path, arr, res, cryptic):
-    """Rows of one chromosome appended to ``path`` by ``spl_tsv_append`` (same bytes as tsv.format_chrom)."""
+def tsv_prepare(arr):
+    """What ``spl_tsv_append`` wants of a chromosome's rows that no count changes -- the strand and gene texts as blobs, the
+    table's columns as the integers it reads -- made once and kept on ``arr``: ``process`` has this done while the alignment
+    file is still being decoded, so that only the formatting itself is left when the counts arrive."""
+    st = getattr(arr, "_tsv_static", None)
+    if st is not None:
+        return st
     if getattr(arr, "_strand_text", 0) is None:      # (a table built from arrays: the texts follow from the arrays, no list of str)
         codes = np.ascontiguousarray(arr.strand, np.uint8)
         there = codes != 0
@@ -406,19 +411,26 @@ def tsv_append(path, arr, res, cryptic):
     else:
         gene_blob, gene_off = _blob(arr.genes)
     c64 = lambda a: np.ascontiguousarray(a, np.int64)   # noqa: E731
-    pos, alpha = c64(arr.pos), c64(arr.alpha)
+    st = dict(strand_blob=strand_blob, strand_off=strand_off, gene_blob=gene_blob, gene_off=gene_off, pos=c64(arr.pos), alpha=c64(arr.alpha),
+              part_off=np.ascontiguousarray(arr.part_off, np.uint32), comp_off=np.ascontiguousarray(arr.comp_off, np.uint32),
+              part_pos=c64(arr.part_pos), edge_cnt=c64(arr.edge_cnt), comp_pos=c64(arr.comp_pos), chrom=arr.chrom.encode("utf-8"))
+    arr._tsv_static = st
+    return st
+
+
+def tsv_append(path, arr, res, cryptic):
+    """Rows of one chromosome appended to ``path`` by ``spl_tsv_append`` (same bytes as tsv.format_chrom)."""
+    st = tsv_prepare(arr)
+    c64 = lambda a: np.ascontiguousarray(a, np.int64)   # noqa: E731
     beta1 = np.ascontiguousarray(res["beta1"], np.uint32)
     b2s = c64(res["beta2_simple"])
     sse = np.ascontiguousarray(res["sse"], np.float64)
     b2c = c64(res["beta2_cryptic"]) if cryptic else None
     b2w = np.ascontiguousarray(res["beta2_weighted"], np.float64) if cryptic else None
-    part_off = np.ascontiguousarray(arr.part_off, np.uint32)
-    comp_off = np.ascontiguousarray(arr.comp_off, np.uint32)
-    part_pos, edge_cnt, comp_pos = c64(arr.part_pos), c64(arr.edge_cnt), c64(arr.comp_pos)
-    _check(lib().spl_tsv_append(os.fsencode(path), arr.chrom.encode("utf-8"), ctypes.c_int64(arr.n), _ptr(pos), strand_blob,
-                                _ptr(strand_off), gene_blob, _ptr(gene_off), _ptr(sse), _ptr(alpha), _ptr(beta1), _ptr(b2s),
-                                ctypes.c_int(1 if cryptic else 0), _ptr(b2c), _ptr(b2w), _ptr(part_off), _ptr(part_pos),
-                                _ptr(edge_cnt), _ptr(comp_off), _ptr(comp_pos)))
+    _check(lib().spl_tsv_append(os.fsencode(path), st["chrom"], ctypes.c_int64(arr.n), _ptr(st["pos"]), st["strand_blob"],
+                                _ptr(st["strand_off"]), st["gene_blob"], _ptr(st["gene_off"]), _ptr(sse), _ptr(st["alpha"]), _ptr(beta1), _ptr(b2s),
+                                ctypes.c_int(1 if cryptic else 0), _ptr(b2c), _ptr(b2w), _ptr(st["part_off"]), _ptr(st["part_pos"]),
+                                _ptr(st["edge_cnt"]), _ptr(st["comp_off"]), _ptr(st["comp_pos"])))
 
 
 def write_bam(path, ref_names, ref_lengths, read_sets, level=1, threads=0, seq_mode=0):

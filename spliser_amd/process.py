@@ -48,6 +48,19 @@ def open_alignments(path, threads=0, stream=False, defer=False):
     raise native.SpliserNativeError(-5, "%s is neither BGZF/BAM nor SAM text" % path)
 
 
+_closers = []
+
+
+def wait_deferred_close():
+    """``process`` hands the closing of its alignment file to a thread of its own and returns; this waits for all of them (a
+    caller that times calls back to back, so that one call's unmapping does not run into the next one's opening).  Returns the
+    seconds waited."""
+    t0 = time.perf_counter()
+    while _closers:
+        _closers.pop().join()
+    return time.perf_counter() - t0
+
+
 def open_and_decode(path, devices, gpuDecode=None, threads=0):
     """The alignment file opened and its decode started: on the GPU(s) -- with several devices every one inflates and extracts
     the stretch of the file that holds its own references (``BamFile.decode_on_devices_async``), and counts them -- or, told so
@@ -89,7 +102,7 @@ def junction_consistency(arr, junctions, offset, is_stranded):
 
 
 def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_cryptic, devices=(0,), combine_mode=0,
-                  log=_log, timings=None, on_result=None, on_junctions=None):
+                  log=_log, timings=None, on_result=None, on_junctions=None, on_tables=None):
     """processSites (SpliSER_v0_1_8.py:681-692) for every chromosome.
 
     One thread and one context per device; the chromosomes of a device share ONE site table in one coordinate space
@@ -122,6 +135,8 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
         if not present:
             log("  (no reference named %s in the alignment file: all beta counts are 0)" % chrom)
         items[chrom] = (arr, reads, present)
+    if on_tables is not None:      # (whoever formats the rows later: these are the tables they will come from)
+        on_tables([a for a, _, _ in items.values()])
     # Which device takes which chromosome is decided before the reads are known (they may still be on their way): the junction
     # read counts of the BED file say where the spliced reads are.
     weights = {c: (r.n if r is not None else int(a.alpha.sum())) + a.n for c, (a, r, _) in items.items()}
@@ -183,9 +198,14 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
         stamp("start")
         with native.Context(device) as ctx:
             stamp("context")
-            for sh in shards:
-                with ctx.upload_sites(sh.sites) as ds:
-                    stamp("site table up")
+            tables = []
+            try:
+                # every shard's site table goes up first: building one is host work (the junction table) that fits beside the
+                # decode, which is still running -- between two shards' counting passes it was 75 ms of an idle device
+                for sh in shards:
+                    tables.append(ctx.upload_sites(sh.sites))
+                stamp("site tables up")
+                for sh, ds in zip(shards, tables):
                     if whole is None:
                         whole = bool(device_decode and source.join_decoders())
                         stamp("decoder joined")
@@ -242,6 +262,9 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                             out[chrom] = (items[chrom][0], res)
                         if on_result is not None:
                             on_result(chrom, items[chrom][0], res)
+            finally:
+                for ds in tables:
+                    ds.free()
 
     threads = [threading.Thread(target=run, args=(dev, chroms)) for dev, chroms in zip(devices, plan)]
     for t in threads:
@@ -270,10 +293,22 @@ class _TsvWriter(object):
         self.closing = False
         self.error = None
         self.seconds = 0.0
+        self.prep = None
         with open(self.path, "w") as fh:
             fh.write(tsv.HEADER)
         self.thread = threading.Thread(target=self._run)
         self.thread.start()
+
+    def expect(self, arrays):
+        """The chromosomes' tables, known before their counts are: what the rows hold of them (texts, the table's own columns) is
+        made ready now, on a thread of its own, beside the counting (``native.tsv_prepare``)."""
+        def run():
+            for arr in arrays:
+                if self.closing:
+                    return
+                native.tsv_prepare(arr)
+        self.prep = threading.Thread(target=run)
+        self.prep.start()
 
     def add(self, chrom, arr, res):
         with self.cond:
@@ -308,6 +343,8 @@ class _TsvWriter(object):
             self.closing = True
             self.cond.notify()
         self.thread.join()
+        if self.prep is not None:
+            self.prep.join()
         if self.error is not None:
             raise self.error
         if missing:
@@ -320,6 +357,8 @@ class _TsvWriter(object):
             self.closing = True
             self.cond.notify()
         self.thread.join()
+        if self.prep is not None:
+            self.prep.join()
 
 
 def write_tsv(output_path, table, results, is_beta2_cryptic):
@@ -359,7 +398,7 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
         jrows = {}
         try:
             results = process_sites(table, source, qChrom, isStranded, strandedType, isbeta2Cryptic, devices=devices, log=log,
-                                    timings=timings, on_result=writer.add,
+                                    timings=timings, on_result=writer.add, on_tables=writer.expect,
                                     on_junctions=(lambda c, rows: jrows.__setitem__(c, rows)) if checkJunctions else None)
             if isinstance(source, native.BamFile) and not source.wait_all():
                 # records of an earlier reference after a later one: chromosomes were counted before they were complete.  (samtools
@@ -369,7 +408,7 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
                 writer = _TsvWriter(outputPath, table, isbeta2Cryptic)
                 jrows = {}
                 results = process_sites(table, source, qChrom, isStranded, strandedType, isbeta2Cryptic, devices=devices, log=lambda m: None,
-                                        timings=timings, on_result=writer.add,
+                                        timings=timings, on_result=writer.add, on_tables=writer.expect,
                                         on_junctions=(lambda c, rows: jrows.__setitem__(c, rows)) if checkJunctions else None)
         except BaseException:
             writer.abandon()
@@ -393,7 +432,9 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
         if hasattr(source, "close"):
             # (closing a decoded BAM gives gigabytes of read arrays back to the system -- a tenth of a second for 200 M reads --
             #  and nobody is waiting for that: on a thread of its own)
-            threading.Thread(target=source.close).start()
+            closer = threading.Thread(target=source.close)
+            closer.start()
+            _closers.append(closer)
     timings["bam_decode"] = "device" if getattr(source, "on_device", False) else "host"
     timings.update(open_s=t_open - t0, site_table_s=t1 - t_open, step3_s=t3 - t1, write_tail_s=t4 - t3, write_s=writer.seconds,
                    close_s=time.perf_counter() - t4, total_s=time.perf_counter() - t0)

@@ -222,7 +222,7 @@ class ChromArrays(object):
     builder made the table; the array builder (fast_sites) leaves ``gene_idx`` (row -> index into ``gene_names``, -1 = NA) and
     the strand bytes instead, and the lists come into being only if somebody asks for them."""
     __slots__ = ("chrom", "n", "pos", "strand", "part_off", "part_pos", "part_site", "edge_cnt",
-                 "comp_off", "comp_pos", "alpha", "_genes", "_strand_text", "gene_idx", "gene_names")
+                 "comp_off", "comp_pos", "alpha", "_genes", "_strand_text", "gene_idx", "gene_names", "_tsv_static")
 
     def __init__(self):
         self._genes = self._strand_text = self.gene_idx = self.gene_names = None

@@ -54,5 +54,6 @@ for k in range(args.runs):
                          strandedType=stranded, isbeta2Cryptic=bool(stranded), log=lambda m: None,
                          devices=tuple(int(d) for d in args.devices.split(",")), gpuDecode=None if args.auto_decode else args.gpu_decode)
     wall = time.perf_counter() - t
+    tm["deferred_close_s"] = process.wait_deferred_close()
     print(json.dumps(dict(run=k, workload=args.workload, reads=n_reads, wall_s=round(wall, 4), reads_per_sec=round(n_reads / wall),
                           bam_bytes=os.path.getsize(prefix + ".bam"), gpu_decode="auto" if args.auto_decode else args.gpu_decode, decoder=tm.pop("bam_decode", None), stages={a: round(b, 4) for a, b in tm.items()})), flush=True)
