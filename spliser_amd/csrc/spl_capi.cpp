@@ -1265,7 +1265,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     int rc = ensure_stage(c);
     if (rc) return rc;
     // ---- everything the streams touch is declared before them: what is declared last goes first, and that is the guard that waits
-    constexpr int NBUF = 2, NCOPY = 1; // (measured twice: four buffers with two windows' copies side by side take longer, 0.68-0.80 s against 0.51-0.58 s for a 14 GB file -- two copying kernels at once get in each other's way in the memory system)
+    constexpr int NBUF = 4, NCOPY = 1; // (NBUF: at most -- n_buf of them are used, below.  NCOPY, measured twice: two windows' copying kernels side by side take longer, 0.68-0.80 s against 0.51-0.58 s for a 14 GB file -- they get in each other's way in the memory system) // (measured twice: four buffers with two windows' copies side by side take longer, 0.68-0.80 s against 0.51-0.58 s for a 14 GB file -- two copying kernels at once get in each other's way in the memory system)
     DevBuf d_image, d_stream[NBUF], d_zwork[NBUF], d_blocks, d_status, d_scan, d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
     std::vector<spl_zblock> blocks;
     std::unique_ptr<uint32_t[]> status;
@@ -1277,7 +1277,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     struct Pipe { // stream A, stream B, their events; waits for everything on the way out, whichever way that is
         spl_ctx *c;
         hipStream_t a = nullptr, b = nullptr, cp[NCOPY] = {nullptr};
-        hipEvent_t k1[NBUF] = {nullptr, nullptr}, k2[NBUF] = {nullptr, nullptr}, freed[NBUF] = {nullptr, nullptr}, setup = nullptr;
+        hipEvent_t k1[NBUF] = {}, k2[NBUF] = {}, freed[NBUF] = {}, setup = nullptr;
         std::vector<hipEvent_t> piece;
         explicit Pipe(spl_ctx *ctx) : c(ctx) {}
         hipError_t make(size_t n_pieces)
@@ -1401,12 +1401,15 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         const size_t b0 = win_at[k], b1 = win_at[k + 1];
         win_cap = std::max(win_cap, blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out);
     }
-    uint32_t match_stride = 0;
-    if (const char *e = getenv("SPL_INFLATE_MATCH_STRIDE")) match_stride = (uint32_t)std::max(8, atoi(e)); // (tests: lists that overflow)
-    const size_t work_bytes = spl_dev_inflate_work_bytes((uint32_t)win_blocks, match_stride);
+    const size_t work_bytes = spl_dev_inflate_work_bytes((uint32_t)win_blocks);
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     free_b += devmem::held_bytes(c->device);
-    const int n_buf = (int)std::min<size_t>((size_t)NBUF, n_win);
+    // Three windows in flight: a window's buffer is free again when its records are extracted, and with two the decoding kernel
+    // of window k + 2 waited for that -- decode, copy, scan and extract of one window in a row, 34 ms for two windows of work
+    // (measured on the 14 GB file: 20 ms a window with two buffers, 18.7 with three, no less with four).
+    int want_buf = 3;
+    if (const char *e = getenv("SPL_INFLATE_BUFFERS")) want_buf = std::min(NBUF, std::max(1, atoi(e)));
+    const int n_buf = (int)std::min<size_t>((size_t)want_buf, n_win);
     if ((double)n_buf * ((double)win_cap + (double)HEAD + (double)work_bytes) + (double)(stream_len - stream_begin) * 0.2 + (double)((size_t)1 << 30) > (double)free_b)
         return to_host("not enough device memory for the inflated stream");
     for (int k = 0; k < n_buf; ++k) {
@@ -1491,15 +1494,14 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         const double w_in = (double)(blocks[b1 - 1].in + blocks[b1 - 1].in_len - blocks[b0].in), w_out = (double)(blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out);
         {
             splprof::Scope p("spl_inflate_decode_kernel", pipe.a, w_in + w_out);
-            HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k), d_status.as<uint32_t>() + b0,
-                                                              d_zwork[k % (size_t)n_buf].p, match_stride, pipe.a));
+            HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_buf].p, pipe.a));
         }
         HIP_TRY(hipEventRecord(pipe.k1[k % (size_t)n_buf], pipe.a));
         hipStream_t cs = pipe.cp[k % (size_t)NCOPY];
         HIP_TRY(hipStreamWaitEvent(cs, pipe.k1[k % (size_t)n_buf], 0));
         {
             splprof::Scope p("spl_inflate_copy_kernel", cs, w_out);
-            HIP_TRY((hipError_t)spl_dev_launch_inflate_copy(d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k), d_zwork[k % (size_t)n_buf].p, match_stride, cs));
+            HIP_TRY((hipError_t)spl_dev_launch_inflate_copy(d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_buf].p, cs));
         }
         HIP_TRY(hipEventRecord(pipe.k2[k % (size_t)n_buf], cs));
         launched_it = true;

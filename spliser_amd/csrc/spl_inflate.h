@@ -29,13 +29,10 @@ struct spl_zblock {
 // next block; behind the last one the caller pads), and the inflated stream writable for 16 bytes past its end: the wave kernel
 // moves 16 bytes at a time.
 #define SPL_Z_IMAGE_PAD 64u
-// The decoding kernel leaves every block's matches to the copying kernel as a list of (place in the block | distance - 1 << 16 |
-// (length - 3) << 32), eight bytes each, in output order (no match is shorter than three bytes: a block has at most 65536 / 3
-// of them), one list of this many entries per block.
-#define SPL_Z_MATCH_STRIDE_MAX 21848u
-// ... or fewer (the caller's choice: memory): a block with more matches than its list holds gets SPL_Z_TOO_MANY from the
-// decoding kernel and is then done by round 2's one-lane-per-block decoder, which needs no list.
-#define SPL_Z_MATCH_STRIDE 12288u
+// Between the decoding and the copying kernel every block has a stream of tokens (spl_inflate_wave.h: literal runs of up to
+// 128 bytes behind a length byte, matches in three bytes): at most five bytes for four of output (a literal of its own and a
+// match of three), so this many bytes per block, 16-byte aligned:
+#define SPL_Z_TOKEN_STRIDE 82048u
 
 // status codes written per block (0 = fine)
 #define SPL_Z_OK 0u
@@ -47,7 +44,6 @@ struct spl_zblock {
 #define SPL_Z_OVERRUN 6u
 #define SPL_Z_SHORT 7u
 #define SPL_Z_BAD_CRC 8u
-#define SPL_Z_TOO_MANY 9u   // (between the kernels of spl_dev_launch_inflate only)
 
 // ---- BAM records out of the inflated stream, one BGZF block per lane ------------------------------------------------
 // What a lane reports about the records that START in its block (spl_bam_scan_kernel).  `start` = the first record boundary at
@@ -89,15 +85,15 @@ int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream_len, int32
 // where the reference id changes along the placed records: (index of the first record of a run, its tid) pairs, unordered
 int spl_dev_launch_bam_bounds(const int32_t *tid, const uint32_t *cig_off, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap, void *stream_handle);
 // image: the whole file in device memory, readable SPL_Z_IMAGE_PAD bytes past its end; out: writable 16 bytes past the last block.
-// work: spl_dev_inflate_work_bytes(n_blocks) bytes of device memory (the blocks' lists of matches between the two kernels), or
+// work: spl_dev_inflate_work_bytes(n_blocks) bytes of device memory (the blocks' token streams between the two kernels), or
 // null for round 2's one-kernel decoder.  stream: the stream to launch on.
-// match_stride: places per block's list (0 = SPL_Z_MATCH_STRIDE; at most SPL_Z_MATCH_STRIDE_MAX; a multiple of 8).
-size_t spl_dev_inflate_work_bytes(uint32_t n_blocks, uint32_t match_stride);
-int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t match_stride, void *stream);
-// ... in two halves, for callers that put them on different streams: the Huffman decoding (and the fallback for blocks whose
-// lists overflow), then the copies
-int spl_dev_launch_inflate_decode(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t match_stride, void *stream);
-int spl_dev_launch_inflate_copy(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, void *work, uint32_t match_stride, void *stream);
+size_t spl_dev_inflate_work_bytes(uint32_t n_blocks);
+int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, void *stream);
+// ... in two halves, for callers that put them on different streams: the Huffman decoding (token streams into `work`), then the
+// copies (the inflated bytes into `out`; a block whose tokens do not give out_len bytes gets SPL_Z_SHORT)
+int spl_dev_launch_inflate_decode(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *work, void *stream);
+int spl_dev_launch_inflate_copy(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, void *stream);
+// CRC32 of every block's bytes against the value in its trailer (blocks that failed before keep their status)
 int spl_dev_launch_crc32(const uint8_t *out, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *stream);
 #ifdef __cplusplus
 }

@@ -7,25 +7,30 @@
 #include "spl_wave.h"
 #include "spl_inflate_wave.h"
 
-// The Huffman decoding, one BGZF block per WAVE, and the copies it leaves to be made, one block per LANE (spl_inflate_wave.h has
-// the method, and is what the host tests run through the wave emulator).
-__global__ __launch_bounds__(64) void spl_inflate_decode_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status,
-                                                                uint64_t *midx_all, uint32_t stride, uint32_t *n_match)
+// The Huffman decoding, one BGZF block per WAVE (the block's symbols as a stream of tokens), and the block's bytes made from
+// that stream, one block per LANE (spl_inflate_wave.h has the method, and is what the host tests run through the wave emulator).
+__global__ __launch_bounds__(64) void spl_inflate_decode_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status,
+                                                                uint8_t *tokens_all, uint32_t *n_tok)
 {
     __shared__ splz::Shared sh;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
     const spl_zblock zb = blocks[b];
     uint32_t n = 0;
-    const uint32_t st = splz::decode_block(sh, image, zb, out_all, midx_all + (size_t)b * stride, stride, n);
-    if (threadIdx.x == 0) { status[b] = st; n_match[b] = st == SPL_Z_OK ? n : 0u; }
+    const uint32_t st = splz::decode_block(sh, image, zb, tokens_all + (size_t)b * SPL_Z_TOKEN_STRIDE, n);
+    if (threadIdx.x == 0) { status[b] = st; n_tok[b] = st == SPL_Z_OK ? n : 0u; }
 }
 
-__global__ __launch_bounds__(64) void spl_inflate_copy_kernel(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, const uint64_t *midx_all, uint32_t stride, const uint32_t *n_match)
+__global__ __launch_bounds__(64) void spl_inflate_copy_kernel(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status, const uint8_t *tokens_all,
+                                                              const uint32_t *n_tok)
 {
+    __shared__ uint32_t lds[64u * splz::COPY_LANE_BYTES / 4u];
     const uint32_t b = blockIdx.x * 64u + threadIdx.x;
     if (b >= n_blocks) return;
-    splz::copy_block(out_all + blocks[b].out, midx_all + (size_t)b * stride, n_match[b]);
+    if (status[b] != SPL_Z_OK) return;
+    uint8_t *const mine = (uint8_t *)lds + threadIdx.x * splz::COPY_LANE_BYTES;
+    const uint32_t made = splz::copy_block(out_all + blocks[b].out, blocks[b].out_len, tokens_all + (size_t)b * SPL_Z_TOKEN_STRIDE, n_tok[b], mine, mine + splz::RING_BYTES);
+    if (made != blocks[b].out_len) status[b] = SPL_Z_SHORT;
 }
 
 namespace {
@@ -172,8 +177,7 @@ __constant__ uint8_t k_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4
 
 } // namespace
 
-// `only`: null, or a status: then only the blocks that have it are done (the others' lanes leave at once).
-__global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status, uint32_t only)
+__global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status)
 {
     const uint32_t b = blockIdx.x * 64u + threadIdx.x;
     // lane-interleaved symbol tables: literal/length (288), distance (32); the code-length code's 19 symbols borrow the
@@ -182,7 +186,6 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
     __shared__ uint32_t s_hi[9 * 64];
     const LdsSyms lsym{s_sym + threadIdx.x, s_hi + threadIdx.x}, dsym{s_sym + 288 * 64 + threadIdx.x, nullptr};
     if (b >= n_blocks) return;
-    if (only != 0u && status[b] != only) return;
     const spl_zblock zb = blocks[b];
     uint8_t *const out = out_all + zb.out;
     const uint32_t out_len = zb.out_len;
@@ -674,44 +677,40 @@ extern "C" int spl_dev_launch_bam_bounds(const int32_t *tid, const uint32_t *cig
     return (int)hipGetLastError();
 }
 
-static uint32_t stride_of(uint32_t match_stride)
-{
-    uint32_t st = match_stride ? match_stride : SPL_Z_MATCH_STRIDE;
-    if (st > SPL_Z_MATCH_STRIDE_MAX) st = SPL_Z_MATCH_STRIDE_MAX;
-    return (st + 7u) & ~7u;
-}
-extern "C" size_t spl_dev_inflate_work_bytes(uint32_t n_blocks, uint32_t match_stride) { return 256 + ((size_t)n_blocks * 4 + 255) / 256 * 256 + (size_t)n_blocks * stride_of(match_stride) * 8; }
+static size_t tokens_at(uint32_t n_blocks) { return ((size_t)n_blocks * 4 + 255) / 256 * 256; }
+extern "C" size_t spl_dev_inflate_work_bytes(uint32_t n_blocks) { return 256 + tokens_at(n_blocks) + (size_t)n_blocks * SPL_Z_TOKEN_STRIDE; }
 
-extern "C" int spl_dev_launch_inflate_decode(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t match_stride, void *stream)
+static bool per_lane_asked()
+{
+    static const bool v = getenv("SPL_INFLATE_PER_LANE") != nullptr; // (round 2's kernel, a block per lane for everything: kept for comparison)
+    return v;
+}
+
+extern "C" int spl_dev_launch_inflate_decode(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *work, void *stream)
+{
+    if (n_blocks == 0 || per_lane_asked() || !work) return 0;
+    hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, status, (uint8_t *)work + tokens_at(n_blocks), (uint32_t *)work);
+    return (int)hipGetLastError();
+}
+
+extern "C" int spl_dev_launch_inflate_copy(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, void *stream)
+{
+    if (n_blocks == 0 || per_lane_asked() || !work) return 0;
+    hipLaunchKernelGGL(spl_inflate_copy_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, blocks, n_blocks, out, status, (const uint8_t *)work + tokens_at(n_blocks),
+                       (const uint32_t *)work);
+    return (int)hipGetLastError();
+}
+
+// (round 2's decoder needs the file image where the others need the tokens: callers that may get either pass it here)
+extern "C" int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, void *stream)
 {
     if (n_blocks == 0) return 0;
-    static const bool per_lane = getenv("SPL_INFLATE_PER_LANE") != nullptr; // (round 2's kernel, a block per lane for everything: kept for comparison)
-    if (per_lane || !work) {
-        hipLaunchKernelGGL(spl_inflate_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status, 0u);
+    if (per_lane_asked() || !work) {
+        hipLaunchKernelGGL(spl_inflate_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status);
         return (int)hipGetLastError();
     }
-    uint32_t *const n_match = (uint32_t *)work;
-    uint64_t *const midx = (uint64_t *)((char *)work + ((size_t)n_blocks * 4 + 255) / 256 * 256);
-    hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status, midx, stride_of(match_stride), n_match);
-    // blocks with more matches than their list holds: by the decoder that needs none
-    hipLaunchKernelGGL(spl_inflate_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status, SPL_Z_TOO_MANY);
-    return (int)hipGetLastError();
-}
-
-extern "C" int spl_dev_launch_inflate_copy(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, void *work, uint32_t match_stride, void *stream)
-{
-    static const bool per_lane = getenv("SPL_INFLATE_PER_LANE") != nullptr;
-    if (n_blocks == 0 || per_lane || !work) return 0;
-    const uint32_t *const n_match = (const uint32_t *)work;
-    const uint64_t *const midx = (const uint64_t *)((const char *)work + ((size_t)n_blocks * 4 + 255) / 256 * 256);
-    hipLaunchKernelGGL(spl_inflate_copy_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, blocks, n_blocks, out, midx, stride_of(match_stride), n_match);
-    return (int)hipGetLastError();
-}
-
-extern "C" int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t match_stride, void *stream)
-{
-    const int rc = spl_dev_launch_inflate_decode(image, blocks, n_blocks, out, status, work, match_stride, stream);
-    return rc ? rc : spl_dev_launch_inflate_copy(blocks, n_blocks, out, work, match_stride, stream);
+    const int rc = spl_dev_launch_inflate_decode(image, blocks, n_blocks, status, work, stream);
+    return rc ? rc : spl_dev_launch_inflate_copy(blocks, n_blocks, out, status, work, stream);
 }
 
 extern "C" int spl_dev_launch_crc32(const uint8_t *out, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *stream)

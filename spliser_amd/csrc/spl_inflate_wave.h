@@ -1,9 +1,20 @@
 // spl_inflate_wave.h -- DEFLATE (RFC 1951) on the device in two kernels (spl_inflate.hip launches them; the bodies are here,
 // written against the primitives of spl_wave.h so that the same source runs on the host under tests/hostsim/wave_emul.h):
 //
-//   decode_block   one BGZF block per WAVE: the Huffman decoding.  Literals go to their places in the inflated stream; a match
-//                  is appended to the block's list of matches: where it goes, distance, length, eight bytes.
-//   copy_block     one BGZF block per LANE: the list's matches made one after the other, each a copy of bytes that are there.
+//   decode_block   one BGZF block per WAVE: the Huffman decoding.  What the block's symbols say is written down as a STREAM OF
+//                  TOKENS, bytes: a run of n literals is n - 1 (0..127) and the n bytes; a match is three bytes,
+//                  0x80 | L & 0x7f, L >> 7 | (D & 0x7f) << 1, D >> 7 with L = length - 3, D = distance - 1.  Nothing of the
+//                  inflated stream is written here.
+//   copy_block     one BGZF block per LANE: the token stream read front to back and the block's bytes made from it -- literals
+//                  copied, matches copied from what is there by then -- through a small window of the newest output in LDS
+//                  (RING bytes a lane): whole 16-byte pieces of the output go to memory once, a match's source is read from the
+//                  window when it lies that close and from memory otherwise, the token stream comes in 64 bytes at a time on a
+//                  fixed beat, asked for a beat before it is needed.  What this is made to avoid: the first version kept lists
+//                  of matches and copied in place, three to four scattered 16-byte accesses per match and 9 000 matches a block
+//                  (22 ms per 49 152 blocks); this one stores every output byte once and loads every token byte once (12.6 ms).
+//                  The window is small on purpose: with 512 bytes a lane (53 KB a wave) the kernel is another millisecond
+//                  faster alone, and its waves leave the decoding kernel, which runs beside it, no LDS to be resident with
+//                  (profiles/r03_inflate_wave_account.md).
 //
 // Why the split.  Round 2 gave every lane a block of its own for everything: a lane's Huffman tables were 356 bytes of LDS and
 // thirty-odd registers (1.75 waves per SIMD), every turn of the 64 lanes ran through all the decoder's branches (330 vector
@@ -11,7 +22,7 @@
 // LDS, 2.9 KB) and read the compressed bytes from a tile of them staged in LDS by coalesced loads.  Copying is what it cannot: a
 // BAM record's matches copy from the record before, whose matches copy from the one before that -- measured with
 // tools/inflate_sim.cpp: about 2 000 dependent steps per block, a dozen copies ready at any time -- so 64 lanes on one block's
-// copies idle (built and measured: 33 of the kernel's 58 ms, profiles/r03_inflate_wave_account.md), while 64 lanes on 64 blocks'
+// copies idle (built and measured: 33 of the kernel's 58 ms, same account), while 64 lanes on 64 blocks'
 // copies are all busy and need no tables.
 //
 // Huffman codes have no markers, so where a lane should start decoding is not known: it is FOUND.  The data of a DEFLATE block
@@ -35,7 +46,7 @@ constexpr uint32_t LUT_L = 852, LUT_D = 592; // entries: root table + the most s
 constexpr uint32_t SUB_BITS = 256;           // bits of DEFLATE data per lane and tile
 constexpr uint32_t TILE_WORDS = 64u * SUB_BITS / 32u;
 constexpr uint32_t TILE_PAD = 16;            // words behind the tile: a symbol that begins in the last subsequence ends there
-constexpr uint32_t QCAP = 640;               // matches per tile (a tile with more is cut short)
+constexpr uint32_t TOKCAP = 5120;            // bytes of token stream per tile (a tile with more is cut short)
 constexpr uint32_t FL_OK = 0, FL_EOB = 1, FL_ERR = 2;
 constexpr uint32_t SYM_EOB = 256, SYM_MATCH = 257, SYM_BAD = 0xffffffffu;
 
@@ -44,10 +55,10 @@ struct Shared {
     uint16_t lut_l[LUT_L];                // literal/length code.  Entry: symbol << 4 | bits; 0x8000 | offset << 4 | sub-table bits; 0 = no such code
     uint16_t lut_d[LUT_D];                // distance code
     uint32_t tile[TILE_WORDS + TILE_PAD]; // the compressed bytes being worked on (while tables are built: work space)
-    uint64_t q[QCAP];                     // the tile's matches in output order (while a header is read: code lengths, the code-length code's table)
+    uint32_t tok[TOKCAP / 4];             // the tile's stretch of the token stream (while a header is read: code lengths, the code-length code's table)
 };
 static_assert(SUB_BITS == 256u, "the tile is staged thirty-two bytes a lane");
-static_assert(QCAP * 8u >= 352u + 256u, "code lengths and the code-length code's table lie in q while a header is read");
+static_assert(TOKCAP >= 352u + 256u + 64u, "code lengths and the code-length code's table lie in tok while a header is read");
 
 // the order in which a dynamic header lists the lengths of the code-length code (RFC 1951, 3.2.7), five bits a place
 constexpr uint64_t pack5(const int *v, int n) { uint64_t r = 0; for (int i = 0; i < n; ++i) r |= (uint64_t)v[i] << (5 * i); return r; }
@@ -203,16 +214,23 @@ WV_DEV uint32_t decode(const Shared &sh, uint32_t base, uint32_t &pos, uint32_t 
     return SYM_MATCH;
 }
 
-// What a lane would produce from `start` to the first symbol boundary at or past `sub_end`.
-struct Count { uint32_t end, n_out, n_match, flag; };
+// What a lane would produce from `start` to the first symbol boundary at or past `sub_end`: bytes of output, bytes of token stream
+// (a lane's literal runs are its own: a run never goes on in the next lane's tokens).
+struct Count { uint32_t end, n_out, n_tok, flag; };
 WV_DEV Count count_from(const Shared &sh, uint32_t base, uint32_t start, uint32_t sub_end)
 {
     Count c{start, 0, 0, FL_OK};
+    uint32_t run = 0; // literals in the run that is open (0: none)
     while (c.end < sub_end) {
         uint32_t len = 0, dist = 0;
         const uint32_t s = decode(sh, base, c.end, len, dist);
-        if (s < 256u) { c.n_out++; continue; }
-        if (s == SYM_MATCH) { c.n_out += len; c.n_match++; continue; }
+        if (s < 256u) {
+            if (run == 0u || run == 128u) { c.n_tok++; run = 0; }
+            c.n_tok++; run++;
+            c.n_out++;
+            continue;
+        }
+        if (s == SYM_MATCH) { c.n_out += len; c.n_tok += 3u; run = 0; continue; }
         c.flag = s == SYM_EOB ? FL_EOB : FL_ERR;
         break;
     }
@@ -229,18 +247,18 @@ WV_DEV void store_n(uint8_t *p, uint64_t lo, uint64_t hi, uint32_t n)
     if (n & 1u) *p = (uint8_t)lo;
 }
 
-// The block `zb` of the file image, by one wave.  midx: room for `stride` places of matches; n_match_out: how many were written.  Returns the block's status (every lane the same).
-WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock &zb, uint8_t *out_all, uint64_t *midx, uint32_t stride, uint32_t &n_match_out)
+// The block `zb` of the file image, by one wave.  stream: room for SPL_Z_TOKEN_STRIDE bytes of tokens (16-byte aligned);
+// n_tok_out: how many were written.  Returns the block's status (every lane the same).
+WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock &zb, uint8_t *stream, uint32_t &n_tok_out)
 {
-    n_match_out = 0;
-    uint32_t n_match = 0;
+    n_tok_out = 0;
+    uint32_t n_tok = 0; // bytes of token stream so far
     const uint32_t l = wv::lane();
     const uint8_t *const in = image + zb.in;
-    uint8_t *const out = out_all + zb.out;
     const uint32_t in_len = zb.in_len, out_len = zb.out_len, end_bits = in_len * 8u;
     if (out_len == 0u) return SPL_Z_OK; // (the EOF marker and other empty blocks: nothing to decode into)
     if (out_len > 65536u || in_len > 65536u) return SPL_Z_OVERRUN; // (not a BGZF block)
-    uint8_t *const lens = (uint8_t *)sh.q; // 352 code lengths while a header is read
+    uint8_t *const lens = (uint8_t *)sh.tok; // 352 code lengths while a header is read
     uint32_t *const work = sh.tile;
     uint32_t pos = 0, at = 0;
     for (uint32_t last = 0; !last;) {
@@ -258,8 +276,15 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             if ((len ^ 0xffffu) != ln >> 16) return SPL_Z_BAD_STORED;
             if (byte + 4u + len > in_len || at + len > out_len) return SPL_Z_OVERRUN;
             const uint8_t *src = in + byte + 4u;
-            for (uint32_t i = l * 4u; i + 4u <= len; i += 256u) wv::st32(out + at + i, wv::ld32(src + i));
-            if ((len & ~3u) + l < len) out[at + (len & ~3u) + l] = src[(len & ~3u) + l];
+            // as literal runs of 128 (the last one shorter): run r is stream bytes [129 r, 129 r + 129)
+            const uint32_t n_runs = (len + 127u) / 128u;
+            for (uint32_t r = l; r < n_runs; r += 64u) {
+                const uint32_t n = len - 128u * r < 128u ? len - 128u * r : 128u;
+                uint8_t *t = stream + n_tok + 129u * r;
+                t[0] = (uint8_t)(n - 1u);
+                for (uint32_t i = 0; i < n; ++i) t[1u + i] = src[128u * r + i];
+            }
+            n_tok += len + n_runs;
             at += len;
             pos = (byte + 4u + len) * 8u;
             continue;
@@ -283,7 +308,7 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             if (l < n_code) lens[clen_order(l)] = (uint8_t)(gbits(in, pos + 3u * l) & 7u);
             pos += 3u * n_code;
             wv::sync();
-            uint16_t *const lut_c = (uint16_t *)sh.q + 176;
+            uint16_t *const lut_c = (uint16_t *)sh.tok + 176;
             if (!build_lut(lens, 19u, ROOT_C, lut_c, 1u << ROOT_C, work)) return SPL_Z_BAD_LENGTHS;
             // the lengths of the two codes, a run-length code of its own: one after the other (every lane does the same)
             const uint32_t n_all = n_lit + n_dist;
@@ -360,95 +385,165 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
                     if (!dead) c = count_from(sh, base, start, sub_end);
                 }
             }
-            // the lanes that count: all that are alive (a suffix of the lanes is dead), short of the one whose matches overflow the queue
-            const uint32_t cum_m = wv::scan_add(dead ? 0u : c.n_match), cum_o = wv::scan_add(dead ? 0u : c.n_out);
-            const uint64_t m_ok = wv::ballot(!dead && cum_m <= QCAP);
+            // the lanes that count: all that are alive (a suffix of the lanes is dead), short of the one whose tokens overflow the tile's room
+            const uint32_t cum_t = wv::scan_add(dead ? 0u : c.n_tok), cum_o = wv::scan_add(dead ? 0u : c.n_out);
+            const uint64_t m_ok = wv::ballot(!dead && cum_t <= TOKCAP);
             const uint32_t n_valid = ~m_ok ? wv::ffs64(~m_ok) : 64u; // (the low run of ones)
             if (n_valid == 0u) return SPL_Z_OVERRUN;
             const bool valid = l < n_valid;
             if (wv::any(valid && c.flag == FL_ERR)) return SPL_Z_BAD_CODE;
             eob = wv::any(valid && c.flag == FL_EOB);
-            const uint32_t total = wv::readlane(cum_o, n_valid - 1u), n_q = wv::readlane(cum_m, n_valid - 1u);
-            if (at + total > out_len) return SPL_Z_OVERRUN;
-            if (n_match + n_q > stride) return SPL_Z_TOO_MANY;
-            // ---- the writing pass: literals to their places, matches to the list
+            const uint32_t total = wv::readlane(cum_o, n_valid - 1u), n_t = wv::readlane(cum_t, n_valid - 1u);
+            if (at + total > out_len || n_tok + n_t > SPL_Z_TOKEN_STRIDE - 64u) return SPL_Z_OVERRUN;
+            // ---- the writing pass: every lane's symbols as tokens, at the lane's place in the tile's stretch of the stream
             bool bad_dist = false;
+            uint8_t *const tok = (uint8_t *)sh.tok;
 #ifndef SPL_EXP_NO_WRITE
             if (valid) {
-                uint32_t p = start, wr = at + cum_o - c.n_out, qi = cum_m - c.n_match;
+                uint32_t p = start, wr = at + cum_o - c.n_out, tp = cum_t - c.n_tok, run = 0, hdr = 0;
                 while (p < sub_end) {
                     uint32_t len = 0, dist = 0;
                     const uint32_t s = decode(sh, base, p, len, dist);
-                    if (s < 256u) { out[wr++] = (uint8_t)s; continue; }
+                    if (s < 256u) {
+                        if (run == 0u || run == 128u) { if (run) tok[hdr] = 127; hdr = tp++; run = 0; }
+                        tok[tp++] = (uint8_t)s;
+                        ++run; ++wr;
+                        continue;
+                    }
+                    if (run) { tok[hdr] = (uint8_t)(run - 1u); run = 0; }
                     if (s != SYM_MATCH) break; // (the end of the block; errors were seen by the counting pass)
                     if (dist > wr) { bad_dist = true; break; }
-                    sh.q[qi++] = (uint64_t)(wr | (dist - 1u) << 16) | (uint64_t)(len - 3u) << 32;
+                    const uint32_t L = len - 3u, D = dist - 1u;
+                    tok[tp] = (uint8_t)(0x80u | (L & 0x7fu)); tok[tp + 1u] = (uint8_t)(L >> 7 | (D & 0x7fu) << 1); tok[tp + 2u] = (uint8_t)(D >> 7);
+                    tp += 3u;
                     wr += len;
                 }
+                if (run) tok[hdr] = (uint8_t)(run - 1u);
             }
 #endif
             if (wv::any(bad_dist)) return SPL_Z_BAD_DISTANCE;
             wv::sync();
-            for (uint32_t t = l; t < n_q; t += 64u) midx[n_match + t] = sh.q[t];
-            n_match += n_q;
+            // the tile's tokens to their place in the block's stream: sixteen bytes a lane and step (what is written beyond n_t is
+            // overwritten by the next tile, or never read)
+            for (uint32_t o = l * 16u; o < n_t; o += 1024u) {
+                const uint64_t lo = (uint64_t)sh.tok[o / 4u] | (uint64_t)sh.tok[o / 4u + 1u] << 32, hi = (uint64_t)sh.tok[o / 4u + 2u] | (uint64_t)sh.tok[o / 4u + 3u] << 32;
+                wv::st128(stream + n_tok + o, lo, hi);
+            }
+            n_tok += n_t;
             wv::sync();
             at += total;
             pos = wv::readlane(c.end, n_valid - 1u);
         }
     }
     if (at != out_len) return SPL_Z_SHORT;
-    n_match_out = n_match;
+    n_tok_out = n_tok;
     return SPL_Z_OK;
 }
 
-// The matches of a block made in the order of its list: every one a copy of bytes that are there by then (literals, and the
-// matches before it).  One lane's work; 64 blocks to a wave, 64 different cache lines to every memory instruction: two matches'
-// entries in one 16-byte load, a piece of up to 16 bytes in one load and at most two stores (the second overlaps the first: a
-// piece of 11 bytes is bytes 0..7 and bytes 3..10).  (Asking for the next piece's bytes before this piece is stored -- two loads
-// on their way -- was built and is slower, 22.5 ms against 19.6 per window of 49 152 blocks.)
-WV_DEV void copy_block(uint8_t *out, const uint64_t *midx, uint32_t n)
+// ---- the copying kernel's body: one lane, one block ------------------------------------------------------------------------
+#ifndef SPLZ_RING
+#define SPLZ_RING 64
+#endif
+#ifndef SPLZ_FIFO
+#define SPLZ_FIFO 128
+#endif
+constexpr uint32_t RING = SPLZ_RING;        // bytes of the output a lane keeps at hand in LDS: a match up to RING - 16 back is copied from there
+constexpr uint32_t RING_BYTES = 16u + RING + 32u; // ... with room in front and behind, so that no piece of 16 bytes ever wraps (mirrored)
+constexpr uint32_t FIFO = SPLZ_FIFO;        // bytes of token stream a lane holds in LDS
+constexpr uint32_t FIFO_BYTES = FIFO + 16u;
+constexpr uint32_t BEAT = 8;          // every BEAT turns: the 64 bytes asked for a beat ago go into the FIFO, the next 64 are asked for
+constexpr uint32_t COPY_LANE_BYTES = RING_BYTES + FIFO_BYTES + 4u; // (an odd number of words: the lanes' windows start in different banks)
+
+// ring: this lane's RING_BYTES, fifo: its FIFO_BYTES (shared memory).  Returns the number of bytes made (the caller compares).
+WV_DEV uint32_t copy_block(uint8_t *out, uint32_t out_len, const uint8_t *stream, uint32_t n_tok, uint8_t *ring_mem, uint8_t *fifo)
 {
-    if (n == 0u) return;
-    uint64_t e0, e1; // entries i (and i + 1 when i is even): two to a load; midx + 2k is 16-byte aligned
-    wv::ld128((const uint8_t *)midx, e0, e1);
-    uint32_t i = 0, d = 0, left = 0, dist = 1;
-    for (;;) {
-        if (left == 0u) {
-            if (i >= n) break;
-            d = (uint32_t)e0 & 0xffffu;
-            dist = ((uint32_t)e0 >> 16) + 1u;
-            left = (uint32_t)(e0 >> 32) + 3u;
-            ++i;
-            if (i & 1u) e0 = e1;
-            else if (i < n) wv::ld128((const uint8_t *)(midx + i), e0, e1);
+    if (n_tok == 0u) return 0u;
+    wv::settle(n_tok);
+    wv::settle(out_len);
+    uint8_t *const ring = ring_mem + 16; // (ring[-16 .. RING + 32))
+    uint32_t sp = 0, f_wr = 0, f_req = 0;   // token bytes consumed / in the FIFO / asked for
+    wv::q128 qa = {}, qb = {}, qc = {}, qd = {}; // the 64 bytes on their way
+    bool pending = false;
+    uint32_t op = 0, flushed = 0;           // bytes made / bytes of them in memory (a multiple of 16)
+    uint32_t lit_left = 0, left = 0, dist = 1;
+    // a piece of 16 bytes (the first k meant) to the window at `op`, mirrored where the window wraps
+    auto to_ring = [&](uint64_t lo, uint64_t hi) {
+        const uint32_t o = op & (RING - 1u);
+        wv::lds_st128(ring + o, lo, hi);
+        if (o < 16u) wv::lds_st128(ring + RING + o, lo, hi);
+        if (o > RING - 16u) wv::lds_st128(ring + o - RING, lo, hi);
+    };
+    for (uint32_t turn = 0;; ++turn) {
+        if ((turn & (BEAT - 1u)) == 0u) { // the beat
+            if (pending && f_wr + 64u - sp <= FIFO) {
+                uint8_t *f = fifo + (f_wr & (FIFO - 1u));
+                wv::mem_wait4(qa, qb, qc, qd);
+                wv::lds_st128q(f, qa); wv::lds_st128q(f + 16, qb); wv::lds_st128q(f + 32, qc); wv::lds_st128q(f + 48, qd);
+                if ((f_wr & (FIFO - 1u)) == 0u) wv::lds_st128q(fifo + FIFO, qa); // (the FIFO's first piece once more behind its end)
+                f_wr += 64u;
+                pending = false;
+            }
+            if (!pending && f_req < n_tok) {
+                const uint8_t *s = stream + f_req;
+                wv::mem_ld128_async(s, qa); wv::mem_ld128_async(s + 16, qb); wv::mem_ld128_async(s + 32, qc); wv::mem_ld128_async(s + 48, qd);
+                f_req += 64u;
+                pending = true;
+            }
         }
-        uint32_t k = left < 16u ? left : 16u;
-        if (dist < 8u) k = k < 8u ? k : 8u;      // (made from the period, below)
-        else if (dist < k) k = dist;             // (only what is there already)
-        uint64_t lo, hi;
-        wv::ld128(out + d - dist, lo, hi);
-        if (dist < 8u) { // the bytes repeat with a period shorter than the piece: the period, as often as it fits
-            lo &= (1ull << (8u * dist)) - 1ull;
-            lo |= lo << (8u * dist);
-            if (dist < 4u) lo |= lo << (16u * dist);
-            if (dist < 2u) lo |= lo << 32;
+        const uint32_t have = (f_wr < n_tok ? f_wr : n_tok) - sp; // token bytes at hand
+        if (lit_left == 0u && left == 0u) { // the next token
+            if (sp >= n_tok) break;
+            if (have < 3u && sp + have < n_tok) continue; // (its bytes are still on their way)
+            const uint8_t *t = fifo + (sp & (FIFO - 1u));
+            const uint32_t c = wv::lds_ld8(t);
+            if (c < 0x80u) { lit_left = c + 1u; sp += 1u; }
+            else {
+                const uint32_t b1 = wv::lds_ld8(t + 1), b2 = wv::lds_ld8(t + 2);
+                left = ((c & 0x7fu) | (b1 & 1u) << 7) + 3u;
+                dist = ((b1 >> 1) | b2 << 7) + 1u;
+                sp += 3u;
+                if (dist > op) return 0xffffffffu; // (the decoding kernel checked: a damaged stream)
+            }
         }
-        uint8_t *const p = out + d;
-        if (k == 16u) wv::st128(p, lo, hi);
-        else if (k >= 8u) { // bytes 0..7, then the last eight (they overlap when k < 16)
-            wv::st64(p, lo);
-            const uint32_t sh8 = 8u * (k - 8u);
-            if (k > 8u) wv::st64(p + k - 8u, sh8 ? lo >> sh8 | hi << (64u - sh8) : lo);
-        } else if (k >= 4u) {
-            wv::st32(p, (uint32_t)lo);
-            if (k > 4u) wv::st32(p + k - 4u, (uint32_t)(lo >> (8u * (k - 4u))));
+        uint32_t k = 0;
+        uint64_t lo = 0, hi = 0;
+        if (lit_left) {
+            const uint32_t avail = (f_wr < n_tok ? f_wr : n_tok) - sp;
+            k = lit_left < 16u ? lit_left : 16u;
+            if (avail < k) { if (avail == 0u) continue; k = avail; }
+            wv::lds_ld128(fifo + (sp & (FIFO - 1u)), lo, hi);
+            sp += k;
+            lit_left -= k;
         } else {
-            if (k & 2u) wv::st16(p, (uint32_t)lo);
-            if (k & 1u) p[k - 1u] = (uint8_t)(lo >> (8u * (k - 1u)));
+            k = left < 16u ? left : 16u;
+            if (dist < 8u) k = k < 8u ? k : 8u;      // (made from the period, below)
+            else if (dist < k) k = dist;             // (only what is there already)
+            if (dist <= RING - 16u) wv::lds_ld128(ring + ((op - dist) & (RING - 1u)), lo, hi);
+            else { wv::mem_ld128(out + op - dist, lo, hi); wv::settle64(lo); wv::settle64(hi); } // (further back than the window: in memory, whole pieces behind `flushed`; waited for here, not where the two ways meet)
+            if (dist < 8u) { // the bytes repeat with a period shorter than the piece: the period, as often as it fits
+                lo &= (1ull << (8u * dist)) - 1ull;
+                lo |= lo << (8u * dist);
+                if (dist < 4u) lo |= lo << (16u * dist);
+                if (dist < 2u) lo |= lo << 32;
+            }
+            left -= k;
         }
-        d += k;
-        left -= k;
+        if (op + k > out_len) return 0xffffffffu;
+        to_ring(lo, hi);
+        op += k;
+        if (op - flushed >= 16u) { // a whole piece of the output: to memory, once
+            uint64_t a, b;
+            wv::lds_ld128(ring + (flushed & (RING - 1u)), a, b);
+            wv::mem_st128(out + flushed, a, b);
+            flushed += 16u;
+        }
     }
+    if (op > flushed) {
+        uint64_t a, b;
+        wv::lds_ld128(ring + (flushed & (RING - 1u)), a, b);
+        store_n(out + flushed, a, b, op - flushed);
+    }
+    return op;
 }
 
 } // namespace splz

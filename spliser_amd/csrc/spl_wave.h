@@ -48,6 +48,27 @@ WV_DEV uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8);
 struct alignas(4) u128 { uint32_t w[4]; };
 WV_DEV void ld128(const uint8_t *p, uint64_t &lo, uint64_t &hi) { u128 v; __builtin_memcpy(&v, p, 16); lo = (uint64_t)v.w[0] | (uint64_t)v.w[1] << 32; hi = (uint64_t)v.w[2] | (uint64_t)v.w[3] << 32; }
 WV_DEV void st128(uint8_t *p, uint64_t lo, uint64_t hi) { u128 v; v.w[0] = (uint32_t)lo; v.w[1] = (uint32_t)(lo >> 32); v.w[2] = (uint32_t)hi; v.w[3] = (uint32_t)(hi >> 32); __builtin_memcpy(p, &v, 16); }
+// ... and to shared / to device memory when the compiler cannot tell which of the two a pointer means (it would use FLAT
+// instructions, whose every wait is for shared AND device memory: a load that is meant to stay in flight would be waited for)
+#define WV_AS3 __attribute__((address_space(3)))
+#define WV_AS1 __attribute__((address_space(1)))
+struct __attribute__((packed, aligned(1))) pk128 { uint64_t a, b; };
+WV_DEV void lds_ld128(const uint8_t *p, uint64_t &lo, uint64_t &hi) { const WV_AS3 pk128 *q = (const WV_AS3 pk128 *)p; lo = q->a; hi = q->b; }
+WV_DEV void lds_st128(uint8_t *p, uint64_t lo, uint64_t hi) { WV_AS3 pk128 *q = (WV_AS3 pk128 *)p; q->a = lo; q->b = hi; }
+WV_DEV uint32_t lds_ld8(const uint8_t *p) { return *(const WV_AS3 uint8_t *)p; }
+WV_DEV void mem_ld128(const uint8_t *p, uint64_t &lo, uint64_t &hi) { const WV_AS1 pk128 *q = (const WV_AS1 pk128 *)p; lo = q->a; hi = q->b; }
+WV_DEV void mem_st128(uint8_t *p, uint64_t lo, uint64_t hi) { WV_AS1 pk128 *q = (WV_AS1 pk128 *)p; q->a = lo; q->b = hi; }
+// Sixteen bytes from device memory that are NOT waited for where the compiler would (its waits are for everything in flight: a
+// load meant to arrive eight turns later would be waited for at the next branch): the load is an instruction the compiler does
+// not look into, its registers stay untouched until mem_wait4 has waited for them, and only then are they read.
+typedef uint32_t q128 __attribute__((ext_vector_type(4)));
+WV_DEV void mem_ld128_async(const uint8_t *p, q128 &v) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); }
+WV_DEV void mem_wait4(q128 &a, q128 &b, q128 &c, q128 &d) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory"); }
+WV_DEV void lds_st128q(uint8_t *p, const q128 &v) { *(WV_AS3 q128 *)p = v; }
+WV_DEV void settle64(uint64_t &v) { asm volatile("" : "+v"(v)); }
+// a value that was loaded from memory is there from here on: said before a loop that keeps loads in flight, so that the wait for
+// this one does not end up inside it (where it would wait for everything)
+WV_DEV void settle(uint32_t &v) { asm volatile("" : "+v"(v)); }
 WV_DEV void st16(uint8_t *p, uint32_t v) { const uint16_t x = (uint16_t)v; __builtin_memcpy(p, &x, 2); }
 WV_DEV void st32(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 WV_DEV void st64(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }

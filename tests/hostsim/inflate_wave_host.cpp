@@ -14,15 +14,21 @@ extern "C" int emul_inflate_blocks(const uint8_t *image, const spl_zblock *block
     static splz::Shared sh;
     for (uint32_t b = 0; b < n; ++b) {
         memset(&sh, 0xEE, sizeof sh); // (nothing may depend on what the wave before left)
-        static std::vector<uint64_t> midx(SPL_Z_MATCH_STRIDE_MAX + 8);
-        uint32_t n_match = 0;
+        static std::vector<uint8_t> tokens(SPL_Z_TOKEN_STRIDE + 256);
+        memset(tokens.data(), 0xEE, tokens.size());
+        uint32_t n_tok = 0;
         const bool ok = wv::run_wave([&]() {
             uint32_t n = 0;
-            const uint32_t st = splz::decode_block(sh, image, blocks[b], out, midx.data(), SPL_Z_MATCH_STRIDE_MAX, n);
-            if (wv::lane() == 0) { status[b] = st; n_match = st == SPL_Z_OK ? n : 0u; }
+            const uint32_t st = splz::decode_block(sh, image, blocks[b], tokens.data(), n);
+            if (wv::lane() == 0) { status[b] = st; n_tok = st == SPL_Z_OK ? n : 0u; }
         });
         if (!ok) return -1 - (int)b;
-        splz::copy_block(out + blocks[b].out, midx.data(), n_match);
+        if (status[b] == SPL_Z_OK) {
+            static uint8_t lane_lds[splz::COPY_LANE_BYTES];
+            memset(lane_lds, 0xEE, sizeof lane_lds);
+            const uint32_t made = splz::copy_block(out + blocks[b].out, blocks[b].out_len, tokens.data(), n_tok, lane_lds, lane_lds + splz::RING_BYTES);
+            if (made != blocks[b].out_len) status[b] = SPL_Z_SHORT;
+        }
     }
     return 0;
 }

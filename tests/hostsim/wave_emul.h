@@ -180,6 +180,17 @@ inline uint32_t ld32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v;
 inline uint64_t ld64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
 inline void ld128(const uint8_t *p, uint64_t &lo, uint64_t &hi) { memcpy(&lo, p, 8); memcpy(&hi, p + 8, 8); }
 inline void st128(uint8_t *p, uint64_t lo, uint64_t hi) { memcpy(p, &lo, 8); memcpy(p + 8, &hi, 8); }
+inline void lds_ld128(const uint8_t *p, uint64_t &lo, uint64_t &hi) { ld128(p, lo, hi); }
+inline void lds_st128(uint8_t *p, uint64_t lo, uint64_t hi) { st128(p, lo, hi); }
+inline uint32_t lds_ld8(const uint8_t *p) { return *p; }
+inline void mem_ld128(const uint8_t *p, uint64_t &lo, uint64_t &hi) { ld128(p, lo, hi); }
+inline void mem_st128(uint8_t *p, uint64_t lo, uint64_t hi) { st128(p, lo, hi); }
+inline void settle(uint32_t &) {}
+inline void settle64(uint64_t &) {}
+struct q128 { uint8_t b[16]; };
+inline void mem_ld128_async(const uint8_t *p, q128 &v) { memcpy(v.b, p, 16); }
+inline void mem_wait4(q128 &, q128 &, q128 &, q128 &) {}
+inline void lds_st128q(uint8_t *p, const q128 &v) { memcpy(p, v.b, 16); }
 inline void st16(uint8_t *p, uint32_t v) { const uint16_t x = (uint16_t)v; memcpy(p, &x, 2); }
 inline void st32(uint8_t *p, uint32_t v) { memcpy(p, &v, 4); }
 inline void st64(uint8_t *p, uint64_t v) { memcpy(p, &v, 8); }

@@ -55,8 +55,8 @@ def _streams():
     return made
 
 
-@pytest.mark.parametrize("stride", [0, 64])   # (64: most blocks' lists of matches overflow and the one-lane-per-block decoder does them)
-def test_inflate_and_crc_kernels_against_zlib(stride):
+@pytest.mark.parametrize("tokens", [True, False])   # (False: no work space = round 2's decoder, a lane per block for everything)
+def test_inflate_and_crc_kernels_against_zlib(tokens):
     native.build()
     lib = native.lib()
     streams = _streams()
@@ -81,9 +81,9 @@ def test_inflate_and_crc_kernels_against_zlib(stride):
     torch.cuda.synchronize()
     args = (ctypes.c_void_p(d_blocks.data_ptr()), ctypes.c_uint32(len(streams)))
     lib.spl_dev_inflate_work_bytes.restype = ctypes.c_size_t
-    d_work = torch.zeros(lib.spl_dev_inflate_work_bytes(ctypes.c_uint32(len(streams)), ctypes.c_uint32(stride)), dtype=torch.uint8, device="cuda:0")
+    d_work = torch.zeros(lib.spl_dev_inflate_work_bytes(ctypes.c_uint32(len(streams))), dtype=torch.uint8, device="cuda:0")
     rc = lib.spl_dev_launch_inflate(ctypes.c_void_p(d_image.data_ptr()), *args, ctypes.c_void_p(d_out.data_ptr()),
-                                    ctypes.c_void_p(d_status.data_ptr()), ctypes.c_void_p(d_work.data_ptr()), ctypes.c_uint32(stride), ctypes.c_void_p(0))
+                                    ctypes.c_void_p(d_status.data_ptr()), ctypes.c_void_p(d_work.data_ptr() if tokens else 0), ctypes.c_void_p(0))
     assert rc == 0
     rc = lib.spl_dev_launch_crc32(ctypes.c_void_p(d_out.data_ptr()), *args, ctypes.c_void_p(d_status.data_ptr()), ctypes.c_void_p(0))
     assert rc == 0
@@ -105,7 +105,7 @@ def test_inflate_and_crc_kernels_against_zlib(stride):
     d_status.fill_(-1)
     torch.cuda.synchronize()
     assert lib.spl_dev_launch_inflate(ctypes.c_void_p(d_image.data_ptr()), *args, ctypes.c_void_p(d_out.data_ptr()),
-                                      ctypes.c_void_p(d_status.data_ptr()), ctypes.c_void_p(d_work.data_ptr()), ctypes.c_uint32(stride), ctypes.c_void_p(0)) == 0
+                                      ctypes.c_void_p(d_status.data_ptr()), ctypes.c_void_p(d_work.data_ptr() if tokens else 0), ctypes.c_void_p(0)) == 0
     assert lib.spl_dev_launch_crc32(ctypes.c_void_p(d_out.data_ptr()), *args, ctypes.c_void_p(d_status.data_ptr()), ctypes.c_void_p(0)) == 0
     torch.cuda.synchronize()
     status = d_status.cpu().numpy()
