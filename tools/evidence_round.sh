@@ -10,6 +10,7 @@ python bench.py --workload mouse_stranded --beta2Cryptic --cache /tmp/wl --e2e o
 tools/e2e_timeline.sh $TAG arabidopsis > /dev/null
 tools/e2e_timeline.sh $TAG human > /dev/null
 tools/e2e_timeline.sh ${TAG}_dev human --auto-decode > /dev/null
+tools/e2e_timeline.sh ${TAG}_q1 human --seq-mode 1 --scale 1.0 --auto-decode > /dev/null
 (python3 tools/pcie_rate.py 5; SPL_STAGE_TIMING=1 python3 tools/pcie_rate.py 3) > gpurun_out/${TAG}_pcie_rate.txt 2>&1
 # host decode against the decode on the GPU (--auto-decode = what `process` does by itself), on files of constant bytes and on
 # files that deflate like real ones (--seq-mode 1)
@@ -22,7 +23,8 @@ export SPL_BAM_TIMING=1
   python3 tools/gpu_decode_steps.py /tmp/wl_files/human_s0.25_q1.bam; python3 tools/gpu_decode_steps.py /tmp/wl_files/human_s0.25_q1.bam --host ) > gpurun_out/${TAG}_gpu_decode.txt 2>&1
 (python3 tools/decode_rate.py /tmp/wl_files/human_s1_q0.bam 8 16 32 64; python3 tools/decode_rate.py /tmp/wl_files/human_s0.25_q1.bam 8 16 32 64) > gpurun_out/${TAG}_decode_rate.txt 2>&1
 unset SPL_BAM_TIMING
-bash tools/prof_inflate_pmc.sh ${TAG}_inflate 0.1 > /dev/null 2>&1
+bash tools/prof_inflate_pmc.sh ${TAG}_inflate 0.25 > /dev/null 2>&1
+bash tools/r03_window_sweep.sh ${TAG} 0.25 49152 > gpurun_out/${TAG}_inflate_kernel_stats.txt 2>&1
 (python3 tools/site_upload_time.py human; python3 tools/site_upload_time.py arabidopsis) > gpurun_out/${TAG}_site_upload.txt 2>&1
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -2 > gpurun_out/${TAG}_gpu_tests.txt
 cat gpurun_out/${TAG}_cold_time.txt gpurun_out/${TAG}_gpu_tests.txt

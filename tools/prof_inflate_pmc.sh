@@ -14,4 +14,5 @@ P cache TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_s
 P fetch FETCH_SIZE
 P write WRITE_SIZE
 P ta TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE
-cd $R && python tools/pmc_summary.py gpurun_out/pmc_${TAG}_insts gpurun_out/pmc_${TAG}_cycles gpurun_out/pmc_${TAG}_cache gpurun_out/pmc_${TAG}_fetch gpurun_out/pmc_${TAG}_write gpurun_out/pmc_${TAG}_ta | grep -i "inflate\|crc\|bam_" | tee gpurun_out/pmc_${TAG}_summary.txt
+P lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS
+cd $R && python tools/pmc_summary.py gpurun_out/pmc_${TAG}_insts gpurun_out/pmc_${TAG}_cycles gpurun_out/pmc_${TAG}_cache gpurun_out/pmc_${TAG}_fetch gpurun_out/pmc_${TAG}_write gpurun_out/pmc_${TAG}_ta gpurun_out/pmc_${TAG}_lds | grep -i "inflate\|crc\|bam_" | tee gpurun_out/pmc_${TAG}_summary.txt
