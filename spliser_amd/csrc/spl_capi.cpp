@@ -1388,11 +1388,10 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     size_t win_blocks = (size_t)49152;
     if (const char *e = getenv("SPL_INFLATE_WINDOW_BLOCKS")) win_blocks = (size_t)std::max(2, atoi(e));
     win_blocks = std::min(win_blocks, n_blocks);
-    // The first windows are short ones: nothing runs behind the first window's decoding kernel until it is through, nor behind
-    // its copying kernel, so the pipeline is filled with an eighth, a quarter and a half of a window before the whole ones.
+    // (Short first windows -- an eighth, a quarter, a half -- were tried to get the copying kernel started earlier, and cost
+    // more than they bring: a launch of the copying kernel takes as long as one lane needs for its block, 9-12 ms however few
+    // blocks it has, so three short launches are 20 ms of that kernel's stream for less than one window's worth of blocks.)
     std::vector<size_t> win_at(1, 0);
-    if (win_blocks >= 8 && !getenv("SPL_INFLATE_NO_RAMP"))
-        for (size_t part = win_blocks / 8; part < win_blocks && win_at.back() + part + win_blocks < n_blocks; part *= 2) win_at.push_back(win_at.back() + part);
     while (win_at.back() < n_blocks) win_at.push_back(std::min(n_blocks, win_at.back() + win_blocks));
     const size_t n_win = win_at.size() - 1;
     const uint64_t HEAD = (uint64_t)8 << 20; // room in front of a window's bytes for what the window before left unfinished

@@ -57,6 +57,7 @@ extern "C" int spl_gene_search(const int64_t *left, const int64_t *right, const 
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -132,6 +133,9 @@ extern "C" int spl_tsv_append(const char *path, const char *chrom, int64_t n_sit
     FILE *f = fopen(path, "ab");
     if (!f) return spl_set_error(SPL_ERR_IO, "cannot open %s for appending", path);
     const size_t chrom_len = strlen(chrom);
+    const bool tm = getenv("SPL_TSV_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     // rows [a, b) as text.  Numbers are written by hand (fmt_int, fmt_fixed below: the digits printf would give, at a tenth of
     // printf's cost -- a row has seven to ten numbers and a table a few hundred thousand rows).
     auto format = [&](int64_t a, int64_t b, std::string &out) {
@@ -177,7 +181,7 @@ extern "C" int spl_tsv_append(const char *path, const char *chrom, int64_t n_sit
         }
     };
     // slices of rows formatted on a few threads (snprintf of a quarter of a million rows is 80 ms on one), written in order
-    const int64_t SLICE = 8192;
+    const int64_t SLICE = 1024;
     const size_t n_slices = (size_t)((n_sites + SLICE - 1) / SLICE);
     std::vector<std::string> text(n_slices);
     {
@@ -197,9 +201,11 @@ extern "C" int spl_tsv_append(const char *path, const char *chrom, int64_t n_sit
         work();
         for (auto &th : pool) th.join();
     }
+    const double t1 = now();
     bool ok = true;
     for (size_t k = 0; k < n_slices && ok; ++k) ok = fwrite(text[k].data(), 1, text[k].size(), f) == text[k].size();
     if (fclose(f) != 0) ok = false;
+    if (tm) fprintf(stderr, "[spl_tsv_append] %lld rows: formatted in %.4f s, written in %.4f s\n", (long long)n_sites, t1 - t0, now() - t1);
     return ok ? SPL_OK : spl_set_error(SPL_ERR_IO, "write error on %s", path);
 }
 

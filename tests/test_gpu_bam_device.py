@@ -205,9 +205,8 @@ def test_reads_laid_out_on_the_device_count_like_the_oracle(seed, stranded, ctx,
 
 @pytest.mark.parametrize("window", ["2", "3", "7", "16", "40"])
 def test_inflate_windows_of_a_few_blocks(ctx, tmp_path, monkeypatch, window):
-    """The stream is inflated, scanned and emptied of its records a window at a time (49 152 blocks in production, the first
-    three an eighth, a quarter and a half of that -- from 8 blocks on here, too): windows of a few blocks on files of a few
-    hundred -- every window ends in the middle of a record, blocks near a window's end are done
+    """The stream is inflated, scanned and emptied of its records a window at a time (49 152 blocks in production): windows of a few
+    blocks on files of a few hundred -- every window ends in the middle of a record, blocks near a window's end are done
     again by the next, the extracted arrays grow as they go -- must give what the host decoder gives; records larger than a
     window are the host decoder's."""
     monkeypatch.setenv("SPL_INFLATE_WINDOW_BLOCKS", window)
