@@ -1405,8 +1405,11 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     free_b += devmem::held_bytes(c->device);
     // Three windows in flight: a window's buffer is free again when its records are extracted, and with two the decoding kernel
     // of window k + 2 waited for that -- decode, copy, scan and extract of one window in a row, 34 ms for two windows of work
-    // (measured on the 14 GB file: 20 ms a window with two buffers, 18.7 with three, no less with four).
-    int want_buf = 3;
+    // (measured on the 14 GB file: 20 ms a window with two buffers, 18.7 with three, no less with four).  The third is taken when
+    // the process holds the memory for it already (a call after another): fresh device memory costs 6-15 ms a gigabyte, which
+    // for 7 GB is more than the 20 ms the buffer saves -- a process that decodes one file (the command line) stays with two.
+    const size_t per_buf = (size_t)win_cap + (size_t)HEAD + work_bytes;
+    int want_buf = devmem::held_bytes(c->device) >= 3 * per_buf ? 3 : 2;
     if (const char *e = getenv("SPL_INFLATE_BUFFERS")) want_buf = std::min(NBUF, std::max(1, atoi(e)));
     const int n_buf = (int)std::min<size_t>((size_t)want_buf, n_win);
     if ((double)n_buf * ((double)win_cap + (double)HEAD + (double)work_bytes) + (double)(stream_len - stream_begin) * 0.2 + (double)((size_t)1 << 30) > (double)free_b)
@@ -1443,11 +1446,11 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     size_t first = 0; // the first block that holds more than BAM header
     if (first_share)
         while (first < n_blocks && blocks[first].out + blocks[first].out_len <= H && !(blocks[first].out + blocks[first].out_len == H && first + 1 == n_blocks)) ++first;
-    // the extracted arrays: as large as the first window says the share will need and a tenth more, larger when that was wrong
+    // the extracted arrays: as large as the first window says the share will need and a fifth more, larger when that was wrong
     uint64_t cap_rec = 0, cap_ops = 0, n_rec = 0, n_ops = 0;
     auto make_room = [&](uint64_t need_rec, uint64_t need_ops, double part_done) -> int {
         if (need_rec <= cap_rec && need_ops <= cap_ops && cap_rec) return SPL_OK;
-        const double scale = 1.1 / std::max(part_done, 1e-6);
+        const double scale = 1.2 / std::max(part_done, 1e-6); // (a fifth more than the windows so far say: growing later means fresh memory and moving what is there)
         const uint64_t want_rec = std::max<uint64_t>(need_rec, (uint64_t)((double)need_rec * scale)) + 1024;
         const uint64_t want_ops = std::max<uint64_t>(need_ops, (uint64_t)((double)need_ops * scale)) + 1024;
         DevBuf pos2, flag2, cigoff2, cigar2, tid2;
