@@ -24,6 +24,7 @@ ap.add_argument("--files", default="/tmp/wl_files")
 ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--devices", default="0", help="e.g. 0,0 = two contexts (and host threads) on GPU 0")
 ap.add_argument("--gpu-decode", action="store_true", help="BGZF inflate and record extraction on the GPU (process(gpuDecode=True))")
+ap.add_argument("--pause", type=float, default=0.0, help="seconds of sleep before the last run")
 ap.add_argument("--auto-decode", action="store_true", help="process(gpuDecode=None): by the file's compression (the product's default)")
 args = ap.parse_args()
 cfg = synth.WORKLOADS[args.workload]
@@ -49,6 +50,8 @@ if not (os.path.exists(prefix + ".bam") and os.path.exists(prefix + ".n")):
     del wl
 n_reads = int(open(prefix + ".n").read())
 for k in range(args.runs):
+    if args.pause and k + 1 == args.runs and k:
+        time.sleep(args.pause)       # (tools/e2e_timeline.py --last-call finds the last call behind this silence)
     t = time.perf_counter()
     tm = process.process(prefix + ".bam", prefix + ".bed", prefix + ".out", annotationFile=prefix + ".gff", isStranded=bool(stranded),
                          strandedType=stranded, isbeta2Cryptic=bool(stranded), log=lambda m: None,

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 --kernel-trace --memory-copy-trace directory of tools/e2e_profile.py --runs 1: the copies and kernels of
-the `process` call on one time axis.   tools/e2e_timeline.py <dir>"""
+"""Summarise a rocprofv3 --kernel-trace --memory-copy-trace directory of tools/e2e_profile.py: the copies and kernels of the
+`process` call on one time axis.   tools/e2e_timeline.py <dir> [--last-call]
+--last-call: the traced process made several calls and slept a second before the last one (e2e_profile.py --pause 1): only what
+lies behind the longest silence in the trace is summarised -- a call of a process that has its context and its memory."""
 import csv
 import glob
 import sys
@@ -29,7 +31,16 @@ kernels.sort()
 copies.sort()
 if not kernels:
     sys.exit("no kernels in the trace")
-# (tools/e2e_timeline.sh traces a process that makes ONE call: everything in the trace belongs to it)
+if "--last-call" in sys.argv[2:]:
+    ev = sorted([(a, b) for a, b, _ in kernels] + [(c[0], c[1]) for c in copies])
+    cut, gap, end = ev[0][0], 0, ev[0][1]
+    for a, b in ev[1:]:
+        if a - end > gap:
+            gap, cut = a - end, a
+        end = max(end, b)
+    kernels = [k for k in kernels if k[0] >= cut]
+    copies = [c for c in copies if c[0] >= cut]
+    print("(the last call of the traced process: what lies behind a silence of %.2f s)" % (gap / 1e9))
 t0 = min([k[0] for k in kernels] + [c[0] for c in copies])
 t1 = max([k[1] for k in kernels] + [c[1] for c in copies])
 
@@ -95,5 +106,5 @@ for name, u in (("H2D", hu), ("kernels", ku)):
         else:
             cur = [a, b]
             events.append((cur, name))
-for (a, b), name in sorted(events, key=lambda e: e[0][0])[:80]:
+for (a, b), name in sorted(events, key=lambda e: e[0][0])[:240]:
     print("  %9.2f .. %9.2f  %s" % ((a - t0) / 1e6, (b - t0) / 1e6, name))

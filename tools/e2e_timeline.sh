@@ -8,6 +8,8 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out /tmp/wl
 cd $R && python3 tools/e2e_profile.py $W --runs 2 "$@" > $R/gpurun_out/${TAG}_e2e_${W}_plain.log 2>&1     # writes the files, warms the page cache
 cd /tmp && rm -rf /tmp/tl_$W
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tl_$W -- python3 $R/tools/e2e_profile.py $W --runs 1 "$@" > $R/gpurun_out/${TAG}_e2e_${W}_traced.log 2>&1
-python3 $R/tools/e2e_timeline.py /tmp/tl_$W > $R/gpurun_out/${TAG}_e2e_${W}_timeline.txt 2>&1
+# (two calls under the tracer, a second of sleep between them: the summary is of the second, a call of a process that has its
+#  HIP context and its device memory -- the first one's is in the trace directory for whoever wants it)
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tl_$W -- python3 $R/tools/e2e_profile.py $W --runs 2 --pause 1 "$@" > $R/gpurun_out/${TAG}_e2e_${W}_traced.log 2>&1
+python3 $R/tools/e2e_timeline.py /tmp/tl_$W --last-call > $R/gpurun_out/${TAG}_e2e_${W}_timeline.txt 2>&1
 tail -3 $R/gpurun_out/${TAG}_e2e_${W}_plain.log; tail -40 $R/gpurun_out/${TAG}_e2e_${W}_timeline.txt
