@@ -247,9 +247,9 @@ int spl_bam_decoded_on_device(spl_bam *bam, int *on_device_out);
 /* A deferred file's other option, said out loud: decode on the host's threads, starting now.  Also ends a reservation that
  * nobody has taken up (its maker failed before it could call spl_bam_decode_device). */
 int spl_bam_start(spl_bam *bam);
-/* Inflated bytes per file byte over the first record blocks of a deferred file (0 = cannot tell): BGZF inflate is what a decode
- * costs, and which side inflates faster depends on this number -- a real library's file (3...4) is twice as fast on the GPU, a
- * file that inflates at memset speed (synthetic data: 50) is faster on the host.  `process` decides by it unless told otherwise. */
+/* Inflated bytes per file byte over the first record blocks of a deferred file (0 = cannot tell).  Diagnostic: BGZF inflate is
+ * what a decode costs; since the wave-per-block decoder the GPU is the faster side for a real library's file (3...4) and for one
+ * that inflates at memset speed (synthetic data: 50) alike, and `process` no longer asks. */
 int spl_bam_compression_ratio(spl_bam *bam, double *ratio_out);
 int spl_bam_wait_ref(spl_bam *bam, int tid, int64_t *n_reads_out, int64_t *max_end_out);
 int spl_bam_wait_all(spl_bam *bam, int *sorted_out);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/r03_token_k2.sh <tag> RING:FIFO ...   (GPU box) -- the copying kernel with a window of the output in LDS
-# (profiles/experiments/r03_copy_kernel_lds_window.patch), by the size of that window: builds each variant, checks it, times
+# (spl_inflate_wave.h: SPLZ_RING / SPLZ_FIFO), by the size of that window: builds each variant, checks it, times
 # process() on the 200 M-read files and the kernels under rocprofv3
 TAG=$1; shift
 export TMPDIR=/tmp
