@@ -1265,7 +1265,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     int rc = ensure_stage(c);
     if (rc) return rc;
     // ---- everything the streams touch is declared before them: what is declared last goes first, and that is the guard that waits
-    constexpr int NBUF = 4, NCOPY = 1; // (NBUF: at most -- n_buf of them are used, below.  NCOPY, measured twice: two windows' copying kernels side by side take longer, 0.68-0.80 s against 0.51-0.58 s for a 14 GB file -- they get in each other's way in the memory system) // (measured twice: four buffers with two windows' copies side by side take longer, 0.68-0.80 s against 0.51-0.58 s for a 14 GB file -- two copying kernels at once get in each other's way in the memory system)
+    constexpr int NBUF = 4, NCOPY = 2; // (at most: n_buf buffers and n_copy streams for the copying kernels are used, below)
     DevBuf d_image, d_stream[NBUF], d_zwork[NBUF], d_blocks, d_status, d_scan, d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
     std::vector<spl_zblock> blocks;
     std::unique_ptr<uint32_t[]> status;
@@ -1276,7 +1276,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     uint32_t n_bounds = 0;
     struct Pipe { // stream A, stream B, their events; waits for everything on the way out, whichever way that is
         spl_ctx *c;
-        hipStream_t a = nullptr, b = nullptr, cp[NCOPY] = {nullptr};
+        hipStream_t a = nullptr, b = nullptr, cp[NCOPY] = {};
         hipEvent_t k1[NBUF] = {}, k2[NBUF] = {}, freed[NBUF] = {}, setup = nullptr;
         std::vector<hipEvent_t> piece;
         explicit Pipe(spl_ctx *ctx) : c(ctx) {}
@@ -1412,6 +1412,8 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     int want_buf = devmem::held_bytes(c->device) >= 3 * per_buf ? 3 : 2;
     if (const char *e = getenv("SPL_INFLATE_BUFFERS")) want_buf = std::min(NBUF, std::max(1, atoi(e)));
     const int n_buf = (int)std::min<size_t>((size_t)want_buf, n_win);
+    int n_copy = 1; // streams the copying kernels take turns on (1: one window's copies behind the other's)
+    if (const char *e = getenv("SPL_INFLATE_COPY_STREAMS")) n_copy = std::min(NCOPY, std::max(1, atoi(e)));
     if ((double)n_buf * ((double)win_cap + (double)HEAD + (double)work_bytes) + (double)(stream_len - stream_begin) * 0.2 + (double)((size_t)1 << 30) > (double)free_b)
         return to_host("not enough device memory for the inflated stream");
     for (int k = 0; k < n_buf; ++k) {
@@ -1499,7 +1501,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_buf].p, pipe.a));
         }
         HIP_TRY(hipEventRecord(pipe.k1[k % (size_t)n_buf], pipe.a));
-        hipStream_t cs = pipe.cp[k % (size_t)NCOPY];
+        hipStream_t cs = pipe.cp[k % (size_t)n_copy];
         HIP_TRY(hipStreamWaitEvent(cs, pipe.k1[k % (size_t)n_buf], 0));
         {
             splprof::Scope p("spl_inflate_copy_kernel", cs, w_out);

@@ -466,6 +466,16 @@ WV_DEV uint32_t copy_block(uint8_t *out, uint32_t out_len, const uint8_t *stream
     bool pending = false;
     uint32_t op = 0, flushed = 0;           // bytes made / bytes of them in memory (a multiple of 16)
     uint32_t lit_left = 0, left = 0, dist = 1;
+    uint64_t ahead_lo = 0, ahead_hi = 0;    // the next piece of a far match, asked for a turn ahead
+    bool ahead = false;
+    // ... and the FIRST piece of the next far match, asked for several turns ahead: a second reader walks the tokens in the FIFO
+    // in front of the first (one token a turn), keeping count of where in the output each begins, and when it comes to a match
+    // whose source lies further back than the window -- and in memory already -- it asks for those 16 bytes and stands still
+    // until the first reader has got there and taken them.
+    uint32_t la_sp = 0, la_op = 0;          // the second reader: token position, and the output position where that token begins
+    uint64_t pre_lo = 0, pre_hi = 0;
+    uint32_t pre_sp = 0;                    // the token the bytes asked for belong to
+    bool pre = false, first = false;
     // a piece of 16 bytes (the first k meant) to the window at `op`, mirrored where the window wraps
     auto to_ring = [&](uint64_t lo, uint64_t hi) {
         const uint32_t o = op & (RING - 1u);
@@ -501,6 +511,8 @@ WV_DEV uint32_t copy_block(uint8_t *out, uint32_t out_len, const uint8_t *stream
                 const uint32_t b1 = wv::lds_ld8(t + 1), b2 = wv::lds_ld8(t + 2);
                 left = ((c & 0x7fu) | (b1 & 1u) << 7) + 3u;
                 dist = ((b1 >> 1) | b2 << 7) + 1u;
+                first = pre && pre_sp == sp;       // (its first sixteen bytes are on their way, or here)
+                if (first) pre = false;
                 sp += 3u;
                 if (dist > op) return 0xffffffffu; // (the decoding kernel checked: a damaged stream)
             }
@@ -516,15 +528,23 @@ WV_DEV uint32_t copy_block(uint8_t *out, uint32_t out_len, const uint8_t *stream
             lit_left -= k;
         } else {
             k = left < 16u ? left : 16u;
-            if (dist < 8u) k = k < 8u ? k : 8u;      // (made from the period, below)
-            else if (dist < k) k = dist;             // (only what is there already)
+            if (dist >= 8u && dist < k) k = dist;    // (only what is there already; below 8 the piece is made from the period)
             if (dist <= RING - 16u) wv::lds_ld128(ring + ((op - dist) & (RING - 1u)), lo, hi);
-            else { wv::mem_ld128(out + op - dist, lo, hi); wv::settle64(lo); wv::settle64(hi); } // (further back than the window: in memory, whole pieces behind `flushed`; waited for here, not where the two ways meet)
-            if (dist < 8u) { // the bytes repeat with a period shorter than the piece: the period, as often as it fits
+#ifdef SPLZ_X_NOFAR
+            else wv::lds_ld128(ring + ((op - dist) & (RING - 1u)), lo, hi);
+#else
+            else if (ahead) { lo = ahead_lo; hi = ahead_hi; wv::settle64(lo); wv::settle64(hi); } // (asked for by the turn before)
+            else if (first) { lo = pre_lo; hi = pre_hi; wv::settle64(lo); wv::settle64(hi); }     // (asked for by the second reader)
+            else { wv::mem_ld128(out + op - dist, lo, hi); wv::settle64(lo); wv::settle64(hi); }
+#endif
+            first = false; // (further back than the window: in memory, whole pieces behind `flushed`; waited for here, not where the two ways meet)
+            if (dist < 8u) { // the bytes repeat with a period shorter than the piece: sixteen bytes of the period
                 lo &= (1ull << (8u * dist)) - 1ull;
                 lo |= lo << (8u * dist);
                 if (dist < 4u) lo |= lo << (16u * dist);
                 if (dist < 2u) lo |= lo << 32;
+                const uint32_t r = (0x1230200u >> (4u * (dist - 1u))) & 7u; // 8 mod dist: where in the period the second half begins
+                hi = r ? lo >> (8u * r) | lo << (8u * (dist - r)) : lo;
             }
             left -= k;
         }
@@ -534,9 +554,44 @@ WV_DEV uint32_t copy_block(uint8_t *out, uint32_t out_len, const uint8_t *stream
         if (op - flushed >= 16u) { // a whole piece of the output: to memory, once
             uint64_t a, b;
             wv::lds_ld128(ring + (flushed & (RING - 1u)), a, b);
+#ifndef SPLZ_X_NOSTORE
             wv::mem_st128(out + flushed, a, b);
+#endif
             flushed += 16u;
         }
+        // a far match that goes on: its next piece is asked for now (behind this turn's store: what it reads is in memory, the
+        // source ends at op - dist + 16 <= flushed as dist > RING - 16 >= 31) and used by the next turn, which then has not
+        // waited for memory at all -- a long match was a chain of round trips, one per 16 bytes
+        ahead = left != 0u && lit_left == 0u && dist > RING - 16u;
+#ifdef SPLZ_X_NOFAR
+        ahead = false;
+#endif
+        if (ahead) wv::mem_ld128(out + op - dist, ahead_lo, ahead_hi);
+#ifndef SPLZ_X_NOFAR
+        if (!pre) { // the second reader's turn: one token
+            const uint32_t next_sp = sp + lit_left, next_op = op + lit_left + left; // where the first reader's next token begins
+            if (la_sp < next_sp) { la_sp = next_sp; la_op = next_op; }
+            const uint32_t there = f_wr < n_tok ? f_wr : n_tok;
+            if (la_sp + 3u <= there) {
+                const uint8_t *t = fifo + (la_sp & (FIFO - 1u));
+                const uint32_t c = wv::lds_ld8(t);
+                if (c < 0x80u) { la_sp += c + 2u; la_op += c + 1u; }
+                else {
+                    const uint32_t b1 = wv::lds_ld8(t + 1), b2 = wv::lds_ld8(t + 2);
+                    const uint32_t len = ((c & 0x7fu) | (b1 & 1u) << 7) + 3u, d = ((b1 >> 1) | b2 << 7) + 1u;
+                    if (d > RING - 16u && d <= la_op) {
+                        if (la_op - d + 16u <= flushed) { // its source is in memory (else: next turn again, more will be)
+                            wv::mem_ld128(out + la_op - d, pre_lo, pre_hi);
+                            pre = true;
+                            pre_sp = la_sp;
+                            la_sp += 3u;
+                            la_op += len;
+                        }
+                    } else { la_sp += 3u; la_op += len; }
+                }
+            }
+        }
+#endif
     }
     if (op > flushed) {
         uint64_t a, b;
