@@ -321,7 +321,23 @@ const char *spl_text_names(const spl_textfile *t, const uint32_t **off_out); /* 
  * Appends the rows of one chromosome to a .SpliSER.tsv file (the caller writes the header line): 12 tab-separated
  * columns, SSE as "%.3f", the two cryptic columns as an integer and "%.5f" or "NA NA" when cryptic == 0, Partners as
  * Python's str(dict) "{pos: count, ...}" in partner order, Competitors as str(list).  Strand and gene texts come as one
- * blob each with n_sites + 1 offsets.  No GPU involved. */
+ * blob each with n_sites + 1 offsets.  No GPU involved.  spl_tsv_append_many: the same for several chromosomes at once, in the
+ * order given (their rows are formatted side by side). */
+typedef struct spl_tsv_rows {
+    const char *chrom;
+    int64_t n_sites;
+    const int64_t *pos;
+    const char *strand_blob; const uint32_t *strand_off;
+    const char *gene_blob; const uint32_t *gene_off;
+    const double *sse;
+    const int64_t *alpha;
+    const uint32_t *beta1;
+    const int64_t *beta2_simple, *beta2_cryptic; /* beta2_cryptic, beta2_weighted: read when cryptic != 0 */
+    const double *beta2_weighted;
+    const uint32_t *part_off; const int64_t *part_pos, *edge_cnt;
+    const uint32_t *comp_off; const int64_t *comp_pos;
+} spl_tsv_rows;
+int spl_tsv_append_many(const char *path, int32_t n_chrom, const spl_tsv_rows *rows, int cryptic);
 int spl_tsv_append(const char *path, const char *chrom, int64_t n_sites, const int64_t *pos, const char *strand_blob,
                    const uint32_t *strand_off, const char *gene_blob, const uint32_t *gene_off, const double *sse,
                    const int64_t *alpha, const uint32_t *beta1, const int64_t *beta2_simple, int cryptic,

@@ -51,7 +51,7 @@ EXPORTS = [
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_cancel", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
-    "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append", "spl_fmt_fixed",
+    "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append", "spl_tsv_append_many", "spl_fmt_fixed",
     "spl_bed_open", "spl_gff_open", "spl_text_close", "spl_text_rows", "spl_text_n_chrom", "spl_text_chrom_name", "spl_text_chrom",
     "spl_text_i64", "spl_text_strand", "spl_text_names",
 ]
@@ -418,19 +418,47 @@ def tsv_prepare(arr):
     return st
 
 
+class spl_tsv_rows(ctypes.Structure):
+    _fields_ = [("chrom", ctypes.c_char_p), ("n_sites", ctypes.c_int64), ("pos", ctypes.c_void_p), ("strand_blob", ctypes.c_char_p),
+                ("strand_off", ctypes.c_void_p), ("gene_blob", ctypes.c_char_p), ("gene_off", ctypes.c_void_p), ("sse", ctypes.c_void_p),
+                ("alpha", ctypes.c_void_p), ("beta1", ctypes.c_void_p), ("beta2_simple", ctypes.c_void_p), ("beta2_cryptic", ctypes.c_void_p),
+                ("beta2_weighted", ctypes.c_void_p), ("part_off", ctypes.c_void_p), ("part_pos", ctypes.c_void_p), ("edge_cnt", ctypes.c_void_p),
+                ("comp_off", ctypes.c_void_p), ("comp_pos", ctypes.c_void_p)]
+
+
+def tsv_append_many(path, items, cryptic):
+    """Rows of several chromosomes, [(ChromArrays, results)], appended to ``path`` in that order by ``spl_tsv_append_many`` (same
+    bytes as tsv.format_chrom for each)."""
+    n = len(items)
+    if n == 0:
+        return
+    rows = (spl_tsv_rows * n)()
+    keep = []
+    addr = lambda a: None if a is None else a.ctypes.data   # noqa: E731
+    c64 = lambda a: np.ascontiguousarray(a, np.int64)       # noqa: E731
+    for k, (arr, res) in enumerate(items):
+        st = tsv_prepare(arr)
+        beta1 = np.ascontiguousarray(res["beta1"], np.uint32)
+        b2s = c64(res["beta2_simple"])
+        sse = np.ascontiguousarray(res["sse"], np.float64)
+        b2c = c64(res["beta2_cryptic"]) if cryptic else None
+        b2w = np.ascontiguousarray(res["beta2_weighted"], np.float64) if cryptic else None
+        keep.append((st, beta1, b2s, sse, b2c, b2w))
+        r = rows[k]
+        r.chrom, r.n_sites = st["chrom"], arr.n
+        r.pos, r.strand_blob, r.strand_off = addr(st["pos"]), st["strand_blob"], addr(st["strand_off"])
+        r.gene_blob, r.gene_off = st["gene_blob"], addr(st["gene_off"])
+        r.sse, r.alpha, r.beta1, r.beta2_simple = addr(sse), addr(st["alpha"]), addr(beta1), addr(b2s)
+        r.beta2_cryptic, r.beta2_weighted = addr(b2c), addr(b2w)
+        r.part_off, r.part_pos, r.edge_cnt = addr(st["part_off"]), addr(st["part_pos"]), addr(st["edge_cnt"])
+        r.comp_off, r.comp_pos = addr(st["comp_off"]), addr(st["comp_pos"])
+    _check(lib().spl_tsv_append_many(os.fsencode(path), ctypes.c_int32(n), rows, ctypes.c_int(1 if cryptic else 0)))
+    del keep
+
+
 def tsv_append(path, arr, res, cryptic):
-    """Rows of one chromosome appended to ``path`` by ``spl_tsv_append`` (same bytes as tsv.format_chrom)."""
-    st = tsv_prepare(arr)
-    c64 = lambda a: np.ascontiguousarray(a, np.int64)   # noqa: E731
-    beta1 = np.ascontiguousarray(res["beta1"], np.uint32)
-    b2s = c64(res["beta2_simple"])
-    sse = np.ascontiguousarray(res["sse"], np.float64)
-    b2c = c64(res["beta2_cryptic"]) if cryptic else None
-    b2w = np.ascontiguousarray(res["beta2_weighted"], np.float64) if cryptic else None
-    _check(lib().spl_tsv_append(os.fsencode(path), st["chrom"], ctypes.c_int64(arr.n), _ptr(st["pos"]), st["strand_blob"],
-                                _ptr(st["strand_off"]), st["gene_blob"], _ptr(st["gene_off"]), _ptr(sse), _ptr(st["alpha"]), _ptr(beta1), _ptr(b2s),
-                                ctypes.c_int(1 if cryptic else 0), _ptr(b2c), _ptr(b2w), _ptr(st["part_off"]), _ptr(st["part_pos"]),
-                                _ptr(st["edge_cnt"]), _ptr(st["comp_off"]), _ptr(st["comp_pos"])))
+    """Rows of one chromosome appended to ``path`` (``spl_tsv_append_many`` with one; same bytes as tsv.format_chrom)."""
+    tsv_append_many(path, [(arr, res)], cryptic)
 
 
 def write_bam(path, ref_names, ref_lengths, read_sets, level=1, threads=0, seq_mode=0):

@@ -325,14 +325,18 @@ class _TsvWriter(object):
                         if self.next >= len(self.order):
                             return
                         if self.order[self.next] in self.ready:
-                            arr, res = self.ready.pop(self.order[self.next])
-                            self.taken.add(self.order[self.next])
+                            batch = []      # everything that is there and next in the table's order: formatted side by side
+                            k = self.next
+                            while k < len(self.order) and self.order[k] in self.ready:
+                                batch.append(self.ready.pop(self.order[k]))
+                                self.taken.add(self.order[k])
+                                k += 1
                             break
                         self.cond.wait()
                 t = time.perf_counter()
-                native.tsv_append(self.path, arr, res, self.cryptic)   # (the file is appended to in order, by this thread only)
+                native.tsv_append_many(self.path, batch, self.cryptic)   # (the file is appended to in order, by this thread only)
                 self.seconds += time.perf_counter() - t
-                self.next += 1
+                self.next += len(batch)
         except BaseException as exc:   # surfaced by close()
             self.error = exc
 
