@@ -194,12 +194,25 @@ WV_DEV void distance_code(uint32_t i, uint32_t &base, uint32_t &extra)
 }
 
 // One symbol at bit `pos` of the tile: a literal (its value), SYM_EOB, SYM_MATCH (len, dist set) or SYM_BAD.  `pos` moves past it.
-WV_DEV uint32_t decode(const Shared &sh, uint32_t base, uint32_t &pos, uint32_t &len, uint32_t &dist)
+// Behind a literal that ends before `stop` a SECOND literal is taken from the bits already at hand (17 at least: enough for any
+// code) if a literal is what follows: lit2 is its value, or NO_LIT2.  A wave's turn costs what its slowest path costs, and the
+// lane with the most turns in a tile is the one whose subsequence is all short literal codes: two to a turn, it has half of them.
+constexpr uint32_t NO_LIT2 = 0xffffffffu;
+WV_DEV uint32_t decode(const Shared &sh, uint32_t base, uint32_t &pos, uint32_t &len, uint32_t &dist, uint32_t stop, uint32_t &lit2)
 {
     uint32_t w = tbits(sh.tile, base, pos), used;
     const uint32_t sym = lut_symbol(sh.lut_l, ROOT_L, w, used);
+    lit2 = NO_LIT2;
     if (sym == SYM_BAD) return SYM_BAD;
-    if (sym <= 256u) { pos += used; return sym; }
+    if (sym <= 256u) {
+        pos += used;
+        if (sym < 256u && pos < stop) {
+            uint32_t used2;
+            const uint32_t s2 = lut_symbol(sh.lut_l, ROOT_L, w >> used, used2);
+            if (s2 < 256u) { lit2 = s2; pos += used2; }
+        }
+        return sym;
+    }
     if (sym > 285u) return SYM_BAD;
     uint32_t b, x;
     length_code(sym - 257u, b, x);
@@ -222,12 +235,17 @@ WV_DEV Count count_from(const Shared &sh, uint32_t base, uint32_t start, uint32_
     Count c{start, 0, 0, FL_OK};
     uint32_t run = 0; // literals in the run that is open (0: none)
     while (c.end < sub_end) {
-        uint32_t len = 0, dist = 0;
-        const uint32_t s = decode(sh, base, c.end, len, dist);
+        uint32_t len = 0, dist = 0, lit2;
+        const uint32_t s = decode(sh, base, c.end, len, dist, sub_end, lit2);
         if (s < 256u) {
             if (run == 0u || run == 128u) { c.n_tok++; run = 0; }
             c.n_tok++; run++;
             c.n_out++;
+            if (lit2 != NO_LIT2) {
+                if (run == 128u) { c.n_tok++; run = 0; }
+                c.n_tok++; run++;
+                c.n_out++;
+            }
             continue;
         }
         if (s == SYM_MATCH) { c.n_out += len; c.n_tok += 3u; run = 0; continue; }
@@ -402,12 +420,17 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             if (valid) {
                 uint32_t p = start, wr = at + cum_o - c.n_out, tp = cum_t - c.n_tok, run = 0, hdr = 0;
                 while (p < sub_end) {
-                    uint32_t len = 0, dist = 0;
-                    const uint32_t s = decode(sh, base, p, len, dist);
+                    uint32_t len = 0, dist = 0, lit2;
+                    const uint32_t s = decode(sh, base, p, len, dist, sub_end, lit2);
                     if (s < 256u) {
                         if (run == 0u || run == 128u) { if (run) tok[hdr] = 127; hdr = tp++; run = 0; }
                         tok[tp++] = (uint8_t)s;
                         ++run; ++wr;
+                        if (lit2 != NO_LIT2) {
+                            if (run == 128u) { tok[hdr] = 127; hdr = tp++; run = 0; }
+                            tok[tp++] = (uint8_t)lit2;
+                            ++run; ++wr;
+                        }
                         continue;
                     }
                     if (run) { tok[hdr] = (uint8_t)(run - 1u); run = 0; }
