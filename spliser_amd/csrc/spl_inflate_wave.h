@@ -8,12 +8,14 @@
 //   copy_block     one BGZF block per LANE: the token stream read front to back and the block's bytes made from it -- literals
 //                  copied, matches copied from what is there by then -- through a small window of the newest output in LDS
 //                  (RING bytes a lane): whole 16-byte pieces of the output go to memory once, a match's source is read from the
-//                  window when it lies that close and from memory otherwise, the token stream comes in 64 bytes at a time on a
-//                  fixed beat, asked for a beat before it is needed.  What this is made to avoid: the first version kept lists
-//                  of matches and copied in place, three to four scattered 16-byte accesses per match and 9 000 matches a block
-//                  (22 ms per 49 152 blocks); this one stores every output byte once and loads every token byte once (12.6 ms).
-//                  The window is small on purpose: with 512 bytes a lane (53 KB a wave) the kernel is another millisecond
-//                  faster alone, and its waves leave the decoding kernel, which runs beside it, no LDS to be resident with
+//                  window when it lies that close and from memory otherwise -- asked for AHEAD: the next piece of a match that
+//                  goes on a turn before it is needed, the first piece of the next far match by a second reader that walks the
+//                  tokens in front of the first --, the token stream comes in 64 bytes at a time on a fixed beat, asked for a
+//                  beat before it is needed.  What this is made to avoid: the first version kept lists of matches and copied
+//                  in place, three to four scattered 16-byte accesses per match and 9 000 matches a block (22 ms per 49 152
+//                  blocks); this one stores every output byte once and loads every token byte once (10.5 ms).  The window is
+//                  small on purpose: with 512 bytes a lane (53 KB a wave) the kernel is another millisecond faster alone, and
+//                  its waves leave the decoding kernel, which runs beside it, no LDS to be resident with
 //                  (profiles/r03_inflate_wave_account.md).
 //
 // Why the split.  Round 2 gave every lane a block of its own for everything: a lane's Huffman tables were 356 bytes of LDS and
@@ -31,7 +33,7 @@
 // it would produce; then every lane takes its predecessor's end as its start and decodes again if that differs, until nothing
 // changes.  Wrongly started decoders fall into step with the true sequence of symbols sooner or later, so a few passes do; lane k
 // is right after pass k + 1 whatever the data.  A prefix sum over the lanes' byte counts places every lane in the output, and a last
-// pass decodes once more for good.
+// pass decodes once more for good.  A turn of any pass takes one symbol, or two when both are literals (decode).
 //
 // Replaces what SpliSER_v0_1_8.py:422 (samtools view) does to every BGZF block it touches.
 #ifndef SPL_INFLATE_WAVE_H

@@ -438,7 +438,7 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
             #  and nobody is waiting for that: on a thread of its own)
             closer = threading.Thread(target=source.close)
             closer.start()
-            _closers.append(closer)
+            _closers[:] = [t for t in _closers if t.is_alive()] + [closer]
     timings["bam_decode"] = "device" if getattr(source, "on_device", False) else "host"
     timings.update(open_s=t_open - t0, site_table_s=t1 - t_open, step3_s=t3 - t1, write_tail_s=t4 - t3, write_s=writer.seconds,
                    close_s=time.perf_counter() - t4, total_s=time.perf_counter() - t0)
