@@ -301,6 +301,7 @@ struct spl_ctx {
     // hipHostRegister: on this stack that costs 0.7 ms per 32 MiB where hipHostMalloc costs 5 (tools/micro/hostmem.cpp), and
     // copies run at 50...55 GB/s from pieces of this size (20 GB/s from 8 MiB pieces).
     struct Stage { char *host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool busy = false, locked = false; };
+    size_t stage_mb = 32; // size of a staging buffer (set when the ring is made)
     std::vector<Stage> stage;
     size_t stage_next = 0;
     hipStream_t copy = nullptr;
@@ -680,6 +681,7 @@ static void build_junction_table(const spl_sites *s, const std::vector<uint8_t> 
 }
 
 static int ensure_stage(spl_ctx *c);
+static int grow_stage(spl_ctx *c, int n);
 
 extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out)
 {
@@ -897,6 +899,15 @@ static int ensure_stage(spl_ctx *c)
         HIP_TRY(hipEventCreate(&c->ev_t1));
         c->stage_timing = true;
     }
+    c->stage_mb = mb;
+    return grow_stage(c, n);
+}
+
+// The staging ring of a context grown to n buffers (never shrunk): page-locked, of the ring's size, from the process's pool of
+// such buffers first.
+static int grow_stage(spl_ctx *c, int n)
+{
+    const size_t mb = c->stage_mb;
     const size_t huge = 2u << 20, bytes = (mb << 20) / huge * huge < huge ? huge : (mb << 20) / huge * huge;
     const bool want_lock = !(getenv("SPL_STAGE_PAGEABLE"));
     {   // buffers a destroyed context of this process left behind (same device, same size): page-locking 96 MiB anew costs 12 ms
@@ -1331,6 +1342,9 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     HIP_TRY(hipMemsetAsync(d_image.as<char>() + n_bytes, 0, SPL_Z_IMAGE_PAD, c->copy));
     // The file's bytes: page cache -> staging buffer -> device.  One reader thread per staging buffer: it preads its pieces (a
     // piece = a buffer's size, dealt round-robin), sends each on its way itself and records the piece's event behind it.
+    // (a reader fills its buffer from the page cache at 8-10 GB/s before the copy engine takes 0.6 ms to empty it: three readers
+    //  bring 25-40 GB/s, and since the kernels got through a window in 16 ms a large file waited for its bytes: six for those)
+    if (n_bytes >= ((size_t)4 << 30) && !getenv("SPL_STAGE_BUFFERS")) { rc = grow_stage(c, 6); if (rc) return rc; }
     const size_t n_stage = c->stage.size();
     const size_t piece = c->stage[0].bytes;
     const size_t n_pieces = (n_bytes + piece - 1) / piece;
