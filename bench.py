@@ -37,6 +37,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # (before torch starts the HIP runtime: spl_create in csrc/spl_capi.cpp says why)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

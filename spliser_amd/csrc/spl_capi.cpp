@@ -424,6 +424,12 @@ static int create_ctx(int device_id, void *stream, bool use_given, spl_ctx **out
 {
     if (!out) return spl_set_error(SPL_ERR_ARG, "spl_create: null output");
     *out = nullptr;
+    // The HIP runtime deals a process's streams out to a few hardware queues (four unless told otherwise), and streams on one
+    // queue run behind each other.  A `process` call has eight (the decode's four, the counting context's three and one for
+    // nobody): with four queues it depends on the order they were made in whether the decoding and the copying kernel overlap
+    // (measured: 0.43 s or 0.75 s for the same 14 GB file; 0.82 s with two queues).  Eight queues, unless the caller has said
+    // otherwise -- and only if the runtime has not been started yet by somebody else (it reads this once).
+    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -1287,15 +1293,18 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     uint32_t n_bounds = 0;
     struct Pipe { // stream A, stream B, their events; waits for everything on the way out, whichever way that is
         spl_ctx *c;
-        hipStream_t a = nullptr, b = nullptr, cp[NCOPY] = {};
+        hipStream_t a = nullptr, b = nullptr, cp[NCOPY] = {}, up2 = nullptr; // (up2: a second stream for the file's pieces, beside the context's copy stream)
         hipEvent_t k1[NBUF] = {}, k2[NBUF] = {}, freed[NBUF] = {}, setup = nullptr;
         std::vector<hipEvent_t> piece;
         explicit Pipe(spl_ctx *ctx) : c(ctx) {}
-        hipError_t make(size_t n_pieces)
+        // (only the streams that will be used: the runtime deals streams out to a few hardware queues, and one more stream --
+        //  made, never used -- put the decoding and the copying kernels behind each other: 0.75 s instead of 0.43 for a 14 GB file)
+        hipError_t make(size_t n_pieces, int n_copy_streams, bool second_upload)
         {
             hipError_t e = hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
             if (e == hipSuccess) e = hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
-            for (int k = 0; k < NCOPY && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&cp[k], hipStreamNonBlocking);
+            for (int k = 0; k < NCOPY && k < n_copy_streams && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&cp[k], hipStreamNonBlocking);
+            if (e == hipSuccess && second_upload) e = hipStreamCreateWithFlags(&up2, hipStreamNonBlocking);
             for (int k = 0; k < NBUF && e == hipSuccess; ++k) {
                 e = hipEventCreateWithFlags(&k1[k], hipEventDisableTiming);
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&k2[k], hipEventDisableTiming);
@@ -1312,12 +1321,14 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             for (int k = 0; k < NCOPY; ++k) if (cp[k]) (void)hipStreamSynchronize(cp[k]);
             if (b) (void)hipStreamSynchronize(b);
             if (c->copy) (void)hipStreamSynchronize(c->copy);
+            if (up2) (void)hipStreamSynchronize(up2);
             for (hipEvent_t e : piece) if (e) (void)hipEventDestroy(e);
             for (int k = 0; k < NBUF; ++k) { if (k1[k]) (void)hipEventDestroy(k1[k]); if (k2[k]) (void)hipEventDestroy(k2[k]); if (freed[k]) (void)hipEventDestroy(freed[k]); }
             if (setup) (void)hipEventDestroy(setup);
             if (a) (void)hipStreamDestroy(a);
             for (int k = 0; k < NCOPY; ++k) if (cp[k]) (void)hipStreamDestroy(cp[k]);
             if (b) (void)hipStreamDestroy(b);
+            if (up2) (void)hipStreamDestroy(up2);
         }
     } pipe(c);
     // ---- the share: which blocks, which bytes of the file
@@ -1348,13 +1359,17 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     const size_t n_stage = c->stage.size();
     const size_t piece = c->stage[0].bytes;
     const size_t n_pieces = (n_bytes + piece - 1) / piece;
-    HIP_TRY(pipe.make(n_pieces));
+    int n_copy = 1; // streams the copying kernels take turns on (1: one window's copies behind the other's)
+    if (const char *e = getenv("SPL_INFLATE_COPY_STREAMS")) n_copy = std::min(NCOPY, std::max(1, atoi(e)));
+    const bool two_up = getenv("SPL_UPLOAD_STREAMS") && atoi(getenv("SPL_UPLOAD_STREAMS")) >= 2; // (the file's pieces on two streams in turn)
+    HIP_TRY(pipe.make(n_pieces, n_copy, two_up));
     std::vector<hipError_t> errs(n_stage, hipSuccess);
     std::vector<std::atomic<int>> sent(n_pieces); // piece k's copy and event are in the copy stream's queue (or will never be: errs)
     for (auto &f : sent) f.store(0, std::memory_order_relaxed);
     std::atomic<int> reader_failed(0);
     const int fd = spl_bam_fd(bam);
     char *const d_img = d_image.as<char>();
+    if (two_up) HIP_TRY(hipStreamSynchronize(c->copy)); // (what was put on the copy stream for the image so far is done before the other stream writes into it)
     auto reader = [&](size_t t) {
         if (hipSetDevice(c->device) != hipSuccess) errs[t] = hipErrorInvalidDevice;
         spl_ctx::Stage &st = c->stage[t];
@@ -1364,9 +1379,10 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 const size_t off = k * piece, n = std::min(piece, n_bytes - off);
                 CopyJob job{st.host, (const char *)image + byte_lo + off, n, n, fd, byte_lo + off};
                 copy_slice(0, &job);
-                errs[t] = hipMemcpyAsync(d_img + off, st.host, n, hipMemcpyHostToDevice, c->copy);
-                if (errs[t] == hipSuccess) { errs[t] = hipEventRecord(st.done, c->copy); st.busy = true; }
-                if (errs[t] == hipSuccess) errs[t] = hipEventRecord(pipe.piece[k], c->copy);
+                hipStream_t up = two_up && (t & 1u) ? pipe.up2 : c->copy;
+                errs[t] = hipMemcpyAsync(d_img + off, st.host, n, hipMemcpyHostToDevice, up);
+                if (errs[t] == hipSuccess) { errs[t] = hipEventRecord(st.done, up); st.busy = true; }
+                if (errs[t] == hipSuccess) errs[t] = hipEventRecord(pipe.piece[k], up);
             }
             if (errs[t] != hipSuccess) reader_failed.store(1, std::memory_order_release);
             sent[k].store(1, std::memory_order_release);
@@ -1426,8 +1442,6 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     int want_buf = devmem::held_bytes(c->device) >= 3 * per_buf ? 3 : 2;
     if (const char *e = getenv("SPL_INFLATE_BUFFERS")) want_buf = std::min(NBUF, std::max(1, atoi(e)));
     const int n_buf = (int)std::min<size_t>((size_t)want_buf, n_win);
-    int n_copy = 1; // streams the copying kernels take turns on (1: one window's copies behind the other's)
-    if (const char *e = getenv("SPL_INFLATE_COPY_STREAMS")) n_copy = std::min(NCOPY, std::max(1, atoi(e)));
     if ((double)n_buf * ((double)win_cap + (double)HEAD + (double)work_bytes) + (double)(stream_len - stream_begin) * 0.2 + (double)((size_t)1 << 30) > (double)free_b)
         return to_host("not enough device memory for the inflated stream");
     for (int k = 0; k < n_buf; ++k) {
@@ -1456,7 +1470,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     HIP_TRY(hipMemsetAsync(d_nbounds.p, 0, 4, pipe.b));
     HIP_TRY(hipEventRecord(pipe.setup, pipe.b));
     HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.setup, 0));
-    for (int k = 0; k < NCOPY; ++k) HIP_TRY(hipStreamWaitEvent(pipe.cp[k], pipe.setup, 0));
+    for (int k = 0; k < n_copy; ++k) HIP_TRY(hipStreamWaitEvent(pipe.cp[k], pipe.setup, 0));
     const uint64_t H = spl_bam_header_end(bam);
     if (first_share && H > stream_len) return to_host("no BAM header");
     size_t first = 0; // the first block that holds more than BAM header
