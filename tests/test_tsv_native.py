@@ -15,7 +15,14 @@ def _native_text(tmp_path, chunks, cryptic):
     for arr, res in chunks:
         native.tsv_append(path, arr, res, cryptic)
     with open(path) as fh:
-        return fh.read()
+        one_by_one = fh.read()
+    # ... and all chromosomes in one call (spl_tsv_append_many: what `process` does with a shard's): the same bytes
+    with open(path, "w") as fh:
+        fh.write(tsv.HEADER)
+    native.tsv_append_many(path, list(chunks), cryptic)
+    with open(path) as fh:
+        assert fh.read() == one_by_one
+    return one_by_one
 
 
 @pytest.mark.parametrize("case,variant,opts", golden_cases(), ids=lambda v: v if isinstance(v, str) else "")
