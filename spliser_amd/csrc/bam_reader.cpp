@@ -261,19 +261,21 @@ void walk_stretch(const uint8_t *file, size_t fsize, size_t from, size_t until, 
     out.ok = true;
 }
 
-// The remainder of the directory in one go; false = nothing done (the caller walks on by itself).
-bool walk_rest_in_parallel(BlockDir &dir, const uint8_t *file, size_t fsize, int n_threads)
+// The directory from where the walk stands up to the first block that begins at or behind `until` (fsize: the remainder of the
+// file) in one go; false = nothing done (the caller walks on by itself).
+bool walk_rest_in_parallel(BlockDir &dir, const uint8_t *file, size_t fsize, int n_threads, size_t until = (size_t)-1)
 {
     const size_t from = dir.off;
+    until = std::min(until, fsize);
     size_t least = (size_t)64 << 20; // (below this the one-thread walk is done before the threads have started)
     if (const char *e = getenv("SPL_WALK_PARALLEL_MIN")) least = (size_t)std::max(4096ll, atoll(e));
-    if (dir.state.load() != 0 || from >= fsize || fsize - from < least) return false;
-    const size_t T = std::min<size_t>((size_t)std::max(2, std::min(n_threads, 32)), (fsize - from) / (least / 4));
+    if (dir.state.load() != 0 || from >= until || until - from < least) return false;
+    const size_t T = std::min<size_t>((size_t)std::max(2, std::min(n_threads, 32)), (until - from) / (least / 4));
     if (T < 2) return false;
     std::vector<Stretch> st(T);
-    const size_t span = (fsize - from + T - 1) / T;
+    const size_t span = (until - from + T - 1) / T;
     std::vector<std::thread> pool;
-    auto work = [&](size_t t) { walk_stretch(file, fsize, from + t * span, std::min(fsize, from + (t + 1) * span), t == 0, st[t]); };
+    auto work = [&](size_t t) { walk_stretch(file, fsize, from + t * span, std::min(until, from + (t + 1) * span), t == 0, st[t]); };
     for (size_t t = 1; t < T; ++t) pool.emplace_back(work, t);
     work(0);
     for (std::thread &th : pool) th.join();
@@ -282,7 +284,8 @@ bool walk_rest_in_parallel(BlockDir &dir, const uint8_t *file, size_t fsize, int
         if (!st[t].ok || (t && st[t].start != st[t - 1].end)) return false;
         n_new += st[t].blocks.size();
     }
-    if (st[T - 1].end != fsize) return false;
+    const bool whole = until == fsize;
+    if (whole && st[T - 1].end != fsize) return false;
     size_t n = dir.n_ready.load(std::memory_order_relaxed);
     if ((n + n_new + BlockDir::CHUNK - 1) / BlockDir::CHUNK > dir.chunks.size()) return false;
     uint64_t uoff = dir.uoff;
@@ -297,11 +300,11 @@ bool walk_rest_in_parallel(BlockDir &dir, const uint8_t *file, size_t fsize, int
             ++n;
         }
     }
-    if (n == 0 || dir.at(n - 1).isize != 0) return false; // (no EOF marker: the one-thread walk says so)
-    dir.off = fsize;
+    if (whole && (n == 0 || dir.at(n - 1).isize != 0)) return false; // (no EOF marker: the one-thread walk says so)
+    dir.off = st[T - 1].end;
     dir.uoff = uoff;
     dir.n_ready.store(n, std::memory_order_release);
-    dir.state.store(1, std::memory_order_release);
+    if (whole) dir.state.store(1, std::memory_order_release);
     return true;
 }
 
@@ -1203,6 +1206,14 @@ int spl_bam_walk_all(spl_bam *bam)
     if (bam->dir.state.load() < 0) return spl_set_error(bam->dir.err_code, "%s", bam->dir.error.c_str());
     return SPL_OK;
 }
+// The directory of the file's first `bytes` (by several threads when that is worth it): for a caller who wants to begin with the
+// first blocks while spl_bam_walk_all does the rest.  Whatever goes wrong here is spl_bam_walk_all's to find and to say.
+void spl_bam_walk_some(spl_bam *bam, size_t bytes)
+{
+    if (bam->dir.state.load() != 0 || getenv("SPL_WALK_ONE_THREAD")) return;
+    (void)walk_rest_in_parallel(bam->dir, (const uint8_t *)bam->map, bam->fsize, bam->n_threads, std::min(bam->fsize, bam->dir.off + bytes));
+}
+bool spl_bam_walk_complete(const spl_bam *bam) { return bam->dir.state.load() == 1; }
 size_t spl_bam_block_count(const spl_bam *bam) { return bam->dir.n_ready.load(); }
 void spl_bam_block_get(const spl_bam *bam, size_t i, spl_bam_block_info *out)
 {

@@ -14,6 +14,8 @@ int spl_bam_source(spl_bam *bam, int tid, splpack::Source *out, int64_t *max_end
 // to the host threads (spl_bam_start_host) or does it elsewhere and gives the result back (spl_bam_adopt).
 struct spl_bam_block_info { uint64_t data_off; uint64_t uoff; uint32_t data_len, isize, crc; };
 int spl_bam_walk_all(spl_bam *bam);                       // the whole block directory, now (SPL_OK or the file's error)
+void spl_bam_walk_some(spl_bam *bam, size_t bytes);
+bool spl_bam_walk_complete(const spl_bam *bam);
 size_t spl_bam_block_count(const spl_bam *bam);
 void spl_bam_block_get(const spl_bam *bam, size_t i, spl_bam_block_info *out);
 const uint8_t *spl_bam_image(const spl_bam *bam, size_t *fsize_out);

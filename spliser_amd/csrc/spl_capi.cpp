@@ -1283,8 +1283,8 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     if (rc) return rc;
     // ---- everything the streams touch is declared before them: what is declared last goes first, and that is the guard that waits
     constexpr int NBUF = 4, NCOPY = 2; // (at most: n_buf buffers and n_copy streams for the copying kernels are used, below)
-    DevBuf d_image, d_stream[NBUF], d_zwork[NBUF], d_blocks, d_status, d_scan, d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
-    std::vector<spl_zblock> blocks;
+    DevBuf d_image, d_stream[NBUF], d_zwork[NBUF], d_blocks0, d_status0, d_blocks, d_status, d_scan, d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
+    std::vector<spl_zblock> blocks, blocks0; // (blocks0: the first window's, for its early launch)
     std::unique_ptr<uint32_t[]> status;
     std::unique_ptr<spl_bscan[]> scan;
     std::unique_ptr<uint64_t[]> rec_off, op_off;
@@ -1393,10 +1393,63 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         void join() { for (std::thread &t : threads) if (t.joinable()) t.join(); }
         ~Crew() { join(); }
     } crew;
-    if (!share) crew.threads.emplace_back([&]() { const double w0 = host_now(); walk_rc = spl_bam_walk_all(bam); t_walk = host_now() - w0; });
+    // ---- the whole file: its first window is on its streams before the directory is complete.  The directory of the file's first
+    // gigabyte takes 3 ms, the rest of a 14 GB file 25: the first window's decoding and copying kernels (23 ms) run beside that.
+    // They get a list of blocks and status words of their own (the file's are allocated when their number is known).
+    size_t win_blocks = (size_t)49152;
+    if (const char *e = getenv("SPL_INFLATE_WINDOW_BLOCKS")) win_blocks = (size_t)std::max(2, atoi(e));
+    const uint64_t HEAD = (uint64_t)8 << 20; // room in front of a window's bytes for what the window before left unfinished
+    const uint8_t *const image0 = d_image.as<uint8_t>() - byte_lo; // (indexed with offsets into the file)
+    size_t pieces_waited = 0;
+    size_t early = 0; // blocks of the first window if it has been launched already (0: not)
     for (size_t t = 0; t < n_stage; ++t) crew.threads.emplace_back(reader, t);
+    if (!share && !getenv("SPL_INFLATE_NO_EARLY")) {
+        spl_bam_walk_some(bam, (size_t)5 << 28); // (1.25 GB: 49 152 blocks of a file that compresses 4x are 0.8 GB)
+        const size_t n_known = spl_bam_block_count(bam);
+        if (n_known >= win_blocks || (n_known >= 2 && spl_bam_walk_complete(bam))) {
+            const size_t b1 = std::min(win_blocks, n_known);
+            blocks0.resize(b1);
+            for (size_t i = 0; i < b1; ++i) {
+                spl_bam_block_info bi;
+                spl_bam_block_get(bam, i, &bi);
+                blocks0[i].in = bi.data_off; blocks0[i].out = bi.uoff; blocks0[i].in_len = bi.data_len; blocks0[i].out_len = bi.isize; blocks0[i].crc = bi.crc; blocks0[i].pad = 0;
+            }
+            const size_t work0 = spl_dev_inflate_work_bytes((uint32_t)b1);
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            free_b += devmem::held_bytes(c->device);
+            if ((double)HEAD + (double)b1 * 65536.0 + (double)work0 + (double)((size_t)2 << 30) < (double)free_b) {
+                HIP_TRY(d_stream[0].get(HEAD + (uint64_t)b1 * 65536u + 256, c->copy)); // (no block inflates to more than 64 KiB)
+                HIP_TRY(d_zwork[0].get(work0, c->copy));
+                HIP_TRY(d_blocks0.get(sizeof(spl_zblock) * b1, c->copy));
+                HIP_TRY(d_status0.get(4 * b1, c->copy));
+                HIP_TRY(hipMemcpyAsync(d_blocks0.p, blocks0.data(), sizeof(spl_zblock) * b1, hipMemcpyHostToDevice, pipe.a));
+                HIP_TRY(hipMemsetAsync(d_status0.p, 0xff, 4 * b1, pipe.a));
+                const size_t last_byte = (size_t)(blocks0[b1 - 1].in + blocks0[b1 - 1].in_len + 8) - byte_lo;
+                const size_t need = std::min(n_pieces, last_byte / piece + 1);
+                for (; pieces_waited < need; ++pieces_waited) {
+                    while (!sent[pieces_waited].load(std::memory_order_acquire)) std::this_thread::yield();
+                    if (reader_failed.load(std::memory_order_acquire)) { for (hipError_t e : errs) HIP_TRY(e); }
+                    HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.piece[pieces_waited], 0));
+                }
+                uint8_t *const stream0 = d_stream[0].as<uint8_t>() + HEAD - blocks0[0].out;
+                const double w_in = (double)(blocks0[b1 - 1].in + blocks0[b1 - 1].in_len - blocks0[0].in), w_out = (double)(blocks0[b1 - 1].out + blocks0[b1 - 1].out_len - blocks0[0].out);
+                {
+                    splprof::Scope p("spl_inflate_decode_kernel", pipe.a, w_in + w_out);
+                    HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks0.as<spl_zblock>(), (uint32_t)b1, d_status0.as<uint32_t>(), d_zwork[0].p, pipe.a));
+                }
+                HIP_TRY(hipEventRecord(pipe.k1[0], pipe.a));
+                HIP_TRY(hipStreamWaitEvent(pipe.cp[0], pipe.k1[0], 0));
+                {
+                    splprof::Scope p("spl_inflate_copy_kernel", pipe.cp[0], w_out);
+                    HIP_TRY((hipError_t)spl_dev_launch_inflate_copy(d_blocks0.as<spl_zblock>(), (uint32_t)b1, stream0, d_status0.as<uint32_t>(), d_zwork[0].p, pipe.cp[0]));
+                }
+                HIP_TRY(hipEventRecord(pipe.k2[0], pipe.cp[0]));
+                early = b1;
+            }
+        }
+    }
     if (!share) {
-        crew.threads[0].join(); // the walk
+        { const double w0 = host_now(); walk_rc = spl_bam_walk_all(bam); t_walk = host_now() - w0; } // (what the early part left)
         if (timing) fprintf(stderr, "[spl_bam_decode_device] (the directory walk took %.4f s)\n", t_walk);
         if (walk_rc) return to_host("block directory");
         fill_whole(bam, sh);
@@ -1415,8 +1468,6 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     const double t_blocks = host_now() - t_begin;
     const uint64_t stream_begin = blocks[0].out, stream_len = blocks[n_blocks - 1].out + blocks[n_blocks - 1].out_len; // (of the share; offsets are the file's)
     // ---- windows
-    size_t win_blocks = (size_t)49152;
-    if (const char *e = getenv("SPL_INFLATE_WINDOW_BLOCKS")) win_blocks = (size_t)std::max(2, atoi(e));
     win_blocks = std::min(win_blocks, n_blocks);
     // (Short first windows -- an eighth, a quarter, a half -- were tried to get the copying kernel started earlier, and cost
     // more than they bring: a launch of the copying kernel takes as long as one lane needs for its block, 9-12 ms however few
@@ -1424,7 +1475,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     std::vector<size_t> win_at(1, 0);
     while (win_at.back() < n_blocks) win_at.push_back(std::min(n_blocks, win_at.back() + win_blocks));
     const size_t n_win = win_at.size() - 1;
-    const uint64_t HEAD = (uint64_t)8 << 20; // room in front of a window's bytes for what the window before left unfinished
+    if (early && early != win_at[1]) return to_host("the first window changed under the decoder"); // (cannot happen: the directory only grows)
     uint64_t win_cap = 0;
     for (size_t k = 0; k < n_win; ++k) {
         const size_t b0 = win_at[k], b1 = win_at[k + 1];
@@ -1445,6 +1496,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     if ((double)n_buf * ((double)win_cap + (double)HEAD + (double)work_bytes) + (double)(stream_len - stream_begin) * 0.2 + (double)((size_t)1 << 30) > (double)free_b)
         return to_host("not enough device memory for the inflated stream");
     for (int k = 0; k < n_buf; ++k) {
+        if (k == 0 && early) continue; // (the first window has its buffers, large enough for any)
         HIP_TRY(d_stream[k].get(HEAD + win_cap + 256, c->copy));
         HIP_TRY(d_zwork[k].get(work_bytes, c->copy));
     }
@@ -1469,6 +1521,10 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     HIP_TRY(hipMemsetAsync(d_maxend.p, 0, 8 * (size_t)std::max(n_ref, 1), pipe.b));
     HIP_TRY(hipMemsetAsync(d_nbounds.p, 0, 4, pipe.b));
     HIP_TRY(hipEventRecord(pipe.setup, pipe.b));
+    if (early) { // what the first window's kernels said about its blocks: to its place among the file's, when they have said it
+        HIP_TRY(hipStreamWaitEvent(pipe.b, pipe.k2[0], 0));
+        HIP_TRY(hipMemcpyAsync(d_status.p, d_status0.p, 4 * early, hipMemcpyDeviceToDevice, pipe.b));
+    }
     HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.setup, 0));
     for (int k = 0; k < n_copy; ++k) HIP_TRY(hipStreamWaitEvent(pipe.cp[k], pipe.setup, 0));
     const uint64_t H = spl_bam_header_end(bam);
@@ -1505,8 +1561,6 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         return SPL_OK;
     };
     // the Huffman decoding of window k on stream A, behind the pieces of the file it reads and behind whoever last used its buffer
-    const uint8_t *const image0 = d_image.as<uint8_t>() - byte_lo; // (indexed with offsets into the file)
-    size_t pieces_waited = 0;
     auto win_range = [&](size_t k, size_t &b0, size_t &b1) { b0 = win_at[k]; b1 = win_at[k + 1]; };
     auto stream0_of = [&](size_t k) { size_t b0, b1; win_range(k, b0, b1); return d_stream[k % (size_t)n_buf].as<uint8_t>() + HEAD - blocks[b0].out; }; // (indexed with offsets into the whole stream)
     auto launch_decode = [&](size_t k, bool wait, bool &launched_it) -> int {
@@ -1544,7 +1598,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     bool expect_known = first_share;
     int32_t last_tid = -1;
     size_t carry = 0; // the first block whose records are not all extracted yet
-    size_t launched = 0; // windows whose decoding has been put on its streams
+    size_t launched = early ? 1 : 0; // windows whose decoding has been put on its streams
     std::vector<double> t_win; // (SPL_BAM_TIMING: when each window's scan was back on the host)
     const double t_setup = host_now() - t_begin;
     for (size_t k = 0; k < n_win; ++k) {
