@@ -199,26 +199,34 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
         with native.Context(device) as ctx:
             stamp("context")
             tables = []
+            laid = {}      # shard index -> its read set, the layout kernels of its chromosomes on their stream
             try:
                 # every shard's site table goes up first: building one is host work (the junction table) that fits beside the
                 # decode, which is still running -- between two shards' counting passes it was 75 ms of an idle device
                 for sh in shards:
                     tables.append(ctx.upload_sites(sh.sites))
                 stamp("site tables up")
-                for sh, ds in zip(shards, tables):
+                def lay_out(k):
+                    sh_k = shards[k]
+                    dr_k = ctx.begin_reads(sum(source.wait_ref(c)[0] for c in sh_k.chroms if items[c][2]))
+                    laid[k] = dr_k
+                    for chrom, off, limit in zip(sh_k.chroms, sh_k.offsets, sh_k.limits):
+                        if items[chrom][2]:
+                            _, max_end = source.wait_ref(chrom)
+                            if max_end > limit:
+                                raise _Replan()
+                            dr_k.add_bam(source, chrom, off)
+                    return dr_k
+                for k_sh, (sh, ds) in enumerate(zip(shards, tables)):
                     if whole is None:
                         whole = bool(device_decode and source.join_decoders())
                         stamp("decoder joined")
                     if whole:
-                        n_expected = sum(source.wait_ref(c)[0] for c in sh.chroms if items[c][2])
-                        with ctx.begin_reads(n_expected) as dr:
-                            for chrom, off, limit in zip(sh.chroms, sh.offsets, sh.limits):
-                                if items[chrom][2]:
-                                    _, max_end = source.wait_ref(chrom)
-                                    if max_end > limit:
-                                        raise _Replan()
-                                    dr.add_bam(source, chrom, off)
-                            stamp("reads laid out")
+                        dr = laid[k_sh] if k_sh in laid else lay_out(k_sh)
+                        if k_sh + 1 < len(shards):
+                            lay_out(k_sh + 1)      # (the next shard's layout kernels run while this one is finished, counted and brought down)
+                        stamp("reads laid out")
+                        try:
                             dr.finish()
                             stamp("read set finished")
                             ctx.count_launch(ds, dr, stranded, combine_mode)
@@ -226,6 +234,9 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                             beta1, b2r, _ = ds.counters()
                             b2s, b2c, b2w, sse = ds.sse_results()
                             stamp("counted, results down")
+                        finally:
+                            dr.free()
+                            del laid[k_sh]
                         stamp("read set freed")
                         for chrom, (r0, r1) in zip(sh.chroms, sh.site_rows):
                             res = dict(beta1=beta1[r0:r1].copy(), beta2_simple=b2s[r0:r1].copy(), beta2_cryptic=b2c[r0:r1].copy(),
@@ -263,6 +274,8 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                         if on_result is not None:
                             on_result(chrom, items[chrom][0], res)
             finally:
+                for dr_left in list(laid.values()):
+                    dr_left.free()
                 for ds in tables:
                     ds.free()
 
