@@ -100,3 +100,15 @@ def test_bam_errors_are_loud(built, tmp_path):
     open(bad, "wb").write(bytes(corrupt))
     with pytest.raises(native.SpliserNativeError):
         native.BamFile(bad)
+
+
+def test_importing_the_package_asks_for_eight_hardware_queues():
+    """The HIP runtime deals streams out to four hardware queues unless told otherwise, and a `process` call has eight streams:
+    the package says so before anything can start the runtime (spl_create's comment has the measurements); what the caller has
+    set stands."""
+    import subprocess
+    import sys
+    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import spliser_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    assert subprocess.check_output([sys.executable, "-c", code], cwd=ROOT).decode().strip() == "8"
+    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '5'; import spliser_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    assert subprocess.check_output([sys.executable, "-c", code], cwd=ROOT).decode().strip() == "5"
