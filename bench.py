@@ -264,6 +264,17 @@ def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode
                                   "its reads) and that as a rate against the 8 TB/s HBM peak; kernels of different streams overlap, "
                                   "so the ms do not add up to the call",
                           "wall_s_of_that_call": prof_run["wall_s"], "kernel_ms_sum": sum(r["ms"] for r in table), "table": table}
+        # what the call as a whole moves, against the two things that can bound it: the link the file crosses (PCIe 5.0 x16:
+        # 64 GB/s nominal; 56 GB/s is what single 32 MB copies reach on this stack, tools/pcie_rate.py) and the kernels
+        inflated = next((r["bytes"] for r in table if r["kernel"] == "spl_crc32_kernel"), None)
+        if best["bam_decode"] == "device" and inflated:
+            file_rate = out["bam_bytes"] / best["wall_s"] / 1e9
+            out["path"] = {"what": "the whole call on the bytes it has to move: the file over PCIe once (nothing else crosses it), its inflated "
+                                   "stream through decode + copies + CRC32 + scan + extraction; a file that deflates 4x is bound by the "
+                                   "link, one that deflates 49x by the copying kernel (DESIGN.md section 7)",
+                           "file_GBps": file_rate, "pcie_peak_GBps": 56.0, "frac_of_pcie": file_rate / 56.0,
+                           "inflated_bytes": inflated, "inflated_GBps": inflated / best["wall_s"] / 1e9}
+
         # parity of the FILE: its whole text against the rows the oracle's numbers give (same table, same format statement)
         tab = process._site_table(prefix + ".bed", "All", "All", 0, prefix + ".gff", "gene", bool(stranded), stranded, noop)
         text = [tsv.HEADER]
