@@ -230,6 +230,8 @@ def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode
             closing = process.wait_deferred_close()     # (the file's unmapping, on a thread of its own: not into the next call's opening)
             return dict(wall_s=wall, reads_per_sec=n_reads / wall, bam_decode=tm.pop("bam_decode", "host"),
                         stages={k2: round(v, 4) for k2, v in tm.items()}, deferred_close_s=round(closing, 4))
+        first = call("w", devices)     # the leg's first call: device memory for this file's sizes is not at hand yet (and, for the
+        #                                first leg, nothing is): reported by itself, the timed calls are the ones behind it
         runs = [call("%d" % k, devices) for k in range(reps)]
         best = min(runs, key=lambda r: r["wall_s"])
         med = statistics.median(r["wall_s"] for r in runs)
@@ -238,11 +240,12 @@ def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode
         out["bam_decode"] = {"host": "on host threads", "device": "on the GPU (BGZF inflate, CRC32, record extraction as kernels)"}[best["bam_decode"]]
         out.update(reads=n_reads, reads_per_sec=best["reads_per_sec"], wall_s=best["wall_s"], stages=best["stages"],
                    median_wall_s=med, median_reads_per_sec=n_reads / med, all_wall_s=[round(r["wall_s"], 4) for r in runs],
-                   first_call_wall_s=runs[0]["wall_s"], runs=len(runs), deferred_close_s=best["deferred_close_s"],
+                   first_call_wall_s=first["wall_s"], runs=len(runs), deferred_close_s=best["deferred_close_s"],
                    what="process(): open BAM + BED/GFF -> Steps 0-2 on the host while the BAM decodes (GPU: the file's bytes up, Huffman "
                         "decoding, copies, CRC32, record extraction, reads laid out by kernels, a window of the stream at a time; host: "
                         "threads, packing, H2D through the staging ring) -> range + literal + scan/SSE kernels, D2H -> .SpliSER.tsv; wall "
-                        "clock of the whole call in a process whose GPU context exists (first_call_wall_s: the call that creates it); "
+                        "clock of the whole call in a process that has its GPU context and, from an earlier call, device memory of this file's "
+                        "sizes at hand (first_call_wall_s: the leg's first call, which has neither yet and is not one of `runs`); "
                         "reads_per_sec / wall_s: the best of `runs` calls, median_*: their median; deferred_close_s: what the call left to a "
                         "thread of its own when it returned (the alignment file closed and unmapped), waited for before the next call")
         if compare_devices is not None:     # the same call on fewer devices: what the others bought
