@@ -1283,7 +1283,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     if (rc) return rc;
     // ---- everything the streams touch is declared before them: what is declared last goes first, and that is the guard that waits
     constexpr int NBUF = 4, NCOPY = 2; // (at most: n_buf buffers and n_copy streams for the copying kernels are used, below)
-    DevBuf d_image, d_stream[NBUF], d_zwork[NBUF], d_blocks0, d_status0, d_blocks, d_status, d_scan, d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
+    DevBuf d_image, d_stream[NBUF], d_zwork[NBUF], d_blocks0, d_status0, d_recs, d_blocks, d_status, d_scan, d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
     std::vector<spl_zblock> blocks, blocks0; // (blocks0: the first window's, for its early launch)
     std::unique_ptr<uint32_t[]> status;
     std::unique_ptr<spl_bscan[]> scan;
@@ -1500,6 +1500,10 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         HIP_TRY(d_stream[k].get(HEAD + win_cap + 256, c->copy));
         HIP_TRY(d_zwork[k].get(work_bytes, c->copy));
     }
+    // where the placed records of a window's blocks begin (scan -> extraction, one window at a time on stream B): room for a window's
+    // blocks and what an 8 MB carry can hold of ordinary ones; a window with more blocks than that is extracted by walking
+    const size_t recs_blocks = std::min(n_blocks, win_blocks + (size_t)32768);
+    HIP_TRY(d_recs.get(2 * (size_t)SPL_BS_REC_CAP * recs_blocks, c->copy));
     HIP_TRY(d_blocks.get(sizeof(spl_zblock) * n_blocks, c->copy));
     HIP_TRY(d_status.get(4 * n_blocks, c->copy));
     HIP_TRY(d_scan.get(sizeof(spl_bscan) * n_blocks, c->copy));
@@ -1625,7 +1629,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         {
             splprof::Scope p("spl_bam_scan_kernel", pipe.b, (double)(win_end - blocks[s0].out));
             HIP_TRY((hipError_t)spl_dev_launch_bam_scan(stream0, win_end, H, n_ref, sh.tid_lo, sh.tid_hi, d_blocks.as<spl_zblock>() + s0, (uint32_t)(b1 - s0), d_scan.as<spl_bscan>() + s0,
-                                                        more ? 1 : 0, pipe.b));
+                                                        more ? 1 : 0, b1 - s0 <= recs_blocks && !getenv("SPL_EXTRACT_WALK") ? d_recs.as<uint16_t>() : nullptr, pipe.b));
         }
         HIP_TRY(hipMemcpyAsync(status.get() + b0, d_status.as<uint32_t>() + b0, 4 * (size_t)nb, hipMemcpyDeviceToHost, pipe.b));
         HIP_TRY(hipMemcpyAsync(scan.get() + s0, d_scan.as<spl_bscan>() + s0, sizeof(spl_bscan) * (b1 - s0), hipMemcpyDeviceToHost, pipe.b));
@@ -1683,7 +1687,8 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             splprof::Scope p("spl_bam_extract_kernel", pipe.b, (double)(blocks[b_done - 1].out + blocks[b_done - 1].out_len - blocks[s0].out));
             HIP_TRY((hipError_t)spl_dev_launch_bam_extract(stream0, win_end, n_ref, sh.tid_lo, sh.tid_hi, d_blocks.as<spl_zblock>() + s0, (uint32_t)nd, d_scan.as<spl_bscan>() + s0,
                                                            d_recoff.as<uint64_t>() + s0, d_opoff.as<uint64_t>() + s0, d_pos.as<int32_t>(), d_flag.as<uint16_t>(),
-                                                           d_cigoff.as<uint32_t>(), d_cigar.as<uint32_t>(), d_tid.as<int32_t>(), d_maxend.as<unsigned long long>(), pipe.b));
+                                                           d_cigoff.as<uint32_t>(), d_cigar.as<uint32_t>(), d_tid.as<int32_t>(), d_maxend.as<unsigned long long>(),
+                                                           b1 - s0 <= recs_blocks && !getenv("SPL_EXTRACT_WALK") ? d_recs.as<uint16_t>() : nullptr, pipe.b));
         }
         if (b_done < b1 && k + 1 < n_win) // what is left of this window: in front of the next one's bytes
             HIP_TRY(hipMemcpyAsync(stream0_of(k + 1) + blocks[b_done].out, stream0 + blocks[b_done].out, (size_t)(win_end - blocks[b_done].out), hipMemcpyDeviceToDevice, pipe.b));

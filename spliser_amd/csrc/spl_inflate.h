@@ -51,6 +51,8 @@ struct spl_zblock {
 // successors chain), except in the block the BAM header ends in; `reached` = the first boundary at or after the block's end,
 // by walking the records from `start`.  The host accepts the lot only if reached[b] == start[b + 1] for every b: by induction
 // from the end of the BAM header every boundary is then a true one (the same argument as the host decoder's, bam_reader.cpp).
+// (a record is 36 bytes at least: no more than this many begin in a block of 64 KiB)
+#define SPL_BS_REC_CAP 1824u
 struct spl_bscan {
     uint64_t start, reached;
     uint32_t n_all;      // records starting in the block
@@ -75,13 +77,16 @@ extern "C" {
 // the window's address minus the window's offset), stream_len = where the window ends, more = the stream goes on behind it.
 // Only records of references tid_lo <= tid < tid_hi count (records without a reference count as reference n_ref): a device that
 // decodes a stretch of the file takes the references that begin there.
+// recs (or null): n_blocks x SPL_BS_REC_CAP 16-bit places; block b's entry j = where its j-th placed record begins, counted from
+// the block's first byte -- what lets the extraction take a block's records 64 at a time instead of walking them.
 int spl_dev_launch_bam_scan(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref, int32_t tid_lo, int32_t tid_hi, const spl_zblock *blocks,
-                            uint32_t n_blocks, spl_bscan *scan, int more, void *stream_handle);
+                            uint32_t n_blocks, spl_bscan *scan, int more, uint16_t *recs, void *stream_handle);
 // rec_off[b] / op_off[b]: index of the block's first placed record / first op in the output arrays.  cig_off gets n + 1 entries
 // (the caller sets entry 0); ref_max_end[tid] = largest last base of a read of the reference (atomicMax; zero it first).
+// recs: what the scan of THESE blocks (same first block, same order) left, or null: then a lane walks its block's records.
 int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream_len, int32_t n_ref, int32_t tid_lo, int32_t tid_hi, const spl_zblock *blocks, uint32_t n_blocks, const spl_bscan *scan,
                                const uint64_t *rec_off, const uint64_t *op_off, int32_t *pos, uint16_t *flag, uint32_t *cig_off, uint32_t *cigar,
-                               int32_t *tid, unsigned long long *ref_max_end, void *stream_handle);
+                               int32_t *tid, unsigned long long *ref_max_end, const uint16_t *recs, void *stream_handle);
 // where the reference id changes along the placed records: (index of the first record of a run, its tid) pairs, unordered
 int spl_dev_launch_bam_bounds(const int32_t *tid, const uint32_t *cig_off, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap, void *stream_handle);
 // image: the whole file in device memory, readable SPL_Z_IMAGE_PAD bytes past its end; out: writable 16 bytes past the last block.

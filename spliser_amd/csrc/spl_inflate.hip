@@ -510,11 +510,12 @@ __device__ __forceinline__ bool plausible_record(const uint8_t *c, const uint8_t
 // `stream_len` = where the inflated bytes end: the stream's end, or (more != 0) the end of the window that is inflated at the
 // moment -- a record that runs past it is then no damage but something for the next window (SPL_BS_INCOMPLETE).
 __global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref, int32_t tid_lo, int32_t tid_hi,
-                                                           const spl_zblock *blocks, uint32_t n_blocks, spl_bscan *scan, uint32_t more)
+                                                           const spl_zblock *blocks, uint32_t n_blocks, spl_bscan *scan, uint32_t more, uint16_t *recs)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
     const uint64_t u0 = blocks[b].out, u1 = u0 + blocks[b].out_len;
+    uint16_t *const mine = recs ? recs + (size_t)b * SPL_BS_REC_CAP : nullptr; // where this block's placed records begin, for the extraction
     const uint8_t *const end = stream + stream_len;
     spl_bscan out;
     out.start = out.reached = u1;
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream,
             if (tid < last_tid) out.flags |= SPL_BS_UNSORTED;
             last_tid = tid;
             out.tid_last = tid;
+            if (mine && out.n_placed < SPL_BS_REC_CAP) mine[out.n_placed] = (uint16_t)(at - u0);
             out.n_placed++;
             out.n_ops += n_cig;
         }
@@ -640,6 +642,88 @@ __global__ __launch_bounds__(64) void spl_bam_extract_kernel(const uint8_t *stre
 }
 
 // Where every reference's records begin: (first record, tid | first CIGAR op << 32) per run of equal tids, in no particular order.
+// The same extraction with a WAVE per block: the scan has left where every placed record of the block begins (16 bits each), so
+// 64 records are read at once -- each lane its record's fixed fields and CIGAR, none waiting for the one before as the walk
+// above has to -- and written side by side: positions, flags and CIGAR offsets of consecutive records by consecutive lanes.
+// Where a record's ops go follows from a prefix sum over the lanes' op counts.
+__global__ __launch_bounds__(64) void spl_bam_extract_wave_kernel(const uint8_t *stream, int32_t n_ref, const spl_zblock *blocks, uint32_t n_blocks, const spl_bscan *scan,
+                                                                   const uint16_t *recs, const uint64_t *rec_off, const uint64_t *op_off, int32_t *pos_out, uint16_t *flag_out,
+                                                                   uint32_t *cig_off, uint32_t *cigar, int32_t *tid_out, unsigned long long *ref_max_end)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const uint32_t n = scan[b].n_placed;
+    if (n == 0) return;
+    const uint32_t l = threadIdx.x;
+    const uint64_t u0 = blocks[b].out, i0 = rec_off[b];
+    const uint16_t *const mine = recs + (size_t)b * SPL_BS_REC_CAP;
+    uint64_t o_base = op_off[b]; // (where the ops of this round's first record go)
+    int32_t run_tid = -1;
+    long long run_end = 0;
+    for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
+        const uint32_t j = j0 + l;
+        const bool have = j < n;
+        uint32_t n_cig = 0, l_name = 0, flag = 0;
+        int32_t tid = -1, pos0 = 0;
+        const uint8_t *r = stream;
+        if (have) {
+            r = stream + u0 + mine[j];
+            u32x4 h0, h1;
+            __builtin_memcpy(&h0, r, 16);
+            __builtin_memcpy(&h1, r + 16, 16);
+            tid = (int32_t)h0.y; pos0 = (int32_t)h0.z;
+            l_name = h0.w & 0xffu; n_cig = h1.x & 0xffffu; flag = h1.x >> 16;
+        }
+        // ops of the records before mine in this round
+        uint32_t incl = n_cig;
+#pragma unroll
+        for (uint32_t s = 1; s < 64u; s <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, s, 64);
+            if (l >= s) incl += up;
+        }
+        const uint64_t o = o_base + incl - n_cig;
+        o_base += (uint32_t)__shfl((int)incl, 63, 64);
+        if (have) {
+            const uint8_t *cig = r + 36 + l_name;
+            long long ref_len = 0;
+            for (uint32_t k = 0; k < n_cig; ++k) {
+                const uint32_t op = ld32(cig + 4ull * k);
+                cigar[o + k] = op;
+                const uint32_t code = op & 15u;
+                if (code == 0u || code == 2u || code == 3u || code == 7u || code == 8u) ref_len += (long long)(op >> 4);
+            }
+            const uint64_t i = i0 + j;
+            pos_out[i] = pos0 + 1;
+            flag_out[i] = (uint16_t)flag;
+            tid_out[i] = tid;
+            cig_off[i + 1] = (uint32_t)(o + n_cig);
+            const long long e = (long long)pos0 + 1 + (ref_len > 0 ? ref_len : 1) - 1;
+            if (tid != run_tid) {
+                if (run_tid >= 0) atomicMax(&ref_max_end[run_tid], (unsigned long long)run_end); // (a block that holds the end of one reference and the beginning of the next)
+                run_tid = tid;
+                run_end = e;
+            } else if (e > run_end) {
+                run_end = e;
+            }
+        }
+    }
+    // the largest end per reference: one atomic for all lanes that hold the same one
+    for (;;) {
+        const unsigned long long pending = __ballot(run_tid >= 0);
+        if (!pending) break;
+        const int first = __ffsll((long long)pending) - 1;
+        const int32_t t = (int32_t)__shfl((int)run_tid, first, 64);
+        long long m = run_tid == t ? run_end : 0;
+#pragma unroll
+        for (uint32_t s = 32; s; s >>= 1) {
+            const long long other = __shfl_xor(m, (int)s, 64);
+            m = other > m ? other : m;
+        }
+        if ((int)l == first) atomicMax(&ref_max_end[t], (unsigned long long)m);
+        if (run_tid == t) run_tid = -1;
+    }
+}
+
 __global__ __launch_bounds__(256) void spl_bam_bounds_kernel(const int32_t *tid, const uint32_t *cig_off, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -651,19 +735,24 @@ __global__ __launch_bounds__(256) void spl_bam_bounds_kernel(const int32_t *tid,
 }
 
 extern "C" int spl_dev_launch_bam_scan(const uint8_t *stream, uint64_t stream_len, uint64_t header_end, int32_t n_ref, int32_t tid_lo, int32_t tid_hi, const spl_zblock *blocks,
-                                       uint32_t n_blocks, spl_bscan *scan, int more, void *st)
+                                       uint32_t n_blocks, spl_bscan *scan, int more, uint16_t *recs, void *st)
 {
     if (n_blocks == 0) return 0;
     const uint32_t L = 8; // (blocks per wave: the kernel is lanes waiting for memory, a wave as slow as its slowest lane -- 1.1 ms per window of 49 152 blocks with 8, 1.7 with 64, 3.9 with 1)
-    hipLaunchKernelGGL(spl_bam_scan_kernel, dim3((n_blocks + L - 1u) / L), dim3(L), 0, (hipStream_t)st, stream, stream_len, header_end, n_ref, tid_lo, tid_hi, blocks, n_blocks, scan, more ? 1u : 0u);
+    hipLaunchKernelGGL(spl_bam_scan_kernel, dim3((n_blocks + L - 1u) / L), dim3(L), 0, (hipStream_t)st, stream, stream_len, header_end, n_ref, tid_lo, tid_hi, blocks, n_blocks, scan, more ? 1u : 0u, recs);
     return (int)hipGetLastError();
 }
 
 extern "C" int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream_len, int32_t n_ref, int32_t tid_lo, int32_t tid_hi, const spl_zblock *blocks, uint32_t n_blocks, const spl_bscan *scan,
                                           const uint64_t *rec_off, const uint64_t *op_off, int32_t *pos, uint16_t *flag, uint32_t *cig_off, uint32_t *cigar,
-                                          int32_t *tid, unsigned long long *ref_max_end, void *st)
+                                          int32_t *tid, unsigned long long *ref_max_end, const uint16_t *recs, void *st)
 {
     if (n_blocks == 0) return 0;
+    if (recs) { // (the scan of these very blocks has left the records' places: a wave per block)
+        hipLaunchKernelGGL(spl_bam_extract_wave_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)st, stream, n_ref, blocks, n_blocks, scan, recs, rec_off, op_off, pos, flag, cig_off, cigar,
+                           tid, ref_max_end);
+        return (int)hipGetLastError();
+    }
     const uint32_t L = 64;
     hipLaunchKernelGGL(spl_bam_extract_kernel, dim3((n_blocks + L - 1u) / L), dim3(L), 0, (hipStream_t)st, stream, stream_len, n_ref, tid_lo, tid_hi, blocks, n_blocks, scan, rec_off,
                        op_off, pos, flag, cig_off, cigar, tid, ref_max_end);
