@@ -219,6 +219,7 @@ def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode
         out["bam_bytes"] = os.path.getsize(prefix + ".bam")
         out["bam_seq_qual"] = ("constant bytes (deflate to almost nothing)" if seq_mode == 0 else
                                "pseudo-random bases, binned qualities in runs (deflate like a real library)")
+        out["bam"] = {0: "const", 1: "seq-like"}[seq_mode]      # (short forms for the compact line)
         n_reads = sum(r.n for r in wl.reads)
 
         def call(tag, devs):
@@ -237,6 +238,7 @@ def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode
         med = statistics.median(r["wall_s"] for r in runs)
         nproc, quota = cpu_budget()
         out["host_cpu"] = {"nproc": nproc, "cpu_quota_cores": quota}
+        out["decode"] = best["bam_decode"]
         out["bam_decode"] = {"host": "on host threads", "device": "on the GPU (BGZF inflate, CRC32, record extraction as kernels)"}[best["bam_decode"]]
         out.update(reads=n_reads, reads_per_sec=best["reads_per_sec"], wall_s=best["wall_s"], stages=best["stages"],
                    median_wall_s=med, median_reads_per_sec=n_reads / med, all_wall_s=[round(r["wall_s"], 4) for r in runs],
@@ -310,6 +312,111 @@ def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out
+
+
+# ---- the line the driver parses ----------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096   # bytes; the driver keeps the last 8 KB of stdout and parses the LAST line: round 3's 23 KB line was cut
+
+
+def _r(x, sig=5):
+    """Numbers as the line carries them: floats to `sig` significant digits (ints, bools, None, strings untouched)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, x))
+    if isinstance(x, np.integer):
+        return int(x)
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def compact_e2e(leg):
+    """One end-to-end leg as scalars only (the prose, the kernel tables and the stages stay in bench_detail.json)."""
+    path = leg.get("path") or {}
+    cpu = leg.get("cpu_e2e") or {}
+    out = {"workload": leg.get("workload"), "bam": leg.get("bam"), "bam_bytes": leg.get("bam_bytes"),
+           "decode": leg.get("decode"), "devices": len(leg.get("devices") or [0]),
+           "wall_s": leg.get("wall_s"), "median_wall_s": leg.get("median_wall_s"), "first_call_wall_s": leg.get("first_call_wall_s"),
+           "reads_per_sec": leg.get("reads_per_sec"), "file_GBps": path.get("file_GBps"), "frac_of_pcie": path.get("frac_of_pcie"),
+           "tsv_matches_oracle": leg.get("tsv_matches_oracle"), "cpu_e2e_reads_per_sec": cpu.get("reads_per_sec")}
+    for k in ("cold_cli_s", "cold_cli_matches"):
+        if leg.get(k) is not None:
+            out[k] = leg[k]
+    cmp_ = leg.get("compared_with")
+    if cmp_:
+        out["one_device_wall_s"] = cmp_.get("wall_s")
+    return {k: v for k, v in out.items() if v is not None}
+
+
+def compact_line(out, detail_name="bench_detail.json"):
+    """The full result `out` -> the ONE line (< LINE_LIMIT bytes) that goes to stdout last: the contract's top-level keys,
+    `roofline` and `cpu_baseline` as numbers, `parity`, one object of scalars per end-to-end leg.  Everything else is in
+    `detail_name`.  Should a future field push the line past the limit, optional blocks are dropped from the back (never the
+    contract's keys, `roofline` or `cpu_baseline`) until it fits: a line the driver can parse beats a complete one it cannot."""
+    r = out.get("roofline") or {}
+    cpu = out.get("cpu_baseline") or None
+    cfg = out.get("config") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "reads_per_sec", "n_gpus", "steps", "warmup", "ms_per_step",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "scale", "parallelism", "seed") if k in cfg}
+    line["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg",
+                                              "launches_timed", "algorithmic_bytes_per_launch")}
+    line["roofline"].update(alone_frac=(r.get("alone") or {}).get("frac"), path_frac=(r.get("path") or {}).get("frac"),
+                            hbm_actual_frac=(r.get("hbm_actual") or {}).get("frac"), traffic_from=r.get("traffic_from"),
+                            lib_sha16=r.get("lib_sha16"), kernel_src_sha16=r.get("kernel_src_sha16"))
+    if cpu:
+        allc = cpu.get("all_cores") or {}
+        line["cpu_baseline"] = {"value": cpu.get("value"), "unit": cpu.get("unit"), "reads_per_sec": cpu.get("reads_per_sec"),
+                                "cores": cpu.get("cores"), "kind": cpu.get("kind"), "sample": cpu.get("sample_short") or cpu.get("sample"),
+                                "all_cores": {"value": allc.get("value"), "reads_per_sec": allc.get("reads_per_sec"),
+                                              "threads": allc.get("threads_used"), "seconds": allc.get("seconds")},
+                                "reference_cost_model_s": (cpu.get("reference_cost_model") or {}).get("estimate_seconds")}
+    else:
+        line["cpu_baseline"] = None
+    par = out.get("parity")
+    line["parity"] = None if not par else {k: par.get(k) for k in ("bit_exact_vs_oracle", "reads", "sites")}
+    line["e2e"] = None if out.get("e2e") is None else [compact_e2e(leg) for leg in out["e2e"]]
+    for k in ("combine", "cold_cli"):
+        if out.get(k) is not None:
+            line[k] = out[k].get("line", out[k]) if isinstance(out[k], dict) else out[k]
+    line["imbalance"] = out.get("imbalance")
+    line["literal_kernel_reads"] = out.get("literal_kernel_reads")
+    line["detail"] = detail_name
+    line = _r(line)
+    text = json.dumps(line, separators=(",", ":"))
+    for victim in ("imbalance", "literal_kernel_reads", "cold_cli", "combine"):   # (never needed so far; see the docstring)
+        if len(text) < LINE_LIMIT:
+            break
+        line.pop(victim, None)
+        text = json.dumps(line, separators=(",", ":"))
+    while len(text) >= LINE_LIMIT and line.get("e2e"):
+        line["e2e"].pop()
+        line["e2e_dropped_for_length"] = line.get("e2e_dropped_for_length", 0) + 1
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def emit(out):
+    """Detail first (a file beside bench.py -- under gpurun_out/ too when that exists -- and an earlier stdout line that starts
+    with a word, so that nothing mistakes it for THE line), then the compact line, last."""
+    detail = json.dumps(out)
+    name = os.environ.get("SPL_BENCH_DETAIL", "bench_detail.json")
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, os.path.basename(name)), "w") as fh:
+                    fh.write(detail + "\n")
+            except OSError:
+                pass
+    sys.stdout.write("bench_detail " + detail + "\n")
+    sys.stdout.write(compact_line(out, os.path.basename(name)) + "\n")
+    sys.stdout.flush()
 
 
 def main():
@@ -487,6 +594,7 @@ def main():
             pairs = int(sum(int(w[0].sum()) + int(w[1].sum()) for w, _ in want.values()))
             cpu = {"value": n_sites / t_cpu1, "unit": "splice sites/s", "reads_per_sec": n_reads / t_cpu1, "cores": 1,
                    "kind": "port",
+                   "sample_short": "whole workload, one pass of oracle/spliser_oracle.c, %.1f s" % t_cpu1,
                    "sample": "the whole workload (%d reads x %d sites), one pass (%.1f s) of oracle/spliser_oracle.c, the "
                              "site-centric C restatement of checkBam + findBeta2Counts + calculateSSE, on 1 thread" % (n_reads, n_sites, t_cpu1),
                    "all_cores": {"value": n_sites / t_all, "reads_per_sec": n_reads / t_all, "nproc": nproc,
@@ -575,7 +683,7 @@ def main():
             "literal_kernel_reads": literal_reads,
             "gen_seconds": t_gen, "upload_seconds": t_up,
         }
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,0 +1,103 @@
+"""bench.py's last stdout line is what the driver parses: it has to be ONE short JSON line whatever the run measured
+(round 3's 23 KB line was cut off by the driver's 8 KB tail and nothing of the round's measurement survived)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def canned(n_legs=9, world=1):
+    leg = {"workload": "human", "bam": "seq-like", "bam_bytes": 14341234567, "decode": "device", "devices": list(range(world)),
+           "wall_s": 0.43312345678, "median_wall_s": 0.4434567891, "first_call_wall_s": 0.80123456, "reads_per_sec": 461234567.891,
+           "path": {"what": "prose " * 60, "file_GBps": 33.123456789, "frac_of_pcie": 0.59123456, "pcie_peak_GBps": 56.0},
+           "tsv_matches_oracle": True, "cpu_e2e": {"what": "prose " * 40, "reads_per_sec": 40912345.678},
+           "what": "prose " * 200, "stages": {"a_s": 0.1, "b_s": 0.2}, "cold_cli_s": 0.7123456, "cold_cli_matches": True,
+           "kernels": {"what": "prose " * 50, "table": [{"kernel": "spl_k%d" % k, "calls": 5, "ms": 1.2345678, "bytes": 123456789} for k in range(9)]}}
+    return {
+        "metric": "splice sites/sec (+ reads/sec) processed", "value": 334710996.8159196, "unit": "splice sites/s",
+        "reads_per_sec": 222796814793.11566, "n_gpus": world, "steps": 20, "warmup": 5, "ms_per_step": 0.8976789016742259,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32/u32 counters, f64 SSE", "data": "synthetic",
+        "config": {"workload": "human: 200000000 reads x 300463 splice sites, 24 chromosomes in 2 shard(s) on rank 0, 150 bp, unstranded",
+                   "scale": 1.0, "parallelism": "chromosome/sample shards, no collectives", "seed": 3, "step": "prose " * 30},
+        "roofline": {"bound": "hbm", "achieved": 4640.32429710635, "peak": 8000.0, "unit": "GB/s", "frac": 0.5800405371382937,
+                     "traffic": 1493338546, "traffic_from": "r03P_traffic.json", "kernel": "spl_count_ranges_kernel",
+                     "kernel_ms_avg": 0.4034253999590874, "launches_timed": 40, "algorithmic_bytes_per_launch": 1872024685.5,
+                     "grid": 15856, "block": 256, "lds_bytes": 17404,
+                     "alone": {"kernel_ms_avg": 0.39, "frac": 0.5949139256781943, "how": "prose " * 20},
+                     "path": {"what": "prose " * 20, "achieved": 4170.8, "frac": 0.5213514214293551},
+                     "hbm_actual": {"what": "prose " * 20, "GBps": 3701.6, "frac": 0.4627059135813722},
+                     "lib_sha16": "c6c68c61bd907ffa", "kernel_src_sha16": "69beb4938a3f2c1f", "ingest_src_sha16": "b8c7ddf82408e0e2"},
+        "cpu_baseline": {"value": 69925.73301240719, "unit": "splice sites/s", "reads_per_sec": 46545320.39712524, "cores": 1,
+                         "kind": "port", "sample": "prose " * 40, "sample_short": "whole workload, one pass of oracle/spliser_oracle.c, 4.3 s",
+                         "all_cores": {"value": 256805.8, "reads_per_sec": 170940063.4, "nproc": 256, "cpu_quota_cores": 16.0,
+                                       "threads_used": 16, "threads": "prose " * 20, "seconds": 1.17, "same_counts_as_1_thread": True},
+                         "reference_cost_model": {"estimate_seconds": 585.8379056, "label": "prose " * 40},
+                         "reference_measured": {"label": "prose " * 40, "cases": [{"name": "x", "reads": 1}] * 4}},
+        "parity": {"reads": 200000000, "sites": 300463, "bit_exact_vs_oracle": True, "of": "the last timed step", "checked": "prose " * 10},
+        "e2e": [dict(leg) for _ in range(n_legs)],
+        "combine": {"line": {"workload": "combine6: 6 x 20 M reads", "process_s": 1.234567, "combine_s": 2.345678, "parse_s": 0.3,
+                             "merge_s": 0.4, "gapfill_s": 0.5, "write_s": 0.6, "queries": 123456, "rows": 1500000, "matches_oracle": True},
+                    "what": "prose " * 100},
+        "imbalance": None if world == 1 else {"reads_per_rank": [25000000] * world, "seconds_per_rank": [0.123456] * world,
+                                              "max_over_mean_reads": 1.2345678},
+        "literal_kernel_reads": 41234, "gen_seconds": 12.3, "upload_seconds": 1.2}
+
+
+def check(text, want_legs):
+    assert "\n" not in text
+    assert len(text.encode("utf-8")) < 4096, len(text)
+    d = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["config"]["workload"].startswith("human")
+    assert "model" not in d["config"]
+    assert d["parity"]["bit_exact_vs_oracle"] is True
+    assert len(d["e2e"]) == want_legs
+    for leg in d["e2e"]:
+        assert all(not isinstance(v, (dict, list)) for v in leg.values()), leg
+    return d
+
+
+def test_compact_line_is_short_and_parses():
+    d = check(bench.compact_line(canned(n_legs=7)), 7)
+    assert abs(d["value"] - 334710996.8159196) / 334710996.8159196 < 1e-4       # (5 significant digits)
+    assert d["e2e"][0]["frac_of_pcie"] == 0.59123 and d["e2e"][0]["cpu_e2e_reads_per_sec"] == 40912000.0
+    assert d["combine"]["matches_oracle"] is True
+
+
+def test_compact_line_eight_ranks():
+    d = check(bench.compact_line(canned(n_legs=4, world=8)), 4)
+    assert len(d["imbalance"]["reads_per_rank"]) == 8
+
+
+def test_compact_line_sheds_before_it_breaks():
+    text = bench.compact_line(canned(n_legs=30))
+    assert len(text) < 4096
+    d = json.loads(text)
+    assert d["roofline"]["frac"] and d["cpu_baseline"]["value"] and d["e2e_dropped_for_length"] > 0
+
+
+def test_no_baseline_no_e2e():
+    out = canned(0)
+    out["cpu_baseline"], out["e2e"], out["parity"] = None, None, None
+    d = json.loads(bench.compact_line(out))
+    assert d["cpu_baseline"] is None and d["e2e"] is None
+
+
+def test_emit_prints_the_compact_line_last(capsys, tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit(canned(n_legs=5))
+    lines = capsys.readouterr().out.strip().split("\n")
+    assert len(lines) == 2 and lines[0].startswith("bench_detail {")
+    check(lines[-1], 5)
+    with open(tmp_path / "bench_detail.json") as fh:
+        assert json.load(fh)["e2e"][0]["kernels"]["table"]
