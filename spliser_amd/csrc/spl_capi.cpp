@@ -429,7 +429,9 @@ static int create_ctx(int device_id, void *stream, bool use_given, spl_ctx **out
     // nobody): with four queues it depends on the order they were made in whether the decoding and the copying kernel overlap
     // (measured: 0.43 s or 0.75 s for the same 14 GB file; 0.82 s with two queues).  Eight queues, unless the caller has said
     // otherwise -- and only if the runtime has not been started yet by somebody else (it reads this once).
-    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // (once, before this library's first HIP call and before it has made a thread: setenv beside another thread's getenv is a race)
+    static std::once_flag queues_once;
+    std::call_once(queues_once, [] { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); });
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -1348,7 +1350,13 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     free_b += devmem::held_bytes(c->device); // (given back before a request fails)
-    if ((double)n_bytes * 2.5 + (double)((size_t)12 << 30) > (double)free_b) return to_host("not enough device memory");
+    // (a first look, before anything is allocated: the image, two windows of a stream that is at most 64 KiB a block with their
+    //  token room -- as many blocks as the file can have, 49 152 at most --, a fifth of the stream for what is extracted; the
+    //  exact sizes are checked again where they are known)
+    {
+        const double blocks_most = std::min((double)49152, (double)n_bytes / 28.0 + 1.0), per_block = 65536.0 + (double)SPL_Z_TOKEN_STRIDE;
+        if ((double)n_bytes * 2.5 + 2.0 * blocks_most * per_block + (double)((size_t)1 << 30) > (double)free_b) return to_host("not enough device memory");
+    }
     HIP_TRY(d_image.get(n_bytes + SPL_Z_IMAGE_PAD, c->copy));
     HIP_TRY(hipMemsetAsync(d_image.as<char>() + n_bytes, 0, SPL_Z_IMAGE_PAD, c->copy));
     // The file's bytes: page cache -> staging buffer -> device.  One reader thread per staging buffer: it preads its pieces (a
@@ -1601,6 +1609,10 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     uint64_t expect = first_share ? H : 0; // the chain of boundaries, from the end of the BAM header (a later share: from its first block's guess)
     bool expect_known = first_share;
     int32_t last_tid = -1;
+    // The neighbours' records at a share's edges are skipped unread -- which is right only where a file sorted by reference has
+    // them: references in front of the share's before its first own record (phase 0), references behind them after its last
+    // (phase 2).  A record of any other reference anywhere else would be extracted by nobody: such a file goes to the host.
+    int edge_phase = 0;
     size_t carry = 0; // the first block whose records are not all extracted yet
     size_t launched = early ? 1 : 0; // windows whose decoding has been put on its streams
     std::vector<double> t_win; // (SPL_BAM_TIMING: when each window's scan was back on the host)
@@ -1659,6 +1671,8 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             else if (expect_known && sc.start != expect) wrong = "a guessed record boundary did not hold";
             else if (sc.n_placed && sc.tid_first < last_tid) wrong = "not sorted by reference";
             else if (sc.n_foreign && !share_edge) wrong = "not sorted by reference";
+            else if (sc.n_foreign > sc.n_foreign_hi && edge_phase > 0) wrong = "not sorted by reference"; // (a reference in front of the share's behind one of its own)
+            else if (sc.n_all && edge_phase > 1) wrong = "not sorted by reference";                        // (one of the share's own behind a later share's)
             if (!last_share && b1 == n_blocks && (sc.flags & SPL_BS_INCOMPLETE) && b + 1 >= b1 && !wrong) {
                 // the last block of a share that is not the file's last: the record that runs on is the next share's
                 sc.flags &= ~SPL_BS_INCOMPLETE;
@@ -1666,6 +1680,8 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             if ((sc.flags & SPL_BS_INCOMPLETE) || (wrong && more && blocks[b].out + reach >= win_end && b1 < n_blocks)) { b_done = b; break; }
             if (wrong) return to_host(wrong);
             if (sc.n_placed) last_tid = sc.tid_last;
+            if (sc.n_all) edge_phase = std::max(edge_phase, 1);
+            if (sc.n_foreign_hi) edge_phase = 2;
             expect = sc.reached;
             expect_known = true;
             n_all += sc.n_all;

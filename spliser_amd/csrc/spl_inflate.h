@@ -61,11 +61,11 @@ struct spl_bscan {
     uint32_t flags;      // SPL_BS_*
     int32_t tid_first, tid_last; // of the placed records (tid_first = -1: none)
     uint32_t n_foreign;  // records starting in the block that belong to references outside [tid_lo, tid_hi): another device's
-    uint32_t pad;
+    uint32_t n_foreign_hi; // ... of those, the ones of references at or behind tid_hi (the others lie in front of tid_lo)
 };
 #define SPL_BS_CORRUPT 1u     // a record that contradicts itself (block_size < 32, fields beyond block_size, stream ends inside it)
 #define SPL_BS_NEEDS_HOST 2u  // a CIGAR parked in a CG tag (more than 65535 ops): the host decoder's business
-#define SPL_BS_UNSORTED 4u    // reference ids go down inside the block
+#define SPL_BS_UNSORTED 4u    // reference ids go down inside the block (over all its records, placed or not, this share's or not)
 #define SPL_BS_NO_START 8u    // no plausible record start found within reach of the block
 #define SPL_BS_INCOMPLETE 16u  // a record of the block runs past the end of what is inflated at the moment (a window of the stream)
 

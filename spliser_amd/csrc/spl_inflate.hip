@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream,
     spl_bscan out;
     out.start = out.reached = u1;
     out.n_all = out.n_placed = out.n_ops = 0;
-    out.n_foreign = out.pad = 0;
+    out.n_foreign = out.n_foreign_hi = 0;
     out.flags = 0;
     out.tid_first = out.tid_last = -1;
     if (u1 <= header_end && !(u1 == header_end && u0 == u1)) { // BAM header bytes only (or an empty block inside them)
@@ -568,7 +568,9 @@ __global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream,
         const uint64_t need = 32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1ull) / 2ull + (uint64_t)l_seq;
         if (need > bs) { out.flags |= SPL_BS_CORRUPT; break; }
         const int32_t tid_eff = tid < 0 || tid >= n_ref ? n_ref : tid; // (records without a reference: behind all others)
-        if (tid_eff < tid_lo || tid_eff >= tid_hi) { out.n_foreign++; at += 4ull + bs; continue; }
+        if (tid_eff < last_tid) out.flags |= SPL_BS_UNSORTED; // (every record counts here, a neighbour's too: the shares are cut on this order)
+        last_tid = tid_eff;
+        if (tid_eff < tid_lo || tid_eff >= tid_hi) { out.n_foreign++; out.n_foreign_hi += tid_eff >= tid_hi ? 1u : 0u; at += 4ull + bs; continue; }
         out.n_all++;
         if (tid >= 0 && tid < n_ref && pos0 >= 0) {
             if (n_cig > 0) {
@@ -576,8 +578,6 @@ __global__ __launch_bounds__(64) void spl_bam_scan_kernel(const uint8_t *stream,
                 if ((op0 & 15u) == 4u && (op0 >> 4) == l_seq && bs > need) out.flags |= SPL_BS_NEEDS_HOST; // maybe a CG tag behind it
             }
             if (out.tid_first < 0) out.tid_first = tid;
-            if (tid < last_tid) out.flags |= SPL_BS_UNSORTED;
-            last_tid = tid;
             out.tid_last = tid;
             if (mine && out.n_placed < SPL_BS_REC_CAP) mine[out.n_placed] = (uint16_t)(at - u0);
             out.n_placed++;
@@ -769,22 +769,16 @@ extern "C" int spl_dev_launch_bam_bounds(const int32_t *tid, const uint32_t *cig
 static size_t tokens_at(uint32_t n_blocks) { return ((size_t)n_blocks * 4 + 255) / 256 * 256; }
 extern "C" size_t spl_dev_inflate_work_bytes(uint32_t n_blocks) { return 256 + tokens_at(n_blocks) + (size_t)n_blocks * SPL_Z_TOKEN_STRIDE; }
 
-static bool per_lane_asked()
-{
-    static const bool v = getenv("SPL_INFLATE_PER_LANE") != nullptr; // (round 2's kernel, a block per lane for everything: kept for comparison)
-    return v;
-}
-
 extern "C" int spl_dev_launch_inflate_decode(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *work, void *stream)
 {
-    if (n_blocks == 0 || per_lane_asked() || !work) return 0;
+    if (n_blocks == 0 || !work) return 0;
     hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, status, (uint8_t *)work + tokens_at(n_blocks), (uint32_t *)work);
     return (int)hipGetLastError();
 }
 
 extern "C" int spl_dev_launch_inflate_copy(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, void *stream)
 {
-    if (n_blocks == 0 || per_lane_asked() || !work) return 0;
+    if (n_blocks == 0 || !work) return 0;
     hipLaunchKernelGGL(spl_inflate_copy_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, blocks, n_blocks, out, status, (const uint8_t *)work + tokens_at(n_blocks),
                        (const uint32_t *)work);
     return (int)hipGetLastError();
@@ -794,7 +788,7 @@ extern "C" int spl_dev_launch_inflate_copy(const spl_zblock *blocks, uint32_t n_
 extern "C" int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, void *stream)
 {
     if (n_blocks == 0) return 0;
-    if (per_lane_asked() || !work) {
+    if (!work) {
         hipLaunchKernelGGL(spl_inflate_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status);
         return (int)hipGetLastError();
     }

@@ -298,6 +298,10 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             const uint8_t *src = in + byte + 4u;
             // as literal runs of 128 (the last one shorter): run r is stream bytes [129 r, 129 r + 129)
             const uint32_t n_runs = (len + 127u) / 128u;
+            // (the same room the Huffman path leaves: sections of both kinds in one block can ask for more tokens than any BAM
+            // writer's block does -- lone literals between 3-byte matches, then one-byte stored sections -- and what follows this
+            // block's room is the next block's)
+            if (n_tok + len + n_runs > SPL_Z_TOKEN_STRIDE - 64u) return SPL_Z_OVERRUN;
             for (uint32_t r = l; r < n_runs; r += 64u) {
                 const uint32_t n = len - 128u * r < 128u ? len - 128u * r : 128u;
                 uint8_t *t = stream + n_tok + 129u * r;

@@ -67,10 +67,14 @@ def open_and_decode(path, devices, gpuDecode=None, threads=0):
     (``gpuDecode=False``), on host threads.  SAM text has one reader."""
     source = open_alignments(path, threads=threads, stream=True, defer=gpuDecode is not False)
     if isinstance(source, native.BamFile) and gpuDecode is not False:
-        if len(devices) > 1:
-            source.decode_on_devices_async(list(devices))
-        else:
-            source.decode_on_device_async(devices[0])
+        try:
+            if len(devices) > 1:
+                source.decode_on_devices_async(list(devices))
+            else:
+                source.decode_on_device_async(devices[0])
+        except BaseException:       # (the share plan walks the whole directory and can fail on a damaged file: the mapping goes with it)
+            source.close()
+            raise
     return source
 
 

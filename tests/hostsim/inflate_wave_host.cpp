@@ -23,6 +23,8 @@ extern "C" int emul_inflate_blocks(const uint8_t *image, const spl_zblock *block
             if (wv::lane() == 0) { status[b] = st; n_tok = st == SPL_Z_OK ? n : 0u; }
         });
         if (!ok) return -1 - (int)b;
+        for (size_t k = SPL_Z_TOKEN_STRIDE; k < tokens.size(); ++k) // (a block's room for tokens ends where the next block's begins)
+            if (tokens[k] != 0xEE) return -100000 - (int)b;
         if (status[b] == SPL_Z_OK) {
             static uint8_t lane_lds[splz::COPY_LANE_BYTES];
             memset(lane_lds, 0xEE, sizeof lane_lds);

@@ -266,3 +266,35 @@ def test_reads_of_every_share_come_back_to_the_host(tmp_path):
     for c in names:
         _same(bam.reads(c), sets[c])
     bam.close()
+
+
+def _take(rs, lo, hi):
+    o0, o1 = int(rs.cig_off[lo]), int(rs.cig_off[hi])
+    return samio.ReadSet(rs.pos[lo:hi], rs.flag[lo:hi], rs.cig_off[lo:hi + 1] - rs.cig_off[lo], rs.cigar[o0:o1])
+
+
+@pytest.mark.parametrize("stray_of,after", [("c0", 40), ("c3", 40), ("c0", 6000)])
+def test_a_stray_record_at_a_shares_edge_is_not_lost(tmp_path, stray_of, after):
+    """a decode in shares skips records of other references in the first and last two blocks of a share as the
+    neighbour's.  In a file that is NOT sorted by reference such a record is nobody's: one record of c0 (or of c3) among the first
+    records of c2, where the second of two shares begins.  The file has to end up with the host decoder, whose reads are all there."""
+    names, sets = _random_sets(97, 6_000, 4)
+    stray = _take(sets[stray_of], 0, 1)
+    after = min(after, sets["c2"].n)
+    order = [("c0", sets["c0"]), ("c1", sets["c1"]), ("c2", _take(sets["c2"], 0, after)), (stray_of, stray)]
+    if after < sets["c2"].n:
+        order.append(("c2", _take(sets["c2"], after, sets["c2"].n)))
+    order.append(("c3", sets["c3"]))
+    path = str(tmp_path / "stray.bam")
+    samio.write_bam(path, names, [10 ** 8] * len(names), order, with_seq=True)
+    bam = native.BamFile(path, defer=True)
+    try:
+        bam.decode_on_devices_async([0, 0])
+    except native.SpliserNativeError:
+        pass                                         # (a plan that cannot be made: the host decoder's file as well)
+    on_device = bam.join_decoders()
+    got = {c: bam.reads(c) for c in names}
+    n = sum(r.n for r in got.values() if r is not None)
+    assert n == sum(sets[c].n for c in names) + 1, "a record was extracted by nobody (device: %s)" % on_device
+    assert got[stray_of].n == sets[stray_of].n + 1
+    bam.close()

@@ -106,3 +106,63 @@ def test_bgzf_blocks_of_a_bam(emul, tmp_path):
     status, got, _, _ = _run(emul, streams)
     assert not status.any()
     assert got[:-128] == b"".join(s[1] for s in streams)
+
+
+class _Bits:
+    """DEFLATE's bit order: fields LSB first, Huffman codes MSB first (RFC 1951 3.1.1)."""
+
+    def __init__(self):
+        self.buf, self.acc, self.n = bytearray(), 0, 0
+
+    def put(self, value, bits):
+        self.acc |= value << self.n
+        self.n += bits
+        while self.n >= 8:
+            self.buf.append(self.acc & 0xff)
+            self.acc >>= 8
+            self.n -= 8
+
+    def code(self, value, bits):
+        self.put(int(format(value, "0%db" % bits)[::-1], 2), bits)
+
+    def align(self):
+        if self.n:
+            self.put(0, 8 - self.n)
+
+
+def _mixed_block(n_pairs, n_stored, seed=5):
+    """One DEFLATE stream: a fixed-code section of `n_pairs` x (lone literal, match of length 3 at distance 1) -- 5 bytes of
+    tokens for 4 of output, the most a Huffman section can ask for -- then `n_stored` stored sections of ONE byte each (2 bytes of
+    tokens per byte of output).  -> (data, comp)"""
+    rng = np.random.default_rng(seed)
+    w, data = _Bits(), bytearray()
+    w.put(0, 1), w.put(1, 2)                        # not the last section, fixed code
+    for lit in rng.integers(0, 144, n_pairs):
+        w.code(0x30 + int(lit), 8)                  # literal 0..143: 8 bits, 00110000 + value
+        w.code(1, 7)                                # 257 = length 3: 7 bits, 0000001
+        w.code(0, 5)                                # distance code 0 = 1
+        data += bytes([int(lit)]) * 4
+    w.code(0, 7)                                    # 256, the section's end
+    for k, b in enumerate(rng.integers(0, 256, n_stored)):
+        w.put(1 if k == n_stored - 1 else 0, 1), w.put(0, 2)
+        w.align()
+        w.put(1, 16), w.put(0xfffe, 16), w.put(int(b), 8)
+        data.append(int(b))
+    w.align()
+    comp = bytes(w.buf)
+    assert zlib.decompress(comp, -15) == bytes(data)
+    return bytes(data), comp
+
+
+def test_stored_sections_cannot_overrun_a_blocks_token_room(emul):
+    """ADVICE round 3: the stored path added its tokens without looking at the room.  15 250 pairs are 76 250 bytes of tokens;
+    4 536 one-byte stored sections behind them want 9 072 more, and a block's room is 82 048: the block has to be REFUSED (the
+    host decoder takes it then), not written over its neighbour -- the emulator's harness checks the bytes behind the room."""
+    over = _mixed_block(15250, 4536)
+    assert len(over[0]) == 65536 and len(over[1]) <= 65536
+    fits = _mixed_block(15250, 2800)
+    status, got, _, _ = _run(emul, [("fits", *fits), ("over", *over), ("fits again", *fits)])
+    assert list(status) == [0, 6, 0]                # SPL_Z_OVERRUN for the middle one, its neighbours untouched
+    assert got[:len(fits[0])] == fits[0]
+    at = len(fits[0]) + len(over[0])
+    assert got[at:at + len(fits[0])] == fits[0]
