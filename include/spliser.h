@@ -349,6 +349,46 @@ int spl_tsv_append(const char *path, const char *chrom, int64_t n_sites, const i
  * tests can hold it against Python over many values. */
 int spl_fmt_fixed(double x, int digits, char *out64);
 
+/* ---- `combine` / `combineShallow`: the host walk on columns (csrc/spl_combine.cpp) --------------------------------------------
+ * Replaces the lock-step loop of SpliSER_v0_1_8.py:820-915 (combine) and :1007-1166 (combineShallow) around the calls of
+ * checkBam (:903): spl_combine_open parses the per-sample .SpliSER.tsv files into columns (SPL_ERR_FORMAT on anything it is
+ * not sure to read the way Python's str.split / int / float / literal_eval would: the caller then walks the files in Python);
+ * spl_combine_region_runs gives what the region order (:761-790) is deduced from; spl_combine_merge is the walk -- merged
+ * sites in output order, and for every sample the gap-fill queries as tables (rows by position per region; strand, partners
+ * and competitors as the walk had them when it reached that sample); the queries are answered through spl_count in
+ * combine mode and handed back with spl_combine_answers; spl_combine_write is outputCombinedLines (:722-740).  No GPU. */
+typedef struct spl_combine spl_combine;
+typedef struct spl_query_table {
+    const char *chrom;            /* region name */
+    int64_t n;                    /* rows */
+    const int64_t *pos;           /* [n] site positions, ascending */
+    const int64_t *site;          /* [n] index of the merged site a row answers */
+    const uint8_t *strand;        /* [n] first byte of the site's strand text at that moment, 0 if it had none */
+    const uint32_t *part_off;     /* [n + 1] */
+    const int64_t *part_pos;      /* partner positions (one-way lists) */
+    const uint32_t *comp_off;     /* [n + 1] */
+    const int64_t *comp_pos;      /* competitor positions */
+} spl_query_table;
+int spl_combine_open(const char *const *tsv_paths, int32_t n_samples, spl_combine **out);
+void spl_combine_close(spl_combine *c);
+int64_t spl_combine_rows(const spl_combine *c, int32_t idx);
+int32_t spl_combine_n_texts(const spl_combine *c);
+const char *spl_combine_text(const spl_combine *c, int32_t id);
+int64_t spl_combine_region_runs(const spl_combine *c, int32_t idx, int32_t *ids, int64_t cap);
+int spl_combine_keep_gene(spl_combine *c, const char *gene);
+int spl_combine_merge(spl_combine *c, const char *const *chroms, int32_t n_chroms, int is_stranded, const char *q_gene, int shallow,
+                      int64_t min_samples, int64_t min_reads, double min_sse);
+int64_t spl_combine_n_sites(const spl_combine *c);
+int64_t spl_combine_n_gap_sites(const spl_combine *c);
+int64_t spl_combine_skipped(const spl_combine *c, const int64_t **pairs);
+int32_t spl_combine_n_tables(const spl_combine *c, int32_t idx);
+int spl_combine_table(const spl_combine *c, int32_t idx, int32_t k, spl_query_table *out);
+int spl_combine_answers(spl_combine *c, int32_t idx, int64_t n, const int64_t *site, const uint32_t *beta1, const uint32_t *beta2_simple);
+int spl_combine_write(const spl_combine *c, const char *path, const char *const *titles, int cryptic);
+
+/* str(x) of a Python float (the beta2_weighted column of .combined.tsv, :735) into out64, NUL-terminated.  Test hook. */
+int spl_fmt_repr(double x, char *out64);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,10 @@ Order dependence that is kept: the gap-fill of sample ``idx`` se
 contributed only by samples with a LOWER index that list the site (:869-904); a stranded gap-fill with no such sample
 has site strand '' and therefore counts nothing.
 """
+import os
 import sys
+import threading
+import time
 from ast import literal_eval
 
 import numpy as np
@@ -72,16 +75,28 @@ def _parse_tsv(path):
 def region_order(per_sample_rows):
     """Deduce one order of regions consistent with every file (:761-790): edges between consecutive regions of each
     file (from an artificial first region), depth-first topological sort in the reference's visiting order."""
-    nodes, before, after = [], [], []
+    runs = []
     for rows in per_sample_rows:
-        prev = "-1"
+        prev, mine = "-1", []
         for r in rows:
             if r.chrom != prev:
-                before.append(prev)
-                after.append(r.chrom)
+                mine.append(r.chrom)
                 prev = r.chrom
-                if r.chrom not in nodes:
-                    nodes.insert(0, r.chrom)
+        runs.append(mine)
+    return region_order_from_runs(runs)
+
+
+def region_order_from_runs(runs):
+    """``region_order`` from what it reads of a file: its regions in order, one entry per run of lines."""
+    nodes, before, after = [], [], []
+    for mine in runs:
+        prev = "-1"
+        for chrom in mine:
+            before.append(prev)
+            after.append(chrom)
+            prev = chrom
+            if chrom not in nodes:
+                nodes.insert(0, chrom)
     if not nodes:
         return []
     nodes.insert(0, "-1")
@@ -220,18 +235,32 @@ class _QueryTable(object):
 
 
 def fill_gaps(merged, bam_paths, is_stranded, stranded_type, devices=(0,), threads=0, log=_log):
-    """Answer every (site, sample) query on the GPUs.  Each sample's BAM is decoded once, in the background (on the GPU when the
-    call has one device, like ``process``); its chromosomes are dealt to the devices (``process.process_sites``: one context per
-    device, a chromosome goes to its GPU as soon as the decoder has it complete) and counted in ``combine_mode`` (a flanking read counts toward beta2Simple, :529-536); several samples are
-    in flight at a time, each starting on another device.  -> {(site index, sample idx): (beta1, beta2Simple)}"""
+    """Answer every (site, sample) query of ``merge_sites``'s result on the GPUs (``fill_tables``).
+    -> {(site index, sample idx): (beta1, beta2Simple)}"""
+    tables = {idx: _QueryTable(qs) for idx, qs in gap_queries(merged).items()}
+    results = {}
+    lock = threading.Lock()
+
+    def take(idx, site, beta1, b2):
+        with lock:
+            for si, x, y in zip(site, beta1.tolist(), b2.tolist()):
+                results[(int(si), idx)] = (int(x), int(y))
+    fill_tables(tables, take, bam_paths, is_stranded, stranded_type, devices=devices, threads=threads, log=log)
+    return results
+
+
+def fill_tables(tables, take, bam_paths, is_stranded, stranded_type, devices=(0,), threads=0, log=_log):
+    """Answer the query tables ``{sample idx: table}`` on the GPUs.  Each sample's BAM is decoded once, in the background (on
+    the GPU when the call has one device, like ``process``); its chromosomes are dealt to the devices
+    (``process.process_sites``: one context per device, a chromosome goes to its GPU as soon as the decoder has it complete) and
+    counted in ``combine_mode`` (a flanking read counts toward beta2Simple, :529-536); several samples are in flight at a time,
+    each starting on another device.  ``take(idx, merged-site indexes, beta1, beta2Simple)`` gets a region's answers."""
     from concurrent.futures import ThreadPoolExecutor
     from . import process as _process
-    per_sample = gap_queries(merged)
-    results = {}
     devices = tuple(devices)
 
     def one(idx):
-        table = _QueryTable(per_sample[idx])
+        table = tables[idx]
         devs = devices[idx % len(devices):] + devices[:idx % len(devices)]
         source = _process.open_and_decode(bam_paths[idx], devs, None, threads)   # (on the sample's first device when it has one device)
         try:
@@ -243,17 +272,34 @@ def fill_gaps(merged, bam_paths, is_stranded, stranded_type, devices=(0,), threa
         finally:
             if hasattr(source, "close"):
                 source.close()
-        res = {}
         for chrom, (_, r) in out.items():
-            for k, si in enumerate(table.site_index[chrom]):
-                res[(si, idx)] = (int(r["beta1"][k]), int(r["beta2s_reads"][k]))
-        return res
+            take(idx, table.site_index[chrom], r["beta1"], r["beta2s_reads"])
 
-    order = sorted(per_sample)
+    order = sorted(tables)
     with ThreadPoolExecutor(max_workers=max(1, min(len(order), max(2, len(devices))))) as pool:
-        for res in pool.map(one, order):
-            results.update(res)
-    return results
+        for _ in pool.map(one, order):
+            pass
+
+
+class _NativeQueryTable(object):
+    """``_QueryTable`` from the tables of the native walk (``native.Combine.tables``)."""
+
+    def __init__(self, tabs):
+        self.chrom_index = [c for c, _ in tabs]
+        self._arrays, self.site_index = {}, {}
+        for chrom, t in tabs:
+            a = _QueryArrays()
+            a.chrom, a.n = chrom, int(t["pos"].shape[0])
+            a.pos, a.strand = t["pos"], t["strand"]
+            a.part_off, a.part_pos, a.comp_off, a.comp_pos = t["part_off"], t["part_pos"], t["comp_off"], t["comp_pos"]
+            a.part_site = np.full(a.part_pos.shape[0], -1, np.int32)
+            a.edge_cnt = np.zeros(a.part_pos.shape[0], np.int64)
+            a.alpha = np.zeros(a.n, np.int64)
+            self._arrays[chrom] = a
+            self.site_index[chrom] = t["site"]
+
+    def chrom_arrays(self, chrom):
+        return self._arrays[chrom]
 
 
 class _QueryArrays(object):
@@ -300,30 +346,100 @@ def write_combined(path, merged, titles, results, cryptic):
 
 
 def combine(samplesFile, outputPath, qGene="All", isStranded=False, strandedType="fr", isbeta2Cryptic=False,
-            devices=(0,), threads=0, log=_log, shallow=None):
+            devices=(0,), threads=0, log=_log, shallow=None, native_walk=None):
+    """-> timings {parse_s, merge_s, gapfill_s, write_s, total_s, walk: "native" | "python", sites, gap_sites, queries}.
+
+    The walk over the files runs on columns in the native library (``native.Combine``); files its parsers do not take -- and
+    ``native_walk=False`` or SPL_COMBINE_PYTHON=1 -- are walked by the Python statement of the same loop below."""
+    t_all = time.perf_counter()
     log("Combining samples...")
     titles, tsvs, bams = read_samples_file(samplesFile, strict=shallow is None)
+    if native_walk is None:
+        native_walk = not os.environ.get("SPL_COMBINE_PYTHON")
+    tm = None
+    if native_walk:
+        try:
+            tm = _combine_native(titles, tsvs, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow)
+        except native.SpliserNativeError as exc:
+            if exc.code != -5:          # (-5: a file that is not the plain text `process` writes -- Python reads it its own way)
+                raise
+    if tm is None:
+        tm = _combine_python(titles, tsvs, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow)
+    if tm:
+        tm["total_s"] = time.perf_counter() - t_all
+    return tm
+
+
+def _combine_native(titles, tsvs, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow):
+    t0 = time.perf_counter()
+    with native.Combine(tsvs) as walk:
+        t_parse = time.perf_counter() - t0
+        log("Establishing order of genomic regions.")
+        chroms = region_order_from_runs(walk.region_runs())
+        if not chroms:
+            log("No genomic regions found - EXITING")
+            return {}
+        log("order of genomic regions deduced: {}".format(chroms))
+        if shallow is not None and qGene != "All":   # combineShallow keeps only the query gene's lines in memory (:948-955)
+            walk.keep_gene(qGene)
+        log("Iterating through files in parallel, to interleave lines and fill gaps.")
+        t0 = time.perf_counter()
+        for pos, seen in walk.merge(chroms, isStranded, qGene, shallow):
+            log("Skipped site {} for insufficient evidence, only {} samples with Site using minimum reads".format(pos, seen))
+        tables = {}
+        n_queries = 0
+        for idx in range(len(titles)):
+            tabs = walk.tables(idx)
+            if tabs:
+                tables[idx] = _NativeQueryTable(tabs)
+                n_queries += sum(int(t["pos"].shape[0]) for _, t in tabs)
+        t_merge = time.perf_counter() - t0
+        n_gap_sites = walk.n_gap_sites
+        t0 = time.perf_counter()
+        if tables:
+            fill_tables(tables, walk.answers, bams, isStranded, strandedType, devices=devices, threads=threads, log=log)
+        t_fill = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        walk.write(outputPath + ".combined.tsv", titles, isbeta2Cryptic)
+        t_write = time.perf_counter() - t0
+        n_sites = walk.n_sites
+    log("Filled in Beta read counts for {} Sites not detected in some samples".format(n_gap_sites))
+    return dict(walk="native", parse_s=t_parse, merge_s=t_merge, gapfill_s=t_fill, write_s=t_write, sites=n_sites, gap_sites=n_gap_sites,
+                queries=n_queries)
+
+
+def _combine_python(titles, tsvs, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow):
+    t0 = time.perf_counter()
     rows = [_parse_tsv(p) for p in tsvs]
+    t_parse = time.perf_counter() - t0
     log("Establishing order of genomic regions.")
     chroms = region_order(rows)
     if not chroms:
         log("No genomic regions found - EXITING")
-        return
+        return {}
     log("order of genomic regions deduced: {}".format(chroms))
     if shallow is not None and qGene != "All":   # combineShallow keeps only the query gene's lines in memory (:948-955)
         rows = [[r for r in file_rows if r.gene == qGene] for file_rows in rows]
     log("Iterating through files in parallel, to interleave lines and fill gaps.")
+    t0 = time.perf_counter()
     merged = merge_sites(rows, chroms, len(titles), isStranded, qGene, shallow=shallow, log=log)
     n_gap_sites = sum(1 for m in merged if m.queries)
+    t_merge = time.perf_counter() - t0
+    t0 = time.perf_counter()
     results = fill_gaps(merged, bams, isStranded, strandedType, devices=devices, threads=threads, log=log) if n_gap_sites else {}
+    t_fill = time.perf_counter() - t0
+    t0 = time.perf_counter()
     write_combined(outputPath + ".combined.tsv", merged, titles, results, isbeta2Cryptic)
+    t_write = time.perf_counter() - t0
     log("Filled in Beta read counts for {} Sites not detected in some samples".format(n_gap_sites))
+    return dict(walk="python", parse_s=t_parse, merge_s=t_merge, gapfill_s=t_fill, write_s=t_write, sites=len(merged), gap_sites=n_gap_sites,
+                queries=sum(len(m.queries) for m in merged))
 
 
 def combineShallow(samplesFile, outputPath, qGene="All", isStranded=False, minSamples=0, minReads=10, minSSE=0.0,
-                   strandedType=None, isbeta2Cryptic=False, devices=(0,), threads=0, log=_log):
+                   strandedType=None, isbeta2Cryptic=False, devices=(0,), threads=0, log=_log, native_walk=None):
     """SpliSER_v0_1_8.py:920-1167: ``combine`` with the per-site evidence filter (a site is processed only when at
     least ``minSamples`` samples list it with >= ``minReads`` reads and SSE >= ``minSSE``)."""
-    combine(samplesFile, outputPath, qGene=qGene, isStranded=isStranded, strandedType=strandedType,
-            isbeta2Cryptic=isbeta2Cryptic, devices=devices, threads=threads, log=log,
-            shallow=(int(minSamples), int(minReads), float(minSSE)))
+    return combine(samplesFile, outputPath, qGene=qGene, isStranded=isStranded, strandedType=strandedType,
+                   isbeta2Cryptic=isbeta2Cryptic, devices=devices, threads=threads, log=log,
+                   shallow=(int(minSamples), int(minReads), float(minSSE)), native_walk=native_walk)

@@ -1,0 +1,675 @@
+// spl_combine.cpp -- the host walk of `combine` / `combineShallow` (SpliSER_v0_1_8.py:742-917, :920-1167) on columns.
+//
+// The reference reads all per-sample .SpliSER.tsv files in lock-step, line by line, and for every site a sample does not list
+// runs checkBam on that sample's BAM (:903).  spliser_amd/combine.py states that walk in Python (merge_sites: the statement the
+// reference-generated goldens and 3 120 runs of the reference's own combine pin) and remains the fallback; at the size of
+// BASELINE config 4 -- six samples of 200 000 rows, 1.5 M output lines -- the interpreter was 30 s around less than a second of
+// GPU work.  Here: the files parsed into columns (a thread per file), the same walk over arrays, the gap-fill queries of every
+// sample as kernel-ready tables (rows by position per region, strand / partners / competitors as the walk had them when it
+// reached that sample: only samples with a LOWER index have contributed, :869-904), the answers taken back as arrays, and
+// outputCombinedLines (:722-740) formatted on threads.  Anything a parser here is not sure to read the way Python's
+// str.split / int / float / literal_eval would makes spl_combine_open fail with SPL_ERR_FORMAT; the caller then takes the
+// Python path, which says what Python says.  No GPU involved.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/spliser.h"
+#include "spl_error.h"
+#include "spl_fmt.h"
+
+namespace {
+
+struct Mapped {
+    const char *p = nullptr;
+    size_t n = 0;
+    bool ok = false;
+    explicit Mapped(const char *path)
+    {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        if (fstat(fd, &st) == 0) {
+            n = (size_t)st.st_size;
+            if (n == 0) ok = true;
+            else {
+                void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) { p = (const char *)m; ok = true; }
+            }
+        }
+        close(fd);
+    }
+    ~Mapped() { if (p) munmap((void *)p, n); }
+};
+
+inline bool is_space(char ch) { return ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r' || ch == '\v' || ch == '\f'; }
+
+// a plain decimal integer, as process writes them: [-]digits, nothing else (Python's int() takes more: those go to Python)
+bool plain_int(const char *s, const char *e, int64_t *out)
+{
+    bool neg = false;
+    if (s < e && *s == '-') { neg = true; ++s; }
+    if (s >= e || e - s > 18) return false;
+    int64_t v = 0;
+    for (; s < e; ++s) {
+        if (*s < '0' || *s > '9') return false;
+        v = v * 10 + (*s - '0');
+    }
+    *out = neg ? -v : v;
+    return true;
+}
+
+// a plain decimal number: [-]digits[.digits][e[+-]digits]; strtod is correctly rounded, like Python's float()
+bool plain_float(const char *s, const char *e, double *out)
+{
+    char buf[48];
+    const size_t n = (size_t)(e - s);
+    if (n == 0 || n >= sizeof buf) return false;
+    const char *q = s;
+    if (q < e && *q == '-') ++q;
+    const char *d0 = q;
+    while (q < e && *q >= '0' && *q <= '9') ++q;
+    bool digits = q > d0;
+    if (q < e && *q == '.') {
+        ++q;
+        const char *f0 = q;
+        while (q < e && *q >= '0' && *q <= '9') ++q;
+        digits = digits || q > f0;
+    }
+    if (!digits) return false;
+    if (q < e && (*q == 'e' || *q == 'E')) {
+        ++q;
+        if (q < e && (*q == '+' || *q == '-')) ++q;
+        const char *x0 = q;
+        while (q < e && *q >= '0' && *q <= '9') ++q;
+        if (q == x0) return false;
+    }
+    if (q != e) return false;
+    memcpy(buf, s, n);
+    buf[n] = 0;
+    *out = strtod(buf, nullptr);
+    return true;
+}
+
+struct Strings { // texts -> small integers
+    std::vector<std::string> text;
+    std::unordered_map<std::string, int32_t> ids;
+    int32_t id(const char *s, const char *e) { return id(std::string(s, e)); }
+    int32_t id(const std::string &key)
+    {
+        auto it = ids.find(key);
+        if (it != ids.end()) return it->second;
+        const int32_t k = (int32_t)text.size();
+        ids.emplace(key, k);
+        text.push_back(key);
+        return k;
+    }
+};
+
+struct SampleFile { // the data lines of one .SpliSER.tsv (combine.py _parse_tsv)
+    Strings names; // of this file alone while it is parsed; ids are the combine's after remap()
+    std::vector<int32_t> chrom, strand, gene;
+    std::vector<int64_t> pos, alpha, beta1, b2s, b2c;
+    std::vector<uint8_t> has_c;
+    std::vector<double> sse, b2w;
+    std::vector<uint32_t> part_off, comp_off;
+    std::vector<int64_t> part_key, part_val, comp;
+    std::string error;
+    size_t rows() const { return pos.size(); }
+};
+
+// "{k: v, k: v}" -> keys / values appended; false on anything else (and on a key that occurs twice: a dict keeps the last value
+// in the first one's place, which nothing `process` writes needs)
+bool parse_dict(const char *s, const char *e, std::vector<int64_t> &keys, std::vector<int64_t> &vals)
+{
+    const size_t first = keys.size();
+    if (e - s < 2 || *s != '{' || e[-1] != '}') return false;
+    ++s; --e;
+    while (s < e && *s == ' ') ++s;
+    if (s == e) return true;
+    for (;;) {
+        const char *q = s;
+        while (q < e && *q != ':' && *q != ' ') ++q;
+        int64_t k, v;
+        if (!plain_int(s, q, &k)) return false;
+        while (q < e && *q == ' ') ++q;
+        if (q >= e || *q != ':') return false;
+        ++q;
+        while (q < e && *q == ' ') ++q;
+        s = q;
+        while (q < e && *q != ',' && *q != ' ') ++q;
+        if (!plain_int(s, q, &v)) return false;
+        for (size_t i = first; i < keys.size(); ++i) if (keys[i] == k) return false;
+        keys.push_back(k);
+        vals.push_back(v);
+        while (q < e && *q == ' ') ++q;
+        if (q == e) return true;
+        if (*q != ',') return false;
+        ++q;
+        while (q < e && *q == ' ') ++q;
+        if (q == e) return false; // (a trailing comma: Python's business)
+        s = q;
+    }
+}
+
+// "[a, b, c]"
+bool parse_list(const char *s, const char *e, std::vector<int64_t> &out)
+{
+    if (e - s < 2 || *s != '[' || e[-1] != ']') return false;
+    ++s; --e;
+    while (s < e && *s == ' ') ++s;
+    if (s == e) return true;
+    for (;;) {
+        const char *q = s;
+        while (q < e && *q != ',' && *q != ' ') ++q;
+        int64_t v;
+        if (!plain_int(s, q, &v)) return false;
+        out.push_back(v);
+        while (q < e && *q == ' ') ++q;
+        if (q == e) return true;
+        if (*q != ',') return false;
+        ++q;
+        while (q < e && *q == ' ') ++q;
+        if (q == e) return false;
+        s = q;
+    }
+}
+
+bool parse_file(const char *path, SampleFile &f)
+{
+    char msg[512];
+    Mapped m(path);
+    if (!m.ok) { snprintf(msg, sizeof msg, "cannot read %s", path); f.error = msg; return false; }
+    f.part_off.push_back(0);
+    f.comp_off.push_back(0);
+    const char *p = m.p, *end = m.p + m.n;
+    int64_t line_no = 0;
+    auto fail = [&](const char *what) { snprintf(msg, sizeof msg, "%s: line %lld %s", path, (long long)line_no, what); f.error = msg; return false; };
+    for (const char *q = p; q < end; ++q)
+        if ((unsigned char)*q >= 128 || *q == '\r' || *q == 0) { line_no = 0; return fail("-- the file holds a byte outside plain ASCII text (or a carriage return)"); }
+    while (p < end) {
+        ++line_no;
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        if (line_no > 1) { // (the first line is the header, whatever it says)
+            while (le > p && is_space(le[-1])) --le; // line.rstrip()
+            const char *field[14];
+            int n_field = 0;
+            field[0] = p;
+            for (const char *q = p; q < le && n_field < 12; ++q)
+                if (*q == '\t') field[++n_field] = q + 1;
+            if (n_field < 11) return fail("has fewer than 12 columns");
+            if (n_field == 11) field[12] = le + 1; // (column k ends at field[k + 1] - 1)
+            auto fe = [&](int k) { return field[k + 1] - 1; };
+            int64_t pos, alpha, beta1, b2s, b2c = 0;
+            double sse, b2w = 0.0;
+            if (!plain_int(field[1], fe(1), &pos) || !plain_int(field[5], fe(5), &alpha) || !plain_int(field[6], fe(6), &beta1) || !plain_int(field[7], fe(7), &b2s))
+                return fail("holds a count or a position that is not a plain integer");
+            if (!plain_float(field[4], fe(4), &sse)) return fail("holds an SSE that is not a plain decimal number");
+            const bool na = fe(8) - field[8] == 2 && field[8][0] == 'N' && field[8][1] == 'A';
+            if (!na && (!plain_int(field[8], fe(8), &b2c) || !plain_float(field[9], fe(9), &b2w))) return fail("holds a cryptic count that is not a plain number");
+            if (!parse_dict(field[10], fe(10), f.part_key, f.part_val)) return fail("has a Partners column that is not {int: int, ...}");
+            if (!parse_list(field[11], fe(11), f.comp)) return fail("has a Competitors column that is not [int, ...]");
+            if (f.part_key.size() > 0xfffffff0ull || f.comp.size() > 0xfffffff0ull) return fail("-- too many partners");
+            f.chrom.push_back(f.names.id(field[0], fe(0)));
+            f.pos.push_back(pos);
+            f.strand.push_back(f.names.id(field[2], fe(2)));
+            f.gene.push_back(f.names.id(field[3], fe(3)));
+            f.sse.push_back(sse);
+            f.alpha.push_back(alpha); f.beta1.push_back(beta1); f.b2s.push_back(b2s);
+            f.has_c.push_back(na ? 0 : 1); f.b2c.push_back(b2c); f.b2w.push_back(b2w);
+            f.part_off.push_back((uint32_t)f.part_key.size());
+            f.comp_off.push_back((uint32_t)f.comp.size());
+        }
+        if (!nl) break;
+        p = nl + 1;
+    }
+    return true;
+}
+
+struct QueryTable { // one sample's gap-fill queries of one region, rows by position (stable: the walk's order among equals)
+    int32_t chrom = -1;
+    std::vector<int64_t> pos, site, part, comp;
+    std::vector<uint8_t> strand;
+    std::vector<uint32_t> part_off, comp_off;
+};
+
+} // namespace
+
+struct spl_combine {
+    int n_samples = 0;
+    Strings names;
+    std::vector<SampleFile> files;
+    // ---- the merged sites (combine.py _Merged), in output order
+    int64_t n_sites = 0, n_gap_sites = 0;
+    std::vector<int32_t> m_chrom, m_strand, m_gene;
+    std::vector<int64_t> m_pos;
+    std::vector<uint8_t> has_row;                 // [site * n_samples + idx]
+    std::vector<int64_t> alpha, beta1, b2s, b2c;  // ...
+    std::vector<double> b2w;                      // ...
+    std::vector<uint64_t> part_off, comp_off;     // per site: its partner keys (insertion order), its competitors (sorted)
+    std::vector<int64_t> part_key, comp;
+    std::vector<int64_t> part_cnt;                // [edge * n_samples + idx]
+    std::vector<int64_t> gap_b1, gap_b2;          // [site * n_samples + idx]: the answers (0 until given)
+    std::vector<std::vector<QueryTable>> tables;  // [idx][k]
+    std::vector<int64_t> skipped;                 // combineShallow: (position, samples with evidence) of every site dropped
+    bool merged = false;
+};
+
+extern "C" int spl_combine_open(const char *const *tsv_paths, int32_t n_samples, spl_combine **out)
+{
+    if (!tsv_paths || !out || n_samples <= 0) return spl_set_error(SPL_ERR_ARG, "spl_combine_open: bad argument");
+    *out = nullptr;
+    spl_combine *c = new (std::nothrow) spl_combine();
+    if (!c) return spl_set_error(SPL_ERR_NOMEM, "out of host memory");
+    c->n_samples = n_samples;
+    c->files.resize((size_t)n_samples);
+    std::vector<uint8_t> ok((size_t)n_samples, 0);
+    {
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            for (;;) {
+                const int k = next.fetch_add(1);
+                if (k >= n_samples) break;
+                ok[(size_t)k] = tsv_paths[k] && parse_file(tsv_paths[k], c->files[(size_t)k]) ? 1 : 0;
+            }
+        };
+        int nt = (int)std::thread::hardware_concurrency();
+        nt = std::max(1, std::min(std::min(nt, 16), (int)n_samples));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
+    }
+    for (int k = 0; k < n_samples; ++k)
+        if (!ok[(size_t)k]) {
+            const std::string why = c->files[(size_t)k].error.empty() ? std::string("null path") : c->files[(size_t)k].error;
+            const bool io = why.compare(0, 11, "cannot read") == 0;
+            delete c;
+            return spl_set_error(io ? SPL_ERR_IO : SPL_ERR_FORMAT, "%s", why.c_str());
+        }
+    // one table of texts for all files (regions, strands, genes are compared across samples)
+    for (SampleFile &f : c->files) {
+        std::vector<int32_t> map(f.names.text.size());
+        for (size_t i = 0; i < map.size(); ++i) map[i] = c->names.id(f.names.text[i]);
+        for (int32_t &v : f.chrom) v = map[(size_t)v];
+        for (int32_t &v : f.strand) v = map[(size_t)v];
+        for (int32_t &v : f.gene) v = map[(size_t)v];
+        f.names = Strings();
+    }
+    *out = c;
+    return SPL_OK;
+}
+
+extern "C" void spl_combine_close(spl_combine *c) { delete c; }
+
+extern "C" int64_t spl_combine_rows(const spl_combine *c, int32_t idx) { return (c && idx >= 0 && idx < c->n_samples) ? (int64_t)c->files[(size_t)idx].rows() : -1; }
+extern "C" int32_t spl_combine_n_texts(const spl_combine *c) { return c ? (int32_t)c->names.text.size() : 0; }
+extern "C" const char *spl_combine_text(const spl_combine *c, int32_t id) { return (c && id >= 0 && (size_t)id < c->names.text.size()) ? c->names.text[(size_t)id].c_str() : nullptr; }
+
+// The regions of sample idx in file order, one entry per run of lines (what region_order, :761-790, reads of a file).
+// Call with ids = NULL for the count.
+extern "C" int64_t spl_combine_region_runs(const spl_combine *c, int32_t idx, int32_t *ids, int64_t cap)
+{
+    if (!c || idx < 0 || idx >= c->n_samples) return -1;
+    const SampleFile &f = c->files[(size_t)idx];
+    int64_t n = 0;
+    for (size_t i = 0; i < f.rows(); ++i)
+        if (i == 0 || f.chrom[i] != f.chrom[i - 1]) {
+            if (ids && n < cap) ids[n] = f.chrom[i];
+            ++n;
+        }
+    return n;
+}
+
+// combineShallow with -g: only the query gene's lines stay (:948-955; before the walk, after the region order)
+extern "C" int spl_combine_keep_gene(spl_combine *c, const char *gene)
+{
+    if (!c || !gene) return spl_set_error(SPL_ERR_ARG, "spl_combine_keep_gene: null argument");
+    if (c->merged) return spl_set_error(SPL_ERR_ARG, "spl_combine_keep_gene: after the merge");
+    const auto it = c->names.ids.find(gene);
+    const int32_t want = it == c->names.ids.end() ? -1 : it->second;
+    for (SampleFile &f : c->files) {
+        size_t w = 0;
+        std::vector<int64_t> pk, pv, cp;
+        std::vector<uint32_t> po(1, 0), co(1, 0);
+        for (size_t i = 0; i < f.rows(); ++i) {
+            if (f.gene[i] != want) continue;
+            f.chrom[w] = f.chrom[i]; f.strand[w] = f.strand[i]; f.gene[w] = f.gene[i]; f.pos[w] = f.pos[i]; f.alpha[w] = f.alpha[i];
+            f.beta1[w] = f.beta1[i]; f.b2s[w] = f.b2s[i]; f.b2c[w] = f.b2c[i]; f.has_c[w] = f.has_c[i]; f.sse[w] = f.sse[i]; f.b2w[w] = f.b2w[i];
+            pk.insert(pk.end(), f.part_key.begin() + f.part_off[i], f.part_key.begin() + f.part_off[i + 1]);
+            pv.insert(pv.end(), f.part_val.begin() + f.part_off[i], f.part_val.begin() + f.part_off[i + 1]);
+            cp.insert(cp.end(), f.comp.begin() + f.comp_off[i], f.comp.begin() + f.comp_off[i + 1]);
+            po.push_back((uint32_t)pk.size());
+            co.push_back((uint32_t)cp.size());
+            ++w;
+        }
+        f.chrom.resize(w); f.strand.resize(w); f.gene.resize(w); f.pos.resize(w); f.alpha.resize(w); f.beta1.resize(w); f.b2s.resize(w);
+        f.b2c.resize(w); f.has_c.resize(w); f.sse.resize(w); f.b2w.resize(w);
+        f.part_key.swap(pk); f.part_val.swap(pv); f.comp.swap(cp); f.part_off.swap(po); f.comp_off.swap(co);
+    }
+    return SPL_OK;
+}
+
+// The lock-step walk (combine.py merge_sites, statement for statement; :820-915 and, with shallow != 0, :1007-1166).
+// chroms: the regions in the order deduced from the files (texts); q_gene: "All" or the gene whose sites are wanted.
+extern "C" int spl_combine_merge(spl_combine *c, const char *const *chroms, int32_t n_chroms, int is_stranded, const char *q_gene, int shallow,
+                                 int64_t min_samples, int64_t min_reads, double min_sse)
+{
+    if (!c || (n_chroms && !chroms) || n_chroms < 0 || !q_gene) return spl_set_error(SPL_ERR_ARG, "spl_combine_merge: bad argument");
+    if (c->merged) return spl_set_error(SPL_ERR_ARG, "spl_combine_merge: called twice");
+    const int ns = c->n_samples;
+    const bool all_genes = strcmp(q_gene, "All") == 0;
+    const int32_t plus = c->names.id(std::string("+")), question = c->names.id(std::string("?")), empty = c->names.id(std::string(""));
+    int32_t want_gene = -2;
+    if (!all_genes) { const auto it = c->names.ids.find(q_gene); want_gene = it == c->names.ids.end() ? -2 : it->second; }
+    std::vector<size_t> cursor((size_t)ns, 0);
+    std::vector<std::vector<int64_t>> q_site((size_t)ns), q_part((size_t)ns), q_comp((size_t)ns); // the queries as the walk meets them
+    std::vector<std::vector<int32_t>> q_strand((size_t)ns);
+    std::vector<std::vector<uint64_t>> q_part_off((size_t)ns), q_comp_off((size_t)ns);
+    for (int i = 0; i < ns; ++i) { q_part_off[(size_t)i].push_back(0); q_comp_off[(size_t)i].push_back(0); }
+    c->part_off.assign(1, 0);
+    c->comp_off.assign(1, 0);
+    std::vector<int64_t> keys, comps, cnts; // of the site being made
+    {   // room for what the walk will make: at most one site per line (the vectors below grew by doubling, a copy of 100 MB each time)
+        size_t rows = 0, edges = 0, comp_n = 0;
+        for (const SampleFile &f : c->files) { rows += f.rows(); edges += f.part_key.size(); comp_n += f.comp.size(); }
+        const size_t guess = rows / (size_t)std::max(1, ns - 1) + 1024; // (sites most samples list: a third more than a file's lines, typically)
+        for (auto *v : {&c->alpha, &c->beta1, &c->b2s, &c->b2c}) v->reserve(guess * (size_t)ns);
+        c->has_row.reserve(guess * (size_t)ns);
+        c->b2w.reserve(guess * (size_t)ns);
+        c->m_chrom.reserve(guess); c->m_strand.reserve(guess); c->m_gene.reserve(guess); c->m_pos.reserve(guess);
+        c->part_off.reserve(guess + 1); c->comp_off.reserve(guess + 1);
+        c->part_key.reserve(edges / (size_t)std::max(1, ns - 1) + 1024);
+        c->part_cnt.reserve((edges / (size_t)std::max(1, ns - 1) + 1024) * (size_t)ns);
+        c->comp.reserve(comp_n / (size_t)std::max(1, ns - 1) + 1024);
+    }
+    const bool timing = getenv("SPL_COMBINE_TIMING") != nullptr;
+    const auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    for (int32_t ci = 0; ci < n_chroms; ++ci) {
+        if (!chroms[ci]) return spl_set_error(SPL_ERR_ARG, "spl_combine_merge: null region");
+        const auto cit = c->names.ids.find(chroms[ci]);
+        if (cit == c->names.ids.end()) continue; // (no file has it)
+        const int32_t chrom = cit->second;
+        for (;;) {
+            int64_t lowest = -1, seen = 0;
+            int32_t lowest_strand = question, gene = empty;
+            for (int idx = 0; idx < ns; ++idx) {
+                const SampleFile &f = c->files[(size_t)idx];
+                const size_t k = cursor[(size_t)idx];
+                if (k >= f.rows() || f.chrom[k] != chrom) continue;
+                const int64_t pos = f.pos[k];
+                if (!shallow) {
+                    if (pos < lowest || lowest == -1 || (is_stranded && pos == lowest && f.strand[k] == plus)) { // :847
+                        lowest = pos; lowest_strand = f.strand[k]; gene = f.gene[k];
+                    }
+                } else {
+                    const bool good = f.alpha[k] + f.beta1[k] + f.b2s[k] >= min_reads && f.sse[k] >= min_sse;
+                    if (pos < lowest || lowest == -1 || (is_stranded && pos == lowest && f.strand[k] != lowest_strand && f.strand[k] == plus)) { // :1066
+                        lowest = pos; lowest_strand = f.strand[k]; gene = f.gene[k];
+                        seen = good ? 1 : 0;
+                    } else if (pos == lowest && good) {
+                        ++seen;
+                    }
+                }
+            }
+            if (lowest == -1) break;
+            if (shallow && seen < min_samples) {
+                c->skipped.push_back(lowest);
+                c->skipped.push_back(seen);
+                for (int idx = 0; idx < ns; ++idx) { // every file whose next line has this POSITION, whatever its region or strand (:1150-1156)
+                    const SampleFile &f = c->files[(size_t)idx];
+                    if (cursor[(size_t)idx] < f.rows() && f.pos[cursor[(size_t)idx]] == lowest) ++cursor[(size_t)idx];
+                }
+                continue;
+            }
+            const bool wanted = all_genes || gene == want_gene;
+            const int64_t si = c->n_sites;
+            int32_t strand = empty;
+            keys.clear(); comps.clear(); cnts.clear();
+            size_t base = 0;
+            if (wanted) {
+                base = c->has_row.size();
+                c->has_row.resize(base + (size_t)ns, 0);
+                c->alpha.resize(base + (size_t)ns, 0); c->beta1.resize(base + (size_t)ns, 0); c->b2s.resize(base + (size_t)ns, 0);
+                c->b2c.resize(base + (size_t)ns, 0); c->b2w.resize(base + (size_t)ns, 0.0);
+            }
+            bool gap = false;
+            for (int idx = 0; idx < ns; ++idx) {
+                const SampleFile &f = c->files[(size_t)idx];
+                const size_t k = cursor[(size_t)idx];
+                if (k < f.rows() && f.chrom[k] == chrom && f.pos[k] == lowest && (!is_stranded || f.strand[k] == lowest_strand)) { // :870
+                    ++cursor[(size_t)idx];
+                    strand = f.strand[k];
+                    if (wanted) {
+                        c->has_row[base + (size_t)idx] = 1;
+                        c->alpha[base + (size_t)idx] += f.alpha[k];
+                        c->beta1[base + (size_t)idx] += f.beta1[k];
+                        c->b2s[base + (size_t)idx] += f.b2s[k];
+                        if (f.has_c[k]) { c->b2c[base + (size_t)idx] += f.b2c[k]; c->b2w[base + (size_t)idx] += f.b2w[k]; }
+                    }
+                    for (uint32_t e = f.part_off[k]; e < f.part_off[k + 1]; ++e) {
+                        size_t j = 0;
+                        while (j < keys.size() && keys[j] != f.part_key[e]) ++j;
+                        if (j == keys.size()) { keys.push_back(f.part_key[e]); cnts.resize(cnts.size() + (size_t)ns, 0); }
+                        cnts[j * (size_t)ns + (size_t)idx] += f.part_val[e];
+                    }
+                    for (uint32_t e = f.comp_off[k]; e < f.comp_off[k + 1]; ++e) {
+                        const int64_t v = f.comp[e];
+                        if (std::find(comps.begin(), comps.end(), v) == comps.end()) comps.insert(std::upper_bound(comps.begin(), comps.end(), v), v);
+                    }
+                } else if (wanted) { // a gap: checkBam on this sample's BAM with the site as it stands NOW (:899-904)
+                    gap = true;
+                    q_site[(size_t)idx].push_back(si);
+                    q_strand[(size_t)idx].push_back(strand);
+                    q_part[(size_t)idx].insert(q_part[(size_t)idx].end(), keys.begin(), keys.end());
+                    q_comp[(size_t)idx].insert(q_comp[(size_t)idx].end(), comps.begin(), comps.end());
+                    q_part_off[(size_t)idx].push_back(q_part[(size_t)idx].size());
+                    q_comp_off[(size_t)idx].push_back(q_comp[(size_t)idx].size());
+                }
+            }
+            if (!wanted) continue;
+            c->m_chrom.push_back(chrom); c->m_pos.push_back(lowest); c->m_strand.push_back(strand); c->m_gene.push_back(gene);
+            c->part_key.insert(c->part_key.end(), keys.begin(), keys.end());
+            c->part_cnt.insert(c->part_cnt.end(), cnts.begin(), cnts.end());
+            c->comp.insert(c->comp.end(), comps.begin(), comps.end());
+            c->part_off.push_back(c->part_key.size());
+            c->comp_off.push_back(c->comp.size());
+            c->n_sites++;
+            if (gap) c->n_gap_sites++;
+        }
+    }
+    const double t_walk = now();
+    c->gap_b1.assign((size_t)c->n_sites * (size_t)ns, 0);
+    c->gap_b2.assign((size_t)c->n_sites * (size_t)ns, 0);
+    // the queries of every sample as tables: one per region (in the order the walk met them), rows by position
+    c->tables.assign((size_t)ns, std::vector<QueryTable>());
+    for (int idx = 0; idx < ns; ++idx) {
+        const std::vector<int64_t> &qs = q_site[(size_t)idx];
+        std::vector<int32_t> order_of; // region id -> table index
+        std::vector<std::vector<size_t>> members;
+        std::unordered_map<int32_t, size_t> where;
+        for (size_t q = 0; q < qs.size(); ++q) {
+            const int32_t ch = c->m_chrom[(size_t)qs[q]];
+            auto it = where.find(ch);
+            if (it == where.end()) { it = where.emplace(ch, members.size()).first; members.emplace_back(); order_of.push_back(ch); }
+            members[it->second].push_back(q);
+        }
+        c->tables[(size_t)idx].resize(members.size());
+        for (size_t t = 0; t < members.size(); ++t) {
+            std::vector<size_t> &mem = members[t];
+            std::stable_sort(mem.begin(), mem.end(), [&](size_t a, size_t b) { return c->m_pos[(size_t)qs[a]] < c->m_pos[(size_t)qs[b]]; });
+            QueryTable &qt = c->tables[(size_t)idx][t];
+            qt.chrom = order_of[t];
+            qt.part_off.push_back(0);
+            qt.comp_off.push_back(0);
+            for (size_t q : mem) {
+                const int64_t site = qs[q];
+                qt.pos.push_back(c->m_pos[(size_t)site]);
+                qt.site.push_back(site);
+                const std::string &st = c->names.text[(size_t)q_strand[(size_t)idx][q]];
+                qt.strand.push_back(st.empty() ? 0 : (uint8_t)st[0]);
+                qt.part.insert(qt.part.end(), q_part[(size_t)idx].begin() + (ptrdiff_t)q_part_off[(size_t)idx][q], q_part[(size_t)idx].begin() + (ptrdiff_t)q_part_off[(size_t)idx][q + 1]);
+                qt.comp.insert(qt.comp.end(), q_comp[(size_t)idx].begin() + (ptrdiff_t)q_comp_off[(size_t)idx][q], q_comp[(size_t)idx].begin() + (ptrdiff_t)q_comp_off[(size_t)idx][q + 1]);
+                if (qt.part.size() > 0xfffffff0ull || qt.comp.size() > 0xfffffff0ull) return spl_set_error(SPL_ERR_RANGE, "spl_combine_merge: a query table with more than 2^32 partners");
+                qt.part_off.push_back((uint32_t)qt.part.size());
+                qt.comp_off.push_back((uint32_t)qt.comp.size());
+            }
+        }
+    }
+    const double t_tables = now();
+    for (SampleFile &f : c->files) f = SampleFile(); // (the walk is over: the columns are not needed again)
+    c->merged = true;
+    if (timing) fprintf(stderr, "[spl_combine_merge] %lld sites (%lld with gaps): walk %.4f s, query tables %.4f s, columns freed %.4f s\n", (long long)c->n_sites,
+                        (long long)c->n_gap_sites, t_walk - t_begin, t_tables - t_walk, now() - t_tables);
+    return SPL_OK;
+}
+
+extern "C" int64_t spl_combine_n_sites(const spl_combine *c) { return c ? c->n_sites : 0; }
+extern "C" int64_t spl_combine_n_gap_sites(const spl_combine *c) { return c ? c->n_gap_sites : 0; }
+// combineShallow: pairs (position, samples with evidence) of the sites dropped, in the walk's order; returns the number of pairs
+extern "C" int64_t spl_combine_skipped(const spl_combine *c, const int64_t **pairs) { if (!c) return 0; if (pairs) *pairs = c->skipped.data(); return (int64_t)(c->skipped.size() / 2); }
+extern "C" int32_t spl_combine_n_tables(const spl_combine *c, int32_t idx) { return (c && c->merged && idx >= 0 && idx < c->n_samples) ? (int32_t)c->tables[(size_t)idx].size() : 0; }
+
+extern "C" int spl_combine_table(const spl_combine *c, int32_t idx, int32_t k, spl_query_table *out)
+{
+    if (!c || !out || !c->merged || idx < 0 || idx >= c->n_samples || k < 0 || (size_t)k >= c->tables[(size_t)idx].size())
+        return spl_set_error(SPL_ERR_ARG, "spl_combine_table: bad argument");
+    const QueryTable &t = c->tables[(size_t)idx][(size_t)k];
+    out->chrom = c->names.text[(size_t)t.chrom].c_str();
+    out->n = (int64_t)t.pos.size();
+    out->pos = t.pos.data(); out->site = t.site.data(); out->strand = t.strand.data();
+    out->part_off = t.part_off.data(); out->part_pos = t.part.data(); out->comp_off = t.comp_off.data(); out->comp_pos = t.comp.data();
+    return SPL_OK;
+}
+
+// The answers of n queries: for merged site site[i] and sample idx, beta1 and beta2Simple (what checkBam counted, combine mode).
+extern "C" int spl_combine_answers(spl_combine *c, int32_t idx, int64_t n, const int64_t *site, const uint32_t *beta1, const uint32_t *beta2_simple)
+{
+    if (!c || !c->merged || idx < 0 || idx >= c->n_samples || n < 0 || (n && (!site || !beta1 || !beta2_simple))) return spl_set_error(SPL_ERR_ARG, "spl_combine_answers: bad argument");
+    for (int64_t i = 0; i < n; ++i) {
+        if (site[i] < 0 || site[i] >= c->n_sites) return spl_set_error(SPL_ERR_ARG, "spl_combine_answers: site %lld out of range", (long long)site[i]);
+        c->gap_b1[(size_t)site[i] * (size_t)c->n_samples + (size_t)idx] = beta1[i];
+        c->gap_b2[(size_t)site[i] * (size_t)c->n_samples + (size_t)idx] = beta2_simple[i];
+    }
+    return SPL_OK;
+}
+
+// outputCombinedLines (:722-740) for every merged site; titles: one per sample.  The file is created (header included).
+extern "C" int spl_combine_write(const spl_combine *c, const char *path, const char *const *titles, int cryptic)
+{
+    if (!c || !path || !titles || !c->merged) return spl_set_error(SPL_ERR_ARG, "spl_combine_write: bad argument");
+    const int ns = c->n_samples;
+    for (int i = 0; i < ns; ++i) if (!titles[i]) return spl_set_error(SPL_ERR_ARG, "spl_combine_write: null title");
+    FILE *f = fopen(path, "wb");
+    if (!f) return spl_set_error(SPL_ERR_IO, "cannot open %s for writing", path);
+    static const char header[] = "Sample\tRegion\tSite\tStrand\tGene\tSSE\talpha_count\tbeta1_count\tbeta2Simple_count\tbeta2Cryptic_count\tbeta2_weighted\tPartners\tCompetitors\n";
+    bool ok = fwrite(header, 1, sizeof header - 1, f) == sizeof header - 1;
+    using splfmt::fmt_fixed; using splfmt::fmt_int; using splfmt::fmt_repr;
+    auto format = [&](int64_t a, int64_t b, std::string &out) {
+        char num[96];
+        std::string comp_txt;
+        out.clear();
+        for (int64_t si = a; si < b; ++si) {
+            comp_txt.assign("[");
+            for (uint64_t e = c->comp_off[(size_t)si]; e < c->comp_off[(size_t)si + 1]; ++e) {
+                if (e != c->comp_off[(size_t)si]) comp_txt.append(", ");
+                comp_txt.append(num, fmt_int(num, c->comp[e]));
+            }
+            comp_txt.append("]\n");
+            const std::string &chrom = c->names.text[(size_t)c->m_chrom[(size_t)si]], &strand = c->names.text[(size_t)c->m_strand[(size_t)si]],
+                              &gene = c->names.text[(size_t)c->m_gene[(size_t)si]];
+            for (int idx = 0; idx < ns; ++idx) {
+                const size_t at = (size_t)si * (size_t)ns + (size_t)idx;
+                int64_t alpha = 0, beta1, b2s;
+                double sse = 0.0;
+                if (c->has_row[at]) { // calculateSSE (:626-639) on the sample's merged numbers
+                    alpha = c->alpha[at]; beta1 = c->beta1[at]; b2s = c->b2s[at];
+                    const int64_t betas = beta1 + b2s;
+                    if (cryptic) {
+                        const double den = (double)alpha + ((double)betas + c->b2w[at]);
+                        sse = den > 0.0 ? (double)alpha / den : 0.0;
+                    } else {
+                        const int64_t den = alpha + betas;
+                        sse = den > 0 ? (double)alpha / (double)den : 0.0;
+                    }
+                } else {
+                    beta1 = c->gap_b1[at]; b2s = c->gap_b2[at];
+                }
+                out.append(titles[idx]);
+                out.push_back('\t');
+                out.append(chrom);
+                out.push_back('\t');
+                out.append(num, fmt_int(num, c->m_pos[(size_t)si]));
+                out.push_back('\t');
+                out.append(strand);
+                out.push_back('\t');
+                out.append(gene);
+                out.push_back('\t');
+                out.append(num, fmt_fixed(num, sse, 3));
+                out.push_back('\t');
+                out.append(num, fmt_int(num, alpha));
+                out.push_back('\t');
+                out.append(num, fmt_int(num, beta1));
+                out.push_back('\t');
+                out.append(num, fmt_int(num, b2s));
+                out.push_back('\t');
+                if (cryptic) {
+                    out.append(num, fmt_int(num, c->b2c[at]));
+                    out.push_back('\t');
+                    out.append(num, fmt_repr(num, c->b2w[at])); // str(float), :735
+                } else {
+                    out.append("NA\tNA");
+                }
+                out.append("\t{");
+                for (uint64_t e = c->part_off[(size_t)si]; e < c->part_off[(size_t)si + 1]; ++e) {
+                    if (e != c->part_off[(size_t)si]) out.append(", ");
+                    out.append(num, fmt_int(num, c->part_key[e]));
+                    out.append(": ");
+                    out.append(num, fmt_int(num, c->part_cnt[e * (uint64_t)ns + (uint64_t)idx]));
+                }
+                out.append("}\t");
+                out.append(comp_txt);
+            }
+        }
+    };
+    const int64_t SLICE = 512; // sites per slice (n_samples lines each)
+    const size_t n_slices = (size_t)((c->n_sites + SLICE - 1) / SLICE);
+    // formatted on threads in rounds of slices, each round written in order while nothing else waits for it: a quarter of a
+    // million sites of six samples are 150 MB of text, which is not kept whole
+    int nt = (int)std::thread::hardware_concurrency();
+    nt = nt > 16 ? 16 : (nt < 1 ? 1 : nt);
+    const size_t round = (size_t)nt * 4;
+    std::vector<std::string> text(round);
+    for (size_t r0 = 0; r0 < n_slices && ok; r0 += round) {
+        const size_t r1 = std::min(n_slices, r0 + round);
+        std::atomic<size_t> next(r0);
+        auto work = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= r1) break;
+                format((int64_t)k * SLICE, std::min<int64_t>(c->n_sites, ((int64_t)k + 1) * SLICE), text[k - r0]);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt && (size_t)t < r1 - r0; ++t) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
+        for (size_t k = r0; k < r1 && ok; ++k) ok = fwrite(text[k - r0].data(), 1, text[k - r0].size(), f) == text[k - r0].size();
+    }
+    if (fclose(f) != 0) ok = false;
+    return ok ? SPL_OK : spl_set_error(SPL_ERR_IO, "write error on %s", path);
+}

@@ -4,6 +4,7 @@
 
 #include "../../include/spliser.h"
 #include "spl_error.h"
+#include "spl_fmt.h"
 
 namespace {
 inline int64_t floor_div2(int64_t v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); } // Python's v // 2
@@ -62,61 +63,22 @@ extern "C" int spl_gene_search(const int64_t *left, const int64_t *right, const 
 #include <thread>
 #include <vector>
 
-namespace {
-
-// "%d" of v into out; returns the length.
-inline size_t fmt_int(char *out, int64_t v)
-{
-    char tmp[24];
-    int n = 0;
-    uint64_t u = v < 0 ? 0ull - (uint64_t)v : (uint64_t)v;
-    do { tmp[n++] = (char)('0' + u % 10u); u /= 10u; } while (u);
-    size_t k = 0;
-    if (v < 0) out[k++] = '-';
-    while (n) out[k++] = tmp[--n];
-    return k;
-}
-
-// "%.<digits>f" of x (digits <= 6) into out, exactly as printf and Python's format() round: to the nearest decimal of the
-// double's EXACT binary value, ties to even.  x = m * 2^e with an integer m: m * 10^digits is split at the binary point with
-// integer arithmetic, nothing is ever rounded before the one decision that matters.  Values this does not cover (negative,
-// not finite, 2^63 / 10^digits and beyond) go to snprintf.
-inline size_t fmt_fixed(char *out, double x, int digits)
-{
-    static const uint64_t pow10[7] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull};
-    if (!(x >= 0.0) || !(x < 9.0e12) || digits > 6) return (size_t)snprintf(out, 64, "%.*f", digits, x);
-    int e = 0;
-    const double f = frexp(x, &e);                    // x = f * 2^e, f in [0.5, 1) (or 0)
-    const uint64_t m = (uint64_t)ldexp(f, 53);         // 53-bit integer, exact
-    const int sh = 53 - e;                             // x = m / 2^sh
-    unsigned __int128 v = (unsigned __int128)m * pow10[digits];
-    uint64_t q;
-    if (sh <= 0) {
-        q = (uint64_t)(v << (-sh));                    // an integer already (x < 9e12: fits)
-    } else if (sh >= 120) {
-        q = 0;                                         // far below half a unit in the last place
-    } else {
-        const unsigned __int128 one = (unsigned __int128)1 << sh;
-        const unsigned __int128 rem = v & (one - 1), half = one >> 1;
-        q = (uint64_t)(v >> sh);
-        if (rem > half || (rem == half && (q & 1u))) ++q;
-    }
-    const uint64_t ip = q / pow10[digits], fp = q % pow10[digits];
-    size_t k = fmt_int(out, (int64_t)ip);
-    if (digits) {
-        out[k++] = '.';
-        for (int d = digits - 1; d >= 0; --d) out[k++] = (char)('0' + (fp / pow10[d]) % 10u);
-    }
-    return k;
-}
-
-} // namespace
+using splfmt::fmt_int;
+using splfmt::fmt_fixed;
 
 // (test hook: the formatter above against printf / Python over many values -- tests/test_tsv_native.py)
 extern "C" int spl_fmt_fixed(double x, int digits, char *out64)
 {
     if (!out64) return spl_set_error(SPL_ERR_ARG, "spl_fmt_fixed: null argument");
     out64[fmt_fixed(out64, x, digits)] = 0;
+    return SPL_OK;
+}
+
+// (test hook: str(float) as Python prints it -- tests/test_combine_native.py)
+extern "C" int spl_fmt_repr(double x, char *out64)
+{
+    if (!out64) return spl_set_error(SPL_ERR_ARG, "spl_fmt_repr: null argument");
+    out64[splfmt::fmt_repr(out64, x)] = 0;
     return SPL_OK;
 }
 

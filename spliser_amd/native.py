@@ -54,6 +54,9 @@ EXPORTS = [
     "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append", "spl_tsv_append_many", "spl_fmt_fixed",
     "spl_bed_open", "spl_gff_open", "spl_text_close", "spl_text_rows", "spl_text_n_chrom", "spl_text_chrom_name", "spl_text_chrom",
     "spl_text_i64", "spl_text_strand", "spl_text_names",
+    "spl_combine_open", "spl_combine_close", "spl_combine_rows", "spl_combine_n_texts", "spl_combine_text", "spl_combine_region_runs",
+    "spl_combine_keep_gene", "spl_combine_merge", "spl_combine_n_sites", "spl_combine_n_gap_sites", "spl_combine_skipped",
+    "spl_combine_n_tables", "spl_combine_table", "spl_combine_answers", "spl_combine_write", "spl_fmt_repr",
 ]
 
 _lib = None
@@ -78,8 +81,11 @@ def lib():
         L.spl_bam_ref_name.restype = ctypes.c_char_p
         L.spl_bam_ref_length.restype = ctypes.c_int64
         L.spl_bam_n_records.restype = ctypes.c_int64
-        for name in ("spl_destroy", "spl_sites_free", "spl_reads_free", "spl_bam_close", "spl_text_close"):
+        for name in ("spl_destroy", "spl_sites_free", "spl_reads_free", "spl_bam_close", "spl_text_close", "spl_combine_close"):
             getattr(L, name).restype = None
+        for name in ("spl_combine_rows", "spl_combine_region_runs", "spl_combine_n_sites", "spl_combine_n_gap_sites", "spl_combine_skipped"):
+            getattr(L, name).restype = ctypes.c_int64
+        L.spl_combine_text.restype = ctypes.c_char_p
         L.spl_text_rows.restype = ctypes.c_int64
         L.spl_text_chrom_name.restype = ctypes.c_char_p
         for name in ("spl_text_chrom", "spl_text_i64", "spl_text_strand", "spl_text_names"):
@@ -760,3 +766,107 @@ def read_bed_columns(path):
 def read_gff_genes(path):
     """-> TextColumns of the ``gene`` lines of a GFF / GTF file, or None when the file must be read line by line."""
     return _text_columns(lib().spl_gff_open, path, False, True)
+
+
+class spl_query_table(ctypes.Structure):
+    _fields_ = [("chrom", ctypes.c_char_p), ("n", ctypes.c_int64), ("pos", ctypes.c_void_p), ("site", ctypes.c_void_p),
+                ("strand", ctypes.c_void_p), ("part_off", ctypes.c_void_p), ("part_pos", ctypes.c_void_p),
+                ("comp_off", ctypes.c_void_p), ("comp_pos", ctypes.c_void_p)]
+
+
+def _view(addr, n, dt):
+    """n items of dtype dt at address addr, copied out (the library owns the memory)."""
+    if n == 0 or not addr:
+        return np.zeros(0, dt)
+    return np.ctypeslib.as_array(ctypes.cast(addr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).copy()
+
+
+class Combine(object):
+    """The host walk of ``combine`` / ``combineShallow`` on columns (``spl_combine_*``, csrc/spl_combine.cpp): the per-sample
+    .SpliSER.tsv files parsed and merged natively, the gap-fill queries as tables, the answers handed back, the .combined.tsv
+    written.  Raises SpliserNativeError with code -5 for files the native parser does not take (spliser_amd/combine.py then
+    walks them in Python)."""
+
+    def __init__(self, tsv_paths):
+        self._h = None
+        self.n = len(tsv_paths)
+        paths = (ctypes.c_char_p * self.n)(*[os.fsencode(p) for p in tsv_paths])
+        h = ctypes.c_void_p()
+        _check(lib().spl_combine_open(paths, ctypes.c_int32(self.n), ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().spl_combine_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+    def rows(self, idx):
+        return int(lib().spl_combine_rows(self._h, ctypes.c_int32(idx)))
+
+    def region_runs(self):
+        """-> per sample the regions of its file in order, one entry per run of lines."""
+        L = lib()
+        out = []
+        for idx in range(self.n):
+            n = int(L.spl_combine_region_runs(self._h, ctypes.c_int32(idx), None, ctypes.c_int64(0)))
+            ids = np.zeros(max(n, 1), np.int32)
+            L.spl_combine_region_runs(self._h, ctypes.c_int32(idx), _ptr(ids), ctypes.c_int64(n))
+            out.append([L.spl_combine_text(self._h, ctypes.c_int32(int(i))).decode("ascii") for i in ids[:n]])
+        return out
+
+    def keep_gene(self, gene):
+        _check(lib().spl_combine_keep_gene(self._h, gene.encode("ascii", "replace")))
+
+    def merge(self, chroms, is_stranded, q_gene, shallow=None):
+        """The lock-step walk.  -> [(position, samples with evidence)] of the sites combineShallow dropped."""
+        names = (ctypes.c_char_p * max(len(chroms), 1))(*[c.encode("ascii", "replace") for c in chroms])
+        ms, mr, me = (0, 0, 0.0) if shallow is None else shallow
+        _check(lib().spl_combine_merge(self._h, names, ctypes.c_int32(len(chroms)), ctypes.c_int(1 if is_stranded else 0),
+                                       q_gene.encode("ascii", "replace"), ctypes.c_int(0 if shallow is None else 1),
+                                       ctypes.c_int64(int(ms)), ctypes.c_int64(int(mr)), ctypes.c_double(float(me))))
+        p = ctypes.c_void_p()
+        n = int(lib().spl_combine_skipped(self._h, ctypes.byref(p)))
+        sk = _view(p.value, 2 * n, np.int64)
+        return [(int(sk[2 * k]), int(sk[2 * k + 1])) for k in range(n)]
+
+    @property
+    def n_sites(self):
+        return int(lib().spl_combine_n_sites(self._h))
+
+    @property
+    def n_gap_sites(self):
+        return int(lib().spl_combine_n_gap_sites(self._h))
+
+    def tables(self, idx):
+        """The gap-fill queries of sample idx: [(region, dict of arrays: pos, site, strand, part_off, part_pos, comp_off, comp_pos)]
+        in the order the walk met the regions, rows by position."""
+        L = lib()
+        out = []
+        for k in range(int(L.spl_combine_n_tables(self._h, ctypes.c_int32(idx)))):
+            t = spl_query_table()
+            _check(L.spl_combine_table(self._h, ctypes.c_int32(idx), ctypes.c_int32(k), ctypes.byref(t)))
+            n = int(t.n)
+            part_off = _view(t.part_off, n + 1, np.uint32)
+            comp_off = _view(t.comp_off, n + 1, np.uint32)
+            out.append((t.chrom.decode("ascii"), dict(
+                pos=_view(t.pos, n, np.int64), site=_view(t.site, n, np.int64), strand=_view(t.strand, n, np.uint8),
+                part_off=part_off, part_pos=_view(t.part_pos, int(part_off[-1]), np.int64),
+                comp_off=comp_off, comp_pos=_view(t.comp_pos, int(comp_off[-1]), np.int64))))
+        return out
+
+    def answers(self, idx, site, beta1, beta2_simple):
+        site, beta1, b2 = _arr(site, np.int64), _arr(beta1, np.uint32), _arr(beta2_simple, np.uint32)
+        _check(lib().spl_combine_answers(self._h, ctypes.c_int32(idx), ctypes.c_int64(site.shape[0]), _ptr(site), _ptr(beta1), _ptr(b2)))
+
+    def write(self, path, titles, cryptic):
+        t = (ctypes.c_char_p * self.n)(*[s.encode("utf-8") for s in titles])
+        _check(lib().spl_combine_write(self._h, os.fsencode(path), t, ctypes.c_int(1 if cryptic else 0)))
