@@ -197,22 +197,60 @@ def run_oracle(items, scode, cryptic, threads):
     return dt, res
 
 
-def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode=None, devices=(0,), cpu_e2e=False, compare_devices=None):
-    """BAM + BED + GFF files of one workload -> spliser_amd.process.process (the CLI's function), timed.  The .SpliSER.tsv is
-    compared, byte for byte, with the text the oracle's numbers give for the same sample (``want``: run_oracle's results)."""
-    import statistics
-    from spliser_amd import native, process, synth, tsv
+def write_e2e_files(name, wl, stranded, seq_mode):
+    """The BAM + BED + GFF files of one end-to-end leg in a directory of their own.  -> {"tmp", "prefix", "files_written_s"}"""
+    from spliser_amd import native, synth
     tmp = tempfile.mkdtemp(prefix="spliser_e2e_")
+    prefix = os.path.join(tmp, name)
+    t = time.perf_counter()
+    synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions, stranded=bool(stranded))
+    synth.write_gff(prefix + ".gff", wl.genome)
+    native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=0, seq_mode=seq_mode)
+    return {"tmp": tmp, "prefix": prefix, "files_written_s": time.perf_counter() - t}
+
+
+def cold_cli(files, stranded, cryptic, runs=2):
+    """`python -m spliser_amd process ...` as a CHILD process, the way the reference is run (one command per interpreter,
+    SpliSER_v0_1_8.py:1295-1361): interpreter start, imports, the library, the HIP context, the first call with nothing at hand,
+    the .SpliSER.tsv.  The parent must not have touched the GPU yet (main() calls this before its first HIP call); the files are
+    in the page cache (just written).  -> {"wall_s": [...], "out": path of the last run's file}"""
+    import subprocess
+    prefix = files["prefix"]
+    walls, tails = [], []
+    for k in range(runs):
+        argv = [sys.executable, "-m", "spliser_amd", "process", "-B", prefix + ".bam", "-b", prefix + ".bed", "-A", prefix + ".gff",
+                "-o", prefix + ".cold%d" % k]
+        if stranded:
+            argv += ["--isStranded", "-s", stranded]
+        if cryptic:
+            argv += ["--beta2Cryptic"]
+        t = time.perf_counter()
+        r = subprocess.run(argv, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+        walls.append(time.perf_counter() - t)
+        tails.append(r.stdout[-300:])
+        if r.returncode != 0:
+            return {"wall_s": walls, "error": "exit %d: %s" % (r.returncode, r.stdout[-400:])}
+    reported = [float(t.rsplit("Total runtime (s):", 1)[1].split()[0]) if "Total runtime (s):" in t else None for t in tails]
+    return {"wall_s": walls, "reported_runtime_s": reported, "out": prefix + ".cold%d.SpliSER.tsv" % (runs - 1),
+            "what": "wall clock of the child process around `python -m spliser_amd process -B -b -A -o` (fork to exit), started before "
+                    "this process made its first HIP call; reported_runtime_s: the `Total runtime (s)` line the command prints, as the "
+                    "reference does (SpliSER_v0_1_8.py:1360-1361)"}
+
+
+def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode=None, devices=(0,), cpu_e2e=False, compare_devices=None,
+            files=None, cold=None):
+    """BAM + BED + GFF files of one workload -> spliser_amd.process.process (the CLI's function), timed.  The .SpliSER.tsv is
+    compared, byte for byte, with the text the oracle's numbers give for the same sample (``want``: run_oracle's results).
+    ``files``: written already (write_e2e_files); ``cold``: what cold_cli measured on them before the GPU was touched."""
+    import statistics
+    from spliser_amd import native, process, tsv
+    if files is None:
+        files = write_e2e_files(name, wl, stranded, seq_mode)
+    tmp, prefix = files["tmp"], files["prefix"]
     out = {"workload": name}
     noop = lambda m: None   # noqa: E731
     try:
-        prefix = os.path.join(tmp, name)
-        t = time.perf_counter()
-        synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions, stranded=bool(stranded))
-        synth.write_gff(prefix + ".gff", wl.genome)
-        native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=0,
-                         seq_mode=seq_mode)
-        out["files_written_s"] = time.perf_counter() - t
+        out["files_written_s"] = files["files_written_s"]
         out["devices"] = list(devices)
         out["bam_decode_asked"] = {None: "default (on the GPU: every device its own stretch of the file)", False: "host threads (process --hostDecode)",
                                    True: "GPU (process --gpuDecode)"}[gpu_decode]
@@ -294,6 +332,13 @@ def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode
         out["tsv_rows"] = got.count("\n") - 1
         out["tsv_matches_oracle"] = bool(got == expected)
         out["tsv_compared"] = "the whole file, byte for byte, against tsv.format_chrom over the oracle's counters and doubles"
+        if cold is not None:
+            out["cold_cli"] = cold
+            if "out" in cold:
+                with open(cold["out"]) as fh:
+                    out["cold_cli_matches"] = bool(fh.read() == expected)
+                out["cold_cli_s"] = min(cold["wall_s"])
+                out["cold_cli_first_s"] = cold["wall_s"][0]
         if cpu_e2e:     # the same work on the host's cores: decode (threads, libdeflate) + the oracle on all of them
             scode = native.STRANDED_CODE[stranded]
             n_threads = max(1, min(nproc, int(round(quota)) if quota else nproc))
@@ -309,6 +354,103 @@ def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode
                                       "the oracle (oracle/spliser_oracle.c) on %d threads; no TSV" % n_threads,
                               "decode_s": t_dec, "oracle_s": t_or, "wall_s": t_dec + t_or, "reads_per_sec": n_reads / (t_dec + t_or),
                               "threads": n_threads, "same_counts": bool(same), "gpu_over_cpu": (t_dec + t_or) / best["wall_s"]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def make_combine_samples(args, n_samples=6):
+    """BASELINE config 4: six samples of ONE A. thaliana-like genome (config 2's, seed 2), reads drawn with seeds 11-16, 15 % of
+    the isoforms not expressed in a sample (its sample-specific gaps).  Generated before the GPU is touched (the generator forks)."""
+    from spliser_amd import synth
+    base = synth.make_genome(synth.WORKLOADS["arabidopsis"]["chroms"], synth.WORKLOADS["arabidopsis"]["n_genes"],
+                             synth.WORKLOADS["arabidopsis"]["intron"], seed=synth.WORKLOADS["arabidopsis"]["seed"])
+    return [synth.Workload("arabidopsis", scale=args.combine_scale, genome=base, read_seed=11 + k, silence=0.15,
+                           workers=max(1, min(32, os.cpu_count() or 1))) for k in range(n_samples)]
+
+
+def combine_leg(samples, threads):
+    """config 4 end to end: `process` for each of the six samples (BAM -> .SpliSER.tsv), then `combine` over them (the files walked
+    in lock-step, every site a sample does not list counted from that sample's BAM on the GPU, .combined.tsv).  The check: the
+    same walk with the ORACLE answering the gap-fill queries from the decoded reads, its file byte for byte against the product's."""
+    from oracle import oracle
+    from spliser_amd import combine as cmb, native, process, synth
+    tmp = tempfile.mkdtemp(prefix="spliser_cmb_")
+    noop = lambda m: None   # noqa: E731
+    out = {}
+    try:
+        t = time.perf_counter()
+        lines, tsvs, bams, titles = [], [], [], []
+        for k, wl in enumerate(samples):
+            prefix = os.path.join(tmp, "s%d" % k)
+            synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions, stranded=False)
+            native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=0, seq_mode=1)
+            titles.append("S%d" % k)
+            tsvs.append(prefix + ".SpliSER.tsv")
+            bams.append(prefix + ".bam")
+            lines.append("S%d\t%s\t%s\n" % (k, tsvs[-1], bams[-1]))
+        sfile = os.path.join(tmp, "samples.tsv")
+        with open(sfile, "w") as fh:
+            fh.writelines(lines)
+        t_files = time.perf_counter() - t
+        n_reads = sum(sum(r.n for r in wl.reads) for wl in samples)
+        t = time.perf_counter()
+        per = []
+        for k in range(len(samples)):
+            t1 = time.perf_counter()
+            process.process(bams[k], os.path.join(tmp, "s%d.bed" % k), os.path.join(tmp, "s%d" % k), log=noop)
+            process.wait_deferred_close()
+            per.append(time.perf_counter() - t1)
+        t_process = time.perf_counter() - t
+        best = None
+        for rep in range(2):        # (the second call finds device memory of the samples' sizes at hand, like the e2e legs' timed calls)
+            t = time.perf_counter()
+            tm = cmb.combine(sfile, os.path.join(tmp, "all"), log=noop)
+            wall = time.perf_counter() - t
+            process.wait_deferred_close()
+            if best is None or wall < best[0]:
+                best = (wall, tm)
+            if rep == 0:
+                first = wall
+        wall, tm = best
+        # the checker: the same walk, the oracle's answers (test infrastructure; never timed as the product)
+        t = time.perf_counter()
+        oracle.set_threads(threads)
+        n_q = 0
+        with native.Combine(tsvs) as walk:
+            walk.merge(cmb.region_order_from_runs(walk.region_runs()), False, "All", None)
+            for idx in range(len(samples)):
+                tabs = walk.tables(idx)
+                if not tabs:
+                    continue
+                names = samples[idx].genome.chrom_names
+                for chrom, tb in tabs:
+                    rd = samples[idx].reads[names.index(chrom)]
+                    b1, b2, _ = oracle.check_bam(tb["pos"], tb["strand"], tb["part_off"], tb["part_pos"], tb["comp_off"], tb["comp_pos"],
+                                                 rd.pos, rd.flag, rd.cig_off, rd.cigar, 0, 1)
+                    walk.answers(idx, tb["site"], b1, b2)
+                    n_q += int(tb["pos"].shape[0])
+            walk.write(os.path.join(tmp, "want.combined.tsv"), titles, False)
+        oracle.set_threads(1)
+        t_check = time.perf_counter() - t
+        with open(os.path.join(tmp, "all.combined.tsv"), "rb") as a, open(os.path.join(tmp, "want.combined.tsv"), "rb") as b:
+            same = a.read() == b.read()
+        host = tm["parse_s"] + tm["merge_s"] + tm["write_s"]
+        out = {"workload": "config 4: %d samples x %d reads (A. thaliana-like genome, seeds 11-%d, 15%% of the isoforms silent per sample)"
+                           % (len(samples), n_reads // len(samples), 10 + len(samples)),
+               "files_written_s": t_files, "process_s": t_process, "process_s_per_sample": [round(v, 4) for v in per],
+               "combine_s": wall, "combine_first_call_s": first, "walk": tm["walk"], "parse_s": tm["parse_s"], "merge_s": tm["merge_s"],
+               "gapfill_s": tm["gapfill_s"], "write_s": tm["write_s"], "host_over_gpu": host / tm["gapfill_s"] if tm["gapfill_s"] else None,
+               "sites": tm["sites"], "gap_sites": tm["gap_sites"], "queries": tm["queries"], "rows": tm["sites"] * len(samples),
+               "combined_bytes": os.path.getsize(os.path.join(tmp, "all.combined.tsv")),
+               "reads_per_sec": n_reads / (t_process + wall), "matches_oracle": bool(same), "queries_checked": n_q, "check_s": t_check,
+               "what": "process x 6 then combine, wall clock of the calls in this process; combine = parse the six .SpliSER.tsv (native, "
+                       "a thread per file) + the lock-step walk (native) + gap fill (each sample's BAM decoded on the GPU once, its "
+                       "queries through the range kernel in combine mode) + .combined.tsv (native); matches_oracle: the file against the "
+                       "same walk with oracle/spliser_oracle.c answering every query from the reads that were written"}
+        out["line"] = {k: out[k] for k in ("workload", "process_s", "combine_s", "parse_s", "merge_s", "gapfill_s", "write_s", "host_over_gpu",
+                                           "queries", "rows", "reads_per_sec", "matches_oracle")}
+        out["line"]["workload"] = "config4: %dx%dM reads" % (len(samples), n_reads // len(samples) // 1000000)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out
@@ -439,6 +581,10 @@ def main():
                     "1 pseudo-random bases + binned qualities (10x the file); default: both")
     ap.add_argument("--e2e-reps", type=int, default=3)
     ap.add_argument("--no-small-leg", action="store_true", help="no A. thaliana end-to-end legs beside the human-scale ones")
+    ap.add_argument("--combine", default="auto", choices=["auto", "on", "off"], help="auto: the config-4 leg (six samples, process x 6 + combine) "
+                    "with the default workload at N = 1; on: with any workload (N = 1)")
+    ap.add_argument("--combine-scale", type=float, default=1.0, help="fraction of 20 M reads per combine sample (debug)")
+    ap.add_argument("--no-cold-cli", action="store_true", help="no `python -m spliser_amd process` child processes before the GPU is touched")
     ap.add_argument("--kernel", default="ranges", choices=["ranges", "ranges_agg", "pairs"],
                     help="ranges = default product path; pairs = the literal per-(read, site) kernel")
     ap.add_argument("--alt-fraction", type=float, default=None, help="(experiment) fraction of genes with alternative isoforms")
@@ -477,10 +623,22 @@ def main():
         small = argparse.Namespace(**vars(args))
         small.workload, small.cache = "arabidopsis", None
         wl_small = build_inputs(small, 0, 1)
+    full_default = args.e2e == "auto" and rank == 0 and world == 1 and args.workload == "human" and args.scale == 1.0
+    cmb_samples = make_combine_samples(args) if ((full_default and args.combine == "auto") or (args.combine == "on" and rank == 0 and world == 1)) else None
     shards = shard.pack(items, concat_reads=False)
     n_reads = sum(rd.n for _, _, rd in items)
     n_sites = sum(arr.n for _, arr, _ in items)
     t_gen = time.perf_counter() - t_gen
+
+    # ---- the command line as users run it, BEFORE this process touches the GPU: the files of the sequence-like legs are written now
+    # (host code) and `python -m spliser_amd process` runs on them as a child, a fresh interpreter each (cold_cli)
+    pre_files, cold = {}, {}
+    if args.e2e == "auto" and rank == 0 and world == 1 and not args.no_cold_cli and (args.e2e_seq_mode in (None, 1)):
+        pre_files[args.workload] = write_e2e_files(args.workload, wl, stranded, 1)
+        cold[args.workload] = cold_cli(pre_files[args.workload], stranded, args.beta2Cryptic)
+        if wl_small is not None:
+            pre_files["arabidopsis"] = write_e2e_files("arabidopsis", wl_small[0], wl_small[3], 1)
+            cold["arabidopsis"] = cold_cli(pre_files["arabidopsis"], wl_small[3], args.beta2Cryptic)
 
     dist = None
     torch.cuda.set_device(local_rank)
@@ -576,6 +734,7 @@ def main():
     cpu = None
     parity = None
     e2e = None
+    combine_res = None
     if rank == 0:
         t_cpu1, want = run_oracle(items, scode, args.beta2Cryptic, 1)
         exact = True
@@ -616,14 +775,21 @@ def main():
             e2e = []
             for q in modes:     # (first the file that deflates like a real library's: the leg that says what the product does)
                 e2e.append(e2e_leg(args.workload, wl, all_items, stranded, args.beta2Cryptic, q, args.e2e_reps, want_all, devices=devs,
-                                   cpu_e2e=(world == 1 and q == 1 and not args.no_cpu_baseline), compare_devices=(0,) if world > 1 else None))
+                                   cpu_e2e=(world == 1 and q == 1 and not args.no_cpu_baseline), compare_devices=(0,) if world > 1 else None,
+                                   files=pre_files.pop(args.workload, None) if q == 1 else None, cold=cold.get(args.workload) if q == 1 else None))
             if wl_small is not None:
                 wl2, _, items2, stranded2 = wl_small
                 _, want2 = run_oracle(items2, native.STRANDED_CODE[stranded2], args.beta2Cryptic, n_threads)
                 for q in modes:
-                    e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, q, args.e2e_reps, want2, cpu_e2e=(q == 1 and not args.no_cpu_baseline)))
+                    e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, q, args.e2e_reps, want2, cpu_e2e=(q == 1 and not args.no_cpu_baseline),
+                                       files=pre_files.pop("arabidopsis", None) if q == 1 else None, cold=cold.get("arabidopsis") if q == 1 else None))
                 if 1 in modes:  # ... and once with the host decoder asked for
                     e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, 1, args.e2e_reps, want2, gpu_decode=False))
+        if cmb_samples is not None:
+            nproc, quota = cpu_budget()
+            combine_res = combine_leg(cmb_samples, max(1, min(nproc, int(round(quota)) if quota else nproc)))
+    for f in pre_files.values():     # (files of legs that did not run)
+        shutil.rmtree(f["tmp"], ignore_errors=True)
     ctx.close()
 
     if rank == 0:
@@ -679,6 +845,7 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
             "e2e": e2e,
+            "combine": combine_res,
             "imbalance": imbalance,
             "literal_kernel_reads": literal_reads,
             "gen_seconds": t_gen, "upload_seconds": t_up,

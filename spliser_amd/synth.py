@@ -310,9 +310,15 @@ def _batch_job(job):
 class Workload(object):
     """A genome + reads per chromosome + the site table inputs derived from them."""
 
-    def __init__(self, name, n_reads=None, seed=None, scale=1.0, batch=2_500_000, workers=None, **over):
+    def __init__(self, name, n_reads=None, seed=None, scale=1.0, batch=2_500_000, workers=None, genome=None, read_seed=None,
+                 silence=0.0, **over):
         """``workers`` processes (fork) generate ``batch``-read slices in parallel; call this BEFORE the
-        process touches the GPU (a forked child must not inherit an initialised HIP runtime)."""
+        process touches the GPU (a forked child must not inherit an initialised HIP runtime).
+
+        ``genome`` / ``read_seed`` / ``silence``: another SAMPLE of a genome that exists already (BASELINE config 4: six samples of
+        one genome, seeds 11-16, 15 % sample-specific junctions) -- the reads drawn with ``read_seed``, and a fraction
+        ``silence`` of the isoforms, picked by that seed, not expressed in this sample: their junctions are what the other
+        samples have and this one does not (`combine` fills those gaps from this sample's BAM)."""
         if workers is None:
             workers = min(8, os.cpu_count() or 1)
         cfg = dict(WORKLOADS[name])
@@ -322,19 +328,26 @@ class Workload(object):
         n_reads = int((cfg["n_reads"] if n_reads is None else n_reads) * scale)
         n_genes = max(2, int(cfg["n_genes"] * (scale if scale < 1.0 else 1.0)))
         self.paired = bool(cfg.get("paired"))
-        self.genome = make_genome(cfg["chroms"], n_genes, cfg["intron"], seed=self.seed,
-                                  alt_fraction=cfg.get("alt_fraction", 0.3))
+        self.genome = genome if genome is not None else make_genome(cfg["chroms"], n_genes, cfg["intron"], seed=self.seed,
+                                                                    alt_fraction=cfg.get("alt_fraction", 0.3))
+        rseed = self.seed if read_seed is None else int(read_seed)
+        expressed = self.genome
+        if silence > 0.0:
+            import copy
+            expressed = copy.copy(self.genome)
+            off = np.random.default_rng(rseed * 7919 + 13).random(len(expressed.iso_weight)) < silence
+            expressed.iso_weight = np.where(off, 0.0, expressed.iso_weight)
         nchr = len(self.genome.chrom_names)
         per_chrom = [[] for _ in range(nchr)]
         jobs = []
         done = k = 0
         while done < n_reads:
             m = min(batch, n_reads - done)
-            jobs.append((m, self.seed * 1000 + k))
+            jobs.append((m, rseed * 1000 + k))
             done += m
             k += 1
         global _POOL_STATE
-        _POOL_STATE = (self.genome, self.paired, nchr)
+        _POOL_STATE = (expressed, self.paired, nchr)
         if workers > 1 and len(jobs) > 1:
             import multiprocessing
             with multiprocessing.get_context("fork").Pool(min(workers, len(jobs))) as pool:
