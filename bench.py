@@ -205,7 +205,8 @@ def write_e2e_files(name, wl, stranded, seq_mode):
     t = time.perf_counter()
     synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions, stranded=bool(stranded))
     synth.write_gff(prefix + ".gff", wl.genome)
-    native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=0, seq_mode=seq_mode)
+    # (seq_mode 2: the file `samtools sort` would leave -- htslib's default level 6, whole records per block, an aligner's fields)
+    native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=6 if seq_mode == 2 else 1, threads=0, seq_mode=seq_mode)
     return {"tmp": tmp, "prefix": prefix, "files_written_s": time.perf_counter() - t}
 
 
@@ -255,9 +256,11 @@ def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode
         out["bam_decode_asked"] = {None: "default (on the GPU: every device its own stretch of the file)", False: "host threads (process --hostDecode)",
                                    True: "GPU (process --gpuDecode)"}[gpu_decode]
         out["bam_bytes"] = os.path.getsize(prefix + ".bam")
-        out["bam_seq_qual"] = ("constant bytes (deflate to almost nothing)" if seq_mode == 0 else
-                               "pseudo-random bases, binned qualities in runs (deflate like a real library)")
-        out["bam"] = {0: "const", 1: "seq-like"}[seq_mode]      # (short forms for the compact line)
+        out["bam_seq_qual"] = {0: "constant bytes (deflate to almost nothing)",
+                               1: "pseudo-random bases, binned qualities in runs (deflate like a real library), zlib level 1, records cut at 0xff00",
+                               2: "htslib-shaped: level 6, whole records per block, Illumina names, MAPQ / bin / mate fields, bases of a reference "
+                                  "(overlapping reads share them), per-cycle NovaSeq quality bins, NH HI AS nM (XS:A, MD:Z) tags"}[seq_mode]
+        out["bam"] = {0: "const", 1: "seq-like", 2: "htslib"}[seq_mode]      # (short forms for the compact line)
         n_reads = sum(r.n for r in wl.reads)
 
         def call(tag, devs):
@@ -577,8 +580,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", default="auto", choices=["auto", "off"], help="auto: the decode-inclusive leg for this workload "
                     "(and for arabidopsis when the workload is human)")
-    ap.add_argument("--e2e-seq-mode", type=int, default=None, choices=[0, 1], help="SEQ / QUAL of the e2e BAMs: 0 constant bytes, "
-                    "1 pseudo-random bases + binned qualities (10x the file); default: both")
+    ap.add_argument("--e2e-seq-mode", type=int, default=None, choices=[0, 1, 2], help="the e2e BAMs: 0 constant SEQ / QUAL bytes, "
+                    "1 pseudo-random bases + binned qualities (10x the file), 2 what an aligner + samtools would write; default: all three")
     ap.add_argument("--e2e-reps", type=int, default=3)
     ap.add_argument("--no-small-leg", action="store_true", help="no A. thaliana end-to-end legs beside the human-scale ones")
     ap.add_argument("--combine", default="auto", choices=["auto", "on", "off"], help="auto: the config-4 leg (six samples, process x 6 + combine) "
@@ -770,7 +773,7 @@ def main():
             nproc, quota = cpu_budget()
             n_threads = max(1, min(nproc, int(round(quota)) if quota else nproc))
             want_all = want if len(all_items) == len(items) else run_oracle(all_items, scode, args.beta2Cryptic, n_threads)[1]
-            modes = [args.e2e_seq_mode] if args.e2e_seq_mode is not None else [1, 0]
+            modes = [args.e2e_seq_mode] if args.e2e_seq_mode is not None else [1, 2, 0]
             devs = tuple(range(world))
             e2e = []
             for q in modes:     # (first the file that deflates like a real library's: the leg that says what the product does)

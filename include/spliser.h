@@ -257,6 +257,10 @@ int spl_bam_wait_all(spl_bam *bam, int *sorted_out);
  * after spl_bam_cancel the decoders stop at their next batch (host) or window (device), a decode that has not begun never
  * does, and waiting calls return with an error. */
 void spl_bam_cancel(spl_bam *bam);
+/* Why the device decoder (spl_bam_decode_device / _share) left this file to the host threads: "" if it did not, otherwise a few
+ * words (not sorted by reference, a CIGAR parked in a CG tag, a block that did not inflate, not enough device memory, ...).  The
+ * pointer is good while the file is open.  (The reference has no counterpart: samtools reads whatever it is given, :422.) */
+const char *spl_bam_decline_reason(spl_bam *bam);
 void spl_bam_close(spl_bam *bam);
 int spl_bam_n_ref(const spl_bam *bam);
 const char *spl_bam_ref_name(const spl_bam *bam, int tid);

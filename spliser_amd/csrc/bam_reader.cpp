@@ -502,6 +502,7 @@ struct spl_bam {
     int claim = 0;             // 0 = nobody decodes yet (deferred open), 1 = the device decoder is at it, 2 = host worker started / arrays adopted
     uint64_t header_bytes = 0; // magic, text and reference dictionary: the first record starts here in the inflated stream
     std::string path;
+    std::string decline_reason; // why the device decoder handed the file to the host threads, if it did
     ~spl_bam();
 };
 
@@ -1140,6 +1141,18 @@ extern "C" int spl_bam_reserve_device(spl_bam *bam)
     bam->reserved = true;
     return SPL_OK;
 }
+// Why the device decoder did not take the file (spl_capi.cpp's to_host): kept for whoever tells the user (process.py logs it once)
+void spl_bam_note_decline(spl_bam *bam, const char *why)
+{
+    std::lock_guard<std::mutex> lock(bam->mu);
+    if (bam->decline_reason.empty()) bam->decline_reason = why ? why : "";
+}
+extern "C" const char *spl_bam_decline_reason(spl_bam *bam)
+{
+    if (!bam) return "";
+    std::lock_guard<std::mutex> lock(bam->mu);
+    return bam->decline_reason.c_str(); // (set at most once, never changed: the pointer stays good while the file is open)
+}
 int spl_bam_device_gives_up(spl_bam *bam)
 {
     std::lock_guard<std::mutex> lock(bam->mu);
@@ -1687,8 +1700,124 @@ bool deflate_all(const std::vector<uint8_t> &raw, int level, void *ld, std::vect
 
 } // namespace
 
+namespace {
+
+inline uint64_t mix64(uint64_t x) { x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; return x ^ (x >> 31); }
+
+// seq_mode 2: one record the way an aligner's output looks after `samtools sort` (what the reference reads through
+// `samtools view`, SpliSER_v0_1_8.py:422): an Illumina read name, MAPQ and bin as htslib computes them, mate fields for paired
+// flags, SEQ taken from a reference that is a function of the position -- overlapping reads share their bases, a few mismatches
+// aside, which is where a sorted BAM's long, far matches come from --, QUAL from a per-cycle distribution of the four NovaSeq
+// bins, and STAR's tags (NH HI AS nM, XS:A on spliced reads, MD:Z on a third).
+void realistic_record(std::vector<uint8_t> &cur, int tid, int64_t ref_len, int32_t pos1, uint32_t flag, const uint32_t *cig, uint32_t n_ops, uint64_t &lcg)
+{
+    auto rnd = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return lcg >> 33; }; // 31 bits
+    uint32_t qlen = 0, rlen = 0;
+    bool spliced = false;
+    for (uint32_t j = 0; j < n_ops; ++j) {
+        const uint32_t c = cig[j] & 15u, l = cig[j] >> 4;
+        if (c == 0 || c == 1 || c == 4 || c == 7 || c == 8) qlen += l;
+        if (c == 0 || c == 2 || c == 3 || c == 7 || c == 8) rlen += l;
+        spliced = spliced || c == 3;
+    }
+    char name[64];
+    const uint32_t tile = (rnd() & 1u ? 1101u : 2101u) + (uint32_t)(rnd() % 78u) + 100u * (uint32_t)(rnd() % 6u);
+    const int l_name = snprintf(name, sizeof name, "A00741:215:HGV2FDSXY:%u:%u:%u:%u", 1u + (unsigned)(rnd() & 3u), tile, 1000u + (unsigned)(rnd() % 31000u),
+                                1000u + (unsigned)(rnd() % 36000u)) + 1;
+    const uint32_t nm = (uint32_t)(rnd() % 100u < 74u ? 0u : (rnd() % 100u < 75u ? 1u : 2u + rnd() % 3u));
+    const uint32_t mq = rnd() % 100u;
+    const uint8_t mapq = mq < 90u ? 255 : (mq < 96u ? 3 : (mq < 99u ? 1 : 0));
+    const int32_t pos0 = pos1 - 1, end0 = pos0 + (int32_t)((rlen && !(flag & 4u)) ? rlen : 1u);
+    uint32_t bin; // reg2bin (SAM specification 5.3)
+    {
+        const int32_t b = pos0, e = end0 - 1;
+        if (b >> 14 == e >> 14) bin = 4681u + (uint32_t)(b >> 14);
+        else if (b >> 17 == e >> 17) bin = 585u + (uint32_t)(b >> 17);
+        else if (b >> 20 == e >> 20) bin = 73u + (uint32_t)(b >> 20);
+        else if (b >> 23 == e >> 23) bin = 9u + (uint32_t)(b >> 23);
+        else if (b >> 26 == e >> 26) bin = 1u + (uint32_t)(b >> 26);
+        else bin = 0;
+    }
+    int32_t mtid = -1, mpos = -1, tlen = 0;
+    if (flag & 1u) { // paired: the mate a fragment length away, on the other strand
+        const int32_t frag = 180 + (int32_t)(rnd() % 320u);
+        mtid = tid;
+        if (flag & 16u) { mpos = std::max(0, end0 - frag); tlen = -(end0 - mpos); }
+        else { mpos = std::min<int64_t>(std::max<int64_t>(ref_len - 1, 0), (int64_t)pos0 + frag - (int32_t)qlen); if (mpos < pos0) mpos = pos0; tlen = mpos + (int32_t)qlen - pos0; }
+    }
+    // tags first (their size is part of block_size)
+    uint8_t tags[96];
+    size_t nt = 0;
+    auto tag_u8 = [&](char a, char b, uint32_t v) {
+        tags[nt++] = (uint8_t)a; tags[nt++] = (uint8_t)b;
+        if (v < 256u) { tags[nt++] = 'C'; tags[nt++] = (uint8_t)v; } else { tags[nt++] = 'S'; tags[nt++] = (uint8_t)v; tags[nt++] = (uint8_t)(v >> 8); }
+    };
+    const uint32_t nh = mapq == 255 ? 1u : (mapq == 3 ? 2u : (mapq == 1 ? 3u + (uint32_t)(rnd() & 1u) : 5u + (uint32_t)(rnd() % 6u)));
+    tag_u8('N', 'H', nh);
+    tag_u8('H', 'I', 1u + (uint32_t)(rnd() % nh));
+    tag_u8('A', 'S', (flag & 1u ? 2u * qlen : qlen) - 2u - 2u * nm);
+    tag_u8('n', 'M', nm);
+    if (spliced) { tags[nt++] = 'X'; tags[nt++] = 'S'; tags[nt++] = 'A'; tags[nt++] = (flag & 16u) ? '-' : '+'; }
+    uint32_t mm_at[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t m = 0; m < nm && m < 8u; ++m) mm_at[m] = qlen ? (uint32_t)(rnd() % qlen) : 0u;
+    if (rnd() % 3u == 0) { // MD:Z (matches between mismatches; which base it was does not matter for what deflate sees)
+        char md[48];
+        int k = 0;
+        if (nm == 0 || qlen == 0) k = snprintf(md, sizeof md, "%u", rlen);
+        else {
+            const uint32_t a = mm_at[0] % (rlen ? rlen : 1u);
+            k = snprintf(md, sizeof md, "%u%c%u", a, "ACGT"[rnd() & 3u], rlen - a - (rlen ? 1u : 0u));
+        }
+        tags[nt++] = 'M'; tags[nt++] = 'D'; tags[nt++] = 'Z';
+        memcpy(tags + nt, md, (size_t)k + 1);
+        nt += (size_t)k + 1;
+    }
+    const uint32_t bs = 32 + (uint32_t)l_name + 4 * n_ops + (qlen + 1) / 2 + qlen + (uint32_t)nt;
+    put32(cur, bs);
+    put32(cur, (uint32_t)tid);
+    put32(cur, (uint32_t)pos0);
+    cur.push_back((uint8_t)l_name); cur.push_back(mapq);
+    put16(cur, bin); put16(cur, n_ops); put16(cur, flag);
+    put32(cur, qlen); put32(cur, (uint32_t)mtid); put32(cur, (uint32_t)mpos); put32(cur, (uint32_t)tlen);
+    cur.insert(cur.end(), name, name + l_name);
+    for (uint32_t j = 0; j < n_ops; ++j) put32(cur, cig[j]);
+    // SEQ: the reference's bases under the aligned blocks, random ones for what the reference does not have (I, S)
+    static const uint8_t code[4] = {1, 2, 4, 8};
+    uint8_t q[2]; // (two bases make a byte)
+    uint32_t qi = 0;
+    int64_t rp = pos0;
+    auto emit = [&](uint8_t b2) {
+        for (uint32_t m = 0; m < nm && m < 8u; ++m) if (mm_at[m] == qi) b2 = (uint8_t)((b2 + 1u + (qi & 1u)) & 3u);
+        q[qi & 1u] = code[b2];
+        if (qi & 1u) cur.push_back((uint8_t)(q[0] << 4 | q[1]));
+        ++qi;
+    };
+    for (uint32_t j = 0; j < n_ops; ++j) {
+        const uint32_t c = cig[j] & 15u, l = cig[j] >> 4;
+        if (c == 0 || c == 7 || c == 8) { for (uint32_t x = 0; x < l; ++x, ++rp) emit((uint8_t)(mix64(((uint64_t)(uint32_t)tid << 40) ^ (uint64_t)rp) >> 62)); }
+        else if (c == 1 || c == 4) { for (uint32_t x = 0; x < l; ++x) emit((uint8_t)(rnd() & 3u)); }
+        else if (c == 2 || c == 3) rp += l;
+    }
+    if (qi & 1u) cur.push_back((uint8_t)(q[0] << 4));
+    // QUAL: NovaSeq's bins (37, 25, 11, 2); the best one less likely towards the read's end, a call like the one before it more often than not
+    uint8_t prev = 37;
+    for (uint32_t j = 0; j < qlen; ++j) {
+        const uint32_t r = (uint32_t)(rnd() % 1000u);
+        if (j && r < 550u) { cur.push_back(prev); continue; }
+        const uint32_t late = qlen ? 120u * j / qlen * j / qlen : 0u; // 0 .. 120 per mille
+        const uint32_t u = (uint32_t)(rnd() % 1000u);
+        prev = u < 930u - late ? 37 : (u < 975u - late / 2u ? 25 : (u < 997u ? 11 : 2));
+        cur.push_back(prev);
+    }
+    cur.insert(cur.end(), tags, tags + nt);
+}
+
+} // namespace
+
 // seq_mode 0: constant SEQ / QUAL bytes (a file that deflates to a few bytes per record); 1: pseudo-random bases and binned
-// qualities in runs, so that records deflate about as well as those of a real library (~4x).
+// qualities in runs, so that records deflate about as well as those of a real library (~4x); 2: records an aligner would write
+// (realistic_record above) in blocks cut the way htslib cuts them -- a record that fits a block is never split (bam_write1's
+// bgzf_flush_try) -- at the compression level asked for (htslib's default is 6).
 extern "C" int spl_bam_write2(const char *path, int n_ref, const char *const *ref_names, const int64_t *ref_lengths,
                               const spl_reads *per_ref, int level, int n_threads, int seq_mode)
 {
@@ -1742,6 +1871,23 @@ extern "C" int spl_bam_write2(const char *path, int n_ref, const char *const *re
                 const spl_reads &r = per_ref[sl.tid];
                 cur.clear();
                 uint64_t lcg = 0x9E3779B97F4A7C15ull * (sl.serial + 1);
+                if (seq_mode == 2) { // whole records per block, like htslib: a block is closed when the next record does not fit
+                    const size_t BLOCK = 0xff00;
+                    for (int64_t k = sl.k0; k < sl.k1 && !sl.bad; ++k) {
+                        const size_t before = cur.size();
+                        realistic_record(cur, sl.tid, ref_lengths[sl.tid], r.pos[k], r.flag[k], r.cigar + r.cig_off[k], r.cig_off[k + 1] - r.cig_off[k], lcg);
+                        if (cur.size() > BLOCK && before) { // the block without this record, the record to the front
+                            if (!deflate_block(cur.data(), before, level, ld, sl.out)) sl.bad = true;
+                            cur.erase(cur.begin(), cur.begin() + (ptrdiff_t)before);
+                        }
+                        while (cur.size() > BLOCK && !sl.bad) { // (a record larger than a block is cut, as htslib cuts it)
+                            if (!deflate_block(cur.data(), BLOCK, level, ld, sl.out)) sl.bad = true;
+                            cur.erase(cur.begin(), cur.begin() + (ptrdiff_t)BLOCK);
+                        }
+                    }
+                    if (!cur.empty() && !sl.bad && !deflate_block(cur.data(), cur.size(), level, ld, sl.out)) sl.bad = true;
+                    continue;
+                }
                 for (int64_t k = sl.k0; k < sl.k1; ++k) {
                     const uint32_t o0 = r.cig_off[k], n_ops = r.cig_off[k + 1] - o0;
                     uint32_t qlen = 0;

@@ -48,6 +48,7 @@ bool spl_bam_cancelled(const spl_bam *bam);                   // spl_bam_cancel 
 void spl_bam_set_fetch(spl_bam *bam, int (*fetch)(void *, int32_t **, uint16_t **, uint32_t **, uint32_t **));
 int spl_bam_start_host(spl_bam *bam);                      // decode on the host's threads unless somebody decodes already
 bool spl_bam_claim_for_device(spl_bam *bam);               // the device decoder takes the file (false: it is taken)
+void spl_bam_note_decline(spl_bam *bam, const char *why); // why the device decoder leaves the file to the host threads
 int spl_bam_device_gives_up(spl_bam *bam);                 // ... and hands it to the host threads after all
 
 #endif

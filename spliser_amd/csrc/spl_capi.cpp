@@ -1275,6 +1275,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     const double t_begin = host_now();
     auto to_host = [&](const char *why) { // not a file for this path: the host threads take it (and find the words for what is wrong with it)
         if (timing) fprintf(stderr, "[spl_bam_decode_device] handing the file to the host decoder: %s\n", why);
+        spl_bam_note_decline(bam, why);
         res.to_host = true;
         return SPL_OK;
     };
@@ -1298,6 +1299,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         hipStream_t a = nullptr, b = nullptr, cp[NCOPY] = {}, up2 = nullptr; // (up2: a second stream for the file's pieces, beside the context's copy stream)
         hipEvent_t k1[NBUF] = {}, k2[NBUF] = {}, freed[NBUF] = {}, setup = nullptr;
         std::vector<hipEvent_t> piece;
+        std::vector<hipEvent_t> dec; // window w's Huffman decoding is done: nobody reads its pieces of the file image again (their slots of the ring are free)
         explicit Pipe(spl_ctx *ctx) : c(ctx) {}
         // (only the streams that will be used: the runtime deals streams out to a few hardware queues, and one more stream --
         //  made, never used -- put the decoding and the copying kernels behind each other: 0.75 s instead of 0.43 for a 14 GB file)
@@ -1315,6 +1317,14 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             if (e == hipSuccess) e = hipEventCreateWithFlags(&setup, hipEventDisableTiming);
             piece.assign(n_pieces, nullptr);
             for (size_t k = 0; k < n_pieces && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&piece[k], hipEventDisableTiming);
+            dec.assign(1, nullptr);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&dec[0], hipEventDisableTiming);
+            return e;
+        }
+        hipError_t make_windows(size_t n_win)
+        {
+            hipError_t e = hipSuccess;
+            while (dec.size() < n_win && e == hipSuccess) { dec.push_back(nullptr); e = hipEventCreateWithFlags(&dec.back(), hipEventDisableTiming); }
             return e;
         }
         ~Pipe()
@@ -1325,6 +1335,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             if (c->copy) (void)hipStreamSynchronize(c->copy);
             if (up2) (void)hipStreamSynchronize(up2);
             for (hipEvent_t e : piece) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : dec) if (e) (void)hipEventDestroy(e);
             for (int k = 0; k < NBUF; ++k) { if (k1[k]) (void)hipEventDestroy(k1[k]); if (k2[k]) (void)hipEventDestroy(k2[k]); if (freed[k]) (void)hipEventDestroy(freed[k]); }
             if (setup) (void)hipEventDestroy(setup);
             if (a) (void)hipStreamDestroy(a);
@@ -1348,25 +1359,69 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     }
     const size_t n_bytes = byte_hi - byte_lo;
     size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    free_b += devmem::held_bytes(c->device); // (given back before a request fails)
-    // (a first look, before anything is allocated: the image, two windows of a stream that is at most 64 KiB a block with their
-    //  token room -- as many blocks as the file can have, 49 152 at most --, a fifth of the stream for what is extracted; the
-    //  exact sizes are checked again where they are known)
-    {
-        const double blocks_most = std::min((double)49152, (double)n_bytes / 28.0 + 1.0), per_block = 65536.0 + (double)SPL_Z_TOKEN_STRIDE;
-        if ((double)n_bytes * 2.5 + 2.0 * blocks_most * per_block + (double)((size_t)1 << 30) > (double)free_b) return to_host("not enough device memory");
-    }
-    HIP_TRY(d_image.get(n_bytes + SPL_Z_IMAGE_PAD, c->copy));
-    HIP_TRY(hipMemsetAsync(d_image.as<char>() + n_bytes, 0, SPL_Z_IMAGE_PAD, c->copy));
+    // (SPL_DEV_FREE_LIMIT_MB: the tests' way to a device with little memory -- every look at the free memory below sees at most this much)
+    const size_t free_limit = getenv("SPL_DEV_FREE_LIMIT_MB") ? (size_t)std::max(1L, atol(getenv("SPL_DEV_FREE_LIMIT_MB"))) << 20 : (size_t)-1;
+    const double slack = free_limit == (size_t)-1 ? (double)((size_t)1 << 30) : (double)((size_t)8 << 20);
+    size_t used_b = 0; // what this call has taken so far (only the tests' limit needs to be told)
+    auto look_at_free = [&]() -> hipError_t {
+        const hipError_t e = hipMemGetInfo(&free_b, &total_b);
+        free_b += devmem::held_bytes(c->device); // (given back before a request fails)
+        if (free_limit != (size_t)-1) free_b = std::min(free_b, free_limit > used_b ? free_limit - used_b : (size_t)0);
+        return e;
+    };
+    HIP_TRY(look_at_free());
     // The file's bytes: page cache -> staging buffer -> device.  One reader thread per staging buffer: it preads its pieces (a
-    // piece = a buffer's size, dealt round-robin), sends each on its way itself and records the piece's event behind it.
+    // piece = what a buffer holds, dealt round-robin), sends each on its way itself and records the piece's event behind it.
     // (a reader fills its buffer from the page cache at 8-10 GB/s before the copy engine takes 0.6 ms to empty it: three readers
     //  bring 25-40 GB/s, and since the kernels got through a window in 16 ms a large file waited for its bytes: six for those)
     if (n_bytes >= ((size_t)4 << 30) && !getenv("SPL_STAGE_BUFFERS")) { rc = grow_stage(c, 6); if (rc) return rc; }
     const size_t n_stage = c->stage.size();
-    const size_t piece = c->stage[0].bytes;
+    // On the device the file exists as a RING of pieces, not whole: only the Huffman decoding reads it, a window of blocks at a
+    // time, so a piece's slot is given to the piece R further on as soon as the last window that reads it has been decoded --
+    // device memory for about four windows' worth of the file (3.4 GB of a 14 GB file's) instead of all of it, whatever the
+    // file's size; fresh device memory is what a new process's first call waits for (6-15 ms a gigabyte).  A block's data is
+    // less than 64 KiB: with every piece goes the beginning of the next (TAIL), so that a block that begins in a piece is in one
+    // piece of memory in that piece's slot.
+    const size_t TAIL = (size_t)65536 + 4096; // (and what the decoder may read beyond a block's end, SPL_Z_IMAGE_PAD)
+    const size_t slot = c->stage[0].bytes;    // a staging buffer holds a piece and its tail
+    if (slot < 4 * TAIL) return to_host("staging buffers too small for the file image's pieces");
+    const size_t piece = slot - TAIL;
     const size_t n_pieces = (n_bytes + piece - 1) / piece;
+    size_t win_blocks = (size_t)49152;
+    if (const char *e = getenv("SPL_INFLATE_WINDOW_BLOCKS")) win_blocks = (size_t)std::max(2, atoi(e));
+    if (!share) spl_bam_walk_some(bam, (size_t)5 << 28); // (1.25 GB of the directory, 3 ms: 49 152 blocks of a file that compresses 4x are 0.8 GB; a share's plan has walked all of it)
+    size_t ring = n_pieces; // slots
+    size_t win_bytes_cap = (size_t)-1; // a window ends where its blocks' bytes in the file would exceed this (so that four windows fit the ring)
+    double per_block_file = 65536.0;
+    {
+        const size_t n_known = spl_bam_block_count(bam);
+        const size_t b_lo = share ? (size_t)share->block_lo : 0, b_hi = share ? (size_t)share->block_hi : n_known;
+        double per_block = 65536.0; // bytes of file per block, from the blocks known so far
+        if (b_hi > b_lo + 1) {
+            spl_bam_block_info f0, f1;
+            spl_bam_block_get(bam, b_lo, &f0);
+            spl_bam_block_get(bam, b_hi - 1, &f1);
+            per_block = (double)(f1.data_off - f0.data_off) / (double)(b_hi - 1 - b_lo);
+        }
+        per_block_file = per_block;
+        const double est_win = per_block * (double)win_blocks;
+        size_t want = (size_t)(4.2 * est_win / (double)piece) + 4;
+        if (const char *e = getenv("SPL_IMAGE_RING_PIECES")) want = (size_t)std::max(4, atoi(e)); // (tests: a ring of a few pieces)
+        if (want < n_pieces) {
+            ring = want;
+            win_bytes_cap = (ring - 3) * piece / 4;
+        }
+    }
+    {   // a first look, before anything is allocated: the ring, two windows of a stream that is at most 64 KiB a block with their
+        // token room, a fifth of the inflated stream for what is extracted; the exact sizes are checked again where they are known
+        const double blocks_all = (double)n_bytes / std::max(per_block_file, 28.0) + 1.0, blocks_most = std::min((double)win_blocks, blocks_all);
+        if ((double)ring * (double)slot + 0.2 * blocks_all * 65536.0 + 2.0 * blocks_most * (65536.0 + (double)SPL_Z_TOKEN_STRIDE) + slack > (double)free_b)
+            return to_host("not enough device memory");
+    }
+    HIP_TRY(d_image.get(ring * slot + SPL_Z_IMAGE_PAD, c->copy));
+    used_b += ring * slot;
+    if (timing) fprintf(stderr, "[spl_bam_decode_device] device %d: the file's %.1f MB as %zu pieces of %.1f MB, %zu slots on the device (%.1f MB)%s\n", c->device, n_bytes / 1e6, n_pieces,
+                        piece / 1e6, ring, ring * slot / 1e6, ring < n_pieces ? "" : ": all of it");
     int n_copy = 1; // streams the copying kernels take turns on (1: one window's copies behind the other's)
     if (const char *e = getenv("SPL_INFLATE_COPY_STREAMS")) n_copy = std::min(NCOPY, std::max(1, atoi(e)));
     const bool two_up = getenv("SPL_UPLOAD_STREAMS") && atoi(getenv("SPL_UPLOAD_STREAMS")) >= 2; // (the file's pieces on two streams in turn)
@@ -1375,6 +1430,11 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     std::vector<std::atomic<int>> sent(n_pieces); // piece k's copy and event are in the copy stream's queue (or will never be: errs)
     for (auto &f : sent) f.store(0, std::memory_order_relaxed);
     std::atomic<int> reader_failed(0);
+    // what the readers need to know before they may overwrite a slot: which window reads a piece last (known when the windows
+    // are: windows_known), and that this window's decoding kernel is on its stream (launched_pub), with its event behind it
+    std::vector<uint32_t> piece_last_win(n_pieces, 0);
+    std::atomic<int> windows_known(0), stop_upload(0);
+    std::atomic<size_t> launched_pub(0);
     const int fd = spl_bam_fd(bam);
     char *const d_img = d_image.as<char>();
     if (two_up) HIP_TRY(hipStreamSynchronize(c->copy)); // (what was put on the copy stream for the image so far is done before the other stream writes into it)
@@ -1382,13 +1442,20 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         if (hipSetDevice(c->device) != hipSuccess) errs[t] = hipErrorInvalidDevice;
         spl_ctx::Stage &st = c->stage[t];
         for (size_t k = t; k < n_pieces; k += n_stage) {
+            hipStream_t up = two_up && (t & 1u) ? pipe.up2 : c->copy;
+            if (errs[t] == hipSuccess && k >= ring) { // the slot's last piece must have been read by everybody who reads it
+                while (!windows_known.load(std::memory_order_acquire) && !stop_upload.load(std::memory_order_acquire)) std::this_thread::yield();
+                const size_t w = windows_known.load(std::memory_order_acquire) ? piece_last_win[k - ring] : 0;
+                while (launched_pub.load(std::memory_order_acquire) <= w && !stop_upload.load(std::memory_order_acquire)) std::this_thread::yield();
+                if (stop_upload.load(std::memory_order_acquire)) errs[t] = hipErrorNotReady; // (the call is on its way out: nobody waits for this piece)
+                else errs[t] = hipStreamWaitEvent(up, pipe.dec[w], 0);
+            }
             if (errs[t] == hipSuccess && st.busy) { errs[t] = hipEventSynchronize(st.done); st.busy = false; }
             if (errs[t] == hipSuccess) {
-                const size_t off = k * piece, n = std::min(piece, n_bytes - off);
+                const size_t off = k * piece, n = std::min(piece + TAIL, n_bytes - off);
                 CopyJob job{st.host, (const char *)image + byte_lo + off, n, n, fd, byte_lo + off};
                 copy_slice(0, &job);
-                hipStream_t up = two_up && (t & 1u) ? pipe.up2 : c->copy;
-                errs[t] = hipMemcpyAsync(d_img + off, st.host, n, hipMemcpyHostToDevice, up);
+                errs[t] = hipMemcpyAsync(d_img + (k % ring) * slot, st.host, n, hipMemcpyHostToDevice, up);
                 if (errs[t] == hipSuccess) { errs[t] = hipEventRecord(st.done, up); st.busy = true; }
                 if (errs[t] == hipSuccess) errs[t] = hipEventRecord(pipe.piece[k], up);
             }
@@ -1396,56 +1463,72 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             sent[k].store(1, std::memory_order_release);
         }
     };
+    // where a block's data lies in the ring (off: its offset in this share's stretch of the file), and the windows' ends
+    auto ring_at = [&](uint64_t file_off) { const size_t o = (size_t)file_off - byte_lo, pc = o / piece; return (uint64_t)((pc % ring) * slot + (o - pc * piece)); };
+    auto piece_of = [&](uint64_t file_off) { return ((size_t)file_off - byte_lo) / piece; };
+    std::vector<uint64_t> foff; // the blocks' offsets in the file (spl_zblock.in is where they lie in the ring)
     struct Crew { // (declared behind everything its threads touch: joined before any of that goes away, on every way out)
         std::vector<std::thread> threads;
+        std::atomic<int> *stop = nullptr;
         void join() { for (std::thread &t : threads) if (t.joinable()) t.join(); }
-        ~Crew() { join(); }
+        ~Crew() { if (stop) stop->store(1, std::memory_order_release); join(); } // (a reader waiting for a slot is told that nobody will free it)
     } crew;
+    crew.stop = &stop_upload;
     // ---- the whole file: its first window is on its streams before the directory is complete.  The directory of the file's first
     // gigabyte takes 3 ms, the rest of a 14 GB file 25: the first window's decoding and copying kernels (23 ms) run beside that.
     // They get a list of blocks and status words of their own (the file's are allocated when their number is known).
-    size_t win_blocks = (size_t)49152;
-    if (const char *e = getenv("SPL_INFLATE_WINDOW_BLOCKS")) win_blocks = (size_t)std::max(2, atoi(e));
     const uint64_t HEAD = (uint64_t)8 << 20; // room in front of a window's bytes for what the window before left unfinished
-    const uint8_t *const image0 = d_image.as<uint8_t>() - byte_lo; // (indexed with offsets into the file)
+    const uint8_t *const image0 = d_image.as<uint8_t>(); // (a block's `in` is its place in the ring)
     size_t pieces_waited = 0;
     size_t early = 0; // blocks of the first window if it has been launched already (0: not)
     for (size_t t = 0; t < n_stage; ++t) crew.threads.emplace_back(reader, t);
+    // where a window that begins with block b0 ends: win_blocks blocks on, or where its bytes in the file would not fit a quarter of the ring
+    auto window_end = [&](const std::vector<uint64_t> &off, size_t b0, size_t n_all) {
+        size_t b1 = std::min(n_all, b0 + win_blocks);
+        if (win_bytes_cap != (size_t)-1 && off[b1 - 1] - off[b0] > win_bytes_cap) {
+            size_t lo2 = b0 + 1, hi2 = b1; // the first b with off[b - 1] - off[b0] > cap is where it must end at the latest
+            while (lo2 < hi2) { const size_t mid = lo2 + (hi2 - lo2) / 2; if (off[mid - 1] - off[b0] > win_bytes_cap) hi2 = mid; else lo2 = mid + 1; }
+            b1 = std::max(b0 + 1, lo2 - 1);
+        }
+        return b1;
+    };
     if (!share && !getenv("SPL_INFLATE_NO_EARLY")) {
-        spl_bam_walk_some(bam, (size_t)5 << 28); // (1.25 GB: 49 152 blocks of a file that compresses 4x are 0.8 GB)
         const size_t n_known = spl_bam_block_count(bam);
         if (n_known >= win_blocks || (n_known >= 2 && spl_bam_walk_complete(bam))) {
-            const size_t b1 = std::min(win_blocks, n_known);
-            blocks0.resize(b1);
-            for (size_t i = 0; i < b1; ++i) {
+            std::vector<uint64_t> off0(std::min(win_blocks, n_known));
+            blocks0.resize(off0.size());
+            for (size_t i = 0; i < off0.size(); ++i) {
                 spl_bam_block_info bi;
                 spl_bam_block_get(bam, i, &bi);
-                blocks0[i].in = bi.data_off; blocks0[i].out = bi.uoff; blocks0[i].in_len = bi.data_len; blocks0[i].out_len = bi.isize; blocks0[i].crc = bi.crc; blocks0[i].pad = 0;
+                off0[i] = bi.data_off;
+                blocks0[i].in = ring_at(bi.data_off); blocks0[i].out = bi.uoff; blocks0[i].in_len = bi.data_len; blocks0[i].out_len = bi.isize; blocks0[i].crc = bi.crc; blocks0[i].pad = 0;
             }
-            const size_t work0 = spl_dev_inflate_work_bytes((uint32_t)b1);
-            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            free_b += devmem::held_bytes(c->device);
-            if ((double)HEAD + (double)b1 * 65536.0 + (double)work0 + (double)((size_t)2 << 30) < (double)free_b) {
-                HIP_TRY(d_stream[0].get(HEAD + (uint64_t)b1 * 65536u + 256, c->copy)); // (no block inflates to more than 64 KiB)
+            const size_t b1 = window_end(off0, 0, off0.size()), b_most = off0.size(); // (b_most: what any window of this file can have -- the buffers serve later windows too)
+            blocks0.resize(b1);
+            const size_t work0 = spl_dev_inflate_work_bytes((uint32_t)b_most);
+            HIP_TRY(look_at_free());
+            if ((double)HEAD + (double)b_most * 65536.0 + (double)work0 + 2.0 * slack < (double)free_b) {
+                HIP_TRY(d_stream[0].get(HEAD + (uint64_t)b_most * 65536u + 256, c->copy)); // (no block inflates to more than 64 KiB)
                 HIP_TRY(d_zwork[0].get(work0, c->copy));
+                used_b += (size_t)HEAD + b_most * 65536u + work0;
                 HIP_TRY(d_blocks0.get(sizeof(spl_zblock) * b1, c->copy));
                 HIP_TRY(d_status0.get(4 * b1, c->copy));
                 HIP_TRY(hipMemcpyAsync(d_blocks0.p, blocks0.data(), sizeof(spl_zblock) * b1, hipMemcpyHostToDevice, pipe.a));
                 HIP_TRY(hipMemsetAsync(d_status0.p, 0xff, 4 * b1, pipe.a));
-                const size_t last_byte = (size_t)(blocks0[b1 - 1].in + blocks0[b1 - 1].in_len + 8) - byte_lo;
-                const size_t need = std::min(n_pieces, last_byte / piece + 1);
+                const size_t need = std::min(n_pieces, piece_of(off0[b1 - 1]) + 1); // (the piece its last block begins in holds all of it)
                 for (; pieces_waited < need; ++pieces_waited) {
                     while (!sent[pieces_waited].load(std::memory_order_acquire)) std::this_thread::yield();
                     if (reader_failed.load(std::memory_order_acquire)) { for (hipError_t e : errs) HIP_TRY(e); }
                     HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.piece[pieces_waited], 0));
                 }
                 uint8_t *const stream0 = d_stream[0].as<uint8_t>() + HEAD - blocks0[0].out;
-                const double w_in = (double)(blocks0[b1 - 1].in + blocks0[b1 - 1].in_len - blocks0[0].in), w_out = (double)(blocks0[b1 - 1].out + blocks0[b1 - 1].out_len - blocks0[0].out);
+                const double w_in = (double)(off0[b1 - 1] + blocks0[b1 - 1].in_len - off0[0]), w_out = (double)(blocks0[b1 - 1].out + blocks0[b1 - 1].out_len - blocks0[0].out);
                 {
                     splprof::Scope p("spl_inflate_decode_kernel", pipe.a, w_in + w_out);
                     HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks0.as<spl_zblock>(), (uint32_t)b1, d_status0.as<uint32_t>(), d_zwork[0].p, pipe.a));
                 }
                 HIP_TRY(hipEventRecord(pipe.k1[0], pipe.a));
+                HIP_TRY(hipEventRecord(pipe.dec[0], pipe.a));
                 HIP_TRY(hipStreamWaitEvent(pipe.cp[0], pipe.k1[0], 0));
                 {
                     splprof::Scope p("spl_inflate_copy_kernel", pipe.cp[0], w_out);
@@ -1468,10 +1551,12 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     if (n_blocks == 0 || n_blocks > 0xfffffff0ull) return to_host("no blocks");
     const bool last_share = hi == n_blocks_file, first_share = lo == 0;
     blocks.resize(n_blocks);
+    foff.resize(n_blocks);
     for (size_t i = 0; i < n_blocks; ++i) {
         spl_bam_block_info bi;
         spl_bam_block_get(bam, lo + i, &bi);
-        blocks[i].in = bi.data_off; blocks[i].out = bi.uoff; blocks[i].in_len = bi.data_len; blocks[i].out_len = bi.isize; blocks[i].crc = bi.crc; blocks[i].pad = 0;
+        foff[i] = bi.data_off;
+        blocks[i].in = ring_at(bi.data_off); blocks[i].out = bi.uoff; blocks[i].in_len = bi.data_len; blocks[i].out_len = bi.isize; blocks[i].crc = bi.crc; blocks[i].pad = 0;
     }
     const double t_blocks = host_now() - t_begin;
     const uint64_t stream_begin = blocks[0].out, stream_len = blocks[n_blocks - 1].out + blocks[n_blocks - 1].out_len; // (of the share; offsets are the file's)
@@ -1481,17 +1566,23 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     // more than they bring: a launch of the copying kernel takes as long as one lane needs for its block, 9-12 ms however few
     // blocks it has, so three short launches are 20 ms of that kernel's stream for less than one window's worth of blocks.)
     std::vector<size_t> win_at(1, 0);
-    while (win_at.back() < n_blocks) win_at.push_back(std::min(n_blocks, win_at.back() + win_blocks));
+    while (win_at.back() < n_blocks) win_at.push_back(window_end(foff, win_at.back(), n_blocks));
     const size_t n_win = win_at.size() - 1;
     if (early && early != win_at[1]) return to_host("the first window changed under the decoder"); // (cannot happen: the directory only grows)
+    HIP_TRY(pipe.make_windows(n_win));
+    for (size_t w = 0; w < n_win; ++w) // (a piece is read last by the window of the last block that begins in it; pieces without one: by the window before)
+        for (size_t pc = piece_of(foff[win_at[w]]), pe = piece_of(foff[win_at[w + 1] - 1]); pc <= pe && pc < n_pieces; ++pc) piece_last_win[pc] = (uint32_t)w;
+    launched_pub.store(early ? 1 : 0, std::memory_order_release);
+    windows_known.store(1, std::memory_order_release);
     uint64_t win_cap = 0;
     for (size_t k = 0; k < n_win; ++k) {
         const size_t b0 = win_at[k], b1 = win_at[k + 1];
         win_cap = std::max(win_cap, blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out);
     }
-    const size_t work_bytes = spl_dev_inflate_work_bytes((uint32_t)win_blocks);
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    free_b += devmem::held_bytes(c->device);
+    size_t most_blocks = 0;
+    for (size_t k = 0; k < n_win; ++k) most_blocks = std::max(most_blocks, win_at[k + 1] - win_at[k]);
+    const size_t work_bytes = spl_dev_inflate_work_bytes((uint32_t)most_blocks);
+    HIP_TRY(look_at_free());
     // Three windows in flight: a window's buffer is free again when its records are extracted, and with two the decoding kernel
     // of window k + 2 waited for that -- decode, copy, scan and extract of one window in a row, 34 ms for two windows of work
     // (measured on the 14 GB file: 20 ms a window with two buffers, 18.7 with three, no less with four).  The third is taken when
@@ -1501,7 +1592,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     int want_buf = devmem::held_bytes(c->device) >= 3 * per_buf ? 3 : 2;
     if (const char *e = getenv("SPL_INFLATE_BUFFERS")) want_buf = std::min(NBUF, std::max(1, atoi(e)));
     const int n_buf = (int)std::min<size_t>((size_t)want_buf, n_win);
-    if ((double)n_buf * ((double)win_cap + (double)HEAD + (double)work_bytes) + (double)(stream_len - stream_begin) * 0.2 + (double)((size_t)1 << 30) > (double)free_b)
+    if ((double)n_buf * ((double)win_cap + (double)HEAD + (double)work_bytes) + (double)(stream_len - stream_begin) * 0.2 + slack > (double)free_b)
         return to_host("not enough device memory for the inflated stream");
     for (int k = 0; k < n_buf; ++k) {
         if (k == 0 && early) continue; // (the first window has its buffers, large enough for any)
@@ -1579,8 +1670,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         size_t b0, b1;
         win_range(k, b0, b1);
         launched_it = false;
-        const size_t last_byte = (size_t)(blocks[b1 - 1].in + blocks[b1 - 1].in_len + 8) - byte_lo;
-        const size_t need = std::min(n_pieces, last_byte / piece + 1);
+        const size_t need = std::min(n_pieces, piece_of(foff[b1 - 1]) + 1); // (the piece its last block begins in holds all of it)
         if (!wait) // (a window ahead of the one the host is at: only if its bytes are on their way already)
             for (size_t q = pieces_waited; q < need; ++q) if (!sent[q].load(std::memory_order_acquire)) return SPL_OK;
         for (; pieces_waited < need; ++pieces_waited) {
@@ -1589,12 +1679,14 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.piece[pieces_waited], 0));
         }
         if (k >= (size_t)n_buf) HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.freed[k % (size_t)n_buf], 0));
-        const double w_in = (double)(blocks[b1 - 1].in + blocks[b1 - 1].in_len - blocks[b0].in), w_out = (double)(blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out);
+        const double w_in = (double)(foff[b1 - 1] + blocks[b1 - 1].in_len - foff[b0]), w_out = (double)(blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out);
         {
             splprof::Scope p("spl_inflate_decode_kernel", pipe.a, w_in + w_out);
             HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_buf].p, pipe.a));
         }
         HIP_TRY(hipEventRecord(pipe.k1[k % (size_t)n_buf], pipe.a));
+        HIP_TRY(hipEventRecord(pipe.dec[k], pipe.a));
+        launched_pub.store(k + 1, std::memory_order_release); // (the readers may give this window's pieces' slots to later pieces, behind that event)
         hipStream_t cs = pipe.cp[k % (size_t)n_copy];
         HIP_TRY(hipStreamWaitEvent(cs, pipe.k1[k % (size_t)n_buf], 0));
         {

@@ -49,7 +49,7 @@ EXPORTS = [
     "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_prof_enable", "spl_prof_report", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
-    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_cancel", "spl_bam_close",
+    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_cancel", "spl_bam_decline_reason", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
     "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append", "spl_tsv_append_many", "spl_fmt_fixed",
     "spl_bed_open", "spl_gff_open", "spl_text_close", "spl_text_rows", "spl_text_n_chrom", "spl_text_chrom_name", "spl_text_chrom",
@@ -79,6 +79,7 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.spl_last_error.restype = ctypes.c_char_p
         L.spl_bam_ref_name.restype = ctypes.c_char_p
+        L.spl_bam_decline_reason.restype = ctypes.c_char_p
         L.spl_bam_ref_length.restype = ctypes.c_int64
         L.spl_bam_n_records.restype = ctypes.c_int64
         for name in ("spl_destroy", "spl_sites_free", "spl_reads_free", "spl_bam_close", "spl_text_close", "spl_combine_close"):
@@ -587,6 +588,10 @@ class BamFile(object):
             t.start()
         self._device_thread = self._device_threads[0]
         return plan
+
+    def decline_reason(self):
+        """Why the device decoder left the file to the host threads ('' if it did not)."""
+        return lib().spl_bam_decline_reason(self._h).decode("utf-8", "replace")
 
     def join_decoders(self):
         """Waits for the device decoders started by ``decode_on_device_async`` / ``decode_on_devices_async``; -> True when the

@@ -434,6 +434,9 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
         except BaseException:
             writer.abandon()
             raise
+        if isinstance(source, native.BamFile) and gpuDecode is not False and source.decline_reason():
+            # (said once, where the user reads it: the host's threads are several times slower than the device on files like this)
+            log("  (the alignment file was decoded on host threads, not on the GPU: %s)" % source.decline_reason())
         t3 = time.perf_counter()
         log("\nOutputting .tsv file")
         writer.close(list(results))

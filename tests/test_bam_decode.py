@@ -48,7 +48,7 @@ def _random_sets(seed, n_per_ref, n_ref):
 
 @pytest.mark.parametrize("env", [dict(), dict(SPL_BAM_BATCH_BLOCKS="1"), dict(SPL_BAM_BATCH_BLOCKS="3"), dict(SPL_BAM_FORCE_RESYNC="1"),
                                  dict(SPL_BAM_BATCH_BLOCKS="2", SPL_BAM_FORCE_RESYNC="1")])
-@pytest.mark.parametrize("seq_mode", [0, 1])
+@pytest.mark.parametrize("seq_mode", [0, 1, 2])
 def test_many_batches(built, tmp_path, monkeypatch, env, seq_mode):
     names, sets = _random_sets(11 + seq_mode, 60_000, 3)
     path = str(tmp_path / "m.bam")

@@ -34,7 +34,7 @@ def _both(path, ctx, names, truth=None):
     return took
 
 
-@pytest.mark.parametrize("seq_mode,level", [(0, 1), (1, 1), (1, 6), (1, 0)])
+@pytest.mark.parametrize("seq_mode,level", [(0, 1), (1, 1), (1, 6), (1, 0), (2, 6), (2, 1), (2, 9)])
 def test_device_decode_matches_host(ctx, tmp_path, seq_mode, level):
     names, sets = _random_sets(21 + seq_mode + level, 50_000, 4)
     path = str(tmp_path / "d.bam")
@@ -210,7 +210,7 @@ def test_inflate_windows_of_a_few_blocks(ctx, tmp_path, monkeypatch, window):
     again by the next, the extracted arrays grow as they go -- must give what the host decoder gives; records larger than a
     window are the host decoder's."""
     monkeypatch.setenv("SPL_INFLATE_WINDOW_BLOCKS", window)
-    for seq_mode, level, seed in ((1, 1, 31), (1, 6, 32), (0, 1, 33), (1, 0, 34)):
+    for seq_mode, level, seed in ((1, 1, 31), (1, 6, 32), (0, 1, 33), (1, 0, 34), (2, 6, 35)):
         names, sets = _random_sets(seed, 30_000, 3)
         path = str(tmp_path / ("w%d.bam" % seed))
         native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=level, threads=3, seq_mode=seq_mode)
@@ -298,3 +298,59 @@ def test_a_stray_record_at_a_shares_edge_is_not_lost(tmp_path, stray_of, after):
     assert n == sum(sets[c].n for c in names) + 1, "a record was extracted by nobody (device: %s)" % on_device
     assert got[stray_of].n == sets[stray_of].n + 1
     bam.close()
+
+
+@pytest.mark.parametrize("ring,window", [("4", None), ("5", "24"), ("9", "40"), ("6", "7")])
+def test_the_file_image_is_a_ring_on_the_device(tmp_path, monkeypatch, ring, window):
+    """Only a few pieces of the file are on the device at a time (spl_capi.cpp decode_share: a piece's slot goes to the piece R
+    further on when the last window that reads it is decoded).  Staging buffers of 2 MB and a ring of 4-9 of them for a file of
+    a dozen pieces: every slot is reused several times, windows end where their bytes would not fit the ring."""
+    monkeypatch.setenv("SPL_STAGE_MB", "2")
+    monkeypatch.setenv("SPL_IMAGE_RING_PIECES", ring)
+    if window:
+        monkeypatch.setenv("SPL_INFLATE_WINDOW_BLOCKS", window)
+    names, sets = _random_sets(53, 90_000, 4)
+    path = str(tmp_path / "ring.bam")
+    native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=3, seq_mode=1)
+    import os
+    assert os.path.getsize(path) > 10 * (2 << 20)
+    with native.Context(0) as ctx:      # (a context of its own: its staging buffers have the size asked for here)
+        assert _both(path, ctx, names, sets) is True
+    bam = native.BamFile(path, defer=True)
+    plan = bam.decode_on_devices_async([0, 0, 0])
+    assert bam.join_decoders() is True and len(plan) == 3
+    for c in names:
+        _same(bam.reads(c), sets[c])
+    bam.close()
+
+
+def test_a_file_larger_than_the_free_device_memory(tmp_path, monkeypatch):
+    """device memory for the decode is O(window) + what is extracted, not O(file).  A device that "has" 128 MB
+    free decodes a file of 140 MB and more on the device (a ring of 2 MB slots, windows of 48 blocks, a quarter of the file's size
+    for the reads it extracts); with 24 MB it declines, says why, and the host threads give the same reads."""
+    import os
+    monkeypatch.setenv("SPL_STAGE_MB", "2")
+    monkeypatch.setenv("SPL_INFLATE_WINDOW_BLOCKS", "48")
+    from spliser_amd import synth
+    wl = synth.Workload("arabidopsis", scale=0.1, seed=14, workers=2)        # 2 M reads of 150 bp: 73 bytes a read in the file, 19 extracted
+    names = wl.genome.chrom_names
+    sets = dict(zip(names, wl.reads))
+    path = str(tmp_path / "big.bam")
+    native.write_bam(path, names, wl.genome.chrom_lengths, wl.reads, level=1, threads=3, seq_mode=1)
+    size_mb = os.path.getsize(path) / 2 ** 20
+    assert size_mb > 135
+    native.lib().spl_trim(-1)        # (nothing held from earlier calls: the limit is all there is)
+    monkeypatch.setenv("SPL_DEV_FREE_LIMIT_MB", "128")
+    with native.Context(0) as ctx:
+        dev = native.BamFile(path, threads=4, defer=True)
+        assert dev.decode_on_device(ctx) is True and dev.decline_reason() == ""
+        for c in names:
+            _same(dev.reads(c), sets[c])
+        dev.close()
+        native.lib().spl_trim(-1)
+        monkeypatch.setenv("SPL_DEV_FREE_LIMIT_MB", "24")
+        dev = native.BamFile(path, threads=4, defer=True)
+        assert dev.decode_on_device(ctx) is False and "device memory" in dev.decline_reason()
+        for c in names:
+            _same(dev.reads(c), sets[c])
+        dev.close()
