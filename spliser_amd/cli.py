@@ -114,6 +114,8 @@ def main(argv=None):
         parser.error("--isStranded requires parameter --strandedType/-s as fr or rf")
     if command == "process":
         from .process import process
+        if __import__("os").environ.get("SPL_PROCESS_TIMING"):
+            sys.stderr.write("[cli] modules of `process` imported %.4f s after main() began\n" % (timeit.default_timer() - start))
         process(devices=devices, threads=threads, **kwargs)
     elif command == "combine":
         from .combine import combine

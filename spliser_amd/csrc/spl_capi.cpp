@@ -14,6 +14,8 @@
 #include <new>
 #include <string>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -1435,6 +1437,9 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     std::vector<uint32_t> piece_last_win(n_pieces, 0);
     std::atomic<int> windows_known(0), stop_upload(0);
     std::atomic<size_t> launched_pub(0);
+    std::mutex up_mu;               // (the readers sleep on this while they wait for a slot, the host loop while it waits for a piece:
+    std::condition_variable up_cv;  //  threads that spin instead eat the CPU time the process is granted, and the others with it)
+    auto up_wake = [&]() { { std::lock_guard<std::mutex> lock(up_mu); } up_cv.notify_all(); };
     const int fd = spl_bam_fd(bam);
     char *const d_img = d_image.as<char>();
     if (two_up) HIP_TRY(hipStreamSynchronize(c->copy)); // (what was put on the copy stream for the image so far is done before the other stream writes into it)
@@ -1444,9 +1449,13 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         for (size_t k = t; k < n_pieces; k += n_stage) {
             hipStream_t up = two_up && (t & 1u) ? pipe.up2 : c->copy;
             if (errs[t] == hipSuccess && k >= ring) { // the slot's last piece must have been read by everybody who reads it
-                while (!windows_known.load(std::memory_order_acquire) && !stop_upload.load(std::memory_order_acquire)) std::this_thread::yield();
-                const size_t w = windows_known.load(std::memory_order_acquire) ? piece_last_win[k - ring] : 0;
-                while (launched_pub.load(std::memory_order_acquire) <= w && !stop_upload.load(std::memory_order_acquire)) std::this_thread::yield();
+                size_t w = 0;
+                {
+                    std::unique_lock<std::mutex> lock(up_mu);
+                    up_cv.wait(lock, [&]() { return windows_known.load(std::memory_order_acquire) || stop_upload.load(std::memory_order_acquire); });
+                    w = windows_known.load(std::memory_order_acquire) ? piece_last_win[k - ring] : 0;
+                    up_cv.wait(lock, [&]() { return launched_pub.load(std::memory_order_acquire) > w || stop_upload.load(std::memory_order_acquire); });
+                }
                 if (stop_upload.load(std::memory_order_acquire)) errs[t] = hipErrorNotReady; // (the call is on its way out: nobody waits for this piece)
                 else errs[t] = hipStreamWaitEvent(up, pipe.dec[w], 0);
             }
@@ -1461,7 +1470,13 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             }
             if (errs[t] != hipSuccess) reader_failed.store(1, std::memory_order_release);
             sent[k].store(1, std::memory_order_release);
+            up_wake();
         }
+    };
+    auto wait_sent = [&](size_t q) { // piece q's copy is on its stream (or never will be: reader_failed)
+        if (sent[q].load(std::memory_order_acquire)) return;
+        std::unique_lock<std::mutex> lock(up_mu);
+        up_cv.wait(lock, [&]() { return sent[q].load(std::memory_order_acquire) != 0; });
     };
     // where a block's data lies in the ring (off: its offset in this share's stretch of the file), and the windows' ends
     auto ring_at = [&](uint64_t file_off) { const size_t o = (size_t)file_off - byte_lo, pc = o / piece; return (uint64_t)((pc % ring) * slot + (o - pc * piece)); };
@@ -1471,9 +1486,11 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         std::vector<std::thread> threads;
         std::atomic<int> *stop = nullptr;
         void join() { for (std::thread &t : threads) if (t.joinable()) t.join(); }
-        ~Crew() { if (stop) stop->store(1, std::memory_order_release); join(); } // (a reader waiting for a slot is told that nobody will free it)
+        std::function<void()> wake;
+        ~Crew() { if (stop) stop->store(1, std::memory_order_release); if (wake) wake(); join(); } // (a reader waiting for a slot is told that nobody will free it)
     } crew;
     crew.stop = &stop_upload;
+    crew.wake = up_wake;
     // ---- the whole file: its first window is on its streams before the directory is complete.  The directory of the file's first
     // gigabyte takes 3 ms, the rest of a 14 GB file 25: the first window's decoding and copying kernels (23 ms) run beside that.
     // They get a list of blocks and status words of their own (the file's are allocated when their number is known).
@@ -1517,7 +1534,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 HIP_TRY(hipMemsetAsync(d_status0.p, 0xff, 4 * b1, pipe.a));
                 const size_t need = std::min(n_pieces, piece_of(off0[b1 - 1]) + 1); // (the piece its last block begins in holds all of it)
                 for (; pieces_waited < need; ++pieces_waited) {
-                    while (!sent[pieces_waited].load(std::memory_order_acquire)) std::this_thread::yield();
+                    wait_sent(pieces_waited);
                     if (reader_failed.load(std::memory_order_acquire)) { for (hipError_t e : errs) HIP_TRY(e); }
                     HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.piece[pieces_waited], 0));
                 }
@@ -1574,6 +1591,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         for (size_t pc = piece_of(foff[win_at[w]]), pe = piece_of(foff[win_at[w + 1] - 1]); pc <= pe && pc < n_pieces; ++pc) piece_last_win[pc] = (uint32_t)w;
     launched_pub.store(early ? 1 : 0, std::memory_order_release);
     windows_known.store(1, std::memory_order_release);
+    up_wake();
     uint64_t win_cap = 0;
     for (size_t k = 0; k < n_win; ++k) {
         const size_t b0 = win_at[k], b1 = win_at[k + 1];
@@ -1674,7 +1692,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         if (!wait) // (a window ahead of the one the host is at: only if its bytes are on their way already)
             for (size_t q = pieces_waited; q < need; ++q) if (!sent[q].load(std::memory_order_acquire)) return SPL_OK;
         for (; pieces_waited < need; ++pieces_waited) {
-            while (!sent[pieces_waited].load(std::memory_order_acquire)) std::this_thread::yield();
+            wait_sent(pieces_waited);
             if (reader_failed.load(std::memory_order_acquire)) { for (hipError_t e : errs) HIP_TRY(e); }
             HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.piece[pieces_waited], 0));
         }
@@ -1687,6 +1705,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         HIP_TRY(hipEventRecord(pipe.k1[k % (size_t)n_buf], pipe.a));
         HIP_TRY(hipEventRecord(pipe.dec[k], pipe.a));
         launched_pub.store(k + 1, std::memory_order_release); // (the readers may give this window's pieces' slots to later pieces, behind that event)
+        up_wake();
         hipStream_t cs = pipe.cp[k % (size_t)n_copy];
         HIP_TRY(hipStreamWaitEvent(cs, pipe.k1[k % (size_t)n_buf], 0));
         {

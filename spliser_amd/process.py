@@ -462,6 +462,8 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
     timings["bam_decode"] = "device" if getattr(source, "on_device", False) else "host"
     timings.update(open_s=t_open - t0, site_table_s=t1 - t_open, step3_s=t3 - t1, write_tail_s=t4 - t3, write_s=writer.seconds,
                    close_s=time.perf_counter() - t4, total_s=time.perf_counter() - t0)
+    if os.environ.get("SPL_PROCESS_TIMING"):
+        sys.stderr.write("[process] %s\n" % ", ".join("%s %.4f" % (k, v) if isinstance(v, float) else "%s %s" % (k, v) for k, v in timings.items()))
     return timings
 
 
