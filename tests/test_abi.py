@@ -112,3 +112,13 @@ def test_importing_the_package_asks_for_eight_hardware_queues():
     assert subprocess.check_output([sys.executable, "-c", code], cwd=ROOT).decode().strip() == "8"
     code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '5'; import spliser_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
     assert subprocess.check_output([sys.executable, "-c", code], cwd=ROOT).decode().strip() == "5"
+
+
+def test_integration_md_quotes_the_stub():
+    """INTEGRATION.md shows spliser_amd/refstub.py itself, not a paraphrase of it (tests/test_refstub_reference.py runs it on the
+    reference's live objects in the build container)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "spliser_amd", "refstub.py")).read()
+    code = src[src.index("import ctypes"):]
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert "```python\n" + code + "```" in doc

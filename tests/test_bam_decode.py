@@ -248,3 +248,72 @@ def test_close_does_not_wait_for_the_rest_of_the_file(built, tmp_path):
     assert time.perf_counter() - t < max(0.05, 0.6 * t_whole)
     late = native.BamFile(path, defer=True)
     late.close()
+
+
+def _plain_sets(sizes, seed=5):
+    """Reference k with sizes[k] reads of 100M (vectorised: the share planner only cares where references begin in the file)."""
+    rng = np.random.default_rng(seed)
+    names = ["chr%d" % (k + 1) for k in range(len(sizes))]
+    sets = {}
+    for c, n in zip(names, sizes):
+        pos = np.sort(rng.integers(1, 50_000_000, n)).astype(np.int32)
+        sets[c] = samio.ReadSet(pos, rng.choice([0, 16], size=n).astype(np.uint16), np.arange(n + 1, dtype=np.uint32), np.full(n, (100 << 4), np.uint32))
+    return names, sets
+
+
+def _plan(bam, want):
+    import ctypes
+    n = ctypes.c_int(0)
+    assert native.lib().spl_bam_share_plan(bam._h, ctypes.c_int(want), ctypes.byref(n)) == 0
+    shares = []
+    for k in range(n.value):
+        lo, hi = ctypes.c_int(0), ctypes.c_int(0)
+        assert native.lib().spl_bam_share_range(bam._h, ctypes.c_int(k), ctypes.byref(lo), ctypes.byref(hi)) == 0
+        shares.append((lo.value, hi.value))
+    return shares
+
+
+HG38_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 58, 64, 46, 50, 156, 57]
+
+
+def test_share_plan_for_eight_devices_on_a_human_shaped_file(built, tmp_path):
+    """The target machine has eight GPUs: a file of 24 references sized like hg38's chromosomes is cut into EIGHT stretches, none
+    empty, every reference in exactly one, in file order, none much larger than the largest chromosome forces."""
+    sizes = [m * 120 for m in HG38_MB]
+    names, sets = _plain_sets(sizes)
+    path = str(tmp_path / "h.bam")
+    native.write_bam(path, names, [3 * 10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=3, seq_mode=1)
+    bam = native.BamFile(path, defer=True)
+    shares = _plan(bam, 8)
+    assert len(shares) == 8
+    assert [lo for lo, _ in shares] == sorted(lo for lo, _ in shares) and shares[0][0] == 0 and shares[-1][1] == len(names) + 1
+    assert all(lo < hi for lo, hi in shares) and all(a[1] == b[0] for a, b in zip(shares, shares[1:]))
+    reads = [sum(sizes[t] for t in range(lo, min(hi, len(names)))) for lo, hi in shares]
+    assert min(reads) > 0 and max(reads) <= 1.6 * sum(sizes) / 8, reads      # (chr1 + chr2 are 16 % of the genome: an eighth is 12.5 %)
+    bam.close()
+
+
+def test_share_plan_with_an_empty_and_a_dominant_reference(built, tmp_path):
+    """One reference holds 40 % of the file (no cut can fall inside it), one has no reads at all: fewer than eight shares may come
+    out, but every reference is in exactly one, every share holds reads, and the reference without reads rides with a neighbour."""
+    sizes = [3000] * 24
+    sizes[2] = 48000
+    sizes[5] = 0
+    names, sets = _plain_sets(sizes, seed=6)
+    path = str(tmp_path / "skew.bam")
+    native.write_bam(path, names, [3 * 10 ** 8] * len(names), [sets[c] for c in names], level=1, threads=3, seq_mode=1)
+    bam = native.BamFile(path, defer=True)
+    shares = _plan(bam, 8)
+    assert 4 <= len(shares) <= 8
+    covered = [t for lo, hi in shares for t in range(lo, hi)]
+    assert covered == list(range(len(names) + 1))
+    for lo, hi in shares:
+        assert sum(sizes[t] for t in range(lo, min(hi, len(names)))) > 0, shares
+    assert sum(1 for lo, hi in shares if lo <= 2 < hi) == 1
+    bam.close()
+    # the host decoder agrees with what was written (the file itself is sound)
+    whole = native.BamFile(path, threads=2)
+    for c in names:
+        got = whole.reads(c)
+        assert (got.n if got is not None else 0) == sets[c].n
+    whole.close()

@@ -54,6 +54,23 @@ def test_config3_human_scale_process(devices, tmp_path, oracle_lib):
     assert open(prefix + ".SpliSER.tsv").read() == _oracle_tsv(oracle_lib, prefix + ".bed", wl, None, False, prefix + ".gff")
 
 
+def test_config3_on_eight_contexts_decodes_in_eight_shares(tmp_path, oracle_lib, monkeypatch):
+    """The target machine has eight GPUs (here: eight contexts on one).  A human-shaped file of 24 chromosomes is cut into eight
+    stretches, none empty; every context inflates, extracts and counts its own; the file is the oracle's."""
+    wl = synth.Workload("human", scale=0.02, workers=4)       # 4 M reads
+    prefix = str(tmp_path / "h8")
+    _files(wl, prefix, seq_mode=1)
+    seen = {}
+    real = native.BamFile.decode_on_devices_async
+    monkeypatch.setattr(native.BamFile, "decode_on_devices_async", lambda self, devs: seen.setdefault("plan", real(self, devs)))
+    tm = proc.process(prefix + ".bam", prefix + ".bed", prefix, annotationFile=prefix + ".gff", log=lambda m: None, devices=(0,) * 8)
+    assert tm["bam_decode"] == "device"
+    plan = seen["plan"]
+    assert len(plan) == 8 and all(names for _, names in plan)
+    assert sorted(c for _, names in plan for c in names) == sorted(wl.genome.chrom_names)
+    assert open(prefix + ".SpliSER.tsv").read() == _oracle_tsv(oracle_lib, prefix + ".bed", wl, None, False, prefix + ".gff")
+
+
 @pytest.mark.parametrize("gpu_decode", [False, True])
 @pytest.mark.parametrize("stranded", [None, "fr"])
 def test_large_read_set_chunks(tmp_path, oracle_lib, monkeypatch, stranded, gpu_decode):
@@ -82,7 +99,7 @@ def test_config5_mouse_stranded_cryptic_process(devices, tmp_path, oracle_lib):
     assert open(prefix + ".SpliSER.tsv").read() == _oracle_tsv(oracle_lib, prefix + ".bed", wl, "fr", True)
 
 
-@pytest.mark.parametrize("devices", ["0", "0,0,0,0"])
+@pytest.mark.parametrize("devices", ["0", "0,0,0,0", "0,0,0,0,0,0,0,0"])
 def test_config4_six_sample_combine(devices, tmp_path, oracle_lib):
     """Six samples of one genome (seeds 11-16: every sample finds its own subset of the rare junctions), `process` each,
     `combine` all; the gap fill against the oracle's counts for the same queries."""
