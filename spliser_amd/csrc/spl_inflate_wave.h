@@ -54,8 +54,8 @@ constexpr uint32_t SYM_EOB = 256, SYM_MATCH = 257, SYM_BAD = 0xffffffffu;
 
 // One wave's shared memory: 10120 bytes (16 waves on a CU's 160 KB).
 struct Shared {
-    uint16_t lut_l[LUT_L];                // literal/length code.  Entry: symbol << 4 | bits; 0x8000 | offset << 4 | sub-table bits; 0 = no such code
-    uint16_t lut_d[LUT_D];                // distance code
+    uint16_t lut_l[LUT_L];                // literal/length code, entries that carry what a symbol MEANS (leaf_l below); 0 = no such code
+    uint16_t lut_d[LUT_D];                // distance code (leaf_d)
     uint32_t tile[TILE_WORDS + TILE_PAD]; // the compressed bytes being worked on (while tables are built: work space)
     uint32_t tok[TOKCAP / 4];             // the tile's stretch of the token stream (while a header is read: code lengths, the code-length code's table)
 };
@@ -73,8 +73,52 @@ WV_DEV uint32_t bitrev(uint32_t v, uint32_t n) { return wv::brev32(v) >> (32u - 
 // 32 bits of the block's data from bit `pos`, straight from memory (headers: every lane asks for the same bytes)
 WV_DEV uint32_t gbits(const uint8_t *in, uint32_t pos) { return (uint32_t)(wv::ld64(in + (pos >> 3)) >> (pos & 7u)); }
 
+// length symbol 257 + i -> (base, extra bits); distance symbol -> the same (RFC 1951, 3.2.5), by arithmetic
+WV_DEV void length_code(uint32_t i, uint32_t &base, uint32_t &extra)
+{
+    extra = i < 8u || i == 28u ? 0u : (i >> 2) - 1u;
+    base = i < 4u ? 3u + i : (i == 28u ? 258u : 3u + ((4u + (i & 3u)) << extra));
+}
+WV_DEV void distance_code(uint32_t i, uint32_t &base, uint32_t &extra)
+{
+    extra = i < 4u ? 0u : (i >> 1) - 1u;
+    base = i < 2u ? 1u + i : 1u + ((2u + (i & 1u)) << extra);
+}
+
+// What a table entry says, twelve bits above the four that hold the code's length (an entry of 0: no such code).  The decoder's
+// turn is a chain of dependent vector instructions that every lane of the wave runs through, whichever symbol its own lane
+// has: what a symbol MEANS is worked out once per table, not once per decoded symbol (18 of a turn's 70 instructions were the
+// arithmetic of length_code / distance_code).
+//   KIND_RAW   the symbol itself (the code-length code)
+//   KIND_LIT   literal or end of block: the symbol, 0..256.  Length symbol 257 + i: 0x800 | extra << 8 | base - 3 (base - 3 is
+//              0..255).  286 and 287 have no entry.
+//   KIND_DIST  distance symbol i: extra << 2 | m with base = 1 + (m << extra), m = i for i < 4, 2 + (i & 1) beyond.  30 and 31
+//              have no entry.
+// A root entry that stands for a sub-table: KIND_LIT has no bit to spare for a flag, so it is the entry whose length field
+// is 0 and which is not 0: (offset - root entries) << 7 | sub-table bits << 4 (1..6, 9 bits of offset: LUT_L - 512 < 512).  The
+// others: 0x8000 | offset << 4 | sub-table bits.
+constexpr int KIND_RAW = 0, KIND_LIT = 1, KIND_DIST = 2;
+template <int KIND>
+WV_DEV uint32_t leaf(uint32_t s)
+{
+    if (KIND == KIND_LIT) {
+        if (s <= 256u) return s;
+        if (s > 285u) return 0xfffu; // (marks "no entry": see build_lut)
+        uint32_t b, x;
+        length_code(s - 257u, b, x);
+        return 0x800u | x << 8 | (b - 3u);
+    }
+    if (KIND == KIND_DIST) {
+        if (s >= 30u) return 0xfffu;
+        const uint32_t x = s < 4u ? 0u : (s >> 1) - 1u, m = s < 4u ? s : 2u + (s & 1u);
+        return x << 2 | m;
+    }
+    return s;
+}
+
 // Canonical code -> look-up table, by the whole wave.  lens[0..n): code lengths (bytes in shared memory); work: 1 << root words.
 // false: the lengths over-subscribe the code space, or need more sub-tables than any valid code does.
+template <int KIND>
 WV_DEV bool build_lut(const uint8_t *lens, uint32_t n, uint32_t root, uint16_t *lut, uint32_t cap, uint32_t *work)
 {
     const uint32_t l = wv::lane();
@@ -140,7 +184,7 @@ WV_DEV bool build_lut(const uint8_t *lens, uint32_t n, uint32_t root, uint16_t *
         const uint32_t b = P < n_root ? work[P] : 0u;
         if (b) {
             work[P] = off << 4 | b;
-            lut[bitrev(P, root)] = (uint16_t)(0x8000u | off << 4 | b);
+            lut[bitrev(P, root)] = KIND == KIND_LIT ? (uint16_t)((off - n_root) << 7 | b << 4) : (uint16_t)(0x8000u | off << 4 | b);
             for (uint32_t k = 0; k < (1u << b); ++k) lut[off + k] = 0;
             off += 1u << b;
         }
@@ -150,11 +194,14 @@ WV_DEV bool build_lut(const uint8_t *lens, uint32_t n, uint32_t root, uint16_t *
     for (int c = 0; c < 5; ++c) {
         const uint32_t len = L[c], s = (uint32_t)c * 64u + l;
         if (!len) continue;
+        const uint32_t what = leaf<KIND>(s);
         if (len <= root) {
-            for (uint32_t k = bitrev(cd[c], len); k < n_root; k += 1u << len) lut[k] = (uint16_t)(s << 4 | len);
+            const uint16_t e = what == 0xfffu ? (uint16_t)0 : (uint16_t)(what << 4 | len); // (a code for a symbol that does not exist decodes to "no such code")
+            for (uint32_t k = bitrev(cd[c], len); k < n_root; k += 1u << len) lut[k] = e;
         } else {
             const uint32_t e = work[cd[c] >> (len - root)], sub = e >> 4, b = e & 15u, rest = len - root;
-            for (uint32_t k = bitrev(cd[c] & ((1u << rest) - 1u), rest); k < (1u << b); k += 1u << rest) lut[sub + k] = (uint16_t)(s << 4 | rest);
+            const uint16_t e2 = what == 0xfffu ? (uint16_t)0 : (uint16_t)(what << 4 | rest);
+            for (uint32_t k = bitrev(cd[c] & ((1u << rest) - 1u), rest); k < (1u << b); k += 1u << rest) lut[sub + k] = e2;
         }
     }
     wv::sync();
@@ -162,6 +209,10 @@ WV_DEV bool build_lut(const uint8_t *lens, uint32_t n, uint32_t root, uint16_t *
 }
 
 // 32 bits of the tile from bit `pos` of the block's data (the tile begins at bit `base`)
+// (Measured and not kept, round 4: the lane's next 64 bits held in registers and topped up from a word asked for a turn ahead,
+// so that the tile's words are off the turn's chain of dependent LDS trips -- 20 vector instructions more per turn for the 64-bit
+// shifts and the conditional top-up, and not a microsecond less: the kernel is bound by instruction issue, not by that chain.
+// profiles/r04l_k1_reader_in_registers_q*.txt)
 WV_DEV uint32_t tbits(const uint32_t *tile, uint32_t base, uint32_t pos)
 {
     const uint32_t rel = pos - base, w = rel >> 5;
@@ -169,63 +220,47 @@ WV_DEV uint32_t tbits(const uint32_t *tile, uint32_t base, uint32_t pos)
     return (uint32_t)(two >> (rel & 31u));
 }
 
-// the code at the head of `w`: symbol, and the bits it takes in `used`; SYM_BAD when there is no such code
-WV_DEV uint32_t lut_symbol(const uint16_t *lut, uint32_t root, uint32_t w, uint32_t &used)
-{
-    uint32_t e = lut[w & ((1u << root) - 1u)];
-    used = 0;
-    if (e & 0x8000u) {
-        used = root;
-        e = lut[((e >> 4) & 0x7ffu) + ((w >> root) & ((1u << (e & 15u)) - 1u))];
-    }
-    if ((e & 15u) == 0u) return SYM_BAD;
-    used += e & 15u;
-    return e >> 4;
-}
-
-// length symbol 257 + i -> (base, extra bits); distance symbol -> the same (RFC 1951, 3.2.5), by arithmetic
-WV_DEV void length_code(uint32_t i, uint32_t &base, uint32_t &extra)
-{
-    extra = i < 8u || i == 28u ? 0u : (i >> 2) - 1u;
-    base = i < 4u ? 3u + i : (i == 28u ? 258u : 3u + ((4u + (i & 3u)) << extra));
-}
-WV_DEV void distance_code(uint32_t i, uint32_t &base, uint32_t &extra)
-{
-    extra = i < 4u ? 0u : (i >> 1) - 1u;
-    base = i < 2u ? 1u + i : 1u + ((2u + (i & 1u)) << extra);
-}
-
 // One symbol at bit `pos` of the tile: a literal (its value), SYM_EOB, SYM_MATCH (len, dist set) or SYM_BAD.  `pos` moves past it.
-// Behind a literal that ends before `stop` a SECOND literal is taken from the bits already at hand (17 at least: enough for any
-// code) if a literal is what follows: lit2 is its value, or NO_LIT2.  A wave's turn costs what its slowest path costs, and the
-// lane with the most turns in a tile is the one whose subsequence is all short literal codes: two to a turn, it has half of them.
+// Behind a literal that ends before `stop` a SECOND literal is taken from the bits already at hand (17 at least) if a literal
+// with a code of the root table is what follows: lit2 is its value, or NO_LIT2.  A wave's turn costs what its slowest path costs,
+// and the lane with the most turns in a tile is the one whose subsequence is all short literal codes: two to a turn, it has half of them.
 constexpr uint32_t NO_LIT2 = 0xffffffffu;
 WV_DEV uint32_t decode(const Shared &sh, uint32_t base, uint32_t &pos, uint32_t &len, uint32_t &dist, uint32_t stop, uint32_t &lit2)
 {
-    uint32_t w = tbits(sh.tile, base, pos), used;
-    const uint32_t sym = lut_symbol(sh.lut_l, ROOT_L, w, used);
+    uint32_t w = tbits(sh.tile, base, pos), used = 0;
+    uint32_t e = sh.lut_l[w & ((1u << ROOT_L) - 1u)];
     lit2 = NO_LIT2;
-    if (sym == SYM_BAD) return SYM_BAD;
-    if (sym <= 256u) {
+    if ((e & 15u) == 0u) { // a sub-table, or no such code
+        if (e == 0u) return SYM_BAD;
+        used = ROOT_L;
+        e = sh.lut_l[(1u << ROOT_L) + (e >> 7) + ((w >> ROOT_L) & ((1u << ((e >> 4) & 7u)) - 1u))];
+        if (e == 0u) return SYM_BAD;
+    }
+    used += e & 15u;
+    if (!(e & 0x8000u)) { // a literal or the end of the block
+        const uint32_t sym = e >> 4;
         pos += used;
-        if (sym < 256u && pos < stop) {
-            uint32_t used2;
-            const uint32_t s2 = lut_symbol(sh.lut_l, ROOT_L, w >> used, used2);
-            if (s2 < 256u) { lit2 = s2; pos += used2; }
+        if (sym < 256u && pos < stop) { // a second literal, if its code is one of the root table's (9 bits at most of the 17 and more at hand)
+            const uint32_t e2 = sh.lut_l[(w >> used) & ((1u << ROOT_L) - 1u)];
+            if ((e2 & 15u) != 0u && e2 < (256u << 4)) { lit2 = e2 >> 4; pos += e2 & 15u; }
         }
         return sym;
     }
-    if (sym > 285u) return SYM_BAD;
-    uint32_t b, x;
-    length_code(sym - 257u, b, x);
-    len = b + ((w >> used) & ((1u << x) - 1u)); // (a code and its extra bits: 20 at most)
-    pos += used + x;
+    const uint32_t xl = (e >> 12) & 7u;
+    len = 3u + ((e >> 4) & 255u) + ((w >> used) & ((1u << xl) - 1u)); // (a code and its extra bits: 20 at most)
+    pos += used + xl;
     w = tbits(sh.tile, base, pos);
-    const uint32_t ds = lut_symbol(sh.lut_d, ROOT_D, w, used);
-    if (ds == SYM_BAD || ds >= 30u) return SYM_BAD;
-    distance_code(ds, b, x);
-    dist = b + ((w >> used) & ((1u << x) - 1u)); // (28 at most)
-    pos += used + x;
+    e = sh.lut_d[w & ((1u << ROOT_D) - 1u)];
+    used = 0;
+    if (e & 0x8000u) {
+        used = ROOT_D;
+        e = sh.lut_d[((e >> 4) & 0x3ffu) + ((w >> ROOT_D) & ((1u << (e & 15u)) - 1u))];
+    }
+    if ((e & 15u) == 0u) return SYM_BAD;
+    used += e & 15u;
+    const uint32_t xd = (e >> 6) & 15u;
+    dist = 1u + (((e >> 4) & 3u) << xd) + ((w >> used) & ((1u << xd) - 1u)); // (28 at most)
+    pos += used + xd;
     return SYM_MATCH;
 }
 
@@ -234,26 +269,27 @@ WV_DEV uint32_t decode(const Shared &sh, uint32_t base, uint32_t &pos, uint32_t 
 struct Count { uint32_t end, n_out, n_tok, flag; };
 WV_DEV Count count_from(const Shared &sh, uint32_t base, uint32_t start, uint32_t sub_end)
 {
+    // tokens = literals + a length byte for every 128 (or fewer) of a run + three bytes a match: the runs' length bytes are
+    // counted where a run ENDS (a turn that takes literals then only adds to two sums)
     Count c{start, 0, 0, FL_OK};
-    uint32_t run = 0; // literals in the run that is open (0: none)
+    uint32_t run = 0, n_lit = 0; // literals in the run that is open; literals so far
     while (c.end < sub_end) {
         uint32_t len = 0, dist = 0, lit2;
         const uint32_t s = decode(sh, base, c.end, len, dist, sub_end, lit2);
         if (s < 256u) {
-            if (run == 0u || run == 128u) { c.n_tok++; run = 0; }
-            c.n_tok++; run++;
-            c.n_out++;
-            if (lit2 != NO_LIT2) {
-                if (run == 128u) { c.n_tok++; run = 0; }
-                c.n_tok++; run++;
-                c.n_out++;
-            }
+            const uint32_t k = lit2 != NO_LIT2 ? 2u : 1u;
+            run += k;
+            n_lit += k;
             continue;
         }
-        if (s == SYM_MATCH) { c.n_out += len; c.n_tok += 3u; run = 0; continue; }
+        c.n_tok += (run + 127u) >> 7;
+        run = 0;
+        if (s == SYM_MATCH) { c.n_out += len; c.n_tok += 3u; continue; }
         c.flag = s == SYM_EOB ? FL_EOB : FL_ERR;
         break;
     }
+    c.n_tok += ((run + 127u) >> 7) + n_lit;
+    c.n_out += n_lit;
     return c;
 }
 
@@ -333,7 +369,7 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             pos += 3u * n_code;
             wv::sync();
             uint16_t *const lut_c = (uint16_t *)sh.tok + 176;
-            if (!build_lut(lens, 19u, ROOT_C, lut_c, 1u << ROOT_C, work)) return SPL_Z_BAD_LENGTHS;
+            if (!build_lut<KIND_RAW>(lens, 19u, ROOT_C, lut_c, 1u << ROOT_C, work)) return SPL_Z_BAD_LENGTHS;
             // the lengths of the two codes, a run-length code of its own: one after the other (every lane does the same)
             const uint32_t n_all = n_lit + n_dist;
             uint32_t idx = 0, err = SPL_Z_OK;
@@ -365,8 +401,8 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             if (lens[32u + 256u] == 0u) return SPL_Z_BAD_LENGTHS; // no end-of-block code
         }
         const uint8_t *const code_lens = type == 1u ? lens : lens + 32u;
-        if (!build_lut(code_lens, n_lit, ROOT_L, sh.lut_l, LUT_L, work)) return SPL_Z_BAD_LENGTHS;
-        if (!build_lut(code_lens + n_lit, n_dist, ROOT_D, sh.lut_d, LUT_D, work)) return SPL_Z_BAD_LENGTHS;
+        if (!build_lut<KIND_LIT>(code_lens, n_lit, ROOT_L, sh.lut_l, LUT_L, work)) return SPL_Z_BAD_LENGTHS;
+        if (!build_lut<KIND_DIST>(code_lens + n_lit, n_dist, ROOT_D, sh.lut_d, LUT_D, work)) return SPL_Z_BAD_LENGTHS;
         // ---- the symbols, a tile at a time
         for (bool eob = false; !eob;) {
             if (pos >= end_bits) return SPL_Z_OVERRUN;

@@ -166,3 +166,21 @@ def test_stored_sections_cannot_overrun_a_blocks_token_room(emul):
     assert got[:len(fits[0])] == fits[0]
     at = len(fits[0]) + len(over[0])
     assert got[at:at + len(fits[0])] == fits[0]
+
+
+def test_literal_runs_longer_than_128_in_one_lane(emul):
+    """Huffman-only streams of bytes that are nearly all the same: the common byte's code is ONE bit, a lane's 256 bits hold two
+    hundred literals and more, so a run's length byte (127 = 128 literals at most) has to be counted and written more than once per
+    lane -- count_from tallies them where a run ends, the writing pass where one begins."""
+    rng = np.random.default_rng(11)
+    streams = []
+    for k, p in enumerate((0.01, 0.03, 0.10)):
+        data = np.where(rng.random(60000) < p, rng.integers(1, 256, 60000), 0).astype(np.uint8).tobytes()
+        comp = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_HUFFMAN_ONLY)
+        streams.append(("skewed%d" % k, data, comp.compress(data) + comp.flush()))
+    status, got, _, _ = _run(emul, streams)
+    at = 0
+    for k, (name, data, comp) in enumerate(streams):
+        assert status[k] == 0, (name, int(status[k]))
+        assert got[at:at + len(data)] == data, name
+        at += len(data)

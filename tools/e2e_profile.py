@@ -43,7 +43,7 @@ if not (os.path.exists(prefix + ".bam") and os.path.exists(prefix + ".n")):
     t = time.perf_counter()
     synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions)
     synth.write_gff(prefix + ".gff", wl.genome)
-    native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=0, seq_mode=args.seq_mode)
+    native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=6 if args.seq_mode == 2 else 1, threads=0, seq_mode=args.seq_mode)
     n_reads = sum(r.n for r in wl.reads)
     open(prefix + ".n", "w").write(str(n_reads))
     print("files written in %.1f s: %s.bam %.1f MB" % (time.perf_counter() - t, prefix, os.path.getsize(prefix + ".bam") / 1e6), flush=True)
