@@ -1378,7 +1378,13 @@ extern "C" int spl_bam_share_plan(spl_bam *bam, int n_shares, int *n_out)
                 const double d = fabs((double)(bb < n_blocks ? bam->dir.at(bb).coff : bam->fsize) - (double)target);
                 if (best_tid < 0 || d < best_d) { best_tid = c; best_block = bb; best_d = d; }
             }
-            if (ok && best_tid >= 0 && best_block < n_blocks) { cut_tid.push_back(best_tid); cut_block.push_back(best_block); }
+            if (ok && best_tid < 0 && cut_tid.back() + 1 < bam->n_refs) {
+                // both references near the target begin at or before the last cut (one reference larger than a share): the next
+                // one then, so that as many shares come out as were asked for while there are references to begin them with
+                best_tid = cut_tid.back() + 1;
+                best_block = first_block_with(best_tid);
+            }
+            if (ok && best_tid >= 0 && best_block < n_blocks && best_block > cut_block.back()) { cut_tid.push_back(best_tid); cut_block.push_back(best_block); }
         }
         if (ld) deflate_lib().free_(ld);
         if (ok && cut_tid.size() > 1) {

@@ -1912,19 +1912,42 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
             cost[k++] = cd.cost;
         }
     }
-    // chunk order of the range kernel: its workgroup b works on slot (b & 7) * per + (b >> 3) (one contiguous eighth of the
-    // reads per XCD, see my_chunk); inside every eighth the chunks go longest first (stable counting sort on the cost)
+    // chunk order of the range kernel: its workgroup b works on slot (b & 7) * per + (b >> 3) (see my_chunk), i.e. XCD x -- the
+    // hardware deals workgroups round-robin over the eight -- walks slots [x * per, (x + 1) * per).  WHICH chunks an XCD gets
+    // decides when it is done, and the launch ends with the slowest of them: a contiguous eighth of the reads each (rounds 1-3)
+    // left one XCD with a third more work than the others on the human-scale sample -- the chunks over well-covered alternative
+    // exons, whose reads take the list pass, lie together -- and the launch's last fifth was that XCD alone (322 us against
+    // 240-255 for the other seven, profiles/r04n_range_xcd_balance.txt).  So the chunks are dealt to the XCDs in small blocks of
+    // consecutive chunks, round-robin: every stretch of the genome is spread over all eight (neighbouring chunks, which share
+    // lines of the position index, still go to one L2 together), whatever makes it expensive -- the cost estimate below knows the
+    // reads' classes, not their rivals.  Inside an XCD's share the chunks go longest first (stable counting sort on the cost).
     {
         const size_t grid = (n + 7) / 8 * 8, per = grid / 8;
+        size_t block = 8; // consecutive chunks that stay together
+        if (const char *e = getenv("SPL_XCD_BLOCK")) block = (size_t)std::max(1, atoi(e)); // (0 or less would be 1; a block as large as the read set = the contiguous eighths)
+        std::vector<uint32_t> dealt(n);
+        {
+            size_t quota[8], have[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t x = 0; x < 8; ++x) quota[x] = std::min(per, n - std::min(n, x * per)); // (only the last slots of the grid may be empty: slot >= n)
+            std::vector<std::vector<uint32_t>> mine(8);
+            for (size_t j = 0; j < n; ++j) {
+                size_t x = block >= n ? std::min<size_t>(j / std::max<size_t>(per, 1), 7) : (j / block) & 7u;
+                for (int tries = 0; tries < 8 && have[x] >= quota[x]; ++tries) x = (x + 1) & 7u;
+                mine[x].push_back((uint32_t)j);
+                have[x]++;
+            }
+            size_t at = 0;
+            for (size_t x = 0; x < 8; ++x) { std::copy(mine[x].begin(), mine[x].end(), dealt.begin() + (ptrdiff_t)at); at += mine[x].size(); }
+        }
         const uint32_t max_cost = (1u << d->chunk_shift) * SPL_W_WIDE;
         std::vector<uint32_t> bucket((size_t)max_cost + 2);
         for (size_t x = 0; x < 8; ++x) {
             const size_t lo = std::min(x * per, n), hi = std::min(lo + per, n);
             if (lo >= hi) continue;
             std::fill(bucket.begin(), bucket.end(), 0u);
-            for (size_t j = lo; j < hi; ++j) bucket[max_cost - std::min(cost[j], max_cost) + 1]++;
+            for (size_t j = lo; j < hi; ++j) bucket[max_cost - std::min(cost[dealt[j]], max_cost) + 1]++;
             for (size_t b = 1; b < bucket.size(); ++b) bucket[b] += bucket[b - 1];
-            for (size_t j = lo; j < hi; ++j) order[lo + bucket[max_cost - std::min(cost[j], max_cost)]++] = (uint32_t)j;
+            for (size_t j = lo; j < hi; ++j) order[lo + bucket[max_cost - std::min(cost[dealt[j]], max_cost)]++] = dealt[j];
         }
     }
     // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks

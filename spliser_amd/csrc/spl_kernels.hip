@@ -569,6 +569,11 @@ __device__ __forceinline__ bool rivals_inline_from(const spl_hot_params &p, spl_
     return true;
 }
 
+// (Measured and not kept, round 4: the wave taking its marked reads a GROUP at a time -- the lanes that hold the same junction
+//  and read strand as the first lane still open, the group's table entry and rivals in scalar registers, a ballot for who covers a
+//  rival with an aligned block, ONE lane adding the group's count -- instead of sixty-four atomics on one LDS word.  Right, and
+//  2 % slower on the human-scale sample, 6 % on A. thaliana: the serialised atomics were never what the pass waited for.
+//  profiles/r04r_range_groups_ab.txt)
 // The same for a twice-spliced read (junctions jl/jr[0..1], aligned blocks blk[0..2]): the two-junction case of
 // rivals_table_path (see there for the rules: a rival is handled under the first junction that lists it, flanking needs
 // "inside that or a later intron", alpha reads and beta1-type reads take double counts on the rival's edges to any junction end
@@ -709,13 +714,18 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     __shared__ uint16_t s_q[NWAVE * SEG];
     __shared__ uint32_t s_qcnt[NWAVE], s_qbase;
 #ifdef SPL_PHASE_WAVES
-    __shared__ uint64_t s_wave_t[2 * NWAVE];
+    __shared__ uint64_t s_wave_t[3 * NWAVE];
     __shared__ uint32_t s_wave_n[NWAVE];
 #endif
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, in an SGPR
     const uint32_t seg0 = wave * SEG;
     const uint32_t lane = (uint32_t)threadIdx.x & 63u;
     uint32_t n_front = 0, n_back = 0, back_done = 0; // (back_done: entries of the back list the list pass is through with)
+    // The once-spliced reads with rivals are not listed: a lane remembers WHICH of its reads they were, two bits per iteration
+    // of the run (a wave has eight iterations of it at most), and the run is streamed a second time for them after the loops
+    // -- coalesced, asked for an iteration ahead, out of the L2 it has just come through -- instead of being gathered read by
+    // read from slots kept in LDS: one memory trip per batch of 128 (the table slots) where the list pass had three in a row.
+    uint32_t fm_mnm = 0, it_mnm = 0;
     auto rank_in = [](unsigned long long m) { // how many lanes below mine are in m (mbcnt: no per-lane mask to keep around)
         return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     };
@@ -737,8 +747,11 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     };
 
     const int tid = threadIdx.x;
-    // workgroup -> slot of its XCD slice (my_chunk) -> chunk: every slice is walked longest chunk first (chunk_order, built
-    // at upload from the packer's cost estimate), so the workgroups that finish a launch are short ones
+    // workgroup -> slot of its XCD's share (my_chunk) -> chunk: every share is walked longest chunk first (chunk_order, built
+    // at upload from the packer's cost estimate), so the workgroups that finish a launch are short ones.
+    // (Measured and not kept, round 4: workgroups that STAY and take chunk after chunk of their XCD's share from a counter, as
+    // many as the chip holds -- to fill the eighth of the workgroup slots that stand empty between a workgroup's end and its
+    // successor's first records: 0.443 ms a launch against 0.39, with ten registers in scratch for the loop around the body.)
     const uint32_t chunk_slot = my_chunk();
     const bool live = chunk_slot < p.n_chunks;
     const uint32_t chunk = live ? p.chunk_order[chunk_slot] : 0u;
@@ -794,7 +807,21 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     __syncthreads();
     SPL_PHASE(1);
     // (the first two words of a bucket entry: all a boundary needs that is no junction end)
+#if defined(SPL_EXP_NOGATHER)
+    // (experiment, never in the product: bucket entries made up from the slot instead of loaded -- no site anywhere, so no range
+    //  and no list either: what the loops cost without their second memory trip and everything behind it)
+    auto fake = [](uint32_t s) { spl_dbk e; e.first = s & 0u; e.occ = 0u; e.rival = 0u; asm volatile("" : "+v"(e.first), "+v"(e.occ), "+v"(e.rival)); return e; };
+    auto dbk2 = [&](uint32_t s) { return fake(s); };
+    auto dbk3 = [&](uint32_t s) { return fake(s); };
+#elif defined(SPL_EXP_NOCOMMIT)
+    // (experiment: the entries are loaded and waited for, then made to say "no site here": the second trip without what follows it)
+    auto hide = [](spl_dbk e) { asm volatile("" :: "v"(e.first), "v"(e.occ), "v"(e.rival)); spl_dbk z; z.first = 0u; z.occ = 0u; z.rival = 0u; asm volatile("" : "+v"(z.first), "+v"(z.occ), "+v"(z.rival)); return z; };
+    auto dbk2 = [&](uint32_t s) { const uint32_t *q = (const uint32_t *)(p.dbucket + s); spl_dbk e; e.first = q[0]; e.occ = q[1]; e.rival = 0u; return hide(e); };
+    auto dbk3 = [&](uint32_t s) { return hide(p.dbucket[s]); };
+#else
     auto dbk2 = [&](uint32_t s) { const uint32_t *q = (const uint32_t *)(p.dbucket + s); spl_dbk e; e.first = q[0]; e.occ = q[1]; e.rival = 0u; return e; };
+    auto dbk3 = [&](uint32_t s) { return p.dbucket[s]; };
+#endif
 
     {
         // One loop per run, the wave's iterations g = wave, wave + 4, ... running through all of them; the records of the NEXT
@@ -808,12 +835,20 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         // ---- simple reads (one aligned op, mapped, in range: the packer checked all that): two boundaries, one range,
         //      nothing else can happen.  Four of them per lane.
         for (; g < g_start[1]; g += NWAVE) {
+#ifdef SPL_EXP_SKIP
+            if (SPL_EXP_SKIP & 1) { asm volatile("" :: "v"(cu0.x), "v"(cu1.x)); fetch_next(); continue; } // (experiment, never in the product: the loop with its records read and nothing done)
+#endif
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t n_run = cv.start[1];
             const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
             int32_t pos[KS], c1[KS];
             spl_dbk e0[KS], e1[KS];
+            // (Measured and not kept, round 4: a bit per bucket -- "it holds a site" -- asked first, for the wave's whole stretch of
+            //  reads with three scalar words and then per lane, so that only the one read in five whose stretch of buckets is not
+            //  empty fetches its two bucket entries (two reads in a hundred lie over a site at all).  Two thirds of the iterations
+            //  then issue no gather -- and the launch is not a microsecond shorter, 2-7 % longer on the other samples: the second
+            //  question is a second trip.  profiles/r04q_range_simple_filter.txt)
 #pragma unroll
             for (uint32_t j = 0; j < KS; ++j) {
                 pos[j] = (int32_t)w[2 * j] + cv.shift;
@@ -840,6 +875,9 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         // ---- once-spliced reads (aligned, N, aligned): the kinds are known, so are the arrays; three ranges
         //      and the junction-table look-up when an end of the junction has rivals.  Two of them per lane.
         for (; g < g_start[2]; g += NWAVE) {
+#ifdef SPL_EXP_SKIP
+            if (SPL_EXP_SKIP & 2) { asm volatile("" :: "v"(cu0.x), "v"(cu1.x)); fetch_next(); continue; }
+#endif
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t n_run = cv.start[2] - cv.start[1];
@@ -851,8 +889,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 pos[j] = (int32_t)w[4 * j] + cv.shift;
                 c0[j] = pos[j] + (int32_t)(w[4 * j + 1] >> 16); c1[j] = c0[j] + (int32_t)w[4 * j + 2]; c2[j] = c1[j] + (int32_t)w[4 * j + 3];
                 ea[j] = dbk2(dbk_slot(p, pos[j] - 1));                                               // ---- trip 2
-                eb[j] = p.dbucket[dbk_slot(p, c0[j] - 1)];   // (the junction ends: with the mask of flagged positions)
-                ec[j] = p.dbucket[dbk_slot(p, c1[j] - 1)];
+                eb[j] = dbk3(dbk_slot(p, c0[j] - 1));   // (the junction ends: with the mask of flagged positions)
+                ec[j] = dbk3(dbk_slot(p, c1[j] - 1));
                 ed[j] = dbk2(dbk_slot(p, c2[j] - 1));
             }
             fetch_next();
@@ -882,15 +920,19 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
                 const bool flagged = alive && ((rv1 | rv2) != 0u); // an end of the junction (c0 - 1, c1 - 1) is an end of a junction with rivals
                 if (__any(flagged)) {
                     const uint32_t slot = cv.start[1] + i0 + j;
-                    push_front(flagged && p.combine_mode, slot);
-                    push_back(flagged && !p.combine_mode, slot);
+                    const bool room = KM * it_mnm + j < 32u; // (always, with chunks of 4096 reads at most; a read that could not be marked is the literal kernel's)
+                    push_front(flagged && (p.combine_mode || !room), slot);
+                    if (room) fm_mnm |= (flagged && !p.combine_mode ? 1u : 0u) << (KM * it_mnm + j);
                 }
             }
+            ++it_mnm;
         }
-        const uint32_t n_back_mnm = n_back; // (the list so far: once-spliced reads; what follows is twice-spliced)
         // ---- twice-spliced reads (aligned, N, aligned, N, aligned; the record holds the five lengths): six boundaries,
         //      five ranges.  One read per lane.
         for (; g < g_start[3]; g += NWAVE) {
+#ifdef SPL_EXP_SKIP
+            if (SPL_EXP_SKIP & 4) { asm volatile("" :: "v"(cu0.x), "v"(cu1.x)); fetch_next(); continue; }
+#endif
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t slot = cv.start[2] + i0;     // of the read in its chunk, run order
@@ -904,8 +946,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             uint32_t sidx2 = 0;
             if (STRANDED) sidx2 = (spl_read_strand(flag, p.stranded) == (uint8_t)'-') ? 1u : 0u;
             const uint32_t a_me = (STRANDED ? 2u : 1u) + sidx2;
-            const spl_dbk f0 = dbk2(dbk_slot(p, pos - 1)), f1 = p.dbucket[dbk_slot(p, c0 - 1)], f2 = p.dbucket[dbk_slot(p, c1 - 1)]; // ---- trip 2
-            const spl_dbk f3 = p.dbucket[dbk_slot(p, c2 - 1)], f4 = p.dbucket[dbk_slot(p, c3 - 1)], f5 = dbk2(dbk_slot(p, c4 - 1));
+            const spl_dbk f0 = dbk2(dbk_slot(p, pos - 1)), f1 = dbk3(dbk_slot(p, c0 - 1)), f2 = dbk3(dbk_slot(p, c1 - 1)); // ---- trip 2
+            const spl_dbk f3 = dbk3(dbk_slot(p, c2 - 1)), f4 = dbk3(dbk_slot(p, c3 - 1)), f5 = dbk2(dbk_slot(p, c4 - 1));
             fetch_next();
             int32_t ua, ub; uint32_t nva, nvb, rvb;
             uint32_t fl1 = 0, fl2 = 0; // junction 1 / 2 has an end with rivals
@@ -940,6 +982,9 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             }
         }
         for (; g < g_total; g += NWAVE) {
+#ifdef SPL_EXP_SKIP
+            if (SPL_EXP_SKIP & 8) { asm volatile("" :: "v"(cu0.x), "v"(cu1.x)); fetch_next(); continue; }
+#endif
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t slot = cv.start[3] + i0;     // of the read in its chunk, run order
@@ -1029,12 +1074,15 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         // Once- and twice-spliced reads with rivals, the wave's own, lanes dense: the junction table says which sites of the read's
         // window are affected and how (rivals_inline); what it cannot decide joins the literal list.  The list is read
         // from its growing end, so the front list can only ever grow into entries that are done with.
-#ifdef SPL_EXP_NO_LIST
+#if defined(SPL_EXP_NO_LIST) || (defined(SPL_EXP_SKIP) && (SPL_EXP_SKIP & 16))
         n_back = 0; // (experiment, never in the product: what the list pass costs -- 28 % of the kernel on config 2)
 #endif
-        // (the list is read from its growing end: entries [0, n_m2) are the twice-spliced reads, [n_m2, n_back) the once-spliced)
-        const uint32_t n_m2 = n_back - (n_back ? n_back_mnm : 0u);
+        // (the list, read from its growing end, holds the twice-spliced reads)
+        const uint32_t n_m2 = n_back;
         for (uint32_t r0 = 0; r0 < n_m2; r0 += 64u) {
+#ifdef SPL_EXP_SKIP
+            if (SPL_EXP_SKIP & 32) break; // (experiment: the twice-spliced reads' list left unread)
+#endif
             const uint32_t j = r0 + lane;
             bool undecided = false;
             uint32_t slot = 0;
@@ -1056,48 +1104,61 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             back_done = r0 + 64u < n_m2 ? r0 + 64u : n_m2;
             if (__any(undecided)) push_front(undecided, slot);
         }
-        // Once-spliced reads, SPL_LIST_K list entries per lane and round: a round is a chain of dependent trips (record, table
-        // slot, sometimes more), and what a wave pays for is the number of rounds -- all the entries' records are asked for
-        // together, then all their slots.  Straight-line up to there: lanes without an entry read the run's first record and
-        // are masked.
-        constexpr int LK = SPL_LIST_K;
-        for (uint32_t r0 = n_m2; r0 < n_back; r0 += 64u * LK) {
-            bool live[LK], undecided[LK];
-            uint32_t slot[LK];
-            uint4 rec[LK];
+#ifdef SPL_PHASE_WAVES
+        if ((tid & 63) == 0) s_wave_t[2 * NWAVE + (tid >> 6)] = wall_clock64(); // (the twice-spliced reads' list is done)
+#endif
+        // Once-spliced reads with rivals: the run once more, for the lanes that marked a read of theirs (fm_mnm).  An iteration's
+        // records are asked for while the one before is worked on; what an iteration then waits for is its reads' table slots.
+#if defined(SPL_EXP_SKIP)
+        if (SPL_EXP_SKIP & 64) fm_mnm = 0;
+#endif
+        if (__any(fm_mnm != 0u)) {
+            const uint32_t n_run = cv.start[2] - cv.start[1];
+            auto fetch_mnm = [&](uint32_t g2) {
+                const uint32_t i0 = (((g2 - g_start[1]) << 6) + lane) * KM;
+                spl_gchar *r = cv.rec + (size_t)(cv.off[1] + (i0 < n_run ? i0 : 0u) * SPL_REC_MNM);
+                cu_i0 = i0;
+                cu0 = ld_g4(r);
+                cu1 = ld_g4(r + 16);
+            };
+            uint32_t g2 = g_start[1] + ((wave + NWAVE - (g_start[1] % NWAVE)) % NWAVE), it2 = 0; // (the wave's first iteration of this run: its iterations are g = wave, wave + 4, ... through all runs)
+            if (g2 < g_start[2]) fetch_mnm(g2);
+            for (; g2 < g_start[2] && KM * it2 < 32u; g2 += NWAVE, ++it2) {
+                const uint32_t i0 = cu_i0;
+                const W4 r0 = cu0, r1 = cu1;
+                fetch_mnm(g2 + NWAVE < g_start[2] ? g2 + NWAVE : g2);
+                const uint32_t bits = (fm_mnm >> (KM * it2)) & ((1u << KM) - 1u);
+                if (!__any(bits != 0u)) continue;
+                const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                bool live[KM], undecided[KM];
+                int32_t pos[KM], c0[KM], c1[KM], c2[KM];
+                uint32_t h[KM];
+                uint4 ent[KM], first[KM];
 #pragma unroll
-            for (int k = 0; k < LK; ++k) {
-                const uint32_t j = r0 + 64u * (uint32_t)k + lane;
-                live[k] = j < n_back;
-                undecided[k] = false;
-                slot[k] = live[k] ? ((uint32_t)s_q[seg0 + SEG - n_back + j] & 0x3fffu) : cv.start[1];
-                rec[k] = ld_g4(cv.rec + (size_t)(cv.off[1] + SPL_REC_MNM * (slot[k] - cv.start[1])));
-            }
-            int32_t pos[LK], c0[LK], c1[LK], c2[LK];
-            uint32_t h[LK];
-            uint4 ent[LK], first[LK];
-#pragma unroll
-            for (int k = 0; k < LK; ++k) {
-                pos[k] = (int32_t)rec[k].x + cv.shift;
-                c0[k] = pos[k] + (int32_t)(rec[k].y >> 16); c1[k] = c0[k] + (int32_t)rec[k].z; c2[k] = c1[k] + (int32_t)rec[k].w;
-                h[k] = junction_hash(c0[k] - 1, c1[k] - 1);
-                const uint4 *hslot = p.jhash + 2u * (h[k] & p.jhash_mask);
-                ent[k] = hslot[0];
-                first[k] = hslot[1];
-            }
-#pragma unroll
-            for (int k = 0; k < LK; ++k) {
-                if (live[k]) {
-                    uint32_t sidx = 0;
-                    if (STRANDED) sidx = (spl_read_strand(rec[k].y & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
-                    const int32_t blk_a[2] = {pos[k], c1[k]}, blk_b[2] = {c0[k] - 1, c2[k] - 1};
-                    undecided[k] = !rivals_inline_from<STRANDED, NARR>(p, lds, wbase, c0[k] - 1, c1[k] - 1, h[k], ent[k], first[k], blk_a, blk_b, sidx);
+                for (uint32_t k = 0; k < KM; ++k) {
+                    live[k] = ((bits >> k) & 1u) != 0u;
+                    undecided[k] = false;
+                    pos[k] = (int32_t)w[4 * k] + cv.shift;
+                    c0[k] = pos[k] + (int32_t)(w[4 * k + 1] >> 16); c1[k] = c0[k] + (int32_t)w[4 * k + 2]; c2[k] = c1[k] + (int32_t)w[4 * k + 3];
+                    h[k] = junction_hash(c0[k] - 1, c1[k] - 1);
+                    ent[k] = first[k] = make_uint4(0x80000000u, 0u, 0u, 0u);
+                    if (live[k]) { // (the marked reads' slots only: one read in ten is marked where alternative sites are few)
+                        const uint4 *hslot = p.jhash + 2u * (h[k] & p.jhash_mask);
+                        ent[k] = hslot[0];
+                        first[k] = hslot[1];
+                    }
                 }
-            }
-            back_done = r0 + 64u * LK < n_back ? r0 + 64u * LK : n_back;
 #pragma unroll
-            for (int k = 0; k < LK; ++k)
-                if (__any(undecided[k])) push_front(undecided[k], slot[k]);
+                for (uint32_t k = 0; k < KM; ++k) {
+                    uint32_t sidx = 0;
+                    if (STRANDED) sidx = (spl_read_strand(w[4 * k + 1] & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
+                    const int32_t blk_a[2] = {pos[k], c1[k]}, blk_b[2] = {c0[k] - 1, c2[k] - 1};
+                    if (live[k]) undecided[k] = !rivals_inline_from<STRANDED, NARR>(p, lds, wbase, c0[k] - 1, c1[k] - 1, h[k], ent[k], first[k], blk_a, blk_b, sidx);
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < KM; ++k)
+                    if (__any(undecided[k])) push_front(undecided[k], cv.start[1] + i0 + k);
+            }
         }
     }
     if ((tid & 63) == 0) s_qcnt[tid >> 6] = n_front;
@@ -1153,7 +1214,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             lo = s_wave_t[w] < lo ? s_wave_t[w] : lo;
             hi = s_wave_t[w] > hi ? s_wave_t[w] : hi;
             hi2 = s_wave_t[NWAVE + w] > hi2 ? s_wave_t[NWAVE + w] : hi2;
-            nmax = s_wave_n[w] > nmax ? s_wave_n[w] : nmax;
+            nmax = s_wave_t[2 * NWAVE + w] > nmax ? s_wave_t[2 * NWAVE + w] : nmax; // (slot 5: the latest end of a twice-spliced list)
         }
         ph_[1] = lo; ph_[3] = hi; ph_[4] = hi2; ph_[5] = nmax;
     }
@@ -1734,8 +1795,9 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
     *grid_out = 0;
     *lds_out = 0;
     if (p->n_reads <= 0 || p->n_sites <= 0) return 0;
-    // grid = 8 * ceil(n_chunks / 8) so that every XCD slice has the same number of slots
-    const uint32_t grid = ((p->n_chunks + 7u) / 8u) * 8u;
+    // grid = 8 * ceil(n_chunks / 8) so that every XCD's share has the same number of slots
+    const uint32_t slots = ((p->n_chunks + 7u) / 8u) * 8u;
+    const uint32_t grid = slots;
     *grid_out = (int)grid;
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
@@ -1750,9 +1812,9 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
 #ifdef SPL_PHASE_TIMING
         static uint64_t *phase_buf = nullptr;
         static size_t phase_cap = 0;
-        if (phase_cap < (size_t)grid * 8) {
+        if (phase_cap < (size_t)slots * 8) {
             if (phase_buf) (void)hipFree(phase_buf);
-            phase_cap = (size_t)grid * 8;
+            phase_cap = (size_t)slots * 8;
             if (hipMalloc((void **)&phase_buf, phase_cap * 8) != hipSuccess) return (int)hipErrorOutOfMemory;
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), &phase_buf, sizeof(phase_buf));
         }
@@ -1769,9 +1831,9 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
 #ifdef SPL_PHASE_TIMING
         if (const char *path = getenv("SPL_PHASE_DUMP")) {
             (void)hipStreamSynchronize(st);
-            uint64_t *host = (uint64_t *)malloc((size_t)grid * 64);
-            (void)hipMemcpy(host, phase_buf, (size_t)grid * 64, hipMemcpyDeviceToHost);
-            if (FILE *f = fopen(path, "wb")) { fwrite(host, 64, grid, f); fclose(f); }
+            uint64_t *host = (uint64_t *)malloc((size_t)slots * 64);
+            (void)hipMemcpy(host, phase_buf, (size_t)slots * 64, hipMemcpyDeviceToHost);
+            if (FILE *f = fopen(path, "wb")) { fwrite(host, 64, slots, f); fclose(f); }
             free(host);
         }
 #endif

@@ -10,10 +10,8 @@ raw = raw[raw[:, 7] > 0]
 t = raw.astype(np.int64)
 us = lambda a, b: (t[:, b] - t[:, a]) / 100.0   # noqa: E731
 rows = (("start -> first wave leaves its loop", 0, 1), ("first -> last wave leaves its loop", 1, 3),
-        ("last loop end -> last list end", 3, 4), ("last list end -> workgroup end (barrier, handover, flush)", 4, 7), ("lifetime", 0, 7))
+        ("last loop end -> last twice-spliced list end", 3, 5), ("-> last once-spliced pass end", 5, 4), ("last loop end -> last list end", 3, 4), ("last list end -> workgroup end (barrier, handover, flush)", 4, 7), ("lifetime", 0, 7))
 for name, a, b in rows:
     d = us(a, b)
     print("  %-58s mean %6.2f us   p50 %6.2f   p90 %6.2f" % (name, d.mean(), np.percentile(d, 50), np.percentile(d, 90)))
-n = t[:, 5]
-print("  longest list of a wave: mean %.1f entries, p50 %d, p90 %d, p99 %d, max %d" % (n.mean(), np.percentile(n, 50), np.percentile(n, 90),
-                                                                                      np.percentile(n, 99), n.max()))
+
