@@ -486,7 +486,7 @@ def compact_e2e(leg):
     path = leg.get("path") or {}
     cpu = leg.get("cpu_e2e") or {}
     out = {"workload": leg.get("workload"), "bam": leg.get("bam"), "bam_bytes": leg.get("bam_bytes"),
-           "decode": leg.get("decode"), "devices": len(leg.get("devices") or [0]),
+           "decode": leg.get("decode"), "devices": len(leg.get("devices") or [0]) if len(leg.get("devices") or [0]) > 1 else None,
            "wall_s": leg.get("wall_s"), "median_wall_s": leg.get("median_wall_s"), "first_call_wall_s": leg.get("first_call_wall_s"),
            "reads_per_sec": leg.get("reads_per_sec"), "file_GBps": path.get("file_GBps"), "frac_of_pcie": path.get("frac_of_pcie"),
            "tsv_matches_oracle": leg.get("tsv_matches_oracle"), "cpu_e2e_reads_per_sec": cpu.get("reads_per_sec")}

@@ -152,6 +152,18 @@ def one_combine_seed(seed):
                 cmb.write_combined(mine, merged, titles, results, cryptic)
                 if open(mine).read() != open(out_ref + ".combined.tsv").read():
                     return "MISMATCH (%s) seed %d stranded %s cryptic %s shallow %r, %d samples" % (command, seed, stype, cryptic, shallow, n_samples)
+                # ... and the native walk (csrc/spl_combine.cpp) with the same answers: the same bytes once more
+                from spliser_amd import native
+                import numpy as np
+                with native.Combine(tsvs) as walk:
+                    walk.merge(cmb.region_order_from_runs(walk.region_runs()), bool(stype), "All", shallow)
+                    for idx in range(len(titles)):
+                        for chrom, tb in walk.tables(idx):
+                            a = [results[(int(si), idx)] for si in tb["site"]]
+                            walk.answers(idx, tb["site"], np.array([x for x, _ in a], np.uint32), np.array([y for _, y in a], np.uint32))
+                    walk.write(mine + ".native", titles, cryptic)
+                if open(mine + ".native").read() != open(out_ref + ".combined.tsv").read():
+                    return "MISMATCH of the native walk (%s) seed %d stranded %s cryptic %s shallow %r, %d samples" % (command, seed, stype, cryptic, shallow, n_samples)
                 runs += 1
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
