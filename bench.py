@@ -773,7 +773,9 @@ def main():
             nproc, quota = cpu_budget()
             n_threads = max(1, min(nproc, int(round(quota)) if quota else nproc))
             want_all = want if len(all_items) == len(items) else run_oracle(all_items, scode, args.beta2Cryptic, n_threads)[1]
-            modes = [args.e2e_seq_mode] if args.e2e_seq_mode is not None else [1, 2, 0]
+            # (N > 1: the sequence-like file only -- rank 0 runs these legs alone after the collectives, on all the node's GPUs and
+            #  once more on one, and the driver's window for the scaling run is not known to be longer than the one-GPU run's)
+            modes = [args.e2e_seq_mode] if args.e2e_seq_mode is not None else ([1, 2, 0] if world == 1 else [1])
             devs = tuple(range(world))
             e2e = []
             for q in modes:     # (first the file that deflates like a real library's: the leg that says what the product does)

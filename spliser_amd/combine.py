@@ -276,7 +276,10 @@ def fill_tables(tables, take, bam_paths, is_stranded, stranded_type, devices=(0,
             take(idx, table.site_index[chrom], r["beta1"], r["beta2s_reads"])
 
     order = sorted(tables)
-    with ThreadPoolExecutor(max_workers=max(1, min(len(order), max(2, len(devices))))) as pool:
+    n_flight = max(2, len(devices))       # samples decoded and counted side by side
+    if os.environ.get("SPL_COMBINE_WORKERS"):
+        n_flight = max(1, int(os.environ["SPL_COMBINE_WORKERS"]))
+    with ThreadPoolExecutor(max_workers=max(1, min(len(order), n_flight))) as pool:
         for _ in pool.map(one, order):
             pass
 
