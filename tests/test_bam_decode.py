@@ -317,3 +317,50 @@ def test_share_plan_with_an_empty_and_a_dominant_reference(built, tmp_path):
         got = whole.reads(c)
         assert (got.n if got is not None else 0) == sets[c].n
     whole.close()
+
+
+def test_htslib_shaped_writer(built, tmp_path):
+    """seq_mode 2 (what the bench's `htslib` legs decode): whole records per BGZF block, as htslib's bam_write1 cuts them; every
+    record well-formed -- Illumina-style name, reg2bin as the SAM specification computes it, mate fields only for paired flags,
+    NH / HI / AS / nM tags (XS:A on spliced reads) -- and the reads that went in come out of the host decoder."""
+    import struct
+    import zlib
+    names, sets = _random_sets(23, 4000, 2)
+    path = str(tmp_path / "h.bam")
+    native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=6, threads=2, seq_mode=2)
+    raw = open(path, "rb").read()
+    at, blocks = 0, []
+    while at < len(raw):
+        bsize = int.from_bytes(raw[at + 16:at + 18], "little") + 1
+        blocks.append(zlib.decompress(raw[at + 18:at + bsize - 8], -15))
+        at += bsize
+    assert blocks[-1] == b""                                   # the EOF marker
+    head = blocks[0]
+    l_text = struct.unpack_from("<i", head, 4)[0]
+    assert head[:4] == b"BAM\x01" and struct.unpack_from("<i", head, 8 + l_text)[0] == len(names)
+    n_rec = n_spliced = 0
+    for blk in blocks[1:-1]:                                   # (the header has a block of its own, as after htslib's flush)
+        p = 0
+        while p < len(blk):
+            bs = struct.unpack_from("<i", blk, p)[0]
+            assert p + 4 + bs <= len(blk), "a record is cut by a block's end"
+            tid, pos0, l_name, mapq, bin_, n_cig, flag, l_seq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", blk, p + 4)
+            name = blk[p + 36:p + 36 + l_name]
+            assert name.endswith(b"\x00") and name.count(b":") == 6
+            cig = struct.unpack_from("<%dI" % n_cig, blk, p + 36 + l_name)
+            rlen = sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3, 7, 8))
+            qlen = sum(c >> 4 for c in cig if (c & 15) in (0, 1, 4, 7, 8))
+            assert l_seq == qlen and bin_ == samio._reg2bin(pos0, pos0 + max(rlen, 1))
+            assert (mtid, mpos, tlen) == (-1, -1, 0) if not flag & 1 else (mtid == tid and mpos >= 0)
+            tags = blk[p + 36 + l_name + 4 * n_cig + (l_seq + 1) // 2 + l_seq:p + 4 + bs]
+            assert tags[:3] == b"NHC" and b"HIC" in tags and b"nMC" in tags and (b"ASC" in tags or b"ASS" in tags)
+            spliced = any((c & 15) == 3 for c in cig)
+            assert (b"XSA" in tags) == spliced
+            n_spliced += spliced
+            n_rec += 1
+            p += 4 + bs
+    assert n_rec == sum(s.n for s in sets.values()) and n_spliced > 0
+    bam = native.BamFile(path, threads=2)
+    for c in names:
+        _same(bam.reads(c), sets[c])
+    bam.close()

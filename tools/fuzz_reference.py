@@ -197,7 +197,7 @@ def main():
                 samples += res[1]
         print("reference combine fuzz ok: seeds %d..%d x {unstranded, fr, rf} x {combine, combineShallow with random -m -r -e}: %d runs of "
               "SpliSER_v0_1_8.py combine / combineShallow over %d samples (2-4 per seed, each through the reference's process first), "
-              ".combined.tsv byte-identical to spliser_amd.combine's host walk with the oracle's gap fill, %.0f s" % (a.first, a.last, runs, samples, time.time() - t0))
+              ".combined.tsv byte-identical to spliser_amd.combine's host walk -- the Python statement and the native one (csrc/spl_combine.cpp) -- with the oracle's gap fill, %.0f s" % (a.first, a.last, runs, samples, time.time() - t0))
         return
     with multiprocessing.get_context("fork").Pool(a.jobs) as pool:
         for res in pool.imap_unordered(one_seed, range(a.first, a.last), chunksize=4):
