@@ -932,7 +932,6 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         for (; g < g_start[3]; g += NWAVE) {
 #ifdef SPL_EXP_SKIP
             if (SPL_EXP_SKIP & 4) { asm volatile("" :: "v"(cu0.x), "v"(cu1.x)); fetch_next(); continue; }
-            if ((SPL_EXP_SKIP & 128) && (((g - g_start[2]) / NWAVE) & 1u)) { asm volatile("" :: "v"(cu0.x), "v"(cu1.x)); fetch_next(); continue; } // (every other iteration only)
 #endif
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;

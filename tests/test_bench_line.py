@@ -101,3 +101,19 @@ def test_emit_prints_the_compact_line_last(capsys, tmp_path, monkeypatch):
     check(lines[-1], 5)
     with open(tmp_path / "bench_detail.json") as fh:
         assert json.load(fh)["e2e"][0]["kernels"]["table"]
+
+
+def test_the_committed_traffic_measurement_is_of_these_kernel_sources():
+    """bench.py quotes `roofline.traffic` (HBM bytes per launch by the PMC counters) from profiles/*_traffic.json only when the file was
+    measured with the kernel sources it runs (kernel_src_sha16: comments and white space aside).  A change to spl_kernels.hip,
+    spl_device.h, spl_pack.h, spl_classify.h or spl_pack.cpp without a new `tools/prof_round.sh` run leaves the driver's line with
+    `traffic: null` -- which is how round 4 nearly went out (an experiment's switch added after the profile run)."""
+    import glob
+    sha = bench.kernel_src_sha16()
+    have = []
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_traffic.json")):
+        with open(path) as fh:
+            t = json.load(fh)
+        if t.get("workload") == "human":
+            have.append(t.get("kernel_src_sha16"))
+    assert sha in have, "no profiles/*_traffic.json for the human workload was measured with the current kernel sources (%s): run tools/prof_round.sh" % sha
