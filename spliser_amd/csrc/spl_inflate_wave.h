@@ -225,42 +225,6 @@ WV_DEV uint32_t tbits(const uint32_t *tile, uint32_t base, uint32_t pos)
 // with a code of the root table is what follows: lit2 is its value, or NO_LIT2.  A wave's turn costs what its slowest path costs,
 // and the lane with the most turns in a tile is the one whose subsequence is all short literal codes: two to a turn, it has half of them.
 constexpr uint32_t NO_LIT2 = 0xffffffffu;
-#ifndef SPLZ_BRANCHY_DECODE
-// Straight-line: a wave's lanes are at literals and at matches in the same turn nearly always, so every path is run through
-// anyway -- as selects, not as regions of their own with the exec mask saved, narrowed and restored around each (the scalar unit,
-// one per CU, had as many instructions to issue for this loop as the four vector units together).  What a lane does not need it
-// looks up all the same, at an index that is in range whatever its bits say.
-WV_DEV uint32_t decode(const Shared &sh, uint32_t base, uint32_t &pos, uint32_t &len, uint32_t &dist, uint32_t stop, uint32_t &lit2)
-{
-    const uint32_t w = tbits(sh.tile, base, pos);
-    const uint32_t e0 = sh.lut_l[w & ((1u << ROOT_L) - 1u)];
-    const bool sub = (e0 & 15u) == 0u; // a sub-table (or no such code: entry 0, whose "sub-table" is the table's first entry again)
-    const uint32_t i1 = sub ? (1u << ROOT_L) + (e0 >> 7) + ((w >> ROOT_L) & ((1u << ((e0 >> 4) & 7u)) - 1u)) : (w & ((1u << ROOT_L) - 1u));
-    const uint32_t e = e0 == 0u ? 0u : sh.lut_l[i1 < LUT_L ? i1 : 0u];
-    uint32_t used = (sub ? ROOT_L : 0u) + (e & 15u);
-    const bool is_match = (e & 0x8000u) != 0u;
-    const uint32_t sym = e >> 4; // (literal or end of block when !is_match)
-    // a second literal behind a literal that ends before `stop`, if its code is one of the root table's
-    const uint32_t e2 = sh.lut_l[(w >> (used & 31u)) & ((1u << ROOT_L) - 1u)];
-    const bool two = !is_match && (e & 15u) != 0u && sym < 256u && pos + used < stop && (e2 & 15u) != 0u && e2 < (256u << 4);
-    lit2 = two ? e2 >> 4 : NO_LIT2;
-    // the length's extra bits, then the distance: looked up by every lane (at this lane's place after a length, wherever that is)
-    const uint32_t xl = (e >> 12) & 7u;
-    len = 3u + ((e >> 4) & 255u) + ((w >> (used & 31u)) & ((1u << xl) - 1u));
-    const uint32_t pos_d = pos + used + (is_match ? xl : 0u);
-    const uint32_t wd = tbits(sh.tile, base, is_match ? pos_d : pos);
-    const uint32_t d0 = sh.lut_d[wd & ((1u << ROOT_D) - 1u)];
-    const bool subd = (d0 & 0x8000u) != 0u;
-    const uint32_t j1 = subd ? ((d0 >> 4) & 0x3ffu) + ((wd >> ROOT_D) & ((1u << (d0 & 15u)) - 1u)) : (wd & ((1u << ROOT_D) - 1u));
-    const uint32_t d = sh.lut_d[j1 < LUT_D ? j1 : 0u];
-    const uint32_t used_d = (subd ? ROOT_D : 0u) + (d & 15u);
-    const uint32_t xd = (d >> 6) & 15u;
-    dist = 1u + (((d >> 4) & 3u) << xd) + ((wd >> (used_d & 31u)) & ((1u << xd) - 1u));
-    const bool bad = (e & 15u) == 0u || (is_match && (d & 15u) == 0u);
-    pos = bad ? pos : (is_match ? pos_d + used_d + xd : pos + used + (two ? e2 & 15u : 0u));
-    return bad ? SYM_BAD : (is_match ? SYM_MATCH : sym);
-}
-#else
 WV_DEV uint32_t decode(const Shared &sh, uint32_t base, uint32_t &pos, uint32_t &len, uint32_t &dist, uint32_t stop, uint32_t &lit2)
 {
     uint32_t w = tbits(sh.tile, base, pos), used = 0;
@@ -300,7 +264,6 @@ WV_DEV uint32_t decode(const Shared &sh, uint32_t base, uint32_t &pos, uint32_t 
     return SYM_MATCH;
 }
 
-#endif
 
 // What a lane would produce from `start` to the first symbol boundary at or past `sub_end`: bytes of output, bytes of token stream
 // (a lane's literal runs are its own: a run never goes on in the next lane's tokens).
