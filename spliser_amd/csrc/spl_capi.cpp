@@ -1299,9 +1299,10 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     struct Pipe { // stream A, stream B, their events; waits for everything on the way out, whichever way that is
         spl_ctx *c;
         hipStream_t a = nullptr, b = nullptr, cp[NCOPY] = {}, up2 = nullptr; // (up2: a second stream for the file's pieces, beside the context's copy stream)
-        hipEvent_t k1[NBUF] = {}, k2[NBUF] = {}, freed[NBUF] = {}, setup = nullptr;
+        hipEvent_t k1[NBUF] = {}, freed[NBUF] = {}, setup = nullptr; // (k1: a token buffer's decoding is done; freed: a stream buffer's records are extracted)
         std::vector<hipEvent_t> piece;
         std::vector<hipEvent_t> dec; // window w's Huffman decoding is done: nobody reads its pieces of the file image again (their slots of the ring are free)
+        std::vector<hipEvent_t> k2;  // window w's copying kernel is done: its bytes are there, its token buffer is free
         explicit Pipe(spl_ctx *ctx) : c(ctx) {}
         // (only the streams that will be used: the runtime deals streams out to a few hardware queues, and one more stream --
         //  made, never used -- put the decoding and the copying kernels behind each other: 0.75 s instead of 0.43 for a 14 GB file)
@@ -1313,7 +1314,6 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             if (e == hipSuccess && second_upload) e = hipStreamCreateWithFlags(&up2, hipStreamNonBlocking);
             for (int k = 0; k < NBUF && e == hipSuccess; ++k) {
                 e = hipEventCreateWithFlags(&k1[k], hipEventDisableTiming);
-                if (e == hipSuccess) e = hipEventCreateWithFlags(&k2[k], hipEventDisableTiming);
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&freed[k], hipEventDisableTiming);
             }
             if (e == hipSuccess) e = hipEventCreateWithFlags(&setup, hipEventDisableTiming);
@@ -1321,12 +1321,15 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             for (size_t k = 0; k < n_pieces && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&piece[k], hipEventDisableTiming);
             dec.assign(1, nullptr);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&dec[0], hipEventDisableTiming);
+            k2.assign(1, nullptr);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&k2[0], hipEventDisableTiming);
             return e;
         }
         hipError_t make_windows(size_t n_win)
         {
             hipError_t e = hipSuccess;
             while (dec.size() < n_win && e == hipSuccess) { dec.push_back(nullptr); e = hipEventCreateWithFlags(&dec.back(), hipEventDisableTiming); }
+            while (k2.size() < n_win && e == hipSuccess) { k2.push_back(nullptr); e = hipEventCreateWithFlags(&k2.back(), hipEventDisableTiming); }
             return e;
         }
         ~Pipe()
@@ -1338,7 +1341,8 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             if (up2) (void)hipStreamSynchronize(up2);
             for (hipEvent_t e : piece) if (e) (void)hipEventDestroy(e);
             for (hipEvent_t e : dec) if (e) (void)hipEventDestroy(e);
-            for (int k = 0; k < NBUF; ++k) { if (k1[k]) (void)hipEventDestroy(k1[k]); if (k2[k]) (void)hipEventDestroy(k2[k]); if (freed[k]) (void)hipEventDestroy(freed[k]); }
+            for (hipEvent_t e : k2) if (e) (void)hipEventDestroy(e);
+            for (int k = 0; k < NBUF; ++k) { if (k1[k]) (void)hipEventDestroy(k1[k]); if (freed[k]) (void)hipEventDestroy(freed[k]); }
             if (setup) (void)hipEventDestroy(setup);
             if (a) (void)hipStreamDestroy(a);
             for (int k = 0; k < NCOPY; ++k) if (cp[k]) (void)hipStreamDestroy(cp[k]);
@@ -1601,21 +1605,24 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     for (size_t k = 0; k < n_win; ++k) most_blocks = std::max(most_blocks, win_at[k + 1] - win_at[k]);
     const size_t work_bytes = spl_dev_inflate_work_bytes((uint32_t)most_blocks);
     HIP_TRY(look_at_free());
-    // Three windows in flight: a window's buffer is free again when its records are extracted, and with two the decoding kernel
-    // of window k + 2 waited for that -- decode, copy, scan and extract of one window in a row, 34 ms for two windows of work
-    // (measured on the 14 GB file: 20 ms a window with two buffers, 18.7 with three, no less with four).  The third is taken when
-    // the process holds the memory for it already (a call after another): fresh device memory costs 6-15 ms a gigabyte, which
-    // for 7 GB is more than the 20 ms the buffer saves -- a process that decodes one file (the command line) stays with two.
-    const size_t per_buf = (size_t)win_cap + (size_t)HEAD + work_bytes;
-    int want_buf = devmem::held_bytes(c->device) >= 3 * per_buf ? 3 : 2;
+    // Windows in flight.  A window has two buffers, each free again when its reader is done: the TOKENS (decoding kernel ->
+    // copying kernel) when the window's copying kernel has run, the inflated BYTES (copying kernel -> CRC32, scan, extraction)
+    // when its records are extracted.  n_zw of the first, n_buf of the second, and each kernel waits for its own buffer only: the
+    // decoding of window k + n_zw begins when the copying of window k is done, the copying of window k + n_buf when window k's
+    // records are out.  (Until round 4 a window had one slot for both, and with two slots the decoding of window k + 2 stood
+    // behind the extraction of window k: decode, copy, CRC32, scan, extract of one window in a row, 29 ms for two windows of work
+    // on an htslib-shaped file; profiles/r04x_window_dependencies.txt.)  Fresh device memory costs 6-15 ms a gigabyte and a token
+    // buffer has four of them, a byte buffer three: a process that decodes one file (the command line) stays with two of each.
+    int want_buf = 2, want_zw = 2;
     if (const char *e = getenv("SPL_INFLATE_BUFFERS")) want_buf = std::min(NBUF, std::max(1, atoi(e)));
-    const int n_buf = (int)std::min<size_t>((size_t)want_buf, n_win);
-    if ((double)n_buf * ((double)win_cap + (double)HEAD + (double)work_bytes) + (double)(stream_len - stream_begin) * 0.2 + slack > (double)free_b)
+    if (const char *e = getenv("SPL_INFLATE_TOKEN_BUFFERS")) want_zw = std::min(NBUF, std::max(1, atoi(e)));
+    const int n_buf = (int)std::min<size_t>((size_t)want_buf, n_win), n_zw = (int)std::min<size_t>((size_t)want_zw, n_win);
+    if ((double)n_buf * ((double)win_cap + (double)HEAD) + (double)n_zw * (double)work_bytes + (double)(stream_len - stream_begin) * 0.2 + slack > (double)free_b)
         return to_host("not enough device memory for the inflated stream");
-    for (int k = 0; k < n_buf; ++k) {
+    for (int k = 0; k < std::max(n_buf, n_zw); ++k) {
         if (k == 0 && early) continue; // (the first window has its buffers, large enough for any)
-        HIP_TRY(d_stream[k].get(HEAD + win_cap + 256, c->copy));
-        HIP_TRY(d_zwork[k].get(work_bytes, c->copy));
+        if (k < n_buf) HIP_TRY(d_stream[k].get(HEAD + win_cap + 256, c->copy));
+        if (k < n_zw) HIP_TRY(d_zwork[k].get(work_bytes, c->copy));
     }
     // where the placed records of a window's blocks begin (scan -> extraction, one window at a time on stream B): room for a window's
     // blocks and what an 8 MB carry can hold of ordinary ones; a window with more blocks than that is extracted by walking
@@ -1681,10 +1688,10 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         cap_ops = want_ops;
         return SPL_OK;
     };
-    // the Huffman decoding of window k on stream A, behind the pieces of the file it reads and behind whoever last used its buffer
     auto win_range = [&](size_t k, size_t &b0, size_t &b1) { b0 = win_at[k]; b1 = win_at[k + 1]; };
     auto stream0_of = [&](size_t k) { size_t b0, b1; win_range(k, b0, b1); return d_stream[k % (size_t)n_buf].as<uint8_t>() + HEAD - blocks[b0].out; }; // (indexed with offsets into the whole stream)
-    auto launch_decode = [&](size_t k, bool wait, bool &launched_it) -> int {
+    // the Huffman decoding of window k on stream A: behind the pieces of the file it reads and behind the copying kernel that read its token buffer last
+    auto launch_k1 = [&](size_t k, bool wait, bool &launched_it) -> int {
         size_t b0, b1;
         win_range(k, b0, b1);
         launched_it = false;
@@ -1696,24 +1703,31 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             if (reader_failed.load(std::memory_order_acquire)) { for (hipError_t e : errs) HIP_TRY(e); }
             HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.piece[pieces_waited], 0));
         }
-        if (k >= (size_t)n_buf) HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.freed[k % (size_t)n_buf], 0));
+        if (k >= (size_t)n_zw) HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.k2[k - (size_t)n_zw], 0));
         const double w_in = (double)(foff[b1 - 1] + blocks[b1 - 1].in_len - foff[b0]), w_out = (double)(blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out);
         {
             splprof::Scope p("spl_inflate_decode_kernel", pipe.a, w_in + w_out);
-            HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_buf].p, pipe.a));
+            HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_zw].p, pipe.a));
         }
-        HIP_TRY(hipEventRecord(pipe.k1[k % (size_t)n_buf], pipe.a));
+        HIP_TRY(hipEventRecord(pipe.k1[k % (size_t)n_zw], pipe.a));
         HIP_TRY(hipEventRecord(pipe.dec[k], pipe.a));
         launched_pub.store(k + 1, std::memory_order_release); // (the readers may give this window's pieces' slots to later pieces, behind that event)
         up_wake();
-        hipStream_t cs = pipe.cp[k % (size_t)n_copy];
-        HIP_TRY(hipStreamWaitEvent(cs, pipe.k1[k % (size_t)n_buf], 0));
-        {
-            splprof::Scope p("spl_inflate_copy_kernel", cs, w_out);
-            HIP_TRY((hipError_t)spl_dev_launch_inflate_copy(d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_buf].p, cs));
-        }
-        HIP_TRY(hipEventRecord(pipe.k2[k % (size_t)n_buf], cs));
         launched_it = true;
+        return SPL_OK;
+    };
+    // its copying kernel: behind the decoding and behind the extraction of the window that had its byte buffer
+    auto launch_k2 = [&](size_t k) -> int {
+        size_t b0, b1;
+        win_range(k, b0, b1);
+        hipStream_t cs = pipe.cp[k % (size_t)n_copy];
+        HIP_TRY(hipStreamWaitEvent(cs, pipe.k1[k % (size_t)n_zw], 0));
+        if (k >= (size_t)n_buf) HIP_TRY(hipStreamWaitEvent(cs, pipe.freed[k % (size_t)n_buf], 0));
+        {
+            splprof::Scope p("spl_inflate_copy_kernel", cs, (double)(blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out));
+            HIP_TRY((hipError_t)spl_dev_launch_inflate_copy(d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_zw].p, cs));
+        }
+        HIP_TRY(hipEventRecord(pipe.k2[k], cs));
         return SPL_OK;
     };
     int64_t n_all = 0;
@@ -1725,20 +1739,31 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     // (phase 2).  A record of any other reference anywhere else would be extracted by nobody: such a file goes to the host.
     int edge_phase = 0;
     size_t carry = 0; // the first block whose records are not all extracted yet
-    size_t launched = early ? 1 : 0; // windows whose decoding has been put on its streams
+    size_t launched = early ? 1 : 0, copying = early ? 1 : 0; // windows whose decoding / whose copying kernel has been put on its stream
     std::vector<double> t_win; // (SPL_BAM_TIMING: when each window's scan was back on the host)
     const double t_setup = host_now() - t_begin;
     for (size_t k = 0; k < n_win; ++k) {
         size_t b0, b1;
         win_range(k, b0, b1);
         if (spl_bam_cancelled(bam)) return to_host("the file is being closed");
-        // (a window's buffer is free again when the extraction of the window that had it is on stream B: windows k .. k + n_buf - 1 fit)
-        while (launched < n_win && launched < k + (size_t)n_buf) {
-            bool did = false;
-            rc = launch_decode(launched, launched == k, did);
-            if (rc) return rc;
-            if (!did) break;
-            ++launched;
+        // Whatever can be put on its stream now.  A copying kernel: its window's decoding is there, and the extraction of the window that
+        // had its byte buffer is on stream B (windows k .. k + n_buf - 1).  A decoding kernel: the copying kernel that reads its token
+        // buffer before it is on its stream (n_zw windows back), and its pieces of the file are on their way (window k's are waited for).
+        for (;;) {
+            bool progress = false;
+            if (copying < launched && copying < k + (size_t)n_buf) {
+                rc = launch_k2(copying);
+                if (rc) return rc;
+                ++copying;
+                progress = true;
+            }
+            if (launched < n_win && launched < copying + (size_t)n_zw) {
+                bool did = false;
+                rc = launch_k1(launched, launched == k, did);
+                if (rc) return rc;
+                if (did) { ++launched; progress = true; }
+            }
+            if (!progress) break;
         }
         const size_t slot = k % (size_t)n_buf;
         const bool more = b1 < n_blocks || !last_share;
@@ -1746,7 +1771,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         const uint64_t win_end = blocks[b1 - 1].out + blocks[b1 - 1].out_len;
         uint8_t *const stream0 = stream0_of(k);
         const size_t s0 = k == 0 ? b0 : carry; // scan and extraction begin with what the window before left
-        HIP_TRY(hipStreamWaitEvent(pipe.b, pipe.k2[slot], 0));
+        HIP_TRY(hipStreamWaitEvent(pipe.b, pipe.k2[k], 0));
         const double win_out = (double)(win_end - blocks[b0].out);
         { splprof::Scope p("spl_crc32_kernel", pipe.b, win_out); HIP_TRY((hipError_t)spl_dev_launch_crc32(stream0, d_blocks.as<spl_zblock>() + b0, nb, d_status.as<uint32_t>() + b0, pipe.b)); }
         {

@@ -6,6 +6,7 @@
 #include "spl_inflate.h"
 #include "spl_wave.h"
 #include "spl_inflate_wave.h"
+#include "spl_crc.h"
 
 // The Huffman decoding, one BGZF block per WAVE (the block's symbols as a stream of tokens), and the block's bytes made from
 // that stream, one block per LANE (spl_inflate_wave.h has the method, and is what the host tests run through the wave emulator).
@@ -429,23 +430,23 @@ __global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, c
     status[b] = err;
 }
 
-// CRC32 (IEEE, reflected) of every block's payload against the value in its trailer: one lane per block.  The payload comes in
-// 16-byte loads, the next one asked for before the current one is worked on (a byte at a time each byte was a trip to the L2:
-// 64 lanes on 64 different lines, 440 cycles a byte), and goes through four tables in LDS a word at a time (slicing by four:
-// the four look-ups of a word do not wait for each other).  Blocks that already failed keep their status.
+// CRC32 (IEEE, reflected) of every block's payload against the value in its trailer: one lane per block -- 768 waves for a window,
+// which leaves the CUs to the decoding kernel beside it -- and the lane's block as S streams (spl_crc.h): S chains of table
+// look-ups and S 16-byte loads in flight instead of one of each (the lane a word after the other waited 2 000 cycles a load:
+// 64 lanes on 64 different lines and nothing else to do).  Tables in LDS: slicing by four, and x^(2^k) for putting the streams'
+// registers together.  Blocks that already failed keep their status.
+template <int S>
 __global__ __launch_bounds__(64) void spl_crc32_kernel(const uint8_t *out_all, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status)
 {
-    __shared__ uint32_t table[4][256]; // table[k][b] = the CRC register after byte b and k zero bytes
-    for (uint32_t i = threadIdx.x; i < 256u; i += 64u) {
-        uint32_t c = i;
-        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
-        table[0][i] = c;
-    }
+    __shared__ uint32_t table[4 * 256]; // table[k * 256 + b] = the CRC register after byte b and k zero bytes
+    __shared__ uint32_t x2n[splcrc::N_X2N];
+    for (uint32_t i = threadIdx.x; i < 256u; i += 64u) table[i] = splcrc::byte_entry(i);
+    if (threadIdx.x < (uint32_t)splcrc::N_X2N) x2n[threadIdx.x] = splcrc::x2n_entry(threadIdx.x);
     __syncthreads();
     for (int k = 1; k < 4; ++k) {
         for (uint32_t i = threadIdx.x; i < 256u; i += 64u) {
-            const uint32_t c = table[k - 1][i];
-            table[k][i] = (c >> 8) ^ table[0][c & 0xffu];
+            const uint32_t c = table[(k - 1) * 256 + i];
+            table[k * 256 + i] = (c >> 8) ^ table[c & 0xffu];
         }
         __syncthreads();
     }
@@ -453,26 +454,7 @@ __global__ __launch_bounds__(64) void spl_crc32_kernel(const uint8_t *out_all, c
     if (b >= n_blocks) return;
     if (status[b] != SPL_Z_OK) return;
     const spl_zblock zb = blocks[b];
-    const uint8_t *p = out_all + zb.out;
-    const uint32_t n = zb.out_len;
-    uint32_t c = 0xffffffffu, i = 0;
-    auto word = [&](uint32_t w) {
-        c ^= w;
-        c = table[3][c & 0xffu] ^ table[2][(c >> 8) & 0xffu] ^ table[1][(c >> 16) & 0xffu] ^ table[0][c >> 24];
-    };
-    if (n >= 16u) {
-        u32x4 cur, next;
-        __builtin_memcpy(&cur, p, 16);
-        for (; i + 32u <= n; i += 16u) {
-            __builtin_memcpy(&next, p + i + 16u, 16);
-            word(cur.x); word(cur.y); word(cur.z); word(cur.w);
-            cur = next;
-        }
-        word(cur.x); word(cur.y); word(cur.z); word(cur.w);
-        i += 16u;
-    }
-    for (; i < n; ++i) c = table[0][(c ^ p[i]) & 0xffu] ^ (c >> 8);
-    if ((c ^ 0xffffffffu) != zb.crc) status[b] = SPL_Z_BAD_CRC;
+    if (splcrc::block<S>(out_all + zb.out, zb.out_len, table, x2n) != zb.crc) status[b] = SPL_Z_BAD_CRC;
 }
 
 // ---- BAM records ---------------------------------------------------------------------------------------------------------
@@ -799,6 +781,8 @@ extern "C" int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *bl
 extern "C" int spl_dev_launch_crc32(const uint8_t *out, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *stream)
 {
     if (n_blocks == 0) return 0;
-    hipLaunchKernelGGL(spl_crc32_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, out, blocks, n_blocks, status);
+    // (four streams a lane: 1.6 ms a window of 43 169 blocks against 2.0 with one and 1.5 with two; 3.5 with eight, whose 64 x 8 lines
+    //  the L1 cannot hold -- profiles/r04v_crc_streams.txt)
+    hipLaunchKernelGGL(spl_crc32_kernel<4>, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, out, blocks, n_blocks, status);
     return (int)hipGetLastError();
 }
