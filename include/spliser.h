@@ -244,6 +244,12 @@ int spl_bam_share_plan(spl_bam *bam, int n_shares, int *n_out);
 int spl_bam_share_range(spl_bam *bam, int k, int *tid_lo_out, int *tid_hi_out);
 int spl_bam_decode_device_share(spl_ctx *ctx, spl_bam *bam, int k, int *on_device_out);
 int spl_bam_decoded_on_device(spl_bam *bam, int *on_device_out);
+/* For whoever runs spl_bam_decode_device / _share on threads of his own and waits for the outcome elsewhere: returns when the
+ * file is no longer the device decoders' to decide about -- *on_device_out = 1: its reads are on the device(s), every reference
+ * complete; 0: the host threads have it (and may still be decoding: spl_bam_wait_ref / _all).  It does not wait for the decoders'
+ * calls to RETURN: a call gives its buffers, streams and events back after it has made the references complete (10 ms for a
+ * large file), and the counting need not stand behind that (`process` Step 3, SpliSER_v0_1_8.py:681-692 per chromosome). */
+int spl_bam_wait_device(spl_bam *bam, int *on_device_out);
 /* A deferred file's other option, said out loud: decode on the host's threads, starting now.  Also ends a reservation that
  * nobody has taken up (its maker failed before it could call spl_bam_decode_device). */
 int spl_bam_start(spl_bam *bam);

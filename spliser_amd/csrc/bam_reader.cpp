@@ -1119,6 +1119,7 @@ int spl_bam_start_host(spl_bam *bam)
     if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_start_host: null argument");
     std::lock_guard<std::mutex> lock(bam->mu);
     if (bam->claim == 0 && !cancelled_locked(bam)) { bam->claim = 2; bam->worker = std::thread(decode_worker, bam); }
+    bam->cv.notify_all(); // (spl_bam_wait_device)
     return SPL_OK;
 }
 
@@ -1157,7 +1158,29 @@ int spl_bam_device_gives_up(spl_bam *bam)
 {
     std::lock_guard<std::mutex> lock(bam->mu);
     if (bam->claim == 1 && !cancelled_locked(bam)) { bam->claim = 2; bam->worker = std::thread(decode_worker, bam); }
+    bam->cv.notify_all(); // (spl_bam_wait_device)
     return SPL_OK;
+}
+
+// Whoever started device decoders on the file (spl_bam_decode_device / _share on threads of the caller) and wants to know how
+// that went: waits until the file is no longer theirs to decide about -- its reads are on the device(s) and every reference is
+// complete (1), or the host threads have the file (0: not sorted by reference, a CIGAR in a CG tag, no device memory ...; they
+// may still be at it, spl_bam_wait_ref / _all wait for them).  It does NOT wait for the decoders' calls to return: what they
+// give back on the way out (buffers, streams, events: 10 ms for a large file) is nobody's business but theirs.
+extern "C" int spl_bam_wait_device(spl_bam *bam, int *on_device_out)
+{
+    if (!bam || !on_device_out) return spl_set_error(SPL_ERR_ARG, "spl_bam_wait_device: null argument");
+    std::unique_lock<std::mutex> lock(bam->mu);
+    bam->cv.wait(lock, [&]() { return bam->claim != 1 || bam->done; });
+    *on_device_out = (bam->shares_on_device || (bam->done && !bam->dev_shares.empty())) ? 1 : 0;
+    return SPL_OK;
+}
+
+// A device decoder that has told the waiters and has only its clearing up left: until the file is being closed (spl_bam_cancel), `seconds` at most.
+void spl_bam_linger(spl_bam *bam, double seconds)
+{
+    std::unique_lock<std::mutex> lock(bam->mu);
+    (void)bam->cv.wait_for(lock, std::chrono::duration<double>(seconds), [&]() { return bam->cancel.load(std::memory_order_acquire); });
 }
 
 // The file is about to be closed: a decode in progress stops at its next batch (host threads) or window (device), a decode that
@@ -1169,6 +1192,7 @@ extern "C" void spl_bam_cancel(spl_bam *bam)
     bam->cancel.store(true, std::memory_order_release);
     std::lock_guard<std::mutex> lock(bam->mu);
     if (bam->claim == 0) (void)cancelled_locked(bam);
+    bam->cv.notify_all();
 }
 bool spl_bam_cancelled(const spl_bam *bam) { return bam->cancel.load(std::memory_order_acquire); }
 
@@ -1445,6 +1469,7 @@ int spl_bam_share_done(spl_bam *bam, int k, void *handle, void (*free_fn)(void *
         bam->share_results.assign(drop.size(), spl_bam::ShareResult());
         for (spl_bam::ShareResult &x : bam->share_results) x.reported = true;
         if (!cancelled_locked(bam)) bam->worker = std::thread(decode_worker, bam);
+        bam->cv.notify_all(); // (spl_bam_wait_device)
         lock.unlock();
         for (spl_bam::ShareResult &x : drop) if (x.handle && x.free_fn) x.free_fn(x.handle);
         return SPL_OK;

@@ -50,5 +50,6 @@ int spl_bam_start_host(spl_bam *bam);                      // decode on the host
 bool spl_bam_claim_for_device(spl_bam *bam);               // the device decoder takes the file (false: it is taken)
 void spl_bam_note_decline(spl_bam *bam, const char *why); // why the device decoder leaves the file to the host threads
 int spl_bam_device_gives_up(spl_bam *bam);                 // ... and hands it to the host threads after all
+void spl_bam_linger(spl_bam *bam, double seconds);       // a decoder with only its clearing up left: until spl_bam_cancel, `seconds` at most
 
 #endif

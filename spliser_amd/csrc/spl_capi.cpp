@@ -153,7 +153,16 @@ static void put(void *p)
         for (size_t k = 0; k < l.size(); ++k)
             if (l[k].p == p) { h = l[k]; l.erase(l.begin() + (long)k); break; }
     }
-    if (h.device < 0 || h.bytes < ((size_t)8 << 20) || h.bytes > limit(h.device)) { (void)hipFree(p); return; }
+    if (h.device < 0 || h.bytes > limit(h.device)) { (void)hipFree(p); return; }
+    if (h.bytes < ((size_t)8 << 20)) {
+        // small ones (chunk descriptors, a decode's lists and counters: a few dozen a call) are kept as well, up to a number: a
+        // hipFree waits for the device and then takes 0.3 ms -- twelve of them between two shards' counting passes were 4 ms of
+        // an idle device (profiles/r04ab_tail.txt)
+        std::lock_guard<std::mutex> lock(mu());
+        size_t n_small = 0;
+        for (const Held &x : held()) if (x.device == h.device && x.bytes < ((size_t)8 << 20)) ++n_small;
+        if (n_small >= 256) { (void)hipFree(p); return; }
+    }
     int cur = 0;
     const bool have = hipGetDevice(&cur) == hipSuccess;
     if (have && cur != h.device) (void)hipSetDevice(h.device);
@@ -1072,6 +1081,7 @@ namespace {
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { devmem::put(p); }
+    void release() { devmem::put(p); p = nullptr; }
     hipError_t get(size_t bytes, hipStream_t) { return devmem::get(&p, bytes ? bytes : 16, 'b'); }
     template <class T> T *as() const { return (T *)p; }
 };
@@ -1208,9 +1218,12 @@ static int add_segment_device(spl_ctx *c, spl_dreads *d, const DeviceReads &dev,
 // that straddles two windows: the bytes from the first block that is not done with to the window's end are copied in front of the
 // next window's buffer (its head room), so that scan and extraction see them in one piece; the blocks are not inflated twice.
 namespace {
-struct ShareOut { DeviceReads *reads = nullptr; int64_t n_all = 0; bool to_host = false; };
+struct ShareOut { DeviceReads *reads = nullptr; int64_t n_all = 0; bool to_host = false; bool published = false; };
+// What the caller of decode_share does with the share's reads, called by decode_share itself as its LAST act before it gives its
+// buffers, streams and events back -- which takes 10 ms for a large file, and whoever waits for the file's references need not.
+typedef std::function<int(ShareOut &)> Publish;
 }
-static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, ShareOut &res);
+static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, ShareOut &res, const Publish &publish);
 
 static void fill_whole(spl_bam *bam, spl_bam_share &sh) { sh.block_lo = 0; sh.block_hi = spl_bam_block_count(bam); sh.tid_lo = 0; sh.tid_hi = spl_bam_n_ref(bam) + 1; }
 
@@ -1220,8 +1233,10 @@ extern "C" int spl_bam_decode_device(spl_ctx *c, spl_bam *bam, int *on_device_ou
     if (on_device_out) *on_device_out = 0;
     if (!spl_bam_claim_for_device(bam)) return SPL_OK; // (being decoded already, by whoever asked first: nothing to do here)
     ShareOut res;
-    int rc = decode_share(c, bam, nullptr, res);
-    if (rc == SPL_OK && !res.to_host && res.reads) {
+    const auto t_call = std::chrono::steady_clock::now();
+    double t_pub = 0;
+    const Publish adopt = [&](ShareOut &res) -> int {
+        int rc = SPL_OK;
         DeviceReads *keep = res.reads;
         const bool eager = getenv("SPL_NO_DEVICE_PACK") != nullptr; // (the round-trip over the host, for A/B: host copies now, nothing kept here)
         if (eager) {
@@ -1239,11 +1254,18 @@ extern "C" int spl_bam_decode_device(spl_ctx *c, spl_bam *bam, int *on_device_ou
             if (rc) spl_bam_set_device_reads(bam, nullptr, nullptr);
         }
         if (rc == SPL_OK && on_device_out) *on_device_out = 1;
-    }
+        t_pub = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count();
+        return rc;
+    };
+    int rc = decode_share(c, bam, nullptr, res, adopt);
+    if (rc == SPL_OK && !res.to_host && res.reads && !res.published) rc = adopt(res); // (SPL_PUBLISH_LATE only: decode_share publishes what it returns)
     // whatever went wrong on the way (device memory, a HIP error, a file this path does not take): the file must not be left
     // without a decoder -- the host threads take it (a no-op when the arrays were adopted); spl_last_error keeps the reason
     (void)spl_bam_device_gives_up(bam);
     if (rc != SPL_OK && getenv("SPL_BAM_TIMING")) fprintf(stderr, "[spl_bam_decode_device] failed (%s): host decoder instead\n", spl_last_error());
+    if (getenv("SPL_BAM_TIMING"))
+        fprintf(stderr, "[spl_bam_decode_device] the file's references were complete %.4f s after the call, the call returned at %.4f s (buffers, streams and events given back)\n", t_pub,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count());
     return SPL_OK;
 }
 
@@ -1258,18 +1280,22 @@ extern "C" int spl_bam_decode_device_share(spl_ctx *c, spl_bam *bam, int k, int 
     int rc = spl_bam_share_get(bam, k, &sh);
     if (rc) return rc;
     ShareOut res;
-    rc = decode_share(c, bam, &sh, res);
+    const Publish report = [&](ShareOut &res) -> int { // (a share that is done: reported at once, the last one to report completes the file)
+        spl_bam_set_fetch(bam, fetch_device_reads);
+        const int rc2 = spl_bam_share_done(bam, k, res.reads, free_device_reads, res.reads->ref_first.data(), res.reads->ref_n.data(), res.reads->ref_max.data(), res.n_all, 0);
+        if (rc2 == SPL_OK && on_device_out) *on_device_out = 1;
+        return rc2;
+    };
+    rc = decode_share(c, bam, &sh, res, report);
+    if (res.published) return rc;
     const bool failed = rc != SPL_OK || res.to_host || !res.reads;
-    if (failed && getenv("SPL_BAM_TIMING")) fprintf(stderr, "[spl_bam_decode_device] share %d not done on its device (%s)\n", k, rc ? spl_last_error() : "handed to the host");
-    if (failed && res.reads) { free_device_reads(res.reads); res.reads = nullptr; }
-    if (!failed) spl_bam_set_fetch(bam, fetch_device_reads);
-    rc = spl_bam_share_done(bam, k, res.reads, free_device_reads, failed ? nullptr : res.reads->ref_first.data(), failed ? nullptr : res.reads->ref_n.data(),
-                            failed ? nullptr : res.reads->ref_max.data(), res.n_all, failed ? 1 : 0);
-    if (rc == SPL_OK && !failed && on_device_out) *on_device_out = 1;
-    return rc;
+    if (!failed) return report(res); // (SPL_PUBLISH_LATE only: decode_share publishes what it returns)
+    if (getenv("SPL_BAM_TIMING")) fprintf(stderr, "[spl_bam_decode_device] share %d not done on its device (%s)\n", k, rc ? spl_last_error() : "handed to the host");
+    if (res.reads) { free_device_reads(res.reads); res.reads = nullptr; }
+    return spl_bam_share_done(bam, k, nullptr, free_device_reads, nullptr, nullptr, nullptr, res.n_all, 1);
 }
 
-static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, ShareOut &res)
+static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, ShareOut &res, const Publish &publish)
 {
     HIP_TRY(hipSetDevice(c->device));
     const bool timing = getenv("SPL_BAM_TIMING") != nullptr;
@@ -1891,7 +1917,22 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         for (double t : t_win) fprintf(stderr, " %.3f", t);
         fprintf(stderr, " s\n");
     }
-    return SPL_OK;
+    // The decode's device buffers go back to the process's pool BEFORE the waiters are told (nothing is in flight: a moment's work):
+    // what they allocate next -- read sets, their control blocks -- finds them there, as it did when this function's return came
+    // first (a control block of 1 GB that had to come fresh from the driver cost 9 ms of the call's last 20).  Streams, events,
+    // the readers' threads and the host's lists go afterwards, on this thread's own time.
+    if (getenv("SPL_PUBLISH_LATE")) return SPL_OK; // (A/B: the caller tells the waiters when everything of this function's has gone, as until round 4)
+    d_image.release();
+    for (int k = 0; k < NBUF; ++k) { d_stream[k].release(); d_zwork[k].release(); }
+    d_blocks0.release(); d_status0.release(); d_recs.release(); d_blocks.release(); d_status.release(); d_scan.release(); d_recoff.release(); d_opoff.release();
+    d_tid.release(); d_maxend.release(); d_bounds.release(); d_nbounds.release();
+    res.published = true;
+    const int told = publish(res);
+    // ... and not at once: 500 events and five streams destroyed are 10 ms of the HIP runtime's locks, which the thread that was
+    // told above needs now -- for the layout kernels, the chunk order's upload, the counting launches (its 9 ms took 17 beside
+    // this thread's clearing up; profiles/r04ab_tail.txt).  This thread stands aside until the file is being closed, or 0.1 s.
+    spl_bam_linger(bam, 0.1);
+    return told;
 }
 
 // The flat chunk list of a read set, the chunk order of the range kernel and the queues.
@@ -1906,6 +1947,9 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
         c->tm_bytes = c->tm_pieces = 0;
     }
     if (d->n_cigar > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops in one read set: use more shards");
+    auto host_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tf0 = host_now();
+    double tf_descs = 0, tf_order = 0, tf_alloc = 0;
     { // the chunk descriptors of segments the device packer laid out: to the host now (the packer's kernels are done by then)
         hipError_t q = hipSuccess;
         bool any = false;
@@ -1917,10 +1961,11 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
             }
         if (any) {
             if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
-            for (spl_dreads::Segment &seg : d->segs) { devmem::put(seg.d_descs); seg.d_descs = nullptr; }
+            // (the descriptors' device copies go back with the read set, spl_reads_free: giving a buffer back waits for the device, and here that is the next read set's layout kernels)
             if (q != hipSuccess) return spl_set_error(SPL_ERR_HIP, "device packer: %s", hipGetErrorString(q));
         }
     }
+    tf_descs = host_now() - tf0;
     const size_t n = d->n_chunks;
     std::vector<spl_chunk_meta> meta(n);
     std::vector<uint32_t> cost(n), order(n);
@@ -1975,6 +2020,7 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
             for (size_t j = lo; j < hi; ++j) order[lo + bucket[max_cost - std::min(cost[dealt[j]], max_cost)]++] = dealt[j];
         }
     }
+    tf_order = host_now() - tf0;
     // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks
     const size_t shard_cap = ((n + 7) / 8) << d->chunk_shift;
     size_t off = 0;
@@ -1990,6 +2036,7 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
     d->queue = (uint32_t *)(d->ctl + o_queue);
     d->queue_alt = c->tail ? (uint32_t *)(d->ctl + o_queue_alt) : d->queue;
     d->queue_cap = (uint32_t)shard_cap;
+    tf_alloc = host_now() - tf0;
     hipError_t q = hipSuccess;
     if (n) {
         if (c->copy == nullptr) { int rc = ensure_stage(c); if (rc) return rc; }
@@ -2000,6 +2047,9 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
     if (q == hipSuccess && c->copy) q = hipStreamSynchronize(c->copy);
     for (spl_ctx::Stage &st : c->stage) st.busy = false;
     if (q != hipSuccess) return spl_set_error(SPL_ERR_HIP, "read set upload: %s", hipGetErrorString(q));
+    if (c->stage_timing)
+        fprintf(stderr, "[spl_reads_finish] %zu chunks: layout kernels done and descriptors down at %.4f s, chunk order %.4f, control block (%.1f MB) %.4f, uploaded %.4f\n", n, tf_descs,
+                tf_order, off / 1e6, tf_alloc, host_now() - tf0);
     d->finished = true;
     return SPL_OK;
 }

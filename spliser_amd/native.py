@@ -49,7 +49,7 @@ EXPORTS = [
     "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_prof_enable", "spl_prof_report", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
-    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_cancel", "spl_bam_decline_reason", "spl_bam_close",
+    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_wait_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_cancel", "spl_bam_decline_reason", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
     "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append", "spl_tsv_append_many", "spl_fmt_fixed",
     "spl_bed_open", "spl_gff_open", "spl_text_close", "spl_text_rows", "spl_text_n_chrom", "spl_text_chrom_name", "spl_text_chrom",
@@ -594,15 +594,17 @@ class BamFile(object):
         return lib().spl_bam_decline_reason(self._h).decode("utf-8", "replace")
 
     def join_decoders(self):
-        """Waits for the device decoders started by ``decode_on_device_async`` / ``decode_on_devices_async``; -> True when the
-        reads are on the device(s)."""
-        for t in getattr(self, "_device_threads", None) or ([self._device_thread] if getattr(self, "_device_thread", None) is not None else []):
-            t.join()
-        if getattr(self, "_device_threads", None):
-            flag = ctypes.c_int(0)
-            _check(lib().spl_bam_decoded_on_device(self._h, ctypes.byref(flag)))
-            self.on_device = bool(flag.value)
-        return bool(self.on_device)
+        """Waits for the OUTCOME of the device decoders started by ``decode_on_device_async`` / ``decode_on_devices_async``; ->
+        True when the reads are on the device(s) and every reference is complete, False when the host threads have the file (they
+        may still be decoding it).  The decoders' threads themselves are joined by ``close``: what they give back on their way
+        out (buffers, streams, events, their context: 10-13 ms for a large file) nobody has to wait for."""
+        threads = getattr(self, "_device_threads", None) or ([self._device_thread] if getattr(self, "_device_thread", None) is not None else [])
+        if not threads:
+            return bool(getattr(self, "on_device", False))
+        flag = ctypes.c_int(0)
+        _check(lib().spl_bam_wait_device(self._h, ctypes.byref(flag)))
+        self.on_device = bool(flag.value)
+        return self.on_device
 
     def decode_on_device(self, ctx):
         """A file opened with ``defer=True``: inflate it and extract its records on the GPU of ``ctx`` (every reference is

@@ -186,6 +186,34 @@ def test_a_reservation_nobody_takes_up_ends_with_the_host_decoder(built, tmp_pat
     for c in names:
         _same(bam.reads(c), sets[c])
     bam.close()
+    # ... and whoever waits for the OUTCOME of the device decoders (process Step 3: join_decoders -> spl_bam_wait_device) is told
+    # "the host threads have it" as soon as that is so -- not after their decode, and not after the decoder thread's exit
+    bam = native.BamFile(path, threads=2, defer=True)
+    bam.decode_on_device_async(device=4096)
+    assert bam.join_decoders() is False
+    for c in names:
+        _same(bam.reads(c), sets[c])
+    bam.close()
+    bam = native.BamFile(path, threads=2, defer=True)
+    bam.decode_on_devices_async([4096, 4097])
+    assert bam.join_decoders() is False and bam.wait_all() is True
+    bam.close()
+    # a file closed while somebody waits for that outcome: the waiter returns (the reservation never taken up, the file cancelled)
+    import threading
+    bam = native.BamFile(path, threads=2, defer=True)
+    assert native.lib().spl_bam_reserve_device(bam._h) == 0
+    got = []
+    bam._device_thread = threading.Thread(target=lambda: None)
+    bam._device_thread.start()
+    w = threading.Thread(target=lambda: got.append(bam.join_decoders()))
+    w.start()
+    w.join(0.2)
+    assert w.is_alive()                        # (nobody has decided yet)
+    native.lib().spl_bam_cancel(bam._h)
+    native.lib().spl_bam_start(bam._h)
+    w.join(10)
+    assert not w.is_alive() and got == [False]
+    bam.close()
 
 
 def test_where_process_decodes(built, tmp_path, monkeypatch):
