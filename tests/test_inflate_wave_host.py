@@ -20,9 +20,11 @@ DEPS = [SRC, os.path.join(ROOT, "tests", "hostsim", "wave_emul.h"), os.path.join
 
 @pytest.fixture(scope="module")
 def emul():
-    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS):
-        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-Wno-unknown-pragmas", "-shared", "-fPIC", "-DEMUL_NO_MAIN", "-o", LIB, SRC, "-lz"])
-    lib = ctypes.CDLL(LIB)
+    extra = os.environ.get("SPL_EMUL_DEFINES", "").split()      # (kernel experiments: e.g. "-DSPLZ_RING=64 -DSPLZ_FIFO=128", the copying kernel's LDS per lane)
+    lib_path = LIB if not extra else LIB.replace(".so", "_exp.so")
+    if extra or not os.path.exists(lib_path) or any(os.path.getmtime(d) > os.path.getmtime(lib_path) for d in DEPS):
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-Wno-unknown-pragmas", "-shared", "-fPIC", "-DEMUL_NO_MAIN"] + extra + ["-o", lib_path, SRC, "-lz"])
+    lib = ctypes.CDLL(lib_path)
     lib.emul_inflate_blocks.restype = ctypes.c_int
     return lib
 
