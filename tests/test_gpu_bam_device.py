@@ -229,6 +229,45 @@ def test_inflate_windows_of_a_few_blocks(ctx, tmp_path, monkeypatch, window):
     dev.close()
 
 
+@pytest.mark.parametrize("bufs", [("1", "1"), ("2", "1"), ("1", "3"), ("3", "2"), ("4", "4")])
+def test_windows_in_flight(ctx, tmp_path, monkeypatch, bufs):
+    """A window's inflated bytes (copying kernel -> CRC32, scan, extraction) and its tokens (decoding kernel -> copying kernel) have
+    buffers of their own, n_buf and n_zw of them, and every kernel waits for the reader of ITS buffer (the decoding of window
+    k + n_zw for the copying of window k, the copying of window k + n_buf for the extraction of window k): any numbers of the two,
+    windows of 3 and 16 blocks on files of a few hundred, must give what the host decoder gives."""
+    monkeypatch.setenv("SPL_INFLATE_BUFFERS", bufs[0])
+    monkeypatch.setenv("SPL_INFLATE_TOKEN_BUFFERS", bufs[1])
+    for window, seq_mode, level, seed in (("3", 1, 1, 41), ("16", 2, 6, 42), ("3", 0, 6, 43)):
+        monkeypatch.setenv("SPL_INFLATE_WINDOW_BLOCKS", window)
+        names, sets = _random_sets(seed, 30_000, 3)
+        path = str(tmp_path / ("f%d.bam" % seed))
+        native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=level, threads=3, seq_mode=seq_mode)
+        assert _both(path, ctx, names, sets) is True
+
+
+@pytest.mark.parametrize("late", [None, "1"])
+def test_references_complete_before_the_decoder_has_cleared_up(tmp_path, monkeypatch, late):
+    """`process` counts as soon as the device decoder has made the file's references complete (spl_bam_wait_device), while the
+    decoder's thread still holds its streams, events and lists (and stands aside until the file is closed); SPL_PUBLISH_LATE=1 is
+    the order until round 4.  Either way the .SpliSER.tsv is the host decoder's, and closing the file ends the decoder's thread."""
+    import threading
+    from spliser_amd import synth
+    from spliser_amd.process import process, wait_deferred_close
+    if late:
+        monkeypatch.setenv("SPL_PUBLISH_LATE", late)
+    wl = synth.Workload("arabidopsis", scale=0.02, seed=14)
+    prefix = str(tmp_path / "p")
+    wl.write_inputs(prefix, bam=False)
+    native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=2, seq_mode=1)
+    n_before = threading.active_count()
+    tm = process(prefix + ".bam", prefix + ".bed", prefix + ".dev", annotationFile=prefix + ".gff", log=lambda m: None)
+    assert tm["bam_decode"] == "device"
+    process(prefix + ".bam", prefix + ".bed", prefix + ".host", annotationFile=prefix + ".gff", gpuDecode=False, log=lambda m: None)
+    assert open(prefix + ".dev.SpliSER.tsv").read() == open(prefix + ".host.SpliSER.tsv").read()
+    wait_deferred_close()
+    assert threading.active_count() <= n_before      # (no decoder thread left lingering behind a closed file)
+
+
 @pytest.mark.parametrize("window", [None, "5"])
 @pytest.mark.parametrize("devices", [(0, 0), (0, 0, 0, 0)])
 def test_process_decodes_in_shares(tmp_path, monkeypatch, devices, window):
