@@ -45,10 +45,16 @@ namespace splz {
 
 constexpr uint32_t ROOT_L = 9, ROOT_D = 6, ROOT_C = 7;
 constexpr uint32_t LUT_L = 852, LUT_D = 592; // entries: root table + the most sub-tables a valid code can need (zlib's ENOUGH_LENS / ENOUGH_DISTS for these roots)
-constexpr uint32_t SUB_BITS = 256;           // bits of DEFLATE data per lane and tile
+#ifndef SPLZ_SUB_BITS
+#define SPLZ_SUB_BITS 256
+#endif
+#ifndef SPLZ_TOKCAP
+#define SPLZ_TOKCAP 5120
+#endif
+constexpr uint32_t SUB_BITS = SPLZ_SUB_BITS; // bits of DEFLATE data per lane and tile (256; 512 measured: profiles/r04ae_k1_occupancy.txt)
 constexpr uint32_t TILE_WORDS = 64u * SUB_BITS / 32u;
 constexpr uint32_t TILE_PAD = 16;            // words behind the tile: a symbol that begins in the last subsequence ends there
-constexpr uint32_t TOKCAP = 5120;            // bytes of token stream per tile (a tile with more is cut short)
+constexpr uint32_t TOKCAP = SPLZ_TOKCAP;     // bytes of token stream per tile (a tile with more is cut short)
 constexpr uint32_t FL_OK = 0, FL_EOB = 1, FL_ERR = 2;
 constexpr uint32_t SYM_EOB = 256, SYM_MATCH = 257, SYM_BAD = 0xffffffffu;
 
@@ -59,7 +65,7 @@ struct Shared {
     uint32_t tile[TILE_WORDS + TILE_PAD]; // the compressed bytes being worked on (while tables are built: work space)
     uint32_t tok[TOKCAP / 4];             // the tile's stretch of the token stream (while a header is read: code lengths, the code-length code's table)
 };
-static_assert(SUB_BITS == 256u, "the tile is staged thirty-two bytes a lane");
+static_assert(SUB_BITS % 256u == 0u, "the tile is staged thirty-two bytes a lane and round");
 static_assert(TOKCAP >= 352u + 256u + 64u, "code lengths and the code-length code's table lie in tok while a header is read");
 
 // the order in which a dynamic header lists the lengths of the code-length code (RFC 1951, 3.2.7), five bits a place
@@ -411,13 +417,15 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             // the tile: 32 bytes per lane, and the words behind it (what lies beyond the block's data is never used: zeros will do,
             // and the image is readable for SPL_Z_IMAGE_PAD bytes past any block)
             {
-                const uint32_t o = byte0 + 32u * l;
-                uint64_t a = 0, b = 0, c = 0, d = 0;
-                if (o + 16u <= in_len + SPL_Z_IMAGE_PAD) { a = wv::ld64(in + o); b = wv::ld64(in + o + 8u); }
-                if (o + 32u <= in_len + SPL_Z_IMAGE_PAD) { c = wv::ld64(in + o + 16u); d = wv::ld64(in + o + 24u); }
-                uint32_t *t = sh.tile + 8u * l;
-                t[0] = (uint32_t)a; t[1] = (uint32_t)(a >> 32); t[2] = (uint32_t)b; t[3] = (uint32_t)(b >> 32);
-                t[4] = (uint32_t)c; t[5] = (uint32_t)(c >> 32); t[6] = (uint32_t)d; t[7] = (uint32_t)(d >> 32);
+                for (uint32_t r = 0; r < SUB_BITS / 256u; ++r) {
+                    const uint32_t o = byte0 + 32u * (l + 64u * r);
+                    uint64_t a = 0, b = 0, c = 0, d = 0;
+                    if (o + 16u <= in_len + SPL_Z_IMAGE_PAD) { a = wv::ld64(in + o); b = wv::ld64(in + o + 8u); }
+                    if (o + 32u <= in_len + SPL_Z_IMAGE_PAD) { c = wv::ld64(in + o + 16u); d = wv::ld64(in + o + 24u); }
+                    uint32_t *t = sh.tile + 8u * (l + 64u * r);
+                    t[0] = (uint32_t)a; t[1] = (uint32_t)(a >> 32); t[2] = (uint32_t)b; t[3] = (uint32_t)(b >> 32);
+                    t[4] = (uint32_t)c; t[5] = (uint32_t)(c >> 32); t[6] = (uint32_t)d; t[7] = (uint32_t)(d >> 32);
+                }
                 if (l < TILE_PAD / 4u) {
                     const uint32_t o2 = byte0 + TILE_WORDS * 4u + 16u * l;
                     uint64_t e = 0, f = 0;
