@@ -499,6 +499,7 @@ struct spl_bam {
     bool shares_on_device = false;
     std::atomic<bool> cancel{false};       // spl_bam_cancel: whoever decodes stops at the next batch / window; nobody starts
     bool reserved = false;     // claim == 1 on behalf of a spl_bam_decode_device call that is still to come
+    bool decoders_apart = false; // the device decoders run on threads of their own (spl_bam_reserve_device was called): somebody else waits for their outcome
     int claim = 0;             // 0 = nobody decodes yet (deferred open), 1 = the device decoder is at it, 2 = host worker started / arrays adopted
     uint64_t header_bytes = 0; // magic, text and reference dictionary: the first record starts here in the inflated stream
     std::string path;
@@ -1140,6 +1141,7 @@ extern "C" int spl_bam_reserve_device(spl_bam *bam)
     if (bam->claim != 0) return spl_set_error(SPL_ERR_ARG, "spl_bam_reserve_device: the file is being decoded already");
     bam->claim = 1;
     bam->reserved = true;
+    bam->decoders_apart = true;
     return SPL_OK;
 }
 // Why the device decoder did not take the file (spl_capi.cpp's to_host): kept for whoever tells the user (process.py logs it once)
@@ -1180,6 +1182,7 @@ extern "C" int spl_bam_wait_device(spl_bam *bam, int *on_device_out)
 void spl_bam_linger(spl_bam *bam, double seconds)
 {
     std::unique_lock<std::mutex> lock(bam->mu);
+    if (!bam->decoders_apart) return; // (the decoder's caller is the one who goes on with the reads: nobody to stand aside for)
     (void)bam->cv.wait_for(lock, std::chrono::duration<double>(seconds), [&]() { return bam->cancel.load(std::memory_order_acquire); });
 }
 

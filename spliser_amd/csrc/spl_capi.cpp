@@ -1343,8 +1343,8 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&freed[k], hipEventDisableTiming);
             }
             if (e == hipSuccess) e = hipEventCreateWithFlags(&setup, hipEventDisableTiming);
-            piece.assign(n_pieces, nullptr);
-            for (size_t k = 0; k < n_pieces && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&piece[k], hipEventDisableTiming);
+            piece.assign(n_pieces, nullptr); // (a piece's event is made by the reader that sends the piece, just before it is recorded: 430 of them
+                                             //  made here were 35-50 ms of a new process's call before its first byte was on its way)
             dec.assign(1, nullptr);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&dec[0], hipEventDisableTiming);
             k2.assign(1, nullptr);
@@ -1402,12 +1402,14 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         return e;
     };
     HIP_TRY(look_at_free());
+    double t_stage = 0, t_image = 0, t_pipe = 0, t_early_bufs = 0, t_early = 0; // (SPL_BAM_TIMING: the way to the first window, seconds after the call began)
     // The file's bytes: page cache -> staging buffer -> device.  One reader thread per staging buffer: it preads its pieces (a
     // piece = what a buffer holds, dealt round-robin), sends each on its way itself and records the piece's event behind it.
     // (a reader fills its buffer from the page cache at 8-10 GB/s before the copy engine takes 0.6 ms to empty it: three readers
     //  bring 25-40 GB/s, and since the kernels got through a window in 16 ms a large file waited for its bytes: six for those)
     if (n_bytes >= ((size_t)4 << 30) && !getenv("SPL_STAGE_BUFFERS")) { rc = grow_stage(c, 6); if (rc) return rc; }
     const size_t n_stage = c->stage.size();
+    t_stage = host_now() - t_begin;
     // On the device the file exists as a RING of pieces, not whole: only the Huffman decoding reads it, a window of blocks at a
     // time, so a piece's slot is given to the piece R further on as soon as the last window that reads it has been decoded --
     // device memory for about four windows' worth of the file (3.4 GB of a 14 GB file's) instead of all of it, whatever the
@@ -1452,12 +1454,14 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     }
     HIP_TRY(d_image.get(ring * slot + SPL_Z_IMAGE_PAD, c->copy));
     used_b += ring * slot;
+    t_image = host_now() - t_begin;
     if (timing) fprintf(stderr, "[spl_bam_decode_device] device %d: the file's %.1f MB as %zu pieces of %.1f MB, %zu slots on the device (%.1f MB)%s\n", c->device, n_bytes / 1e6, n_pieces,
                         piece / 1e6, ring, ring * slot / 1e6, ring < n_pieces ? "" : ": all of it");
     int n_copy = 1; // streams the copying kernels take turns on (1: one window's copies behind the other's)
     if (const char *e = getenv("SPL_INFLATE_COPY_STREAMS")) n_copy = std::min(NCOPY, std::max(1, atoi(e)));
     const bool two_up = getenv("SPL_UPLOAD_STREAMS") && atoi(getenv("SPL_UPLOAD_STREAMS")) >= 2; // (the file's pieces on two streams in turn)
     HIP_TRY(pipe.make(n_pieces, n_copy, two_up));
+    t_pipe = host_now() - t_begin;
     std::vector<hipError_t> errs(n_stage, hipSuccess);
     std::vector<std::atomic<int>> sent(n_pieces); // piece k's copy and event are in the copy stream's queue (or will never be: errs)
     for (auto &f : sent) f.store(0, std::memory_order_relaxed);
@@ -1496,6 +1500,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 copy_slice(0, &job);
                 errs[t] = hipMemcpyAsync(d_img + (k % ring) * slot, st.host, n, hipMemcpyHostToDevice, up);
                 if (errs[t] == hipSuccess) { errs[t] = hipEventRecord(st.done, up); st.busy = true; }
+                if (errs[t] == hipSuccess) errs[t] = hipEventCreateWithFlags(&pipe.piece[k], hipEventDisableTiming); // (piece k is this reader's alone; whoever waits for it looks after sent[k])
                 if (errs[t] == hipSuccess) errs[t] = hipEventRecord(pipe.piece[k], up);
             }
             if (errs[t] != hipSuccess) reader_failed.store(1, std::memory_order_release);
@@ -1558,6 +1563,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 HIP_TRY(d_stream[0].get(HEAD + (uint64_t)b_most * 65536u + 256, c->copy)); // (no block inflates to more than 64 KiB)
                 HIP_TRY(d_zwork[0].get(work0, c->copy));
                 used_b += (size_t)HEAD + b_most * 65536u + work0;
+                t_early_bufs = host_now() - t_begin;
                 HIP_TRY(d_blocks0.get(sizeof(spl_zblock) * b1, c->copy));
                 HIP_TRY(d_status0.get(4 * b1, c->copy));
                 HIP_TRY(hipMemcpyAsync(d_blocks0.p, blocks0.data(), sizeof(spl_zblock) * b1, hipMemcpyHostToDevice, pipe.a));
@@ -1583,6 +1589,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 }
                 HIP_TRY(hipEventRecord(pipe.k2[0], pipe.cp[0]));
                 early = b1;
+                t_early = host_now() - t_begin;
             }
         }
     }
@@ -1913,6 +1920,8 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     if (timing) fprintf(stderr, "[spl_bam_decode_device] device %d: blocks %zu..%zu, %.1f MB -> %.1f MB inflated in %zu window%s, %llu placed records of %lld: %.4f s\n", c->device, lo, hi,
                         n_bytes / 1e6, (stream_len - stream_begin) / 1e6, n_win, n_win == 1 ? "" : "s", (unsigned long long)n_rec, (long long)n_all, host_now() - t_begin);
     if (timing) {
+        fprintf(stderr, "[spl_bam_decode_device] device %d: staging buffers at %.4f s, the ring's memory %.4f, streams and events %.4f, the first window's buffers %.4f, its kernels on their streams %.4f\n",
+                c->device, t_stage, t_image, t_pipe, t_early_bufs, t_early);
         fprintf(stderr, "[spl_bam_decode_device] device %d: directory at %.4f s, block list %.4f, buffers %.4f, set up %.4f; windows scanned at", c->device, t_walked, t_blocks, t_bufs, t_setup);
         for (double t : t_win) fprintf(stderr, " %.3f", t);
         fprintf(stderr, " s\n");
