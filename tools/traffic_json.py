@@ -22,8 +22,11 @@ def mean(counter, sub):
                 vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     if not vals:
         return None, 0
-    name = max(vals, key=lambda k: len(vals[k]))
-    return sum(vals[name]) / len(vals[name]), len(vals[name])
+    # the mean over ALL launches of the kernel, whichever of its instantiations a shard's read set takes (a set of 64 M reads and
+    # more is cut into chunks of twice the size: another instantiation) -- bench.py's algorithmic bytes per launch are the mean
+    # over the shards' launches as well
+    every = [v for name in vals for v in vals[name]]
+    return sum(every) / len(every), len(every)
 
 
 fetch, n = mean("FETCH_SIZE", "fetch")
