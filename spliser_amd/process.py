@@ -227,12 +227,13 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                         stamp("decoder joined")
                     if whole:
                         dr = laid[k_sh] if k_sh in laid else lay_out(k_sh)
-                        if k_sh + 1 < len(shards):
-                            lay_out(k_sh + 1)      # (the next shard's layout kernels run while this one is finished, counted and brought down)
                         stamp("reads laid out")
                         try:
                             dr.finish()
                             stamp("read set finished")
+                            if k_sh + 1 < len(shards):
+                                lay_out(k_sh + 1)  # (the next shard's layout kernels run while this one is counted and brought down -- put on their
+                                                   #  stream only now: this shard's chunk descriptors come down the same stream, and stood behind them)
                             ctx.count_launch(ds, dr, stranded, combine_mode)
                             ctx.sse_launch(ds, is_beta2_cryptic)
                             beta1, b2r, _ = ds.counters()
