@@ -1345,10 +1345,12 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             if (e == hipSuccess) e = hipEventCreateWithFlags(&setup, hipEventDisableTiming);
             piece.assign(n_pieces, nullptr); // (a piece's event is made by the reader that sends the piece, just before it is recorded: 430 of them
                                              //  made here were 35-50 ms of a new process's call before its first byte was on its way)
-            dec.assign(1, nullptr);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&dec[0], hipEventDisableTiming);
-            k2.assign(1, nullptr);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&k2[0], hipEventDisableTiming);
+            dec.assign(2, nullptr); // (the first two windows' are needed before the number of windows is known)
+            k2.assign(2, nullptr);
+            for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+                e = hipEventCreateWithFlags(&dec[(size_t)k], hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&k2[(size_t)k], hipEventDisableTiming);
+            }
             return e;
         }
         hipError_t make_windows(size_t n_win)
@@ -1532,7 +1534,9 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     const uint64_t HEAD = (uint64_t)8 << 20; // room in front of a window's bytes for what the window before left unfinished
     const uint8_t *const image0 = d_image.as<uint8_t>(); // (a block's `in` is its place in the ring)
     size_t pieces_waited = 0;
-    size_t early = 0; // blocks of the first window if it has been launched already (0: not)
+    size_t early = 0;  // blocks of the first window if it has been launched already (0: not)
+    size_t early2 = 0; // where the second window ends if ITS decoding kernel has been launched as well (0: not)
+    struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } walker; // (the rest of the directory, walked beside the second window's launch)
     for (size_t t = 0; t < n_stage; ++t) crew.threads.emplace_back(reader, t);
     // where a window that begins with block b0 ends: win_blocks blocks on, or where its bytes in the file would not fit a quarter of the ring
     auto window_end = [&](const std::vector<uint64_t> &off, size_t b0, size_t n_all) {
@@ -1547,7 +1551,11 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     if (!share && !getenv("SPL_INFLATE_NO_EARLY")) {
         const size_t n_known = spl_bam_block_count(bam);
         if (n_known >= win_blocks || (n_known >= 2 && spl_bam_walk_complete(bam))) {
-            std::vector<uint64_t> off0(std::min(win_blocks, n_known));
+            // (two windows' worth of the list when the directory so far holds them: the second window's decoding kernel goes out early too)
+            int early_zw = 2;
+            if (const char *e = getenv("SPL_INFLATE_TOKEN_BUFFERS")) early_zw = atoi(e);
+            const bool two = n_known >= 2 * win_blocks && early_zw >= 2 && !getenv("SPL_INFLATE_ONE_EARLY");
+            std::vector<uint64_t> off0(two ? 2 * win_blocks : std::min(win_blocks, n_known));
             blocks0.resize(off0.size());
             for (size_t i = 0; i < off0.size(); ++i) {
                 spl_bam_block_info bi;
@@ -1555,8 +1563,9 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 off0[i] = bi.data_off;
                 blocks0[i].in = ring_at(bi.data_off); blocks0[i].out = bi.uoff; blocks0[i].in_len = bi.data_len; blocks0[i].out_len = bi.isize; blocks0[i].crc = bi.crc; blocks0[i].pad = 0;
             }
-            const size_t b1 = window_end(off0, 0, off0.size()), b_most = off0.size(); // (b_most: what any window of this file can have -- the buffers serve later windows too)
-            blocks0.resize(b1);
+            const size_t b1 = window_end(off0, 0, off0.size()), b_most = std::min(win_blocks, n_known); // (b_most: what any window of this file can have -- the buffers serve later windows too)
+            const size_t b2 = two ? window_end(off0, b1, off0.size()) : b1; // (where the second window ends)
+            blocks0.resize(b2);
             const size_t work0 = spl_dev_inflate_work_bytes((uint32_t)b_most);
             HIP_TRY(look_at_free());
             if ((double)HEAD + (double)b_most * 65536.0 + (double)work0 + 2.0 * slack < (double)free_b) {
@@ -1564,10 +1573,10 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 HIP_TRY(d_zwork[0].get(work0, c->copy));
                 used_b += (size_t)HEAD + b_most * 65536u + work0;
                 t_early_bufs = host_now() - t_begin;
-                HIP_TRY(d_blocks0.get(sizeof(spl_zblock) * b1, c->copy));
-                HIP_TRY(d_status0.get(4 * b1, c->copy));
-                HIP_TRY(hipMemcpyAsync(d_blocks0.p, blocks0.data(), sizeof(spl_zblock) * b1, hipMemcpyHostToDevice, pipe.a));
-                HIP_TRY(hipMemsetAsync(d_status0.p, 0xff, 4 * b1, pipe.a));
+                HIP_TRY(d_blocks0.get(sizeof(spl_zblock) * b2, c->copy));
+                HIP_TRY(d_status0.get(4 * b2, c->copy));
+                HIP_TRY(hipMemcpyAsync(d_blocks0.p, blocks0.data(), sizeof(spl_zblock) * b2, hipMemcpyHostToDevice, pipe.a));
+                HIP_TRY(hipMemsetAsync(d_status0.p, 0xff, 4 * b2, pipe.a));
                 const size_t need = std::min(n_pieces, piece_of(off0[b1 - 1]) + 1); // (the piece its last block begins in holds all of it)
                 for (; pieces_waited < need; ++pieces_waited) {
                     wait_sent(pieces_waited);
@@ -1590,12 +1599,37 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 HIP_TRY(hipEventRecord(pipe.k2[0], pipe.cp[0]));
                 early = b1;
                 t_early = host_now() - t_begin;
+                // The second window's Huffman decoding behind the first's, before the directory is complete: the walk of the rest
+                // (25-30 ms of a large file, on a thread of its own from here) and the list of all blocks (10 ms) kept the host away
+                // from its loop until the first window's kernels had long finished -- 30 ms of an idle device at the start of a
+                // call whose clock is the decoding kernels one behind the other (profiles/r04ap_second_window_early.txt).
+                // Its copying kernel, CRC32 and the rest are the loop's (they need the second byte buffer and the file's lists).
+                if (b2 > b1) HIP_TRY(look_at_free());
+                if (b2 > b1 && (double)work0 + 2.0 * slack < (double)free_b) {
+                    walker.t = std::thread([&]() { const double w0 = host_now(); walk_rc = spl_bam_walk_all(bam); t_walk = host_now() - w0; });
+                    HIP_TRY(d_zwork[1].get(work0, c->copy));
+                    used_b += work0;
+                    const size_t need2 = std::min(n_pieces, piece_of(off0[b2 - 1]) + 1);
+                    for (; pieces_waited < need2; ++pieces_waited) {
+                        wait_sent(pieces_waited);
+                        if (reader_failed.load(std::memory_order_acquire)) { for (hipError_t e : errs) HIP_TRY(e); }
+                        HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.piece[pieces_waited], 0));
+                    }
+                    {
+                        splprof::Scope p("spl_inflate_decode_kernel", pipe.a, (double)(off0[b2 - 1] + blocks0[b2 - 1].in_len - off0[b1]) + (double)(blocks0[b2 - 1].out + blocks0[b2 - 1].out_len - blocks0[b1].out));
+                        HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks0.as<spl_zblock>() + b1, (uint32_t)(b2 - b1), d_status0.as<uint32_t>() + b1, d_zwork[1].p, pipe.a));
+                    }
+                    HIP_TRY(hipEventRecord(pipe.k1[1], pipe.a));
+                    HIP_TRY(hipEventRecord(pipe.dec[1], pipe.a));
+                    early2 = b2;
+                }
             }
         }
     }
     if (!share) {
-        { const double w0 = host_now(); walk_rc = spl_bam_walk_all(bam); t_walk = host_now() - w0; } // (what the early part left)
-        if (timing) fprintf(stderr, "[spl_bam_decode_device] (the directory walk took %.4f s)\n", t_walk);
+        if (walker.t.joinable()) walker.t.join();
+        else { const double w0 = host_now(); walk_rc = spl_bam_walk_all(bam); t_walk = host_now() - w0; } // (what the early part left)
+        if (timing) fprintf(stderr, "[spl_bam_decode_device] (the directory walk took %.4f s%s)\n", t_walk, early2 ? ", beside the second window's launch" : "");
         if (walk_rc) return to_host("block directory");
         fill_whole(bam, sh);
     }
@@ -1623,10 +1657,12 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     while (win_at.back() < n_blocks) win_at.push_back(window_end(foff, win_at.back(), n_blocks));
     const size_t n_win = win_at.size() - 1;
     if (early && early != win_at[1]) return to_host("the first window changed under the decoder"); // (cannot happen: the directory only grows)
+    if (early2 && (n_win < 2 || early2 != win_at[2])) return to_host("the second window changed under the decoder");
     HIP_TRY(pipe.make_windows(n_win));
     for (size_t w = 0; w < n_win; ++w) // (a piece is read last by the window of the last block that begins in it; pieces without one: by the window before)
         for (size_t pc = piece_of(foff[win_at[w]]), pe = piece_of(foff[win_at[w + 1] - 1]); pc <= pe && pc < n_pieces; ++pc) piece_last_win[pc] = (uint32_t)w;
-    launched_pub.store(early ? 1 : 0, std::memory_order_release);
+    const size_t n_early = early2 ? 2 : early ? 1 : 0; // windows whose decoding kernel is out already: they work on the early list of blocks and its status words
+    launched_pub.store(n_early, std::memory_order_release);
     windows_known.store(1, std::memory_order_release);
     up_wake();
     uint64_t win_cap = 0;
@@ -1655,7 +1691,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     for (int k = 0; k < std::max(n_buf, n_zw); ++k) {
         if (k == 0 && early) continue; // (the first window has its buffers, large enough for any)
         if (k < n_buf) HIP_TRY(d_stream[k].get(HEAD + win_cap + 256, c->copy));
-        if (k < n_zw) HIP_TRY(d_zwork[k].get(work_bytes, c->copy));
+        if (k < n_zw && !(k == 1 && early2)) HIP_TRY(d_zwork[k].get(work_bytes, c->copy)); // (the second window's tokens have theirs if its decoding went out early)
     }
     // where the placed records of a window's blocks begin (scan -> extraction, one window at a time on stream B): room for a window's
     // blocks and what an 8 MB carry can hold of ordinary ones; a window with more blocks than that is extracted by walking
@@ -1682,10 +1718,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     HIP_TRY(hipMemsetAsync(d_maxend.p, 0, 8 * (size_t)std::max(n_ref, 1), pipe.b));
     HIP_TRY(hipMemsetAsync(d_nbounds.p, 0, 4, pipe.b));
     HIP_TRY(hipEventRecord(pipe.setup, pipe.b));
-    if (early) { // what the first window's kernels said about its blocks: to its place among the file's, when they have said it
-        HIP_TRY(hipStreamWaitEvent(pipe.b, pipe.k2[0], 0));
-        HIP_TRY(hipMemcpyAsync(d_status.p, d_status0.p, 4 * early, hipMemcpyDeviceToDevice, pipe.b));
-    }
+    // (what the early windows' kernels said about their blocks goes to its place among the file's when they have said it: the loop, behind the window's copying kernel)
     HIP_TRY(hipStreamWaitEvent(pipe.a, pipe.setup, 0));
     for (int k = 0; k < n_copy; ++k) HIP_TRY(hipStreamWaitEvent(pipe.cp[k], pipe.setup, 0));
     const uint64_t H = spl_bam_header_end(bam);
@@ -1756,9 +1789,11 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         hipStream_t cs = pipe.cp[k % (size_t)n_copy];
         HIP_TRY(hipStreamWaitEvent(cs, pipe.k1[k % (size_t)n_zw], 0));
         if (k >= (size_t)n_buf) HIP_TRY(hipStreamWaitEvent(cs, pipe.freed[k % (size_t)n_buf], 0));
+        const bool from_early = k < n_early; // (its decoding kernel left the blocks' status in the early list's words)
         {
             splprof::Scope p("spl_inflate_copy_kernel", cs, (double)(blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out));
-            HIP_TRY((hipError_t)spl_dev_launch_inflate_copy(d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_zw].p, cs));
+            HIP_TRY((hipError_t)spl_dev_launch_inflate_copy((from_early ? d_blocks0 : d_blocks).as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k),
+                                                            (from_early ? d_status0 : d_status).as<uint32_t>() + b0, d_zwork[k % (size_t)n_zw].p, cs));
         }
         HIP_TRY(hipEventRecord(pipe.k2[k], cs));
         return SPL_OK;
@@ -1772,7 +1807,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     // (phase 2).  A record of any other reference anywhere else would be extracted by nobody: such a file goes to the host.
     int edge_phase = 0;
     size_t carry = 0; // the first block whose records are not all extracted yet
-    size_t launched = early ? 1 : 0, copying = early ? 1 : 0; // windows whose decoding / whose copying kernel has been put on its stream
+    size_t launched = n_early, copying = early ? 1 : 0; // windows whose decoding / whose copying kernel has been put on its stream
     std::vector<double> t_win; // (SPL_BAM_TIMING: when each window's scan was back on the host)
     const double t_setup = host_now() - t_begin;
     for (size_t k = 0; k < n_win; ++k) {
@@ -1805,6 +1840,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         uint8_t *const stream0 = stream0_of(k);
         const size_t s0 = k == 0 ? b0 : carry; // scan and extraction begin with what the window before left
         HIP_TRY(hipStreamWaitEvent(pipe.b, pipe.k2[k], 0));
+        if (k < n_early) HIP_TRY(hipMemcpyAsync(d_status.as<uint32_t>() + b0, d_status0.as<uint32_t>() + b0, 4 * (size_t)nb, hipMemcpyDeviceToDevice, pipe.b)); // (an early window's status words: to their place among the file's)
         const double win_out = (double)(win_end - blocks[b0].out);
         { splprof::Scope p("spl_crc32_kernel", pipe.b, win_out); HIP_TRY((hipError_t)spl_dev_launch_crc32(stream0, d_blocks.as<spl_zblock>() + b0, nb, d_status.as<uint32_t>() + b0, pipe.b)); }
         {
