@@ -66,11 +66,7 @@ __device__ __forceinline__ uint32_t my_chunk()
 // A chunk's descriptor as wave-uniform values (the index is uniform: scalar loads).
 // (the addresses arrive as integers: typed as GLOBAL pointers, or every load through them is a flat_load -- and a wave with a
 //  flat load outstanding can only ever wait for ALL its memory operations, which is the end of any prefetching)
-#ifdef SPL_NO_GLOBAL
-#define SPL_GLOBAL
-#else
 #define SPL_GLOBAL __attribute__((address_space(1)))
-#endif
 typedef SPL_GLOBAL const char spl_gchar;
 typedef SPL_GLOBAL const uint32_t spl_gu32;
 typedef uint32_t spl_u32x2 __attribute__((ext_vector_type(2))); // (built-in vectors: loadable from any address space)
@@ -472,11 +468,6 @@ __device__ __forceinline__ void commit_key(const spl_hot_params &p, spl_lds_i32 
         const int arr = (int)(key & 3u);
         const int32_t d = (int32_t)(key >> 2);
         const uint32_t loc = (uint32_t)(d - wbase);
-#ifdef SPL_EXP_FLAT_COMMIT
-        // (experiment, never in the product: every lane adds to a word of its own -- what the kernel would cost if no two lanes
-        //  of an LDS atomic ever met in a bank; results are wrong by construction)
-        { const uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); __hip_atomic_fetch_add(lds + ln, amount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
-#endif
         // (an LDS-typed pointer: ds_add on one side, a global atomic on the other, never a flat atomic on a selected address)
         if (loc <= (uint32_t)WIN) __hip_atomic_fetch_add(lds + (arr * (WIN + 1) + (int)loc), amount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + d], amount);
@@ -676,23 +667,8 @@ __device__ __forceinline__ bool rivals_inline2(const spl_hot_params &p, spl_lds_
 // to the four waves.  No LDS staging, no barriers inside the loop, few registers and a small argument block (everything the
 // literal paths need lives in spl_count_literal_kernel): reads that need a literal decision -- unmapped-but-placed records and
 // reads with a junction end that has rival sites the junction table cannot settle -- are appended to a queue.
-// Development aid, compiled out of the product (make EXTRA=-DSPL_PHASE_TIMING): wave 0 of every workgroup stamps the
-// 100 MHz wall clock at the phase borders of the range kernel; tools/phase_report.py turns the dump into a timeline.
-#if defined(SPL_PHASE_TIMING) || defined(SPL_PHASE_LITERAL)
-__device__ uint64_t *g_phase;
-#endif
-#ifdef SPL_PHASE_TIMING
-#define SPL_PHASE_DECL uint64_t ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#ifndef SPL_PHASE_SET
-#define SPL_PHASE_SET 0xc3 /* which stamps are taken (bit per slot): every stamp costs two SGPRs the kernel does not have */
-#endif
-#define SPL_PHASE(slot) do { if ((SPL_PHASE_SET >> (slot)) & 1) ph_[slot] = wall_clock64(); } while (0) /* constant slots only */
-#define SPL_PHASE_WRITE do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) g_phase[(size_t)blockIdx.x * 8 + k_] = ph_[k_]; } while (0)
-#else
-#define SPL_PHASE_DECL do { } while (0)
-#define SPL_PHASE(slot) do { } while (0)
-#define SPL_PHASE_WRITE do { } while (0)
-#endif
+// (The instrumented builds this kernel was tuned with -- phase stamps, knock-out variants -- are a patch, not part of this
+//  source: profiles/experiments/r05_range_kernel_instrumentation.patch.)
 
 // Default (AGG false): plain LDS atomics, 64 VGPRs = 8 waves per SIMD (the kernel lives on how many waves are there to
 // cover each other's memory trips and barriers; the register cap costs nothing -- no scratch).  Merging the atomics of
@@ -713,10 +689,6 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     constexpr uint32_t SEG = BIG ? SPL_WAVE_READS_BIG : SPL_WAVE_READS;
     __shared__ uint16_t s_q[NWAVE * SEG];
     __shared__ uint32_t s_qcnt[NWAVE], s_qbase;
-#ifdef SPL_PHASE_WAVES
-    __shared__ uint64_t s_wave_t[3 * NWAVE];
-    __shared__ uint32_t s_wave_n[NWAVE];
-#endif
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, in an SGPR
     const uint32_t seg0 = wave * SEG;
     const uint32_t lane = (uint32_t)threadIdx.x & 63u;
@@ -756,8 +728,6 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     const bool live = chunk_slot < p.n_chunks;
     const uint32_t chunk = live ? p.chunk_order[chunk_slot] : 0u;
     const ChunkView cv = chunk_view(p.chunk_meta + chunk);
-    SPL_PHASE_DECL;
-    SPL_PHASE(0);
     // Wave-iterations of the chunk.  A wave-iteration takes 64 * K consecutive reads of ONE run, K per lane: K = 4 for simple reads
     // (32 bytes of records per lane), 2 for once-spliced ones (32 bytes), 1 for the rest (24 bytes).  Run r has iters[r]
     // wave-iterations, the first being number g_start[r] of the chunk.
@@ -805,23 +775,9 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     { const int32_t fp = cv.first_pos + cv.shift; uint32_t nv; const spl_dbk e = p.dbucket[dbk_slot(p, fp - 1)]; dbk_resolve(p, fp - 1, e, wbase, nv); }
     for (int j = tid; j < NARR * (WIN + 1); j += SPL_BLOCK) lds[j] = 0;
     __syncthreads();
-    SPL_PHASE(1);
     // (the first two words of a bucket entry: all a boundary needs that is no junction end)
-#if defined(SPL_EXP_NOGATHER)
-    // (experiment, never in the product: bucket entries made up from the slot instead of loaded -- no site anywhere, so no range
-    //  and no list either: what the loops cost without their second memory trip and everything behind it)
-    auto fake = [](uint32_t s) { spl_dbk e; e.first = s & 0u; e.occ = 0u; e.rival = 0u; asm volatile("" : "+v"(e.first), "+v"(e.occ), "+v"(e.rival)); return e; };
-    auto dbk2 = [&](uint32_t s) { return fake(s); };
-    auto dbk3 = [&](uint32_t s) { return fake(s); };
-#elif defined(SPL_EXP_NOCOMMIT)
-    // (experiment: the entries are loaded and waited for, then made to say "no site here": the second trip without what follows it)
-    auto hide = [](spl_dbk e) { asm volatile("" :: "v"(e.first), "v"(e.occ), "v"(e.rival)); spl_dbk z; z.first = 0u; z.occ = 0u; z.rival = 0u; asm volatile("" : "+v"(z.first), "+v"(z.occ), "+v"(z.rival)); return z; };
-    auto dbk2 = [&](uint32_t s) { const uint32_t *q = (const uint32_t *)(p.dbucket + s); spl_dbk e; e.first = q[0]; e.occ = q[1]; e.rival = 0u; return hide(e); };
-    auto dbk3 = [&](uint32_t s) { return hide(p.dbucket[s]); };
-#else
     auto dbk2 = [&](uint32_t s) { const uint32_t *q = (const uint32_t *)(p.dbucket + s); spl_dbk e; e.first = q[0]; e.occ = q[1]; e.rival = 0u; return e; };
     auto dbk3 = [&](uint32_t s) { return p.dbucket[s]; };
-#endif
 
     {
         // One loop per run, the wave's iterations g = wave, wave + 4, ... running through all of them; the records of the NEXT
@@ -835,9 +791,6 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         // ---- simple reads (one aligned op, mapped, in range: the packer checked all that): two boundaries, one range,
         //      nothing else can happen.  Four of them per lane.
         for (; g < g_start[1]; g += NWAVE) {
-#ifdef SPL_EXP_SKIP
-            if (SPL_EXP_SKIP & 1) { asm volatile("" :: "v"(cu0.x), "v"(cu1.x)); fetch_next(); continue; } // (experiment, never in the product: the loop with its records read and nothing done)
-#endif
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t n_run = cv.start[1];
@@ -875,9 +828,6 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         // ---- once-spliced reads (aligned, N, aligned): the kinds are known, so are the arrays; three ranges
         //      and the junction-table look-up when an end of the junction has rivals.  Two of them per lane.
         for (; g < g_start[2]; g += NWAVE) {
-#ifdef SPL_EXP_SKIP
-            if (SPL_EXP_SKIP & 2) { asm volatile("" :: "v"(cu0.x), "v"(cu1.x)); fetch_next(); continue; }
-#endif
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t n_run = cv.start[2] - cv.start[1];
@@ -930,9 +880,6 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         // ---- twice-spliced reads (aligned, N, aligned, N, aligned; the record holds the five lengths): six boundaries,
         //      five ranges.  One read per lane.
         for (; g < g_start[3]; g += NWAVE) {
-#ifdef SPL_EXP_SKIP
-            if (SPL_EXP_SKIP & 4) { asm volatile("" :: "v"(cu0.x), "v"(cu1.x)); fetch_next(); continue; }
-#endif
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t slot = cv.start[2] + i0;     // of the read in its chunk, run order
@@ -982,9 +929,6 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             }
         }
         for (; g < g_total; g += NWAVE) {
-#ifdef SPL_EXP_SKIP
-            if (SPL_EXP_SKIP & 8) { asm volatile("" :: "v"(cu0.x), "v"(cu1.x)); fetch_next(); continue; }
-#endif
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t slot = cv.start[3] + i0;     // of the read in its chunk, run order
@@ -1065,24 +1009,12 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             const bool flagged = !literal && alive && rival;
             if (__any(literal || flagged)) push_front(literal || flagged, slot);
         }
-#ifdef SPL_PHASE_WAVES
-        if ((tid & 63) == 0) { // (development aid: when did each wave leave its loop, how long is its list)
-            s_wave_t[tid >> 6] = wall_clock64();
-            s_wave_n[tid >> 6] = n_back;
-        }
-#endif
         // Once- and twice-spliced reads with rivals, the wave's own, lanes dense: the junction table says which sites of the read's
         // window are affected and how (rivals_inline); what it cannot decide joins the literal list.  The list is read
         // from its growing end, so the front list can only ever grow into entries that are done with.
-#if defined(SPL_EXP_NO_LIST) || (defined(SPL_EXP_SKIP) && (SPL_EXP_SKIP & 16))
-        n_back = 0; // (experiment, never in the product: what the list pass costs -- 28 % of the kernel on config 2)
-#endif
         // (the list, read from its growing end, holds the twice-spliced reads)
         const uint32_t n_m2 = n_back;
         for (uint32_t r0 = 0; r0 < n_m2; r0 += 64u) {
-#ifdef SPL_EXP_SKIP
-            if (SPL_EXP_SKIP & 32) break; // (experiment: the twice-spliced reads' list left unread)
-#endif
             const uint32_t j = r0 + lane;
             bool undecided = false;
             uint32_t slot = 0;
@@ -1104,14 +1036,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             back_done = r0 + 64u < n_m2 ? r0 + 64u : n_m2;
             if (__any(undecided)) push_front(undecided, slot);
         }
-#ifdef SPL_PHASE_WAVES
-        if ((tid & 63) == 0) s_wave_t[2 * NWAVE + (tid >> 6)] = wall_clock64(); // (the twice-spliced reads' list is done)
-#endif
         // Once-spliced reads with rivals: the run once more, for the lanes that marked a read of theirs (fm_mnm).  An iteration's
         // records are asked for while the one before is worked on; what an iteration then waits for is its reads' table slots.
-#if defined(SPL_EXP_SKIP)
-        if (SPL_EXP_SKIP & 64) fm_mnm = 0;
-#endif
         if (__any(fm_mnm != 0u)) {
             const uint32_t n_run = cv.start[2] - cv.start[1];
             auto fetch_mnm = [&](uint32_t g2) {
@@ -1162,14 +1088,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         }
     }
     if ((tid & 63) == 0) s_qcnt[tid >> 6] = n_front;
-#ifdef SPL_PHASE_WAVES
-    if ((tid & 63) == 0) s_wave_t[NWAVE + (tid >> 6)] = wall_clock64();
-#endif
-    SPL_PHASE(6);
     __syncthreads();
-#ifdef SPL_PHASE_TAIL
-    SPL_PHASE(3); // with SPL_PHASE_TAIL slots 3 and 4 look inside the epilogue: barrier passed, queue handed over
-#endif
     // Hand the chunk's queue over: one returning atomic per workgroup on the counter of its XCD shard (8 counters, so
     // no single word sees more than a few reservations per microsecond), then a dense copy of packed indexes.
     // (Per-chunk regions without any atomic were tried: the range kernel gains 1 %, the literal kernel then has to walk
@@ -1195,9 +1114,6 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             dst[j] = first | (uint32_t)s_q[w * SEG + (j - base)];
         }
     }
-#ifdef SPL_PHASE_TAIL
-    SPL_PHASE(4);
-#endif
     for (int j = tid; j < NARR * (WIN + 1); j += SPL_BLOCK) {
         const int32_t v = lds[j];
         if (v) {
@@ -1205,24 +1121,6 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             atomicAdd(&p.diff[(int64_t)arr * p.diff_stride + wbase + loc], v);
         }
     }
-    SPL_PHASE(7);
-#ifdef SPL_PHASE_WAVES
-    // slots 1, 3, 4, 5: earliest / latest loop end over the waves, latest list end, longest list
-    {
-        uint64_t lo = ~0ull, hi = 0, hi2 = 0, nmax = 0;
-        for (int w = 0; w < NWAVE; ++w) {
-            lo = s_wave_t[w] < lo ? s_wave_t[w] : lo;
-            hi = s_wave_t[w] > hi ? s_wave_t[w] : hi;
-            hi2 = s_wave_t[NWAVE + w] > hi2 ? s_wave_t[NWAVE + w] : hi2;
-            nmax = s_wave_t[2 * NWAVE + w] > nmax ? s_wave_t[2 * NWAVE + w] : nmax; // (slot 5: the latest end of a twice-spliced list)
-        }
-        ph_[1] = lo; ph_[3] = hi; ph_[4] = hi2; ph_[5] = nmax;
-    }
-#endif
-#ifdef SPL_PHASE_TIMING
-    ph_[2] = (uint64_t)__builtin_amdgcn_s_getreg(0xF804) | ((uint64_t)__builtin_amdgcn_s_getreg(0xF814) << 32); // HW_ID, XCC_ID
-#endif
-    SPL_PHASE_WRITE;
 }
 
 namespace {
@@ -1236,16 +1134,10 @@ namespace {
 // covered with t+1 by an aligned block -> beta1-type.  Anything the table cannot decide exactly (a junction that is not
 // in the BED file but touches flagged sites, a rival that is itself a junction end of the read, entries marked complex,
 // combine mode) returns false and the read takes rivals_closed_form.  Updates go to the global difference arrays.
-#ifdef SPL_PHASE_LITERAL
-__device__ unsigned long long g_tp_fail[8]; // why reads leave the table path (development aid)
-#define SPL_TP_FAIL(code) do { atomicAdd(&g_tp_fail[code], 1ull); return false; } while (0)
-#else
-#define SPL_TP_FAIL(code) return false
-#endif
 template <bool STRANDED>
 __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int32_t pos, uint32_t flag, const uint32_t *ops, uint32_t n_ops)
 {
-    if (p.combine_mode) SPL_TP_FAIL(1);
+    if (p.combine_mode) return false;
     int32_t blk_a[SPL_CF_BLK], blk_b[SPL_CF_BLK], jl[SPL_CF_JUNC], jr[SPL_CF_JUNC];
     int n_blk = 0, n_j = 0;
     int32_t cur = pos;
@@ -1257,12 +1149,12 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
         const int32_t start = cur;
         cur += d;
         if (code == SPL_OP_N) {
-            if (n_j == SPL_CF_JUNC) SPL_TP_FAIL(2);
+            if (n_j == SPL_CF_JUNC) return false;
 #pragma unroll
             for (int j = 0; j < SPL_CF_JUNC; ++j) if (j == n_j) { jl[j] = start - 1; jr[j] = cur - 1; }
             ++n_j;
         } else if (code != SPL_OP_D && d >= 2) {
-            if (n_blk == SPL_CF_BLK) SPL_TP_FAIL(3);
+            if (n_blk == SPL_CF_BLK) return false;
 #pragma unroll
             for (int j = 0; j < SPL_CF_BLK; ++j) if (j == n_blk) { blk_a[j] = start; blk_b[j] = cur - 1; }
             ++n_blk;
@@ -1295,9 +1187,9 @@ __device__ __forceinline__ bool rivals_table_path(const spl_count_params &p, int
             if (ent.x == 0x80000000u) break;
         }
         if (found) {
-            if (ent.w & SPL_JF_COMPLEX) SPL_TP_FAIL(4);
-            if ((ent.w & SPL_JF_COUNT_MASK) > 16u) SPL_TP_FAIL(5);
-            if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) SPL_TP_FAIL(6);
+            if (ent.w & SPL_JF_COMPLEX) return false;
+            if ((ent.w & SPL_JF_COUNT_MASK) > 16u) return false;
+            if (!STRANDED && (ent.w & SPL_JF_MULTIROW)) return false;
             r_off[j] = ent.z; r_n[j] = ent.w & SPL_JF_COUNT_MASK;
         } // (not in the table: no site has this junction as a rival's -- the table is complete)
     }
@@ -1380,9 +1272,6 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
     // The 8 shard regions are walked as ONE index space (a wave must not pay the latency chain once per shard).
     // Entries are packed indexes: the read is taken from the range kernel's own arrays (one trip), its ops are inline
     // or start at the stored offset.
-#ifdef SPL_PHASE_LITERAL
-    uint64_t lt_[4] = {(uint64_t)wall_clock64(), 0, 0, 0};
-#endif
     uint32_t start[9];
     start[0] = 0;
 #pragma unroll
@@ -1418,34 +1307,14 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
                 ops = row;
             }
             if (rv.neg) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
-#ifdef SPL_PHASE_LITERAL
-            asm volatile("s_nop 0" ::"v"(pos), "v"(flag));
-            lt_[1] = wall_clock64(); // after the read's words arrived
-#endif
             int64_t ref_len; bool hn;
             spl_read_extent(ops, n_ops, &ref_len, &hn);
-#ifdef SPL_PHASE_LITERAL
-            asm volatile("s_nop 0" ::"v"((int32_t)ref_len));
-            lt_[2] = wall_clock64(); // after the ops were walked once
-#endif
             if ((int64_t)pos + ref_len > (int64_t)SPL_COORD_MAX) { atomicOr(p.err, SPL_DEV_ERR_RANGE); continue; }
             if (flag & 4u) { unmapped_read<STRANDED>(p, pos, flag, ops, n_ops); continue; }
-#ifdef SPL_PHASE_LITERAL
-            const bool tp_ = rivals_table_path<STRANDED>(p, pos, flag, ops, n_ops);
-            if (!tp_) rivals_literal<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
-            atomicAdd((unsigned long long *)&g_phase[(size_t)blockIdx.x * 8 + 4], tp_ ? 1ull : 0ull);
-            atomicAdd((unsigned long long *)&g_phase[(size_t)blockIdx.x * 8 + 6], !tp_ ? 1ull : 0ull);
-            continue;
-#endif
             if (rivals_table_path<STRANDED>(p, pos, flag, ops, n_ops)) continue;
             rivals_literal<STRANDED>(p, pos, flag, ops, n_ops, (int32_t)((int64_t)pos + (ref_len > 0 ? ref_len : 1) - 1));
         }
     }
-#ifdef SPL_PHASE_LITERAL
-    lt_[3] = wall_clock64();
-    if (threadIdx.x == 0) for (int k_ = 0; k_ < 4; ++k_) g_phase[(size_t)blockIdx.x * 8 + k_] = lt_[k_];
-    if (threadIdx.x == 0) g_phase[(size_t)blockIdx.x * 8 + 7] = (uint64_t)__popcll(__ballot(1)) + 1; // marks the row as written
-#endif
 }
 
 // =========================================================================================================
@@ -1809,16 +1678,6 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
         const bool big = h->chunk_shift == SPL_CHUNK_BIG_SHIFT;
         *lds_out = (p->stranded ? 4 * (SPL_WIN_STRANDED + 1) : 2 * (SPL_WIN + 1)) * 4 + SPL_WAVES * (big ? SPL_WAVE_READS_BIG : SPL_WAVE_READS) * 2 + 4 * SPL_WAVES + 4; // difference windows + the waves' lists
         const bool agg = (variant & 2) != 0;
-#ifdef SPL_PHASE_TIMING
-        static uint64_t *phase_buf = nullptr;
-        static size_t phase_cap = 0;
-        if (phase_cap < (size_t)slots * 8) {
-            if (phase_buf) (void)hipFree(phase_buf);
-            phase_cap = (size_t)slots * 8;
-            if (hipMalloc((void **)&phase_buf, phase_cap * 8) != hipSuccess) return (int)hipErrorOutOfMemory;
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), &phase_buf, sizeof(phase_buf));
-        }
-#endif
 #define SPL_LAUNCH_RANGES(S, A, B) hipExtLaunchKernelGGL((spl_count_ranges_kernel<S, A, B>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h)
         if (p->stranded) {
             if (agg) { if (big) SPL_LAUNCH_RANGES(true, true, true); else SPL_LAUNCH_RANGES(true, true, false); }
@@ -1828,15 +1687,6 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
             else { if (big) SPL_LAUNCH_RANGES(false, false, true); else SPL_LAUNCH_RANGES(false, false, false); }
         }
 #undef SPL_LAUNCH_RANGES
-#ifdef SPL_PHASE_TIMING
-        if (const char *path = getenv("SPL_PHASE_DUMP")) {
-            (void)hipStreamSynchronize(st);
-            uint64_t *host = (uint64_t *)malloc((size_t)slots * 64);
-            (void)hipMemcpy(host, phase_buf, (size_t)slots * 64, hipMemcpyDeviceToHost);
-            if (FILE *f = fopen(path, "wb")) { fwrite(host, 64, slots, f); fclose(f); }
-            free(host);
-        }
-#endif
     }
     return (int)hipGetLastError();
 }
@@ -1846,29 +1696,8 @@ extern "C" int spl_dev_launch_literal(const spl_count_params *p, const spl_queue
     if (p->n_reads <= 0 || p->n_sites <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t grid = SPL_LITERAL_WAVES;
-#ifdef SPL_PHASE_LITERAL
-    static uint64_t *phase_buf = nullptr;
-    if (!phase_buf) {
-        if (hipMalloc((void **)&phase_buf, (size_t)grid * 64) != hipSuccess) return (int)hipErrorOutOfMemory;
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), &phase_buf, sizeof(phase_buf));
-    }
-    (void)hipMemsetAsync(phase_buf, 0, (size_t)grid * 64, st);
-#endif
     if (p->stranded) hipLaunchKernelGGL(spl_count_literal_kernel<true>, dim3(grid), dim3(64), 0, st, *p, *q);
     else hipLaunchKernelGGL(spl_count_literal_kernel<false>, dim3(grid), dim3(64), 0, st, *p, *q);
-#ifdef SPL_PHASE_LITERAL
-    if (const char *path = getenv("SPL_PHASE_DUMP")) {
-        (void)hipStreamSynchronize(st);
-        uint64_t *host = (uint64_t *)malloc((size_t)grid * 64);
-        (void)hipMemcpy(host, phase_buf, (size_t)grid * 64, hipMemcpyDeviceToHost);
-        if (FILE *f = fopen(path, "wb")) { fwrite(host, 64, grid, f); fclose(f); }
-        free(host);
-        unsigned long long why[8];
-        (void)hipMemcpyFromSymbol(why, HIP_SYMBOL(g_tp_fail), sizeof(why));
-        fprintf(stderr, "table path left for: combine %llu, junctions %llu, blocks %llu, complex %llu, >16 rivals %llu, multirow %llu, unlisted+flag %llu (cumulative)\n",
-                why[1], why[2], why[3], why[4], why[5], why[6], why[7]);
-    }
-#endif
     return (int)hipGetLastError();
 }
 
