@@ -174,6 +174,21 @@ int spl_reads_add(spl_ctx *ctx, spl_dreads *dr, const spl_reads *reads, int32_t 
 int spl_reads_add_bam(spl_ctx *ctx, spl_dreads *dr, spl_bam *bam, int tid, int32_t pos_shift);
 int spl_reads_finish(spl_ctx *ctx, spl_dreads *dr);
 void spl_reads_free(spl_ctx *ctx, spl_dreads *dr);
+/* BAM-native reads RESIDENT IN HBM, as the arrays they are (what checkBam reads from a SAM line, SpliSER_v0_1_8.py:434-437, and
+ * nothing else): n_seg host segments laid end to end in device arrays pos / flag / cig_off / cigar -- what a decode on the
+ * device leaves (spl_bam_decode_device) and what SURVEY.md 8(d)'s "kernel-only from device-resident SoA" starts from.  A read
+ * set is laid out from them ON THE DEVICE (spl_devpack.hip: one kernel, every read fetched and classified once) by
+ * spl_reads_add_soa + spl_reads_finish; spl_reads_relayout runs that layout again into the same records (bench.py's step:
+ * arrays -> records -> counters, every step).  The handle may be freed while read sets made from it live (they share the arrays). */
+typedef struct spl_dsoa spl_dsoa;
+int spl_soa_upload(spl_ctx *ctx, int n_seg, const spl_reads *segs, spl_dsoa **out);
+void spl_soa_free(spl_ctx *ctx, spl_dsoa *soa);
+int spl_reads_add_soa(spl_ctx *ctx, spl_dreads *dr, spl_dsoa *soa, int seg, int32_t pos_shift);
+int spl_reads_relayout(spl_ctx *ctx, spl_dreads *dr);
+/* What the layout moves for a finished read set: the BAM-native arrays read (10 bytes a read + 4 an op) and the records written. */
+int spl_reads_layout_bytes(spl_ctx *ctx, const spl_dreads *dr, int64_t *soa_bytes_out, int64_t *record_bytes_out);
+/* ... and the durations of the layout kernel's launches since spl_kernel_timing_begin (call before spl_kernel_timing_collect) */
+int spl_layout_timing_collect(spl_ctx *ctx, float *ms_out, int capacity, int *n_out);
 /* The host packer alone (no GPU involved; diagnostic and test hook): sizes of what an upload of `reads` would send, and --
  * into buffers of those sizes, when given -- the bytes: chunk descriptors (32 bytes each: record offset u64, wide-op offset
  * u64, first POS i32, cost u32, reads per run u16[4]), the record blob, the wide ops. */

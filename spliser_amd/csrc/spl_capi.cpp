@@ -331,6 +331,8 @@ struct spl_ctx {
     std::vector<hipEvent_t> k_ev; // pairs
     int k_used = 0;
     bool k_on = false;
+    std::vector<hipEvent_t> l_ev; // ... and around the layout kernel (spl_devpack.hip), same switch
+    int l_used = 0;
 };
 
 struct spl_dsites {
@@ -387,35 +389,48 @@ struct spl_dsites {
     const double *sse_view = nullptr;   // what spl_sse_download hands out
 };
 
+struct DeviceReads;
 struct spl_dreads {
-    // A read set = segments (one reference of a BAM file, one caller array, ...) packed on the host into the chunked layout of
-    // spl_pack.h, each in a device allocation of its own with a coordinate shift of its own; the kernels see one flat list of
-    // chunk descriptors.
+    // A read set = segments (one reference of a BAM file, one caller array, ...) in the chunked layout of spl_pack.h, each with a
+    // coordinate shift of its own; the kernels see one flat list of chunk descriptors.  A segment packed on the HOST
+    // (add_segment) has a device allocation of its own; segments whose reads are on the device already, BAM-native
+    // (add_segment_device), are laid out there when the read set is finished: ONE launch of the layout kernel for all segments
+    // that come from the same arrays (a Group), into record slots of one slab.
     struct Segment {
-        char *slab = nullptr;       // records, then the wide ops
+        char *slab = nullptr;       // host-packed: records, then the wide ops
         uint64_t rec_bytes = 0, n_wide = 0;
         int64_t n_reads = 0, n_ops = 0;
         int32_t shift = 0;
-        std::vector<splpack::ChunkDesc> chunks;
-        // a segment laid out by the device packer: its chunk descriptors are still on the device (n_dev of them, then two words
-        // of totals) until the read set is finished -- nothing waits for the packer's kernels before that
-        splpack::ChunkDesc *d_descs = nullptr;
-        size_t n_dev = 0;
+        std::vector<splpack::ChunkDesc> chunks; // host-packed
+        int group = -1;             // laid out on the device: which group, which of its segments
+        size_t group_seg = 0;
+    };
+    struct Group {
+        DeviceReads *src = nullptr;          // (a reference is held: WIDE reads' ops are read from its arrays)
+        std::vector<spl_layout_seg> segs;
+        uint32_t n_chunks = 0;
+        char *slab = nullptr;                // n_chunks record slots
+        spl_layout_seg *d_segs = nullptr;    // the segments, then chunk -> segment
+        uint32_t *d_chunk_seg = nullptr;
     };
     std::vector<Segment> segs;
+    std::vector<Group> groups;
     int64_t n_reads = 0, n_cigar = 0;
     uint32_t n_chunks = 0;
+    uint32_t n_slots = 0;           // slots of the range kernel's grid: 8 * spl_order_per(n_chunks)
     uint32_t chunk_shift = SPL_CHUNK_SHIFT; // reads per chunk of this set (fixed when it is begun: spl_reads_begin_sized)
     bool finished = false;
-    char *ctl = nullptr;            // chunk descriptors, chunk order, the queues (allocated by spl_reads_finish)
+    char *ctl = nullptr;            // chunk descriptors, costs, chunk order, the queues (allocated by spl_reads_finish)
     spl_chunk_meta *meta = nullptr;
-    uint32_t *chunk_order = nullptr; // slot of an XCD slice -> chunk, longest first
+    uint32_t *cost = nullptr;
+    uint32_t *chunk_order = nullptr; // slot of an XCD share -> chunk, longest first (0xffffffff: none)
     uint32_t *queue = nullptr; // reads the range kernel hands to the literal kernel (the counters are with the site table)
     uint32_t *queue_alt = nullptr;     // ... and the buffer the NEXT pass writes while this pass's literal kernel still reads
     uint32_t *queue_total = nullptr;   // entries the last pass queued (written by its literal kernel)
     uint32_t queue_cap = 0;
     mutable int queue_turn = 0;        // which of the two the next pass takes
     mutable bool queued_pass = false;  // the last counting pass over this read set had a literal kernel
+    mutable int64_t tail_pass = -1;    // the context's pass number of the last counting pass over this set that has a tail on the tail stream
 };
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -508,6 +523,7 @@ extern "C" void spl_destroy(spl_ctx *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->k_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->l_ev) (void)hipEventDestroy(e);
     if (c->d_err) (void)hipFree(c->d_err);
     free_stage(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -569,8 +585,27 @@ extern "C" int spl_kernel_timing_begin(spl_ctx *c, int max_records)
         HIP_TRY(hipEventCreate(&e));
         c->k_ev.push_back(e);
     }
+    while ((int)c->l_ev.size() < 2 * max_records) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->l_ev.push_back(e);
+    }
     c->k_used = 0;
+    c->l_used = 0;
     c->k_on = max_records > 0;
+    return SPL_OK;
+}
+
+// The layout kernel's launches since spl_kernel_timing_begin (spl_reads_finish, spl_reads_relayout).  Call BEFORE
+// spl_kernel_timing_collect, which ends the recording.
+extern "C" int spl_layout_timing_collect(spl_ctx *c, float *ms_out, int capacity, int *n_out)
+{
+    if (!c || !n_out || (capacity > 0 && !ms_out)) return spl_set_error(SPL_ERR_ARG, "spl_layout_timing_collect: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int n = std::min(c->l_used, capacity);
+    for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms_out[i], c->l_ev[2 * i], c->l_ev[2 * i + 1]));
+    *n_out = n;
     return SPL_OK;
 }
 
@@ -1103,17 +1138,21 @@ void copy_slice(size_t k, void *arg)
 }
 } // namespace
 
-// What spl_bam_decode_device leaves on the device: the file's placed records, BAM-native, and where each reference's are.
+// What spl_bam_decode_device leaves on the device (and what spl_soa_upload brings up): placed records, BAM-native, and where each
+// reference's (segment's) are.  Shared: the file that decoded them holds a reference, and so does every read set that was laid
+// out from them (its WIDE reads' ops are read from the cigar array, not copied) -- the arrays go when the last one lets go.
 struct DeviceReads {
     int device = 0;
     void *pos = nullptr, *flag = nullptr, *cig_off = nullptr, *cigar = nullptr;
     int64_t n_rec = 0, n_ops = 0;
     std::vector<int64_t> ref_first, ref_n, ref_max, ref_ops;
+    std::atomic<int> refs{1};
 };
 static void free_device_reads(void *h)
 {
     DeviceReads *r = (DeviceReads *)h;
     if (!r) return;
+    if (r->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
     int cur = 0;
     const bool have = hipGetDevice(&cur) == hipSuccess;
     (void)hipSetDevice(r->device);
@@ -1163,11 +1202,11 @@ static int fetch_device_reads(void *h, int32_t **pos_out, uint16_t **flag_out, u
     return SPL_OK;
 }
 
-// One more segment of a read set, packed ON THE DEVICE from reads that are there already (add_segment is the host's version).
-// Three launches on the copy stream and no wait: room for the records is taken for the worst case (24 bytes a read: 288 GB are
-// there to be used), the chunk descriptors come to the host when the read set is finished.
-static int add_segment_device(spl_ctx *c, spl_dreads *d, const DeviceReads &dev, int64_t first, int64_t n_reads, int64_t n_ops, int32_t shift, int64_t max_end)
+// One more segment of a read set from reads that are on the device already, BAM-native (add_segment is the host's version):
+// only noted here -- the layout kernel runs once for all such segments when the read set is finished (finish_reads).
+static int add_segment_device(spl_ctx *c, spl_dreads *d, DeviceReads *dev, int64_t first, int64_t n_reads, int64_t n_ops, int32_t shift, int64_t max_end)
 {
+    (void)c;
     if (d->finished) return spl_set_error(SPL_ERR_ARG, "the read set is finished: no more segments");
     if (n_reads == 0) return SPL_OK;
     if (d->n_reads + n_reads > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "n_reads out of range (counters are 32-bit)");
@@ -1175,35 +1214,29 @@ static int add_segment_device(spl_ctx *c, spl_dreads *d, const DeviceReads &dev,
         return spl_set_error(SPL_ERR_RANGE, "a read ends beyond coordinate %d once its segment is moved by %d: split the shard (spliser_amd/shard.py)",
                              SPL_COORD_MAX, shift);
     if (n_ops > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops in one segment: use more shards");
-    int rc = ensure_stage(c);
-    if (rc) return rc;
+    if (first < 0 || first + n_reads > dev->n_rec) return spl_set_error(SPL_ERR_ARG, "segment outside the device arrays");
     const uint32_t chunk = 1u << d->chunk_shift;
-    const size_t n_chunks = (size_t)((n_reads + chunk - 1) / chunk);
+    const uint32_t n_chunks = spl_layout_seg_chunks(first, n_reads, chunk);
     if ((uint64_t)d->n_chunks + n_chunks > (1ull << (32 - d->chunk_shift))) return spl_set_error(SPL_ERR_ARG, "too many reads in one read set: use more shards");
-    const spl_devreads src{(const int32_t *)dev.pos, (const uint16_t *)dev.flag, (const uint32_t *)dev.cig_off, (const uint32_t *)dev.cigar};
+    size_t g = 0;
+    while (g < d->groups.size() && d->groups[g].src != dev) ++g;
+    if (g == d->groups.size()) {
+        d->groups.emplace_back();
+        d->groups[g].src = dev;
+        dev->refs.fetch_add(1, std::memory_order_relaxed);
+    }
+    spl_dreads::Group &grp = d->groups[g];
+    spl_layout_seg ls;
+    ls.first = first; ls.n_reads = n_reads; ls.chunk0 = d->n_chunks; ls.dev0 = grp.n_chunks; ls.n_chunks = n_chunks; ls.shift = shift;
+    grp.segs.push_back(ls);
+    grp.n_chunks += n_chunks;
     d->segs.emplace_back();
     spl_dreads::Segment &seg = d->segs.back();
-    const size_t rec_al = align_up((size_t)n_reads * SPL_REC_OTHER + n_chunks * 32);
-    const size_t slab_bytes = rec_al + 4 * (size_t)n_ops + 256;
-    hipError_t q = devmem::get((void **)&seg.d_descs, sizeof(splpack::ChunkDesc) * n_chunks + 16, 'd');
-    if (q == hipSuccess) q = devmem::get((void **)&seg.slab, slab_bytes, 'R');
-    const double in_bytes = 10.0 * (double)n_reads + 4.0 * (double)n_ops;
-    if (q == hipSuccess) { splprof::Scope p("spl_devpack_count_kernel", c->copy, in_bytes); q = (hipError_t)spl_dev_launch_pack_count(&src, first, n_reads, chunk, seg.d_descs, c->copy); }
-    if (q == hipSuccess) { splprof::Scope p("spl_devpack_offsets_kernel", c->copy, 32.0 * (double)n_chunks); q = (hipError_t)spl_dev_launch_pack_offsets(seg.d_descs, (uint32_t)n_chunks, seg.d_descs + n_chunks, c->copy); }
-    if (q == hipSuccess) { splprof::Scope p("spl_devpack_emit_kernel", c->copy, in_bytes + 8.0 * (double)n_reads + 4.0 * (double)n_ops); q = (hipError_t)spl_dev_launch_pack_emit(&src, first, n_reads, chunk, seg.d_descs, seg.slab, seg.slab + rec_al, c->copy); }
-    if (q != hipSuccess) {
-        (void)hipStreamSynchronize(c->copy);
-        devmem::put(seg.d_descs);
-        devmem::put(seg.slab);
-        d->segs.pop_back();
-        return spl_set_error(SPL_ERR_HIP, "device packer: %s", hipGetErrorString(q));
-    }
-    seg.n_dev = n_chunks;
-    seg.rec_bytes = rec_al; seg.n_wide = (uint64_t)n_ops; // (upper bounds: what finish_reads makes the wide ops' address from)
+    seg.group = (int)g; seg.group_seg = grp.segs.size() - 1;
     seg.n_reads = n_reads; seg.n_ops = n_ops; seg.shift = shift;
     d->n_reads += n_reads;
     d->n_cigar += n_ops;
-    d->n_chunks += (uint32_t)n_chunks;
+    d->n_chunks += n_chunks;
     return SPL_OK;
 }
 
@@ -1980,6 +2013,36 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     return told;
 }
 
+// The layout kernel over every group of a read set (segments whose reads are on the device, BAM-native), then the chunk order
+// of the range kernel from the chunks' costs: launches on the context's main stream, nothing for the host to wait for.
+static int launch_layout(spl_ctx *c, spl_dreads *d)
+{
+    const uint32_t chunk = 1u << d->chunk_shift;
+    for (spl_dreads::Group &g : d->groups) {
+        spl_layout_params lp;
+        lp.src = spl_devreads{(const int32_t *)g.src->pos, (const uint16_t *)g.src->flag, (const uint32_t *)g.src->cig_off, (const uint32_t *)g.src->cigar};
+        lp.n_rec = g.src->n_rec; lp.n_ops = g.src->n_ops;
+        lp.segs = g.d_segs; lp.chunk_seg = g.d_chunk_seg; lp.rec_base = (uint8_t *)g.slab; lp.meta = d->meta; lp.cost = d->cost;
+        int64_t n_reads = 0, n_ops = 0;
+        for (const spl_layout_seg &ls : g.segs) n_reads += ls.n_reads;
+        for (const spl_dreads::Segment &seg : d->segs) if (seg.group >= 0 && &d->groups[(size_t)seg.group] == &g) n_ops += seg.n_ops;
+        const bool timed = c->k_on && (size_t)(2 * c->l_used + 1) < c->l_ev.size();
+        int rc;
+        { // (bytes: the arrays read once, 10 bytes a read and 4 an op)
+            splprof::Scope prof("spl_layout_kernel", c->stream, 10.0 * (double)n_reads + 4.0 * (double)n_ops);
+            rc = spl_dev_launch_layout(&lp, g.n_chunks, chunk, c->stream, timed ? (void *)c->l_ev[2 * c->l_used] : nullptr, timed ? (void *)c->l_ev[2 * c->l_used + 1] : nullptr);
+        }
+        if (timed) c->l_used++;
+        if (rc) return spl_set_error(SPL_ERR_HIP, "layout kernel launch: %s", hipGetErrorString((hipError_t)rc));
+    }
+    if (d->n_chunks) {
+        splprof::Scope prof("spl_chunk_order_kernel", c->stream, 8.0 * (double)d->n_chunks);
+        const int rc = spl_dev_launch_chunk_order(d->cost, d->n_chunks, chunk, d->chunk_order, c->stream);
+        if (rc) return spl_set_error(SPL_ERR_HIP, "chunk order kernel launch: %s", hipGetErrorString((hipError_t)rc));
+    }
+    return SPL_OK;
+}
+
 // The flat chunk list of a read set, the chunk order of the range kernel and the queues.
 static int finish_reads(spl_ctx *c, spl_dreads *d)
 {
@@ -1994,109 +2057,90 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
     if (d->n_cigar > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops in one read set: use more shards");
     auto host_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tf0 = host_now();
-    double tf_descs = 0, tf_order = 0, tf_alloc = 0;
-    { // the chunk descriptors of segments the device packer laid out: to the host now (the packer's kernels are done by then)
-        hipError_t q = hipSuccess;
-        bool any = false;
-        for (spl_dreads::Segment &seg : d->segs)
-            if (seg.d_descs) {
-                seg.chunks.resize(seg.n_dev);
-                if (q == hipSuccess) q = hipMemcpyAsync(seg.chunks.data(), seg.d_descs, sizeof(splpack::ChunkDesc) * seg.n_dev, hipMemcpyDeviceToHost, c->copy);
-                any = true;
-            }
-        if (any) {
-            if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
-            // (the descriptors' device copies go back with the read set, spl_reads_free: giving a buffer back waits for the device, and here that is the next read set's layout kernels)
-            if (q != hipSuccess) return spl_set_error(SPL_ERR_HIP, "device packer: %s", hipGetErrorString(q));
-        }
-    }
-    tf_descs = host_now() - tf0;
     const size_t n = d->n_chunks;
-    std::vector<spl_chunk_meta> meta(n);
-    std::vector<uint32_t> cost(n), order(n);
-    size_t k = 0;
-    for (const spl_dreads::Segment &seg : d->segs) {
-        const uint64_t rec_al = align_up((size_t)seg.rec_bytes);
-        for (const splpack::ChunkDesc &cd : seg.chunks) {
-            spl_chunk_meta &m = meta[k];
-            m.rec = (uint64_t)(uintptr_t)seg.slab + cd.rec_off;
-            m.wide = (uint64_t)(uintptr_t)seg.slab + rec_al;
-            m.shift = seg.shift;
-            m.first_pos = cd.first_pos;
-            for (int r = 0; r < SPL_RC_RUNS; ++r) m.n[r] = cd.n[r];
-            cost[k++] = cd.cost;
-        }
-    }
-    // chunk order of the range kernel: its workgroup b works on slot (b & 7) * per + (b >> 3) (see my_chunk), i.e. XCD x -- the
-    // hardware deals workgroups round-robin over the eight -- walks slots [x * per, (x + 1) * per).  WHICH chunks an XCD gets
-    // decides when it is done, and the launch ends with the slowest of them: a contiguous eighth of the reads each (rounds 1-3)
-    // left one XCD with a third more work than the others on the human-scale sample -- the chunks over well-covered alternative
-    // exons, whose reads take the list pass, lie together -- and the launch's last fifth was that XCD alone (322 us against
-    // 240-255 for the other seven, profiles/r04n_range_xcd_balance.txt).  So the chunks are dealt to the XCDs in small blocks of
-    // consecutive chunks, round-robin: every stretch of the genome is spread over all eight (neighbouring chunks, which share
-    // lines of the position index, still go to one L2 together), whatever makes it expensive -- the cost estimate below knows the
-    // reads' classes, not their rivals.  Inside an XCD's share the chunks go longest first (stable counting sort on the cost).
-    {
-        const size_t grid = (n + 7) / 8 * 8, per = grid / 8;
-        size_t block = 8; // consecutive chunks that stay together
-        if (const char *e = getenv("SPL_XCD_BLOCK")) block = (size_t)std::max(1, atoi(e)); // (0 or less would be 1; a block as large as the read set = the contiguous eighths)
-        std::vector<uint32_t> dealt(n);
-        {
-            size_t quota[8], have[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (size_t x = 0; x < 8; ++x) quota[x] = std::min(per, n - std::min(n, x * per)); // (only the last slots of the grid may be empty: slot >= n)
-            std::vector<std::vector<uint32_t>> mine(8);
-            for (size_t j = 0; j < n; ++j) {
-                size_t x = block >= n ? std::min<size_t>(j / std::max<size_t>(per, 1), 7) : (j / block) & 7u;
-                for (int tries = 0; tries < 8 && have[x] >= quota[x]; ++tries) x = (x + 1) & 7u;
-                mine[x].push_back((uint32_t)j);
-                have[x]++;
-            }
-            size_t at = 0;
-            for (size_t x = 0; x < 8; ++x) { std::copy(mine[x].begin(), mine[x].end(), dealt.begin() + (ptrdiff_t)at); at += mine[x].size(); }
-        }
-        const uint32_t max_cost = (1u << d->chunk_shift) * SPL_W_WIDE;
-        std::vector<uint32_t> bucket((size_t)max_cost + 2);
-        for (size_t x = 0; x < 8; ++x) {
-            const size_t lo = std::min(x * per, n), hi = std::min(lo + per, n);
-            if (lo >= hi) continue;
-            std::fill(bucket.begin(), bucket.end(), 0u);
-            for (size_t j = lo; j < hi; ++j) bucket[max_cost - std::min(cost[dealt[j]], max_cost) + 1]++;
-            for (size_t b = 1; b < bucket.size(); ++b) bucket[b] += bucket[b - 1];
-            for (size_t j = lo; j < hi; ++j) order[lo + bucket[max_cost - std::min(cost[dealt[j]], max_cost)]++] = dealt[j];
-        }
-    }
-    tf_order = host_now() - tf0;
-    // literal queue: one region per XCD shard (workgroup index & 7), each big enough for all of that shard's chunks
-    const size_t shard_cap = ((n + 7) / 8) << d->chunk_shift;
+    const uint32_t per = spl_order_per((uint32_t)n);
+    d->n_slots = 8u * per;
+    // literal queue: one region per XCD share (workgroup index & 7), each big enough for all of that share's chunks
+    const size_t shard_cap = (size_t)per << d->chunk_shift;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
-    const size_t o_meta = take(sizeof(spl_chunk_meta) * std::max<size_t>(n, 1)), o_order = take(4 * std::max<size_t>(n, 1));
+    const size_t o_meta = take(sizeof(spl_chunk_meta) * std::max<size_t>(n, 1)), o_cost = take(4 * std::max<size_t>(n, 1)), o_order = take(4 * std::max<size_t>(d->n_slots, 1));
     const size_t o_total = take(4);
     const size_t o_queue = take(4 * 8 * shard_cap), o_queue_alt = take(c->tail ? 4 * 8 * shard_cap : 0);
     hipError_t e = devmem::get((void **)&d->ctl, std::max<size_t>(off, 256), 'c');
     if (e != hipSuccess) return spl_set_error(SPL_ERR_HIP, "hipMalloc(%zu) for the read set: %s", off, hipGetErrorString(e));
     d->meta = (spl_chunk_meta *)(d->ctl + o_meta);
+    d->cost = (uint32_t *)(d->ctl + o_cost);
     d->chunk_order = (uint32_t *)(d->ctl + o_order);
     d->queue_total = (uint32_t *)(d->ctl + o_total);
     d->queue = (uint32_t *)(d->ctl + o_queue);
     d->queue_alt = c->tail ? (uint32_t *)(d->ctl + o_queue_alt) : d->queue;
     d->queue_cap = (uint32_t)shard_cap;
-    tf_alloc = host_now() - tf0;
+    const double tf_alloc = host_now() - tf0;
+    // host-packed segments: their chunks' descriptors and costs go up (stretches of the flat lists)
     hipError_t q = hipSuccess;
-    if (n) {
-        if (c->copy == nullptr) { int rc = ensure_stage(c); if (rc) return rc; }
-        q = hipMemcpyAsync(d->meta, meta.data(), sizeof(spl_chunk_meta) * n, hipMemcpyHostToDevice, c->copy);
-        if (q == hipSuccess) q = hipMemcpyAsync(d->chunk_order, order.data(), 4 * n, hipMemcpyHostToDevice, c->copy);
+    std::vector<spl_chunk_meta> meta;
+    std::vector<uint32_t> cost;
+    bool host_segs = false;
+    {
+        size_t k = 0;
+        for (const spl_dreads::Segment &seg : d->segs) {
+            if (seg.group >= 0) { k += d->groups[(size_t)seg.group].segs[seg.group_seg].n_chunks; continue; }
+            if (seg.chunks.empty()) continue;
+            if (!host_segs) { meta.resize(n); cost.resize(n); host_segs = true; }
+            const uint64_t rec_al = align_up((size_t)seg.rec_bytes);
+            const size_t k0 = k;
+            for (const splpack::ChunkDesc &cd : seg.chunks) {
+                spl_chunk_meta &m = meta[k];
+                m.rec = (uint64_t)(uintptr_t)seg.slab + cd.rec_off;
+                m.wide = (uint64_t)(uintptr_t)seg.slab + rec_al;
+                m.shift = seg.shift;
+                m.first_pos = cd.first_pos;
+                for (int r = 0; r < SPL_RC_RUNS; ++r) m.n[r] = cd.n[r];
+                cost[k++] = cd.cost;
+            }
+            if (c->copy == nullptr) { int rc = ensure_stage(c); if (rc) return rc; }
+            if (q == hipSuccess) q = hipMemcpyAsync(d->meta + k0, meta.data() + k0, sizeof(spl_chunk_meta) * (k - k0), hipMemcpyHostToDevice, c->copy);
+            if (q == hipSuccess) q = hipMemcpyAsync(d->cost + k0, cost.data() + k0, 4 * (k - k0), hipMemcpyHostToDevice, c->copy);
+        }
     }
-    // (everything the segments queued on the copy stream is over with this; the vectors above die at return)
-    if (q == hipSuccess && c->copy) q = hipStreamSynchronize(c->copy);
+    // (everything the host-packed segments queued on the copy stream is over with this; the vectors above die at return)
+    if (q == hipSuccess && c->copy && (host_segs || !c->stage.empty())) q = hipStreamSynchronize(c->copy);
     for (spl_ctx::Stage &st : c->stage) st.busy = false;
     if (q != hipSuccess) return spl_set_error(SPL_ERR_HIP, "read set upload: %s", hipGetErrorString(q));
+    // segments on the device: record slots, the segment list and the chunk -> segment map of every group
+    const uint32_t chunk = 1u << d->chunk_shift;
+    for (spl_dreads::Group &g : d->groups) {
+        const size_t seg_bytes = align_up(sizeof(spl_layout_seg) * g.segs.size());
+        e = devmem::get((void **)&g.slab, SPL_LAYOUT_SLOT(chunk) * (size_t)g.n_chunks + 256, 'R');
+        if (e == hipSuccess) e = devmem::get((void **)&g.d_segs, seg_bytes + 4 * (size_t)g.n_chunks + 16, 'd');
+        if (e != hipSuccess) return spl_set_error(SPL_ERR_HIP, "hipMalloc for the device layout of %u chunks: %s", g.n_chunks, hipGetErrorString(e));
+        g.d_chunk_seg = (uint32_t *)((char *)g.d_segs + seg_bytes);
+        HIP_TRY(hipMemcpyAsync(g.d_segs, g.segs.data(), sizeof(spl_layout_seg) * g.segs.size(), hipMemcpyHostToDevice, c->stream)); // (g.segs lives as long as the read set)
+        const int rc = spl_dev_launch_layout_map(g.d_segs, (uint32_t)g.segs.size(), g.d_chunk_seg, c->stream);
+        if (rc) return spl_set_error(SPL_ERR_HIP, "layout map kernel launch: %s", hipGetErrorString((hipError_t)rc));
+    }
+    const int rc = launch_layout(c, d);
+    if (rc) return rc;
     if (c->stage_timing)
-        fprintf(stderr, "[spl_reads_finish] %zu chunks: layout kernels done and descriptors down at %.4f s, chunk order %.4f, control block (%.1f MB) %.4f, uploaded %.4f\n", n, tf_descs,
-                tf_order, off / 1e6, tf_alloc, host_now() - tf0);
+        fprintf(stderr, "[spl_reads_finish] %zu chunks (%zu group(s) laid out on the device): control block (%.1f MB) at %.4f s, launched %.4f\n", n, d->groups.size(), off / 1e6,
+                tf_alloc, host_now() - tf0);
     d->finished = true;
     return SPL_OK;
+}
+
+// The layout again, into the same record slots (bench.py's step: BAM-native arrays -> records -> counters, every step).
+extern "C" int spl_reads_relayout(spl_ctx *c, spl_dreads *d)
+{
+    if (!c || !d) return spl_set_error(SPL_ERR_ARG, "spl_reads_relayout: null argument");
+    if (!d->finished) return spl_set_error(SPL_ERR_ARG, "spl_reads_relayout: the read set is not finished (spl_reads_finish)");
+    if (d->groups.empty()) return spl_set_error(SPL_ERR_ARG, "spl_reads_relayout: no segment of this read set was laid out on the device");
+    HIP_TRY(hipSetDevice(c->device));
+    // The literal kernel of the last pass over THIS set reads the records this rewrites: wait for that tail, not for all of them
+    // (another shard's tail may run beside this layout).  Pass q's range kernel waited for tail q - 2, so a tail three passes
+    // back and more is over as far as the main stream is concerned.
+    if (c->tail && d->tail_pass >= 0 && (uint64_t)d->tail_pass + 3 > c->n_pass) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail[d->tail_pass % 4], 0));
+    return launch_layout(c, d);
 }
 
 static int source_of(const spl_reads *r, splpack::Source &src, int64_t *max_end, const char *who)
@@ -2182,11 +2226,11 @@ extern "C" int spl_reads_add_bam(spl_ctx *c, spl_dreads *d, spl_bam *bam, int ti
     HIP_TRY(hipSetDevice(c->device));
     int rc = spl_bam_wait_ref(bam, tid, nullptr, nullptr);
     if (rc) return rc;
-    if (const DeviceReads *dev = (const DeviceReads *)spl_bam_device_reads(bam, tid)) {
+    if (DeviceReads *dev = (DeviceReads *)spl_bam_device_reads(bam, tid)) {
         // decoded on this device, and the arrays are still there: laid out there, nothing crosses PCIe
         if (dev->device == c->device && tid >= 0 && (size_t)tid < dev->ref_n.size()) {
             const size_t t = (size_t)tid;
-            return add_segment_device(c, d, *dev, dev->ref_first[t], dev->ref_n[t], dev->ref_ops[t], pos_shift, dev->ref_n[t] ? dev->ref_max[t] : -1);
+            return add_segment_device(c, d, dev, dev->ref_first[t], dev->ref_n[t], dev->ref_ops[t], pos_shift, dev->ref_n[t] ? dev->ref_max[t] : -1);
         }
     }
     splpack::Source src;
@@ -2194,6 +2238,136 @@ extern "C" int spl_reads_add_bam(spl_ctx *c, spl_dreads *d, spl_bam *bam, int ti
     rc = spl_bam_source(bam, tid, &src, &max_end); // (the views are what the host packer reads; reads that stayed on another device come to the host here)
     if (rc) return rc;
     return add_segment(c, d, src, pos_shift, max_end);
+}
+
+// ---- BAM-native reads resident on the device, from a caller's arrays ------------------------------------------------
+struct spl_dsoa { DeviceReads *reads = nullptr; };
+
+namespace {
+struct MaxEndJob { const spl_reads *r; int64_t per; std::vector<int64_t> *best; };
+void max_end_slice(size_t k, void *arg)
+{
+    const MaxEndJob &j = *(const MaxEndJob *)arg;
+    const spl_reads *r = j.r;
+    const int64_t a = (int64_t)k * j.per, b = std::min(r->n_reads, a + j.per);
+    int64_t best = 0;
+    for (int64_t i = a; i < b; ++i) {
+        int64_t len = 0;
+        for (uint32_t q = r->cig_off[i]; q < r->cig_off[i + 1]; ++q) {
+            const uint32_t code = r->cigar[q] & 15u;
+            if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) len += r->cigar[q] >> 4;
+        }
+        const int64_t e = (int64_t)r->pos[i] + (len > 0 ? len : 1) - 1;
+        if (e > best && e <= (int64_t)SPL_COORD_MAX) best = e; // (reads out of range as they stand: the kernels report them)
+    }
+    (*j.best)[k] = best;
+}
+} // namespace
+
+extern "C" int spl_soa_upload(spl_ctx *c, int n_seg, const spl_reads *segs, spl_dsoa **out)
+{
+    if (!c || !out || n_seg < 0 || (n_seg && !segs)) return spl_set_error(SPL_ERR_ARG, "spl_soa_upload: null argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    int64_t n_rec = 0, n_ops = 0;
+    for (int k = 0; k < n_seg; ++k) {
+        const spl_reads &r = segs[k];
+        if (r.n_reads < 0) return spl_set_error(SPL_ERR_ARG, "spl_soa_upload: negative n_reads");
+        if (r.n_reads && (!r.pos || !r.flag || !r.cig_off)) return spl_set_error(SPL_ERR_ARG, "read set has null arrays");
+        if (r.n_reads && r.cig_off[0] != 0) return spl_set_error(SPL_ERR_ARG, "cig_off[0] must be 0");
+        if (r.n_reads && r.cig_off[r.n_reads] && !r.cigar) return spl_set_error(SPL_ERR_ARG, "cigar is null");
+        n_rec += r.n_reads;
+        n_ops += r.n_reads ? (int64_t)r.cig_off[r.n_reads] : 0;
+    }
+    if (n_ops > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops: use more shards");
+    DeviceReads *dev = new (std::nothrow) DeviceReads();
+    if (!dev) return spl_set_error(SPL_ERR_NOMEM, "out of host memory");
+    dev->device = c->device;
+    dev->n_rec = n_rec; dev->n_ops = n_ops;
+    const size_t ns = (size_t)std::max(n_seg, 1);
+    dev->ref_first.assign(ns, 0); dev->ref_n.assign(ns, 0); dev->ref_max.assign(ns, 0); dev->ref_ops.assign(ns, 0);
+    hipError_t q = devmem::get(&dev->pos, 4 * (size_t)n_rec + 64, 'b');
+    if (q == hipSuccess) q = devmem::get(&dev->flag, 2 * (size_t)n_rec + 64, 'b');
+    if (q == hipSuccess) q = devmem::get(&dev->cig_off, 4 * ((size_t)n_rec + 1) + 64, 'b');
+    if (q == hipSuccess) q = devmem::get(&dev->cigar, 4 * (size_t)n_ops + 64, 'b');
+    int64_t at = 0, op_at = 0;
+    std::vector<uint32_t> off; // (a segment's offsets, moved behind the ops of the segments before it)
+    for (int k = 0; k < n_seg && q == hipSuccess; ++k) {
+        const spl_reads &r = segs[k];
+        const int64_t g = r.n_reads ? (int64_t)r.cig_off[r.n_reads] : 0;
+        dev->ref_first[(size_t)k] = at; dev->ref_n[(size_t)k] = r.n_reads; dev->ref_ops[(size_t)k] = g;
+        if (r.n_reads) {
+            const size_t slices = (size_t)std::min<int64_t>(64, (r.n_reads + 65535) / 65536);
+            std::vector<int64_t> best(slices, 0);
+            MaxEndJob job{&r, (r.n_reads + (int64_t)slices - 1) / (int64_t)slices, &best};
+            splpack::parallel_for(slices, std::max(1, c->pack_threads), max_end_slice, &job);
+            dev->ref_max[(size_t)k] = *std::max_element(best.begin(), best.end());
+            q = hipMemcpy((int32_t *)dev->pos + at, r.pos, 4 * (size_t)r.n_reads, hipMemcpyHostToDevice);
+            if (q == hipSuccess) q = hipMemcpy((uint16_t *)dev->flag + at, r.flag, 2 * (size_t)r.n_reads, hipMemcpyHostToDevice);
+            if (q == hipSuccess && g) q = hipMemcpy((uint32_t *)dev->cigar + op_at, r.cigar, 4 * (size_t)g, hipMemcpyHostToDevice);
+            off.resize((size_t)r.n_reads);
+            for (int64_t i = 0; i < r.n_reads; ++i) off[(size_t)i] = (uint32_t)(op_at + r.cig_off[i]);
+            if (q == hipSuccess) q = hipMemcpy((uint32_t *)dev->cig_off + at, off.data(), 4 * (size_t)r.n_reads, hipMemcpyHostToDevice);
+        }
+        at += r.n_reads;
+        op_at += g;
+    }
+    const uint32_t last = (uint32_t)op_at;
+    if (q == hipSuccess) q = hipMemcpy((uint32_t *)dev->cig_off + at, &last, 4, hipMemcpyHostToDevice);
+    spl_dsoa *h = q == hipSuccess ? new (std::nothrow) spl_dsoa() : nullptr;
+    if (!h) {
+        free_device_reads(dev);
+        return q == hipSuccess ? spl_set_error(SPL_ERR_NOMEM, "out of host memory") : spl_set_error(SPL_ERR_HIP, "spl_soa_upload: %s", hipGetErrorString(q));
+    }
+    h->reads = dev;
+    *out = h;
+    return SPL_OK;
+}
+
+extern "C" void spl_soa_free(spl_ctx *c, spl_dsoa *soa)
+{
+    if (!soa) return;
+    if (c) (void)hipSetDevice(c->device);
+    free_device_reads(soa->reads); // (read sets laid out from the arrays keep them alive)
+    delete soa;
+}
+
+extern "C" int spl_reads_add_soa(spl_ctx *c, spl_dreads *d, spl_dsoa *soa, int seg, int32_t pos_shift)
+{
+    if (!c || !d || !soa) return spl_set_error(SPL_ERR_ARG, "spl_reads_add_soa: null argument");
+    DeviceReads *dev = soa->reads;
+    if (seg < 0 || (size_t)seg >= dev->ref_n.size()) return spl_set_error(SPL_ERR_ARG, "spl_reads_add_soa: no segment %d", seg);
+    if (dev->device != c->device) return spl_set_error(SPL_ERR_ARG, "spl_reads_add_soa: the arrays are on device %d, the context on %d", dev->device, c->device);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t t = (size_t)seg;
+    return add_segment_device(c, d, dev, dev->ref_first[t], dev->ref_n[t], dev->ref_ops[t], pos_shift, dev->ref_n[t] && pos_shift != 0 ? dev->ref_max[t] : -1);
+}
+
+// What the layout kernel moves for this read set: the BAM-native arrays it reads (10 bytes a read and 4 an op: every input
+// once) and the records it writes (the chunks' record areas as laid out, padding between runs included).  Waits for the layout.
+extern "C" int spl_reads_layout_bytes(spl_ctx *c, const spl_dreads *d, int64_t *soa_bytes_out, int64_t *record_bytes_out)
+{
+    if (!c || !d || !soa_bytes_out || !record_bytes_out) return spl_set_error(SPL_ERR_ARG, "spl_reads_layout_bytes: null argument");
+    if (!d->finished) return spl_set_error(SPL_ERR_ARG, "spl_reads_layout_bytes: the read set is not finished (spl_reads_finish)");
+    HIP_TRY(hipSetDevice(c->device));
+    int64_t soa = 0, rec = 0;
+    std::vector<spl_chunk_meta> meta(d->n_chunks);
+    if (d->n_chunks) {
+        HIP_TRY(hipMemcpyAsync(meta.data(), d->meta, sizeof(spl_chunk_meta) * d->n_chunks, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    size_t k = 0;
+    for (const spl_dreads::Segment &seg : d->segs) {
+        const size_t nc = seg.group >= 0 ? d->groups[(size_t)seg.group].segs[seg.group_seg].n_chunks : seg.chunks.size();
+        if (seg.group >= 0) {
+            soa += 10 * seg.n_reads + 4 * seg.n_ops;
+            for (size_t j = 0; j < nc; ++j) rec += (int64_t)spl_run_offset(meta[k + j].n, 4);
+        }
+        k += nc;
+    }
+    *soa_bytes_out = soa;
+    *record_bytes_out = rec;
+    return SPL_OK;
 }
 
 extern "C" int spl_reads_finish(spl_ctx *c, spl_dreads *d)
@@ -2210,7 +2384,8 @@ extern "C" void spl_reads_free(spl_ctx *c, spl_dreads *d)
     if (c && c->copy) (void)hipStreamSynchronize(c->copy);
     if (c && c->tail) (void)hipStreamSynchronize(c->tail); // (a tail may still be reading these buffers; hipFree itself waits
     if (c && c->stream) (void)hipStreamSynchronize(c->stream); //  for the device, this makes it independent of that)
-    for (spl_dreads::Segment &seg : d->segs) { devmem::put(seg.slab); devmem::put(seg.d_descs); }
+    for (spl_dreads::Segment &seg : d->segs) devmem::put(seg.slab);
+    for (spl_dreads::Group &g : d->groups) { devmem::put(g.slab); devmem::put(g.d_segs); free_device_reads(g.src); }
     devmem::put(d->ctl);
     delete d;
 }
@@ -2288,7 +2463,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     p.jhash = ds->jhash; p.jhash_mask = ds->jhash_mask; p.jrivals = ds->jrivals;
     spl_hot_params h;
     memset(&h, 0, sizeof(h));
-    h.n_chunks = p.n_chunks; h.chunk_shift = dr->chunk_shift; h.chunk_meta = dr->meta; h.chunk_order = dr->chunk_order; h.part_pos = ds->part_pos;
+    h.n_chunks = dr->n_slots; h.chunk_shift = dr->chunk_shift; h.chunk_meta = dr->meta; h.chunk_order = dr->chunk_order; h.part_pos = ds->part_pos;
     h.dbucket = p.dbucket; h.n_dbuckets = p.n_dbuckets; h.dbase = p.dbase; h.n_dpos = p.n_dpos;
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = queue; h.queue_n = ds->queue_n; h.err = ds->err;
@@ -2348,6 +2523,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
         ds->sse_fused = q.with_sse != 0;
         if (piped) {
             HIP_TRY(hipEventRecord(c->ev_tail[c->n_pass % 4], c->tail));
+            dr->tail_pass = (int64_t)c->n_pass;
             c->n_pass++;
             c->tail_pending = true;
         }

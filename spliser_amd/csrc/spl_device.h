@@ -104,10 +104,10 @@ struct spl_count_params {
 
 // Argument block of the range kernel: only what the straight-line path touches (keeps it out of SGPR spills).
 struct spl_hot_params {
-    uint32_t n_chunks;
+    uint32_t n_chunks;           // SLOTS of the chunk order = workgroups of the launch (8 equal XCD shares)
     uint32_t chunk_shift;        // log2 of the reads per chunk of this read set (SPL_CHUNK_SHIFT or SPL_CHUNK_BIG_SHIFT)
-    const spl_chunk_meta *chunk_meta; // [n_chunks] (spl_pack.h)
-    const uint32_t *chunk_order; // [n_chunks] slot of an XCD slice -> chunk, longest chunk first within every slice
+    const spl_chunk_meta *chunk_meta; // [chunks] (spl_pack.h)
+    const uint32_t *chunk_order; // [n_chunks] slot of an XCD share -> chunk, longest chunk first within every share; 0xffffffff = none
     const int32_t *part_pos;     // partner positions (CSR values): the twice-spliced junction-table pass scans a rival's list
     const spl_dbk *dbucket;    // 32 bp buckets
     uint32_t n_dbuckets;

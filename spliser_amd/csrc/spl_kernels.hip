@@ -725,8 +725,9 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     // many as the chip holds -- to fill the eighth of the workgroup slots that stand empty between a workgroup's end and its
     // successor's first records: 0.443 ms a launch against 0.39, with ten registers in scratch for the loop around the body.)
     const uint32_t chunk_slot = my_chunk();
-    const bool live = chunk_slot < p.n_chunks;
-    const uint32_t chunk = live ? p.chunk_order[chunk_slot] : 0u;
+    const uint32_t ordered = chunk_slot < p.n_chunks ? p.chunk_order[chunk_slot] : 0xffffffffu; // (p.n_chunks: the SLOTS; a share's last ones may be empty)
+    const bool live = ordered != 0xffffffffu;
+    const uint32_t chunk = live ? ordered : 0u;
     const ChunkView cv = chunk_view(p.chunk_meta + chunk);
     // Wave-iterations of the chunk.  A wave-iteration takes 64 * K consecutive reads of ONE run, K per lane: K = 4 for simple reads
     // (32 bytes of records per lane), 2 for once-spliced ones (32 bytes), 1 for the rest (24 bytes).  Run r has iters[r]
@@ -1664,8 +1665,9 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
     *grid_out = 0;
     *lds_out = 0;
     if (p->n_reads <= 0 || p->n_sites <= 0) return 0;
-    // grid = 8 * ceil(n_chunks / 8) so that every XCD's share has the same number of slots
-    const uint32_t slots = ((p->n_chunks + 7u) / 8u) * 8u;
+    // grid = 8 * ceil(n_chunks / 8) so that every XCD's share has the same number of slots; the range kernel's slots are the
+    // chunk order's (spl_chunk_order_kernel: whole blocks of 8 chunks per share, so a few more)
+    const uint32_t slots = variant == 1 ? ((p->n_chunks + 7u) / 8u) * 8u : h->n_chunks;
     const uint32_t grid = slots;
     *grid_out = (int)grid;
     hipStream_t st = (hipStream_t)stream;

@@ -108,8 +108,10 @@ struct Rec {
     uint32_t weight;
 };
 
-// What checkBam's walk depends on (:436-559), in the form the range kernel wants it.  One read.
-SPL_PACK_HD void classify(int32_t pos, uint32_t flag, const uint32_t *ops, uint32_t n_all, uint32_t wide_index, Rec &r)
+// What checkBam's walk depends on (:436-559), in the form the range kernel wants it.  One read; ops(k) is its k-th CIGAR op
+// (the host packer reads them through a pointer, the layout kernel out of its workgroup's LDS: one classifier, the same bytes).
+template <class Ops>
+SPL_PACK_HD void classify_ops(int32_t pos, uint32_t flag, const Ops &ops, uint32_t n_all, uint32_t wide_index, Rec &r)
 {
     uint32_t n = n_all;
     uint32_t c5[5] = {0xfu, 0xfu, 0xfu, 0xfu, 0xfu}; // the first five reference-consuming ops
@@ -118,15 +120,15 @@ SPL_PACK_HD void classify(int32_t pos, uint32_t flag, const uint32_t *ops, uint3
     if (n_all <= (uint32_t)SPL_PACK_SCAN_OPS) {
         m = 0;
         for (uint32_t k = 0; k < n_all; ++k) {
-            const uint32_t op = ops[k];
+            const uint32_t op = ops(k);
             if (kind_of(op) == 0u) continue;
-            if (m < 5u) c5[m] = op;
+            for (uint32_t q = 0; q < 5u; ++q) c5[q] = m == q ? op : c5[q]; // (no indexing by m: the five stay in registers on the device)
             ++m;
         }
         if (m <= 3u) { n = m; w0 = c5[0]; w1 = c5[1]; w2 = c5[2]; }
     }
     const bool wide = n > 3u;
-    if (wide) { w0 = ops[0]; w1 = ops[1]; w2 = wide_index; n = n_all; }
+    if (wide) { w0 = ops(0u); w1 = ops(1u); w2 = wide_index; n = n_all; }
     const bool placed = !(flag & 4u) && pos >= 0;
     const int64_t room = (int64_t)SPL_COORD_MAX - (int64_t)pos;
     r.n_wide = 0;
@@ -171,6 +173,15 @@ SPL_PACK_HD void classify(int32_t pos, uint32_t flag, const uint32_t *ops, uint3
     r.w[5] = n;
     r.n_wide = wide ? n_all : 0u;
     r.weight = wide ? SPL_W_WIDE : SPL_W_NARROW;
+}
+
+struct PtrOps {
+    const uint32_t *p;
+    SPL_PACK_HD uint32_t operator()(uint32_t k) const { return p[k]; }
+};
+SPL_PACK_HD void classify(int32_t pos, uint32_t flag, const uint32_t *ops, uint32_t n_all, uint32_t wide_index, Rec &r)
+{
+    classify_ops(pos, flag, PtrOps{ops}, n_all, wide_index, r);
 }
 
 } // namespace splrec

@@ -48,6 +48,7 @@ EXPORTS = [
     "spl_abi_version", "spl_last_error", "spl_device_count", "spl_trim", "spl_create", "spl_create_on_stream", "spl_destroy",
     "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_prof_enable", "spl_prof_report", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
+    "spl_soa_upload", "spl_soa_free", "spl_reads_add_soa", "spl_reads_relayout", "spl_layout_timing_collect", "spl_reads_layout_bytes",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_wait_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_cancel", "spl_bam_decline_reason", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
@@ -82,7 +83,7 @@ def lib():
         L.spl_bam_decline_reason.restype = ctypes.c_char_p
         L.spl_bam_ref_length.restype = ctypes.c_int64
         L.spl_bam_n_records.restype = ctypes.c_int64
-        for name in ("spl_destroy", "spl_sites_free", "spl_reads_free", "spl_bam_close", "spl_text_close", "spl_combine_close"):
+        for name in ("spl_destroy", "spl_sites_free", "spl_reads_free", "spl_soa_free", "spl_bam_close", "spl_text_close", "spl_combine_close"):
             getattr(L, name).restype = None
         for name in ("spl_combine_rows", "spl_combine_region_runs", "spl_combine_n_sites", "spl_combine_n_gap_sites", "spl_combine_skipped"):
             getattr(L, name).restype = ctypes.c_int64
@@ -244,6 +245,37 @@ class Context(object):
         _check(lib().spl_reads_upload_segments(self._h, ctypes.c_int(n), segs, shifts, ctypes.byref(h)))
         return DeviceReads(self, h, total)
 
+    def upload_soa(self, segments):
+        """segments: [ReadArrays-like with .c] -> the BAM-native arrays as they are, laid end to end in device memory
+        (``spl_soa_upload``): what a decode on the device leaves.  Read sets are laid out from them by the layout kernel
+        (``DeviceReads.add_soa`` + ``finish``; ``relayout``)."""
+        n = len(segments)
+        segs = (spl_reads * max(n, 1))()
+        for k, reads in enumerate(segments):
+            segs[k] = reads.c
+        h = ctypes.c_void_p()
+        _check(lib().spl_soa_upload(self._h, ctypes.c_int(n), segs, ctypes.byref(h)))
+        return DeviceSoA(self, h, [r.n for r in segments])
+
+    def layout_read_segments(self, soa, shifts):
+        """One read set from all segments of a ``DeviceSoA``, segment k moved by shifts[k]: the layout kernel's launch is
+        queued, nothing is waited for."""
+        dr = self.begin_reads(sum(soa.n))
+        try:
+            for k, shift in enumerate(shifts):
+                dr.add_soa(soa, k, shift)
+            return dr.finish()
+        except Exception:
+            dr.free()
+            raise
+
+    def layout_timing_collect(self, capacity=4096):
+        """Durations (ms) of the layout kernel's launches since ``kernel_timing_begin`` (before ``kernel_timing_collect``)."""
+        ms = (ctypes.c_float * capacity)()
+        n = ctypes.c_int(0)
+        _check(lib().spl_layout_timing_collect(self._h, ms, ctypes.c_int(capacity), ctypes.byref(n)))
+        return [ms[i] for i in range(n.value)]
+
     def count_launch(self, dsites, dreads, stranded=0, combine_mode=0, flags=0):
         opts = spl_opts(int(stranded), int(combine_mode), int(flags))
         _check(lib().spl_count_launch(self._h, dsites._h, dreads._h, ctypes.byref(opts)))
@@ -329,9 +361,24 @@ class DeviceReads(object):
         self.n += n_reads
         return n_reads
 
+    def add_soa(self, soa, seg, shift=0):
+        """One more segment: segment ``seg`` of BAM-native arrays resident on the device (``Context.upload_soa``)."""
+        _check(lib().spl_reads_add_soa(self.ctx._h, self._h, soa._h, ctypes.c_int(int(seg)), ctypes.c_int32(int(shift))))
+        self.n += soa.n[seg]
+
     def finish(self):
         _check(lib().spl_reads_finish(self.ctx._h, self._h))
         return self
+
+    def layout_bytes(self):
+        """-> (bytes of BAM-native arrays the layout kernel reads, bytes of records it writes) for this read set."""
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(lib().spl_reads_layout_bytes(self.ctx._h, self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def relayout(self):
+        """The layout kernel once more, into the same records (segments that were laid out on the device)."""
+        _check(lib().spl_reads_relayout(self.ctx._h, self._h))
 
     def __enter__(self):
         return self
@@ -360,6 +407,23 @@ class DeviceReads(object):
     def free(self):
         if self._h:
             lib().spl_reads_free(self.ctx._h, self._h)
+            self._h = ctypes.c_void_p()
+
+
+class DeviceSoA(object):
+    """BAM-native reads (pos, flag, cig_off, cigar) resident in HBM; ``n`` = reads per segment."""
+    def __init__(self, ctx, h, n):
+        self.ctx, self._h, self.n = ctx, h, list(n)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+    def free(self):
+        if self._h:
+            lib().spl_soa_free(self.ctx._h, self._h)
             self._h = ctypes.c_void_p()
 
 

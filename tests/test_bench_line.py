@@ -22,10 +22,16 @@ def canned(n_legs=9, world=1):
         "reads_per_sec": 222796814793.11566, "n_gpus": world, "steps": 20, "warmup": 5, "ms_per_step": 0.8976789016742259,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32/u32 counters, f64 SSE", "data": "synthetic",
         "config": {"workload": "human: 200000000 reads x 300463 splice sites, 24 chromosomes in 2 shard(s) on rank 0, 150 bp, unstranded",
-                   "scale": 1.0, "parallelism": "chromosome/sample shards, no collectives", "seed": 3, "step": "prose " * 30},
+                   "scale": 1.0, "parallelism": "chromosome/sample shards, no collectives", "seed": 3, "step": "BAM-native arrays resident in HBM -> layout + range + literal + scan/SSE kernels of every shard, barrier between steps"},
         "roofline": {"bound": "hbm", "achieved": 4640.32429710635, "peak": 8000.0, "unit": "GB/s", "frac": 0.5800405371382937,
                      "traffic": 1493338546, "traffic_from": "r03P_traffic.json", "kernel": "spl_count_ranges_kernel",
                      "kernel_ms_avg": 0.4034253999590874, "launches_timed": 40, "algorithmic_bytes_per_launch": 1872024685.5,
+                     "layout": {"kernel": "spl_layout_kernel", "kernel_ms_avg": 0.6123456789, "launches_timed": 40, "algorithmic_bytes_per_launch": 3120000000.5,
+                                "arrays_read": 1870000000.5, "records_written": 1250000000.0, "achieved": 5095.123456, "frac": 0.636890432, "what": "prose " * 20},
+                     "range": {"kernel": "spl_count_ranges_kernel", "kernel_ms_avg": 0.4034253999590874, "launches_timed": 40,
+                               "algorithmic_bytes_per_launch": 1872024685.5, "achieved": 4640.32429710635, "frac": 0.5800405371382937, "what": "prose " * 20},
+                     "count_only": {"what": "prose " * 20, "ms_per_step": 0.8976789016742259, "reads_per_sec": 222796814793.11566, "path_frac": 0.5213514214293551},
+                     "range_traffic": 1493338546, "range_traffic_from": "r03P_traffic.json", "second_kernel": "spl_count_ranges_kernel",
                      "grid": 15856, "block": 256, "lds_bytes": 17404,
                      "alone": {"kernel_ms_avg": 0.39, "frac": 0.5949139256781943, "how": "prose " * 20},
                      "path": {"what": "prose " * 20, "achieved": 4170.8, "frac": 0.5213514214293551},
@@ -49,7 +55,7 @@ def canned(n_legs=9, world=1):
 
 def check(text, want_legs):
     assert "\n" not in text
-    assert len(text.encode("utf-8")) < 4096, len(text)
+    assert len(text.encode("utf-8")) < bench.LINE_LIMIT, len(text)
     d = json.loads(text)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -81,7 +87,7 @@ def test_compact_line_eight_ranks():
 
 def test_compact_line_sheds_before_it_breaks():
     text = bench.compact_line(canned(n_legs=30))
-    assert len(text) < 4096
+    assert len(text) < bench.LINE_LIMIT
     d = json.loads(text)
     assert d["roofline"]["frac"] and d["cpu_baseline"]["value"] and d["e2e_dropped_for_length"] > 0
 

@@ -1,0 +1,172 @@
+"""The layout kernel (spliser_amd/csrc/spl_devpack.hip): BAM-native arrays resident on the device -> the chunked, class-partitioned
+records of spl_pack.h, one launch per read set, every read classified once -- held to the oracle through the counting kernels
+(SpliSER_v0_1_8.py:408-559 is what both restate), on reads made to cross every boundary the kernel has: threads of four reads,
+waves, chunks (cells of the grid over the arrays' indexes), segments that begin anywhere, CIGAR stretches longer than the
+workgroup's stage in LDS."""
+import numpy as np
+import pytest
+
+import helpers
+import randcase
+from spliser_amd import native, samio
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    native.build()
+    with native.Context(0) as c:
+        yield c
+
+
+def _repeat(rs, times, order=None):
+    """Every read `times` times (runs of each class cross threads, waves and chunks), optionally re-ordered."""
+    keep = np.repeat(np.arange(rs.n), times)
+    if order is not None:
+        keep = keep[order(len(keep))]
+    n_ops = np.diff(rs.cig_off.astype(np.int64))
+    op_idx = np.concatenate([np.arange(rs.cig_off[i], rs.cig_off[i + 1]) for i in keep]) if len(keep) else np.zeros(0, np.int64)
+    return samio.ReadSet(rs.pos[keep], rs.flag[keep], np.concatenate(([0], np.cumsum(n_ops[keep]))).astype(np.uint32),
+                         rs.cigar[op_idx.astype(np.int64)])
+
+
+def _arrays(rs):
+    return native.ReadArrays(rs.pos, rs.flag, rs.cig_off, rs.cigar)
+
+
+def _count_soa(ctx, arr, segments, stranded, combine=0, expected=0):
+    """segments: [(ReadSet, shift)] -> counters after upload_soa + layout + one counting pass."""
+    with ctx.upload_soa([_arrays(rs) for rs, _ in segments]) as soa:
+        with ctx.upload_sites(native.SiteArrays.from_chrom(arr)) as ds:
+            dr = ctx.begin_reads(expected)
+            try:
+                for k, (_, shift) in enumerate(segments):
+                    dr.add_soa(soa, k, shift)
+                dr.finish()
+                ctx.count_launch(ds, dr, stranded, combine)
+                first = ds.counters()
+                dr.relayout()                      # the same records once more, then the same counters
+                ctx.count_launch(ds, dr, stranded, combine)
+                again = ds.counters()
+            finally:
+                dr.free()
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
+    return first
+
+
+@pytest.mark.parametrize("seed", range(0, 12))
+@pytest.mark.parametrize("stranded", [0, 1, 2])
+@pytest.mark.parametrize("chunk", ["2048", "4096"])
+def test_layout_kernel_counts_like_the_oracle(seed, stranded, chunk, ctx, oracle_lib, monkeypatch):
+    arr, rs = randcase.make_case(seed + 900, bool(stranded))
+    if arr.n == 0 or rs.n == 0:
+        pytest.skip("empty case")
+    monkeypatch.setenv("SPL_FORCE_CHUNK", chunk)
+    big = _repeat(rs, 67)
+    ocount, _ = helpers.oracle_engine(oracle_lib)
+    want = ocount(arr, big, stranded, 0)
+    got = _count_soa(ctx, arr, [(big, 0)], stranded)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+
+
+@pytest.mark.parametrize("seed", range(0, 6))
+@pytest.mark.parametrize("combine", [0, 1])
+def test_segments_that_begin_anywhere(seed, combine, ctx, oracle_lib, monkeypatch):
+    """Several segments laid end to end in one set of arrays, their lengths anything (1, 3, 2047, 4097 ... reads), so that segments
+    begin and end at every offset inside a thread's four reads and inside a chunk's cell, and two segments share a cell; an
+    empty segment between them."""
+    arr, rs = randcase.make_case(seed + 950, False)
+    if arr.n == 0 or rs.n == 0:
+        pytest.skip("empty case")
+    rng = np.random.default_rng(seed)
+    big = _repeat(rs, 41)
+    cuts = sorted(set(int(x) for x in rng.integers(0, big.n, 5)) | {1, 3, min(big.n, 2047), min(big.n, 4097)})
+    bounds = [0] + [c for c in cuts if 0 < c < big.n] + [big.n]
+    segs = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        o0, o1 = int(big.cig_off[a]), int(big.cig_off[b])
+        segs.append(samio.ReadSet(big.pos[a:b], big.flag[a:b], (big.cig_off[a:b + 1] - o0).astype(np.uint32), big.cigar[o0:o1]))
+    segs.insert(2, samio.ReadSet.empty())
+    ocount, _ = helpers.oracle_engine(oracle_lib)
+    want = ocount(arr, big, 0, combine)
+    for chunk in ("2048", "4096"):
+        monkeypatch.setenv("SPL_FORCE_CHUNK", chunk)
+        got = _count_soa(ctx, arr, [(s, 0) for s in segs], 0, combine)
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g)
+
+
+def test_cigars_longer_than_the_stage(ctx, oracle_lib):
+    """Long-read CIGARs: hundreds of ops a read, so that a chunk's ops are many times the 4 ops a read the workgroup stages in
+    LDS -- ops beyond the stage come from memory, WIDE reads' ops are read by the counting kernels from the array they came in."""
+    arr, _ = randcase.make_case(977, False)
+    rng = np.random.default_rng(5)
+    lo, hi = int(arr.pos.min()) - 50, int(arr.pos.max()) + 50
+    pos, flag, offs, ops = [], [], [0], []
+    for i in range(9000):
+        start = int(rng.integers(max(1, lo - 400), hi))
+        n = int(rng.integers(1, 260)) if i % 3 else int(rng.integers(1, 4))
+        for k in range(n):
+            code = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 7, 8]))
+            ops.append((int(rng.integers(1, 9)) << 4) | code)
+        pos.append(start); flag.append(int(rng.choice([0, 16]))); offs.append(len(ops))
+    order = np.argsort(np.array(pos), kind="stable")
+    rs0 = samio.ReadSet(np.array(pos, np.int32), np.array(flag, np.uint16), np.array(offs, np.uint32), np.array(ops, np.uint32))
+    rs = _repeat(rs0, 1, order=lambda n: order)
+    ocount, _ = helpers.oracle_engine(oracle_lib)
+    want = ocount(arr, rs, 0, 0)
+    got = _count_soa(ctx, arr, [(rs, 0)], 0)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+
+
+def test_device_and_host_segments_in_one_read_set(ctx, oracle_lib):
+    """A read set may hold segments packed on the host (spl_reads_add) beside segments laid out on the device (spl_reads_add_soa):
+    one flat chunk list, one chunk order."""
+    arr, rs = randcase.make_case(931, False)
+    big = _repeat(rs, 53)
+    ocount, _ = helpers.oracle_engine(oracle_lib)
+    w1 = ocount(arr, big, 0, 0)
+    with ctx.upload_soa([_arrays(big)]) as soa, ctx.upload_sites(native.SiteArrays.from_chrom(arr)) as ds:
+        with ctx.begin_reads() as dr:
+            dr.add(_arrays(big), 0)
+            dr.add_soa(soa, 0, 0)
+            dr.add(_arrays(big), 0)
+            dr.finish()
+            ctx.count_launch(ds, dr, 0, 0)
+            got = ds.counters()
+    for w, g in zip(w1, got):
+        assert np.array_equal(3 * w.astype(np.int64), g.astype(np.int64))
+
+
+def test_the_arrays_outlive_their_handle(ctx, oracle_lib):
+    """WIDE reads' ops are read from the uploaded cigar array: the read set keeps it alive after spl_soa_free."""
+    arr, rs = randcase.make_case(933, False)
+    big = _repeat(rs, 29)
+    ocount, _ = helpers.oracle_engine(oracle_lib)
+    want = ocount(arr, big, 0, 0)
+    soa = ctx.upload_soa([_arrays(big)])
+    dr = ctx.layout_read_segments(soa, [0])
+    soa.free()
+    junk = ctx.upload_soa([_arrays(big)])       # (something else takes freed memory, were it freed)
+    with ctx.upload_sites(native.SiteArrays.from_chrom(arr)) as ds:
+        ctx.count_launch(ds, dr, 0, 0)
+        got = ds.counters()
+    dr.free()
+    junk.free()
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+
+
+def test_shifted_segments_and_the_coordinate_limit(ctx):
+    """A segment moved beyond the coordinate space is refused at spl_reads_add_soa, as spl_reads_add refuses it."""
+    rs = samio.ReadSet(np.array([100], np.int32), np.array([0], np.uint16), np.array([0, 1], np.uint32), np.array([(50 << 4) | 0], np.uint32))
+    with ctx.upload_soa([_arrays(rs)]) as soa:
+        with ctx.begin_reads() as dr:
+            with pytest.raises(native.SpliserNativeError):
+                dr.add_soa(soa, 0, 2147483500)
+            with pytest.raises(native.SpliserNativeError):
+                dr.add_soa(soa, 3, 0)
