@@ -6,9 +6,15 @@ from .cli import main
 rc = main()
 # Everything the command writes is written and closed when main() returns.  What is left -- the alignment file's mapping (14 GB
 # take 0.07 s to unmap), tens of GB of device memory, the HIP runtime's own teardown: 0.16-0.2 s for a human-scale sample -- the
-# kernel takes back faster than the process can hand it back: leave at once (SPL_NO_FAST_EXIT=1 for the ordinary way out).
+# kernel takes back faster than the process can hand it back: leave at once.  NOT when something rides along that writes its
+# output at exit -- a profiler's or tracer's preloaded library (rocprofv3, LD_PRELOAD tools), coverage -- or when asked not to
+# (SPL_NO_FAST_EXIT=1): then the ordinary way out, with atexit handlers, static destructors and the closing thread joined.
 sys.stdout.flush()
 sys.stderr.flush()
-if os.environ.get("SPL_NO_FAST_EXIT"):
+_rides_along = any(os.environ.get(k) for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD",
+                                               "COVERAGE_PROCESS_START", "COV_CORE_SOURCE")) or "coverage" in sys.modules or sys.gettrace() is not None
+if os.environ.get("SPL_NO_FAST_EXIT") or _rides_along:
+    from .process import wait_deferred_close
+    wait_deferred_close()
     sys.exit(rc)
 os._exit(rc or 0)

@@ -361,11 +361,20 @@ def combine(samplesFile, outputPath, qGene="All", isStranded=False, strandedType
         native_walk = not os.environ.get("SPL_COMBINE_PYTHON")
     tm = None
     if native_walk:
+        # Only the OPENING of the sample files decides between the two walks (-5 there: a file that is not the plain text `process`
+        # writes -- Python reads it its own way).  -5 is also what a damaged BAM gives during the gap fill: that is the run's
+        # error, not a reason to parse, merge and fill everything a second time in Python and fail again.
+        walk = None
         try:
-            tm = _combine_native(titles, tsvs, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow)
+            t_open = time.perf_counter()
+            if qGene is not None and any(ord(ch) > 127 for ch in str(qGene)):
+                raise native.SpliserNativeError(-5, "a gene name outside ASCII is the Python walk's")
+            walk = native.Combine(tsvs)
         except native.SpliserNativeError as exc:
-            if exc.code != -5:          # (-5: a file that is not the plain text `process` writes -- Python reads it its own way)
+            if exc.code != -5:
                 raise
+        if walk is not None:
+            tm = _combine_native(walk, time.perf_counter() - t_open, titles, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow)
     if tm is None:
         tm = _combine_python(titles, tsvs, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow)
     if tm:
@@ -373,10 +382,8 @@ def combine(samplesFile, outputPath, qGene="All", isStranded=False, strandedType
     return tm
 
 
-def _combine_native(titles, tsvs, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow):
-    t0 = time.perf_counter()
-    with native.Combine(tsvs) as walk:
-        t_parse = time.perf_counter() - t0
+def _combine_native(walk, t_parse, titles, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow):
+    with walk:
         log("Establishing order of genomic regions.")
         chroms = region_order_from_runs(walk.region_runs())
         if not chroms:

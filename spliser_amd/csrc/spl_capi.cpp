@@ -410,8 +410,8 @@ struct spl_dreads {
         std::vector<spl_layout_seg> segs;
         uint32_t n_chunks = 0;
         char *slab = nullptr;                // n_chunks record slots
-        spl_layout_seg *d_segs = nullptr;    // the segments, then chunk -> segment
-        uint32_t *d_chunk_seg = nullptr;
+        spl_layout_seg *d_segs = nullptr;    // the segments, then the chunks' descriptors (spl_layout_map_kernel)
+        spl_layout_chunk *d_chunks = nullptr;
     };
     std::vector<Segment> segs;
     std::vector<Group> groups;
@@ -2022,7 +2022,10 @@ static int launch_layout(spl_ctx *c, spl_dreads *d)
         spl_layout_params lp;
         lp.src = spl_devreads{(const int32_t *)g.src->pos, (const uint16_t *)g.src->flag, (const uint32_t *)g.src->cig_off, (const uint32_t *)g.src->cigar};
         lp.n_rec = g.src->n_rec; lp.n_ops = g.src->n_ops;
-        lp.segs = g.d_segs; lp.chunk_seg = g.d_chunk_seg; lp.rec_base = (uint8_t *)g.slab; lp.meta = d->meta; lp.cost = d->cost;
+        lp.chunks = g.d_chunks; lp.rec_base = (uint8_t *)g.slab; lp.meta = d->meta; lp.cost = d->cost;
+        // (the chunks' descriptors hold offsets read from the arrays: made anew whenever the layout runs)
+        const int rc0 = spl_dev_launch_layout_map(&lp.src, g.d_segs, (uint32_t)g.segs.size(), chunk, g.d_chunks, c->stream);
+        if (rc0) return spl_set_error(SPL_ERR_HIP, "layout map kernel launch: %s", hipGetErrorString((hipError_t)rc0));
         int64_t n_reads = 0, n_ops = 0;
         for (const spl_layout_seg &ls : g.segs) n_reads += ls.n_reads;
         for (const spl_dreads::Segment &seg : d->segs) if (seg.group >= 0 && &d->groups[(size_t)seg.group] == &g) n_ops += seg.n_ops;
@@ -2113,12 +2116,10 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
     for (spl_dreads::Group &g : d->groups) {
         const size_t seg_bytes = align_up(sizeof(spl_layout_seg) * g.segs.size());
         e = devmem::get((void **)&g.slab, SPL_LAYOUT_SLOT(chunk) * (size_t)g.n_chunks + 256, 'R');
-        if (e == hipSuccess) e = devmem::get((void **)&g.d_segs, seg_bytes + 4 * (size_t)g.n_chunks + 16, 'd');
+        if (e == hipSuccess) e = devmem::get((void **)&g.d_segs, seg_bytes + sizeof(spl_layout_chunk) * (size_t)g.n_chunks + 16, 'd');
         if (e != hipSuccess) return spl_set_error(SPL_ERR_HIP, "hipMalloc for the device layout of %u chunks: %s", g.n_chunks, hipGetErrorString(e));
-        g.d_chunk_seg = (uint32_t *)((char *)g.d_segs + seg_bytes);
+        g.d_chunks = (spl_layout_chunk *)((char *)g.d_segs + seg_bytes);
         HIP_TRY(hipMemcpyAsync(g.d_segs, g.segs.data(), sizeof(spl_layout_seg) * g.segs.size(), hipMemcpyHostToDevice, c->stream)); // (g.segs lives as long as the read set)
-        const int rc = spl_dev_launch_layout_map(g.d_segs, (uint32_t)g.segs.size(), g.d_chunk_seg, c->stream);
-        if (rc) return spl_set_error(SPL_ERR_HIP, "layout map kernel launch: %s", hipGetErrorString((hipError_t)rc));
     }
     const int rc = launch_layout(c, d);
     if (rc) return rc;

@@ -71,6 +71,15 @@ bool plain_int(const char *s, const char *e, int64_t *out)
     return true;
 }
 
+// ... inside a {k: v} or [a, b] literal, which the reference reads with literal_eval: Python's grammar has no leading zeros there
+// ("007" is a SyntaxError where int("007") is 7) -- such a file is Python's to judge
+bool literal_int(const char *s, const char *e, int64_t *out)
+{
+    const char *d = s < e && *s == '-' ? s + 1 : s;
+    if (e - d > 1 && *d == '0') return false;
+    return plain_int(s, e, out);
+}
+
 // a plain decimal number: [-]digits[.digits][e[+-]digits]; strtod is correctly rounded, like Python's float()
 bool plain_float(const char *s, const char *e, double *out)
 {
@@ -143,14 +152,14 @@ bool parse_dict(const char *s, const char *e, std::vector<int64_t> &keys, std::v
         const char *q = s;
         while (q < e && *q != ':' && *q != ' ') ++q;
         int64_t k, v;
-        if (!plain_int(s, q, &k)) return false;
+        if (!literal_int(s, q, &k)) return false;
         while (q < e && *q == ' ') ++q;
         if (q >= e || *q != ':') return false;
         ++q;
         while (q < e && *q == ' ') ++q;
         s = q;
         while (q < e && *q != ',' && *q != ' ') ++q;
-        if (!plain_int(s, q, &v)) return false;
+        if (!literal_int(s, q, &v)) return false;
         for (size_t i = first; i < keys.size(); ++i) if (keys[i] == k) return false;
         keys.push_back(k);
         vals.push_back(v);
@@ -175,7 +184,7 @@ bool parse_list(const char *s, const char *e, std::vector<int64_t> &out)
         const char *q = s;
         while (q < e && *q != ',' && *q != ' ') ++q;
         int64_t v;
-        if (!plain_int(s, q, &v)) return false;
+        if (!literal_int(s, q, &v)) return false;
         out.push_back(v);
         while (q < e && *q == ' ') ++q;
         if (q == e) return true;

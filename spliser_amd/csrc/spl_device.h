@@ -16,9 +16,10 @@
 #define SPL_WAVES (SPL_BLOCK / 64)
 // The range kernel deals the wave-iterations of a chunk (64 * K reads of ONE run each, K = 4 / 2 / 1 / 1 by run; a run's last one
 // may be partial) round-robin to its four waves.  Simple reads are never listed; of the others a wave can get a quarter of the
-// chunk plus what the alignment of the runs' partial iterations adds: at most 577 of a 2048-read chunk and 1089 of a 4096-read one
-// (enumerated over the run sizes); s_q has 640 / 1152 entries per wave, and a launch that ever needed more says so
-// (SPL_DEV_ERR_TABLE) instead of dropping a read.
+// chunk plus what the alignment of the runs' partial iterations adds: at most 577 of a 2048-read chunk -- s_q has 640 entries per
+// wave -- and 1089 of a 4096-read one, which 640 entries hold in every chunk but one of nothing but flagged spliced reads: a list
+// that is full hands its entries straight to the literal queue (push_direct), no read is dropped.  (Round 4 gave chunks of 4096
+// reads 1152 entries a wave: 24.5 KB of LDS per workgroup in the stranded instantiation, six workgroups per CU instead of eight.)
 #ifndef SPL_K_SIMPLE
 #define SPL_K_SIMPLE 4                   // reads per lane and wave-iteration: simple reads (8-byte records)
 #define SPL_K_MNM 2                      // ... once-spliced reads (16-byte records)
@@ -30,7 +31,6 @@
 #define SPL_WAVE_ITERS 10
 #endif
 #define SPL_WAVE_READS (64 * SPL_WAVE_ITERS)
-#define SPL_WAVE_READS_BIG (64 * (2 * SPL_WAVE_ITERS - 2)) // chunks of SPL_CHUNK_BIG: 8 once-spliced iterations of 128 per wave at most, and the partial ones
 #define SPL_WIN 1020                     // distinct site positions a workgroup privatises in LDS (pair kernel; range kernel unstranded)
 #define SPL_WIN_STRANDED 956             // ... range kernel, stranded: 4 windows + the lists, 8 workgroups in 160 KB
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over

@@ -30,12 +30,23 @@ struct spl_layout_seg {
 // range kernel's last loads of a run (spl_kernels.hip: fetch).
 #define SPL_LAYOUT_SLOT(chunk_reads) ((size_t)(chunk_reads) * SPL_REC_OTHER + 256u)
 
+// What a workgroup of the layout kernel needs to know about its chunk, in ONE scalar load (made from the segments and the
+// arrays' CIGAR offsets by spl_layout_map_kernel: a workgroup that first had to look its segment up, then the offsets of its
+// first and last read, had three memory trips behind it before its first op was asked for).
+struct spl_layout_chunk {
+    int64_t lo;                // index of the chunk's first read in the arrays (its cell of the grid: lo & ~(chunk - 1))
+    uint32_t n;                // reads
+    uint32_t o_lo, o_hi;       // its ops: cigar[o_lo .. o_hi)
+    uint32_t seg_op0;          // the first op of its segment (WIDE reads' indexes count from there)
+    int32_t shift;
+    uint32_t flat;             // its index in the read set's flat chunk list
+};
+
 struct spl_layout_params {
     spl_devreads src;
     int64_t n_rec;             // reads in the arrays (cig_off has n_rec + 1 entries): no load goes beyond them
     int64_t n_ops;             // ops in the arrays
-    const spl_layout_seg *segs;
-    const uint32_t *chunk_seg; // [chunks of this launch] -> segment
+    const spl_layout_chunk *chunks; // [chunks of this launch]
     uint8_t *rec_base;         // record slots, SPL_LAYOUT_SLOT apart
     spl_chunk_meta *meta;      // [flat chunk list]
     uint32_t *cost;            // [flat chunk list] what a chunk will cost the range kernel, roughly (SPL_W_*)
@@ -51,8 +62,8 @@ static inline uint32_t spl_order_per(uint32_t n_chunks) { return ((n_chunks + 7u
 #ifdef __cplusplus
 extern "C" {
 #endif
-// chunk_seg[seg.dev0 + j] = index of seg, for every segment (device arrays)
-int spl_dev_launch_layout_map(const spl_layout_seg *segs, uint32_t n_segs, uint32_t *chunk_seg, void *stream);
+// chunks[seg.dev0 + j] = the j-th chunk of seg, for every segment (device arrays; chunk = reads per chunk)
+int spl_dev_launch_layout_map(const spl_devreads *src, const spl_layout_seg *segs, uint32_t n_segs, uint32_t chunk, spl_layout_chunk *chunks, void *stream);
 // the layout itself: one workgroup per chunk of the launch (chunk = reads per chunk, 2048 or 4096)
 int spl_dev_launch_layout(const spl_layout_params *p, uint32_t n_dev_chunks, uint32_t chunk, void *stream, void *ev_start, void *ev_stop);
 // cost[n_chunks] -> order[8 * spl_order_per(n_chunks)]: the range kernel's slots, XCD share by XCD share, longest chunk first;

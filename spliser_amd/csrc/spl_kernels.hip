@@ -686,7 +686,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     // (finished from the junction table by the wave itself right after its loop, see below).  Only the owning wave touches a
     // segment, so the fill counts are wave-uniform registers and slots are handed out by ballot, not by atomics.
     constexpr int NWAVE = SPL_WAVES;
-    constexpr uint32_t SEG = BIG ? SPL_WAVE_READS_BIG : SPL_WAVE_READS;
+    constexpr uint32_t SEG = SPL_WAVE_READS;
     __shared__ uint16_t s_q[NWAVE * SEG];
     __shared__ uint32_t s_qcnt[NWAVE], s_qbase;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, in an SGPR
@@ -701,26 +701,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     auto rank_in = [](unsigned long long m) { // how many lanes below mine are in m (mbcnt: no per-lane mask to keep around)
         return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     };
-    // (a segment cannot overflow -- see SPL_WAVE_ITERS -- but if that reasoning were ever wrong the launch must say so, not
-    //  count some reads twice: an entry that does not fit is dropped and the error word set)
-    auto push_front = [&](bool want, uint32_t slot) {
-        const unsigned long long m = __ballot(want);
-        const uint32_t n = (uint32_t)__popcll(m);
-        if (n_front + n_back - back_done + n > SEG) { if (lane == 0) atomicOr(p.err, SPL_DEV_ERR_TABLE); return; }
-        if (want) s_q[seg0 + n_front + rank_in(m)] = (uint16_t)slot;
-        n_front += n;
-    };
-    auto push_back = [&](bool want, uint32_t slot) {
-        const unsigned long long m = __ballot(want);
-        const uint32_t n = (uint32_t)__popcll(m);
-        if (n_front + n_back + n > SEG) { if (lane == 0) atomicOr(p.err, SPL_DEV_ERR_TABLE); return; }
-        if (want) s_q[seg0 + SEG - 1u - n_back - rank_in(m)] = (uint16_t)slot;
-        n_back += n;
-    };
-
-    const int tid = threadIdx.x;
-    // workgroup -> slot of its XCD's share (my_chunk) -> chunk: every share is walked longest chunk first (chunk_order, built
-    // at upload from the packer's cost estimate), so the workgroups that finish a launch are short ones.
+    // workgroup -> slot of its XCD's share (my_chunk) -> chunk: every share is walked longest chunk first (chunk_order, made
+    // from the layout's cost estimate by spl_chunk_order_kernel), so the workgroups that finish a launch are short ones.
     // (Measured and not kept, round 4: workgroups that STAY and take chunk after chunk of their XCD's share from a counter, as
     // many as the chip holds -- to fill the eighth of the workgroup slots that stand empty between a workgroup's end and its
     // successor's first records: 0.443 ms a launch against 0.39, with ten registers in scratch for the loop around the body.)
@@ -728,6 +710,33 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     const uint32_t ordered = chunk_slot < p.n_chunks ? p.chunk_order[chunk_slot] : 0xffffffffu; // (p.n_chunks: the SLOTS; a share's last ones may be empty)
     const bool live = ordered != 0xffffffffu;
     const uint32_t chunk = live ? ordered : 0u;
+    // A segment holds what a wave lists in all but pathological chunks (SEG entries for the ~1000 reads a wave walks; simple reads
+    // are never listed).  A list that is full does not drop a read: its entries go straight into the literal queue -- one
+    // returning atomic per push instead of one per workgroup, on a path that a chunk of mostly flagged spliced reads takes --,
+    // and a twice-spliced read that finds the back list full is the literal kernel's (which takes any read).
+    auto push_direct = [&](bool want, uint32_t slot, unsigned long long m, uint32_t n) {
+        const uint32_t shard = blockIdx.x & 7u;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&p.queue_n[shard * SPL_COUNTER_STRIDE], n);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (want) p.queue[(size_t)shard * p.queue_cap + base + rank_in(m)] = (chunk << (BIG ? SPL_CHUNK_BIG_SHIFT : SPL_CHUNK_SHIFT)) | slot;
+    };
+    auto push_front = [&](bool want, uint32_t slot) {
+        const unsigned long long m = __ballot(want);
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (n_front + n_back - back_done + n > SEG) { push_direct(want, slot, m, n); return; }
+        if (want) s_q[seg0 + n_front + rank_in(m)] = (uint16_t)slot;
+        n_front += n;
+    };
+    auto push_back = [&](bool want, uint32_t slot) {
+        const unsigned long long m = __ballot(want);
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (n_front + n_back + n > SEG) { push_front(want, slot & 0x3fffu); return; }
+        if (want) s_q[seg0 + SEG - 1u - n_back - rank_in(m)] = (uint16_t)slot;
+        n_back += n;
+    };
+
+    const int tid = threadIdx.x;
     const ChunkView cv = chunk_view(p.chunk_meta + chunk);
     // Wave-iterations of the chunk.  A wave-iteration takes 64 * K consecutive reads of ONE run, K per lane: K = 4 for simple reads
     // (32 bytes of records per lane), 2 for once-spliced ones (32 bytes), 1 for the rest (24 bytes).  Run r has iters[r]
@@ -1678,7 +1687,7 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
         else hipExtLaunchKernelGGL(spl_count_pairs_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *p);
     } else {
         const bool big = h->chunk_shift == SPL_CHUNK_BIG_SHIFT;
-        *lds_out = (p->stranded ? 4 * (SPL_WIN_STRANDED + 1) : 2 * (SPL_WIN + 1)) * 4 + SPL_WAVES * (big ? SPL_WAVE_READS_BIG : SPL_WAVE_READS) * 2 + 4 * SPL_WAVES + 4; // difference windows + the waves' lists
+        *lds_out = (p->stranded ? 4 * (SPL_WIN_STRANDED + 1) : 2 * (SPL_WIN + 1)) * 4 + SPL_WAVES * SPL_WAVE_READS * 2 + 4 * SPL_WAVES + 4; // difference windows + the waves' lists
         const bool agg = (variant & 2) != 0;
 #define SPL_LAUNCH_RANGES(S, A, B) hipExtLaunchKernelGGL((spl_count_ranges_kernel<S, A, B>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h)
         if (p->stranded) {

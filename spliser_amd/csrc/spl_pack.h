@@ -175,7 +175,138 @@ SPL_PACK_HD void classify_ops(int32_t pos, uint32_t flag, const Ops &ops, uint32
     r.weight = wide ? SPL_W_WIDE : SPL_W_NARROW;
 }
 
+// The same decision with fewer instructions, for the layout kernel (spl_devpack.hip), where classifying 200 M reads was what the
+// launch took: a CIGAR of up to SPL_PACK_SCAN_OPS ops is looked at as a bit mask of its reference-consuming ops -- when every op
+// consumes (no clips, no insertions: most reads) the first five are the ops as they stand, otherwise the j-th consuming op is
+// the op at the mask's j-th set bit (count-trailing-zeros, no per-op select chains).  Must give what classify_ops gives, field
+// for field: tests/test_pack_host.py holds the two against each other on the host.
+SPL_PACK_HD uint32_t ctz32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_ctz(x);
+#else
+    uint32_t n = 0;
+    while (n < 32u && !((x >> n) & 1u)) ++n;
+    return n;
+#endif
+}
+// The record of a read whose reference-consuming ops are known: m of them (0xffffffff: a CIGAR too long to look at), the first
+// five c0 .. c4 (what stands in those beyond m is looked at by nobody), and the CIGAR's first two ops as they stand, op0 and op1
+// (a WIDE record's words; anything when the CIGAR has fewer than four ops).  Straight-line: selects, no branches -- on the device
+// every branch here is a mask juggle and a merge of seven registers; coordinates in 32 bits (five lengths of 28 bits cannot wrap).
+SPL_PACK_HD void finish_record(int32_t pos, uint32_t flag, uint32_t m, uint32_t n_all, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t c4,
+                               uint32_t op0, uint32_t op1, uint32_t wide_index, Rec &r)
+{
+    const bool wide = m > 3u;
+    const uint32_t n = wide ? n_all : m;
+    // placed, and in the coordinate space at all (a POS beyond it leaves no room for any length, not even 0: OTHER)
+    const bool placed = !(flag & 4u) && pos >= 0 && pos <= (int32_t)SPL_COORD_MAX;
+    const uint32_t room = (uint32_t)SPL_COORD_MAX - (uint32_t)pos;
+    const uint32_t l0 = c0 >> 4, l1 = c1 >> 4, l2 = c2 >> 4, l3 = c3 >> 4, l4 = c4 >> 4;
+    const bool k0 = placed && kind_of(c0) == 1u && l0 < 65536u, k2 = kind_of(c2) == 1u && kind_of(c1) == 2u;
+    const bool simple = k0 && m == 1u && l0 <= room;
+    const bool mnm = k0 && m == 3u && k2 && l0 + l1 + l2 <= room;
+    const bool m2 = k0 && m == 5u && k2 && kind_of(c3) == 2u && kind_of(c4) == 1u && l2 < 65536u && l4 < 65536u && l0 + l1 + l2 + l3 + l4 <= room;
+    const bool other = !(simple || mnm || m2);
+    const uint32_t x0 = wide ? op0 : (m > 0u ? c0 : 0xfu), x1 = wide ? op1 : (m > 1u ? c1 : 0xfu), x2 = wide ? wide_index : (m > 2u ? c2 : 0xfu);
+    r.run = simple ? SPL_RC_SIMPLE : (mnm ? SPL_RC_MNM : (m2 ? SPL_RC_M2 : SPL_RC_OTHER));
+    r.w[0] = (uint32_t)pos;
+    r.w[1] = flag | (other ? ((n < SPL_NOPS_SAT ? n : SPL_NOPS_SAT) << 16) | ((wide ? SPL_RC_WIDE : SPL_RC_NARROW) << SPL_RC_SHIFT) : l0 << 16);
+    r.w[2] = other ? x0 : l1;
+    r.w[3] = other ? x1 : (m2 ? l2 | (l4 << 16) : l2);
+    r.w[4] = other ? x2 : l3;
+    r.w[5] = other ? n : 0u;
+    r.n_wide = wide && other ? n_all : 0u;
+    r.weight = simple ? SPL_W_SIMPLE : (mnm ? SPL_W_MNM : (m2 ? SPL_W_M2 : (wide ? SPL_W_WIDE : SPL_W_NARROW)));
+}
+
+// The layout kernel's straight-line path: a read of at most five ops that all consume the reference (no clips, no insertions:
+// most reads) from its first five ops o0 .. o4 -- what stands in those beyond n_all is anything (the neighbour's ops) and is
+// masked.  -> true when the read IS such a read; r is its record then (field for field classify_ops's), garbage otherwise.
+// The five kinds side by side, two bits each: a class is one comparison of that signature.
+SPL_PACK_HD bool classify_fast5(int32_t pos, uint32_t flag, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, uint32_t o4, uint32_t n_all,
+                                uint32_t wide_index, Rec &r)
+{
+    const uint32_t m = n_all < 5u ? n_all : 5u;
+    const uint32_t used = (1u << (2u * m)) - 1u;
+    const uint32_t sig = (kind_of(o0) | (kind_of(o1) << 2) | (kind_of(o2) << 4) | (kind_of(o3) << 6) | (kind_of(o4) << 8)) & used;
+    const bool fast = n_all <= 5u && ((sig | (sig >> 1)) & 0x155u) == (0x155u & used); // every op of the CIGAR consumes
+    const bool placed = !(flag & 4u) && pos >= 0 && pos <= (int32_t)SPL_COORD_MAX;
+    const uint32_t room = (uint32_t)SPL_COORD_MAX - (uint32_t)pos;
+    const uint32_t l0 = o0 >> 4, l1 = o1 >> 4, l2 = o2 >> 4, l3 = o3 >> 4, l4 = o4 >> 4;
+    const bool lim0 = placed && l0 < 65536u;
+    // (all ops consume, so a signature says how many there are: 01 = M; 01 10 01 = M N M; 01 10 01 10 01 = M N M N M)
+    const bool simple = lim0 && sig == 0x1u && l0 <= room;
+    const bool mnm = lim0 && sig == 0x19u && l0 + l1 + l2 <= room;
+    const bool m2 = lim0 && sig == 0x199u && l2 < 65536u && l4 < 65536u && l0 + l1 + l2 + l3 + l4 <= room;
+    const bool other = !(simple || mnm || m2);
+    const bool wide = m > 3u;
+    const uint32_t x0 = (wide || m > 0u) ? o0 : 0xfu, x1 = (wide || m > 1u) ? o1 : 0xfu, x2 = wide ? wide_index : (m > 2u ? o2 : 0xfu);
+    r.run = simple ? SPL_RC_SIMPLE : (mnm ? SPL_RC_MNM : (m2 ? SPL_RC_M2 : SPL_RC_OTHER));
+    r.w[0] = (uint32_t)pos;
+    r.w[1] = flag | (other ? (m << 16) | ((wide ? SPL_RC_WIDE : SPL_RC_NARROW) << SPL_RC_SHIFT) : l0 << 16);
+    r.w[2] = other ? x0 : l1;
+    r.w[3] = other ? x1 : (m2 ? l2 | (l4 << 16) : l2);
+    r.w[4] = other ? x2 : l3;
+    r.w[5] = other ? m : 0u;
+    r.n_wide = wide && other ? n_all : 0u;
+    r.weight = simple ? SPL_W_SIMPLE : (mnm ? SPL_W_MNM : (m2 ? SPL_W_M2 : (wide ? SPL_W_WIDE : SPL_W_NARROW)));
+    return fast;
+}
+
+// bit (code) set: the op consumes the reference (M D N = X)
+#define SPL_CONSUMES_BITS ((1u << 0) | (1u << 2) | (1u << 3) | (1u << 7) | (1u << 8))
+// Which of a CIGAR's first five ops consume the reference, as a bit mask cut to its n_all ops (n_all <= 5).
+SPL_PACK_HD uint32_t consuming_mask5(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, uint32_t o4, uint32_t n_all)
+{
+    return (((SPL_CONSUMES_BITS >> (o0 & 15u)) & 1u) | (((SPL_CONSUMES_BITS >> (o1 & 15u)) & 1u) << 1) | (((SPL_CONSUMES_BITS >> (o2 & 15u)) & 1u) << 2) |
+            (((SPL_CONSUMES_BITS >> (o3 & 15u)) & 1u) << 3) | (((SPL_CONSUMES_BITS >> (o4 & 15u)) & 1u) << 4)) & ((1u << n_all) - 1u);
+}
+
+// An accessor with `padded = true` promises that ops(k) may be called for every k < SPL_PACK_SCAN_OPS whatever the read's number
+// of ops (what comes back beyond them is ignored): the first five ops are then five unconditional reads.
+template <class Ops>
+SPL_PACK_HD void classify_lean(int32_t pos, uint32_t flag, const Ops &ops, uint32_t n_all, uint32_t wide_index, Rec &r)
+{
+    uint32_t m = 0xffffffffu, c0 = 0xfu, c1 = 0xfu, c2 = 0xfu, c3 = 0xfu, c4 = 0xfu;
+    uint32_t o0 = 0xfu, o1 = 0xfu, o2 = 0xfu, o3 = 0xfu, o4 = 0xfu;
+    if (Ops::padded) {
+        o0 = ops(0u); o1 = ops(1u); o2 = ops(2u); o3 = ops(3u); o4 = ops(4u);
+    } else {
+        if (n_all > 0u) o0 = ops(0u);
+        if (n_all > 1u) o1 = ops(1u);
+        if (n_all > 2u) o2 = ops(2u);
+        if (n_all > 3u) o3 = ops(3u);
+        if (n_all > 4u) o4 = ops(4u);
+    }
+    if (n_all <= (uint32_t)SPL_PACK_SCAN_OPS) {
+        uint32_t hi = 0; // the consuming bits of ops 5..7
+        if (n_all > 5u) {
+            hi = ((SPL_CONSUMES_BITS >> (ops(5u) & 15u)) & 1u) << 5;
+            if (n_all > 6u) hi |= ((SPL_CONSUMES_BITS >> (ops(6u) & 15u)) & 1u) << 6;
+            if (n_all > 7u) hi |= ((SPL_CONSUMES_BITS >> (ops(7u) & 15u)) & 1u) << 7;
+        }
+        const uint32_t full = (1u << n_all) - 1u;
+        const uint32_t mask = consuming_mask5(o0, o1, o2, o3, o4, n_all < 5u ? n_all : 5u) | hi;
+        if (mask == full) { // every op consumes the reference: nothing to drop, the first five are the ops as they stand
+            m = n_all;
+            c0 = o0; c1 = o1; c2 = o2; c3 = o3; c4 = o4;
+        } else { // the j-th consuming op is the op at the mask's j-th set bit
+            uint32_t mm = mask;
+            m = 0;
+            if (mm) { c0 = ops(ctz32(mm)); mm &= mm - 1u; ++m; }
+            if (mm) { c1 = ops(ctz32(mm)); mm &= mm - 1u; ++m; }
+            if (mm) { c2 = ops(ctz32(mm)); mm &= mm - 1u; ++m; }
+            if (mm) { c3 = ops(ctz32(mm)); mm &= mm - 1u; ++m; }
+            if (mm) { c4 = ops(ctz32(mm)); mm &= mm - 1u; ++m; }
+            while (mm) { mm &= mm - 1u; ++m; }
+        }
+    }
+    finish_record(pos, flag, m, n_all, c0, c1, c2, c3, c4, o0, o1, wide_index, r);
+}
+
 struct PtrOps {
+    static constexpr bool padded = false;
     const uint32_t *p;
     SPL_PACK_HD uint32_t operator()(uint32_t k) const { return p[k]; }
 };

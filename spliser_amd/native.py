@@ -852,6 +852,15 @@ def _view(addr, n, dt):
     return np.ctypeslib.as_array(ctypes.cast(addr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).copy()
 
 
+def _ascii_gene(gene):
+    """The native walk compares gene names as bytes of files it has checked to be ASCII: a name outside ASCII can match nothing there,
+    and must not be turned into '?' (a gene may be called that) -- the Python walk takes it."""
+    try:
+        return str(gene).encode("ascii")
+    except UnicodeEncodeError:
+        raise SpliserNativeError(-5, "gene name %r is not ASCII: the Python walk of combine takes it" % (gene,))
+
+
 class Combine(object):
     """The host walk of ``combine`` / ``combineShallow`` on columns (``spl_combine_*``, csrc/spl_combine.cpp): the per-sample
     .SpliSER.tsv files parsed and merged natively, the gap-fill queries as tables, the answers handed back, the .combined.tsv
@@ -895,14 +904,14 @@ class Combine(object):
         return out
 
     def keep_gene(self, gene):
-        _check(lib().spl_combine_keep_gene(self._h, gene.encode("ascii", "replace")))
+        _check(lib().spl_combine_keep_gene(self._h, _ascii_gene(gene)))
 
     def merge(self, chroms, is_stranded, q_gene, shallow=None):
         """The lock-step walk.  -> [(position, samples with evidence)] of the sites combineShallow dropped."""
         names = (ctypes.c_char_p * max(len(chroms), 1))(*[c.encode("ascii", "replace") for c in chroms])
         ms, mr, me = (0, 0, 0.0) if shallow is None else shallow
         _check(lib().spl_combine_merge(self._h, names, ctypes.c_int32(len(chroms)), ctypes.c_int(1 if is_stranded else 0),
-                                       q_gene.encode("ascii", "replace"), ctypes.c_int(0 if shallow is None else 1),
+                                       _ascii_gene(q_gene), ctypes.c_int(0 if shallow is None else 1),
                                        ctypes.c_int64(int(ms)), ctypes.c_int64(int(mr)), ctypes.c_double(float(me))))
         p = ctypes.c_void_p()
         n = int(lib().spl_combine_skipped(self._h, ctypes.byref(p)))

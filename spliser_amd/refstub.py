@@ -84,7 +84,11 @@ def make_process_sites(g, lib_path="libspliser_hip.so"):
                 s.addBeta1Count(int(b1[i]), sample)
                 s.addBeta2SimpleCount(int(b2s[i]), sample)
                 s.addBeta2CrypticCount(int(b2c[i]), sample)
-                s.updateBeta2Weighted([float(b2w[i])])
+                vals = list(s.getBeta2WeightedCounts())          # (findBeta2Counts replaces the whole list, :623: only
+                if len(vals) != numsamples:                      #  this sample's entry is this call's to set)
+                    vals = [0.00] * numsamples
+                vals[sample] = float(b2w[i])
+                s.updateBeta2Weighted(vals)
                 s.setSSE(float(sse[i]), sample)
         spl.spl_bam_close(bam)
         spl.spl_destroy(ctx)

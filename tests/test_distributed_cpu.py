@@ -1,6 +1,7 @@
-"""N > 1 paths on CPU: chromosome -> device assignment, shard packing round trip, and a world_size-2 gloo run
-of the rank/shard logic bench.py uses (weak scaling: every rank owns its own sample; the only collectives are the
-timing barrier and the MAX/SUM reductions)."""
+"""N > 1 paths on CPU: chromosome -> device assignment, shard packing round trip, and world_size-2 gloo runs of the
+rank/shard logic bench.py uses -- weak scaling (every rank owns its own sample) and STRONG scaling, bench.py's default for
+N > 1 (one sample, its chromosomes dealt to the ranks: bench.rank_items, bench.reduce_report); the only collectives are the
+timing barrier and the MAX/SUM reductions of the report."""
 import os
 import socket
 import sys
@@ -129,3 +130,71 @@ def test_two_rank_gloo_weak_scaling_reduction():
     elapsed, tot = out.get()
     assert elapsed == 2.0                      # MAX over ranks
     assert tot[0] == 6000.0 and tot[1] > 0     # reads summed over both samples
+
+
+def _strong_worker(rank, world, port, out):
+    """What a rank of `bench.py --gpus 2` does with the sample, the oracle standing in for the device: the same sample on every
+    rank, bench.rank_items picks the rank's chromosomes, bench.reduce_report makes the report."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import tempfile
+    import torch.distributed as dist
+    import bench
+    from oracle import oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wl = synth.Workload("arabidopsis", scale=0.003, seed=21, workers=1)
+    tmp = tempfile.mkdtemp()
+    synth.write_bed(os.path.join(tmp, "j.bed"), wl.genome.chrom_names, wl.junctions)
+    t = sites.SiteTable()
+    t.add_bed(os.path.join(tmp, "j.bed"))
+    t.find_competitors()
+    items = [(c, t.chrom_arrays(c), wl.reads[i]) for i, c in enumerate(wl.genome.chrom_names) if t.chrom_arrays(c).n]
+    mine = bench.rank_items(items, "strong", world, rank)
+    res = {}
+    for c, arr, rd in mine:
+        res[c] = oracle.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos, rd.pos, rd.flag, rd.cig_off, rd.cigar)
+    dist.barrier()
+    n_reads, n_sites = sum(rd.n for _, _, rd in mine), sum(arr.n for _, arr, _ in mine)
+    report = bench.reduce_report(dist, rank, world, n_reads, n_sites, 0.5 + rank, "cpu")
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object({c: [a.tolist() for a in v] for c, v in res.items()}, gathered, dst=0)   # (the TEST's own collective, not bench.py's)
+    if rank == 0:
+        whole = {c: [a.tolist() for a in oracle.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos,
+                                                         rd.pos, rd.flag, rd.cig_off, rd.cigar)] for c, arr, rd in items}
+        out.put((report, gathered, whole, {c: rd.n for c, _, rd in items}, sum(arr.n for _, arr, _ in items)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_strong_split_union_is_the_whole():
+    """bench.py's default for N > 1: ONE sample, its chromosomes dealt to the ranks.  Every chromosome goes to exactly one rank,
+    the union of the ranks' counters is the oracle's on the whole sample, and the report carries the imbalance."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strong_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    (elapsed, tot_reads, tot_sites, imbalance), gathered, whole, reads_by_chrom, n_sites = out.get()
+    n_reads = sum(reads_by_chrom.values())
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert elapsed == 1.5                                   # MAX over ranks
+    assert tot_reads == float(n_reads) and tot_sites == float(n_sites)
+    assert not (set(gathered[0]) & set(gathered[1]))        # no chromosome twice ...
+    union = dict(gathered[0])
+    union.update(gathered[1])
+    assert union == whole                                   # ... none missing, every counter the whole sample's
+    assert len(gathered[0]) >= 1 and len(gathered[1]) >= 1
+    assert imbalance["reads_per_rank"] == [sum(reads_by_chrom[c] for c in g) for g in gathered]
+    assert sum(imbalance["reads_per_rank"]) == n_reads and imbalance["seconds_per_rank"] == [0.5, 1.5]
+    assert 1.0 <= imbalance["max_over_mean_reads"] < 2.0
+
+
+def test_bench_refuses_a_world_that_is_not_its_gpus(tmp_path):
+    """`--gpus N` is what the driver passes: a launcher that made another number of ranks is an error, not a silent one-GPU run."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.001"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -143,3 +143,54 @@ def test_pack_many_chunks():
                          np.concatenate((reads.cigar, long_read.cigar)))
     desc = check(both, threads=4)
     assert int(desc["n"][:, 1].sum()) > 0 and int(desc["n"][:, 0].sum()) > 0
+
+
+def test_the_layout_kernels_classifier_is_the_host_packers():
+    """spl_pack.h has the read classifier twice: classify_ops (the host packer's, checked above against the Python statement of the
+    layout rules) and classify_lean + classify_fast5 (the layout kernel's, spl_devpack.hip: the same decision from a bit mask of the
+    consuming ops, and straight-line from a signature of the first five ops' kinds for CIGARs without clips or insertions).
+    Built for the host (tests/hostsim/pack_classify_host.cpp) and run side by side on CIGARs of every shape: 0 ... 12 ops of every
+    code including the undefined ones, lengths around 65535 / 65536 and 2^28 - 1, POS negative and at the end of the coordinate
+    space, flag 0x4 -- every field the layout uses must agree."""
+    import ctypes
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+    so, src = os.path.join(here, "libpack_classify_host.so"), os.path.join(here, "pack_classify_host.cpp")
+    hdr = os.path.join(here, "..", "..", "spliser_amd", "csrc", "spl_pack.h")
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in (src, hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    lib.classify_compare.restype = ctypes.c_int64
+    rng = np.random.default_rng(77)
+    n = 400_000
+    n_ops = rng.choice([0, 1, 1, 1, 2, 3, 3, 3, 4, 5, 5, 5, 6, 7, 8, 8, 9, 12], n)
+    cig_off = np.concatenate(([0], np.cumsum(n_ops))).astype(np.uint32)
+    total = int(cig_off[-1])
+    # op codes: mostly M / N with clips and indels between, every code 0..15 now and then
+    codes = rng.choice([0, 0, 0, 0, 3, 3, 3, 1, 2, 4, 5, 7, 8, 6, 9, 15], total).astype(np.uint32)
+    regular = rng.random(n) < 0.5           # half of the reads: M (N M)* with optional clips, the shapes the runs exist for
+    for i in np.nonzero(regular)[0][:150_000]:
+        a, b = int(cig_off[i]), int(cig_off[i + 1])
+        k = b - a
+        if k == 0:
+            continue
+        pat = [0, 3] * k
+        seq = pat[:k] if k % 2 else [4] + pat[:k - 1]
+        if k >= 3 and rng.random() < 0.3:
+            seq[-1] = 4 if seq[-1] == 3 else seq[-1]
+        codes[a:b] = seq
+    lens = rng.choice([1, 2, 50, 100, 150, 65535, 65536, 70000, (1 << 28) - 1], total,
+                      p=[0.1, 0.1, 0.2, 0.2, 0.25, 0.05, 0.05, 0.03, 0.02]).astype(np.uint32)
+    cigar = np.concatenate((((lens << 4) | codes).astype(np.uint32), rng.integers(0, 2 ** 32, 8, dtype=np.uint64).astype(np.uint32)))   # (+ 8 words of anything behind the last read)
+    pos = rng.choice([1, 100, 5_000_000, COORD_MAX - 100, COORD_MAX, -1, -5, 2147483647], n,
+                     p=[0.1, 0.3, 0.4, 0.05, 0.05, 0.04, 0.03, 0.03]).astype(np.int32)
+    flag = rng.choice([0, 16, 99, 147, 4, 20, 256, 2048, 65535], n).astype(np.uint16)
+    first = ctypes.c_int64(-1)
+
+    def p(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+    bad = lib.classify_compare(ctypes.c_int64(n), p(pos), p(flag), p(cig_off), p(cigar), ctypes.byref(first))
+    i = first.value
+    assert bad == 0, "classify_lean differs from classify_ops on %d reads, first: pos %d flag %d ops %s" % (
+        bad, pos[i], flag[i], [(int(o) >> 4, int(o) & 15) for o in cigar[cig_off[i]:cig_off[i + 1]]])
