@@ -96,11 +96,11 @@ def lib_sha16():
     return h.hexdigest()[:16]
 
 
-KERNEL_SOURCES = ("spl_kernels.hip", "spl_device.h", "spl_pack.h", "spl_classify.h", "spl_pack.cpp")
+KERNEL_SOURCES = ("spl_kernels.hip", "spl_device.h", "spl_pack.h", "spl_classify.h", "spl_pack.cpp", "spl_devpack.hip", "spl_devpack.h")
 
 
 def kernel_src_sha16():
-    """What the HBM traffic of the range kernel depends on: the kernel's sources and the packer that lays out what it reads,
+    """What the HBM traffic of the step's kernels depends on: the range kernel's sources and the layout kernel / packer that lays out what it reads,
     comments and white space aside (tools/traffic_json.py stamps a measurement with the same hash).  Host-side changes elsewhere
     in the library, and comments, leave it alone."""
     h = hashlib.sha256()
@@ -404,21 +404,35 @@ def combine_leg(samples, threads):
         per = []
         for k in range(len(samples)):
             t1 = time.perf_counter()
-            process.process(bams[k], os.path.join(tmp, "s%d.bed" % k), os.path.join(tmp, "s%d" % k), log=noop)
+            tmk = process.process(bams[k], os.path.join(tmp, "s%d.bed" % k), os.path.join(tmp, "s%d" % k), log=noop, keepReads=True)
             process.wait_deferred_close()
             per.append(time.perf_counter() - t1)
+            keep_s = keep_s + tmk.get("keep_reads_s", 0.0) if k else tmk.get("keep_reads_s", 0.0)
         t_process = time.perf_counter() - t
-        best = None
-        for rep in range(2):        # (the second call finds device memory of the samples' sizes at hand, like the e2e legs' timed calls)
-            t = time.perf_counter()
-            tm = cmb.combine(sfile, os.path.join(tmp, "all"), log=noop)
-            wall = time.perf_counter() - t
-            process.wait_deferred_close()
-            if best is None or wall < best[0]:
-                best = (wall, tm)
-            if rep == 0:
-                first = wall
-        wall, tm = best
+
+        def timed_combine(out_name):
+            best = None
+            for rep in range(2):    # (the second call finds device memory of the samples' sizes at hand, like the e2e legs' timed calls)
+                t = time.perf_counter()
+                tm = cmb.combine(sfile, os.path.join(tmp, out_name), log=noop)
+                wall = time.perf_counter() - t
+                process.wait_deferred_close()
+                if best is None or wall < best[0]:
+                    best = (wall, tm)
+                if rep == 0:
+                    first = wall
+            return best[0], best[1], first
+        # `combine` as `process --keepReads` lets it run: every sample's flag / POS / CIGAR from the file process left (readstore:
+        # only while it is that BAM's), no BAM decoded twice -- and, beside it, from the BAMs alone (what the reference's workflow
+        # does, SpliSER_v0_1_8.py:903, and what this build does without --keepReads)
+        wall, tm, first = timed_combine("all")
+        os.environ["SPL_IGNORE_KEPT_READS"] = "1"
+        try:
+            wall_bams, tm_bams, _ = timed_combine("from_bams")
+        finally:
+            del os.environ["SPL_IGNORE_KEPT_READS"]
+        with open(os.path.join(tmp, "all.combined.tsv"), "rb") as a, open(os.path.join(tmp, "from_bams.combined.tsv"), "rb") as b:
+            kept_same = a.read() == b.read()
         # the checker: the same walk, the oracle's answers (test infrastructure; never timed as the product)
         t = time.perf_counter()
         oracle.set_threads(threads)
@@ -441,21 +455,49 @@ def combine_leg(samples, threads):
         t_check = time.perf_counter() - t
         with open(os.path.join(tmp, "all.combined.tsv"), "rb") as a, open(os.path.join(tmp, "want.combined.tsv"), "rb") as b:
             same = a.read() == b.read()
+        # ... and the native WALK itself (parsers, lock-step walk, writer: what the check above shares with the product) against the
+        # Python statement of the same walk -- what the reference-generated goldens pin -- on the samples' rows of ONE chromosome
+        # (the interpreter takes 50 s for all five), no gap fill on either side: the two files byte for byte
+        t = time.perf_counter()
+        small = min(samples[0].genome.chrom_names, key=lambda c: samples[0].genome.chrom_lengths[samples[0].genome.chrom_names.index(c)])
+        cut = []
+        for k, path in enumerate(tsvs):
+            dst = os.path.join(tmp, "cut%d.tsv" % k)
+            with open(path) as fh, open(dst, "w") as out_fh:
+                for n_line, text in enumerate(fh):
+                    if n_line == 0 or text.startswith(small + "\t"):
+                        out_fh.write(text)
+            cut.append(dst)
+        rows = [cmb._parse_tsv(q) for q in cut]
+        order = cmb.region_order(rows)
+        merged = cmb.merge_sites(rows, order, len(titles), False, "All")
+        cmb.write_combined(os.path.join(tmp, "cut_py.combined.tsv"), merged, titles, {}, False)
+        with native.Combine(cut) as walk:
+            walk.merge(cmb.region_order_from_runs(walk.region_runs()), False, "All", None)
+            walk.write(os.path.join(tmp, "cut_native.combined.tsv"), titles, False)
+        with open(os.path.join(tmp, "cut_py.combined.tsv"), "rb") as a, open(os.path.join(tmp, "cut_native.combined.tsv"), "rb") as b:
+            walk_same = a.read() == b.read()
+        t_walk_check = time.perf_counter() - t
         host = tm["parse_s"] + tm["merge_s"] + tm["write_s"]
         out = {"workload": "config 4: %d samples x %d reads (A. thaliana-like genome, seeds 11-%d, 15%% of the isoforms silent per sample)"
                            % (len(samples), n_reads // len(samples), 10 + len(samples)),
                "files_written_s": t_files, "process_s": t_process, "process_s_per_sample": [round(v, 4) for v in per],
-               "combine_s": wall, "combine_first_call_s": first, "walk": tm["walk"], "parse_s": tm["parse_s"], "merge_s": tm["merge_s"],
+               "combine_s": wall, "combine_first_call_s": first, "combine_from_bams_s": wall_bams, "gapfill_from_bams_s": tm_bams["gapfill_s"],
+               "keep_reads_s": keep_s, "kept_reads_same_file": bool(kept_same),
+               "walk": tm["walk"], "parse_s": tm["parse_s"], "merge_s": tm["merge_s"],
                "gapfill_s": tm["gapfill_s"], "write_s": tm["write_s"], "host_over_gpu": host / tm["gapfill_s"] if tm["gapfill_s"] else None,
                "sites": tm["sites"], "gap_sites": tm["gap_sites"], "queries": tm["queries"], "rows": tm["sites"] * len(samples),
                "combined_bytes": os.path.getsize(os.path.join(tmp, "all.combined.tsv")),
                "reads_per_sec": n_reads / (t_process + wall), "matches_oracle": bool(same), "queries_checked": n_q, "check_s": t_check,
-               "what": "process x 6 then combine, wall clock of the calls in this process; combine = parse the six .SpliSER.tsv (native, "
+               "walk_matches_python": bool(walk_same), "walk_check": "%s of the six files through combine.py's own parse / merge_sites / write_combined and through the native walk, no gap fill: %d sites, %.1f s" % (small, len(merged), t_walk_check),
+               "what": "process --keepReads x 6 then combine, wall clock of the calls in this process (process_s includes writing the kept reads, keep_reads_s of it; "
+                       "combine_s takes them, combine_from_bams_s decodes the six BAMs again); combine = parse the six .SpliSER.tsv (native, "
                        "a thread per file) + the lock-step walk (native) + gap fill (each sample's BAM decoded on the GPU once, its "
                        "queries through the range kernel in combine mode) + .combined.tsv (native); matches_oracle: the file against the "
                        "same walk with oracle/spliser_oracle.c answering every query from the reads that were written"}
         out["line"] = {k: out[k] for k in ("workload", "process_s", "combine_s", "parse_s", "merge_s", "gapfill_s", "write_s", "host_over_gpu",
-                                           "queries", "rows", "reads_per_sec", "matches_oracle")}
+                                           "queries", "rows", "reads_per_sec", "matches_oracle", "walk_matches_python", "combine_from_bams_s", "keep_reads_s",
+                                           "kept_reads_same_file")}
         out["line"]["workload"] = "config4: %dx%dM reads" % (len(samples), n_reads // len(samples) // 1000000)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -887,7 +929,7 @@ def main():
         # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from a committed
         # rocprofv3 --pmc run of this command (profiles/*_traffic.json, made by tools/prof_pmc.sh) and are quoted only for the
         # workload AND the kernel sources (kernel + packer) they were measured with.
-        traffic, traffic_from = None, None
+        traffic, traffic_from, layout_traffic = None, None, None
         import glob
         sha, ksha = lib_sha16(), kernel_src_sha16()
         for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_traffic.json")), reverse=True):
@@ -895,6 +937,7 @@ def main():
                 tj = json.load(fh)
             if tj.get("kernel_src_sha16") == ksha and tj.get("workload") == args.workload and args.scale == 1.0 and args.kernel == "ranges":
                 traffic, traffic_from = tj["hbm_bytes_per_launch"], os.path.basename(tpath)
+                layout_traffic = (tj.get("layout") or {}).get("hbm_bytes_per_launch")
                 break
         k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         l_avg_ms = float(np.mean(layout_ms)) if layout_ms else float("nan")
@@ -931,7 +974,7 @@ def main():
                        "step": "BAM-native arrays resident in HBM -> layout + range + literal + scan/SSE kernels of every shard, %s"
                                % ("no barrier between steps (pipelined)" if args.pipelined else "barrier between steps")},
             "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["frac"], "traffic": traffic if dom is range_obj else None, "traffic_from": traffic_from if dom is range_obj else None,
+                         "frac": dom["frac"], "traffic": traffic if dom is range_obj else layout_traffic, "traffic_from": traffic_from,
                          "kernel": dom["kernel"], "kernel_ms_avg": dom["kernel_ms_avg"], "launches_timed": dom["launches_timed"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                          "what": dom["what"],

@@ -45,6 +45,9 @@ def build_parser():
                         "that way); changes no result")
     p.add_argument("--hostDecode", dest="gpuDecode", action="store_false",
                    help="(this build only) decode the BAM on host threads")
+    p.add_argument("--keepReads", dest="keepReads", default=False, action="store_true",
+                   help="(this build only) also write <outputPath>.SpliSER.reads (flag, POS, CIGAR of every read): combine takes it "
+                        "instead of decoding the BAM again while it is still that BAM's")
     _engine_flags(p)
     c = sub.add_parser("combine")
     c.add_argument("-S", "--samplesFile", dest="samplesFile", required=True,

@@ -234,7 +234,7 @@ class _QueryTable(object):
         return self._arrays[chrom]
 
 
-def fill_gaps(merged, bam_paths, is_stranded, stranded_type, devices=(0,), threads=0, log=_log):
+def fill_gaps(merged, bam_paths, is_stranded, stranded_type, devices=(0,), threads=0, log=_log, kept_reads=None):
     """Answer every (site, sample) query of ``merge_sites``'s result on the GPUs (``fill_tables``).
     -> {(site index, sample idx): (beta1, beta2Simple)}"""
     tables = {idx: _QueryTable(qs) for idx, qs in gap_queries(merged).items()}
@@ -245,24 +245,29 @@ def fill_gaps(merged, bam_paths, is_stranded, stranded_type, devices=(0,), threa
         with lock:
             for si, x, y in zip(site, beta1.tolist(), b2.tolist()):
                 results[(int(si), idx)] = (int(x), int(y))
-    fill_tables(tables, take, bam_paths, is_stranded, stranded_type, devices=devices, threads=threads, log=log)
+    fill_tables(tables, take, bam_paths, is_stranded, stranded_type, devices=devices, threads=threads, log=log, kept_reads=kept_reads)
     return results
 
 
-def fill_tables(tables, take, bam_paths, is_stranded, stranded_type, devices=(0,), threads=0, log=_log):
+def fill_tables(tables, take, bam_paths, is_stranded, stranded_type, devices=(0,), threads=0, log=_log, kept_reads=None):
     """Answer the query tables ``{sample idx: table}`` on the GPUs.  Each sample's BAM is decoded once, in the background (on
     the GPU when the call has one device, like ``process``); its chromosomes are dealt to the devices
     (``process.process_sites``: one context per device, a chromosome goes to its GPU as soon as the decoder has it complete) and
     counted in ``combine_mode`` (a flanking read counts toward beta2Simple, :529-536); several samples are in flight at a time,
     each starting on another device.  ``take(idx, merged-site indexes, beta1, beta2Simple)`` gets a region's answers."""
     from concurrent.futures import ThreadPoolExecutor
-    from . import process as _process
+    from . import process as _process, readstore
     devices = tuple(devices)
 
     def one(idx):
         table = tables[idx]
         devs = devices[idx % len(devices):] + devices[:idx % len(devices)]
-        source = _process.open_and_decode(bam_paths[idx], devs, None, threads)   # (on the sample's first device when it has one device)
+        # what `process --keepReads` left of this very BAM (readstore: keyed by the BAM's size, time and edges), or the BAM again
+        source = readstore.open_if_fresh(kept_reads[idx], bam_paths[idx]) if kept_reads and kept_reads[idx] else None
+        if source is not None:
+            log("  ({}: reads kept by process, {} not decoded again)".format(os.path.basename(kept_reads[idx]), os.path.basename(bam_paths[idx])))
+        else:
+            source = _process.open_and_decode(bam_paths[idx], devs, None, threads)   # (on the sample's first device when it has one device)
         try:
             out = _process.process_sites(table, source, "All", is_stranded, stranded_type, False, devices=devs, combine_mode=1,
                                          log=lambda m: None)
@@ -359,6 +364,9 @@ def combine(samplesFile, outputPath, qGene="All", isStranded=False, strandedType
     titles, tsvs, bams = read_samples_file(samplesFile, strict=shallow is None)
     if native_walk is None:
         native_walk = not os.environ.get("SPL_COMBINE_PYTHON")
+    # what `process --keepReads` may have left beside each sample's .SpliSER.tsv (taken only if it is still its BAM's: readstore)
+    from . import readstore
+    kept = None if os.environ.get("SPL_IGNORE_KEPT_READS") else [readstore.path_for_tsv(p) for p in tsvs]
     tm = None
     if native_walk:
         # Only the OPENING of the sample files decides between the two walks (-5 there: a file that is not the plain text `process`
@@ -374,15 +382,15 @@ def combine(samplesFile, outputPath, qGene="All", isStranded=False, strandedType
             if exc.code != -5:
                 raise
         if walk is not None:
-            tm = _combine_native(walk, time.perf_counter() - t_open, titles, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow)
+            tm = _combine_native(walk, time.perf_counter() - t_open, titles, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow, kept)
     if tm is None:
-        tm = _combine_python(titles, tsvs, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow)
+        tm = _combine_python(titles, tsvs, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow, kept)
     if tm:
         tm["total_s"] = time.perf_counter() - t_all
     return tm
 
 
-def _combine_native(walk, t_parse, titles, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow):
+def _combine_native(walk, t_parse, titles, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow, kept=None):
     with walk:
         log("Establishing order of genomic regions.")
         chroms = region_order_from_runs(walk.region_runs())
@@ -407,7 +415,7 @@ def _combine_native(walk, t_parse, titles, bams, outputPath, qGene, isStranded, 
         n_gap_sites = walk.n_gap_sites
         t0 = time.perf_counter()
         if tables:
-            fill_tables(tables, walk.answers, bams, isStranded, strandedType, devices=devices, threads=threads, log=log)
+            fill_tables(tables, walk.answers, bams, isStranded, strandedType, devices=devices, threads=threads, log=log, kept_reads=kept)
         t_fill = time.perf_counter() - t0
         t0 = time.perf_counter()
         walk.write(outputPath + ".combined.tsv", titles, isbeta2Cryptic)
@@ -418,7 +426,7 @@ def _combine_native(walk, t_parse, titles, bams, outputPath, qGene, isStranded, 
                 queries=n_queries)
 
 
-def _combine_python(titles, tsvs, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow):
+def _combine_python(titles, tsvs, bams, outputPath, qGene, isStranded, strandedType, isbeta2Cryptic, devices, threads, log, shallow, kept=None):
     t0 = time.perf_counter()
     rows = [_parse_tsv(p) for p in tsvs]
     t_parse = time.perf_counter() - t0
@@ -436,7 +444,7 @@ def _combine_python(titles, tsvs, bams, outputPath, qGene, isStranded, strandedT
     n_gap_sites = sum(1 for m in merged if m.queries)
     t_merge = time.perf_counter() - t0
     t0 = time.perf_counter()
-    results = fill_gaps(merged, bams, isStranded, strandedType, devices=devices, threads=threads, log=log) if n_gap_sites else {}
+    results = fill_gaps(merged, bams, isStranded, strandedType, devices=devices, threads=threads, log=log, kept_reads=kept) if n_gap_sites else {}
     t_fill = time.perf_counter() - t0
     t0 = time.perf_counter()
     write_combined(outputPath + ".combined.tsv", merged, titles, results, isbeta2Cryptic)

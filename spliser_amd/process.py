@@ -393,7 +393,7 @@ def write_tsv(output_path, table, results, is_beta2_cryptic):
 
 def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0, annotationFile=None, aType="gene",
             isStranded=False, strandedType=None, isbeta2Cryptic=False, devices=(0,), threads=0, log=_log, checkJunctions=False,
-            gpuDecode=None):
+            gpuDecode=None, keepReads=False):
     """SpliSER_v0_1_8.py:695-720, keyword-compatible with the reference's argparse dests.
 
     ``checkJunctions`` (this build only; changes no result): also derive every chromosome's junction table from the reads on
@@ -403,7 +403,11 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
     ``gpuDecode`` (this build only; changes no result): True = the BAM goes to the GPU as it is -- BGZF inflate, CRC32 and the
     extraction of POS / FLAG / CIGAR happen there (``spl_bam_decode_device``); files that path does not take (unsorted, CG-tag
     CIGARs, damaged) are decoded by the host threads all the same.  False = host threads.  None (default) = the GPU: with several
-    devices every one decodes the stretch of the file that holds the references it then counts (``open_and_decode``)."""
+    devices every one decodes the stretch of the file that holds the references it then counts (``open_and_decode``).
+
+    ``keepReads`` (this build only; changes no result): also leave ``<outputPath>.SpliSER.reads`` -- flag, POS and CIGAR of every
+    placed record, all ``checkBam`` reads of an alignment -- which ``combine`` takes instead of decoding the BAM again, as long
+    as it is still that BAM's (``readstore``)."""
     timings = {}
     t0 = time.perf_counter()
     # The alignment file does not depend on Steps 0-2: it is decoded on native threads while the site table is built here, and
@@ -452,6 +456,12 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
                         fh.write("%s\t%d\t%d\t%s\t%d\t%d\t%s\n" % (chrom, l, r, st, a, b, status))
             if n_more:
                 log("WARNING: %d junction(s) of %s carry more reads than %s holds for them -- do the two files belong together?" % (n_more, inBed, inBAM))
+        if keepReads and isinstance(source, native.BamFile):
+            from . import readstore
+            t_keep = time.perf_counter()
+            kept = [(name, source.reads(name)) for name in source.ref_names]
+            readstore.save(outputPath + readstore.SUFFIX, inBAM, [(name, rs) for name, rs in kept if rs is not None])
+            timings["keep_reads_s"] = time.perf_counter() - t_keep
         t4 = time.perf_counter()
     finally:
         if hasattr(source, "close"):

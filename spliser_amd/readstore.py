@@ -1,0 +1,134 @@
+"""``<out>.SpliSER.reads``: what ``process`` read from a sample's BAM, kept for ``combine`` (this build only; off by default).
+
+The reference's ``combine`` goes back to a sample's BAM for every site the sample does not list (SpliSER_v0_1_8.py:869-904,
+``checkBam`` at :903); here that is one more decode of the whole file per sample -- most of ``combine``'s time.  What
+``checkBam`` reads from an alignment is flag, POS and CIGAR (:434-437): ``process --keepReads`` leaves exactly those, per
+reference, BAM-native (pos int32, flag uint16, cig_off uint32, cigar uint32: 18.8 bytes a 150 bp read, a fifth of the BAM),
+next to its ``.SpliSER.tsv``; ``combine`` takes them instead of the BAM WHEN THEY ARE THE BAM'S: the file is keyed by the BAM's
+size, its modification time and the CRC32 of its first and last 64 KiB, and anything else -- another BAM, a newer one, a
+truncated or foreign file -- is ignored and the BAM decoded as always.
+"""
+import json
+import os
+import struct
+import zlib
+
+import numpy as np
+
+from . import samio
+
+MAGIC = b"SPLREADS"
+VERSION = 1
+SUFFIX = ".SpliSER.reads"
+_EDGE = 65536
+
+
+def path_for_tsv(tsv_path):
+    """``X.SpliSER.tsv`` -> ``X.SpliSER.reads`` (None for a file that is not named like ``process``'s output)."""
+    tail = ".SpliSER.tsv"
+    return tsv_path[:-len(tail)] + SUFFIX if tsv_path.endswith(tail) else None
+
+
+def bam_key(bam_path):
+    """(size, mtime in ns, CRC32 over the first and the last 64 KiB) of the alignment file."""
+    st = os.stat(bam_path)
+    crc = 0
+    with open(bam_path, "rb") as fh:
+        crc = zlib.crc32(fh.read(_EDGE), crc)
+        if st.st_size > _EDGE:
+            fh.seek(max(_EDGE, st.st_size - _EDGE))
+            crc = zlib.crc32(fh.read(_EDGE), crc)
+    return int(st.st_size), int(st.st_mtime_ns), crc & 0xFFFFFFFF
+
+
+def save(path, bam_path, reads_by_ref):
+    """reads_by_ref: [(reference name, ReadSet)] in file order.  Written beside its final name and moved there whole."""
+    size, mtime_ns, crc = bam_key(bam_path)
+    refs = [{"name": name, "n": int(rs.n), "ops": int(rs.cig_off[rs.n]) - int(rs.cig_off[0]) if rs.n else 0, "max_end": int(rs.max_end)}
+            for name, rs in reads_by_ref]
+    head = json.dumps({"version": VERSION, "bam_size": size, "bam_mtime_ns": mtime_ns, "bam_crc32": crc, "refs": refs}).encode("utf-8")
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as fh:
+        fh.write(MAGIC + struct.pack("<II", VERSION, len(head)) + head)
+        fh.write(b"\0" * (-fh.tell() % 64))
+        for kind, dt in (("pos", np.int32), ("flag", np.uint16), ("cig_off", np.uint32), ("cigar", np.uint32)):
+            for _, rs in reads_by_ref:
+                a = getattr(rs, kind)
+                base = int(rs.cig_off[0]) if rs.n else 0     # (offsets count from the reference's first op)
+                if kind == "cig_off":
+                    a = (a[:rs.n + 1].astype(np.int64) - base).astype(np.uint32) if rs.n else np.zeros(1, np.uint32)
+                elif kind == "cigar":
+                    a = a[base:int(rs.cig_off[rs.n])] if rs.n else a[:0]
+                else:
+                    a = a[:rs.n]
+                np.ascontiguousarray(a, dtype=dt).tofile(fh)
+            fh.write(b"\0" * (-fh.tell() % 64))
+    os.replace(tmp, path)
+
+
+class ReadStore(object):
+    """The reads of a ``.SpliSER.reads`` file as a source for ``process_sites``: ``reads(chrom)`` -> ReadSet (views of the mapped
+    file) or None for a reference the BAM does not have."""
+
+    def __init__(self, path, head, mm):
+        self.path, self._mm = path, mm
+        self._sets = {}
+        refs = head["refs"]
+        n_all, ops_all = sum(r["n"] for r in refs), sum(r["ops"] for r in refs)
+        at = 16 + head["_head_len"]
+        at += -at % 64
+
+        def take(count, dt):
+            nonlocal at
+            a = np.frombuffer(mm, dtype=dt, count=count, offset=at)
+            at += count * np.dtype(dt).itemsize
+            at += -at % 64
+            return a
+        pos, flag = take(n_all, np.int32), take(n_all, np.uint16)
+        cig_off, cigar = take(n_all + len(refs), np.uint32), take(ops_all, np.uint32)
+        r0 = o0 = c0 = 0
+        for r in refs:
+            n, ops = r["n"], r["ops"]
+            self._sets[r["name"]] = samio.ReadSet(pos[r0:r0 + n], flag[r0:r0 + n], cig_off[c0:c0 + n + 1], cigar[o0:o0 + ops], max_end=r["max_end"])
+            r0, o0, c0 = r0 + n, o0 + ops, c0 + n + 1
+        self.n_reads = n_all
+
+    def reads(self, chrom):
+        return self._sets.get(chrom)
+
+    def close(self):
+        self._sets = {}
+        self._mm = None
+
+
+def open_if_fresh(path, bam_path):
+    """-> ReadStore when ``path`` holds the reads of exactly this alignment file, None otherwise (missing, another version,
+    damaged, or the BAM has changed since)."""
+    import mmap
+    if not path or not os.path.exists(path):
+        return None
+    try:
+        with open(path, "rb") as fh:
+            fixed = fh.read(16)
+            if len(fixed) < 16 or fixed[:8] != MAGIC:
+                return None
+            version, head_len = struct.unpack("<II", fixed[8:16])
+            if version != VERSION or head_len > (1 << 26):
+                return None
+            head = json.loads(fh.read(head_len).decode("utf-8"))
+            if (head.get("bam_size"), head.get("bam_mtime_ns"), head.get("bam_crc32")) != bam_key(bam_path):
+                return None
+            refs = head["refs"]
+            n_all, ops_all = sum(r["n"] for r in refs), sum(r["ops"] for r in refs)
+            need = 16 + head_len
+            need += -need % 64
+            for count, size in ((n_all, 4), (n_all, 2), (n_all + len(refs), 4), (ops_all, 4)):
+                need += count * size
+                need += -need % 64
+            if os.fstat(fh.fileno()).st_size < need:
+                return None
+            head["_head_len"] = head_len
+            mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        return ReadStore(path, head, mm)
+    except (OSError, ValueError, KeyError, TypeError):
+        return None

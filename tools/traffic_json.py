@@ -14,11 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, args = sys.argv[1], sys.argv[2:]
 
 
-def mean(counter, sub):
+def mean(counter, sub, kernel="spl_count_ranges_kernel"):
     vals = collections.defaultdict(list)
     for path in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, sub), "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] == counter and "spl_count_ranges_kernel" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and kernel in r["Kernel_Name"]:
                 vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     if not vals:
         return None, 0
@@ -42,7 +42,7 @@ def strip_source(text):   # (= bench.py strip_source: comments and white space d
 
 
 kh = hashlib.sha256()
-for name in ("spl_kernels.hip", "spl_device.h", "spl_pack.h", "spl_classify.h", "spl_pack.cpp"):   # (= bench.py KERNEL_SOURCES)
+for name in ("spl_kernels.hip", "spl_device.h", "spl_pack.h", "spl_classify.h", "spl_pack.cpp", "spl_devpack.hip", "spl_devpack.h"):   # (= bench.py KERNEL_SOURCES)
     kh.update(strip_source(open(os.path.join(ROOT, "spliser_amd", "csrc", name), "rb").read().decode("utf-8", "replace")).encode("utf-8"))
 workload = args[args.index("--workload") + 1] if "--workload" in args else "human"
 out = {"workload": workload, "bench_args": args, "lib_sha16": h, "kernel_src_sha16": kh.hexdigest()[:16], "kernel": "spl_count_ranges_kernel", "dispatches": n,
@@ -52,4 +52,10 @@ out = {"workload": workload, "bench_args": args, "lib_sha16": h, "kernel_src_sha
                      "record stream; this kernel's mix of 8 / 16 / 24-byte record loads and 8-byte gathers was calibrated at 1.927 on a "
                      "stream of known size (profiles/r01e_traffic.json), which is what is applied; WRITE_SIZE is exact",
        "hbm_bytes_per_launch": None if fetch is None else int(fetch * 1024 * 1.927 + (write or 0) * 1024)}
+# the layout kernel of the same step: 16-byte coalesced loads throughout (the guide's x 2 for FETCH_SIZE), 8 / 16-byte stores
+lf, ln = mean("FETCH_SIZE", "fetch", "spl_layout_kernel")
+lw, _ = mean("WRITE_SIZE", "write", "spl_layout_kernel")
+out["layout"] = {"kernel": "spl_layout_kernel", "dispatches": ln, "FETCH_SIZE_KB": lf, "WRITE_SIZE_KB": lw,
+                 "correction": "FETCH_SIZE x 2 (wide coalesced loads: MI355X_MICROARCH.md, HBM), WRITE_SIZE as it is",
+                 "hbm_bytes_per_launch": None if lf is None else int(lf * 1024 * 2 + (lw or 0) * 1024)}
 print(json.dumps(out, indent=1))
