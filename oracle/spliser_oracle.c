@@ -290,13 +290,25 @@ int orc_beta2_sse(int64_t n_sites, const int32_t *site_pos, const uint32_t *part
             const int64_t ppos = site_pos[p];
             int64_t doubles = dbl[e];
             int have_double_key = dbl[e] != 0;                        /* dict key created by checkBam adders */
-            for (uint32_t f = part_off[p]; f < part_off[p + 1]; ++f) { /* pSite.getPartnerCounts().items() (:592) */
-                const int64_t cpos = part_pos[f];
-                const int64_t cnt = edge_cnt[f];
-                if ((ppos > t && cpos < t) || (ppos < t && cpos > t)) { /* :594-599 */
-                    b2simple += cnt;
-                    doubles += cnt;
-                    have_double_key = 1;
+            /* PartnerBeta2DoubleCounts is keyed by the partner's POSITION (:598): what an earlier partner at the same position
+             * added to it (two Site objects at one position: strands '+' and '?', a junction whose ends coincide) is there when
+             * this one is looked at (:608) */
+            for (uint32_t e2 = part_off[s]; e2 <= e; ++e2) {
+                const int32_t q = part_site[e2];
+                if (q < 0 || site_pos[q] != ppos) continue;
+                for (uint32_t f = part_off[q]; f < part_off[q + 1]; ++f) { /* pSite.getPartnerCounts().items() (:592) */
+                    const int64_t cpos = part_pos[f];
+                    const int64_t cnt = edge_cnt[f];
+                    if (f > part_off[q]) { /* (a dict: a position listed twice by q's own edges is one item) */
+                        int seen = 0;
+                        for (uint32_t f2 = part_off[q]; f2 < f; ++f2) seen |= part_pos[f2] == part_pos[f];
+                        if (seen) continue;
+                    }
+                    if ((ppos > t && cpos < t) || (ppos < t && cpos > t)) { /* :594-599 */
+                        if (e2 == e) b2simple += cnt;
+                        doubles += cnt;
+                        have_double_key = 1;
+                    }
                 }
             }
             const int64_t p_alpha = alpha[p];                          /* :602 */

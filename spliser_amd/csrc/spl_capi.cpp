@@ -2291,8 +2291,37 @@ extern "C" int spl_soa_upload(spl_ctx *c, int n_seg, const spl_reads *segs, spl_
     if (q == hipSuccess) q = devmem::get(&dev->flag, 2 * (size_t)n_rec + 64, 'b');
     if (q == hipSuccess) q = devmem::get(&dev->cig_off, 4 * ((size_t)n_rec + 1) + 64, 'b');
     if (q == hipSuccess) q = devmem::get(&dev->cigar, 4 * (size_t)n_ops + 64, 'b');
+    // The arrays go up as they are, through the context's ring of page-locked staging buffers: a piece is copied into a buffer by
+    // the packing threads side by side (the CIGAR offsets moved behind the ops of the segments before theirs on the way), and is
+    // on the copy stream while the next piece is copied -- a caller's pageable array straight into hipMemcpy is a third of that.
+    int rc = q == hipSuccess ? ensure_stage(c) : SPL_OK;
+    if (rc) { free_device_reads(dev); return rc; }
+    struct Piece { char *dst; const char *src; size_t bytes; uint32_t add; bool offsets; size_t per; };
+    auto slice = [](size_t k, void *arg) {
+        const Piece &pc = *(const Piece *)arg;
+        const size_t a = k * pc.per, b = std::min(pc.bytes, a + pc.per);
+        if (a >= b) return;
+        if (!pc.offsets || pc.add == 0u) { memcpy(pc.dst + a, pc.src + a, b - a); return; }
+        const uint32_t *in = (const uint32_t *)(pc.src + a);
+        uint32_t *out = (uint32_t *)(pc.dst + a);
+        for (size_t i = 0; i < (b - a) / 4; ++i) out[i] = in[i] + pc.add;
+    };
+    auto send = [&](void *dst_dev, const void *src, size_t bytes, uint32_t add, bool offsets) {
+        for (size_t done = 0; done < bytes && q == hipSuccess;) {
+            spl_ctx::Stage &st = c->stage[c->stage_next];
+            c->stage_next = (c->stage_next + 1) % c->stage.size();
+            if (st.busy) { q = hipEventSynchronize(st.done); st.busy = false; if (q != hipSuccess) break; }
+            const size_t n = std::min(bytes - done, st.bytes / 64 * 64);
+            Piece pc{st.host, (const char *)src + done, n, add, offsets, 0};
+            const size_t slices = std::max<size_t>(1, std::min<size_t>((size_t)c->pack_threads * 2, n >> 16));
+            pc.per = ((n + slices - 1) / slices + 63) / 64 * 64;
+            splpack::parallel_for(slices, c->pack_threads, slice, &pc);
+            q = hipMemcpyAsync((char *)dst_dev + done, st.host, n, hipMemcpyHostToDevice, c->copy);
+            if (q == hipSuccess) { q = hipEventRecord(st.done, c->copy); st.busy = true; }
+            done += n;
+        }
+    };
     int64_t at = 0, op_at = 0;
-    std::vector<uint32_t> off; // (a segment's offsets, moved behind the ops of the segments before it)
     for (int k = 0; k < n_seg && q == hipSuccess; ++k) {
         const spl_reads &r = segs[k];
         const int64_t g = r.n_reads ? (int64_t)r.cig_off[r.n_reads] : 0;
@@ -2303,18 +2332,18 @@ extern "C" int spl_soa_upload(spl_ctx *c, int n_seg, const spl_reads *segs, spl_
             MaxEndJob job{&r, (r.n_reads + (int64_t)slices - 1) / (int64_t)slices, &best};
             splpack::parallel_for(slices, std::max(1, c->pack_threads), max_end_slice, &job);
             dev->ref_max[(size_t)k] = *std::max_element(best.begin(), best.end());
-            q = hipMemcpy((int32_t *)dev->pos + at, r.pos, 4 * (size_t)r.n_reads, hipMemcpyHostToDevice);
-            if (q == hipSuccess) q = hipMemcpy((uint16_t *)dev->flag + at, r.flag, 2 * (size_t)r.n_reads, hipMemcpyHostToDevice);
-            if (q == hipSuccess && g) q = hipMemcpy((uint32_t *)dev->cigar + op_at, r.cigar, 4 * (size_t)g, hipMemcpyHostToDevice);
-            off.resize((size_t)r.n_reads);
-            for (int64_t i = 0; i < r.n_reads; ++i) off[(size_t)i] = (uint32_t)(op_at + r.cig_off[i]);
-            if (q == hipSuccess) q = hipMemcpy((uint32_t *)dev->cig_off + at, off.data(), 4 * (size_t)r.n_reads, hipMemcpyHostToDevice);
+            send((int32_t *)dev->pos + at, r.pos, 4 * (size_t)r.n_reads, 0u, false);
+            send((uint16_t *)dev->flag + at, r.flag, 2 * (size_t)r.n_reads, 0u, false);
+            if (g) send((uint32_t *)dev->cigar + op_at, r.cigar, 4 * (size_t)g, 0u, false);
+            send((uint32_t *)dev->cig_off + at, r.cig_off, 4 * (size_t)r.n_reads, (uint32_t)op_at, true);
         }
         at += r.n_reads;
         op_at += g;
     }
     const uint32_t last = (uint32_t)op_at;
-    if (q == hipSuccess) q = hipMemcpy((uint32_t *)dev->cig_off + at, &last, 4, hipMemcpyHostToDevice);
+    if (q == hipSuccess) q = hipMemcpyAsync((uint32_t *)dev->cig_off + at, &last, 4, hipMemcpyHostToDevice, c->copy);
+    if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
+    for (spl_ctx::Stage &st : c->stage) st.busy = false;
     spl_dsoa *h = q == hipSuccess ? new (std::nothrow) spl_dsoa() : nullptr;
     if (!h) {
         free_device_reads(dev);

@@ -130,8 +130,15 @@ extern "C" int spl_tsv_append_many(const char *path, int32_t n_chrom, const spl_
                 out.append("NA\tNA");
             }
             out.append("\t{");
+            bool first_pair = true;
             for (uint32_t e = r.part_off[i]; e < r.part_off[i + 1]; ++e) {
-                if (e != r.part_off[i]) out.append(", ");
+                // (the column is str(dict) of PartnerCounts, :652: a row with two partner SITES at one position -- two edges -- has
+                //  the position once)
+                bool listed = false;
+                for (uint32_t e2 = r.part_off[i]; e2 < e && !listed; ++e2) listed = r.part_pos[e2] == r.part_pos[e];
+                if (listed) continue;
+                if (!first_pair) out.append(", ");
+                first_pair = false;
                 out.append(num, fmt_int(num, r.part_pos[e]));
                 out.append(": ");
                 out.append(num, fmt_int(num, r.edge_cnt[e]));

@@ -1351,14 +1351,24 @@ __device__ __forceinline__ void sse_site_core(const spl_sse_params &p, int64_t s
         const int64_t ppos = p.site_pos[ps];
         int64_t doubles = p.dbl[e];
         bool have_key = doubles != 0;
-        const uint32_t f1 = p.part_off[ps + 1];
-        for (uint32_t f = p.part_off[ps]; f < f1; ++f) { // pSite.getPartnerCounts().items() (:592)
-            const int64_t cpos = p.part_pos[f];
-            if ((ppos > t && cpos < t) || (ppos < t && cpos > t)) { // junction (pSite, c) flanks t (:594-599)
-                const int64_t cnt = p.edge_cnt[f];
-                b2simple += cnt;
-                doubles += cnt;
-                have_key = true;
+        // PartnerBeta2DoubleCounts is keyed by the partner's POSITION (:598): what an earlier partner at the same position added to
+        // it is there when this one is looked at (:608).  Two partner sites at one position are two edges (a stranded analysis of a
+        // BED file with strands that are none, a junction whose ends coincide); for every other row e2 == e is the only turn.
+        for (uint32_t e2 = e0; e2 <= e; ++e2) {
+            const int32_t qs = e2 == e ? ps : p.part_site[e2];
+            if (qs < 0 || (e2 != e && p.site_pos[qs] != ppos)) continue;
+            const uint32_t f0 = p.part_off[qs], f1 = p.part_off[qs + 1];
+            for (uint32_t f = f0; f < f1; ++f) { // pSite.getPartnerCounts().items() (:592)
+                const int64_t cpos = p.part_pos[f];
+                if ((ppos > t && cpos < t) || (ppos < t && cpos > t)) { // junction (pSite, c) flanks t (:594-599)
+                    bool listed = false; // (a dict: a position the partner's own edges name twice is one item)
+                    for (uint32_t f2 = f0; f2 < f; ++f2) listed |= p.part_pos[f2] == p.part_pos[f];
+                    if (listed) continue;
+                    const int64_t cnt = p.edge_cnt[f];
+                    if (e2 == e) b2simple += cnt;
+                    doubles += cnt;
+                    have_key = true;
+                }
             }
         }
         const int64_t shared = p.edge_cnt[e];          // PartnerCounts[pSite.pos] (:604)

@@ -26,9 +26,10 @@ class _Opts(ctypes.Structure):
 
 def marshal_sites(sites, sample=0):
     """One chromosome's Site objects (already in ``Site.__lt__`` order, as ``site2D_array[k]`` is) -> the arrays of ``spl_sites``:
-    rows in that order; a row's partners in ``PartnerCounts`` insertion order (= the Partners column's order), each with the row
-    of the partner Site (``getPartners()`` holds the objects; of two partners at one position the FIRST in the list counts, as
-    for the reference's own look-ups) and the junction's read count; competitors as ``getCompetitorPos()`` has them."""
+    rows in that order; a row's partners as its ``getPartners()`` list has them (the order of the Partners column), one edge per
+    partner Site with that Site's row and the read count ``PartnerCounts`` holds for its position (two partner Sites at one
+    position -- a BED strand that is none in a stranded analysis -- are two edges); competitors as ``getCompetitorPos()`` has
+    them."""
     row = {id(s): i for i, s in enumerate(sites)}
     pos = np.array([s.getPos() for s in sites], np.int32)
     strand = np.array([ord(s.getStrand()[:1] or "\0") for s in sites], np.uint8)
@@ -36,11 +37,11 @@ def marshal_sites(sites, sample=0):
     comp_off = part_off.copy()
     part_pos, part_site, edge_cnt, comp_pos = [], [], [], []
     for i, s in enumerate(sites):
-        rows = {p.getPos(): row[id(p)] for p in reversed(s.getPartners())}
-        for ppos, counts in s.getPartnerCounts().items():   # insertion order = Partners column order
-            part_pos.append(ppos)
-            part_site.append(rows.get(ppos, -1))
-            edge_cnt.append(counts[sample])
+        counts = s.getPartnerCounts()
+        for p in s.getPartners():               # the Site objects findBeta2Counts walks (:590); the Partners column's order
+            part_pos.append(p.getPos())
+            part_site.append(row.get(id(p), -1))
+            edge_cnt.append(counts[p.getPos()][sample])
         comp_pos += s.getCompetitorPos()
         part_off[i + 1], comp_off[i + 1] = len(part_pos), len(comp_pos)
     return dict(pos=pos, strand=strand, part_off=part_off, part_pos=np.array(part_pos, np.int32),

@@ -16,6 +16,7 @@ alpha / Partners / Competitors columns and the Gene column, so it follows the re
 (including the ones that look accidental) exactly.
 """
 import bisect
+import os
 
 import numpy as np
 
@@ -215,6 +216,60 @@ class _Site(object):
 _STRAND_RANK = {"+": 0, "-": 1}
 
 
+def _site_before(a, b, is_stranded):
+    """Site.__lt__ (Gene_Site_Iter_Graph_v0_1_8.py:123-136): by position; at one position of a stranded analysis '+' is before '-'
+    and every other pair of strands answers None there -- not before."""
+    if a.pos != b.pos:
+        return a.pos < b.pos
+    return bool(is_stranded and a.strand == "+" and b.strand == "-")
+
+
+def _array_insort(arr, site, is_stranded):
+    """bisect.insort(arr, site): behind everything it is not before."""
+    lo, hi = 0, len(arr)
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if _site_before(site, arr[mid], is_stranded):
+            hi = mid
+        else:
+            lo = mid + 1
+    arr.insert(lo, site)
+
+
+def _array_search(arr, pos, strand, is_stranded):
+    """binary_site_search (SpliSER_v0_1_8.py:175-225) on the reference's own list: the index it returns, or -1.  Its bisection
+    keeps two trackers and gives up when it visits an index twice in a row; a site at the position that does not suit the query
+    is followed by ONE look at each neighbour (below first, the one above wins) and the search ends there."""
+    n = len(arr)
+    if n == 0:          # (the reference does not search an empty list, :290-296)
+        return -1
+    free = _strand_free(strand, is_stranded)
+    pos = int(pos)
+    idx = nxt = n // 2
+    top, bottom, last = n, 0, -1
+    while True:
+        here = arr[idx].pos
+        if here == pos:
+            if free or arr[idx].strand == strand:
+                return idx
+            hit = -1
+            for k in (idx - 1, idx + 1):
+                if 0 <= k < n and arr[k].pos == pos and arr[k].strand == strand:
+                    hit = k
+            return hit
+        if pos >= here:
+            nxt = idx + (top - idx) // 2
+            bottom = idx
+        else:
+            nxt = idx - (idx - bottom) // 2
+            top = idx
+            if idx == 1:
+                nxt = 0
+        if idx == last:
+            return -1
+        last, idx = idx, nxt
+
+
 class ChromArrays(object):
     """SoA + CSR view of one chromosome's sites (the payload of ``spl_sites``).
 
@@ -256,10 +311,24 @@ class SiteTable(object):
         self.chrom_index = self.bins.chrom_index       # shared list: BED chromosomes are appended to it
         self.sites = {c: [] for c in self.chrom_index}  # site2D_array (:25), kept in Site.__lt__ order
         self._by_pos = {c: {} for c in self.chrom_index}
+        self._exact = {}      # chrom -> its sites as the reference's list has them (see _find)
         self.assessed = self.created = self.assigned = 0
 
     # -- lookup with binary_site_search's acceptance rule (:198-207) -------------------------------
+    # As long as no two sites of a chromosome can answer the same query, a dictionary by position says what the reference's
+    # bisection finds.  They can when a query does not care about strand (an unstranded analysis, or a BED strand other than
+    # '+' / '-') and a position holds more than one site: a line whose two ends coincide (both look-ups precede both
+    # insertions, :291-292), or -- stranded -- a '?' line at a position that has its '+' and '-' site.  WHICH of them the
+    # reference takes is where its bisection happens to land (:175-225), and where a new site goes among equals is where
+    # bisect.insort under Site.__lt__ puts it (a comparison of '?' with '+' answers None there).  From the first line that can
+    # make such a position on, the chromosome's sites are therefore kept as the reference keeps them -- a list in its order --
+    # and looked up and inserted with its own steps (_array_search, _array_insort); tools/fuzz_reference.py holds that to the
+    # reference itself.
     def _find(self, chrom, pos, strand):
+        arr = self._exact.get(chrom)
+        if arr is not None:
+            k = _array_search(arr, pos, strand, self.is_stranded)
+            return arr[k] if k >= 0 else None
         group = self._by_pos[chrom].get(pos)
         if not group:
             return None
@@ -275,8 +344,22 @@ class SiteTable(object):
         in a stranded analysis '+' sorts before '-' at equal pos."""
         group = self._by_pos[chrom].setdefault(site.pos, [])
         group.append(site)
-        if self.is_stranded and len(group) > 1:
+        arr = self._exact.get(chrom)
+        if arr is not None:
+            _array_insort(arr, site, self.is_stranded)
+        elif self.is_stranded and len(group) > 1:
             group.sort(key=lambda s: _STRAND_RANK.get(s.strand, 2))  # stable
+
+    def _keep_as_the_reference_does(self, chrom):
+        """From here on this chromosome's sites live in a list in the reference's order (so far: ascending position, '+' before
+        '-': what the groups hold)."""
+        if chrom in self._exact or os.environ.get("SPL_SITES_FIRST_AT_POSITION"):   # (the switch: round 4's look-ups, for tools/fuzz_reference.py's comparison)
+            return
+        by_pos = self._by_pos[chrom]
+        arr = []
+        for pos in sorted(by_pos):
+            arr.extend(by_pos[pos])
+        self._exact[chrom] = arr
 
     def add_bed(self, bed_path, q_chrom="All", q_gene="All", max_intron=0):
         """findAlphaCounts for one sample."""
@@ -309,6 +392,8 @@ class SiteTable(object):
                     if not (l_in or r_in):
                         continue
                 self.assessed += 2
+                if leftpos == rightpos or (self.is_stranded and strand != "+" and strand != "-"):
+                    self._keep_as_the_reference_does(chrom)      # (two sites may come to share a position for one query)
                 # both look-ups happen before either insertion (:291-292)
                 found = [self._find(chrom, leftpos, strand), self._find(chrom, rightpos, strand)]
                 pair = []
@@ -348,8 +433,11 @@ class SiteTable(object):
     def _finalise_order(self):
         for chrom, by_pos in self._by_pos.items():
             ordered = []
-            for pos in sorted(by_pos):
-                ordered.extend(by_pos[pos])
+            if chrom in self._exact:
+                ordered = list(self._exact[chrom])
+            else:
+                for pos in sorted(by_pos):
+                    ordered.extend(by_pos[pos])
             for row, site in enumerate(ordered):
                 site.row = row
             self.sites[chrom] = ordered
@@ -379,7 +467,11 @@ class SiteTable(object):
         out.alpha = np.fromiter((s.alpha for s in sites), dtype=np.int64, count=n)
         out.genes = [s.gene.name for s in sites]
         out.strand_text = [s.strand for s in sites]
-        deg = np.fromiter((len(s.partner_counts) for s in sites), dtype=np.int64, count=n)
+        # A row's partner edges are its Partners LIST (the Site objects findBeta2Counts walks, :590), one edge each, with the count
+        # PartnerCounts holds for the partner's position (:604).  Two partners at one position -- a '+' and a '?' site of a stranded
+        # analysis, the two sites of a junction whose ends coincide -- are two edges with the same position and count: the TSV's
+        # Partners column (a dict by position) shows one, the sums over partners take both.
+        deg = np.fromiter((len(s.partner_sites) for s in sites), dtype=np.int64, count=n)
         out.part_off = np.zeros(n + 1, dtype=np.uint32)
         np.cumsum(deg, out=out.part_off[1:])
         n_part = int(out.part_off[-1])
@@ -388,13 +480,10 @@ class SiteTable(object):
         out.edge_cnt = np.empty(n_part, dtype=np.int64)
         e = 0
         for s in sites:
-            rows = {}
-            for p in s.partner_sites:      # first Partners entry wins for a given position
-                rows.setdefault(p.pos, p.row)
-            for ppos, cnt in s.partner_counts.items():
-                out.part_pos[e] = ppos
-                out.part_site[e] = rows.get(ppos, -1)
-                out.edge_cnt[e] = cnt
+            for p in s.partner_sites:
+                out.part_pos[e] = p.pos
+                out.part_site[e] = p.row
+                out.edge_cnt[e] = s.partner_counts[p.pos]
                 e += 1
         cdeg = np.fromiter((len(s.competitors) for s in sites), dtype=np.int64, count=n)
         out.comp_off = np.zeros(n + 1, dtype=np.uint32)

@@ -34,7 +34,10 @@ def format_chrom(arr, res, cryptic):
         a, b = po[i], po[i + 1]
         c, d = co[i], co[i + 1]
         mid = ("%d\t%s" % (b2c[i], b2w[i])) if cryptic else "NA\tNA"
-        partners = "{" + ", ".join(["%d: %d" % pc for pc in zip(ppos[a:b], pcnt[a:b])]) + "}"
+        pairs = list(zip(ppos[a:b], pcnt[a:b]))
+        if len(set(ppos[a:b])) != b - a:          # (two partner sites at one position: the dict has the position once, :652)
+            pairs = list(dict(pairs).items())
+        partners = "{" + ", ".join(["%d: %d" % pc for pc in pairs]) + "}"
         competitors = "[" + ", ".join(map(str, cpos[c:d])) + "]"
         out.append("%s\t%d\t%s\t%s\t%s\t%d\t%d\t%d\t%s\t%s\t%s\n" % (
             chrom, pos[i], strand_text[i], genes[i], sse[i], alpha[i], beta1[i], b2s[i], mid, partners, competitors))

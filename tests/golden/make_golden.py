@@ -262,7 +262,29 @@ def case_single_gene():
                           "all_annot": {"gff": True}})
 
 
+def case_odd_strands():
+    """What a careful pipeline never feeds `process` and the reference processes all the same: BED strands that are neither '+' nor
+    '-' IN A STRANDED ANALYSIS (such a junction's look-ups take whichever site the reference's bisection lands on, :198, and a
+    new '?' site goes among the '+' / '-' sites of its position where bisect.insort under Site.__lt__ puts it), and junctions whose
+    two ends coincide (both look-ups precede both insertions, :291-292: two sites at one position from one line) -- positions
+    that hold several Site objects, partner lists that name a position twice."""
+    reads, juncs, gff = random_case(13, n_genes=5, n_reads=700, chroms=("Chr1",))
+    rng = random.Random(1313)
+    odd = []
+    for (c, l, r, sc, st) in juncs:
+        odd.append((c, l, r, sc, st))
+        if rng.random() < 0.45:       # the same junction, or one sharing an end, once more with a strand that is none
+            odd.append((c, l, r if rng.random() < 0.6 else r + rng.choice([4, 9]), rng.randint(0, 5), rng.choice("?.")))
+        if rng.random() < 0.12:
+            odd.append((c, l, l, rng.randint(1, 4), rng.choice("+-?")))
+    rng.shuffle(odd)
+    return dict(reads=reads, juncs=odd, gff=gff,
+                variants={"fr": {"stranded": "fr"}, "rf_cryptic": {"stranded": "rf", "cryptic": True}, "unstranded_cryptic": {"cryptic": True},
+                          "annot_fr_cryptic": {"gff": True, "stranded": "fr", "cryptic": True}})
+
+
 CASES = {
+    "odd_strands": case_odd_strands,
     "kat1": case_kat1, "kat2": case_kat2, "kat3": case_kat3, "kat4": case_kat4, "kat5": case_kat5,
     "cigar_corners": case_cigar_corners, "multichrom": case_multichrom,
     "random_a": lambda: case_random(7), "random_b": lambda: case_random(8, n_genes=10, n_reads=2400, chroms=("Chr1", "Chr2", "ChrM")),

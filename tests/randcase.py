@@ -9,7 +9,7 @@ import numpy as np
 from spliser_amd import samio, sites
 
 
-def make_case(seed, stranded, dirpath=None):
+def make_case(seed, stranded, dirpath=None, odd=False):
     """-> (ChromArrays of the table built from the case's BED file, ReadSet).  With ``dirpath`` the inputs are also left there as
     ``junctions.bed`` and ``reads.sam`` (what the reference takes)."""
     rng = np.random.default_rng(seed)
@@ -21,6 +21,13 @@ def make_case(seed, stranded, dirpath=None):
         strand = "+" if rng.random() < 0.5 else "-"
         if not stranded and rng.random() < 0.3:
             strand = "?"
+        if odd and rng.random() < 0.35:      # a strand that is neither '+' nor '-' in ANY analysis (a stranded one too: such a
+            strand = str(rng.choice(["?", "."]))   # query takes whichever site the reference's bisection lands on, :198)
+        l, r = int(positions[a]), int(positions[b])
+        if odd and rng.random() < 0.12:      # a junction whose two ends coincide: two sites at one position from one line (:291-292)
+            r = l
+        juncs.append(("c1", l, r, int(rng.integers(0, 9)), strand))
+        continue
         juncs.append(("c1", int(positions[a]), int(positions[b]), int(rng.integers(0, 9)), strand))
     tmp = dirpath or tempfile.mkdtemp(prefix="spl_rand_")
     bed = os.path.join(tmp, "junctions.bed" if dirpath else "j.bed")

@@ -32,6 +32,7 @@ class _Site(object):
     def addBeta2SimpleCount(self, v, sample): self.b2s[sample] += v
     def addBeta2CrypticCount(self, v, sample): self.b2c[sample] += v
     def updateBeta2Weighted(self, values): self.b2w = values
+    def getBeta2WeightedCounts(self): return self.b2w
     def setSSE(self, v, sample): self.sse[sample] = v
 
 
@@ -46,7 +47,7 @@ def _sites_of(arr):
     return sites
 
 
-@pytest.mark.parametrize("case,variant,opts", [c for c in golden_cases() if c[0] in ("kat1", "kat2", "kat5", "multichrom", "random_a", "cigar_corners")])
+@pytest.mark.parametrize("case,variant,opts", [c for c in golden_cases() if c[0] in ("kat1", "kat2", "kat5", "multichrom", "random_a", "cigar_corners", "odd_strands")])
 def test_the_stub_fills_the_sites_like_the_reference(case, variant, opts, tmp_path):
     case_dir = os.path.join(helpers.GOLDEN, case)
     if not os.path.isfile(os.path.join(case_dir, "junctions.bed")) or opts.get("gene"):

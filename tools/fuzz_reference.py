@@ -32,6 +32,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle", "refharness"))
 
 
+ODD = False      # --odd-strands: BED strands '?' / '.' in stranded analyses too, junctions whose two ends coincide
+
+
 def one_seed(seed):
     import numpy as np
     import randcase
@@ -42,7 +45,7 @@ def one_seed(seed):
     for stranded in (None, "fr", "rf"):
         tmp = tempfile.mkdtemp(prefix="spl_fuzzref_")
         try:
-            arr, rs = randcase.make_case(seed, bool(stranded), dirpath=tmp)
+            arr, rs = randcase.make_case(seed, bool(stranded), dirpath=tmp, odd=ODD)
             if arr.n == 0:
                 continue
             scode = {None: 0, "fr": 1, "rf": 2}[stranded]
@@ -73,20 +76,26 @@ def one_seed(seed):
                         return "MISMATCH (site %d: %r != %r) %s" % (i, got, want, tag)
                     # PartnerBeta2DoubleCounts as the reference leaves it: what checkBam added (:527, :551) plus, per partner, the
                     # counts of that partner's junctions flanking the site, which findBeta2Counts adds to the same dict (:594-599)
-                    dbl = {}
+                    # (a dict by POSITION: two partner sites at one position -- two edges -- share an entry: checkBam's count once, the
+                    #  flanking junctions of both, each of a partner's junctions once however often its lists name the position)
+                    dbl, from_reads = {}, {}
                     t = int(arr.pos[i])
                     for e in range(int(arr.part_off[i]), int(arr.part_off[i + 1])):
-                        ps = int(arr.part_site[e])
-                        total, have = int(cnt[2][e]), bool(cnt[2][e])
+                        ps, key = int(arr.part_site[e]), int(arr.part_pos[e])
+                        if key not in from_reads:
+                            from_reads[key] = int(cnt[2][e])
+                            if cnt[2][e]:
+                                dbl[key] = int(cnt[2][e])
                         if ps >= 0:
                             pp = int(arr.pos[ps])
+                            seen = set()
                             for f in range(int(arr.part_off[ps]), int(arr.part_off[ps + 1])):
                                 cp = int(arr.part_pos[f])
+                                if cp in seen:
+                                    continue
+                                seen.add(cp)
                                 if (pp > t and cp < t) or (pp < t and cp > t):
-                                    total += int(arr.edge_cnt[f])
-                                    have = True
-                        if have:
-                            dbl[int(arr.part_pos[e])] = total
+                                    dbl[key] = dbl.get(key, 0) + int(arr.edge_cnt[f])
                     if dbl != {int(k): int(v) for k, v in ref["double"]}:
                         return "MISMATCH (double counts of site %d: %r != %r) %s" % (i, dbl, ref["double"], tag)
                 runs += 1
@@ -176,7 +185,11 @@ def main():
     ap.add_argument("last", type=int)
     ap.add_argument("--jobs", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--combine", action="store_true", help="the real reference's combine / combineShallow against the product's host walk")
+    ap.add_argument("--odd-strands", action="store_true", help="process: BED strands other than + / - in stranded analyses as well, and junctions whose "
+                    "ends coincide -- positions that hold several sites for one query (binary_site_search's landing, SpliSER_v0_1_8.py:175-225)")
     a = ap.parse_args()
+    global ODD
+    ODD = a.odd_strands           # (the pool forks after this: the workers see it)
     import run_reference
     if not run_reference.reference_available():
         sys.exit("reference not available at %s (container-only tool)" % run_reference.REFERENCE_DIR)
@@ -207,8 +220,9 @@ def main():
                 sys.exit(1)
             runs += res[0]
             reads += res[1]
-    print("reference fuzz ok: seeds %d..%d x {unstranded, fr, rf} x {plain, --beta2Cryptic}: %d runs of SpliSER_v0_1_8.py process, "
-          "%d reads, TSV byte-identical, counters and doubles of every site identical, %.0f s" % (a.first, a.last, runs, reads, time.time() - t0))
+    print("reference fuzz ok%s: seeds %d..%d x {unstranded, fr, rf} x {plain, --beta2Cryptic}: %d runs of SpliSER_v0_1_8.py process, "
+          "%d reads, TSV byte-identical, counters and doubles of every site identical, %.0f s"
+          % (" (--odd-strands: BED strands '?' / '.' in stranded analyses too, junctions whose ends coincide)" if ODD else "", a.first, a.last, runs, reads, time.time() - t0))
 
 
 if __name__ == "__main__":
