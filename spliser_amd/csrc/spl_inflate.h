@@ -4,10 +4,9 @@
 // streams.  Two kernels inflate them (spl_inflate_wave.h has the method): the Huffman decoding, a WAVE per block -- 64 lanes
 // share one pair of look-up tables in LDS and find their places in the block's bits by decoding from guessed starts until the
 // guesses agree -- writes what the block's symbols say as a stream of tokens; the block's bytes are made from that stream by a
-// LANE per block.  Round 2's decoder, a lane per block for everything (canonical Huffman decoding by code length, tables per
-// lane), remains as spl_inflate_kernel for comparison: spl_dev_launch_inflate runs it when it is given no work space, or under
-// SPL_INFLATE_PER_LANE=1.  Every loop of either is bounded by the block's own sizes: a corrupt block ends with an error code in
-// its status word, never with a hang or a read beyond the image's padding.
+// LANE per block.  Every loop of either is bounded by the block's own sizes: a corrupt block ends with an error code in its status
+// word, never with a hang or a read beyond the image's padding.  (Round 2's decoder -- a lane per block for everything, canonical
+// Huffman decoding by code length with tables per lane -- was kept beside them for comparison until round 5: git history.)
 //
 // The inflate and CRC kernels are what `process` replaces the host's libdeflate + CRC32 threads with (bam_reader.cpp,
 // decode_worker; `--hostDecode` keeps those); replaces SpliSER_v0_1_8.py:422 (samtools view) all the same.

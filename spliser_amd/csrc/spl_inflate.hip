@@ -34,401 +34,7 @@ __global__ __launch_bounds__(64) void spl_inflate_copy_kernel(const spl_zblock *
     if (made != blocks[b].out_len) status[b] = SPL_Z_SHORT;
 }
 
-namespace {
-
-// (pointers into the file image say "global memory" in their type: the image's address goes through an integer to be aligned,
-// after which the compiler no longer knows, and a FLAT load counts as an LDS operation too -- every wait for a table look-up
-// would then wait for the read-ahead word as well, a trip to memory on the dependent chain of the symbols)
-typedef const __attribute__((address_space(1))) uint32_t *gptr32;
-typedef const __attribute__((address_space(1))) uint8_t *gptr8;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-struct BitReader {
-    gptr32 p;            // the word after `ahead`
-    const uint8_t *end;  // one past the block's DEFLATE data
-    uint64_t buf;
-    uint32_t cnt;        // valid bits in buf
-    uint32_t ahead;      // the next word of the image, asked for when the previous one was taken: a refill never waits for memory
-    __device__ __forceinline__ void init(const uint8_t *at, const uint8_t *e)
-    {
-        end = e;
-        const uintptr_t a = (uintptr_t)at;
-        p = (gptr32)(a & ~(uintptr_t)3);
-        const uint32_t skip = (uint32_t)(a & 3u) * 8u;
-        buf = (uint64_t)(*p++) >> skip;
-        cnt = 32u - skip;
-        ahead = *p++;
-    }
-    __device__ __forceinline__ void refill()
-    {
-        if (cnt <= 32u) { buf |= (uint64_t)ahead << cnt; cnt += 32u; ahead = *p++; }
-    }
-    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
-    __device__ __forceinline__ void drop(uint32_t n) { buf >>= n; cnt -= n; }
-    __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
-    // bytes of the block consumed so far (whole bytes still in the buffer, and the word read ahead, given back)
-    __device__ __forceinline__ const uint8_t *pos() const { return (const uint8_t *)(p - 1) - (cnt >> 3); }
-};
-
-// A canonical Huffman table, decoded without a loop over code lengths: limit[len] = the first 15-bit left-justified code value
-// that is NOT a code of `len` bits or fewer (non-decreasing in len, limit[0] = 0), so the length of the code at the head of the
-// bit buffer is the number of limits its left-justified value has reached.  Two limits to a word, both compared by ONE
-// subtraction: with v < 0x8000 and limits <= 0x8000, (0x8000 + v - limit) has bit 15 set exactly when v >= limit and never
-// borrows from its neighbour -- eight subtractions, eight masked population counts.  The symbol's place in the table's array
-// is base[len] + (v >> (15 - len)), base[len] = (symbols with shorter codes) - (first code of that length): one value per
-// length, picked from eight more registers.
-struct Table {
-    uint32_t w[8]; // limit[len] = (w[len >> 1] >> (16 * (len & 1))) & 0xffff, len = 0..15
-    uint32_t b[8]; // base[len] as int16, packed the same way
-};
-
-// The symbols of a lane's tables live in LDS, entry-major (entry e of lane l at [e * 64 + l]): a look-up is a ds_read instead
-// of a trip to the lane's scratch -- the look-up sits on the dependent chain of every symbol.  A byte per symbol plus, for the
-// literal/length table, a bit per entry for "256 and above": 354 bytes per lane, seven workgroups in a CU's 160 KB.
-struct LdsSyms {
-    uint8_t *lo;   // &bytes[lane]
-    uint32_t *hi;  // &bits[lane] (word w of lane l at [w * 64 + l]) or nullptr for tables whose symbols fit a byte
-    __device__ __forceinline__ int get(int e) const
-    {
-        int v = lo[e * 64];
-        if (hi) v |= (int)((hi[(e >> 5) * 64] >> (e & 31)) & 1u) << 8;
-        return v;
-    }
-    __device__ __forceinline__ void set(int e, int v) const
-    {
-        lo[e * 64] = (uint8_t)v;
-        if (hi) {
-            uint32_t &w = hi[(e >> 5) * 64];
-            w = (w & ~(1u << (e & 31))) | ((uint32_t)(v >> 8) << (e & 31));
-        }
-    }
-};
-
-__device__ __forceinline__ bool build_table(const uint8_t *lengths, int n, Table &c, const LdsSyms &symbol)
-{
-    uint16_t count[16], offs[16], limit[16], base[16];
-#pragma unroll
-    for (int l = 0; l < 16; ++l) count[l] = 0;
-    for (int s = 0; s < n; ++s) count[lengths[s]]++;
-    count[0] = 0;
-    // over-subscribed sets are an error; incomplete ones are legal only in the cases RFC 1951 allows, which the decode
-    // handles by finding no code
-    int left = 1;
-#pragma unroll
-    for (int l = 1; l < 16; ++l) {
-        left <<= 1;
-        left -= (int)count[l];
-        if (left < 0) return false;
-    }
-    offs[1] = 0;
-#pragma unroll
-    for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
-    int code = 0;
-    limit[0] = 0;
-    base[0] = 0;
-#pragma unroll
-    for (int l = 1; l < 16; ++l) {
-        base[l] = (uint16_t)((int)offs[l] - code); // (code = the first code of length l)
-        code += (int)count[l];
-        limit[l] = (uint16_t)(code << (15 - l)); // (<= 0x8000: the set is not over-subscribed)
-        code <<= 1;
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) c.b[k] = (uint32_t)base[2 * k] | ((uint32_t)base[2 * k + 1] << 16);
-    for (int s = 0; s < n; ++s)
-        if (lengths[s]) symbol.set(offs[lengths[s]]++, s);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) c.w[k] = (uint32_t)limit[2 * k] | ((uint32_t)limit[2 * k + 1] << 16);
-    return true;
-}
-
-// One symbol from the bits in the buffer (the caller has refilled it: 15 bits at most).  -1: no code matches (corrupt data,
-// or an incomplete table was asked for a code it does not have).
-__device__ __forceinline__ int decode_symbol(BitReader &br, const Table &c, const LdsSyms &symbol)
-{
-    const uint32_t v = __brev((uint32_t)br.buf) >> 17; // the next 15 bits, first bit on top: codes are packed from their top bit
-    const uint32_t vv = v * 0x10001u + 0x80008000u;
-    uint32_t len = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) len += (uint32_t)__popc((vv - c.w[k]) & 0x80008000u);
-    if (len > 15u) return -1; // (v >= limit[15])
-    const uint32_t i = len >> 1;
-    const uint32_t x0 = (i & 1u) ? c.b[1] : c.b[0], x1 = (i & 1u) ? c.b[3] : c.b[2], x2 = (i & 1u) ? c.b[5] : c.b[4], x3 = (i & 1u) ? c.b[7] : c.b[6];
-    const uint32_t y0 = (i & 2u) ? x1 : x0, y1 = (i & 2u) ? x3 : x2;
-    const uint32_t z = (i & 4u) ? y1 : y0;
-    const int base = (int)(int16_t)(uint16_t)(z >> (16u * (len & 1u)));
-    br.drop(len);
-    return symbol.get(base + (int)(v >> (15u - len)));
-}
-
-// Length symbol 257 + i -> (base, extra bits); distance symbol -> the same (RFC 1951, 3.2.5), by arithmetic: the tables would be
-// a trip to LDS on the symbol's dependent chain.
-__device__ __forceinline__ void length_code(uint32_t i, uint32_t &base, uint32_t &extra)
-{
-    extra = i < 8u || i == 28u ? 0u : (i >> 2) - 1u;
-    base = i < 4u ? 3u + i : (i == 28u ? 258u : 3u + ((4u + (i & 3u)) << extra));
-}
-__device__ __forceinline__ void distance_code(uint32_t i, uint32_t &base, uint32_t &extra)
-{
-    extra = i < 4u ? 0u : (i >> 1) - 1u;
-    base = i < 2u ? 1u + i : 1u + ((2u + (i & 1u)) << extra);
-}
-
-__constant__ uint8_t k_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
-} // namespace
-
-__global__ __launch_bounds__(64) void spl_inflate_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status)
-{
-    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
-    // lane-interleaved symbol tables: literal/length (288), distance (32); the code-length code's 19 symbols borrow the
-    // distance table's place while the lengths are being read
-    __shared__ uint8_t s_sym[(288 + 32) * 64];
-    __shared__ uint32_t s_hi[9 * 64];
-    const LdsSyms lsym{s_sym + threadIdx.x, s_hi + threadIdx.x}, dsym{s_sym + 288 * 64 + threadIdx.x, nullptr};
-    if (b >= n_blocks) return;
-    const spl_zblock zb = blocks[b];
-    uint8_t *const out = out_all + zb.out;
-    const uint32_t out_len = zb.out_len;
-    uint32_t at = 0; // bytes written
-    uint32_t err = SPL_Z_OK;
-    if (out_len == 0) { status[b] = SPL_Z_OK; return; } // (the EOF marker and other empty blocks: nothing to decode into)
-    BitReader br;
-    br.init(image + zb.in, image + zb.in + zb.in_len);
-    uint8_t lengths[320];
-    Table lc, dc;
-    uint64_t window = 0; // the last eight bytes of the output, the most recent one on top
-    for (int last = 0; !last && err == SPL_Z_OK;) {
-        br.refill();
-        last = (int)br.take(1);
-        const uint32_t type = br.take(2);
-        if (type == 0u) { // stored: skip to a byte boundary, LEN, NLEN, bytes
-            br.drop(br.cnt & 7u);
-            br.refill();
-            const uint32_t len = br.take(16);
-            br.refill();
-            const uint32_t nlen = br.take(16);
-            if ((len ^ 0xffffu) != nlen) { err = SPL_Z_BAD_STORED; break; }
-            const uint8_t *src = br.pos();
-            if (src + len > br.end || at + len > out_len) { err = SPL_Z_OVERRUN; break; }
-            for (uint32_t i = 0; i < len; ++i) { out[at + i] = src[i]; window = (window >> 8) | ((uint64_t)src[i] << 56); }
-            at += len;
-            br.init(src + len, br.end);
-            continue;
-        }
-        if (type == 3u) { err = SPL_Z_BAD_BLOCK_TYPE; break; }
-        if (type == 1u) { // fixed codes
-            int s = 0;
-            for (; s < 144; ++s) lengths[s] = 8;
-            for (; s < 256; ++s) lengths[s] = 9;
-            for (; s < 280; ++s) lengths[s] = 7;
-            for (; s < 288; ++s) lengths[s] = 8;
-            build_table(lengths, 288, lc, lsym);
-            for (s = 0; s < 30; ++s) lengths[s] = 5;
-            build_table(lengths, 30, dc, dsym);
-        } else { // dynamic codes
-            br.refill();
-            const int nlen = (int)br.take(5) + 257, ndist = (int)br.take(5) + 1, ncode = (int)br.take(4) + 4;
-            if (nlen > 286 || ndist > 30) { err = SPL_Z_BAD_LENGTHS; break; }
-            uint8_t cl[19];
-#pragma unroll
-            for (int i = 0; i < 19; ++i) cl[i] = 0;
-            // (a header is bounded by the block's own bytes like everything else: the read-ahead runs 12 bytes past what has been
-            //  consumed, the image is readable SPL_Z_IMAGE_PAD bytes past any block -- beyond end + 24 the data is corrupt)
-            const gptr8 stop_h = (gptr8)(br.end + 24);
-            for (int i = 0; i < ncode && (gptr8)br.p <= stop_h; ++i) { br.refill(); cl[k_clen_order[i]] = (uint8_t)br.take(3); }
-            if ((gptr8)br.p > stop_h) { err = SPL_Z_OVERRUN; break; }
-            Table cc;
-            const LdsSyms csym = dsym;
-            if (!build_table(cl, 19, cc, csym)) { err = SPL_Z_BAD_LENGTHS; break; }
-            int idx = 0;
-            while (idx < nlen + ndist) {
-                if ((gptr8)br.p > stop_h) { err = SPL_Z_OVERRUN; break; }
-                br.refill();
-                const int sym = decode_symbol(br, cc, csym);
-                if (sym < 0) { err = SPL_Z_BAD_CODE; break; }
-                if (sym < 16) { lengths[idx++] = (uint8_t)sym; continue; }
-                int prev = 0, rep;
-                br.refill();
-                if (sym == 16) {
-                    if (idx == 0) { err = SPL_Z_BAD_LENGTHS; break; }
-                    prev = lengths[idx - 1];
-                    rep = 3 + (int)br.take(2);
-                } else if (sym == 17) {
-                    rep = 3 + (int)br.take(3);
-                } else {
-                    rep = 11 + (int)br.take(7);
-                }
-                if (idx + rep > nlen + ndist) { err = SPL_Z_BAD_LENGTHS; break; }
-                while (rep--) lengths[idx++] = (uint8_t)prev;
-            }
-            if (err != SPL_Z_OK) break;
-            if (lengths[256] == 0) { err = SPL_Z_BAD_LENGTHS; break; } // no end-of-block code
-            if (!build_table(lengths, nlen, lc, lsym)) { err = SPL_Z_BAD_LENGTHS; break; }
-            if (!build_table(lengths + nlen, ndist, dc, dsym)) { err = SPL_Z_BAD_LENGTHS; break; }
-        }
-        // The symbols of the block, as a state machine that does ONE small thing per turn -- a literal/length symbol, a distance
-        // symbol, or a piece of a pending copy.  The 64 lanes of a wave take their turns together: a loop that finished a
-        // 258-byte copy before looking at the next symbol would make 63 lanes wait for the longest copy among them at every
-        // step (that version ran at a twelfth of this one's speed).
-        //
-        // A turn has a memory half and a decoding half, and nothing in a turn waits for memory it has asked for itself:
-        // what the memory half asks for -- the next word of the block, the source bytes of a copy -- is used by the memory
-        // half of the NEXT turn, and what the decoding half produces -- a literal -- is stored by the next turn's memory half.
-        // The wave's one wait per turn is then for operations issued a whole symbol decode earlier, instead of a round trip to
-        // the L2 after every load and an acknowledged store before every refill (62 % of the kernel's time, by SQ_WAIT_ANY).
-        // `window` = the last eight bytes of the output: a copy at a distance of eight or less is made from it, no load at all.
-        uint32_t copy_left = 0, copy_dist = 0, want_dist = 0;
-        uint32_t lit = 0, n_lit = 0; // literals of the last turn (two at most), not yet stored
-        bool eob = false, loaded = false;
-        uint32_t wide = 0; // what has been asked for: 0 = eight bytes, 1 = 32, 2 = 64
-        uint64_t w0 = 0; // eight source bytes of a copy, or
-        u32x4 wa = {0, 0, 0, 0}, wb = {0, 0, 0, 0}, wc = {0, 0, 0, 0}, wd = {0, 0, 0, 0}; // thirty-two (wa, wb) or sixty-four
-        const gptr8 stop = (gptr8)(br.end + 24); // (the read-ahead runs 12 bytes past what has been consumed: beyond this, the data is corrupt)
-        for (uint32_t turns = 0;; ++turns) {
-            // the turn's one wait for memory: everything the previous turn asked for, asked for before its decoding half.
-            // (Said to the compiler as a use of all of it, here: left to itself it waits where each value is first touched, for
-            // everything in flight at that point -- this turn's stores and loads included.)
-            asm volatile("" : "+v"(w0), "+v"(wa), "+v"(wb), "+v"(wc), "+v"(wd), "+v"(br.ahead));
-            if (turns > 2u * out_len + 4096u || (gptr8)br.p > stop) { err = SPL_Z_OVERRUN; break; }
-            br.refill(); // (33 bits or more after this: a symbol and its extra bits are 28 at most)
-            // ---- the memory half: stores first (they may be what the loads after them read), then the loads
-            if (n_lit) {
-                if (n_lit == 2u) { const uint16_t two = (uint16_t)lit; __builtin_memcpy(out + at - 2u, &two, 2); }
-                else out[at - 1u] = (uint8_t)lit;
-                n_lit = 0;
-            }
-            if (eob) break; // (seen behind a literal in the last turn)
-            if (copy_left) {
-                uint64_t bytes = 0;
-                bool narrow = false;
-                if (copy_dist <= 8u) {
-                    // the next bytes repeat the last copy_dist ones: double the pattern until it covers eight bytes
-                    uint64_t rep = copy_dist == 8u ? window : (window >> (8u * (8u - copy_dist)));
-                    if (copy_dist < 8u) rep &= (1ull << (8u * copy_dist)) - 1ull;
-                    if (copy_dist < 2u) rep |= rep << 8;
-                    if (copy_dist < 3u) rep |= rep << 16;
-                    else if (copy_dist == 3u) rep |= rep << 24;
-                    if (copy_dist < 5u) { if (copy_dist == 3u) rep |= rep << 48; else rep |= rep << 32; }
-                    else if (copy_dist < 8u) rep |= rep << (8u * copy_dist);
-                    bytes = rep;
-                    narrow = true;
-                } else if (loaded) {
-                    if (wide == 2u) {
-                        __builtin_memcpy(out + at, &wa, 16);
-                        __builtin_memcpy(out + at + 16, &wb, 16);
-                        __builtin_memcpy(out + at + 32, &wc, 16);
-                        __builtin_memcpy(out + at + 48, &wd, 16);
-                        window = (uint64_t)wd.z | ((uint64_t)wd.w << 32);
-                        at += 64u;
-                        copy_left -= 64u;
-                    } else if (wide == 1u) {
-                        __builtin_memcpy(out + at, &wa, 16);
-                        __builtin_memcpy(out + at + 16, &wb, 16);
-                        window = (uint64_t)wb.z | ((uint64_t)wb.w << 32);
-                        at += 32u;
-                        copy_left -= 32u;
-                    } else {
-                        bytes = w0;
-                        narrow = true;
-                    }
-                    loaded = false;
-                }
-                if (narrow) {
-                    // eight bytes at out + at, the first n of them meant: stored whole when the ones beyond are this lane's to
-                    // overwrite later (all but the last seven bytes of a block)
-                    const uint32_t n = copy_left < 8u ? copy_left : 8u;
-                    if (at + 8u <= out_len) {
-                        __builtin_memcpy(out + at, &bytes, 8);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            if ((uint32_t)k < n) out[at + (uint32_t)k] = (uint8_t)(bytes >> (8 * k));
-                    }
-                    window = n == 8u ? bytes : ((window >> (8u * n)) | (bytes << (8u * (8u - n))));
-                    at += n;
-                    copy_left -= n;
-                }
-                if (copy_left && copy_dist > 8u) {
-                    // the next piece's source: behind `at` in full (the distance is more than its length), stored already
-                    const uint8_t *src = out + at - copy_dist;
-                    wide = copy_dist >= 64u && copy_left >= 64u ? 2u : (copy_dist >= 32u && copy_left >= 32u ? 1u : 0u);
-                    if (wide) {
-                        __builtin_memcpy(&wa, src, 16);
-                        __builtin_memcpy(&wb, src + 16, 16);
-                        if (wide == 2u) {
-                            __builtin_memcpy(&wc, src + 32, 16);
-                            __builtin_memcpy(&wd, src + 48, 16);
-                        }
-                    } else {
-                        __builtin_memcpy(&w0, src, 8);
-                    }
-                    loaded = true;
-                }
-            }
-            if (copy_left) continue;
-            // ---- the decoding half.  One decode per turn whichever table the lane is at (a length is followed by a distance):
-            // the lanes that want a distance symbol and those that want a literal/length symbol go through the same
-            // instructions with their own limits, bases and symbol arrays -- two decode blocks in a row cost every turn twice
-            const bool is_dist = want_dist != 0u;
-            Table tc;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { tc.w[k] = is_dist ? dc.w[k] : lc.w[k]; tc.b[k] = is_dist ? dc.b[k] : lc.b[k]; }
-            const LdsSyms ts{is_dist ? dsym.lo : lsym.lo, lsym.hi};
-            int sym = decode_symbol(br, tc, ts);
-            if (sym < 0) { err = SPL_Z_BAD_CODE; break; }
-            if (is_dist) {
-                const uint32_t ds = (uint32_t)sym & 0xffu; // (the high bit belongs to the literal/length table: meaningless here)
-                if (ds >= 30u) { err = SPL_Z_BAD_CODE; break; }
-                uint32_t base, extra;
-                distance_code(ds, base, extra);
-                copy_dist = base + br.take(extra);
-                if (copy_dist > at) { err = SPL_Z_BAD_DISTANCE; break; }
-                copy_left = want_dist;
-                if (at + copy_left > out_len) { err = SPL_Z_OVERRUN; break; }
-                want_dist = 0;
-                continue;
-            }
-            if (sym < 256) {
-                if (at >= out_len) { err = SPL_Z_OVERRUN; break; }
-                lit = (uint32_t)sym;
-                n_lit = 1; // (stored by the next turn, behind `at`)
-                ++at;
-                window = (window >> 8) | ((uint64_t)sym << 56);
-                // a second symbol in the same turn when the bits are there (a code and a length's extra bits: 20 at most):
-                // most symbols are literals, and the turn's memory half, its wait and its bookkeeping are then paid once for two
-                if (br.cnt >= 20u) {
-                    const int s2 = decode_symbol(br, lc, lsym);
-                    if (s2 < 0) { err = SPL_Z_BAD_CODE; break; }
-                    if (s2 < 256) {
-                        if (at >= out_len) { err = SPL_Z_OVERRUN; break; }
-                        lit |= (uint32_t)s2 << 8;
-                        n_lit = 2;
-                        ++at;
-                        window = (window >> 8) | ((uint64_t)s2 << 56);
-                    } else if (s2 == 256) {
-                        eob = true; // (the literal is still to be stored: the next turn does that and leaves)
-                    } else {
-                        const uint32_t l2 = (uint32_t)s2 - 257u;
-                        if (l2 >= 29u) { err = SPL_Z_BAD_CODE; break; }
-                        uint32_t base, extra;
-                        length_code(l2, base, extra);
-                        want_dist = base + br.take(extra);
-                    }
-                }
-                continue;
-            }
-            if (sym == 256) break;
-            const uint32_t ls = (uint32_t)sym - 257u;
-            if (ls >= 29u) { err = SPL_Z_BAD_CODE; break; }
-            uint32_t base, extra;
-            length_code(ls, base, extra);
-            want_dist = base + br.take(extra); // (the length, 3..258: a distance symbol follows)
-        }
-    }
-    if (err == SPL_Z_OK && at != out_len) err = SPL_Z_SHORT;
-    status[b] = err;
-}
 
 // CRC32 (IEEE, reflected) of every block's payload against the value in its trailer: one lane per block -- 768 waves for a window,
 // which leaves the CUs to the decoding kernel beside it -- and the lane's block as S streams (spl_crc.h): S chains of table
@@ -770,10 +376,7 @@ extern "C" int spl_dev_launch_inflate_copy(const spl_zblock *blocks, uint32_t n_
 extern "C" int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, void *stream)
 {
     if (n_blocks == 0) return 0;
-    if (!work) {
-        hipLaunchKernelGGL(spl_inflate_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, out, status);
-        return (int)hipGetLastError();
-    }
+    if (!work) return (int)hipErrorInvalidValue; // (the two kernels exchange the blocks' token streams there: spl_dev_inflate_work_bytes)
     const int rc = spl_dev_launch_inflate_decode(image, blocks, n_blocks, status, work, stream);
     return rc ? rc : spl_dev_launch_inflate_copy(blocks, n_blocks, out, status, work, stream);
 }
