@@ -24,7 +24,7 @@ export SPL_BAM_TIMING=1
 (python3 tools/decode_rate.py /tmp/wl_files/human_s1_q0.bam 8 16 32 64; python3 tools/decode_rate.py /tmp/wl_files/human_s0.25_q1.bam 8 16 32 64) > gpurun_out/${TAG}_decode_rate.txt 2>&1
 unset SPL_BAM_TIMING
 bash tools/prof_inflate_pmc.sh ${TAG}_inflate 0.25 > /dev/null 2>&1
-bash tools/r03_window_sweep.sh ${TAG} 0.25 49152 > gpurun_out/${TAG}_inflate_kernel_stats.txt 2>&1
+bash tools/window_sweep.sh ${TAG} 0.25 49152 > gpurun_out/${TAG}_inflate_kernel_stats.txt 2>&1
 (python3 tools/site_upload_time.py human; python3 tools/site_upload_time.py arabidopsis) > gpurun_out/${TAG}_site_upload.txt 2>&1
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -2 > gpurun_out/${TAG}_gpu_tests.txt
 cat gpurun_out/${TAG}_cold_time.txt gpurun_out/${TAG}_gpu_tests.txt
