@@ -1251,12 +1251,12 @@ static int add_segment_device(spl_ctx *c, spl_dreads *d, DeviceReads *dev, int64
 // that straddles two windows: the bytes from the first block that is not done with to the window's end are copied in front of the
 // next window's buffer (its head room), so that scan and extraction see them in one piece; the blocks are not inflated twice.
 namespace {
-struct ShareOut { DeviceReads *reads = nullptr; int64_t n_all = 0; bool to_host = false; bool published = false; };
+struct ShareOut { DeviceReads *reads = nullptr; int64_t n_all = 0; bool to_host = false; bool published = false; bool more_tokens = false; };
 // What the caller of decode_share does with the share's reads, called by decode_share itself as its LAST act before it gives its
 // buffers, streams and events back -- which takes 10 ms for a large file, and whoever waits for the file's references need not.
 typedef std::function<int(ShareOut &)> Publish;
 }
-static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, ShareOut &res, const Publish &publish);
+static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, ShareOut &res, const Publish &publish, bool all_token_room = false);
 
 static void fill_whole(spl_bam *bam, spl_bam_share &sh) { sh.block_lo = 0; sh.block_hi = spl_bam_block_count(bam); sh.tid_lo = 0; sh.tid_hi = spl_bam_n_ref(bam) + 1; }
 
@@ -1291,6 +1291,7 @@ extern "C" int spl_bam_decode_device(spl_ctx *c, spl_bam *bam, int *on_device_ou
         return rc;
     };
     int rc = decode_share(c, bam, nullptr, res, adopt);
+    if (rc == SPL_OK && res.more_tokens) { res = ShareOut(); rc = decode_share(c, bam, nullptr, res, adopt, true); }
     if (rc == SPL_OK && !res.to_host && res.reads && !res.published) rc = adopt(res); // (SPL_PUBLISH_LATE only: decode_share publishes what it returns)
     // whatever went wrong on the way (device memory, a HIP error, a file this path does not take): the file must not be left
     // without a decoder -- the host threads take it (a no-op when the arrays were adopted); spl_last_error keeps the reason
@@ -1320,6 +1321,7 @@ extern "C" int spl_bam_decode_device_share(spl_ctx *c, spl_bam *bam, int k, int 
         return rc2;
     };
     rc = decode_share(c, bam, &sh, res, report);
+    if (rc == SPL_OK && res.more_tokens) { res = ShareOut(); rc = decode_share(c, bam, &sh, res, report, true); }
     if (res.published) return rc;
     const bool failed = rc != SPL_OK || res.to_host || !res.reads;
     if (!failed) return report(res); // (SPL_PUBLISH_LATE only: decode_share publishes what it returns)
@@ -1328,7 +1330,7 @@ extern "C" int spl_bam_decode_device_share(spl_ctx *c, spl_bam *bam, int k, int 
     return spl_bam_share_done(bam, k, nullptr, free_device_reads, nullptr, nullptr, nullptr, res.n_all, 1);
 }
 
-static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, ShareOut &res, const Publish &publish)
+static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, ShareOut &res, const Publish &publish, bool all_token_room)
 {
     HIP_TRY(hipSetDevice(c->device));
     const bool timing = getenv("SPL_BAM_TIMING") != nullptr;
@@ -1481,10 +1483,24 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             win_bytes_cap = (ring - 3) * piece / 4;
         }
     }
+    // Token room per block (decoding kernel -> copying kernel).  The worst case is 82 048 bytes -- five bytes of tokens for four
+    // of output -- and what BAM blocks take is 1.3 to 1.8 times their compressed size (29 KB where a block deflates to 16.6 KB):
+    // two token buffers at the worst case are 8 GB of the 26 GB a new process's first call waited for.  So: 2.5 times the file's
+    // mean compressed block + 4 KB, and a block that needs more says so (SPL_Z_TOKENS) -- the share is then decoded again with
+    // all of it (no real file was seen to; zlib's Z_HUFFMAN_ONLY streams in the tests do).  SPL_Z_ALL_TOKEN_ROOM=1: always all.
+    uint32_t tok_stride = SPL_Z_TOKEN_STRIDE;
+    if (!all_token_room && !getenv("SPL_Z_ALL_TOKEN_ROOM")) {
+        const double want = 2.5 * per_block_file + 4096.0;
+        tok_stride = (uint32_t)std::min<double>((double)SPL_Z_TOKEN_STRIDE, std::max(8192.0, want));
+        if (const char *e = getenv("SPL_Z_TOKEN_ROOM")) tok_stride = (uint32_t)std::max(512, atoi(e)); // (tests: a room most blocks do not fit)
+        tok_stride = (tok_stride + 63u) & ~63u;
+        if (tok_stride > SPL_Z_TOKEN_STRIDE) tok_stride = SPL_Z_TOKEN_STRIDE;
+    }
+    if (timing) fprintf(stderr, "[spl_bam_decode_device] device %d: %u bytes of token room a block (%.0f bytes of file a block)\n", c->device, tok_stride, per_block_file);
     {   // a first look, before anything is allocated: the ring, two windows of a stream that is at most 64 KiB a block with their
         // token room, a fifth of the inflated stream for what is extracted; the exact sizes are checked again where they are known
         const double blocks_all = (double)n_bytes / std::max(per_block_file, 28.0) + 1.0, blocks_most = std::min((double)win_blocks, blocks_all);
-        if ((double)ring * (double)slot + 0.2 * blocks_all * 65536.0 + 2.0 * blocks_most * (65536.0 + (double)SPL_Z_TOKEN_STRIDE) + slack > (double)free_b)
+        if ((double)ring * (double)slot + 0.2 * blocks_all * 65536.0 + 2.0 * blocks_most * (65536.0 + (double)tok_stride) + slack > (double)free_b)
             return to_host("not enough device memory");
     }
     HIP_TRY(d_image.get(ring * slot + SPL_Z_IMAGE_PAD, c->copy));
@@ -1599,7 +1615,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             const size_t b1 = window_end(off0, 0, off0.size()), b_most = std::min(win_blocks, n_known); // (b_most: what any window of this file can have -- the buffers serve later windows too)
             const size_t b2 = two ? window_end(off0, b1, off0.size()) : b1; // (where the second window ends)
             blocks0.resize(b2);
-            const size_t work0 = spl_dev_inflate_work_bytes((uint32_t)b_most);
+            const size_t work0 = spl_dev_inflate_work_bytes2((uint32_t)b_most, tok_stride);
             HIP_TRY(look_at_free());
             if ((double)HEAD + (double)b_most * 65536.0 + (double)work0 + 2.0 * slack < (double)free_b) {
                 HIP_TRY(d_stream[0].get(HEAD + (uint64_t)b_most * 65536u + 256, c->copy)); // (no block inflates to more than 64 KiB)
@@ -1620,14 +1636,14 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 const double w_in = (double)(off0[b1 - 1] + blocks0[b1 - 1].in_len - off0[0]), w_out = (double)(blocks0[b1 - 1].out + blocks0[b1 - 1].out_len - blocks0[0].out);
                 {
                     splprof::Scope p("spl_inflate_decode_kernel", pipe.a, w_in + w_out);
-                    HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks0.as<spl_zblock>(), (uint32_t)b1, d_status0.as<uint32_t>(), d_zwork[0].p, pipe.a));
+                    HIP_TRY((hipError_t)spl_dev_launch_inflate_decode2(image0, d_blocks0.as<spl_zblock>(), (uint32_t)b1, d_status0.as<uint32_t>(), d_zwork[0].p, tok_stride, pipe.a));
                 }
                 HIP_TRY(hipEventRecord(pipe.k1[0], pipe.a));
                 HIP_TRY(hipEventRecord(pipe.dec[0], pipe.a));
                 HIP_TRY(hipStreamWaitEvent(pipe.cp[0], pipe.k1[0], 0));
                 {
                     splprof::Scope p("spl_inflate_copy_kernel", pipe.cp[0], w_out);
-                    HIP_TRY((hipError_t)spl_dev_launch_inflate_copy(d_blocks0.as<spl_zblock>(), (uint32_t)b1, stream0, d_status0.as<uint32_t>(), d_zwork[0].p, pipe.cp[0]));
+                    HIP_TRY((hipError_t)spl_dev_launch_inflate_copy2(d_blocks0.as<spl_zblock>(), (uint32_t)b1, stream0, d_status0.as<uint32_t>(), d_zwork[0].p, tok_stride, pipe.cp[0]));
                 }
                 HIP_TRY(hipEventRecord(pipe.k2[0], pipe.cp[0]));
                 early = b1;
@@ -1650,7 +1666,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                     }
                     {
                         splprof::Scope p("spl_inflate_decode_kernel", pipe.a, (double)(off0[b2 - 1] + blocks0[b2 - 1].in_len - off0[b1]) + (double)(blocks0[b2 - 1].out + blocks0[b2 - 1].out_len - blocks0[b1].out));
-                        HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks0.as<spl_zblock>() + b1, (uint32_t)(b2 - b1), d_status0.as<uint32_t>() + b1, d_zwork[1].p, pipe.a));
+                        HIP_TRY((hipError_t)spl_dev_launch_inflate_decode2(image0, d_blocks0.as<spl_zblock>() + b1, (uint32_t)(b2 - b1), d_status0.as<uint32_t>() + b1, d_zwork[1].p, tok_stride, pipe.a));
                     }
                     HIP_TRY(hipEventRecord(pipe.k1[1], pipe.a));
                     HIP_TRY(hipEventRecord(pipe.dec[1], pipe.a));
@@ -1705,7 +1721,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     }
     size_t most_blocks = 0;
     for (size_t k = 0; k < n_win; ++k) most_blocks = std::max(most_blocks, win_at[k + 1] - win_at[k]);
-    const size_t work_bytes = spl_dev_inflate_work_bytes((uint32_t)most_blocks);
+    const size_t work_bytes = spl_dev_inflate_work_bytes2((uint32_t)most_blocks, tok_stride);
     HIP_TRY(look_at_free());
     // Windows in flight.  A window has two buffers, each free again when its reader is done: the TOKENS (decoding kernel ->
     // copying kernel) when the window's copying kernel has run, the inflated BYTES (copying kernel -> CRC32, scan, extraction)
@@ -1806,7 +1822,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         const double w_in = (double)(foff[b1 - 1] + blocks[b1 - 1].in_len - foff[b0]), w_out = (double)(blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out);
         {
             splprof::Scope p("spl_inflate_decode_kernel", pipe.a, w_in + w_out);
-            HIP_TRY((hipError_t)spl_dev_launch_inflate_decode(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_zw].p, pipe.a));
+            HIP_TRY((hipError_t)spl_dev_launch_inflate_decode2(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_zw].p, tok_stride, pipe.a));
         }
         HIP_TRY(hipEventRecord(pipe.k1[k % (size_t)n_zw], pipe.a));
         HIP_TRY(hipEventRecord(pipe.dec[k], pipe.a));
@@ -1825,8 +1841,8 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         const bool from_early = k < n_early; // (its decoding kernel left the blocks' status in the early list's words)
         {
             splprof::Scope p("spl_inflate_copy_kernel", cs, (double)(blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out));
-            HIP_TRY((hipError_t)spl_dev_launch_inflate_copy((from_early ? d_blocks0 : d_blocks).as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k),
-                                                            (from_early ? d_status0 : d_status).as<uint32_t>() + b0, d_zwork[k % (size_t)n_zw].p, cs));
+            HIP_TRY((hipError_t)spl_dev_launch_inflate_copy2((from_early ? d_blocks0 : d_blocks).as<spl_zblock>() + b0, (uint32_t)(b1 - b0), stream0_of(k),
+                                                             (from_early ? d_status0 : d_status).as<uint32_t>() + b0, d_zwork[k % (size_t)n_zw].p, tok_stride, cs));
         }
         HIP_TRY(hipEventRecord(pipe.k2[k], cs));
         return SPL_OK;
@@ -1885,6 +1901,12 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         HIP_TRY(hipMemcpyAsync(scan.get() + s0, d_scan.as<spl_bscan>() + s0, sizeof(spl_bscan) * (b1 - s0), hipMemcpyDeviceToHost, pipe.b));
         HIP_TRY(hipStreamSynchronize(pipe.b));
         if (timing) t_win.push_back(host_now() - t_begin);
+        for (size_t i = b0; i < b1; ++i)
+            if (status[i] == SPL_Z_TOKENS && tok_stride < SPL_Z_TOKEN_STRIDE) { // (a block wants more token room than this file's were given: again, with all of it)
+                if (timing) fprintf(stderr, "[spl_bam_decode_device] block %zu needs more than %u bytes of token room: the share again with %u\n", i, tok_stride, SPL_Z_TOKEN_STRIDE);
+                res.more_tokens = true;
+                return SPL_OK;
+            }
         for (size_t i = b0; i < b1; ++i)
             if (status[i] != SPL_Z_OK) return to_host("a block did not inflate (or its CRC32 is wrong)");
         // Which of the window's blocks are done with: all whose records end inside it.  A block near the window's end may have

@@ -43,6 +43,7 @@ struct spl_zblock {
 #define SPL_Z_OVERRUN 6u
 #define SPL_Z_SHORT 7u
 #define SPL_Z_BAD_CRC 8u
+#define SPL_Z_TOKENS 9u        // the block's tokens do not fit the room it was given (a caller that gave less than SPL_Z_TOKEN_STRIDE: again, with all of it)
 
 // ---- BAM records out of the inflated stream, one BGZF block per lane ------------------------------------------------
 // What a lane reports about the records that START in its block (spl_bam_scan_kernel).  `start` = the first record boundary at
@@ -92,6 +93,11 @@ int spl_dev_launch_bam_bounds(const int32_t *tid, const uint32_t *cig_off, uint6
 // work: spl_dev_inflate_work_bytes(n_blocks) bytes of device memory (the blocks' token streams between the two kernels), or
 // null for round 2's one-kernel decoder.  stream: the stream to launch on.
 size_t spl_dev_inflate_work_bytes(uint32_t n_blocks);
+// ... with `stride` bytes of token room a block instead of SPL_Z_TOKEN_STRIDE (a multiple of 16; a block that needs more gets
+// SPL_Z_TOKENS): what real files' blocks need is a third of the worst case, and a first call waits for every gigabyte it is given
+size_t spl_dev_inflate_work_bytes2(uint32_t n_blocks, uint32_t stride);
+int spl_dev_launch_inflate_decode2(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *work, uint32_t stride, void *stream);
+int spl_dev_launch_inflate_copy2(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t stride, void *stream);
 int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, void *stream);
 // ... in two halves, for callers that put them on different streams: the Huffman decoding (token streams into `work`), then the
 // copies (the inflated bytes into `out`; a block whose tokens do not give out_len bytes gets SPL_Z_SHORT)

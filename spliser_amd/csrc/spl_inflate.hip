@@ -11,26 +11,26 @@
 // The Huffman decoding, one BGZF block per WAVE (the block's symbols as a stream of tokens), and the block's bytes made from
 // that stream, one block per LANE (spl_inflate_wave.h has the method, and is what the host tests run through the wave emulator).
 __global__ __launch_bounds__(64) void spl_inflate_decode_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status,
-                                                                uint8_t *tokens_all, uint32_t *n_tok)
+                                                                uint8_t *tokens_all, uint32_t *n_tok, uint32_t stride)
 {
     __shared__ splz::Shared sh;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
     const spl_zblock zb = blocks[b];
     uint32_t n = 0;
-    const uint32_t st = splz::decode_block(sh, image, zb, tokens_all + (size_t)b * SPL_Z_TOKEN_STRIDE, n);
+    const uint32_t st = splz::decode_block(sh, image, zb, tokens_all + (size_t)b * stride, n, stride);
     if (threadIdx.x == 0) { status[b] = st; n_tok[b] = st == SPL_Z_OK ? n : 0u; }
 }
 
 __global__ __launch_bounds__(64) void spl_inflate_copy_kernel(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status, const uint8_t *tokens_all,
-                                                              const uint32_t *n_tok)
+                                                              const uint32_t *n_tok, uint32_t stride)
 {
     __shared__ uint32_t lds[64u * splz::COPY_LANE_BYTES / 4u];
     const uint32_t b = blockIdx.x * 64u + threadIdx.x;
     if (b >= n_blocks) return;
     if (status[b] != SPL_Z_OK) return;
     uint8_t *const mine = (uint8_t *)lds + threadIdx.x * splz::COPY_LANE_BYTES;
-    const uint32_t made = splz::copy_block(out_all + blocks[b].out, blocks[b].out_len, tokens_all + (size_t)b * SPL_Z_TOKEN_STRIDE, n_tok[b], mine, mine + splz::RING_BYTES);
+    const uint32_t made = splz::copy_block(out_all + blocks[b].out, blocks[b].out_len, tokens_all + (size_t)b * stride, n_tok[b], mine, mine + splz::RING_BYTES);
     if (made != blocks[b].out_len) status[b] = SPL_Z_SHORT;
 }
 
@@ -355,24 +355,35 @@ extern "C" int spl_dev_launch_bam_bounds(const int32_t *tid, const uint32_t *cig
 }
 
 static size_t tokens_at(uint32_t n_blocks) { return ((size_t)n_blocks * 4 + 255) / 256 * 256; }
-extern "C" size_t spl_dev_inflate_work_bytes(uint32_t n_blocks) { return 256 + tokens_at(n_blocks) + (size_t)n_blocks * SPL_Z_TOKEN_STRIDE; }
+extern "C" size_t spl_dev_inflate_work_bytes2(uint32_t n_blocks, uint32_t stride) { return 256 + tokens_at(n_blocks) + (size_t)n_blocks * stride; }
+extern "C" size_t spl_dev_inflate_work_bytes(uint32_t n_blocks) { return spl_dev_inflate_work_bytes2(n_blocks, SPL_Z_TOKEN_STRIDE); }
+
+extern "C" int spl_dev_launch_inflate_decode2(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *work, uint32_t stride, void *stream)
+{
+    if (n_blocks == 0 || !work) return 0;
+    if (stride < 256u || stride > SPL_Z_TOKEN_STRIDE || (stride & 15u)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, status, (uint8_t *)work + tokens_at(n_blocks), (uint32_t *)work, stride);
+    return (int)hipGetLastError();
+}
+
+extern "C" int spl_dev_launch_inflate_copy2(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t stride, void *stream)
+{
+    if (n_blocks == 0 || !work) return 0;
+    hipLaunchKernelGGL(spl_inflate_copy_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, blocks, n_blocks, out, status, (const uint8_t *)work + tokens_at(n_blocks),
+                       (const uint32_t *)work, stride);
+    return (int)hipGetLastError();
+}
 
 extern "C" int spl_dev_launch_inflate_decode(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *work, void *stream)
 {
-    if (n_blocks == 0 || !work) return 0;
-    hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, status, (uint8_t *)work + tokens_at(n_blocks), (uint32_t *)work);
-    return (int)hipGetLastError();
+    return spl_dev_launch_inflate_decode2(image, blocks, n_blocks, status, work, SPL_Z_TOKEN_STRIDE, stream);
 }
 
 extern "C" int spl_dev_launch_inflate_copy(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, void *stream)
 {
-    if (n_blocks == 0 || !work) return 0;
-    hipLaunchKernelGGL(spl_inflate_copy_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, blocks, n_blocks, out, status, (const uint8_t *)work + tokens_at(n_blocks),
-                       (const uint32_t *)work);
-    return (int)hipGetLastError();
+    return spl_dev_launch_inflate_copy2(blocks, n_blocks, out, status, work, SPL_Z_TOKEN_STRIDE, stream);
 }
 
-// (round 2's decoder needs the file image where the others need the tokens: callers that may get either pass it here)
 extern "C" int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, void *stream)
 {
     if (n_blocks == 0) return 0;

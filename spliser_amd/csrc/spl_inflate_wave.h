@@ -310,9 +310,10 @@ WV_DEV void store_n(uint8_t *p, uint64_t lo, uint64_t hi, uint32_t n)
     if (n & 1u) *p = (uint8_t)lo;
 }
 
-// The block `zb` of the file image, by one wave.  stream: room for SPL_Z_TOKEN_STRIDE bytes of tokens (16-byte aligned);
-// n_tok_out: how many were written.  Returns the block's status (every lane the same).
-WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock &zb, uint8_t *stream, uint32_t &n_tok_out)
+// The block `zb` of the file image, by one wave.  stream: room for tok_cap bytes of tokens (16-byte aligned; SPL_Z_TOKEN_STRIDE
+// holds any block's, a caller that gives less gets SPL_Z_OVERRUN for a block that needs more); n_tok_out: how many were written.
+// Returns the block's status (every lane the same).
+WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock &zb, uint8_t *stream, uint32_t &n_tok_out, uint32_t tok_cap = SPL_Z_TOKEN_STRIDE)
 {
     n_tok_out = 0;
     uint32_t n_tok = 0; // bytes of token stream so far
@@ -344,7 +345,7 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             // (the same room the Huffman path leaves: sections of both kinds in one block can ask for more tokens than any BAM
             // writer's block does -- lone literals between 3-byte matches, then one-byte stored sections -- and what follows this
             // block's room is the next block's)
-            if (n_tok + len + n_runs > SPL_Z_TOKEN_STRIDE - 64u) return SPL_Z_OVERRUN;
+            if (n_tok + len + n_runs > tok_cap - 64u) return SPL_Z_TOKENS;
             for (uint32_t r = l; r < n_runs; r += 64u) {
                 const uint32_t n = len - 128u * r < 128u ? len - 128u * r : 128u;
                 uint8_t *t = stream + n_tok + 129u * r;
@@ -463,7 +464,8 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             if (wv::any(valid && c.flag == FL_ERR)) return SPL_Z_BAD_CODE;
             eob = wv::any(valid && c.flag == FL_EOB);
             const uint32_t total = wv::readlane(cum_o, n_valid - 1u), n_t = wv::readlane(cum_t, n_valid - 1u);
-            if (at + total > out_len || n_tok + n_t > SPL_Z_TOKEN_STRIDE - 64u) return SPL_Z_OVERRUN;
+            if (at + total > out_len) return SPL_Z_OVERRUN;
+            if (n_tok + n_t > tok_cap - 64u) return SPL_Z_TOKENS;
             // ---- the writing pass: every lane's symbols as tokens, at the lane's place in the tile's stretch of the stream
             bool bad_dist = false;
             uint8_t *const tok = (uint8_t *)sh.tok;

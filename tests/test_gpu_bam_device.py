@@ -203,6 +203,21 @@ def test_reads_laid_out_on_the_device_count_like_the_oracle(seed, stranded, ctx,
             assert np.array_equal(w, g)
 
 
+@pytest.mark.parametrize("room", ["600", "4096", "20000"])
+def test_a_block_that_needs_more_token_room_than_its_file_was_given(ctx, tmp_path, monkeypatch, room):
+    """The decoding kernel's token room per block is sized from the file's mean compressed block (a third of the worst case for real
+    files); a block that needs more says so (SPL_Z_TOKENS) and the share is decoded again with the worst case's room -- in whole
+    and in shares, with windows of a few blocks, the result what the host decoder gives."""
+    monkeypatch.setenv("SPL_Z_TOKEN_ROOM", room)
+    for window, seq_mode, level, seed in ((None, 1, 1, 51), ("5", 2, 6, 52), (None, 1, 0, 53)):
+        if window:
+            monkeypatch.setenv("SPL_INFLATE_WINDOW_BLOCKS", window)
+        names, sets = _random_sets(seed, 30_000, 3)
+        path = str(tmp_path / ("t%d.bam" % seed))
+        native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=level, threads=3, seq_mode=seq_mode)
+        assert _both(path, ctx, names, sets) is True
+
+
 @pytest.mark.parametrize("window", ["2", "3", "7", "16", "40"])
 def test_inflate_windows_of_a_few_blocks(ctx, tmp_path, monkeypatch, window):
     """The stream is inflated, scanned and emptied of its records a window at a time (49 152 blocks in production): windows of a few
