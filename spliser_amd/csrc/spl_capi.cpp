@@ -2231,6 +2231,8 @@ static int64_t max_end_of(const spl_reads *r)
     return best;
 }
 
+static int upload_native(spl_ctx *c, int n_seg, const spl_reads *segs, DeviceReads **out);
+
 extern "C" int spl_reads_add(spl_ctx *c, spl_dreads *d, const spl_reads *reads, int32_t pos_shift)
 {
     if (!c || !d || !reads) return spl_set_error(SPL_ERR_ARG, "spl_reads_add: null argument");
@@ -2239,6 +2241,18 @@ extern "C" int spl_reads_add(spl_ctx *c, spl_dreads *d, const spl_reads *reads, 
     int64_t max_end;
     int rc = source_of(reads, src, &max_end, "spl_reads_add");
     if (rc) return rc;
+    // The arrays go up as they are and the layout kernel makes the records (spl_devpack.hip), as for a BAM decoded on the device:
+    // the host's threads copy, they do not classify and pack (which was the larger part of a hand-over: 18 ms for 20 M reads,
+    // 8 of them the copies).  SPL_HOST_PACK=1: the host packer's way (what the host BAM decoder's reads take; A/B).
+    static const bool host_pack = getenv("SPL_HOST_PACK") != nullptr;
+    if (!host_pack && reads->n_reads >= 4096) {
+        DeviceReads *dev = nullptr;
+        rc = upload_native(c, 1, reads, &dev);
+        if (rc) return rc;
+        rc = add_segment_device(c, d, dev, 0, dev->n_rec, dev->n_ops, pos_shift, pos_shift != 0 ? dev->ref_max[0] : -1);
+        free_device_reads(dev); // (the read set holds them now)
+        return rc;
+    }
     if (pos_shift != 0) max_end = max_end_of(reads);
     return add_segment(c, d, src, pos_shift, max_end);
 }
@@ -2287,15 +2301,15 @@ void max_end_slice(size_t k, void *arg)
 }
 } // namespace
 
-extern "C" int spl_soa_upload(spl_ctx *c, int n_seg, const spl_reads *segs, spl_dsoa **out)
+// n_seg host segments as they are -> one set of device arrays (DeviceReads, one reference held by the caller).
+static int upload_native(spl_ctx *c, int n_seg, const spl_reads *segs, DeviceReads **out)
 {
-    if (!c || !out || n_seg < 0 || (n_seg && !segs)) return spl_set_error(SPL_ERR_ARG, "spl_soa_upload: null argument");
     *out = nullptr;
     HIP_TRY(hipSetDevice(c->device));
     int64_t n_rec = 0, n_ops = 0;
     for (int k = 0; k < n_seg; ++k) {
         const spl_reads &r = segs[k];
-        if (r.n_reads < 0) return spl_set_error(SPL_ERR_ARG, "spl_soa_upload: negative n_reads");
+        if (r.n_reads < 0) return spl_set_error(SPL_ERR_ARG, "negative n_reads");
         if (r.n_reads && (!r.pos || !r.flag || !r.cig_off)) return spl_set_error(SPL_ERR_ARG, "read set has null arrays");
         if (r.n_reads && r.cig_off[0] != 0) return spl_set_error(SPL_ERR_ARG, "cig_off[0] must be 0");
         if (r.n_reads && r.cig_off[r.n_reads] && !r.cigar) return spl_set_error(SPL_ERR_ARG, "cigar is null");
@@ -2366,11 +2380,23 @@ extern "C" int spl_soa_upload(spl_ctx *c, int n_seg, const spl_reads *segs, spl_
     if (q == hipSuccess) q = hipMemcpyAsync((uint32_t *)dev->cig_off + at, &last, 4, hipMemcpyHostToDevice, c->copy);
     if (q == hipSuccess) q = hipStreamSynchronize(c->copy);
     for (spl_ctx::Stage &st : c->stage) st.busy = false;
-    spl_dsoa *h = q == hipSuccess ? new (std::nothrow) spl_dsoa() : nullptr;
-    if (!h) {
+    if (q != hipSuccess) {
         free_device_reads(dev);
-        return q == hipSuccess ? spl_set_error(SPL_ERR_NOMEM, "out of host memory") : spl_set_error(SPL_ERR_HIP, "spl_soa_upload: %s", hipGetErrorString(q));
+        return spl_set_error(SPL_ERR_HIP, "reads to the device: %s", hipGetErrorString(q));
     }
+    *out = dev;
+    return SPL_OK;
+}
+
+extern "C" int spl_soa_upload(spl_ctx *c, int n_seg, const spl_reads *segs, spl_dsoa **out)
+{
+    if (!c || !out || n_seg < 0 || (n_seg && !segs)) return spl_set_error(SPL_ERR_ARG, "spl_soa_upload: null argument");
+    *out = nullptr;
+    DeviceReads *dev = nullptr;
+    const int rc = upload_native(c, n_seg, segs, &dev);
+    if (rc) return rc;
+    spl_dsoa *h = new (std::nothrow) spl_dsoa();
+    if (!h) { free_device_reads(dev); return spl_set_error(SPL_ERR_NOMEM, "out of host memory"); }
     h->reads = dev;
     *out = h;
     return SPL_OK;
