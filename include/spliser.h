@@ -182,6 +182,8 @@ void spl_reads_free(spl_ctx *ctx, spl_dreads *dr);
  * arrays -> records -> counters, every step).  The handle may be freed while read sets made from it live (they share the arrays). */
 typedef struct spl_dsoa spl_dsoa;
 int spl_soa_upload(spl_ctx *ctx, int n_seg, const spl_reads *segs, spl_dsoa **out);
+/* ... with max_end[k] = the last base (1-based) any read of segment k covers, where the caller knows it (null, or < 0: computed) */
+int spl_soa_upload2(spl_ctx *ctx, int n_seg, const spl_reads *segs, const int64_t *max_end, spl_dsoa **out);
 void spl_soa_free(spl_ctx *ctx, spl_dsoa *soa);
 int spl_reads_add_soa(spl_ctx *ctx, spl_dreads *dr, spl_dsoa *soa, int seg, int32_t pos_shift);
 int spl_reads_relayout(spl_ctx *ctx, spl_dreads *dr);

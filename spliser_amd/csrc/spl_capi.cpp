@@ -2231,7 +2231,7 @@ static int64_t max_end_of(const spl_reads *r)
     return best;
 }
 
-static int upload_native(spl_ctx *c, int n_seg, const spl_reads *segs, DeviceReads **out);
+static int upload_native(spl_ctx *c, int n_seg, const spl_reads *segs, DeviceReads **out, const int64_t *max_end = nullptr);
 
 extern "C" int spl_reads_add(spl_ctx *c, spl_dreads *d, const spl_reads *reads, int32_t pos_shift)
 {
@@ -2302,7 +2302,7 @@ void max_end_slice(size_t k, void *arg)
 } // namespace
 
 // n_seg host segments as they are -> one set of device arrays (DeviceReads, one reference held by the caller).
-static int upload_native(spl_ctx *c, int n_seg, const spl_reads *segs, DeviceReads **out)
+static int upload_native(spl_ctx *c, int n_seg, const spl_reads *segs, DeviceReads **out, const int64_t *max_end)
 {
     *out = nullptr;
     HIP_TRY(hipSetDevice(c->device));
@@ -2363,11 +2363,14 @@ static int upload_native(spl_ctx *c, int n_seg, const spl_reads *segs, DeviceRea
         const int64_t g = r.n_reads ? (int64_t)r.cig_off[r.n_reads] : 0;
         dev->ref_first[(size_t)k] = at; dev->ref_n[(size_t)k] = r.n_reads; dev->ref_ops[(size_t)k] = g;
         if (r.n_reads) {
-            const size_t slices = (size_t)std::min<int64_t>(64, (r.n_reads + 65535) / 65536);
-            std::vector<int64_t> best(slices, 0);
-            MaxEndJob job{&r, (r.n_reads + (int64_t)slices - 1) / (int64_t)slices, &best};
-            splpack::parallel_for(slices, std::max(1, c->pack_threads), max_end_slice, &job);
-            dev->ref_max[(size_t)k] = *std::max_element(best.begin(), best.end());
+            if (max_end && max_end[k] >= 0) dev->ref_max[(size_t)k] = max_end[k]; // (the caller knows: a decoder's arrays, a kept file's)
+            else {
+                const size_t slices = (size_t)std::min<int64_t>(64, (r.n_reads + 65535) / 65536);
+                std::vector<int64_t> best(slices, 0);
+                MaxEndJob job{&r, (r.n_reads + (int64_t)slices - 1) / (int64_t)slices, &best};
+                splpack::parallel_for(slices, std::max(1, c->pack_threads), max_end_slice, &job);
+                dev->ref_max[(size_t)k] = *std::max_element(best.begin(), best.end());
+            }
             send((int32_t *)dev->pos + at, r.pos, 4 * (size_t)r.n_reads, 0u, false);
             send((uint16_t *)dev->flag + at, r.flag, 2 * (size_t)r.n_reads, 0u, false);
             if (g) send((uint32_t *)dev->cigar + op_at, r.cigar, 4 * (size_t)g, 0u, false);
@@ -2388,12 +2391,16 @@ static int upload_native(spl_ctx *c, int n_seg, const spl_reads *segs, DeviceRea
     return SPL_OK;
 }
 
-extern "C" int spl_soa_upload(spl_ctx *c, int n_seg, const spl_reads *segs, spl_dsoa **out)
+extern "C" int spl_soa_upload(spl_ctx *c, int n_seg, const spl_reads *segs, spl_dsoa **out) { return spl_soa_upload2(c, n_seg, segs, nullptr, out); }
+
+// ... max_end[k] (or null; an entry < 0 = not known): the last base any read of segment k covers, 1-based, where the caller knows
+// it (a decoder does, a file of kept reads does): saves a pass over every CIGAR on the host
+extern "C" int spl_soa_upload2(spl_ctx *c, int n_seg, const spl_reads *segs, const int64_t *max_end, spl_dsoa **out)
 {
     if (!c || !out || n_seg < 0 || (n_seg && !segs)) return spl_set_error(SPL_ERR_ARG, "spl_soa_upload: null argument");
     *out = nullptr;
     DeviceReads *dev = nullptr;
-    const int rc = upload_native(c, n_seg, segs, &dev);
+    const int rc = upload_native(c, n_seg, segs, &dev, max_end);
     if (rc) return rc;
     spl_dsoa *h = new (std::nothrow) spl_dsoa();
     if (!h) { free_device_reads(dev); return spl_set_error(SPL_ERR_NOMEM, "out of host memory"); }

@@ -48,7 +48,7 @@ EXPORTS = [
     "spl_abi_version", "spl_last_error", "spl_device_count", "spl_trim", "spl_create", "spl_create_on_stream", "spl_destroy",
     "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_prof_enable", "spl_prof_report", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
-    "spl_soa_upload", "spl_soa_free", "spl_reads_add_soa", "spl_reads_relayout", "spl_layout_timing_collect", "spl_reads_layout_bytes",
+    "spl_soa_upload", "spl_soa_upload2", "spl_soa_free", "spl_reads_add_soa", "spl_reads_relayout", "spl_layout_timing_collect", "spl_reads_layout_bytes",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_wait_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_cancel", "spl_bam_decline_reason", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
@@ -245,16 +245,17 @@ class Context(object):
         _check(lib().spl_reads_upload_segments(self._h, ctypes.c_int(n), segs, shifts, ctypes.byref(h)))
         return DeviceReads(self, h, total)
 
-    def upload_soa(self, segments):
+    def upload_soa(self, segments, max_ends=None):
         """segments: [ReadArrays-like with .c] -> the BAM-native arrays as they are, laid end to end in device memory
         (``spl_soa_upload``): what a decode on the device leaves.  Read sets are laid out from them by the layout kernel
-        (``DeviceReads.add_soa`` + ``finish``; ``relayout``)."""
+        (``DeviceReads.add_soa`` + ``finish``; ``relayout``).  ``max_ends``: per segment the last base its reads cover, if known."""
         n = len(segments)
         segs = (spl_reads * max(n, 1))()
         for k, reads in enumerate(segments):
             segs[k] = reads.c
         h = ctypes.c_void_p()
-        _check(lib().spl_soa_upload(self._h, ctypes.c_int(n), segs, ctypes.byref(h)))
+        ends = None if max_ends is None else (ctypes.c_int64 * max(n, 1))(*[int(v) if v is not None else -1 for v in max_ends])
+        _check(lib().spl_soa_upload2(self._h, ctypes.c_int(n), segs, ends, ctypes.byref(h)))
         return DeviceSoA(self, h, [r.n for r in segments])
 
     def layout_read_segments(self, soa, shifts):
