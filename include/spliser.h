@@ -153,11 +153,13 @@ int spl_sse(spl_ctx *ctx, const spl_sites *sites, const uint32_t *beta1, const u
 /* ---- device-resident pipeline (bench.py, multi-shard overlap) ---------------------------------- */
 int spl_sites_upload(spl_ctx *ctx, const spl_sites *sites, spl_dsites **out);
 void spl_sites_free(spl_ctx *ctx, spl_dsites *ds);
-/* A read set on the device.  The kernels do not read the BAM-native arrays: on its way to the GPU every read set is packed,
- * on host threads, into chunks of 2048 reads, each chunk partitioned by the kind of read (unspliced / once-spliced /
- * twice-spliced / anything else) with records as wide as the kind needs (8 / 16 / 24 bytes; spliser_amd/csrc/spl_pack.h),
- * piece by piece through a ring of page-locked staging buffers, the DMA of one piece running while the next is packed.
- * The caller's arrays are not needed after the call returns. */
+/* A read set on the device.  The counting kernels do not read the BAM-native arrays: a read set is cut into chunks of 2048
+ * (or 4096) reads, each chunk partitioned by the kind of read (unspliced / once-spliced / twice-spliced / anything else) with
+ * records as wide as the kind needs (8 / 16 / 24 bytes; spliser_amd/csrc/spl_pack.h).  A caller's arrays go up as they are --
+ * piece by piece through a ring of page-locked staging buffers, the DMA of one piece running while the next is staged -- and
+ * the layout kernel (spliser_amd/csrc/spl_devpack.hip) writes the records on the device; sets of fewer than 4096 reads, and
+ * the reads of a BAM decoded on host threads, are packed by host threads instead.  The caller's arrays are not needed after
+ * the call returns. */
 int spl_reads_upload(spl_ctx *ctx, const spl_reads *reads, spl_dreads **out);
 /* Same, from n_seg host segments laid end to end: segment k is moved by pos_shift[k] into the shard's coordinate space
  * (spliser_amd/shard.py packs several chromosomes into one launch that way).  Reads keep segment order. */

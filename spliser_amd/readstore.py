@@ -91,8 +91,8 @@ def save(path, bam_path, reads_by_ref, threads=8):
 
 
 class ReadStore(object):
-    """The reads of a ``.SpliSER.reads`` file as a source for ``process_sites``: ``reads(chrom)`` -> ReadSet (views of the mapped
-    file) or None for a reference the BAM does not have."""
+    """The reads of a ``.SpliSER.reads`` file as a source for ``process_sites``: ``reads(chrom)`` -> ReadSet (views of the file's
+    bytes in memory) or None for a reference the BAM does not have."""
 
     def __init__(self, path, head, mm):
         self.path, self._mm = path, mm
@@ -128,7 +128,6 @@ class ReadStore(object):
 def open_if_fresh(path, bam_path):
     """-> ReadStore when ``path`` holds the reads of exactly this alignment file, None otherwise (missing, another version,
     damaged, or the BAM has changed since)."""
-    import mmap
     if not path or not os.path.exists(path):
         return None
     try:
@@ -152,7 +151,22 @@ def open_if_fresh(path, bam_path):
             if os.fstat(fh.fileno()).st_size < need:
                 return None
             head["_head_len"] = head_len
-            mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
-        return ReadStore(path, head, mm)
+            # the arrays into memory of this process, pieces of 16 MB on a few threads (os.preadv leaves the interpreter's lock):
+            # through a mapping every 4 KB page is a fault of its own, 90 000 of them for a 20 M-read sample
+            from concurrent.futures import ThreadPoolExecutor
+            buf = np.empty(need, np.uint8)
+            view = memoryview(buf)
+            fd, piece = fh.fileno(), 16 << 20
+
+            def get(lo):
+                hi = min(need, lo + piece)
+                while lo < hi:
+                    n = os.preadv(fd, [view[lo:hi]], lo)
+                    if n <= 0:
+                        raise OSError("short read")
+                    lo += n
+            with ThreadPoolExecutor(max_workers=8) as pool:
+                list(pool.map(get, range(0, need, piece)))
+        return ReadStore(path, head, buf)
     except (OSError, ValueError, KeyError, TypeError):
         return None
