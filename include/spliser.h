@@ -155,11 +155,11 @@ int spl_sites_upload(spl_ctx *ctx, const spl_sites *sites, spl_dsites **out);
 void spl_sites_free(spl_ctx *ctx, spl_dsites *ds);
 /* A read set on the device.  The counting kernels do not read the BAM-native arrays: a read set is cut into chunks of 2048
  * (or 4096) reads, each chunk partitioned by the kind of read (unspliced / once-spliced / twice-spliced / anything else) with
- * records as wide as the kind needs (8 / 16 / 24 bytes; spliser_amd/csrc/spl_pack.h).  A caller's arrays go up as they are --
- * piece by piece through a ring of page-locked staging buffers, the DMA of one piece running while the next is staged -- and
- * the layout kernel (spliser_amd/csrc/spl_devpack.hip) writes the records on the device; sets of fewer than 4096 reads, and
- * the reads of a BAM decoded on host threads, are packed by host threads instead.  The caller's arrays are not needed after
- * the call returns. */
+ * records as wide as the kind needs (8 / 16 / 24 bytes; spliser_amd/csrc/spl_pack.h).  A caller's HOST arrays are packed that
+ * way by host threads on their way up, piece by piece through a ring of page-locked staging buffers, the DMA of one piece
+ * running while the next is packed (the records are two thirds of the arrays' bytes, and a hand-over is bound by PCIe); reads
+ * that are in device memory already (spl_bam_decode_device, spl_soa_upload) are laid out by the layout kernel
+ * (spliser_amd/csrc/spl_devpack.hip).  The caller's arrays are not needed after the call returns. */
 int spl_reads_upload(spl_ctx *ctx, const spl_reads *reads, spl_dreads **out);
 /* Same, from n_seg host segments laid end to end: segment k is moved by pos_shift[k] into the shard's coordinate space
  * (spliser_amd/shard.py packs several chromosomes into one launch that way).  Reads keep segment order. */
@@ -173,6 +173,8 @@ int spl_reads_begin(spl_ctx *ctx, spl_dreads **out);
  * cut into chunks of 4096 instead of 2048 reads, which suits launches of that size (3.5 % on 100 M reads) and no others. */
 int spl_reads_begin_sized(spl_ctx *ctx, int64_t expected_reads, spl_dreads **out);
 int spl_reads_add(spl_ctx *ctx, spl_dreads *dr, const spl_reads *reads, int32_t pos_shift);
+/* ... known_max_end: the last base (1-based) any of the reads covers, if the caller knows it (< 0: computed when needed) */
+int spl_reads_add2(spl_ctx *ctx, spl_dreads *dr, const spl_reads *reads, int32_t pos_shift, int64_t known_max_end);
 int spl_reads_add_bam(spl_ctx *ctx, spl_dreads *dr, spl_bam *bam, int tid, int32_t pos_shift);
 int spl_reads_finish(spl_ctx *ctx, spl_dreads *dr);
 void spl_reads_free(spl_ctx *ctx, spl_dreads *dr);

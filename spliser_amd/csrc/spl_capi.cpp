@@ -2233,7 +2233,11 @@ static int64_t max_end_of(const spl_reads *r)
 
 static int upload_native(spl_ctx *c, int n_seg, const spl_reads *segs, DeviceReads **out, const int64_t *max_end = nullptr);
 
-extern "C" int spl_reads_add(spl_ctx *c, spl_dreads *d, const spl_reads *reads, int32_t pos_shift)
+extern "C" int spl_reads_add(spl_ctx *c, spl_dreads *d, const spl_reads *reads, int32_t pos_shift) { return spl_reads_add2(c, d, reads, pos_shift, -1); }
+
+// ... known_max_end: the last base (1-based) any of the reads covers, where the caller knows it (< 0: looked for here when the
+// segment is moved, a pass over every CIGAR)
+extern "C" int spl_reads_add2(spl_ctx *c, spl_dreads *d, const spl_reads *reads, int32_t pos_shift, int64_t known_max_end)
 {
     if (!c || !d || !reads) return spl_set_error(SPL_ERR_ARG, "spl_reads_add: null argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -2241,19 +2245,21 @@ extern "C" int spl_reads_add(spl_ctx *c, spl_dreads *d, const spl_reads *reads, 
     int64_t max_end;
     int rc = source_of(reads, src, &max_end, "spl_reads_add");
     if (rc) return rc;
-    // The arrays go up as they are and the layout kernel makes the records (spl_devpack.hip), as for a BAM decoded on the device:
-    // the host's threads copy, they do not classify and pack (which was the larger part of a hand-over: 18 ms for 20 M reads,
-    // 8 of them the copies).  SPL_HOST_PACK=1: the host packer's way (what the host BAM decoder's reads take; A/B).
-    static const bool host_pack = getenv("SPL_HOST_PACK") != nullptr;
-    if (!host_pack && reads->n_reads >= 4096) {
+    // SPL_RAW_UPLOAD=1 (A/B): the arrays go up as they are and the layout kernel makes the records (spl_devpack.hip), as for a BAM
+    // decoded on the device.  Not the default: a hand-over is bound by what crosses PCIe and by the copies into the staging
+    // buffers, and the records the host's threads pack on the way are two thirds of the arrays' bytes (20 M reads: 13.7 ms
+    // packed against 18.6 ms as they are, one box, profiles/r05R_pcie_rate.txt).
+    static const bool raw_upload = getenv("SPL_RAW_UPLOAD") != nullptr;
+    if (raw_upload && reads->n_reads >= 4096) {
         DeviceReads *dev = nullptr;
-        rc = upload_native(c, 1, reads, &dev);
+        const int64_t no_end = 0;
+        rc = upload_native(c, 1, reads, &dev, pos_shift == 0 ? &no_end : (known_max_end >= 0 ? &known_max_end : nullptr));
         if (rc) return rc;
         rc = add_segment_device(c, d, dev, 0, dev->n_rec, dev->n_ops, pos_shift, pos_shift != 0 ? dev->ref_max[0] : -1);
         free_device_reads(dev); // (the read set holds them now)
         return rc;
     }
-    if (pos_shift != 0) max_end = max_end_of(reads);
+    if (pos_shift != 0) max_end = known_max_end >= 0 ? known_max_end : max_end_of(reads);
     return add_segment(c, d, src, pos_shift, max_end);
 }
 

@@ -47,7 +47,7 @@ OPT_WAVE_AGGREGATION = 2
 EXPORTS = [
     "spl_abi_version", "spl_last_error", "spl_device_count", "spl_trim", "spl_create", "spl_create_on_stream", "spl_destroy",
     "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_prof_enable", "spl_prof_report", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
-    "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add_bam", "spl_reads_finish",
+    "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add2", "spl_reads_add_bam", "spl_reads_finish",
     "spl_soa_upload", "spl_soa_upload2", "spl_soa_free", "spl_reads_add_soa", "spl_reads_relayout", "spl_layout_timing_collect", "spl_reads_layout_bytes",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
     "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_wait_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_cancel", "spl_bam_decline_reason", "spl_bam_close",
@@ -348,9 +348,11 @@ class DeviceReads(object):
     def __init__(self, ctx, h, n):
         self.ctx, self._h, self.n = ctx, h, n
 
-    def add(self, reads, shift=0):
-        """One more segment from host arrays (``ReadArrays``), moved by ``shift`` into the shard's coordinate space."""
-        _check(lib().spl_reads_add(self.ctx._h, self._h, ctypes.byref(reads.c), ctypes.c_int32(int(shift))))
+    def add(self, reads, shift=0, max_end=None):
+        """One more segment from host arrays (``ReadArrays``), moved by ``shift`` into the shard's coordinate space.  ``max_end``:
+        the last base the reads cover, if known (a decoder's arrays, a kept file's)."""
+        _check(lib().spl_reads_add2(self.ctx._h, self._h, ctypes.byref(reads.c), ctypes.c_int32(int(shift)),
+                                    ctypes.c_int64(-1 if max_end is None else int(max_end))))
         self.n += reads.n
 
     def add_bam(self, bam, chrom, shift=0):

@@ -264,13 +264,7 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                                 dr.add_bam(source, chrom, off)
                             elif items[chrom][1] is not None and items[chrom][1].n:
                                 rs = items[chrom][1]
-                                if rs.n >= 65536:
-                                    # arrays of some size (the reads `process --keepReads` left, a SAM file's): up as they are and
-                                    # laid out by the layout kernel, like a BAM's after its decode on the device
-                                    with ctx.upload_soa([native.ReadArrays(rs.pos, rs.flag, rs.cig_off, rs.cigar)], [getattr(rs, "max_end", None)]) as soa:
-                                        dr.add_soa(soa, 0, off)
-                                else:
-                                    dr.add(native.ReadArrays(rs.pos, rs.flag, rs.cig_off, rs.cigar), off)
+                                dr.add(native.ReadArrays(rs.pos, rs.flag, rs.cig_off, rs.cigar), off, getattr(rs, "max_end", None))
                             dr.finish()
                             ctx.count_launch(ds, dr, stranded, combine_mode)
                             ctx.sse_launch(ds, is_beta2_cryptic)
