@@ -17,6 +17,7 @@ from spliser_amd import native, samio  # noqa: E402
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
 device_path = "--device-path" in sys.argv
+odd = "--odd" in sys.argv      # every second seed: BED strands that are none in stranded analyses too, junctions whose ends coincide
 import tempfile  # noqa: E402
 tmpdir = tempfile.mkdtemp(prefix="spl_fuzz_")
 n_device = 0
@@ -26,7 +27,7 @@ n_cases = n_reads = 0
 with native.Context(0) as ctx:
     for seed in range(first, last):
         for stranded in (0, 1, 2):
-            arr, rs = randcase.make_case(seed, bool(stranded))
+            arr, rs = randcase.make_case(seed, bool(stranded), odd=odd and seed % 2 == 1)
             if arr.n == 0 or rs.n == 0:
                 continue
             variants = [rs]
