@@ -2035,19 +2035,32 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     return told;
 }
 
-// The layout kernel over every group of a read set (segments whose reads are on the device, BAM-native), then the chunk order
-// of the range kernel from the chunks' costs: launches on the context's main stream, nothing for the host to wait for.
+// What a read set's device segments need between the arrays and the counters, on the context's main stream, nothing for the host
+// to wait for: per group the chunks' descriptors and cost estimates (from their numbers of reads and ops), the chunk order of the
+// range kernel from the costs (host-packed chunks' are up already), then the layout kernel per group -- the records and the
+// chunks' spl_chunk_meta -- and the range kernel can follow it directly.
 static int launch_layout(spl_ctx *c, spl_dreads *d)
 {
     const uint32_t chunk = 1u << d->chunk_shift;
+    std::vector<spl_layout_params> lps;
     for (spl_dreads::Group &g : d->groups) {
         spl_layout_params lp;
         lp.src = spl_devreads{(const int32_t *)g.src->pos, (const uint16_t *)g.src->flag, (const uint32_t *)g.src->cig_off, (const uint32_t *)g.src->cigar};
         lp.n_rec = g.src->n_rec; lp.n_ops = g.src->n_ops;
-        lp.chunks = g.d_chunks; lp.rec_base = (uint8_t *)g.slab; lp.meta = d->meta; lp.cost = d->cost;
+        lp.chunks = g.d_chunks; lp.rec_base = (uint8_t *)g.slab; lp.meta = d->meta;
         // (the chunks' descriptors hold offsets read from the arrays: made anew whenever the layout runs)
-        const int rc0 = spl_dev_launch_layout_map(&lp.src, g.d_segs, (uint32_t)g.segs.size(), chunk, g.d_chunks, c->stream);
+        const int rc0 = spl_dev_launch_layout_map(&lp.src, g.d_segs, (uint32_t)g.segs.size(), g.n_chunks, chunk, g.d_chunks, d->cost, c->stream);
         if (rc0) return spl_set_error(SPL_ERR_HIP, "layout map kernel launch: %s", hipGetErrorString((hipError_t)rc0));
+        lps.push_back(lp);
+    }
+    if (d->n_chunks) {
+        splprof::Scope prof("spl_chunk_order_kernel", c->stream, 8.0 * (double)d->n_chunks);
+        const int rc = spl_dev_launch_chunk_order(d->cost, d->n_chunks, chunk, d->chunk_order, c->stream);
+        if (rc) return spl_set_error(SPL_ERR_HIP, "chunk order kernel launch: %s", hipGetErrorString((hipError_t)rc));
+    }
+    size_t gi = 0;
+    for (spl_dreads::Group &g : d->groups) {
+        const spl_layout_params &lp = lps[gi++];
         int64_t n_reads = 0, n_ops = 0;
         for (const spl_layout_seg &ls : g.segs) n_reads += ls.n_reads;
         for (const spl_dreads::Segment &seg : d->segs) if (seg.group >= 0 && &d->groups[(size_t)seg.group] == &g) n_ops += seg.n_ops;
@@ -2059,11 +2072,6 @@ static int launch_layout(spl_ctx *c, spl_dreads *d)
         }
         if (timed) c->l_used++;
         if (rc) return spl_set_error(SPL_ERR_HIP, "layout kernel launch: %s", hipGetErrorString((hipError_t)rc));
-    }
-    if (d->n_chunks) {
-        splprof::Scope prof("spl_chunk_order_kernel", c->stream, 8.0 * (double)d->n_chunks);
-        const int rc = spl_dev_launch_chunk_order(d->cost, d->n_chunks, chunk, d->chunk_order, c->stream);
-        if (rc) return spl_set_error(SPL_ERR_HIP, "chunk order kernel launch: %s", hipGetErrorString((hipError_t)rc));
     }
     return SPL_OK;
 }

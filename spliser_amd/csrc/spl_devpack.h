@@ -49,7 +49,6 @@ struct spl_layout_params {
     const spl_layout_chunk *chunks; // [chunks of this launch]
     uint8_t *rec_base;         // record slots, SPL_LAYOUT_SLOT apart
     spl_chunk_meta *meta;      // [flat chunk list]
-    uint32_t *cost;            // [flat chunk list] what a chunk will cost the range kernel, roughly (SPL_W_*)
 };
 
 static inline uint32_t spl_layout_seg_chunks(int64_t first, int64_t n_reads, uint32_t chunk)
@@ -62,8 +61,10 @@ static inline uint32_t spl_order_per(uint32_t n_chunks) { return ((n_chunks + 7u
 #ifdef __cplusplus
 extern "C" {
 #endif
-// chunks[seg.dev0 + j] = the j-th chunk of seg, for every segment (device arrays; chunk = reads per chunk)
-int spl_dev_launch_layout_map(const spl_devreads *src, const spl_layout_seg *segs, uint32_t n_segs, uint32_t chunk, spl_layout_chunk *chunks, void *stream);
+// chunks[k] = the launch's k-th chunk (which segment's, where its reads and ops lie), cost[its flat index] = what it will cost the
+// range kernel, roughly, from its numbers of reads and ops (device arrays; chunk = reads per chunk)
+int spl_dev_launch_layout_map(const spl_devreads *src, const spl_layout_seg *segs, uint32_t n_segs, uint32_t n_chunks, uint32_t chunk, spl_layout_chunk *chunks, uint32_t *cost,
+                              void *stream);
 // the layout itself: one workgroup per chunk of the launch (chunk = reads per chunk, 2048 or 4096)
 int spl_dev_launch_layout(const spl_layout_params *p, uint32_t n_dev_chunks, uint32_t chunk, void *stream, void *ev_start, void *ev_stop);
 // cost[n_chunks] -> order[8 * spl_order_per(n_chunks)]: the range kernel's slots, XCD share by XCD share, longest chunk first;

@@ -13,8 +13,9 @@
 //     lanes' per-run counts, the waves' totals through LDS -- the runs keep file order;
 //   * the chunk writes into a record slot of its own (worst-case size), so no workgroup waits for another's count; WIDE reads'
 //     ops are not copied at all: their index points into the array they came from, which the read set keeps alive;
-//   * the chunk's descriptor (spl_chunk_meta) and its cost estimate are written by the kernel: nothing comes down to the host.
-// The range kernel's chunk order (XCD share by XCD share, longest first) is made from the costs by spl_chunk_order_kernel.
+//   * the chunk's descriptor (spl_chunk_meta) is written by the kernel: nothing comes down to the host.
+// The range kernel's chunk order (XCD share by XCD share, longest first) is made by spl_chunk_order_kernel BEFORE the layout, from
+// cost estimates that need the chunks' numbers of reads and ops only (spl_layout_map_kernel): layout -> range with nothing between.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -63,22 +64,31 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 
 } // namespace
 
-__global__ __launch_bounds__(256) void spl_layout_map_kernel(const spl_devreads src, const spl_layout_seg *segs, uint32_t chunk, spl_layout_chunk *chunks)
+// A thread per chunk of the launch: which segment it is of (a bisection over the segments' first chunks), where its reads and
+// its ops lie, and what it will cost the range kernel, roughly -- from its numbers of reads and ops alone (a simple read is one op
+// and weighs 2, a once-spliced one three and 5, a twice-spliced one five and 9: (3 ops + reads) / 2), so that the chunk order can be
+// made BEFORE the records are (spl_chunk_order_kernel) and nothing stands between the layout kernel and the range kernel.
+__global__ __launch_bounds__(256) void spl_layout_map_kernel(const spl_devreads src, const spl_layout_seg *segs, uint32_t n_segs, uint32_t n_chunks, uint32_t chunk,
+                                                             spl_layout_chunk *chunks, uint32_t *cost)
 {
-    const spl_layout_seg s = segs[blockIdx.x];
-    const uint32_t seg_op0 = src.cig_off[s.first];
-    const int64_t cell0 = s.first / chunk;
-    for (uint32_t j = threadIdx.x; j < s.n_chunks; j += 256u) {
-        const int64_t a = (cell0 + j) * (int64_t)chunk, b = a + chunk;
-        spl_layout_chunk c;
-        c.lo = s.first > a ? s.first : a;
-        const int64_t hi = s.first + s.n_reads < b ? s.first + s.n_reads : b;
-        c.n = (uint32_t)(hi - c.lo);
-        c.o_lo = src.cig_off[c.lo]; c.o_hi = src.cig_off[hi]; c.seg_op0 = seg_op0;
-        c.shift = s.shift;
-        c.flat = s.chunk0 + j;
-        chunks[s.dev0 + j] = c;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n_chunks) return;
+    uint32_t a = 0, b = n_segs; // the last segment whose first chunk is <= k
+    while (b - a > 1u) {
+        const uint32_t mid = (a + b) >> 1;
+        if (segs[mid].dev0 <= k) a = mid; else b = mid;
     }
+    const spl_layout_seg s = segs[a];
+    const int64_t cell = s.first / chunk + (int64_t)(k - s.dev0), c0 = cell * (int64_t)chunk, c1 = c0 + chunk;
+    spl_layout_chunk c;
+    c.lo = s.first > c0 ? s.first : c0;
+    const int64_t hi = s.first + s.n_reads < c1 ? s.first + s.n_reads : c1;
+    c.n = (uint32_t)(hi - c.lo);
+    c.o_lo = src.cig_off[c.lo]; c.o_hi = src.cig_off[hi]; c.seg_op0 = src.cig_off[s.first];
+    c.shift = s.shift;
+    c.flat = s.chunk0 + (k - s.dev0);
+    chunks[k] = c;
+    cost[c.flat] = (3u * (c.o_hi - c.o_lo) + c.n) / 2u;
 }
 
 template <int C>
@@ -88,14 +98,12 @@ __global__ __launch_bounds__(C / 4) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     constexpr uint32_t PAD = SPL_PACK_SCAN_OPS;               // a read is classified from a stage that holds its first eight ops
     __shared__ uint32_t s_ops[STAGE];
     __shared__ uint32_t s_cnt[NW][2];
-    __shared__ uint32_t s_cost;
     __shared__ int32_t s_first; // POS of the chunk's first read in file order: base of the range kernel's LDS window
     const uint32_t k = blockIdx.x, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const spl_layout_chunk ch = p.chunks[k]; // (wave-uniform: one scalar load)
     const int64_t lo = ch.lo, hi = ch.lo + ch.n;
     const int64_t g = (lo & ~(int64_t)(C - 1)) + 4 * (int64_t)t; // the thread's first read
     const uint32_t o_lo = ch.o_lo, o_hi = ch.o_hi, seg_op0 = ch.seg_op0;
-    if (t == 0) s_cost = 0;
 
     // ---- the one memory trip: the thread's four reads (one load per array) and the chunk's ops, everything asked for at once
     int32_t pos[4] = {0, 0, 0, 0};
@@ -191,21 +199,17 @@ __global__ __launch_bounds__(C / 4) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         fill(ws);
         __syncthreads();
     }
-    uint32_t c01 = 0, c23 = 0, cost = 0; // reads per run: run 0 | run 1 << 16, run 2 | run 3 << 16
+    uint32_t c01 = 0, c23 = 0; // reads per run: run 0 | run 1 << 16, run 2 | run 3 << 16
     uint32_t run[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         run[j] = (runs >> (3 * j)) & 7u;
-        const bool is_wide = (w[j][1] >> SPL_RC_SHIFT) == SPL_RC_WIDE;
-        cost += run[j] == SPL_RC_SIMPLE ? SPL_W_SIMPLE : (run[j] == SPL_RC_MNM ? SPL_W_MNM : (run[j] == SPL_RC_M2 ? SPL_W_M2 : (run[j] == SPL_RC_OTHER ? (is_wide ? SPL_W_WIDE : SPL_W_NARROW) : 0u)));
         c01 += run[j] == SPL_RC_SIMPLE ? 1u : (run[j] == SPL_RC_MNM ? 0x10000u : 0u);
         c23 += run[j] == SPL_RC_M2 ? 1u : (run[j] == SPL_RC_OTHER ? 0x10000u : 0u);
     }
 
     // ---- ranks: prefix sums over the lanes (DPP: row shifts, then the rows' totals broadcast), the waves' totals through LDS
     const uint32_t i01 = wave_scan(c01), i23 = wave_scan(c23);
-    cost = wave_scan(cost); // (lane 63 has the wave's sum)
-    if (lane == 63u && cost) atomicAdd(&s_cost, cost);
     if (lane == 63u) { s_cnt[wave][0] = i01; s_cnt[wave][1] = i23; }
     if (lo >= g && lo < g + 4) {
         const uint32_t e = (uint32_t)(lo - g);
@@ -248,7 +252,6 @@ __global__ __launch_bounds__(C / 4) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         m.first_pos = s_first;
         m.n[0] = (uint16_t)n0; m.n[1] = (uint16_t)n1; m.n[2] = (uint16_t)n2; m.n[3] = (uint16_t)n3;
         p.meta[ch.flat] = m;
-        p.cost[ch.flat] = s_cost;
     }
 }
 
@@ -296,10 +299,11 @@ __global__ __launch_bounds__(1024) void spl_chunk_order_kernel(const uint32_t *c
     for (uint32_t s = total + t; s < per; s += 1024u) mine[s] = 0xffffffffu;
 }
 
-extern "C" int spl_dev_launch_layout_map(const spl_devreads *src, const spl_layout_seg *segs, uint32_t n_segs, uint32_t chunk, spl_layout_chunk *chunks, void *stream)
+extern "C" int spl_dev_launch_layout_map(const spl_devreads *src, const spl_layout_seg *segs, uint32_t n_segs, uint32_t n_chunks, uint32_t chunk, spl_layout_chunk *chunks,
+                                         uint32_t *cost, void *stream)
 {
-    if (!n_segs) return 0;
-    hipLaunchKernelGGL(spl_layout_map_kernel, dim3(n_segs), dim3(256), 0, (hipStream_t)stream, *src, segs, chunk, chunks);
+    if (!n_segs || !n_chunks) return 0;
+    hipLaunchKernelGGL(spl_layout_map_kernel, dim3((n_chunks + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, *src, segs, n_segs, n_chunks, chunk, chunks, cost);
     return (int)hipGetLastError();
 }
 

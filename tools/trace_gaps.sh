@@ -10,7 +10,7 @@ find /tmp/tr -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 -c "
 import csv
 rows=[r for r in csv.DictReader(open('{}')) if 'spl_' in r['Kernel_Name'] and 'pack' not in r['Kernel_Name'] and 'dbuckets' not in r['Kernel_Name']]
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-rows=rows[-33:-15]   # (the last 15 launches are bench.py's five lone passes after the timed region)
+rows=rows[-102:-78]   # (8 steps of 12 launches -- per shard: map, layout, order, range, literal, scan --, then 8 count-only steps of 6 and five lone passes of 6: the last two timed steps)
 t0=int(rows[0]['Start_Timestamp'])
 for r in rows:
     print('%-26s q%-3s %9.1f %9.1f  (%6.1f us)' % (r['Kernel_Name'].replace('void ','')[:26], r.get('Queue_Id','?'), (int(r['Start_Timestamp'])-t0)/1e3, (int(r['End_Timestamp'])-t0)/1e3, (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3))
