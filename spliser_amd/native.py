@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# SPLISER_HIP_LIB: load another build of the same library (kernel experiments: tools/exp_modes.sh)
+# SPLISER_HIP_LIB: load another build of the same library (A/B runs of two builds on one box)
 LIB_PATH = os.environ.get("SPLISER_HIP_LIB") or os.path.join(HERE, "libspliser_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 

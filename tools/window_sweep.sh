@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/r03_window_sweep.sh <tag> <scale> W1 W2 ...   (GPU box) -- kernel times of the device decode by window size
+# usage: tools/window_sweep.sh <tag> <scale> W1 W2 ...   (GPU box) -- kernel times of the device decode by window size
 TAG=$1; SCALE=$2; shift 2
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
