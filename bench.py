@@ -275,8 +275,12 @@ def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode
             closing = process.wait_deferred_close()     # (the file's unmapping, on a thread of its own: not into the next call's opening)
             return dict(wall_s=wall, reads_per_sec=n_reads / wall, bam_decode=tm.pop("bam_decode", "host"),
                         stages={k2: round(v, 4) for k2, v in tm.items()}, deferred_close_s=round(closing, 4))
+        import torch
+        free_before = [torch.cuda.mem_get_info(d)[0] for d in devices]
         first = call("w", devices)     # the leg's first call: device memory for this file's sizes is not at hand yet (and, for the
         #                                first leg, nothing is): reported by itself, the timed calls are the ones behind it
+        # (what the first call took from the driver and the process still holds -- live or in the library's pool for the next call)
+        out["first_call_device_gb"] = round(sum(b - torch.cuda.mem_get_info(d)[0] for b, d in zip(free_before, devices)) / 1e9, 2)
         runs = [call("%d" % k, devices) for k in range(reps)]
         best = min(runs, key=lambda r: r["wall_s"])
         med = statistics.median(r["wall_s"] for r in runs)
@@ -532,7 +536,7 @@ def compact_e2e(leg):
     cpu = leg.get("cpu_e2e") or {}
     out = {"workload": leg.get("workload"), "bam": leg.get("bam"), "bam_bytes": leg.get("bam_bytes"),
            "decode": leg.get("decode"), "devices": len(leg.get("devices") or [0]) if len(leg.get("devices") or [0]) > 1 else None,
-           "wall_s": leg.get("wall_s"), "median_wall_s": leg.get("median_wall_s"), "first_call_wall_s": leg.get("first_call_wall_s"),
+           "wall_s": leg.get("wall_s"), "median_wall_s": leg.get("median_wall_s"), "first_call_wall_s": leg.get("first_call_wall_s"), "first_call_device_gb": leg.get("first_call_device_gb"),
            "reads_per_sec": leg.get("reads_per_sec"), "file_GBps": path.get("file_GBps"), "frac_of_pcie": path.get("frac_of_pcie"),
            "tsv_matches_oracle": leg.get("tsv_matches_oracle"), "cpu_e2e_reads_per_sec": cpu.get("reads_per_sec")}
     for k in ("cold_cli_s", "cold_cli_matches"):

@@ -170,3 +170,28 @@ def test_shifted_segments_and_the_coordinate_limit(ctx):
                 dr.add_soa(soa, 0, 2147483500)
             with pytest.raises(native.SpliserNativeError):
                 dr.add_soa(soa, 3, 0)
+
+
+def test_two_read_sets_laid_out_again_and_counted_in_turn(ctx, oracle_lib):
+    """bench.py's step: every shard's records made again from its arrays, then counted; several steps in a row, the counters of
+    the first and the last step the oracle's."""
+    ocount, _ = helpers.oracle_engine(oracle_lib)
+    shards = []
+    for seed in (941, 942):
+        arr, rs = randcase.make_case(seed, False)
+        big = _repeat(rs, 151)
+        soa = ctx.upload_soa([_arrays(big)])
+        shards.append((ocount(arr, big, 0, 0), ctx.upload_sites(native.SiteArrays.from_chrom(arr)), ctx.layout_read_segments(soa, [0]), soa))
+    try:
+        for step in range(4):
+            for _, ds, dr, _ in shards:
+                dr.relayout()
+                ctx.count_launch(ds, dr, 0, 0)
+            ctx.pass_barrier()
+            if step in (0, 3):
+                for want, ds, _, _ in shards[::-1]:
+                    for w, g in zip(want, ds.counters()):
+                        assert np.array_equal(w, g)
+    finally:
+        for _, ds, dr, soa in shards:
+            dr.free(); soa.free(); ds.free()
