@@ -96,7 +96,7 @@ def lib_sha16():
     return h.hexdigest()[:16]
 
 
-KERNEL_SOURCES = ("spl_kernels.hip", "spl_device.h", "spl_pack.h", "spl_classify.h", "spl_pack.cpp", "spl_devpack.hip", "spl_devpack.h")
+KERNEL_SOURCES = ("spl_kernels.hip", "spl_device.h", "spl_pack.h", "spl_classify.h", "spl_pack.cpp", "spl_devpack.hip", "spl_devpack.h", "spl_layout_tile.h")
 
 
 def kernel_src_sha16():
@@ -567,7 +567,10 @@ def compact_line(out, detail_name="bench_detail.json"):
                             range_alone_frac=(r.get("alone") or {}).get("frac"), path_frac=(r.get("path") or {}).get("frac"),
                             count_only={k: co.get(k) for k in ("ms_per_step", "reads_per_sec", "path_frac")},
                             range_traffic=r.get("range_traffic"), range_hbm_actual_frac=(r.get("hbm_actual") or {}).get("frac"),
-                            traffic_from=r.get("traffic_from") or r.get("range_traffic_from"),
+                            traffic_from=r.get("traffic_from") or r.get("range_traffic_from"), fused=r.get("fused"),
+                            two_kernels=(None if not r.get("two_kernels") else
+                                         {k: r["two_kernels"].get(k) for k in ("ms_per_step", "layout_kernel_ms_avg", "range_kernel_ms_avg", "layout_frac", "range_frac",
+                                                                                "path_frac", "same_counters")}),
                             lib_sha16=r.get("lib_sha16"), kernel_src_sha16=r.get("kernel_src_sha16"))
     if cpu:
         allc = cpu.get("all_cores") or {}
@@ -844,6 +847,41 @@ def main():
             ctx.sync()
     kernel_ms_alone = ctx.kernel_timing_collect(5 * len(dev) + 8)
     info = ctx.launch_info()
+    # (c) a fused pass (no records in memory: layout_bytes says 0 written) beside what it replaced: the same shards as read sets
+    # with records in memory (SPL_FUSED=0), every step the layout kernel and the range kernel -- rounds 1-5's two kernels
+    fused = all(b == 0 for _, b in layout_bytes) and args.kernel == "ranges" and not scode
+    two_kernels = None
+    if fused:
+        os.environ["SPL_FUSED"] = "0"
+        try:
+            packed = [(ds, ctx.layout_read_segments(soa, [shift for _, shift in sh.read_segments])) for (ds, _, soa), sh in zip(dev, shards)]
+        finally:
+            del os.environ["SPL_FUSED"]
+        n2 = max(2, min(args.steps, 10))
+
+        def step2():
+            for ds, dr in packed:
+                dr.relayout()
+                ctx.count_launch(ds, dr, scode, 0, kflags)
+                ctx.sse_launch(ds, args.beta2Cryptic)
+            ctx.pass_barrier()
+        for _ in range(2):
+            step2()
+        ctx.sync()
+        ctx.kernel_timing_begin(n2 * len(packed))
+        t2 = time.perf_counter()
+        for _ in range(n2):
+            step2()
+        ctx.sync()
+        t2 = (time.perf_counter() - t2) / n2
+        l2 = ctx.layout_timing_collect(n2 * len(packed) + 8)
+        k2 = ctx.kernel_timing_collect(n2 * len(packed) + 8)
+        lb2 = [dr.layout_bytes() for _, dr in packed]
+        same2 = all(all(np.array_equal(a, b) for a, b in zip(ds.counters(), g)) for (ds, _), g in zip(packed, gpu_counts))
+        two_kernels = {"ms_per_step": t2 * 1e3, "layout_kernel_ms_avg": float(np.mean(l2)) if l2 else None, "range_kernel_ms_avg": float(np.mean(k2)) if k2 else None,
+                       "layout_bytes_per_launch": sum(a + b for a, b in lb2) / max(len(lb2), 1), "same_counters": bool(same2), "steps": n2}
+        for _, dr in packed:
+            dr.free()
     for cp in copies:
         for ds, dr, soa in cp:
             dr.free()
@@ -953,13 +991,23 @@ def main():
         layout_gbs = (soa_per_launch + rec_per_launch) / (l_avg_ms * 1e-3) / 1e9 if layout_ms else float("nan")
         ms_per_step = elapsed / args.steps * 1e3
         path_gbs = alg_bytes / (my_elapsed / args.steps) / 1e9
-        range_obj = {"kernel": "spl_count_%s_kernel" % args.kernel.split("_")[0], "kernel_ms_avg": k_avg_ms, "launches_timed": len(kernel_ms),
+        range_obj = {"kernel": "spl_count_%s_kernel%s" % (args.kernel.split("_")[0], "<FUSED>" if fused else ""), "kernel_ms_avg": k_avg_ms, "launches_timed": len(kernel_ms),
                      "algorithmic_bytes_per_launch": bytes_per_launch, "achieved": range_gbs, "frac": range_gbs / HBM_PEAK_GBS,
-                     "what": "SURVEY 8(d)'s bytes (the BAM-native inputs once, the outputs once) / the range kernel's mean duration: rounds 1-4's roofline.frac"}
-        layout_obj = {"kernel": "spl_layout_kernel", "kernel_ms_avg": l_avg_ms, "launches_timed": len(layout_ms),
+                     "what": ("SURVEY 8(d)'s bytes (the BAM-native inputs once, the outputs once) / the fused range kernel's mean duration: the kernel reads the "
+                              "BAM-native arrays itself and makes a tile's records in LDS -- no layout kernel, no records in memory" if fused else
+                              "SURVEY 8(d)'s bytes (the BAM-native inputs once, the outputs once) / the range kernel's mean duration: rounds 1-4's roofline.frac")}
+        layout_obj = {"kernel": "spl_layout_kernel", "kernel_ms_avg": l_avg_ms if layout_ms else None, "launches_timed": len(layout_ms),
                       "algorithmic_bytes_per_launch": soa_per_launch + rec_per_launch, "arrays_read": soa_per_launch, "records_written": rec_per_launch,
-                      "achieved": layout_gbs, "frac": layout_gbs / HBM_PEAK_GBS,
-                      "what": "the arrays read once (10 B a read + 4 B an op) + the records written once / the layout kernel's mean duration"}
+                      "achieved": layout_gbs if layout_ms else None, "frac": layout_gbs / HBM_PEAK_GBS if layout_ms else None,
+                      "what": ("not launched: the pass is fused (see range)" if fused else
+                               "the arrays read once (10 B a read + 4 B an op) + the records written once / the layout kernel's mean duration")}
+        if two_kernels is not None:
+            tk = two_kernels
+            tk["what"] = ("the same shards as read sets with records in memory (SPL_FUSED=0): layout kernel + range kernel every step, what rounds 1-5 "
+                          "timed; frac: each kernel's bytes (layout: arrays read + records written; range: SURVEY 8(d)'s) / its duration / the HBM peak")
+            tk["layout_frac"] = tk["layout_bytes_per_launch"] / (tk["layout_kernel_ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS if tk["layout_kernel_ms_avg"] else None
+            tk["range_frac"] = bytes_per_launch / (tk["range_kernel_ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS if tk["range_kernel_ms_avg"] else None
+            tk["path_frac"] = alg_bytes / (tk["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         # THE roofline object is the dominant kernel's: whichever of the two takes longer per launch
         dom, other = (layout_obj, range_obj) if (layout_ms and l_avg_ms >= k_avg_ms) else (range_obj, layout_obj)
         out = {
@@ -975,14 +1023,15 @@ def main():
                                    % (args.workload, int(tot_reads), int(tot_sites), " per GPU" if args.scaling == "weak" and world > 1 else "",
                                       len(items), len(dev), stranded or "unstranded"),
                        "scale": args.scale, "parallelism": "chromosome/sample shards, no collectives", "seed": synth.WORKLOADS[args.workload]["seed"],
-                       "step": "BAM-native arrays resident in HBM -> layout + range + literal + scan/SSE kernels of every shard, %s"
-                               % ("no barrier between steps (pipelined)" if args.pipelined else "barrier between steps")},
+                       "step": "BAM-native arrays resident in HBM -> %s + literal + scan/SSE kernels of every shard, %s"
+                               % ("chunk map + order, fused range kernel (records made in LDS)" if fused else "layout + range",
+                                  "no barrier between steps (pipelined)" if args.pipelined else "barrier between steps")},
             "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["frac"], "traffic": traffic if dom is range_obj else layout_traffic, "traffic_from": traffic_from,
                          "kernel": dom["kernel"], "kernel_ms_avg": dom["kernel_ms_avg"], "launches_timed": dom["launches_timed"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                          "what": dom["what"],
-                         "layout": layout_obj, "range": range_obj, "second_kernel": other["kernel"],
+                         "layout": layout_obj, "range": range_obj, "second_kernel": None if fused else other["kernel"], "fused": fused, "two_kernels": two_kernels,
                          "range_traffic": traffic, "range_traffic_from": traffic_from,
                          "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"],
                          "alone": (None if not kernel_ms_alone else
@@ -991,7 +1040,8 @@ def main():
                                     "how": "the range kernel: 5 more launches after the timed region, each followed by a sync"}),
                          "path": {"what": "SURVEY 8(d)'s algorithmic bytes of a step / time of a step: every kernel of the pass (layout included) and the gaps between them",
                                   "achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS},
-                         "count_only": {"what": "the step as rounds 1-4 timed it: from the records on (range + literal + scan), no layout",
+                         "count_only": {"what": ("the step without the chunk map and order kernels (they need the CIGAR offsets only)" if fused else
+                                                 "the step as rounds 1-4 timed it: from the records on (range + literal + scan), no layout"),
                                         "ms_per_step": count_only_s * 1e3, "reads_per_sec": n_reads / count_only_s,
                                         "path_frac": alg_bytes / count_only_s / 1e9 / HBM_PEAK_GBS},
                          "hbm_actual": (None if not traffic or not kernel_ms else

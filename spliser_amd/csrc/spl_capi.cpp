@@ -419,6 +419,10 @@ struct spl_dreads {
     uint32_t n_chunks = 0;
     uint32_t n_slots = 0;           // slots of the range kernel's grid: 8 * spl_order_per(n_chunks)
     uint32_t chunk_shift = SPL_CHUNK_SHIFT; // reads per chunk of this set (fixed when it is begun: spl_reads_begin_sized)
+    // FUSED: every segment of the set lies in ONE set of device arrays, and the counting pass reads those arrays itself
+    // (spl_count_ranges_kernel<.., FUSED>: a chunk's records made in LDS, a tile of SPL_TILE_FUSED reads at a time) -- no record slots, no
+    // layout kernel.  What needs records in memory (the pair kernel, spl_reads_junctions) lays the set out first (unfuse).
+    bool fused = false;
     bool finished = false;
     char *ctl = nullptr;            // chunk descriptors, costs, chunk order, the queues (allocated by spl_reads_finish)
     spl_chunk_meta *meta = nullptr;
@@ -2059,6 +2063,7 @@ static int launch_layout(spl_ctx *c, spl_dreads *d)
         if (rc) return spl_set_error(SPL_ERR_HIP, "chunk order kernel launch: %s", hipGetErrorString((hipError_t)rc));
     }
     size_t gi = 0;
+    if (d->fused) return SPL_OK; // (the counting pass makes its records itself)
     for (spl_dreads::Group &g : d->groups) {
         const spl_layout_params &lp = lps[gi++];
         int64_t n_reads = 0, n_ops = 0;
@@ -2076,6 +2081,13 @@ static int launch_layout(spl_ctx *c, spl_dreads *d)
     return SPL_OK;
 }
 
+// SPL_FUSED=0: every read set gets its records in memory (the layout kernel), as before round 5's fused pass.
+static bool fused_wanted()
+{
+    const char *e = getenv("SPL_FUSED");
+    return !e || atoi(e) != 0;
+}
+
 // The flat chunk list of a read set, the chunk order of the range kernel and the queues.
 static int finish_reads(spl_ctx *c, spl_dreads *d)
 {
@@ -2090,6 +2102,9 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
     if (d->n_cigar > 0xfffffff0LL) return spl_set_error(SPL_ERR_ARG, "more than 2^32 CIGAR ops in one read set: use more shards");
     auto host_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tf0 = host_now();
+    bool all_device = !d->segs.empty();
+    for (const spl_dreads::Segment &seg : d->segs) all_device = all_device && seg.group >= 0;
+    d->fused = fused_wanted() && all_device && d->groups.size() == 1;
     const size_t n = d->n_chunks;
     const uint32_t per = spl_order_per((uint32_t)n);
     d->n_slots = 8u * per;
@@ -2145,7 +2160,7 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
     const uint32_t chunk = 1u << d->chunk_shift;
     for (spl_dreads::Group &g : d->groups) {
         const size_t seg_bytes = align_up(sizeof(spl_layout_seg) * g.segs.size());
-        e = devmem::get((void **)&g.slab, SPL_LAYOUT_SLOT(chunk) * (size_t)g.n_chunks + 256, 'R');
+        e = d->fused ? hipSuccess : devmem::get((void **)&g.slab, SPL_LAYOUT_SLOT(chunk) * (size_t)g.n_chunks + 256, 'R');
         if (e == hipSuccess) e = devmem::get((void **)&g.d_segs, seg_bytes + sizeof(spl_layout_chunk) * (size_t)g.n_chunks + 16, 'd');
         if (e != hipSuccess) return spl_set_error(SPL_ERR_HIP, "hipMalloc for the device layout of %u chunks: %s", g.n_chunks, hipGetErrorString(e));
         g.d_chunks = (spl_layout_chunk *)((char *)g.d_segs + seg_bytes);
@@ -2158,6 +2173,19 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
                 tf_alloc, host_now() - tf0);
     d->finished = true;
     return SPL_OK;
+}
+
+// A fused read set gets records in memory after all: the chunk size it would have had, record slots, the layout kernel.
+static int unfuse(spl_ctx *c, spl_dreads *d)
+{
+    if (!d->fused) return SPL_OK;
+    d->fused = false;
+    const uint32_t chunk = 1u << d->chunk_shift;
+    for (spl_dreads::Group &g : d->groups) {
+        const hipError_t e = devmem::get((void **)&g.slab, SPL_LAYOUT_SLOT(chunk) * (size_t)g.n_chunks + 256, 'R');
+        if (e != hipSuccess) return spl_set_error(SPL_ERR_HIP, "hipMalloc for the device layout of %u chunks: %s", g.n_chunks, hipGetErrorString(e));
+    }
+    return launch_layout(c, d);
 }
 
 // The layout again, into the same record slots (bench.py's step: BAM-native arrays -> records -> counters, every step).
@@ -2451,6 +2479,12 @@ extern "C" int spl_reads_layout_bytes(spl_ctx *c, const spl_dreads *d, int64_t *
     HIP_TRY(hipSetDevice(c->device));
     int64_t soa = 0, rec = 0;
     std::vector<spl_chunk_meta> meta(d->n_chunks);
+    if (d->fused) { // no records are written: what the counting pass reads is the arrays
+        for (const spl_dreads::Segment &seg : d->segs) soa += 10 * seg.n_reads + 4 * seg.n_ops;
+        *soa_bytes_out = soa;
+        *record_bytes_out = 0;
+        return SPL_OK;
+    }
     if (d->n_chunks) {
         HIP_TRY(hipMemcpyAsync(meta.data(), d->meta, sizeof(spl_chunk_meta) * d->n_chunks, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2544,6 +2578,10 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     } else if (int rc0 = spl_dev_launch_clear(ds->beta1, ds->counter_bytes, c->stream)) // (in place: the copy in use)
         return spl_set_error(SPL_ERR_HIP, "clear kernel launch: %s", hipGetErrorString((hipError_t)rc0));
     if (!dr->finished) return spl_set_error(SPL_ERR_ARG, "spl_count_launch: the read set is not finished (spl_reads_finish)");
+    // The fused pass is the unstranded range kernel's: a stranded pass has four difference windows, not two, and with the tile's
+    // records beside them three workgroups fit a CU, not four -- measured slower than layout + range (mouse, 100 M reads: 1.37 ms a
+    // step against 1.20); the pair kernel and the merging variant read records.  Such a pass lays the set out first, once.
+    if (dr->fused && (variant != 0 || o->stranded)) { const int rc0 = unfuse(c, const_cast<spl_dreads *>(dr)); if (rc0) return rc0; }
     uint32_t *const queue = dr->queue_turn ? dr->queue_alt : dr->queue;
     dr->queue_turn ^= 1;
     dr->queued_pass = false;
@@ -2567,6 +2605,12 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     h.stranded = o->stranded; h.diff = p.diff; h.diff_stride = p.diff_stride;
     h.queue = queue; h.queue_n = ds->queue_n; h.err = ds->err;
     h.queue_cap = dr->queue_cap;
+    if (dr->fused) {
+        const spl_dreads::Group &g = dr->groups[0];
+        h.cells = g.d_chunks;
+        h.src = spl_devreads{(const int32_t *)g.src->pos, (const uint16_t *)g.src->flag, (const uint32_t *)g.src->cig_off, (const uint32_t *)g.src->cigar};
+        h.src_n_rec = g.src->n_rec; h.src_n_ops = g.src->n_ops;
+    }
     h.jhash = ds->jhash; h.jhash_mask = ds->jhash_mask; h.jrivals = ds->jrivals; h.dbl = ds->dbl; h.combine_mode = o->combine_mode ? 1 : 0;
 
     p.bucket = ds->bucket; p.n_buckets = ds->n_buckets; p.bucket_base = ds->bucket_base; p.bucket_shift = ds->bucket_shift;
@@ -2598,6 +2642,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
         spl_queue_params lq;
         lq.queue = queue; lq.queue_n = ds->queue_n; lq.queue_cap = h.queue_cap; lq.chunk_shift = dr->chunk_shift; lq.queue_total = dr->queue_total;
         lq.clear_region = (uint4 *)ds->region[to_clear]; lq.clear_n16 = ds->counter_bytes / 16;
+        lq.cells = h.cells; lq.src = h.src;
         lq.diff = ds->diff; lq.block_sums = ds->block_sums; lq.diff_stride = ds->diff_stride; lq.n_dpos = ds->n_dpos;
         lq.scan_blocks = ds->scan_blocks; lq.scan_arrays = o->stranded ? 4 : 2;
         rc = spl_dev_launch_literal(&p, &lq, ts);
@@ -2722,6 +2767,7 @@ extern "C" int spl_junctions(spl_ctx *c, const spl_dreads *dr, int stranded, int
     unsigned long long *keys = (unsigned long long *)buf, *out_keys = keys + slots;
     uint32_t *vals = (uint32_t *)(out_keys + slots), *out_vals = vals + 3 * slots, *n_dev = out_vals + 3 * slots;
     if (!dr->finished) { (void)hipFree(buf); return spl_set_error(SPL_ERR_ARG, "spl_junctions: the read set is not finished (spl_reads_finish)"); }
+    if (dr->fused) { const int rc0 = unfuse(c, const_cast<spl_dreads *>(dr)); if (rc0) { (void)hipFree(buf); return rc0; } } // (the junction kernel reads records)
     int rc = spl_dev_launch_junctions(dr->meta, dr->n_chunks, stranded, (uint32_t)min_anchor, (uint32_t)min_intron,
                                       (uint32_t)max_intron, keys, vals, (uint32_t)slots, out_keys,
                                       out_vals, n_dev, c->d_err, c->stream);

@@ -6,6 +6,7 @@
 #include <hip/hip_vector_types.h>
 
 #include "spl_pack.h"
+#include "spl_devpack.h"
 
 // Launch geometry of the classification kernels (see DESIGN.md "Kernels").
 #ifndef SPL_BLOCK
@@ -31,6 +32,12 @@
 #define SPL_WAVE_ITERS 10
 #endif
 #define SPL_WAVE_READS (64 * SPL_WAVE_ITERS)
+#define SPL_TILE_FUSED_SHIFT 10           // reads per tile of a fused pass: the records of 1024 reads are 24.8 KB of LDS at most
+#define SPL_TILE_FUSED (1 << SPL_TILE_FUSED_SHIFT)
+#define SPL_BLOCK_FUSED 256              // threads of its workgroups: four reads of a tile a thread (512 threads, two reads each, eight
+                                         // waves to count a tile: 1.25 ms a launch against 0.94 -- what a wave does per tile whatever its
+                                         // share of it is what the pass spends its instructions on)
+#define SPL_WAVE_READS_FUSED 512         // a wave's list entries there (4 workgroups of 39 KB on a CU)
 #define SPL_WIN 1020                     // distinct site positions a workgroup privatises in LDS (pair kernel; range kernel unstranded)
 #define SPL_WIN_STRANDED 956             // ... range kernel, stranded: 4 windows + the lists, 8 workgroups in 160 KB
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
@@ -126,6 +133,11 @@ struct spl_hot_params {
     uint32_t *queue_n;           // entries used per region, counter k at word k * SPL_COUNTER_STRIDE
     uint32_t queue_cap;
     int32_t *err;
+    // the FUSED instantiation (reads counted straight from the BAM-native arrays, see spl_count_ranges_kernel): the chunks are
+    // cells of the grid over the arrays' indexes; chunk_meta is not looked at
+    const spl_layout_chunk *cells; // [chunks] (spl_devpack.h; made by spl_layout_map_kernel)
+    spl_devreads src;
+    int64_t src_n_rec, src_n_ops;
 };
 
 // the literal kernel's view of the queue (entries: chunk << SPL_CHUNK_SHIFT | slot of the read in its chunk, run order)
@@ -142,6 +154,9 @@ struct spl_queue_params {
     // ... and the other copy of the counter region is cleared for the next counting pass
     uint4 *clear_region;
     size_t clear_n16;
+    // entries of a FUSED pass: chunk << chunk_shift | index of the read in the chunk's cell of the arrays
+    const spl_layout_chunk *cells; // null: the entries are slots of packed chunks
+    spl_devreads src;
 };
 
 struct spl_sse_params {

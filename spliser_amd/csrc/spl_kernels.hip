@@ -30,6 +30,7 @@
 #define SPL_HD __device__ __forceinline__
 #include "spl_classify.h"
 #include "spl_device.h"
+#include "spl_layout_tile.h"
 
 namespace {
 
@@ -670,12 +671,23 @@ __device__ __forceinline__ bool rivals_inline2(const spl_hot_params &p, spl_lds_
 // (The instrumented builds this kernel was tuned with -- phase stamps, knock-out variants -- are a patch, not part of this
 //  source: profiles/experiments/r05_range_kernel_instrumentation.patch.)
 
+// FUSED (round 5): the same pass over a read set that is still BAM-native arrays in device memory (spl_devpack.h: the chunks are
+// cells of the grid over the arrays' indexes, p.cells) -- the workgroup takes its chunk a TILE of 1024 reads at a time, makes the
+// tile's records itself with the layout kernel's code (spl_layout_tile.h: a thread's four reads, the tile's ops through LDS,
+// classification, ranks by prefix sums) but into LDS, where the ops were, and counts them from there with the code below: the
+// records -- 12.7 bytes a read written and read again, beside 18.7 of arrays -- never go to memory, and there is no layout
+// launch.  The difference windows, the lists' front parts and the window's base belong to the chunk, not the tile.  39 KB of
+// LDS, 96 VGPRs: four workgroups a CU.  Unstranded passes only (four windows leave room for three workgroups: slower than layout +
+// range); a queue entry names its read by its place in the arrays (s_idx), which is where the literal kernel then reads it.
+// Measured (human-scale, 100 M reads a launch): 0.94-0.98 ms against 0.655-0.67 + 0.375-0.39 for layout + range.  Asking for the next
+// tile's reads before this tile is counted gained nothing (a wave's memory operations return in order: the first bucket entry
+// waits for them), 512 threads -- two reads each, eight waves counting a tile -- took 1.25 ms: profiles/r05X_fused_pass.txt.
 // Default (AGG false): plain LDS atomics, 64 VGPRs = 8 waves per SIMD (the kernel lives on how many waves are there to
 // cover each other's memory trips and barriers; the register cap costs nothing -- no scratch).  Merging the atomics of
 // neighbouring lanes first (AGG, SPL_OPT_WAVE_AGGREGATION) needs a few more registers than that cap allows and was
 // never faster in measurements, not even at 8000 reads per site; it stays as a variant for parity tests.
-template <bool STRANDED, bool AGG, bool BIG>
-__global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ? 4 : 8, 8))) void spl_count_ranges_kernel(const spl_hot_params p)
+template <bool STRANDED, bool AGG, bool BIG, bool FUSED>
+__global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(FUSED || AGG ? 4 : 8, 8))) void spl_count_ranges_kernel(const spl_hot_params p)
 {
     constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
     constexpr int WIN = STRANDED ? SPL_WIN_STRANDED : SPL_WIN;
@@ -685,8 +697,20 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     // from the front the reads for the literal kernel, from the back the once- and twice-spliced reads whose junction has rivals
     // (finished from the junction table by the wave itself right after its loop, see below).  Only the owning wave touches a
     // segment, so the fill counts are wave-uniform registers and slots are handed out by ballot, not by atomics.
-    constexpr int NWAVE = SPL_WAVES;
-    constexpr uint32_t SEG = SPL_WAVE_READS;
+    constexpr int BLOCK = FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK, NWAVE = BLOCK / 64;
+    constexpr int RPT = (int)SPL_TILE_FUSED / SPL_BLOCK_FUSED; // FUSED: reads a thread takes of a tile
+    constexpr uint32_t SEG = FUSED ? SPL_WAVE_READS_FUSED : SPL_WAVE_READS;
+    constexpr uint32_t CSHIFT = BIG ? SPL_CHUNK_BIG_SHIFT : SPL_CHUNK_SHIFT;
+    // FUSED: the chunk's records are made here, in LDS, from the BAM-native arrays (spl_layout_tile.h: the layout kernel's body),
+    // a TILE of SPL_TILE_FUSED reads at a time, and counted from there -- they never exist in memory.  While a tile is counted the
+    // next one's reads are on their way into registers.  s_rec: first the stage of the tile's ops, then its records.
+    constexpr uint32_t TILE = SPL_TILE_FUSED, TILES = FUSED ? (1u << CSHIFT) / TILE : 1u;
+    constexpr uint32_t REC_BYTES = FUSED ? (uint32_t)SPL_LAYOUT_SLOT(TILE) : 16u;
+    __shared__ uint4 s_rec[REC_BYTES / 16u];
+    __shared__ uint16_t s_idx[FUSED ? TILE : 1];   // read q of the tile's runs 1 .. 3 -> its index in the chunk's cell of the arrays
+    __shared__ uint32_t s_lay[2 * NWAVE];
+    typedef __attribute__((address_space(3))) const char spl_lchar;
+    spl_lchar *const lrec = (spl_lchar *)s_rec;
     __shared__ uint16_t s_q[NWAVE * SEG];
     __shared__ uint32_t s_qcnt[NWAVE], s_qbase;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, in an SGPR
@@ -714,18 +738,20 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     // are never listed).  A list that is full does not drop a read: its entries go straight into the literal queue -- one
     // returning atomic per push instead of one per workgroup, on a path that a chunk of mostly flagged spliced reads takes --,
     // and a twice-spliced read that finds the back list full is the literal kernel's (which takes any read).
+    uint32_t n_simple = 0; // (FUSED: s_idx counts from the first read that is not a simple one)
+    auto entry_of = [&](uint32_t slot) { return FUSED ? (uint32_t)((__attribute__((address_space(3))) const uint16_t *)s_idx)[(slot & 0x3fffu) - n_simple] : slot; };
     auto push_direct = [&](bool want, uint32_t slot, unsigned long long m, uint32_t n) {
         const uint32_t shard = blockIdx.x & 7u;
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&p.queue_n[shard * SPL_COUNTER_STRIDE], n);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (want) p.queue[(size_t)shard * p.queue_cap + base + rank_in(m)] = (chunk << (BIG ? SPL_CHUNK_BIG_SHIFT : SPL_CHUNK_SHIFT)) | slot;
+        if (want) p.queue[(size_t)shard * p.queue_cap + base + rank_in(m)] = (chunk << CSHIFT) | entry_of(slot);
     };
     auto push_front = [&](bool want, uint32_t slot) {
         const unsigned long long m = __ballot(want);
         const uint32_t n = (uint32_t)__popcll(m);
         if (n_front + n_back - back_done + n > SEG) { push_direct(want, slot, m, n); return; }
-        if (want) s_q[seg0 + n_front + rank_in(m)] = (uint16_t)slot;
+        if (want) s_q[seg0 + n_front + rank_in(m)] = (uint16_t)entry_of(slot); // (FUSED: the tile's records are gone when the list is handed over)
         n_front += n;
     };
     auto push_back = [&](bool want, uint32_t slot) {
@@ -737,7 +763,79 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
     };
 
     const int tid = threadIdx.x;
-    const ChunkView cv = chunk_view(p.chunk_meta + chunk);
+    int32_t wbase = 0;
+    ChunkView cv;
+    // (the first two words of a bucket entry: all a boundary needs that is no junction end)
+    auto dbk2 = [&](uint32_t s) { const uint32_t *q = (const uint32_t *)(p.dbucket + s); spl_dbk e; e.first = q[0]; e.occ = q[1]; e.rival = 0u; return e; };
+    auto dbk3 = [&](uint32_t s) { return p.dbucket[s]; };
+    // ---- FUSED: the chunk's tiles.  Tile k is the part [lo, hi) of the chunk in cell [g0 + k TILE, + TILE) of the arrays' indexes.
+    spl_layout_chunk ch;
+    uint32_t tile = 0, tile_last = 0;
+    uint32_t ob[TILES + 1]; // cig_off at the tiles' boundaries
+    auto span_of = [&](uint32_t k) {
+        const int64_t g0 = ch.lo & ~(int64_t)((1u << CSHIFT) - 1u), hi = ch.lo + ch.n;
+        spllay::TileSpan sp;
+        sp.cell0 = g0 + (int64_t)k * TILE;
+        sp.lo = sp.cell0 > ch.lo ? sp.cell0 : ch.lo;
+        sp.hi = sp.cell0 + TILE < hi ? sp.cell0 + TILE : hi;
+        uint32_t a = ob[0], b = ob[1];
+#pragma unroll
+        for (uint32_t q = 1; q < TILES; ++q) { a = k == q ? ob[q] : a; b = k == q ? ob[q + 1] : b; }
+        sp.o_lo = a; sp.o_hi = b; sp.o_fetch_hi = ch.o_hi; sp.seg_op0 = ch.seg_op0;
+        return sp;
+    };
+    if constexpr (FUSED) {
+        if (!live) return; // (the whole workgroup: before any barrier)
+        ch = p.cells[chunk];
+        const int64_t g0 = ch.lo & ~(int64_t)((1u << CSHIFT) - 1u), hi = ch.lo + ch.n;
+        tile = (uint32_t)((ch.lo - g0) >> SPL_TILE_FUSED_SHIFT);
+        tile_last = (uint32_t)((hi - 1 - g0) >> SPL_TILE_FUSED_SHIFT);
+        // (the window's base: the bucket entry of the chunk's first POS is asked for now, beside the arrays)
+        const int32_t fp0 = p.src.pos[ch.lo] + ch.shift;
+        const spl_dbk e_first = p.dbucket[dbk_slot(p, fp0 - 1)];
+#pragma unroll
+        for (uint32_t q = 0; q <= TILES; ++q) {
+            int64_t i = g0 + (int64_t)q * TILE;
+            i = i < ch.lo ? ch.lo : (i > hi ? hi : i);
+            ob[q] = q == 0u ? ch.o_lo : (q == TILES ? ch.o_hi : p.src.cig_off[i]);
+        }
+        for (int j = tid; j < NARR * (WIN + 1); j += BLOCK) lds[j] = 0; // (a barrier lies between this and the first count: tile_finish has three)
+        cv.rec = nullptr;
+        cv.wide = (spl_gu32 *)(p.src.cigar + ch.seg_op0);
+        cv.shift = ch.shift;
+        cv.first_pos = fp0 - ch.shift;
+        { uint32_t nv; dbk_resolve(p, fp0 - 1, e_first, wbase, nv); }
+    } else {
+        cv = chunk_view(p.chunk_meta + chunk);
+    }
+    // a record's 16 / 8 bytes at a byte offset of the chunk's record area
+    typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+    auto ld_r4 = [&](uint32_t at) {
+        if constexpr (FUSED) { const u32x4_a8 v = *(__attribute__((address_space(3))) const u32x4_a8 *)(lrec + at); return make_uint4(v.x, v.y, v.z, v.w); }
+        else return ld_g4(cv.rec + (size_t)at);
+    };
+    auto ld_r2 = [&](uint32_t at) {
+        if constexpr (FUSED) { const spl_u32x2 v = *(__attribute__((address_space(3))) const spl_u32x2 *)(lrec + at); return make_uint2(v.x, v.y); }
+        else return ld_g2(cv.rec + (size_t)at);
+    };
+    for (;;) { // the chunk's tiles (FUSED), or the chunk in one piece
+    if constexpr (FUSED) {
+        const spllay::TileSpan sp = span_of(tile);
+        uint32_t n[4];
+        {
+            spllay::TileLoads<(int)TILE, RPT> L;
+            spllay::tile_issue<(int)TILE, RPT>(p.src, p.src_n_rec, p.src_n_ops, sp, L);
+            spllay::tile_finish<(int)TILE, RPT>(p.src, p.src_n_ops, sp, L, (spllay::lay_lds_w32 *)s_rec, (spllay::lay_lds_w32 *)s_lay,
+                                                spllay::RecordsInLds{(spllay::lay_lds_u8 *)s_rec, (spllay::lay_lds_u16 *)s_idx, tile * TILE}, n);
+        }
+        cv.start[0] = 0; cv.start[1] = n[0]; cv.start[2] = n[0] + n[1]; cv.start[3] = n[0] + n[1] + n[2]; cv.start[4] = n[0] + n[1] + n[2] + n[3];
+        cv.off[0] = 0;
+        cv.off[1] = (n[0] * SPL_REC_SIMPLE + 15u) & ~15u;
+        cv.off[2] = cv.off[1] + n[1] * SPL_REC_MNM;
+        cv.off[3] = cv.off[2] + n[2] * SPL_REC_M2;
+        n_simple = n[0];
+        __syncthreads(); // the tile's records are there
+    }
     // Wave-iterations of the chunk.  A wave-iteration takes 64 * K consecutive reads of ONE run, K per lane: K = 4 for simple reads
     // (32 bytes of records per lane), 2 for once-spliced ones (32 bytes), 1 for the rest (24 bytes).  Run r has iters[r]
     // wave-iterations, the first being number g_start[r] of the chunk.
@@ -776,18 +874,16 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         // only if every way through the loop body issues the same number after the bucket loads can the wait for the bucket
         // entries leave these two in flight (a branch here turns that wait into "wait for everything").  A 24-byte record's
         // second load takes 8 bytes of its neighbour along.
-        spl_gchar *r = cv.rec + (size_t)(off + (i0 < n_run ? i0 : 0u) * size);
-        cu0 = ld_g4(r);
-        cu1 = ld_g4(r + 16);
+        const uint32_t r = off + (i0 < n_run ? i0 : 0u) * size;
+        cu0 = ld_r4(r);
+        cu1 = ld_r4(r + 16u);
     };
     if (wave < g_total) fetch(wave);
-    int32_t wbase = 0;
-    { const int32_t fp = cv.first_pos + cv.shift; uint32_t nv; const spl_dbk e = p.dbucket[dbk_slot(p, fp - 1)]; dbk_resolve(p, fp - 1, e, wbase, nv); }
-    for (int j = tid; j < NARR * (WIN + 1); j += SPL_BLOCK) lds[j] = 0;
-    __syncthreads();
-    // (the first two words of a bucket entry: all a boundary needs that is no junction end)
-    auto dbk2 = [&](uint32_t s) { const uint32_t *q = (const uint32_t *)(p.dbucket + s); spl_dbk e; e.first = q[0]; e.occ = q[1]; e.rival = 0u; return e; };
-    auto dbk3 = [&](uint32_t s) { return p.dbucket[s]; };
+    if constexpr (!FUSED) {
+        { const int32_t fp = cv.first_pos + cv.shift; uint32_t nv; const spl_dbk e = p.dbucket[dbk_slot(p, fp - 1)]; dbk_resolve(p, fp - 1, e, wbase, nv); }
+        for (int j = tid; j < NARR * (WIN + 1); j += BLOCK) lds[j] = 0;
+        __syncthreads();
+    }
 
     {
         // One loop per run, the wave's iterations g = wave, wave + 4, ... running through all of them; the records of the NEXT
@@ -1031,8 +1127,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             if (j < n_m2) {
                 const uint32_t entry = s_q[seg0 + SEG - n_back + j];
                 slot = entry & 0x3fffu;
-                spl_gchar *q = cv.rec + (size_t)(cv.off[2] + SPL_REC_M2 * (slot - cv.start[2]));
-                const uint2 ra = ld_g2(q), rb = ld_g2(q + 8), rc = ld_g2(q + 16);
+                const uint32_t q = cv.off[2] + SPL_REC_M2 * (slot - cv.start[2]);
+                const uint2 ra = ld_r2(q), rb = ld_r2(q + 8u), rc = ld_r2(q + 16u);
                 const int32_t pos = (int32_t)ra.x + cv.shift;
                 uint32_t sidx = 0;
                 if (STRANDED) sidx = (spl_read_strand(ra.y & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
@@ -1052,10 +1148,10 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             const uint32_t n_run = cv.start[2] - cv.start[1];
             auto fetch_mnm = [&](uint32_t g2) {
                 const uint32_t i0 = (((g2 - g_start[1]) << 6) + lane) * KM;
-                spl_gchar *r = cv.rec + (size_t)(cv.off[1] + (i0 < n_run ? i0 : 0u) * SPL_REC_MNM);
+                const uint32_t r = cv.off[1] + (i0 < n_run ? i0 : 0u) * SPL_REC_MNM;
                 cu_i0 = i0;
-                cu0 = ld_g4(r);
-                cu1 = ld_g4(r + 16);
+                cu0 = ld_r4(r);
+                cu1 = ld_r4(r + 16u);
             };
             uint32_t g2 = g_start[1] + ((wave + NWAVE - (g_start[1] % NWAVE)) % NWAVE), it2 = 0; // (the wave's first iteration of this run: its iterations are g = wave, wave + 4, ... through all runs)
             if (g2 < g_start[2]) fetch_mnm(g2);
@@ -1097,6 +1193,14 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             }
         }
     }
+    if constexpr (!FUSED) break;
+    else {
+        if (tile == tile_last) break;
+        ++tile;
+        fm_mnm = 0; it_mnm = 0; n_back = 0; back_done = 0; // (the wave's lists of the tile's own reads are through; the front list goes on)
+        __syncthreads(); // everybody is through with the tile's records: the next tile's ops take their place
+    }
+    } // tiles
     if ((tid & 63) == 0) s_qcnt[tid >> 6] = n_front;
     __syncthreads();
     // Hand the chunk's queue over: one returning atomic per workgroup on the counter of its XCD shard (8 counters, so
@@ -1113,8 +1217,8 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
         if (tid == 0) s_qbase = atomicAdd(&p.queue_n[shard * SPL_COUNTER_STRIDE], qn); // a cache line per counter
         __syncthreads();
         uint32_t *dst = p.queue + (size_t)shard * p.queue_cap + s_qbase;
-        const uint32_t first = chunk << (BIG ? SPL_CHUNK_BIG_SHIFT : SPL_CHUNK_SHIFT);
-        for (uint32_t j = tid; j < qn; j += SPL_BLOCK) {
+        const uint32_t first = chunk << CSHIFT;
+        for (uint32_t j = tid; j < qn; j += BLOCK) {
             uint32_t w = 0;
 #pragma unroll
             for (int k = 1; k < NWAVE; ++k) w += (j >= q_start[k]) ? 1u : 0u;
@@ -1124,7 +1228,7 @@ __global__ __launch_bounds__(SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(AGG ?
             dst[j] = first | (uint32_t)s_q[w * SEG + (j - base)];
         }
     }
-    for (int j = tid; j < NARR * (WIN + 1); j += SPL_BLOCK) {
+    for (int j = tid; j < NARR * (WIN + 1); j += BLOCK) {
         const int32_t v = lds[j];
         if (v) {
             const int arr = j / (WIN + 1), loc = j - arr * (WIN + 1);
@@ -1301,9 +1405,22 @@ __global__ __launch_bounds__(64) void spl_count_literal_kernel(const spl_count_p
 #pragma unroll
             for (int sh = 0; sh < 8; ++sh) base = (shard == (uint32_t)sh) ? start[sh] : base;
             const uint32_t entry = q.queue[(size_t)shard * q.queue_cap + (g - base)]; // chunk << SPL_CHUNK_SHIFT | slot
-            const ChunkView cv = chunk_view(p.chunk_meta + (entry >> q.chunk_shift));
             uint32_t *row = s_ops[threadIdx.x];
-            const ReadView rv = read_at(cv, entry & ((1u << q.chunk_shift) - 1u), row);
+            ReadView rv;
+            if (q.cells) { // a fused pass: the read as it lies in the arrays, every op of it
+                const spl_layout_chunk ch = q.cells[entry >> q.chunk_shift];
+                const int64_t i = (ch.lo & ~(int64_t)((1u << q.chunk_shift) - 1u)) + (int64_t)(entry & ((1u << q.chunk_shift) - 1u));
+                const int32_t pos0 = q.src.pos[i];
+                const uint32_t c0 = q.src.cig_off[i], c1 = q.src.cig_off[i + 1];
+                rv.flag = q.src.flag[i];
+                rv.n_ops = c1 - c0;
+                rv.ops = q.src.cigar + c0;
+                rv.neg = pos0 < 0;
+                rv.pos = pos0 + ch.shift;
+            } else {
+                const ChunkView cv = chunk_view(p.chunk_meta + (entry >> q.chunk_shift));
+                rv = read_at(cv, entry & ((1u << q.chunk_shift) - 1u), row);
+            }
             const int32_t pos = rv.pos;
             const uint32_t flag = rv.flag;
             uint32_t n_ops = rv.n_ops;
@@ -1699,8 +1816,15 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
         const bool big = h->chunk_shift == SPL_CHUNK_BIG_SHIFT;
         *lds_out = (p->stranded ? 4 * (SPL_WIN_STRANDED + 1) : 2 * (SPL_WIN + 1)) * 4 + SPL_WAVES * SPL_WAVE_READS * 2 + 4 * SPL_WAVES + 4; // difference windows + the waves' lists
         const bool agg = (variant & 2) != 0;
-#define SPL_LAUNCH_RANGES(S, A, B) hipExtLaunchKernelGGL((spl_count_ranges_kernel<S, A, B>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h)
-        if (p->stranded) {
+#define SPL_LAUNCH_RANGES(S, A, B) hipExtLaunchKernelGGL((spl_count_ranges_kernel<S, A, B, false>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h)
+        if (h->cells) { // the fused pass: straight from the BAM-native arrays
+            if (agg) return (int)hipErrorInvalidValue;
+            *lds_out += (int)SPL_LAYOUT_SLOT(SPL_TILE_FUSED) + 2 * SPL_TILE_FUSED + (SPL_BLOCK_FUSED / 64) * SPL_WAVE_READS_FUSED * 2 - SPL_WAVES * SPL_WAVE_READS * 2;
+            if (p->stranded) return (int)hipErrorInvalidValue; // (spl_count_launch lays a fused set out before a stranded pass)
+#define SPL_LAUNCH_FUSED(B) hipExtLaunchKernelGGL((spl_count_ranges_kernel<false, false, B, true>), dim3(grid), dim3(SPL_BLOCK_FUSED), 0, st, e0, e1, 0, *h)
+            if (big) SPL_LAUNCH_FUSED(true); else SPL_LAUNCH_FUSED(false);
+#undef SPL_LAUNCH_FUSED
+        } else if (p->stranded) {
             if (agg) { if (big) SPL_LAUNCH_RANGES(true, true, true); else SPL_LAUNCH_RANGES(true, true, false); }
             else { if (big) SPL_LAUNCH_RANGES(true, false, true); else SPL_LAUNCH_RANGES(true, false, false); }
         } else {

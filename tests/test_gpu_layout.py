@@ -1,8 +1,10 @@
-"""The layout kernel (spliser_amd/csrc/spl_devpack.hip): BAM-native arrays resident on the device -> the chunked, class-partitioned
-records of spl_pack.h, one launch per read set, every read classified once -- held to the oracle through the counting kernels
-(SpliSER_v0_1_8.py:408-559 is what both restate), on reads made to cross every boundary the kernel has: threads of four reads,
-waves, chunks (cells of the grid over the arrays' indexes), segments that begin anywhere, CIGAR stretches longer than the
-workgroup's stage in LDS."""
+"""BAM-native arrays resident on the device -> counters, both ways the library has: the layout kernel
+(spliser_amd/csrc/spl_devpack.hip: the chunked, class-partitioned records of spl_pack.h in memory, one launch per read set, every
+read classified once) followed by the range kernel, and the FUSED range kernel (spl_kernels.hip: an unstranded pass over a read
+set whose segments lie in one set of arrays makes a tile's records in LDS and counts them there; SPL_FUSED=0 turns it off) -- held
+to the oracle (SpliSER_v0_1_8.py:408-559 is what all restate), on reads made to cross every boundary the kernels have: threads of
+four reads, waves, tiles, chunks (cells of the grid over the arrays' indexes), segments that begin anywhere, CIGAR stretches longer
+than the workgroup's stage in LDS."""
 import numpy as np
 import pytest
 
@@ -59,11 +61,17 @@ def _count_soa(ctx, arr, segments, stranded, combine=0, expected=0):
 @pytest.mark.parametrize("seed", range(0, 12))
 @pytest.mark.parametrize("stranded", [0, 1, 2])
 @pytest.mark.parametrize("chunk", ["2048", "4096"])
-def test_layout_kernel_counts_like_the_oracle(seed, stranded, chunk, ctx, oracle_lib, monkeypatch):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_layout_kernel_counts_like_the_oracle(seed, stranded, chunk, fused, ctx, oracle_lib, monkeypatch):
+    """fused = 1 (the default): an unstranded pass is the fused kernel's; a stranded one lays the set out first (the layout kernel, then
+    the range kernel).  fused = 0: layout + range whatever the pass."""
     arr, rs = randcase.make_case(seed + 900, bool(stranded))
     if arr.n == 0 or rs.n == 0:
         pytest.skip("empty case")
+    if fused == "0" and stranded:
+        pytest.skip("the same path as fused = 1: a stranded pass is never fused")
     monkeypatch.setenv("SPL_FORCE_CHUNK", chunk)
+    monkeypatch.setenv("SPL_FUSED", fused)
     big = _repeat(rs, 67)
     ocount, _ = helpers.oracle_engine(oracle_lib)
     want = ocount(arr, big, stranded, 0)
@@ -92,16 +100,19 @@ def test_segments_that_begin_anywhere(seed, combine, ctx, oracle_lib, monkeypatc
     segs.insert(2, samio.ReadSet.empty())
     ocount, _ = helpers.oracle_engine(oracle_lib)
     want = ocount(arr, big, 0, combine)
-    for chunk in ("2048", "4096"):
+    for chunk, fused in (("2048", "1"), ("4096", "1"), ("2048", "0"), ("4096", "0")):
         monkeypatch.setenv("SPL_FORCE_CHUNK", chunk)
+        monkeypatch.setenv("SPL_FUSED", fused)
         got = _count_soa(ctx, arr, [(s, 0) for s in segs], 0, combine)
         for w, g in zip(want, got):
             assert np.array_equal(w, g)
 
 
-def test_cigars_longer_than_the_stage(ctx, oracle_lib):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_cigars_longer_than_the_stage(fused, ctx, oracle_lib, monkeypatch):
     """Long-read CIGARs: hundreds of ops a read, so that a chunk's ops are many times the 4 ops a read the workgroup stages in
     LDS -- ops beyond the stage come from memory, WIDE reads' ops are read by the counting kernels from the array they came in."""
+    monkeypatch.setenv("SPL_FUSED", fused)
     arr, _ = randcase.make_case(977, False)
     rng = np.random.default_rng(5)
     lo, hi = int(arr.pos.min()) - 50, int(arr.pos.max()) + 50
@@ -195,3 +206,47 @@ def test_two_read_sets_laid_out_again_and_counted_in_turn(ctx, oracle_lib):
     finally:
         for _, ds, dr, soa in shards:
             dr.free(); soa.free(); ds.free()
+
+
+def test_a_fused_read_set_is_laid_out_when_a_pass_needs_records(ctx, oracle_lib):
+    """A read set finished fused has no records in memory (spl_reads_layout_bytes: 0 written).  The pair kernel, a stranded pass and
+    spl_junctions read records: the set is laid out then, once, and counts the same before and after."""
+    arr, rs = randcase.make_case(936, False)
+    big = _repeat(rs, 97)
+    ocount, _ = helpers.oracle_engine(oracle_lib)
+    want = ocount(arr, big, 0, 0)
+    want_fr = ocount(arr, big, 1, 0)
+    with ctx.upload_soa([_arrays(big)]) as soa, ctx.upload_sites(native.SiteArrays.from_chrom(arr)) as ds:
+        dr = ctx.layout_read_segments(soa, [0])
+        try:
+            read, written = dr.layout_bytes()
+            assert read == 10 * big.n + 4 * len(big.cigar) and written == 0
+            ctx.count_launch(ds, dr, 0, 0)
+            for w, g in zip(want, ds.counters()):
+                assert np.array_equal(w, g)
+            assert dr.layout_bytes()[1] == 0                      # (still fused)
+            ctx.count_launch(ds, dr, 1, 0)                        # a stranded pass
+            for w, g in zip(want_fr, ds.counters()):
+                assert np.array_equal(w, g)
+            assert dr.layout_bytes()[1] > 0                       # (records in memory now)
+            ctx.count_launch(ds, dr, 0, 0)                        # ... and the unstranded pass over them
+            for w, g in zip(want, ds.counters()):
+                assert np.array_equal(w, g)
+        finally:
+            dr.free()
+        dr = ctx.layout_read_segments(soa, [0])
+        try:
+            ctx.count_launch(ds, dr, 0, 0, native.OPT_PAIR_KERNEL)   # the literal (read, site) kernel reads records
+            for w, g in zip(want, ds.counters()):
+                assert np.array_equal(w, g)
+            assert dr.layout_bytes()[1] > 0
+        finally:
+            dr.free()
+        dr = ctx.layout_read_segments(soa, [0])
+        fused_junctions = dr.junctions()
+        dr.free()
+    with ctx.upload_reads(_arrays(big)) as packed:
+        host_junctions = packed.junctions()
+    assert len(host_junctions["left"]) > 0
+    for k in host_junctions:
+        assert np.array_equal(fused_junctions[k], host_junctions[k]), k

@@ -14,11 +14,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, args = sys.argv[1], sys.argv[2:]
 
 
-def mean(counter, sub, kernel="spl_count_ranges_kernel"):
+def is_fused(name):   # spl_count_ranges_kernel<STRANDED, AGG, BIG, FUSED>
+    return "spl_count_ranges_kernel" in name and name.rstrip().rstrip(">").rstrip().endswith("true") and name.count(",") == 3
+
+
+def mean(counter, sub, kernel="spl_count_ranges_kernel", fused=None):
     vals = collections.defaultdict(list)
     for path in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, sub), "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] == counter and kernel in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and kernel in r["Kernel_Name"] and (fused is None or is_fused(r["Kernel_Name"]) == fused):
                 vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     if not vals:
         return None, 0
@@ -29,8 +33,13 @@ def mean(counter, sub, kernel="spl_count_ranges_kernel"):
     return sum(every) / len(every), len(every)
 
 
-fetch, n = mean("FETCH_SIZE", "fetch")
-write, _ = mean("WRITE_SIZE", "write")
+# a fused pass (the range kernel reads the BAM-native arrays itself): its launches are the step's; the launches of the two-kernel
+# comparison leg of the same bench.py run (layout + range, records in memory) are reported beside them
+fetch, n = mean("FETCH_SIZE", "fetch", fused=True)
+FUSED = fetch is not None
+if not FUSED:
+    fetch, n = mean("FETCH_SIZE", "fetch")
+write, _ = mean("WRITE_SIZE", "write", fused=True if FUSED else None)
 h = hashlib.sha256(open(os.path.join(ROOT, "spliser_amd", "libspliser_hip.so"), "rb").read()).hexdigest()[:16]
 import re
 
@@ -42,7 +51,7 @@ def strip_source(text):   # (= bench.py strip_source: comments and white space d
 
 
 kh = hashlib.sha256()
-for name in ("spl_kernels.hip", "spl_device.h", "spl_pack.h", "spl_classify.h", "spl_pack.cpp", "spl_devpack.hip", "spl_devpack.h"):   # (= bench.py KERNEL_SOURCES)
+for name in ("spl_kernels.hip", "spl_device.h", "spl_pack.h", "spl_classify.h", "spl_pack.cpp", "spl_devpack.hip", "spl_devpack.h", "spl_layout_tile.h"):   # (= bench.py KERNEL_SOURCES)
     kh.update(strip_source(open(os.path.join(ROOT, "spliser_amd", "csrc", name), "rb").read().decode("utf-8", "replace")).encode("utf-8"))
 workload = args[args.index("--workload") + 1] if "--workload" in args else "human"
 out = {"workload": workload, "bench_args": args, "lib_sha16": h, "kernel_src_sha16": kh.hexdigest()[:16], "kernel": "spl_count_ranges_kernel", "dispatches": n,
@@ -51,7 +60,15 @@ out = {"workload": workload, "bench_args": args, "lib_sha16": h, "kernel_src_sha
        "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read (MI355X_MICROARCH.md, HBM): x 2 for the "
                      "record stream; this kernel's mix of 8 / 16 / 24-byte record loads and 8-byte gathers was calibrated at 1.927 on a "
                      "stream of known size (profiles/r01e_traffic.json), which is what is applied; WRITE_SIZE is exact",
-       "hbm_bytes_per_launch": None if fetch is None else int(fetch * 1024 * 1.927 + (write or 0) * 1024)}
+       "hbm_bytes_per_launch": None if fetch is None else int(fetch * 1024 * (2.0 if FUSED else 1.927) + (write or 0) * 1024)}
+if FUSED:
+    out["kernel"] = "spl_count_ranges_kernel<FUSED>"
+    out["correction"] = ("FETCH_SIZE x 2 (the fused pass reads the BAM-native arrays with 16-byte coalesced loads, as the layout kernel does: "
+                         "MI355X_MICROARCH.md, HBM; its 8 / 12-byte index gathers are a few per cent of the bytes), WRITE_SIZE as it is")
+    rf, rn = mean("FETCH_SIZE", "fetch", fused=False)
+    rw, _ = mean("WRITE_SIZE", "write", fused=False)
+    out["two_kernels_range"] = {"kernel": "spl_count_ranges_kernel (records in memory: the comparison leg)", "dispatches": rn, "FETCH_SIZE_KB": rf, "WRITE_SIZE_KB": rw,
+                                "hbm_bytes_per_launch": None if rf is None else int(rf * 1024 * 1.927 + (rw or 0) * 1024)}
 # the layout kernel of the same step: 16-byte coalesced loads throughout (the guide's x 2 for FETCH_SIZE), 8 / 16-byte stores
 lf, ln = mean("FETCH_SIZE", "fetch", "spl_layout_kernel")
 lw, _ = mean("WRITE_SIZE", "write", "spl_layout_kernel")
