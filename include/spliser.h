@@ -181,9 +181,13 @@ void spl_reads_free(spl_ctx *ctx, spl_dreads *dr);
 /* BAM-native reads RESIDENT IN HBM, as the arrays they are (what checkBam reads from a SAM line, SpliSER_v0_1_8.py:434-437, and
  * nothing else): n_seg host segments laid end to end in device arrays pos / flag / cig_off / cigar -- what a decode on the
  * device leaves (spl_bam_decode_device) and what SURVEY.md 8(d)'s "kernel-only from device-resident SoA" starts from.  A read
- * set is laid out from them ON THE DEVICE (spl_devpack.hip: one kernel, every read fetched and classified once) by
- * spl_reads_add_soa + spl_reads_finish; spl_reads_relayout runs that layout again into the same records (bench.py's step:
- * arrays -> records -> counters, every step).  The handle may be freed while read sets made from it live (they share the arrays). */
+ * set is made from them ON THE DEVICE by spl_reads_add_soa + spl_reads_finish.  A set whose segments all lie in ONE such handle
+ * stays arrays ("fused"): an unstranded spl_count_launch reads them itself and makes its records in LDS (spl_kernels.hip, the
+ * FUSED range kernel) -- no records in memory, no layout launch; a pass that needs records (stranded, the pair kernel,
+ * spl_junctions), a set of several handles or with host-packed segments, or SPL_FUSED=0, gets them from the layout kernel
+ * (spl_devpack.hip: one launch, every read fetched and classified once).  spl_reads_relayout does again what spl_reads_finish
+ * launched -- the chunks' descriptors and order, and the layout kernel where the set has records -- so that a bench.py step is
+ * arrays -> counters, every step.  The handle may be freed while read sets made from it live (they share the arrays). */
 typedef struct spl_dsoa spl_dsoa;
 int spl_soa_upload(spl_ctx *ctx, int n_seg, const spl_reads *segs, spl_dsoa **out);
 /* ... with max_end[k] = the last base (1-based) any read of segment k covers, where the caller knows it (null, or < 0: computed) */
@@ -191,7 +195,8 @@ int spl_soa_upload2(spl_ctx *ctx, int n_seg, const spl_reads *segs, const int64_
 void spl_soa_free(spl_ctx *ctx, spl_dsoa *soa);
 int spl_reads_add_soa(spl_ctx *ctx, spl_dreads *dr, spl_dsoa *soa, int seg, int32_t pos_shift);
 int spl_reads_relayout(spl_ctx *ctx, spl_dreads *dr);
-/* What the layout moves for a finished read set: the BAM-native arrays read (10 bytes a read + 4 an op) and the records written. */
+/* What the layout moves for a finished read set: the BAM-native arrays read (10 bytes a read + 4 an op) and the records written
+ * (0 while the set is fused). */
 int spl_reads_layout_bytes(spl_ctx *ctx, const spl_dreads *dr, int64_t *soa_bytes_out, int64_t *record_bytes_out);
 /* ... and the durations of the layout kernel's launches since spl_kernel_timing_begin (call before spl_kernel_timing_collect) */
 int spl_layout_timing_collect(spl_ctx *ctx, float *ms_out, int capacity, int *n_out);

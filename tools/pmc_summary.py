@@ -13,4 +13,4 @@ for d in sys.argv[1:]:
         for k, cs in agg.items():
             if "spl_" not in k:
                 continue
-            print(k.split("(")[0][:48], {c: round(sum(v) / len(v)) for c, v in sorted(cs.items())}, "n=%d" % len(next(iter(cs.values()))))
+            print(k.split("(")[0][:64], {c: round(sum(v) / len(v)) for c, v in sorted(cs.items())}, "n=%d" % len(next(iter(cs.values()))))

@@ -8,14 +8,17 @@ import glob
 import hashlib
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, args = sys.argv[1], sys.argv[2:]
 
 
-def is_fused(name):   # spl_count_ranges_kernel<STRANDED, AGG, BIG, FUSED>
-    return "spl_count_ranges_kernel" in name and name.rstrip().rstrip(">").rstrip().endswith("true") and name.count(",") == 3
+def is_fused(name):   # void spl_count_ranges_kernel<STRANDED, AGG, BIG, FUSED>(spl_hot_params)
+    m = re.search(r"spl_count_ranges_kernel<([^>]*)>", name)
+    a = [x.strip() for x in m.group(1).split(",")] if m else []
+    return len(a) == 4 and a[3] == "true"
 
 
 def mean(counter, sub, kernel="spl_count_ranges_kernel", fused=None):
