@@ -849,7 +849,7 @@ def main():
     info = ctx.launch_info()
     # (c) a fused pass (no records in memory: layout_bytes says 0 written) beside what it replaced: the same shards as read sets
     # with records in memory (SPL_FUSED=0), every step the layout kernel and the range kernel -- rounds 1-5's two kernels
-    fused = all(b == 0 for _, b in layout_bytes) and args.kernel == "ranges" and not scode
+    fused = all(b == 0 for _, b in layout_bytes) and args.kernel == "ranges"
     two_kernels = None
     if fused:
         os.environ["SPL_FUSED"] = "0"

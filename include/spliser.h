@@ -182,8 +182,8 @@ void spl_reads_free(spl_ctx *ctx, spl_dreads *dr);
  * nothing else): n_seg host segments laid end to end in device arrays pos / flag / cig_off / cigar -- what a decode on the
  * device leaves (spl_bam_decode_device) and what SURVEY.md 8(d)'s "kernel-only from device-resident SoA" starts from.  A read
  * set is made from them ON THE DEVICE by spl_reads_add_soa + spl_reads_finish.  A set whose segments all lie in ONE such handle
- * stays arrays ("fused"): an unstranded spl_count_launch reads them itself and makes its records in LDS (spl_kernels.hip, the
- * FUSED range kernel) -- no records in memory, no layout launch; a pass that needs records (stranded, the pair kernel,
+ * stays arrays ("fused"): spl_count_launch reads them itself and makes its records in LDS (spl_kernels.hip, the FUSED range
+ * kernel) -- no records in memory, no layout launch; what needs records (the pair kernel, the merging variant,
  * spl_junctions), a set of several handles or with host-packed segments, or SPL_FUSED=0, gets them from the layout kernel
  * (spl_devpack.hip: one launch, every read fetched and classified once).  spl_reads_relayout does again what spl_reads_finish
  * launched -- the chunks' descriptors and order, and the layout kernel where the set has records -- so that a bench.py step is

@@ -2578,10 +2578,7 @@ extern "C" int spl_count_launch(spl_ctx *c, spl_dsites *ds, const spl_dreads *dr
     } else if (int rc0 = spl_dev_launch_clear(ds->beta1, ds->counter_bytes, c->stream)) // (in place: the copy in use)
         return spl_set_error(SPL_ERR_HIP, "clear kernel launch: %s", hipGetErrorString((hipError_t)rc0));
     if (!dr->finished) return spl_set_error(SPL_ERR_ARG, "spl_count_launch: the read set is not finished (spl_reads_finish)");
-    // The fused pass is the unstranded range kernel's: a stranded pass has four difference windows, not two, and with the tile's
-    // records beside them three workgroups fit a CU, not four -- measured slower than layout + range (mouse, 100 M reads: 1.37 ms a
-    // step against 1.20); the pair kernel and the merging variant read records.  Such a pass lays the set out first, once.
-    if (dr->fused && (variant != 0 || o->stranded)) { const int rc0 = unfuse(c, const_cast<spl_dreads *>(dr)); if (rc0) return rc0; }
+    if (dr->fused && variant != 0) { const int rc0 = unfuse(c, const_cast<spl_dreads *>(dr)); if (rc0) return rc0; } // (the pair kernel and the merging variant read records)
     uint32_t *const queue = dr->queue_turn ? dr->queue_alt : dr->queue;
     dr->queue_turn ^= 1;
     dr->queued_pass = false;

@@ -40,6 +40,7 @@
 #define SPL_WAVE_READS_FUSED 512         // a wave's list entries there (4 workgroups of 39 KB on a CU)
 #define SPL_WIN 1020                     // distinct site positions a workgroup privatises in LDS (pair kernel; range kernel unstranded)
 #define SPL_WIN_STRANDED 956             // ... range kernel, stranded: 4 windows + the lists, 8 workgroups in 160 KB
+#define SPL_WIN_STRANDED_FUSED 508       // ... the fused pass, stranded: 4 windows of 2 KB beside a tile's records, 4 workgroups in 160 KB
 #define SPL_SERIAL_MAX 8                 // pair kernel: sites a lane classifies alone before the wave takes over
 #ifndef SPL_AGG_ROUNDS
 #define SPL_AGG_ROUNDS 2                 // distinct addresses agg_add merges across the wave before it falls back to plain atomics

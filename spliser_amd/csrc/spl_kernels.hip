@@ -446,7 +446,7 @@ typedef __attribute__((address_space(3))) int32_t spl_lds_i32; // the difference
 // All 64 lanes call this together.  Lanes that add `sign` to the same key = (dpos << 2 | array) and sit next to each
 // other form a run; the first lane of each run adds sign * run-length once.  (Equal keys that are NOT adjacent make
 // several runs: still correct, just more atomics -- that only happens for unsorted input.)
-template <int NARR, bool AGG>
+template <int NARR, bool AGG, int WIN = (NARR == 4 ? SPL_WIN_STRANDED : SPL_WIN)>
 __device__ __forceinline__ void commit_key(const spl_hot_params &p, spl_lds_i32 *lds, int32_t wbase, bool valid, uint32_t key, int32_t sign)
 {
     int32_t amount = sign;
@@ -465,7 +465,6 @@ __device__ __forceinline__ void commit_key(const spl_hot_params &p, spl_lds_i32 
         go = head;
     }
     if (go) {
-        constexpr int WIN = NARR == 4 ? SPL_WIN_STRANDED : SPL_WIN;
         const int arr = (int)(key & 3u);
         const int32_t d = (int32_t)(key >> 2);
         const uint32_t loc = (uint32_t)(d - wbase);
@@ -517,7 +516,7 @@ __device__ __forceinline__ uint32_t junction_hash(int32_t l, int32_t r)
 
 // (ent, first) = the two quads of slot h & mask, already loaded by the caller -- who may have asked for several reads' slots in
 // one trip -- further probes and further rival records are fetched here.
-template <bool STRANDED, int NARR>
+template <bool STRANDED, int NARR, int WIN = (NARR == 4 ? SPL_WIN_STRANDED : SPL_WIN)>
 __device__ __forceinline__ bool rivals_inline_from(const spl_hot_params &p, spl_lds_i32 *lds, int32_t wbase, int32_t l, int32_t r, uint32_t h,
                                                    uint4 ent, uint4 first, const int32_t *blk_a, const int32_t *blk_b, uint32_t sidx)
 {
@@ -542,17 +541,17 @@ __device__ __forceinline__ bool rivals_inline_from(const spl_hot_params &p, spl_
         if (STRANDED && ((rv.y >> 30) != (sidx ? 2u : 1u))) continue; // strand_ok false: the ranges added nothing
         const uint32_t a_b1 = sidx, a_me = (STRANDED ? 2u : 1u) + sidx;
         if (t > l && t < r) { // flanking: not counted by `process` (:529-536)
-            commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_me, -1);
-            commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, 1);
+            commit_key<NARR, false, WIN>(p, lds, wbase, true, (td << 2) | a_me, -1);
+            commit_key<NARR, false, WIN>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, 1);
         } else {
             bool cov = false;
 #pragma unroll
             for (int j = 0; j < 2; ++j) cov |= (blk_a[j] <= t) && (t + 1 <= blk_b[j]);
             if (cov) { // beta1-type (:544-556)
-                commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_b1, -1);
-                commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_b1, 1);
-                commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_me, 1);
-                commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, -1);
+                commit_key<NARR, false, WIN>(p, lds, wbase, true, (td << 2) | a_b1, -1);
+                commit_key<NARR, false, WIN>(p, lds, wbase, true, ((td + 1u) << 2) | a_b1, 1);
+                commit_key<NARR, false, WIN>(p, lds, wbase, true, (td << 2) | a_me, 1);
+                commit_key<NARR, false, WIN>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, -1);
                 if (rv.z != 0xffffffffu) agg_add(&p.dbl[rv.z & 0x7fffffffu], 1);
                 if (rv.w != 0xffffffffu) agg_add(&p.dbl[rv.w], 1);
             }
@@ -571,7 +570,7 @@ __device__ __forceinline__ bool rivals_inline_from(const spl_hot_params &p, spl_
 // "inside that or a later intron", alpha reads and beta1-type reads take double counts on the rival's edges to any junction end
 // of the read except the partner used).  flagged[j]: an end of junction j carries a rival bit -- such a junction must be in
 // the table, or the read is the literal kernel's.  Point updates go to the LDS difference windows.
-template <bool STRANDED, int NARR>
+template <bool STRANDED, int NARR, int WIN = (NARR == 4 ? SPL_WIN_STRANDED : SPL_WIN)>
 __device__ __forceinline__ bool rivals_inline2(const spl_hot_params &p, spl_lds_i32 *lds, int32_t wbase, const int32_t (&jl)[2],
                                                const int32_t (&jr)[2], const bool (&flagged)[2], const int32_t (&blk_a)[3],
                                                const int32_t (&blk_b)[3], uint32_t sidx)
@@ -642,14 +641,14 @@ __device__ __forceinline__ bool rivals_inline2(const spl_hot_params &p, spl_lds_
                     if (is_end && !(alpha && pp == pu)) agg_add(&p.dbl[rx.y + e2], 1);
                 }
                 if (beta1type) {
-                    commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_b1, -1);
-                    commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_b1, 1);
-                    commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_me, 1);
-                    commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, -1);
+                    commit_key<NARR, false, WIN>(p, lds, wbase, true, (td << 2) | a_b1, -1);
+                    commit_key<NARR, false, WIN>(p, lds, wbase, true, ((td + 1u) << 2) | a_b1, 1);
+                    commit_key<NARR, false, WIN>(p, lds, wbase, true, (td << 2) | a_me, 1);
+                    commit_key<NARR, false, WIN>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, -1);
                 }
             } else if (inside >= j && strand_ok) { // flanking: the ME range counted it, `process` does not
-                commit_key<NARR, false>(p, lds, wbase, true, (td << 2) | a_me, -1);
-                commit_key<NARR, false>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, 1);
+                commit_key<NARR, false, WIN>(p, lds, wbase, true, (td << 2) | a_me, -1);
+                commit_key<NARR, false, WIN>(p, lds, wbase, true, ((td + 1u) << 2) | a_me, 1);
             }
         }
     }
@@ -677,8 +676,9 @@ __device__ __forceinline__ bool rivals_inline2(const spl_hot_params &p, spl_lds_
 // classification, ranks by prefix sums) but into LDS, where the ops were, and counts them from there with the code below: the
 // records -- 12.7 bytes a read written and read again, beside 18.7 of arrays -- never go to memory, and there is no layout
 // launch.  The difference windows, the lists' front parts and the window's base belong to the chunk, not the tile.  39 KB of
-// LDS, 96 VGPRs: four workgroups a CU.  Unstranded passes only (four windows leave room for three workgroups: slower than layout +
-// range); a queue entry names its read by its place in the arrays (s_idx), which is where the literal kernel then reads it.
+// LDS, 96 VGPRs: four workgroups a CU -- a stranded pass with windows of 508 distinct positions instead of 956 (with 956, three
+// workgroups a CU: slower than layout + range; what lies outside a window goes to the global arrays either way).  A queue entry
+// names its read by its place in the arrays (s_idx), which is where the literal kernel then reads it.
 // Measured (human-scale, 100 M reads a launch): 0.94-0.98 ms against 0.655-0.67 + 0.375-0.39 for layout + range.  Asking for the next
 // tile's reads before this tile is counted gained nothing (a wave's memory operations return in order: the first bucket entry
 // waits for them), 512 threads -- two reads each, eight waves counting a tile -- took 1.25 ms: profiles/r05X_fused_pass.txt.
@@ -690,7 +690,7 @@ template <bool STRANDED, bool AGG, bool BIG, bool FUSED>
 __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__((amdgpu_waves_per_eu(FUSED || AGG ? 4 : 8, 8))) void spl_count_ranges_kernel(const spl_hot_params p)
 {
     constexpr int NARR = STRANDED ? 4 : 2; // {beta1, ME} x {read strand +, -}
-    constexpr int WIN = STRANDED ? SPL_WIN_STRANDED : SPL_WIN;
+    constexpr int WIN = STRANDED ? (FUSED ? SPL_WIN_STRANDED_FUSED : SPL_WIN_STRANDED) : SPL_WIN;
     __shared__ int32_t lds_words[NARR * (WIN + 1)];
     spl_lds_i32 *const lds = (spl_lds_i32 *)lds_words;
     // Each wave owns one segment of s_q (as many entries as it can have reads) with two lists of chunk-relative slots:
@@ -926,8 +926,8 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
                 uint32_t arr = 0;
                 if (STRANDED) arr = (spl_read_strand(w[2 * j + 1] & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
                 if (__any(emit)) {
-                    commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
-                    commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)ub << 2) | arr, -1);
+                    commit_key<NARR, AGG, WIN>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
+                    commit_key<NARR, AGG, WIN>(p, lds, wbase, emit, ((uint32_t)ub << 2) | arr, -1);
                 }
             }
         }
@@ -961,8 +961,8 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
                     const int32_t lo = ua + (int32_t)nva;
                     const bool em = alive && ub > lo;
                     if (__any(em)) {
-                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | arr, 1);
-                        commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | arr, -1);
+                        commit_key<NARR, AGG, WIN>(p, lds, wbase, em, ((uint32_t)lo << 2) | arr, 1);
+                        commit_key<NARR, AGG, WIN>(p, lds, wbase, em, ((uint32_t)ub << 2) | arr, -1);
                     }
                     ua = ub; nva = nvb;
                 };
@@ -1008,8 +1008,8 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
                 const int32_t lo = ua + (int32_t)nva;
                 const bool em = alive && ub > lo;
                 if (__any(em)) {
-                    commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)lo << 2) | arr, 1);
-                    commit_key<NARR, AGG>(p, lds, wbase, em, ((uint32_t)ub << 2) | arr, -1);
+                    commit_key<NARR, AGG, WIN>(p, lds, wbase, em, ((uint32_t)lo << 2) | arr, 1);
+                    commit_key<NARR, AGG, WIN>(p, lds, wbase, em, ((uint32_t)ub << 2) | arr, -1);
                 }
                 ua = ub; nva = nvb;
             };
@@ -1096,8 +1096,8 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
                     // junction ends: lSite is the previous boundary's position, rSite this one's
                     rival |= (kk == 2u) & ((prv | rv) != 0u);
                     if (__any(emit)) {
-                        commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
-                        commit_key<NARR, AGG>(p, lds, wbase, emit, ((uint32_t)u << 2) | arr, -1);
+                        commit_key<NARR, AGG, WIN>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
+                        commit_key<NARR, AGG, WIN>(p, lds, wbase, emit, ((uint32_t)u << 2) | arr, -1);
                     }
                     if (kk) { pu = u; pnv = nv; prv = rv; }
                 }
@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
                 const int32_t jl[2] = {c0 - 1, c2 - 1}, jr[2] = {c1 - 1, c3 - 1};
                 const bool jf[2] = {((entry >> 14) & 1u) != 0u, (entry >> 15) != 0u};
                 const int32_t blk_a[3] = {pos, c1, c3}, blk_b[3] = {c0 - 1, c2 - 1, c4 - 1};
-                undecided = !rivals_inline2<STRANDED, NARR>(p, lds, wbase, jl, jr, jf, blk_a, blk_b, sidx);
+                undecided = !rivals_inline2<STRANDED, NARR, WIN>(p, lds, wbase, jl, jr, jf, blk_a, blk_b, sidx);
             }
             back_done = r0 + 64u < n_m2 ? r0 + 64u : n_m2;
             if (__any(undecided)) push_front(undecided, slot);
@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
                     uint32_t sidx = 0;
                     if (STRANDED) sidx = (spl_read_strand(w[4 * k + 1] & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
                     const int32_t blk_a[2] = {pos[k], c1[k]}, blk_b[2] = {c0[k] - 1, c2[k] - 1};
-                    if (live[k]) undecided[k] = !rivals_inline_from<STRANDED, NARR>(p, lds, wbase, c0[k] - 1, c1[k] - 1, h[k], ent[k], first[k], blk_a, blk_b, sidx);
+                    if (live[k]) undecided[k] = !rivals_inline_from<STRANDED, NARR, WIN>(p, lds, wbase, c0[k] - 1, c1[k] - 1, h[k], ent[k], first[k], blk_a, blk_b, sidx);
                 }
 #pragma unroll
                 for (uint32_t k = 0; k < KM; ++k)
@@ -1814,15 +1814,15 @@ extern "C" int spl_dev_launch_count(const spl_count_params *p, const spl_hot_par
         else hipExtLaunchKernelGGL(spl_count_pairs_kernel<false>, dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *p);
     } else {
         const bool big = h->chunk_shift == SPL_CHUNK_BIG_SHIFT;
-        *lds_out = (p->stranded ? 4 * (SPL_WIN_STRANDED + 1) : 2 * (SPL_WIN + 1)) * 4 + SPL_WAVES * SPL_WAVE_READS * 2 + 4 * SPL_WAVES + 4; // difference windows + the waves' lists
+        *lds_out = (p->stranded ? 4 * ((h->cells ? SPL_WIN_STRANDED_FUSED : SPL_WIN_STRANDED) + 1) : 2 * (SPL_WIN + 1)) * 4 + SPL_WAVES * SPL_WAVE_READS * 2 + 4 * SPL_WAVES + 4; // difference windows + the waves' lists
         const bool agg = (variant & 2) != 0;
 #define SPL_LAUNCH_RANGES(S, A, B) hipExtLaunchKernelGGL((spl_count_ranges_kernel<S, A, B, false>), dim3(grid), dim3(SPL_BLOCK), 0, st, e0, e1, 0, *h)
         if (h->cells) { // the fused pass: straight from the BAM-native arrays
             if (agg) return (int)hipErrorInvalidValue;
             *lds_out += (int)SPL_LAYOUT_SLOT(SPL_TILE_FUSED) + 2 * SPL_TILE_FUSED + (SPL_BLOCK_FUSED / 64) * SPL_WAVE_READS_FUSED * 2 - SPL_WAVES * SPL_WAVE_READS * 2;
-            if (p->stranded) return (int)hipErrorInvalidValue; // (spl_count_launch lays a fused set out before a stranded pass)
-#define SPL_LAUNCH_FUSED(B) hipExtLaunchKernelGGL((spl_count_ranges_kernel<false, false, B, true>), dim3(grid), dim3(SPL_BLOCK_FUSED), 0, st, e0, e1, 0, *h)
-            if (big) SPL_LAUNCH_FUSED(true); else SPL_LAUNCH_FUSED(false);
+#define SPL_LAUNCH_FUSED(S, B) hipExtLaunchKernelGGL((spl_count_ranges_kernel<S, false, B, true>), dim3(grid), dim3(SPL_BLOCK_FUSED), 0, st, e0, e1, 0, *h)
+            if (p->stranded) { if (big) SPL_LAUNCH_FUSED(true, true); else SPL_LAUNCH_FUSED(true, false); }
+            else { if (big) SPL_LAUNCH_FUSED(false, true); else SPL_LAUNCH_FUSED(false, false); }
 #undef SPL_LAUNCH_FUSED
         } else if (p->stranded) {
             if (agg) { if (big) SPL_LAUNCH_RANGES(true, true, true); else SPL_LAUNCH_RANGES(true, true, false); }

@@ -1,6 +1,6 @@
 """BAM-native arrays resident on the device -> counters, both ways the library has: the layout kernel
 (spliser_amd/csrc/spl_devpack.hip: the chunked, class-partitioned records of spl_pack.h in memory, one launch per read set, every
-read classified once) followed by the range kernel, and the FUSED range kernel (spl_kernels.hip: an unstranded pass over a read
+read classified once) followed by the range kernel, and the FUSED range kernel (spl_kernels.hip: a pass over a read
 set whose segments lie in one set of arrays makes a tile's records in LDS and counts them there; SPL_FUSED=0 turns it off) -- held
 to the oracle (SpliSER_v0_1_8.py:408-559 is what all restate), on reads made to cross every boundary the kernels have: threads of
 four reads, waves, tiles, chunks (cells of the grid over the arrays' indexes), segments that begin anywhere, CIGAR stretches longer
@@ -63,13 +63,10 @@ def _count_soa(ctx, arr, segments, stranded, combine=0, expected=0):
 @pytest.mark.parametrize("chunk", ["2048", "4096"])
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_layout_kernel_counts_like_the_oracle(seed, stranded, chunk, fused, ctx, oracle_lib, monkeypatch):
-    """fused = 1 (the default): an unstranded pass is the fused kernel's; a stranded one lays the set out first (the layout kernel, then
-    the range kernel).  fused = 0: layout + range whatever the pass."""
+    """fused = 1 (the default): the fused kernel's pass (a stranded one with its smaller windows).  fused = 0: layout + range."""
     arr, rs = randcase.make_case(seed + 900, bool(stranded))
     if arr.n == 0 or rs.n == 0:
         pytest.skip("empty case")
-    if fused == "0" and stranded:
-        pytest.skip("the same path as fused = 1: a stranded pass is never fused")
     monkeypatch.setenv("SPL_FORCE_CHUNK", chunk)
     monkeypatch.setenv("SPL_FUSED", fused)
     big = _repeat(rs, 67)
@@ -209,8 +206,8 @@ def test_two_read_sets_laid_out_again_and_counted_in_turn(ctx, oracle_lib):
 
 
 def test_a_fused_read_set_is_laid_out_when_a_pass_needs_records(ctx, oracle_lib):
-    """A read set finished fused has no records in memory (spl_reads_layout_bytes: 0 written).  The pair kernel, a stranded pass and
-    spl_junctions read records: the set is laid out then, once, and counts the same before and after."""
+    """A read set finished fused has no records in memory (spl_reads_layout_bytes: 0 written).  The pair kernel and spl_junctions
+    read records: the set is laid out then, once, and counts the same before and after."""
     arr, rs = randcase.make_case(936, False)
     big = _repeat(rs, 97)
     ocount, _ = helpers.oracle_engine(oracle_lib)
@@ -224,12 +221,15 @@ def test_a_fused_read_set_is_laid_out_when_a_pass_needs_records(ctx, oracle_lib)
             ctx.count_launch(ds, dr, 0, 0)
             for w, g in zip(want, ds.counters()):
                 assert np.array_equal(w, g)
-            assert dr.layout_bytes()[1] == 0                      # (still fused)
-            ctx.count_launch(ds, dr, 1, 0)                        # a stranded pass
+            ctx.count_launch(ds, dr, 1, 0)                        # a stranded pass: fused as well
             for w, g in zip(want_fr, ds.counters()):
                 assert np.array_equal(w, g)
+            assert dr.layout_bytes()[1] == 0                      # (still fused)
+            ctx.count_launch(ds, dr, 0, 0, native.OPT_WAVE_AGGREGATION)   # the merging variant reads records
+            for w, g in zip(want, ds.counters()):
+                assert np.array_equal(w, g)
             assert dr.layout_bytes()[1] > 0                       # (records in memory now)
-            ctx.count_launch(ds, dr, 0, 0)                        # ... and the unstranded pass over them
+            ctx.count_launch(ds, dr, 0, 0)                        # ... and the plain pass over them
             for w, g in zip(want, ds.counters()):
                 assert np.array_equal(w, g)
         finally:
