@@ -106,9 +106,13 @@ __device__ __forceinline__ void tile_issue(const spl_devreads &src, int64_t n_re
     for (int j = 0; j <= R; ++j) L.co[j] = 0;
 #pragma unroll
     for (int j = 0; j < R / 2; ++j) L.fw[j] = 0;
-    const bool mine = g + R > sp.lo && g < sp.hi; // (a partial cell's threads outside the segment load nothing)
+    // (places in the cell are 32-bit: the span's bounds relative to the cell are uniform, a thread's reads R t .. R t + R - 1)
+    const uint32_t r0 = (uint32_t)R * t, lo_r = (uint32_t)(sp.lo - sp.cell0), hi_r = (uint32_t)(sp.hi - sp.cell0);
+    const int64_t left = n_rec - sp.cell0;
+    const uint32_t rec_r = left < (int64_t)C ? (uint32_t)left : (uint32_t)C; // reads the arrays have from the cell's first on, at most C
+    const bool mine = r0 + R > lo_r && r0 < hi_r; // (a partial cell's threads outside the segment load nothing)
     if (mine) {
-        if (g + R <= n_rec) {
+        if (r0 + R <= rec_r) {
             if constexpr (R == 4) {
                 const lay_u32x4 pv = *(const lay_u32x4 *)(src.pos + g);
                 const lay_u32x2 fv = *(const lay_u32x2 *)(src.flag + g);
@@ -163,8 +167,8 @@ __device__ __forceinline__ void tile_finish(const spl_devreads &src, int64_t n_o
     static_assert(NW <= 16, "the waves' totals are summed inside one row of lanes");
     constexpr uint32_t PAD = SPL_PACK_SCAN_OPS;               // a read is classified from a stage that holds its first eight ops
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const int64_t lo = sp.lo, hi = sp.hi;
     const int64_t g = sp.cell0 + R * (int64_t)t;
+    const uint32_t r0 = (uint32_t)R * t, lo_r = (uint32_t)(sp.lo - sp.cell0), hi_r = (uint32_t)(sp.hi - sp.cell0);
     const uint32_t o_hi = sp.o_hi, seg_op0 = sp.seg_op0;
     int32_t pos[R];
     uint32_t flag[R], co[R + 1];
@@ -206,8 +210,7 @@ __device__ __forceinline__ void tile_finish(const spl_devreads &src, int64_t n_o
     uint32_t runs = 0, pend = 0; // run of read j: bits 3j .. 3j + 2 (4 = no read); pending: bit j
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const int64_t i = g + j;
-        const bool valid = i >= lo && i < hi;
+        const bool valid = r0 + (uint32_t)j >= lo_r && r0 + (uint32_t)j < hi_r;
         const uint32_t rel0 = co[j] - (uint32_t)ws;
         const bool inside = rel0 + PAD <= STAGE;
         lay_lds_u32 *o = (lay_lds_u32 *)s_ops + (inside ? rel0 : 0u);
