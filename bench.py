@@ -3,12 +3,15 @@
 
 One "step" = ONE pass of the hot path over one synthetic sample whose reads are resident in HBM as the BAM-native arrays the
 boundary takes and a decode on the device leaves -- pos, flag, cig_off, cigar: what checkBam reads from a SAM line
-(SpliSER_v0_1_8.py:434-437), SURVEY.md 8(d)'s "device-resident SoA".  For every shard of the sample: the LAYOUT kernel (arrays ->
-per-class records, every CIGAR parsed once: the first half of the per-read walk, :436-512), the range kernel (the checkBam loop,
+(SpliSER_v0_1_8.py:434-437), SURVEY.md 8(d)'s "device-resident SoA".  For every shard of the sample: the chunks' descriptors and
+order (two small kernels over the CIGAR offsets), the FUSED range kernel (it reads the arrays itself: every CIGAR parsed once
+into per-class records in LDS, the first half of the per-read walk, :436-512, and counted from there, the checkBam loop,
 :408-559), the literal kernel and the scan with findBeta2Counts + calculateSSE (:581-639).  A step ends with a device-side
 barrier: the next step's first kernel does not start before this step's last one has finished, as in a `process` run, which
-counts a read set once (``--pipelined`` drops the barrier: many samples in a row).  Rounds 1-4 timed the step from the records
-on; that figure stays in the line as ``roofline.count_only``.
+counts a read set once (``--pipelined`` drops the barrier: many samples in a row).  After the timed region the same shards are
+run the way the round timed them before the fused pass -- a LAYOUT kernel writing the records to memory, then the range kernel
+over them (``roofline.two_kernels``; SPL_FUSED=0 makes that the step) -- and, as rounds 1-4 did, from the records on
+(``roofline.count_only``).
 
 Default workload = BASELINE.json configs[2], the largest single-GPU configuration ("synthetic human-scale: 200 M reads x 300 k
 splice sites, HBM-roofline run"), synthesised from a seed (spliser_amd/synth.py) because there is no network and the reference
