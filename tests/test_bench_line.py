@@ -12,7 +12,7 @@ import bench  # noqa: E402
 
 def canned(n_legs=9, world=1):
     leg = {"workload": "human", "bam": "seq-like", "bam_bytes": 14341234567, "decode": "device", "devices": list(range(world)),
-           "wall_s": 0.43312345678, "median_wall_s": 0.4434567891, "first_call_wall_s": 0.80123456, "reads_per_sec": 461234567.891,
+           "wall_s": 0.43312345678, "median_wall_s": 0.4434567891, "first_call_wall_s": 0.80123456, "first_call_device_gb": 13.41, "reads_per_sec": 461234567.891,
            "path": {"what": "prose " * 60, "file_GBps": 33.123456789, "frac_of_pcie": 0.59123456, "pcie_peak_GBps": 56.0},
            "tsv_matches_oracle": True, "cpu_e2e": {"what": "prose " * 40, "reads_per_sec": 40912345.678},
            "what": "prose " * 200, "stages": {"a_s": 0.1, "b_s": 0.2}, "cold_cli_s": 0.7123456, "cold_cli_matches": True,
@@ -31,7 +31,9 @@ def canned(n_legs=9, world=1):
                      "range": {"kernel": "spl_count_ranges_kernel", "kernel_ms_avg": 0.4034253999590874, "launches_timed": 40,
                                "algorithmic_bytes_per_launch": 1872024685.5, "achieved": 4640.32429710635, "frac": 0.5800405371382937, "what": "prose " * 20},
                      "count_only": {"what": "prose " * 20, "ms_per_step": 0.8976789016742259, "reads_per_sec": 222796814793.11566, "path_frac": 0.5213514214293551},
-                     "range_traffic": 1493338546, "range_traffic_from": "r03P_traffic.json", "second_kernel": "spl_count_ranges_kernel",
+                     "range_traffic": 1493338546, "range_traffic_from": "r03P_traffic.json", "second_kernel": "spl_count_ranges_kernel", "fused": True,
+                     "two_kernels": {"ms_per_step": 2.3104123456, "layout_kernel_ms_avg": 0.669312345, "range_kernel_ms_avg": 0.388223456, "layout_bytes_per_launch": 3130000000.5,
+                                     "same_counters": True, "steps": 10, "what": "prose " * 30, "layout_frac": 0.58528123, "range_frac": 0.60276123, "path_frac": 0.20256123},
                      "grid": 15856, "block": 256, "lds_bytes": 17404,
                      "alone": {"kernel_ms_avg": 0.39, "frac": 0.5949139256781943, "how": "prose " * 20},
                      "path": {"what": "prose " * 20, "achieved": 4170.8, "frac": 0.5213514214293551},
@@ -78,6 +80,8 @@ def test_compact_line_is_short_and_parses():
     assert abs(d["value"] - 334710996.8159196) / 334710996.8159196 < 1e-4       # (5 significant digits)
     assert d["e2e"][0]["frac_of_pcie"] == 0.59123 and d["e2e"][0]["cpu_e2e_reads_per_sec"] == 40912000.0
     assert d["combine"]["matches_oracle"] is True
+    assert d["roofline"]["fused"] is True and d["roofline"]["two_kernels"]["same_counters"] is True
+    assert "what" not in d["roofline"]["two_kernels"] and d["e2e"][0]["first_call_device_gb"] == 13.41
 
 
 def test_compact_line_eight_ranks():
