@@ -878,7 +878,7 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
         cu0 = ld_r4(r);
         cu1 = ld_r4(r + 16u);
     };
-    if (wave < g_total) fetch(wave);
+    if constexpr (!FUSED) { if (wave < g_total) fetch(wave); }
     if constexpr (!FUSED) {
         { const int32_t fp = cv.first_pos + cv.shift; uint32_t nv; const spl_dbk e = p.dbucket[dbk_slot(p, fp - 1)]; dbk_resolve(p, fp - 1, e, wbase, nv); }
         for (int j = tid; j < NARR * (WIN + 1); j += BLOCK) lds[j] = 0;
@@ -893,10 +893,21 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
         // Straight-line up to the commits: lanes past the end of a run are masked, all loads of a trip issue back to
         // back.  Control flow is wave-uniform around every commit_key (all 64 lanes reach it).
         uint32_t g = live ? wave : g_start[SPL_RC_RUNS]; // (a workgroup without a chunk has chunk 0's descriptor and no iteration at all)
-        auto fetch_next = [&]() { fetch(g + NWAVE < g_total ? g + NWAVE : g); }; // (the last iteration asks for itself again)
+        auto fetch_next = [&]() { if constexpr (!FUSED) fetch(g + NWAVE < g_total ? g + NWAVE : g); }; // (the last iteration asks for itself again)
+        // FUSED: the records are in LDS -- nothing to ask for ahead: an iteration reads its own at its top, its run known
+        auto take = [&](uint32_t gs, uint32_t n_run, uint32_t off, uint32_t size, uint32_t per) {
+            if constexpr (FUSED) {
+                const uint32_t i0 = (((g - gs) << 6) + lane) * per;
+                cu_i0 = i0;
+                const uint32_t r = off + (i0 < n_run ? i0 : 0u) * size;
+                cu0 = ld_r4(r);
+                cu1 = ld_r4(r + 16u);
+            }
+        };
         // ---- simple reads (one aligned op, mapped, in range: the packer checked all that): two boundaries, one range,
         //      nothing else can happen.  Four of them per lane.
         for (; g < g_start[1]; g += NWAVE) {
+            take(0u, cv.start[1], 0u, SPL_REC_SIMPLE, KS);
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t n_run = cv.start[1];
@@ -934,6 +945,7 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
         // ---- once-spliced reads (aligned, N, aligned): the kinds are known, so are the arrays; three ranges
         //      and the junction-table look-up when an end of the junction has rivals.  Two of them per lane.
         for (; g < g_start[2]; g += NWAVE) {
+            take(g_start[1], cv.start[2] - cv.start[1], cv.off[1], SPL_REC_MNM, KM);
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t n_run = cv.start[2] - cv.start[1];
@@ -986,6 +998,7 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
         // ---- twice-spliced reads (aligned, N, aligned, N, aligned; the record holds the five lengths): six boundaries,
         //      five ranges.  One read per lane.
         for (; g < g_start[3]; g += NWAVE) {
+            take(g_start[2], cv.start[3] - cv.start[2], cv.off[2], SPL_REC_M2, 1u);
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t slot = cv.start[2] + i0;     // of the read in its chunk, run order
@@ -1035,6 +1048,7 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
             }
         }
         for (; g < g_total; g += NWAVE) {
+            take(g_start[3], cv.start[4] - cv.start[3], cv.off[3], SPL_REC_OTHER, 1u);
             const uint32_t i0 = cu_i0;
             const W4 r0 = cu0, r1 = cu1;
             const uint32_t slot = cv.start[3] + i0;     // of the read in its chunk, run order
