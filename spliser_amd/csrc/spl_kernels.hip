@@ -1168,13 +1168,19 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
                 cu1 = ld_r4(r + 16u);
             };
             uint32_t g2 = g_start[1] + ((wave + NWAVE - (g_start[1] % NWAVE)) % NWAVE), it2 = 0; // (the wave's first iteration of this run: its iterations are g = wave, wave + 4, ... through all runs)
-            if (g2 < g_start[2]) fetch_mnm(g2);
+            if constexpr (!FUSED) { if (g2 < g_start[2]) fetch_mnm(g2); }
             for (; g2 < g_start[2] && KM * it2 < 32u; g2 += NWAVE, ++it2) {
+                const uint32_t bits = (fm_mnm >> (KM * it2)) & ((1u << KM) - 1u);
+                if constexpr (FUSED) { // (records out of LDS: only an iteration with a marked read takes its own)
+                    if (!__any(bits != 0u)) continue;
+                    fetch_mnm(g2);
+                }
                 const uint32_t i0 = cu_i0;
                 const W4 r0 = cu0, r1 = cu1;
-                fetch_mnm(g2 + NWAVE < g_start[2] ? g2 + NWAVE : g2);
-                const uint32_t bits = (fm_mnm >> (KM * it2)) & ((1u << KM) - 1u);
-                if (!__any(bits != 0u)) continue;
+                if constexpr (!FUSED) {
+                    fetch_mnm(g2 + NWAVE < g_start[2] ? g2 + NWAVE : g2);
+                    if (!__any(bits != 0u)) continue;
+                }
                 const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
                 bool live[KM], undecided[KM];
                 int32_t pos[KM], c0[KM], c1[KM], c2[KM];
