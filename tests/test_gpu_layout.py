@@ -250,3 +250,22 @@ def test_a_fused_read_set_is_laid_out_when_a_pass_needs_records(ctx, oracle_lib)
     assert len(host_junctions["left"]) > 0
     for k in host_junctions:
         assert np.array_equal(fused_junctions[k], host_junctions[k]), k
+
+
+def test_segments_from_two_sets_of_arrays(ctx, oracle_lib):
+    """A read set whose segments lie in two handles' arrays is not fused (the fused pass reads ONE set of arrays): both are laid
+    out, each by its own launch, and counted together."""
+    arr, rs = randcase.make_case(938, False)
+    big = _repeat(rs, 61)
+    ocount, _ = helpers.oracle_engine(oracle_lib)
+    want = ocount(arr, big, 0, 0)
+    with ctx.upload_soa([_arrays(big)]) as a, ctx.upload_soa([_arrays(big)]) as b, ctx.upload_sites(native.SiteArrays.from_chrom(arr)) as ds:
+        with ctx.begin_reads() as dr:
+            dr.add_soa(a, 0, 0)
+            dr.add_soa(b, 0, 0)
+            dr.finish()
+            assert dr.layout_bytes()[1] > 0          # (records in memory: not fused)
+            ctx.count_launch(ds, dr, 0, 0)
+            got = ds.counters()
+    for w, g in zip(want, got):
+        assert np.array_equal(2 * w.astype(np.int64), g.astype(np.int64))
