@@ -256,19 +256,32 @@ int spl_bam_decode_device(spl_ctx *ctx, spl_bam *bam, int *on_device_out);
  * references: the file is marked as taken by the device decoder now, so that those waits wait instead of starting the host
  * decode.  The promise must be kept (spl_bam_decode_device) or taken back (spl_bam_start), or the waits never end. */
 int spl_bam_reserve_device(spl_bam *bam);
-/* The same decode in SHARES, one per device (replaces SpliSER_v0_1_8.py:422 per chromosome shard): a BAM
- * file is sorted by reference and its BGZF blocks are independent, so every device can take the stretch of the file where its own
- * references' records begin -- over its own PCIe link, into its own memory, no exchange.  spl_bam_share_plan cuts the file into up
- * to n_shares stretches of about equal size at reference boundaries (block directory, then a bisection that inflates one block
- * per probe on the host) and says how many it made (*n_out; fewer than asked when the file has few references);
- * spl_bam_share_range says which references share k holds (tid_lo <= tid < tid_hi; the last share also holds the records without
- * a reference).  The file is then reserved (spl_bam_reserve_device) and EVERY share decoded by a
- * spl_bam_decode_device_share call, each on the context of the device that is to count its references; the file is complete
- * when the last of them returns.  Should any share not be decodable on its device, all of them are dropped and the host threads
- * decode the file (*on_device_out = 0 from that share's call; spl_bam_decoded_on_device says how it ended). */
+/* The same decode in SHARES, one per device (replaces SpliSER_v0_1_8.py:422 for a stretch of the file): a
+ * BAM file's BGZF blocks are independent, so every device can take its own stretch -- over its own PCIe link, into its own memory,
+ * no exchange.  spl_bam_share_plan cuts the file into up to n_shares stretches of EQUAL size in file bytes, at any BGZF block: a
+ * share owns the records that begin in its blocks (the plan finds the record boundary at every cut by inflating a few blocks on
+ * the host; a share's decoder must arrive exactly at the next share's first record, or the plan is dropped), so a reference may
+ * lie in several shares.  That is what the per-site loop allows (processSites, :681-692: nothing in it needs a whole chromosome)
+ * and what checkBam's counters allow (:519-559 only ever add one per read): each device counts its stretch of a reference
+ * against the reference's whole site table, the host adds the partial beta1 / beta2s_reads / dbl arrays, and one spl_sse call
+ * runs on the sums -- still no collective.  *n_out = the shares made (fewer than asked for only when the file has fewer blocks).
+ * spl_bam_share_range: the references share k CAN hold records of (tid_lo <= tid < tid_hi; a superset by at most one at the upper
+ * end; the last share also holds the records without a reference); spl_bam_share_info: the bytes of the file its own blocks take
+ * (what the balance of the plan is judged by), the stretch [u_lo, u_hi) of the inflated stream its records begin in, and the
+ * blocks it inflates behind its own for the end of its last record.  The file is then reserved (spl_bam_reserve_device) and
+ * EVERY share decoded by a spl_bam_decode_device_share call, each on the context of the device that is to count it; the file is
+ * complete when the last of them returns.  Should any share not be decodable on its device, all of them are dropped and the host
+ * threads decode the file (*on_device_out = 0 from that share's call; spl_bam_decoded_on_device says how it ended).  Afterwards
+ * spl_bam_share_ref says what share k holds of a reference and spl_reads_add_bam_share adds exactly that to a read set on the
+ * share's device.  spl_bam_share_count_host (diagnostic, no GPU): the records of share k per reference by the host's inflate and
+ * a plain walk from u_lo that must arrive at u_hi -- per_tid[n_ref + 1], the last entry the records without a reference. */
 int spl_bam_share_plan(spl_bam *bam, int n_shares, int *n_out);
 int spl_bam_share_range(spl_bam *bam, int k, int *tid_lo_out, int *tid_hi_out);
+int spl_bam_share_info(spl_bam *bam, int k, int64_t *file_bytes_out, int64_t *u_lo_out, int64_t *u_hi_out, int64_t *tail_blocks_out);
+int spl_bam_share_count_host(spl_bam *bam, int k, int64_t *per_tid);
 int spl_bam_decode_device_share(spl_ctx *ctx, spl_bam *bam, int k, int *on_device_out);
+int spl_bam_share_ref(spl_bam *bam, int k, int tid, int64_t *n_reads_out, int64_t *max_end_out);
+int spl_reads_add_bam_share(spl_ctx *ctx, spl_dreads *dr, spl_bam *bam, int share, int tid, int32_t pos_shift);
 int spl_bam_decoded_on_device(spl_bam *bam, int *on_device_out);
 /* For whoever runs spl_bam_decode_device / _share on threads of his own and waits for the outcome elsewhere: returns when the
  * file is no longer the device decoders' to decide about -- *on_device_out = 1: its reads are on the device(s), every reference

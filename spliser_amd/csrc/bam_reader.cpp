@@ -451,6 +451,8 @@ struct RefFinal {
 struct PendingPart {
     int32_t tid = 0;
     RefReads reads;
+    int share = -1;     // reads left on a device: the share whose arrays hold them (-1: a whole-file decode's) ...
+    int64_t first = 0;  // ... and the part's first record in those arrays
 };
 
 // A BAM file being decoded (or decoded).  The decode runs on a thread of its own (which drives the inflate and parse pools);
@@ -487,10 +489,9 @@ struct spl_bam {
     bool lazy = false;
     bool fetching = false;     // somebody is copying a share's reads to the host right now (fetch_lazy)
     int (*dev_fetch)(void *, int32_t **, uint16_t **, uint32_t **, uint32_t **) = nullptr;
-    std::vector<int64_t> lazy_first;       // first record of every reference in the arrays of the share that holds it
     // what the device decoder(s) left in device memory for the device packer (spl_capi.cpp), and how to give it back: one handle
     // for a whole-file decode, one per share otherwise
-    struct DevShare { void *handle = nullptr; void (*free_fn)(void *) = nullptr; int32_t tid_lo = 0, tid_hi = 0; bool fetched = false; };
+    struct DevShare { void *handle = nullptr; void (*free_fn)(void *) = nullptr; int share = -1; bool fetched = false; };
     std::vector<DevShare> dev_shares;
     // a decode in shares (spl_bam_share_plan): the plan, and what the shares' decoders have reported so far
     std::vector<spl_bam_share> shares;
@@ -1269,12 +1270,22 @@ void spl_bam_set_device_reads(spl_bam *bam, void *handle, void (*free_fn)(void *
     std::lock_guard<std::mutex> lock(bam->mu);
     for (spl_bam::DevShare &d : bam->dev_shares) if (d.handle && d.free_fn) d.free_fn(d.handle);
     bam->dev_shares.clear();
-    if (handle) { spl_bam::DevShare d; d.handle = handle; d.free_fn = free_fn; d.tid_lo = 0; d.tid_hi = bam->n_refs + 1; bam->dev_shares.push_back(d); }
+    if (handle) { spl_bam::DevShare d; d.handle = handle; d.free_fn = free_fn; d.share = -1; bam->dev_shares.push_back(d); }
 }
 void *spl_bam_device_reads(spl_bam *bam, int tid)
 {
     std::lock_guard<std::mutex> lock(bam->mu);
-    for (const spl_bam::DevShare &d : bam->dev_shares) if (tid >= d.tid_lo && tid < d.tid_hi) return d.handle;
+    if (tid < 0 || tid >= bam->n_refs || bam->dev_shares.empty()) return nullptr;
+    if (bam->parts[(size_t)tid].empty()) return bam->dev_shares[0].handle; // (no reads: any handle says so)
+    const int share = bam->parts[(size_t)tid][0]->share;
+    for (const PendingPart *pp : bam->parts[(size_t)tid]) if (pp->share != share) return nullptr; // (in several shares: no single handle)
+    for (const spl_bam::DevShare &d : bam->dev_shares) if (d.share == share) return d.handle;
+    return nullptr;
+}
+void *spl_bam_share_reads(spl_bam *bam, int share)
+{
+    std::lock_guard<std::mutex> lock(bam->mu);
+    for (const spl_bam::DevShare &d : bam->dev_shares) if (d.share == share) return d.handle;
     return nullptr;
 }
 const uint8_t *spl_bam_image(const spl_bam *bam, size_t *fsize_out) { if (fsize_out) *fsize_out = bam->fsize; return (const uint8_t *)bam->map; }
@@ -1291,11 +1302,11 @@ int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off,
     const bool have = pos != nullptr; // (nullptr: the arrays stay on the device until somebody asks, spl_bam_set_fetch)
     if (have) { bam->slabs.push_back(pos); bam->slabs.push_back(flag); bam->slabs.push_back(cig_off); bam->slabs.push_back(cigar); }
     bam->lazy = !have;
-    bam->lazy_first.assign(ref_first, ref_first + bam->n_refs);
     for (int t = 0; t < bam->n_refs; ++t) {
         if (ref_n[t] <= 0) continue;
         PendingPart *pp = new PendingPart();
         pp->tid = t;
+        pp->first = ref_first[t];
         RefReads &r = pp->reads;
         r.n = (size_t)ref_n[t];
         if (have) {
@@ -1320,42 +1331,43 @@ int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off,
 
 // ---- a decode in shares ------------------------------------------------------------------------------------------------
 namespace {
-// The reference (records without one: n_refs) of the last record that begins in block b -- or, when none does, of the first
-// record behind it -- by inflating the block and a few behind it.  -2: cannot tell.
-int last_tid_of_block(spl_bam *bam, size_t b, void *ld, std::vector<uint8_t> &buf)
+// The first record that begins at or after the beginning of block b: where in the inflated stream (*u_out) and of which
+// reference (*tid_out; records without one: n_refs) -- by inflating the block and a few behind it.  false: cannot tell.
+// (A block's first bytes are the tail of the record before: the boundary is a GUESS, find_record_start's -- a plausible record
+// whose successors chain -- and whoever decodes the stretch in front of it must arrive exactly there, or the plan is dropped.)
+bool first_record_at(spl_bam *bam, size_t b, void *ld, std::vector<uint8_t> &buf, uint64_t *u_out, int32_t *tid_out)
 {
     const uint8_t *file = (const uint8_t *)bam->map;
     const size_t n_blocks = bam->dir.n_ready.load();
-    for (int hop = 0; hop < 64 && b < n_blocks; ++hop, ++b) {
-        const Block &blk = bam->dir.at(b);
-        if (blk.uoff + blk.isize <= bam->header_bytes) continue; // (BAM header only)
+    if (b >= n_blocks) return false;
+    const uint64_t u0 = bam->dir.at(b).uoff;
+    // enough bytes for a record that begins near the block's end and the three behind it that must chain: 6 blocks, more while
+    // nothing has been found (a record larger than a block)
+    for (size_t want = 6; want <= 96; want *= 4) {
         size_t len = 0, nb = 0;
-        for (size_t k = b; k < n_blocks && nb < 6; ++k, ++nb) len += bam->dir.at(k).isize;
+        for (size_t k = b; k < n_blocks && nb < want; ++k, ++nb) len += bam->dir.at(k).isize;
         buf.resize(len + 64);
         size_t at = 0;
         for (size_t k = b; k < b + nb; ++k) {
-            if (!inflate_block(file, bam->dir.at(k), buf.data() + at, ld)) return -2;
+            if (!inflate_block(file, bam->dir.at(k), buf.data() + at, ld)) return false;
             at += bam->dir.at(k).isize;
         }
         const uint8_t *const end = buf.data() + len;
-        const size_t u1 = blk.isize;
-        size_t start;
-        if (blk.uoff <= bam->header_bytes) start = (size_t)(bam->header_bytes - blk.uoff);
-        else start = (size_t)(find_record_start(buf.data(), end, bam->n_refs) - buf.data());
-        int last = -2;
-        size_t p = start;
-        while (p + 36 <= len) {
-            const int32_t tid = le32s(buf.data() + p + 4);
-            const uint32_t bs = le32(buf.data() + p);
-            if (bs < 32) return -2;
-            const int eff = tid < 0 || tid >= bam->n_refs ? bam->n_refs : tid;
-            if (p >= u1) { if (last == -2) last = eff; break; } // (nothing began in the block: the first record behind it)
-            last = eff;
-            p += 4 + (size_t)bs;
+        const uint8_t *c = u0 <= bam->header_bytes ? buf.data() + (size_t)(bam->header_bytes - u0) : find_record_start(buf.data(), end, bam->n_refs);
+        if (u0 <= bam->header_bytes && (size_t)(bam->header_bytes - u0) > len) return false;
+        if (c + 36 <= end) {
+            const int32_t tid = le32s(c + 4);
+            *u_out = u0 + (uint64_t)(c - buf.data());
+            *tid_out = tid < 0 || tid >= bam->n_refs ? bam->n_refs : tid;
+            return true;
         }
-        if (last != -2) return last;
+        if (b + nb >= n_blocks) { // nothing begins behind here: the end of the stream is the boundary
+            *u_out = u0 + len;
+            *tid_out = bam->n_refs;
+            return true;
+        }
     }
-    return b >= n_blocks ? bam->n_refs : -2; // (behind the last record: behind every reference)
+    return false;
 }
 } // namespace
 
@@ -1369,67 +1381,110 @@ extern "C" int spl_bam_share_plan(spl_bam *bam, int n_shares, int *n_out)
     int rc = spl_bam_walk_all(bam);
     if (rc) return rc;
     const size_t n_blocks = bam->dir.n_ready.load();
-    std::vector<spl_bam_share> plan;
     const int32_t all = bam->n_refs + 1;
-    auto whole = [&]() { plan.clear(); plan.push_back(spl_bam_share{0, n_blocks, 0, all}); };
-    whole();
-    if (n_shares > 1 && n_blocks > 8 && bam->n_refs > 1) {
+    const uint64_t stream_end = n_blocks ? bam->dir.at(n_blocks - 1).uoff + bam->dir.at(n_blocks - 1).isize : 0;
+    std::vector<size_t> cut_block{0};
+    std::vector<uint64_t> cut_u{bam->header_bytes};
+    std::vector<int32_t> cut_tid{0};
+    if (n_shares > 1 && n_blocks > 8) {
         void *ld = deflate_lib().ok ? deflate_lib().alloc() : nullptr;
         std::vector<uint8_t> buf;
-        bool ok = true;
         const bool dbg = getenv("SPL_BAM_TIMING") != nullptr;
-        auto g = [&](size_t b) { const int t = last_tid_of_block(bam, b, ld, buf); if (t == -2) ok = false; if (dbg) fprintf(stderr, "[share plan] block %zu: reference %d\n", b, t); return t; };
-        auto first_block_with = [&](int32_t tid) { // the first block b with g(b) >= tid (g does not decrease in a sorted file)
-            size_t lo = 0, hi = n_blocks; // (g(hi) >= tid: everything is below the end)
-            while (lo < hi && ok) {
-                const size_t mid = lo + (hi - lo) / 2;
-                if (g(mid) >= tid) hi = mid; else lo = mid + 1;
-            }
-            return lo;
-        };
-        std::vector<int32_t> cut_tid{0};
-        std::vector<size_t> cut_block{0};
-        for (int k = 1; k < n_shares && ok; ++k) {
-            const size_t target = (size_t)((double)bam->fsize * k / n_shares);
-            size_t lo = 0, hi = n_blocks; // the block at the target offset
+        // where the records begin in the file: the shares are equal parts of what lies behind the header's blocks
+        size_t first_rec_block = 0;
+        while (first_rec_block + 1 < n_blocks && bam->dir.at(first_rec_block + 1).uoff <= bam->header_bytes) ++first_rec_block;
+        const double byte0 = (double)bam->dir.at(first_rec_block).coff, byte1 = (double)bam->fsize;
+        for (int k = 1; k < n_shares; ++k) {
+            const size_t target = (size_t)(byte0 + (byte1 - byte0) * k / n_shares);
+            size_t lo = 0, hi = n_blocks; // the block that begins nearest to the target offset
             while (lo + 1 < hi) { const size_t mid = lo + (hi - lo) / 2; if (bam->dir.at(mid).coff <= target) lo = mid; else hi = mid; }
-            const int t = g(lo);
-            if (!ok) break;
-            // the reference there begins at or before the target, the next one behind it: the nearer of the two
-            const int32_t cands[2] = {(int32_t)t, (int32_t)t + 1};
-            int32_t best_tid = -1; size_t best_block = 0; double best_d = 0;
-            for (int32_t c : cands) {
-                if (c <= cut_tid.back() || c >= bam->n_refs) continue; // (no share of its own for the records without a reference)
-                const size_t bb = first_block_with(c);
-                if (!ok) break;
-                const double d = fabs((double)(bb < n_blocks ? bam->dir.at(bb).coff : bam->fsize) - (double)target);
-                if (best_tid < 0 || d < best_d) { best_tid = c; best_block = bb; best_d = d; }
-            }
-            if (ok && best_tid < 0 && cut_tid.back() + 1 < bam->n_refs) {
-                // both references near the target begin at or before the last cut (one reference larger than a share): the next
-                // one then, so that as many shares come out as were asked for while there are references to begin them with
-                best_tid = cut_tid.back() + 1;
-                best_block = first_block_with(best_tid);
-            }
-            if (ok && best_tid >= 0 && best_block < n_blocks && best_block > cut_block.back()) { cut_tid.push_back(best_tid); cut_block.push_back(best_block); }
+            size_t b = lo;
+            if (lo + 1 < n_blocks && bam->dir.at(lo + 1).coff - target < target - bam->dir.at(lo).coff) b = lo + 1;
+            if (b <= cut_block.back() || b <= first_rec_block || b >= n_blocks) continue; // (more shares asked for than the file has blocks to begin them with)
+            uint64_t u = 0; int32_t tid = 0;
+            if (!first_record_at(bam, b, ld, buf, &u, &tid)) { if (dbg) fprintf(stderr, "[share plan] block %zu: no record boundary found\n", b); continue; }
+            if (dbg) fprintf(stderr, "[share plan] cut %d: block %zu, first record at %llu, reference %d\n", k, b, (unsigned long long)u, tid);
+            if (u <= cut_u.back() || u >= stream_end || tid < cut_tid.back()) continue; // (nothing begins between two cuts; or a file that is not sorted: the decoders will say so)
+            cut_block.push_back(b); cut_u.push_back(u); cut_tid.push_back(tid);
         }
         if (ld) deflate_lib().free_(ld);
-        if (ok && cut_tid.size() > 1) {
-            plan.clear();
-            for (size_t k = 0; k < cut_tid.size(); ++k) {
-                const bool last = k + 1 == cut_tid.size();
-                spl_bam_share sh;
-                sh.tid_lo = cut_tid[k];
-                sh.tid_hi = last ? all : cut_tid[k + 1];
-                sh.block_lo = cut_block[k];
-                sh.block_hi = last ? n_blocks : std::min(n_blocks, cut_block[k + 1] + 1); // (the block the next reference begins in holds the last of ours)
-                plan.push_back(sh);
-            }
-        }
+    }
+    std::vector<spl_bam_share> plan;
+    for (size_t k = 0; k < cut_block.size(); ++k) {
+        const bool last = k + 1 == cut_block.size();
+        spl_bam_share sh;
+        sh.block_lo = cut_block[k];
+        sh.block_own = last ? n_blocks : cut_block[k + 1];
+        sh.u_lo = cut_u[k];
+        sh.u_hi = last ? stream_end : cut_u[k + 1];
+        sh.tid_lo = cut_tid[k];
+        sh.tid_hi = last ? all : cut_tid[k + 1] + 1;
+        size_t hi = (size_t)sh.block_own; // the blocks that hold the end of the share's last record
+        while (hi < n_blocks && bam->dir.at(hi).uoff < sh.u_hi) ++hi;
+        if (hi < n_blocks) ++hi; // (and one more: whoever looks for the boundary u_hi itself -- a last block no record begins in -- needs a record's worth of bytes behind it)
+        sh.block_hi = hi;
+        plan.push_back(sh);
     }
     std::lock_guard<std::mutex> lock(bam->mu);
     if (bam->shares.empty()) { bam->shares = plan; bam->share_results.assign(plan.size(), spl_bam::ShareResult()); }
     if (n_out) *n_out = (int)bam->shares.size();
+    return SPL_OK;
+}
+
+// What share k is: the bytes of the file its own blocks take (what its device uploads and inflates, the tail aside), and the
+// stretch of the inflated stream its records begin in.  Any output may be null.
+extern "C" int spl_bam_share_info(spl_bam *bam, int k, int64_t *file_bytes_out, int64_t *u_lo_out, int64_t *u_hi_out, int64_t *tail_blocks_out)
+{
+    if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_share_info: null argument");
+    spl_bam_share sh;
+    const int rc = spl_bam_share_get(bam, k, &sh);
+    if (rc) return rc;
+    const size_t n_blocks = bam->dir.n_ready.load();
+    const uint64_t c0 = bam->dir.at((size_t)sh.block_lo).coff, c1 = sh.block_own < n_blocks ? bam->dir.at((size_t)sh.block_own).coff : bam->fsize;
+    if (file_bytes_out) *file_bytes_out = (int64_t)(c1 - c0);
+    if (u_lo_out) *u_lo_out = (int64_t)sh.u_lo;
+    if (u_hi_out) *u_hi_out = (int64_t)sh.u_hi;
+    if (tail_blocks_out) *tail_blocks_out = (int64_t)(sh.block_hi - sh.block_own);
+    return SPL_OK;
+}
+
+// The records of share k by the HOST's inflate and a plain walk from u_lo: how many per reference (per_tid[n_ref + 1], the last
+// entry the records without a reference).  The walk must arrive exactly at u_hi -- what the device decoder of the share is held
+// to as well.  Diagnostic / test hook: the sum over the shares is the file.
+extern "C" int spl_bam_share_count_host(spl_bam *bam, int k, int64_t *per_tid)
+{
+    if (!bam || !per_tid) return spl_set_error(SPL_ERR_ARG, "spl_bam_share_count_host: null argument");
+    spl_bam_share sh;
+    const int rc = spl_bam_share_get(bam, k, &sh);
+    if (rc) return rc;
+    for (int t = 0; t <= bam->n_refs; ++t) per_tid[t] = 0;
+    const uint8_t *file = (const uint8_t *)bam->map;
+    void *ld = deflate_lib().ok ? deflate_lib().alloc() : nullptr;
+    std::vector<uint8_t> buf;
+    size_t len = 0;
+    for (size_t b = (size_t)sh.block_lo; b < (size_t)sh.block_hi; ++b) len += bam->dir.at(b).isize;
+    buf.resize(len + 64);
+    size_t at = 0;
+    bool ok = true;
+    for (size_t b = (size_t)sh.block_lo; b < (size_t)sh.block_hi && ok; ++b) {
+        ok = inflate_block(file, bam->dir.at(b), buf.data() + at, ld);
+        at += bam->dir.at(b).isize;
+    }
+    if (ld) deflate_lib().free_(ld);
+    if (!ok) return spl_set_error(SPL_ERR_FORMAT, "%s: a block of share %d does not inflate", bam->path.c_str(), k);
+    const uint64_t u0 = bam->dir.at((size_t)sh.block_lo).uoff;
+    uint64_t u = sh.u_lo;
+    while (u < sh.u_hi) {
+        if (u - u0 + 36 > len) return spl_set_error(SPL_ERR_FORMAT, "%s: share %d: a record runs past the share's blocks", bam->path.c_str(), k);
+        const uint8_t *c = buf.data() + (size_t)(u - u0);
+        const uint32_t bs = le32(c);
+        if (bs < 32) return spl_set_error(SPL_ERR_FORMAT, "%s: share %d: corrupt record", bam->path.c_str(), k);
+        const int32_t tid = le32s(c + 4);
+        per_tid[tid < 0 || tid >= bam->n_refs ? bam->n_refs : tid]++;
+        u += 4ull + bs;
+    }
+    if (u != sh.u_hi) return spl_set_error(SPL_ERR_FORMAT, "%s: share %d: the walk from %llu arrives at %llu, not at the next share's first record %llu", bam->path.c_str(), k,
+                                           (unsigned long long)sh.u_lo, (unsigned long long)u, (unsigned long long)sh.u_hi);
     return SPL_OK;
 }
 
@@ -1466,6 +1521,15 @@ int spl_bam_share_done(spl_bam *bam, int k, void *handle, void (*free_fn)(void *
     if (!all) return SPL_OK;
     if (bam->claim != 1) return SPL_OK; // (somebody gave the file to the host threads meanwhile)
     bam->claim = 2;
+    if (!any_failed) { // every share was sorted by reference in itself; so must the shares be among each other
+        int last_tid = -1;
+        for (const spl_bam::ShareResult &x : bam->share_results) {
+            int lo = -1, hi = -1;
+            for (int t = 0; t < bam->n_refs; ++t) if (x.n[(size_t)t] > 0) { if (lo < 0) lo = t; hi = t; }
+            if (lo >= 0 && lo < last_tid) { any_failed = true; if (bam->decline_reason.empty()) bam->decline_reason = "not sorted by reference"; }
+            if (hi >= 0) last_tid = hi;
+        }
+    }
     if (any_failed) { // everything the devices have is dropped: the host threads decode the file
         std::vector<spl_bam::ShareResult> drop;
         drop.swap(bam->share_results);
@@ -1478,26 +1542,25 @@ int spl_bam_share_done(spl_bam *bam, int k, void *handle, void (*free_fn)(void *
         return SPL_OK;
     }
     bam->lazy = true;
-    bam->lazy_first.assign((size_t)bam->n_refs, 0);
     int64_t n_all = 0;
     for (size_t s = 0; s < bam->share_results.size(); ++s) {
         spl_bam::ShareResult &x = bam->share_results[s];
-        const spl_bam_share &sh = bam->shares[s];
         spl_bam::DevShare d;
-        d.handle = x.handle; d.free_fn = x.free_fn; d.tid_lo = sh.tid_lo; d.tid_hi = sh.tid_hi;
+        d.handle = x.handle; d.free_fn = x.free_fn; d.share = (int)s;
         x.handle = nullptr;
         bam->dev_shares.push_back(d);
         n_all += x.n_records;
-        for (int t = std::max(0, (int)sh.tid_lo); t < bam->n_refs && t < sh.tid_hi; ++t) {
+        for (int t = 0; t < bam->n_refs; ++t) { // (a reference may have a part in several shares: file order = share order)
             if (x.n[(size_t)t] <= 0) continue;
             PendingPart *pp = new PendingPart();
             pp->tid = t;
+            pp->share = (int)s;
+            pp->first = x.first[(size_t)t];
             pp->reads.n = (size_t)x.n[(size_t)t];
             pp->reads.max_end = x.max_end[(size_t)t];
             bam->parts[(size_t)t].push_back(pp);
-            bam->ref_reads[(size_t)t] = x.n[(size_t)t];
-            bam->ref_max_end[(size_t)t] = x.max_end[(size_t)t];
-            bam->lazy_first[(size_t)t] = x.first[(size_t)t];
+            bam->ref_reads[(size_t)t] += x.n[(size_t)t];
+            bam->ref_max_end[(size_t)t] = std::max(bam->ref_max_end[(size_t)t], x.max_end[(size_t)t]);
         }
     }
     bam->n_records = n_all;
@@ -1517,6 +1580,20 @@ extern "C" int spl_bam_share_range(spl_bam *bam, int k, int *tid_lo_out, int *ti
     if (rc) return rc;
     if (tid_lo_out) *tid_lo_out = sh.tid_lo;
     if (tid_hi_out) *tid_hi_out = sh.tid_hi;
+    return SPL_OK;
+}
+
+// What share k holds of reference `tid`, once the shares' decoders are done (spl_bam_wait_device): the number of its records
+// there and the last base any of them covers.
+extern "C" int spl_bam_share_ref(spl_bam *bam, int k, int tid, int64_t *n_reads_out, int64_t *max_end_out)
+{
+    if (!bam) return spl_set_error(SPL_ERR_ARG, "spl_bam_share_ref: null argument");
+    std::lock_guard<std::mutex> lock(bam->mu);
+    if (k < 0 || (size_t)k >= bam->share_results.size() || tid < 0 || tid >= bam->n_refs) return spl_set_error(SPL_ERR_ARG, "spl_bam_share_ref: no such share or reference");
+    const spl_bam::ShareResult &x = bam->share_results[(size_t)k];
+    if (!x.reported || x.failed || x.n.size() != (size_t)bam->n_refs) return spl_set_error(SPL_ERR_ARG, "spl_bam_share_ref: share %d has not been decoded on a device", k);
+    if (n_reads_out) *n_reads_out = x.n[(size_t)tid];
+    if (max_end_out) *max_end_out = x.max_end[(size_t)tid];
     return SPL_OK;
 }
 
@@ -1554,7 +1631,7 @@ static int fetch_lazy(spl_bam *bam, std::unique_lock<std::mutex> &lock)
         if (k == bam->dev_shares.size()) { bam->lazy = false; return SPL_OK; }
         bam->fetching = true;
         void *const handle = bam->dev_shares[k].handle;
-        const int32_t tid_lo = bam->dev_shares[k].tid_lo, tid_hi = bam->dev_shares[k].tid_hi;
+        const int share = bam->dev_shares[k].share;
         int32_t *pos = nullptr; uint16_t *flag = nullptr; uint32_t *cig_off = nullptr, *cigar = nullptr;
         lock.unlock();
         const int rc = bam->dev_fetch(handle, &pos, &flag, &cig_off, &cigar);
@@ -1562,10 +1639,11 @@ static int fetch_lazy(spl_bam *bam, std::unique_lock<std::mutex> &lock)
         bam->fetching = false;
         if (rc) { bam->cv.notify_all(); return rc; }
         bam->slabs.push_back(pos); bam->slabs.push_back(flag); bam->slabs.push_back(cig_off); bam->slabs.push_back(cigar);
-        for (int t = std::max(0, (int)tid_lo); t < bam->n_refs && t < tid_hi; ++t) {
+        for (int t = 0; t < bam->n_refs; ++t) {
             for (PendingPart *pp : bam->parts[(size_t)t]) {
+                if (pp->share != share) continue;
                 RefReads &r = pp->reads;
-                const int64_t first = bam->lazy_first[(size_t)t];
+                const int64_t first = pp->first;
                 r.pos = pos + first;
                 r.flag = flag + first;
                 r.cig_off = cig_off + first;

@@ -28,16 +28,21 @@ int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off,
                   const int64_t *ref_max_end, int64_t n_records_total);
 // what the device decoder keeps in device memory for the device packer: an opaque handle, freed with the file
 void spl_bam_set_device_reads(spl_bam *bam, void *handle, void (*free_fn)(void *));
-void *spl_bam_device_reads(spl_bam *bam, int tid);          // the handle that holds reference `tid` (several after a decode in shares)
+void *spl_bam_device_reads(spl_bam *bam, int tid);          // the handle that holds ALL of reference `tid` (null: none does -- no device decode, or the reference lies in several shares)
+void *spl_bam_share_reads(spl_bam *bam, int share);         // what share `share` left in device memory (null: nothing)
 
-// ---- a decode in SHARES: each device takes the stretch of the file where its references' records begin ----------------
-// BGZF blocks [block_lo, block_hi) and the references tid_lo <= tid < tid_hi (records without a reference count as n_ref).
-// Both ends of a stretch may hold records of a neighbour's references: they are skipped, not decoded twice.
-struct spl_bam_share { uint64_t block_lo, block_hi; int32_t tid_lo, tid_hi; };
-// Cuts the file into up to n_shares stretches of about equal size at reference boundaries (found by inflating a block per probe
-// on the host).  The whole block directory is walked first.  Once per file; later calls return the first plan.
+// ---- a decode in SHARES: each device takes a stretch of the file, cut at ANY BGZF block ---------------------------------
+// A share owns the records that BEGIN in blocks [block_lo, block_own) -- in the inflated stream: at offsets [u_lo, u_hi), both
+// record boundaries the plan found by inflating a few blocks at every cut on the host -- and inflates blocks [block_lo,
+// block_hi): the tail [block_own, block_hi) holds the end of its last record and nothing else of its own.  A reference's records
+// may lie in several shares (counters are additive per read, SpliSER_v0_1_8.py:519-559: each device counts its stretch against the
+// reference's whole site table); tid_lo <= tid < tid_hi are the references a share CAN hold records of (records without a
+// reference count as n_ref; the last share's tid_hi = n_ref + 1).
+struct spl_bam_share { uint64_t block_lo, block_hi; int32_t tid_lo, tid_hi; uint64_t block_own, u_lo, u_hi; };
+// Cuts the file into up to n_shares stretches of equal size in file bytes.  The whole block directory is walked first.  Once per
+// file; later calls return the first plan.
 int spl_bam_share_get(spl_bam *bam, int k, spl_bam_share *out);
-// A share's decoder is done: `handle` holds its references (share-local first record per reference in ref_first), or failed != 0.
+// A share's decoder is done: `handle` holds its records (share-local first record per reference in ref_first), or failed != 0.
 // When the last share has reported the file is complete -- or, if one failed, everything is dropped and the host threads decode.
 int spl_bam_share_done(spl_bam *bam, int k, void *handle, void (*free_fn)(void *), const int64_t *ref_first, const int64_t *ref_n,
                        const int64_t *ref_max_end, int64_t n_records, int failed);

@@ -1262,7 +1262,11 @@ typedef std::function<int(ShareOut &)> Publish;
 }
 static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, ShareOut &res, const Publish &publish, bool all_token_room = false);
 
-static void fill_whole(spl_bam *bam, spl_bam_share &sh) { sh.block_lo = 0; sh.block_hi = spl_bam_block_count(bam); sh.tid_lo = 0; sh.tid_hi = spl_bam_n_ref(bam) + 1; }
+static void fill_whole(spl_bam *bam, spl_bam_share &sh)
+{
+    sh.block_lo = 0; sh.block_hi = sh.block_own = spl_bam_block_count(bam); sh.tid_lo = 0; sh.tid_hi = spl_bam_n_ref(bam) + 1;
+    sh.u_lo = spl_bam_header_end(bam); sh.u_hi = 0; // (u_hi: the stream's end, which decode_share knows from the last block)
+}
 
 extern "C" int spl_bam_decode_device(spl_ctx *c, spl_bam *bam, int *on_device_out)
 {
@@ -1691,6 +1695,10 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     const size_t lo = (size_t)sh.block_lo, hi = (size_t)sh.block_hi, n_blocks = hi - lo;
     if (n_blocks == 0 || n_blocks > 0xfffffff0ull) return to_host("no blocks");
     const bool last_share = hi == n_blocks_file, first_share = lo == 0;
+    // The share's OWN blocks: the records that begin in them are its records.  The blocks behind them (a share that is not the
+    // file's last) are inflated for the end of its last record and otherwise left alone -- the next share's device has them too.
+    const size_t n_own = (size_t)sh.block_own - lo;
+    if (n_own == 0 || n_own > n_blocks) return to_host("a share without blocks of its own");
     blocks.resize(n_blocks);
     foff.resize(n_blocks);
     for (size_t i = 0; i < n_blocks; ++i) {
@@ -1748,7 +1756,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     }
     // where the placed records of a window's blocks begin (scan -> extraction, one window at a time on stream B): room for a window's
     // blocks and what an 8 MB carry can hold of ordinary ones; a window with more blocks than that is extracted by walking
-    const size_t recs_blocks = std::min(n_blocks, win_blocks + (size_t)32768);
+    const size_t recs_blocks = std::min(n_own, win_blocks + (size_t)32768);
     HIP_TRY(d_recs.get(2 * (size_t)SPL_BS_REC_CAP * recs_blocks, c->copy));
     HIP_TRY(d_blocks.get(sizeof(spl_zblock) * n_blocks, c->copy));
     HIP_TRY(d_status.get(4 * n_blocks, c->copy));
@@ -1852,13 +1860,12 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         return SPL_OK;
     };
     int64_t n_all = 0;
-    uint64_t expect = first_share ? H : 0; // the chain of boundaries, from the end of the BAM header (a later share: from its first block's guess)
-    bool expect_known = first_share;
+    // The chain of record boundaries: from the end of the BAM header, or (a later share) from the first record that begins in the
+    // share's first block -- which the plan found on the host, and which the share in front of this one must arrive at: every
+    // share's chain ends exactly where the next one's begins (checked below), so every record is somebody's and nobody's twice.
+    uint64_t expect = first_share ? H : sh.u_lo;
+    const bool expect_known = true;
     int32_t last_tid = -1;
-    // The neighbours' records at a share's edges are skipped unread -- which is right only where a file sorted by reference has
-    // them: references in front of the share's before its first own record (phase 0), references behind them after its last
-    // (phase 2).  A record of any other reference anywhere else would be extracted by nobody: such a file goes to the host.
-    int edge_phase = 0;
     size_t carry = 0; // the first block whose records are not all extracted yet
     size_t launched = n_early, copying = early ? 1 : 0; // windows whose decoding / whose copying kernel has been put on its stream
     std::vector<double> t_win; // (SPL_BAM_TIMING: when each window's scan was back on the host)
@@ -1887,22 +1894,24 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             if (!progress) break;
         }
         const size_t slot = k % (size_t)n_buf;
-        const bool more = b1 < n_blocks || !last_share;
+        const bool more = b1 < n_blocks; // (behind the last window nothing follows: a share's tail blocks hold the end of its last record)
         const uint32_t nb = (uint32_t)(b1 - b0);
         const uint64_t win_end = blocks[b1 - 1].out + blocks[b1 - 1].out_len;
         uint8_t *const stream0 = stream0_of(k);
         const size_t s0 = k == 0 ? b0 : carry; // scan and extraction begin with what the window before left
+        const size_t b1s = std::min(b1, n_own); // ... and end with the share's own blocks
         HIP_TRY(hipStreamWaitEvent(pipe.b, pipe.k2[k], 0));
         if (k < n_early) HIP_TRY(hipMemcpyAsync(d_status.as<uint32_t>() + b0, d_status0.as<uint32_t>() + b0, 4 * (size_t)nb, hipMemcpyDeviceToDevice, pipe.b)); // (an early window's status words: to their place among the file's)
         const double win_out = (double)(win_end - blocks[b0].out);
         { splprof::Scope p("spl_crc32_kernel", pipe.b, win_out); HIP_TRY((hipError_t)spl_dev_launch_crc32(stream0, d_blocks.as<spl_zblock>() + b0, nb, d_status.as<uint32_t>() + b0, pipe.b)); }
-        {
-            splprof::Scope p("spl_bam_scan_kernel", pipe.b, (double)(win_end - blocks[s0].out));
-            HIP_TRY((hipError_t)spl_dev_launch_bam_scan(stream0, win_end, H, n_ref, sh.tid_lo, sh.tid_hi, d_blocks.as<spl_zblock>() + s0, (uint32_t)(b1 - s0), d_scan.as<spl_bscan>() + s0,
-                                                        more ? 1 : 0, b1 - s0 <= recs_blocks && !getenv("SPL_EXTRACT_WALK") ? d_recs.as<uint16_t>() : nullptr, pipe.b));
+        const bool with_recs = b1s > s0 && b1s - s0 <= recs_blocks && !getenv("SPL_EXTRACT_WALK");
+        if (b1s > s0) {
+            splprof::Scope p("spl_bam_scan_kernel", pipe.b, (double)(blocks[b1s - 1].out + blocks[b1s - 1].out_len - blocks[s0].out));
+            HIP_TRY((hipError_t)spl_dev_launch_bam_scan(stream0, win_end, H, n_ref, 0, n_ref + 1, d_blocks.as<spl_zblock>() + s0, (uint32_t)(b1s - s0), d_scan.as<spl_bscan>() + s0,
+                                                        more ? 1 : 0, with_recs ? d_recs.as<uint16_t>() : nullptr, pipe.b));
         }
         HIP_TRY(hipMemcpyAsync(status.get() + b0, d_status.as<uint32_t>() + b0, 4 * (size_t)nb, hipMemcpyDeviceToHost, pipe.b));
-        HIP_TRY(hipMemcpyAsync(scan.get() + s0, d_scan.as<spl_bscan>() + s0, sizeof(spl_bscan) * (b1 - s0), hipMemcpyDeviceToHost, pipe.b));
+        if (b1s > s0) HIP_TRY(hipMemcpyAsync(scan.get() + s0, d_scan.as<spl_bscan>() + s0, sizeof(spl_bscan) * (b1s - s0), hipMemcpyDeviceToHost, pipe.b));
         HIP_TRY(hipStreamSynchronize(pipe.b));
         if (timing) t_win.push_back(host_now() - t_begin);
         for (size_t i = b0; i < b1; ++i)
@@ -1916,9 +1925,9 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         // Which of the window's blocks are done with: all whose records end inside it.  A block near the window's end may have
         // looked for its first record, or walked its last one, into bytes that are not there yet: it is told by its flag, or
         // -- within reach of the end -- by anything being wrong with it, and is looked at again with the next window.
-        const uint64_t reach = std::min<uint64_t>((win_end - blocks[s0].out) / 2, ((uint64_t)5 << 18));
-        size_t b_done = b1;
-        for (size_t b = s0; b < b1; ++b) {
+        const uint64_t reach = b1s > s0 ? std::min<uint64_t>((win_end - blocks[s0].out) / 2, ((uint64_t)5 << 18)) : 0;
+        size_t b_done = std::max(b1s, s0);
+        for (size_t b = s0; b < b1s; ++b) {
             spl_bscan &sc = scan[b];
             if (first_share && b < first) { // (BAM header only: nothing to extract)
                 sc.n_placed = 0;
@@ -1926,7 +1935,6 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 op_off[b + 1] = op_off[b];
                 continue;
             }
-            const bool share_edge = !(lo + b >= (size_t)sh.block_lo + 2 && lo + b + 2 < (size_t)sh.block_hi); // (the neighbours' records may lie here)
             const char *wrong = nullptr;
             if (sc.flags & SPL_BS_CORRUPT) wrong = "a record contradicts itself";
             else if (sc.flags & SPL_BS_NO_START) wrong = "no record boundary found near a block";
@@ -1934,26 +1942,16 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             else if (sc.flags & SPL_BS_UNSORTED) wrong = "not sorted by reference";
             else if (expect_known && sc.start != expect) wrong = "a guessed record boundary did not hold";
             else if (sc.n_placed && sc.tid_first < last_tid) wrong = "not sorted by reference";
-            else if (sc.n_foreign && !share_edge) wrong = "not sorted by reference";
-            else if (sc.n_foreign > sc.n_foreign_hi && edge_phase > 0) wrong = "not sorted by reference"; // (a reference in front of the share's behind one of its own)
-            else if (sc.n_all && edge_phase > 1) wrong = "not sorted by reference";                        // (one of the share's own behind a later share's)
-            if (!last_share && b1 == n_blocks && (sc.flags & SPL_BS_INCOMPLETE) && b + 1 >= b1 && !wrong) {
-                // the last block of a share that is not the file's last: the record that runs on is the next share's
-                sc.flags &= ~SPL_BS_INCOMPLETE;
-            }
-            if ((sc.flags & SPL_BS_INCOMPLETE) || (wrong && more && blocks[b].out + reach >= win_end && b1 < n_blocks)) { b_done = b; break; }
+            if ((sc.flags & SPL_BS_INCOMPLETE) || (wrong && more && blocks[b].out + reach >= win_end)) { b_done = b; break; }
             if (wrong) return to_host(wrong);
             if (sc.n_placed) last_tid = sc.tid_last;
-            if (sc.n_all) edge_phase = std::max(edge_phase, 1);
-            if (sc.n_foreign_hi) edge_phase = 2;
             expect = sc.reached;
-            expect_known = true;
             n_all += sc.n_all;
             rec_off[b + 1] = rec_off[b] + sc.n_placed;
             op_off[b + 1] = op_off[b] + sc.n_ops;
         }
-        if (b_done < b1 && b1 == n_blocks) return to_host(last_share ? "the file ends inside a record" : "a record runs past the share's last block");
-        if (b_done < b1 && win_end - blocks[b_done].out > HEAD) return to_host("a record larger than the room between two windows");
+        if (b_done < b1s && b1 == n_blocks) return to_host(last_share ? "the file ends inside a record" : "a record runs past the blocks behind a share");
+        if (b_done < b1s && win_end - blocks[b_done].out > HEAD) return to_host("a record larger than the room between two windows");
         if (op_off[b_done] > 0xfffffff0ull) return to_host("more than 2^32 CIGAR operations");
         if (b_done > s0) {
             rc = make_room(rec_off[b_done], op_off[b_done], (double)(blocks[b_done - 1].out + blocks[b_done - 1].out_len - stream_begin) / (double)std::max<uint64_t>(stream_len - stream_begin, 1));
@@ -1965,16 +1963,19 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             HIP_TRY(hipMemcpyAsync(d_opoff.as<uint64_t>() + s0, op_off.get() + s0, 8 * nd, hipMemcpyHostToDevice, pipe.b));
             HIP_TRY(hipMemcpyAsync(d_scan.as<spl_bscan>() + s0, scan.get() + s0, sizeof(spl_bscan) * nd, hipMemcpyHostToDevice, pipe.b));
             splprof::Scope p("spl_bam_extract_kernel", pipe.b, (double)(blocks[b_done - 1].out + blocks[b_done - 1].out_len - blocks[s0].out));
-            HIP_TRY((hipError_t)spl_dev_launch_bam_extract(stream0, win_end, n_ref, sh.tid_lo, sh.tid_hi, d_blocks.as<spl_zblock>() + s0, (uint32_t)nd, d_scan.as<spl_bscan>() + s0,
+            HIP_TRY((hipError_t)spl_dev_launch_bam_extract(stream0, win_end, n_ref, 0, n_ref + 1, d_blocks.as<spl_zblock>() + s0, (uint32_t)nd, d_scan.as<spl_bscan>() + s0,
                                                            d_recoff.as<uint64_t>() + s0, d_opoff.as<uint64_t>() + s0, d_pos.as<int32_t>(), d_flag.as<uint16_t>(),
                                                            d_cigoff.as<uint32_t>(), d_cigar.as<uint32_t>(), d_tid.as<int32_t>(), d_maxend.as<unsigned long long>(),
-                                                           b1 - s0 <= recs_blocks && !getenv("SPL_EXTRACT_WALK") ? d_recs.as<uint16_t>() : nullptr, pipe.b));
+                                                           with_recs ? d_recs.as<uint16_t>() : nullptr, pipe.b));
         }
-        if (b_done < b1 && k + 1 < n_win) // what is left of this window: in front of the next one's bytes
+        if (b_done < b1s && k + 1 < n_win) // what is left of this window: in front of the next one's bytes
             HIP_TRY(hipMemcpyAsync(stream0_of(k + 1) + blocks[b_done].out, stream0 + blocks[b_done].out, (size_t)(win_end - blocks[b_done].out), hipMemcpyDeviceToDevice, pipe.b));
         HIP_TRY(hipEventRecord(pipe.freed[slot], pipe.b));
         carry = b_done;
     }
+    if (carry < n_own) return to_host("a share's last blocks were never done with");
+    // every record that begins in the share's own blocks has been walked: the walk must have arrived where the next share's begins
+    if (!last_share && expect != sh.u_hi) return to_host("a share's records do not end where the next share's begin");
     if (last_share && expect_known && expect != stream_len) return to_host("the file ends inside a record");
     if (!cap_rec) { rc = make_room(0, 0, 1.0); if (rc) return rc; } // (a share without a record of its own)
     HIP_TRY((hipError_t)spl_dev_launch_bam_bounds(d_tid.as<int32_t>(), d_cigoff.as<uint32_t>(), n_rec, d_bounds.as<uint64_t>(), d_nbounds.as<uint32_t>(), cap, pipe.b));
@@ -2317,6 +2318,22 @@ extern "C" int spl_reads_add_bam(spl_ctx *c, spl_dreads *d, spl_bam *bam, int ti
     rc = spl_bam_source(bam, tid, &src, &max_end); // (the views are what the host packer reads; reads that stayed on another device come to the host here)
     if (rc) return rc;
     return add_segment(c, d, src, pos_shift, max_end);
+}
+
+// The records of reference `tid` that SHARE `share` of a decode in shares left on its device (spl_bam_decode_device_share): a
+// reference cut by a share boundary is counted piece by piece, each piece where it was decoded, against the reference's whole
+// site table -- the counters of checkBam only ever add one per read (SpliSER_v0_1_8.py:519-559), so the pieces' counters add up.
+// The context must be on the share's device.
+extern "C" int spl_reads_add_bam_share(spl_ctx *c, spl_dreads *d, spl_bam *bam, int share, int tid, int32_t pos_shift)
+{
+    if (!c || !d || !bam) return spl_set_error(SPL_ERR_ARG, "spl_reads_add_bam_share: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    DeviceReads *dev = (DeviceReads *)spl_bam_share_reads(bam, share);
+    if (!dev) return spl_set_error(SPL_ERR_ARG, "spl_reads_add_bam_share: share %d has nothing on a device", share);
+    if (dev->device != c->device) return spl_set_error(SPL_ERR_ARG, "spl_reads_add_bam_share: share %d was decoded on device %d, the context is on device %d", share, dev->device, c->device);
+    if (tid < 0 || (size_t)tid >= dev->ref_n.size()) return spl_set_error(SPL_ERR_ARG, "tid %d out of range", tid);
+    const size_t t = (size_t)tid;
+    return add_segment_device(c, d, dev, dev->ref_first[t], dev->ref_n[t], dev->ref_ops[t], pos_shift, dev->ref_n[t] ? dev->ref_max[t] : -1);
 }
 
 // ---- BAM-native reads resident on the device, from a caller's arrays ------------------------------------------------

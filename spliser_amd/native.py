@@ -47,10 +47,10 @@ OPT_WAVE_AGGREGATION = 2
 EXPORTS = [
     "spl_abi_version", "spl_last_error", "spl_device_count", "spl_trim", "spl_create", "spl_create_on_stream", "spl_destroy",
     "spl_sync", "spl_pass_barrier", "spl_timer_begin", "spl_timer_end", "spl_kernel_timing_begin", "spl_kernel_timing_collect", "spl_prof_enable", "spl_prof_report", "spl_count", "spl_sse", "spl_sites_upload", "spl_sites_free",
-    "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add2", "spl_reads_add_bam", "spl_reads_finish",
+    "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add2", "spl_reads_add_bam", "spl_reads_add_bam_share", "spl_reads_finish",
     "spl_soa_upload", "spl_soa_upload2", "spl_soa_free", "spl_reads_add_soa", "spl_reads_relayout", "spl_layout_timing_collect", "spl_reads_layout_bytes",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
-    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_wait_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_cancel", "spl_bam_decline_reason", "spl_bam_close",
+    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_share_info", "spl_bam_share_count_host", "spl_bam_share_ref", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_wait_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_cancel", "spl_bam_decline_reason", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
     "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append", "spl_tsv_append_many", "spl_fmt_fixed",
     "spl_bed_open", "spl_gff_open", "spl_text_close", "spl_text_rows", "spl_text_n_chrom", "spl_text_chrom_name", "spl_text_chrom",
@@ -364,6 +364,15 @@ class DeviceReads(object):
         self.n += n_reads
         return n_reads
 
+    def add_bam_share(self, bam, share, chrom, shift=0):
+        """One more segment: what share ``share`` of a decode in shares holds of reference ``chrom``, from that share's arrays on
+        this device (``BamFile.decode_on_devices_async``; the decoders must be done: ``join_decoders``).  -> number of reads added."""
+        n_reads, _ = bam.share_ref(share, chrom)
+        if n_reads:
+            _check(lib().spl_reads_add_bam_share(self.ctx._h, self._h, bam._h, ctypes.c_int(int(share)), ctypes.c_int(bam._tid[chrom]), ctypes.c_int32(int(shift))))
+            self.n += n_reads
+        return n_reads
+
     def add_soa(self, soa, seg, shift=0):
         """One more segment: segment ``seg`` of BAM-native arrays resident on the device (``Context.upload_soa``)."""
         _check(lib().spl_reads_add_soa(self.ctx._h, self._h, soa._h, ctypes.c_int(int(seg)), ctypes.c_int32(int(shift))))
@@ -623,20 +632,24 @@ class BamFile(object):
 
     def decode_on_devices_async(self, devices):
         """The decode in SHARES, one per entry of ``devices`` (a device may appear more than once: a context each): the file is
-        cut at reference boundaries into stretches of about equal size, and every device inflates and extracts its own stretch
-        -- the references that begin there -- over its own PCIe link.  -> [(device, [reference names])], the plan: whoever counts
-        a reference should do it on the device that holds its reads (``shares``).  Threads in ``_device_threads``."""
+        cut into stretches of EQUAL size in file bytes, at any BGZF block (``spl_bam_share_plan``), and every device inflates and
+        extracts its own stretch over its own PCIe link.  A reference may lie in several shares: each device counts its stretch
+        against the reference's whole site table and the partial counters are added (``process.process_sites``).  -> [(device,
+        [names of the references the share can hold records of])], the plan (``shares``; ``share_bytes``: the file bytes of each;
+        ``share_ref`` says what a share really holds once the decoders are done).  Threads in ``_device_threads``."""
         import threading
         n = ctypes.c_int(0)
         _check(lib().spl_bam_share_plan(self._h, ctypes.c_int(len(devices)), ctypes.byref(n)))
         _check(lib().spl_bam_reserve_device(self._h))
         self.on_device = False
-        plan = []
+        plan, sizes = [], []
         for k in range(n.value):
             lo, hi = ctypes.c_int(0), ctypes.c_int(0)
             _check(lib().spl_bam_share_range(self._h, ctypes.c_int(k), ctypes.byref(lo), ctypes.byref(hi)))
             plan.append((devices[k], [self.ref_names[t] for t in range(lo.value, min(hi.value, len(self.ref_names)))]))
+            sizes.append(self.share_info(k)["file_bytes"])
         self.shares = plan
+        self.share_bytes = sizes
         self._share_errors = []
 
         def run(k, device):
@@ -655,6 +668,25 @@ class BamFile(object):
             t.start()
         self._device_thread = self._device_threads[0]
         return plan
+
+    def share_info(self, k):
+        """-> {file_bytes, u_lo, u_hi, tail_blocks} of share ``k`` of the plan (``spl_bam_share_info``)."""
+        v = [ctypes.c_int64(0) for _ in range(4)]
+        _check(lib().spl_bam_share_info(self._h, ctypes.c_int(int(k)), *[ctypes.byref(x) for x in v]))
+        return dict(file_bytes=v[0].value, u_lo=v[1].value, u_hi=v[2].value, tail_blocks=v[3].value)
+
+    def share_ref(self, k, chrom):
+        """-> (reads, largest end coordinate) of what share ``k`` holds of reference ``chrom`` (after ``join_decoders`` said True)."""
+        n, me = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(lib().spl_bam_share_ref(self._h, ctypes.c_int(int(k)), ctypes.c_int(self._tid[chrom]), ctypes.byref(n), ctypes.byref(me)))
+        return n.value, me.value
+
+    def share_count_host(self, k):
+        """-> records of share ``k`` per reference by the host's inflate and a plain walk (the last entry: records without a
+        reference); raises when the walk from the share's first record does not arrive at the next share's.  No GPU."""
+        out = (ctypes.c_int64 * (len(self.ref_names) + 1))()
+        _check(lib().spl_bam_share_count_host(self._h, ctypes.c_int(int(k)), out))
+        return list(out)
 
     def decline_reason(self):
         """Why the device decoder left the file to the host threads ('' if it did not)."""

@@ -17,6 +17,8 @@ import sys
 import threading
 import time
 
+import numpy as np
+
 from . import fast_sites, native, samio, shard, sites, tsv
 
 
@@ -145,18 +147,24 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
     # read counts of the BED file say where the spliced reads are.
     weights = {c: (r.n if r is not None else int(a.alpha.sum())) + a.n for c, (a, r, _) in items.items()}
     shares = getattr(source, "shares", None) if is_bam else None
+    listed = None    # the file is being decoded in shares: chromosome -> the shares (= positions in `devices`) that can hold reads of it
     if shares and len(devices) >= len(shares) and [d for d, _ in shares] == list(devices[:len(shares)]):
-        # the file is being decoded in shares, a device each: a chromosome is counted where its reads are (the others, if any, by the first)
-        where = {c: k for k, (_, names) in enumerate(shares) for c in names}
+        # A share is a stretch of the FILE (spl_bam_share_plan: equal parts, cut at any BGZF block), so a chromosome's reads may lie
+        # on several devices.  Each counts its stretch against the chromosome's whole site table; checkBam's counters only ever add
+        # one per read (SpliSER_v0_1_8.py:519-559), so the partial beta1 / beta2Simple-reads / double-count arrays are added on the
+        # host and findBeta2Counts + calculateSSE (:581-639) run once on the sums -- no read twice, nothing exchanged between devices.
+        listed = {c: [k for k, (_, names) in enumerate(shares) if c in names] or [0] for c in items}
         plan = [[] for _ in devices]
         for c in items:
-            plan[where.get(c, 0)].append(c)
+            for k in listed[c]:
+                plan[k].append(c)
     else:
         plan = shard.assign(weights, len(devices))
     out, errors = {}, []
     lock = threading.Lock()
+    partial = {}     # chromosome -> {share: (beta1, beta2s_reads, dbl)} of the devices that have counted their stretch of it
 
-    def run(device, chroms):
+    def run(k_dev, device, chroms):
         try:
             if not chroms:
                 return
@@ -176,7 +184,7 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                 if os.environ.get("SPL_PROCESS_TIMING"):
                     sys.stderr.write("[process] device %d: %s plan %.4f s after Step 3 began\n" % (device, "exact" if exact else "first", time.perf_counter() - t_enter))
                 try:
-                    _count_shards(device, shards)
+                    _count_shards(k_dev, device, shards)
                     break
                 except _Replan:
                     if exact:
@@ -188,7 +196,19 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
             with lock:
                 errors.append(exc)
 
-    def _count_shards(device, shards):
+    def _finish_split(ctx, chrom, pieces):
+        """A chromosome whose reads were counted on several devices: the sums of their counters, then findBeta2Counts +
+        calculateSSE on them (``spl_sse``, on the context of whichever device brought the last piece)."""
+        arr = items[chrom][0]
+        beta1, b2r, dbl = (sum(p[j].astype(np.int64) for p in pieces).astype(np.uint32) for j in range(3))
+        b2s, b2c, b2w, sse = ctx.sse(native.SiteArrays.from_chrom(arr), beta1, b2r, dbl, is_beta2_cryptic)
+        res = dict(beta1=beta1, beta2_simple=b2s, beta2_cryptic=b2c, beta2_weighted=b2w, sse=sse, beta2s_reads=b2r)
+        with lock:
+            out[chrom] = (arr, res)
+        if on_result is not None:
+            on_result(chrom, arr, res)
+
+    def _count_shards(k_dev, device, shards):
         # the device decoder delivers every reference at once: nothing to stream chromosome by chromosome, so all chromosomes of
         # a shard are laid out as ONE read set and counted in one pass.  (Whether it did is asked when the first site table is
         # up: context and table take 10 ms that the decode's last kernels can run beside.)
@@ -210,16 +230,24 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                 for sh in shards:
                     tables.append(ctx.upload_sites(sh.sites))
                 stamp("site tables up")
+                def held(chrom):    # what this device holds of a chromosome: (reads, their largest end)
+                    if not items[chrom][2]:
+                        return 0, 0
+                    return source.share_ref(k_dev, chrom) if listed is not None else source.wait_ref(chrom)
+
                 def lay_out(k):
                     sh_k = shards[k]
-                    dr_k = ctx.begin_reads(sum(source.wait_ref(c)[0] for c in sh_k.chroms if items[c][2]))
+                    dr_k = ctx.begin_reads(sum(held(c)[0] for c in sh_k.chroms))
                     laid[k] = dr_k
                     for chrom, off, limit in zip(sh_k.chroms, sh_k.offsets, sh_k.limits):
-                        if items[chrom][2]:
-                            _, max_end = source.wait_ref(chrom)
+                        n_held, max_end = held(chrom)
+                        if n_held:
                             if max_end > limit:
                                 raise _Replan()
-                            dr_k.add_bam(source, chrom, off)
+                            if listed is not None:
+                                dr_k.add_bam_share(source, k_dev, chrom, off)
+                            else:
+                                dr_k.add_bam(source, chrom, off)
                     return dr_k
                 for k_sh, (sh, ds) in enumerate(zip(shards, tables)):
                     if whole is None:
@@ -236,14 +264,29 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                                                    #  stream only now: this shard's chunk descriptors come down the same stream, and stood behind them)
                             ctx.count_launch(ds, dr, stranded, combine_mode)
                             ctx.sse_launch(ds, is_beta2_cryptic)
-                            beta1, b2r, _ = ds.counters()
+                            beta1, b2r, dbl = ds.counters()
                             b2s, b2c, b2w, sse = ds.sse_results()
                             stamp("counted, results down")
                         finally:
                             dr.free()
                             del laid[k_sh]
                         stamp("read set freed")
-                        for chrom, (r0, r1) in zip(sh.chroms, sh.site_rows):
+                        for chrom, (r0, r1), (e0, e1) in zip(sh.chroms, sh.site_rows, sh.edge_rows):
+                            if listed is not None:
+                                # who holds reads of this chromosome (every device thread asks the same finished decode: the same answer)
+                                holders = [j for j in listed[chrom] if items[chrom][2] and source.share_ref(j, chrom)[0] > 0]
+                                if len(holders) > 1:
+                                    if k_dev not in holders:
+                                        continue
+                                    with lock:
+                                        got = partial.setdefault(chrom, {})
+                                        got[k_dev] = (beta1[r0:r1].copy(), b2r[r0:r1].copy(), dbl[e0:e1].copy())
+                                        pieces = [got[j] for j in holders] if len(got) == len(holders) else None
+                                    if pieces is not None:     # (the last piece: this thread adds them up)
+                                        _finish_split(ctx, chrom, pieces)
+                                    continue
+                                if k_dev != (holders or listed[chrom])[0]:
+                                    continue    # (listed here, but all its reads are on another device -- or it has none, and the first listed takes it)
                             res = dict(beta1=beta1[r0:r1].copy(), beta2_simple=b2s[r0:r1].copy(), beta2_cryptic=b2c[r0:r1].copy(),
                                        beta2_weighted=b2w[r0:r1].copy(), sse=sse[r0:r1].copy(), beta2s_reads=b2r[r0:r1].copy())
                             with lock:
@@ -256,6 +299,8 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                                 "%s +%.4f" % (w, t - stamps[k - 1][1]) for k, (w, t) in enumerate(stamps) if k)))
                         continue
                     for chrom, off, limit, (r0, r1) in zip(sh.chroms, sh.offsets, sh.limits, sh.site_rows):
+                        if listed is not None and listed[chrom][0] != k_dev:
+                            continue    # (the host's threads decoded the file after all: a chromosome is whole, and the first device listed for it counts it)
                         with ctx.begin_reads() as dr:
                             if is_bam and items[chrom][2]:
                                 _, max_end = source.wait_ref(chrom)
@@ -284,7 +329,7 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                 for ds in tables:
                     ds.free()
 
-    threads = [threading.Thread(target=run, args=(dev, chroms)) for dev, chroms in zip(devices, plan)]
+    threads = [threading.Thread(target=run, args=(k, dev, chroms)) for k, (dev, chroms) in enumerate(zip(devices, plan))]
     for t in threads:
         t.start()
     for t in threads:

@@ -56,19 +56,65 @@ def test_config3_human_scale_process(devices, tmp_path, oracle_lib):
 
 def test_config3_on_eight_contexts_decodes_in_eight_shares(tmp_path, oracle_lib, monkeypatch):
     """The target machine has eight GPUs (here: eight contexts on one).  A human-shaped file of 24 chromosomes is cut into eight
-    stretches, none empty; every context inflates, extracts and counts its own; the file is the oracle's."""
+    stretches of equal size in file bytes -- anywhere, so chromosomes lie across contexts; every context inflates, extracts and
+    counts its own stretch, the partial counters of a cut chromosome are added; the file is the oracle's."""
     wl = synth.Workload("human", scale=0.02, workers=4)       # 4 M reads
     prefix = str(tmp_path / "h8")
     _files(wl, prefix, seq_mode=1)
     seen = {}
     real = native.BamFile.decode_on_devices_async
-    monkeypatch.setattr(native.BamFile, "decode_on_devices_async", lambda self, devs: seen.setdefault("plan", real(self, devs)))
+
+    def spy(self, devs):
+        seen["plan"] = real(self, devs)
+        seen["bytes"] = list(self.share_bytes)
+        return seen["plan"]
+    monkeypatch.setattr(native.BamFile, "decode_on_devices_async", spy)
     tm = proc.process(prefix + ".bam", prefix + ".bed", prefix, annotationFile=prefix + ".gff", log=lambda m: None, devices=(0,) * 8)
     assert tm["bam_decode"] == "device"
     plan = seen["plan"]
     assert len(plan) == 8 and all(names for _, names in plan)
-    assert sorted(c for _, names in plan for c in names) == sorted(wl.genome.chrom_names)
+    assert sorted(set(c for _, names in plan for c in names)) == sorted(wl.genome.chrom_names)
+    assert max(seen["bytes"]) <= 1.05 * sum(seen["bytes"]) / 8, seen["bytes"]
     assert open(prefix + ".SpliSER.tsv").read() == _oracle_tsv(oracle_lib, prefix + ".bed", wl, None, False, prefix + ".gff")
+
+
+@pytest.mark.parametrize("stranded", [None, "fr"])
+@pytest.mark.parametrize("n_ctx", [8, 3])
+def test_five_chromosomes_on_eight_contexts(tmp_path, oracle_lib, monkeypatch, n_ctx, stranded):
+    """whole-reference shares gave an A. thaliana file (five chromosomes) five shares at most.  Shares are stretches of
+    the FILE now: `process(devices=(0,) * 8)` makes eight, none empty, every chromosome's reads on two or three contexts, each
+    counted against the chromosome's whole table, the partial beta1 / beta2Simple / double counts added on the host before
+    findBeta2Counts + calculateSSE run once on the sums -- and the .SpliSER.tsv is the oracle's, unstranded and `fr` + cryptic."""
+    wl = synth.Workload("arabidopsis", scale=0.05, seed=23, workers=4)       # 1 M reads
+    if stranded:
+        for r in wl.reads:       # paired-end flags, so that both strands' windows are used
+            r.flag[:] = np.random.default_rng(5).choice(np.array([99, 147, 83, 163], np.uint16), size=r.n)
+    prefix = str(tmp_path / "a8")
+    _files(wl, prefix, seq_mode=1)
+    seen = {}
+    real = native.BamFile.decode_on_devices_async
+    real_join = native.BamFile.join_decoders
+
+    def spy(self, devs):
+        seen["plan"] = real(self, devs)
+        return seen["plan"]
+
+    def spy_join(self):
+        ok = real_join(self)
+        if ok and "held" not in seen and getattr(self, "shares", None):
+            seen["held"] = [[self.share_ref(k, c)[0] for c in wl.genome.chrom_names] for k in range(len(self.shares))]
+        return ok
+    monkeypatch.setattr(native.BamFile, "decode_on_devices_async", spy)
+    monkeypatch.setattr(native.BamFile, "join_decoders", spy_join)
+    tm = proc.process(prefix + ".bam", prefix + ".bed", prefix, annotationFile=prefix + ".gff", log=lambda m: None, devices=(0,) * n_ctx,
+                      isStranded=bool(stranded), strandedType=stranded, isbeta2Cryptic=bool(stranded))
+    assert tm["bam_decode"] == "device"
+    assert len(seen["plan"]) == n_ctx
+    held = np.array(seen["held"])
+    assert held.shape == (n_ctx, 5) and np.all(held.sum(axis=1) > 0)                     # no share without reads
+    assert held.sum(axis=0).tolist() == [r.n for r in wl.reads]                         # every read on exactly one context
+    assert np.any((held > 0).sum(axis=0) > 1)                                            # chromosomes ARE cut
+    assert open(prefix + ".SpliSER.tsv").read() == _oracle_tsv(oracle_lib, prefix + ".bed", wl, stranded, bool(stranded), prefix + ".gff")
 
 
 @pytest.mark.parametrize("gpu_decode", [False, True])
