@@ -3,10 +3,13 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "spl_inflate.h"
 #include "spl_wave.h"
 #include "spl_inflate_wave.h"
 #include "spl_crc.h"
+#include "spl_crc_wave.h"
 
 // The Huffman decoding, one BGZF block per WAVE (the block's symbols as a stream of tokens), and the block's bytes made from
 // that stream, one block per LANE (spl_inflate_wave.h has the method, and is what the host tests run through the wave emulator).
@@ -61,6 +64,24 @@ __global__ __launch_bounds__(64) void spl_crc32_kernel(const uint8_t *out_all, c
     if (status[b] != SPL_Z_OK) return;
     const spl_zblock zb = blocks[b];
     if (splcrc::block<S>(out_all + zb.out, zb.out_len, table, x2n) != zb.crc) status[b] = SPL_Z_BAD_CRC;
+}
+
+// CRC32 a block per WAVE (spl_crc_wave.h, round 6): rows of 1024 bytes, a coalesced 16-byte load and twenty independent look-ups a
+// lane and row.  Workgroups of four waves share the twenty tables (20 KB of LDS: seven workgroups a CU) and stay: a wave takes
+// block after block (its number, + the grid's waves, ...), so that the tables are made once per workgroup, not per block.
+__global__ __launch_bounds__(256) void spl_crc32_wave_kernel(const uint8_t *out_all, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status)
+{
+    __shared__ uint32_t t[splcrc::W_TABLE_WORDS + splcrc::W_SCRATCH_WORDS];
+    splcrc::wave_tables(t, threadIdx.x, 256u);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t factor = splcrc::wave_lane_factor(lane);
+    const uint32_t n_waves = gridDim.x * 4u;
+    for (uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6))); b < n_blocks; b += n_waves) {
+        if (status[b] != SPL_Z_OK) continue; // (blocks that already failed keep their status)
+        const spl_zblock zb = blocks[b];
+        const uint32_t c = splcrc::wave_block(out_all + zb.out, zb.out_len, t, factor);
+        if (lane == 0u && c != zb.crc) status[b] = SPL_Z_BAD_CRC;
+    }
 }
 
 // ---- BAM records ---------------------------------------------------------------------------------------------------------
@@ -395,8 +416,14 @@ extern "C" int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *bl
 extern "C" int spl_dev_launch_crc32(const uint8_t *out, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *stream)
 {
     if (n_blocks == 0) return 0;
-    // (four streams a lane: 1.6 ms a window of 43 169 blocks against 2.0 with one and 1.5 with two; 3.5 with eight, whose 64 x 8 lines
-    //  the L1 cannot hold -- profiles/r04v_crc_streams.txt)
-    hipLaunchKernelGGL(spl_crc32_kernel<4>, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, out, blocks, n_blocks, status);
+    // SPL_CRC_LANES=1 (A/B): round 4's kernel, a block per lane as four streams (1.6 ms a window of 43 169 blocks alone, 2-4 in the pipeline)
+    static const bool per_lane = getenv("SPL_CRC_LANES") != nullptr;
+    if (per_lane) {
+        hipLaunchKernelGGL(spl_crc32_kernel<4>, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, out, blocks, n_blocks, status);
+        return (int)hipGetLastError();
+    }
+    // a block per wave, four waves a workgroup, at most six workgroups per CU's worth of grid: the waves take block after block
+    const uint32_t groups = std::min<uint32_t>((n_blocks + 3u) / 4u, 256u * 6u);
+    hipLaunchKernelGGL(spl_crc32_wave_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, out, blocks, n_blocks, status);
     return (int)hipGetLastError();
 }

@@ -56,6 +56,7 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 // Where a chunk's records go.  In memory: the chunk's slot (spl_layout_kernel).
 struct RecordsInMemory {
     static constexpr bool wants_index = false;
+    static constexpr bool clip_tier = false;   // (the layout kernel lives on its 64 registers: the clips' straight-line path would spill six of them)
     uint8_t *rec_base;
     size_t slot_bytes;
     __device__ __forceinline__ uint8_t *rec() const { return rec_base + (size_t)blockIdx.x * slot_bytes; } // (not kept across the classification: two scalar registers fewer there)
@@ -68,6 +69,7 @@ struct RecordsInMemory {
 // kernel is told when such a read is handed on.
 struct RecordsInLds {
     static constexpr bool wants_index = true;
+    static constexpr bool clip_tier = true;
     lay_lds_u8 *rec;
     lay_lds_u16 *idx;
     uint32_t base;         // of the tile in the chunk's cell
@@ -221,6 +223,25 @@ __device__ __forceinline__ void tile_finish(const spl_devreads &src, int64_t n_o
 #pragma unroll
         for (int q = 0; q < 6; ++q) w[j][q] = r.w[q];
         __builtin_amdgcn_sched_barrier(0); // (one read after the other: four chains side by side do not fit the 64 registers that keep two workgroups on a CU)
+    }
+    // ---- reads with ONE op in front and / or behind that does not consume the reference (a local aligner's soft and hard clips:
+    // a sizeable share of a real library's reads): the same straight-line decision from the ops between the clips
+    // (classify_clipped), taken by a wave only if it has such a read at all.  What is still pending afterwards -- insertions,
+    // clips on clips, long CIGARs -- goes through the general classifier below.
+    if (Sink::clip_tier && __any(pend != 0u)) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const uint32_t rel0 = co[j] - (uint32_t)ws;
+            const bool inside = rel0 + PAD <= STAGE;
+            splrec::Rec r;
+            const bool fast = splrec::classify_clipped(pos[j], flag[j], StagedOps{(lay_lds_u32 *)s_ops + (inside ? rel0 : 0u)}, co[j + 1] - co[j], co[j] - seg_op0, r);
+            const bool take = ((pend >> j) & 1u) != 0u && fast && inside;
+            runs = take ? (runs & ~(7u << (3 * j))) | (r.run << (3 * j)) : runs;
+            pend = take ? pend & ~(1u << j) : pend;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) w[j][q] = take ? r.w[q] : w[j][q];
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     for (;;) {
         if (__any(pend != 0u)) {

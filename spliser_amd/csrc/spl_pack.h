@@ -220,20 +220,23 @@ SPL_PACK_HD void finish_record(int32_t pos, uint32_t flag, uint32_t m, uint32_t 
     r.weight = simple ? SPL_W_SIMPLE : (mnm ? SPL_W_MNM : (m2 ? SPL_W_M2 : (wide ? SPL_W_WIDE : SPL_W_NARROW)));
 }
 
-// The layout kernel's straight-line path: a read of at most five ops that all consume the reference (no clips, no insertions:
-// most reads) from its first five ops o0 .. o4 -- what stands in those beyond n_all is anything (the neighbour's ops) and is
-// masked.  -> true when the read IS such a read; r is its record then (field for field classify_ops's), garbage otherwise.
+// The layout kernel's straight-line path: a read whose CIGAR is at most five ops that all consume the reference, between at most ONE
+// op in front and ONE behind that do not (soft / hard clips as a local aligner writes them: "5S95M100N50M", "70M80N75M5S" -- to
+// checkBam's walk such ops are nothing, SpliSER_v0_1_8.py:457-464).  p0 .. p4 = the ops from the first one behind the leading clip on
+// (what stands in those beyond n_eff is anything and is masked), n_eff = the ops between the clips; op0, op1, n_all = the CIGAR as
+// it stands (a WIDE record keeps its first two ops and its length as they are).  -> true when the n_eff ops ARE at most five and
+// all consume; r is the read's record then (field for field classify_ops's), garbage otherwise.
 // The five kinds side by side, two bits each: a class is one comparison of that signature.
-SPL_PACK_HD bool classify_fast5(int32_t pos, uint32_t flag, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, uint32_t o4, uint32_t n_all,
-                                uint32_t wide_index, Rec &r)
+SPL_PACK_HD bool classify_clip5(int32_t pos, uint32_t flag, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, uint32_t n_eff,
+                                uint32_t op0, uint32_t op1, uint32_t n_all, uint32_t wide_index, Rec &r)
 {
-    const uint32_t m = n_all < 5u ? n_all : 5u;
+    const uint32_t m = n_eff < 5u ? n_eff : 5u;
     const uint32_t used = (1u << (2u * m)) - 1u;
-    const uint32_t sig = (kind_of(o0) | (kind_of(o1) << 2) | (kind_of(o2) << 4) | (kind_of(o3) << 6) | (kind_of(o4) << 8)) & used;
-    const bool fast = n_all <= 5u && ((sig | (sig >> 1)) & 0x155u) == (0x155u & used); // every op of the CIGAR consumes
+    const uint32_t sig = (kind_of(p0) | (kind_of(p1) << 2) | (kind_of(p2) << 4) | (kind_of(p3) << 6) | (kind_of(p4) << 8)) & used;
+    const bool fast = n_eff <= 5u && ((sig | (sig >> 1)) & 0x155u) == (0x155u & used); // every op between the clips consumes
     const bool placed = !(flag & 4u) && pos >= 0 && pos <= (int32_t)SPL_COORD_MAX;
     const uint32_t room = (uint32_t)SPL_COORD_MAX - (uint32_t)pos;
-    const uint32_t l0 = o0 >> 4, l1 = o1 >> 4, l2 = o2 >> 4, l3 = o3 >> 4, l4 = o4 >> 4;
+    const uint32_t l0 = p0 >> 4, l1 = p1 >> 4, l2 = p2 >> 4, l3 = p3 >> 4, l4 = p4 >> 4;
     const bool lim0 = placed && l0 < 65536u;
     // (all ops consume, so a signature says how many there are: 01 = M; 01 10 01 = M N M; 01 10 01 10 01 = M N M N M)
     const bool simple = lim0 && sig == 0x1u && l0 <= room;
@@ -241,17 +244,36 @@ SPL_PACK_HD bool classify_fast5(int32_t pos, uint32_t flag, uint32_t o0, uint32_
     const bool m2 = lim0 && sig == 0x199u && l2 < 65536u && l4 < 65536u && l0 + l1 + l2 + l3 + l4 <= room;
     const bool other = !(simple || mnm || m2);
     const bool wide = m > 3u;
-    const uint32_t x0 = (wide || m > 0u) ? o0 : 0xfu, x1 = (wide || m > 1u) ? o1 : 0xfu, x2 = wide ? wide_index : (m > 2u ? o2 : 0xfu);
+    const uint32_t n_rec = wide ? (n_all < SPL_NOPS_SAT ? n_all : SPL_NOPS_SAT) : m;
+    const uint32_t x0 = wide ? op0 : (m > 0u ? p0 : 0xfu), x1 = wide ? op1 : (m > 1u ? p1 : 0xfu), x2 = wide ? wide_index : (m > 2u ? p2 : 0xfu);
     r.run = simple ? SPL_RC_SIMPLE : (mnm ? SPL_RC_MNM : (m2 ? SPL_RC_M2 : SPL_RC_OTHER));
     r.w[0] = (uint32_t)pos;
-    r.w[1] = flag | (other ? (m << 16) | ((wide ? SPL_RC_WIDE : SPL_RC_NARROW) << SPL_RC_SHIFT) : l0 << 16);
+    r.w[1] = flag | (other ? (n_rec << 16) | ((wide ? SPL_RC_WIDE : SPL_RC_NARROW) << SPL_RC_SHIFT) : l0 << 16);
     r.w[2] = other ? x0 : l1;
     r.w[3] = other ? x1 : (m2 ? l2 | (l4 << 16) : l2);
     r.w[4] = other ? x2 : l3;
-    r.w[5] = other ? m : 0u;
+    r.w[5] = other ? (wide ? n_all : m) : 0u;
     r.n_wide = wide && other ? n_all : 0u;
     r.weight = simple ? SPL_W_SIMPLE : (mnm ? SPL_W_MNM : (m2 ? SPL_W_M2 : (wide ? SPL_W_WIDE : SPL_W_NARROW)));
     return fast;
+}
+// ... without clips: the CIGAR's first five ops as they stand
+SPL_PACK_HD bool classify_fast5(int32_t pos, uint32_t flag, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, uint32_t o4, uint32_t n_all,
+                                uint32_t wide_index, Rec &r)
+{
+    return classify_clip5(pos, flag, o0, o1, o2, o3, o4, n_all, o0, o1, n_all, wide_index, r);
+}
+// ... and with them: the clips found and stepped over.  `ops` must be readable for every k < SPL_PACK_SCAN_OPS whatever the read's
+// number of ops (padded).  -> true for CIGARs of at most seven ops that are [clip] + at most five consuming ops + [clip].
+template <class Ops>
+SPL_PACK_HD bool classify_clipped(int32_t pos, uint32_t flag, const Ops &ops, uint32_t n_all, uint32_t wide_index, Rec &r)
+{
+    const uint32_t f0 = ops(0u), last = ops((n_all - 1u) & 7u);
+    const uint32_t lead = (n_all > 0u && kind_of(f0) == 0u) ? 1u : 0u;
+    const uint32_t trail = (n_all > lead && kind_of(last) == 0u) ? 1u : 0u;
+    const uint32_t n_eff = n_all - lead - trail;
+    const bool fast = classify_clip5(pos, flag, ops(lead), ops(lead + 1u), ops(lead + 2u), ops(lead + 3u), ops(lead + 4u), n_eff, f0, ops(1u), n_all, wide_index, r);
+    return fast && n_all <= 7u;
 }
 
 // bit (code) set: the op consumes the reference (M D N = X)

@@ -38,6 +38,23 @@ extern "C" int64_t classify_compare(int64_t n_reads, const int32_t *pos, const u
                 for (uint32_t q = 0; q < words && same; ++q) same = a.w[q] == f.w[q];
             }
         }
+        // ... and the path for reads with a clip in front and / or behind (classify_clipped): "mine" exactly for CIGARs of at most seven
+        // ops that are [one non-consuming op] + at most five ops that all consume + [one non-consuming op], classify_ops's record for those
+        {
+            splrec::Rec f;
+            memset(&f, 0, sizeof f);
+            const bool mine = splrec::classify_clipped(pos[i], flag[i], splrec::PtrOps{ops}, n, 12345u + (uint32_t)i, f);
+            uint32_t lo = 0, hi = n;
+            if (hi > lo && splrec::kind_of(ops[lo]) == 0u) ++lo;
+            if (hi > lo && splrec::kind_of(ops[hi - 1u]) == 0u) --hi;
+            bool all = n <= 7u && hi - lo <= 5u;
+            for (uint32_t q = lo; q < hi && all; ++q) all = splrec::kind_of(ops[q]) != 0u;
+            same = same && mine == all;
+            if (mine && all) {
+                same = same && a.run == f.run && a.n_wide == f.n_wide && a.weight == f.weight;
+                for (uint32_t q = 0; q < words && same; ++q) same = a.w[q] == f.w[q];
+            }
+        }
         if (!same) {
             if (*first_bad < 0) *first_bad = i;
             ++bad;
