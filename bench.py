@@ -512,7 +512,7 @@ def combine_leg(samples, threads):
 
 
 # ---- the line the driver parses ----------------------------------------------------------------------------------------------
-LINE_LIMIT = 5120   # bytes; the driver keeps the last 8 KB of stdout and parses the LAST line: round 3's 23 KB line was cut
+LINE_LIMIT = 6144   # bytes; the driver keeps the last 8 KB of stdout and parses the LAST line: round 3's 23 KB line was cut
 
 
 def _r(x, sig=5):
@@ -590,12 +590,14 @@ def compact_line(out, detail_name="bench_detail.json"):
     for k in ("combine", "cold_cli"):
         if out.get(k) is not None:
             line[k] = out[k].get("line", out[k]) if isinstance(out[k], dict) else out[k]
+    if out.get("other_steps"):
+        line["other_steps"] = [{k: o.get(k) for k in ("workload", "reads", "ms_per_step", "kernel_ms_avg", "frac", "bit_exact_vs_oracle")} for o in out["other_steps"]]
     line["imbalance"] = out.get("imbalance")
     line["literal_kernel_reads"] = out.get("literal_kernel_reads")
     line["detail"] = detail_name
     line = _r(line)
     text = json.dumps(line, separators=(",", ":"))
-    for victim in ("imbalance", "literal_kernel_reads", "cold_cli", "combine"):   # (never needed so far; see the docstring)
+    for victim in ("imbalance", "literal_kernel_reads", "cold_cli", "combine", "other_steps"):   # (never needed so far; see the docstring)
         if len(text) < LINE_LIMIT:
             break
         line.pop(victim, None)
@@ -622,6 +624,59 @@ def emit(out):
     sys.stdout.write("bench_detail " + detail + "\n")
     sys.stdout.write(compact_line(out, os.path.basename(name)) + "\n")
     sys.stdout.flush()
+
+
+def resident_step(ctx, items, stranded, cryptic, steps, warmup, threads):
+    """The timed step of the line for ANOTHER sample, in the same process: the BAM-native arrays of `items` resident in HBM, per
+    shard chunk map + order, the fused range kernel, literal, scan/SSE, a barrier between steps; the last step's counters and
+    doubles against the oracle on the whole sample.  -> scalars for the line's `other_steps`."""
+    from spliser_amd import native, shard
+    scode = native.STRANDED_CODE[stranded]
+    shards = shard.pack(items, concat_reads=False)
+    dev = []
+    for sh in shards:
+        soa = ctx.upload_soa([rd for rd, _ in sh.read_segments])
+        dev.append((ctx.upload_sites(sh.sites), ctx.layout_read_segments(soa, [shift for _, shift in sh.read_segments]), soa))
+    ctx.sync()
+    alg = sum(native.algorithmic_bytes(ds, dr) for ds, dr, _ in dev)
+    fused = all(dr.layout_bytes()[1] == 0 for _, dr, _ in dev)
+
+    def step():
+        for ds, dr, _ in dev:
+            dr.relayout()
+            ctx.count_launch(ds, dr, scode, 0, 0)
+            ctx.sse_launch(ds, cryptic)
+        ctx.pass_barrier()
+    for _ in range(warmup):
+        step()
+    ctx.sync()
+    ctx.kernel_timing_begin(steps * len(dev))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    elapsed = (time.perf_counter() - t0) / steps
+    kms = ctx.kernel_timing_collect(steps * len(dev) + 8)
+    counts = [ds.counters() for ds, _, _ in dev]
+    sses = [ds.sse_results() for ds, _, _ in dev]
+    for ds, dr, soa in dev:
+        dr.free()
+        soa.free()
+        ds.free()
+    _, want = run_oracle(items, scode, cryptic, threads)
+    exact = True
+    for sh, cnts, sse in zip(shards, counts, sses):
+        for chrom, (r0, r1), (e0, e1) in zip(sh.chroms, sh.site_rows, sh.edge_rows):
+            (w1, w2, w3), wsse = want[chrom]
+            exact &= np.array_equal(cnts[0][r0:r1], w1) and np.array_equal(cnts[1][r0:r1], w2) and np.array_equal(cnts[2][e0:e1], w3)
+            exact &= all(np.array_equal(g[r0:r1], w) for g, w in zip(sse, wsse))
+    n_reads = sum(rd.n for _, _, rd in items)
+    k_avg = float(np.mean(kms)) if kms else float("nan")
+    per_launch = alg / max(len(dev), 1)
+    return {"reads": n_reads, "sites": sum(arr.n for _, arr, _ in items), "shards": len(dev), "stranded": stranded, "cryptic": bool(cryptic), "fused": bool(fused),
+            "ms_per_step": elapsed * 1e3, "reads_per_sec": n_reads / elapsed, "kernel_ms_avg": k_avg,
+            "frac": per_launch / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS if kms else None, "path_frac": alg / elapsed / 1e9 / HBM_PEAK_GBS,
+            "bit_exact_vs_oracle": bool(exact)}
 
 
 def rank_items(items, scaling, world, rank):
@@ -695,6 +750,8 @@ def main():
     ap.add_argument("--combine", default="auto", choices=["auto", "on", "off"], help="auto: the config-4 leg (six samples, process x 6 + combine) "
                     "with the default workload at N = 1; on: with any workload (N = 1)")
     ap.add_argument("--combine-scale", type=float, default=1.0, help="fraction of 20 M reads per combine sample (debug)")
+    ap.add_argument("--no-other-steps", action="store_true", help="no resident steps of the other configurations (mouse paired fr + cryptic, A. thaliana, "
+                    "this workload with soft clips) behind the timed one")
     ap.add_argument("--no-cold-cli", action="store_true", help="no `python -m spliser_amd process` child processes before the GPU is touched")
     ap.add_argument("--kernel", default="ranges", choices=["ranges", "ranges_agg", "pairs"],
                     help="ranges = default product path; pairs = the literal per-(read, site) kernel")
@@ -741,6 +798,21 @@ def main():
         small.workload, small.cache = "arabidopsis", None
         wl_small = build_inputs(small, 0, 1)
     full_default = args.e2e == "auto" and rank == 0 and world == 1 and args.workload == "human" and args.scale == 1.0
+    # ... and so do the OTHER configurations whose resident step rides in the line (`other_steps`): config 5's shape (mouse, paired
+    # flags, `fr` + cryptic: the STRANDED fused instantiation), config 2 (the small leg's sample, above), and this workload with a
+    # local aligner's soft clips on three reads in ten
+    others = []
+    if rank == 0 and world == 1 and args.workload == "human" and not args.no_other_steps and args.kernel == "ranges" and args.soft_clips == 0:
+        ms = argparse.Namespace(**vars(args))
+        ms.workload, ms.cache, ms.stranded = "mouse_stranded", None, None
+        wl_m, _, items_m, stranded_m = build_inputs(ms, 0, 1)
+        others.append(("mouse_stranded fr+cryptic", items_m, stranded_m, True))
+        del wl_m
+        if wl_small is not None:
+            others.append(("arabidopsis", wl_small[2], wl_small[3], args.beta2Cryptic))
+        from spliser_amd import synth as _synth
+        clipped = [(c, arr, _synth.add_soft_clips(rd, 0.3, seed=100 + k)) for k, (c, arr, rd) in enumerate(items)]
+        others.append(("%s clipped30" % args.workload, clipped, stranded, args.beta2Cryptic))
     cmb_samples = make_combine_samples(args) if ((full_default and args.combine == "auto") or (args.combine == "on" and rank == 0 and world == 1)) else None
     shards = shard.pack(items, concat_reads=False)
     n_reads = sum(rd.n for _, _, rd in items)
@@ -911,6 +983,7 @@ def main():
     parity = None
     e2e = None
     combine_res = None
+    other_steps = None
     if rank == 0:
         t_cpu1, want = run_oracle(items, scode, args.beta2Cryptic, 1)
         exact = True
@@ -942,6 +1015,16 @@ def main():
                                                      "(Python per counted (read, site) pair, P >= %d) for SpliSER v0.1.8 on one core "
                                                      "(BASELINE.md; SpliSER_v0_1_8.py:422, :427-559)" % pairs},
                    "reference_measured": reference_measured()}
+        other_steps = []
+        if others:
+            nproc, quota = cpu_budget()
+            n_threads = max(1, min(nproc, int(round(quota)) if quota else nproc))
+            while others:
+                name, o_items, o_stranded, o_cryptic = others.pop(0)
+                res = resident_step(ctx, o_items, o_stranded, o_cryptic, max(5, min(args.steps, 20)), 2, n_threads)
+                res["workload"] = name
+                other_steps.append(res)
+                del o_items
         if args.e2e == "auto":
             nproc, quota = cpu_budget()
             n_threads = max(1, min(nproc, int(round(quota)) if quota else nproc))
@@ -1056,6 +1139,7 @@ def main():
             "parity": parity,
             "e2e": e2e,
             "combine": combine_res,
+            "other_steps": other_steps or None,
             "imbalance": imbalance,
             "literal_kernel_reads": literal_reads,
             "gen_seconds": t_gen, "upload_seconds": t_up,

@@ -27,8 +27,6 @@ def make_case(seed, stranded, dirpath=None, odd=False):
         if odd and rng.random() < 0.12:      # a junction whose two ends coincide: two sites at one position from one line (:291-292)
             r = l
         juncs.append(("c1", l, r, int(rng.integers(0, 9)), strand))
-        continue
-        juncs.append(("c1", int(positions[a]), int(positions[b]), int(rng.integers(0, 9)), strand))
     tmp = dirpath or tempfile.mkdtemp(prefix="spl_rand_")
     bed = os.path.join(tmp, "junctions.bed" if dirpath else "j.bed")
     with open(bed, "w") as fh:

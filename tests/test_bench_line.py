@@ -50,6 +50,12 @@ def canned(n_legs=9, world=1):
         "combine": {"line": {"workload": "combine6: 6 x 20 M reads", "process_s": 1.234567, "combine_s": 2.345678, "parse_s": 0.3,
                              "merge_s": 0.4, "gapfill_s": 0.5, "write_s": 0.6, "queries": 123456, "rows": 1500000, "matches_oracle": True},
                     "what": "prose " * 100},
+        "other_steps": [{"workload": "mouse_stranded fr+cryptic", "reads": 100000000, "sites": 229000, "shards": 2, "stranded": "fr", "cryptic": True, "fused": True,
+                         "ms_per_step": 1.0871234, "reads_per_sec": 9.2e10, "kernel_ms_avg": 0.48412345, "frac": 0.2421234, "path_frac": 0.2151234, "bit_exact_vs_oracle": True},
+                        {"workload": "arabidopsis", "reads": 20000000, "sites": 180000, "shards": 1, "stranded": None, "cryptic": False, "fused": True,
+                         "ms_per_step": 0.3011234, "reads_per_sec": 6.6e10, "kernel_ms_avg": 0.2211234, "frac": 0.2101234, "path_frac": 0.1561234, "bit_exact_vs_oracle": True},
+                        {"workload": "human clipped30", "reads": 200000000, "sites": 300463, "shards": 2, "stranded": None, "cryptic": False, "fused": True,
+                         "ms_per_step": 2.2011234, "reads_per_sec": 9.1e10, "kernel_ms_avg": 1.0211234, "frac": 0.2301234, "path_frac": 0.2101234, "bit_exact_vs_oracle": True}],
         "imbalance": None if world == 1 else {"reads_per_rank": [25000000] * world, "seconds_per_rank": [0.123456] * world,
                                               "max_over_mean_reads": 1.2345678},
         "literal_kernel_reads": 41234, "gen_seconds": 12.3, "upload_seconds": 1.2}
@@ -82,6 +88,9 @@ def test_compact_line_is_short_and_parses():
     assert d["combine"]["matches_oracle"] is True
     assert d["roofline"]["fused"] is True and d["roofline"]["two_kernels"]["same_counters"] is True
     assert "what" not in d["roofline"]["two_kernels"] and d["e2e"][0]["first_call_device_gb"] == 13.41
+    # the other configurations' resident steps ride in the line: config 5's shape, config 2, the clipped sample
+    assert [o["workload"] for o in d["other_steps"]] == ["mouse_stranded fr+cryptic", "arabidopsis", "human clipped30"]
+    assert all(o["bit_exact_vs_oracle"] is True and o["ms_per_step"] and o["frac"] for o in d["other_steps"])
 
 
 def test_compact_line_eight_ranks():

@@ -77,6 +77,70 @@ def test_layout_kernel_counts_like_the_oracle(seed, stranded, chunk, fused, ctx,
         assert np.array_equal(w, g)
 
 
+@pytest.mark.parametrize("seed", range(0, 8))
+@pytest.mark.parametrize("stranded", [1, 2])
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_stranded_pass_in_combine_mode(seed, stranded, fused, ctx, oracle_lib, monkeypatch):
+    """What `combine` over the kept reads of a STRANDED library takes (only the builder's fuzz had it): the stranded
+    instantiation of the fused kernel (windows of 508 distinct positions) with combine_mode = 1 -- a flanking read counts toward
+    beta2Simple (SpliSER_v0_1_8.py:529-536) -- and layout + range beside it, both chunk sizes."""
+    arr, rs = randcase.make_case(seed + 1200, True)
+    if arr.n == 0 or rs.n == 0:
+        pytest.skip("empty case")
+    big = _repeat(rs, 53)
+    ocount, _ = helpers.oracle_engine(oracle_lib)
+    want = ocount(arr, big, stranded, 1)
+    monkeypatch.setenv("SPL_FUSED", fused)
+    for chunk in ("2048", "4096"):
+        monkeypatch.setenv("SPL_FORCE_CHUNK", chunk)
+        got = _count_soa(ctx, arr, [(big, 0)], stranded, 1)
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g)
+
+
+def _with_clips(rs, seed, fraction=0.6):
+    """Soft / hard clips in front of and behind the reads' CIGARs, as a local aligner writes them: one op each side mostly, now and
+    then two (H then S), now and then an insertion inside -- POS and the aligned part stay as they are."""
+    rng = np.random.default_rng(seed)
+    off = rs.cig_off.astype(np.int64)
+    ops, offs = [], [0]
+    for i in range(rs.n):
+        mine = [int(x) for x in rs.cigar[off[i]:off[i + 1]]]
+        if rng.random() < fraction and mine:
+            how = int(rng.integers(0, 8))
+            lead = [(int(rng.integers(1, 30)) << 4) | int(rng.choice([4, 5]))] if how & 1 else []
+            trail = [(int(rng.integers(1, 30)) << 4) | int(rng.choice([4, 5]))] if how & 2 else []
+            if how == 7:
+                lead = [(3 << 4) | 5] + lead             # H S ... : two ops in front
+            if how == 4 and (mine[0] >> 4) > 4 and (mine[0] & 15) == 0:      # an insertion inside the first aligned block
+                a = mine[0] >> 4
+                mine = [((a // 2) << 4), (2 << 4) | 1, ((a - a // 2) << 4)] + mine[1:]
+            mine = lead + mine + trail
+        ops.extend(mine)
+        offs.append(len(ops))
+    return samio.ReadSet(rs.pos, rs.flag, np.array(offs, np.uint32), np.array(ops, np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(0, 10))
+@pytest.mark.parametrize("stranded", [0, 1])
+def test_clipped_reads_take_the_straight_line_path_and_count_alike(seed, stranded, ctx, oracle_lib, monkeypatch):
+    """Reads with one clip in front and / or behind are classified by the fused kernel's second straight-line tier
+    (spl_pack.h: classify_clipped); two ops in front, or an insertion inside, go on to the general classifier.  To checkBam such
+    ops are nothing (SpliSER_v0_1_8.py:457-464): the counters are the oracle's on the clipped CIGARs, and the same as layout +
+    range's (whose layout kernel has no such tier)."""
+    arr, rs = randcase.make_case(seed + 1300, bool(stranded))
+    if arr.n == 0 or rs.n == 0:
+        pytest.skip("empty case")
+    big = _with_clips(_repeat(rs, 37), seed)
+    ocount, _ = helpers.oracle_engine(oracle_lib)
+    want = ocount(arr, big, stranded, 0)
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SPL_FUSED", fused)
+        got = _count_soa(ctx, arr, [(big, 0)], stranded)
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g)
+
+
 @pytest.mark.parametrize("seed", range(0, 6))
 @pytest.mark.parametrize("combine", [0, 1])
 def test_segments_that_begin_anywhere(seed, combine, ctx, oracle_lib, monkeypatch):
