@@ -2180,13 +2180,25 @@ static int finish_reads(spl_ctx *c, spl_dreads *d)
 static int unfuse(spl_ctx *c, spl_dreads *d)
 {
     if (!d->fused) return SPL_OK;
-    d->fused = false;
+    // (the callers hold the set through a pointer to const -- a counting pass does not change what a read set IS -- and this gives
+    //  it records all the same: a set is either fused or laid out, never half of it.  Should a slot not be had, or the layout not
+    //  be launched, the slots that were got go back and the set stays fused: a later default pass counts it as before.)
     const uint32_t chunk = 1u << d->chunk_shift;
+    int rc = SPL_OK;
     for (spl_dreads::Group &g : d->groups) {
         const hipError_t e = devmem::get((void **)&g.slab, SPL_LAYOUT_SLOT(chunk) * (size_t)g.n_chunks + 256, 'R');
-        if (e != hipSuccess) return spl_set_error(SPL_ERR_HIP, "hipMalloc for the device layout of %u chunks: %s", g.n_chunks, hipGetErrorString(e));
+        if (e != hipSuccess) { rc = spl_set_error(SPL_ERR_HIP, "hipMalloc for the device layout of %u chunks: %s", g.n_chunks, hipGetErrorString(e)); break; }
     }
-    return launch_layout(c, d);
+    if (rc == SPL_OK) {
+        d->fused = false;
+        rc = launch_layout(c, d);
+    }
+    if (rc != SPL_OK) {
+        d->fused = true;
+        for (spl_dreads::Group &g : d->groups)
+            if (g.slab) { devmem::put(g.slab); g.slab = nullptr; }
+    }
+    return rc;
 }
 
 // The layout again, into the same record slots (bench.py's step: BAM-native arrays -> records -> counters, every step).

@@ -142,7 +142,7 @@ extern "C" int spl_dev_launch_layout(const spl_layout_params *p, uint32_t n_dev_
 extern "C" int spl_dev_launch_chunk_order(const uint32_t *cost, uint32_t n_chunks, uint32_t chunk, uint32_t *order, void *stream)
 {
     if (!n_chunks) return 0;
-    (void)chunk; // (costs are at most chunk * SPL_W_WIDE = 57 344: cost / 16 is below the 4096 keys for both chunk sizes)
+    (void)chunk; // (the map kernel's estimate, (3 ops + reads) / 2, has no bound of its own for long-read chunks: the order kernel's key_of clamps it to its 4096 keys)
     hipLaunchKernelGGL(spl_chunk_order_kernel, dim3(8), dim3(1024), 0, (hipStream_t)stream, cost, n_chunks, spl_order_per(n_chunks), order);
     return (int)hipGetLastError();
 }

@@ -90,8 +90,8 @@ int spl_dev_launch_bam_extract(const uint8_t *stream, uint64_t stream_len, int32
 // where the reference id changes along the placed records: (index of the first record of a run, its tid) pairs, unordered
 int spl_dev_launch_bam_bounds(const int32_t *tid, const uint32_t *cig_off, uint64_t n, uint64_t *bounds, uint32_t *n_bounds, uint32_t cap, void *stream_handle);
 // image: the whole file in device memory, readable SPL_Z_IMAGE_PAD bytes past its end; out: writable 16 bytes past the last block.
-// work: spl_dev_inflate_work_bytes(n_blocks) bytes of device memory (the blocks' token streams between the two kernels), or
-// null for round 2's one-kernel decoder.  stream: the stream to launch on.
+// work: spl_dev_inflate_work_bytes(n_blocks) bytes of device memory (the blocks' token streams between the two kernels); null is
+// an error (hipErrorInvalidValue) for every launcher that takes it.  stream: the stream to launch on.
 size_t spl_dev_inflate_work_bytes(uint32_t n_blocks);
 // ... with `stride` bytes of token room a block instead of SPL_Z_TOKEN_STRIDE (a multiple of 16; a block that needs more gets
 // SPL_Z_TOKENS): what real files' blocks need is a third of the worst case, and a first call waits for every gigabyte it is given

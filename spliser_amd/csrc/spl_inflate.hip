@@ -381,7 +381,8 @@ extern "C" size_t spl_dev_inflate_work_bytes(uint32_t n_blocks) { return spl_dev
 
 extern "C" int spl_dev_launch_inflate_decode2(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *work, uint32_t stride, void *stream)
 {
-    if (n_blocks == 0 || !work) return 0;
+    if (n_blocks == 0) return 0;
+    if (!work) return (int)hipErrorInvalidValue; // (nothing would be launched and the blocks' status words left as they were: an error, not a success)
     if (stride < 256u || stride > SPL_Z_TOKEN_STRIDE || (stride & 15u)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, status, (uint8_t *)work + tokens_at(n_blocks), (uint32_t *)work, stride);
     return (int)hipGetLastError();
@@ -389,7 +390,8 @@ extern "C" int spl_dev_launch_inflate_decode2(const uint8_t *image, const spl_zb
 
 extern "C" int spl_dev_launch_inflate_copy2(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t stride, void *stream)
 {
-    if (n_blocks == 0 || !work) return 0;
+    if (n_blocks == 0) return 0;
+    if (!work) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(spl_inflate_copy_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, blocks, n_blocks, out, status, (const uint8_t *)work + tokens_at(n_blocks),
                        (const uint32_t *)work, stride);
     return (int)hipGetLastError();

@@ -702,8 +702,8 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
     constexpr uint32_t SEG = FUSED ? SPL_WAVE_READS_FUSED : SPL_WAVE_READS;
     constexpr uint32_t CSHIFT = BIG ? SPL_CHUNK_BIG_SHIFT : SPL_CHUNK_SHIFT;
     // FUSED: the chunk's records are made here, in LDS, from the BAM-native arrays (spl_layout_tile.h: the layout kernel's body),
-    // a TILE of SPL_TILE_FUSED reads at a time, and counted from there -- they never exist in memory.  While a tile is counted the
-    // next one's reads are on their way into registers.  s_rec: first the stage of the tile's ops, then its records.
+    // a TILE of SPL_TILE_FUSED reads at a time, and counted from there -- they never exist in memory (a tile's reads are asked for
+    // when the tile before is through: asking earlier was measured and bought nothing, profiles/r05X_fused_pass.txt).  s_rec: first the stage of the tile's ops, then its records.
     constexpr uint32_t TILE = SPL_TILE_FUSED, TILES = FUSED ? (1u << CSHIFT) / TILE : 1u;
     constexpr uint32_t REC_BYTES = FUSED ? (uint32_t)SPL_LAYOUT_SLOT(TILE) : 16u;
     __shared__ uint4 s_rec[REC_BYTES / 16u];

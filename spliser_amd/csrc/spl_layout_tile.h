@@ -205,9 +205,11 @@ __device__ __forceinline__ void tile_finish(const spl_devreads &src, int64_t n_o
     for (uint32_t q = 0; q < (uint32_t)R; ++q) *(__attribute__((address_space(3))) lay_u32x4 *)(s_ops + 4u * (t + q * T)) = L.v[q];
     __syncthreads();
 
-    // ---- classify: four records in registers.  Straight-line for the reads of at most five ops that all consume the reference
-    // (classify_fast5: no branch, the four reads' chains side by side); the others -- clips, insertions, long CIGARs, ops beyond
-    // the first window -- are left pending and done by the lanes that hold them, through the general classifier.
+    // ---- classify: four records in registers.  Straight-line, no branch, the four reads' chains side by side: in the fused kernel
+    // the three plain shapes from the op codes alone (classify_plain), then -- a wave that has anything else -- every class of
+    // at most five consuming ops between at most one clip either side (classify_clipped, below); in the layout kernel the reads of
+    // at most five ops that all consume the reference (classify_fast5).  What is left -- insertions, clips on clips, long CIGARs,
+    // ops beyond the first window -- is pending and done by the lanes that hold it, through the general classifier.
     uint32_t w[R][6];
     uint32_t runs = 0, pend = 0; // run of read j: bits 3j .. 3j + 2 (4 = no read); pending: bit j
 #pragma unroll
@@ -217,7 +219,9 @@ __device__ __forceinline__ void tile_finish(const spl_devreads &src, int64_t n_o
         const bool inside = rel0 + PAD <= STAGE;
         lay_lds_u32 *o = (lay_lds_u32 *)s_ops + (inside ? rel0 : 0u);
         splrec::Rec r;
-        const bool fast = splrec::classify_fast5(pos[j], flag[j], o[0], o[1], o[2], o[3], o[4], co[j + 1] - co[j], co[j] - seg_op0, r);
+        bool fast;
+        if constexpr (Sink::clip_tier) fast = splrec::classify_plain(pos[j], flag[j], o[0], o[1], o[2], o[3], o[4], co[j + 1] - co[j], r); // (what is not one of the three plain shapes: the next tier)
+        else fast = splrec::classify_fast5(pos[j], flag[j], o[0], o[1], o[2], o[3], o[4], co[j + 1] - co[j], co[j] - seg_op0, r);
         pend |= (valid && !(fast && inside) ? 1u : 0u) << j;
         runs |= (valid ? r.run : (uint32_t)SPL_RC_RUNS) << (3 * j);
 #pragma unroll

@@ -257,6 +257,34 @@ SPL_PACK_HD bool classify_clip5(int32_t pos, uint32_t flag, uint32_t p0, uint32_
     r.weight = simple ? SPL_W_SIMPLE : (mnm ? SPL_W_MNM : (m2 ? SPL_W_M2 : (wide ? SPL_W_WIDE : SPL_W_NARROW)));
     return fast;
 }
+// The three shapes nine reads in ten have, decided from the op CODES alone: "M", "M N M", "M N M N M" with op M itself (an aligner
+// writes = and X only when asked to; those, like everything else, are the other classifiers' business).  A read that is one of the
+// three AND within the limits of its record (placed, lengths below 65536 where the record holds them in 16 bits, its end inside the
+// coordinate space) -> true and its record in r, field for field classify_ops's; false -> r is garbage.  Half the instructions of
+// classify_fast5, which decides every class from the kinds' signature: in the fused kernel this is what every read takes first.
+SPL_PACK_HD bool classify_plain(int32_t pos, uint32_t flag, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, uint32_t o4, uint32_t n_all, Rec &r)
+{
+    const bool placed = !(flag & 4u) && pos >= 0 && pos <= (int32_t)SPL_COORD_MAX;
+    const uint32_t room = (uint32_t)SPL_COORD_MAX - (uint32_t)pos;
+    const uint32_t l0 = o0 >> 4, l1 = o1 >> 4, l2 = o2 >> 4, l3 = o3 >> 4, l4 = o4 >> 4;
+    const bool m0 = placed && (o0 & 15u) == 0u && l0 < 65536u;
+    const bool mnm_codes = ((o2 & 15u) | ((o1 & 15u) ^ 3u)) == 0u;   // op 1 is N, op 2 is M
+    const bool m2_codes = ((o4 & 15u) | ((o3 & 15u) ^ 3u)) == 0u;    // op 3 is N, op 4 is M
+    const bool simple = m0 && n_all == 1u && l0 <= room;
+    const bool mnm = m0 && n_all == 3u && mnm_codes && l0 + l1 + l2 <= room;
+    const bool m2 = m0 && n_all == 5u && mnm_codes && m2_codes && l2 < 65536u && l4 < 65536u && l0 + l1 + l2 + l3 + l4 <= room;
+    r.run = simple ? SPL_RC_SIMPLE : (mnm ? SPL_RC_MNM : SPL_RC_M2);
+    r.w[0] = (uint32_t)pos;
+    r.w[1] = flag | l0 << 16;
+    r.w[2] = l1;
+    r.w[3] = m2 ? l2 | (l4 << 16) : l2;
+    r.w[4] = l3;
+    r.w[5] = 0u;
+    r.n_wide = 0u;
+    r.weight = simple ? SPL_W_SIMPLE : (mnm ? SPL_W_MNM : SPL_W_M2);
+    return simple || mnm || m2;
+}
+
 // ... without clips: the CIGAR's first five ops as they stand
 SPL_PACK_HD bool classify_fast5(int32_t pos, uint32_t flag, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, uint32_t o4, uint32_t n_all,
                                 uint32_t wide_index, Rec &r)

@@ -260,8 +260,8 @@ def process_sites(table, source, q_chrom, is_stranded, stranded_type, is_beta2_c
                             dr.finish()
                             stamp("read set finished")
                             if k_sh + 1 < len(shards):
-                                lay_out(k_sh + 1)  # (the next shard's layout kernels run while this one is counted and brought down -- put on their
-                                                   #  stream only now: this shard's chunk descriptors come down the same stream, and stood behind them)
+                                lay_out(k_sh + 1)  # (the next shard's segments are noted while this one is counted and brought down; since the fused
+                                                   #  pass nothing is launched for them before their own finish())
                             ctx.count_launch(ds, dr, stranded, combine_mode)
                             ctx.sse_launch(ds, is_beta2_cryptic)
                             beta1, b2r, dbl = ds.counters()

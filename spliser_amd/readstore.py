@@ -18,9 +18,27 @@ import numpy as np
 from . import samio
 
 MAGIC = b"SPLREADS"
-VERSION = 1
+VERSION = 2       # (2: the payload's checksum in the header)
 SUFFIX = ".SpliSER.reads"
 _EDGE = 65536
+_PIECE = 16 << 20
+
+
+def _digest(view):
+    """64 bits over a piece of the payload: xxh3 (10 GB/s, and it leaves the interpreter's lock) where the module is there, CRC32 otherwise."""
+    try:
+        import xxhash
+        return xxhash.xxh3_64_intdigest(view)
+    except ImportError:
+        return zlib.crc32(view) & 0xFFFFFFFF
+
+
+def _payload_sum(pieces, threads=8):
+    """The payload's checksum: the pieces' digests (16 MB each, taken side by side on a few threads) hashed in file order."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+        digests = list(pool.map(_digest, pieces))
+    return "%016x" % _digest(struct.pack("<%dQ" % len(digests), *digests))
 
 
 def path_for_tsv(tsv_path):
@@ -49,8 +67,9 @@ def save(path, bam_path, reads_by_ref, threads=8):
     size, mtime_ns, crc = bam_key(bam_path)
     refs = [{"name": name, "n": int(rs.n), "ops": int(rs.cig_off[rs.n]) - int(rs.cig_off[0]) if rs.n else 0, "max_end": int(rs.max_end)}
             for name, rs in reads_by_ref]
-    head = json.dumps({"version": VERSION, "bam_size": size, "bam_mtime_ns": mtime_ns, "bam_crc32": crc, "refs": refs}).encode("utf-8")
-    fixed = MAGIC + struct.pack("<II", VERSION, len(head)) + head
+    head_of = lambda digest: json.dumps({"version": VERSION, "bam_size": size, "bam_mtime_ns": mtime_ns, "bam_crc32": crc, "payload_sum": digest,   # noqa: E731
+                                         "refs": refs}).encode("utf-8")
+    fixed = MAGIC + struct.pack("<II", VERSION, len(head_of("0" * 16))) + head_of("0" * 16)     # (its length does not depend on the digest)
     at = len(fixed) + (-len(fixed) % 64)
     jobs = []      # (file offset, contiguous array)
     for kind, dt in (("pos", np.int32), ("flag", np.uint16), ("cig_off", np.uint32), ("cigar", np.uint32)):
@@ -74,9 +93,11 @@ def save(path, bam_path, reads_by_ref, threads=8):
     fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
     try:
         os.ftruncate(fd, at)
-        os.pwrite(fd, fixed, 0)
-        piece = 16 << 20
+        piece = _PIECE
         parts = [(off + lo, memoryview(a).cast("B")[lo:lo + piece]) for off, a in jobs for lo in range(0, a.nbytes, piece)]
+        # the checksum of what goes out, array by array in pieces of 16 MB (what open_if_fresh takes again, the same way)
+        head = head_of(_payload_sum([v for _, v in parts], threads))
+        os.pwrite(fd, MAGIC + struct.pack("<II", VERSION, len(head)) + head, 0)
 
         def put(part):
             off, view = part
@@ -110,9 +131,23 @@ class ReadStore(object):
             return a
         pos, flag = take(n_all, np.int32), take(n_all, np.uint16)
         cig_off, cigar = take(n_all + len(refs), np.uint32), take(ops_all, np.uint32)
+        # The payload is what the header's checksum says, and every reference's CIGAR offsets begin at 0, never step back and end at
+        # its number of ops: whoever walks cigar[cig_off[i] .. cig_off[i + 1]) (the native packer does, without asking) stays inside
+        # the file.  ValueError: the caller decodes the BAM instead.
+        pieces, b = [], {"pos": 0, "flag": 0, "cig_off": 0, "cigar": 0}     # (the pieces `save` took: array by array, reference by reference)
+        for kind, arr, per in (("pos", pos, lambda r: r["n"]), ("flag", flag, lambda r: r["n"]), ("cig_off", cig_off, lambda r: r["n"] + 1), ("cigar", cigar, lambda r: r["ops"])):
+            for r in refs:
+                a = arr[b[kind]:b[kind] + per(r)]
+                b[kind] += per(r)
+                pieces.extend(memoryview(a).cast("B")[lo:lo + _PIECE] for lo in range(0, a.nbytes, _PIECE))
+        if _payload_sum(pieces) != head.get("payload_sum"):
+            raise ValueError("%s: the payload is not what its checksum says" % path)
         r0 = o0 = c0 = 0
         for r in refs:
             n, ops = r["n"], r["ops"]
+            off = cig_off[c0:c0 + n + 1]
+            if int(off[0]) != 0 or int(off[n]) != ops or (n and not bool(np.all(off[1:] >= off[:-1]))):
+                raise ValueError("%s: CIGAR offsets of %s are not those of %d ops" % (path, r["name"], ops))
             self._sets[r["name"]] = samio.ReadSet(pos[r0:r0 + n], flag[r0:r0 + n], cig_off[c0:c0 + n + 1], cigar[o0:o0 + ops], max_end=r["max_end"])
             r0, o0, c0 = r0 + n, o0 + ops, c0 + n + 1
         self.n_reads = n_all
@@ -142,6 +177,8 @@ def open_if_fresh(path, bam_path):
             if (head.get("bam_size"), head.get("bam_mtime_ns"), head.get("bam_crc32")) != bam_key(bam_path):
                 return None
             refs = head["refs"]
+            if any(not isinstance(r.get("n"), int) or not isinstance(r.get("ops"), int) or r["n"] < 0 or r["ops"] < 0 for r in refs):
+                return None
             n_all, ops_all = sum(r["n"] for r in refs), sum(r["ops"] for r in refs)
             need = 16 + head_len
             need += -need % 64

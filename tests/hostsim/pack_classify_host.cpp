@@ -55,6 +55,20 @@ extern "C" int64_t classify_compare(int64_t n_reads, const int32_t *pos, const u
                 for (uint32_t q = 0; q < words && same; ++q) same = a.w[q] == f.w[q];
             }
         }
+        // ... and the first thing the fused kernel asks (classify_plain): "mine" for the reads that are M, M N M or M N M N M with op M
+        // itself and get a record of those runs; classify_ops's record then
+        {
+            splrec::Rec f;
+            memset(&f, 0, sizeof f);
+            const bool mine = splrec::classify_plain(pos[i], flag[i], ops[0], ops[1], ops[2], ops[3], ops[4], n, f);
+            bool shape = (n == 1u || n == 3u || n == 5u) && a.run != SPL_RC_OTHER;
+            for (uint32_t q = 0; q < n && shape; ++q) shape = (ops[q] & 15u) == ((q & 1u) ? 3u : 0u);
+            same = same && mine == shape;
+            if (mine && shape) {
+                same = same && a.run == f.run && a.n_wide == f.n_wide && a.weight == f.weight;
+                for (uint32_t q = 0; q < words && same; ++q) same = a.w[q] == f.w[q];
+            }
+        }
         if (!same) {
             if (*first_bad < 0) *first_bad = i;
             ++bad;

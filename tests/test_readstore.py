@@ -120,3 +120,40 @@ def test_combine_takes_kept_reads_and_ignores_stale_ones(tmp_path):
     assert open(str(tmp_path / "stale.combined.tsv"), "rb").read() == open(str(tmp_path / "stale_bams.combined.tsv"), "rb").read()
     assert open(str(tmp_path / "stale.combined.tsv"), "rb").read() != open(str(tmp_path / "kept.combined.tsv"), "rb").read()
     process.wait_deferred_close()
+
+
+def test_a_damaged_payload_is_not_taken(tmp_path):
+    """a file of the right size and the right key whose payload is damaged -- a flipped byte among the CIGAR ops, CIGAR
+    offsets that step back or end elsewhere than the reference's number of ops, negative counts in the header -- is not a source
+    of reads: ``open_if_fresh`` gives None (and ``combine`` decodes the BAM)."""
+    import json
+    import struct
+    wl, bam = _sample(tmp_path)
+    path = str(tmp_path / "s.SpliSER.reads")
+    sets = [(c, wl.reads[i]) for i, c in enumerate(wl.genome.chrom_names)]
+    readstore.save(path, bam, sets)
+    whole = bytearray(open(path, "rb").read())
+    assert readstore.open_if_fresh(path, bam) is not None
+    # one byte of the last array (the CIGAR ops)
+    bad = bytearray(whole)
+    bad[len(bad) - 200] ^= 0x10
+    open(path, "wb").write(bad)
+    assert readstore.open_if_fresh(path, bam) is None
+    # the header's counts made negative (same length of text: "n": 12 -> "n": -2 is not, so: rewrite the header whole)
+    head_len = struct.unpack("<I", whole[12:16])[0]
+    head = json.loads(whole[16:16 + head_len].decode("utf-8"))
+    head["refs"][0]["n"] = -head["refs"][0]["n"]
+    text = json.dumps(head).encode("utf-8")
+    if len(text) <= head_len:
+        text = text + b" " * (head_len - len(text))
+        open(path, "wb").write(whole[:16] + text + whole[16 + head_len:])
+        assert readstore.open_if_fresh(path, bam) is None
+    # CIGAR offsets that step back, the checksum made to fit them (a writer's bug rather than a damaged disk)
+    rs = sets[0][1]
+    off = rs.cig_off[:rs.n + 1].copy()
+    off[rs.n // 2] = off[rs.n // 2 + 1] + 7
+    broken = [(sets[0][0], samio.ReadSet(rs.pos, rs.flag, off, rs.cigar, max_end=rs.max_end))] + sets[1:]
+    readstore.save(path, bam, broken)
+    assert readstore.open_if_fresh(path, bam) is None
+    readstore.save(path, bam, sets)
+    assert readstore.open_if_fresh(path, bam) is not None
