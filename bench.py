@@ -52,17 +52,34 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def build_inputs(args, rank, world):
-    """-> (workload, table, items [(chrom, ChromArrays, ReadSet)], stranded)"""
+    """-> (workload, table, items [(chrom, ChromArrays, ReadSet)], stranded).
+
+    Strong scaling with several ranks: ONE sample, cut into `world` stretches of equal numbers of reads in file order, a chromosome
+    cut anywhere (synth.strong_plan: what `process --gpus N` does to a BAM file); a rank generates the chromosomes its stretch
+    touches and nothing else (the same reads the whole sample has there), builds the site tables of those, and its items are
+    its PIECES: (chromosome, the chromosome's whole table, the rank's stretch of its reads).  args.strong_pieces then says which."""
     from spliser_amd import fast_sites, sites, synth
     cfg = synth.WORKLOADS[args.workload]
     stranded = args.stranded or ("fr" if cfg.get("paired") else None)
     seed = cfg["seed"] + (rank if args.scaling == "weak" else 0)
+    pieces = None
+    if args.scaling == "strong" and world > 1:
+        n_genes = max(2, int(cfg["n_genes"] * (args.scale if args.scale < 1.0 else 1.0))) if args.genes is None else args.genes
+        genome = synth.make_genome(cfg["chroms"], n_genes, cfg["intron"], seed=seed, alt_fraction=cfg.get("alt_fraction", 0.3) if args.alt_fraction is None else args.alt_fraction)
+        expected = synth.expected_reads_per_chrom(genome, int(cfg["n_reads"] * args.scale))
+        plan = synth.strong_plan(expected, world)
+        pieces = plan[rank]
+        wl = synth.Workload(args.workload, scale=args.scale, seed=seed, genome=genome, keep_chroms=sorted(set(c for c, _, _ in pieces)),
+                            workers=max(1, min(32, (os.cpu_count() or 1) // max(world, 1))))
+        args.strong_pieces = {"plan": plan, "expected_reads": [float(e) for e in expected]}
     cache = None
     if args.cache:
         os.makedirs(args.cache, exist_ok=True)
         cache = os.path.join(args.cache, "%s_s%g_seed%d%s.npz" % (args.workload, args.scale, seed,
                                                                    "" if args.genes is None else "_g%d" % args.genes))
-    if cache and os.path.exists(cache):
+    if pieces is not None:
+        pass
+    elif cache and os.path.exists(cache):
         wl = synth.Workload.load(cache, args.workload)
     else:
         over = {} if args.alt_fraction is None else {"alt_fraction": args.alt_fraction}
@@ -84,6 +101,13 @@ def build_inputs(args, rank, world):
         table.find_competitors()
     shutil.rmtree(tmp, ignore_errors=True)
     items = []
+    if pieces is not None:
+        for ci, f0, f1 in pieces:
+            c, rs = wl.genome.chrom_names[ci], wl.reads[ci]
+            arr = table.chrom_arrays(c)
+            if arr.n:
+                items.append((c, arr, rs.take(int(f0 * rs.n), rs.n if f1 >= 1.0 else int(f1 * rs.n))))
+        return wl, table, items, stranded
     for i, c in enumerate(wl.genome.chrom_names):
         arr = table.chrom_arrays(c)
         if arr.n:
@@ -276,6 +300,9 @@ def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode
                                  gpuDecode=gpu_decode, devices=tuple(devs))
             wall = time.perf_counter() - t0
             closing = process.wait_deferred_close()     # (the file's unmapping, on a thread of its own: not into the next call's opening)
+            share = tm.pop("share_bytes", None)
+            if share and len(devs) > 1:     # the plan of a decode in shares: how even the devices' stretches of the file are
+                out["share_plan"] = {"shares": len(share), "file_bytes": share, "max_over_mean_bytes": max(share) / (sum(share) / len(share))}
             return dict(wall_s=wall, reads_per_sec=n_reads / wall, bam_decode=tm.pop("bam_decode", "host"),
                         stages={k2: round(v, 4) for k2, v in tm.items()}, deferred_close_s=round(closing, 4))
         import torch
@@ -548,6 +575,8 @@ def compact_e2e(leg):
     cmp_ = leg.get("compared_with")
     if cmp_:
         out["one_device_wall_s"] = cmp_.get("wall_s")
+    if leg.get("share_plan"):
+        out["shares"], out["share_max_over_mean"] = leg["share_plan"]["shares"], leg["share_plan"]["max_over_mean_bytes"]
     return {k: v for k, v in out.items() if v is not None}
 
 
@@ -679,22 +708,34 @@ def resident_step(ctx, items, stranded, cryptic, steps, warmup, threads):
             "bit_exact_vs_oracle": bool(exact)}
 
 
-def rank_items(items, scaling, world, rank):
-    """The chromosomes rank `rank` of `world` works on.  strong (`process --gpus N`): ONE sample, its chromosomes dealt to the
-    ranks by reads + sites, longest first (shard.assign) -- every chromosome to exactly one rank; weak: every rank its own sample."""
-    from spliser_amd import shard
-    if scaling == "strong" and world > 1:
-        mine = set(shard.assign({c: rd.n + arr.n for c, arr, rd in items}, world)[rank])
-        return [it for it in items if it[0] in mine]
-    return items
+def rank_pieces(items, world, rank, expected=None):
+    """The pieces rank `rank` of `world` works on in a strong-scaling run, from the WHOLE sample's items [(chromosome, table, reads)]
+    in file order: the sample's reads cut into `world` stretches of equal numbers (synth.strong_plan over `expected` reads per
+    chromosome -- the real numbers when none are given), a chromosome cut anywhere -> [(chromosome, the chromosome's whole table,
+    the rank's stretch of its reads)].  Every read is in exactly one rank's pieces; what a rank counts are PARTIAL counters of its
+    chromosomes (checkBam only ever adds one per read, SpliSER_v0_1_8.py:519-559: the ranks' counters add up to the sample's).
+    main() does the same without ever holding the whole sample (build_inputs); this is the statement the CPU tests hold."""
+    from spliser_amd import synth
+    exp = [float(rd.n) for _, _, rd in items] if expected is None else list(expected)
+    out = []
+    for ci, f0, f1 in synth.strong_plan(exp, world)[rank]:
+        c, arr, rd = items[ci]
+        out.append((c, arr, rd.take(int(f0 * rd.n), rd.n if f1 >= 1.0 else int(f1 * rd.n))))
+    return out
 
 
-def reduce_report(dist, rank, world, n_reads, n_sites, elapsed, device):
-    """The report's only collectives: MAX of the ranks' times, SUM of their units, the per-rank table (imbalance).
+def reduce_report(dist, rank, world, n_reads, n_sites, elapsed, device, exact=None):
+    """The report's only collectives: MAX of the ranks' times, SUM of their units, the per-rank table (imbalance) -- and, where
+    every rank has checked its own counters against the oracle (`exact`), whether ALL did (imbalance["all_ranks_exact"]).
     -> (elapsed over ranks, reads of all ranks, sites of all ranks, imbalance)."""
     import torch
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = None
+    if exact is not None:
+        e = torch.tensor([1.0 if exact else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(e, op=dist.ReduceOp.MIN)
+        ok = bool(e.item() > 0.5)
     c = torch.tensor([float(n_reads), float(n_sites)], dtype=torch.float64, device=device)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     per = torch.zeros(world, 2, dtype=torch.float64, device=device)
@@ -703,6 +744,8 @@ def reduce_report(dist, rank, world, n_reads, n_sites, elapsed, device):
     imbalance = {"reads_per_rank": [int(v) for v in per[:, 0].tolist()],
                  "seconds_per_rank": [round(float(v), 6) for v in per[:, 1].tolist()],
                  "max_over_mean_reads": float(per[:, 0].max() / per[:, 0].mean()) if float(per[:, 0].sum()) > 0 else None}
+    if ok is not None:
+        imbalance["all_ranks_exact"] = ok
     return float(t.item()), float(c[0].item()), float(c[1].item()), imbalance
 
 
@@ -788,9 +831,15 @@ def main():
 
     # ---- synthetic sample of this rank (generated BEFORE the GPU is touched: the generator forks) -----
     t_gen = time.perf_counter()
-    wl, table, items, stranded = build_inputs(args, rank, world)
-    all_items = items
-    items = rank_items(items, args.scaling, world, rank)   # `process --gpus N`: chromosomes by read count, longest first
+    wl, table, items, stranded = build_inputs(args, rank, world)   # (strong scaling, N > 1: the rank's own stretch of ONE sample, and nothing else of it)
+    strong = getattr(args, "strong_pieces", None)
+    # N > 1: rank 0's end-to-end legs (process(devices = all the node's GPUs) on ONE file, after the collectives) have a sample of
+    # their own -- config 2's shape, five chromosomes: what whole-reference shares could give five GPUs at most
+    wl_e2e = None
+    if args.e2e == "auto" and rank == 0 and world > 1:
+        small = argparse.Namespace(**vars(args))
+        small.workload, small.cache, small.scaling = "arabidopsis", None, "weak"
+        wl_e2e = build_inputs(small, 0, 1)
     # the e2e leg of the smaller configuration wants a sample of its own: generated now, for the same reason
     wl_small = None
     if args.e2e == "auto" and rank == 0 and world == 1 and args.workload == "human" and args.scale == 1.0 and not args.no_small_leg:
@@ -817,6 +866,9 @@ def main():
     shards = shard.pack(items, concat_reads=False)
     n_reads = sum(rd.n for _, _, rd in items)
     n_sites = sum(arr.n for _, arr, _ in items)
+    if strong is not None:     # (a cut chromosome's sites are counted against by several ranks: each its share of them, so that the ranks' sums are the sample's)
+        share = {wl.genome.chrom_names[ci]: (f1 - f0) for ci, f0, f1 in strong["plan"][rank]}
+        n_sites = sum(arr.n * share.get(c, 1.0) for c, arr, _ in items)
     t_gen = time.perf_counter() - t_gen
 
     # ---- the command line as users run it, BEFORE this process touches the GPU: the files of the sequence-like legs are written now
@@ -967,7 +1019,21 @@ def main():
     imbalance = None
     my_elapsed = elapsed
     if dist is not None:
-        elapsed, tot_reads, tot_sites, imbalance = reduce_report(dist, rank, world, n_reads, n_sites, my_elapsed, red_device)
+        exact_rank = None
+        if strong is not None:
+            # every rank holds its own stretch against the oracle: the PARTIAL counters of its pieces (and what findBeta2Counts +
+            # calculateSSE make of them) are what the oracle gives for the same reads against the same tables
+            nproc, quota = cpu_budget()
+            _, want_mine = run_oracle(items, scode, args.beta2Cryptic, max(1, int((quota or nproc) // world)))
+            exact_rank = True
+            for sh, cnts, sses in zip(shards, gpu_counts, gpu_sse):
+                for chrom, (r0, r1), (e0, e1) in zip(sh.chroms, sh.site_rows, sh.edge_rows):
+                    (w1, w2, w3), wsse = want_mine[chrom]
+                    exact_rank &= np.array_equal(cnts[0][r0:r1], w1) and np.array_equal(cnts[1][r0:r1], w2) and np.array_equal(cnts[2][e0:e1], w3)
+                    exact_rank &= all(np.array_equal(g[r0:r1], w) for g, w in zip(sses, wsse))
+        elapsed, tot_reads, tot_sites, imbalance = reduce_report(dist, rank, world, n_reads, n_sites, my_elapsed, red_device, exact=exact_rank)
+        if strong is not None:
+            imbalance["split"] = "one sample cut into %d stretches of equal expected reads in file order, chromosomes cut anywhere; every rank generated its own stretch only" % world
         # the collectives are over: what follows (parity, the end-to-end legs over ALL the node's GPUs) is rank 0's alone, the other
         # ranks give their GPUs back
         dist.barrier()
@@ -994,6 +1060,9 @@ def main():
                 exact &= all(np.array_equal(g[r0:r1], w) for g, w in zip(sses, wsse))
         parity = {"reads": n_reads, "sites": n_sites, "bit_exact_vs_oracle": bool(exact), "of": "the last timed step",
                   "checked": "beta1, beta2Simple(reads), double counts, beta2Simple, beta2Cryptic, beta2Weighted, SSE"}
+        if imbalance is not None and "all_ranks_exact" in imbalance:     # (strong scaling: every rank checked its own stretch's partial counters)
+            parity.update(reads=int(tot_reads), sites=int(round(tot_sites)), bit_exact_vs_oracle=bool(exact and imbalance["all_ranks_exact"]),
+                          of="the last timed step, every rank its own stretch of the sample (partial counters of cut chromosomes)")
         if world == 1 and not args.no_cpu_baseline:
             nproc, quota = cpu_budget()
             n_threads = max(1, min(nproc, int(round(quota)) if quota else nproc))
@@ -1028,16 +1097,20 @@ def main():
         if args.e2e == "auto":
             nproc, quota = cpu_budget()
             n_threads = max(1, min(nproc, int(round(quota)) if quota else nproc))
-            want_all = want if len(all_items) == len(items) else run_oracle(all_items, scode, args.beta2Cryptic, n_threads)[1]
             # (N > 1: the sequence-like file only -- rank 0 runs these legs alone after the collectives, on all the node's GPUs and
             #  once more on one, and the driver's window for the scaling run is not known to be longer than the one-GPU run's)
             modes = [args.e2e_seq_mode] if args.e2e_seq_mode is not None else ([1, 2, 0] if world == 1 else [1])
-            devs = tuple(range(world))
+            devs = tuple(d % max(n_dev, 1) for d in range(world))     # (--share-devices: the ranks' devices, as the ranks took them)
             e2e = []
-            for q in modes:     # (first the file that deflates like a real library's: the leg that says what the product does)
-                e2e.append(e2e_leg(args.workload, wl, all_items, stranded, args.beta2Cryptic, q, args.e2e_reps, want_all, devices=devs,
-                                   cpu_e2e=(world == 1 and q == 1 and not args.no_cpu_baseline), compare_devices=(0,) if world > 1 else None,
+            for q in modes if world == 1 else []:     # (first the file that deflates like a real library's: the leg that says what the product does)
+                e2e.append(e2e_leg(args.workload, wl, items, stranded, args.beta2Cryptic, q, args.e2e_reps, want, devices=devs,
+                                   cpu_e2e=(q == 1 and not args.no_cpu_baseline),
                                    files=pre_files.pop(args.workload, None) if q == 1 else None, cold=cold.get(args.workload) if q == 1 else None))
+            if wl_e2e is not None:     # N > 1: ONE file on all the node's GPUs, every device its own stretch of it -- beside the same call on one
+                wl2, _, items2, stranded2 = wl_e2e
+                _, want2 = run_oracle(items2, native.STRANDED_CODE[stranded2], args.beta2Cryptic, n_threads)
+                for q in modes:
+                    e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, q, args.e2e_reps, want2, devices=devs, compare_devices=(0,)))
             if wl_small is not None:
                 wl2, _, items2, stranded2 = wl_small
                 _, want2 = run_oracle(items2, native.STRANDED_CODE[stranded2], args.beta2Cryptic, n_threads)

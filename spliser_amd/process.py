@@ -516,6 +516,8 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
             closer.start()
             _closers[:] = [t for t in _closers if t.is_alive()] + [closer]
     timings["bam_decode"] = "device" if getattr(source, "on_device", False) else "host"
+    if getattr(source, "share_bytes", None):     # (a decode in shares: the file bytes of each device's stretch -- the plan's balance)
+        timings["share_bytes"] = [int(b) for b in source.share_bytes]
     timings.update(open_s=t_open - t0, site_table_s=t1 - t_open, step3_s=t3 - t1, write_tail_s=t4 - t3, write_s=writer.seconds,
                    close_s=time.perf_counter() - t4, total_s=time.perf_counter() - t0)
     if os.environ.get("SPL_PROCESS_TIMING"):

@@ -60,6 +60,16 @@ class ReadSet(object):
         ref_len = csum[self.cig_off[1:].astype(np.int64)] - csum[self.cig_off[:-1].astype(np.int64)]
         return int((self.pos.astype(np.int64) + np.maximum(ref_len, 1) - 1).max())
 
+    def take(self, lo, hi):
+        """Reads [lo, hi) as a ReadSet of their own (views where the arrays allow; the CIGAR offsets begin at 0 again; the bound on
+        their ends is the whole set's, which it cannot exceed)."""
+        lo, hi = max(0, int(lo)), min(self.n, int(hi))
+        if hi <= lo:
+            return ReadSet.empty()
+        o0, o1 = int(self.cig_off[lo]), int(self.cig_off[hi])
+        off = self.cig_off[lo:hi + 1] if o0 == 0 else (self.cig_off[lo:hi + 1].astype(np.int64) - o0).astype(np.uint32)
+        return ReadSet(self.pos[lo:hi], self.flag[lo:hi], off, self.cigar[o0:o1], max_end=self.max_end)
+
     @classmethod
     def empty(cls):
         return cls(np.zeros(0, np.int32), np.zeros(0, np.uint16), np.zeros(1, np.uint32), np.zeros(0, np.uint32), 0)

@@ -134,9 +134,52 @@ def _paired_flags(rng, n, gene_minus):
     return flag
 
 
-def make_reads(genome, n_reads, seed=0, read_len=READ_LEN, genomic_fraction=0.10, paired=False, stranded_single=False):
+def expected_reads_per_chrom(genome, n_reads, read_len=READ_LEN, genomic_fraction=0.10):
+    """What ``make_reads`` draws per chromosome ON AVERAGE (the isoform and gene weights it samples from, summed by chromosome):
+    deterministic, no read is made.  What bench.py's strong-scaling plan cuts the sample by before any rank has generated it."""
+    g = genome
+    ex_len = g.ex_end - g.ex_start + 1
+    csum = np.concatenate(([0], np.cumsum(ex_len)))
+    iso_tlen = csum[g.iso_off[1:]] - csum[g.iso_off[:-1]]
+    w = g.iso_weight * np.maximum(iso_tlen - read_len + 1, 0)
+    n_chr = len(g.chrom_names)
+    n_gen = int(round(n_reads * genomic_fraction))
+    tx = np.bincount(g.gene_chrom[g.iso_gene], weights=w, minlength=n_chr)
+    gw = np.bincount(g.iso_gene, weights=g.iso_weight, minlength=len(g.gene_start)) * np.maximum(g.gene_end - g.gene_start + 1, 1)
+    gen = np.bincount(g.gene_chrom, weights=gw, minlength=n_chr)
+    return (n_reads - n_gen) * tx / max(tx.sum(), 1e-300) + n_gen * gen / max(gen.sum(), 1e-300)
+
+
+def strong_plan(expected, world):
+    """ONE sample cut into ``world`` stretches of equal (expected) numbers of reads in file order -- chromosome after chromosome,
+    a chromosome cut anywhere: what `process --gpus N` does to a BAM (spl_bam_share_plan), for bench.py's resident step.
+    -> per rank [(chromosome index, f0, f1)]: the rank's piece of that chromosome is its reads [floor(f0 n), floor(f1 n)) of the n
+    it really has.  Every rank makes the same plan; every read is in exactly one piece."""
+    total = float(np.sum(expected))
+    plan = [[] for _ in range(world)]
+    if total <= 0:
+        return plan
+    at = 0.0
+    for c, e in enumerate(expected):
+        e = float(e)
+        if e <= 0:
+            continue
+        for r in range(world):
+            lo, hi = max(at, total * r / world), min(at + e, total * (r + 1) / world)
+            if hi > lo:
+                f0, f1 = (lo - at) / e, (hi - at) / e
+                plan[r].append((c, 0.0 if lo <= at else f0, 1.0 if hi >= at + e else f1))
+        at += e
+    return plan
+
+
+def make_reads(genome, n_reads, seed=0, read_len=READ_LEN, genomic_fraction=0.10, paired=False, stranded_single=False, keep_chroms=None):
     """Sample reads.  (1 - genomic_fraction) come from isoforms (spliced where they cross exon edges),
-    the rest are unspliced genomic reads inside gene spans (pre-mRNA / retained introns -> beta1)."""
+    the rest are unspliced genomic reads inside gene spans (pre-mRNA / retained introns -> beta1).
+
+    ``keep_chroms`` (a set of chromosome indexes): the SAME sample's reads on those chromosomes only -- every random number is
+    drawn as for the whole sample, the reads of other chromosomes are dropped before their CIGARs are made (most of the work):
+    what a rank of a strong-scaling run generates of a sample it shares with the other ranks."""
     rng = np.random.default_rng(seed)
     g = genome
     ex_len = g.ex_end - g.ex_start + 1
@@ -155,6 +198,14 @@ def make_reads(genome, n_reads, seed=0, read_len=READ_LEN, genomic_fraction=0.10
     iso = np.searchsorted(cw, rng.random(n_tx) * cw[-1], side="right")
     iso = np.minimum(iso, n_iso - 1)
     x = (rng.random(n_tx) * usable[iso]).astype(np.int64)           # transcript offset of the read start
+    keep_tx = keep_gen = None
+    if keep_chroms is not None:
+        # (the genomic reads' and the flags' numbers are drawn further down from the same stream: drawn in full there too)
+        in_set = np.zeros(len(g.chrom_names), bool)
+        in_set[list(keep_chroms)] = True
+        keep_tx = in_set[g.gene_chrom[g.iso_gene[iso]]]
+        iso, x = iso[keep_tx], x[keep_tx]
+        n_tx = int(keep_tx.sum())
     # first exon: largest e in the isoform with ex_tstart[e] <= x  (global searchsorted on a monotone key)
     big = int(iso_tlen.max()) + 1
     key_ex = ex_iso * big + ex_tstart
@@ -195,6 +246,10 @@ def make_reads(genome, n_reads, seed=0, read_len=READ_LEN, genomic_fraction=0.10
     gg = np.minimum(np.searchsorted(cg, rng.random(n_gen) * cg[-1], side="right"), len(gw) - 1)
     gpos = g.gene_start[gg] - read_len // 2 + (rng.random(n_gen) * (g.gene_end[gg] - g.gene_start[gg] + 1)).astype(np.int64)
     gpos = np.maximum(gpos, 1)
+    if keep_chroms is not None:
+        keep_gen = in_set[g.gene_chrom[gg]]
+        gg, gpos = gg[keep_gen], gpos[keep_gen]
+        n_gen = int(keep_gen.sum())
 
     all_gene = np.concatenate((gene, gg))
     all_pos = np.concatenate((pos, gpos))
@@ -202,7 +257,17 @@ def make_reads(genome, n_reads, seed=0, read_len=READ_LEN, genomic_fraction=0.10
     chrom = g.gene_chrom[all_gene]
     minus = g.gene_strand[all_gene] == ord("-")
     n = n_reads
-    if paired:
+    if keep_chroms is not None:     # the flags' random numbers for ALL reads of the sample, then this subset's
+        keep_all = np.concatenate((keep_tx, keep_gen))
+        n = int(keep_all.sum())
+        if paired:
+            first = (rng.random(n_reads) < 0.5)[keep_all]
+            flag = np.where(minus, np.where(first, 83, 163), np.where(first, 99, 147)).astype(np.uint16)
+        elif stranded_single:
+            flag = np.where(minus, 16, 0).astype(np.uint16)
+        else:
+            flag = np.where((rng.random(n_reads) < 0.5)[keep_all], 16, 0).astype(np.uint16)
+    elif paired:
         flag = _paired_flags(rng, n, minus)
     elif stranded_single:
         flag = np.where(minus, 16, 0).astype(np.uint16)
@@ -300,8 +365,8 @@ class _Junctions(object):
 
 def _batch_job(job):
     m, seed = job
-    genome, paired, nchr = _POOL_STATE
-    rb = make_reads(genome, m, seed=seed, paired=paired)
+    genome, paired, nchr, keep = _POOL_STATE
+    rb = make_reads(genome, m, seed=seed, paired=paired, keep_chroms=keep)
     j = _Junctions()
     j.junc_chrom, j.junc_left, j.junc_right, j.junc_strand = rb.junc_chrom, rb.junc_left, rb.junc_right, rb.junc_strand
     return split_by_chrom(rb, nchr), j
@@ -311,14 +376,17 @@ class Workload(object):
     """A genome + reads per chromosome + the site table inputs derived from them."""
 
     def __init__(self, name, n_reads=None, seed=None, scale=1.0, batch=2_500_000, workers=None, genome=None, read_seed=None,
-                 silence=0.0, **over):
+                 silence=0.0, keep_chroms=None, **over):
         """``workers`` processes (fork) generate ``batch``-read slices in parallel; call this BEFORE the
         process touches the GPU (a forked child must not inherit an initialised HIP runtime).
 
         ``genome`` / ``read_seed`` / ``silence``: another SAMPLE of a genome that exists already (BASELINE config 4: six samples of
         one genome, seeds 11-16, 15 % sample-specific junctions) -- the reads drawn with ``read_seed``, and a fraction
         ``silence`` of the isoforms, picked by that seed, not expressed in this sample: their junctions are what the other
-        samples have and this one does not (`combine` fills those gaps from this sample's BAM)."""
+        samples have and this one does not (`combine` fills those gaps from this sample's BAM).
+
+        ``keep_chroms`` (chromosome indexes): only those chromosomes' reads (and junctions) of the sample are made -- the same
+        reads the whole sample has there (``make_reads``); the other chromosomes stay empty."""
         if workers is None:
             workers = min(8, os.cpu_count() or 1)
         cfg = dict(WORKLOADS[name])
@@ -347,7 +415,7 @@ class Workload(object):
             done += m
             k += 1
         global _POOL_STATE
-        _POOL_STATE = (expressed, self.paired, nchr)
+        _POOL_STATE = (expressed, self.paired, nchr, None if keep_chroms is None else set(int(c) for c in keep_chroms))
         if workers > 1 and len(jobs) > 1:
             import multiprocessing
             with multiprocessing.get_context("fork").Pool(min(workers, len(jobs))) as pool:

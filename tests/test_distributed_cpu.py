@@ -1,7 +1,7 @@
 """N > 1 paths on CPU: chromosome -> device assignment, shard packing round trip, and world_size-2 gloo runs of the
 rank/shard logic bench.py uses -- weak scaling (every rank owns its own sample) and STRONG scaling, bench.py's default for
-N > 1 (one sample, its chromosomes dealt to the ranks: bench.rank_items, bench.reduce_report); the only collectives are the
-timing barrier and the MAX/SUM reductions of the report."""
+N > 1 (one sample cut into equal stretches of reads, chromosomes cut anywhere, partial counters that add up: bench.rank_pieces,
+bench.reduce_report); the only collectives are the timing barrier and the MAX/MIN/SUM reductions of the report."""
 import os
 import socket
 import sys
@@ -133,8 +133,9 @@ def test_two_rank_gloo_weak_scaling_reduction():
 
 
 def _strong_worker(rank, world, port, out):
-    """What a rank of `bench.py --gpus 2` does with the sample, the oracle standing in for the device: the same sample on every
-    rank, bench.rank_items picks the rank's chromosomes, bench.reduce_report makes the report."""
+    """What a rank of `bench.py --gpus 2` does with the sample, the oracle standing in for the device: ONE sample cut into `world`
+    stretches of equal numbers of reads in file order -- chromosomes cut anywhere (bench.rank_pieces = synth.strong_plan) --, the
+    rank counts its pieces against its chromosomes' WHOLE tables, bench.reduce_report makes the report."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     import tempfile
@@ -149,15 +150,17 @@ def _strong_worker(rank, world, port, out):
     t.add_bed(os.path.join(tmp, "j.bed"))
     t.find_competitors()
     items = [(c, t.chrom_arrays(c), wl.reads[i]) for i, c in enumerate(wl.genome.chrom_names) if t.chrom_arrays(c).n]
-    mine = bench.rank_items(items, "strong", world, rank)
+    mine = bench.rank_pieces(items, world, rank)
     res = {}
     for c, arr, rd in mine:
         res[c] = oracle.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos, rd.pos, rd.flag, rd.cig_off, rd.cigar)
     dist.barrier()
-    n_reads, n_sites = sum(rd.n for _, _, rd in mine), sum(arr.n for _, arr, _ in mine)
-    report = bench.reduce_report(dist, rank, world, n_reads, n_sites, 0.5 + rank, "cpu")
+    n_reads = sum(rd.n for _, _, rd in mine)
+    whole_n = {c: rd.n for c, _, rd in items}
+    n_sites = sum(arr.n * rd.n / max(whole_n[c], 1) for c, arr, rd in mine)
+    report = bench.reduce_report(dist, rank, world, n_reads, n_sites, 0.5 + rank, "cpu", exact=True)
     gathered = [None] * world if rank == 0 else None
-    dist.gather_object({c: [a.tolist() for a in v] for c, v in res.items()}, gathered, dst=0)   # (the TEST's own collective, not bench.py's)
+    dist.gather_object({c: ([a.tolist() for a in v], rd.n) for (c, _, rd), v in zip(mine, res.values())}, gathered, dst=0)   # (the TEST's own collective, not bench.py's)
     if rank == 0:
         whole = {c: [a.tolist() for a in oracle.check_bam(arr.pos, arr.strand, arr.part_off, arr.part_pos, arr.comp_off, arr.comp_pos,
                                                          rd.pos, rd.flag, rd.cig_off, rd.cigar)] for c, arr, rd in items}
@@ -165,9 +168,11 @@ def _strong_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_strong_split_union_is_the_whole():
-    """bench.py's default for N > 1: ONE sample, its chromosomes dealt to the ranks.  Every chromosome goes to exactly one rank,
-    the union of the ranks' counters is the oracle's on the whole sample, and the report carries the imbalance."""
+def test_two_rank_gloo_strong_split_cuts_a_chromosome_and_the_sums_are_the_whole():
+    """bench.py's default for N > 1 (and what `process --gpus N` does to a BAM): ONE sample in stretches of equal numbers of reads,
+    a chromosome cut anywhere.  Two ranks: every read on exactly one, ONE chromosome on both -- and the ranks' partial counters of
+    it, added, are the oracle's on the whole chromosome (checkBam only ever adds one per read, SpliSER_v0_1_8.py:519-559); the
+    report carries the balance."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.SimpleQueue()
@@ -181,15 +186,48 @@ def test_two_rank_gloo_strong_split_union_is_the_whole():
         p.join(180)
         assert p.exitcode == 0
     assert elapsed == 1.5                                   # MAX over ranks
-    assert tot_reads == float(n_reads) and tot_sites == float(n_sites)
-    assert not (set(gathered[0]) & set(gathered[1]))        # no chromosome twice ...
-    union = dict(gathered[0])
-    union.update(gathered[1])
-    assert union == whole                                   # ... none missing, every counter the whole sample's
-    assert len(gathered[0]) >= 1 and len(gathered[1]) >= 1
-    assert imbalance["reads_per_rank"] == [sum(reads_by_chrom[c] for c in g) for g in gathered]
+    assert tot_reads == float(n_reads) and abs(tot_sites - n_sites) < 1e-6 * n_sites + 1e-9
+    both = set(gathered[0]) & set(gathered[1])
+    assert len(both) == 1                                   # the cut falls inside one chromosome: both ranks count it ...
+    summed = {}
+    for g in gathered:
+        for c, (counters, n) in g.items():
+            if c in summed:
+                summed[c] = ([(np.array(a) + np.array(b)).tolist() for a, b in zip(summed[c][0], counters)], summed[c][1] + n)
+            else:
+                summed[c] = (counters, n)
+    assert {c: v[0] for c, v in summed.items()} == whole    # ... and the sums are the whole sample's counters, every chromosome's
+    assert {c: v[1] for c, v in summed.items()} == reads_by_chrom      # every read on exactly one rank
+    assert imbalance["reads_per_rank"] == [sum(n for _, n in g.values()) for g in gathered]
     assert sum(imbalance["reads_per_rank"]) == n_reads and imbalance["seconds_per_rank"] == [0.5, 1.5]
-    assert 1.0 <= imbalance["max_over_mean_reads"] < 2.0
+    assert 1.0 <= imbalance["max_over_mean_reads"] < 1.001 and imbalance["all_ranks_exact"] is True
+
+
+def test_strong_plan_and_a_rank_that_generates_its_own_stretch_only():
+    """synth.strong_plan cuts by the EXPECTED reads per chromosome (known before any read is made), and a rank generates the
+    chromosomes of its stretch only (Workload(keep_chroms=...)): the same reads the whole sample has there.  Eight ranks on a
+    five-chromosome genome: every rank has work, the pieces tile every chromosome exactly, and rank 3's pieces made from its own
+    partial sample are the pieces cut from the whole one."""
+    wl = synth.Workload("arabidopsis", scale=0.004, seed=23, workers=1)
+    expected = synth.expected_reads_per_chrom(wl.genome, wl.n_reads)
+    actual = np.array([r.n for r in wl.reads], float)
+    assert np.all(np.abs(expected - actual) < 0.03 * actual + 50)
+    plan = synth.strong_plan(expected, 8)
+    assert len(plan) == 8 and all(plan)
+    for c in range(5):
+        cuts = sorted((f0, f1) for pieces in plan for ci, f0, f1 in pieces if ci == c)
+        assert cuts[0][0] == 0.0 and cuts[-1][1] == 1.0 and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    exp_share = [sum(expected[ci] * (f1 - f0) for ci, f0, f1 in pieces) for pieces in plan]
+    assert max(exp_share) / (sum(exp_share) / 8) < 1.0001
+    mine = plan[3]
+    part = synth.Workload("arabidopsis", scale=0.004, seed=23, workers=1, genome=wl.genome, keep_chroms=sorted(set(c for c, _, _ in mine)))
+    for ci, f0, f1 in mine:
+        a, b = wl.reads[ci], part.reads[ci]
+        assert a.n == b.n
+        pa = a.take(int(f0 * a.n), a.n if f1 >= 1.0 else int(f1 * a.n))
+        pb = b.take(int(f0 * b.n), b.n if f1 >= 1.0 else int(f1 * b.n))
+        assert pa.n > 0 and np.array_equal(pa.pos, pb.pos) and np.array_equal(pa.flag, pb.flag) and np.array_equal(pa.cigar, pb.cigar) and np.array_equal(pa.cig_off, pb.cig_off)
+    assert all(part.reads[c].n == 0 for c in range(5) if c not in set(ci for ci, _, _ in mine))
 
 
 def test_bench_refuses_a_world_that_is_not_its_gpus(tmp_path):
