@@ -435,13 +435,14 @@ def combine_leg(samples, threads):
         t_files = time.perf_counter() - t
         n_reads = sum(sum(r.n for r in wl.reads) for wl in samples)
         t = time.perf_counter()
-        per = []
+        per, kept_tm = [], []
         for k in range(len(samples)):
             t1 = time.perf_counter()
             tmk = process.process(bams[k], os.path.join(tmp, "s%d.bed" % k), os.path.join(tmp, "s%d" % k), log=noop, keepReads=True)
-            process.wait_deferred_close()
-            per.append(time.perf_counter() - t1)
-            keep_s = keep_s + tmk.get("keep_reads_s", 0.0) if k else tmk.get("keep_reads_s", 0.0)
+            per.append(time.perf_counter() - t1)      # (the call: its .SpliSER.tsv is there; its kept reads go out beside the next sample's call)
+            kept_tm.append(tmk)
+        process.wait_deferred_close()                 # ... and process_s ends when the last sample's are on the disk
+        keep_s = sum(tmk.get("keep_reads_s", 0.0) for tmk in kept_tm)
         t_process = time.perf_counter() - t
 
         def timed_combine(out_name):

@@ -120,6 +120,9 @@ def main(argv=None):
         if __import__("os").environ.get("SPL_PROCESS_TIMING"):
             sys.stderr.write("[cli] modules of `process` imported %.4f s after main() began\n" % (timeit.default_timer() - start))
         process(devices=devices, threads=threads, **kwargs)
+        if kwargs.get("keepReads"):      # (the kept reads go out on the thread that closes the alignment file: the command is done when they are)
+            from .process import wait_deferred_close
+            wait_deferred_close()
     elif command == "combine":
         from .combine import combine
         combine(devices=devices, threads=threads, **kwargs)

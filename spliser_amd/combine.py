@@ -249,7 +249,26 @@ def fill_gaps(merged, bam_paths, is_stranded, stranded_type, devices=(0,), threa
     return results
 
 
-def fill_tables(tables, take, bam_paths, is_stranded, stranded_type, devices=(0,), threads=0, log=_log, kept_reads=None):
+def open_kept_reads(kept_reads, bam_paths):
+    """The samples' kept reads (``process --keepReads``), opened on a few threads while the caller does something else (the walk
+    over the sample files does not need them; opening one maps 0.4 GB and checks it against its checksum): -> a function
+    ``idx -> ReadStore or None`` that waits for that sample's.  Samples without such a file, or with a stale one, give None."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import readstore
+    if not kept_reads:
+        return lambda idx: None
+    pool = ThreadPoolExecutor(max_workers=3)
+    futures = {idx: pool.submit(readstore.open_if_fresh, path, bam_paths[idx]) for idx, path in enumerate(kept_reads) if path}
+    pool.shutdown(wait=False)
+
+    def get(idx):
+        f = futures.pop(idx, None)
+        return f.result() if f is not None else None
+    get.close = lambda: [f.result().close() for f in list(futures.values()) if f.result() is not None] and futures.clear()   # (what nobody took)
+    return get
+
+
+def fill_tables(tables, take, bam_paths, is_stranded, stranded_type, devices=(0,), threads=0, log=_log, kept_reads=None, opened=None):
     """Answer the query tables ``{sample idx: table}`` on the GPUs.  Each sample's BAM is decoded once, in the background (on
     the GPU when the call has one device, like ``process``); its chromosomes are dealt to the devices
     (``process.process_sites``: one context per device, a chromosome goes to its GPU as soon as the decoder has it complete) and
@@ -263,7 +282,10 @@ def fill_tables(tables, take, bam_paths, is_stranded, stranded_type, devices=(0,
         table = tables[idx]
         devs = devices[idx % len(devices):] + devices[:idx % len(devices)]
         # what `process --keepReads` left of this very BAM (readstore: keyed by the BAM's size, time and edges), or the BAM again
-        source = readstore.open_if_fresh(kept_reads[idx], bam_paths[idx]) if kept_reads and kept_reads[idx] else None
+        if opened is not None:
+            source = opened(idx)          # (opened while the files were walked: open_kept_reads)
+        else:
+            source = readstore.open_if_fresh(kept_reads[idx], bam_paths[idx]) if kept_reads and kept_reads[idx] else None
         if source is not None:
             log("  ({}: reads kept by process, {} not decoded again)".format(os.path.basename(kept_reads[idx]), os.path.basename(bam_paths[idx])))
         else:
@@ -360,6 +382,8 @@ def combine(samplesFile, outputPath, qGene="All", isStranded=False, strandedType
     The walk over the files runs on columns in the native library (``native.Combine``); files its parsers do not take -- and
     ``native_walk=False`` or SPL_COMBINE_PYTHON=1 -- are walked by the Python statement of the same loop below."""
     t_all = time.perf_counter()
+    from . import process as _proc
+    _proc.wait_deferred_close()       # (`process --keepReads` calls of this very interpreter may still be writing what this call is about to look for)
     log("Combining samples...")
     titles, tsvs, bams = read_samples_file(samplesFile, strict=shallow is None)
     if native_walk is None:
@@ -402,6 +426,7 @@ def _combine_native(walk, t_parse, titles, bams, outputPath, qGene, isStranded, 
             walk.keep_gene(qGene)
         log("Iterating through files in parallel, to interleave lines and fill gaps.")
         t0 = time.perf_counter()
+        opened = open_kept_reads(kept, bams)      # (beside the walk: the gap fill finds the samples' kept reads open)
         for pos, seen in walk.merge(chroms, isStranded, qGene, shallow):
             log("Skipped site {} for insufficient evidence, only {} samples with Site using minimum reads".format(pos, seen))
         tables = {}
@@ -415,7 +440,9 @@ def _combine_native(walk, t_parse, titles, bams, outputPath, qGene, isStranded, 
         n_gap_sites = walk.n_gap_sites
         t0 = time.perf_counter()
         if tables:
-            fill_tables(tables, walk.answers, bams, isStranded, strandedType, devices=devices, threads=threads, log=log, kept_reads=kept)
+            fill_tables(tables, walk.answers, bams, isStranded, strandedType, devices=devices, threads=threads, log=log, kept_reads=kept, opened=opened)
+        if hasattr(opened, "close"):
+            opened.close()
         t_fill = time.perf_counter() - t0
         t0 = time.perf_counter()
         walk.write(outputPath + ".combined.tsv", titles, isbeta2Cryptic)

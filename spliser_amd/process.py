@@ -459,6 +459,7 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
     # goes on decoding while Step 3 counts the chromosomes that are complete.  An unreadable file is an error here already
     # (block directory and header are read by the opening call).
     source = open_and_decode(inBAM, devices, gpuDecode, threads)     # (the decode runs beside Steps 0-2, wherever it runs)
+    keep = None      # (--keepReads: what the closing thread does first)
     try:
         t_open = time.perf_counter()
         table = _site_table(inBed, qGene, qChrom, maxIntronSize, annotationFile, aType, isStranded, strandedType, log)
@@ -502,17 +503,34 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
             if n_more:
                 log("WARNING: %d junction(s) of %s carry more reads than %s holds for them -- do the two files belong together?" % (n_more, inBed, inBAM))
         if keepReads and isinstance(source, native.BamFile):
+            # The kept reads -- every reference's arrays down from the device(s), then 19 bytes a read to the file -- are nothing the
+            # .SpliSER.tsv waits for: they go out on the thread that closes the alignment file afterwards (wait_deferred_close waits
+            # for both; `combine` does before it looks for such files; the interpreter does before it exits).  The file appears whole
+            # or not at all (readstore.save writes beside its name and moves).
             from . import readstore
-            t_keep = time.perf_counter()
-            kept = [(name, source.reads(name)) for name in source.ref_names]
-            readstore.save(outputPath + readstore.SUFFIX, inBAM, [(name, rs) for name, rs in kept if rs is not None])
-            timings["keep_reads_s"] = time.perf_counter() - t_keep
+
+            def keep():
+                t_keep = time.perf_counter()
+                kept = [(name, source.reads(name)) for name in source.ref_names]
+                readstore.save(outputPath + readstore.SUFFIX, inBAM, [(name, rs) for name, rs in kept if rs is not None])
+                timings["keep_reads_s"] = time.perf_counter() - t_keep
         t4 = time.perf_counter()
+    except BaseException:
+        keep = None
+        raise
     finally:
         if hasattr(source, "close"):
             # (closing a decoded BAM gives gigabytes of read arrays back to the system -- a tenth of a second for 200 M reads --
             #  and nobody is waiting for that: on a thread of its own)
-            closer = threading.Thread(target=source.close)
+            def finish(keep=keep):
+                try:
+                    if keep is not None:
+                        keep()
+                except BaseException as exc:      # (said, not lost: the .SpliSER.tsv is written and right; `combine` decodes the BAM when the file is not there)
+                    sys.stderr.write("process: the reads could not be kept (%s)\n" % exc)
+                finally:
+                    source.close()
+            closer = threading.Thread(target=finish)
             closer.start()
             _closers[:] = [t for t in _closers if t.is_alive()] + [closer]
     timings["bam_decode"] = "device" if getattr(source, "on_device", False) else "host"

@@ -93,6 +93,8 @@ def test_combine_takes_kept_reads_and_ignores_stale_ones(tmp_path):
         synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions, stranded=False)
         native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=2, seq_mode=1)
         tm = process.process(prefix + ".bam", prefix + ".bed", prefix, keepReads=True, log=lambda m: None)
+        assert os.path.exists(prefix + ".SpliSER.tsv")       # (the call's own output is there when it returns ...)
+        process.wait_deferred_close()                        # (... the kept reads when the thread that closes the alignment file is through)
         assert "keep_reads_s" in tm and os.path.exists(prefix + ".SpliSER.reads")
         lines.append("S%d\t%s.SpliSER.tsv\t%s.bam\n" % (k, prefix, prefix))
     process.wait_deferred_close()

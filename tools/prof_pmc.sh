@@ -4,9 +4,9 @@ TAG=$1; shift
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out /tmp/wl
-cd $R && python bench.py --cache /tmp/wl --no-cpu-baseline --e2e off --steps 3 "$@" > $R/gpurun_out/${TAG}_warm.log 2>&1
+cd $R && python bench.py --cache /tmp/wl --no-cpu-baseline --e2e off --no-other-steps --steps 3 "$@" > $R/gpurun_out/${TAG}_warm.log 2>&1
 cd /tmp
-P() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_${TAG}_$name -- python3 $R/bench.py --cache /tmp/wl --no-cpu-baseline --e2e off --steps 3 --warmup 1 "${BENCH_ARGS[@]}" > $R/gpurun_out/pmc_${TAG}_$name.log 2>&1; }
+P() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_${TAG}_$name -- python3 $R/bench.py --cache /tmp/wl --no-cpu-baseline --e2e off --no-other-steps --steps 3 --warmup 1 "${BENCH_ARGS[@]}" > $R/gpurun_out/pmc_${TAG}_$name.log 2>&1; }
 BENCH_ARGS=("$@")
 P insts SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT
 P cycles SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS

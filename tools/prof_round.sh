@@ -11,7 +11,7 @@ mkdir -p $R/gpurun_out /tmp/wl
 cd $R
 python bench.py --cache /tmp/wl "$@" > $R/gpurun_out/${TAG}_bench.json.log 2> $R/gpurun_out/${TAG}_bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py --cache /tmp/wl --no-cpu-baseline --e2e off "$@" > $R/gpurun_out/${TAG}_prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py --cache /tmp/wl --no-cpu-baseline --e2e off --no-other-steps "$@" > $R/gpurun_out/${TAG}_prof_bench.log 2>&1
 find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $R/gpurun_out/${TAG}_kernel_stats.csv
 cd $R
 ./tools/prof_pmc.sh $TAG "$@" > /dev/null 2>&1
