@@ -852,12 +852,16 @@ def main():
     # flags, `fr` + cryptic: the STRANDED fused instantiation), config 2 (the small leg's sample, above), and this workload with a
     # local aligner's soft clips on three reads in ten
     others = []
+    wl_mouse_e2e = None
     if rank == 0 and world == 1 and args.workload == "human" and not args.no_other_steps and args.kernel == "ranges" and args.soft_clips == 0:
         ms = argparse.Namespace(**vars(args))
         ms.workload, ms.cache, ms.stranded = "mouse_stranded", None, None
         wl_m, _, items_m, stranded_m = build_inputs(ms, 0, 1)
         others.append(("mouse_stranded fr+cryptic", items_m, stranded_m, True))
         del wl_m
+        if full_default and args.e2e_seq_mode is None:     # ... and a quarter of it as a FILE: paired flags through the device decoder, `fr` + cryptic end to end
+            ms.scale = 0.25
+            wl_mouse_e2e = build_inputs(ms, 0, 1)
         if wl_small is not None:
             others.append(("arabidopsis", wl_small[2], wl_small[3], args.beta2Cryptic))
         from spliser_amd import synth as _synth
@@ -1120,6 +1124,10 @@ def main():
                                        files=pre_files.pop("arabidopsis", None) if q == 1 else None, cold=cold.get("arabidopsis") if q == 1 else None))
                 if 1 in modes:  # ... and once with the host decoder asked for
                     e2e.append(e2e_leg("arabidopsis", wl2, items2, stranded2, args.beta2Cryptic, 1, args.e2e_reps, want2, gpu_decode=False))
+            if wl_mouse_e2e is not None:     # config 5's shape as a file (25 M reads, flags 99 / 147 / 83 / 163): --isStranded -s fr --beta2Cryptic
+                wl3, _, items3, stranded3 = wl_mouse_e2e
+                _, want3 = run_oracle(items3, native.STRANDED_CODE[stranded3], True, n_threads)
+                e2e.append(e2e_leg("mouse_stranded", wl3, items3, stranded3, True, 1, args.e2e_reps, want3))
         if cmb_samples is not None:
             nproc, quota = cpu_budget()
             combine_res = combine_leg(cmb_samples, max(1, min(nproc, int(round(quota)) if quota else nproc)))

@@ -474,6 +474,30 @@ __device__ __forceinline__ void commit_key(const spl_hot_params &p, spl_lds_i32 
     }
 }
 
+// A range of distinct positions [lo, ub) of difference array `arr`: +1 at lo, -1 at ub -- the two commit_keys of every range, with
+// what they share done once: both ends inside the workgroup's window (nearly always: the window is the chunk's) are two LDS adds
+// behind ONE test; anything else takes the two separate ways.  All 64 lanes call this together.
+template <int NARR, bool AGG, int WIN>
+__device__ __forceinline__ void commit_range(const spl_hot_params &p, spl_lds_i32 *lds, int32_t wbase, bool em, int32_t lo, int32_t ub, uint32_t arr)
+{
+    if (AGG) {
+        commit_key<NARR, AGG, WIN>(p, lds, wbase, em, ((uint32_t)lo << 2) | arr, 1);
+        commit_key<NARR, AGG, WIN>(p, lds, wbase, em, ((uint32_t)ub << 2) | arr, -1);
+        return;
+    }
+    const uint32_t a = (uint32_t)(lo - wbase), b = (uint32_t)(ub - wbase);
+    const bool inside = a <= (uint32_t)WIN && b <= (uint32_t)WIN;
+    if (em && inside) {
+        spl_lds_i32 *const row = lds + (int)arr * (WIN + 1);
+        __hip_atomic_fetch_add(row + (int)a, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(row + (int)b, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (__any(em && !inside)) {
+        commit_key<NARR, false, WIN>(p, lds, wbase, em && !inside, ((uint32_t)lo << 2) | arr, 1);
+        commit_key<NARR, false, WIN>(p, lds, wbase, em && !inside, ((uint32_t)ub << 2) | arr, -1);
+    }
+}
+
 // atomicAdd(addr, delta) with delta = +1 or -1, merged over the lanes of the wave that are executing it right now
 // and target the same word: one atomic per distinct address instead of one per lane.
 __device__ __forceinline__ void agg_add(uint32_t *addr, int32_t delta)
@@ -766,8 +790,13 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
     int32_t wbase = 0;
     ChunkView cv;
     // (the first two words of a bucket entry: all a boundary needs that is no junction end)
-    auto dbk2 = [&](uint32_t s) { const uint32_t *q = (const uint32_t *)(p.dbucket + s); spl_dbk e; e.first = q[0]; e.occ = q[1]; e.rival = 0u; return e; };
-    auto dbk3 = [&](uint32_t s) { return p.dbucket[s]; };
+    // (an entry's place as a 32-bit byte offset from the table's base -- 12 s by a shift and a shift-and-add; the table is below 4 GB --
+    //  so that the load is "scalar base + 32-bit lane offset": the 64-bit base + 12 s the compiler makes of an indexed pointer is a
+    //  v_mad_u64_u32 per boundary, a quarter-rate instruction, three boundaries a read)
+    typedef __attribute__((address_space(1))) const uint32_t spl_gdw;
+    auto dbk_at = [&](uint32_t s) { return (spl_gdw *)((__attribute__((address_space(1))) const char *)p.dbucket + (size_t)((s << 3) + (s << 2))); };
+    auto dbk2 = [&](uint32_t s) { spl_gdw *q = dbk_at(s); spl_dbk e; e.first = q[0]; e.occ = q[1]; e.rival = 0u; return e; };
+    auto dbk3 = [&](uint32_t s) { spl_gdw *q = dbk_at(s); spl_dbk e; e.first = q[0]; e.occ = q[1]; e.rival = q[2]; return e; };
     // ---- FUSED: the chunk's tiles.  Tile k is the part [lo, hi) of the chunk in cell [g0 + k TILE, + TILE) of the arrays' indexes.
     spl_layout_chunk ch;
     uint32_t tile = 0, tile_last = 0;
@@ -936,10 +965,7 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
                 const bool emit = i0 + j < n_run && ub > lo;
                 uint32_t arr = 0;
                 if (STRANDED) arr = (spl_read_strand(w[2 * j + 1] & 0xffffu, p.stranded) == (uint8_t)'-') ? 1u : 0u;
-                if (__any(emit)) {
-                    commit_key<NARR, AGG, WIN>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
-                    commit_key<NARR, AGG, WIN>(p, lds, wbase, emit, ((uint32_t)ub << 2) | arr, -1);
-                }
+                if (__any(emit)) commit_range<NARR, AGG, WIN>(p, lds, wbase, emit, lo, ub, arr);
             }
         }
         // ---- once-spliced reads (aligned, N, aligned): the kinds are known, so are the arrays; three ranges
@@ -972,10 +998,7 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
                 auto range = [&](uint32_t arr) {
                     const int32_t lo = ua + (int32_t)nva;
                     const bool em = alive && ub > lo;
-                    if (__any(em)) {
-                        commit_key<NARR, AGG, WIN>(p, lds, wbase, em, ((uint32_t)lo << 2) | arr, 1);
-                        commit_key<NARR, AGG, WIN>(p, lds, wbase, em, ((uint32_t)ub << 2) | arr, -1);
-                    }
+                    if (__any(em)) commit_range<NARR, AGG, WIN>(p, lds, wbase, em, lo, ub, arr);
                     ua = ub; nva = nvb;
                 };
                 dbk_resolve(p, pos[j] - 1, ea[j], ua, nva);
@@ -1020,10 +1043,7 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
             auto range = [&](uint32_t arr) {
                 const int32_t lo = ua + (int32_t)nva;
                 const bool em = alive && ub > lo;
-                if (__any(em)) {
-                    commit_key<NARR, AGG, WIN>(p, lds, wbase, em, ((uint32_t)lo << 2) | arr, 1);
-                    commit_key<NARR, AGG, WIN>(p, lds, wbase, em, ((uint32_t)ub << 2) | arr, -1);
-                }
+                if (__any(em)) commit_range<NARR, AGG, WIN>(p, lds, wbase, em, lo, ub, arr);
                 ua = ub; nva = nvb;
             };
             dbk_resolve(p, pos - 1, f0, ua, nva);
@@ -1109,10 +1129,7 @@ __global__ __launch_bounds__(FUSED ? SPL_BLOCK_FUSED : SPL_BLOCK) __attribute__(
                     const uint32_t arr = (kk == 2u ? (STRANDED ? 2u : 1u) : 0u) + sidx;
                     // junction ends: lSite is the previous boundary's position, rSite this one's
                     rival |= (kk == 2u) & ((prv | rv) != 0u);
-                    if (__any(emit)) {
-                        commit_key<NARR, AGG, WIN>(p, lds, wbase, emit, ((uint32_t)lo << 2) | arr, 1);
-                        commit_key<NARR, AGG, WIN>(p, lds, wbase, emit, ((uint32_t)u << 2) | arr, -1);
-                    }
+                    if (__any(emit)) commit_range<NARR, AGG, WIN>(p, lds, wbase, emit, lo, u, arr);
                     if (kk) { pu = u; pnv = nv; prv = rv; }
                 }
                 const bool more = alive && wide && k_next < n_ops;
