@@ -14,14 +14,14 @@
 // The Huffman decoding, one BGZF block per WAVE (the block's symbols as a stream of tokens), and the block's bytes made from
 // that stream, one block per LANE (spl_inflate_wave.h has the method, and is what the host tests run through the wave emulator).
 __global__ __launch_bounds__(64) void spl_inflate_decode_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status,
-                                                                uint8_t *tokens_all, uint32_t *n_tok, uint32_t stride)
+                                                                uint8_t *tokens_all, uint32_t *n_tok, uint32_t stride, uint32_t opts)
 {
     __shared__ splz::Shared sh;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
     const spl_zblock zb = blocks[b];
     uint32_t n = 0;
-    const uint32_t st = splz::decode_block(sh, image, zb, tokens_all + (size_t)b * stride, n, stride);
+    const uint32_t st = splz::decode_block(sh, image, zb, tokens_all + (size_t)b * stride, n, stride, opts);
     if (threadIdx.x == 0) { status[b] = st; n_tok[b] = st == SPL_Z_OK ? n : 0u; }
 }
 
@@ -384,7 +384,9 @@ extern "C" int spl_dev_launch_inflate_decode2(const uint8_t *image, const spl_zb
     if (n_blocks == 0) return 0;
     if (!work) return (int)hipErrorInvalidValue; // (nothing would be launched and the blocks' status words left as they were: an error, not a success)
     if (stride < 256u || stride > SPL_Z_TOKEN_STRIDE || (stride & 15u)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, status, (uint8_t *)work + tokens_at(n_blocks), (uint32_t *)work, stride);
+    // SPL_Z_WRITING_PASS=1 (A/B): every tile's tokens by a writing pass of their own, as until round 5 (now: written while the last count is taken)
+    static const uint32_t opts = getenv("SPL_Z_WRITING_PASS") ? splz::OPT_WRITING_PASS : 0u;
+    hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, status, (uint8_t *)work + tokens_at(n_blocks), (uint32_t *)work, stride, opts);
     return (int)hipGetLastError();
 }
 

@@ -56,6 +56,7 @@ constexpr uint32_t TILE_WORDS = 64u * SUB_BITS / 32u;
 constexpr uint32_t TILE_PAD = 16;            // words behind the tile: a symbol that begins in the last subsequence ends there
 constexpr uint32_t TOKCAP = SPLZ_TOKCAP;     // bytes of token stream per tile (a tile with more is cut short)
 constexpr uint32_t FL_OK = 0, FL_EOB = 1, FL_ERR = 2;
+constexpr uint32_t OPT_WRITING_PASS = 1; // decode_block: every tile's tokens by a writing pass of their own (rounds 3-5's way; A/B and tests)
 constexpr uint32_t SYM_EOB = 256, SYM_MATCH = 257, SYM_BAD = 0xffffffffu;
 
 // One wave's shared memory: 10120 bytes (16 waves on a CU's 160 KB).
@@ -300,6 +301,47 @@ WV_DEV Count count_from(const Shared &sh, uint32_t base, uint32_t start, uint32_
     return c;
 }
 
+// The same walk WITH its tokens: written to tok[0 .. cap) as the writing pass of decode_block writes them (a lane's literal runs
+// are its own), counted like count_from counts them.  fits: all of them found room (the counts are right either way).  need: the
+// largest (distance - bytes this lane had made before the match) of its matches: the match reaches back past the block's first
+// byte if that exceeds the output position the lane starts at, which is known only when all lanes' counts are (decode_block).
+// Why: a tile's symbols were decoded once more after the last count, by a pass of all lanes that did nothing but write down what
+// the count had seen -- one pass of the tile's four or five.  Here the LAST count is that pass.
+WV_DEV Count emit_from(const Shared &sh, uint32_t base, uint32_t start, uint32_t sub_end, uint8_t *tok, uint32_t cap, uint32_t &need, bool &fits)
+{
+    Count c{start, 0, 0, FL_OK};
+    uint32_t tp = 0, run = 0, hdr = 0, wr = 0;
+    need = 0;
+    auto put = [&](uint32_t at, uint32_t v) { if (at < cap) tok[at] = (uint8_t)v; };
+    while (c.end < sub_end) {
+        uint32_t len = 0, dist = 0, lit2;
+        const uint32_t s = decode(sh, base, c.end, len, dist, sub_end, lit2);
+        if (s < 256u) {
+            if (run == 0u || run == 128u) { if (run) put(hdr, 127u); hdr = tp++; run = 0; }
+            put(tp++, s);
+            ++run; ++wr;
+            if (lit2 != NO_LIT2) {
+                if (run == 128u) { put(hdr, 127u); hdr = tp++; run = 0; }
+                put(tp++, lit2);
+                ++run; ++wr;
+            }
+            continue;
+        }
+        if (run) { put(hdr, run - 1u); run = 0; }
+        if (s != SYM_MATCH) { c.flag = s == SYM_EOB ? FL_EOB : FL_ERR; break; }
+        if (dist > wr && dist - wr > need) need = dist - wr;
+        const uint32_t L = len - 3u, D = dist - 1u;
+        put(tp, 0x80u | (L & 0x7fu)); put(tp + 1u, L >> 7 | (D & 0x7fu) << 1); put(tp + 2u, D >> 7);
+        tp += 3u;
+        wr += len;
+    }
+    if (run) put(hdr, run - 1u);
+    c.n_tok = tp;
+    c.n_out = wr;
+    fits = tp <= cap;
+    return c;
+}
+
 // n bytes (1..16) of (lo, hi) to p
 WV_DEV void store_n(uint8_t *p, uint64_t lo, uint64_t hi, uint32_t n)
 {
@@ -312,8 +354,9 @@ WV_DEV void store_n(uint8_t *p, uint64_t lo, uint64_t hi, uint32_t n)
 
 // The block `zb` of the file image, by one wave.  stream: room for tok_cap bytes of tokens (16-byte aligned; SPL_Z_TOKEN_STRIDE
 // holds any block's, a caller that gives less gets SPL_Z_OVERRUN for a block that needs more); n_tok_out: how many were written.
-// Returns the block's status (every lane the same).
-WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock &zb, uint8_t *stream, uint32_t &n_tok_out, uint32_t tok_cap = SPL_Z_TOKEN_STRIDE)
+// opts: OPT_* bits.  Returns the block's status (every lane the same).
+WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock &zb, uint8_t *stream, uint32_t &n_tok_out, uint32_t tok_cap = SPL_Z_TOKEN_STRIDE,
+                             uint32_t opts = 0)
 {
     n_tok_out = 0;
     uint32_t n_tok = 0; // bytes of token stream so far
@@ -442,22 +485,44 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             bool dead = l != 0u && sub_begin >= end_bits;
             Count c{start, 0, 0, FL_OK};
             if (!dead) c = count_from(sh, base, start, sub_end);
+            // From the first correction on a lane writes its tokens down WHILE it counts (emit_from), into a place of its own in the
+            // token room sized by what its first, guessed decode counted and a little more (a corrected start moves a lane's count
+            // by a few bytes): when the starts have settled the tokens are there, and the writing pass below -- all the tile's
+            // symbols decoded once more -- is not needed; a tile whose places do not fit the room, or a lane whose tokens do not
+            // fit its place, takes that pass as before.
+            uint8_t *const tok = (uint8_t *)sh.tok;
+            const uint32_t place_len = dead ? 0u : c.n_tok + 12u;
+            const uint32_t place_incl = wv::scan_add(place_len);
+            const bool places = !(opts & OPT_WRITING_PASS) && wv::readlane(place_incl, 63u) <= TOKCAP;
+            uint8_t *const place = tok + (place_incl - place_len);
+            bool emitted = false, fits = true;
+            uint32_t need = 0;
             for (uint32_t pass = 0;; ++pass) {
                 if (pass > 66u) return SPL_Z_OVERRUN; // (cannot happen: lane k is settled after pass k + 1)
                 const uint32_t p_end = wv::shfl_up(c.end, 1u), p_flag = wv::shfl_up(c.flag, 1u), p_dead = wv::shfl_up(dead ? 1u : 0u, 1u);
                 const bool want_dead = l != 0u && (p_dead != 0u || p_flag != FL_OK || p_end >= end_bits);
                 const bool redo = l != 0u && (want_dead != dead || (!want_dead && p_end != start));
                 if (!wv::any(redo)) break;
-                if (redo) {
-                    dead = want_dead;
-                    start = p_end;
+                // (the first round is nearly every lane's: whoever is right already -- lane 0, a lucky guess -- writes its tokens with it)
+                if (redo || (places && pass == 0u && !dead)) {
+                    if (redo) { dead = want_dead; start = p_end; }
                     c = Count{start, 0, 0, FL_OK};
-                    if (!dead) c = count_from(sh, base, start, sub_end);
+                    emitted = false;
+                    if (!dead && places) { c = emit_from(sh, base, start, sub_end, place, place_len, need, fits); emitted = true; }
+                    else if (!dead) c = count_from(sh, base, start, sub_end);
                 }
             }
+            if (places && wv::any(!dead && !emitted)) { // (no round at all, or a lane that came alive again: its tokens now)
+                if (!dead && !emitted) { c = emit_from(sh, base, start, sub_end, place, place_len, need, fits); emitted = true; }
+            }
+            // (a lane whose tokens did not fit its place -- its guessed decode had counted something else altogether -- writes them once
+            //  more behind the others, into room of exactly their size; should even that not fit, the writing pass below takes the tile)
+            const bool misfit = places && !dead && !fits;
+            const uint32_t again_len = misfit ? c.n_tok : 0u, again_incl = wv::scan_add(again_len);
+            const bool in_place = places && wv::readlane(again_incl, 63u) <= TOKCAP;
             // the lanes that count: all that are alive (a suffix of the lanes is dead), short of the one whose tokens overflow the tile's room
             const uint32_t cum_t = wv::scan_add(dead ? 0u : c.n_tok), cum_o = wv::scan_add(dead ? 0u : c.n_out);
-            const uint64_t m_ok = wv::ballot(!dead && cum_t <= TOKCAP);
+            const uint64_t m_ok = wv::ballot(!dead && (in_place || cum_t <= TOKCAP));
             const uint32_t n_valid = ~m_ok ? wv::ffs64(~m_ok) : 64u; // (the low run of ones)
             if (n_valid == 0u) return SPL_Z_OVERRUN;
             const bool valid = l < n_valid;
@@ -466,9 +531,36 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             const uint32_t total = wv::readlane(cum_o, n_valid - 1u), n_t = wv::readlane(cum_t, n_valid - 1u);
             if (at + total > out_len) return SPL_Z_OVERRUN;
             if (n_tok + n_t > tok_cap - 64u) return SPL_Z_TOKENS;
+            if (in_place) {
+                // the tokens are written: each lane's to its stretch of the block's stream, sixteen bytes at a time, the last ones exactly
+                if (wv::any(valid && need > at + cum_o - c.n_out)) return SPL_Z_BAD_DISTANCE;
+                uint8_t *const dst = stream + n_tok + (cum_t - c.n_tok);
+                auto copy_out = [&](const uint8_t *from) {
+                    for (uint32_t o = 0; o < c.n_tok; o += 16u) {
+                        uint64_t lo, hi;
+                        wv::lds_ld128(from + o, lo, hi);
+                        store_n(dst + o, lo, hi, c.n_tok - o < 16u ? c.n_tok - o : 16u);
+                    }
+                };
+                if (valid && !misfit) copy_out(place);
+                if (wv::any(valid && misfit)) {
+                    wv::sync(); // (the places are read: the room is free)
+                    if (valid && misfit) {
+                        uint8_t *const again = tok + (again_incl - again_len);
+                        uint32_t need2;
+                        bool fits2;
+                        (void)emit_from(sh, base, start, sub_end, again, again_len, need2, fits2);
+                        copy_out(again);
+                    }
+                }
+                n_tok += n_t;
+                wv::sync();
+                at += total;
+                pos = wv::readlane(c.end, n_valid - 1u);
+                continue;
+            }
             // ---- the writing pass: every lane's symbols as tokens, at the lane's place in the tile's stretch of the stream
             bool bad_dist = false;
-            uint8_t *const tok = (uint8_t *)sh.tok;
 #ifndef SPL_EXP_NO_WRITE
             if (valid) {
                 uint32_t p = start, wr = at + cum_o - c.n_out, tp = cum_t - c.n_tok, run = 0, hdr = 0;

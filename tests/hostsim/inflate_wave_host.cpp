@@ -23,6 +23,21 @@ extern "C" int emul_inflate_blocks(const uint8_t *image, const spl_zblock *block
             if (wv::lane() == 0) { status[b] = st; n_tok = st == SPL_Z_OK ? n : 0u; }
         });
         if (!ok) return -1 - (int)b;
+        // ... and once more with every tile's tokens by a writing pass of their own (what a tile falls back to): the same status,
+        // the same token stream, byte for byte
+        {
+            static std::vector<uint8_t> tokens2(SPL_Z_TOKEN_STRIDE + 256);
+            memset(tokens2.data(), 0xEE, tokens2.size());
+            memset(&sh, 0xEE, sizeof sh);
+            uint32_t st2 = 99, n2 = 0;
+            const bool ok2 = wv::run_wave([&]() {
+                uint32_t n = 0;
+                const uint32_t st = splz::decode_block(sh, image, blocks[b], tokens2.data(), n, SPL_Z_TOKEN_STRIDE, splz::OPT_WRITING_PASS);
+                if (wv::lane() == 0) { st2 = st; n2 = st == SPL_Z_OK ? n : 0u; }
+            });
+            if (!ok2) return -200000 - (int)b;
+            if (st2 != status[b] || n2 != n_tok || (n_tok && memcmp(tokens.data(), tokens2.data(), n_tok) != 0)) return -300000 - (int)b;
+        }
         for (size_t k = SPL_Z_TOKEN_STRIDE; k < tokens.size(); ++k) // (a block's room for tokens ends where the next block's begins)
             if (tokens[k] != 0xEE) return -100000 - (int)b;
         if (status[b] == SPL_Z_OK) {
