@@ -386,6 +386,9 @@ extern "C" int spl_dev_launch_inflate_decode2(const uint8_t *image, const spl_zb
     if (stride < 256u || stride > SPL_Z_TOKEN_STRIDE || (stride & 15u)) return (int)hipErrorInvalidValue;
     // SPL_Z_WRITING_PASS=1 (A/B): every tile's tokens by a writing pass of their own, as until round 5 (now: written while the last count is taken)
     static const uint32_t opts = getenv("SPL_Z_WRITING_PASS") ? splz::OPT_WRITING_PASS : 0u;
+    // (measured, round 6: fewer decoding waves a CU -- 12, 9, 8 instead of the 16 that fill its LDS, by padding -- make room for the
+    //  copying kernel's waves and only slow the decoder, 294 -> 345 / 412 / 468 ms a human file, the copying kernel 234 -> 215:
+    //  profiles/r06n_decode_lds_pad_q2.txt)
     hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, status, (uint8_t *)work + tokens_at(n_blocks), (uint32_t *)work, stride, opts);
     return (int)hipGetLastError();
 }

@@ -56,6 +56,10 @@ constexpr uint32_t TILE_WORDS = 64u * SUB_BITS / 32u;
 constexpr uint32_t TILE_PAD = 16;            // words behind the tile: a symbol that begins in the last subsequence ends there
 constexpr uint32_t TOKCAP = SPLZ_TOKCAP;     // bytes of token stream per tile (a tile with more is cut short)
 constexpr uint32_t FL_OK = 0, FL_EOB = 1, FL_ERR = 2;
+#ifndef SPLZ_EMIT_ROUNDS
+#define SPLZ_EMIT_ROUNDS 2
+#endif
+constexpr uint32_t EMIT_ROUNDS = SPLZ_EMIT_ROUNDS; // rounds of correction in which a corrected lane writes its tokens down at once (decode_block)
 constexpr uint32_t OPT_WRITING_PASS = 1; // decode_block: every tile's tokens by a writing pass of their own (rounds 3-5's way; A/B and tests)
 constexpr uint32_t SYM_EOB = 256, SYM_MATCH = 257, SYM_BAD = 0xffffffffu;
 
@@ -508,7 +512,10 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
                     if (redo) { dead = want_dead; start = p_end; }
                     c = Count{start, 0, 0, FL_OK};
                     emitted = false;
-                    if (!dead && places) { c = emit_from(sh, base, start, sub_end, place, place_len, need, fits); emitted = true; }
+                    // (the first two rounds settle all but a tile's stragglers -- where the codes at hand are all about as long as each
+                    //  other the true start travels one lane a round, a dozen rounds and more: those rounds only count, and the lanes
+                    //  they corrected write their tokens in one round of their own behind the loop)
+                    if (!dead && places && pass < EMIT_ROUNDS) { c = emit_from(sh, base, start, sub_end, place, place_len, need, fits); emitted = true; }
                     else if (!dead) c = count_from(sh, base, start, sub_end);
                 }
             }
