@@ -268,98 +268,6 @@ def open_kept_reads(kept_reads, bam_paths):
     return get
 
 
-class _ResidentFill(object):
-    """The gap fill of the samples whose reads `process --keepReads` left, in two halves around the walk over the sample files:
-    BEFORE the walk's tables exist a few threads -- a context each, samples dealt round robin -- open the samples' kept reads and
-    send them up as they are (``Context.upload_soa``: flag, POS, CIGAR resident on the device, 19 bytes a read; nothing of it
-    depends on the walk); AFTER, per sample: the query table up, a read set laid out from the resident arrays in the table's
-    coordinate space, ONE counting pass in combine mode (a flanking read counts toward beta2Simple, SpliSER_v0_1_8.py:529-536),
-    the answers to ``take``.  What is left of the gap fill behind the walk is the counting; the uploads ran beside it.
-    Samples without such a file (or with a stale one) are not touched: ``finish`` says which were done."""
-
-    def __init__(self, kept_reads, bam_paths, devices, log=_log, workers=2):
-        self.kept, self.bams, self.log = kept_reads or [], bam_paths, log
-        self.todo = [idx for idx, p in enumerate(self.kept) if p]
-        self.n_workers = max(1, min(workers, len(self.todo)))
-        self.devices = tuple(devices)
-        self.ready = threading.Event()      # the walk's tables are there (or the run is over)
-        self.tables, self.take, self.stranded = None, None, 0
-        self.done, self.errors = set(), []
-        self.lock = threading.Lock()
-        self.threads = [threading.Thread(target=self._run, args=(w,)) for w in range(self.n_workers)] if self.todo else []
-        for t in self.threads:
-            t.start()
-
-    def _run(self, w):
-        from . import readstore
-        held = []       # (idx, store, soa, {chrom: segment})
-        ctx = None
-        try:
-            for idx in self.todo[w::self.n_workers]:
-                store = readstore.open_if_fresh(self.kept[idx], self.bams[idx])
-                if store is None:
-                    continue
-                if ctx is None:
-                    ctx = native.Context(self.devices[w % len(self.devices)])
-                names = [c for c, rs in store._sets.items() if rs.n]
-                sets = [store.reads(c) for c in names]
-                soa = ctx.upload_soa([native.ReadArrays(rs.pos, rs.flag, rs.cig_off, rs.cigar) for rs in sets], max_ends=[rs.max_end for rs in sets])
-                held.append((idx, store, soa, {c: k for k, c in enumerate(names)}))
-            self.ready.wait()
-            if self.tables is None:
-                return
-            for idx, store, soa, seg_of in held:
-                table = self.tables.get(idx)
-                if table is not None:
-                    self.log("  ({}: reads kept by process, {} not decoded again)".format(os.path.basename(self.kept[idx]), os.path.basename(self.bams[idx])))
-                    self._count(ctx, idx, table, store, soa, seg_of)
-                with self.lock:
-                    self.done.add(idx)
-        except BaseException as exc:      # (surfaced by finish)
-            with self.lock:
-                self.errors.append(exc)
-        finally:
-            for _, store, soa, _ in held:
-                soa.free()
-                store.close()
-            if ctx is not None:
-                ctx.close()
-
-    def _count(self, ctx, idx, table, store, soa, seg_of):
-        from . import shard
-        items = [(c, table.chrom_arrays(c), store.reads(c)) for c in table.chrom_index]
-        for sh in shard.pack(items, concat_reads=False):
-            with ctx.upload_sites(sh.sites) as ds:
-                dr = ctx.begin_reads(sum(soa.n[seg_of[c]] for c in sh.chroms if c in seg_of))
-                try:
-                    for chrom, off in zip(sh.chroms, sh.offsets):
-                        if chrom in seg_of:
-                            dr.add_soa(soa, seg_of[chrom], off)
-                    dr.finish()
-                    ctx.count_launch(ds, dr, self.stranded, 1)
-                    beta1, b2r, _ = ds.counters()
-                finally:
-                    dr.free()
-            for chrom, (r0, r1) in zip(sh.chroms, sh.site_rows):
-                self.take(idx, table.site_index[chrom], beta1[r0:r1], b2r[r0:r1])
-
-    def finish(self, tables, take, is_stranded, stranded_type):
-        """The walk's tables are there: count.  -> the samples that were answered here (the others' BAMs are the caller's)."""
-        self.tables, self.take = tables, take
-        self.stranded = native.STRANDED_CODE[stranded_type] if is_stranded else 0
-        self.ready.set()
-        for t in self.threads:
-            t.join()
-        if self.errors:
-            raise self.errors[0]
-        return set(self.done)
-
-    def abandon(self):
-        self.ready.set()
-        for t in self.threads:
-            t.join()
-
-
 def fill_tables(tables, take, bam_paths, is_stranded, stranded_type, devices=(0,), threads=0, log=_log, kept_reads=None, opened=None):
     """Answer the query tables ``{sample idx: table}`` on the GPUs.  Each sample's BAM is decoded once, in the background (on
     the GPU when the call has one device, like ``process``); its chromosomes are dealt to the devices
@@ -518,27 +426,23 @@ def _combine_native(walk, t_parse, titles, bams, outputPath, qGene, isStranded, 
             walk.keep_gene(qGene)
         log("Iterating through files in parallel, to interleave lines and fill gaps.")
         t0 = time.perf_counter()
-        resident = _ResidentFill(kept, bams, devices, log=log)      # (beside the walk: the samples' kept reads on their way to the device)
-        try:
-            for pos, seen in walk.merge(chroms, isStranded, qGene, shallow):
-                log("Skipped site {} for insufficient evidence, only {} samples with Site using minimum reads".format(pos, seen))
-            tables = {}
-            n_queries = 0
-            for idx in range(len(titles)):
-                tabs = walk.tables(idx)
-                if tabs:
-                    tables[idx] = _NativeQueryTable(tabs)
-                    n_queries += sum(int(t["pos"].shape[0]) for _, t in tabs)
-            t_merge = time.perf_counter() - t0
-            n_gap_sites = walk.n_gap_sites
-            t0 = time.perf_counter()
-            done = resident.finish(tables, walk.answers, isStranded, strandedType)
-            rest = {idx: t for idx, t in tables.items() if idx not in done}
-            if rest:      # (samples without kept reads: their BAMs, decoded again)
-                fill_tables(rest, walk.answers, bams, isStranded, strandedType, devices=devices, threads=threads, log=log, kept_reads=None)
-        except BaseException:
-            resident.abandon()      # (its threads wait for the tables: told that none are coming)
-            raise
+        opened = open_kept_reads(kept, bams)      # (beside the walk: the gap fill finds the samples' kept reads open)
+        for pos, seen in walk.merge(chroms, isStranded, qGene, shallow):
+            log("Skipped site {} for insufficient evidence, only {} samples with Site using minimum reads".format(pos, seen))
+        tables = {}
+        n_queries = 0
+        for idx in range(len(titles)):
+            tabs = walk.tables(idx)
+            if tabs:
+                tables[idx] = _NativeQueryTable(tabs)
+                n_queries += sum(int(t["pos"].shape[0]) for _, t in tabs)
+        t_merge = time.perf_counter() - t0
+        n_gap_sites = walk.n_gap_sites
+        t0 = time.perf_counter()
+        if tables:
+            fill_tables(tables, walk.answers, bams, isStranded, strandedType, devices=devices, threads=threads, log=log, kept_reads=kept, opened=opened)
+        if hasattr(opened, "close"):
+            opened.close()
         t_fill = time.perf_counter() - t0
         t0 = time.perf_counter()
         walk.write(outputPath + ".combined.tsv", titles, isbeta2Cryptic)
