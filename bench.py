@@ -307,9 +307,16 @@ def e2e_leg(name, wl, items, stranded, cryptic, seq_mode, reps, want, gpu_decode
                         stages={k2: round(v, 4) for k2, v in tm.items()}, deferred_close_s=round(closing, 4))
         import torch
         free_before = [torch.cuda.mem_get_info(d)[0] for d in devices]
+        prof_first = bool(os.environ.get("SPL_BENCH_PROF_FIRST"))     # (diagnostic: the first call's kernels by the library's stopwatch)
+        if prof_first:
+            native.prof_enable(True)
         first = call("w", devices)     # the leg's first call: device memory for this file's sizes is not at hand yet (and, for the
         #                                first leg, nothing is): reported by itself, the timed calls are the ones behind it
         # (what the first call took from the driver and the process still holds -- live or in the library's pool for the next call)
+        if prof_first:
+            out["first_call_kernels"] = [{"kernel": k["kernel"], "calls": k["calls"], "ms": round(k["ms"], 2)} for k in native.prof_report()[:8]]
+            native.prof_enable(False)
+            sys.stderr.write("[bench] first call %.3f s, kernels: %s\n" % (first["wall_s"], out["first_call_kernels"]))
         out["first_call_device_gb"] = round(sum(b - torch.cuda.mem_get_info(d)[0] for b, d in zip(free_before, devices)) / 1e9, 2)
         runs = [call("%d" % k, devices) for k in range(reps)]
         best = min(runs, key=lambda r: r["wall_s"])

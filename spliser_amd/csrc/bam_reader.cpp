@@ -1371,6 +1371,48 @@ bool first_record_at(spl_bam *bam, size_t b, void *ld, std::vector<uint8_t> &buf
 }
 } // namespace
 
+// What the records of blocks [b_lo, b_hi) take, from three places in them (the stretch's beginning, a third and two thirds of
+// the way; the block directory must hold them): records, their CIGAR ops, and the inflated bytes both were counted in -- the
+// host inflates half a dozen blocks at each place and walks the whole records in them.  For the device decoder's first guess
+// at the room its extracted arrays need, before anything runs on the device (spl_capi.cpp); false: cannot tell.
+bool spl_bam_sample_density(spl_bam *bam, size_t b_lo, size_t b_hi, uint64_t *n_rec_out, uint64_t *n_ops_out, uint64_t *n_bytes_out)
+{
+    const size_t n_blocks = bam->dir.n_ready.load();
+    b_hi = std::min(b_hi, n_blocks);
+    if (b_lo >= b_hi) return false;
+    void *ld = deflate_lib().ok ? deflate_lib().alloc() : nullptr;
+    std::vector<uint8_t> buf;
+    uint64_t n_rec = 0, n_ops = 0, n_bytes = 0;
+    size_t last = (size_t)-1;
+    for (int k = 0; k < 3; ++k) {
+        const size_t b = b_lo + (b_hi - b_lo) * (size_t)k / 3;
+        if (b == last) continue;
+        last = b;
+        uint64_t u = 0;
+        int32_t tid = 0;
+        if (!first_record_at(bam, b, ld, buf, &u, &tid)) continue;
+        const uint8_t *const end = buf.data() + (buf.size() - 64);
+        const uint8_t *c = buf.data() + (size_t)(u - bam->dir.at(b).uoff), *const c0 = c;
+        uint64_t rec = 0, ops = 0;
+        while (c + 36 <= end) {
+            const uint32_t block_size = le32(c);
+            if (block_size < 32 || block_size > (1u << 28) || c + 4 + block_size > end) break;
+            ops += (uint64_t)c[16] | ((uint64_t)c[17] << 8);
+            ++rec;
+            c += 4 + (size_t)block_size;
+        }
+        if (!rec) continue;
+        n_rec += rec;
+        n_ops += ops;
+        n_bytes += (uint64_t)(c - c0);
+    }
+    if (ld) deflate_lib().free_(ld);
+    *n_rec_out = n_rec;
+    *n_ops_out = n_ops;
+    *n_bytes_out = n_bytes;
+    return n_rec != 0 && n_bytes != 0;
+}
+
 extern "C" int spl_bam_share_plan(spl_bam *bam, int n_shares, int *n_out)
 {
     if (!bam || n_shares < 1) return spl_set_error(SPL_ERR_ARG, "spl_bam_share_plan: bad argument");

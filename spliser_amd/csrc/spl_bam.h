@@ -22,6 +22,8 @@ const uint8_t *spl_bam_image(const spl_bam *bam, size_t *fsize_out);
 int spl_bam_fd(const spl_bam *bam);                        // the open file (pread: bytes without touching the mapping's page tables)
 uint64_t spl_bam_header_end(const spl_bam *bam);           // where the first record starts in the inflated stream
 int spl_bam_thread_count(const spl_bam *bam);
+// records, CIGAR ops and the inflated bytes they were counted in, sampled on the host at three places of blocks [b_lo, b_hi)
+bool spl_bam_sample_density(spl_bam *bam, size_t b_lo, size_t b_hi, uint64_t *n_rec_out, uint64_t *n_ops_out, uint64_t *n_bytes_out);
 // The placed records of the whole file in file order as four malloc'ed arrays (the file takes them over and frees them with
 // free()); reference t has records [ref_first[t], ref_first[t] + ref_n[t]), cig_off holds n_total + 1 offsets into cigar.
 int spl_bam_adopt(spl_bam *bam, int32_t *pos, uint16_t *flag, uint32_t *cig_off, uint32_t *cigar, const int64_t *ref_first, const int64_t *ref_n,

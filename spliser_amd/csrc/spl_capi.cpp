@@ -129,9 +129,14 @@ static hipError_t get(void **out, size_t bytes, char tag = 'x')
         if (best < v.size()) { p = v[best].p; cap = v[best].bytes; v.erase(v.begin() + (long)best); }
     }
     if (!p) {
+        static const bool timing = getenv("SPL_DEV_TIMING") != nullptr; // (diagnostic: what the driver took for memory the pool did not have)
+        const auto t0 = std::chrono::steady_clock::now();
         e = hipMalloc(&p, bytes);
         if (e != hipSuccess) { (void)hipGetLastError(); flush(device); e = hipMalloc(&p, bytes); }
         if (e != hipSuccess) return e;
+        if (timing)
+            fprintf(stderr, "[devmem] hipMalloc of %.1f MB ('%c') on device %d: %.2f ms; the pool holds %.1f MB\n", (double)bytes / 1e6, tag, device,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3, (double)held_bytes(device) / 1e6);
     }
     { std::lock_guard<std::mutex> lock(mu()); lent().push_back(Held{device, p, cap}); }
     if (poison) { // (and done before anybody's stream touches the buffer: a memset on the null stream does not wait for, or hold up, the others)
@@ -977,19 +982,41 @@ static int grow_stage(spl_ctx *c, int n)
             pool.erase(pool.begin() + (long)k);
         }
     }
-    for (int k = (int)c->stage.size(); k < n; ++k) {
-        spl_ctx::Stage st;
+    // the missing ones side by side, a thread each: touching 32 MiB and locking it is 3-8 ms of a new process's first call, six
+    // of them one behind the other were 15-50 ms before the file's first byte was on its way
+    const int n_new = n - (int)c->stage.size();
+    if (n_new <= 0) return SPL_OK;
+    std::vector<spl_ctx::Stage> made((size_t)n_new);
+    std::vector<int> why((size_t)n_new, SPL_OK);
+    auto make = [&](int k) {
+        spl_ctx::Stage &st = made[(size_t)k];
         void *p = nullptr;
-        if (posix_memalign(&p, huge, bytes) != 0) return spl_set_error(SPL_ERR_NOMEM, "out of host memory for the staging buffers");
+        if (hipSetDevice(c->device) != hipSuccess) { why[(size_t)k] = SPL_ERR_HIP; return; }
+        if (posix_memalign(&p, huge, bytes) != 0) { why[(size_t)k] = SPL_ERR_NOMEM; return; }
         (void)madvise(p, bytes, MADV_HUGEPAGE);
         memset(p, 0, bytes); // touch: the pages exist before they are locked
         st.host = (char *)p;
         st.bytes = bytes;
         st.locked = want_lock && hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess; // (pageable works too, slower)
-        if (hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) { if (st.locked) (void)hipHostUnregister(p); free(p); return spl_set_error(SPL_ERR_HIP, "hipEventCreate failed"); }
-        c->stage.push_back(st);
+        if (hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) {
+            if (st.locked) (void)hipHostUnregister(p);
+            free(p);
+            st = spl_ctx::Stage();
+            why[(size_t)k] = SPL_ERR_HIP;
+        }
+    };
+    {
+        std::vector<std::thread> crew;
+        for (int k = 1; k < n_new; ++k) crew.emplace_back(make, k);
+        make(0);
+        for (std::thread &t : crew) t.join();
     }
-    return SPL_OK;
+    int rc = SPL_OK;
+    for (int k = 0; k < n_new; ++k) {
+        if (why[(size_t)k] == SPL_OK) { c->stage.push_back(made[(size_t)k]); continue; }
+        if (rc == SPL_OK) rc = why[(size_t)k] == SPL_ERR_NOMEM ? spl_set_error(SPL_ERR_NOMEM, "out of host memory for the staging buffers") : spl_set_error(SPL_ERR_HIP, "hipEventCreate failed");
+    }
+    return rc;
 }
 
 static void free_stage(spl_ctx *c)
@@ -1373,13 +1400,47 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         std::vector<hipEvent_t> dec; // window w's Huffman decoding is done: nobody reads its pieces of the file image again (their slots of the ring are free)
         std::vector<hipEvent_t> k2;  // window w's copying kernel is done: its bytes are there, its token buffer is free
         explicit Pipe(spl_ctx *ctx) : c(ctx) {}
+        bool keep = false;
+        int n_copy_made = 0;
+        struct Kept { int device, n_copy; hipStream_t a, b, up, cp[NCOPY]; };
+        hipStream_t up = nullptr; // the file's pieces: a stream of this pipeline's own at the low level (a queue of its own again); without levels the context's copy stream
+        hipStream_t upload() const { return up ? up : c->copy; }
+        static std::mutex &kept_mu() { static std::mutex m; return m; }
+        static std::vector<Kept> &kept() { static std::vector<Kept> *v = new std::vector<Kept>(); return *v; }
         // (only the streams that will be used: the runtime deals streams out to a few hardware queues, and one more stream --
         //  made, never used -- put the decoding and the copying kernels behind each other: 0.75 s instead of 0.43 for a 14 GB file)
+        // Which hardware queue a stream gets is the runtime's choice -- the least used of four per priority level, whatever else
+        // the process has made streams for -- and two of this pipeline's streams on one queue are one behind the other: the
+        // first call of a process that already had a context took 0.70 s where its later calls took 0.36, windows of 39 ms
+        // instead of 15, the same as every call with GPU_MAX_HW_QUEUES=2 (profiles/r06s_first_call.txt).  Priority levels have
+        // queues of their own: the three kernel streams are made at the high level -- nothing else of this library is, so each
+        // gets a queue -- and the file's pieces go up on a stream of the pipeline's own at the low level (its barrier packets wait
+        // for DMA: nobody's kernels may stand behind them, the counting passes of chromosomes that are complete included).  The
+        // process keeps the four for its next call on the device (~Pipe): made anew after they had been given back they were seen
+        // to share a queue again.  SPL_STREAM_PRIORITIES=0: all at the normal level and made per call, as before (2, 3, 4: the
+        // variants measured in the profile).
         hipError_t make(size_t n_pieces, int n_copy_streams, bool second_upload)
         {
-            hipError_t e = hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
-            for (int k = 0; k < NCOPY && k < n_copy_streams && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&cp[k], hipStreamNonBlocking);
+            int least = 0, greatest = 0;
+            const char *pe = getenv("SPL_STREAM_PRIORITIES");
+            const bool levels = !(pe && pe[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least;
+            if (!levels) (void)hipGetLastError();
+            auto stream_at = [&](hipStream_t *s, int priority) { return levels ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority) : hipStreamCreateWithFlags(s, hipStreamNonBlocking); };
+            hipError_t e = hipSuccess;
+            keep = levels && !(pe && pe[0] == '3');
+            if (keep) { // the streams an earlier call of this process left (and their queues with them: see ~Pipe)
+                std::lock_guard<std::mutex> lock(kept_mu());
+                std::vector<Kept> &v = kept();
+                for (size_t k = 0; k < v.size(); ++k)
+                    if (v[k].device == c->device && v[k].n_copy == n_copy_streams) { a = v[k].a; b = v[k].b; up = v[k].up; for (int q = 0; q < NCOPY; ++q) cp[q] = v[k].cp[q]; v.erase(v.begin() + (long)k); break; }
+            }
+            n_copy_made = n_copy_streams;
+            if (!a) {
+                e = stream_at(&a, greatest);
+                if (e == hipSuccess) e = stream_at(&b, pe && pe[0] == '2' ? least : greatest);
+                for (int k = 0; k < NCOPY && k < n_copy_streams && e == hipSuccess; ++k) e = stream_at(&cp[k], greatest);
+                if (e == hipSuccess && levels && !(pe && pe[0] == '4')) e = stream_at(&up, least);
+            }
             if (e == hipSuccess && second_upload) e = hipStreamCreateWithFlags(&up2, hipStreamNonBlocking);
             for (int k = 0; k < NBUF && e == hipSuccess; ++k) {
                 e = hipEventCreateWithFlags(&k1[k], hipEventDisableTiming);
@@ -1409,16 +1470,30 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             for (int k = 0; k < NCOPY; ++k) if (cp[k]) (void)hipStreamSynchronize(cp[k]);
             if (b) (void)hipStreamSynchronize(b);
             if (c->copy) (void)hipStreamSynchronize(c->copy);
+            if (up) (void)hipStreamSynchronize(up);
             if (up2) (void)hipStreamSynchronize(up2);
             for (hipEvent_t e : piece) if (e) (void)hipEventDestroy(e);
             for (hipEvent_t e : dec) if (e) (void)hipEventDestroy(e);
             for (hipEvent_t e : k2) if (e) (void)hipEventDestroy(e);
             for (int k = 0; k < NBUF; ++k) { if (k1[k]) (void)hipEventDestroy(k1[k]); if (freed[k]) (void)hipEventDestroy(freed[k]); }
             if (setup) (void)hipEventDestroy(setup);
+            if (up2) (void)hipStreamDestroy(up2);
+            // The three streams stay with the process for its next call on this device (idle: everything on them has been waited
+            // for above): the queues the runtime gave them the first time were each its own, and a stream made anew after they
+            // had been given back was seen to share one (windows of 25 ms instead of 15 from the second call on).
+            if (keep && a && b && cp[0]) {
+                std::lock_guard<std::mutex> lock(kept_mu());
+                if (kept().size() < 16) {
+                    Kept k{c->device, n_copy_made, a, b, up, {}};
+                    for (int q = 0; q < NCOPY; ++q) k.cp[q] = cp[q];
+                    kept().push_back(k);
+                    return;
+                }
+            }
             if (a) (void)hipStreamDestroy(a);
             for (int k = 0; k < NCOPY; ++k) if (cp[k]) (void)hipStreamDestroy(cp[k]);
             if (b) (void)hipStreamDestroy(b);
-            if (up2) (void)hipStreamDestroy(up2);
+            if (up) (void)hipStreamDestroy(up);
         }
     } pipe(c);
     // ---- the share: which blocks, which bytes of the file
@@ -1521,6 +1596,34 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     const bool two_up = getenv("SPL_UPLOAD_STREAMS") && atoi(getenv("SPL_UPLOAD_STREAMS")) >= 2; // (the file's pieces on two streams in turn)
     HIP_TRY(pipe.make(n_pieces, n_copy, two_up));
     t_pipe = host_now() - t_begin;
+    // The extracted arrays' first size, BEFORE anything runs on the device: device memory asked for while kernels are running was
+    // seen to take 30-60 ms a request on one box of four (profiles/r06s_first_call.txt; an idle device: 0.3 ms), and the arrays used to
+    // be sized from the first window's scan -- four or five such requests between the first window and the second.  So the host
+    // looks at a few blocks itself (spl_bam_sample_density: records and CIGAR ops per inflated byte at three places), a quarter
+    // is added, and make_room below finds the room there -- or grows it, as before, where the sample was wrong.
+    uint64_t cap_rec = 0, cap_ops = 0, n_rec = 0, n_ops = 0;
+    auto early_room = [&](size_t b_lo, size_t b_hi, double inflated_bytes) -> int {
+        if (cap_rec || getenv("SPL_NO_EARLY_ROOM")) return SPL_OK;
+        uint64_t s_rec = 0, s_ops = 0, s_bytes = 0;
+        if (!spl_bam_sample_density(bam, b_lo, b_hi, &s_rec, &s_ops, &s_bytes)) return SPL_OK;
+        const double scale = 1.25 * inflated_bytes / (double)s_bytes;
+        const uint64_t want_rec = (uint64_t)std::min((double)s_rec * scale, inflated_bytes / 36.0) + 1024;
+        const uint64_t want_ops = (uint64_t)std::min((double)s_ops * scale, inflated_bytes / 4.0) + 1024;
+        HIP_TRY(look_at_free());
+        if ((double)(14 * want_rec + 4 * want_ops) > (double)free_b / 3.0) return SPL_OK; // (a guess must not be what the windows' buffers go without)
+        HIP_TRY(d_pos.get(4 * want_rec, pipe.b));
+        HIP_TRY(d_flag.get(2 * want_rec, pipe.b));
+        HIP_TRY(d_cigoff.get(4 * (want_rec + 1), pipe.b));
+        HIP_TRY(d_cigar.get(4 * want_ops, pipe.b));
+        HIP_TRY(d_tid.get(4 * want_rec, pipe.b));
+        HIP_TRY(hipMemsetAsync(d_cigoff.p, 0, 4, pipe.b));
+        used_b += (size_t)(14 * want_rec + 4 * want_ops);
+        cap_rec = want_rec;
+        cap_ops = want_ops;
+        if (timing) fprintf(stderr, "[spl_bam_decode_device] device %d: room for %llu records and %llu CIGAR ops from %llu records in %.1f KB on the host\n", c->device,
+                            (unsigned long long)want_rec, (unsigned long long)want_ops, (unsigned long long)s_rec, (double)s_bytes / 1e3);
+        return SPL_OK;
+    };
     std::vector<hipError_t> errs(n_stage, hipSuccess);
     std::vector<std::atomic<int>> sent(n_pieces); // piece k's copy and event are in the copy stream's queue (or will never be: errs)
     for (auto &f : sent) f.store(0, std::memory_order_relaxed);
@@ -1535,12 +1638,12 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     auto up_wake = [&]() { { std::lock_guard<std::mutex> lock(up_mu); } up_cv.notify_all(); };
     const int fd = spl_bam_fd(bam);
     char *const d_img = d_image.as<char>();
-    if (two_up) HIP_TRY(hipStreamSynchronize(c->copy)); // (what was put on the copy stream for the image so far is done before the other stream writes into it)
+    if (two_up || pipe.up) HIP_TRY(hipStreamSynchronize(c->copy)); // (what was put on the copy stream for the image so far is done before the other stream writes into it)
     auto reader = [&](size_t t) {
         if (hipSetDevice(c->device) != hipSuccess) errs[t] = hipErrorInvalidDevice;
         spl_ctx::Stage &st = c->stage[t];
         for (size_t k = t; k < n_pieces; k += n_stage) {
-            hipStream_t up = two_up && (t & 1u) ? pipe.up2 : c->copy;
+            hipStream_t up = two_up && (t & 1u) ? pipe.up2 : pipe.upload();
             if (errs[t] == hipSuccess && k >= ring) { // the slot's last piece must have been read by everybody who reads it
                 size_t w = 0;
                 {
@@ -1594,7 +1697,16 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     size_t early = 0;  // blocks of the first window if it has been launched already (0: not)
     size_t early2 = 0; // where the second window ends if ITS decoding kernel has been launched as well (0: not)
     struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } walker; // (the rest of the directory, walked beside the second window's launch)
-    for (size_t t = 0; t < n_stage; ++t) crew.threads.emplace_back(reader, t);
+    // (the readers start when the device memory the call can size by now has been asked for: a request for gigabytes made while
+    //  the copy engines are busy with the file's pieces was seen to take 20-25 ms a gigabyte, 0.1 ms before: SPL_READERS_FIRST=1
+    //  for the old order)
+    bool readers_started = false;
+    auto start_readers = [&]() {
+        if (readers_started) return;
+        readers_started = true;
+        for (size_t t = 0; t < n_stage; ++t) crew.threads.emplace_back(reader, t);
+    };
+    if (getenv("SPL_READERS_FIRST")) start_readers();
     // where a window that begins with block b0 ends: win_blocks blocks on, or where its bytes in the file would not fit a quarter of the ring
     auto window_end = [&](const std::vector<uint64_t> &off, size_t b0, size_t n_all) {
         size_t b1 = std::min(n_all, b0 + win_blocks);
@@ -1629,6 +1741,22 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 HIP_TRY(d_stream[0].get(HEAD + (uint64_t)b_most * 65536u + 256, c->copy)); // (no block inflates to more than 64 KiB)
                 HIP_TRY(d_zwork[0].get(work0, c->copy));
                 used_b += (size_t)HEAD + b_most * 65536u + work0;
+                // (the second window's buffers and the extracted arrays too while the device is idle -- see early_room)
+                HIP_TRY(look_at_free());
+                const bool more_windows = two || (double)n_bytes / std::max(per_block_file, 28.0) > 1.02 * (double)b_most; // (as far as the directory so far can tell)
+                if (more_windows && (double)HEAD + (double)b_most * 65536.0 + (double)work0 + 2.0 * slack < (double)free_b && !getenv("SPL_NO_EARLY_ROOM")) {
+                    HIP_TRY(d_stream[1].get(HEAD + (uint64_t)b_most * 65536u + 256, c->copy));
+                    HIP_TRY(d_zwork[1].get(work0, c->copy));
+                    used_b += (size_t)HEAD + b_most * 65536u + work0;
+                }
+                {
+                    spl_bam_block_info last;
+                    spl_bam_block_get(bam, n_known - 1, &last);
+                    const double ratio = (double)(last.uoff + last.isize) / (double)std::max<uint64_t>(last.data_off + last.data_len, 1);
+                    rc = early_room(0, n_known, ratio * (double)n_bytes);
+                    if (rc) return rc;
+                }
+                start_readers();
                 t_early_bufs = host_now() - t_begin;
                 HIP_TRY(d_blocks0.get(sizeof(spl_zblock) * b2, c->copy));
                 HIP_TRY(d_status0.get(4 * b2, c->copy));
@@ -1664,8 +1792,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 if (b2 > b1) HIP_TRY(look_at_free());
                 if (b2 > b1 && (double)work0 + 2.0 * slack < (double)free_b) {
                     walker.t = std::thread([&]() { const double w0 = host_now(); walk_rc = spl_bam_walk_all(bam); t_walk = host_now() - w0; });
-                    HIP_TRY(d_zwork[1].get(work0, c->copy));
-                    used_b += work0;
+                    if (!d_zwork[1].p) { HIP_TRY(d_zwork[1].get(work0, c->copy)); used_b += work0; }
                     const size_t need2 = std::min(n_pieces, piece_of(off0[b2 - 1]) + 1);
                     for (; pieces_waited < need2; ++pieces_waited) {
                         wait_sent(pieces_waited);
@@ -1683,6 +1810,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             }
         }
     }
+    if (!share) start_readers(); // (a share's: behind its buffers, below -- its directory is complete and the rest takes a millisecond)
     if (!share) {
         if (walker.t.joinable()) walker.t.join();
         else { const double w0 = host_now(); walk_rc = spl_bam_walk_all(bam); t_walk = host_now() - w0; } // (what the early part left)
@@ -1751,9 +1879,12 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         return to_host("not enough device memory for the inflated stream");
     for (int k = 0; k < std::max(n_buf, n_zw); ++k) {
         if (k == 0 && early) continue; // (the first window has its buffers, large enough for any)
-        if (k < n_buf) HIP_TRY(d_stream[k].get(HEAD + win_cap + 256, c->copy));
-        if (k < n_zw && !(k == 1 && early2)) HIP_TRY(d_zwork[k].get(work_bytes, c->copy)); // (the second window's tokens have theirs if its decoding went out early)
+        if (k < n_buf && !d_stream[k].p) HIP_TRY(d_stream[k].get(HEAD + win_cap + 256, c->copy)); // (the early ones are large enough for any window)
+        if (k < n_zw && !d_zwork[k].p) HIP_TRY(d_zwork[k].get(work_bytes, c->copy));
     }
+    rc = early_room(lo, lo + n_own, (double)(blocks[n_own - 1].out + blocks[n_own - 1].out_len - stream_begin)); // (a share, or a file whose first window did not go out early: nothing runs yet)
+    if (rc) return rc;
+    start_readers();
     // where the placed records of a window's blocks begin (scan -> extraction, one window at a time on stream B): room for a window's
     // blocks and what an 8 MB carry can hold of ordinary ones; a window with more blocks than that is extracted by walking
     const size_t recs_blocks = std::min(n_own, win_blocks + (size_t)32768);
@@ -1788,7 +1919,6 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     if (first_share)
         while (first < n_blocks && blocks[first].out + blocks[first].out_len <= H && !(blocks[first].out + blocks[first].out_len == H && first + 1 == n_blocks)) ++first;
     // the extracted arrays: as large as the first window says the share will need and a fifth more, larger when that was wrong
-    uint64_t cap_rec = 0, cap_ops = 0, n_rec = 0, n_ops = 0;
     auto make_room = [&](uint64_t need_rec, uint64_t need_ops, double part_done) -> int {
         if (need_rec <= cap_rec && need_ops <= cap_ops && cap_rec) return SPL_OK;
         const double scale = 1.2 / std::max(part_done, 1e-6); // (a fifth more than the windows so far say: growing later means fresh memory and moving what is there)

@@ -306,7 +306,7 @@ def _plan(bam, want):
 HG38_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 58, 64, 46, 50, 156, 57]
 
 
-def _check_plan(shares, sizes, want, balance):
+def _check_plan(shares, sizes, want, balance, unplaced=0):
     """Every record is in exactly one share (the host's walk of every share arrives at the next share's first record, and the
     shares' records per reference add up to the file's), the references a share holds are among those it says it can hold, the
     shares are in file order and equal in file bytes."""
@@ -320,7 +320,7 @@ def _check_plan(shares, sizes, want, balance):
         held = np.nonzero(per)[0]
         assert len(held) and held.min() >= lo and held.max() < hi
         assert hi - lo <= (held.max() - held.min() + 1) + 1      # (a superset by one reference at most)
-    assert total[:-1].tolist() == list(sizes) and total[-1] == 0
+    assert total[:-1].tolist() == list(sizes) and total[-1] == unplaced
     size = [info["file_bytes"] for _, _, info, _ in shares]
     assert max(size) <= balance * sum(size) / len(size), size
 
@@ -368,6 +368,39 @@ def test_share_plan_on_a_five_chromosome_genome_and_odd_files(built, tmp_path):
         got = whole.reads(c)
         assert (got.n if got is not None else 0) == sets[c].n
     whole.close()
+
+
+def edge_file(path, seed, n=900, unplaced=700):
+    """A file for a share's edges to fall on: records longer than a BGZF block (2 % of them, 70-260 kb of SEQ and QUAL), a
+    reference without reads between two that have them, records without a reference after the last one."""
+    rng = np.random.default_rng(seed)
+    names = ["c0", "gap", "c1", "c2"]
+    sets = {}
+    for c in ("c0", "c1", "c2"):
+        pos = np.sort(rng.integers(1, 10 ** 7, n)).astype(np.int32)
+        long_one = rng.random(n) < 0.02
+        ops, off = [], [0]
+        for i in range(n):
+            if long_one[i]:
+                ops += [(int(rng.integers(70_000, 260_000)) << 4) | 0]
+            else:
+                ops += [(int(rng.integers(20, 90)) << 4) | 0, (int(rng.integers(60, 5000)) << 4) | 3, (int(rng.integers(20, 90)) << 4) | 0]
+            off.append(len(ops))
+        sets[c] = samio.ReadSet(pos, rng.choice([0, 16, 99, 147], size=n).astype(np.uint16), np.array(off, np.uint32), np.array(ops, np.uint32))
+    sets["gap"] = samio.ReadSet(np.zeros(0, np.int32), np.zeros(0, np.uint16), np.zeros(1, np.uint32), np.zeros(0, np.uint32))
+    samio.write_bam(path, names, [10 ** 8] * 4, [(c, sets[c]) for c in ("c0", "c1", "c2")], with_seq=True, unplaced=unplaced, level=1)
+    return names, sets
+
+
+@pytest.mark.parametrize("want", [2, 3, 5, 8])
+def test_share_plan_over_long_records_and_an_unplaced_tail(built, tmp_path, want):
+    """Cuts that fall inside records of several blocks, next to a reference without reads and among the records without a
+    reference: the plan still gives every record to exactly one share."""
+    path = str(tmp_path / "edges.bam")
+    names, sets = edge_file(path, 5 + want)
+    bam = native.BamFile(path, defer=True)
+    _check_plan(_plan(bam, want), [sets[c].n for c in names], want, 1.6, unplaced=700)
+    bam.close()
 
 
 def test_htslib_shaped_writer(built, tmp_path):

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from spliser_amd import native, samio
-from test_bam_decode import _random_sets, _same
+from test_bam_decode import _random_sets, _same, edge_file
 
 pytestmark = pytest.mark.gpu
 
@@ -320,6 +320,29 @@ def test_reads_of_every_share_come_back_to_the_host(tmp_path):
     assert bam.join_decoders() is True and len(plan) == 3
     for c in names:
         _same(bam.reads(c), sets[c])
+    bam.close()
+
+
+@pytest.mark.parametrize("n_shares", [2, 3, 5, 8])
+def test_shares_over_long_records_an_empty_reference_and_an_unplaced_tail(tmp_path, n_shares):
+    """What a share's edge may fall on: records longer than a BGZF block (the first record of a share then begins several blocks
+    past its first block), a reference without reads between two that have them, and records without a reference after the last
+    one.  Whichever decoder ends up with the file, every read is there once and ``n_records`` counts the unplaced ones."""
+    path = str(tmp_path / "edges.bam")
+    names, sets = edge_file(path, 5 + n_shares)
+    bam = native.BamFile(path, defer=True)
+    try:
+        bam.decode_on_devices_async([0] * n_shares)
+    except native.SpliserNativeError:
+        pass
+    bam.join_decoders()
+    assert bam.n_records == 3 * 900 + 700
+    for c in names:
+        got = bam.reads(c)
+        if sets[c].n == 0:
+            assert got is None or got.n == 0
+        else:
+            _same(got, sets[c])
     bam.close()
 
 

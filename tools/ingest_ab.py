@@ -26,6 +26,7 @@ ap.add_argument("--configs", default="default:")
 ap.add_argument("--devices", default="0")
 ap.add_argument("--files", default="/tmp/wl_files")
 ap.add_argument("--child", default=None)
+ap.add_argument("--show-stderr", action="store_true", help="print what the children wrote to stderr (SPL_BAM_TIMING=1's stamps)")
 args = ap.parse_args()
 
 prefix = os.path.join(args.files, "%s_s%g_q%d" % (args.workload, args.scale, args.seq_mode))
@@ -60,7 +61,9 @@ if args.child is None:
                 continue
             results[name].append(json.loads(line[-1]))
             r = results[name][-1]
-            print("round %d %-12s walls %s  kernels(ms/call): %s" % (rnd, name, " ".join("%.3f" % w for w in r["walls"]),
+            if args.show_stderr and out.stderr:
+                print(out.stderr, flush=True)
+            print("round %d %-12s first %.3f walls %s  kernels(ms/call): %s" % (rnd, name, r["first"], " ".join("%.3f" % w for w in r["walls"]),
                                                                      ", ".join("%s %.1f" % (k["kernel"].replace("spl_", "").replace("_kernel", ""), k["ms"] / r["calls"]) for k in r["kernels"][:8])), flush=True)
     print(json.dumps(results))
 else:
@@ -69,7 +72,10 @@ else:
     n_reads = int(open(prefix + ".n").read())
     devices = tuple(int(d) for d in args.devices.split(","))
     walls = []
-    process.process(prefix + ".bam", prefix + ".bed", prefix + ".out", annotationFile=prefix + ".gff", log=lambda m: None, devices=devices)   # (warm: memory pool, page cache)
+    native.Context(devices[0]).close()      # (the GPU context and the code object: not the first call's to pay for, as in bench.py)
+    t = time.perf_counter()
+    process.process(prefix + ".bam", prefix + ".bed", prefix + ".out", annotationFile=prefix + ".gff", log=lambda m: None, devices=devices)   # (the first call: no device memory at hand yet)
+    first = time.perf_counter() - t
     process.wait_deferred_close()
     native.prof_enable(True)
     for k in range(args.runs):
@@ -79,4 +85,4 @@ else:
         process.wait_deferred_close()
     rep = native.prof_report()
     native.prof_enable(False)
-    print(json.dumps(dict(config=args.child, reads=n_reads, bam_bytes=os.path.getsize(prefix + ".bam"), calls=args.runs, walls=[round(w, 4) for w in walls], kernels=rep)))
+    print(json.dumps(dict(config=args.child, reads=n_reads, bam_bytes=os.path.getsize(prefix + ".bam"), calls=args.runs, first=round(first, 4), walls=[round(w, 4) for w in walls], kernels=rep)))
