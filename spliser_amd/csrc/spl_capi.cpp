@@ -743,7 +743,7 @@ static void build_junction_table(const spl_sites *s, const std::vector<uint8_t> 
     if (jrivals.empty()) jrivals.assign(2, make_uint4(0, 0, 0xffffffffu, 0xffffffffu));
 }
 
-static int ensure_stage(spl_ctx *c);
+static int ensure_stage(spl_ctx *c, int n_min = 0);
 static int grow_stage(spl_ctx *c, int n);
 
 extern "C" int spl_sites_upload(spl_ctx *c, const spl_sites *s, spl_dsites **out)
@@ -942,9 +942,9 @@ static std::mutex &stage_pool_mu() { static std::mutex m; return m; }
 static std::vector<PooledStage> &stage_pool() { static std::vector<PooledStage> *p = new std::vector<PooledStage>(); return *p; } // (never destroyed: no order-of-exit games with the HIP runtime)
 
 // The staging ring and the copy stream of a context (created at the first upload).
-static int ensure_stage(spl_ctx *c)
+static int ensure_stage(spl_ctx *c, int n_min)
 {
-    if (!c->stage.empty()) return SPL_OK;
+    if (!c->stage.empty()) return (int)c->stage.size() < n_min ? grow_stage(c, n_min) : SPL_OK;
     size_t mb = 32;
     int n = 3;
     if (const char *e = getenv("SPL_STAGE_MB")) { const long v = atol(e); if (v >= 1 && v <= 4096) mb = (size_t)v; }
@@ -963,35 +963,21 @@ static int ensure_stage(spl_ctx *c)
         c->stage_timing = true;
     }
     c->stage_mb = mb;
-    return grow_stage(c, n);
+    return grow_stage(c, getenv("SPL_STAGE_BUFFERS") ? n : std::max(n, n_min)); // (all the buffers the caller will want in one go: they are made side by side)
 }
 
-// The staging ring of a context grown to n buffers (never shrunk): page-locked, of the ring's size, from the process's pool of
-// such buffers first.
-static int grow_stage(spl_ctx *c, int n)
+static size_t stage_bytes_of(size_t mb) { const size_t huge = 2u << 20; return (mb << 20) / huge * huge < huge ? huge : (mb << 20) / huge * huge; }
+
+// n_new page-locked staging buffers of `bytes` for `device`, made side by side, a thread each: touching 32 MiB and locking it is
+// 3-8 ms of a new process's first call, six of them one behind the other were 15-50 ms before the file's first byte was on its way
+static void make_stage_buffers(int device, size_t bytes, bool want_lock, std::vector<spl_ctx::Stage> &made, std::vector<int> &why)
 {
-    const size_t mb = c->stage_mb;
-    const size_t huge = 2u << 20, bytes = (mb << 20) / huge * huge < huge ? huge : (mb << 20) / huge * huge;
-    const bool want_lock = !(getenv("SPL_STAGE_PAGEABLE"));
-    {   // buffers a destroyed context of this process left behind (same device, same size): page-locking 96 MiB anew costs 12 ms
-        std::lock_guard<std::mutex> lock(stage_pool_mu());
-        std::vector<PooledStage> &pool = stage_pool();
-        for (size_t k = pool.size(); k-- > 0 && (int)c->stage.size() < n;) {
-            if (pool[k].device != c->device || pool[k].st.bytes != bytes || pool[k].st.locked != want_lock) continue;
-            c->stage.push_back(pool[k].st);
-            pool.erase(pool.begin() + (long)k);
-        }
-    }
-    // the missing ones side by side, a thread each: touching 32 MiB and locking it is 3-8 ms of a new process's first call, six
-    // of them one behind the other were 15-50 ms before the file's first byte was on its way
-    const int n_new = n - (int)c->stage.size();
-    if (n_new <= 0) return SPL_OK;
-    std::vector<spl_ctx::Stage> made((size_t)n_new);
-    std::vector<int> why((size_t)n_new, SPL_OK);
+    const size_t huge = 2u << 20;
+    const int n_new = (int)made.size();
     auto make = [&](int k) {
         spl_ctx::Stage &st = made[(size_t)k];
         void *p = nullptr;
-        if (hipSetDevice(c->device) != hipSuccess) { why[(size_t)k] = SPL_ERR_HIP; return; }
+        if (hipSetDevice(device) != hipSuccess) { why[(size_t)k] = SPL_ERR_HIP; return; }
         if (posix_memalign(&p, huge, bytes) != 0) { why[(size_t)k] = SPL_ERR_NOMEM; return; }
         (void)madvise(p, bytes, MADV_HUGEPAGE);
         memset(p, 0, bytes); // touch: the pages exist before they are locked
@@ -1005,12 +991,32 @@ static int grow_stage(spl_ctx *c, int n)
             why[(size_t)k] = SPL_ERR_HIP;
         }
     };
-    {
-        std::vector<std::thread> crew;
-        for (int k = 1; k < n_new; ++k) crew.emplace_back(make, k);
-        make(0);
-        for (std::thread &t : crew) t.join();
+    std::vector<std::thread> crew;
+    for (int k = 1; k < n_new; ++k) crew.emplace_back(make, k);
+    if (n_new > 0) make(0);
+    for (std::thread &t : crew) t.join();
+}
+
+// The staging ring of a context grown to n buffers (never shrunk): page-locked, of the ring's size, from the process's pool of
+// such buffers first.
+static int grow_stage(spl_ctx *c, int n)
+{
+    const size_t bytes = stage_bytes_of(c->stage_mb);
+    const bool want_lock = !(getenv("SPL_STAGE_PAGEABLE"));
+    {   // buffers a destroyed context of this process left behind (same device, same size): page-locking 96 MiB anew costs 12 ms
+        std::lock_guard<std::mutex> lock(stage_pool_mu());
+        std::vector<PooledStage> &pool = stage_pool();
+        for (size_t k = pool.size(); k-- > 0 && (int)c->stage.size() < n;) {
+            if (pool[k].device != c->device || pool[k].st.bytes != bytes || pool[k].st.locked != want_lock) continue;
+            c->stage.push_back(pool[k].st);
+            pool.erase(pool.begin() + (long)k);
+        }
     }
+    const int n_new = n - (int)c->stage.size();
+    if (n_new <= 0) return SPL_OK;
+    std::vector<spl_ctx::Stage> made((size_t)n_new);
+    std::vector<int> why((size_t)n_new, SPL_OK);
+    make_stage_buffers(c->device, bytes, want_lock, made, why);
     int rc = SPL_OK;
     for (int k = 0; k < n_new; ++k) {
         if (why[(size_t)k] == SPL_OK) { c->stage.push_back(made[(size_t)k]); continue; }
@@ -1144,6 +1150,38 @@ static int add_segment(spl_ctx *c, spl_dreads *d, const splpack::Source &src, in
 // (spl_devpack.hip, add_segment_device), the host gets copies only when it asks (fetch_device_reads).
 namespace {
 // Device memory of the decode (devmem above: the file image and the inflated stream are the buffers that made it necessary).
+// The decode pipeline's streams (decode_share's Pipe), kept by the process between calls.
+namespace pipestreams {
+constexpr int NCOPY = 2;
+struct Kept { int device, n_copy; hipStream_t a, b, up, cp[NCOPY]; };
+static std::mutex &mu() { static std::mutex m; return m; }
+static std::vector<Kept> &kept() { static std::vector<Kept> *v = new std::vector<Kept>(); return *v; }
+// priority levels in use (SPL_STREAM_PRIORITIES=0: no) and their range on the current device
+static bool levels(int *least_out, int *greatest_out)
+{
+    int least = 0, greatest = 0;
+    const char *pe = getenv("SPL_STREAM_PRIORITIES");
+    const bool on = !(pe && pe[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least;
+    if (!on) (void)hipGetLastError();
+    if (least_out) *least_out = least;
+    if (greatest_out) *greatest_out = greatest;
+    return on;
+}
+// k.n_copy copy-kernel streams, the decoding kernel's, the short kernels' and the upload's, on the current device (see Pipe::make)
+static hipError_t create(Kept &k)
+{
+    int least = 0, greatest = 0;
+    const char *pe = getenv("SPL_STREAM_PRIORITIES");
+    const bool lv = levels(&least, &greatest);
+    auto stream_at = [&](hipStream_t *s, int priority) { return lv ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority) : hipStreamCreateWithFlags(s, hipStreamNonBlocking); };
+    hipError_t e = stream_at(&k.a, greatest);
+    if (e == hipSuccess) e = stream_at(&k.b, pe && pe[0] == '2' ? least : greatest);
+    for (int q = 0; q < NCOPY && q < k.n_copy && e == hipSuccess; ++q) e = stream_at(&k.cp[q], greatest);
+    if (e == hipSuccess && lv && !(pe && pe[0] == '4')) e = stream_at(&k.up, least);
+    return e;
+}
+} // namespace pipestreams
+
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { devmem::put(p); }
@@ -1380,10 +1418,9 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     size_t fsize = 0;
     const uint8_t *image = spl_bam_image(bam, &fsize);
     const int n_ref = spl_bam_n_ref(bam);
-    int rc = ensure_stage(c);
-    if (rc) return rc;
+    int rc = SPL_OK;
     // ---- everything the streams touch is declared before them: what is declared last goes first, and that is the guard that waits
-    constexpr int NBUF = 4, NCOPY = 2; // (at most: n_buf buffers and n_copy streams for the copying kernels are used, below)
+    constexpr int NBUF = 4, NCOPY = pipestreams::NCOPY; // (at most: n_buf buffers and n_copy streams for the copying kernels are used, below)
     DevBuf d_image, d_stream[NBUF], d_zwork[NBUF], d_blocks0, d_status0, d_recs, d_blocks, d_status, d_scan, d_recoff, d_opoff, d_pos, d_flag, d_cigoff, d_cigar, d_tid, d_maxend, d_bounds, d_nbounds;
     std::vector<spl_zblock> blocks, blocks0; // (blocks0: the first window's, for its early launch)
     std::unique_ptr<uint32_t[]> status;
@@ -1402,11 +1439,11 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         explicit Pipe(spl_ctx *ctx) : c(ctx) {}
         bool keep = false;
         int n_copy_made = 0;
-        struct Kept { int device, n_copy; hipStream_t a, b, up, cp[NCOPY]; };
+        using Kept = pipestreams::Kept;
         hipStream_t up = nullptr; // the file's pieces: a stream of this pipeline's own at the low level (a queue of its own again); without levels the context's copy stream
         hipStream_t upload() const { return up ? up : c->copy; }
-        static std::mutex &kept_mu() { static std::mutex m; return m; }
-        static std::vector<Kept> &kept() { static std::vector<Kept> *v = new std::vector<Kept>(); return *v; }
+        static std::mutex &kept_mu() { return pipestreams::mu(); }
+        static std::vector<Kept> &kept() { return pipestreams::kept(); }
         // (only the streams that will be used: the runtime deals streams out to a few hardware queues, and one more stream --
         //  made, never used -- put the decoding and the copying kernels behind each other: 0.75 s instead of 0.43 for a 14 GB file)
         // Which hardware queue a stream gets is the runtime's choice -- the least used of four per priority level, whatever else
@@ -1421,13 +1458,9 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         // variants measured in the profile).
         hipError_t make(size_t n_pieces, int n_copy_streams, bool second_upload)
         {
-            int least = 0, greatest = 0;
             const char *pe = getenv("SPL_STREAM_PRIORITIES");
-            const bool levels = !(pe && pe[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least;
-            if (!levels) (void)hipGetLastError();
-            auto stream_at = [&](hipStream_t *s, int priority) { return levels ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority) : hipStreamCreateWithFlags(s, hipStreamNonBlocking); };
             hipError_t e = hipSuccess;
-            keep = levels && !(pe && pe[0] == '3');
+            keep = pipestreams::levels(nullptr, nullptr) && !(pe && pe[0] == '3');
             if (keep) { // the streams an earlier call of this process left (and their queues with them: see ~Pipe)
                 std::lock_guard<std::mutex> lock(kept_mu());
                 std::vector<Kept> &v = kept();
@@ -1436,10 +1469,10 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             }
             n_copy_made = n_copy_streams;
             if (!a) {
-                e = stream_at(&a, greatest);
-                if (e == hipSuccess) e = stream_at(&b, pe && pe[0] == '2' ? least : greatest);
-                for (int k = 0; k < NCOPY && k < n_copy_streams && e == hipSuccess; ++k) e = stream_at(&cp[k], greatest);
-                if (e == hipSuccess && levels && !(pe && pe[0] == '4')) e = stream_at(&up, least);
+                Kept made{c->device, n_copy_streams, nullptr, nullptr, nullptr, {}};
+                e = pipestreams::create(made);
+                a = made.a; b = made.b; up = made.up;
+                for (int q = 0; q < NCOPY; ++q) cp[q] = made.cp[q];
             }
             if (e == hipSuccess && second_upload) e = hipStreamCreateWithFlags(&up2, hipStreamNonBlocking);
             for (int k = 0; k < NBUF && e == hipSuccess; ++k) {
@@ -1527,7 +1560,11 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     // piece = what a buffer holds, dealt round-robin), sends each on its way itself and records the piece's event behind it.
     // (a reader fills its buffer from the page cache at 8-10 GB/s before the copy engine takes 0.6 ms to empty it: three readers
     //  bring 25-40 GB/s, and since the kernels got through a window in 16 ms a large file waited for its bytes: six for those)
-    if (n_bytes >= ((size_t)4 << 30) && !getenv("SPL_STAGE_BUFFERS")) { rc = grow_stage(c, 6); if (rc) return rc; }
+    int n_copy = 1; // streams the copying kernels take turns on (1: one window's copies behind the other's)
+    if (const char *e = getenv("SPL_INFLATE_COPY_STREAMS")) n_copy = std::min(NCOPY, std::max(1, atoi(e)));
+    const bool two_up = getenv("SPL_UPLOAD_STREAMS") && atoi(getenv("SPL_UPLOAD_STREAMS")) >= 2; // (the file's pieces on two streams in turn)
+    rc = ensure_stage(c, n_bytes >= ((size_t)4 << 30) && !getenv("SPL_STAGE_BUFFERS") ? 6 : 0);
+    if (rc) return rc;
     const size_t n_stage = c->stage.size();
     t_stage = host_now() - t_begin;
     // On the device the file exists as a RING of pieces, not whole: only the Huffman decoding reads it, a window of blocks at a
@@ -1591,9 +1628,6 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     t_image = host_now() - t_begin;
     if (timing) fprintf(stderr, "[spl_bam_decode_device] device %d: the file's %.1f MB as %zu pieces of %.1f MB, %zu slots on the device (%.1f MB)%s\n", c->device, n_bytes / 1e6, n_pieces,
                         piece / 1e6, ring, ring * slot / 1e6, ring < n_pieces ? "" : ": all of it");
-    int n_copy = 1; // streams the copying kernels take turns on (1: one window's copies behind the other's)
-    if (const char *e = getenv("SPL_INFLATE_COPY_STREAMS")) n_copy = std::min(NCOPY, std::max(1, atoi(e)));
-    const bool two_up = getenv("SPL_UPLOAD_STREAMS") && atoi(getenv("SPL_UPLOAD_STREAMS")) >= 2; // (the file's pieces on two streams in turn)
     HIP_TRY(pipe.make(n_pieces, n_copy, two_up));
     t_pipe = host_now() - t_begin;
     // The extracted arrays' first size, BEFORE anything runs on the device: device memory asked for while kernels are running was

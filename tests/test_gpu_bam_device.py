@@ -434,3 +434,34 @@ def test_a_file_larger_than_the_free_device_memory(tmp_path, monkeypatch):
         for c in names:
             _same(dev.reads(c), sets[c])
         dev.close()
+
+
+@pytest.mark.parametrize("stranded", [None, "rf"])
+def test_the_command_line_as_a_child_process(tmp_path, stranded):
+    """``python -m spliser_amd process`` the way a user runs it -- a fresh interpreter that leaves through ``os._exit`` (``__main__``) --
+    writes the file the function writes in this process, twice (the second child finds the first's file in the page cache); a usage
+    error still ends with argparse's exit code."""
+    import os
+    import subprocess
+    import sys
+    from spliser_amd import synth
+    from spliser_amd.process import process
+    wl = synth.Workload("mouse_stranded" if stranded else "arabidopsis", scale=0.01, seed=21)
+    prefix = str(tmp_path / "s")
+    synth.write_bed(prefix + ".bed", wl.genome.chrom_names, wl.junctions, stranded=bool(stranded))
+    synth.write_gff(prefix + ".gff", wl.genome)
+    native.write_bam(prefix + ".bam", wl.genome.chrom_names, wl.genome.chrom_lengths, wl.reads, level=1, threads=2, seq_mode=1)
+    process(prefix + ".bam", prefix + ".bed", prefix + ".here", annotationFile=prefix + ".gff", isStranded=bool(stranded), strandedType=stranded,
+            log=lambda m: None)
+    want = open(prefix + ".here.SpliSER.tsv").read()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for k, extra in enumerate(({}, {})):
+        argv = [sys.executable, "-m", "spliser_amd", "process", "-B", prefix + ".bam", "-b", prefix + ".bed", "-A", prefix + ".gff", "-o", prefix + ".cli%d" % k]
+        if stranded:
+            argv += ["--isStranded", "-s", stranded]
+        r = subprocess.run(argv, cwd=root, env=dict(os.environ, **extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:]
+        assert open(prefix + ".cli%d.SpliSER.tsv" % k).read() == want
+    r = subprocess.run([sys.executable, "-m", "spliser_amd", "process", "-B", prefix + ".bam"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       universal_newlines=True, timeout=300)
+    assert r.returncode == 2 and "required" in r.stdout
