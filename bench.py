@@ -971,6 +971,31 @@ def main():
     # outside the timed region: (a) the step as rounds 1-4 timed it -- from the records on, no layout -- for continuity
     # (roofline.count_only); (b) the range kernel with nothing beside it (a sync after every launch, so that the tail of a pass
     # is over before the next range kernel starts)
+    # WEAK beside strong (N > 1, strong mode): a step of N passes over the rank's own stretch -- every GPU counts as many reads a
+    # step as the one GPU of an N = 1 run does, in launches of 1/N the size -- timed the same way (barrier, MAX over ranks below)
+    weak_elapsed = None
+    if dist is not None and args.scaling == "strong" and world > 1:
+        fence()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            for _rep in range(world):
+                for ds, dr, _ in dev:
+                    dr.relayout()
+                    ctx.count_launch(ds, dr, scode, 0, kflags)
+                    ctx.sse_launch(ds, args.beta2Cryptic)
+            if not args.pipelined:
+                ctx.pass_barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        weak_elapsed = time.perf_counter() - tw
+        wt = torch.tensor([weak_elapsed], dtype=torch.float64, device=red_device)
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        weak_elapsed = float(wt.item())
+        same_w = all(all(np.array_equal(a, b) for a, b in zip(ds.counters(), g)) for (ds, _, _), g in zip(dev, gpu_counts))
+        we = torch.tensor([1.0 if same_w else 0.0], dtype=torch.float64, device=red_device)
+        dist.all_reduce(we, op=dist.ReduceOp.MIN)
+        weak_same = bool(we.item() > 0.5)
     step_no[0] = 0
     fence()
     t1 = time.perf_counter()
@@ -1044,6 +1069,11 @@ def main():
                     exact_rank &= np.array_equal(cnts[0][r0:r1], w1) and np.array_equal(cnts[1][r0:r1], w2) and np.array_equal(cnts[2][e0:e1], w3)
                     exact_rank &= all(np.array_equal(g[r0:r1], w) for g, w in zip(sses, wsse))
         elapsed, tot_reads, tot_sites, imbalance = reduce_report(dist, rank, world, n_reads, n_sites, my_elapsed, red_device, exact=exact_rank)
+        if weak_elapsed is not None:
+            imbalance["weak_beside"] = {"value": tot_sites * world * args.steps / weak_elapsed, "reads_per_sec": tot_reads * world * args.steps / weak_elapsed,
+                                        "ms_per_step": weak_elapsed / args.steps * 1e3, "same_counters": weak_same,
+                                        "what": "weak scaling beside the strong figure: a step = every rank counts its own stretch %d times (the reads one GPU "
+                                                "counts a step at N = 1, in launches of 1/%d the size); barrier + MAX over ranks as for `value`" % (world, world)}
         if strong is not None:
             imbalance["split"] = "one sample cut into %d stretches of equal expected reads in file order, chromosomes cut anywhere; every rank generated its own stretch only" % world
         # the collectives are over: what follows (parity, the end-to-end legs over ALL the node's GPUs) is rank 0's alone, the other
