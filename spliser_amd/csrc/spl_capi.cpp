@@ -1256,7 +1256,25 @@ static int fetch_device_reads(void *h, int32_t **pos_out, uint16_t **flag_out, u
     hipStream_t st = nullptr;
     if (ok && q == hipSuccess) q = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     if (ok && q == hipSuccess) {
-        for (Arr &a : arr) if (a.bytes >= (1u << 20)) a.pinned = hipHostRegister(a.host, a.bytes, hipHostRegisterDefault) == hipSuccess; // (locking faults the pages in)
+        // The pages first, on several threads: locking a fresh array faults its pages in one by one on the calling thread -- 0.33 GB
+        // of a 20 M-read sample were 50 ms of the 80 this call took (`process --keepReads`, profiles/r06x_keep_reads.txt) --, a touch
+        // per 2 MiB from eight threads is the same zeroing side by side.  Then the arrays are locked side by side as well.
+        {
+            struct Touch { char *p; size_t bytes; };
+            std::vector<Touch> spans;
+            const size_t step = (size_t)16 << 20;
+            for (Arr &a : arr) for (size_t at = 0; at < a.bytes; at += step) spans.push_back(Touch{(char *)a.host + at, std::min(step, a.bytes - at)});
+            auto touch = [](size_t k, void *arg) {
+                const Touch &t = (*(const std::vector<Touch> *)arg)[k];
+                for (size_t at = 0; at < t.bytes; at += 4096) ((volatile char *)t.p)[at] = 0;
+            };
+            splpack::parallel_for(spans.size(), 8, touch, &spans);
+            std::vector<std::thread> lockers;
+            for (Arr &a : arr)
+                if (a.bytes >= (1u << 20))
+                    lockers.emplace_back([&a, r]() { a.pinned = hipSetDevice(r->device) == hipSuccess && hipHostRegister(a.host, a.bytes, hipHostRegisterDefault) == hipSuccess; });
+            for (std::thread &t : lockers) t.join();
+        }
         for (Arr &a : arr) if (q == hipSuccess && a.bytes) q = hipMemcpyAsync(a.host, a.dev, a.bytes, hipMemcpyDeviceToHost, st);
         if (q == hipSuccess) q = hipStreamSynchronize(st);
         for (Arr &a : arr) if (a.pinned) (void)hipHostUnregister(a.host);

@@ -512,8 +512,11 @@ def process(inBAM, inBed, outputPath, qGene="All", qChrom="All", maxIntronSize=0
             def keep():
                 t_keep = time.perf_counter()
                 kept = [(name, source.reads(name)) for name in source.ref_names]
+                t_down = time.perf_counter()
                 readstore.save(outputPath + readstore.SUFFIX, inBAM, [(name, rs) for name, rs in kept if rs is not None])
                 timings["keep_reads_s"] = time.perf_counter() - t_keep
+                if os.environ.get("SPL_PROCESS_TIMING"):
+                    sys.stderr.write("[process] kept reads: down from the device %.4f s, written %.4f s\n" % (t_down - t_keep, time.perf_counter() - t_down))
         t4 = time.perf_counter()
     except BaseException:
         keep = None

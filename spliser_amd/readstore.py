@@ -64,7 +64,11 @@ def save(path, bam_path, reads_by_ref, threads=8):
     go out in pieces of 16 MB on a few threads (``os.pwrite`` leaves the interpreter's lock: one thread copies 4 GB/s into the
     page cache, and a 20 M-read sample is 0.4 GB)."""
     from concurrent.futures import ThreadPoolExecutor
+    import sys
+    import time
+    t0 = time.perf_counter()
     size, mtime_ns, crc = bam_key(bam_path)
+    t_key = time.perf_counter()
     refs = [{"name": name, "n": int(rs.n), "ops": int(rs.cig_off[rs.n]) - int(rs.cig_off[0]) if rs.n else 0, "max_end": int(rs.max_end)}
             for name, rs in reads_by_ref]
     head_of = lambda digest: json.dumps({"version": VERSION, "bam_size": size, "bam_mtime_ns": mtime_ns, "bam_crc32": crc, "payload_sum": digest,   # noqa: E731
@@ -96,7 +100,9 @@ def save(path, bam_path, reads_by_ref, threads=8):
         piece = _PIECE
         parts = [(off + lo, memoryview(a).cast("B")[lo:lo + piece]) for off, a in jobs for lo in range(0, a.nbytes, piece)]
         # the checksum of what goes out, array by array in pieces of 16 MB (what open_if_fresh takes again, the same way)
+        t_jobs = time.perf_counter()
         head = head_of(_payload_sum([v for _, v in parts], threads))
+        t_sum = time.perf_counter()
         os.pwrite(fd, MAGIC + struct.pack("<II", VERSION, len(head)) + head, 0)
 
         def put(part):
@@ -106,6 +112,9 @@ def save(path, bam_path, reads_by_ref, threads=8):
                 off, view = off + n, view[n:]
         with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
             list(pool.map(put, parts))
+        if os.environ.get("SPL_PROCESS_TIMING"):
+            sys.stderr.write("[readstore] key of the BAM %.4f s, arrays made contiguous %.4f, checksum %.4f, %d pieces written %.4f\n"
+                             % (t_key - t0, t_jobs - t_key, t_sum - t_jobs, len(parts), time.perf_counter() - t_sum))
     finally:
         os.close(fd)
     os.replace(tmp, path)
