@@ -296,6 +296,10 @@ int spl_bam_start(spl_bam *bam);
  * what a decode costs; since the wave-per-block decoder the GPU is the faster side for a real library's file (3...4) and for one
  * that inflates at memset speed (synthetic data: 50) alike, and `process` no longer asks. */
 int spl_bam_compression_ratio(spl_bam *bam, double *ratio_out);
+/* Records, their CIGAR ops, and the inflated bytes both were counted in, sampled on the host at three places of the file (the
+ * whole block directory is walked first): out3 = {records, ops, bytes}.  What the device decoder sizes its extracted arrays by
+ * before anything runs on the device (spl_capi.cpp: early_room); here for tests and diagnostics.  SPL_ERR_FORMAT: cannot tell. */
+int spl_bam_sample(spl_bam *bam, int64_t *out3);
 int spl_bam_wait_ref(spl_bam *bam, int tid, int64_t *n_reads_out, int64_t *max_end_out);
 int spl_bam_wait_all(spl_bam *bam, int *sorted_out);
 /* spl_bam_close waits for a decode in progress to END.  A caller who only wants to leave (something else failed) says so first:

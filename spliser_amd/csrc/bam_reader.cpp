@@ -1413,6 +1413,18 @@ bool spl_bam_sample_density(spl_bam *bam, size_t b_lo, size_t b_hi, uint64_t *n_
     return n_rec != 0 && n_bytes != 0;
 }
 
+extern "C" int spl_bam_sample(spl_bam *bam, int64_t *out3)
+{
+    if (!bam || !out3) return spl_set_error(SPL_ERR_ARG, "spl_bam_sample: null argument");
+    const int rc = spl_bam_walk_all(bam);
+    if (rc) return rc;
+    uint64_t n_rec = 0, n_ops = 0, n_bytes = 0;
+    if (!spl_bam_sample_density(bam, 0, bam->dir.n_ready.load(), &n_rec, &n_ops, &n_bytes))
+        return spl_set_error(SPL_ERR_FORMAT, "%s: no whole record found where the sample looked", bam->path.c_str());
+    out3[0] = (int64_t)n_rec; out3[1] = (int64_t)n_ops; out3[2] = (int64_t)n_bytes;
+    return SPL_OK;
+}
+
 extern "C" int spl_bam_share_plan(spl_bam *bam, int n_shares, int *n_out)
 {
     if (!bam || n_shares < 1) return spl_set_error(SPL_ERR_ARG, "spl_bam_share_plan: bad argument");

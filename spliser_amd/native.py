@@ -50,7 +50,7 @@ EXPORTS = [
     "spl_reads_upload", "spl_reads_upload_segments", "spl_reads_begin", "spl_reads_begin_sized", "spl_reads_add", "spl_reads_add2", "spl_reads_add_bam", "spl_reads_add_bam_share", "spl_reads_finish",
     "spl_soa_upload", "spl_soa_upload2", "spl_soa_free", "spl_reads_add_soa", "spl_reads_relayout", "spl_layout_timing_collect", "spl_reads_layout_bytes",
     "spl_pack_host", "spl_reads_free", "spl_count_launch", "spl_sse_launch", "spl_counters_download",
-    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_share_info", "spl_bam_share_count_host", "spl_bam_share_ref", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_wait_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_cancel", "spl_bam_decline_reason", "spl_bam_close",
+    "spl_sse_download", "spl_count_algorithmic_bytes", "spl_literal_queue_size", "spl_last_launch_info", "spl_bam_open", "spl_bam_open_stream", "spl_bam_open_deferred", "spl_bam_decode_device", "spl_bam_reserve_device", "spl_bam_share_plan", "spl_bam_share_range", "spl_bam_share_info", "spl_bam_share_count_host", "spl_bam_share_ref", "spl_bam_decode_device_share", "spl_bam_decoded_on_device", "spl_bam_wait_device", "spl_bam_start", "spl_bam_compression_ratio", "spl_bam_sample", "spl_bam_wait_ref", "spl_bam_wait_all", "spl_bam_cancel", "spl_bam_decline_reason", "spl_bam_close",
     "spl_bam_n_ref", "spl_bam_ref_name", "spl_bam_ref_length", "spl_bam_n_records", "spl_bam_reads", "spl_bam_write", "spl_bam_write2",
     "spl_gene_search", "spl_junctions", "spl_junctions_get", "spl_tsv_append", "spl_tsv_append_many", "spl_fmt_fixed",
     "spl_bed_open", "spl_gff_open", "spl_text_close", "spl_text_rows", "spl_text_n_chrom", "spl_text_chrom_name", "spl_text_chrom",
@@ -668,6 +668,12 @@ class BamFile(object):
             t.start()
         self._device_thread = self._device_threads[0]
         return plan
+
+    def sample(self):
+        """-> (records, CIGAR ops, inflated bytes) of what the host sampled at three places of the file (``spl_bam_sample``)."""
+        out = (ctypes.c_int64 * 3)()
+        _check(lib().spl_bam_sample(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def share_info(self, k):
         """-> {file_bytes, u_lo, u_hi, tail_blocks} of share ``k`` of the plan (``spl_bam_share_info``)."""

@@ -403,6 +403,39 @@ def test_share_plan_over_long_records_and_an_unplaced_tail(built, tmp_path, want
     bam.close()
 
 
+@pytest.mark.parametrize("seq_mode,level", [(1, 1), (2, 6), (0, 1)])
+def test_the_hosts_sample_of_a_file_says_what_its_records_take(built, tmp_path, seq_mode, level):
+    """``spl_bam_sample`` (what the device decoder sizes its arrays by before it has scanned a window): records and CIGAR ops per
+    inflated byte from three places of the file, within a fifth of the file's own -- and the long-record file's, whose sample
+    falls between records of 200 kb."""
+    names, sets = _random_sets(33, 60_000, 3)
+    path = str(tmp_path / "s.bam")
+    native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=level, threads=2, seq_mode=seq_mode)
+    bam = native.BamFile(path, defer=True)
+    rec, ops, nbytes = bam.sample()
+    bam.close()
+    whole = native.BamFile(path, threads=2)
+    n_all = sum(whole.reads(c).n for c in names)
+    ops_all = sum(int(whole.reads(c).cig_off[-1]) for c in names)
+    whole.close()
+    inflated = 0
+    import gzip
+    with gzip.open(path, "rb") as fh:
+        while True:
+            chunk = fh.read(1 << 24)
+            if not chunk:
+                break
+            inflated += len(chunk)
+    assert rec > 100 and abs(rec / nbytes - n_all / inflated) < 0.2 * n_all / inflated
+    assert abs(ops / nbytes - ops_all / inflated) < 0.25 * ops_all / inflated
+    path2 = str(tmp_path / "edges.bam")
+    names2, sets2 = edge_file(path2, 9)
+    bam = native.BamFile(path2, defer=True)
+    rec, ops, nbytes = bam.sample()
+    bam.close()
+    assert rec > 0 and nbytes > 0 and ops >= rec
+
+
 def test_htslib_shaped_writer(built, tmp_path):
     """seq_mode 2 (what the bench's `htslib` legs decode): whole records per BGZF block, as htslib's bam_write1 cuts them; every
     record well-formed -- Illumina-style name, reg2bin as the SAM specification computes it, mate fields only for paired flags,
