@@ -459,14 +459,9 @@ static int create_ctx(int device_id, void *stream, bool use_given, spl_ctx **out
 {
     if (!out) return spl_set_error(SPL_ERR_ARG, "spl_create: null output");
     *out = nullptr;
-    // The HIP runtime deals a process's streams out to a few hardware queues (four unless told otherwise), and streams on one
-    // queue run behind each other.  A `process` call has eight (the decode's four, the counting context's three and one for
-    // nobody): with four queues it depends on the order they were made in whether the decoding and the copying kernel overlap
-    // (measured: 0.43 s or 0.75 s for the same 14 GB file; 0.82 s with two queues).  Eight queues, unless the caller has said
-    // otherwise -- and only if the runtime has not been started yet by somebody else (it reads this once).
-    // (once, before this library's first HIP call and before it has made a thread: setenv beside another thread's getenv is a race)
-    static std::once_flag queues_once;
-    std::call_once(queues_once, [] { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); });
+    // (Rounds 3-5 asked the runtime for eight hardware queues a priority level here -- GPU_MAX_HW_QUEUES, if nobody had started it
+    //  yet -- so that the decode's streams would not share one.  They have levels of their own now (decode_share: Pipe::make), and
+    //  with eight the cold command line was slower than with the runtime's four: profiles/r06s_first_call.txt, 6.)
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)

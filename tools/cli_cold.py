@@ -3,6 +3,26 @@
 tools/cli_cold.py file.bam file.bed file.gff"""
 import sys
 import time
+if len(sys.argv) > 1 and sys.argv[1] == "--walls":
+    # tools/cli_cold.py --walls file.bam file.bed file.gff [runs]: `python -m spliser_amd process` as a child, with the child's own
+    # wall-clock stamps (SPL_CLI_STAMPS=1): what lies before its main() -- the interpreter, the imports -- and behind it, until the
+    # parent has it back (the kernel taking the process apart: its mappings, its device memory, its queues)
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bam, bed, gff = sys.argv[2:5]
+    for k in range(int(sys.argv[5]) if len(sys.argv) > 5 else 5):
+        t_spawn = time.time()
+        r = subprocess.run([sys.executable, "-m", "spliser_amd", "process", "-B", bam, "-b", bed, "-A", gff, "-o", "/tmp/cli_cold_walls"] + os.environ.get("SPL_COLD_EXTRA", "").split(), cwd=root,
+                           env=dict(os.environ, SPL_CLI_STAMPS="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+        t_back = time.time()
+        st = {m.group(1): float(m.group(2)) for m in re.finditer(r"\[cli stamp\] ([a-z_ ]+) ([0-9.]+)", r.stdout)}
+        rt = re.search(r"Total runtime \(s\): \t([0-9.]+)", r.stdout)
+        print("wall %.3f = to __main__ %.3f + imports %.3f + main() %.3f (prints %s) + from main()'s return until the parent has it back %.3f"
+              % (t_back - t_spawn, st["__main__"] - t_spawn, st["imported"] - st["__main__"], st["main returned"] - st["imported"], rt.group(1)[:5] if rt else "?",
+                 t_back - st["main returned"]) + (" (%.3f of it behind os._exit)" % (t_back - st["leaving"]) if "leaving" in st else ""), flush=True)
+    sys.exit(0)
 t0 = time.perf_counter()
 import os
 if os.environ.get("SPL_COLD_IMPORT_TORCH"):     # (which HIP runtime the process ends up with: torch brings its own copy)

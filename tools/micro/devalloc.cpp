@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <unistd.h>
+#include <time.h>
 #include <thread>
 #include <vector>
 
@@ -30,15 +31,27 @@ int main(int argc, char **argv)
     if (argc >= 3 && !strcmp(argv[1], "dirty")) { // leave `argv[2]` GiB of device memory written to and not freed: what a process that exits leaves the driver
         const int n = atoi(argv[2]);
         double t_alloc = 0;
+        std::vector<void *> held;
         for (int k = 0; k < n; k += 4) {
             void *p = nullptr;
             const double t0 = now();
             if (hipMalloc(&p, 4 * GB) != hipSuccess) { printf("dirty: stopped at %d GiB\n", k); break; }
             t_alloc += now() - t0;
             CK(hipMemset(p, 0x77, 4 * GB));
+            held.push_back(p);
         }
         CK(hipDeviceSynchronize());
         printf("dirty: %d GiB written, hipMalloc took %.1f ms of it; leaving without freeing\n", n, t_alloc * 1e3);
+        if (argc >= 4 && !strcmp(argv[3], "free")) { // ... or freeing first: what does the process's end cost then?
+            const double t0 = now();
+            for (void *p : held) CK(hipFree(p));
+            printf("dirty: hipFree of all of it %.1f ms\n", (now() - t0) * 1e3);
+        }
+        {
+            struct timespec ts;
+            clock_gettime(CLOCK_REALTIME, &ts);
+            printf("leaving at %.6f\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec);
+        }
         fflush(stdout);
         _exit(0);
     }
