@@ -244,6 +244,21 @@ def test_inflate_windows_of_a_few_blocks(ctx, tmp_path, monkeypatch, window):
     dev.close()
 
 
+@pytest.mark.parametrize("levels", ["0", "1", "2", "3", "4"])
+def test_stream_set_ups_of_the_decode(ctx, tmp_path, monkeypatch, levels):
+    """SPL_STREAM_PRIORITIES: the decode's streams at priority levels of their own and kept by the process (1, the default), all at
+    the normal level and made per call as in rounds 3-5 (0), and the variants the profile measured (2: the short kernels' stream at
+    the low level; 3: made per call; 4: the file's pieces on the context's copy stream) -- windows of a few blocks, several calls
+    in a row (the second finds the first's streams), the same reads every way."""
+    monkeypatch.setenv("SPL_STREAM_PRIORITIES", levels)
+    monkeypatch.setenv("SPL_INFLATE_WINDOW_BLOCKS", "9")
+    for seq_mode, level, seed in ((1, 1, 51), (2, 6, 52), (1, 1, 53)):
+        names, sets = _random_sets(seed, 30_000, 3)
+        path = str(tmp_path / ("p%d.bam" % seed))
+        native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=level, threads=3, seq_mode=seq_mode)
+        assert _both(path, ctx, names, sets) is True
+
+
 @pytest.mark.parametrize("bufs", [("1", "1"), ("2", "1"), ("1", "3"), ("3", "2"), ("4", "4")])
 def test_windows_in_flight(ctx, tmp_path, monkeypatch, bufs):
     """A window's inflated bytes (copying kernel -> CRC32, scan, extraction) and its tokens (decoding kernel -> copying kernel) have
