@@ -1597,6 +1597,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     size_t ring = n_pieces; // slots
     size_t win_bytes_cap = (size_t)-1; // a window ends where its blocks' bytes in the file would exceed this (so that four windows fit the ring)
     double per_block_file = 65536.0;
+    uint32_t max_block_file = 0; // the most bytes of file any block known so far has
     {
         const size_t n_known = spl_bam_block_count(bam);
         const size_t b_lo = share ? (size_t)share->block_lo : 0, b_hi = share ? (size_t)share->block_hi : n_known;
@@ -1608,6 +1609,11 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
             per_block = (double)(f1.data_off - f0.data_off) / (double)(b_hi - 1 - b_lo);
         }
         per_block_file = per_block;
+        for (size_t i = b_lo; i < b_hi; ++i) { // (the largest block so far: the token room below goes by it)
+            spl_bam_block_info bi;
+            spl_bam_block_get(bam, i, &bi);
+            max_block_file = std::max<uint32_t>(max_block_file, bi.data_len);
+        }
         const double est_win = per_block * (double)win_blocks;
         size_t want = (size_t)(4.2 * est_win / (double)piece) + 4;
         if (const char *e = getenv("SPL_IMAGE_RING_PIECES")) want = (size_t)std::max(4, atoi(e)); // (tests: a ring of a few pieces)
@@ -1618,18 +1624,24 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     }
     // Token room per block (decoding kernel -> copying kernel).  The worst case is 82 048 bytes -- five bytes of tokens for four
     // of output -- and what BAM blocks take is 1.3 to 1.8 times their compressed size (29 KB where a block deflates to 16.6 KB):
-    // two token buffers at the worst case are 8 GB of the 26 GB a new process's first call waited for.  So: 2.5 times the file's
-    // mean compressed block + 4 KB, and a block that needs more says so (SPL_Z_TOKENS) -- the share is then decoded again with
-    // all of it (no real file was seen to; zlib's Z_HUFFMAN_ONLY streams in the tests do).  SPL_Z_ALL_TOKEN_ROOM=1: always all.
+    // two token buffers at the worst case are 8 GB of the 26 GB a new process's first call waited for.  So: 2.25 times the
+    // LARGEST compressed block the directory holds by now + 4 KB, and a block that needs more says so (SPL_Z_TOKENS) -- the share
+    // is then decoded again with all of it: zlib's Z_HUFFMAN_ONLY streams in the tests do, and until round 6, when the room
+    // went by the MEAN block (2.5 times it), so did every call on the bench's own htslib-shaped file -- its blocks deflate to
+    // 7.6 KB on average and to 15-18 KB at most, and one block in the first window always needed more than 23 KB: the call began
+    // twice, 0.37 s instead of 0.32 (profiles/r06G_decode_five_waves.txt).  SPL_Z_ALL_TOKEN_ROOM=1: always all.
     uint32_t tok_stride = SPL_Z_TOKEN_STRIDE;
     if (!all_token_room && !getenv("SPL_Z_ALL_TOKEN_ROOM")) {
-        const double want = 2.5 * per_block_file + 4096.0;
+        const double want = getenv("SPL_Z_ROOM_BY_MEAN") ? 2.5 * per_block_file + 4096.0 : 2.25 * (double)std::max<uint32_t>(max_block_file, (uint32_t)per_block_file) + 4096.0;
         tok_stride = (uint32_t)std::min<double>((double)SPL_Z_TOKEN_STRIDE, std::max(8192.0, want));
         if (const char *e = getenv("SPL_Z_TOKEN_ROOM")) tok_stride = (uint32_t)std::max(512, atoi(e)); // (tests: a room most blocks do not fit)
         tok_stride = (tok_stride + 63u) & ~63u;
         if (tok_stride > SPL_Z_TOKEN_STRIDE) tok_stride = SPL_Z_TOKEN_STRIDE;
     }
-    if (timing) fprintf(stderr, "[spl_bam_decode_device] device %d: %u bytes of token room a block (%.0f bytes of file a block)\n", c->device, tok_stride, per_block_file);
+    // which decoding kernel: the denser one for files whose blocks deflate well (spl_inflate.hip)
+    const uint32_t k1_flags = per_block_file <= 12288.0 ? SPL_Z_LAUNCH_DENSE : 0u;
+    if (timing) fprintf(stderr, "[spl_bam_decode_device] device %d: %u bytes of token room a block (%.0f bytes of file a block, %u at most)%s\n", c->device, tok_stride, per_block_file,
+                        max_block_file, k1_flags ? ", the denser decoding kernel" : "");
     {   // a first look, before anything is allocated: the ring, two windows of a stream that is at most 64 KiB a block with their
         // token room, a fifth of the inflated stream for what is extracted; the exact sizes are checked again where they are known
         const double blocks_all = (double)n_bytes / std::max(per_block_file, 28.0) + 1.0, blocks_most = std::min((double)win_blocks, blocks_all);
@@ -1819,7 +1831,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 const double w_in = (double)(off0[b1 - 1] + blocks0[b1 - 1].in_len - off0[0]), w_out = (double)(blocks0[b1 - 1].out + blocks0[b1 - 1].out_len - blocks0[0].out);
                 {
                     splprof::Scope p("spl_inflate_decode_kernel", pipe.a, w_in + w_out);
-                    HIP_TRY((hipError_t)spl_dev_launch_inflate_decode2(image0, d_blocks0.as<spl_zblock>(), (uint32_t)b1, d_status0.as<uint32_t>(), d_zwork[0].p, tok_stride, pipe.a));
+                    HIP_TRY((hipError_t)spl_dev_launch_inflate_decode3(image0, d_blocks0.as<spl_zblock>(), (uint32_t)b1, d_status0.as<uint32_t>(), d_zwork[0].p, tok_stride, k1_flags, pipe.a));
                 }
                 HIP_TRY(hipEventRecord(pipe.k1[0], pipe.a));
                 HIP_TRY(hipEventRecord(pipe.dec[0], pipe.a));
@@ -1848,7 +1860,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                     }
                     {
                         splprof::Scope p("spl_inflate_decode_kernel", pipe.a, (double)(off0[b2 - 1] + blocks0[b2 - 1].in_len - off0[b1]) + (double)(blocks0[b2 - 1].out + blocks0[b2 - 1].out_len - blocks0[b1].out));
-                        HIP_TRY((hipError_t)spl_dev_launch_inflate_decode2(image0, d_blocks0.as<spl_zblock>() + b1, (uint32_t)(b2 - b1), d_status0.as<uint32_t>() + b1, d_zwork[1].p, tok_stride, pipe.a));
+                        HIP_TRY((hipError_t)spl_dev_launch_inflate_decode3(image0, d_blocks0.as<spl_zblock>() + b1, (uint32_t)(b2 - b1), d_status0.as<uint32_t>() + b1, d_zwork[1].p, tok_stride, k1_flags, pipe.a));
                     }
                     HIP_TRY(hipEventRecord(pipe.k1[1], pipe.a));
                     HIP_TRY(hipEventRecord(pipe.dec[1], pipe.a));
@@ -2011,7 +2023,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         const double w_in = (double)(foff[b1 - 1] + blocks[b1 - 1].in_len - foff[b0]), w_out = (double)(blocks[b1 - 1].out + blocks[b1 - 1].out_len - blocks[b0].out);
         {
             splprof::Scope p("spl_inflate_decode_kernel", pipe.a, w_in + w_out);
-            HIP_TRY((hipError_t)spl_dev_launch_inflate_decode2(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_zw].p, tok_stride, pipe.a));
+            HIP_TRY((hipError_t)spl_dev_launch_inflate_decode3(image0, d_blocks.as<spl_zblock>() + b0, (uint32_t)(b1 - b0), d_status.as<uint32_t>() + b0, d_zwork[k % (size_t)n_zw].p, tok_stride, k1_flags, pipe.a));
         }
         HIP_TRY(hipEventRecord(pipe.k1[k % (size_t)n_zw], pipe.a));
         HIP_TRY(hipEventRecord(pipe.dec[k], pipe.a));

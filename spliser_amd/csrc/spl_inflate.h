@@ -97,6 +97,11 @@ size_t spl_dev_inflate_work_bytes(uint32_t n_blocks);
 // SPL_Z_TOKENS): what real files' blocks need is a third of the worst case, and a first call waits for every gigabyte it is given
 size_t spl_dev_inflate_work_bytes2(uint32_t n_blocks, uint32_t stride);
 int spl_dev_launch_inflate_decode2(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *work, uint32_t stride, void *stream);
+// ... told which of the two decoding kernels to take (SPL_Z_LAUNCH_DENSE: the one with five waves a SIMD and 3 KB of token room a
+// tile, for files whose blocks deflate to 12 KB or less on average; decode2 decides by the stride alone).  SPL_Z_DENSE=0 / 1 in the
+// environment overrides either.
+#define SPL_Z_LAUNCH_DENSE 1u
+int spl_dev_launch_inflate_decode3(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *work, uint32_t stride, uint32_t flags, void *stream);
 int spl_dev_launch_inflate_copy2(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, uint32_t stride, void *stream);
 int spl_dev_launch_inflate(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, void *work, void *stream);
 // ... in two halves, for callers that put them on different streams: the Huffman decoding (token streams into `work`), then the

@@ -25,6 +25,26 @@ __global__ __launch_bounds__(64) void spl_inflate_decode_kernel(const uint8_t *i
     if (threadIdx.x == 0) { status[b] = st; n_tok[b] = st == SPL_Z_OK ? n : 0u; }
 }
 
+// The same kernel for files whose blocks deflate well (an aligner's BAM through samtools: 7-8 KB a block): FIVE waves a SIMD instead
+// of four.  What holds the kernel at four is its 10 KB of LDS a wave and its 120 registers; a tile of such a block has fewer tokens
+// (more of its output comes from matches), so 3 KB of token room a tile do where 5 are kept for blocks of literals, and the compiler
+// is held to 96 registers (nine of them spilled, in the header's parsing).  The waves' waits are what the kernel has most of
+// (41 % of its cycles): htslib-shaped human file 295 -> 276 ms of it a call, the call 0.379 -> 0.360 s; on the sequence-like file,
+// whose tiles would be cut short, it is 13 % slower and not used (profiles/r06G_decode_five_waves.txt).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void spl_inflate_decode_dense_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks,
+                                                                                                                     uint32_t *status, uint8_t *tokens_all, uint32_t *n_tok, uint32_t stride,
+                                                                                                                     uint32_t opts)
+{
+    __shared__ uint32_t raw[(sizeof(splz::Shared) - (splz::TOKCAP - splz::TOKCAP_SMALL)) / 4u]; // (Shared without the end of its last member)
+    splz::Shared &sh = *reinterpret_cast<splz::Shared *>(raw);
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const spl_zblock zb = blocks[b];
+    uint32_t n = 0;
+    const uint32_t st = splz::decode_block<splz::TOKCAP_SMALL>(sh, image, zb, tokens_all + (size_t)b * stride, n, stride, opts);
+    if (threadIdx.x == 0) { status[b] = st; n_tok[b] = st == SPL_Z_OK ? n : 0u; }
+}
+
 __global__ __launch_bounds__(64) void spl_inflate_copy_kernel(const spl_zblock *blocks, uint32_t n_blocks, uint8_t *out_all, uint32_t *status, const uint8_t *tokens_all,
                                                               const uint32_t *n_tok, uint32_t stride)
 {
@@ -381,6 +401,12 @@ extern "C" size_t spl_dev_inflate_work_bytes(uint32_t n_blocks) { return spl_dev
 
 extern "C" int spl_dev_launch_inflate_decode2(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *work, uint32_t stride, void *stream)
 {
+    // (by the stride alone: the token room a caller gives says how well its blocks deflate -- 2.5 x a block + 4 KB is the rule of thumb)
+    return spl_dev_launch_inflate_decode3(image, blocks, n_blocks, status, work, stride, stride <= 34816u ? SPL_Z_LAUNCH_DENSE : 0u, stream);
+}
+
+extern "C" int spl_dev_launch_inflate_decode3(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks, uint32_t *status, void *work, uint32_t stride, uint32_t flags, void *stream)
+{
     if (n_blocks == 0) return 0;
     if (!work) return (int)hipErrorInvalidValue; // (nothing would be launched and the blocks' status words left as they were: an error, not a success)
     if (stride < 256u || stride > SPL_Z_TOKEN_STRIDE || (stride & 15u)) return (int)hipErrorInvalidValue;
@@ -389,7 +415,15 @@ extern "C" int spl_dev_launch_inflate_decode2(const uint8_t *image, const spl_zb
     // (measured, round 6: fewer decoding waves a CU -- 12, 9, 8 instead of the 16 that fill its LDS, by padding -- make room for the
     //  copying kernel's waves and only slow the decoder, 294 -> 345 / 412 / 468 ms a human file, the copying kernel 234 -> 215:
     //  profiles/r06n_decode_lds_pad_q2.txt)
-    hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, status, (uint8_t *)work + tokens_at(n_blocks), (uint32_t *)work, stride, opts);
+    // Which kernel: the caller's word (spl_capi.cpp: files whose blocks deflate to 12 KB or less on average get the denser one).
+    // SPL_Z_DENSE=1 / 0: always / never (tests, A/B).
+    const char *const de = getenv("SPL_Z_DENSE"); // (looked up at every launch: the tests switch it)
+    const int dense_env = de ? atoi(de) : -1;
+    const bool dense = dense_env >= 0 ? dense_env != 0 : (flags & SPL_Z_LAUNCH_DENSE) != 0u;
+    if (dense)
+        hipLaunchKernelGGL(spl_inflate_decode_dense_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, status, (uint8_t *)work + tokens_at(n_blocks), (uint32_t *)work, stride, opts);
+    else
+        hipLaunchKernelGGL(spl_inflate_decode_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, image, blocks, n_blocks, status, (uint8_t *)work + tokens_at(n_blocks), (uint32_t *)work, stride, opts);
     return (int)hipGetLastError();
 }
 

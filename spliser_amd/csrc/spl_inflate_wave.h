@@ -55,6 +55,7 @@ constexpr uint32_t SUB_BITS = SPLZ_SUB_BITS; // bits of DEFLATE data per lane an
 constexpr uint32_t TILE_WORDS = 64u * SUB_BITS / 32u;
 constexpr uint32_t TILE_PAD = 16;            // words behind the tile: a symbol that begins in the last subsequence ends there
 constexpr uint32_t TOKCAP = SPLZ_TOKCAP;     // bytes of token stream per tile (a tile with more is cut short)
+constexpr uint32_t TOKCAP_SMALL = 3072;      // ... in the kernel for blocks that deflate well (spl_inflate.hip: five waves a SIMD instead of four)
 constexpr uint32_t FL_OK = 0, FL_EOB = 1, FL_ERR = 2;
 #ifndef SPLZ_EMIT_ROUNDS
 #define SPLZ_EMIT_ROUNDS 2
@@ -359,9 +360,13 @@ WV_DEV void store_n(uint8_t *p, uint64_t lo, uint64_t hi, uint32_t n)
 // The block `zb` of the file image, by one wave.  stream: room for tok_cap bytes of tokens (16-byte aligned; SPL_Z_TOKEN_STRIDE
 // holds any block's, a caller that gives less gets SPL_Z_OVERRUN for a block that needs more); n_tok_out: how many were written.
 // opts: OPT_* bits.  Returns the block's status (every lane the same).
+// CAP: the bytes of sh.tok the tiles may use (TOKCAP: all of it; TOKCAP_SMALL: what a wave of the denser kernel has, whose shared
+// memory ends that much earlier -- tok is Shared's last member).  Same tokens whatever CAP: a tile with more is cut short.
+template <uint32_t CAP = TOKCAP>
 WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock &zb, uint8_t *stream, uint32_t &n_tok_out, uint32_t tok_cap = SPL_Z_TOKEN_STRIDE,
                              uint32_t opts = 0)
 {
+    static_assert(CAP <= TOKCAP && CAP >= 352u + 256u + 64u && CAP % 16u == 0u, "the tiles' share of Shared::tok");
     n_tok_out = 0;
     uint32_t n_tok = 0; // bytes of token stream so far
     const uint32_t l = wv::lane();
@@ -497,7 +502,7 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             uint8_t *const tok = (uint8_t *)sh.tok;
             const uint32_t place_len = dead ? 0u : c.n_tok + 12u;
             const uint32_t place_incl = wv::scan_add(place_len);
-            const bool places = !(opts & OPT_WRITING_PASS) && wv::readlane(place_incl, 63u) <= TOKCAP;
+            const bool places = !(opts & OPT_WRITING_PASS) && wv::readlane(place_incl, 63u) <= CAP;
             uint8_t *const place = tok + (place_incl - place_len);
             bool emitted = false, fits = true;
             uint32_t need = 0;
@@ -526,10 +531,10 @@ WV_DEV uint32_t decode_block(Shared &sh, const uint8_t *image, const spl_zblock 
             //  more behind the others, into room of exactly their size; should even that not fit, the writing pass below takes the tile)
             const bool misfit = places && !dead && !fits;
             const uint32_t again_len = misfit ? c.n_tok : 0u, again_incl = wv::scan_add(again_len);
-            const bool in_place = places && wv::readlane(again_incl, 63u) <= TOKCAP;
+            const bool in_place = places && wv::readlane(again_incl, 63u) <= CAP;
             // the lanes that count: all that are alive (a suffix of the lanes is dead), short of the one whose tokens overflow the tile's room
             const uint32_t cum_t = wv::scan_add(dead ? 0u : c.n_tok), cum_o = wv::scan_add(dead ? 0u : c.n_out);
-            const uint64_t m_ok = wv::ballot(!dead && (in_place || cum_t <= TOKCAP));
+            const uint64_t m_ok = wv::ballot(!dead && (in_place || cum_t <= CAP));
             const uint32_t n_valid = ~m_ok ? wv::ffs64(~m_ok) : 64u; // (the low run of ones)
             if (n_valid == 0u) return SPL_Z_OVERRUN;
             const bool valid = l < n_valid;

@@ -38,6 +38,35 @@ extern "C" int emul_inflate_blocks(const uint8_t *image, const spl_zblock *block
             if (!ok2) return -200000 - (int)b;
             if (st2 != status[b] || n2 != n_tok || (n_tok && memcmp(tokens.data(), tokens2.data(), n_tok) != 0)) return -300000 - (int)b;
         }
+        // ... and once more the way the denser kernel does (spl_inflate_decode_dense_kernel: its wave's shared memory ends
+        // TOKCAP - TOKCAP_SMALL bytes earlier): the same status, nothing written behind the smaller token room, and -- tiles may
+        // be cut elsewhere, so the tokens may be other tokens -- the same bytes out of the copying
+        {
+            static std::vector<uint8_t> tokens3(SPL_Z_TOKEN_STRIDE + 256);
+            memset(tokens3.data(), 0xEE, tokens3.size());
+            memset(&sh, 0xEE, sizeof sh);
+            uint32_t st3 = 99, n3 = 0;
+            const bool ok3 = wv::run_wave([&]() {
+                uint32_t n = 0;
+                const uint32_t st = splz::decode_block<splz::TOKCAP_SMALL>(sh, image, blocks[b], tokens3.data(), n);
+                if (wv::lane() == 0) { st3 = st; n3 = st == SPL_Z_OK ? n : 0u; }
+            });
+            if (!ok3) return -400000 - (int)b;
+            if (st3 != status[b]) return -500000 - (int)b;
+            for (uint32_t k = splz::TOKCAP_SMALL / 4u; k < splz::TOKCAP / 4u; ++k)
+                if (sh.tok[k] != 0xEEEEEEEEu) return -600000 - (int)b; // (memory the denser kernel's wave does not have)
+            if (st3 == SPL_Z_OK) {
+                static std::vector<uint8_t> out3(65536 + 64);
+                static uint8_t lane_lds3[splz::COPY_LANE_BYTES];
+                memset(lane_lds3, 0xEE, sizeof lane_lds3);
+                const uint32_t made3 = splz::copy_block(out3.data(), blocks[b].out_len, tokens3.data(), n3, lane_lds3, lane_lds3 + splz::RING_BYTES);
+                static uint8_t lane_lds1[splz::COPY_LANE_BYTES];
+                static std::vector<uint8_t> out1(65536 + 64);
+                memset(lane_lds1, 0xEE, sizeof lane_lds1);
+                const uint32_t made1 = splz::copy_block(out1.data(), blocks[b].out_len, tokens.data(), n_tok, lane_lds1, lane_lds1 + splz::RING_BYTES);
+                if (made3 != made1 || (made1 == blocks[b].out_len && memcmp(out1.data(), out3.data(), made1) != 0)) return -700000 - (int)b;
+            }
+        }
         for (size_t k = SPL_Z_TOKEN_STRIDE; k < tokens.size(); ++k) // (a block's room for tokens ends where the next block's begins)
             if (tokens[k] != 0xEE) return -100000 - (int)b;
         if (status[b] == SPL_Z_OK) {

@@ -244,6 +244,20 @@ def test_inflate_windows_of_a_few_blocks(ctx, tmp_path, monkeypatch, window):
     dev.close()
 
 
+@pytest.mark.parametrize("dense", ["0", "1"])
+def test_either_decoding_kernel_on_every_kind_of_file(ctx, tmp_path, monkeypatch, dense):
+    """SPL_Z_DENSE: the decoding kernel for blocks of literals (0) and the denser one for blocks that deflate well (1), each forced
+    onto files of both kinds -- sequence-like at level 1, htslib-shaped at level 6, constant bytes, stored blocks -- windows of a
+    few blocks: what the host decoder gives, either way."""
+    monkeypatch.setenv("SPL_Z_DENSE", dense)
+    monkeypatch.setenv("SPL_INFLATE_WINDOW_BLOCKS", "11")
+    for seq_mode, level, seed in ((1, 1, 71), (2, 6, 72), (0, 1, 73), (1, 0, 74), (2, 9, 75), (1, 6, 76)):
+        names, sets = _random_sets(seed, 30_000, 3)
+        path = str(tmp_path / ("d%d.bam" % seed))
+        native.write_bam(path, names, [10 ** 8] * len(names), [sets[c] for c in names], level=level, threads=3, seq_mode=seq_mode)
+        assert _both(path, ctx, names, sets) is True
+
+
 @pytest.mark.parametrize("levels", ["0", "1", "2", "3", "4"])
 def test_stream_set_ups_of_the_decode(ctx, tmp_path, monkeypatch, levels):
     """SPL_STREAM_PRIORITIES: the decode's streams at priority levels of their own and kept by the process (1, the default), all at

@@ -55,7 +55,11 @@ def _streams():
     return made
 
 
-def test_inflate_and_crc_kernels_against_zlib():
+@pytest.mark.parametrize("dense", ["0", "1"])
+def test_inflate_and_crc_kernels_against_zlib(monkeypatch, dense):
+    """... with either decoding kernel: the one with 5 KB of token room a tile and four waves a SIMD, and the denser one (3 KB,
+    five waves) that files of well-deflating blocks get (SPL_Z_DENSE forces one)."""
+    monkeypatch.setenv("SPL_Z_DENSE", dense)
     tokens = True
     native.build()
     lib = native.lib()
