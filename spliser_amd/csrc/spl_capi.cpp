@@ -1981,6 +1981,8 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     auto make_room = [&](uint64_t need_rec, uint64_t need_ops, double part_done) -> int {
         if (need_rec <= cap_rec && need_ops <= cap_ops && cap_rec) return SPL_OK;
         const double scale = 1.2 / std::max(part_done, 1e-6); // (a fifth more than the windows so far say: growing later means fresh memory and moving what is there)
+        if (timing && cap_rec) fprintf(stderr, "[spl_bam_decode_device] device %d: the extracted arrays grow (%llu records and %llu ops needed %.0f %% into the stretch, room for %llu and %llu)\n",
+                                       c->device, (unsigned long long)need_rec, (unsigned long long)need_ops, 100.0 * part_done, (unsigned long long)cap_rec, (unsigned long long)cap_ops);
         const uint64_t want_rec = std::max<uint64_t>(need_rec, (uint64_t)((double)need_rec * scale)) + 1024;
         const uint64_t want_ops = std::max<uint64_t>(need_ops, (uint64_t)((double)need_ops * scale)) + 1024;
         DevBuf pos2, flag2, cigoff2, cigar2, tid2;
