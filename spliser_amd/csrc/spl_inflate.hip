@@ -31,7 +31,10 @@ __global__ __launch_bounds__(64) void spl_inflate_decode_kernel(const uint8_t *i
 // is held to 96 registers (nine of them spilled, in the header's parsing).  The waves' waits are what the kernel has most of
 // (41 % of its cycles): htslib-shaped human file 295 -> 276 ms of it a call, the call 0.379 -> 0.360 s; on the sequence-like file,
 // whose tiles would be cut short, it is 13 % slower and not used (profiles/r06G_decode_five_waves.txt).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void spl_inflate_decode_dense_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks,
+#ifndef SPLZ_DENSE_WAVES
+#define SPLZ_DENSE_WAVES 5 // (6 with SPLZ_TOKCAP_SMALL=1792 was built too: 80 registers, 22 of them spilled -- profiles/r06G_decode_five_waves.txt)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPLZ_DENSE_WAVES, SPLZ_DENSE_WAVES))) void spl_inflate_decode_dense_kernel(const uint8_t *image, const spl_zblock *blocks, uint32_t n_blocks,
                                                                                                                      uint32_t *status, uint8_t *tokens_all, uint32_t *n_tok, uint32_t stride,
                                                                                                                      uint32_t opts)
 {

@@ -55,7 +55,10 @@ constexpr uint32_t SUB_BITS = SPLZ_SUB_BITS; // bits of DEFLATE data per lane an
 constexpr uint32_t TILE_WORDS = 64u * SUB_BITS / 32u;
 constexpr uint32_t TILE_PAD = 16;            // words behind the tile: a symbol that begins in the last subsequence ends there
 constexpr uint32_t TOKCAP = SPLZ_TOKCAP;     // bytes of token stream per tile (a tile with more is cut short)
-constexpr uint32_t TOKCAP_SMALL = 3072;      // ... in the kernel for blocks that deflate well (spl_inflate.hip: five waves a SIMD instead of four)
+#ifndef SPLZ_TOKCAP_SMALL
+#define SPLZ_TOKCAP_SMALL 3072
+#endif
+constexpr uint32_t TOKCAP_SMALL = SPLZ_TOKCAP_SMALL; // ... in the kernel for blocks that deflate well (spl_inflate.hip: five waves a SIMD instead of four)
 constexpr uint32_t FL_OK = 0, FL_EOB = 1, FL_ERR = 2;
 #ifndef SPLZ_EMIT_ROUNDS
 #define SPLZ_EMIT_ROUNDS 2
