@@ -1666,8 +1666,11 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         uint64_t s_rec = 0, s_ops = 0, s_bytes = 0;
         if (!spl_bam_sample_density(bam, b_lo, b_hi, &s_rec, &s_ops, &s_bytes)) return SPL_OK;
         const double scale = 1.25 * inflated_bytes / (double)s_bytes;
+        // (ops a read differ from gene to gene more than bytes a record do: three places of a 20 M-read file said 1.5 where the
+        //  file had 2.15, and its arrays grew behind the last window -- the smaller the file, the more room its guess gets)
+        const double scale_ops = (inflated_bytes < 16e9 ? 1.6 : 1.3) * inflated_bytes / (double)s_bytes;
         const uint64_t want_rec = (uint64_t)std::min((double)s_rec * scale, inflated_bytes / 36.0) + 1024;
-        const uint64_t want_ops = (uint64_t)std::min((double)s_ops * scale, inflated_bytes / 4.0) + 1024;
+        const uint64_t want_ops = (uint64_t)std::min((double)s_ops * scale_ops, inflated_bytes / 4.0) + 1024;
         HIP_TRY(look_at_free());
         if ((double)(14 * want_rec + 4 * want_ops) > (double)free_b / 3.0) return SPL_OK; // (a guess must not be what the windows' buffers go without)
         HIP_TRY(d_pos.get(4 * want_rec, pipe.b));
