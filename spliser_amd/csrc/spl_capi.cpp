@@ -1741,6 +1741,7 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     auto ring_at = [&](uint64_t file_off) { const size_t o = (size_t)file_off - byte_lo, pc = o / piece; return (uint64_t)((pc % ring) * slot + (o - pc * piece)); };
     auto piece_of = [&](uint64_t file_off) { return ((size_t)file_off - byte_lo) / piece; };
     std::vector<uint64_t> foff; // the blocks' offsets in the file (spl_zblock.in is where they lie in the ring)
+    size_t blocks_listed = 0;   // blocks and foff hold the whole file's list already (made by the walker thread)
     struct Crew { // (declared behind everything its threads touch: joined before any of that goes away, on every way out)
         std::vector<std::thread> threads;
         std::atomic<int> *stop = nullptr;
@@ -1779,6 +1780,24 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
         }
         return b1;
     };
+    if (!share) // the rest of the directory -- 25-30 ms of a 14 GB file -- and the list of all its blocks (9 ms) on a thread of their own, from here: beside the first windows' uploads and launches
+        walker.t = std::thread([&]() {
+            const double w0 = host_now();
+            walk_rc = spl_bam_walk_all(bam);
+            t_walk = host_now() - w0;
+            if (walk_rc) return;
+            const size_t n_all = spl_bam_block_count(bam);
+            if (n_all == 0 || n_all > 0xfffffff0ull) return;
+            blocks.resize(n_all);
+            foff.resize(n_all);
+            for (size_t i = 0; i < n_all; ++i) {
+                spl_bam_block_info bi;
+                spl_bam_block_get(bam, i, &bi);
+                foff[i] = bi.data_off;
+                blocks[i].in = ring_at(bi.data_off); blocks[i].out = bi.uoff; blocks[i].in_len = bi.data_len; blocks[i].out_len = bi.isize; blocks[i].crc = bi.crc; blocks[i].pad = 0;
+            }
+            blocks_listed = n_all;
+        });
     if (!share && !getenv("SPL_INFLATE_NO_EARLY")) {
         const size_t n_known = spl_bam_block_count(bam);
         if (n_known >= win_blocks || (n_known >= 2 && spl_bam_walk_complete(bam))) {
@@ -1853,7 +1872,6 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                 // Its copying kernel, CRC32 and the rest are the loop's (they need the second byte buffer and the file's lists).
                 if (b2 > b1) HIP_TRY(look_at_free());
                 if (b2 > b1 && (double)work0 + 2.0 * slack < (double)free_b) {
-                    walker.t = std::thread([&]() { const double w0 = host_now(); walk_rc = spl_bam_walk_all(bam); t_walk = host_now() - w0; });
                     if (!d_zwork[1].p) { HIP_TRY(d_zwork[1].get(work0, c->copy)); used_b += work0; }
                     const size_t need2 = std::min(n_pieces, piece_of(off0[b2 - 1]) + 1);
                     for (; pieces_waited < need2; ++pieces_waited) {
@@ -1889,13 +1907,15 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     // file's last) are inflated for the end of its last record and otherwise left alone -- the next share's device has them too.
     const size_t n_own = (size_t)sh.block_own - lo;
     if (n_own == 0 || n_own > n_blocks) return to_host("a share without blocks of its own");
-    blocks.resize(n_blocks);
-    foff.resize(n_blocks);
-    for (size_t i = 0; i < n_blocks; ++i) {
-        spl_bam_block_info bi;
-        spl_bam_block_get(bam, lo + i, &bi);
-        foff[i] = bi.data_off;
-        blocks[i].in = ring_at(bi.data_off); blocks[i].out = bi.uoff; blocks[i].in_len = bi.data_len; blocks[i].out_len = bi.isize; blocks[i].crc = bi.crc; blocks[i].pad = 0;
+    if (!(blocks_listed == n_blocks && lo == 0)) { // (not listed beside the walk: a share, a file whose second window did not go out early)
+        blocks.resize(n_blocks);
+        foff.resize(n_blocks);
+        for (size_t i = 0; i < n_blocks; ++i) {
+            spl_bam_block_info bi;
+            spl_bam_block_get(bam, lo + i, &bi);
+            foff[i] = bi.data_off;
+            blocks[i].in = ring_at(bi.data_off); blocks[i].out = bi.uoff; blocks[i].in_len = bi.data_len; blocks[i].out_len = bi.isize; blocks[i].crc = bi.crc; blocks[i].pad = 0;
+        }
     }
     const double t_blocks = host_now() - t_begin;
     const uint64_t stream_begin = blocks[0].out, stream_len = blocks[n_blocks - 1].out + blocks[n_blocks - 1].out_len; // (of the share; offsets are the file's)
