@@ -1655,11 +1655,12 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
                         piece / 1e6, ring, ring * slot / 1e6, ring < n_pieces ? "" : ": all of it");
     HIP_TRY(pipe.make(n_pieces, n_copy, two_up));
     t_pipe = host_now() - t_begin;
-    // The extracted arrays' first size, BEFORE anything runs on the device: device memory asked for while kernels are running was
-    // seen to take 30-60 ms a request on one box of four (profiles/r06s_first_call.txt; an idle device: 0.3 ms), and the arrays used to
-    // be sized from the first window's scan -- four or five such requests between the first window and the second.  So the host
-    // looks at a few blocks itself (spl_bam_sample_density: records and CIGAR ops per inflated byte at three places), a quarter
-    // is added, and make_room below finds the room there -- or grows it, as before, where the sample was wrong.
+    // The extracted arrays' first size, BEFORE the first window has been scanned.  They used to be sized from that scan: four or five
+    // requests for gigabytes on the host's loop between the first window and the second -- and on a box in use a request costs
+    // 27-28 ms a gigabyte, the driver clearing what it hands out (profiles/r06s_first_call.txt, 7; nothing where the memory is the
+    // process's own, kept from an earlier call).  So the host looks at a few blocks itself (spl_bam_sample_density: records and
+    // CIGAR ops per inflated byte at three places), a quarter is added, the arrays are asked for with the windows' buffers ahead
+    // of the first launch, and make_room below finds the room there -- or grows it, as before, where the sample was wrong.
     uint64_t cap_rec = 0, cap_ops = 0, n_rec = 0, n_ops = 0;
     auto early_room = [&](size_t b_lo, size_t b_hi, double inflated_bytes) -> int {
         if (cap_rec || getenv("SPL_NO_EARLY_ROOM")) return SPL_OK;
@@ -1760,9 +1761,8 @@ static int decode_share(spl_ctx *c, spl_bam *bam, const spl_bam_share *share, Sh
     size_t early = 0;  // blocks of the first window if it has been launched already (0: not)
     size_t early2 = 0; // where the second window ends if ITS decoding kernel has been launched as well (0: not)
     struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } walker; // (the rest of the directory, walked beside the second window's launch)
-    // (the readers start when the device memory the call can size by now has been asked for: a request for gigabytes made while
-    //  the copy engines are busy with the file's pieces was seen to take 20-25 ms a gigabyte, 0.1 ms before: SPL_READERS_FIRST=1
-    //  for the old order)
+    // (the readers start when the device memory the call can size by now has been asked for -- where the driver clears what it
+    //  hands out the process's other HIP calls wait for it anyway; SPL_READERS_FIRST=1: the readers first, as until round 6)
     bool readers_started = false;
     auto start_readers = [&]() {
         if (readers_started) return;
