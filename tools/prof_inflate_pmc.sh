@@ -1,11 +1,12 @@
 #!/bin/bash
-# usage: tools/prof_inflate_pmc.sh <tag> [scale]   (GPU box) -- counters of the device BAM decode's kernels: separate --pmc passes
-TAG=$1; SCALE=${2:-0.1}
+# usage: tools/prof_inflate_pmc.sh <tag> [scale] [seq-mode]   (GPU box) -- counters of the device BAM decode's kernels: separate --pmc passes
+# (seq-mode 1: the sequence-like file; 2: the htslib-shaped one, whose blocks get the denser decoding kernel)
+TAG=$1; SCALE=${2:-0.1}; Q=${3:-1}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
-cd $R && python tools/e2e_profile.py human --seq-mode 1 --scale $SCALE --auto-decode --runs 1 > $R/gpurun_out/${TAG}_warm.log 2>&1
-F=/tmp/wl_files/human_s${SCALE}_q1.bam
+cd $R && python tools/e2e_profile.py human --seq-mode $Q --scale $SCALE --auto-decode --runs 1 > $R/gpurun_out/${TAG}_warm.log 2>&1
+F=/tmp/wl_files/human_s${SCALE}_q${Q}.bam
 cd /tmp
 P() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_${TAG}_$name -- python3 $R/tools/gpu_decode_steps.py $F > $R/gpurun_out/pmc_${TAG}_$name.log 2>&1; }
 P insts SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT
